@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: imports the REFERENCE (read-only, /root/reference) on CPU and dumps
+small input/output fixtures under tests/golden/.
+
+Runs ONLY in the authoring container (the reference never travels to the GPU box).  Everything here
+is test infrastructure.  Parameters are never stored: both this script and the tests regenerate them
+by name with dir_amd.synth (counter-based RNG), so the fixtures hold inputs + expected outputs only.
+
+Stubs (none carries hot-path arithmetic):
+  timm.models.layers (DropPath never instantiated: transformer/mixSTE.py:118,133),
+  torchvision.models (ImageNet weight download: models/dir.py:490-498),
+  cv2 / imgaug / yacs (top-level imports of utils/utils.py),
+  mano.webuser.smpl_handpca_wrapper_HAND_only.ready_arguments (licensed pkl loader:
+  manopth/manopth/manolayer.py:65) -> synthetic MANO tables of the real shapes.
+  torch.Tensor.cuda / nn.Module.cuda -> identity (models/dir.py:514).
+
+usage: python oracle/gen_golden.py [--only NAME ...]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from dir_amd import synth  # noqa: E402
+from oracle.golden_inputs import MANO_CASES, bone_uv, edge_uv, mano_inputs, stage_inputs  # noqa: E402
+
+REF = '/root/reference'
+OUT = os.path.join(REPO, 'tests', 'golden')
+SEED = 1234
+
+
+# ----------------------------------------------------------------------------- reference import
+class _R(object):
+    """mimics a chumpy array: the ndarray lives in `.r`"""
+
+    def __init__(self, a):
+        self.r = a
+
+
+def _fake_ready_arguments(path):
+    side = 'left' if 'LEFT' in os.path.basename(path) else 'right'
+    t = synth.synthetic_mano_tables(side, SEED)
+    return {
+        'hands_components': t['hands_components'], 'hands_mean': t['hands_mean'],
+        'betas': _R(t['betas']), 'shapedirs': _R(t['shapedirs']), 'posedirs': _R(t['posedirs']),
+        'v_template': _R(t['v_template']), 'weights': _R(t['weights']),
+        'J_regressor': sp.csc_matrix(t['J_regressor']), 'f': t['f'], 'kintree_table': t['kintree_table'],
+    }
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [REF, os.path.join(REF, 'manopth')]
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(nn.Identity):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    mod('timm'); mod('timm.models')
+    mod('timm.models.layers', DropPath=DropPath, to_2tuple=lambda x: (x, x), trunc_normal_=lambda *a, **k: None)
+
+    class _W:
+        IMAGENET1K_V2 = None
+    mod('torchvision')
+    mod('torchvision.models', resnet50=lambda weights=None: nn.Module(), ResNet50_Weights=_W)
+    mod('cv2')
+    ia = mod('imgaug')
+    ia.augmenters = mod('imgaug.augmenters')
+    mod('yacs')
+    mod('yacs.config', CfgNode=dict)
+    mod('mano'); mod('mano.webuser')
+    mod('mano.webuser.smpl_handpca_wrapper_HAND_only', ready_arguments=_fake_ready_arguments)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+
+
+def load_synth(module, seed=SEED):
+    sd = module.state_dict()
+    shapes = {k: tuple(v.shape) for k, v in sd.items()}
+    vals = synth.synth_state_dict(shapes, seed)
+    module.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in vals.items()}, strict=True)
+    return shapes
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print('  wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------- G1 MANO
+
+
+def gen_mano():
+    from manopth.manolayer import ManoLayer
+    from manopth import rot6d
+    from manopth.tensutils import th_posemap_axisang
+    out = {}
+    for side in ('left', 'right'):
+        for center in (0, 9, -1):
+            for flat in (False, True):
+                if flat and center != 0:
+                    continue
+                layer = ManoLayer(root_rot_mode='6D', joint_rot_mode='axisang', use_pca=True, mano_root='unused',
+                                  side=side, ncomps=45, center_idx=(None if center < 0 else center),
+                                  flat_hand_mean=flat, robust_rot=True)
+                for case in MANO_CASES:
+                    if (center != 0 or flat) and case not in ('normal', 'zero_pose'):
+                        continue
+                    pose, betas = mano_inputs(case)
+                    tp, tb = torch.from_numpy(pose), torch.from_numpy(betas)
+                    verts, joints = layer(tp, tb)
+                    tag = '%s_c%d_f%d_%s' % (side, center, int(flat), case)
+                    out[tag + '.pose'] = pose
+                    out[tag + '.betas'] = betas
+                    out[tag + '.verts'] = verts
+                    out[tag + '.joints'] = joints
+                    if center == 0 and not flat:
+                        full = torch.cat([tp[:, :6], layer.th_hands_mean + tp[:, 6:].mm(layer.th_selected_comps)], 1)
+                        out[tag + '.root_rot'] = rot6d.robust_compute_rotation_matrix_from_ortho6d(full[:, :6])
+                        out[tag + '.rot_map'] = th_posemap_axisang(full[:, 6:])[1]
+    save('g1_mano', **out)
+
+
+# ----------------------------------------------------------------------------- G2 PGCN
+def gen_pgcn():
+    from SemGCN.utils import adj_mx_from_edges, get_sketch_setting
+    from SemGCN.p_gcn import ResSimplePGCN
+    from SemGCN.p_graph_conv import PGraphConv
+    import torch.nn.functional as F
+    adj = adj_mx_from_edges(21, get_sketch_setting(), sparse=False, eye=False)
+    net = ResSimplePGCN(adj, 128, num_layers=4).eval()
+    load_synth(net)
+    x = torch.from_numpy(synth.synth_input('pgcn.x', (2, 21, 128), SEED))
+    acts = {}
+    for i, l in enumerate(net.gconv_layers):
+        l.gconv.register_forward_hook(lambda m, a, o, i=i: acts.__setitem__('gconv%d' % i, o.clone()))
+        l.register_forward_hook(lambda m, a, o, i=i: acts.__setitem__('layer%d' % i, o.clone()))
+    with torch.no_grad():
+        y = net(x.clone())
+        g0 = net.gconv_layers[0].gconv
+        A1 = -9e15 * torch.ones_like(g0.adj_1)
+        A1[g0.m_1] = g0.e_1
+        A1 = F.softmax(A1, dim=1)
+        single = PGraphConv(128, 128, adj).eval()
+        load_synth(single)
+        ys = single(x.clone())
+    nz = np.stack(np.nonzero(adj.numpy() > 0), 1)
+    save('g2_pgcn', x=x, y=y, A1=A1, adj=adj, edge_order=nz, single_y=ys, **acts)
+
+
+# ----------------------------------------------------------------------------- G3 STE
+def gen_ste():
+    from transformer.mixSTE import STE
+    net = STE(num_joints=42, in_chans=128, out_dim=64, depth=4).eval()
+    load_synth(net)
+    x = torch.from_numpy(synth.synth_input('ste.x', (2, 42, 128), SEED))
+    acts = {}
+    cnt = [0]
+
+    def hook(m, a, o):
+        acts['after_norm%d' % cnt[0]] = o.clone()
+        cnt[0] += 1
+    net.spatial_norm.register_forward_hook(hook)
+    probs = {}
+    net.STEblocks[1].attn.attn_drop.register_forward_hook(lambda m, a, o: probs.__setitem__('p', o.clone()))
+    with torch.no_grad():
+        y = net(x.clone())
+    save('g3_ste', x=x, y=y, attn_probs_block1=probs['p'], **acts)
+
+
+# ----------------------------------------------------------------------------- G4 grid tokens
+def gen_grid():
+    from models.dir import ImgFeature2JointFeature
+    out = {}
+    net = ImgFeature2JointFeature(256, 128).eval()
+    load_synth(net)
+    for S in (16, 32):
+        feat = torch.from_numpy(synth.synth_input('grid.feat%d' % S, (2, 256, S, S), SEED))
+        uv = torch.from_numpy(edge_uv('grid.uv%d' % S, 2, S))
+        with torch.no_grad():
+            y = net(feat, uv)
+            sampled = torch.nn.functional.grid_sample(feat, uv.unsqueeze(1)).squeeze(-2)
+        out['S%d.uv' % S] = uv
+        out['S%d.y' % S] = y            # [2, 128*21] channel-major flatten (models/dir.py:200)
+        out['S%d.sampled' % S] = sampled  # [2,256,21]
+    save('g4_grid', **out)
+
+
+# ----------------------------------------------------------------------------- G5 bone_proj
+def gen_bone():
+    from models.dir import Joint2BoneFeature
+    out = {}
+    for S, dist in ((16, 1), (32, 2)):
+        net = Joint2BoneFeature(256, 128, 64, 21, S, 'unused', 0, distance=dist).eval()
+        uv = torch.from_numpy(bone_uv('bone.uv%d' % S, 2, S))
+        feat = torch.from_numpy(synth.synth_input('bone.feat%d' % S, (2, 21, 64), SEED))
+        with torch.no_grad():
+            y = net.bone_proj(uv, feat)
+        out['S%d.uv' % S] = uv
+        out['S%d.y' % S] = y            # [2,1280,S,S]
+    save('g5_bone', **out)
+
+
+# ----------------------------------------------------------------------------- G6 refinement stage
+def gen_stage():
+    from models.dir import Joint2BoneFeature
+    for S, dist in ((16, 1), (32, 2)):
+        net = Joint2BoneFeature(256, 128, 64, 21, S, 'unused', 0, distance=dist).eval()
+        shapes = load_synth(net)
+        ins = [torch.from_numpy(a) for a in stage_inputs(S)]
+        with torch.no_grad():
+            result, feats = net(*ins)
+        out = {k: v for k, v in result.items() if v is not None}
+        out['img_feat'] = feats['img_feat']
+        out['joint_feat_left'] = feats['joint_feat_left']
+        out['joint_feat_right'] = feats['joint_feat_right']
+        vis = feats['vis_img_feat']
+        out['vis_sum'] = vis.double().sum(dim=(2, 3))
+        out['vis_slice'] = vis[:, 0:1280:97]
+        save('g6_stage%d' % S, **out)
+        with open(os.path.join(OUT, 'manifest_stage%d.json' % S), 'w') as f:
+            json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+
+
+# ----------------------------------------------------------------------------- G7 full DIR
+def gen_full():
+    from models.dir import DIR
+    net = DIR(21, 'unused', 0).eval()
+    shapes = load_synth(net)
+    with open(os.path.join(OUT, 'manifest_dir.json'), 'w') as f:
+        json.dump({k: list(v) for k, v in shapes.items()}, f, indent=0)
+    B = 2
+    img = torch.from_numpy(synth.synth_input('dir.img', (B, 3, 256, 256), SEED))
+    taps = {}
+
+    def tap(name):
+        def h(m, a, o):
+            t = o[1]['img_feat'] if isinstance(o, tuple) else o
+            taps[name + '.sum'] = t.double().sum(dim=(2, 3))
+            taps[name + '.abssum'] = t.double().abs().sum(dim=(2, 3))
+            taps[name + '.slice'] = t[:, :4].clone()
+        return h
+    for name, m in [('c1', net.backbone.layer1), ('c2', net.backbone.layer2), ('c3', net.backbone.layer3),
+                    ('c4', net.backbone.layer4), ('skip4', net.decoder.skip_layer4),
+                    ('fusion4', net.decoder.fusion_layer4), ('proj4', net.decoder.projecter_4),
+                    ('enh4', net.decoder.enhance_layer4), ('fusion3', net.decoder.fusion_layer3),
+                    ('proj3', net.decoder.projecter_3), ('enh3', net.decoder.enhance_layer3),
+                    ('final', net.decoder.conv_final), ('stem', net.backbone.maxpool)]:
+        m.register_forward_hook(tap(name))
+    with torch.no_grad():
+        outs, loss = net({'img': img}, None, None)
+    assert loss == {}
+    out = dict(taps)
+    for i in range(3):
+        for k, v in outs[i].items():
+            if v is not None:
+                out['s%d.%s' % (i, k)] = v
+    out['seg'] = outs[3]['seg']
+    out['dense'] = outs[3]['dense']
+    pf = outs[3]['proj_feat']
+    out['proj_feat.sum'] = pf.double().sum(dim=(2, 3))
+    out['proj_feat.slice'] = pf[:, 0:1280:97]
+    for i in range(3):
+        uv = outs[i]['pd_joint_uv_left']
+        print('   stage %d uv range [%.3f, %.3f]  verts absmax %.4f' % (
+            i, float(uv.min()), float(uv.max()), float(outs[i]['pd_mesh_xyz_left'].abs().max())))
+    print('   c4 absmean %.3f' % float(taps['c4.abssum'].sum() / (B * 2048 * 64)))
+    save('g7_dir', **out)
+
+
+GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+        'stage': gen_stage, 'full': gen_full}
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*', default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    import_reference()
+    import warnings
+    warnings.filterwarnings('ignore')
+    for name, fn in GENS.items():
+        if args.only and name not in args.only:
+            continue
+        print('[gen_golden] ' + name)
+        fn()

@@ -1,0 +1,212 @@
+"""Pins the CPU oracle (oracle/*.py) against golden vectors produced by the reference itself
+(oracle/gen_golden.py imports /root/reference; fixtures in tests/golden/).  CPU-only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, maxabs, relerr
+from dir_amd import synth
+from oracle import mano as OM
+from oracle import nnops as N
+from oracle import tokens as OT
+from oracle.dir_forward import dir_forward
+
+SEED = 1234
+
+
+def shapes_of(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def sub_shapes(shapes, prefix):
+    return {k[len(prefix):]: v for k, v in shapes.items() if k.startswith(prefix)}
+
+
+# ------------------------------------------------------------------ G1 MANO (a8)
+def _mano_tags(g):
+    return sorted({k.rsplit('.', 1)[0] for k in g if k.endswith('.pose')})
+
+
+def test_mano_matches_reference(golden):
+    g = golden('g1_mano')
+    tags = _mano_tags(g)
+    assert len(tags) == 22
+    for tag in tags:
+        side, c, f, case = tag.split('_', 3)
+        center = int(c[1:])
+        buf = synth.mano_buffers(side, SEED, flat_hand_mean=bool(int(f[1:])))
+        v, j = OM.mano_forward(buf, g[tag + '.pose'], g[tag + '.betas'], side, None if center < 0 else center)
+        # metres; 1e-4 mm == 1e-7 m is the north-star tolerance.  'large' multiplies the pose by 5
+        # (angles of tens of radians): fp32 sin/cos argument rounding alone is ~1e-6 there.
+        tol = 1e-7 if case != 'large' else 2e-6
+        assert maxabs(v, g[tag + '.verts']) < tol, tag
+        assert maxabs(j, g[tag + '.joints']) < tol, tag
+
+
+def test_mano_intermediates(golden):
+    g = golden('g1_mano')
+    for side in ('left', 'right'):
+        tag = side + '_c0_f0_normal'
+        buf = synth.mano_buffers(side, SEED)
+        _, _, aux = OM.mano_forward(buf, g[tag + '.pose'], g[tag + '.betas'], side, 0, return_aux=True)
+        assert maxabs(aux['root_rot'], g[tag + '.root_rot']) < 5e-7
+        assert maxabs(aux['rot_map'], g[tag + '.rot_map']) < 5e-7
+
+
+def test_mano_fp64_arbitration(golden):
+    """fp64 oracle vs the reference's fp32 output: bounds the reference's own rounding error."""
+    g = golden('g1_mano')
+    tag = 'right_c0_f0_normal'
+    buf = synth.mano_buffers('right', SEED)
+    v, j = OM.mano_forward(buf, g[tag + '.pose'].astype(np.float64), g[tag + '.betas'].astype(np.float64), 'right', 0)
+    assert maxabs(v, g[tag + '.verts']) < 1e-7
+
+
+def test_mano_index_tables():
+    assert OM.TIPS['right'] == [745, 317, 444, 556, 673] and OM.TIPS['left'] == [745, 317, 445, 556, 673]
+    assert sorted(OM.REORDER_J) == list(range(21)) and sorted(OM.REORDER_T) == list(range(16))
+
+
+# ------------------------------------------------------------------ G2 P-GCN (a5)
+def _pgcn_shapes(prefix=''):
+    s = {}
+    for i in range(4):
+        p = '%sgconv_layers.%d.' % (prefix, i)
+        s.update({p + 'gconv.W': (2, 21, 128, 128), p + 'gconv.e_0': (1, 21), p + 'gconv.e_1': (1, 40),
+                  p + 'gconv.bias': (128,), p + 'bn.weight': (128,), p + 'bn.bias': (128,),
+                  p + 'bn.running_mean': (128,), p + 'bn.running_var': (128,), p + 'bn.num_batches_tracked': ()})
+    return s
+
+
+def test_pgcn_matches_reference(golden):
+    g = golden('g2_pgcn')
+    mask = OT.adjacency_mask()
+    assert np.array_equal(mask, g['adj'] > 0)
+    assert np.array_equal(np.stack(np.nonzero(mask), 1), g['edge_order'])     # row-major nonzero order
+    sd = synth.synth_state_dict(_pgcn_shapes(), SEED)
+    P = N.Params(sd)
+    assert maxabs(OT.edge_softmax(P['gconv_layers.0.gconv.e_1'], mask), g['A1']) < 1e-7
+    acts = []
+    y = OT.pgcn_stack(g['x'], P, collect=acts)
+    for i in range(4):
+        assert relerr(acts[i], g['layer%d' % i]) < 2e-6
+    assert relerr(y, g['y']) < 2e-6
+    y0 = OT.pgraphconv(g['x'], P.sub('gconv_layers.0.gconv'))
+    assert relerr(y0, g['gconv0']) < 2e-6
+    single = synth.synth_state_dict({'W': (2, 21, 128, 128), 'e_0': (1, 21), 'e_1': (1, 40), 'bias': (128,)}, SEED)
+    assert relerr(OT.pgraphconv(g['x'], N.Params(single)), g['single_y']) < 2e-6
+
+
+# ------------------------------------------------------------------ G3 STE (a6)
+def ste_shapes():
+    s = {'spatial_pos_embed': (1, 42, 128), 'spatial_norm.weight': (128,), 'spatial_norm.bias': (128,),
+         'head.0.weight': (128,), 'head.0.bias': (128,), 'head.1.weight': (64, 128), 'head.1.bias': (64,)}
+    for i in range(4):
+        p = 'STEblocks.%d.' % i
+        s.update({p + 'norm1.weight': (128,), p + 'norm1.bias': (128,), p + 'norm2.weight': (128,),
+                  p + 'norm2.bias': (128,), p + 'attn.qkv.weight': (384, 128), p + 'attn.qkv.bias': (384,),
+                  p + 'attn.proj.weight': (128, 128), p + 'attn.proj.bias': (128,),
+                  p + 'mlp.fc1.weight': (256, 128), p + 'mlp.fc1.bias': (256,),
+                  p + 'mlp.fc2.weight': (128, 256), p + 'mlp.fc2.bias': (128,)})
+    return s
+
+
+def test_ste_matches_reference(golden):
+    g = golden('g3_ste')
+    sd = synth.synth_state_dict(ste_shapes(), SEED)
+    col = {}
+    y = OT.ste_forward(g['x'], N.Params(sd), collect=col)
+    assert maxabs(col['probs'], g['attn_probs_block1']) < 1e-6
+    for i in range(3):
+        assert maxabs(col['after_norm'][i], g['after_norm%d' % i]) < 2e-5
+    assert maxabs(y, g['y']) < 2e-5
+
+
+# ------------------------------------------------------------------ G4 grid-sample tokens (a4)
+def test_grid_tokens_match_reference(golden):
+    g = golden('g4_grid')
+    shapes = {'filters.0.weight': (128, 256, 1), 'filters.0.bias': (128,), 'filters.1.weight': (128,),
+              'filters.1.bias': (128,), 'filters.1.running_mean': (128,), 'filters.1.running_var': (128,),
+              'filters.1.num_batches_tracked': (), 'filters.3.weight': (128, 128, 1), 'filters.3.bias': (128,)}
+    P = N.Params(synth.synth_state_dict(shapes, SEED))
+    for S in (16, 32):
+        feat = synth.synth_input('grid.feat%d' % S, (2, 256, S, S), SEED)
+        uv = g['S%d.uv' % S]
+        assert maxabs(N.grid_sample_points(feat, uv), g['S%d.sampled' % S]) < 2e-6
+        y = OT.img2joint(feat, uv, P)                                   # [B,21,128]
+        ref = g['S%d.y' % S].reshape(2, 128, 21).transpose(0, 2, 1)     # models/dir.py:94
+        assert maxabs(y, ref) < 1e-5
+
+
+# ------------------------------------------------------------------ G5 bone_proj (a10)
+def test_bone_proj_matches_reference(golden):
+    g = golden('g5_bone')
+    for S, dist in ((16, 1), (32, 2)):
+        feat = synth.synth_input('bone.feat%d' % S, (2, 21, 64), SEED)
+        y = OT.bone_proj(g['S%d.uv' % S], feat, S, dist)
+        ref = g['S%d.y' % S]
+        assert y.shape == ref.shape == (2, 1280, S, S)
+        assert np.array_equal(y != 0, ref != 0), 'mask differs (S=%d)' % S      # bit-exact support
+        assert not np.isnan(ref).any()
+        assert maxabs(y, ref) < 1e-6
+        frac = float((ref != 0).mean())
+        assert 0.005 < frac < 0.5
+
+
+# ------------------------------------------------------------------ G6 refinement stage
+@pytest.mark.parametrize('S,dist', [(16, 1), (32, 2)])
+def test_stage_matches_reference(golden, S, dist):
+    g = golden('g6_stage%d' % S)
+    shapes = shapes_of('manifest_stage%d.json' % S)
+    sd = synth.synth_state_dict(shapes, SEED)
+    p = 'stage%d.' % S
+    B = 2
+    ins = dict(img_feat=synth.synth_input(p + 'img_feat', (B, 256, S, S), SEED),
+               xyz_l=synth.synth_input(p + 'xyz_l', (B, 21, 3), SEED) * np.float32(0.05),
+               xyz_r=synth.synth_input(p + 'xyz_r', (B, 21, 3), SEED) * np.float32(0.05),
+               para_l=synth.synth_input(p + 'para_l', (B, 64), SEED),
+               para_r=synth.synth_input(p + 'para_r', (B, 64), SEED),
+               offset=synth.synth_input(p + 'offset', (B, 1, 3), SEED))
+    from oracle.golden_inputs import bone_uv
+    uv_l, uv_r = bone_uv(p + 'uv_l', B, S), bone_uv(p + 'uv_r', B, S)
+    res, ft = OT.stage_forward(N.Params(sd), S, dist, ins['img_feat'], ins['xyz_l'], ins['xyz_r'], uv_l, uv_r,
+                               ins['para_l'], ins['para_r'], ins['offset'])
+    assert maxabs(res['pd_mano_para_left'], g['pd_mano_para_left']) < 2e-5
+    assert maxabs(res['pd_offset'], g['pd_offset']) < 2e-5
+    for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right'):
+        assert maxabs(res[k], g[k]) < 2e-6, k            # metres (fp32 token path upstream of MANO)
+    for k in ('pd_joint_uv_left', 'pd_joint_uv_right'):
+        assert maxabs(res[k], g[k]) < 2e-5, k
+    assert maxabs(ft['joint_feat_left'], g['joint_feat_left']) < 2e-5
+    assert relerr(ft['img_feat'], g['img_feat']) < 2e-5
+    assert relerr(ft['vis_img_feat'].astype(np.float64).sum((2, 3)), g['vis_sum']) < 1e-4
+
+
+# ------------------------------------------------------------------ G7 full DIR.forward
+def test_full_dir_matches_reference(golden):
+    g = golden('g7_dir')
+    shapes = shapes_of('manifest_dir.json')
+    assert len(shapes) == 963
+    sd = synth.synth_state_dict(shapes, SEED)
+    img = synth.synth_input('dir.img', (2, 3, 256, 256), SEED)
+    taps = {}
+    outs = dir_forward(sd, img, taps=taps)
+    for name in ('stem', 'c1', 'c2', 'c3', 'c4', 'skip4', 'fusion4', 'proj4', 'enh4', 'fusion3', 'proj3', 'enh3',
+                 'final'):
+        assert relerr(taps[name][:, :4], g[name + '.slice']) < 2e-4, name
+        assert relerr(np.abs(taps[name]).astype(np.float64).sum((2, 3)), g[name + '.abssum']) < 1e-4, name
+    worst = 0.0
+    for i in range(3):
+        for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right'):
+            worst = max(worst, maxabs(outs[i][k], g['s%d.%s' % (i, k)]))
+        for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_proj_left', 'pd_proj_right', 'pd_offset'):
+            assert maxabs(outs[i][k], g['s%d.%s' % (i, k)]) < 5e-4, (i, k)
+        assert outs[i]['pd_rel_joint'] is None
+    # end-to-end fp32 with a different (BLAS) summation order than ATen: positions agree to ~1e-3 mm
+    assert worst < 5e-6, worst
+    assert relerr(outs[3]['seg'], g['seg']) < 5e-4
+    assert relerr(outs[3]['dense'], g['dense']) < 5e-4
+    assert relerr(outs[3]['proj_feat'][:, 0:1280:97], g['proj_feat.slice']) < 5e-4
