@@ -1,0 +1,78 @@
+"""ctypes binding of libdir_hip.so (the C ABI declared in include/dir_hip.h).
+
+There is NO fallback: if the library is missing or a call fails this raises.  torch is imported first so
+that the HIP runtime PyTorch-ROCm already mapped (libamdhip64.so.7) is the one the library binds to; the
+kernels then run on torch's current stream against torch-owned device memory.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdir_hip.so')
+_lib = None
+
+
+class DirHipError(RuntimeError):
+    pass
+
+
+class ManoTables(C.Structure):
+    _fields_ = [('shapedirs_t', C.c_void_p), ('posedirs_t', C.c_void_p), ('v_template', C.c_void_p),
+                ('j_regressor', C.c_void_p), ('weights', C.c_void_p), ('hands_mean', C.c_void_p),
+                ('comps', C.c_void_p), ('side', C.c_int32), ('center_idx', C.c_int32), ('root_palm', C.c_int32)]
+
+
+_p, _i = C.c_void_p, C.c_int
+_SIGNATURES = {
+    'dir_abi_version': (C.c_int, []),
+    'dir_last_error': (C.c_char_p, []),
+    'dir_device_info': (C.c_int, [C.c_char_p, _i, C.POINTER(C.c_int)]),
+    'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (maps torch's libamdhip64 first)
+        if not os.path.exists(LIB_PATH):
+            raise DirHipError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              '(or python dir_amd/build.py). There is no CPU fallback.' % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)       # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if l.dir_abi_version() != 1:
+            raise DirHipError('libdir_hip.so ABI version %d != 1' % l.dir_abi_version())
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DirHipError('%s failed (%d): %s' % (what, rc, lib().dir_last_error().decode()))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DirHipError('dir_amd kernels run on the GPU only: got a %s tensor (no CPU fallback exists)'
+                              % t.device)
+
+
+def f32c(t):
+    """contiguous float32 view/copy (plumbing only)."""
+    import torch
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

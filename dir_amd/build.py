@@ -1,0 +1,69 @@
+"""Builds dir_amd/lib/libdir_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU.  Objects are rebuilt only when their source (or a header) is newer.
+The library links against libamdhip64.so.7 by SONAME only: inside a PyTorch-ROCm process the loader
+reuses the runtime torch already mapped, so kernels run on torch's streams and device pointers.
+"""
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build', 'obj')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libdir_hip.so')
+ARCH = 'gfx950'
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-fno-gpu-rdc']
+
+
+def hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found (need ROCm with gfx950 support)')
+    return exe
+
+
+def _newest_header():
+    hs = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(HERE, '..', 'include', '*.h'))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src) + '.o')
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header()):
+        return obj, False
+    cmd = [hipcc()] + FLAGS + ['-c', src, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+        if verbose:
+            print('[dir_amd.build] linked %s (%d objects, %d recompiled)' % (LIB, len(objs), sum(c for _, c in res)))
+    elif verbose:
+        print('[dir_amd.build] %s up to date' % LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

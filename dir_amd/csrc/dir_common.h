@@ -1,0 +1,44 @@
+// Shared helpers for libdir_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dir_hip.h"
+
+namespace dir {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return DIR_E_LAUNCH;
+    }
+    return DIR_OK;
+}
+
+#define DIR_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            dir::set_error(__VA_ARGS__); \
+            return DIR_E_INVALID;       \
+        }                               \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace dir

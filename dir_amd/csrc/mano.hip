@@ -1,0 +1,246 @@
+// Fused MANO forward for gfx950: PCA -> Rodrigues (via quaternion) -> robust 6D root rotation -> shape
+// and pose blend shapes -> 3-level kinematic chain -> LBS -> fingertips -> joint reorder -> root
+// centring -> weak-perspective projection.  One 256-thread workgroup per sample; every intermediate
+// lives in LDS (~11 KB), tables are read k-major (coalesced) and stay L2 resident across the batch.
+//
+// Replaces manopth/manopth/manolayer.py:110-270 (+ rodrigues_layer.py:15-54, rot6d.py:26-60,
+// tensutils.py:6-42) and utils/utils.py:47-63 of the reference: ~4040 ATen op calls and a host sync
+// per call there, one launch here.
+#include "dir_common.h"
+
+namespace {
+
+constexpr int NV = 778, NV3 = 2334, NJ = 16;
+
+__constant__ int kReorderJ[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
+__constant__ int kTips[2][5] = {{745, 317, 444, 556, 673}, {745, 317, 445, 556, 673}};
+
+struct ManoArgs {
+    dir_mano_tables t;
+    const float* pose; int pose_stride;
+    const float* betas; int betas_stride;
+    const float* cam; int cam_stride;
+    float* verts; float* joints; float* joint_uv; float* mesh_uv; int32_t* flags;
+};
+
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
+    // rot6d.py:54-60: v / max(|v|, 1e-8)
+    float m = fmaxf(sqrtf(x * x + y * y + z * z), 1e-8f);
+    x /= m; y /= m; z /= m;
+}
+
+__global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
+    __shared__ float s_v[NV3];          // v_shaped -> v_posed -> skinned vertices (in place)
+    __shared__ float s_pose[51], s_beta[10], s_cam[3];
+    __shared__ float s_full[45];        // axis-angle of the 15 articulated joints
+    __shared__ float s_rot[15 * 9];     // rotation matrices (row major)
+    __shared__ float s_pm[135];         // pose map = R - I
+    __shared__ float s_root[9];
+    __shared__ float s_J[NJ * 3];
+    __shared__ float s_A[NJ * 12];      // global transforms (top 3 rows), th_j joint order
+    __shared__ float s_A2[NJ * 12];     // with the rest-pose joint removed: A' = A - pack(A.[J;0])
+    __shared__ float s_jtr[21 * 3];
+    __shared__ float s_c[3];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    if (tid < 51) s_pose[tid] = a.pose[(size_t)b * a.pose_stride + tid];
+    if (tid >= 64 && tid < 74) s_beta[tid - 64] = a.betas[(size_t)b * a.betas_stride + tid - 64];
+    if (tid >= 128 && tid < 131) s_cam[tid - 128] = a.cam ? a.cam[(size_t)b * a.cam_stride + tid - 128] : 0.f;
+    __syncthreads();
+
+    // ---- PCA coefficients -> axis angle (manolayer.py:131-144) ; shape blend (manolayer.py:180-182)
+    if (tid < 45) {
+        float acc = 0.f;
+        for (int k = 0; k < 45; ++k) acc = fmaf(s_pose[6 + k], a.t.comps[k * 45 + tid], acc);
+        s_full[tid] = a.t.hands_mean[tid] + acc;
+    }
+    for (int i = tid; i < NV3; i += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc = fmaf(a.t.shapedirs_t[k * NV3 + i], s_beta[k], acc);
+        s_v[i] = acc + a.t.v_template[i];
+    }
+    if (tid == 64) {
+        // robust 6D -> rotation (rot6d.py:26-51): columns (x', y', z)
+        float x0 = s_pose[0], x1 = s_pose[1], x2 = s_pose[2], y0 = s_pose[3], y1 = s_pose[4], y2 = s_pose[5];
+        normalize3(x0, x1, x2);
+        normalize3(y0, y1, y2);
+        float m0 = x0 + y0, m1 = x1 + y1, m2 = x2 + y2;
+        float o0 = x0 - y0, o1 = x1 - y1, o2 = x2 - y2;
+        normalize3(m0, m1, m2);
+        normalize3(o0, o1, o2);
+        x0 = m0 + o0; x1 = m1 + o1; x2 = m2 + o2;
+        y0 = m0 - o0; y1 = m1 - o1; y2 = m2 - o2;
+        normalize3(x0, x1, x2);
+        normalize3(y0, y1, y2);
+        float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
+        normalize3(z0, z1, z2);
+        s_root[0] = x0; s_root[1] = y0; s_root[2] = z0;
+        s_root[3] = x1; s_root[4] = y1; s_root[5] = z1;
+        s_root[6] = x2; s_root[7] = y2; s_root[8] = z2;
+        if (a.flags) {
+            float det = x0 * (y1 * z2 - z1 * y2) - y0 * (x1 * z2 - z1 * x2) + z0 * (x1 * y2 - y1 * x2);
+            a.flags[b] = det < 0.f ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- Rodrigues via quaternion (rodrigues_layer.py:43-54, 15-40)
+    if (tid < 15) {
+        float vx = s_full[3 * tid], vy = s_full[3 * tid + 1], vz = s_full[3 * tid + 2];
+        float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
+        float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+        float ax = vx / angle, ay = vy / angle, az = vz / angle;
+        float half = angle * 0.5f;
+        float w = cosf(half), sn = sinf(half);
+        float x = sn * ax, y = sn * ay, z = sn * az;
+        float qn = sqrtf(w * w + x * x + y * y + z * z);
+        w /= qn; x /= qn; y /= qn; z /= qn;
+        float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
+        float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
+        float* R = s_rot + 9 * tid;
+        R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;     R[2] = 2 * wy + 2 * xz;
+        R[3] = 2 * wz + 2 * xy;   R[4] = w2 - x2 + y2 - z2;   R[5] = 2 * yz - 2 * wx;
+        R[6] = 2 * xz - 2 * wy;   R[7] = 2 * wx + 2 * yz;     R[8] = w2 - x2 - y2 + z2;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) s_pm[9 * tid + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+    }
+    // ---- joint regression from the shaped template (manolayer.py:183): 48 dot products of length 778
+    for (int o = wave; o < NJ * 3; o += 4) {
+        const int j = o / 3, c = o - 3 * j;
+        float acc = 0.f;
+        for (int v = lane; v < NV; v += 64) acc = fmaf(a.t.j_regressor[j * NV + v], s_v[3 * v + c], acc);
+        acc = dir::wave_sum(acc);
+        if (lane == 0) s_J[o] = acc;
+    }
+    __syncthreads();
+
+    // ---- pose blend shapes (manolayer.py:186-187)
+    for (int i = tid; i < NV3; i += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < 135; ++k) acc = fmaf(a.t.posedirs_t[k * NV3 + i], s_pm[k], acc);
+        s_v[i] += acc;
+    }
+    // ---- kinematic chain (manolayer.py:192-229): finger f owns joints 1+3f, 2+3f, 3+3f
+    if (tid < 5) {
+        float A[12];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            A[4 * r + 0] = s_root[3 * r + 0]; A[4 * r + 1] = s_root[3 * r + 1]; A[4 * r + 2] = s_root[3 * r + 2];
+            A[4 * r + 3] = s_J[r];
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) s_A[e] = A[e];
+        }
+        int parent = 0;
+        for (int l = 0; l < 3; ++l) {
+            const int j = 1 + 3 * tid + l;
+            const float* R = s_rot + 9 * (j - 1);
+            const float t0 = s_J[3 * j] - s_J[3 * parent], t1 = s_J[3 * j + 1] - s_J[3 * parent + 1],
+                        t2 = s_J[3 * j + 2] - s_J[3 * parent + 2];
+            float N[12];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float a0 = A[4 * r], a1 = A[4 * r + 1], a2 = A[4 * r + 2], a3 = A[4 * r + 3];
+                N[4 * r + 0] = a0 * R[0] + a1 * R[3] + a2 * R[6];
+                N[4 * r + 1] = a0 * R[1] + a1 * R[4] + a2 * R[7];
+                N[4 * r + 2] = a0 * R[2] + a1 * R[5] + a2 * R[8];
+                N[4 * r + 3] = a0 * t0 + a1 * t1 + a2 * t2 + a3;
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { A[e] = N[e]; s_A[12 * j + e] = N[e]; }
+            parent = j;
+        }
+    }
+    __syncthreads();
+    if (tid < NJ) {   // A' = A - pack(A.[J;0])  (manolayer.py:231-234)
+        const float* A = s_A + 12 * tid;
+        const float j0 = s_J[3 * tid], j1 = s_J[3 * tid + 1], j2 = s_J[3 * tid + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            s_A2[12 * tid + 4 * r + 0] = A[4 * r + 0];
+            s_A2[12 * tid + 4 * r + 1] = A[4 * r + 1];
+            s_A2[12 * tid + 4 * r + 2] = A[4 * r + 2];
+            s_A2[12 * tid + 4 * r + 3] = A[4 * r + 3] - (A[4 * r] * j0 + A[4 * r + 1] * j1 + A[4 * r + 2] * j2);
+        }
+    }
+    __syncthreads();
+
+    // ---- linear blend skinning (manolayer.py:236-246): T = sum_k w[v][k] A'[k]; vert = T.[v_posed;1]
+    for (int v = tid; v < NV; v += 256) {
+        const float4* wp = reinterpret_cast<const float4*>(a.t.weights + 16 * v);
+        float w[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 t4 = wp[q];
+            w[4 * q] = t4.x; w[4 * q + 1] = t4.y; w[4 * q + 2] = t4.z; w[4 * q + 3] = t4.w;
+        }
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = fmaf(s_A2[12 * k + e], w[k], T[e]);
+        }
+        const float x = s_v[3 * v], y = s_v[3 * v + 1], z = s_v[3 * v + 2];
+        s_v[3 * v + 0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        s_v[3 * v + 1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        s_v[3 * v + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
+    __syncthreads();
+
+    // ---- joints: 16 chain joints + 5 fingertip vertices, reordered (manolayer.py:247-259)
+    if (tid < 21) {
+        const int src = kReorderJ[tid];
+        float x, y, z;
+        if (src == 0 && a.t.root_palm) {
+            x = (s_v[3 * 95] + s_v[3 * 22]) / 2; y = (s_v[3 * 95 + 1] + s_v[3 * 22 + 1]) / 2;
+            z = (s_v[3 * 95 + 2] + s_v[3 * 22 + 2]) / 2;
+        } else if (src < 16) { x = s_A[12 * src + 3]; y = s_A[12 * src + 7]; z = s_A[12 * src + 11]; }
+        else { const int v = kTips[a.t.side][src - 16]; x = s_v[3 * v]; y = s_v[3 * v + 1]; z = s_v[3 * v + 2]; }
+        s_jtr[3 * tid] = x; s_jtr[3 * tid + 1] = y; s_jtr[3 * tid + 2] = z;
+    }
+    __syncthreads();
+    if (tid < 3) s_c[tid] = a.t.center_idx >= 0 ? s_jtr[3 * a.t.center_idx + tid] : 0.f;   // manolayer.py:261-265
+    __syncthreads();
+
+    const float sc = s_cam[0], tx = s_cam[1], ty = s_cam[2];
+    float* vout = a.verts + (size_t)b * NV3;
+    for (int i = tid; i < NV3; i += 256) vout[i] = s_v[i] - s_c[i % 3];
+    if (tid < 63) a.joints[(size_t)b * 63 + tid] = s_jtr[tid] - s_c[tid % 3];
+    if (a.cam) {   // utils/utils.py:47-63: uv = s * xy + t
+        if (a.joint_uv && tid >= 64 && tid < 64 + 42) {
+            const int i = tid - 64, j = i >> 1, c = i & 1;
+            a.joint_uv[(size_t)b * 42 + i] = sc * (s_jtr[3 * j + c] - s_c[c]) + (c ? ty : tx);
+        }
+        if (a.mesh_uv) {
+            float* mo = a.mesh_uv + (size_t)b * NV * 2;
+            for (int i = tid; i < NV * 2; i += 256) {
+                const int v = i >> 1, c = i & 1;
+                mo[i] = sc * (s_v[3 * v + c] - s_c[c]) + (c ? ty : tx);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dir_mano_forward(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
+                                int betas_stride, const float* cam, int cam_stride, float* verts, float* joints,
+                                float* joint_uv, float* mesh_uv, int32_t* flags_out, int B, void* stream) {
+    DIR_REQUIRE(t && pose && betas && verts && joints, "dir_mano_forward: null pointer");
+    DIR_REQUIRE(t->shapedirs_t && t->posedirs_t && t->v_template && t->j_regressor && t->weights &&
+                    t->hands_mean && t->comps, "dir_mano_forward: null table");
+    DIR_REQUIRE(B >= 0 && pose_stride >= 51 && betas_stride >= 10, "dir_mano_forward: bad B/stride");
+    DIR_REQUIRE(t->side == 0 || t->side == 1, "dir_mano_forward: side must be 0 (right) or 1 (left)");
+    DIR_REQUIRE(t->center_idx >= -1 && t->center_idx < 21, "dir_mano_forward: center_idx out of range");
+    DIR_REQUIRE(cam == nullptr || cam_stride >= 3, "dir_mano_forward: bad cam stride");
+    if (B == 0) return DIR_OK;
+    ManoArgs a{*t, pose, pose_stride, betas, betas_stride, cam, cam_stride, verts, joints, joint_uv, mesh_uv, flags_out};
+    hipLaunchKernelGGL(mano_forward_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    return dir::check_launch("dir_mano_forward");
+}
