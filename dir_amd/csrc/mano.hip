@@ -24,7 +24,9 @@ struct ManoArgs {
 };
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
-    // rot6d.py:54-60: v / max(|v|, 1e-8)
+    // rot6d.py:54-60: v / max(|v|, 1e-8).  No FMA contraction: the robust-6D construction is
+    // ill-conditioned for near-parallel inputs (x - y tiny), so follow the reference's op sequence exactly.
+#pragma clang fp contract(off)
     float m = fmaxf(sqrtf(x * x + y * y + z * z), 1e-8f);
     x /= m; y /= m; z /= m;
 }
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
     }
     if (tid == 64) {
         // robust 6D -> rotation (rot6d.py:26-51): columns (x', y', z)
+#pragma clang fp contract(off)
         float x0 = s_pose[0], x1 = s_pose[1], x2 = s_pose[2], y0 = s_pose[3], y1 = s_pose[4], y2 = s_pose[5];
         normalize3(x0, x1, x2);
         normalize3(y0, y1, y2);
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
 
     // ---- Rodrigues via quaternion (rodrigues_layer.py:43-54, 15-40)
     if (tid < 15) {
+#pragma clang fp contract(off)
         float vx = s_full[3 * tid], vy = s_full[3 * tid + 1], vz = s_full[3 * tid + 2];
         float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
         float angle = sqrtf(ex * ex + ey * ey + ez * ez);
@@ -232,14 +236,14 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
 extern "C" int dir_mano_forward(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
                                 int betas_stride, const float* cam, int cam_stride, float* verts, float* joints,
                                 float* joint_uv, float* mesh_uv, int32_t* flags_out, int B, void* stream) {
+    if (B == 0) return DIR_OK;   /* empty batch: nothing to do, pointers may be null */
     DIR_REQUIRE(t && pose && betas && verts && joints, "dir_mano_forward: null pointer");
     DIR_REQUIRE(t->shapedirs_t && t->posedirs_t && t->v_template && t->j_regressor && t->weights &&
                     t->hands_mean && t->comps, "dir_mano_forward: null table");
-    DIR_REQUIRE(B >= 0 && pose_stride >= 51 && betas_stride >= 10, "dir_mano_forward: bad B/stride");
+    DIR_REQUIRE(B > 0 && pose_stride >= 51 && betas_stride >= 10, "dir_mano_forward: bad B/stride");
     DIR_REQUIRE(t->side == 0 || t->side == 1, "dir_mano_forward: side must be 0 (right) or 1 (left)");
     DIR_REQUIRE(t->center_idx >= -1 && t->center_idx < 21, "dir_mano_forward: center_idx out of range");
     DIR_REQUIRE(cam == nullptr || cam_stride >= 3, "dir_mano_forward: bad cam stride");
-    if (B == 0) return DIR_OK;
     ManoArgs a{*t, pose, pose_stride, betas, betas_stride, cam, cam_stride, verts, joints, joint_uv, mesh_uv, flags_out};
     hipLaunchKernelGGL(mano_forward_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     return dir::check_launch("dir_mano_forward");

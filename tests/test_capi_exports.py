@@ -14,6 +14,7 @@ def declared_symbols():
 
 
 def test_library_exports_every_declared_symbol():
+    import torch  # noqa: F401  (same load order as the product path: torch's HIP runtime first)
     from dir_amd import build
     path = build.build(verbose=False)
     lib = ctypes.CDLL(path)
