@@ -22,11 +22,21 @@ class ManoTables(C.Structure):
                 ('comps', C.c_void_p), ('side', C.c_int32), ('center_idx', C.c_int32), ('root_palm', C.c_int32)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'B', 'H', 'W', 'Cin', 'in_cstride', 'in_coff', 'Cout', 'out_cstride', 'out_coff', 'res_cstride', 'res_coff',
+        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags')]
+
+
+DT_F32, DT_BF16 = 0, 1
+CONV_RELU, CONV_PRE_RELU = 1, 2
+
 _p, _i = C.c_void_p, C.c_int
 _SIGNATURES = {
     'dir_abi_version': (C.c_int, []),
     'dir_last_error': (C.c_char_p, []),
     'dir_device_info': (C.c_int, [C.c_char_p, _i, C.POINTER(C.c_int)]),
+    'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
 

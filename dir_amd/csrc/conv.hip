@@ -1,0 +1,283 @@
+// Implicit-GEMM 2-D convolution on the gfx950 matrix cores (a1/a2/a3/a11: every Conv2d on the DIR path).
+//
+//   y[m][n] = epilogue( sum_k A[m][k] * Wt[n][k] ),   m = (b,oy,ox) output pixel, n = output channel,
+//   k = (ky,kx,c) with c fastest  ->  activations NHWC, weights [Cout][kh][kw][Cin]: both operands are
+//   K-contiguous, so the A gather (im2col) is a 128-byte coalesced row segment per pixel and tap.
+//
+// One K-slab = 128 bytes per row for both precisions (32 fp32 / 64 bf16 channels).  A 32x32 MFMA lane
+// (i = lane&31, h = lane>>5) owns the contiguous 64-byte half h of row i of the slab: 4 x ds_read_b128
+// feed 16 x v_mfma_f32_32x32x2_f32 (fp32: exact fmaf chain) or 4 x v_mfma_f32_32x32x16_bf16.  Any
+// bijection of k is legal as long as A and W use the same one.  LDS rows are padded 128 -> 144 B, which
+// makes the ds_read_b128 pattern conflict free (bank step 36 dwords).
+//
+// Block = 256 threads (2x2 waves), tile 128(M) x 128(N), each wave 64x64 = 2x2 MFMA tiles (64 acc VGPRs).
+// Global -> registers -> LDS double buffering, one barrier per K-slab; the next slab's global loads are
+// in flight during the MFMAs.  Zero padding, M/N tails and the optional pre-activation BatchNorm+ReLU
+// (hourglass.Residual, models/backbone/hourglass.py:55-70) are handled in the register stage.
+// Epilogue: per-channel scale/shift (folded BatchNorm / bias), optional residual add, optional ReLU,
+// optional channel offset/stride so a conv can write straight into a slice of a concat buffer.
+//
+// Replaces the ATen/MKL-DNN (cuDNN in the original) calls under models/backbone/resnet.py:120-140,243-255,
+// models/backbone/hourglass.py:10-30,55-70 and models/dir.py:57-62,227-241,404-420.
+#include "dir_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;
+
+constexpr int BM = 128, BN = 128, LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
+constexpr int TILE_BYTES = BM * LDS_STRIDE;  // 18432 per operand per buffer
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Tr;
+template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };    // EPC = elems per 16-B chunk
+template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
+
+struct ConvArgs {
+    const void* x; const void* w; const float* scale; const float* shift;
+    const float* pre_scale; const float* pre_shift; const void* res; void* y;
+    int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
+    int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
+};
+
+template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <typename TO> __device__ __forceinline__ float load_res(const TO* p);
+template <> __device__ __forceinline__ float load_res<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_res<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+// pre-activation BN (+ReLU) applied to one 16-byte chunk of input channels starting at channel c
+template <typename TI>
+__device__ __forceinline__ uint4 prologue(uint4 v, const float* ps, const float* pb, int c, bool relu);
+template <>
+__device__ __forceinline__ uint4 prologue<float>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
+    float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[e] = fmaf(f[e], ps[c + e], pb[c + e]);
+        if (relu) f[e] = fmaxf(f[e], 0.f);
+    }
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+template <>
+__device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
+    uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float lo = bf2f((bf16_t)(u[e] & 0xffffu)), hi = bf2f((bf16_t)(u[e] >> 16));
+        lo = fmaf(lo, ps[c + 2 * e], pb[c + 2 * e]);
+        hi = fmaf(hi, ps[c + 2 * e + 1], pb[c + 2 * e + 1]);
+        if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+        u[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+    return make_uint4(u[0], u[1], u[2], u[3]);
+}
+
+template <typename TI>
+__device__ __forceinline__ void mma_slab(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc);
+template <>
+__device__ __forceinline__ void mma_slab<float>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].x), __uint_as_float(bf[q].x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].y), __uint_as_float(bf[q].y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].z), __uint_as_float(bf[q].z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].w), __uint_as_float(bf[q].w), acc, 0, 0, 0);
+    }
+}
+template <>
+__device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
+                                                      __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][A|B]
+    constexpr int EPC = Tr<TI>::EPC, BK = Tr<TI>::BK;
+
+    // XCD-aware tile order: contiguous tile ranges share one XCD's L2 (block b runs on XCD b % 8)
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const TI* __restrict__ x = (const TI*)a.x;
+    const TI* __restrict__ w = (const TI*)a.w;
+
+    // ---- per-thread loader state: 4 A chunks + 4 B chunks of 16 bytes per K-slab
+    long long abase[4];
+    int aiy[4], aix[4];
+    long long bbase[4];
+    bool bval[4];
+    const int col = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        const int m = m0 + row;
+        if (m < a.M) {
+            const int b = m / (a.Ho * a.Wo);
+            const int rem = m - b * (a.Ho * a.Wo);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            aiy[i] = oy * a.stride - a.pad;
+            aix[i] = ox * a.stride - a.pad;
+            abase[i] = ((long long)(b * a.H + aiy[i]) * a.W + aix[i]) * a.in_cs + a.in_co + col * EPC;
+        } else {
+            aiy[i] = -(1 << 28);   // always out of bounds -> zero rows
+            aix[i] = 0;
+            abase[i] = 0;
+        }
+        const int n = n0 + row;
+        bval[i] = n < a.Cout;
+        bbase[i] = (long long)n * a.K + col * EPC;
+    }
+
+    uint4 ra[4], rb[4];
+    const bool has_pre = a.pre_scale != nullptr;
+    const bool pre_relu = (a.flags & 2) != 0;
+
+    auto gload = [&](int ks) {
+        const int k0 = ks * BK;
+        const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+        const long long toff = (long long)(ky * a.W + kx) * a.in_cs + c0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = aiy[i] + ky, ix = aix[i] + kx;
+            const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                v = *reinterpret_cast<const uint4*>(x + abase[i] + toff);
+                if (has_pre) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
+            }
+            ra[i] = v;
+            rb[i] = bval[i] ? *reinterpret_cast<const uint4*>(w + bbase[i] + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* sa = smem + buf * 2 * TILE_BYTES;
+        char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = ((tid >> 3) + 32 * i) * LDS_STRIDE + col * 16;
+            *reinterpret_cast<uint4*>(sa + off) = ra[i];
+            *reinterpret_cast<uint4*>(sb + off) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 64;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < a.nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < a.nk) gload(ks + 1);
+        const char* sa = smem + buf * 2 * TILE_BYTES + (wm * 64) * LDS_STRIDE + frag_off;
+        const char* sb = smem + buf * 2 * TILE_BYTES + TILE_BYTES + (wn * 64) * LDS_STRIDE + frag_off;
+        uint4 af[2][4], bfr[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                af[i][q] = *reinterpret_cast<const uint4*>(sa + i * 32 * LDS_STRIDE + q * 16);
+                bfr[i][q] = *reinterpret_cast<const uint4*>(sb + i * 32 * LDS_STRIDE + q * 16);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
+        if (ks + 1 < a.nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    TO* __restrict__ y = (TO*)a.y;
+    const TO* __restrict__ res = (const TO*)a.res;
+    const bool relu = (a.flags & 1) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (n >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        const float sh = a.shift ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= a.M) continue;
+                float v = fmaf(acc[i][j][r], sc, sh);
+                if (res) v += load_res<TO>(res + (long long)m * a.res_cs + a.res_co + n);
+                if (relu) v = fmaxf(v, 0.f);
+                store_out<TO>(y + (long long)m * a.out_cs + a.out_co + n, v);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,
+                                  const float* shift, const float* pre_scale, const float* pre_shift,
+                                  const void* residual, void* y, void* stream) {
+    DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
+    DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
+    DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
+    const bool f32 = d->in_dtype == DIR_DT_F32;
+    DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16, "dir_conv2d_forward: in_dtype must be f32 or bf16");
+    DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == DIR_DT_BF16, "dir_conv2d_forward: bad out_dtype");
+    DIR_REQUIRE(!(f32 && d->out_dtype == DIR_DT_BF16), "dir_conv2d_forward: f32 in / bf16 out not built");
+    const int BK = f32 ? 32 : 64, EPC = f32 ? 4 : 8;
+    DIR_REQUIRE(d->Cin % BK == 0, "dir_conv2d_forward: Cin=%d must be a multiple of %d", d->Cin, BK);
+    const int in_cs = d->in_cstride ? d->in_cstride : d->Cin;
+    const int out_cs = d->out_cstride ? d->out_cstride : d->Cout;
+    const int res_cs = d->res_cstride ? d->res_cstride : d->Cout;
+    DIR_REQUIRE(in_cs % EPC == 0 && d->in_coff % EPC == 0, "dir_conv2d_forward: input channel slice must be 16-byte aligned");
+    DIR_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "dir_conv2d_forward: pre_scale/pre_shift go together");
+    ConvArgs a;
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.pre_scale = pre_scale; a.pre_shift = pre_shift;
+    a.res = residual; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = in_cs; a.in_co = d->in_coff;
+    a.Cout = d->Cout; a.out_cs = out_cs; a.out_co = d->out_coff; a.res_cs = res_cs; a.res_co = d->res_coff;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    a.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    DIR_REQUIRE(a.Ho > 0 && a.Wo > 0, "dir_conv2d_forward: empty output");
+    const long long M = (long long)d->B * a.Ho * a.Wo;
+    DIR_REQUIRE(M < (1ll << 31), "dir_conv2d_forward: too many output pixels");
+    a.M = (int)M; a.K = d->kh * d->kw * d->Cin; a.nk = a.K / BK;
+    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (d->Cout + BN - 1) / BN; a.flags = d->flags;
+    dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (f32) hipLaunchKernelGGL((conv_igemm_kernel<float, float>), grid, block, 0, s, a);
+    else if (d->out_dtype == DIR_DT_BF16) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, float>), grid, block, 0, s, a);
+    return dir::check_launch("dir_conv2d_forward");
+}

@@ -1,0 +1,53 @@
+"""Thin torch-tensor front ends of the C ABI (plumbing only: pointer/shape marshalling, no arithmetic).
+Feature maps are NHWC torch tensors (float32 or bfloat16) on the GPU."""
+import torch
+
+from . import _capi
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return DT_F32
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    raise _capi.DirHipError('unsupported dtype %s' % t.dtype)
+
+
+def pack_conv_weight(w_oihw, dtype=torch.float32):
+    """nn.Conv2d weight [Cout,Cin,kh,kw] -> [Cout,kh,kw,Cin] contiguous in the compute dtype."""
+    return w_oihw.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
+                pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
+                res_coff=0):
+    """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf]."""
+    _capi.require_cuda(x, w_ohwi, scale, shift, residual, pre_scale, pre_shift, out)
+    assert x.is_contiguous() and w_ohwi.is_contiguous() and x.dim() == 4
+    B, H, W, cbuf = x.shape
+    Cout, kh, kw, Cin = w_ohwi.shape
+    if cin is None:
+        cin = Cin
+    assert cin == Cin and w_ohwi.dtype == x.dtype
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        odt = out_dtype or x.dtype
+        out = torch.empty(B, Ho, Wo, Cout, device=x.device, dtype=odt)
+    assert out.is_contiguous() and out.shape[:3] == (B, Ho, Wo)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == out.dtype and residual.shape[:3] == (B, Ho, Wo)
+    for v in (scale, shift):
+        assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
+    for v in (pre_scale, pre_shift):
+        assert v is None or (v.dtype == torch.float32 and v.numel() == Cin and v.is_contiguous())
+    d = ConvDesc(B, H, W, Cin, cbuf, in_coff, Cout, out.shape[3], out_coff,
+                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, _dt(x), _dt(out),
+                 (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0))
+    with torch.cuda.device(x.device):
+        rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift),
+                                            _capi.ptr(pre_scale), _capi.ptr(pre_shift), _capi.ptr(residual),
+                                            _capi.ptr(out), _capi.stream_ptr())
+    _capi.check(rc, 'dir_conv2d_forward')
+    return out

@@ -76,6 +76,40 @@ int dir_mano_forward(const dir_mano_tables* tables_host, const float* pose, int 
                      float* verts, float* joints, float* joint_uv, float* mesh_uv, int32_t* flags_out,
                      int B, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores
+ * replaces every nn.Conv2d (+ the BatchNorm / bias / ReLU / residual add around it) on the path:
+ * models/backbone/resnet.py:120-140,243-255 (Bottleneck, stem excluded), models/backbone/hourglass.py:10-30,
+ * 55-70 (Conv, pre-activation Residual), models/dir.py:57-62 (fusion), :227-241 (attention), :404-420 (heads).
+ *
+ * x  : NHWC activations, B*H*W pixels of in_cstride channels; channels [in_coff, in_coff+Cin) are read
+ * w  : [Cout][kh][kw][Cin] in in_dtype  (= torch weight.permute(0,2,3,1))
+ * y  : NHWC, out_cstride channels per pixel, channels [out_coff, out_coff+Cout) are written
+ *      y = relu?( acc * scale[n] + shift[n] + residual[m][n] )        (scale/shift/residual optional)
+ * pre_scale/pre_shift [Cin] (optional): the input is first mapped x -> relu?(x*pre_scale + pre_shift)
+ *      (eval-mode BatchNorm+ReLU in front of the conv; zero padding is applied AFTER this map)
+ * dtype: in_dtype f32 computes with v_mfma_f32_32x32x2_f32 (exact fp32), bf16 with v_mfma_f32_32x32x16_bf16
+ *      (fp32 accumulate).  Cin must be a multiple of 32 (f32) / 64 (bf16); *_cstride = 0 means dense.
+ */
+#define DIR_DT_F32 0
+#define DIR_DT_BF16 1
+#define DIR_CONV_RELU 1
+#define DIR_CONV_PRE_RELU 2
+
+typedef struct dir_conv_desc {
+    int32_t B, H, W;
+    int32_t Cin, in_cstride, in_coff;
+    int32_t Cout, out_cstride, out_coff;
+    int32_t res_cstride, res_coff;
+    int32_t kh, kw, stride, pad;
+    int32_t in_dtype, out_dtype; /* DIR_DT_*; residual is read in out_dtype */
+    int32_t flags;               /* DIR_CONV_* */
+} dir_conv_desc;
+
+int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
+                       const float* shift, const float* pre_scale, const float* pre_shift,
+                       const void* residual, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

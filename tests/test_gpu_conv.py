@@ -1,0 +1,112 @@
+"""GPU parity (a1/a2/a3/a11): MFMA implicit-GEMM convolution through the C ABI vs the numpy oracle conv2d.
+fp32 path = v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate): tolerance 2e-5 relative to the output
+scale (summation order differs from BLAS).  bf16 path: inputs/weights rounded to bf16, fp32 accumulate; compared
+against the oracle run on the bf16-rounded operands, tolerance 1e-2 of the output scale when the output is bf16."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import relerr
+from dir_amd import functional as F
+from dir_amd import synth
+from oracle import nnops as N
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+CASES = [
+    # B, H, W, Cin, Cout, k, s, p
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 16, 16, 128, 256, 1, 1, 0),
+    (3, 15, 13, 64, 96, 3, 2, 1),       # odd sizes, stride 2, Cout tail inside a tile, M tail
+    (2, 32, 32, 256, 128, 1, 2, 0),     # strided 1x1 (ResNet downsample)
+    (1, 8, 8, 2048, 200, 3, 1, 1),      # long K (InitRegressor attention shape, Cout cut down)
+    (2, 9, 9, 64, 130, 3, 1, 1),        # two N tiles with a ragged second one
+]
+
+
+def to_nhwc(a):
+    return np.ascontiguousarray(a.transpose(0, 2, 3, 1))
+
+
+def bf16_round(a):
+    return torch.from_numpy(a).to(torch.bfloat16).float().numpy()
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv_matches_oracle(case, dtype):
+    B, H, W, Ci, Co, k, s, p = case
+    tag = 'conv.%s' % '_'.join(map(str, case))
+    x = synth.synth_input(tag + '.x', (B, Ci, H, W), SEED)
+    w = synth.synth_input(tag + '.w', (Co, Ci, k, k), SEED) * np.float32(np.sqrt(2.0 / (k * k * Ci)))
+    scale = synth.synth_input(tag + '.s', (Co,), SEED, kind='uniform', lo=0.5, hi=1.5)
+    shift = synth.synth_input(tag + '.b', (Co,), SEED) * np.float32(0.3)
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    if dtype == 'bf16':
+        x, w = bf16_round(x), bf16_round(w)
+    ref = N.conv2d(x.astype(np.float64), w.astype(np.float64), None, s, p)
+    ref = ref * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    ref_relu = np.maximum(ref, 0)
+    dx = torch.from_numpy(to_nhwc(x)).cuda().to(tdt)
+    dw = F.pack_conv_weight(torch.from_numpy(w).cuda(), tdt)
+    y = F.conv2d_nhwc(dx, dw, s, p, torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda(), relu=True)
+    got = y.float().cpu().numpy().transpose(0, 3, 1, 2)
+    tol = 2e-5 if dtype == 'f32' else 1e-2
+    assert relerr(got, ref_relu) < tol
+    if dtype == 'bf16':     # fp32 output from bf16 operands: only accumulation-order error remains
+        y32 = F.conv2d_nhwc(dx, dw, s, p, torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda(),
+                            out_dtype=torch.float32)
+        assert relerr(y32.cpu().numpy().transpose(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_conv_prologue_residual_and_concat_slices(dtype):
+    """pre-activation BN+ReLU on the input (hourglass.Residual), residual add, and channel-slice I/O."""
+    B, H, W, Ci, Co = 2, 12, 12, 128, 64
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    xbuf = synth.synth_input('convp.x', (B, Ci + 64, H, W), SEED)
+    w = synth.synth_input('convp.w', (Co, Ci, 3, 3), SEED) * np.float32(0.05)
+    ps = synth.synth_input('convp.ps', (Ci,), SEED, kind='uniform', lo=0.5, hi=1.5)
+    pb = synth.synth_input('convp.pb', (Ci,), SEED) * np.float32(0.5)
+    res = synth.synth_input('convp.res', (B, Co, H, W), SEED)
+    bias = synth.synth_input('convp.bias', (Co,), SEED)
+    if dtype == 'bf16':
+        xbuf, w, res = bf16_round(xbuf), bf16_round(w), bf16_round(res)
+    xin = xbuf[:, 64:]                                       # the conv reads channels [64, 64+Ci)
+    act = np.maximum(xin.astype(np.float64) * ps.reshape(1, -1, 1, 1) + pb.reshape(1, -1, 1, 1), 0)
+    if dtype == 'bf16':
+        act = bf16_round(act.astype(np.float32)).astype(np.float64)   # the kernel re-rounds the activated input
+    ref = N.conv2d(act, w.astype(np.float64), bias.astype(np.float64), 1, 1) + res
+    dx = torch.from_numpy(to_nhwc(xbuf)).cuda().to(tdt)
+    dw = F.pack_conv_weight(torch.from_numpy(w).cuda(), tdt)
+    out = torch.full((B, H, W, Co + 32), 7.0, device='cuda', dtype=tdt)
+    dres = torch.from_numpy(to_nhwc(res)).cuda().to(tdt)
+    F.conv2d_nhwc(dx, dw, 1, 1, None, torch.from_numpy(bias).cuda(), residual=dres, pre_scale=torch.from_numpy(ps).cuda(),
+                  pre_shift=torch.from_numpy(pb).cuda(), pre_relu=True, out=out, out_coff=32, in_coff=64, cin=Ci)
+    got = out.float().cpu().numpy()
+    assert np.all(got[..., :32] == 7.0)                     # untouched slice of the concat buffer
+    assert relerr(got[..., 32:].transpose(0, 3, 1, 2), ref) < (2e-5 if dtype == 'f32' else 1e-2)
+
+
+def test_conv_linearity_full_size():
+    """size-independent property at a BASELINE config-2 shape (B=64, fusion conv 2560->256 @16x16, bf16):
+    conv(x1 + x2) == conv(x1) + conv(x2) up to bf16 output rounding, and zero input -> shift only."""
+    B, S, Ci, Co = 64, 16, 2560, 256
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x1 = (torch.randn(B, S, S, Ci, device='cuda', generator=g) * 0.5).bfloat16()
+    x2 = torch.zeros_like(x1)
+    x2[:, ::3, ::2, ::5] = 1.0
+    w = (torch.randn(Co, 3, 3, Ci, device='cuda', generator=g) * 0.01).bfloat16()
+    y1 = F.conv2d_nhwc(x1, w, 1, 1, out_dtype=torch.float32)
+    y2 = F.conv2d_nhwc(x2, w, 1, 1, out_dtype=torch.float32)
+    y12 = F.conv2d_nhwc((x1.float() + x2.float()).bfloat16(), w, 1, 1, out_dtype=torch.float32)
+    # x1+x2 is re-rounded to bf16: compare against conv of the rounded sum's decomposition instead
+    xs = (x1.float() + x2.float()).bfloat16()
+    y_rest = F.conv2d_nhwc((xs.float() - x2.float()).bfloat16(), w, 1, 1, out_dtype=torch.float32)
+    scale = float(y12.abs().max())
+    assert float((y12 - (y_rest + y2)).abs().max()) / scale < 2e-2
+    assert float((y1 - y_rest).abs().max()) / scale < 2e-2
+    z = F.conv2d_nhwc(torch.zeros_like(x1), w, 1, 1, shift=torch.arange(Co, device='cuda', dtype=torch.float32),
+                      out_dtype=torch.float32)
+    assert torch.equal(z[3, 5, 7], torch.arange(Co, device='cuda', dtype=torch.float32))
