@@ -25,7 +25,35 @@ class ManoTables(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'B', 'H', 'W', 'Cin', 'in_cstride', 'in_coff', 'Cout', 'out_cstride', 'out_coff', 'res_cstride', 'res_coff',
-        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags')]
+        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')]
+
+
+class TokenMlp(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('w1t', 's1', 'b1', 'w2t', 'b2')]
+
+
+class PgcnLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('W', 'e1', 'bias', 'bn_scale', 'bn_shift')] + [('relu', C.c_int32)]
+
+
+class SteBlock(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('ln1_w', 'ln1_b', 'qkv_wt', 'qkv_b', 'proj_wt', 'proj_b', 'ln2_w', 'ln2_b',
+                                          'fc1_wt', 'fc1_b', 'fc2_wt', 'fc2_b')]
+
+
+class SteParams(C.Structure):
+    _fields_ = [('pos_embed', C.c_void_p), ('blocks', SteBlock * 3), ('num_blocks', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('snorm_w', 'snorm_b', 'head_ln_w', 'head_ln_b', 'head_wt', 'head_b')]
+
+
+class RegressParams(C.Structure):
+    _fields_ = [('mano_w', C.c_void_p * 2), ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p),
+                ('emb', TokenMlp)]
+
+
+class InitHeadParams(C.Structure):
+    _fields_ = [('attn_w', C.c_void_p * 2), ('attn_b', C.c_float * 2), ('mano_w', C.c_void_p * 2),
+                ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p)]
 
 
 DT_F32, DT_BF16 = 0, 1
@@ -37,6 +65,16 @@ _SIGNATURES = {
     'dir_last_error': (C.c_char_p, []),
     'dir_device_info': (C.c_int, [C.c_char_p, _i, C.POINTER(C.c_int)]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'dir_bone_proj_forward': (C.c_int, [_p, _p, _p, _p, _p, _i, _i, C.c_float, _i, _p]),
+    'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),
+                                          C.POINTER(TokenMlp), C.POINTER(TokenMlp), _p, _p, _i, _p]),
+    'dir_pgcn_stack_forward': (C.c_int, [C.POINTER(PgcnLayer), _i, _p, _p, _p, C.c_longlong, _p, _i, _p]),
+    'dir_ste_forward': (C.c_int, [C.POINTER(SteParams), _p, _p, _p, _i, _p]),
+    'dir_regress_forward': (C.c_int, [C.POINTER(RegressParams), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
 

@@ -259,7 +259,11 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
     const int in_cs = d->in_cstride ? d->in_cstride : d->Cin;
     const int out_cs = d->out_cstride ? d->out_cstride : d->Cout;
     const int res_cs = d->res_cstride ? d->res_cstride : d->Cout;
-    DIR_REQUIRE(in_cs % EPC == 0 && d->in_coff % EPC == 0, "dir_conv2d_forward: input channel slice must be 16-byte aligned");
+    // every 16-byte A chunk must be aligned: either whole pixels are (in_cs % EPC == 0), or -- the pre-padded NHWC4
+    // stem image -- rows and the horizontal stride are (kw == 1, pad == 0)
+    DIR_REQUIRE(d->in_coff % EPC == 0 && (in_cs % EPC == 0 || (d->kw == 1 && d->pad == 0 && (in_cs * d->stride) % EPC == 0 &&
+                                                             (in_cs * d->W) % EPC == 0)),
+                "dir_conv2d_forward: input channel slice must be 16-byte aligned");
     DIR_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "dir_conv2d_forward: pre_scale/pre_shift go together");
     ConvArgs a;
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.pre_scale = pre_scale; a.pre_shift = pre_shift;
@@ -267,8 +271,8 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = in_cs; a.in_co = d->in_coff;
     a.Cout = d->Cout; a.out_cs = out_cs; a.out_co = d->out_coff; a.res_cs = res_cs; a.res_co = d->res_coff;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
-    a.Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
-    a.Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    a.Ho = d->Ho > 0 ? d->Ho : (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    a.Wo = d->Wo > 0 ? d->Wo : (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     DIR_REQUIRE(a.Ho > 0 && a.Wo > 0, "dir_conv2d_forward: empty output");
     const long long M = (long long)d->B * a.Ho * a.Wo;
     DIR_REQUIRE(M < (1ll << 31), "dir_conv2d_forward: too many output pixels");

@@ -1,0 +1,338 @@
+// HBM-bound spatial kernels of the DIR path (NHWC feature maps, fp32 or bf16 storage, fp32 math):
+//   dir_stem_prep            NCHW fp32 image -> zero-padded NHWC4 so the 7x7/s2 stem becomes an implicit GEMM
+//   dir_maxpool3x3s2         models/backbone/resnet.py:247 (MaxPool2d(3,2,1))
+//   dir_upsample2x_bilinear  models/dir.py:392,398,442,459 (nn.Upsample(scale_factor=2,'bilinear'), align_corners=False),
+//                            written straight into a channel slice of the concat buffer
+//   dir_init_head_forward    models/dir.py:263-270 (1x1 conv -> sigmoid attention, attention-weighted pooling, Linears)
+//   dir_bone_proj_forward    models/dir.py:132-174 (bone_proj / lineseg_dists) for both hands, NHWC [B,S,S,2560]
+#include "dir_common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ------------------------------------------------------------------------------------------ stem prep
+template <typename T>
+__global__ void stem_prep_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int Hp,
+                                 int Wp, int pad) {
+    // one thread per padded pixel; writes 4 channels (RGB + 0)
+    const long long n = (long long)B * Hp * Wp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const int yp = (int)((i / Wp) % Hp);
+        const int b = (int)(i / ((long long)Wp * Hp));
+        const int x = xp - pad, y = yp - pad;
+        float v[3] = {0.f, 0.f, 0.f};
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = img[((long long)(b * 3 + c) * H + y) * W + x];
+        }
+        T* o = out + i * 4;
+        st<T>(o, v[0]); st<T>(o + 1, v[1]); st<T>(o + 2, v[2]); st<T>(o + 3, 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ maxpool
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+    const long long n = (long long)B * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float m = -INFINITY;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                m = fmaxf(m, ld<T>(x + ((long long)(b * H + iy) * W + ix) * C + c));
+            }
+        }
+        st<T>(y + i, m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ upsample
+template <typename T>
+__global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int ocs, int oco) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long n = (long long)B * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        // src = (dst + 0.5) * 0.5 - 0.5, clamped at 0 (ATen area_pixel_compute_source_index, align_corners=False)
+        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - y0, lx = sx - x0;
+        const T* base = x + (long long)b * H * W * C + c;
+        const float v00 = ld<T>(base + ((long long)y0 * W + x0) * C), v01 = ld<T>(base + ((long long)y0 * W + x1) * C);
+        const float v10 = ld<T>(base + ((long long)y1 * W + x0) * C), v11 = ld<T>(base + ((long long)y1 * W + x1) * C);
+        const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
+        st<T>(y + ((long long)(b * Ho + oy) * Wo + ox) * ocs + oco + c, top * (1.f - ly) + bot * ly);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ init head
+struct InitHeadArgs {
+    dir_init_head_params p;
+    const void* c4; const void* h[2];
+    float* para[2]; float* offset;
+    int HW, C, Ch;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void init_head_kernel(InitHeadArgs a) {
+    // one block per sample.  LDS: attention weights [2][HW], pooled features [3][C] (left, right, mean)
+    extern __shared__ float sm[];
+    float* s_attn = sm;                 // [2][HW]
+    float* s_feat = sm + 2 * a.HW;      // [3][C]
+    __shared__ float s_den[2];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HW = a.HW, C = a.C, Ch = a.Ch;
+    const T* c4 = (const T*)a.c4 + (long long)b * HW * C;
+    // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232)
+    for (int o = wave; o < 2 * HW; o += 4) {
+        const int s = o / HW, px = o - s * HW;
+        const T* h = (const T*)a.h[s] + ((long long)b * HW + px) * Ch;
+        const float* w = a.p.attn_w[s];
+        float acc = 0.f;
+        for (int k = lane; k < Ch; k += 64) acc = fmaf(ld<T>(h + k), w[k], acc);
+        acc = dir::wave_sum(acc);
+        if (lane == 0) s_attn[o] = 1.f / (1.f + expf(-(acc + a.p.attn_b[s])));
+    }
+    __syncthreads();
+    if (tid < 2) {
+        float d = 0.f;
+        for (int px = 0; px < HW; ++px) d += s_attn[tid * HW + px];
+        s_den[tid] = d + 1e-8f;                                     // models/dir.py:264
+    }
+    __syncthreads();
+    // 2) attention-weighted pooling and the plain spatial mean (models/dir.py:264-268)
+    for (int c = tid; c < C; c += 256) {
+        float fl = 0.f, fr = 0.f, fm = 0.f;
+        for (int px = 0; px < HW; ++px) {
+            const float v = ld<T>(c4 + (long long)px * C + c);
+            fl = fmaf(v, s_attn[px], fl);
+            fr = fmaf(v, s_attn[HW + px], fr);
+            fm += v;
+        }
+        s_feat[c] = fl / s_den[0];
+        s_feat[C + c] = fr / s_den[1];
+        s_feat[2 * C + c] = fm / (float)HW;
+    }
+    __syncthreads();
+    // 3) Linears: mano_left/right (64 outputs each) and offset (3) (models/dir.py:268-270)
+    for (int o = wave; o < 131; o += 4) {
+        const float* w; const float* f; float bias; float* dst;
+        if (o < 64) { w = a.p.mano_w[0] + (long long)o * C; f = s_feat; bias = a.p.mano_b[0][o]; dst = a.para[0] + (long long)b * 64 + o; }
+        else if (o < 128) { w = a.p.mano_w[1] + (long long)(o - 64) * C; f = s_feat + C; bias = a.p.mano_b[1][o - 64]; dst = a.para[1] + (long long)b * 64 + o - 64; }
+        else { w = a.p.off_w + (long long)(o - 128) * C; f = s_feat + 2 * C; bias = a.p.off_b[o - 128]; dst = a.offset + (long long)b * 3 + o - 128; }
+        float acc = 0.f;
+        for (int k = lane; k < C; k += 64) acc = fmaf(f[k], w[k], acc);
+        acc = dir::wave_sum(acc);
+        if (lane == 0) *dst = acc + bias;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bone_proj
+__constant__ int kParent[20] = {0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0, 17, 18, 19};
+__constant__ int kChild[20] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20};
+
+struct BoneArgs {
+    const float* uv[2]; const float* emb; void* out; float* vis;
+    int B, S; float distance;
+};
+
+// correctly rounded hypot (products of two floats are exact in double): ATen's CPU kernel (Sleef hypotf_u05) and
+// glibc are correctly rounded, the device libm's hypotf is not, and pixels lying exactly on the capsule boundary
+// flip on a 1-ulp difference.
+__device__ __forceinline__ float hypot_cr(float x, float y) {
+    return (float)sqrt((double)x * (double)x + (double)y * (double)y);
+}
+
+// point-segment distance exactly as lineseg_dists (models/dir.py:132-144): same fp32 op sequence, no FMA
+// contraction, so the `distance < threshold` mask is bit-identical to the reference's.
+__device__ __forceinline__ void bone_weights(float px, float py, float ax, float ay, float bx, float by, float thr,
+                                             float& wa, float& wb, bool& inside) {
+#pragma clang fp contract(off)
+    const float dbx = bx - ax, dby = by - ay;
+    const float len = hypot_cr(dbx, dby);
+    const float dx = dbx / len, dy = dby / len;
+    const float s = (ax - px) * dx + (ay - py) * dy;
+    const float t = (px - bx) * dx + (py - by) * dy;
+    const float h = fmaxf(fmaxf(s, t), 0.f);
+    const float dpx = px - ax, dpy = py - ay;
+    const float c = dpx * dy - dpy * dx;
+    const float dist = hypot_cr(h, c);
+    inside = dist < thr;                                  // NaN (zero-length bone) -> false, like torch.lt
+    // F.pairwise_distance(p, a): || p - a + 1e-6 ||_2  (models/dir.py:164-167)
+    const float eax = px - ax + 1e-6f, eay = py - ay + 1e-6f;
+    const float ebx = px - bx + 1e-6f, eby = py - by + 1e-6f;
+    const float da = sqrtf(eax * eax + eay * eay), db = sqrtf(ebx * ebx + eby * eby);
+    wa = 1.f - da / (da + db);
+    wb = 1.f - db / (da + db);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
+    // one block per (sample, image row).  LDS: token features [42][64], per-(x,hand,bone) weights and mask.
+    extern __shared__ float sm[];
+    const int S = a.S;
+    float* s_emb = sm;                       // [42*64]
+    float* s_wa = s_emb + 42 * 64;           // [S*40]
+    float* s_wb = s_wa + S * 40;             // [S*40]
+    float* s_uv = s_wb + S * 40;             // [42*2] pixel units
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(s_uv + 84);   // [S*40] capsule mask
+    const int b = blockIdx.x / S, y = blockIdx.x - b * S, tid = threadIdx.x;
+    for (int i = tid; i < 42 * 64; i += 256) s_emb[i] = a.emb[(long long)b * 42 * 64 + i];
+    if (tid < 84) {
+#pragma clang fp contract(off)
+        const int hand = tid / 42, r = tid - hand * 42;
+        const float v = a.uv[hand][(long long)b * 42 + r];
+        s_uv[tid] = (v + 1.f) / 2.f * (float)S;                      // models/dir.py:150
+    }
+    __syncthreads();
+    const float py = (float)y + 0.5f;                                 // img_gird: (x+0.5, y+0.5), models/dir.py:66-70
+    for (int i = tid; i < S * 40; i += 256) {
+        const int x = i / 40, hb = i - x * 40, hand = hb / 20, bone = hb - hand * 20;
+        const float* uv = s_uv + hand * 42;
+        const int pa = kParent[bone], ch = kChild[bone];
+        float wa, wb; bool in;
+        bone_weights((float)x + 0.5f, py, uv[2 * pa], uv[2 * pa + 1], uv[2 * ch], uv[2 * ch + 1], a.distance, wa, wb, in);
+        s_wa[i] = wa;
+        s_wb[i] = wb;
+        s_in[i] = in ? 1 : 0;
+    }
+    __syncthreads();
+    // NHWC write: [b][y][x][hand*1280 + bone*64 + c], 8 channels per thread-item, fully coalesced
+    T* orow = (T*)a.out + ((long long)(b * S + y) * S) * 2560;
+    for (int i = tid; i < S * 40 * 8; i += 256) {
+        const int c8 = i & 7, xhb = i >> 3;
+        const int x = xhb / 40, hb = xhb - x * 40, hand = hb / 20, bone = hb - hand * 20;
+        const float wa = s_wa[xhb], wb = s_wb[xhb];
+        const bool masked = s_in[xhb] == 0;                            // torch.where(mask, v, 0), models/dir.py:172
+        const float* fa = s_emb + (hand * 21 + kParent[bone]) * 64 + c8 * 8;
+        const float* fb = s_emb + (hand * 21 + kChild[bone]) * 64 + c8 * 8;
+        T* o = orow + (long long)x * 2560 + hb * 64 + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma clang fp contract(off)
+            const float v = masked ? 0.f : fa[e] * wa + fb[e] * wb;    // models/dir.py:170-172
+            st<T>(o + e, v);
+        }
+    }
+    if (a.vis) {
+        // vis_img_feat = left + right, NCHW fp32 [B,1280,S,S] (models/dir.py:128,481): threads run along x
+        float* vrow = a.vis + (long long)b * 1280 * S * S + (long long)y * S;
+        for (int i = tid; i < 1280 * S; i += 256) {
+            const int x = i % S, ch = i / S, bone = ch >> 6, c = ch & 63;
+            float acc = 0.f;
+#pragma unroll
+            for (int hand = 0; hand < 2; ++hand) {
+#pragma clang fp contract(off)
+                const int xhb = x * 40 + hand * 20 + bone;
+                const float wa = s_wa[xhb], wb = s_wb[xhb];
+                const float v = (s_in[xhb] == 0) ? 0.f
+                                           : s_emb[(hand * 21 + kParent[bone]) * 64 + c] * wa +
+                                                 s_emb[(hand * 21 + kChild[bone]) * 64 + c] * wb;
+                acc = hand == 0 ? v : acc + v;
+            }
+            vrow[(long long)ch * S * S + x] = acc;
+        }
+    }
+}
+
+inline int grid_for(long long n, int block = 256) {
+    long long g = (n + block - 1) / block;
+    return (int)(g > 256 * 16 ? 256 * 16 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int W, int Hp, int Wp, int pad,
+                             int dtype, void* stream) {
+    DIR_REQUIRE(img_nchw && out && B > 0 && H > 0 && W > 0 && Hp >= H + pad && Wp >= W + pad, "dir_stem_prep: bad args");
+    const long long n = (long long)B * Hp * Wp;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((stem_prep_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hp, Wp, pad);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad);
+    else DIR_REQUIRE(false, "dir_stem_prep: bad dtype");
+    return dir::check_launch("dir_stem_prep");
+}
+
+extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+    DIR_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "dir_maxpool3x3s2: bad args");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long n = (long long)B * Ho * Wo * C;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((maxpool_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((maxpool_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+    else DIR_REQUIRE(false, "dir_maxpool3x3s2: bad dtype");
+    return dir::check_launch("dir_maxpool3x3s2");
+}
+
+extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, int out_cstride,
+                                       int out_coff, int dtype, void* stream) {
+    DIR_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "dir_upsample2x_bilinear: bad args");
+    const int ocs = out_cstride ? out_cstride : C;
+    const long long n = (long long)B * 4 * H * W * C;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((upsample_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((upsample_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
+    else DIR_REQUIRE(false, "dir_upsample2x_bilinear: bad dtype");
+    return dir::check_launch("dir_upsample2x_bilinear");
+}
+
+extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* c4, const void* h_left,
+                                     const void* h_right, float* para_left, float* para_right, float* offset, int B,
+                                     int HW, int C, int Ch, int dtype, void* stream) {
+    DIR_REQUIRE(p && c4 && h_left && h_right && para_left && para_right && offset, "dir_init_head_forward: null pointer");
+    DIR_REQUIRE(B > 0 && HW > 0 && C > 0 && Ch > 0, "dir_init_head_forward: bad shape");
+    InitHeadArgs a;
+    a.p = *p; a.c4 = c4; a.h[0] = h_left; a.h[1] = h_right; a.para[0] = para_left; a.para[1] = para_right;
+    a.offset = offset; a.HW = HW; a.C = C; a.Ch = Ch;
+    const size_t lds = (size_t)(2 * HW + 3 * C) * sizeof(float);
+    DIR_REQUIRE(lds <= 60000, "dir_init_head_forward: feature too large for LDS");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((init_head_kernel<float>), dim3(B), dim3(256), lds, s, a);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((init_head_kernel<bf16_t>), dim3(B), dim3(256), lds, s, a);
+    else DIR_REQUIRE(false, "dir_init_head_forward: bad dtype");
+    return dir::check_launch("dir_init_head_forward");
+}
+
+extern "C" int dir_bone_proj_forward(const float* uv_left, const float* uv_right, const float* emb, void* out,
+                                     float* vis_nchw, int B, int S, float distance, int dtype, void* stream) {
+    DIR_REQUIRE(uv_left && uv_right && emb && out, "dir_bone_proj_forward: null pointer");
+    DIR_REQUIRE(B > 0 && S > 0 && S <= 64, "dir_bone_proj_forward: bad shape");
+    BoneArgs a;
+    a.uv[0] = uv_left; a.uv[1] = uv_right; a.emb = emb; a.out = out; a.vis = vis_nchw; a.B = B; a.S = S;
+    a.distance = distance;
+    const size_t lds = (size_t)(42 * 64 + 2 * S * 40 + 84) * sizeof(float) + (size_t)S * 40;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((bone_proj_kernel<float>), dim3(B * S), dim3(256), lds, s, a);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((bone_proj_kernel<bf16_t>), dim3(B * S), dim3(256), lds, s, a);
+    else DIR_REQUIRE(false, "dir_bone_proj_forward: bad dtype");
+    return dir::check_launch("dir_bone_proj_forward");
+}

@@ -1,0 +1,151 @@
+// a6: mixSTE spatial transformer encoder over the 42 joint tokens of both hands, one workgroup per sample.
+// Replaces transformer/mixSTE.py:194-205 (STE.forward), :129-131 (Block), :76-97 (Attention), :39-44 (Mlp):
+//   x += pos_embed ; for blocks 1..depth-1 (block 0 is never executed by the reference):
+//       x += proj(softmax(q k^T * 32^-0.5) v) ; x += fc2(gelu_erf(fc1(LN(x)))) ; x = spatial_norm(x)
+//   y = Linear(LN_1e-5(x)).
+// All activations ([42][128] residual stream, [42][384] qkv / [42][256] MLP hidden, 4 x [42][42] attention
+// probabilities) stay in LDS (~136 KB of the CU's 160 KB); LayerNorm and softmax reduce with wavefront shuffles
+// (one wave per token / per attention row); weights are read k-major (coalesced along the output column) from L2.
+// fp32 throughout (feeds MANO; ~36 MFLOP per sample).
+#include "dir_common.h"
+
+namespace {
+
+constexpr int NT = 42, D = 128, HEADS = 4, HD = 32, NTHREADS = 512, NWAVES = 8;
+constexpr int TG = 7, NGROUPS = 6;   // 6 groups of 7 tokens
+
+struct SteArgs {
+    dir_ste_params p;
+    float* x_inout; const float* x_in; float* y; int nblocks;
+};
+
+// LayerNorm over the channel dim, one wave per token (2 channels per lane), two-pass variance like ATen
+__device__ __forceinline__ void layernorm_tokens(const float* s_in, float* s_out, const float* w, const float* b,
+                                                 float eps, int wave, int lane) {
+    for (int t = wave; t < NT; t += NWAVES) {
+        const float v0 = s_in[t * D + lane], v1 = s_in[t * D + 64 + lane];
+        const float mean = dir::wave_sum(v0 + v1) * (1.f / D);
+        const float d0 = v0 - mean, d1 = v1 - mean;
+        const float var = dir::wave_sum(d0 * d0 + d1 * d1) * (1.f / D);
+        const float rstd = 1.f / sqrtf(var + eps);
+        s_out[t * D + lane] = d0 * rstd * w[lane] + b[lane];
+        s_out[t * D + 64 + lane] = d1 * rstd * w[64 + lane] + b[64 + lane];
+    }
+}
+
+// out[t][n] = f( sum_k s_in[t][k] * Wt[k][n] + bias[n] ), t < 42.  Work item = (token group, n); consecutive
+// lanes take consecutive n (coalesced weight reads, LDS operand broadcast).
+template <int K, typename F>
+__device__ __forceinline__ void linear_tokens(const float* s_in, int ldi, const float* __restrict__ Wt,
+                                              const float* __restrict__ bias, int N, int tid, F store) {
+    for (int item = tid; item < NGROUPS * N; item += NTHREADS) {
+        const int tg = item / N, n = item - tg * N;
+        float acc[TG];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = 0.f;
+        const float* xin = s_in + tg * TG * ldi;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float w = Wt[(long long)k * N + n];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t] = fmaf(xin[t * ldi + k], w, acc[t]);
+        }
+        const float bv = bias[n];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) store(tg * TG + t, n, acc[t] + bv);
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * NT * D + NT * 384 + HEADS * NT * NT];   // 135,744 B
+    float* s_x = sm;                      // [42][128] residual stream
+    float* s_n = s_x + NT * D;            // [42][128] LayerNorm output / attention output
+    float* s_big = s_n + NT * D;          // [42][384] qkv, later [42][256] MLP hidden
+    float* s_p = s_big + NT * 384;        // [4][42][42] attention probabilities
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const float* xin = a.x_in + (long long)b * NT * D;
+    for (int i = tid; i < NT * D; i += NTHREADS) {
+        const float v = xin[i] + a.p.pos_embed[i];                      // x += spatial_pos_embed (mixSTE.py:196)
+        s_x[i] = v;
+        if (a.x_inout) a.x_inout[(long long)b * NT * D + i] = v;        // the reference mutates its input in place
+    }
+    __syncthreads();
+
+    for (int blk = 0; blk < a.nblocks; ++blk) {
+        const dir_ste_block& P = a.p.blocks[blk];
+        // ---- attention branch
+        layernorm_tokens(s_x, s_n, P.ln1_w, P.ln1_b, 1e-6f, wave, lane);
+        __syncthreads();
+        linear_tokens<D>(s_n, D, P.qkv_wt, P.qkv_b, 384, tid, [&](int t, int n, float v) { s_big[t * 384 + n] = v; });
+        __syncthreads();
+        // scores: qkv column layout is (3, heads, 32) (mixSTE.py:78): q = [0,128), k = [128,256), v = [256,384)
+        const float scale = 0.17677669529663687f;                       // 32 ** -0.5
+        for (int i = tid; i < HEADS * NT * NT; i += NTHREADS) {
+            const int h = i / (NT * NT), r = i - h * NT * NT, qi = r / NT, kj = r - qi * NT;
+            const float* q = s_big + qi * 384 + h * HD;
+            const float* k = s_big + kj * 384 + 128 + h * HD;
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc = fmaf(q[d], k[d], acc);
+            s_p[i] = acc * scale;
+        }
+        __syncthreads();
+        for (int row = wave; row < HEADS * NT; row += NWAVES) {        // softmax: one wave per row of 42
+            float v = lane < NT ? s_p[row * NT + lane] : -INFINITY;
+            const float mx = dir::wave_max(v);
+            const float e = lane < NT ? expf(v - mx) : 0.f;
+            const float sum = dir::wave_sum(e);
+            if (lane < NT) s_p[row * NT + lane] = e / sum;
+        }
+        __syncthreads();
+        for (int i = tid; i < NT * D; i += NTHREADS) {                  // o = P v, heads concatenated (mixSTE.py:94)
+            const int t = i >> 7, c = i & 127, h = c >> 5;
+            const float* p = s_p + (h * NT + t) * NT;
+            float acc = 0.f;
+            for (int j = 0; j < NT; ++j) acc = fmaf(p[j], s_big[j * 384 + 256 + c], acc);
+            s_n[i] = acc;
+        }
+        __syncthreads();
+        linear_tokens<D>(s_n, D, P.proj_wt, P.proj_b, D, tid, [&](int t, int n, float v) { s_x[t * D + n] += v; });
+        __syncthreads();
+        // ---- MLP branch
+        layernorm_tokens(s_x, s_n, P.ln2_w, P.ln2_b, 1e-6f, wave, lane);
+        __syncthreads();
+        linear_tokens<D>(s_n, D, P.fc1_wt, P.fc1_b, 256, tid, [&](int t, int n, float v) {
+            s_big[t * 256 + n] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));          // exact GELU
+        });
+        __syncthreads();
+        linear_tokens<256>(s_big, 256, P.fc2_wt, P.fc2_b, D, tid, [&](int t, int n, float v) { s_x[t * D + n] += v; });
+        __syncthreads();
+        // ---- spatial_norm after every block (mixSTE.py:200)
+        layernorm_tokens(s_x, s_n, a.p.snorm_w, a.p.snorm_b, 1e-6f, wave, lane);
+        __syncthreads();
+        for (int i = tid; i < NT * D; i += NTHREADS) s_x[i] = s_n[i];
+        __syncthreads();
+    }
+    // ---- head: LayerNorm(eps 1e-5) + Linear 128 -> 64 (mixSTE.py:187-190)
+    layernorm_tokens(s_x, s_n, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, wave, lane);
+    __syncthreads();
+    float* y = a.y + (long long)b * NT * 64;
+    linear_tokens<D>(s_n, D, a.p.head_wt, a.p.head_b, 64, tid, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+}
+
+}  // namespace
+
+extern "C" int dir_ste_forward(const dir_ste_params* p, const float* x, float* x_pos_out, float* y, int B,
+                               void* stream) {
+    DIR_REQUIRE(p && x && y, "dir_ste_forward: null pointer");
+    DIR_REQUIRE(B > 0 && p->num_blocks >= 0 && p->num_blocks <= 3, "dir_ste_forward: bad B / num_blocks");
+    DIR_REQUIRE(p->pos_embed && p->snorm_w && p->snorm_b && p->head_ln_w && p->head_ln_b && p->head_wt && p->head_b,
+                "dir_ste_forward: null parameter");
+    for (int i = 0; i < p->num_blocks; ++i) {
+        const dir_ste_block& b = p->blocks[i];
+        DIR_REQUIRE(b.ln1_w && b.ln1_b && b.qkv_wt && b.qkv_b && b.proj_wt && b.proj_b && b.ln2_w && b.ln2_b &&
+                        b.fc1_wt && b.fc1_b && b.fc2_wt && b.fc2_b, "dir_ste_forward: null block parameter");
+    }
+    SteArgs a;
+    a.p = *p; a.x_in = x; a.x_inout = x_pos_out; a.y = y; a.nblocks = p->num_blocks;
+    hipLaunchKernelGGL(ste_kernel, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    return dir::check_launch("dir_ste_forward");
+}

@@ -1,0 +1,383 @@
+// Joint-token kernels of one DIR refinement stage (fp32 throughout: these feed MANO, whose 1e-4 mm parity
+// budget leaves no room for reduced precision; the work is ~0.1 GFLOP/image, launch/HBM bound, not MFMA bound).
+//
+//   dir_grid_tokens_forward  a4+a12: F.grid_sample at 21 joint uv + Conv1d-BN-ReLU-Conv1d, pos_emb, global_pos_emb
+//                            (models/dir.py:94-101,106-107,197-200)
+//   dir_pgcn_stack_forward   a5: ResSimplePGCN = 4 x [PGraphConv -> BN1d -> ReLU]
+//                            (SemGCN/p_graph_conv.py:39-59, SemGCN/p_gcn.py:20-27,71-73)
+//   dir_regress_forward      a7+a12: RegressorOffset Linears + proj_feat_emb (models/dir.py:118-119,339-351)
+//
+// P-GCN decomposition: the per-node weights W[2][21][128][128] (2.75 MB/layer) dominate the bytes, activations are
+// 10x smaller.  One workgroup owns (hand, node j, 64-column slice): it streams its 2 x 128x64 weight slice ONCE
+// (coalesced along the output column) and applies it to that node's row of every sample in the batch held in LDS.
+// The neighbour mix  out[j] = h0[j] + sum_k softmax(e_1)[j,k] h1[k] + b  (<= 5 neighbours on the hand skeleton),
+// BatchNorm and ReLU of layer l are applied in the LDS-staging prologue of layer l+1, so a layer is ONE launch.
+#include "dir_common.h"
+
+namespace {
+
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+constexpr int NJ = 21;
+
+// hand skeleton adjacency in CSR form; entries are in the row-major nonzero order that indexes e_1
+// (SemGCN/utils.py:66-71 edges, SemGCN/p_graph_conv.py:26-30 mask order)
+__constant__ int kNbrOff[22] = {0, 5, 7, 9, 11, 12, 14, 16, 18, 19, 21, 23, 25, 26, 28, 30, 32, 33, 35, 37, 39, 40};
+__constant__ int kNbrIdx[40] = {1, 5, 9, 13, 17, 0, 2, 1, 3, 2, 4, 3, 0, 6, 5, 7, 6, 8, 7, 0,
+                                10, 9, 11, 10, 12, 11, 0, 14, 13, 15, 14, 16, 15, 0, 18, 17, 19, 18, 20, 19};
+
+// --------------------------------------------------------------------------------------------- grid tokens
+struct GridArgs {
+    const void* feat; int S; int C; int fcs; int fco;
+    const float* uv[2]; const float* xyz[2]; const float* offset;
+    dir_token_mlp img2joint[2]; dir_token_mlp pos_emb[2]; dir_token_mlp gpos;
+    float* x0; float* g;       // [2][B][21][128]
+    int B;
+};
+
+// Conv1d(k=1) -> folded BN -> ReLU -> Conv1d(k=1) over 21 tokens.  Thread (o, g) owns output channel o for the
+// tokens j = g, g+2, ...  s_in [21][K1], s_hid [21][128]; result accumulated into acc[].
+template <int K1>
+__device__ __forceinline__ void token_mlp128(const float* s_in, const dir_token_mlp& m, float* s_hid, float (&acc)[11],
+                                             int o, int g) {
+    float h[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) h[t] = 0.f;
+    for (int k = 0; k < K1; ++k) {
+        const float w = m.w1t[k * 128 + o];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const int j = g + 2 * t;
+            if (j < NJ) h[t] = fmaf(w, s_in[j * K1 + k], h[t]);
+        }
+    }
+    const float s1 = m.s1[o], b1 = m.b1[o];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const int j = g + 2 * t;
+        if (j < NJ) s_hid[j * 128 + o] = fmaxf(fmaf(h[t], s1, b1), 0.f);
+    }
+    __syncthreads();
+    float a2[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) a2[t] = 0.f;
+    for (int k = 0; k < 128; ++k) {
+        const float w = m.w2t[k * 128 + o];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const int j = g + 2 * t;
+            if (j < NJ) a2[t] = fmaf(w, s_hid[j * 128 + k], a2[t]);
+        }
+    }
+    const float b2 = m.b2[o];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) acc[t] += a2[t] + b2;
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
+    __shared__ float s_samp[NJ * 256];
+    __shared__ float s_hid[NJ * 128];
+    __shared__ float s_p[NJ * 3], s_q[NJ * 3];
+    __shared__ float s_w[NJ * 4];
+    __shared__ int s_i[NJ * 4];
+    const int b = blockIdx.x, hand = blockIdx.y, tid = threadIdx.x;
+    const int S = a.S, C = a.C;
+    if (tid < NJ) {
+        // F.grid_sample, bilinear / zeros / align_corners=False: ix = ((u + 1) * W - 1) / 2
+#pragma clang fp contract(off)
+        const float u = a.uv[hand][((long long)b * NJ + tid) * 2], v = a.uv[hand][((long long)b * NJ + tid) * 2 + 1];
+        const float ix = ((u + 1.f) * (float)S - 1.f) / 2.f, iy = ((v + 1.f) * (float)S - 1.f) / 2.f;
+        const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.f, y1 = y0 + 1.f;
+        const float wx[2] = {x1 - ix, ix - x0}, wy[2] = {y1 - iy, iy - y0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {            // order nw, ne, sw, se
+            const float xx = (t & 1) ? x1 : x0, yy = (t & 2) ? y1 : y0;
+            const bool ok = xx >= 0.f && xx <= (float)(S - 1) && yy >= 0.f && yy <= (float)(S - 1);
+            s_w[tid * 4 + t] = ok ? wx[t & 1] * wy[t >> 1] : 0.f;
+            s_i[tid * 4 + t] = ok ? ((int)yy * S + (int)xx) : -1;
+        }
+    }
+    if (tid >= 64 && tid < 64 + NJ * 3) {
+#pragma clang fp contract(off)
+        const int i = tid - 64, c = i % 3;
+        const float p = a.xyz[hand][(long long)b * NJ * 3 + i] / 0.15f;          // models/dir.py:97
+        const float off = a.offset[(long long)b * 3 + c] / 2.f;
+        s_p[i] = p;
+        s_q[i] = hand == 0 ? p - off : p + off;                                   // models/dir.py:106-107
+    }
+    __syncthreads();
+    const T* fb = (const T*)a.feat + (long long)b * S * S * a.fcs + a.fco;
+    for (int i = tid; i < NJ * C; i += 256) {
+        const int j = i / C, c = i - j * C;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pix = s_i[j * 4 + t];
+            if (pix >= 0) acc += ld<T>(fb + (long long)pix * a.fcs + c) * s_w[j * 4 + t];
+        }
+        s_samp[j * 256 + c] = acc;
+    }
+    __syncthreads();
+    const int o = tid & 127, g = tid >> 7;
+    float acc[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) acc[t] = 0.f;
+    token_mlp128<256>(s_samp, a.img2joint[hand], s_hid, acc, o, g);
+    token_mlp128<3>(s_p, a.pos_emb[hand], s_hid, acc, o, g);                      // x0 = pos + img (models/dir.py:100)
+    float* x0 = a.x0 + ((long long)hand * a.B + b) * NJ * 128;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const int j = g + 2 * t;
+        if (j < NJ) x0[j * 128 + o] = acc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 11; ++t) acc[t] = 0.f;
+    token_mlp128<3>(s_q, a.gpos, s_hid, acc, o, g);
+    float* gp = a.g + ((long long)hand * a.B + b) * NJ * 128;
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const int j = g + 2 * t;
+        if (j < NJ) gp[j * 128 + o] = acc[t];
+    }
+}
+
+// --------------------------------------------------------------------------------------------- P-GCN
+struct PgcnArgs {
+    const float* W; const float* x_in;          // layer weights [2][21][128][128]; x_in [B][21][128] (layer 0 only)
+    const float* h_prev;                        // [B][21][256] = (h0 | h1) of the previous layer (layers >= 1)
+    const float* e1_prev; const float* bias_prev; const float* bns_prev; const float* bnb_prev; int relu_prev;
+    float* h_out;                               // [B][21][256]
+    int B;
+};
+
+__device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (&w)[5], int (&idx)[5], int& deg) {
+    // row j of softmax(A_1) where A_1 = -9e15 off the skeleton edges (SemGCN/p_graph_conv.py:43-50)
+    const int o0 = kNbrOff[j];
+    deg = kNbrOff[j + 1] - o0;
+    float mx = -INFINITY;
+    for (int t = 0; t < deg; ++t) mx = fmaxf(mx, e1[o0 + t]);
+    float sum = 0.f;
+    for (int t = 0; t < deg; ++t) { w[t] = expf(e1[o0 + t] - mx); sum += w[t]; idx[t] = kNbrIdx[o0 + t]; }
+    for (int t = 0; t < deg; ++t) w[t] /= sum;
+}
+
+// grid (21 nodes, 2 slices of 64 output columns).  256 threads: o = tid & 63, bg = tid >> 6 (16 samples each).
+__global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs a) {
+    __shared__ float s_x[64 * 128];
+    const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
+    const int o = slice * 64 + (tid & 63), bg = tid >> 6;
+    float wgt[5]; int nidx[5]; int deg = 0;
+    if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
+    const float* W0 = a.W + ((long long)j * 128) * 128 + o;
+    const float* W1 = a.W + ((long long)(NJ + j) * 128) * 128 + o;
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        const int nb = min(64, a.B - b0);
+        // ---- stage this node's input rows for 64 samples; layers >= 1 finish the previous layer here
+        for (int i = tid; i < 64 * 128; i += 256) {
+            const int bb = i >> 7, k = i & 127;
+            float v = 0.f;
+            if (bb < nb) {
+                const long long b = b0 + bb;
+                if (!a.h_prev) v = a.x_in[(b * NJ + j) * 128 + k];
+                else {
+                    const float* hb = a.h_prev + b * NJ * 256;
+                    float acc = 0.f;
+                    for (int t = 0; t < deg; ++t) acc = fmaf(wgt[t], hb[nidx[t] * 256 + 128 + k], acc);
+                    v = hb[j * 256 + k] + acc + a.bias_prev[k];                     // output_0 + output_1 + bias
+                    v = fmaf(v, a.bns_prev[k], a.bnb_prev[k]);                      // BN1d (eval)
+                    if (a.relu_prev) v = fmaxf(v, 0.f);
+                }
+            }
+            s_x[i] = v;
+        }
+        __syncthreads();
+        float a0[16], a1[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+        for (int k = 0; k < 128; k += 4) {
+            float w0[4], w1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { w0[q] = W0[(k + q) * 128]; w1[q] = W1[(k + q) * 128]; }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float4 xv = *reinterpret_cast<const float4*>(s_x + (bg * 16 + t) * 128 + k);
+                a0[t] = fmaf(xv.x, w0[0], a0[t]); a0[t] = fmaf(xv.y, w0[1], a0[t]);
+                a0[t] = fmaf(xv.z, w0[2], a0[t]); a0[t] = fmaf(xv.w, w0[3], a0[t]);
+                a1[t] = fmaf(xv.x, w1[0], a1[t]); a1[t] = fmaf(xv.y, w1[1], a1[t]);
+                a1[t] = fmaf(xv.z, w1[2], a1[t]); a1[t] = fmaf(xv.w, w1[3], a1[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int bb = bg * 16 + t;
+            if (bb < nb) {
+                float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
+                hb[o] = a0[t];
+                hb[128 + o] = a1[t];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct MixArgs {
+    const float* h; const float* e1; const float* bias; const float* bns; const float* bnb;
+    const float* add; float* out; long long out_bstride; int B; int relu;
+};
+// finishes the last layer: out[b][j][:] = relu(bn(h0 + A1 h1 + bias)) (+ add)
+__global__ __launch_bounds__(128) void pgcn_mix_kernel(MixArgs a) {
+    const int b = blockIdx.x, j = blockIdx.y, k = threadIdx.x;
+    float wgt[5]; int nidx[5]; int deg;
+    edge_softmax_row(a.e1, j, wgt, nidx, deg);
+    const float* hb = a.h + (long long)b * NJ * 256;
+    float acc = 0.f;
+    for (int t = 0; t < deg; ++t) acc = fmaf(wgt[t], hb[nidx[t] * 256 + 128 + k], acc);
+    float v = hb[j * 256 + k] + acc + a.bias[k];
+    v = fmaf(v, a.bns[k], a.bnb[k]);
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.add) v += a.add[((long long)b * NJ + j) * 128 + k];
+    a.out[(long long)b * a.out_bstride + j * 128 + k] = v;
+}
+
+// --------------------------------------------------------------------------------------------- regressor
+struct RegArgs {
+    dir_regress_params p;
+    const float* tok; const float* prev_para[2]; const float* prev_off;
+    float* para[2]; float* off; float* emb;
+};
+
+__global__ __launch_bounds__(256) void regress_kernel(RegArgs a) {
+    __shared__ float s_tok[42 * 64];
+    __shared__ float s_hid[42 * 64];
+    __shared__ float s_para[2 * 64];
+    __shared__ float s_off[3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 42 * 64; i += 256) s_tok[i] = a.tok[(long long)b * 42 * 64 + i];
+    if (tid < 128) s_para[tid] = a.prev_para[tid >> 6][(long long)b * 64 + (tid & 63)];
+    if (tid >= 128 && tid < 131) s_off[tid - 128] = a.prev_off[(long long)b * 3 + tid - 128];
+    __syncthreads();
+    // Linear(1408 -> 64) x 2 and Linear(2691 -> 3) (models/dir.py:342-351); token flatten is joint-major j*64+c
+    for (int o = wave; o < 131; o += 4) {
+        float acc = 0.f;
+        if (o < 128) {
+            const int s = o >> 6, oo = o & 63;
+            const float* w = a.p.mano_w[s] + (long long)oo * 1408;
+            const float* t = s_tok + s * 1344;
+            for (int k = lane; k < 1344; k += 64) acc = fmaf(t[k], w[k], acc);
+            acc = fmaf(s_para[s * 64 + lane], w[1344 + lane], acc);
+            acc = dir::wave_sum(acc);
+            if (lane == 0) a.para[s][(long long)b * 64 + oo] = acc + a.p.mano_b[s][oo];
+        } else {
+            const int oo = o - 128;
+            const float* w = a.p.off_w + (long long)oo * 2691;
+            for (int k = lane; k < 2688; k += 64) acc = fmaf(s_tok[k], w[k], acc);
+            if (lane < 3) acc = fmaf(s_off[lane], w[2688 + lane], acc);
+            acc = dir::wave_sum(acc);
+            if (lane == 0) a.off[(long long)b * 3 + oo] = acc + a.p.off_b[oo];
+        }
+    }
+    // proj_feat_emb: Conv1d(64,64,1) -> BN -> ReLU -> Conv1d(64,64,1) on every token (models/dir.py:51-56,118-119)
+    const dir_token_mlp& m = a.p.emb;
+    const int o = tid & 63, g = tid >> 6;
+    float h[11];
+#pragma unroll
+    for (int t = 0; t < 11; ++t) h[t] = 0.f;
+    for (int k = 0; k < 64; ++k) {
+        const float w = m.w1t[k * 64 + o];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const int j = g + 4 * t;
+            if (j < 42) h[t] = fmaf(w, s_tok[j * 64 + k], h[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const int j = g + 4 * t;
+        if (j < 42) s_hid[j * 64 + o] = fmaxf(fmaf(h[t], m.s1[o], m.b1[o]), 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 11; ++t) h[t] = 0.f;
+    for (int k = 0; k < 64; ++k) {
+        const float w = m.w2t[k * 64 + o];
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            const int j = g + 4 * t;
+            if (j < 42) h[t] = fmaf(w, s_hid[j * 64 + k], h[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 11; ++t) {
+        const int j = g + 4 * t;
+        if (j < 42) a.emb[((long long)b * 42 + j) * 64 + o] = h[t] + m.b2[o];
+    }
+}
+
+bool mlp_ok(const dir_token_mlp& m) { return m.w1t && m.s1 && m.b1 && m.w2t && m.b2; }
+
+}  // namespace
+
+extern "C" int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, int C, int feat_cstride, int feat_coff,
+                                       const float* uv_left,
+                                       const float* uv_right, const float* xyz_left, const float* xyz_right,
+                                       const float* offset, const dir_token_mlp* img2joint_lr,
+                                       const dir_token_mlp* pos_emb_lr, const dir_token_mlp* global_pos_emb,
+                                       float* x0, float* gpos, int B, void* stream) {
+    DIR_REQUIRE(feat && uv_left && uv_right && xyz_left && xyz_right && offset && img2joint_lr && pos_emb_lr &&
+                    global_pos_emb && x0 && gpos, "dir_grid_tokens_forward: null pointer");
+    DIR_REQUIRE(B > 0 && S > 0 && C == 256, "dir_grid_tokens_forward: need B>0, S>0, C==256");
+    DIR_REQUIRE(mlp_ok(img2joint_lr[0]) && mlp_ok(img2joint_lr[1]) && mlp_ok(pos_emb_lr[0]) && mlp_ok(pos_emb_lr[1]) &&
+                    mlp_ok(*global_pos_emb), "dir_grid_tokens_forward: incomplete MLP parameters");
+    GridArgs a;
+    a.feat = feat; a.S = S; a.C = C; a.fcs = feat_cstride ? feat_cstride : C; a.fco = feat_coff; a.uv[0] = uv_left; a.uv[1] = uv_right; a.xyz[0] = xyz_left; a.xyz[1] = xyz_right;
+    a.offset = offset; a.img2joint[0] = img2joint_lr[0]; a.img2joint[1] = img2joint_lr[1];
+    a.pos_emb[0] = pos_emb_lr[0]; a.pos_emb[1] = pos_emb_lr[1]; a.gpos = *global_pos_emb; a.x0 = x0; a.g = gpos; a.B = B;
+    hipStream_t s = (hipStream_t)stream;
+    if (feat_dtype == DIR_DT_F32) hipLaunchKernelGGL((grid_tokens_kernel<float>), dim3(B, 2), dim3(256), 0, s, a);
+    else if (feat_dtype == DIR_DT_BF16) hipLaunchKernelGGL((grid_tokens_kernel<bf16_t>), dim3(B, 2), dim3(256), 0, s, a);
+    else DIR_REQUIRE(false, "dir_grid_tokens_forward: bad dtype");
+    return dir::check_launch("dir_grid_tokens_forward");
+}
+
+extern "C" int dir_pgcn_stack_forward(const dir_pgcn_layer* layers, int num_layers, const float* x, const float* add,
+                                      float* out, long long out_bstride, float* scratch, int B, void* stream) {
+    DIR_REQUIRE(layers && x && out && scratch, "dir_pgcn_stack_forward: null pointer");
+    DIR_REQUIRE(num_layers >= 1 && B > 0 && out_bstride >= NJ * 128, "dir_pgcn_stack_forward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* hbuf[2] = {scratch, scratch + (long long)B * NJ * 256};
+    for (int l = 0; l < num_layers; ++l) {
+        const dir_pgcn_layer& L = layers[l];
+        DIR_REQUIRE(L.W && L.e1 && L.bias && L.bn_scale && L.bn_shift, "dir_pgcn_stack_forward: null layer parameter");
+        PgcnArgs a;
+        a.W = L.W; a.x_in = x; a.h_prev = l ? hbuf[(l - 1) & 1] : nullptr;
+        a.e1_prev = l ? layers[l - 1].e1 : nullptr; a.bias_prev = l ? layers[l - 1].bias : nullptr;
+        a.bns_prev = l ? layers[l - 1].bn_scale : nullptr; a.bnb_prev = l ? layers[l - 1].bn_shift : nullptr;
+        a.relu_prev = l ? layers[l - 1].relu : 0;
+        a.h_out = hbuf[l & 1]; a.B = B;
+        hipLaunchKernelGGL(pgcn_layer_kernel, dim3(NJ, 2), dim3(256), 0, s, a);
+    }
+    const dir_pgcn_layer& L = layers[num_layers - 1];
+    MixArgs m{hbuf[(num_layers - 1) & 1], L.e1, L.bias, L.bn_scale, L.bn_shift, add, out, out_bstride, B, L.relu};
+    hipLaunchKernelGGL(pgcn_mix_kernel, dim3(B, NJ), dim3(128), 0, s, m);
+    return dir::check_launch("dir_pgcn_stack_forward");
+}
+
+extern "C" int dir_regress_forward(const dir_regress_params* p, const float* tok, const float* prev_para_left,
+                                   const float* prev_para_right, const float* prev_offset, float* para_left,
+                                   float* para_right, float* offset, float* emb, int B, void* stream) {
+    DIR_REQUIRE(p && tok && prev_para_left && prev_para_right && prev_offset && para_left && para_right && offset && emb,
+                "dir_regress_forward: null pointer");
+    DIR_REQUIRE(B > 0 && p->mano_w[0] && p->mano_w[1] && p->mano_b[0] && p->mano_b[1] && p->off_w && p->off_b &&
+                    mlp_ok(p->emb), "dir_regress_forward: bad arguments");
+    RegArgs a;
+    a.p = *p; a.tok = tok; a.prev_para[0] = prev_para_left; a.prev_para[1] = prev_para_right; a.prev_off = prev_offset;
+    a.para[0] = para_left; a.para[1] = para_right; a.off = offset; a.emb = emb;
+    hipLaunchKernelGGL(regress_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    return dir::check_launch("dir_regress_forward");
+}

@@ -1,0 +1,400 @@
+"""Execution plan of DIR.forward (eval) on MI355X: parameter packing + the kernel sequence.
+
+Host-side plumbing only: every arithmetic step is a call into libdir_hip.so (include/dir_hip.h).  The plan keeps
+feature maps NHWC in the compute dtype (bf16 = BASELINE.json config 2, or fp32 = exact-parity mode), the joint
+tokens / MANO path in fp32, folds eval-mode BatchNorm + conv bias into per-channel scale/shift epilogues
+(models/backbone/resnet.py:120-140) or prologues (pre-activation hourglass.Residual, models/backbone/hourglass.py:55-70),
+lets convs write straight into channel slices of the concat buffers (models/dir.py:444,455,461,470), and launches
+on torch's current stream so the whole forward can be captured in a HIP graph (torch.cuda.graph).
+
+State-dict keys are the reference's (963 keys, tests/golden/manifest_dir.json).
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
+
+F32 = torch.float32
+
+
+def _dt(dtype):
+    return DT_F32 if dtype == torch.float32 else DT_BF16
+
+
+def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
+    """eval BatchNorm (after an optional conv bias) as y = x*scale + shift; folded in fp64."""
+    g, b = sd[prefix + '.weight'].double(), sd[prefix + '.bias'].double()
+    m, v = sd[prefix + '.running_mean'].double(), sd[prefix + '.running_var'].double()
+    scale = g / torch.sqrt(v + eps)
+    shift = b - m * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.double() * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+class ConvOp(object):
+    """one dir_conv2d_forward call with packed parameters"""
+
+    def __init__(self, w_oihw, dtype, stride=1, pad=0, scale=None, shift=None, relu=False, pre=None, pre_relu=False,
+                 out_dtype=None):
+        self.w = w_oihw.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
+        self.cout, self.kh, self.kw, self.cin = self.w.shape
+        self.stride, self.pad, self.dtype = stride, pad, dtype
+        self.out_dtype = out_dtype or dtype
+        self.scale = None if scale is None else scale.float().contiguous()
+        self.shift = None if shift is None else shift.float().contiguous()
+        self.pre_scale, self.pre_shift = (None, None) if pre is None else (pre[0].contiguous(), pre[1].contiguous())
+        self.flags = (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0)
+        self.ho = self.wo = 0
+        self.in_cs_override = None
+
+    def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0):
+        B, H, W, cbuf = x.shape
+        ho = self.ho or (H + 2 * self.pad - self.kh) // self.stride + 1
+        wo = self.wo or (W + 2 * self.pad - self.kw) // self.stride + 1
+        if out is None:
+            out = torch.empty(B, ho, wo, self.cout, device=x.device, dtype=self.out_dtype)
+        d = ConvDesc(B, H, W, self.cin, self.in_cs_override or cbuf, in_coff, self.cout, out.shape[3], out_coff,
+                     residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
+                     _dt(self.dtype), _dt(out.dtype), self.flags, self.ho, self.wo)
+        rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
+                                            _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
+                                            _capi.ptr(residual), _capi.ptr(out), _capi.stream_ptr())
+        _capi.check(rc, 'dir_conv2d_forward')
+        return out
+
+
+def pack_token_mlp(sd, prefix, keep):
+    """nn.Sequential(Conv1d(k=1), BatchNorm1d, ReLU, Conv1d(k=1)) -> dir_token_mlp (k-major weights, folded BN)."""
+    w1 = sd[prefix + '.0.weight'][:, :, 0]
+    s1, b1 = bn_fold(sd, prefix + '.1', sd[prefix + '.0.bias'])
+    t = dict(w1t=w1.t().contiguous().float(), s1=s1, b1=b1,
+             w2t=sd[prefix + '.3.weight'][:, :, 0].t().contiguous().float(), b2=sd[prefix + '.3.bias'].float().contiguous())
+    keep.append(t)
+    return _capi.TokenMlp(*(t[k].data_ptr() for k in ('w1t', 's1', 'b1', 'w2t', 'b2')))
+
+
+def pack_pgcn(sd, prefix, keep, num_layers=4):
+    arr = (_capi.PgcnLayer * num_layers)()
+    for i in range(num_layers):
+        p = '%s.gconv_layers.%d' % (prefix, i)
+        s, b = bn_fold(sd, p + '.bn')
+        t = dict(W=sd[p + '.gconv.W'].float().contiguous(), e1=sd[p + '.gconv.e_1'].float().reshape(-1).contiguous(),
+                 bias=sd[p + '.gconv.bias'].float().contiguous(), s=s, b=b)
+        keep.append(t)
+        arr[i] = _capi.PgcnLayer(t['W'].data_ptr(), t['e1'].data_ptr(), t['bias'].data_ptr(), s.data_ptr(), b.data_ptr(), 1)
+    return arr
+
+
+def pack_ste(sd, prefix, keep, depth=4):
+    def f(k):
+        t = sd[prefix + '.' + k].float().contiguous()
+        keep.append(t)
+        return t.data_ptr()
+
+    def ft(k):
+        t = sd[prefix + '.' + k].float().t().contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    P = _capi.SteParams()
+    pe = sd[prefix + '.spatial_pos_embed'].float().reshape(42, 128).contiguous()
+    keep.append(pe)
+    P.pos_embed = pe.data_ptr()
+    for i in range(1, depth):                       # block 0 is never executed (transformer/mixSTE.py:197)
+        b = 'STEblocks.%d.' % i
+        P.blocks[i - 1] = _capi.SteBlock(f(b + 'norm1.weight'), f(b + 'norm1.bias'), ft(b + 'attn.qkv.weight'),
+                                         f(b + 'attn.qkv.bias'), ft(b + 'attn.proj.weight'), f(b + 'attn.proj.bias'),
+                                         f(b + 'norm2.weight'), f(b + 'norm2.bias'), ft(b + 'mlp.fc1.weight'),
+                                         f(b + 'mlp.fc1.bias'), ft(b + 'mlp.fc2.weight'), f(b + 'mlp.fc2.bias'))
+    P.num_blocks = depth - 1
+    P.snorm_w, P.snorm_b = f('spatial_norm.weight'), f('spatial_norm.bias')
+    P.head_ln_w, P.head_ln_b = f('head.0.weight'), f('head.0.bias')
+    P.head_wt, P.head_b = ft('head.1.weight'), f('head.1.bias')
+    return P
+
+
+def pack_mano(sd, prefix, side, center_idx, keep):
+    f = lambda k: sd[prefix + '.' + k].float()  # noqa: E731
+    t = dict(shapedirs_t=f('th_shapedirs').reshape(2334, 10).t().contiguous(),
+             posedirs_t=f('th_posedirs').reshape(2334, 135).t().contiguous(),
+             v_template=f('th_v_template').reshape(2334).contiguous(), j_regressor=f('th_J_regressor').contiguous(),
+             weights=f('th_weights').contiguous(), hands_mean=f('th_hands_mean').reshape(45).contiguous(),
+             comps=f('th_selected_comps').contiguous())
+    keep.append(t)
+    return _capi.ManoTables(t['shapedirs_t'].data_ptr(), t['posedirs_t'].data_ptr(), t['v_template'].data_ptr(),
+                            t['j_regressor'].data_ptr(), t['weights'].data_ptr(), t['hands_mean'].data_ptr(),
+                            t['comps'].data_ptr(), 0 if side == 'right' else 1,
+                            -1 if center_idx is None else int(center_idx), 0)
+
+
+class ResidualOp(object):
+    """hourglass.Residual (models/backbone/hourglass.py:33-70), all convs carry a bias"""
+
+    def __init__(self, sd, p, dtype):
+        w = lambda k: sd['%s.%s.conv.weight' % (p, k)]  # noqa: E731
+        b = lambda k: sd['%s.%s.conv.bias' % (p, k)]  # noqa: E731
+        self.need_skip = w('skip_layer').shape[0] != w('skip_layer').shape[1]
+        self.skip = ConvOp(w('skip_layer'), dtype, shift=b('skip_layer'))
+        s2, h2 = bn_fold(sd, p + '.bn2', b('conv1'))
+        self.c1 = ConvOp(w('conv1'), dtype, scale=s2, shift=h2, relu=True, pre=bn_fold(sd, p + '.bn1'), pre_relu=True)
+        s3, h3 = bn_fold(sd, p + '.bn3', b('conv2'))
+        self.c2 = ConvOp(w('conv2'), dtype, pad=1, scale=s3, shift=h3, relu=True)
+        self.c3 = ConvOp(w('conv3'), dtype, shift=b('conv3'))
+
+    def __call__(self, x, out=None, out_coff=0):
+        res = self.skip(x) if self.need_skip else x
+        return self.c3(self.c2(self.c1(x)), out=out, out_coff=out_coff, residual=res)
+
+
+class StageOp(object):
+    """Joint2BoneFeature (models/dir.py:19-174) packed for one pyramid level"""
+
+    def __init__(self, sd, p, S, distance, dtype, root_joint, keep):
+        self.S, self.distance, self.dtype = S, float(distance), dtype
+        self.img2joint = (_capi.TokenMlp * 2)(pack_token_mlp(sd, p + '.img2joint_left.filters', keep),
+                                              pack_token_mlp(sd, p + '.img2joint_right.filters', keep))
+        self.pos_emb = (_capi.TokenMlp * 2)(pack_token_mlp(sd, p + '.pos_emb_left', keep),
+                                            pack_token_mlp(sd, p + '.pos_emb_right', keep))
+        self.gpos = pack_token_mlp(sd, p + '.global_pos_emb', keep)
+        self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep), pack_pgcn(sd, p + '.gcn_right', keep))
+        self.ste = pack_ste(sd, p + '.interaction', keep)
+        R = _capi.RegressParams()
+        t = dict(wl=sd[p + '.regressor.mano_left.weight'].float().contiguous(),
+                 wr=sd[p + '.regressor.mano_right.weight'].float().contiguous(),
+                 bl=sd[p + '.regressor.mano_left.bias'].float().contiguous(),
+                 br=sd[p + '.regressor.mano_right.bias'].float().contiguous(),
+                 wo=sd[p + '.regressor.offset.weight'].float().contiguous(),
+                 bo=sd[p + '.regressor.offset.bias'].float().contiguous())
+        keep.append(t)
+        R.mano_w[0], R.mano_w[1], R.mano_b[0], R.mano_b[1] = (t[k].data_ptr() for k in ('wl', 'wr', 'bl', 'br'))
+        R.off_w, R.off_b = t['wo'].data_ptr(), t['bo'].data_ptr()
+        R.emb = pack_token_mlp(sd, p + '.proj_feat_emb', keep)
+        self.reg = R
+        self.mano = (pack_mano(sd, p + '.regressor.mano_layer_left', 'left', root_joint, keep),
+                     pack_mano(sd, p + '.regressor.mano_layer_right', 'right', root_joint, keep))
+        s, h = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])
+        self.fusion0 = ConvOp(sd[p + '.fusion.0.weight'], dtype, pad=1, scale=s, shift=h, relu=True)
+        self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
+
+
+def run_mano(tables, para, B, want_uv=True):
+    """MANO + projection straight out of the 64-wide parameter vector (models/dir.py:272-280)."""
+    dev = para.device
+    verts = torch.empty(B, 778, 3, device=dev, dtype=F32)
+    joints = torch.empty(B, 21, 3, device=dev, dtype=F32)
+    juv = torch.empty(B, 21, 2, device=dev, dtype=F32) if want_uv else None
+    base = para.data_ptr()
+    rc = _capi.lib().dir_mano_forward(tables, C.c_void_p(base), 64, C.c_void_p(base + 51 * 4), 64,
+                                      C.c_void_p(base + 61 * 4), 64, _capi.ptr(verts), _capi.ptr(joints),
+                                      _capi.ptr(juv), None, None, B, _capi.stream_ptr())
+    _capi.check(rc, 'dir_mano_forward')
+    return verts, joints, juv
+
+
+class DirEngine(object):
+    def __init__(self, state_dict, dtype=torch.bfloat16, root_joint=0, device='cuda'):
+        assert dtype in (torch.bfloat16, torch.float32)
+        _capi.lib()
+        self.dtype, self.device = dtype, torch.device(device)
+        sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
+        self.keep = []
+        self._pack(sd, root_joint)
+
+    # ------------------------------------------------------------------------------------------ packing
+    def _pack(self, sd, root_joint):
+        dt, keep = self.dtype, self.keep
+        # stem: 7x7/s2 conv over the pre-padded NHWC4 image; one "tap" = an image row window of KW pixels x 4 channels
+        self.kwin = 8 if dt == torch.float32 else 16
+        w = sd['backbone.conv1.weight']                                  # [64,3,7,7]
+        wp = torch.zeros(64, self.kwin * 4, 7, 1, device=self.device, dtype=F32)    # [Cout, Cin', kh, kw=1]
+        for kx in range(7):
+            wp[:, kx * 4:kx * 4 + 3, :, 0] = w[:, :, :, kx]
+        s, h = bn_fold(sd, 'backbone.bn1')
+        self.stem = ConvOp(wp, dt, stride=2, pad=0, scale=s, shift=h, relu=True)
+        self.stem.ho = self.stem.wo = 128
+        self.stem.in_cs_override = 4
+        self.layers = []
+        for li, n in enumerate((3, 4, 6, 3), start=1):
+            blocks = []
+            for b in range(n):
+                p = 'backbone.layer%d.%d' % (li, b)
+                stride = 2 if (b == 0 and li > 1) else 1
+                s1, h1 = bn_fold(sd, p + '.bn1')
+                s2, h2 = bn_fold(sd, p + '.bn2')
+                s3, h3 = bn_fold(sd, p + '.bn3')
+                blk = dict(c1=ConvOp(sd[p + '.conv1.weight'], dt, scale=s1, shift=h1, relu=True),
+                           c2=ConvOp(sd[p + '.conv2.weight'], dt, stride=stride, pad=1, scale=s2, shift=h2, relu=True),
+                           c3=ConvOp(sd[p + '.conv3.weight'], dt, scale=s3, shift=h3, relu=True), ds=None)
+                if (p + '.downsample.0.weight') in sd:
+                    sd_, hd_ = bn_fold(sd, p + '.downsample.1')
+                    blk['ds'] = ConvOp(sd[p + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
+                blocks.append(blk)
+            self.layers.append(blocks)
+        # InitRegressor
+        p = 'init_regressor'
+        self.attn = []
+        H = _capi.InitHeadParams()
+        t = {}
+        for i, side in enumerate(('left', 'right')):
+            a = '%s.attention_%s' % (p, side)
+            s, h = bn_fold(sd, a + '.1', sd[a + '.0.bias'])
+            self.attn.append(ConvOp(sd[a + '.0.weight'], dt, pad=1, scale=s, shift=h, relu=True))
+            t['aw%d' % i] = sd[a + '.3.weight'].float().reshape(-1).contiguous()
+            H.attn_w[i] = t['aw%d' % i].data_ptr()
+            H.attn_b[i] = float(sd[a + '.3.bias'].float().item())
+            t['mw%d' % i] = sd['%s.mano_%s.weight' % (p, side)].float().contiguous()
+            t['mb%d' % i] = sd['%s.mano_%s.bias' % (p, side)].float().contiguous()
+            H.mano_w[i], H.mano_b[i] = t['mw%d' % i].data_ptr(), t['mb%d' % i].data_ptr()
+        t['ow'], t['ob'] = sd[p + '.offset.weight'].float().contiguous(), sd[p + '.offset.bias'].float().contiguous()
+        H.off_w, H.off_b = t['ow'].data_ptr(), t['ob'].data_ptr()
+        keep.append(t)
+        self.init_head = H
+        self.init_mano = (pack_mano(sd, p + '.mano_layer_left', 'left', root_joint, keep),
+                          pack_mano(sd, p + '.mano_layer_right', 'right', root_joint, keep))
+        # decoder
+        d = 'decoder'
+        self.res = {k: ResidualOp(sd, '%s.%s' % (d, k), dt) for k in (
+            'skip_layer4', 'fusion_layer4', 'enhance_layer4', 'skip_layer3', 'fusion_layer3', 'enhance_layer3')}
+        self.stage4 = StageOp(sd, d + '.projecter_4', 16, 1, dt, root_joint, keep)
+        self.stage3 = StageOp(sd, d + '.projecter_3', 32, 2, dt, root_joint, keep)
+        s, h = bn_fold(sd, d + '.conv_final.1')
+        self.final0 = ConvOp(sd[d + '.conv_final.0.weight'], dt, pad=1, scale=s, shift=h, relu=True)
+        self.final3 = ConvOp(sd[d + '.conv_final.3.weight'], dt, shift=sd[d + '.conv_final.3.bias'])
+        self.heads = {}
+        for k in ('seg', 'dense'):
+            s, h = bn_fold(sd, '%s.%s.1' % (d, k), sd['%s.%s.0.bias' % (d, k)])
+            self.heads[k] = (ConvOp(sd['%s.%s.0.weight' % (d, k)], dt, pad=1, scale=s, shift=h, relu=True),
+                             ConvOp(sd['%s.%s.3.weight' % (d, k)], dt, shift=sd['%s.%s.3.bias' % (d, k)], out_dtype=F32))
+
+    # ------------------------------------------------------------------------------------------ pieces
+    def backbone(self, img):
+        L, dt, dev = _capi.lib(), self.dtype, self.device
+        B = img.shape[0]
+        # 3 blank pixels top/left; wide enough for the last window (column 2*127 + kwin - 1), rows 16-byte aligned
+        Hp, Wp = 262, (272 if self.kwin == 16 else 264)
+        xp = torch.empty(B, Hp, Wp, 4, device=dev, dtype=dt)
+        _capi.check(L.dir_stem_prep(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hp, Wp, 3, _dt(dt), _capi.stream_ptr()),
+                    'dir_stem_prep')
+        s1 = self.stem(xp)                                                       # [B,128,128,64]
+        x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
+        _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),
+                    'dir_maxpool3x3s2')
+        feats = []
+        for blocks in self.layers:
+            for blk in blocks:
+                idn = blk['ds'](x) if blk['ds'] is not None else x
+                x = blk['c3'](blk['c2'](blk['c1'](x)), residual=idn)
+            feats.append(x)
+        return feats
+
+    def init_regressor(self, c4):
+        L, dev = _capi.lib(), self.device
+        B = c4.shape[0]
+        hl, hr = self.attn[0](c4), self.attn[1](c4)
+        para_l = torch.empty(B, 64, device=dev, dtype=F32)
+        para_r = torch.empty(B, 64, device=dev, dtype=F32)
+        off = torch.empty(B, 3, device=dev, dtype=F32)
+        _capi.check(L.dir_init_head_forward(self.init_head, _capi.ptr(c4), _capi.ptr(hl), _capi.ptr(hr), _capi.ptr(para_l),
+                                            _capi.ptr(para_r), _capi.ptr(off), B, c4.shape[1] * c4.shape[2], c4.shape[3],
+                                            hl.shape[3], _dt(self.dtype), _capi.stream_ptr()), 'dir_init_head_forward')
+        return self.mano_outputs(self.init_mano, para_l, para_r, off)
+
+    def mano_outputs(self, tables, para_l, para_r, off):
+        B = para_l.shape[0]
+        vl, jl, uvl = run_mano(tables[0], para_l, B)
+        vr, jr, uvr = run_mano(tables[1], para_r, B)
+        return {'pd_offset': off, 'pd_mano_para_left': para_l, 'pd_mano_para_right': para_r,
+                'pd_proj_left': para_l[:, 61:64], 'pd_proj_right': para_r[:, 61:64],
+                'pd_mesh_xyz_left': vl, 'pd_mesh_xyz_right': vr, 'pd_joint_xyz_left': jl, 'pd_joint_xyz_right': jr,
+                'pd_joint_uv_left': uvl, 'pd_joint_uv_right': uvr, 'pd_rel_joint': None}
+
+    def stage(self, st, feat_buf, feat_cs, prev, img_out, img_coff, want_vis):
+        """Joint2BoneFeature.forward.  feat_buf: NHWC buffer whose channels [0,256) are fusion_feat; the stage's
+        img_feat is written into img_out[..., img_coff:img_coff+256]."""
+        L, dev = _capi.lib(), self.device
+        B, S = feat_buf.shape[0], st.S
+        sp = _capi.stream_ptr()
+        x0 = torch.empty(2, B, 21, 128, device=dev, dtype=F32)
+        gp = torch.empty(2, B, 21, 128, device=dev, dtype=F32)
+        _capi.check(L.dir_grid_tokens_forward(
+            _capi.ptr(feat_buf), _dt(self.dtype), S, 256, feat_cs, 0, _capi.ptr(prev['pd_joint_uv_left']),
+            _capi.ptr(prev['pd_joint_uv_right']), _capi.ptr(prev['pd_joint_xyz_left']),
+            _capi.ptr(prev['pd_joint_xyz_right']), _capi.ptr(prev['pd_offset']), st.img2joint, st.pos_emb,
+            C.byref(st.gpos), _capi.ptr(x0), _capi.ptr(gp), B, sp), 'dir_grid_tokens_forward')
+        tok = torch.empty(B, 42, 128, device=dev, dtype=F32)
+        scratch = torch.empty(2, B, 21, 256, device=dev, dtype=F32)
+        for hand in range(2):
+            _capi.check(L.dir_pgcn_stack_forward(st.gcn[hand], 4, _capi.ptr(x0[hand]), _capi.ptr(gp[hand]),
+                                                 C.c_void_p(tok.data_ptr() + hand * 21 * 128 * 4), 42 * 128,
+                                                 _capi.ptr(scratch), B, sp), 'dir_pgcn_stack_forward')
+        y = torch.empty(B, 42, 64, device=dev, dtype=F32)
+        _capi.check(L.dir_ste_forward(C.byref(st.ste), _capi.ptr(tok), None, _capi.ptr(y), B, sp), 'dir_ste_forward')
+        para_l = torch.empty(B, 64, device=dev, dtype=F32)
+        para_r = torch.empty(B, 64, device=dev, dtype=F32)
+        off = torch.empty(B, 3, device=dev, dtype=F32)
+        emb = torch.empty(B, 42, 64, device=dev, dtype=F32)
+        _capi.check(L.dir_regress_forward(C.byref(st.reg), _capi.ptr(y), _capi.ptr(prev['pd_mano_para_left']),
+                                          _capi.ptr(prev['pd_mano_para_right']), _capi.ptr(prev['pd_offset']),
+                                          _capi.ptr(para_l), _capi.ptr(para_r), _capi.ptr(off), _capi.ptr(emb), B, sp),
+                    'dir_regress_forward')
+        res = self.mano_outputs(st.mano, para_l, para_r, off)
+        bone = torch.empty(B, S, S, 2560, device=dev, dtype=self.dtype)
+        vis = torch.empty(B, 1280, S, S, device=dev, dtype=F32) if want_vis else None
+        _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
+                                            _capi.ptr(emb), _capi.ptr(bone), _capi.ptr(vis), B, S, st.distance,
+                                            _dt(self.dtype), sp), 'dir_bone_proj_forward')
+        st.fusion3(st.fusion0(bone), out=img_out, out_coff=img_coff)
+        res['joint_feat'] = emb
+        res['vis_img_feat'] = vis
+        return res
+
+    def upsample_into(self, x, out, coff):
+        B, H, W, Cc = x.shape
+        _capi.check(_capi.lib().dir_upsample2x_bilinear(_capi.ptr(x), _capi.ptr(out), B, H, W, Cc, out.shape[3], coff,
+                                                        _dt(self.dtype), _capi.stream_ptr()), 'dir_upsample2x_bilinear')
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, img, want_proj_feat=True, taps=None):
+        """img: float32 NCHW [B,3,256,256] on the GPU.  Returns outs_list exactly like DIR.forward (models/dir.py:521-540);
+        tensors are engine-owned buffers (valid until the next forward when run under a captured graph)."""
+        _capi.require_cuda(img)
+        assert img.dtype == F32 and img.is_contiguous() and img.shape[1:] == (3, 256, 256)
+        dt, dev = self.dtype, self.device
+        B = img.shape[0]
+        feats = self.backbone(img)
+        c1, c2, c3, c4 = feats
+        init = self.init_regressor(c4)
+        # ---- stage 1 @16x16 (models/dir.py:442-456)
+        cat4 = torch.empty(B, 16, 16, 2304, device=dev, dtype=dt)
+        self.upsample_into(c4, cat4, 0)
+        self.res['skip_layer4'](c3, out=cat4, out_coff=2048)
+        enh4_in = torch.empty(B, 16, 16, 512, device=dev, dtype=dt)             # cat(fusion_feat, img_feat)
+        self.res['fusion_layer4'](cat4, out=enh4_in, out_coff=0)
+        r4 = self.stage(self.stage4, enh4_in, 512, init, enh4_in, 256, False)
+        e4 = self.res['enhance_layer4'](enh4_in)
+        # ---- stage 2 @32x32 (models/dir.py:459-471)
+        cat3 = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
+        self.upsample_into(e4, cat3, 0)
+        self.res['skip_layer3'](c2, out=cat3, out_coff=256)
+        enh3_in = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
+        self.res['fusion_layer3'](cat3, out=enh3_in, out_coff=0)
+        r3 = self.stage(self.stage3, enh3_in, 512, r4, enh3_in, 256, want_proj_feat)
+        e3 = self.res['enhance_layer3'](enh3_in)
+        # ---- heads (models/dir.py:474-476)
+        feat = self.final3(self.final0(e3))
+        seg = self.heads['seg'][1](self.heads['seg'][0](feat))                   # NHWC fp32 [B,32,32,3]
+        dense = self.heads['dense'][1](self.heads['dense'][0](feat))
+        if taps is not None:
+            taps.update(c1=c1, c2=c2, c3=c3, c4=c4, fusion4=enh4_in[..., :256], proj4=enh4_in[..., 256:], enh4=e4,
+                        fusion3=enh3_in[..., :256], proj3=enh3_in[..., 256:], enh3=e3, final=feat,
+                        skip4=cat4[..., 2048:])
+        outs = []
+        for o in (init, r4, r3):
+            outs.append({k: o[k] for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_xyz_left',
+                                           'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right',
+                                           'pd_proj_left', 'pd_proj_right', 'pd_offset', 'pd_rel_joint')})
+        outs.append({'dense': dense.permute(0, 3, 1, 2), 'seg': seg.permute(0, 3, 1, 2),
+                     'proj_feat': r3['vis_img_feat']})
+        return outs

@@ -104,11 +104,122 @@ typedef struct dir_conv_desc {
     int32_t kh, kw, stride, pad;
     int32_t in_dtype, out_dtype; /* DIR_DT_*; residual is read in out_dtype */
     int32_t flags;               /* DIR_CONV_* */
+    int32_t Ho, Wo;              /* 0 = (H + 2*pad - kh)/stride + 1 ; set explicitly for the pre-padded stem image */
 } dir_conv_desc;
 
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HBM-bound spatial helpers (NHWC, dtype = DIR_DT_*; arithmetic in fp32)
+ */
+/* NCHW fp32 image [B,3,H,W] -> zero-padded NHWC4 [B,Hp,Wp,4] (RGB0) with `pad` blank pixels top/left, so that the
+ * 7x7/s2 stem (models/backbone/resnet.py:176,244) becomes a kh=7,kw=1 implicit GEMM over contiguous pixel windows. */
+int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int W, int Hp, int Wp, int pad, int dtype,
+                  void* stream);
+/* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:179,247): [B,H,W,C] -> [B,(H+1)/2,(W+1)/2,C] */
+int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+/* nn.Upsample(scale_factor=2, mode='bilinear') (models/dir.py:392,398; align_corners=False): [B,H,W,C] ->
+ * channels [out_coff, out_coff+C) of y [B,2H,2W,out_cstride] (out_cstride 0 = C) */
+int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, int out_cstride, int out_coff,
+                            int dtype, void* stream);
+
+/* InitRegressor tail (models/dir.py:263-270): 1x1 conv Ch->1 + sigmoid attention, attention-weighted pooling
+ * of c4 (+1e-8), plain mean, Linear C->64 (left, right) and C->3 (offset). */
+typedef struct dir_init_head_params {
+    const float* attn_w[2]; /* [Ch]    attention_{left,right}.3.weight */
+    float attn_b[2];        /*         attention_{left,right}.3.bias   */
+    const float* mano_w[2]; /* [64][C] mano_{left,right}.weight        */
+    const float* mano_b[2]; /* [64]                                    */
+    const float* off_w;     /* [3][C]  offset.weight                   */
+    const float* off_b;     /* [3]                                     */
+} dir_init_head_params;
+/* c4 [B,HW,C]; h_left/h_right [B,HW,Ch] = relu(bn(conv3x3(c4))) of each attention branch (dtype);
+ * outputs fp32: para_left/right [B,64], offset [B,3]. */
+int dir_init_head_forward(const dir_init_head_params* params_host, const void* c4, const void* h_left,
+                          const void* h_right, float* para_left, float* para_right, float* offset, int B, int HW,
+                          int C, int Ch, int dtype, void* stream);
+
+/* a10: Joint2BoneFeature.bone_proj + lineseg_dists (models/dir.py:132-174) for BOTH hands.
+ * uv_left/right [B,21,2] in [-1,1]; emb [B,42,64] (tokens 0..20 left, 21..41 right);
+ * out NHWC [B,S,S,2560] (channel = hand*1280 + bone*64 + c == torch.cat((left,right),1) of models/dir.py:122);
+ * vis_nchw (optional) fp32 [B,1280,S,S] = left + right (vis_img_feat / proj_feat, models/dir.py:128,481).
+ * The capsule mask `distance < thr` follows the reference's fp32 op order exactly (bit-exact support). */
+int dir_bone_proj_forward(const float* uv_left, const float* uv_right, const float* emb, void* out, float* vis_nchw,
+                          int B, int S, float distance, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Joint-token operators of a refinement stage (all fp32)
+ */
+/* Conv1d(k=1) -> BatchNorm1d(eval) -> ReLU -> Conv1d(k=1) on tokens (models/dir.py:31-56,180-185), weights k-major:
+ *   hid = relu((w1t^T x) * s1 + b1)   with s1 = gamma/sqrt(var+eps), b1 = (conv_bias - mean)*s1 + beta
+ *   out = w2t^T hid + b2 */
+typedef struct dir_token_mlp {
+    const float* w1t; /* [Cin][Cmid]  */
+    const float* s1;  /* [Cmid]       */
+    const float* b1;  /* [Cmid]       */
+    const float* w2t; /* [Cmid][Cout] */
+    const float* b2;  /* [Cout]       */
+} dir_token_mlp;
+
+/* a4 + a12: ImgFeature2JointFeature.forward (models/dir.py:197-200: F.grid_sample bilinear / zeros /
+ * align_corners=False at the 21 joint uv, then Conv1d 256->128, BN, ReLU, Conv1d 128->128), pos_emb_{left,right}
+ * (xyz/0.15, models/dir.py:97-98) and global_pos_emb (xyz/0.15 -/+ offset/2, models/dir.py:106-107), both hands.
+ * feat NHWC [B,S,S,feat_cstride] (feat_dtype), channels [feat_coff, feat_coff+256) are sampled (feat_cstride 0 =
+ * dense); uv [B,21,2]; xyz [B,21,3]; offset [B,3];
+ * x0   [2][B][21][128] = pos_emb + img2joint (GCN input, models/dir.py:100-101), hand 0 = left
+ * gpos [2][B][21][128] = global_pos_emb output. */
+int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, int C, int feat_cstride, int feat_coff,
+                            const float* uv_left,
+                            const float* uv_right, const float* xyz_left, const float* xyz_right, const float* offset,
+                            const dir_token_mlp* img2joint_lr_host, const dir_token_mlp* pos_emb_lr_host,
+                            const dir_token_mlp* global_pos_emb_host, float* x0, float* gpos, int B, void* stream);
+
+/* a5: one _GraphConv = PGraphConv + BatchNorm1d(eval) + ReLU (SemGCN/p_graph_conv.py:39-59, SemGCN/p_gcn.py:20-27) */
+typedef struct dir_pgcn_layer {
+    const float* W;        /* [2][21][128][128]  gconv.W  (reference layout)                     */
+    const float* e1;       /* [40]               gconv.e_1, row-major nonzero order of adj > 0    */
+    const float* bias;     /* [128]              gconv.bias                                       */
+    const float* bn_scale; /* [128]              gamma / sqrt(var + eps)                          */
+    const float* bn_shift; /* [128]              beta - mean * bn_scale                           */
+    int32_t relu;          /* 1: ReLU after BN (the _GraphConv of the network); 0: bare PGraphConv (scale 1, shift 0) */
+} dir_pgcn_layer;
+/* ResSimplePGCN.forward (SemGCN/p_gcn.py:71-73): x [B,21,128] -> out; `add` (optional, [B,21,128]) is added after the
+ * last layer (global_pos_emb, models/dir.py:109-110); out rows are out_bstride floats apart so both hands can write
+ * into one [B,42,128] token buffer.  e_0 is a dead parameter (softmax of a diagonal-only mask == I). scratch: 2*B*21*256
+ * floats. */
+int dir_pgcn_stack_forward(const dir_pgcn_layer* layers_host, int num_layers, const float* x, const float* add,
+                           float* out, long long out_bstride, float* scratch, int B, void* stream);
+
+/* a6: STE.forward (transformer/mixSTE.py:194-205) on [B,42,128] -> [B,42,64]; weights k-major ([in][out]). */
+typedef struct dir_ste_block {
+    const float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc1_wt, *fc1_b, *fc2_wt, *fc2_b;
+} dir_ste_block;
+typedef struct dir_ste_params {
+    const float* pos_embed;  /* [42][128] */
+    dir_ste_block blocks[3]; /* STEblocks[1..3]: block 0 is never executed (transformer/mixSTE.py:197) */
+    int32_t num_blocks;      /* depth - 1 */
+    const float *snorm_w, *snorm_b, *head_ln_w, *head_ln_b, *head_wt /* [128][64] */, *head_b;
+} dir_ste_params;
+/* x_pos_out (optional): receives x + pos_embed, reproducing the reference's in-place `x += pos` on its input. */
+int dir_ste_forward(const dir_ste_params* params_host, const float* x, float* x_pos_out, float* y, int B,
+                    void* stream);
+
+/* a7 + a12: RegressorOffset Linears (models/dir.py:342-351) + proj_feat_emb (models/dir.py:118-119).
+ * tok [B,42,64]; prev_para_* [B,64] (detached previous mano_para); prev_offset [B,3];
+ * para_* [B,64] = Linear(cat(tok_hand.flatten(), prev_para)), offset [B,3] = Linear(cat(tokL, tokR, prev_offset)),
+ * emb [B,42,64] = proj_feat_emb(tok). */
+typedef struct dir_regress_params {
+    const float* mano_w[2]; /* [64][1408] regressor.mano_{left,right}.weight */
+    const float* mano_b[2]; /* [64]                                          */
+    const float* off_w;     /* [3][2691]  regressor.offset.weight            */
+    const float* off_b;     /* [3]                                           */
+    dir_token_mlp emb;      /* 64 -> 64 -> 64                                */
+} dir_regress_params;
+int dir_regress_forward(const dir_regress_params* params_host, const float* tok, const float* prev_para_left,
+                        const float* prev_para_right, const float* prev_offset, float* para_left, float* para_right,
+                        float* offset, float* emb, int B, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,183 @@
+"""GPU parity for the joint-token kernels (a4, a5, a6, a7, a10, a12) through the C ABI, against the goldens the
+reference produced (tests/golden) and the numpy oracle.  fp32; tolerances are those the oracle itself meets."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, maxabs, relerr
+from dir_amd import _capi, engine, synth
+from oracle import nnops as N
+from oracle import tokens as OT
+from oracle.golden_inputs import bone_uv
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+
+def dev(a):
+    """numpy -> cuda tensor.  Callers must keep the result referenced until the kernel has been enqueued: a bare
+    _capi.ptr(dev(x)) would take the address of a temporary the caching allocator may hand out again."""
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def pgcn_shapes(prefix=''):
+    s = {}
+    for i in range(4):
+        p = '%sgconv_layers.%d.' % (prefix, i)
+        s.update({p + 'gconv.W': (2, 21, 128, 128), p + 'gconv.e_0': (1, 21), p + 'gconv.e_1': (1, 40),
+                  p + 'gconv.bias': (128,), p + 'bn.weight': (128,), p + 'bn.bias': (128,),
+                  p + 'bn.running_mean': (128,), p + 'bn.running_var': (128,), p + 'bn.num_batches_tracked': ()})
+    return s
+
+
+def test_pgcn_stack_vs_reference(golden):
+    g = golden('g2_pgcn')
+    sd = {('gcn.' + k): dev(v) for k, v in synth.synth_state_dict(pgcn_shapes(), SEED).items()}
+    keep = []
+    layers = engine.pack_pgcn(sd, 'gcn', keep)
+    x = torch.from_numpy(g['x']).cuda()
+    B = x.shape[0]
+    out = torch.empty(B, 21, 128, device='cuda')
+    scratch = torch.empty(2, B, 21, 256, device='cuda')
+    _capi.check(_capi.lib().dir_pgcn_stack_forward(layers, 4, _capi.ptr(x), None, _capi.ptr(out), 21 * 128,
+                                                   _capi.ptr(scratch), B, _capi.stream_ptr()), 'pgcn')
+    assert relerr(out.cpu().numpy(), g['y']) < 2e-6
+    # single layer, BN+ReLU on: compare with the per-layer activation of the golden
+    _capi.check(_capi.lib().dir_pgcn_stack_forward(layers, 1, _capi.ptr(x), None, _capi.ptr(out), 21 * 128,
+                                                   _capi.ptr(scratch), B, _capi.stream_ptr()), 'pgcn')
+    assert relerr(out.cpu().numpy(), g['layer0']) < 2e-6
+
+
+def test_pgcn_batch_sizes_and_add():
+    """B not a multiple of the 64-sample LDS chunk, B > 64, the `add` term and the [B,42,128] strided output."""
+    sdn = synth.synth_state_dict(pgcn_shapes(), SEED)
+    sd = {('gcn.' + k): torch.from_numpy(v).cuda() for k, v in sdn.items()}
+    keep = []
+    layers = engine.pack_pgcn(sd, 'gcn', keep)
+    for B in (1, 7, 64, 150):
+        x = synth.synth_input('pgcn.bs%d' % B, (B, 21, 128), SEED)
+        add = synth.synth_input('pgcn.add%d' % B, (B, 21, 128), SEED)
+        ref = OT.pgcn_stack(x, N.Params(sdn)) + add
+        tok = torch.zeros(B, 42, 128, device='cuda')
+        scratch = torch.empty(2, B, 21, 256, device='cuda')
+        dx, dadd = dev(x), dev(add)
+        _capi.check(_capi.lib().dir_pgcn_stack_forward(layers, 4, _capi.ptr(dx), _capi.ptr(dadd),
+                                                       C.c_void_p(tok.data_ptr() + 21 * 128 * 4), 42 * 128,
+                                                       _capi.ptr(scratch), B, _capi.stream_ptr()), 'pgcn')
+        assert relerr(tok[:, 21:].cpu().numpy(), ref) < 3e-6
+        assert float(tok[:, :21].abs().max()) == 0.0
+
+
+def ste_shapes(prefix):
+    s = {'spatial_pos_embed': (1, 42, 128), 'spatial_norm.weight': (128,), 'spatial_norm.bias': (128,),
+         'head.0.weight': (128,), 'head.0.bias': (128,), 'head.1.weight': (64, 128), 'head.1.bias': (64,)}
+    for i in range(4):
+        p = 'STEblocks.%d.' % i
+        s.update({p + 'norm1.weight': (128,), p + 'norm1.bias': (128,), p + 'norm2.weight': (128,),
+                  p + 'norm2.bias': (128,), p + 'attn.qkv.weight': (384, 128), p + 'attn.qkv.bias': (384,),
+                  p + 'attn.proj.weight': (128, 128), p + 'attn.proj.bias': (128,),
+                  p + 'mlp.fc1.weight': (256, 128), p + 'mlp.fc1.bias': (256,),
+                  p + 'mlp.fc2.weight': (128, 256), p + 'mlp.fc2.bias': (128,)})
+    return s
+
+
+def test_ste_vs_reference(golden):
+    g = golden('g3_ste')
+    sdn = synth.synth_state_dict(ste_shapes(''), SEED)
+    sd = {('ste.' + k): torch.from_numpy(v).cuda() for k, v in sdn.items()}
+    keep = []
+    P = engine.pack_ste(sd, 'ste', keep)
+    x = torch.from_numpy(g['x']).cuda()
+    xpos = torch.empty_like(x)
+    y = torch.empty(2, 42, 64, device='cuda')
+    _capi.check(_capi.lib().dir_ste_forward(C.byref(P), _capi.ptr(x), _capi.ptr(xpos), _capi.ptr(y), 2, _capi.stream_ptr()), 'ste')
+    assert maxabs(y.cpu().numpy(), g['y']) < 2e-5
+    assert maxabs(xpos.cpu().numpy(), g['x'] + sdn['spatial_pos_embed']) < 1e-7     # the in-place `x += pos`
+    # larger batch vs the oracle
+    xb = synth.synth_input('ste.big', (33, 42, 128), SEED)
+    yb = torch.empty(33, 42, 64, device='cuda')
+    dxb = dev(xb)
+    _capi.check(_capi.lib().dir_ste_forward(C.byref(P), _capi.ptr(dxb), None, _capi.ptr(yb), 33,
+                                            _capi.stream_ptr()), 'ste')
+    assert maxabs(yb.cpu().numpy(), OT.ste_forward(xb, N.Params(sdn))) < 3e-5
+
+
+def test_bone_proj_vs_reference(golden):
+    g = golden('g5_bone')
+    for S, dist in ((16, 1), (32, 2)):
+        uv = g['S%d.uv' % S]
+        feat = synth.synth_input('bone.feat%d' % S, (2, 21, 64), SEED)
+        ref = g['S%d.y' % S]                                                     # [2,1280,S,S] one hand
+        # left hand = the golden case, right hand = the same joints mirrored (exercises the second slice)
+        uv_r = uv.copy(); uv_r[..., 0] *= -1
+        emb = np.concatenate([feat, feat[:, ::-1].copy()], 1)                    # [2,42,64]
+        ref_r = OT.bone_proj(uv_r, emb[:, 21:], S, dist)
+        duv, duvr, demb = dev(uv), dev(uv_r), dev(emb)
+        for tdt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 2e-2)):
+            out = torch.empty(2, S, S, 2560, device='cuda', dtype=tdt)
+            vis = torch.empty(2, 1280, S, S, device='cuda')
+            _capi.check(_capi.lib().dir_bone_proj_forward(
+                _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), _capi.ptr(out), _capi.ptr(vis), 2, S, float(dist),
+                0 if tdt == torch.float32 else 1, _capi.stream_ptr()), 'bone_proj')
+            got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
+            assert np.array_equal(got[:, :1280] != 0, ref != 0), 'capsule mask differs from the reference (S=%d)' % S
+            assert np.array_equal(got[:, 1280:] != 0, ref_r != 0)
+            assert maxabs(got[:, :1280], ref) < tol and maxabs(got[:, 1280:], ref_r) < tol
+            assert maxabs(vis.cpu().numpy(), ref + ref_r) < 2e-6                 # vis is fp32 regardless of dtype
+
+
+def stage_sd(S):
+    with open(os.path.join(GOLDEN, 'manifest_stage%d.json' % S)) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sdn = synth.synth_state_dict(shapes, SEED)
+    return sdn, {('st.' + k): torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sdn.items()}
+
+
+@pytest.mark.parametrize('S,dist', [(16, 1), (32, 2)])
+def test_grid_tokens_and_regress_vs_oracle(golden, S, dist):
+    """dir_grid_tokens_forward and dir_regress_forward in isolation (the stage golden covers their composition)."""
+    sdn, sd = stage_sd(S)
+    keep = []
+    st = engine.StageOp(sd, 'st', S, dist, torch.float32, 0, keep)
+    P = N.Params(sdn)
+    B = 3
+    feat = synth.synth_input('gt.feat', (B, 256, S, S), SEED)
+    uv = [bone_uv('gt.uv%d' % h, B, S) for h in range(2)]
+    xyz = [synth.synth_input('gt.xyz%d' % h, (B, 21, 3), SEED) * np.float32(0.05) for h in range(2)]
+    off = synth.synth_input('gt.off', (B, 3), SEED)
+    # feature map inside a wider NHWC buffer at channel offset 64 (slice addressing)
+    fbuf = torch.zeros(B, S, S, 384, device='cuda')
+    fbuf[..., 64:320] = dev(feat.transpose(0, 2, 3, 1))
+    x0 = torch.empty(2, B, 21, 128, device='cuda'); gp = torch.empty(2, B, 21, 128, device='cuda')
+    duv, dxyz, doff = [dev(u) for u in uv], [dev(v) for v in xyz], dev(off)
+    _capi.check(_capi.lib().dir_grid_tokens_forward(
+        _capi.ptr(fbuf), 0, S, 256, 384, 64, _capi.ptr(duv[0]), _capi.ptr(duv[1]), _capi.ptr(dxyz[0]),
+        _capi.ptr(dxyz[1]), _capi.ptr(doff), st.img2joint, st.pos_emb, C.byref(st.gpos), _capi.ptr(x0),
+        _capi.ptr(gp), B, _capi.stream_ptr()), 'grid_tokens')
+    for h, side in enumerate(('left', 'right')):
+        img = OT.img2joint(feat, uv[h], P.sub('img2joint_' + side))
+        pos = OT.token_mlp(xyz[h].transpose(0, 2, 1) / np.float32(0.15), P.sub('pos_emb_' + side)).transpose(0, 2, 1)
+        q = xyz[h] / np.float32(0.15) + (off[:, None] / 2) * (1 if h else -1)
+        gref = OT.token_mlp(q.transpose(0, 2, 1), P.sub('global_pos_emb')).transpose(0, 2, 1)
+        assert maxabs(x0[h].cpu().numpy(), pos + img) < 2e-5
+        assert maxabs(gp[h].cpu().numpy(), gref) < 2e-5
+    # regress
+    tok = synth.synth_input('rg.tok', (B, 42, 64), SEED)
+    pl, pr = synth.synth_input('rg.pl', (B, 64), SEED), synth.synth_input('rg.pr', (B, 64), SEED)
+    o = [torch.empty(B, 64, device='cuda'), torch.empty(B, 64, device='cuda'), torch.empty(B, 3, device='cuda'),
+         torch.empty(B, 42, 64, device='cuda')]
+    dtok, dpl, dpr = dev(tok), dev(pl), dev(pr)
+    _capi.check(_capi.lib().dir_regress_forward(C.byref(st.reg), _capi.ptr(dtok), _capi.ptr(dpl), _capi.ptr(dpr),
+                                                _capi.ptr(doff), _capi.ptr(o[0]), _capi.ptr(o[1]), _capi.ptr(o[2]),
+                                                _capi.ptr(o[3]), B, _capi.stream_ptr()), 'regress')
+    R = P.sub('regressor')
+    fl, fr = tok[:, :21].reshape(B, -1), tok[:, 21:].reshape(B, -1)
+    assert maxabs(o[0].cpu().numpy(), N.linear(np.concatenate([fl, pl], 1), R['mano_left.weight'], R['mano_left.bias'])) < 1e-5
+    assert maxabs(o[1].cpu().numpy(), N.linear(np.concatenate([fr, pr], 1), R['mano_right.weight'], R['mano_right.bias'])) < 1e-5
+    assert maxabs(o[2].cpu().numpy(), N.linear(np.concatenate([fl, fr, off], 1), R['offset.weight'], R['offset.bias'])) < 1e-5
+    emb = OT.token_mlp(tok.transpose(0, 2, 1), P.sub('proj_feat_emb')).transpose(0, 2, 1)
+    assert maxabs(o[3].cpu().numpy(), emb) < 1e-5
