@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of DIR.forward (eval, 3 stage outputs) on synthetic 256x256 batches, BASELINE.json config 2
+(batch 64 per GPU, ResNet-50 + init regression + 2 refinement stages, bf16 feature maps / fp32 token+MANO path).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = one forward of the hot path over one batch already resident in HBM.  The forward is captured once in a
+HIP graph and replayed.  Images are independent (eval-mode BN), so N GPUs shard the batch with NO data-path collective
+(weak scaling: 64 images per GPU); the only collectives are the timing barrier and a MAX over ranks.
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around every launch of the dominant kernel
+(the MFMA implicit-GEMM convolution) in an instrumented eager pass on the same stream; `cpu_baseline` times the numpy
+oracle (oracle/, the CPU restatement of the reference) on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+ALG_GFLOP_PER_IMAGE = 36.80                     # BASELINE.md section 2 (reference, torch flop counter)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=8)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dir_amd import engine as E
+    from dir_amd import synth
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd_np = synth.synth_state_dict(shapes, 1234)
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    eng = E.DirEngine(sd, dtype=tdt, device=dev)
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    img = torch.randn(B, 3, 256, 256, device=dev, generator=g)
+
+    # ---- build the step (HIP graph of the whole forward)
+    outs = eng.forward(img)                       # eager once: allocator warm-up, lazy init
+    torch.cuda.synchronize()
+    if args.no_graph:
+        step = lambda: eng.forward(img)           # noqa: E731
+    else:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outs = eng.forward(img)
+        step = graph.replay
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    barrier()
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+    finite = bool(torch.isfinite(outs[2]['pd_mesh_xyz_left']).all())
+
+    # ---- roofline of the dominant kernel: HIP events around every conv launch, eager, same stream
+    roof = None
+    if rank == 0:
+        tag = 'conv_igemm<%s,%s>' % (args.dtype, args.dtype)
+        E.PROFILE = []
+        eng.forward(img)
+        torch.cuda.synchronize()
+        E.PROFILE = []
+        reps = 3
+        for _ in range(reps):
+            eng.forward(img)
+        torch.cuda.synchronize()
+        rec = [(t_, f_, e0.elapsed_time(e1)) for t_, f_, e0, e1 in E.PROFILE]
+        E.PROFILE = None
+        dom = [(f_, ms) for t_, f_, ms in rec if t_ == tag]
+        n_launch = len(dom) // reps
+        flops_per_launch = sum(f_ for f_, _ in dom) / len(dom)
+        ms_per_launch = sum(ms for _, ms in dom) / len(dom)
+        achieved = flops_per_launch / (ms_per_launch * 1e-3)
+        conv_ms = sum(ms for _, _, ms in rec) / reps
+        roof = {'bound': 'mfma', 'kernel': tag, 'achieved': round(achieved / 1e12, 2), 'peak': PEAK[args.dtype] / 1e12,
+                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK[args.dtype], 4), 'traffic': None,
+                'launches_per_step': n_launch, 'avg_launch_us': round(ms_per_launch * 1e3, 2),
+                'alg_gflop_per_launch': round(flops_per_launch / 1e9, 3),
+                'all_conv_ms_per_step': round(conv_ms, 3),
+                'whole_step_tflops': round(ALG_GFLOP_PER_IMAGE * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2)}
+
+    # ---- CPU baseline: the numpy oracle on the host cores (rank 0, single-GPU runs only), bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.dir_forward import dir_forward
+        nthreads = os.cpu_count()
+        try:
+            from threadpoolctl import threadpool_info
+            nthreads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+        except Exception:
+            pass
+        n = args.cpu_sample
+        ximg = img[:n].cpu().numpy()
+        dir_forward(sd_np, ximg[:1])              # warm-up (BLAS thread pool, page faults)
+        t0 = time.perf_counter()
+        dir_forward(sd_np, ximg)
+        tc = time.perf_counter() - t0
+        cpu = {'value': round(n / tc, 3), 'unit': 'images/sec', 'cores': int(nthreads), 'kind': 'port',
+               'sample': '%d images, one fp32 forward of oracle/dir_forward.py (numpy + OpenBLAS), %.1f s' % (n, tc)}
+
+    if rank == 0:
+        line = {'metric': 'images/sec at 256x256 bs=64, 3 stage outputs (DIR.forward eval)', 'value': round(value, 1),
+                'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': args.dtype, 'data': 'synthetic',
+                'config': {'workload': 'BASELINE configs[1]: batch 64 synthetic 256x256 per GPU, ResNet-50 + init '
+                                       'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads',
+                           'batch_per_gpu': B, 'graph': not args.no_graph, 'weights': 'synthetic (dir_amd.synth seed 1234)',
+                           'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite},
+                'roofline': roof, 'cpu_baseline': cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -17,6 +17,7 @@ from . import _capi
 from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
 
 F32 = torch.float32
+PROFILE = None     # set to a list to record (kernel tag, algorithmic flops, start event, end event) per conv launch
 
 
 def _dt(dtype):
@@ -49,6 +50,7 @@ class ConvOp(object):
         self.flags = (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0)
         self.ho = self.wo = 0
         self.in_cs_override = None
+        self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
 
     def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0):
         B, H, W, cbuf = x.shape
@@ -59,10 +61,17 @@ class ConvOp(object):
         d = ConvDesc(B, H, W, self.cin, self.in_cs_override or cbuf, in_coff, self.cout, out.shape[3], out_coff,
                      residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
                      _dt(self.dtype), _dt(out.dtype), self.flags, self.ho, self.wo)
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
                                             _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
                                             _capi.ptr(residual), _capi.ptr(out), _capi.stream_ptr())
         _capi.check(rc, 'dir_conv2d_forward')
+        if PROFILE is not None:
+            e1.record()
+            tag = 'conv_igemm<%s,%s>' % ('f32' if self.dtype == F32 else 'bf16', 'f32' if out.dtype == F32 else 'bf16')
+            PROFILE.append((tag, 2.0 * B * ho * wo * self.cout * self.alg_k, e0, e1))
         return out
 
 
@@ -127,6 +136,74 @@ def pack_mano(sd, prefix, side, center_idx, keep):
                             t['j_regressor'].data_ptr(), t['weights'].data_ptr(), t['hands_mean'].data_ptr(),
                             t['comps'].data_ptr(), 0 if side == 'right' else 1,
                             -1 if center_idx is None else int(center_idx), 0)
+
+
+class BackboneOp(object):
+    """ResNet-50 pyramid (models/backbone/resnet.py:243-255): stem as a kh=7,kw=1 implicit GEMM over a pre-padded
+    NHWC4 image, maxpool, 16 bottlenecks with BN folded into the conv epilogues and the residual add + ReLU fused."""
+
+    def __init__(self, sd, p, dtype, device):
+        dt = self.dtype = dtype
+        self.device = device
+        # one "tap" = an image-row window of kwin pixels x 4 channels (RGB0); zero weights beyond the 7 real taps
+        self.kwin = 8 if dt == torch.float32 else 16
+        w = sd[p + '.conv1.weight']                                       # [64,3,7,7]
+        wp = torch.zeros(64, self.kwin * 4, 7, 1, device=w.device, dtype=F32)     # [Cout, Cin', kh, kw=1]
+        for kx in range(7):
+            wp[:, kx * 4:kx * 4 + 3, :, 0] = w[:, :, :, kx]
+        s, h = bn_fold(sd, p + '.bn1')
+        self.stem = ConvOp(wp, dt, stride=2, pad=0, scale=s, shift=h, relu=True)
+        self.stem.ho = self.stem.wo = 128
+        self.stem.alg_k = 147
+        self.layers = []
+        for li, n in enumerate((3, 4, 6, 3), start=1):
+            blocks = []
+            for b in range(n):
+                q = '%s.layer%d.%d' % (p, li, b)
+                stride = 2 if (b == 0 and li > 1) else 1
+                s1, h1 = bn_fold(sd, q + '.bn1')
+                s2, h2 = bn_fold(sd, q + '.bn2')
+                s3, h3 = bn_fold(sd, q + '.bn3')
+                blk = dict(c1=ConvOp(sd[q + '.conv1.weight'], dt, scale=s1, shift=h1, relu=True),
+                           c2=ConvOp(sd[q + '.conv2.weight'], dt, stride=stride, pad=1, scale=s2, shift=h2, relu=True),
+                           c3=ConvOp(sd[q + '.conv3.weight'], dt, scale=s3, shift=h3, relu=True), ds=None)
+                if (q + '.downsample.0.weight') in sd:
+                    sd_, hd_ = bn_fold(sd, q + '.downsample.1')
+                    blk['ds'] = ConvOp(sd[q + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
+                blocks.append(blk)
+            self.layers.append(blocks)
+
+    def __call__(self, img):
+        L, dt, dev = _capi.lib(), self.dtype, self.device
+        B = img.shape[0]
+        # 3 blank pixels top/left; wide enough for the last window (column 2*127 + kwin - 1), rows 16-byte aligned
+        Hp, Wp = 262, (272 if self.kwin == 16 else 264)
+        xp = torch.empty(B, Hp, Wp, 4, device=dev, dtype=dt)
+        _capi.check(L.dir_stem_prep(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hp, Wp, 3, _dt(dt), _capi.stream_ptr()),
+                    'dir_stem_prep')
+        s1 = self.stem(xp)                                                       # [B,128,128,64]
+        x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
+        _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),
+                    'dir_maxpool3x3s2')
+        feats = []
+        for blocks in self.layers:
+            for blk in blocks:
+                idn = blk['ds'](x) if blk['ds'] is not None else x
+                x = blk['c3'](blk['c2'](blk['c1'](x)), residual=idn)
+            feats.append(x)
+        return feats
+
+
+def backbone_standalone(module, x, compute_dtype=torch.float32):
+    """ResNet.forward of the mirror module: NCHW float32 in, [c1..c4] NCHW float32 out."""
+    _capi.require_cuda(x)
+    if module.training:
+        raise NotImplementedError('dir_amd implements the inference path (eval-mode BatchNorm); call .eval()')
+    sd = {'b.' + k: v.detach() for k, v in module.state_dict().items()}
+    op = BackboneOp(sd, 'b', compute_dtype, x.device)
+    with torch.cuda.device(x.device):
+        feats = op(_capi.f32c(x.detach()))
+    return [f.permute(0, 3, 1, 2).float() for f in feats]
 
 
 class ResidualOp(object):
@@ -205,33 +282,7 @@ class DirEngine(object):
     # ------------------------------------------------------------------------------------------ packing
     def _pack(self, sd, root_joint):
         dt, keep = self.dtype, self.keep
-        # stem: 7x7/s2 conv over the pre-padded NHWC4 image; one "tap" = an image row window of KW pixels x 4 channels
-        self.kwin = 8 if dt == torch.float32 else 16
-        w = sd['backbone.conv1.weight']                                  # [64,3,7,7]
-        wp = torch.zeros(64, self.kwin * 4, 7, 1, device=self.device, dtype=F32)    # [Cout, Cin', kh, kw=1]
-        for kx in range(7):
-            wp[:, kx * 4:kx * 4 + 3, :, 0] = w[:, :, :, kx]
-        s, h = bn_fold(sd, 'backbone.bn1')
-        self.stem = ConvOp(wp, dt, stride=2, pad=0, scale=s, shift=h, relu=True)
-        self.stem.ho = self.stem.wo = 128
-        self.stem.in_cs_override = 4
-        self.layers = []
-        for li, n in enumerate((3, 4, 6, 3), start=1):
-            blocks = []
-            for b in range(n):
-                p = 'backbone.layer%d.%d' % (li, b)
-                stride = 2 if (b == 0 and li > 1) else 1
-                s1, h1 = bn_fold(sd, p + '.bn1')
-                s2, h2 = bn_fold(sd, p + '.bn2')
-                s3, h3 = bn_fold(sd, p + '.bn3')
-                blk = dict(c1=ConvOp(sd[p + '.conv1.weight'], dt, scale=s1, shift=h1, relu=True),
-                           c2=ConvOp(sd[p + '.conv2.weight'], dt, stride=stride, pad=1, scale=s2, shift=h2, relu=True),
-                           c3=ConvOp(sd[p + '.conv3.weight'], dt, scale=s3, shift=h3, relu=True), ds=None)
-                if (p + '.downsample.0.weight') in sd:
-                    sd_, hd_ = bn_fold(sd, p + '.downsample.1')
-                    blk['ds'] = ConvOp(sd[p + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
-                blocks.append(blk)
-            self.layers.append(blocks)
+        self.bb = BackboneOp(sd, 'backbone', dt, self.device)
         # InitRegressor
         p = 'init_regressor'
         self.attn = []
@@ -269,26 +320,6 @@ class DirEngine(object):
                              ConvOp(sd['%s.%s.3.weight' % (d, k)], dt, shift=sd['%s.%s.3.bias' % (d, k)], out_dtype=F32))
 
     # ------------------------------------------------------------------------------------------ pieces
-    def backbone(self, img):
-        L, dt, dev = _capi.lib(), self.dtype, self.device
-        B = img.shape[0]
-        # 3 blank pixels top/left; wide enough for the last window (column 2*127 + kwin - 1), rows 16-byte aligned
-        Hp, Wp = 262, (272 if self.kwin == 16 else 264)
-        xp = torch.empty(B, Hp, Wp, 4, device=dev, dtype=dt)
-        _capi.check(L.dir_stem_prep(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hp, Wp, 3, _dt(dt), _capi.stream_ptr()),
-                    'dir_stem_prep')
-        s1 = self.stem(xp)                                                       # [B,128,128,64]
-        x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
-        _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),
-                    'dir_maxpool3x3s2')
-        feats = []
-        for blocks in self.layers:
-            for blk in blocks:
-                idn = blk['ds'](x) if blk['ds'] is not None else x
-                x = blk['c3'](blk['c2'](blk['c1'](x)), residual=idn)
-            feats.append(x)
-        return feats
-
     def init_regressor(self, c4):
         L, dev = _capi.lib(), self.device
         B = c4.shape[0]
@@ -363,7 +394,7 @@ class DirEngine(object):
         assert img.dtype == F32 and img.is_contiguous() and img.shape[1:] == (3, 256, 256)
         dt, dev = self.dtype, self.device
         B = img.shape[0]
-        feats = self.backbone(img)
+        feats = self.bb(img)
         c1, c2, c3, c4 = feats
         init = self.init_regressor(c4)
         # ---- stage 1 @16x16 (models/dir.py:442-456)

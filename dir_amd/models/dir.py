@@ -1,0 +1,170 @@
+"""Drop-in for the reference's models/dir.py (DIR and its sub-modules): identical constructor signatures, parameter
+tree and state-dict keys (963 keys; a reference checkpoint's ['net'] loads with strict=True), identical forward
+signature and output structure (models/dir.py:513-540).  The classes below are parameter containers; DIR.forward runs
+the whole eval-mode path through dir_amd.engine.DirEngine, i.e. through libdir_hip.so (include/dir_hip.h).
+
+Scope: inference.  `self.training == True` raises NotImplementedError (loss block + backward are row
+8f.2, "next").  `compute_dtype` selects bf16 feature maps (BASELINE config 2, default) or exact-fp32 MFMA convs.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _capi
+from ..engine import DirEngine
+from ..manopth.manolayer import ManoLayer as ObmanManoLayer
+from ..SemGCN.p_gcn import ResSimplePGCN
+from ..SemGCN.utils import adj_mx_from_edges, get_sketch_setting
+from ..transformer.mixSTE import STE
+from .backbone.hourglass import Residual
+from .backbone.resnet import resnet50 as ResNet50
+
+
+def _token_mlp(cin, cmid, cout):
+    return nn.Sequential(nn.Conv1d(cin, cmid, 1), nn.BatchNorm1d(cmid), nn.ReLU(), nn.Conv1d(cmid, cout, 1))
+
+
+def _mano_pair(mano_path, root_joint):
+    kw = dict(root_rot_mode='6D', joint_rot_mode='axisang', use_pca=True, mano_root=mano_path, ncomps=45,
+              center_idx=root_joint, flat_hand_mean=False, robust_rot=True)
+    return ObmanManoLayer(side='right', **kw), ObmanManoLayer(side='left', **kw)
+
+
+def _fix_shape(mano_layer_left, mano_layer_right):
+    # models/dir.py:306-309
+    if torch.sum(torch.abs(mano_layer_left.th_shapedirs[:, 0, :] - mano_layer_right.th_shapedirs[:, 0, :])) < 1:
+        print('Fix shapedirs bug of MANO')
+        mano_layer_left.th_shapedirs[:, 0, :] *= -1
+
+
+class ImgFeature2JointFeature(nn.Module):
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.filters = _token_mlp(in_dim, out_dim, out_dim)
+
+
+class RegressorOffset(nn.Module):
+    def __init__(self, feat_dim, mano_path, root_joint):
+        super().__init__()
+        self.mano_layer_right, self.mano_layer_left = _mano_pair(mano_path, root_joint)
+        _fix_shape(self.mano_layer_left, self.mano_layer_right)
+        d = 3 * 2 + 15 * 3 + 10 + 3
+        self.mano_left = nn.Linear(feat_dim + d, d)
+        self.mano_right = nn.Linear(feat_dim + d, d)
+        self.offset = nn.Linear(feat_dim * 2 + 3, 3)
+        for m in (self.mano_left, self.mano_right, self.offset):
+            m.weight.data.normal_(0, 0.001)
+
+
+class Joint2BoneFeature(nn.Module):
+    def __init__(self, img_feat_dim, emd_dim, joint_dim, joint_num, feature_size, mano_pth, root_joint, distance=1):
+        super().__init__()
+        adj = adj_mx_from_edges(joint_num, get_sketch_setting(), sparse=False, eye=False)
+        self.bone_num = 20
+        self.parent = torch.Tensor([0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0, 17, 18, 19]).long()
+        self.child = torch.Tensor([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20]).long()
+        self.gcn_left = ResSimplePGCN(adj, emd_dim, num_layers=4)
+        self.gcn_right = ResSimplePGCN(adj, emd_dim, num_layers=4)
+        self.img2joint_left = ImgFeature2JointFeature(img_feat_dim, emd_dim)
+        self.img2joint_right = ImgFeature2JointFeature(img_feat_dim, emd_dim)
+        self.pos_emb_left = _token_mlp(3, emd_dim, emd_dim)
+        self.pos_emb_right = _token_mlp(3, emd_dim, emd_dim)
+        self.global_pos_emb = _token_mlp(3, emd_dim, emd_dim)
+        self.interaction = STE(num_joints=joint_num * 2, in_chans=emd_dim, out_dim=joint_dim, depth=4)
+        self.proj_feat_emb = _token_mlp(joint_dim, joint_dim, joint_dim)
+        self.fusion = nn.Sequential(nn.Conv2d(joint_dim * self.bone_num * 2, img_feat_dim, 3, 1, 1),
+                                    nn.BatchNorm2d(img_feat_dim), nn.ReLU(), nn.Conv2d(img_feat_dim, img_feat_dim, 1))
+        self.regressor = RegressorOffset(joint_num * joint_dim, mano_pth, root_joint)
+        c = torch.arange(feature_size) + 0.5
+        gx, gy = torch.meshgrid(c, c, indexing='ij')
+        self.register_buffer('img_gird', torch.stack((gy, gx), dim=-1).reshape([feature_size ** 2, 2]).contiguous())
+        self.joint_dim, self.joint_num, self.feature_size, self.distance = joint_dim, joint_num, feature_size, distance
+
+    def bone_proj(self, joint_uv, joint_feat):
+        """models/dir.py:146-174 for ONE hand: [B,21,2], [B,21,64] -> [B,1280,S,S] (float32)."""
+        _capi.require_cuda(joint_uv, joint_feat)
+        B, S = joint_feat.shape[0], self.feature_size
+        uv = _capi.f32c(joint_uv.detach())
+        emb = torch.cat([joint_feat.detach().float(), joint_feat.detach().float()], 1).contiguous()
+        out = torch.empty(B, S, S, 2560, device=uv.device)
+        with torch.cuda.device(uv.device):
+            _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(uv), _capi.ptr(uv), _capi.ptr(emb), _capi.ptr(out),
+                                                          None, B, S, float(self.distance), 0, _capi.stream_ptr()),
+                        'dir_bone_proj_forward')
+        return out[..., :1280].permute(0, 3, 1, 2)
+
+
+class InitRegressor(nn.Module):
+    def __init__(self, feat_dim, mano_path, root_joint):
+        super().__init__()
+        self.mano_layer_right, self.mano_layer_left = _mano_pair(mano_path, root_joint)
+        _fix_shape(self.mano_layer_left, self.mano_layer_right)
+
+        def attn():
+            return nn.Sequential(nn.Conv2d(feat_dim, feat_dim // 2, 3, 1, 1), nn.BatchNorm2d(feat_dim // 2), nn.ReLU(),
+                                 nn.Conv2d(feat_dim // 2, 1, 1, 1), nn.Sigmoid())
+        self.attention_left, self.attention_right = attn(), attn()
+        self.offset = nn.Linear(feat_dim, 3)
+        self.mano_left = nn.Linear(feat_dim, 64)
+        self.mano_right = nn.Linear(feat_dim, 64)
+        for m in (self.mano_left, self.mano_right, self.offset):
+            m.weight.data.normal_(0, 0.001)
+
+
+class FusionJointInterIterDecoder(nn.Module):
+    def __init__(self, joint_num, mano_pth, root_joint, inDim=[2048, 1024, 512, 256], fDim=[256, 256, 256, 256]):
+        super().__init__()
+        self.up4 = nn.Upsample(scale_factor=2, mode='bilinear')
+        self.skip_layer4 = Residual(inDim[1], fDim[0])
+        self.fusion_layer4 = Residual(inDim[0] + fDim[0], fDim[1])
+        self.projecter_4 = Joint2BoneFeature(fDim[1], 128, 64, joint_num, 16, mano_pth, root_joint, distance=1)
+        self.enhance_layer4 = Residual(fDim[1] * 2, fDim[1])
+        self.up3 = nn.Upsample(scale_factor=2, mode='bilinear')
+        self.skip_layer3 = Residual(inDim[2], fDim[1])
+        self.fusion_layer3 = Residual(fDim[1] * 2, fDim[2])
+        self.projecter_3 = Joint2BoneFeature(fDim[2], 128, 64, joint_num, 32, mano_pth, root_joint, distance=2)
+        self.enhance_layer3 = Residual(fDim[2] * 2, fDim[2])
+        self.conv_final = nn.Sequential(nn.Conv2d(fDim[3], fDim[3], 3, 1, 1, bias=False), nn.BatchNorm2d(fDim[3]),
+                                        nn.ReLU(True), nn.Conv2d(fDim[3], fDim[3], 1, 1))
+
+        def head():
+            return nn.Sequential(nn.Conv2d(fDim[3], fDim[3] // 2, 3, 1, 1), nn.BatchNorm2d(fDim[3] // 2), nn.ReLU(),
+                                 nn.Conv2d(fDim[3] // 2, 3, 1, 1))
+        self.seg, self.dense = head(), head()
+
+
+class DIR(nn.Module):
+    def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.joint_num = joint_num
+        self.root_joint = root_joint
+        self.compute_dtype = compute_dtype
+        self.backbone = ResNet50()        # ImageNet weights are a download in the reference (models/dir.py:490-498)
+        self.mesh_sample_num = joint_num
+        self.init_regressor = InitRegressor(self.backbone.inplanes, mano_path, root_joint)
+        self.decoder = FusionJointInterIterDecoder(self.joint_num, mano_path, root_joint)
+        self.coord_weight, self.dense_weight = 10, 1
+        self.seg_loss = nn.CrossEntropyLoss(weight=torch.Tensor([.1, 0.45, 0.45]))     # state-dict key seg_loss.weight
+        self._engine, self._engine_key = None, None
+
+    def engine(self):
+        """(re)pack the parameters when any of them changed (load_state_dict, .to(), in-place edits)."""
+        key = (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        if key != self._engine_key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            dev = next(self.parameters()).device
+            if dev.type != 'cuda':
+                raise _capi.DirHipError('DIR runs on the GPU only: call .cuda() first (no CPU fallback exists)')
+            self._engine = DirEngine(sd, dtype=self.compute_dtype, root_joint=self.root_joint, device=dev)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, input, target, meta_info):
+        if self.training:
+            raise NotImplementedError('dir_amd implements DIR.forward in eval mode (inference hot path); the loss block '
+                                      'of models/dir.py:542-594 is not built yet -- call .eval()')
+        x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
+        eng = self.engine()
+        with torch.cuda.device(x.device), torch.no_grad():
+            outs = eng.forward(_capi.f32c(x))
+        outs_list = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs]
+        return outs_list, {}

@@ -1,0 +1,80 @@
+"""CPU-only: the drop-in boundary.  The dir_amd modules expose the reference's class names, constructor
+signatures and -- key for loading a reference checkpoint -- exactly the reference's state-dict keys and shapes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+
+def manifest(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return {k: tuple(v) for k, v in json.load(f).items()}
+
+
+def test_dir_state_dict_matches_reference_manifest():
+    from dir_amd.models.dir import DIR
+    net = DIR(21, './misc/mano', 0)
+    ours = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    ref = manifest('manifest_dir.json')
+    assert len(ref) == 963
+    assert sorted(ours) == sorted(ref)
+    assert ours == ref
+    # a state dict with the reference's keys loads strictly (what apps/eval.py:107-108 does with strict=False)
+    from dir_amd import synth
+    vals = synth.synth_state_dict(ref, 1234)
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in vals.items()}, strict=True)
+    assert hasattr(net.init_regressor.mano_layer_left, 'th_faces')        # read by train.py / models/dir.py:507-510
+
+
+def test_stage_state_dict_matches_reference_manifest():
+    from dir_amd.models.dir import Joint2BoneFeature
+    for S, dist in ((16, 1), (32, 2)):
+        m = Joint2BoneFeature(256, 128, 64, 21, S, 'unused', 0, distance=dist)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == manifest('manifest_stage%d.json' % S)
+        c = np.arange(S, dtype=np.float32) + 0.5
+        assert np.allclose(m.img_gird.numpy()[:3], [[c[0], c[0]], [c[1], c[0]], [c[2], c[0]]])   # (x+0.5, y+0.5)
+
+
+def test_reference_call_signatures():
+    import inspect
+    from dir_amd.manopth.manolayer import ManoLayer
+    from dir_amd.models.dir import DIR
+    from dir_amd.SemGCN.p_gcn import ResSimplePGCN
+    from dir_amd.SemGCN.p_graph_conv import PGraphConv
+    from dir_amd.SemGCN.utils import adj_mx_from_edges, get_sketch_setting
+    from dir_amd.transformer.mixSTE import STE
+    assert list(inspect.signature(DIR.__init__).parameters)[:4] == ['self', 'joint_num', 'mano_path', 'root_joint']
+    assert list(inspect.signature(DIR.forward).parameters) == ['self', 'input', 'target', 'meta_info']
+    assert list(inspect.signature(ManoLayer.forward).parameters) == ['self', 'th_pose_coeffs', 'th_betas', 'th_trans',
+                                                                     'root_palm', 'share_betas']
+    assert list(inspect.signature(PGraphConv.__init__).parameters) == ['self', 'in_features', 'out_features', 'adj', 'bias']
+    assert list(inspect.signature(STE.__init__).parameters)[:5] == ['self', 'num_joints', 'in_chans', 'out_dim', 'depth']
+    adj = adj_mx_from_edges(21, get_sketch_setting(), sparse=False, eye=False)
+    assert adj.shape == (21, 21) and int((adj > 0).sum()) == 40 and float(adj[0].sum()) == pytest.approx(1.0)
+    g = ResSimplePGCN(adj, 128, num_layers=4)
+    assert g.gconv_layers[0].gconv.W.shape == (2, 21, 128, 128) and g.gconv_layers[0].gconv.e_1.shape == (1, 40)
+    with pytest.raises(NotImplementedError):
+        PGraphConv(64, 64, adj)
+
+
+def test_eval_only_and_gpu_only():
+    from dir_amd import _capi
+    from dir_amd.models.dir import DIR
+    net = DIR(21, 'unused', 0)
+    with pytest.raises(NotImplementedError):
+        net.train()({'img': torch.zeros(1, 3, 256, 256)}, None, None)
+
+
+def test_csr_adjacency_constants_match_edge_order(golden):
+    """the __constant__ CSR tables in dir_amd/csrc/tokens.hip index e_1 in the reference's row-major nonzero order."""
+    import re
+    src = open(os.path.join(os.path.dirname(GOLDEN), '..', 'dir_amd', 'csrc', 'tokens.hip')).read()
+    off = [int(v) for v in re.search(r'kNbrOff\[22\] = \{([^}]*)\}', src).group(1).split(',')]
+    idx = [int(v) for v in re.search(r'kNbrIdx\[40\] = \{([^}]*)\}', src).group(1).split(',')]
+    order = golden('g2_pgcn')['edge_order']
+    rows = [r for r in range(21) for _ in range(off[r + 1] - off[r])]
+    assert np.array_equal(np.stack([rows, idx], 1), order)

@@ -93,3 +93,38 @@ def test_engine_batch_independence(dir_state):
     v = outs[2]['pd_mesh_xyz_left']
     assert torch.equal(v[0], v[2]) and torch.equal(v[1], v[3]) and torch.equal(v[0], v[12])
     assert not torch.equal(v[0], v[1])
+
+
+def test_dir_module_dropin(golden, dir_state):
+    """models.dir.DIR mirror: load a state dict with the reference's keys, call forward like apps/eval.py:167-172."""
+    from dir_amd.models.dir import DIR
+    g = golden('g7_dir')
+    sd, img = dir_state
+    net = DIR(21, './misc/mano', 0, compute_dtype=torch.float32)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    outs, loss = net({'img': img.cpu()}, None, None)         # the module moves the input itself
+    assert loss == {} and len(outs) == 4
+    assert sorted(outs[0]) == sorted(['pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right',
+                                      'pd_joint_xyz_left', 'pd_joint_xyz_right', 'pd_proj_left', 'pd_proj_right',
+                                      'pd_offset', 'pd_rel_joint'])
+    assert sorted(outs[3]) == ['dense', 'proj_feat', 'seg']
+    assert maxabs(outs[2]['pd_mesh_xyz_left'].cpu().numpy(), g['s2.pd_mesh_xyz_left']) < 5e-6
+    assert outs[3]['seg'].shape == (2, 3, 32, 32) and outs[3]['proj_feat'].shape == (2, 1280, 32, 32)
+    # sub-module drop-ins on the same weights
+    c1, c2, c3, c4 = net.backbone(img)
+    assert c4.shape == (2, 2048, 8, 8) and relerr(c4.cpu().numpy()[:, :4], g['c4.slice']) < 3e-4
+    from oracle import nnops as N
+    from oracle import tokens as OT
+    st = net.decoder.projecter_4
+    x = torch.from_numpy(synth.synth_input('mod.gcn', (3, 21, 128), SEED)).cuda()
+    P = N.Params({k: v.cpu().numpy() for k, v in st.gcn_left.state_dict().items()})
+    assert relerr(st.gcn_left(x).cpu().numpy(), OT.pgcn_stack(x.cpu().numpy(), P)) < 3e-6
+    assert relerr(st.gcn_left.gconv_layers[0].gconv(x).cpu().numpy(),
+                  OT.pgraphconv(x.cpu().numpy(), P.sub('gconv_layers.0.gconv'))) < 3e-6
+    t = torch.from_numpy(synth.synth_input('mod.ste', (2, 42, 128), SEED)).cuda()
+    t0 = t.clone()
+    Ps = N.Params({k: v.cpu().numpy() for k, v in st.interaction.state_dict().items()})
+    y = st.interaction(t)
+    assert maxabs(y.cpu().numpy(), OT.ste_forward(t0.cpu().numpy(), Ps)) < 3e-5
+    assert maxabs(t.cpu().numpy(), t0.cpu().numpy() + Ps['spatial_pos_embed']) < 1e-7      # in-place `x += pos`
