@@ -39,18 +39,15 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
+    from dir_amd import dist as D
     from dir_amd import engine as E
     from dir_amd import synth
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    rank, world, local = D.init_from_env('nccl', dev)          # nccl == RCCL on ROCm
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
@@ -74,9 +71,7 @@ def main():
         step = graph.replay
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier(dev)
 
     for _ in range(args.warmup):
         step()
@@ -86,10 +81,7 @@ def main():
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.max_over_ranks(dt, dev)
     barrier()
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt

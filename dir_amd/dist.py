@@ -1,0 +1,75 @@
+"""Multi-GPU sharding of the DIR hot path: images are independent in eval mode (BatchNorm uses running
+statistics, no cross-sample op), so N GPUs = N processes that each run the whole path on their own shard of the batch
+with replicated weights and NO data-path collective.  The only collectives are control-plane: a barrier around timed
+regions, a MAX over ranks of the elapsed time, and an all-gather of per-image results for evaluation.
+
+Backend: "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" on CPU (used by the tests).  Rendezvous on 127.0.0.1."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None, device=None):
+    """(rank, world, local_rank).  Initialises the default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl' and device is not None:
+            kw['device_id'] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_range(n, rank, world):
+    """contiguous shard [start, stop) of n independent images for `rank`; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def barrier(device=None):
+    if device is not None and device.type == 'cuda':
+        torch.cuda.synchronize(device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_shards(local, n_total):
+    """all-gather per-image results (first dim = images of this rank's shard, contiguous shards in rank order) back
+    into the full [n_total, ...] tensor on every rank.  Shards may differ in length by one (padded for the collective)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return local
+    world = dist.get_world_size()
+    longest = (n_total + world - 1) // world
+    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = []
+    for r, p in enumerate(parts):
+        a, b = shard_range(n_total, r, world)
+        out.append(p[:b - a])
+    return torch.cat(out, 0)

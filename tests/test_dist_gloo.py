@@ -1,0 +1,60 @@
+"""CPU, world_size 2, gloo: the N>1 path of the hot path is pure sharding (independent images, no data-path
+collective); this covers the control-plane pieces bench.py and an evaluation loop rely on."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from dir_amd import dist as D
+    r, w, _ = D.init_from_env('gloo')
+    a, b = D.shard_range(n_total, r, w)
+    # "process" the shard: a per-image result that identifies the image
+    local = torch.arange(a, b, dtype=torch.float32).reshape(-1, 1).repeat(1, 3) * 2.0
+    D.barrier()
+    full = D.gather_shards(local, n_total)
+    tmax = D.max_over_ranks(1.0 + rank)
+    tsum = D.sum_over_ranks(b - a)
+    q.put((rank, (a, b), full[:, 0].tolist(), tmax, tsum))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_total', [7, 64])
+def test_sharding_and_control_collectives_world2(n_total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, f0, m0, t0), (r1, s1, f1, m1, t1) = res
+    assert s0[0] == 0 and s0[1] == s1[0] and s1[1] == n_total and abs((s0[1] - s0[0]) - (s1[1] - s1[0])) <= 1
+    expect = [2.0 * i for i in range(n_total)]
+    assert f0 == expect and f1 == expect                 # every image exactly once, in order, on every rank
+    assert m0 == m1 == 2.0 and t0 == t1 == float(n_total)
+
+
+def test_shard_range_partitions():
+    from dir_amd.dist import shard_range
+    for n in (0, 1, 5, 64, 1000):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
