@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=8)
+    ap.add_argument('--dump-conv', action='store_true', help='print per-shape conv timings (stderr)')
     args = ap.parse_args()
 
     import numpy as np
@@ -99,7 +100,14 @@ def main():
         for _ in range(reps):
             eng.forward(img)
         torch.cuda.synchronize()
-        rec = [(t_, f_, e0.elapsed_time(e1)) for t_, f_, e0, e1 in E.PROFILE]
+        rec = [(t_, f_, e0.elapsed_time(e1)) for t_, f_, e0, e1, _ in E.PROFILE]
+        if args.dump_conv:
+            agg = {}
+            for t_, f_, e0, e1, shp in E.PROFILE:
+                a = agg.setdefault((t_, shp), [0, 0.0, 0.0])
+                a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f_
+            for (t_, shp), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                sys.stderr.write('%-24s %-40s x%-3d %8.3f ms/step %8.1f TFLOP/s\n' % (t_, shp, n // reps, ms / reps, fl / ms / 1e9))
         E.PROFILE = None
         dom = [(f_, ms) for t_, f_, ms in rec if t_ == tag]
         n_launch = len(dom) // reps

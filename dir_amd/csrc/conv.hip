@@ -10,12 +10,15 @@
 // bijection of k is legal as long as A and W use the same one.  LDS rows are padded 128 -> 144 B, which
 // makes the ds_read_b128 pattern conflict free (bank step 36 dwords).
 //
-// Block = 256 threads (2x2 waves), tile 128(M) x 128(N), each wave 64x64 = 2x2 MFMA tiles (64 acc VGPRs).
+// Block = 256 threads (2x2 waves); tile (64|128)(M) x (64|128)(N) picked per layer (launch_conv): each wave owns
+// MI x NJ MFMA tiles of 32x32 (up to 64 acc VGPRs).
 // Global -> registers -> LDS double buffering, one barrier per K-slab; the next slab's global loads are
 // in flight during the MFMAs.  Zero padding, M/N tails and the optional pre-activation BatchNorm+ReLU
 // (hourglass.Residual, models/backbone/hourglass.py:55-70) are handled in the register stage.
 // Epilogue: per-channel scale/shift (folded BatchNorm / bias), optional residual add, optional ReLU,
-// optional channel offset/stride so a conv can write straight into a slice of a concat buffer.
+// optional channel offset/stride so a conv can write straight into a slice of a concat buffer.  The fp32 tile is
+// staged through LDS (reusing the pipeline buffers) so HBM sees 16-byte coalesced row segments for the output and
+// the residual -- the 1x1 bottleneck convs (K = 64..256) are HBM-bound and live or die by this.
 //
 // Replaces the ATen/MKL-DNN (cuDNN in the original) calls under models/backbone/resnet.py:120-140,243-255,
 // models/backbone/hourglass.py:10-30,55-70 and models/dir.py:57-62,227-241,404-420.
@@ -27,8 +30,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short bf16_t;
 
-constexpr int BM = 128, BN = 128, LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
-constexpr int TILE_BYTES = BM * LDS_STRIDE;  // 18432 per operand per buffer
+constexpr int LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -102,10 +104,44 @@ __device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uin
                                                       __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
 }
 
-template <typename TI, typename TO>
+// 16-byte vector of output elements (coalesced epilogue)
+template <typename TO> struct OutVec;
+template <> struct OutVec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct OutVec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f((bf16_t)(u[e] & 0xffffu)); v[2 * e + 1] = bf2f((bf16_t)(u[e] >> 16)); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+// MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
+template <typename TI, typename TO, int MI, int NJ>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // [buf][A|B]
+    constexpr int BM = 64 * MI, BN = 64 * NJ;
+    constexpr int A_BYTES = BM * LDS_STRIDE, B_BYTES = BN * LDS_STRIDE, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int STAGE_BYTES = BM * BN * 4;
+    constexpr int SMEM = (2 * BUF_BYTES > STAGE_BYTES) ? 2 * BUF_BYTES : STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
     constexpr int EPC = Tr<TI>::EPC, BK = Tr<TI>::BK;
+    constexpr int ACH = BM / 32, BCH = BN / 32;      // 16-byte chunks per thread per K-slab (A, B)
 
     // XCD-aware tile order: contiguous tile ranges share one XCD's L2 (block b runs on XCD b % 8)
     const int nwg = a.tiles_m * a.tiles_n;
@@ -123,16 +159,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const TI* __restrict__ x = (const TI*)a.x;
     const TI* __restrict__ w = (const TI*)a.w;
 
-    // ---- per-thread loader state: 4 A chunks + 4 B chunks of 16 bytes per K-slab
-    long long abase[4];
-    int aiy[4], aix[4];
-    long long bbase[4];
-    bool bval[4];
+    // ---- per-thread loader state
+    long long abase[ACH];
+    int aiy[ACH], aix[ACH];
+    long long bbase[BCH];
+    bool bval[BCH];
     const int col = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i;
-        const int m = m0 + row;
+    for (int i = 0; i < ACH; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
         if (m < a.M) {
             const int b = m / (a.Ho * a.Wo);
             const int rem = m - b * (a.Ho * a.Wo);
@@ -145,12 +180,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             aix[i] = 0;
             abase[i] = 0;
         }
-        const int n = n0 + row;
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int n = n0 + (tid >> 3) + 32 * i;
         bval[i] = n < a.Cout;
         bbase[i] = (long long)n * a.K + col * EPC;
     }
 
-    uint4 ra[4], rb[4];
+    uint4 ra[ACH], rb[BCH];
     const bool has_pre = a.pre_scale != nullptr;
     const bool pre_relu = (a.flags & 2) != 0;
 
@@ -160,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
         const long long toff = (long long)(ky * a.W + kx) * a.in_cs + c0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < ACH; ++i) {
             const int iy = aiy[i] + ky, ix = aix[i] + kx;
             const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -169,25 +207,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 if (has_pre) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
             }
             ra[i] = v;
-            rb[i] = bval[i] ? *reinterpret_cast<const uint4*>(w + bbase[i] + k0) : make_uint4(0, 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i)
+            rb[i] = bval[i] ? *reinterpret_cast<const uint4*>(w + bbase[i] + k0) : make_uint4(0, 0, 0, 0);
     };
     auto lstore = [&](int buf) {
-        char* sa = smem + buf * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
+        char* sa = smem + buf * BUF_BYTES;
+        char* sb = sa + A_BYTES;
+        const int off0 = (tid >> 3) * LDS_STRIDE + col * 16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = ((tid >> 3) + 32 * i) * LDS_STRIDE + col * 16;
-            *reinterpret_cast<uint4*>(sa + off) = ra[i];
-            *reinterpret_cast<uint4*>(sb + off) = rb[i];
-        }
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<uint4*>(sa + off0 + 32 * i * LDS_STRIDE) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) *reinterpret_cast<uint4*>(sb + off0 + 32 * i * LDS_STRIDE) = rb[i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -199,39 +238,81 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int ks = 0; ks < a.nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < a.nk) gload(ks + 1);
-        const char* sa = smem + buf * 2 * TILE_BYTES + (wm * 64) * LDS_STRIDE + frag_off;
-        const char* sb = smem + buf * 2 * TILE_BYTES + TILE_BYTES + (wn * 64) * LDS_STRIDE + frag_off;
-        uint4 af[2][4], bfr[2][4];
+        const char* sa = smem + buf * BUF_BYTES + (wm * MI * 32) * LDS_STRIDE + frag_off;
+        const char* sb = smem + buf * BUF_BYTES + A_BYTES + (wn * NJ * 32) * LDS_STRIDE + frag_off;
+        uint4 af[MI][4], bfr[NJ][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                af[i][q] = *reinterpret_cast<const uint4*>(sa + i * 32 * LDS_STRIDE + q * 16);
-                bfr[i][q] = *reinterpret_cast<const uint4*>(sb + i * 32 * LDS_STRIDE + q * 16);
-            }
+            for (int q = 0; q < 4; ++q) af[i][q] = *reinterpret_cast<const uint4*>(sa + i * 32 * LDS_STRIDE + q * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
+            for (int q = 0; q < 4; ++q) bfr[j][q] = *reinterpret_cast<const uint4*>(sb + j * 32 * LDS_STRIDE + q * 16);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
         if (ks + 1 < a.nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     TO* __restrict__ y = (TO*)a.y;
     const TO* __restrict__ res = (const TO*)a.res;
     const bool relu = (a.flags & 1) != 0;
+    if (a.flags & 4) {
+        // coalesced path: scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM
+        float* st = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int cl = wn * NJ * 32 + j * 32 + (lane & 31);
+            const int n = n0 + cl;
+            const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+            const float sh = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    st[rl * BN + cl] = fmaf(acc[i][j][r], sc, sh);
+                }
+        }
+        __syncthreads();
+        constexpr int VN = OutVec<TO>::N, CPR = BN / VN;          // chunks per tile row
+        for (int c = tid; c < BM * CPR; c += 256) {
+            const int rl = c / CPR, cc = (c - rl * CPR) * VN;
+            const int m = m0 + rl, n = n0 + cc;
+            if (m >= a.M || n >= a.Cout) continue;
+            float v[VN];
+            const float4* sp = reinterpret_cast<const float4*>(st + rl * BN + cc);
+#pragma unroll
+            for (int q = 0; q < VN / 4; ++q) { const float4 t = sp[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+            if (res) {
+                float rv[VN];
+                OutVec<TO>::load(res + (long long)m * a.res_cs + a.res_co + n, rv);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) v[e] += rv[e];
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            OutVec<TO>::store(y + (long long)m * a.out_cs + a.out_co + n, v);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * NJ * 32 + j * 32 + (lane & 31);
         if (n >= a.Cout) continue;
         const float sc = a.scale ? a.scale[n] : 1.f;
         const float sh = a.shift ? a.shift[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= a.M) continue;
                 float v = fmaf(acc[i][j][r], sc, sh);
                 if (res) v += load_res<TO>(res + (long long)m * a.res_cs + a.res_co + n);
@@ -240,6 +321,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             }
         }
     }
+}
+
+template <typename TI, typename TO>
+void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
+    ConvArgs a = a0;
+    // tile shape: 64-wide N tile for Cout <= 64 (no half-empty MFMA tiles); 64-tall M tile when the 128-tall grid
+    // would not even put two workgroups on every CU (8x8 / 16x16 feature maps)
+    const bool n64 = a.Cout <= 64;
+    const int bn = n64 ? 64 : 128;
+    const int tiles_n = (a.Cout + bn - 1) / bn;
+    const bool m64 = (long long)((a.M + 127) / 128) * tiles_n <= (long long)num_cu;
+    const int bm = m64 ? 64 : 128;
+    a.tiles_m = (a.M + bm - 1) / bm;
+    a.tiles_n = tiles_n;
+    dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    if (!m64 && !n64) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 2, 2>), grid, block, 0, s, a);
+    else if (!m64 && n64) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 2, 1>), grid, block, 0, s, a);
+    else if (m64 && !n64) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 1, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 1, 1>), grid, block, 0, s, a);
 }
 
 }  // namespace
@@ -277,11 +377,22 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
     const long long M = (long long)d->B * a.Ho * a.Wo;
     DIR_REQUIRE(M < (1ll << 31), "dir_conv2d_forward: too many output pixels");
     a.M = (int)M; a.K = d->kh * d->kw * d->Cin; a.nk = a.K / BK;
-    a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (d->Cout + BN - 1) / BN; a.flags = d->flags;
-    dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    a.tiles_m = a.tiles_n = 0;
+    a.flags = d->flags & 3;
+    // coalesced (LDS-staged, 16-byte) epilogue whenever every output / residual row segment is 16-byte aligned
+    const int epo = d->out_dtype == DIR_DT_F32 ? 4 : 8;
+    const bool vec = d->Cout % epo == 0 && out_cs % epo == 0 && d->out_coff % epo == 0 &&
+                     (residual == nullptr || (res_cs % epo == 0 && d->res_coff % epo == 0));
+    if (vec) a.flags |= 4;
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (f32) hipLaunchKernelGGL((conv_igemm_kernel<float, float>), grid, block, 0, s, a);
-    else if (d->out_dtype == DIR_DT_BF16) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, bf16_t>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, float>), grid, block, 0, s, a);
+    if (f32) launch_conv<float, float>(a, num_cu, s);
+    else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
+    else launch_conv<bf16_t, float>(a, num_cu, s);
     return dir::check_launch("dir_conv2d_forward");
 }

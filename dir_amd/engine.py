@@ -71,7 +71,9 @@ class ConvOp(object):
         if PROFILE is not None:
             e1.record()
             tag = 'conv_igemm<%s,%s>' % ('f32' if self.dtype == F32 else 'bf16', 'f32' if out.dtype == F32 else 'bf16')
-            PROFILE.append((tag, 2.0 * B * ho * wo * self.cout * self.alg_k, e0, e1))
+            PROFILE.append((tag, 2.0 * B * ho * wo * self.cout * self.alg_k, e0, e1,
+                            'M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
+                                                           self.kw, self.stride)))
         return out
 
 
