@@ -47,12 +47,12 @@ class SteParams(C.Structure):
 
 
 class RegressParams(C.Structure):
-    _fields_ = [('mano_w', C.c_void_p * 2), ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p),
+    _fields_ = [('mano_wt', C.c_void_p), ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p),
                 ('emb', TokenMlp)]
 
 
 class InitHeadParams(C.Structure):
-    _fields_ = [('attn_w', C.c_void_p * 2), ('attn_b', C.c_float * 2), ('mano_w', C.c_void_p * 2),
+    _fields_ = [('attn_w', C.c_void_p * 2), ('attn_b', C.c_float * 2), ('mano_wt', C.c_void_p),
                 ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p)]
 
 
@@ -73,8 +73,10 @@ _SIGNATURES = {
     'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),
                                           C.POINTER(TokenMlp), C.POINTER(TokenMlp), _p, _p, _i, _p]),
     'dir_pgcn_stack_forward': (C.c_int, [C.POINTER(PgcnLayer), _i, _p, _p, _p, C.c_longlong, _p, _i, _p]),
+    'dir_pgcn_stack_forward_pair': (C.c_int, [C.POINTER(PgcnLayer), C.POINTER(PgcnLayer), _i, _p, _p, _p, _p, _i, _p]),
     'dir_ste_forward': (C.c_int, [C.POINTER(SteParams), _p, _p, _p, _i, _p]),
     'dir_regress_forward': (C.c_int, [C.POINTER(RegressParams), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
 

@@ -1,7 +1,8 @@
 // Fused MANO forward for gfx950: PCA -> Rodrigues (via quaternion) -> robust 6D root rotation -> shape
 // and pose blend shapes -> 3-level kinematic chain -> LBS -> fingertips -> joint reorder -> root
-// centring -> weak-perspective projection.  One 256-thread workgroup per sample; every intermediate
-// lives in LDS (~11 KB), tables are read k-major (coalesced) and stay L2 resident across the batch.
+// centring -> weak-perspective projection.  One 640-thread workgroup per (sample, hand) -- both hands of a stage go
+// in ONE launch -- every intermediate lives in LDS (~11 KB); tables are read k-major with 16-byte loads (rows padded
+// to 2336 floats) and stay L2 resident across the batch.
 //
 // Replaces manopth/manopth/manolayer.py:110-270 (+ rodrigues_layer.py:15-54, rot6d.py:26-60,
 // tensutils.py:6-42) and utils/utils.py:47-63 of the reference: ~4040 ATen op calls and a host sync
@@ -10,18 +11,19 @@
 
 namespace {
 
-constexpr int NV = 778, NV3 = 2334, NJ = 16;
+constexpr int NV = 778, NV3 = 2334, NV3P = 2336, NJ = 16, NTHR = 640;   // table rows padded to 2336 floats (16-B aligned)
 
 __constant__ int kReorderJ[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
 __constant__ int kTips[2][5] = {{745, 317, 444, 556, 673}, {745, 317, 445, 556, 673}};
 
-struct ManoArgs {
+struct ManoHand {
     dir_mano_tables t;
     const float* pose; int pose_stride;
     const float* betas; int betas_stride;
     const float* cam; int cam_stride;
     float* verts; float* joints; float* joint_uv; float* mesh_uv; int32_t* flags;
 };
+struct ManoArgs { ManoHand h[2]; };
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     // rot6d.py:54-60: v / max(|v|, 1e-8).  No FMA contraction: the robust-6D construction is
@@ -31,8 +33,9 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     x /= m; y /= m; z /= m;
 }
 
-__global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
-    __shared__ float s_v[NV3];          // v_shaped -> v_posed -> skinned vertices (in place)
+__global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
+    const ManoHand& a = args.h[blockIdx.y];
+    __shared__ float s_v[NV3P];         // v_shaped -> v_posed -> skinned vertices (in place)
     __shared__ float s_pose[51], s_beta[10], s_cam[3];
     __shared__ float s_full[45];        // axis-angle of the 15 articulated joints
     __shared__ float s_rot[15 * 9];     // rotation matrices (row major)
@@ -58,10 +61,10 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
         for (int k = 0; k < 45; ++k) acc = fmaf(s_pose[6 + k], a.t.comps[k * 45 + tid], acc);
         s_full[tid] = a.t.hands_mean[tid] + acc;
     }
-    for (int i = tid; i < NV3; i += 256) {
+    for (int i = tid; i < NV3; i += NTHR) {
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc = fmaf(a.t.shapedirs_t[k * NV3 + i], s_beta[k], acc);
+        for (int k = 0; k < 10; ++k) acc = fmaf(a.t.shapedirs_t[k * NV3P + i], s_beta[k], acc);
         s_v[i] = acc + a.t.v_template[i];
     }
     if (tid == 64) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
         for (int e = 0; e < 9; ++e) s_pm[9 * tid + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
     }
     // ---- joint regression from the shaped template (manolayer.py:183): 48 dot products of length 778
-    for (int o = wave; o < NJ * 3; o += 4) {
+    for (int o = wave; o < NJ * 3; o += NTHR / 64) {
         const int j = o / 3, c = o - 3 * j;
         float acc = 0.f;
         for (int v = lane; v < NV; v += 64) acc = fmaf(a.t.j_regressor[j * NV + v], s_v[3 * v + c], acc);
@@ -121,11 +124,19 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
     }
     __syncthreads();
 
-    // ---- pose blend shapes (manolayer.py:186-187)
-    for (int i = tid; i < NV3; i += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < 135; ++k) acc = fmaf(a.t.posedirs_t[k * NV3 + i], s_pm[k], acc);
-        s_v[i] += acc;
+    // ---- pose blend shapes (manolayer.py:186-187): 584 threads x float4 of the k-major table, 9 loads in flight
+    if (tid < NV3P / 4) {
+        const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + tid;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 9
+        for (int k = 0; k < 135; ++k) {
+            const float4 p = pd[k * (NV3P / 4)];
+            const float w = s_pm[k];
+            acc.x = fmaf(p.x, w, acc.x); acc.y = fmaf(p.y, w, acc.y); acc.z = fmaf(p.z, w, acc.z); acc.w = fmaf(p.w, w, acc.w);
+        }
+        const int i = 4 * tid;
+        s_v[i] += acc.x; s_v[i + 1] += acc.y;
+        if (i + 2 < NV3) { s_v[i + 2] += acc.z; s_v[i + 3] += acc.w; }
     }
     // ---- kinematic chain (manolayer.py:192-229): finger f owns joints 1+3f, 2+3f, 3+3f
     if (tid < 5) {
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
     __syncthreads();
 
     // ---- linear blend skinning (manolayer.py:236-246): T = sum_k w[v][k] A'[k]; vert = T.[v_posed;1]
-    for (int v = tid; v < NV; v += 256) {
+    for (int v = tid; v < NV; v += NTHR) {
         const float4* wp = reinterpret_cast<const float4*>(a.t.weights + 16 * v);
         float w[16];
 #pragma unroll
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
 
     const float sc = s_cam[0], tx = s_cam[1], ty = s_cam[2];
     float* vout = a.verts + (size_t)b * NV3;
-    for (int i = tid; i < NV3; i += 256) vout[i] = s_v[i] - s_c[i % 3];
+    for (int i = tid; i < NV3; i += NTHR) vout[i] = s_v[i] - s_c[i % 3];
     if (tid < 63) a.joints[(size_t)b * 63 + tid] = s_jtr[tid] - s_c[tid % 3];
     if (a.cam) {   // utils/utils.py:47-63: uv = s * xy + t
         if (a.joint_uv && tid >= 64 && tid < 64 + 42) {
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
         }
         if (a.mesh_uv) {
             float* mo = a.mesh_uv + (size_t)b * NV * 2;
-            for (int i = tid; i < NV * 2; i += 256) {
+            for (int i = tid; i < NV * 2; i += NTHR) {
                 const int v = i >> 1, c = i & 1;
                 mo[i] = sc * (s_v[3 * v + c] - s_c[c]) + (c ? ty : tx);
             }
@@ -233,18 +244,49 @@ __global__ __launch_bounds__(256) void mano_forward_kernel(ManoArgs a) {
 
 }  // namespace
 
+static int check_hand(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
+                      int betas_stride, const float* cam, int cam_stride, float* verts, float* joints) {
+    DIR_REQUIRE(t && pose && betas && verts && joints, "dir_mano_forward: null pointer");
+    DIR_REQUIRE(t->shapedirs_t && t->posedirs_t && t->v_template && t->j_regressor && t->weights &&
+                    t->hands_mean && t->comps, "dir_mano_forward: null table");
+    DIR_REQUIRE(pose_stride >= 51 && betas_stride >= 10, "dir_mano_forward: bad stride");
+    DIR_REQUIRE(t->side == 0 || t->side == 1, "dir_mano_forward: side must be 0 (right) or 1 (left)");
+    DIR_REQUIRE(t->center_idx >= -1 && t->center_idx < 21, "dir_mano_forward: center_idx out of range");
+    DIR_REQUIRE(cam == nullptr || cam_stride >= 3, "dir_mano_forward: bad cam stride");
+    DIR_REQUIRE(((uintptr_t)t->posedirs_t & 15) == 0 && ((uintptr_t)t->weights & 15) == 0,
+                "dir_mano_forward: posedirs_t / weights must be 16-byte aligned");
+    return DIR_OK;
+}
+
 extern "C" int dir_mano_forward(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
                                 int betas_stride, const float* cam, int cam_stride, float* verts, float* joints,
                                 float* joint_uv, float* mesh_uv, int32_t* flags_out, int B, void* stream) {
     if (B == 0) return DIR_OK;   /* empty batch: nothing to do, pointers may be null */
-    DIR_REQUIRE(t && pose && betas && verts && joints, "dir_mano_forward: null pointer");
-    DIR_REQUIRE(t->shapedirs_t && t->posedirs_t && t->v_template && t->j_regressor && t->weights &&
-                    t->hands_mean && t->comps, "dir_mano_forward: null table");
-    DIR_REQUIRE(B > 0 && pose_stride >= 51 && betas_stride >= 10, "dir_mano_forward: bad B/stride");
-    DIR_REQUIRE(t->side == 0 || t->side == 1, "dir_mano_forward: side must be 0 (right) or 1 (left)");
-    DIR_REQUIRE(t->center_idx >= -1 && t->center_idx < 21, "dir_mano_forward: center_idx out of range");
-    DIR_REQUIRE(cam == nullptr || cam_stride >= 3, "dir_mano_forward: bad cam stride");
-    ManoArgs a{*t, pose, pose_stride, betas, betas_stride, cam, cam_stride, verts, joints, joint_uv, mesh_uv, flags_out};
-    hipLaunchKernelGGL(mano_forward_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    DIR_REQUIRE(B > 0, "dir_mano_forward: bad B");
+    int rc = check_hand(t, pose, pose_stride, betas, betas_stride, cam, cam_stride, verts, joints);
+    if (rc) return rc;
+    ManoArgs a;
+    a.h[0] = ManoHand{*t, pose, pose_stride, betas, betas_stride, cam, cam_stride, verts, joints, joint_uv, mesh_uv, flags_out};
+    a.h[1] = a.h[0];
+    hipLaunchKernelGGL(mano_forward_kernel, dim3(B, 1), dim3(NTHR), 0, (hipStream_t)stream, a);
     return dir::check_launch("dir_mano_forward");
+}
+
+extern "C" int dir_mano_forward_pair(const dir_mano_tables* tables_lr, const float* const* pose_lr, int pose_stride,
+                                     const float* const* betas_lr, int betas_stride, const float* const* cam_lr,
+                                     int cam_stride, float* const* verts_lr, float* const* joints_lr,
+                                     float* const* joint_uv_lr, int B, void* stream) {
+    if (B == 0) return DIR_OK;
+    DIR_REQUIRE(B > 0 && tables_lr && pose_lr && betas_lr && verts_lr && joints_lr, "dir_mano_forward_pair: bad arguments");
+    ManoArgs a;
+    for (int h = 0; h < 2; ++h) {
+        const float* cam = cam_lr ? cam_lr[h] : nullptr;
+        int rc = check_hand(&tables_lr[h], pose_lr[h], pose_stride, betas_lr[h], betas_stride, cam, cam_stride, verts_lr[h],
+                            joints_lr[h]);
+        if (rc) return rc;
+        a.h[h] = ManoHand{tables_lr[h], pose_lr[h], pose_stride, betas_lr[h], betas_stride, cam, cam_stride, verts_lr[h],
+                          joints_lr[h], joint_uv_lr ? joint_uv_lr[h] : nullptr, nullptr, nullptr};
+    }
+    hipLaunchKernelGGL(mano_forward_kernel, dim3(B, 2), dim3(NTHR), 0, (hipStream_t)stream, a);
+    return dir::check_launch("dir_mano_forward_pair");
 }

@@ -23,6 +23,34 @@ template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// 16-byte vectors of T
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f((bf16_t)(u[e] & 0xffffu)); v[2 * e + 1] = bf2f((bf16_t)(u[e] >> 16)); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
 // ------------------------------------------------------------------------------------------ stem prep
 template <typename T>
 __global__ void stem_prep_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int Hp,
@@ -47,14 +75,18 @@ __global__ void stem_prep_kernel(const float* __restrict__ img, T* __restrict__ 
 // ------------------------------------------------------------------------------------------ maxpool
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
-    const long long n = (long long)B * Ho * Wo * C;
+    constexpr int VN = Vec<T>::N;
+    const int CV = C / VN;
+    const long long n = (long long)B * Ho * Wo * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long p = i / C;
+        const int c = (int)(i % CV) * VN;
+        long long p = i / CV;
         const int ox = (int)(p % Wo); p /= Wo;
         const int oy = (int)(p % Ho);
         const int b = (int)(p / Ho);
-        float m = -INFINITY;
+        float m[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) m[e] = -INFINITY;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * 2 - 1 + ky;
@@ -63,21 +95,25 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 if (ix < 0 || ix >= W) continue;
-                m = fmaxf(m, ld<T>(x + ((long long)(b * H + iy) * W + ix) * C + c));
+                float v[VN];
+                Vec<T>::load(x + ((long long)(b * H + iy) * W + ix) * C + c, v);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) m[e] = fmaxf(m[e], v[e]);
             }
         }
-        st<T>(y + i, m);
+        Vec<T>::store(y + ((long long)(b * Ho + oy) * Wo + ox) * C + c, m);
     }
 }
 
 // ------------------------------------------------------------------------------------------ upsample
 template <typename T>
 __global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int ocs, int oco) {
-    const int Ho = 2 * H, Wo = 2 * W;
-    const long long n = (long long)B * Ho * Wo * C;
+    constexpr int VN = Vec<T>::N;
+    const int Ho = 2 * H, Wo = 2 * W, CV = C / VN;
+    const long long n = (long long)B * Ho * Wo * CV;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long p = i / C;
+        const int c = (int)(i % CV) * VN;
+        long long p = i / CV;
         const int ox = (int)(p % Wo); p /= Wo;
         const int oy = (int)(p % Ho);
         const int b = (int)(p / Ho);
@@ -87,10 +123,17 @@ __global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int 
         const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
         const float ly = sy - y0, lx = sx - x0;
         const T* base = x + (long long)b * H * W * C + c;
-        const float v00 = ld<T>(base + ((long long)y0 * W + x0) * C), v01 = ld<T>(base + ((long long)y0 * W + x1) * C);
-        const float v10 = ld<T>(base + ((long long)y1 * W + x0) * C), v11 = ld<T>(base + ((long long)y1 * W + x1) * C);
-        const float top = v00 * (1.f - lx) + v01 * lx, bot = v10 * (1.f - lx) + v11 * lx;
-        st<T>(y + ((long long)(b * Ho + oy) * Wo + ox) * ocs + oco + c, top * (1.f - ly) + bot * ly);
+        float v00[VN], v01[VN], v10[VN], v11[VN], o[VN];
+        Vec<T>::load(base + ((long long)y0 * W + x0) * C, v00);
+        Vec<T>::load(base + ((long long)y0 * W + x1) * C, v01);
+        Vec<T>::load(base + ((long long)y1 * W + x0) * C, v10);
+        Vec<T>::load(base + ((long long)y1 * W + x1) * C, v11);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            const float top = v00[e] * (1.f - lx) + v01[e] * lx, bot = v10[e] * (1.f - lx) + v11[e] * lx;
+            o[e] = top * (1.f - ly) + bot * ly;
+        }
+        Vec<T>::store(y + ((long long)(b * Ho + oy) * Wo + ox) * ocs + oco + c, o);
     }
 }
 
@@ -103,22 +146,29 @@ struct InitHeadArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void init_head_kernel(InitHeadArgs a) {
-    // one block per sample.  LDS: attention weights [2][HW], pooled features [3][C] (left, right, mean)
-    extern __shared__ float sm[];
+__global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
+    // one 512-thread block per sample.  LDS: attention weights [2][HW], pooled features [3][C] (left, right, mean)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int VN = Vec<T>::N;
     float* s_attn = sm;                 // [2][HW]
     float* s_feat = sm + 2 * a.HW;      // [3][C]
     __shared__ float s_den[2];
+    __shared__ float s_part[4][128];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int HW = a.HW, C = a.C, Ch = a.Ch;
     const T* c4 = (const T*)a.c4 + (long long)b * HW * C;
-    // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232)
-    for (int o = wave; o < 2 * HW; o += 4) {
+    // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232); one wave per (hand, pixel) dot product
+    for (int o = wave; o < 2 * HW; o += 8) {
         const int s = o / HW, px = o - s * HW;
         const T* h = (const T*)a.h[s] + ((long long)b * HW + px) * Ch;
         const float* w = a.p.attn_w[s];
         float acc = 0.f;
-        for (int k = lane; k < Ch; k += 64) acc = fmaf(ld<T>(h + k), w[k], acc);
+        for (int k = lane * VN; k < Ch; k += 64 * VN) {
+            float v[VN];
+            Vec<T>::load(h + k, v);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc = fmaf(v[e], w[k + e], acc);
+        }
         acc = dir::wave_sum(acc);
         if (lane == 0) s_attn[o] = 1.f / (1.f + expf(-(acc + a.p.attn_b[s])));
     }
@@ -129,30 +179,56 @@ __global__ __launch_bounds__(256) void init_head_kernel(InitHeadArgs a) {
         s_den[tid] = d + 1e-8f;                                     // models/dir.py:264
     }
     __syncthreads();
-    // 2) attention-weighted pooling and the plain spatial mean (models/dir.py:264-268)
-    for (int c = tid; c < C; c += 256) {
-        float fl = 0.f, fr = 0.f, fm = 0.f;
+    // 2) attention-weighted pooling and the plain spatial mean (models/dir.py:264-268): VN channels per thread
+    for (int c = tid * VN; c < C; c += 512 * VN) {
+        float fl[VN], fr[VN], fm[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { fl[e] = 0.f; fr[e] = 0.f; fm[e] = 0.f; }
+#pragma unroll 8
         for (int px = 0; px < HW; ++px) {
-            const float v = ld<T>(c4 + (long long)px * C + c);
-            fl = fmaf(v, s_attn[px], fl);
-            fr = fmaf(v, s_attn[HW + px], fr);
-            fm += v;
+            float v[VN];
+            Vec<T>::load(c4 + (long long)px * C + c, v);
+            const float al = s_attn[px], ar = s_attn[HW + px];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { fl[e] = fmaf(v[e], al, fl[e]); fr[e] = fmaf(v[e], ar, fr[e]); fm[e] += v[e]; }
         }
-        s_feat[c] = fl / s_den[0];
-        s_feat[C + c] = fr / s_den[1];
-        s_feat[2 * C + c] = fm / (float)HW;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            s_feat[c + e] = fl[e] / s_den[0];
+            s_feat[C + c + e] = fr[e] / s_den[1];
+            s_feat[2 * C + c + e] = fm[e] / (float)HW;
+        }
     }
     __syncthreads();
-    // 3) Linears: mano_left/right (64 outputs each) and offset (3) (models/dir.py:268-270)
-    for (int o = wave; o < 131; o += 4) {
-        const float* w; const float* f; float bias; float* dst;
-        if (o < 64) { w = a.p.mano_w[0] + (long long)o * C; f = s_feat; bias = a.p.mano_b[0][o]; dst = a.para[0] + (long long)b * 64 + o; }
-        else if (o < 128) { w = a.p.mano_w[1] + (long long)(o - 64) * C; f = s_feat + C; bias = a.p.mano_b[1][o - 64]; dst = a.para[1] + (long long)b * 64 + o - 64; }
-        else { w = a.p.off_w + (long long)(o - 128) * C; f = s_feat + 2 * C; bias = a.p.off_b[o - 128]; dst = a.offset + (long long)b * 3 + o - 128; }
+    // 3) Linears (models/dir.py:268-270).  mano_{left,right}: thread = (output o of 128, K quarter), k-major weights,
+    //    16 loads in flight; offset (3 outputs): waves 0..2, lane-strided.
+    {
+        const int o = tid & 127, ks = tid >> 7, kq = C / 4;
+        const float* f = s_feat + (o >> 6) * C + ks * kq;
+        const float* w = a.p.mano_wt + (long long)(ks * kq) * 128 + o;
         float acc = 0.f;
+        for (int k0 = 0; k0 < kq; k0 += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w[(k0 + u) * 128];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fmaf(f[k0 + u], wv[u], acc);
+        }
+        s_part[ks][o] = acc;
+    }
+    if (wave < 3) {
+        const float* w = a.p.off_w + (long long)wave * C;
+        const float* f = s_feat + 2 * C;
+        float acc = 0.f;
+#pragma unroll 8
         for (int k = lane; k < C; k += 64) acc = fmaf(f[k], w[k], acc);
         acc = dir::wave_sum(acc);
-        if (lane == 0) *dst = acc + bias;
+        if (lane == 0) a.offset[(long long)b * 3 + wave] = acc + a.p.off_b[wave];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int s = tid >> 6, oo = tid & 63;
+        a.para[s][(long long)b * 64 + oo] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + a.p.mano_b[s][oo];
     }
 }
 
@@ -236,30 +312,42 @@ __global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
         const float* fa = s_emb + (hand * 21 + kParent[bone]) * 64 + c8 * 8;
         const float* fb = s_emb + (hand * 21 + kChild[bone]) * 64 + c8 * 8;
         T* o = orow + (long long)x * 2560 + hb * 64 + c8 * 8;
+        float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma clang fp contract(off)
-            const float v = masked ? 0.f : fa[e] * wa + fb[e] * wb;    // models/dir.py:170-172
-            st<T>(o + e, v);
+            v[e] = masked ? 0.f : fa[e] * wa + fb[e] * wb;             // models/dir.py:170-172
+        }
+        if (sizeof(T) == 2) Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(o), v);
+        else {
+            const float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+            Vec<float>::store(reinterpret_cast<float*>(o), lo);
+            Vec<float>::store(reinterpret_cast<float*>(o) + 4, hi);
         }
     }
     if (a.vis) {
         // vis_img_feat = left + right, NCHW fp32 [B,1280,S,S] (models/dir.py:128,481): threads run along x
         float* vrow = a.vis + (long long)b * 1280 * S * S + (long long)y * S;
-        for (int i = tid; i < 1280 * S; i += 256) {
-            const int x = i % S, ch = i / S, bone = ch >> 6, c = ch & 63;
-            float acc = 0.f;
+        const int S4 = S / 4;
+        for (int i = tid; i < 1280 * S4; i += 256) {
+            const int x4 = (i % S4) * 4, ch = i / S4, bone = ch >> 6, c = ch & 63;
+            float out4[4];
 #pragma unroll
-            for (int hand = 0; hand < 2; ++hand) {
+            for (int q = 0; q < 4; ++q) {
+                float acc = 0.f;
+#pragma unroll
+                for (int hand = 0; hand < 2; ++hand) {
 #pragma clang fp contract(off)
-                const int xhb = x * 40 + hand * 20 + bone;
-                const float wa = s_wa[xhb], wb = s_wb[xhb];
-                const float v = (s_in[xhb] == 0) ? 0.f
-                                           : s_emb[(hand * 21 + kParent[bone]) * 64 + c] * wa +
-                                                 s_emb[(hand * 21 + kChild[bone]) * 64 + c] * wb;
-                acc = hand == 0 ? v : acc + v;
+                    const int xhb = (x4 + q) * 40 + hand * 20 + bone;
+                    const float wa = s_wa[xhb], wb = s_wb[xhb];
+                    const float v = (s_in[xhb] == 0) ? 0.f
+                                                     : s_emb[(hand * 21 + kParent[bone]) * 64 + c] * wa +
+                                                           s_emb[(hand * 21 + kChild[bone]) * 64 + c] * wb;
+                    acc = hand == 0 ? v : acc + v;
+                }
+                out4[q] = acc;
             }
-            vrow[(long long)ch * S * S + x] = acc;
+            Vec<float>::store(vrow + (long long)ch * S * S + x4, out4);
         }
     }
 }
@@ -284,8 +372,9 @@ extern "C" int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int
 
 extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
     DIR_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "dir_maxpool3x3s2: bad args");
+    DIR_REQUIRE(C % 8 == 0, "dir_maxpool3x3s2: C must be a multiple of 8 (16-byte channel vectors)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long long n = (long long)B * Ho * Wo * C;
+    const long long n = (long long)B * Ho * Wo * (C / 4);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) hipLaunchKernelGGL((maxpool_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
     else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((maxpool_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
@@ -297,7 +386,8 @@ extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int
                                        int out_coff, int dtype, void* stream) {
     DIR_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "dir_upsample2x_bilinear: bad args");
     const int ocs = out_cstride ? out_cstride : C;
-    const long long n = (long long)B * 4 * H * W * C;
+    DIR_REQUIRE(C % 8 == 0 && ocs % 8 == 0 && out_coff % 8 == 0, "dir_upsample2x_bilinear: channel counts/offsets must be multiples of 8");
+    const long long n = (long long)B * 4 * H * W * (C / 4);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) hipLaunchKernelGGL((upsample_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
     else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((upsample_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
@@ -315,9 +405,10 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
     a.offset = offset; a.HW = HW; a.C = C; a.Ch = Ch;
     const size_t lds = (size_t)(2 * HW + 3 * C) * sizeof(float);
     DIR_REQUIRE(lds <= 60000, "dir_init_head_forward: feature too large for LDS");
+    DIR_REQUIRE(C % 64 == 0 && Ch % 8 == 0 && (2 * HW) % 4 == 0 && p->mano_wt, "dir_init_head_forward: need C % 64 == 0, Ch % 8 == 0");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((init_head_kernel<float>), dim3(B), dim3(256), lds, s, a);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((init_head_kernel<bf16_t>), dim3(B), dim3(256), lds, s, a);
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((init_head_kernel<float>), dim3(B), dim3(512), lds, s, a);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((init_head_kernel<bf16_t>), dim3(B), dim3(512), lds, s, a);
     else DIR_REQUIRE(false, "dir_init_head_forward: bad dtype");
     return dir::check_launch("dir_init_head_forward");
 }
@@ -325,7 +416,7 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
 extern "C" int dir_bone_proj_forward(const float* uv_left, const float* uv_right, const float* emb, void* out,
                                      float* vis_nchw, int B, int S, float distance, int dtype, void* stream) {
     DIR_REQUIRE(uv_left && uv_right && emb && out, "dir_bone_proj_forward: null pointer");
-    DIR_REQUIRE(B > 0 && S > 0 && S <= 64, "dir_bone_proj_forward: bad shape");
+    DIR_REQUIRE(B > 0 && S > 0 && S <= 64 && S % 4 == 0, "dir_bone_proj_forward: bad shape (S must be a multiple of 4, <= 64)");
     BoneArgs a;
     a.uv[0] = uv_left; a.uv[1] = uv_right; a.emb = emb; a.out = out; a.vis = vis_nchw; a.B = B; a.S = S;
     a.distance = distance;

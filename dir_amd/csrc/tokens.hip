@@ -44,16 +44,21 @@ struct GridArgs {
 template <int K1>
 __device__ __forceinline__ void token_mlp128(const float* s_in, const dir_token_mlp& m, float* s_hid, float (&acc)[11],
                                              int o, int g) {
+    constexpr int U = (K1 >= 16) ? 16 : K1;        // weight loads kept in flight (the loop is L2-latency bound)
     float h[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) h[t] = 0.f;
-    for (int k = 0; k < K1; ++k) {
-        const float w = m.w1t[k * 128 + o];
+    for (int k0 = 0; k0 < K1; k0 += U) {
+        float w[U];
 #pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            const int j = g + 2 * t;
-            if (j < NJ) h[t] = fmaf(w, s_in[j * K1 + k], h[t]);
-        }
+        for (int u = 0; u < U; ++u) w[u] = m.w1t[(k0 + u) * 128 + o];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                const int j = g + 2 * t;
+                if (j < NJ) h[t] = fmaf(w[u], s_in[j * K1 + k0 + u], h[t]);
+            }
     }
     const float s1 = m.s1[o], b1 = m.b1[o];
 #pragma unroll
@@ -65,13 +70,17 @@ __device__ __forceinline__ void token_mlp128(const float* s_in, const dir_token_
     float a2[11];
 #pragma unroll
     for (int t = 0; t < 11; ++t) a2[t] = 0.f;
-    for (int k = 0; k < 128; ++k) {
-        const float w = m.w2t[k * 128 + o];
+    for (int k0 = 0; k0 < 128; k0 += 16) {
+        float w[16];
 #pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            const int j = g + 2 * t;
-            if (j < NJ) a2[t] = fmaf(w, s_hid[j * 128 + k], a2[t]);
-        }
+        for (int u = 0; u < 16; ++u) w[u] = m.w2t[(k0 + u) * 128 + o];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                const int j = g + 2 * t;
+                if (j < NJ) a2[t] = fmaf(w[u], s_hid[j * 128 + k0 + u], a2[t]);
+            }
     }
     const float b2 = m.b2[o];
 #pragma unroll
@@ -148,13 +157,13 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------- P-GCN
-struct PgcnArgs {
+struct PgcnHand {
     const float* W; const float* x_in;          // layer weights [2][21][128][128]; x_in [B][21][128] (layer 0 only)
     const float* h_prev;                        // [B][21][256] = (h0 | h1) of the previous layer (layers >= 1)
     const float* e1_prev; const float* bias_prev; const float* bns_prev; const float* bnb_prev; int relu_prev;
     float* h_out;                               // [B][21][256]
-    int B;
 };
+struct PgcnArgs { PgcnHand h[2]; int B; int nchunk; };
 
 __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (&w)[5], int (&idx)[5], int& deg) {
     // row j of softmax(A_1) where A_1 = -9e15 off the skeleton edges (SemGCN/p_graph_conv.py:43-50)
@@ -167,71 +176,80 @@ __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (
     for (int t = 0; t < deg; ++t) w[t] /= sum;
 }
 
-// grid (21 nodes, 2 slices of 64 output columns).  256 threads: o = tid & 63, bg = tid >> 6 (16 samples each).
-__global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs a) {
-    __shared__ float s_x[64 * 128];
+constexpr int PG_BC = 16;   // samples per workgroup
+
+// grid (21 nodes, 2 slices of 64 output columns, hands x batch chunks).  256 threads: o = tid & 63, bg = tid >> 6
+// (4 samples each).  The 2 x 128x64 weight slice is read coalesced along the output column, 8 k-rows in flight.
+__global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
+    __shared__ __attribute__((aligned(16))) float s_x[PG_BC * 128];
     const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
+    const int hand = blockIdx.z / args.nchunk, chunk = blockIdx.z - hand * args.nchunk;
+    const PgcnHand& a = args.h[hand];
     const int o = slice * 64 + (tid & 63), bg = tid >> 6;
+    const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
     float wgt[5]; int nidx[5]; int deg = 0;
     if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
     const float* W0 = a.W + ((long long)j * 128) * 128 + o;
     const float* W1 = a.W + ((long long)(NJ + j) * 128) * 128 + o;
-    for (int b0 = 0; b0 < a.B; b0 += 64) {
-        const int nb = min(64, a.B - b0);
-        // ---- stage this node's input rows for 64 samples; layers >= 1 finish the previous layer here
-        for (int i = tid; i < 64 * 128; i += 256) {
-            const int bb = i >> 7, k = i & 127;
-            float v = 0.f;
-            if (bb < nb) {
-                const long long b = b0 + bb;
-                if (!a.h_prev) v = a.x_in[(b * NJ + j) * 128 + k];
-                else {
-                    const float* hb = a.h_prev + b * NJ * 256;
-                    float acc = 0.f;
-                    for (int t = 0; t < deg; ++t) acc = fmaf(wgt[t], hb[nidx[t] * 256 + 128 + k], acc);
-                    v = hb[j * 256 + k] + acc + a.bias_prev[k];                     // output_0 + output_1 + bias
-                    v = fmaf(v, a.bns_prev[k], a.bnb_prev[k]);                      // BN1d (eval)
-                    if (a.relu_prev) v = fmaxf(v, 0.f);
-                }
-            }
-            s_x[i] = v;
-        }
-        __syncthreads();
-        float a0[16], a1[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
-        for (int k = 0; k < 128; k += 4) {
-            float w0[4], w1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { w0[q] = W0[(k + q) * 128]; w1[q] = W1[(k + q) * 128]; }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float4 xv = *reinterpret_cast<const float4*>(s_x + (bg * 16 + t) * 128 + k);
-                a0[t] = fmaf(xv.x, w0[0], a0[t]); a0[t] = fmaf(xv.y, w0[1], a0[t]);
-                a0[t] = fmaf(xv.z, w0[2], a0[t]); a0[t] = fmaf(xv.w, w0[3], a0[t]);
-                a1[t] = fmaf(xv.x, w1[0], a1[t]); a1[t] = fmaf(xv.y, w1[1], a1[t]);
-                a1[t] = fmaf(xv.z, w1[2], a1[t]); a1[t] = fmaf(xv.w, w1[3], a1[t]);
+    // ---- stage this node's input rows; layers >= 1 finish the previous layer here (mix + bias + BN + ReLU)
+    for (int i = tid; i < PG_BC * 128; i += 256) {
+        const int bb = i >> 7, k = i & 127;
+        float v = 0.f;
+        if (bb < nb) {
+            const long long b = b0 + bb;
+            if (!a.h_prev) v = a.x_in[(b * NJ + j) * 128 + k];
+            else {
+                const float* hb = a.h_prev + b * NJ * 256;
+                float acc = 0.f;
+                for (int t = 0; t < deg; ++t) acc = fmaf(wgt[t], hb[nidx[t] * 256 + 128 + k], acc);
+                v = hb[j * 256 + k] + acc + a.bias_prev[k];                     // output_0 + output_1 + bias
+                v = fmaf(v, a.bns_prev[k], a.bnb_prev[k]);                      // BN1d (eval)
+                if (a.relu_prev) v = fmaxf(v, 0.f);
             }
         }
+        s_x[i] = v;
+    }
+    __syncthreads();
+    float a0[4], a1[4];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int bb = bg * 16 + t;
-            if (bb < nb) {
-                float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
-                hb[o] = a0[t];
-                hb[128 + o] = a1[t];
-            }
+    for (int t = 0; t < 4; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+    for (int k = 0; k < 128; k += 8) {
+        float w0[8], w1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { w0[q] = W0[(k + q) * 128]; w1[q] = W1[(k + q) * 128]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 xa = *reinterpret_cast<const float4*>(s_x + (bg * 4 + t) * 128 + k);
+            const float4 xb = *reinterpret_cast<const float4*>(s_x + (bg * 4 + t) * 128 + k + 4);
+            a0[t] = fmaf(xa.x, w0[0], a0[t]); a0[t] = fmaf(xa.y, w0[1], a0[t]);
+            a0[t] = fmaf(xa.z, w0[2], a0[t]); a0[t] = fmaf(xa.w, w0[3], a0[t]);
+            a0[t] = fmaf(xb.x, w0[4], a0[t]); a0[t] = fmaf(xb.y, w0[5], a0[t]);
+            a0[t] = fmaf(xb.z, w0[6], a0[t]); a0[t] = fmaf(xb.w, w0[7], a0[t]);
+            a1[t] = fmaf(xa.x, w1[0], a1[t]); a1[t] = fmaf(xa.y, w1[1], a1[t]);
+            a1[t] = fmaf(xa.z, w1[2], a1[t]); a1[t] = fmaf(xa.w, w1[3], a1[t]);
+            a1[t] = fmaf(xb.x, w1[4], a1[t]); a1[t] = fmaf(xb.y, w1[5], a1[t]);
+            a1[t] = fmaf(xb.z, w1[6], a1[t]); a1[t] = fmaf(xb.w, w1[7], a1[t]);
         }
-        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int bb = bg * 4 + t;
+        if (bb < nb) {
+            float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
+            hb[o] = a0[t];
+            hb[128 + o] = a1[t];
+        }
     }
 }
 
-struct MixArgs {
+struct MixHand {
     const float* h; const float* e1; const float* bias; const float* bns; const float* bnb;
-    const float* add; float* out; long long out_bstride; int B; int relu;
+    const float* add; float* out; int relu;
 };
-// finishes the last layer: out[b][j][:] = relu(bn(h0 + A1 h1 + bias)) (+ add)
-__global__ __launch_bounds__(128) void pgcn_mix_kernel(MixArgs a) {
+struct MixArgs { MixHand h[2]; long long out_bstride; };
+// finishes the last layer: out[b][j][:] = relu(bn(h0 + A1 h1 + bias)) (+ add).  grid (B, 21, hands)
+__global__ __launch_bounds__(128) void pgcn_mix_kernel(MixArgs args) {
+    const MixHand& a = args.h[blockIdx.z];
     const int b = blockIdx.x, j = blockIdx.y, k = threadIdx.x;
     float wgt[5]; int nidx[5]; int deg;
     edge_softmax_row(a.e1, j, wgt, nidx, deg);
@@ -242,7 +260,7 @@ __global__ __launch_bounds__(128) void pgcn_mix_kernel(MixArgs a) {
     v = fmaf(v, a.bns[k], a.bnb[k]);
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.add) v += a.add[((long long)b * NJ + j) * 128 + k];
-    a.out[(long long)b * a.out_bstride + j * 128 + k] = v;
+    a.out[(long long)b * args.out_bstride + j * 128 + k] = v;
 }
 
 // --------------------------------------------------------------------------------------------- regressor
@@ -252,70 +270,85 @@ struct RegArgs {
     float* para[2]; float* off; float* emb;
 };
 
-__global__ __launch_bounds__(256) void regress_kernel(RegArgs a) {
-    __shared__ float s_tok[42 * 64];
+// one 512-thread workgroup per sample
+__global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
+    __shared__ float s_in[2][1408];        // per hand: 21*64 token features | previous mano_para (models/dir.py:344-345)
     __shared__ float s_hid[42 * 64];
-    __shared__ float s_para[2 * 64];
-    __shared__ float s_off[3];
+    __shared__ float s_part[4][128];
+    __shared__ float s_off[3], s_red[8][3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 42 * 64; i += 256) s_tok[i] = a.tok[(long long)b * 42 * 64 + i];
-    if (tid < 128) s_para[tid] = a.prev_para[tid >> 6][(long long)b * 64 + (tid & 63)];
+    for (int i = tid; i < 42 * 64; i += 512) {
+        const int hand = i / 1344;
+        s_in[hand][i - hand * 1344] = a.tok[(long long)b * 42 * 64 + i];
+    }
+    if (tid < 128) s_in[tid >> 6][1344 + (tid & 63)] = a.prev_para[tid >> 6][(long long)b * 64 + (tid & 63)];
     if (tid >= 128 && tid < 131) s_off[tid - 128] = a.prev_off[(long long)b * 3 + tid - 128];
     __syncthreads();
-    // Linear(1408 -> 64) x 2 and Linear(2691 -> 3) (models/dir.py:342-351); token flatten is joint-major j*64+c
-    for (int o = wave; o < 131; o += 4) {
+    {   // Linear(1408 -> 64) x 2 (models/dir.py:350-351): thread = (output o of 128, K quarter), weights k-major
+        const int o = tid & 127, ks = tid >> 7;
+        const float* in = s_in[o >> 6] + ks * 352;
+        const float* w = a.p.mano_wt + (long long)(ks * 352) * 128 + o;
         float acc = 0.f;
-        if (o < 128) {
-            const int s = o >> 6, oo = o & 63;
-            const float* w = a.p.mano_w[s] + (long long)oo * 1408;
-            const float* t = s_tok + s * 1344;
-            for (int k = lane; k < 1344; k += 64) acc = fmaf(t[k], w[k], acc);
-            acc = fmaf(s_para[s * 64 + lane], w[1344 + lane], acc);
-            acc = dir::wave_sum(acc);
-            if (lane == 0) a.para[s][(long long)b * 64 + oo] = acc + a.p.mano_b[s][oo];
-        } else {
-            const int oo = o - 128;
-            const float* w = a.p.off_w + (long long)oo * 2691;
-            for (int k = lane; k < 2688; k += 64) acc = fmaf(s_tok[k], w[k], acc);
-            if (lane < 3) acc = fmaf(s_off[lane], w[2688 + lane], acc);
-            acc = dir::wave_sum(acc);
-            if (lane == 0) a.off[(long long)b * 3 + oo] = acc + a.p.off_b[oo];
+        for (int k0 = 0; k0 < 352; k0 += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w[(k0 + u) * 128];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = fmaf(in[k0 + u], wv[u], acc);
         }
+        s_part[ks][o] = acc;
+    }
+    {   // Linear(2691 -> 3) (models/dir.py:347-348) over cat(tokL, tokR, prev_offset)
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (int k = tid; k < 2688; k += 512) {
+            const float x = k < 1344 ? s_in[0][k] : s_in[1][k - 1344];
+            p0 = fmaf(x, a.p.off_w[k], p0); p1 = fmaf(x, a.p.off_w[2691 + k], p1); p2 = fmaf(x, a.p.off_w[2 * 2691 + k], p2);
+        }
+        p0 = dir::wave_sum(p0); p1 = dir::wave_sum(p1); p2 = dir::wave_sum(p2);
+        if (lane == 0) { s_red[wave][0] = p0; s_red[wave][1] = p1; s_red[wave][2] = p2; }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int s = tid >> 6, oo = tid & 63;
+        a.para[s][(long long)b * 64 + oo] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + a.p.mano_b[s][oo];
+    } else if (tid < 131) {
+        const int oo = tid - 128;
+        float acc = 0.f;
+        for (int w8 = 0; w8 < 8; ++w8) acc += s_red[w8][oo];
+        for (int q = 0; q < 3; ++q) acc = fmaf(s_off[q], a.p.off_w[oo * 2691 + 2688 + q], acc);
+        a.off[(long long)b * 3 + oo] = acc + a.p.off_b[oo];
     }
     // proj_feat_emb: Conv1d(64,64,1) -> BN -> ReLU -> Conv1d(64,64,1) on every token (models/dir.py:51-56,118-119)
     const dir_token_mlp& m = a.p.emb;
-    const int o = tid & 63, g = tid >> 6;
-    float h[11];
+    const int o = tid & 63, g = tid >> 6;            // 8 token groups: tokens g, g+8, ...
+    float h[6];
+    float wv[64];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) h[t] = 0.f;
-    for (int k = 0; k < 64; ++k) {
-        const float w = m.w1t[k * 64 + o];
+    for (int k = 0; k < 64; ++k) wv[k] = m.w1t[k * 64 + o];
 #pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            const int j = g + 4 * t;
-            if (j < 42) h[t] = fmaf(w, s_tok[j * 64 + k], h[t]);
+    for (int t = 0; t < 6; ++t) {
+        const int j = g + 8 * t;
+        float acc = 0.f;
+        if (j < 42) {
+            const float* x = (j < 21) ? s_in[0] + j * 64 : s_in[1] + (j - 21) * 64;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc = fmaf(wv[k], x[k], acc);
+            s_hid[j * 64 + o] = fmaxf(fmaf(acc, m.s1[o], m.b1[o]), 0.f);
         }
-    }
-#pragma unroll
-    for (int t = 0; t < 11; ++t) {
-        const int j = g + 4 * t;
-        if (j < 42) s_hid[j * 64 + o] = fmaxf(fmaf(h[t], m.s1[o], m.b1[o]), 0.f);
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 11; ++t) h[t] = 0.f;
-    for (int k = 0; k < 64; ++k) {
-        const float w = m.w2t[k * 64 + o];
+    for (int k = 0; k < 64; ++k) wv[k] = m.w2t[k * 64 + o];
 #pragma unroll
-        for (int t = 0; t < 11; ++t) {
-            const int j = g + 4 * t;
-            if (j < 42) h[t] = fmaf(w, s_hid[j * 64 + k], h[t]);
+    for (int t = 0; t < 6; ++t) {
+        const int j = g + 8 * t;
+        if (j < 42) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) acc = fmaf(wv[k], s_hid[j * 64 + k], acc);
+            h[t] = acc;
+            a.emb[((long long)b * 42 + j) * 64 + o] = h[t] + m.b2[o];
         }
-    }
-#pragma unroll
-    for (int t = 0; t < 11; ++t) {
-        const int j = g + 4 * t;
-        if (j < 42) a.emb[((long long)b * 42 + j) * 64 + o] = h[t] + m.b2[o];
     }
 }
 
@@ -345,27 +378,63 @@ extern "C" int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, 
     return dir::check_launch("dir_grid_tokens_forward");
 }
 
+static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers, const float* const* x,
+                    const float* const* add, float* const* out, long long out_bstride, float* const* scratch, int B,
+                    hipStream_t s) {
+    DIR_REQUIRE(num_layers >= 1 && B > 0 && out_bstride >= NJ * 128, "dir_pgcn_stack_forward: bad arguments");
+    const int nchunk = (B + PG_BC - 1) / PG_BC;
+    for (int l = 0; l < num_layers; ++l) {
+        PgcnArgs a;
+        a.B = B; a.nchunk = nchunk;
+        for (int h = 0; h < 2; ++h) {
+            const int hh = h < nh ? h : 0;
+            const dir_pgcn_layer& L = layers[hh][l];
+            DIR_REQUIRE(L.W && L.e1 && L.bias && L.bn_scale && L.bn_shift, "dir_pgcn_stack_forward: null layer parameter");
+            float* hbuf[2] = {scratch[hh], scratch[hh] + (long long)B * NJ * 256};
+            PgcnHand& g = a.h[h];
+            g.W = L.W; g.x_in = x[hh]; g.h_prev = l ? hbuf[(l - 1) & 1] : nullptr;
+            g.e1_prev = l ? layers[hh][l - 1].e1 : nullptr; g.bias_prev = l ? layers[hh][l - 1].bias : nullptr;
+            g.bns_prev = l ? layers[hh][l - 1].bn_scale : nullptr; g.bnb_prev = l ? layers[hh][l - 1].bn_shift : nullptr;
+            g.relu_prev = l ? layers[hh][l - 1].relu : 0;
+            g.h_out = hbuf[l & 1];
+        }
+        hipLaunchKernelGGL(pgcn_layer_kernel, dim3(NJ, 2, nh * nchunk), dim3(256), 0, s, a);
+    }
+    MixArgs m;
+    m.out_bstride = out_bstride;
+    for (int h = 0; h < 2; ++h) {
+        const int hh = h < nh ? h : 0;
+        const dir_pgcn_layer& L = layers[hh][num_layers - 1];
+        float* hb = scratch[hh] + (((num_layers - 1) & 1) ? (long long)B * NJ * 256 : 0);
+        m.h[h] = MixHand{hb, L.e1, L.bias, L.bn_scale, L.bn_shift, add ? add[hh] : nullptr, out[hh], L.relu};
+    }
+    hipLaunchKernelGGL(pgcn_mix_kernel, dim3(B, NJ, nh), dim3(128), 0, s, m);
+    return dir::check_launch("dir_pgcn_stack_forward");
+}
+
 extern "C" int dir_pgcn_stack_forward(const dir_pgcn_layer* layers, int num_layers, const float* x, const float* add,
                                       float* out, long long out_bstride, float* scratch, int B, void* stream) {
     DIR_REQUIRE(layers && x && out && scratch, "dir_pgcn_stack_forward: null pointer");
-    DIR_REQUIRE(num_layers >= 1 && B > 0 && out_bstride >= NJ * 128, "dir_pgcn_stack_forward: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    float* hbuf[2] = {scratch, scratch + (long long)B * NJ * 256};
-    for (int l = 0; l < num_layers; ++l) {
-        const dir_pgcn_layer& L = layers[l];
-        DIR_REQUIRE(L.W && L.e1 && L.bias && L.bn_scale && L.bn_shift, "dir_pgcn_stack_forward: null layer parameter");
-        PgcnArgs a;
-        a.W = L.W; a.x_in = x; a.h_prev = l ? hbuf[(l - 1) & 1] : nullptr;
-        a.e1_prev = l ? layers[l - 1].e1 : nullptr; a.bias_prev = l ? layers[l - 1].bias : nullptr;
-        a.bns_prev = l ? layers[l - 1].bn_scale : nullptr; a.bnb_prev = l ? layers[l - 1].bn_shift : nullptr;
-        a.relu_prev = l ? layers[l - 1].relu : 0;
-        a.h_out = hbuf[l & 1]; a.B = B;
-        hipLaunchKernelGGL(pgcn_layer_kernel, dim3(NJ, 2), dim3(256), 0, s, a);
-    }
-    const dir_pgcn_layer& L = layers[num_layers - 1];
-    MixArgs m{hbuf[(num_layers - 1) & 1], L.e1, L.bias, L.bn_scale, L.bn_shift, add, out, out_bstride, B, L.relu};
-    hipLaunchKernelGGL(pgcn_mix_kernel, dim3(B, NJ), dim3(128), 0, s, m);
-    return dir::check_launch("dir_pgcn_stack_forward");
+    const dir_pgcn_layer* lp[1] = {layers};
+    const float* xp[1] = {x};
+    const float* ap[1] = {add};
+    float* op[1] = {out};
+    float* sp[1] = {scratch};
+    return pgcn_run(lp, 1, num_layers, xp, add ? ap : nullptr, op, out_bstride, sp, B, (hipStream_t)stream);
+}
+
+extern "C" int dir_pgcn_stack_forward_pair(const dir_pgcn_layer* layers_left, const dir_pgcn_layer* layers_right,
+                                           int num_layers, const float* x_lr, const float* add_lr, float* tokens,
+                                           float* scratch, int B, void* stream) {
+    DIR_REQUIRE(layers_left && layers_right && x_lr && tokens && scratch, "dir_pgcn_stack_forward_pair: null pointer");
+    DIR_REQUIRE(B > 0, "dir_pgcn_stack_forward_pair: bad B");
+    const long long hs = (long long)B * NJ * 128;
+    const dir_pgcn_layer* lp[2] = {layers_left, layers_right};
+    const float* xp[2] = {x_lr, x_lr + hs};
+    const float* ap[2] = {add_lr, add_lr ? add_lr + hs : nullptr};
+    float* op[2] = {tokens, tokens + NJ * 128};
+    float* sp[2] = {scratch, scratch + 2 * (long long)B * NJ * 256};
+    return pgcn_run(lp, 2, num_layers, xp, add_lr ? ap : nullptr, op, 42 * 128, sp, B, (hipStream_t)stream);
 }
 
 extern "C" int dir_regress_forward(const dir_regress_params* p, const float* tok, const float* prev_para_left,
@@ -373,11 +442,11 @@ extern "C" int dir_regress_forward(const dir_regress_params* p, const float* tok
                                    float* para_right, float* offset, float* emb, int B, void* stream) {
     DIR_REQUIRE(p && tok && prev_para_left && prev_para_right && prev_offset && para_left && para_right && offset && emb,
                 "dir_regress_forward: null pointer");
-    DIR_REQUIRE(B > 0 && p->mano_w[0] && p->mano_w[1] && p->mano_b[0] && p->mano_b[1] && p->off_w && p->off_b &&
-                    mlp_ok(p->emb), "dir_regress_forward: bad arguments");
+    DIR_REQUIRE(B > 0 && p->mano_wt && p->mano_b[0] && p->mano_b[1] && p->off_w && p->off_b && mlp_ok(p->emb),
+                "dir_regress_forward: bad arguments");
     RegArgs a;
     a.p = *p; a.tok = tok; a.prev_para[0] = prev_para_left; a.prev_para[1] = prev_para_right; a.prev_off = prev_offset;
     a.para[0] = para_left; a.para[1] = para_right; a.off = offset; a.emb = emb;
-    hipLaunchKernelGGL(regress_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(regress_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, a);
     return dir::check_launch("dir_regress_forward");
 }

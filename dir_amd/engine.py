@@ -126,10 +126,17 @@ def pack_ste(sd, prefix, keep, depth=4):
     return P
 
 
+def _pad_rows(t, width=2336):
+    """[K, 2334] -> contiguous [K, 2336] (zero padded): 16-byte aligned rows for the MANO kernel's float4 reads"""
+    out = torch.zeros(t.shape[0], width, device=t.device, dtype=torch.float32)
+    out[:, :t.shape[1]] = t
+    return out
+
+
 def pack_mano(sd, prefix, side, center_idx, keep):
     f = lambda k: sd[prefix + '.' + k].float()  # noqa: E731
-    t = dict(shapedirs_t=f('th_shapedirs').reshape(2334, 10).t().contiguous(),
-             posedirs_t=f('th_posedirs').reshape(2334, 135).t().contiguous(),
+    t = dict(shapedirs_t=_pad_rows(f('th_shapedirs').reshape(2334, 10).t()),
+             posedirs_t=_pad_rows(f('th_posedirs').reshape(2334, 135).t()),
              v_template=f('th_v_template').reshape(2334).contiguous(), j_regressor=f('th_J_regressor').contiguous(),
              weights=f('th_weights').contiguous(), hands_mean=f('th_hands_mean').reshape(45).contiguous(),
              comps=f('th_selected_comps').contiguous())
@@ -240,14 +247,14 @@ class StageOp(object):
         self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep), pack_pgcn(sd, p + '.gcn_right', keep))
         self.ste = pack_ste(sd, p + '.interaction', keep)
         R = _capi.RegressParams()
-        t = dict(wl=sd[p + '.regressor.mano_left.weight'].float().contiguous(),
-                 wr=sd[p + '.regressor.mano_right.weight'].float().contiguous(),
+        t = dict(wt=torch.cat([sd[p + '.regressor.mano_left.weight'].float().t(),
+                               sd[p + '.regressor.mano_right.weight'].float().t()], 1).contiguous(),     # [1408][128]
                  bl=sd[p + '.regressor.mano_left.bias'].float().contiguous(),
                  br=sd[p + '.regressor.mano_right.bias'].float().contiguous(),
                  wo=sd[p + '.regressor.offset.weight'].float().contiguous(),
                  bo=sd[p + '.regressor.offset.bias'].float().contiguous())
         keep.append(t)
-        R.mano_w[0], R.mano_w[1], R.mano_b[0], R.mano_b[1] = (t[k].data_ptr() for k in ('wl', 'wr', 'bl', 'br'))
+        R.mano_wt, R.mano_b[0], R.mano_b[1] = (t[k].data_ptr() for k in ('wt', 'bl', 'br'))
         R.off_w, R.off_b = t['wo'].data_ptr(), t['bo'].data_ptr()
         R.emb = pack_token_mlp(sd, p + '.proj_feat_emb', keep)
         self.reg = R
@@ -258,18 +265,21 @@ class StageOp(object):
         self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
 
 
-def run_mano(tables, para, B, want_uv=True):
-    """MANO + projection straight out of the 64-wide parameter vector (models/dir.py:272-280)."""
-    dev = para.device
-    verts = torch.empty(B, 778, 3, device=dev, dtype=F32)
-    joints = torch.empty(B, 21, 3, device=dev, dtype=F32)
-    juv = torch.empty(B, 21, 2, device=dev, dtype=F32) if want_uv else None
-    base = para.data_ptr()
-    rc = _capi.lib().dir_mano_forward(tables, C.c_void_p(base), 64, C.c_void_p(base + 51 * 4), 64,
-                                      C.c_void_p(base + 61 * 4), 64, _capi.ptr(verts), _capi.ptr(joints),
-                                      _capi.ptr(juv), None, None, B, _capi.stream_ptr())
-    _capi.check(rc, 'dir_mano_forward')
-    return verts, joints, juv
+def run_mano_pair(tables_lr, para_l, para_r, B):
+    """MANO + projection for both hands in one launch, straight out of the 64-wide parameter vectors
+    (pose = para[:, :51], betas = para[:, 51:61], cam = para[:, 61:64]; models/dir.py:272-280)."""
+    dev = para_l.device
+    out = [[torch.empty(B, 778, 3, device=dev, dtype=F32), torch.empty(B, 21, 3, device=dev, dtype=F32),
+            torch.empty(B, 21, 2, device=dev, dtype=F32)] for _ in range(2)]
+    P2 = C.c_void_p * 2
+    base = (para_l.data_ptr(), para_r.data_ptr())
+    tabs = (_capi.ManoTables * 2)(tables_lr[0], tables_lr[1])
+    rc = _capi.lib().dir_mano_forward_pair(
+        tabs, P2(base[0], base[1]), 64, P2(base[0] + 51 * 4, base[1] + 51 * 4), 64, P2(base[0] + 61 * 4, base[1] + 61 * 4), 64,
+        P2(out[0][0].data_ptr(), out[1][0].data_ptr()), P2(out[0][1].data_ptr(), out[1][1].data_ptr()),
+        P2(out[0][2].data_ptr(), out[1][2].data_ptr()), B, _capi.stream_ptr())
+    _capi.check(rc, 'dir_mano_forward_pair')
+    return out
 
 
 class DirEngine(object):
@@ -297,9 +307,11 @@ class DirEngine(object):
             t['aw%d' % i] = sd[a + '.3.weight'].float().reshape(-1).contiguous()
             H.attn_w[i] = t['aw%d' % i].data_ptr()
             H.attn_b[i] = float(sd[a + '.3.bias'].float().item())
-            t['mw%d' % i] = sd['%s.mano_%s.weight' % (p, side)].float().contiguous()
             t['mb%d' % i] = sd['%s.mano_%s.bias' % (p, side)].float().contiguous()
-            H.mano_w[i], H.mano_b[i] = t['mw%d' % i].data_ptr(), t['mb%d' % i].data_ptr()
+            H.mano_b[i] = t['mb%d' % i].data_ptr()
+        t['mwt'] = torch.cat([sd[p + '.mano_left.weight'].float().t(), sd[p + '.mano_right.weight'].float().t()],
+                             1).contiguous()                               # [2048][128] k-major
+        H.mano_wt = t['mwt'].data_ptr()
         t['ow'], t['ob'] = sd[p + '.offset.weight'].float().contiguous(), sd[p + '.offset.bias'].float().contiguous()
         H.off_w, H.off_b = t['ow'].data_ptr(), t['ob'].data_ptr()
         keep.append(t)
@@ -336,8 +348,7 @@ class DirEngine(object):
 
     def mano_outputs(self, tables, para_l, para_r, off):
         B = para_l.shape[0]
-        vl, jl, uvl = run_mano(tables[0], para_l, B)
-        vr, jr, uvr = run_mano(tables[1], para_r, B)
+        (vl, jl, uvl), (vr, jr, uvr) = run_mano_pair(tables, para_l, para_r, B)
         return {'pd_offset': off, 'pd_mano_para_left': para_l, 'pd_mano_para_right': para_r,
                 'pd_proj_left': para_l[:, 61:64], 'pd_proj_right': para_r[:, 61:64],
                 'pd_mesh_xyz_left': vl, 'pd_mesh_xyz_right': vr, 'pd_joint_xyz_left': jl, 'pd_joint_xyz_right': jr,
@@ -357,11 +368,9 @@ class DirEngine(object):
             _capi.ptr(prev['pd_joint_xyz_right']), _capi.ptr(prev['pd_offset']), st.img2joint, st.pos_emb,
             C.byref(st.gpos), _capi.ptr(x0), _capi.ptr(gp), B, sp), 'dir_grid_tokens_forward')
         tok = torch.empty(B, 42, 128, device=dev, dtype=F32)
-        scratch = torch.empty(2, B, 21, 256, device=dev, dtype=F32)
-        for hand in range(2):
-            _capi.check(L.dir_pgcn_stack_forward(st.gcn[hand], 4, _capi.ptr(x0[hand]), _capi.ptr(gp[hand]),
-                                                 C.c_void_p(tok.data_ptr() + hand * 21 * 128 * 4), 42 * 128,
-                                                 _capi.ptr(scratch), B, sp), 'dir_pgcn_stack_forward')
+        scratch = torch.empty(4, B, 21, 256, device=dev, dtype=F32)
+        _capi.check(L.dir_pgcn_stack_forward_pair(st.gcn[0], st.gcn[1], 4, _capi.ptr(x0), _capi.ptr(gp), _capi.ptr(tok),
+                                                  _capi.ptr(scratch), B, sp), 'dir_pgcn_stack_forward_pair')
         y = torch.empty(B, 42, 64, device=dev, dtype=F32)
         _capi.check(L.dir_ste_forward(C.byref(st.ste), _capi.ptr(tok), None, _capi.ptr(y), B, sp), 'dir_ste_forward')
         para_l = torch.empty(B, 64, device=dev, dtype=F32)

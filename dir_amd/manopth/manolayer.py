@@ -17,6 +17,7 @@ import torch
 from torch.nn import Module
 
 from .. import _capi, synth
+from ..engine import _pad_rows
 
 
 class ManoLayer(Module):
@@ -53,8 +54,8 @@ class ManoLayer(Module):
             _capi.require_cuda(*bufs)
             f = _capi.f32c
             self._packed = dict(
-                shapedirs_t=f(self.th_shapedirs.reshape(2334, 10).t()),
-                posedirs_t=f(self.th_posedirs.reshape(2334, 135).t()),
+                shapedirs_t=_pad_rows(self.th_shapedirs.float().reshape(2334, 10).t()),
+                posedirs_t=_pad_rows(self.th_posedirs.float().reshape(2334, 135).t()),
                 v_template=f(self.th_v_template.reshape(2334)),
                 j_regressor=f(self.th_J_regressor), weights=f(self.th_weights),
                 hands_mean=f(self.th_hands_mean.reshape(45)), comps=f(self.th_selected_comps))

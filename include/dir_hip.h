@@ -44,8 +44,8 @@ int dir_device_info(char* arch_host, int arch_len, int* num_cu_host);
  * and utils/utils.py:47-63 (projection_batch_xy).
  *
  * Tables (float32, device).  Layouts are k-major so the blend-shape contractions read coalesced:
- *   shapedirs_t [10][2334]   = th_shapedirs[778,3,10]  transposed   (2334 = 778*3, index v*3+c)
- *   posedirs_t  [135][2334]  = th_posedirs[778,3,135]  transposed
+ *   shapedirs_t [10][2336]   = th_shapedirs[778,3,10]  transposed, rows zero-padded 2334 -> 2336 (index v*3+c)
+ *   posedirs_t  [135][2336]  = th_posedirs[778,3,135]  transposed, rows zero-padded (16-byte aligned rows)
  *   v_template  [2334]
  *   j_regressor [16][778]
  *   weights     [778][16]
@@ -75,6 +75,13 @@ int dir_mano_forward(const dir_mano_tables* tables_host, const float* pose, int 
                      const float* betas, int betas_stride, const float* cam, int cam_stride,
                      float* verts, float* joints, float* joint_uv, float* mesh_uv, int32_t* flags_out,
                      int B, void* stream);
+
+/* Both hands of one stage in ONE launch (grid = B x 2).  tables_lr[2] = {left, right}; the *_lr arguments are HOST
+ * arrays of two device pointers.  cam_lr / joint_uv_lr may be NULL. */
+int dir_mano_forward_pair(const dir_mano_tables* tables_lr_host, const float* const* pose_lr_host, int pose_stride,
+                          const float* const* betas_lr_host, int betas_stride, const float* const* cam_lr_host,
+                          int cam_stride, float* const* verts_lr_host, float* const* joints_lr_host,
+                          float* const* joint_uv_lr_host, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores
@@ -130,7 +137,7 @@ int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, 
 typedef struct dir_init_head_params {
     const float* attn_w[2]; /* [Ch]    attention_{left,right}.3.weight */
     float attn_b[2];        /*         attention_{left,right}.3.bias   */
-    const float* mano_w[2]; /* [64][C] mano_{left,right}.weight        */
+    const float* mano_wt;   /* [C][128] k-major: column o < 64 = mano_left.weight[o, :], o >= 64 = mano_right.weight[o-64, :] */
     const float* mano_b[2]; /* [64]                                    */
     const float* off_w;     /* [3][C]  offset.weight                   */
     const float* off_b;     /* [3]                                     */
@@ -192,6 +199,12 @@ typedef struct dir_pgcn_layer {
 int dir_pgcn_stack_forward(const dir_pgcn_layer* layers_host, int num_layers, const float* x, const float* add,
                            float* out, long long out_bstride, float* scratch, int B, void* stream);
 
+/* both hands in one launch sequence: x_lr / add_lr [2][B][21][128] (hand 0 = left), tokens [B][42][128] (left tokens
+ * 0..20, right 21..41), scratch 4*B*21*256 floats. */
+int dir_pgcn_stack_forward_pair(const dir_pgcn_layer* layers_left_host, const dir_pgcn_layer* layers_right_host,
+                                int num_layers, const float* x_lr, const float* add_lr, float* tokens, float* scratch,
+                                int B, void* stream);
+
 /* a6: STE.forward (transformer/mixSTE.py:194-205) on [B,42,128] -> [B,42,64]; weights k-major ([in][out]). */
 typedef struct dir_ste_block {
     const float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc1_wt, *fc1_b, *fc2_wt, *fc2_b;
@@ -211,7 +224,8 @@ int dir_ste_forward(const dir_ste_params* params_host, const float* x, float* x_
  * para_* [B,64] = Linear(cat(tok_hand.flatten(), prev_para)), offset [B,3] = Linear(cat(tokL, tokR, prev_offset)),
  * emb [B,42,64] = proj_feat_emb(tok). */
 typedef struct dir_regress_params {
-    const float* mano_w[2]; /* [64][1408] regressor.mano_{left,right}.weight */
+    const float* mano_wt;   /* [1408][128] k-major: column o < 64 = regressor.mano_left.weight[o, :],
+                               o >= 64 = regressor.mano_right.weight[o - 64, :]                       */
     const float* mano_b[2]; /* [64]                                          */
     const float* off_w;     /* [3][2691]  regressor.offset.weight            */
     const float* off_b;     /* [3]                                           */
