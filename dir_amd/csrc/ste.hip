@@ -3,16 +3,20 @@
 //   x += pos_embed ; for blocks 1..depth-1 (block 0 is never executed by the reference):
 //       x += proj(softmax(q k^T * 32^-0.5) v) ; x += fc2(gelu_erf(fc1(LN(x)))) ; x = spatial_norm(x)
 //   y = Linear(LN_1e-5(x)).
-// All activations ([42][128] residual stream, [42][384] qkv / [42][256] MLP hidden, 4 x [42][42] attention
-// probabilities) stay in LDS (~136 KB of the CU's 160 KB); LayerNorm and softmax reduce with wavefront shuffles
-// (one wave per token / per attention row); weights are read k-major (coalesced along the output column) from L2.
-// fp32 throughout (feeds MANO; ~36 MFLOP per sample).
+// All activations ([48][128] residual stream, [48][384] qkv / [48][256] MLP hidden, 4 x [42][42] attention
+// probabilities) stay in LDS (~149 KB of the CU's 160 KB); the six Linear layers per block run on the fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32 = exact fp32 fmaf chains, so the 1e-4 mm MANO budget downstream is untouched) with
+// the weight fragment prefetched k-major from L2; LayerNorm and softmax reduce with wavefront shuffles (one wave
+// per token / per attention row).  ~36 MFLOP per sample.
 #include "dir_common.h"
 
 namespace {
 
-constexpr int NT = 42, D = 128, HEADS = 4, HD = 32, NTHREADS = 512, NWAVES = 8;
-constexpr int TG = 7, NGROUPS = 6;   // 6 groups of 7 tokens
+constexpr int NT = 42, NTP = 48, D = 128, HEADS = 4, HD = 32, NTHREADS = 512, NWAVES = 8;
+// LDS row strides: +2 floats makes the MFMA A-operand reads (lane -> row l&15, k l>>4) bank-conflict free
+constexpr int LDX = D + 2, LDQ = 384 + 2, LDH = 256 + 2;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct SteArgs {
     dir_ste_params p;
@@ -23,51 +27,64 @@ struct SteArgs {
 __device__ __forceinline__ void layernorm_tokens(const float* s_in, float* s_out, const float* w, const float* b,
                                                  float eps, int wave, int lane) {
     for (int t = wave; t < NT; t += NWAVES) {
-        const float v0 = s_in[t * D + lane], v1 = s_in[t * D + 64 + lane];
+        const float v0 = s_in[t * LDX + lane], v1 = s_in[t * LDX + 64 + lane];
         const float mean = dir::wave_sum(v0 + v1) * (1.f / D);
         const float d0 = v0 - mean, d1 = v1 - mean;
         const float var = dir::wave_sum(d0 * d0 + d1 * d1) * (1.f / D);
         const float rstd = 1.f / sqrtf(var + eps);
-        s_out[t * D + lane] = d0 * rstd * w[lane] + b[lane];
-        s_out[t * D + 64 + lane] = d1 * rstd * w[64 + lane] + b[64 + lane];
+        s_out[t * LDX + lane] = d0 * rstd * w[lane] + b[lane];
+        s_out[t * LDX + 64 + lane] = d1 * rstd * w[64 + lane] + b[64 + lane];
     }
 }
 
-// out[t][n] = f( sum_k s_in[t][k] * Wt[k][n] + bias[n] ), t < 42.  Work item = (token group, n); consecutive
-// lanes take consecutive n (coalesced weight reads, LDS operand broadcast).
+// out[t][n] = f( sum_k s_in[t][k] * Wt[k][n] + bias[n] ), t < 42, on the fp32 matrix cores.
+// v_mfma_f32_16x16x4_f32: A lane (i = l&15, k = l>>4), B lane (k = l>>4, j = l&15), D lane col = l&15, row = 4*(l>>4)+r;
+// the result is a k-ordered fp32 fmaf chain (exact fp32).  A wave owns a 16-column tile for all three 16-row token
+// tiles; its whole K x 16 weight fragment is prefetched into registers first (one L2 latency per tile).
 template <int K, typename F>
-__device__ __forceinline__ void linear_tokens(const float* s_in, int ldi, const float* __restrict__ Wt,
-                                              const float* __restrict__ bias, int N, int tid, F store) {
-    for (int item = tid; item < NGROUPS * N; item += NTHREADS) {
-        const int tg = item / N, n = item - tg * N;
-        float acc[TG];
+__device__ __forceinline__ void linear_mfma(const float* s_in, int ldi, const float* __restrict__ Wt,
+                                            const float* __restrict__ bias, int N, int wave, int lane, F store) {
+    const int li = lane & 15, lk = lane >> 4;
+    for (int nt = wave; nt < N / 16; nt += NWAVES) {
+        const int n = nt * 16 + li;
+        float bv[K / 4];
 #pragma unroll
-        for (int t = 0; t < TG; ++t) acc[t] = 0.f;
-        const float* xin = s_in + tg * TG * ldi;
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-            const float w = Wt[(long long)k * N + n];
+        for (int kk = 0; kk < K / 4; ++kk) bv[kk] = Wt[(long long)(4 * kk + lk) * N + n];
+        f32x4 acc[3];
 #pragma unroll
-            for (int t = 0; t < TG; ++t) acc[t] = fmaf(xin[t * ldi + k], w, acc[t]);
+        for (int m = 0; m < 3; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* ap = s_in + li * ldi + lk;
+#pragma unroll
+        for (int kk = 0; kk < K / 4; ++kk) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[m * 16 * ldi + 4 * kk], bv[kk], acc[m], 0, 0, 0);
         }
-        const float bv = bias[n];
+        const float bb = bias[n];
 #pragma unroll
-        for (int t = 0; t < TG; ++t) store(tg * TG + t, n, acc[t] + bv);
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = m * 16 + lk * 4 + r;
+                if (t < NT) store(t, n, acc[m][r] + bb);
+            }
     }
 }
 
 __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * NT * D + NT * 384 + HEADS * NT * NT];   // 135,744 B
-    float* s_x = sm;                      // [42][128] residual stream
-    float* s_n = s_x + NT * D;            // [42][128] LayerNorm output / attention output
-    float* s_big = s_n + NT * D;          // [42][384] qkv, later [42][256] MLP hidden
-    float* s_p = s_big + NT * 384;        // [4][42][42] attention probabilities
+    __shared__ __attribute__((aligned(16))) float sm[2 * NTP * LDX + NTP * LDQ + HEADS * NT * NT];   // 152,256 B
+    float* s_x = sm;                      // [48][130] residual stream (rows 42..47: zero padding of the MFMA row tile)
+    float* s_n = s_x + NTP * LDX;         // [48][130] LayerNorm output / attention output
+    float* s_big = s_n + NTP * LDX;       // [48][386] qkv, later [48][258] MLP hidden
+    float* s_p = s_big + NTP * LDQ;       // [4][42][42] attention probabilities
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+    for (int i = tid; i < (NTP - NT) * LDX; i += NTHREADS) { s_x[NT * LDX + i] = 0.f; s_n[NT * LDX + i] = 0.f; }
+    for (int i = tid; i < (NTP - NT) * LDQ; i += NTHREADS) s_big[NT * LDQ + i] = 0.f;
     const float* xin = a.x_in + (long long)b * NT * D;
     for (int i = tid; i < NT * D; i += NTHREADS) {
         const float v = xin[i] + a.p.pos_embed[i];                      // x += spatial_pos_embed (mixSTE.py:196)
-        s_x[i] = v;
+        s_x[(i >> 7) * LDX + (i & 127)] = v;
         if (a.x_inout) a.x_inout[(long long)b * NT * D + i] = v;        // the reference mutates its input in place
     }
     __syncthreads();
@@ -77,14 +94,14 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         // ---- attention branch
         layernorm_tokens(s_x, s_n, P.ln1_w, P.ln1_b, 1e-6f, wave, lane);
         __syncthreads();
-        linear_tokens<D>(s_n, D, P.qkv_wt, P.qkv_b, 384, tid, [&](int t, int n, float v) { s_big[t * 384 + n] = v; });
+        linear_mfma<D>(s_n, LDX, P.qkv_wt, P.qkv_b, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
         __syncthreads();
         // scores: qkv column layout is (3, heads, 32) (mixSTE.py:78): q = [0,128), k = [128,256), v = [256,384)
         const float scale = 0.17677669529663687f;                       // 32 ** -0.5
         for (int i = tid; i < HEADS * NT * NT; i += NTHREADS) {
             const int h = i / (NT * NT), r = i - h * NT * NT, qi = r / NT, kj = r - qi * NT;
-            const float* q = s_big + qi * 384 + h * HD;
-            const float* k = s_big + kj * 384 + 128 + h * HD;
+            const float* q = s_big + qi * LDQ + h * HD;
+            const float* k = s_big + kj * LDQ + 128 + h * HD;
             float acc = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) acc = fmaf(q[d], k[d], acc);
@@ -103,32 +120,33 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
             const int t = i >> 7, c = i & 127, h = c >> 5;
             const float* p = s_p + (h * NT + t) * NT;
             float acc = 0.f;
-            for (int j = 0; j < NT; ++j) acc = fmaf(p[j], s_big[j * 384 + 256 + c], acc);
-            s_n[i] = acc;
+#pragma unroll 6
+            for (int j = 0; j < NT; ++j) acc = fmaf(p[j], s_big[j * LDQ + 256 + c], acc);
+            s_n[t * LDX + c] = acc;
         }
         __syncthreads();
-        linear_tokens<D>(s_n, D, P.proj_wt, P.proj_b, D, tid, [&](int t, int n, float v) { s_x[t * D + n] += v; });
+        linear_mfma<D>(s_n, LDX, P.proj_wt, P.proj_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
         __syncthreads();
         // ---- MLP branch
         layernorm_tokens(s_x, s_n, P.ln2_w, P.ln2_b, 1e-6f, wave, lane);
         __syncthreads();
-        linear_tokens<D>(s_n, D, P.fc1_wt, P.fc1_b, 256, tid, [&](int t, int n, float v) {
-            s_big[t * 256 + n] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));          // exact GELU
+        linear_mfma<D>(s_n, LDX, P.fc1_wt, P.fc1_b, 256, wave, lane, [&](int t, int n, float v) {
+            s_big[t * LDH + n] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));          // exact GELU
         });
         __syncthreads();
-        linear_tokens<256>(s_big, 256, P.fc2_wt, P.fc2_b, D, tid, [&](int t, int n, float v) { s_x[t * D + n] += v; });
+        linear_mfma<256>(s_big, LDH, P.fc2_wt, P.fc2_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
         __syncthreads();
         // ---- spatial_norm after every block (mixSTE.py:200)
         layernorm_tokens(s_x, s_n, a.p.snorm_w, a.p.snorm_b, 1e-6f, wave, lane);
         __syncthreads();
-        for (int i = tid; i < NT * D; i += NTHREADS) s_x[i] = s_n[i];
+        for (int i = tid; i < NT * D; i += NTHREADS) s_x[(i >> 7) * LDX + (i & 127)] = s_n[(i >> 7) * LDX + (i & 127)];
         __syncthreads();
     }
     // ---- head: LayerNorm(eps 1e-5) + Linear 128 -> 64 (mixSTE.py:187-190)
     layernorm_tokens(s_x, s_n, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, wave, lane);
     __syncthreads();
     float* y = a.y + (long long)b * NT * 64;
-    linear_tokens<D>(s_n, D, a.p.head_wt, a.p.head_b, 64, tid, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    linear_mfma<D>(s_n, LDX, a.p.head_wt, a.p.head_b, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
 }
 
 }  // namespace
