@@ -48,7 +48,11 @@ struct ConvArgs {
     const float* pre_scale; const float* pre_shift; const void* res; void* y;
     int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
     int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
+    const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
+                                        // each 64-channel input group; K-slabs that cannot touch a tile are skipped
 };
+
+constexpr int MAX_SLABS = 768;
 
 template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
@@ -232,12 +236,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 64;
 
-    gload(0);
-    lstore(0);
+    // ---- optional sparse-K: compact, ordered list of the K-slabs whose input group can be non-zero for this tile
+    __shared__ short s_list[MAX_SLABS];
+    __shared__ unsigned char s_flag[MAX_SLABS];
+    __shared__ int s_nact;
+    int nact = a.nk;
+    const bool sparse = a.bbox != nullptr;
+    if (sparse) {
+        const int hw = a.Ho * a.Wo;
+        const int b = m0 / hw, rem0 = m0 - b * hw;                 // host guarantees hw % BM == 0: one image per tile
+        const int oy0 = rem0 / a.Wo, oy1 = (rem0 + BM - 1) / a.Wo;
+        const bool fullw = BM >= a.Wo;
+        const int ox0 = fullw ? 0 : rem0 - oy0 * a.Wo, ox1 = fullw ? a.Wo - 1 : ox0 + BM - 1;
+        for (int ks = tid; ks < a.nk; ks += 256) {
+            const int k0 = ks * BK, tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            const int* bb = a.bbox + ((long long)b * a.bbox_groups + c0 / 64) * 4;
+            const int y0 = oy0 * a.stride - a.pad + ky, y1 = oy1 * a.stride - a.pad + ky;
+            const int x0 = ox0 * a.stride - a.pad + kx, x1 = ox1 * a.stride - a.pad + kx;
+            s_flag[ks] = (y1 >= bb[0] && y0 <= bb[1] && x1 >= bb[2] && x0 <= bb[3]) ? 1 : 0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int cnt = 0;
+            for (int base = 0; base < a.nk; base += 64) {
+                const int ks = base + lane;
+                const bool f = ks < a.nk && s_flag[ks];
+                const unsigned long long mask = __ballot(f);
+                if (f) s_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (short)ks;
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) s_nact = cnt;
+        }
+        __syncthreads();
+        nact = s_nact;
+    }
+    auto slab = [&](int i) { return sparse ? (int)s_list[i] : i; };
+
+    if (nact > 0) {
+        gload(slab(0));
+        lstore(0);
+    }
     __syncthreads();
-    for (int ks = 0; ks < a.nk; ++ks) {
+    for (int ks = 0; ks < nact; ++ks) {
         const int buf = ks & 1;
-        if (ks + 1 < a.nk) gload(ks + 1);
+        if (ks + 1 < nact) gload(slab(ks + 1));
         const char* sa = smem + buf * BUF_BYTES + (wm * MI * 32) * LDS_STRIDE + frag_off;
         const char* sb = smem + buf * BUF_BYTES + A_BYTES + (wn * NJ * 32) * LDS_STRIDE + frag_off;
         uint4 af[MI][4], bfr[NJ][4];
@@ -253,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
-        if (ks + 1 < a.nk) lstore(buf ^ 1);
+        if (ks + 1 < nact) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -344,9 +387,9 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,
-                                  const float* shift, const float* pre_scale, const float* pre_shift,
-                                  const void* residual, void* y, void* stream) {
+static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                        const float* pre_scale, const float* pre_shift, const void* residual, void* y,
+                        const int32_t* bbox, void* stream) {
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
@@ -379,6 +422,9 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
     a.M = (int)M; a.K = d->kh * d->kw * d->Cin; a.nk = a.K / BK;
     a.tiles_m = a.tiles_n = 0;
     a.flags = d->flags & 3;
+    // sparse-K needs whole tiles inside one image and a slab to sit inside one 64-channel group
+    a.bbox = nullptr; a.bbox_groups = d->Cin / 64;
+    if (bbox && d->Cin % 64 == 0 && (a.Ho * a.Wo) % 128 == 0 && a.nk <= MAX_SLABS && pre_scale == nullptr) a.bbox = bbox;
     // coalesced (LDS-staged, 16-byte) epilogue whenever every output / residual row segment is 16-byte aligned
     const int epo = d->out_dtype == DIR_DT_F32 ? 4 : 8;
     const bool vec = d->Cout % epo == 0 && out_cs % epo == 0 && d->out_coff % epo == 0 &&
@@ -395,4 +441,17 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
     else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
     else launch_conv<bf16_t, float>(a, num_cu, s);
     return dir::check_launch("dir_conv2d_forward");
+}
+
+extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,
+                                  const float* shift, const float* pre_scale, const float* pre_shift,
+                                  const void* residual, void* y, void* stream) {
+    return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream);
+}
+
+extern "C" int dir_conv2d_sparse_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,
+                                         const float* shift, const void* residual, void* y, const int32_t* group_bbox,
+                                         void* stream) {
+    DIR_REQUIRE(group_bbox, "dir_conv2d_sparse_forward: null bbox");
+    return conv_forward(d, x, w, scale, shift, nullptr, nullptr, residual, y, group_bbox, stream);
 }

@@ -237,7 +237,7 @@ __constant__ int kParent[20] = {0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14,
 __constant__ int kChild[20] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20};
 
 struct BoneArgs {
-    const float* uv[2]; const float* emb; void* out; float* vis;
+    const float* uv[2]; const float* emb; void* out; float* vis; int* bbox;
     int B, S; float distance;
 };
 
@@ -290,6 +290,26 @@ __global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
         s_uv[tid] = (v + 1.f) / 2.f * (float)S;                      // models/dir.py:150
     }
     __syncthreads();
+    if (a.bbox && y == 0 && tid < 40) {
+        // conservative pixel bounding box of the capsule of (hand, bone) = channel group tid of the NHWC output:
+        // a pixel centre (x+.5, y+.5) can only be inside if it is within `distance` of the segment's own box.
+        const int hand = tid / 20, bone = tid - hand * 20;
+        const float* uv = s_uv + hand * 42;
+        const float ax = uv[2 * kParent[bone]], ay = uv[2 * kParent[bone] + 1];
+        const float bx = uv[2 * kChild[bone]], by = uv[2 * kChild[bone] + 1];
+        int* bb = a.bbox + ((long long)b * 40 + tid) * 4;
+        const float d = a.distance;
+        const float ylo = fminf(ay, by) - d - 0.5f, yhi = fmaxf(ay, by) + d - 0.5f;
+        const float xlo = fminf(ax, bx) - d - 0.5f, xhi = fmaxf(ax, bx) + d - 0.5f;
+        const bool finite = (ax - ax == 0.f) && (ay - ay == 0.f) && (bx - bx == 0.f) && (by - by == 0.f);
+        // NaN / inf joints give a NaN or inf distance for every pixel -> mask all false -> empty box
+        if (!finite) { bb[0] = 1; bb[1] = 0; bb[2] = 1; bb[3] = 0; }
+        else {
+            const float fs = (float)(S - 1);
+            bb[0] = (int)fminf(fmaxf(floorf(ylo), 0.f), fs + 1.f); bb[1] = (int)fmaxf(fminf(ceilf(yhi), fs), -1.f);
+            bb[2] = (int)fminf(fmaxf(floorf(xlo), 0.f), fs + 1.f); bb[3] = (int)fmaxf(fminf(ceilf(xhi), fs), -1.f);
+        }
+    }
     const float py = (float)y + 0.5f;                                 // img_gird: (x+0.5, y+0.5), models/dir.py:66-70
     for (int i = tid; i < S * 40; i += 256) {
         const int x = i / 40, hb = i - x * 40, hand = hb / 20, bone = hb - hand * 20;
@@ -414,11 +434,12 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
 }
 
 extern "C" int dir_bone_proj_forward(const float* uv_left, const float* uv_right, const float* emb, void* out,
-                                     float* vis_nchw, int B, int S, float distance, int dtype, void* stream) {
+                                     float* vis_nchw, int32_t* group_bbox, int B, int S, float distance, int dtype,
+                                     void* stream) {
     DIR_REQUIRE(uv_left && uv_right && emb && out, "dir_bone_proj_forward: null pointer");
     DIR_REQUIRE(B > 0 && S > 0 && S <= 64 && S % 4 == 0, "dir_bone_proj_forward: bad shape (S must be a multiple of 4, <= 64)");
     BoneArgs a;
-    a.uv[0] = uv_left; a.uv[1] = uv_right; a.emb = emb; a.out = out; a.vis = vis_nchw; a.B = B; a.S = S;
+    a.uv[0] = uv_left; a.uv[1] = uv_right; a.emb = emb; a.out = out; a.vis = vis_nchw; a.bbox = group_bbox; a.B = B; a.S = S;
     a.distance = distance;
     const size_t lds = (size_t)(42 * 64 + 2 * S * 40 + 84) * sizeof(float) + (size_t)S * 40;
     hipStream_t s = (hipStream_t)stream;

@@ -52,7 +52,7 @@ class ConvOp(object):
         self.in_cs_override = None
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
 
-    def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0):
+    def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None):
         B, H, W, cbuf = x.shape
         ho = self.ho or (H + 2 * self.pad - self.kh) // self.stride + 1
         wo = self.wo or (W + 2 * self.pad - self.kw) // self.stride + 1
@@ -64,9 +64,15 @@ class ConvOp(object):
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
-                                            _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
-                                            _capi.ptr(residual), _capi.ptr(out), _capi.stream_ptr())
+        if bbox is not None:
+            rc = _capi.lib().dir_conv2d_sparse_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
+                                                       _capi.ptr(self.shift), _capi.ptr(residual), _capi.ptr(out),
+                                                       _capi.ptr(bbox), _capi.stream_ptr())
+        else:
+            rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
+                                                _capi.ptr(self.shift), _capi.ptr(self.pre_scale),
+                                                _capi.ptr(self.pre_shift), _capi.ptr(residual), _capi.ptr(out),
+                                                _capi.stream_ptr())
         _capi.check(rc, 'dir_conv2d_forward')
         if PROFILE is not None:
             e1.record()
@@ -283,8 +289,9 @@ def run_mano_pair(tables_lr, para_l, para_r, B):
 
 
 class DirEngine(object):
-    def __init__(self, state_dict, dtype=torch.bfloat16, root_joint=0, device='cuda'):
+    def __init__(self, state_dict, dtype=torch.bfloat16, root_joint=0, device='cuda', sparse_fusion=True):
         assert dtype in (torch.bfloat16, torch.float32)
+        self.sparse_fusion = sparse_fusion     # skip all-zero (tap, bone) K-slabs in the fusion conv (bit-identical)
         _capi.lib()
         self.dtype, self.device = dtype, torch.device(device)
         sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
@@ -384,10 +391,11 @@ class DirEngine(object):
         res = self.mano_outputs(st.mano, para_l, para_r, off)
         bone = torch.empty(B, S, S, 2560, device=dev, dtype=self.dtype)
         vis = torch.empty(B, 1280, S, S, device=dev, dtype=F32) if want_vis else None
+        bbox = torch.empty(B, 40, 4, device=dev, dtype=torch.int32)
         _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
-                                            _capi.ptr(emb), _capi.ptr(bone), _capi.ptr(vis), B, S, st.distance,
-                                            _dt(self.dtype), sp), 'dir_bone_proj_forward')
-        st.fusion3(st.fusion0(bone), out=img_out, out_coff=img_coff)
+                                            _capi.ptr(emb), _capi.ptr(bone), _capi.ptr(vis), _capi.ptr(bbox), B, S,
+                                            st.distance, _dt(self.dtype), sp), 'dir_bone_proj_forward')
+        st.fusion3(st.fusion0(bone, bbox=bbox if self.sparse_fusion else None), out=img_out, out_coff=img_coff)
         res['joint_feat'] = emb
         res['vis_img_feat'] = vis
         return res

@@ -88,7 +88,7 @@ class Joint2BoneFeature(nn.Module):
         out = torch.empty(B, S, S, 2560, device=uv.device)
         with torch.cuda.device(uv.device):
             _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(uv), _capi.ptr(uv), _capi.ptr(emb), _capi.ptr(out),
-                                                          None, B, S, float(self.distance), 0, _capi.stream_ptr()),
+                                                          None, None, B, S, float(self.distance), 0, _capi.stream_ptr()),
                         'dir_bone_proj_forward')
         return out[..., :1280].permute(0, 3, 1, 2)
 

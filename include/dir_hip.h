@@ -118,6 +118,15 @@ int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
 
+/* a11 with a10's sparsity: same as dir_conv2d_forward (no prologue), plus group_bbox int32 [B][Cin/64][4] = for every
+ * image and every 64-channel input group the pixel box (ymin,ymax,xmin,xmax) outside which that group is exactly zero.
+ * K-slabs (tap x group) that cannot touch an output tile are skipped: the sum only loses exact-zero products, so the
+ * result is bit-identical to the dense call.  The rasterised bone features (models/dir.py:146-174) are ~93 % zeros and
+ * one group == one (hand, bone).  Falls back to dense when (Ho*Wo) % 128 != 0 or Cin % 64 != 0. */
+int dir_conv2d_sparse_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
+                              const float* shift, const void* residual, void* y, const int32_t* group_bbox,
+                              void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound spatial helpers (NHWC, dtype = DIR_DT_*; arithmetic in fp32)
  */
@@ -152,9 +161,11 @@ int dir_init_head_forward(const dir_init_head_params* params_host, const void* c
  * uv_left/right [B,21,2] in [-1,1]; emb [B,42,64] (tokens 0..20 left, 21..41 right);
  * out NHWC [B,S,S,2560] (channel = hand*1280 + bone*64 + c == torch.cat((left,right),1) of models/dir.py:122);
  * vis_nchw (optional) fp32 [B,1280,S,S] = left + right (vis_img_feat / proj_feat, models/dir.py:128,481).
- * The capsule mask `distance < thr` follows the reference's fp32 op order exactly (bit-exact support). */
+ * The capsule mask `distance < thr` follows the reference's fp32 op order exactly (bit-exact support).
+ * group_bbox (optional) int32 [B][40][4]: conservative pixel box (ymin,ymax,xmin,xmax; empty when min > max) outside
+ * which channel group hand*20+bone (64 channels) of `out` is exactly zero -- input of dir_conv2d_sparse_forward. */
 int dir_bone_proj_forward(const float* uv_left, const float* uv_right, const float* emb, void* out, float* vis_nchw,
-                          int B, int S, float distance, int dtype, void* stream);
+                          int32_t* group_bbox, int B, int S, float distance, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Joint-token operators of a refinement stage (all fp32)

@@ -128,3 +128,16 @@ def test_dir_module_dropin(golden, dir_state):
     y = st.interaction(t)
     assert maxabs(y.cpu().numpy(), OT.ste_forward(t0.cpu().numpy(), Ps)) < 3e-5
     assert maxabs(t.cpu().numpy(), t0.cpu().numpy() + Ps['spatial_pos_embed']) < 1e-7      # in-place `x += pos`
+
+
+def test_sparse_fusion_is_bit_identical(dir_state):
+    """skipping the all-zero (tap, bone) K-slabs of the fusion conv changes nothing, end to end (B=2 has 2*256 and
+    2*1024 pixels: tiles of 64/128 rows stay inside one image)."""
+    sd, img = dir_state
+    for dt in (torch.bfloat16, torch.float32):
+        a = DirEngine(sd, dtype=dt, sparse_fusion=True).forward(img)
+        b = DirEngine(sd, dtype=dt, sparse_fusion=False).forward(img)
+        for i in range(3):
+            for k in ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset'):
+                assert torch.equal(a[i][k], b[i][k]), (dt, i, k)
+        assert torch.equal(a[3]['seg'], b[3]['seg']) and torch.equal(a[3]['proj_feat'], b[3]['proj_feat'])

@@ -121,7 +121,7 @@ def test_bone_proj_vs_reference(golden):
             out = torch.empty(2, S, S, 2560, device='cuda', dtype=tdt)
             vis = torch.empty(2, 1280, S, S, device='cuda')
             _capi.check(_capi.lib().dir_bone_proj_forward(
-                _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), _capi.ptr(out), _capi.ptr(vis), 2, S, float(dist),
+                _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), _capi.ptr(out), _capi.ptr(vis), None, 2, S, float(dist),
                 0 if tdt == torch.float32 else 1, _capi.stream_ptr()), 'bone_proj')
             got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
             assert np.array_equal(got[:, :1280] != 0, ref != 0), 'capsule mask differs from the reference (S=%d)' % S
@@ -181,3 +181,48 @@ def test_grid_tokens_and_regress_vs_oracle(golden, S, dist):
     assert maxabs(o[2].cpu().numpy(), N.linear(np.concatenate([fl, fr, off], 1), R['offset.weight'], R['offset.bias'])) < 1e-5
     emb = OT.token_mlp(tok.transpose(0, 2, 1), P.sub('proj_feat_emb')).transpose(0, 2, 1)
     assert maxabs(o[3].cpu().numpy(), emb) < 1e-5
+
+
+def test_bone_bbox_is_conservative_and_sparse_conv_is_bit_identical(golden):
+    """dir_bone_proj_forward's per-(hand,bone) pixel boxes must contain every non-zero of the rasterised features
+    (degenerate / off-image / coincident joints included), and dir_conv2d_sparse_forward, which skips the K-slabs
+    those boxes rule out, must reproduce the dense convolution bit for bit."""
+    from dir_amd import functional as F
+    g = golden('g5_bone')
+    for S, dist in ((16, 1), (32, 2)):
+        uv = g['S%d.uv' % S].copy()
+        uv_r = uv.copy(); uv_r[..., 0] *= -1
+        uv_r[1, 3] = np.nan                                   # NaN joint: its two bones rasterise to nothing
+        uv_r[0, 17:] = 3.0                                    # a finger completely outside the image
+        B = uv.shape[0]
+        emb = synth.synth_input('bbox.emb%d' % S, (B, 42, 64), SEED)
+        duv, duvr, demb = dev(uv), dev(uv_r), dev(emb)
+        for tdt in (torch.bfloat16, torch.float32):
+            out = torch.empty(B, S, S, 2560, device='cuda', dtype=tdt)
+            bbox = torch.full((B, 40, 4), -77, device='cuda', dtype=torch.int32)
+            _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), _capi.ptr(out),
+                                                          None, _capi.ptr(bbox), B, S, float(dist),
+                                                          0 if tdt == torch.float32 else 1, _capi.stream_ptr()), 'bone')
+            nz = (out.float().reshape(B, S, S, 40, 64) != 0).any(-1).cpu().numpy()          # [B,S,S,40]
+            bb = bbox.cpu().numpy()
+            assert (bb != -77).all()
+            empty = 0
+            for b in range(B):
+                for gI in range(40):
+                    ys, xs = np.nonzero(nz[b, :, :, gI])
+                    y0, y1, x0, x1 = bb[b, gI]
+                    if len(ys):
+                        assert y0 <= ys.min() and ys.max() <= y1 and x0 <= xs.min() and xs.max() <= x1, (S, b, gI)
+                    empty += int(y0 > y1 or x0 > x1)
+            assert empty >= 2                                   # the NaN bones (and possibly off-image ones) are empty
+            frac = np.mean([(max(0, bb[b, gI, 1] - bb[b, gI, 0] + 1) * max(0, bb[b, gI, 3] - bb[b, gI, 2] + 1)) / (S * S)
+                            for b in range(B) for gI in range(40)])
+            assert frac < 0.5                                   # the boxes are tight enough to be worth something
+            w = (torch.randn(256, 3, 3, 2560, device='cuda') * 0.02).to(tdt)
+            shift = torch.randn(256, device='cuda')
+            dense = F.conv2d_nhwc(out, w, 1, 1, shift=shift, relu=True)
+            d = _capi.ConvDesc(B, S, S, 2560, 2560, 0, 256, 256, 0, 0, 0, 3, 3, 1, 1, F._dt(out), F._dt(out), 1, 0, 0)
+            sparse = torch.empty_like(dense)
+            _capi.check(_capi.lib().dir_conv2d_sparse_forward(d, _capi.ptr(out), _capi.ptr(w), None, _capi.ptr(shift), None,
+                                                              _capi.ptr(sparse), _capi.ptr(bbox), _capi.stream_ptr()), 'sparse')
+            assert torch.equal(dense, sparse), 'sparse-K conv differs from dense (S=%d, %s)' % (S, tdt)

@@ -14,7 +14,7 @@ for S,dist in ((16,1),(32,2)):
     emb = np.concatenate([feat,feat],1)
     duv, demb = dev(uv), dev(emb)
     o = torch.empty(2,S,S,2560,device='cuda')
-    _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(duv),_capi.ptr(duv),_capi.ptr(demb),_capi.ptr(o),None,2,S,float(dist),0,_capi.stream_ptr()),'b')
+    _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(duv),_capi.ptr(duv),_capi.ptr(demb),_capi.ptr(o),None,None,2,S,float(dist),0,_capi.stream_ptr()),'b')
     got = o.cpu().numpy()                                         # [2,S,S,2560]
     gm = (got[...,:1280].reshape(2,S,S,20,64)!=0).any(-1)
     rm = (ref.reshape(2,20,64,S,S)!=0).any(2).transpose(0,2,3,1)

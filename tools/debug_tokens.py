@@ -33,7 +33,7 @@ uv = bone_uv('bone.uv%d'%S,2,S); feat = synth.synth_input('bone.feat%d'%S,(2,21,
 ref,mask = OT.bone_proj(uv,feat,S,dist,return_mask=True)
 emb = np.concatenate([feat,feat],1)
 o = torch.empty(2,S,S,2560,device='cuda'); 
-_capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(dev(uv)),_capi.ptr(dev(uv)),_capi.ptr(dev(emb)),_capi.ptr(o),None,2,S,float(dist),0,_capi.stream_ptr()),'b')
+_capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(dev(uv)),_capi.ptr(dev(uv)),_capi.ptr(dev(emb)),_capi.ptr(o),None,None,2,S,float(dist),0,_capi.stream_ptr()),'b')
 got = o.cpu().numpy().transpose(0,3,1,2)
 gm = (got[:,:1280].reshape(2,20,64,S,S)!=0).any(2)   # [2,20,S,S]
 rm = mask.transpose(0,3,1,2)
