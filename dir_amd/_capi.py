@@ -68,7 +68,7 @@ _SIGNATURES = {
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_bone_proj_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _i, _p]),
     'dir_conv2d_sparse_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),

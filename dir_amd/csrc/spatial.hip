@@ -142,7 +142,7 @@ struct InitHeadArgs {
     dir_init_head_params p;
     const void* c4; const void* h[2];
     float* para[2]; float* offset;
-    int HW, C, Ch;
+    int HW, C, Ch, hcs;
 };
 
 template <typename T>
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
     // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232); one wave per (hand, pixel) dot product
     for (int o = wave; o < 2 * HW; o += 8) {
         const int s = o / HW, px = o - s * HW;
-        const T* h = (const T*)a.h[s] + ((long long)b * HW + px) * Ch;
+        const T* h = (const T*)a.h[s] + ((long long)b * HW + px) * a.hcs;
         const float* w = a.p.attn_w[s];
         float acc = 0.f;
         for (int k = lane * VN; k < Ch; k += 64 * VN) {
@@ -416,13 +416,14 @@ extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int
 }
 
 extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* c4, const void* h_left,
-                                     const void* h_right, float* para_left, float* para_right, float* offset, int B,
-                                     int HW, int C, int Ch, int dtype, void* stream) {
+                                     const void* h_right, int h_cstride, float* para_left, float* para_right,
+                                     float* offset, int B, int HW, int C, int Ch, int dtype, void* stream) {
     DIR_REQUIRE(p && c4 && h_left && h_right && para_left && para_right && offset, "dir_init_head_forward: null pointer");
     DIR_REQUIRE(B > 0 && HW > 0 && C > 0 && Ch > 0, "dir_init_head_forward: bad shape");
     InitHeadArgs a;
     a.p = *p; a.c4 = c4; a.h[0] = h_left; a.h[1] = h_right; a.para[0] = para_left; a.para[1] = para_right;
-    a.offset = offset; a.HW = HW; a.C = C; a.Ch = Ch;
+    a.offset = offset; a.HW = HW; a.C = C; a.Ch = Ch; a.hcs = h_cstride ? h_cstride : Ch;
+    DIR_REQUIRE(a.hcs % 8 == 0, "dir_init_head_forward: h_cstride must be a multiple of 8");
     const size_t lds = (size_t)(2 * HW + 3 * C) * sizeof(float);
     DIR_REQUIRE(lds <= 60000, "dir_init_head_forward: feature too large for LDS");
     DIR_REQUIRE(C % 64 == 0 && Ch % 8 == 0 && (2 * HW) % 4 == 0 && p->mano_wt, "dir_init_head_forward: need C % 64 == 0, Ch % 8 == 0");

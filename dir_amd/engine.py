@@ -304,18 +304,20 @@ class DirEngine(object):
         self.bb = BackboneOp(sd, 'backbone', dt, self.device)
         # InitRegressor
         p = 'init_regressor'
-        self.attn = []
         H = _capi.InitHeadParams()
         t = {}
+        # both attention branches read c4: ONE 3x3 conv with N = 2 x 1024 (left | right), A operand streamed once
+        aw, asc, ash = [], [], []
         for i, side in enumerate(('left', 'right')):
             a = '%s.attention_%s' % (p, side)
             s, h = bn_fold(sd, a + '.1', sd[a + '.0.bias'])
-            self.attn.append(ConvOp(sd[a + '.0.weight'], dt, pad=1, scale=s, shift=h, relu=True))
+            aw.append(sd[a + '.0.weight']); asc.append(s); ash.append(h)
             t['aw%d' % i] = sd[a + '.3.weight'].float().reshape(-1).contiguous()
             H.attn_w[i] = t['aw%d' % i].data_ptr()
             H.attn_b[i] = float(sd[a + '.3.bias'].float().item())
             t['mb%d' % i] = sd['%s.mano_%s.bias' % (p, side)].float().contiguous()
             H.mano_b[i] = t['mb%d' % i].data_ptr()
+        self.attn = ConvOp(torch.cat(aw, 0), dt, pad=1, scale=torch.cat(asc), shift=torch.cat(ash), relu=True)
         t['mwt'] = torch.cat([sd[p + '.mano_left.weight'].float().t(), sd[p + '.mano_right.weight'].float().t()],
                              1).contiguous()                               # [2048][128] k-major
         H.mano_wt = t['mwt'].data_ptr()
@@ -344,13 +346,16 @@ class DirEngine(object):
     def init_regressor(self, c4):
         L, dev = _capi.lib(), self.device
         B = c4.shape[0]
-        hl, hr = self.attn[0](c4), self.attn[1](c4)
+        hh = self.attn(c4)                                   # [B,8,8,2048] = (left 1024 | right 1024)
+        ch = hh.shape[3] // 2
+        esz = hh.element_size()
         para_l = torch.empty(B, 64, device=dev, dtype=F32)
         para_r = torch.empty(B, 64, device=dev, dtype=F32)
         off = torch.empty(B, 3, device=dev, dtype=F32)
-        _capi.check(L.dir_init_head_forward(self.init_head, _capi.ptr(c4), _capi.ptr(hl), _capi.ptr(hr), _capi.ptr(para_l),
+        _capi.check(L.dir_init_head_forward(self.init_head, _capi.ptr(c4), C.c_void_p(hh.data_ptr()),
+                                            C.c_void_p(hh.data_ptr() + ch * esz), 2 * ch, _capi.ptr(para_l),
                                             _capi.ptr(para_r), _capi.ptr(off), B, c4.shape[1] * c4.shape[2], c4.shape[3],
-                                            hl.shape[3], _dt(self.dtype), _capi.stream_ptr()), 'dir_init_head_forward')
+                                            ch, _dt(self.dtype), _capi.stream_ptr()), 'dir_init_head_forward')
         return self.mano_outputs(self.init_mano, para_l, para_r, off)
 
     def mano_outputs(self, tables, para_l, para_r, off):

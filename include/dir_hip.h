@@ -151,11 +151,12 @@ typedef struct dir_init_head_params {
     const float* off_w;     /* [3][C]  offset.weight                   */
     const float* off_b;     /* [3]                                     */
 } dir_init_head_params;
-/* c4 [B,HW,C]; h_left/h_right [B,HW,Ch] = relu(bn(conv3x3(c4))) of each attention branch (dtype);
- * outputs fp32: para_left/right [B,64], offset [B,3]. */
+/* c4 [B,HW,C]; h_left/h_right = relu(bn(conv3x3(c4))) of each attention branch (dtype): Ch channels per pixel, pixels
+ * h_cstride elements apart (0 = Ch) -- both branches may live in one [B,HW,2*Ch] buffer produced by a single N=2*Ch
+ * convolution; outputs fp32: para_left/right [B,64], offset [B,3]. */
 int dir_init_head_forward(const dir_init_head_params* params_host, const void* c4, const void* h_left,
-                          const void* h_right, float* para_left, float* para_right, float* offset, int B, int HW,
-                          int C, int Ch, int dtype, void* stream);
+                          const void* h_right, int h_cstride, float* para_left, float* para_right, float* offset,
+                          int B, int HW, int C, int Ch, int dtype, void* stream);
 
 /* a10: Joint2BoneFeature.bone_proj + lineseg_dists (models/dir.py:132-174) for BOTH hands.
  * uv_left/right [B,21,2] in [-1,1]; emb [B,42,64] (tokens 0..20 left, 21..41 right);
