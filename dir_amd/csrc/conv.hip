@@ -12,9 +12,10 @@
 //
 // Block = 256 threads (2x2 waves); tile (64|128)(M) x (64|128)(N) picked per layer (launch_conv): each wave owns
 // MI x NJ MFMA tiles of 32x32 (up to 64 acc VGPRs).
-// Global -> registers -> LDS double buffering, one barrier per K-slab; the next slab's global loads are
-// in flight during the MFMAs.  Zero padding, M/N tails and the optional pre-activation BatchNorm+ReLU
-// (hourglass.Residual, models/backbone/hourglass.py:55-70) are handled in the register stage.
+// Global -> registers -> LDS, double-buffered LDS + two register stages (prefetch distance 2), one barrier per
+// K-slab.  Loads are hardware-bounds-checked buffer loads (out-of-range offset -> zeros): zero padding and the M / N
+// tails cost a select on a per-row tap bitmask computed once.  The optional pre-activation BatchNorm+ReLU
+// (hourglass.Residual, models/backbone/hourglass.py:55-70) is applied in the register stage.
 // Epilogue: per-channel scale/shift (folded BatchNorm / bias), optional residual add, optional ReLU,
 // optional channel offset/stride so a conv can write straight into a slice of a concat buffer.  The fp32 tile is
 // staged through LDS (reusing the pipeline buffers) so HBM sees 16-byte coalesced row segments for the output and
@@ -24,12 +25,43 @@
 // models/backbone/hourglass.py:10-30,55-70 and models/dir.py:57-62,227-241,404-420.
 #include "dir_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned short bf16_t;
+typedef int __attribute__((ext_vector_type(4))) i32x4;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 
+// Buffer load the COMPILER DOES NOT TRACK (inline asm): hipcc's wait-count pass drains every in-flight load at the
+// loop back-edge, which collapses a distance-2 software pipeline to distance 1.  These loads are waited for by hand
+// with counted s_waitcnt vmcnt(N) (wait_stage) so the newest stage stays in flight across the barrier.
+__device__ __forceinline__ u32x4 buffer_load_untracked(i32x4 rsrc, unsigned voff, unsigned soff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
+// wait until at most N untracked loads are outstanding; the registers of the stage being released are tied to the
+// statement so no consumer can be scheduled above it
+template <int N, int NA, int NB>
+__device__ __forceinline__ void wait_stage(u32x4 (&a)[NA], u32x4 (&b)[NB]) {
+    static_assert(NA <= 4 && NB <= 4, "stage too large");
+    if constexpr (NA == 4 && NB == 4)
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+    else if constexpr (NA == 4 && NB == 2)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+    else if constexpr (NA == 2 && NB == 4)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+    else
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+}
+
+// Register-destination loads hidden from the compiler turned out UNSAFE here: hipcc may split / copy the live range of
+// an asm-loaded register (e.g. at the loop header) before the data has landed -> intermittent garbage on large grids.
+// Kept for reference; the deep pipeline is built on LDS-DMA instead (no VGPR destination).
+constexpr bool UNTRACKED = false;
 constexpr int LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -48,6 +80,7 @@ struct ConvArgs {
     const float* pre_scale; const float* pre_shift; const void* res; void* y;
     int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
     int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
+    unsigned x_bytes, w_bytes;          // buffer sizes for the hardware bounds check
     const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
                                         // each 64-channel input group; K-slabs that cannot touch a tile are skipped
 };
@@ -137,7 +170,7 @@ template <> struct OutVec<bf16_t> {
 };
 
 // MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
-template <typename TI, typename TO, int MI, int NJ>
+template <typename TI, typename TO, int MI, int NJ, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BM = 64 * MI, BN = 64 * NJ;
     constexpr int A_BYTES = BM * LDS_STRIDE, B_BYTES = BN * LDS_STRIDE, BUF_BYTES = A_BYTES + B_BYTES;
@@ -163,67 +196,82 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const TI* __restrict__ x = (const TI*)a.x;
     const TI* __restrict__ w = (const TI*)a.w;
 
-    // ---- per-thread loader state
-    long long abase[ACH];
-    int aiy[ACH], aix[ACH];
-    long long bbase[BCH];
-    bool bval[BCH];
+    // ---- per-thread loader state.  Loads are hardware-bounds-checked buffer loads: an out-of-range byte offset
+    //      returns zeros, so zero padding, the M tail and the Cout tail cost one v_cndmask instead of branches.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, a.w_bytes, 0x00020000);
+    const i32x4 xd = {(int)(unsigned)(unsigned long long)x, (int)(unsigned)((unsigned long long)x >> 32), (int)a.x_bytes, 0x00020000};
+    const i32x4 wd = {(int)(unsigned)(unsigned long long)w, (int)(unsigned)((unsigned long long)w >> 32), (int)a.w_bytes, 0x00020000};
+    constexpr unsigned OOB = 0x80000000u;            // > any buffer size accepted by the host wrapper (< 2 GiB)
+    constexpr int ES = (int)sizeof(TI);
+    int avoff[ACH];                                  // byte offset of (b, iy0, ix0, chunk) -- may be negative
+    unsigned amask[ACH];                             // bit t: tap t of this row is inside the image (and m < M)
+    unsigned bvoff[BCH];
     const int col = tid & 7;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
+        avoff[i] = 0;
+        amask[i] = 0;
         if (m < a.M) {
             const int b = m / (a.Ho * a.Wo);
             const int rem = m - b * (a.Ho * a.Wo);
             const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            aiy[i] = oy * a.stride - a.pad;
-            aix[i] = ox * a.stride - a.pad;
-            abase[i] = ((long long)(b * a.H + aiy[i]) * a.W + aix[i]) * a.in_cs + a.in_co + col * EPC;
-        } else {
-            aiy[i] = -(1 << 28);   // always out of bounds -> zero rows
-            aix[i] = 0;
-            abase[i] = 0;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            avoff[i] = (((b * a.H + iy0) * a.W + ix0) * a.in_cs + a.in_co + col * EPC) * ES;
+            unsigned msk = 0;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx) {
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) msk |= 1u << (ky * a.kw + kx);
+                }
+            amask[i] = msk;
         }
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
         const int n = n0 + (tid >> 3) + 32 * i;
-        bval[i] = n < a.Cout;
-        bbase[i] = (long long)n * a.K + col * EPC;
+        bvoff[i] = n < a.Cout ? (unsigned)((n * a.K + col * EPC) * ES) : OOB;
     }
 
-    uint4 ra[ACH], rb[BCH];
-    const bool has_pre = a.pre_scale != nullptr;
+    u32x4 ra[2][ACH], rb[2][BCH];                    // two register stages: prefetch distance 2
     const bool pre_relu = (a.flags & 2) != 0;
 
-    auto gload = [&](int ks) {
+    auto gload = [&](auto P, int ks) {
+        constexpr int p = decltype(P)::value;
         const int k0 = ks * BK;
         const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
-        const long long toff = (long long)(ky * a.W + kx) * a.in_cs + c0;
+        const int toff = ((ky * a.W + kx) * a.in_cs + c0) * ES;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
-            const int iy = aiy[i] + ky, ix = aix[i] + kx;
-            const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                v = *reinterpret_cast<const uint4*>(x + abase[i] + toff);
-                if (has_pre) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
+            const bool ok = (amask[i] >> tap) & 1u;
+            const unsigned vo = ok ? (unsigned)(avoff[i] + toff) : OOB;
+            if constexpr (PRE || !UNTRACKED) {     // compiler-tracked load (the prologue consumes the data at once)
+                uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
+                if constexpr (PRE) {
+                    if (ok) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
+                }
+                ra[p][i] = __builtin_bit_cast(u32x4, v);
+            } else {
+                ra[p][i] = buffer_load_untracked(xd, vo, 0);
             }
-            ra[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < BCH; ++i)
-            rb[i] = bval[i] ? *reinterpret_cast<const uint4*>(w + bbase[i] + k0) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < BCH; ++i) {
+            if constexpr (PRE || !UNTRACKED) rb[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[i], k0 * ES, 0));
+            else rb[p][i] = buffer_load_untracked(wd, bvoff[i], (unsigned)(k0 * ES));
+        }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](auto P, int buf) {
+        constexpr int p = decltype(P)::value;
         char* sa = smem + buf * BUF_BYTES;
         char* sb = sa + A_BYTES;
         const int off0 = (tid >> 3) * LDS_STRIDE + col * 16;
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) *reinterpret_cast<uint4*>(sa + off0 + 32 * i * LDS_STRIDE) = ra[i];
+        for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(sa + off0 + 32 * i * LDS_STRIDE) = ra[p][i];
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) *reinterpret_cast<uint4*>(sb + off0 + 32 * i * LDS_STRIDE) = rb[i];
+        for (int i = 0; i < BCH; ++i) *reinterpret_cast<u32x4*>(sb + off0 + 32 * i * LDS_STRIDE) = rb[p][i];
     };
 
     f32x16 acc[MI][NJ];
@@ -272,17 +320,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         nact = s_nact;
     }
     auto slab = [&](int i) { return sparse ? (int)s_list[i] : i; };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 
-    if (nact > 0) {
-        gload(slab(0));
-        lstore(0);
-    }
-    __syncthreads();
-    for (int ks = 0; ks < nact; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nact) gload(slab(ks + 1));
-        const char* sa = smem + buf * BUF_BYTES + (wm * MI * 32) * LDS_STRIDE + frag_off;
-        const char* sb = smem + buf * BUF_BYTES + A_BYTES + (wn * NJ * 32) * LDS_STRIDE + frag_off;
+    // slab i travels: global --(iteration i-2)--> register stage i&1 --(end of iteration i-1)--> LDS buffer i&1
+    auto step = [&](auto P, int ks) {
+        constexpr int p = decltype(P)::value;
+        using Q = std::integral_constant<int, p ^ 1>;
+        if (ks + 2 < nact) gload(P, slab(ks + 2));
+        const char* sa = smem + p * BUF_BYTES + (wm * MI * 32) * LDS_STRIDE + frag_off;
+        const char* sb = smem + p * BUF_BYTES + A_BYTES + (wn * NJ * 32) * LDS_STRIDE + frag_off;
         uint4 af[MI][4], bfr[NJ][4];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -296,8 +343,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
-        if (ks + 1 < nact) lstore(buf ^ 1);
+        if (ks + 1 < nact) {
+            if constexpr (!PRE && UNTRACKED) {     // stage Q (slab ks+1) was issued before this iteration's ACH+BCH loads
+                if (ks + 2 < nact) wait_stage<ACH + BCH>(ra[p ^ 1], rb[p ^ 1]);
+                else wait_stage<0>(ra[p ^ 1], rb[p ^ 1]);
+            }
+            lstore(Q{}, p ^ 1);
+        }
         __syncthreads();
+    };
+
+    if (nact > 0) {
+        gload(P0{}, slab(0));
+        if constexpr (!PRE && UNTRACKED) wait_stage<0>(ra[0], rb[0]);
+        lstore(P0{}, 0);
+    }
+    if (nact > 1) gload(P1{}, slab(1));
+    __syncthreads();
+    for (int ks = 0; ks < nact; ks += 2) {
+        step(P0{}, ks);
+        if (ks + 1 < nact) step(P1{}, ks + 1);
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -379,10 +444,17 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
-    if (!m64 && !n64) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 2, 2>), grid, block, 0, s, a);
-    else if (!m64 && n64) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 2, 1>), grid, block, 0, s, a);
-    else if (m64 && !n64) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 1, 2>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, 1, 1>), grid, block, 0, s, a);
+    const bool pre = a.pre_scale != nullptr;
+#define DIR_LAUNCH(MI_, NJ_)                                                                                   \
+    do {                                                                                                       \
+        if (pre) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, true>), grid, block, 0, s, a);       \
+        else hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, false>), grid, block, 0, s, a);          \
+    } while (0)
+    if (!m64 && !n64) DIR_LAUNCH(2, 2);
+    else if (!m64 && n64) DIR_LAUNCH(2, 1);
+    else if (m64 && !n64) DIR_LAUNCH(1, 2);
+    else DIR_LAUNCH(1, 1);
+#undef DIR_LAUNCH
 }
 
 }  // namespace
@@ -422,6 +494,11 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     a.M = (int)M; a.K = d->kh * d->kw * d->Cin; a.nk = a.K / BK;
     a.tiles_m = a.tiles_n = 0;
     a.flags = d->flags & 3;
+    DIR_REQUIRE(d->kh * d->kw <= 32, "dir_conv2d_forward: at most 32 taps");
+    const long long xb = (long long)d->B * d->H * d->W * in_cs * (f32 ? 4 : 2);
+    const long long wb = (long long)d->Cout * a.K * (f32 ? 4 : 2);
+    DIR_REQUIRE(xb < (1ll << 31) && wb < (1ll << 31), "dir_conv2d_forward: tensors must be < 2 GiB (32-bit buffer offsets)");
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
     // sparse-K needs whole tiles inside one image and a slab to sit inside one 64-channel group
     a.bbox = nullptr; a.bbox_groups = d->Cin / 64;
     if (bbox && d->Cin % 64 == 0 && (a.Ho * a.Wo) % 128 == 0 && a.nk <= MAX_SLABS && pre_scale == nullptr) a.bbox = bbox;

@@ -110,3 +110,22 @@ def test_conv_linearity_full_size():
     z = F.conv2d_nhwc(torch.zeros_like(x1), w, 1, 1, shift=torch.arange(Co, device='cuda', dtype=torch.float32),
                       out_dtype=torch.float32)
     assert torch.equal(z[3, 5, 7], torch.arange(Co, device='cuda', dtype=torch.float32))
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 64, 256, 1), (64, 64, 128, 256, 1), (64, 64, 192, 256, 1), (64, 64, 64, 256, 3),
+                                   (64, 32, 512, 128, 1), (64, 8, 2048, 512, 1)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_conv_full_size_chunk_consistency(shape, dtype):
+    """BASELINE config-2 sizes (B=64, thousands of workgroups in flight).  Size-independent property: every image is
+    convolved independently, so the full-batch result must equal, bit for bit, the result of running 8-image chunks
+    (a size the oracle comparison above covers) -- repeated, because a software-pipelining bug shows up only
+    intermittently and only under a full grid."""
+    B, H, Ci, Co, k = shape
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(B, H, H, Ci, device='cuda', generator=g).to(dtype)
+    w = (torch.randn(Co, k, k, Ci, device='cuda', generator=g) * 0.05).to(dtype)
+    ref = torch.cat([F.conv2d_nhwc(x[i:i + 8].contiguous(), w, 1, k // 2) for i in range(0, B, 8)], 0)
+    assert torch.isfinite(ref.float()).all()
+    for _ in range(4):
+        y = F.conv2d_nhwc(x, w, 1, k // 2)
+        assert torch.equal(y, ref)
