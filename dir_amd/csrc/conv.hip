@@ -58,6 +58,13 @@ __device__ __forceinline__ void wait_stage(u32x4 (&a)[NA], u32x4 (&b)[NB]) {
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
 }
 
+// 16-byte-per-lane LDS-DMA: global -> LDS without a VGPR destination.  `lds` must be wave-uniform; lane L lands at
+// lds + 16*L.  An out-of-range voff writes zeros.  (Kept in a __device__ function: used directly inside the __global__
+// template, the host pass silently drops the kernel stub.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
 // Register-destination loads hidden from the compiler turned out UNSAFE here: hipcc may split / copy the live range of
 // an asm-loaded register (e.g. at the loop header) before the data has landed -> intermittent garbage on large grids.
 // Kept for reference; the deep pipeline is built on LDS-DMA instead (no VGPR destination).
@@ -172,8 +179,14 @@ template <> struct OutVec<bf16_t> {
 // MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
 template <typename TI, typename TO, int MI, int NJ, bool PRE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+    // DMA: K-slabs go global -> LDS directly (buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS image of a
+    // wave-level DMA is lane-linear (8 rows x 128 B per instruction), so rows are unpadded and the bank-conflict-free
+    // layout is obtained by XOR-swizzling the 16-byte chunk index on the SOURCE address: chunk c of row r lives at
+    // position c ^ ((r >> 1) & 7).  The prologue variant must touch the data in registers and keeps the staged path.
+    constexpr bool DMA = !PRE;
+    constexpr int ROW = DMA ? 128 : LDS_STRIDE;
     constexpr int BM = 64 * MI, BN = 64 * NJ;
-    constexpr int A_BYTES = BM * LDS_STRIDE, B_BYTES = BN * LDS_STRIDE, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int STAGE_BYTES = BM * BN * 4;
     constexpr int SMEM = (2 * BUF_BYTES > STAGE_BYTES) ? 2 * BUF_BYTES : STAGE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -207,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     int avoff[ACH];                                  // byte offset of (b, iy0, ix0, chunk) -- may be negative
     unsigned amask[ACH];                             // bit t: tap t of this row is inside the image (and m < M)
     unsigned bvoff[BCH];
-    const int col = tid & 7;
+    // row handled by this thread in chunk-group i is (tid >> 3) + 32*i: ((row >> 1) & 7) == (tid >> 4) & 7 for every i
+    const int col = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
@@ -234,13 +248,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         bvoff[i] = n < a.Cout ? (unsigned)((n * a.K + col * EPC) * ES) : OOB;
     }
 
+    const int ntaps = a.kh * a.kw;
     u32x4 ra[2][ACH], rb[2][BCH];                    // two register stages: prefetch distance 2
     const bool pre_relu = (a.flags & 2) != 0;
 
     auto gload = [&](auto P, int ks) {
         constexpr int p = decltype(P)::value;
-        const int k0 = ks * BK;
-        const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+        // K order: channel slab outer, taps inner -- consecutive slabs touch the same pixels' cache lines (shifted
+        // by one tap), so the im2col re-reads hit L1/L2 instead of re-streaming the feature map once per tap
+        const int cs = ks / ntaps, tap = ks - cs * ntaps;
+        const int c0 = cs * BK, k0 = tap * a.Cin + c0;
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
         const int toff = ((ky * a.W + kx) * a.in_cs + c0) * ES;
 #pragma unroll
@@ -274,6 +291,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < BCH; ++i) *reinterpret_cast<u32x4*>(sb + off0 + 32 * i * LDS_STRIDE) = rb[p][i];
     };
 
+    // LDS-DMA of one K-slab into buffer `buf`: wave w writes row groups (w + 4*i) * 8 .. +7 (1 KiB each)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma = [&](int buf, int ks) {
+        const int cs = ks / ntaps, tap = ks - cs * ntaps;
+        const int c0 = cs * BK, k0 = tap * a.Cin + c0;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+        const int toff = ((ky * a.W + kx) * a.in_cs + c0) * ES;
+        char* sa = smem + buf * BUF_BYTES + wave_u * 1024;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const bool ok = (amask[i] >> tap) & 1u;
+            const unsigned vo = ok ? (unsigned)(avoff[i] + toff) : OOB;       // out of range -> zeros land in LDS
+            lds_dma16(xr, sa + i * 4096, vo, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i)
+            lds_dma16(wr, sa + A_BYTES + i * 4096, bvoff[i], (unsigned)(k0 * ES));
+    };
+
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -282,7 +318,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int frag_off = (lane & 31) * LDS_STRIDE + (lane >> 5) * 64;
+    // fragment addressing: lane (i = lane & 31, h = lane >> 5) reads the 64-byte half h of row i
+    const int frag_off = (lane & 31) * ROW + (DMA ? 0 : (lane >> 5) * 64);
+    int qoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = DMA ? ((((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4) : q * 16;
 
     // ---- optional sparse-K: compact, ordered list of the K-slabs whose input group can be non-zero for this tile
     __shared__ short s_list[MAX_SLABS];
@@ -297,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const bool fullw = BM >= a.Wo;
         const int ox0 = fullw ? 0 : rem0 - oy0 * a.Wo, ox1 = fullw ? a.Wo - 1 : ox0 + BM - 1;
         for (int ks = tid; ks < a.nk; ks += 256) {
-            const int k0 = ks * BK, tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+            const int cs = ks / ntaps, tap = ks - cs * ntaps, c0 = cs * BK;
             const int ky = tap / a.kw, kx = tap - ky * a.kw;
             const int* bb = a.bbox + ((long long)b * a.bbox_groups + c0 / 64) * 4;
             const int y0 = oy0 * a.stride - a.pad + ky, y1 = oy1 * a.stride - a.pad + ky;
@@ -327,38 +367,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     auto step = [&](auto P, int ks) {
         constexpr int p = decltype(P)::value;
         using Q = std::integral_constant<int, p ^ 1>;
-        if (ks + 2 < nact) gload(P, slab(ks + 2));
-        const char* sa = smem + p * BUF_BYTES + (wm * MI * 32) * LDS_STRIDE + frag_off;
-        const char* sb = smem + p * BUF_BYTES + A_BYTES + (wn * NJ * 32) * LDS_STRIDE + frag_off;
+        if constexpr (!DMA) {
+            if (ks + 2 < nact) gload(P, slab(ks + 2));
+        }
+        const char* sa = smem + p * BUF_BYTES + (wm * MI * 32) * ROW + frag_off;
+        const char* sb = smem + p * BUF_BYTES + A_BYTES + (wn * NJ * 32) * ROW + frag_off;
         uint4 af[MI][4], bfr[NJ][4];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) af[i][q] = *reinterpret_cast<const uint4*>(sa + i * 32 * LDS_STRIDE + q * 16);
+            for (int q = 0; q < 4; ++q) af[i][q] = *reinterpret_cast<const uint4*>(sa + i * 32 * ROW + qoff[q]);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bfr[j][q] = *reinterpret_cast<const uint4*>(sb + j * 32 * LDS_STRIDE + q * 16);
+            for (int q = 0; q < 4; ++q) bfr[j][q] = *reinterpret_cast<const uint4*>(sb + j * 32 * ROW + qoff[q]);
+        if constexpr (DMA) {
+            // the other buffer was last read in the previous iteration (all waves have passed its closing barrier):
+            // refill it now so the transfer overlaps this slab's MFMAs; __syncthreads() below drains it (vmcnt(0))
+            if (ks + 1 < nact) dma(p ^ 1, slab(ks + 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
-        if (ks + 1 < nact) {
-            if constexpr (!PRE && UNTRACKED) {     // stage Q (slab ks+1) was issued before this iteration's ACH+BCH loads
-                if (ks + 2 < nact) wait_stage<ACH + BCH>(ra[p ^ 1], rb[p ^ 1]);
-                else wait_stage<0>(ra[p ^ 1], rb[p ^ 1]);
-            }
-            lstore(Q{}, p ^ 1);
+        if constexpr (!DMA) {
+            if (ks + 1 < nact) lstore(Q{}, p ^ 1);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);      // keep the DMA drain + barrier BELOW the MFMAs it overlaps with
         }
         __syncthreads();
     };
 
-    if (nact > 0) {
-        gload(P0{}, slab(0));
-        if constexpr (!PRE && UNTRACKED) wait_stage<0>(ra[0], rb[0]);
-        lstore(P0{}, 0);
+    if constexpr (DMA) {
+        if (nact > 0) dma(0, slab(0));
+    } else {
+        if (nact > 0) {
+            gload(P0{}, slab(0));
+            lstore(P0{}, 0);
+        }
+        if (nact > 1) gload(P1{}, slab(1));
     }
-    if (nact > 1) gload(P1{}, slab(1));
     __syncthreads();
     for (int ks = 0; ks < nact; ks += 2) {
         step(P0{}, ks);
