@@ -18,7 +18,7 @@ class DirHipError(RuntimeError):
 
 class ManoTables(C.Structure):
     _fields_ = [('shapedirs_t', C.c_void_p), ('posedirs_t', C.c_void_p), ('v_template', C.c_void_p),
-                ('j_regressor', C.c_void_p), ('weights', C.c_void_p), ('hands_mean', C.c_void_p),
+                ('j_template', C.c_void_p), ('j_shapedirs', C.c_void_p), ('weights', C.c_void_p), ('hands_mean', C.c_void_p),
                 ('comps', C.c_void_p), ('side', C.c_int32), ('center_idx', C.c_int32), ('root_palm', C.c_int32)]
 
 

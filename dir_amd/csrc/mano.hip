@@ -114,13 +114,15 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) s_pm[9 * tid + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
     }
-    // ---- joint regression from the shaped template (manolayer.py:183): 48 dot products of length 778
-    for (int o = wave; o < NJ * 3; o += NTHR / 64) {
-        const int j = o / 3, c = o - 3 * j;
-        float acc = 0.f;
-        for (int v = lane; v < NV; v += 64) acc = fmaf(a.t.j_regressor[j * NV + v], s_v[3 * v + c], acc);
-        acc = dir::wave_sum(acc);
-        if (lane == 0) s_J[o] = acc;
+    // ---- joint regression from the shaped template (manolayer.py:183).  J = Jreg (v_template + shapedirs beta) is
+    //      linear in beta: j_template = Jreg v_template [16,3] and j_shapedirs = Jreg shapedirs [16,3,10] are folded once
+    //      at pack time (fp64), replacing 48 dot products of length 778 per sample by 48 of length 10.
+    if (tid >= 128 && tid < 128 + NJ * 3) {
+        const int o = tid - 128;
+        float acc = a.t.j_template[o];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc = fmaf(a.t.j_shapedirs[o * 10 + k], s_beta[k], acc);
+        s_J[o] = acc;
     }
     __syncthreads();
 
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
 static int check_hand(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
                       int betas_stride, const float* cam, int cam_stride, float* verts, float* joints) {
     DIR_REQUIRE(t && pose && betas && verts && joints, "dir_mano_forward: null pointer");
-    DIR_REQUIRE(t->shapedirs_t && t->posedirs_t && t->v_template && t->j_regressor && t->weights &&
+    DIR_REQUIRE(t->shapedirs_t && t->posedirs_t && t->v_template && t->j_template && t->j_shapedirs && t->weights &&
                     t->hands_mean && t->comps, "dir_mano_forward: null table");
     DIR_REQUIRE(pose_stride >= 51 && betas_stride >= 10, "dir_mano_forward: bad stride");
     DIR_REQUIRE(t->side == 0 || t->side == 1, "dir_mano_forward: side must be 0 (right) or 1 (left)");

@@ -3,20 +3,22 @@
 //   x += pos_embed ; for blocks 1..depth-1 (block 0 is never executed by the reference):
 //       x += proj(softmax(q k^T * 32^-0.5) v) ; x += fc2(gelu_erf(fc1(LN(x)))) ; x = spatial_norm(x)
 //   y = Linear(LN_1e-5(x)).
-// All activations ([48][128] residual stream, [48][384] qkv / [48][256] MLP hidden, 4 x [42][42] attention
-// probabilities) stay in LDS (~149 KB of the CU's 160 KB); the six Linear layers per block run on the fp32 matrix
+// All activations ([48][128] residual stream, [48][384] qkv / [48][256] MLP hidden, 4 x [48][44] attention
+// probabilities) stay in LDS (~154 KB of the CU's 160 KB); the six Linear layers per block, q k^T and P v run on the fp32 matrix
 // cores (v_mfma_f32_16x16x4_f32 = exact fp32 fmaf chains, so the 1e-4 mm MANO budget downstream is untouched) with
 // the weight fragment prefetched k-major from L2; LayerNorm and softmax reduce with wavefront shuffles (one wave
 // per token / per attention row).  ~36 MFLOP per sample.
 #include "dir_common.h"
+#include "dir_mfma.h"
 
 namespace {
 
 constexpr int NT = 42, NTP = 48, D = 128, HEADS = 4, HD = 32, NTHREADS = 512, NWAVES = 8;
 // LDS row strides: +2 floats makes the MFMA A-operand reads (lane -> row l&15, k l>>4) bank-conflict free
 constexpr int LDX = D + 2, LDQ = 384 + 2, LDH = 256 + 2;
+constexpr int LDP = 44;               // attention rows: 42 keys + 2 zero columns (K of the P.V MFMA is padded to 44)
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+using dir::f32x4;
 
 struct SteArgs {
     dir_ste_params p;
@@ -72,15 +74,16 @@ __device__ __forceinline__ void linear_mfma(const float* s_in, int ldi, const fl
 }
 
 __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * NTP * LDX + NTP * LDQ + HEADS * NT * NT];   // 152,256 B
+    __shared__ __attribute__((aligned(16))) float sm[2 * NTP * LDX + NTP * LDQ + HEADS * NTP * LDP];   // 157,824 B
     float* s_x = sm;                      // [48][130] residual stream (rows 42..47: zero padding of the MFMA row tile)
     float* s_n = s_x + NTP * LDX;         // [48][130] LayerNorm output / attention output
     float* s_big = s_n + NTP * LDX;       // [48][386] qkv, later [48][258] MLP hidden
-    float* s_p = s_big + NTP * LDQ;       // [4][42][42] attention probabilities
+    float* s_p = s_big + NTP * LDQ;       // [4][48][44] attention scores / probabilities (padding: zero columns 42,43)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int i = tid; i < (NTP - NT) * LDX; i += NTHREADS) { s_x[NT * LDX + i] = 0.f; s_n[NT * LDX + i] = 0.f; }
     for (int i = tid; i < (NTP - NT) * LDQ; i += NTHREADS) s_big[NT * LDQ + i] = 0.f;
+    for (int i = tid; i < HEADS * NTP * LDP; i += NTHREADS) s_p[i] = 0.f;
     const float* xin = a.x_in + (long long)b * NT * D;
     for (int i = tid; i < NT * D; i += NTHREADS) {
         const float v = xin[i] + a.p.pos_embed[i];                      // x += spatial_pos_embed (mixSTE.py:196)
@@ -96,33 +99,54 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         __syncthreads();
         linear_mfma<D>(s_n, LDX, P.qkv_wt, P.qkv_b, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
         __syncthreads();
-        // scores: qkv column layout is (3, heads, 32) (mixSTE.py:78): q = [0,128), k = [128,256), v = [256,384)
+        // scores S = q k^T * 32^-0.5 per head on the matrix cores.  qkv column layout is (3, heads, 32) (mixSTE.py:78):
+        // q = [0,128), k = [128,256), v = [256,384).  36 tiles of 16x16 (4 heads x 3 x 3), K = 32.
         const float scale = 0.17677669529663687f;                       // 32 ** -0.5
-        for (int i = tid; i < HEADS * NT * NT; i += NTHREADS) {
-            const int h = i / (NT * NT), r = i - h * NT * NT, qi = r / NT, kj = r - qi * NT;
-            const float* q = s_big + qi * LDQ + h * HD;
-            const float* k = s_big + kj * LDQ + 128 + h * HD;
-            float acc = 0.f;
+        {
+            const int li = lane & 15, lk = lane >> 4;
+            for (int tile = wave; tile < HEADS * 9; tile += NWAVES) {
+                const int h = tile / 9, mt = (tile - h * 9) / 3, nt = tile - h * 9 - mt * 3;
+                const float* qa = s_big + (mt * 16 + li) * LDQ + h * HD + lk;
+                const float* kb = s_big + (nt * 16 + li) * LDQ + 128 + h * HD + lk;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < HD; ++d) acc = fmaf(q[d], k[d], acc);
-            s_p[i] = acc * scale;
+                for (int kk = 0; kk < HD / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[4 * kk], kb[4 * kk], acc, 0, 0, 0);
+                const int col = nt * 16 + li;
+                if (col < LDP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        s_p[(h * NTP + mt * 16 + lk * 4 + r) * LDP + col] = col < NT ? acc[r] * scale : 0.f;
+                }
+            }
         }
         __syncthreads();
         for (int row = wave; row < HEADS * NT; row += NWAVES) {        // softmax: one wave per row of 42
-            float v = lane < NT ? s_p[row * NT + lane] : -INFINITY;
+            float* pr = s_p + ((row / NT) * NTP + row % NT) * LDP;
+            float v = lane < NT ? pr[lane] : -INFINITY;
             const float mx = dir::wave_max(v);
             const float e = lane < NT ? expf(v - mx) : 0.f;
             const float sum = dir::wave_sum(e);
-            if (lane < NT) s_p[row * NT + lane] = e / sum;
+            if (lane < NT) pr[lane] = e / sum;
         }
         __syncthreads();
-        for (int i = tid; i < NT * D; i += NTHREADS) {                  // o = P v, heads concatenated (mixSTE.py:94)
-            const int t = i >> 7, c = i & 127, h = c >> 5;
-            const float* p = s_p + (h * NT + t) * NT;
-            float acc = 0.f;
-#pragma unroll 6
-            for (int j = 0; j < NT; ++j) acc = fmaf(p[j], s_big[j * LDQ + 256 + c], acc);
-            s_n[t * LDX + c] = acc;
+        // o = P v, heads concatenated (mixSTE.py:94): 24 tiles (4 heads x 3 row tiles x 2 column tiles), K = 44
+        // (probability columns 42,43 and v rows 42..47 are zero)
+        {
+            const int li = lane & 15, lk = lane >> 4;
+            for (int tile = wave; tile < HEADS * 6; tile += NWAVES) {
+                const int h = tile / 6, mt = (tile - h * 6) >> 1, nt = tile & 1;
+                const float* pa = s_p + (h * NTP + mt * 16 + li) * LDP + lk;
+                const float* vb = s_big + lk * LDQ + 256 + h * HD + nt * 16 + li;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < LDP / 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], vb[4 * kk * LDQ], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = mt * 16 + lk * 4 + r;
+                    if (t < NT) s_n[t * LDX + h * HD + nt * 16 + li] = acc[r];
+                }
+            }
         }
         __syncthreads();
         linear_mfma<D>(s_n, LDX, P.proj_wt, P.proj_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });

@@ -13,8 +13,11 @@
 // The neighbour mix  out[j] = h0[j] + sum_k softmax(e_1)[j,k] h1[k] + b  (<= 5 neighbours on the hand skeleton),
 // BatchNorm and ReLU of layer l are applied in the LDS-staging prologue of layer l+1, so a layer is ONE launch.
 #include "dir_common.h"
+#include "dir_mfma.h"
 
 namespace {
+
+using dir::f32x4;
 
 typedef unsigned short bf16_t;
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -39,63 +42,35 @@ struct GridArgs {
     int B;
 };
 
-// Conv1d(k=1) -> folded BN -> ReLU -> Conv1d(k=1) over 21 tokens.  Thread (o, g) owns output channel o for the
-// tokens j = g, g+2, ...  s_in [21][K1], s_hid [21][128]; result accumulated into acc[].
-template <int K1>
-__device__ __forceinline__ void token_mlp128(const float* s_in, const dir_token_mlp& m, float* s_hid, float (&acc)[11],
-                                             int o, int g) {
-    constexpr int U = (K1 >= 16) ? 16 : K1;        // weight loads kept in flight (the loop is L2-latency bound)
-    float h[11];
+constexpr int GT_ROWS = 32;            // 21 tokens padded to two 16-row MFMA tiles
+constexpr int LDS_S = 256 + 2, LDS_H = 128 + 2;
+
+// second Conv1d of a token MLP on the matrix cores: acc[tile][m] += hid[32 x 128] * w2t[128 x 128]; wave w owns the
+// output column tiles w and w + 4
+__device__ __forceinline__ void mlp_out_mfma(const float* s_hid, const dir_token_mlp& m, int wave, int lane,
+                                             f32x4 (&acc)[2][2]) {
 #pragma unroll
-    for (int t = 0; t < 11; ++t) h[t] = 0.f;
-    for (int k0 = 0; k0 < K1; k0 += U) {
-        float w[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = m.w1t[(k0 + u) * 128 + o];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int t = 0; t < 11; ++t) {
-                const int j = g + 2 * t;
-                if (j < NJ) h[t] = fmaf(w[u], s_in[j * K1 + k0 + u], h[t]);
-            }
+    for (int t = 0; t < 2; ++t) dir::mfma_tile_f32<128, 2>(s_hid, LDS_H, m.w2t, 128, (wave + 4 * t) * 16, lane, acc[t]);
+}
+
+// first Conv1d (K = 3) + folded BN + ReLU of the positional MLPs: plain VALU, writes hid[21][128]
+__device__ __forceinline__ void mlp_in3(const float* s_in, const dir_token_mlp& m, float* s_hid, int tid) {
+    const int o = tid & 127;
+    const float w0 = m.w1t[o], w1 = m.w1t[128 + o], w2 = m.w1t[256 + o], s1 = m.s1[o], b1 = m.b1[o];
+    for (int j = tid >> 7; j < NJ; j += 2) {
+        const float h = fmaf(w2, s_in[j * 3 + 2], fmaf(w1, s_in[j * 3 + 1], w0 * s_in[j * 3]));
+        s_hid[j * LDS_H + o] = fmaxf(fmaf(h, s1, b1), 0.f);
     }
-    const float s1 = m.s1[o], b1 = m.b1[o];
-#pragma unroll
-    for (int t = 0; t < 11; ++t) {
-        const int j = g + 2 * t;
-        if (j < NJ) s_hid[j * 128 + o] = fmaxf(fmaf(h[t], s1, b1), 0.f);
-    }
-    __syncthreads();
-    float a2[11];
-#pragma unroll
-    for (int t = 0; t < 11; ++t) a2[t] = 0.f;
-    for (int k0 = 0; k0 < 128; k0 += 16) {
-        float w[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = m.w2t[(k0 + u) * 128 + o];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int t = 0; t < 11; ++t) {
-                const int j = g + 2 * t;
-                if (j < NJ) a2[t] = fmaf(w[u], s_hid[j * 128 + k0 + u], a2[t]);
-            }
-    }
-    const float b2 = m.b2[o];
-#pragma unroll
-    for (int t = 0; t < 11; ++t) acc[t] += a2[t] + b2;
-    __syncthreads();
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
-    __shared__ float s_samp[NJ * 256];
-    __shared__ float s_hid[NJ * 128];
+    __shared__ float s_samp[GT_ROWS * LDS_S];
+    __shared__ float s_hid[GT_ROWS * LDS_H];
     __shared__ float s_p[NJ * 3], s_q[NJ * 3];
     __shared__ float s_w[NJ * 4];
     __shared__ int s_i[NJ * 4];
-    const int b = blockIdx.x, hand = blockIdx.y, tid = threadIdx.x;
+    const int b = blockIdx.x, hand = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = a.S, C = a.C;
     if (tid < NJ) {
         // F.grid_sample, bilinear / zeros / align_corners=False: ix = ((u + 1) * W - 1) / 2
@@ -120,6 +95,9 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
         s_p[i] = p;
         s_q[i] = hand == 0 ? p - off : p + off;                                   // models/dir.py:106-107
     }
+    // padding rows of the MFMA row tiles stay zero for the whole kernel
+    for (int i = tid; i < (GT_ROWS - NJ) * LDS_S; i += 256) s_samp[NJ * LDS_S + i] = 0.f;
+    for (int i = tid; i < (GT_ROWS - NJ) * LDS_H; i += 256) s_hid[NJ * LDS_H + i] = 0.f;
     __syncthreads();
     const T* fb = (const T*)a.feat + (long long)b * S * S * a.fcs + a.fco;
     for (int i = tid; i < NJ * C; i += 256) {
@@ -130,29 +108,74 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
             const int pix = s_i[j * 4 + t];
             if (pix >= 0) acc += ld<T>(fb + (long long)pix * a.fcs + c) * s_w[j * 4 + t];
         }
-        s_samp[j * 256 + c] = acc;
+        s_samp[j * LDS_S + c] = acc;
     }
     __syncthreads();
-    const int o = tid & 127, g = tid >> 7;
-    float acc[11];
+    const int li = lane & 15, lk = lane >> 4;
+    // ---- img2joint: Conv1d 256 -> 128 (+BN+ReLU) on the matrix cores -> hid
+    {
+        const dir_token_mlp& m = a.img2joint[hand];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) acc[t] = 0.f;
-    token_mlp128<256>(s_samp, a.img2joint[hand], s_hid, acc, o, g);
-    token_mlp128<3>(s_p, a.pos_emb[hand], s_hid, acc, o, g);                      // x0 = pos + img (models/dir.py:100)
+        for (int t = 0; t < 2; ++t) {
+            f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            const int n0 = (wave + 4 * t) * 16, n = n0 + li;
+            dir::mfma_tile_f32<256, 2>(s_samp, LDS_S, m.w1t, 128, n0, lane, h);
+            const float s1 = m.s1[n], b1 = m.b1[n];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = mt * 16 + lk * 4 + r;
+                    if (j < NJ) s_hid[j * LDS_H + n] = fmaxf(fmaf(h[mt][r], s1, b1), 0.f);
+                }
+        }
+    }
+    __syncthreads();
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mlp_out_mfma(s_hid, a.img2joint[hand], wave, lane, acc);
+    __syncthreads();
+    // ---- pos_emb: x0 = pos + img (models/dir.py:100) accumulates into the same tiles
+    mlp_in3(s_p, a.pos_emb[hand], s_hid, tid);
+    __syncthreads();
+    mlp_out_mfma(s_hid, a.pos_emb[hand], wave, lane, acc);
     float* x0 = a.x0 + ((long long)hand * a.B + b) * NJ * 128;
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-        const int j = g + 2 * t;
-        if (j < NJ) x0[j * 128 + o] = acc[t];
-    }
+    for (int t = 0; t < 2; ++t) {
+        const int n = (wave + 4 * t) * 16 + li;
+        const float b2 = a.img2joint[hand].b2[n] + a.pos_emb[hand].b2[n];
 #pragma unroll
-    for (int t = 0; t < 11; ++t) acc[t] = 0.f;
-    token_mlp128<3>(s_q, a.gpos, s_hid, acc, o, g);
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = mt * 16 + lk * 4 + r;
+                if (j < NJ) x0[j * 128 + n] = acc[t][mt][r] + b2;
+            }
+    }
+    __syncthreads();
+    // ---- global_pos_emb
+    mlp_in3(s_q, a.gpos, s_hid, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mlp_out_mfma(s_hid, a.gpos, wave, lane, acc);
     float* gp = a.g + ((long long)hand * a.B + b) * NJ * 128;
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-        const int j = g + 2 * t;
-        if (j < NJ) gp[j * 128 + o] = acc[t];
+    for (int t = 0; t < 2; ++t) {
+        const int n = (wave + 4 * t) * 16 + li;
+        const float b2 = a.gpos.b2[n];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = mt * 16 + lk * 4 + r;
+                if (j < NJ) gp[j * 128 + n] = acc[t][mt][r] + b2;
+            }
     }
 }
 
@@ -176,21 +199,20 @@ __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (
     for (int t = 0; t < deg; ++t) w[t] /= sum;
 }
 
-constexpr int PG_BC = 16;   // samples per workgroup
+constexpr int PG_BC = 16;   // samples per workgroup = one 16-row MFMA tile
+constexpr int PG_LD = 128 + 2;
 
-// grid (21 nodes, 2 slices of 64 output columns, hands x batch chunks).  256 threads: o = tid & 63, bg = tid >> 6
-// (4 samples each).  The 2 x 128x64 weight slice is read coalesced along the output column, 8 k-rows in flight.
+// grid (21 nodes, 2 slices of 64 output columns, hands x batch chunks), 256 threads.  A = the node's input rows of 16
+// samples (LDS), B = the node's own W0 / W1 column tiles (k-major in the reference layout [2][21][k][o]); wave w owns
+// output columns slice*64 + 16w .. +15 of both matrices.
 __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
-    __shared__ __attribute__((aligned(16))) float s_x[PG_BC * 128];
-    const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x;
+    __shared__ float s_x[PG_BC * PG_LD];
+    const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hand = blockIdx.z / args.nchunk, chunk = blockIdx.z - hand * args.nchunk;
     const PgcnHand& a = args.h[hand];
-    const int o = slice * 64 + (tid & 63), bg = tid >> 6;
     const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
     float wgt[5]; int nidx[5]; int deg = 0;
     if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
-    const float* W0 = a.W + ((long long)j * 128) * 128 + o;
-    const float* W1 = a.W + ((long long)(NJ + j) * 128) * 128 + o;
     // ---- stage this node's input rows; layers >= 1 finish the previous layer here (mix + bias + BN + ReLU)
     for (int i = tid; i < PG_BC * 128; i += 256) {
         const int bb = i >> 7, k = i & 127;
@@ -207,37 +229,20 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
                 if (a.relu_prev) v = fmaxf(v, 0.f);
             }
         }
-        s_x[i] = v;
+        s_x[bb * PG_LD + k] = v;
     }
     __syncthreads();
-    float a0[4], a1[4];
+    const int n0 = slice * 64 + wave * 16, li = lane & 15, lk = lane >> 4;
+    f32x4 a0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, a1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    dir::mfma_tile_f32<128, 1>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
+    dir::mfma_tile_f32<128, 1>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
-    for (int k = 0; k < 128; k += 8) {
-        float w0[8], w1[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { w0[q] = W0[(k + q) * 128]; w1[q] = W1[(k + q) * 128]; }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 xa = *reinterpret_cast<const float4*>(s_x + (bg * 4 + t) * 128 + k);
-            const float4 xb = *reinterpret_cast<const float4*>(s_x + (bg * 4 + t) * 128 + k + 4);
-            a0[t] = fmaf(xa.x, w0[0], a0[t]); a0[t] = fmaf(xa.y, w0[1], a0[t]);
-            a0[t] = fmaf(xa.z, w0[2], a0[t]); a0[t] = fmaf(xa.w, w0[3], a0[t]);
-            a0[t] = fmaf(xb.x, w0[4], a0[t]); a0[t] = fmaf(xb.y, w0[5], a0[t]);
-            a0[t] = fmaf(xb.z, w0[6], a0[t]); a0[t] = fmaf(xb.w, w0[7], a0[t]);
-            a1[t] = fmaf(xa.x, w1[0], a1[t]); a1[t] = fmaf(xa.y, w1[1], a1[t]);
-            a1[t] = fmaf(xa.z, w1[2], a1[t]); a1[t] = fmaf(xa.w, w1[3], a1[t]);
-            a1[t] = fmaf(xb.x, w1[4], a1[t]); a1[t] = fmaf(xb.y, w1[5], a1[t]);
-            a1[t] = fmaf(xb.z, w1[6], a1[t]); a1[t] = fmaf(xb.w, w1[7], a1[t]);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int bb = bg * 4 + t;
+    for (int r = 0; r < 4; ++r) {
+        const int bb = lk * 4 + r;
         if (bb < nb) {
             float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
-            hb[o] = a0[t];
-            hb[128 + o] = a1[t];
+            hb[n0 + li] = a0[0][r];
+            hb[128 + n0 + li] = a1[0][r];
         }
     }
 }

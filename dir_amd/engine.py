@@ -143,12 +143,15 @@ def pack_mano(sd, prefix, side, center_idx, keep):
     f = lambda k: sd[prefix + '.' + k].float()  # noqa: E731
     t = dict(shapedirs_t=_pad_rows(f('th_shapedirs').reshape(2334, 10).t()),
              posedirs_t=_pad_rows(f('th_posedirs').reshape(2334, 135).t()),
-             v_template=f('th_v_template').reshape(2334).contiguous(), j_regressor=f('th_J_regressor').contiguous(),
+             v_template=f('th_v_template').reshape(2334).contiguous(),
+             j_template=(f('th_J_regressor').double() @ f('th_v_template').double().reshape(778, 3)).float().contiguous(),
+             j_shapedirs=torch.einsum('jv,vck->jck', f('th_J_regressor').double(),
+                                      f('th_shapedirs').double()).float().contiguous(),
              weights=f('th_weights').contiguous(), hands_mean=f('th_hands_mean').reshape(45).contiguous(),
              comps=f('th_selected_comps').contiguous())
     keep.append(t)
     return _capi.ManoTables(t['shapedirs_t'].data_ptr(), t['posedirs_t'].data_ptr(), t['v_template'].data_ptr(),
-                            t['j_regressor'].data_ptr(), t['weights'].data_ptr(), t['hands_mean'].data_ptr(),
+                            t['j_template'].data_ptr(), t['j_shapedirs'].data_ptr(), t['weights'].data_ptr(), t['hands_mean'].data_ptr(),
                             t['comps'].data_ptr(), 0 if side == 'right' else 1,
                             -1 if center_idx is None else int(center_idx), 0)
 

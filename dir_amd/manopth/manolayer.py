@@ -57,7 +57,10 @@ class ManoLayer(Module):
                 shapedirs_t=_pad_rows(self.th_shapedirs.float().reshape(2334, 10).t()),
                 posedirs_t=_pad_rows(self.th_posedirs.float().reshape(2334, 135).t()),
                 v_template=f(self.th_v_template.reshape(2334)),
-                j_regressor=f(self.th_J_regressor), weights=f(self.th_weights),
+                j_template=(self.th_J_regressor.double() @ self.th_v_template.double().reshape(778, 3)).float().contiguous(),
+                j_shapedirs=torch.einsum('jv,vck->jck', self.th_J_regressor.double(),
+                                         self.th_shapedirs.double()).float().contiguous(),
+                weights=f(self.th_weights),
                 hands_mean=f(self.th_hands_mean.reshape(45)), comps=f(self.th_selected_comps))
             self._packed_key = key
         return self._packed
@@ -65,7 +68,7 @@ class ManoLayer(Module):
     def c_tables(self, center_idx, root_palm=False):
         p = self._tables()
         return _capi.ManoTables(p['shapedirs_t'].data_ptr(), p['posedirs_t'].data_ptr(), p['v_template'].data_ptr(),
-                                p['j_regressor'].data_ptr(), p['weights'].data_ptr(), p['hands_mean'].data_ptr(),
+                                p['j_template'].data_ptr(), p['j_shapedirs'].data_ptr(), p['weights'].data_ptr(), p['hands_mean'].data_ptr(),
                                 p['comps'].data_ptr(), 0 if self.side == 'right' else 1,
                                 -1 if center_idx is None else int(center_idx), int(bool(root_palm)))
 

@@ -47,7 +47,8 @@ int dir_device_info(char* arch_host, int arch_len, int* num_cu_host);
  *   shapedirs_t [10][2336]   = th_shapedirs[778,3,10]  transposed, rows zero-padded 2334 -> 2336 (index v*3+c)
  *   posedirs_t  [135][2336]  = th_posedirs[778,3,135]  transposed, rows zero-padded (16-byte aligned rows)
  *   v_template  [2334]
- *   j_regressor [16][778]
+ *   j_template  [16][3]      = th_J_regressor @ th_v_template            (folded once, in fp64)
+ *   j_shapedirs [16][3][10]  = th_J_regressor @ th_shapedirs              (J is linear in beta)
  *   weights     [778][16]
  *   hands_mean  [45]
  *   comps       [45][45]      th_selected_comps (row k = PCA component k)
@@ -56,7 +57,8 @@ typedef struct dir_mano_tables {
     const float* shapedirs_t;
     const float* posedirs_t;
     const float* v_template;
-    const float* j_regressor;
+    const float* j_template;
+    const float* j_shapedirs;
     const float* weights;
     const float* hands_mean;
     const float* comps;
