@@ -488,7 +488,9 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const bool n64 = a.Cout <= 64;
     const int bn = n64 ? 64 : 128;
     const int tiles_n = (a.Cout + bn - 1) / bn;
-    const bool m64 = (long long)((a.M + 127) / 128) * tiles_n <= (long long)num_cu;
+    // ... or when the reduction is so short (<= 4 slabs) that the layer is HBM-bound: smaller tiles = more workgroups
+    // per CU = more bytes in flight
+    const bool m64 = (long long)((a.M + 127) / 128) * tiles_n <= (long long)num_cu || a.nk <= 4;
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
