@@ -25,6 +25,7 @@
 // models/backbone/hourglass.py:10-30,55-70 and models/dir.py:57-62,227-241,404-420.
 #include "dir_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -490,7 +491,9 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const int tiles_n = (a.Cout + bn - 1) / bn;
     // ... or when the reduction is so short (<= 4 slabs) that the layer is HBM-bound: smaller tiles = more workgroups
     // per CU = more bytes in flight
-    const bool m64 = (long long)((a.M + 127) / 128) * tiles_n <= (long long)num_cu || a.nk <= 4;
+    const bool m64_auto = (long long)((a.M + 127) / 128) * tiles_n <= (long long)num_cu || a.nk <= 4;
+    static const int force_m64 = getenv("DIR_FORCE_M64") ? atoi(getenv("DIR_FORCE_M64")) : -1;   // tuning aid
+    const bool m64 = force_m64 >= 0 ? (force_m64 != 0) : m64_auto;
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;

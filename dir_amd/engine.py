@@ -77,9 +77,11 @@ class ConvOp(object):
         if PROFILE is not None:
             e1.record()
             tag = 'conv_igemm<%s,%s>' % ('f32' if self.dtype == F32 else 'bf16', 'f32' if out.dtype == F32 else 'bf16')
+            nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
+                      + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
             PROFILE.append((tag, 2.0 * B * ho * wo * self.cout * self.alg_k, e0, e1,
                             'M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
-                                                           self.kw, self.stride)))
+                                                           self.kw, self.stride), nbytes))
         return out
 
 
