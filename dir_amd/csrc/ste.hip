@@ -16,7 +16,9 @@ namespace {
 constexpr int NT = 42, NTP = 48, D = 128, HEADS = 4, HD = 32, NTHREADS = 512, NWAVES = 8;
 // LDS row strides: +2 floats makes the MFMA A-operand reads (lane -> row l&15, k l>>4) bank-conflict free
 constexpr int LDX = D + 2, LDQ = 384 + 2, LDH = 256 + 2;
-constexpr int LDP = 44;               // attention rows: 42 keys + 2 zero columns (K of the P.V MFMA is padded to 44)
+constexpr int LDP = 45;               // attention rows: 42 keys + 2 zero columns (K of the P.V MFMA is padded to 44);
+                                      // odd stride: thread-per-row softmax and the MFMA operand reads are conflict free
+constexpr int KP = 44;
 
 using dir::f32x4;
 
@@ -25,17 +27,41 @@ struct SteArgs {
     float* x_inout; const float* x_in; float* y; int nblocks;
 };
 
-// LayerNorm over the channel dim, one wave per token (2 channels per lane), two-pass variance like ATen
+// sum over the 16 lanes of a DPP row (all lanes receive it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror.
+// (wave shuffles go through ds_bpermute, ~10x the latency of a DPP modifier)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// LayerNorm over the channel dim (two-pass variance like ATen): 16 lanes per token (channels li, li+16, ...), four
+// tokens per wave, 32 tokens per round.  s_out may alias s_in (every element is read and written by the same lane).
 __device__ __forceinline__ void layernorm_tokens(const float* s_in, float* s_out, const float* w, const float* b,
                                                  float eps, int wave, int lane) {
-    for (int t = wave; t < NT; t += NWAVES) {
-        const float v0 = s_in[t * LDX + lane], v1 = s_in[t * LDX + 64 + lane];
-        const float mean = dir::wave_sum(v0 + v1) * (1.f / D);
-        const float d0 = v0 - mean, d1 = v1 - mean;
-        const float var = dir::wave_sum(d0 * d0 + d1 * d1) * (1.f / D);
-        const float rstd = 1.f / sqrtf(var + eps);
-        s_out[t * LDX + lane] = d0 * rstd * w[lane] + b[lane];
-        s_out[t * LDX + 64 + lane] = d1 * rstd * w[64 + lane] + b[64 + lane];
+    const int li = lane & 15;
+    float wv[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wv[e] = w[li + 16 * e]; bv[e] = b[li + 16 * e]; }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int t = (rr * NWAVES + wave) * 4 + (lane >> 4);
+        const bool live = t < NT;
+        const float* src = s_in + (live ? t : 0) * LDX + li;
+        float v[8], sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = src[16 * e]; sum += v[e]; }
+        const float mean = row16_sum(sum) * (1.f / D);
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] -= mean; sq = fmaf(v[e], v[e], sq); }
+        const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / D) + eps);
+        if (live) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_out[t * LDX + li + 16 * e] = v[e] * rstd * wv[e] + bv[e];
+        }
     }
 }
 
@@ -74,7 +100,7 @@ __device__ __forceinline__ void linear_mfma(const float* s_in, int ldi, const fl
 }
 
 __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * NTP * LDX + NTP * LDQ + HEADS * NTP * LDP];   // 157,824 B
+    __shared__ __attribute__((aligned(16))) float sm[2 * NTP * LDX + NTP * LDQ + HEADS * NTP * LDP];   // 158,592 B
     float* s_x = sm;                      // [48][130] residual stream (rows 42..47: zero padding of the MFMA row tile)
     float* s_n = s_x + NTP * LDX;         // [48][130] LayerNorm output / attention output
     float* s_big = s_n + NTP * LDX;       // [48][386] qkv, later [48][258] MLP hidden
@@ -83,7 +109,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
 
     for (int i = tid; i < (NTP - NT) * LDX; i += NTHREADS) { s_x[NT * LDX + i] = 0.f; s_n[NT * LDX + i] = 0.f; }
     for (int i = tid; i < (NTP - NT) * LDQ; i += NTHREADS) s_big[NT * LDQ + i] = 0.f;
-    for (int i = tid; i < HEADS * NTP * LDP; i += NTHREADS) s_p[i] = 0.f;
+    for (int i = tid; i < HEADS * NTP * LDP; i += NTHREADS) s_p[i] = 0.f;   // padding rows/columns must stay finite
     const float* xin = a.x_in + (long long)b * NT * D;
     for (int i = tid; i < NT * D; i += NTHREADS) {
         const float v = xin[i] + a.p.pos_embed[i];                      // x += spatial_pos_embed (mixSTE.py:196)
@@ -112,7 +138,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < HD / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[4 * kk], kb[4 * kk], acc, 0, 0, 0);
                 const int col = nt * 16 + li;
-                if (col < LDP) {
+                if (col < KP) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         s_p[(h * NTP + mt * 16 + lk * 4 + r) * LDP + col] = col < NT ? acc[r] * scale : 0.f;
@@ -120,13 +146,15 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
             }
         }
         __syncthreads();
-        for (int row = wave; row < HEADS * NT; row += NWAVES) {        // softmax: one wave per row of 42
-            float* pr = s_p + ((row / NT) * NTP + row % NT) * LDP;
-            float v = lane < NT ? pr[lane] : -INFINITY;
-            const float mx = dir::wave_max(v);
-            const float e = lane < NT ? expf(v - mx) : 0.f;
-            const float sum = dir::wave_sum(e);
-            if (lane < NT) pr[lane] = e / sum;
+        if (tid < HEADS * NT) {                                         // softmax: one thread per row, row in registers
+            float* pr = s_p + ((tid / NT) * NTP + tid % NT) * LDP;
+            float v[NT], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { v[j] = pr[j]; mx = fmaxf(mx, v[j]); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { v[j] = expf(v[j] - mx); sum += v[j]; }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) pr[j] = v[j] / sum;
         }
         __syncthreads();
         // o = P v, heads concatenated (mixSTE.py:94): 24 tiles (4 heads x 3 row tiles x 2 column tiles), K = 44
@@ -139,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
                 const float* vb = s_big + lk * LDQ + 256 + h * HD + nt * 16 + li;
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < LDP / 4; ++kk)
+                for (int kk = 0; kk < KP / 4; ++kk)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], vb[4 * kk * LDQ], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -161,9 +189,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         linear_mfma<256>(s_big, LDH, P.fc2_wt, P.fc2_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
         __syncthreads();
         // ---- spatial_norm after every block (mixSTE.py:200)
-        layernorm_tokens(s_x, s_n, a.p.snorm_w, a.p.snorm_b, 1e-6f, wave, lane);
-        __syncthreads();
-        for (int i = tid; i < NT * D; i += NTHREADS) s_x[(i >> 7) * LDX + (i & 127)] = s_n[(i >> 7) * LDX + (i & 127)];
+        layernorm_tokens(s_x, s_x, a.p.snorm_w, a.p.snorm_b, 1e-6f, wave, lane);      // in place
         __syncthreads();
     }
     // ---- head: LayerNorm(eps 1e-5) + Linear 128 -> 64 (mixSTE.py:187-190)
