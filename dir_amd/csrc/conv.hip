@@ -486,7 +486,10 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     ConvArgs a = a0;
     // tile shape: 64-wide N tile for Cout <= 64 (no half-empty MFMA tiles); 64-tall M tile when the 128-tall grid
     // would not even put two workgroups on every CU (8x8 / 16x16 feature maps)
-    const bool n64 = a.Cout <= 64;
+    bool n64 = a.Cout <= 64;
+    // if even the 64x128 grid leaves at most one workgroup per CU, halve the N tile too (64x64: 4 WGs/CU by LDS)
+    static const int force_n64 = getenv("DIR_FORCE_N64") ? atoi(getenv("DIR_FORCE_N64")) : -1;   // tuning aid
+    if (!n64 && force_n64 != 0 && ((long long)((a.M + 63) / 64) * ((a.Cout + 127) / 128) <= (long long)num_cu || force_n64 == 1)) n64 = true;
     const int bn = n64 ? 64 : 128;
     const int tiles_n = (a.Cout + bn - 1) / bn;
     // ... or when the reduction is so short (<= 4 slabs) that the layer is HBM-bound: smaller tiles = more workgroups
