@@ -66,6 +66,18 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
+// Same transfer, but issued through inline asm so that hipcc's wait-count pass does NOT see it: the compiler would
+// otherwise drain every in-flight DMA (vmcnt(0)) before the next ds_read / barrier, which caps the pipeline at one slab
+// in flight.  No VGPR is written, so the register hazard of an untracked load does not exist here; completion is
+// tracked by hand with counted s_waitcnt vmcnt(N).  M0 (LDS base of the transfer) is saved and restored inside the
+// statement.  `lds_addr` = LDS byte address (wave-uniform).
+__device__ __forceinline__ void lds_dma16_untracked(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // Register-destination loads hidden from the compiler turned out UNSAFE here: hipcc may split / copy the live range of
 // an asm-loaded register (e.g. at the loop header) before the data has landed -> intermittent garbage on large grids.
 // Kept for reference; the deep pipeline is built on LDS-DMA instead (no VGPR destination).
@@ -178,7 +190,7 @@ template <> struct OutVec<bf16_t> {
 };
 
 // MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
-template <typename TI, typename TO, int MI, int NJ, bool PRE>
+template <typename TI, typename TO, int MI, int NJ, bool PRE, bool RING>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // DMA: K-slabs go global -> LDS directly (buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS image of a
     // wave-level DMA is lane-linear (8 rows x 128 B per instruction), so rows are unpadded and the bank-conflict-free
@@ -188,8 +200,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int ROW = DMA ? 128 : LDS_STRIDE;
     constexpr int BM = 64 * MI, BN = 64 * NJ;
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
+    // RING3: three LDS buffers, two K-slabs in flight (untracked asm DMA + counted vmcnt); used when three buffers still
+    // leave >= 2 workgroups per CU (every tile shape except 128x128, which keeps the 2-buffer compiler-tracked path)
+    constexpr bool RING3 = DMA && RING && !(MI == 2 && NJ == 2);
+    constexpr int NBUF = RING3 ? 3 : 2;
     constexpr int STAGE_BYTES = BM * BN * 4;
-    constexpr int SMEM = (2 * BUF_BYTES > STAGE_BYTES) ? 2 * BUF_BYTES : STAGE_BYTES;
+    constexpr int SMEM = (NBUF * BUF_BYTES > STAGE_BYTES) ? NBUF * BUF_BYTES : STAGE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     constexpr int EPC = Tr<TI>::EPC, BK = Tr<TI>::BK;
     constexpr int ACH = BM / 32, BCH = BN / 32;      // 16-byte chunks per thread per K-slab (A, B)
@@ -311,6 +327,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             lds_dma16(wr, sa + A_BYTES + i * 4096, bvoff[i], (unsigned)(k0 * ES));
     };
 
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    auto dma_ring = [&](int buf, int ks, bool live) {      // !live: every lane out of range -> zeros, branch-free code
+        const int cs = ks / ntaps, tap = ks - cs * ntaps;
+        const int c0 = cs * BK, k0 = tap * a.Cin + c0;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+        const int toff = ((ky * a.W + kx) * a.in_cs + c0) * ES;
+        const unsigned sa = lds_base + buf * BUF_BYTES + wave_u * 1024;
+#pragma unroll
+        for (int i = 0; i < ACH; ++i) {
+            const bool ok = ((amask[i] >> tap) & 1u) && live;
+            lds_dma16_untracked(xd, sa + i * 4096, ok ? (unsigned)(avoff[i] + toff) : OOB, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i)
+            lds_dma16_untracked(wd, sa + A_BYTES + i * 4096, live ? bvoff[i] : OOB, (unsigned)(k0 * ES));
+    };
+
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -400,7 +433,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     };
 
-    if constexpr (DMA) {
+    if constexpr (RING3) {
+        // slab i lives in buffer i % 3.  Iteration ks: (1) wait until this wave's pieces of slab ks have landed -- the
+        // only younger DMAs are slab ks+1's, NP pieces -- (2) barrier: every wave's pieces have landed AND every wave is
+        // done reading buffer (ks-1) % 3, (3) refill that buffer with slab ks+2, (4) MFMAs on slab ks.
+        constexpr int NP = ACH + BCH;
+        dma_ring(0, nact > 0 ? slab(0) : 0, nact > 0);
+        dma_ring(1, nact > 1 ? slab(1) : 0, nact > 1);
+        int buf = 0;
+        for (int ks = 0; ks < nact; ++ks) {
+            wait_vmcnt<NP>();
+            __syncthreads();
+            {
+                const int nb = buf == 0 ? 2 : buf - 1;          // (ks + 2) % 3
+                const bool more = ks + 2 < nact;
+                dma_ring(nb, more ? slab(ks + 2) : 0, more);
+            }
+            const char* sa = smem + buf * BUF_BYTES + (wm * MI * 32) * ROW + frag_off;
+            const char* sb = smem + buf * BUF_BYTES + A_BYTES + (wn * NJ * 32) * ROW + frag_off;
+            uint4 af[MI][4], bfr[NJ][4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) af[i][q] = *reinterpret_cast<const uint4*>(sa + i * 32 * ROW + qoff[q]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bfr[j][q] = *reinterpret_cast<const uint4*>(sb + j * 32 * ROW + qoff[q]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        wait_vmcnt<0>();                 // the trailing (out-of-range) refills must land before the LDS is reused
+        __syncthreads();
+    } else if constexpr (DMA) {
         if (nact > 0) dma(0, slab(0));
     } else {
         if (nact > 0) {
@@ -409,10 +477,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
         if (nact > 1) gload(P1{}, slab(1));
     }
-    __syncthreads();
-    for (int ks = 0; ks < nact; ks += 2) {
-        step(P0{}, ks);
-        if (ks + 1 < nact) step(P1{}, ks + 1);
+    if constexpr (!RING3) {
+        __syncthreads();
+        for (int ks = 0; ks < nact; ks += 2) {
+            step(P0{}, ks);
+            if (ks + 1 < nact) step(P1{}, ks + 1);
+        }
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -502,10 +572,15 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     a.tiles_n = tiles_n;
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     const bool pre = a.pre_scale != nullptr;
+    // 3-buffer ring (two slabs in flight) pays once the reduction is long enough to amortise its two-slab prologue
+    static const int ring_min = getenv("DIR_RING_MIN_NK") ? atoi(getenv("DIR_RING_MIN_NK")) : 12;   // tuning aid
+    const bool ring = a.nk >= ring_min;
 #define DIR_LAUNCH(MI_, NJ_)                                                                                   \
     do {                                                                                                       \
-        if (pre) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, true>), grid, block, 0, s, a);       \
-        else hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, false>), grid, block, 0, s, a);          \
+        if (pre) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, true, false>), grid, block, 0, s, a);       \
+        else if (ring && !(MI_ == 2 && NJ_ == 2))                                                                    \
+            hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, false, true>), grid, block, 0, s, a);            \
+        else hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, false, false>), grid, block, 0, s, a);          \
     } while (0)
     if (!m64 && !n64) DIR_LAUNCH(2, 2);
     else if (!m64 && n64) DIR_LAUNCH(2, 1);
