@@ -141,3 +141,17 @@ def test_sparse_fusion_is_bit_identical(dir_state):
             for k in ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset'):
                 assert torch.equal(a[i][k], b[i][k]), (dt, i, k)
         assert torch.equal(a[3]['seg'], b[3]['seg']) and torch.equal(a[3]['proj_feat'], b[3]['proj_feat'])
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_engine_odd_batch_sizes(dir_state, dt):
+    """ragged sizes: B = 1, 3, 5 (M tails in every conv, partial P-GCN sample chunks) equal the per-image results."""
+    sd, img = dir_state
+    eng = DirEngine(sd, dtype=dt)
+    five = torch.cat([img, img.flip(0), img[:1] * 0.5], 0).contiguous()
+    ref = [eng.forward(five[i:i + 1].contiguous()) for i in range(5)]
+    ref_v = torch.cat([r[2]['pd_mesh_xyz_right'].clone() for r in ref], 0)
+    ref_seg = torch.cat([r[3]['seg'].clone() for r in ref], 0)
+    for B in (3, 5):
+        o = eng.forward(five[:B].contiguous())
+        assert torch.equal(o[2]['pd_mesh_xyz_right'], ref_v[:B]) and torch.equal(o[3]['seg'], ref_seg[:B]), (B, dt)
