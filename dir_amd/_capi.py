@@ -56,6 +56,17 @@ class InitHeadParams(C.Structure):
                 ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p)]
 
 
+class EvalInputs(C.Structure):
+    _fields_ = [('verts_pd', C.c_void_p * 2), ('pd_offset', C.c_void_p), ('verts_gt', C.c_void_p * 2),
+                ('verts2d_gt', C.c_void_p * 2), ('cam', C.c_void_p), ('jr', C.c_void_p * 2)]
+
+
+class EvalOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('joint_err', 'vert_err', 'joint2d_err', 'vert2d_err', 'joints_pd', 'joints_gt',
+                                          'root_err')]
+
+
+ABI_VERSION = 2          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -77,6 +88,8 @@ _SIGNATURES = {
     'dir_pgcn_stack_forward_pair': (C.c_int, [C.POINTER(PgcnLayer), C.POINTER(PgcnLayer), _i, _p, _p, _p, _p, _i, _p]),
     'dir_ste_forward': (C.c_int, [C.POINTER(SteParams), _p, _p, _p, _i, _p]),
     'dir_regress_forward': (C.c_int, [C.POINTER(RegressParams), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    'dir_joint_regress_forward': (C.c_int, [_p, _p, _p, _i, _p]),
+    'dir_eval_metrics_forward': (C.c_int, [C.POINTER(EvalInputs), C.POINTER(EvalOutputs), _i, _i, _i, _p]),
     'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
@@ -93,8 +106,8 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)       # AttributeError if the library does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if l.dir_abi_version() != 1:
-            raise DirHipError('libdir_hip.so ABI version %d != 1' % l.dir_abi_version())
+        if l.dir_abi_version() != ABI_VERSION:
+            raise DirHipError('libdir_hip.so ABI version %d != %d' % (l.dir_abi_version(), ABI_VERSION))
         _lib = l
     return _lib
 

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's apps/eval.py evaluation loop, on libdir_hip.so.
+
+  Jr              apps/eval.py:22-44   same constructor / __call__; the matmul runs in dir_joint_regress_forward
+  EvalMetrics     apps/eval.py:128-306 the per-batch maths (:151-241) is ONE dir_eval_metrics_forward launch per batch;
+                                       per-sample errors stay on the GPU until summarize()/save_txt(), which reduce and
+                                       format exactly like :246-306 (numpy float32 means, *1000 for mm, '%.3f' files)
+  evaluate        apps/eval.py:137-241 the loop: network(...) -> metrics.update(...)
+Dataset, checkpoint download and MANO pkl loading are out of scope (SURVEY.md 8 'out'): the caller supplies the batches
+(the reference's dataloader tuple layout) and the two [16,778] joint regressors.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import _capi
+
+TIP_VERTS = (745, 317, 444, 556, 673)
+NEW_ORDER = (0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20)
+
+
+class Jr:
+    """apps/eval.py:22-44"""
+
+    def __init__(self, J_regressor, device='cuda'):
+        self.device = device
+        self.process_J_regressor(J_regressor)
+
+    def process_J_regressor(self, J_regressor):
+        J = J_regressor.clone().detach().float()
+        tips = torch.zeros_like(J[:5])
+        for r, v in enumerate(TIP_VERTS):
+            tips[r, v] = 1.0
+        self.J_regressor = torch.cat([J, tips], 0)[list(NEW_ORDER)].contiguous().to(self.device)
+
+    def __call__(self, v):
+        _capi.require_cuda(v, self.J_regressor)
+        v = _capi.f32c(v)
+        out = torch.empty(v.shape[0], 21, 3, device=v.device)
+        with torch.cuda.device(v.device):
+            _capi.check(_capi.lib().dir_joint_regress_forward(_capi.ptr(self.J_regressor), _capi.ptr(v), _capi.ptr(out),
+                                                              v.shape[0], _capi.stream_ptr()), 'dir_joint_regress_forward')
+        return out
+
+
+_KEYS = ('joint_err', 'vert_err', 'joint2d_err', 'vert2d_err', 'joints_pd', 'joints_gt', 'root_err')
+_SHAPES = {'joint_err': (2, 21), 'vert_err': (2, 778), 'joint2d_err': (2, 21), 'vert2d_err': (2, 778),
+           'joints_pd': (2, 21, 3), 'joints_gt': (2, 21, 3), 'root_err': ()}
+
+
+def eval_batch(J_regressor, verts_pd, pd_offset, verts_gt, verts2d_gt, cam, root_joint=0, scale=True):
+    """apps/eval.py:151-241 for one batch.  J_regressor = {'left': Jr, 'right': Jr}; verts_* = {'left': [B,778,3], ...};
+    verts2d_gt = {'left': [B,778,2], ...}; returns a dict of device tensors (hand axis: 0 = left, 1 = right)."""
+    ts = [_capi.f32c(verts_pd[s]) for s in ('left', 'right')] + [_capi.f32c(pd_offset)] + \
+         [_capi.f32c(verts_gt[s]) for s in ('left', 'right')] + [_capi.f32c(verts2d_gt[s]) for s in ('left', 'right')] + \
+         [_capi.f32c(cam), J_regressor['left'].J_regressor, J_regressor['right'].J_regressor]
+    _capi.require_cuda(*ts)
+    B, dev = ts[0].shape[0], ts[0].device
+    for t, shp in zip(ts, [(B, 778, 3)] * 2 + [(B, 3)] + [(B, 778, 3)] * 2 + [(B, 778, 2)] * 2 + [(B, 3, 3), (21, 778), (21, 778)]):
+        if tuple(t.shape) != shp:
+            raise _capi.DirHipError('eval_batch: tensor of shape %s where %s is expected' % (tuple(t.shape), shp))
+    ins = _capi.EvalInputs()
+    p = [t.data_ptr() for t in ts]
+    ins.verts_pd[0], ins.verts_pd[1], ins.pd_offset = p[0], p[1], p[2]
+    ins.verts_gt[0], ins.verts_gt[1], ins.verts2d_gt[0], ins.verts2d_gt[1] = p[3], p[4], p[5], p[6]
+    ins.cam, ins.jr[0], ins.jr[1] = p[7], p[8], p[9]
+    res = {k: torch.empty((B,) + _SHAPES[k], device=dev) for k in _KEYS}
+    outs = _capi.EvalOutputs(*[res[k].data_ptr() for k in _KEYS])
+    with torch.cuda.device(dev):
+        _capi.check(_capi.lib().dir_eval_metrics_forward(ins, outs, B, int(root_joint), int(bool(scale)), _capi.stream_ptr()),
+                    'dir_eval_metrics_forward')
+    return res
+
+
+class EvalMetrics:
+    """The accumulators of apps/eval.py:128-136 and their reduction (:246-306)."""
+
+    def __init__(self, J_regressor, root_joint=0, scale=True, stage_num=3):
+        self.J_regressor, self.root_joint, self.scale, self.stage_num = J_regressor, root_joint, scale, stage_num
+        self.batches = []
+
+    def update(self, result, data):
+        """`result` = network(...)[0]; `data` = the dataloader tuple of apps/eval.py:139-149."""
+        r = result[self.stage_num - 1]
+        out = eval_batch(self.J_regressor, {'left': r['pd_mesh_xyz_left'], 'right': r['pd_mesh_xyz_right']}, r['pd_offset'],
+                         {'left': data[3].cuda(), 'right': data[5].cuda()},
+                         {'left': data[7].cuda(), 'right': data[9].cuda()}, data[10].cuda(), self.root_joint, self.scale)
+        self.batches.append(out)
+        return out
+
+    def arrays(self):
+        """the concatenated numpy arrays of :246-270, named as the reference names them."""
+        cat = {k: torch.cat([b[k] for b in self.batches], 0).cpu().numpy() for k in _KEYS}
+        a = {}
+        for h, side in enumerate(('left', 'right')):
+            a['joints_loss_' + side] = cat['joint_err'][:, h]
+            a['verts_loss_' + side] = cat['vert_err'][:, h]
+            a['joints_2d_loss_' + side] = cat['joint2d_err'][:, h]
+            a['verts_2d_loss_' + side] = cat['vert2d_err'][:, h]
+            a['joints_xyz_%s_pd' % side] = cat['joints_pd'][:, h].reshape(-1, 63)
+            a['joints_xyz_%s_gt' % side] = cat['joints_gt'][:, h].reshape(-1, 63)
+        a['root_loss'] = cat['root_err'].reshape(-1)
+        return a
+
+    def summarize(self):
+        """:285-306 (the printed numbers)."""
+        a, s = self.arrays(), {}
+        for nm, key, mul in (('joint_mm', 'joints_loss_', 1000), ('vert_mm', 'verts_loss_', 1000),
+                             ('joint_px', 'joints_2d_loss_', 1), ('vert_px', 'verts_2d_loss_', 1)):
+            l, r = a[key + 'left'].mean() * mul, a[key + 'right'].mean() * mul
+            s[nm] = {'left': float(l), 'right': float(r), 'all': float((l + r) / 2)}
+        s['root_mm'] = float(a['root_loss'].mean() * 1000)
+        return s
+
+    def save_txt(self, file_folder):
+        """:272-283: the same twelve text files."""
+        os.makedirs(file_folder, exist_ok=True)
+        a = self.arrays()
+        w = lambda n, x: np.savetxt(os.path.join(file_folder, n), x, fmt='%.3f')  # noqa: E731
+        w('left_joint.txt', a['joints_xyz_left_pd'] * 1000)
+        w('right_joint.txt', a['joints_xyz_right_pd'] * 1000)
+        w('joint_left_error.txt', a['joints_loss_left'] * 1000)
+        w('joint_right_error.txt', a['joints_loss_right'] * 1000)
+        w('mesh_left_error.txt', a['verts_loss_left'].mean(-1) * 1000)
+        w('mesh_right_error.txt', a['verts_loss_right'].mean(-1) * 1000)
+        w('joint_2d_left_error.txt', a['joints_2d_loss_left'])
+        w('joint_2d_right_error.txt', a['joints_2d_loss_right'])
+        w('mesh_2d_left_error.txt', a['verts_2d_loss_left'].mean(-1))
+        w('mesh_2d_right_error.txt', a['verts_2d_loss_right'].mean(-1))
+        w('root_loss.txt', a['root_loss'] * 1000)
+        w('volume.txt', a['joints_loss_right'] * 1000)
+
+    def report(self):
+        """the print block of :295-306"""
+        s = self.summarize()
+        lines = []
+        for title, key, unit in (('joint mean error:', 'joint_mm', 'mm'), ('vert mean error:', 'vert_mm', 'mm'),
+                                 ('pixel joint mean error:', 'joint_px', 'mm'), ('pixel vert mean error:', 'vert_px', 'mm')):
+            lines += [title, '    left: {} {u}, right: {} {u}'.format(s[key]['left'], s[key]['right'], u=unit),
+                      '    all: {} {u}'.format(s[key]['all'], u=unit)]
+        lines.append('root error: {} mm'.format(s['root_mm']))
+        return '\n'.join(lines)
+
+
+def evaluate(network, dataloader, J_regressor, root_joint=0, scale=True, stage_num=3):
+    """apps/eval.py:137-241."""
+    m = EvalMetrics(J_regressor, root_joint, scale, stage_num)
+    with torch.no_grad():
+        for data in dataloader:
+            result, _ = network({'img': data[0].cuda()}, None, None)
+            m.update(result, data)
+    return m

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 1
+#define DIR_ABI_VERSION 2
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -248,6 +248,33 @@ typedef struct dir_regress_params {
 int dir_regress_forward(const dir_regress_params* params_host, const float* tok, const float* prev_para_left,
                         const float* prev_para_right, const float* prev_offset, float* para_left, float* para_right,
                         float* offset, float* emb, int B, void* stream);
+
+/* ---- evaluation-metric maths of apps/eval.py --------------------------------------------------
+ * f1a: Jr.__call__ (apps/eval.py:43-44): joints[B,21,3] = jr[21,778] @ verts[B,778,3].  `jr` is the Jr-processed
+ * regressor (16 MANO rows + 5 one-hot fingertip rows, re-ordered; built on the host by dir_amd.apps.eval.Jr).
+ * Dot products accumulate in fp64 and round once to fp32. */
+int dir_joint_regress_forward(const float* jr, const float* verts, float* joints, int B, void* stream);
+
+/* f1b: the per-batch body of the eval loop, apps/eval.py:151-241, for both hands (index 0 = left, 1 = right).
+ * Inputs (device, fp32, contiguous): verts_pd[h] [B,778,3] = result[-1]['pd_mesh_xyz_*'] (:171-172), pd_offset [B,3]
+ * (:170, multiplied by 0.15 inside), verts_gt[h] [B,778,3] = data[3]/data[5] (camera space), verts2d_gt[h] [B,778,2] =
+ * data[7]/data[9], cam [B,3,3] = data[10], jr[h] [21,778].
+ * Outputs (any may be NULL): joint_err/joint2d_err [B,2,21], vert_err/vert2d_err [B,2,778] (:192,204,217,225: L2 norms,
+ * metres / pixels), joints_pd/joints_gt [B,2,21,3] (:195-196: aligned prediction, root-relative GT), root_err [B]
+ * (:233-239).  root_joint = opt.root_joint (0 wrist | 9 middle MCP), use_scale = opt.scale (:180-185). */
+typedef struct dir_eval_inputs {
+    const float* verts_pd[2];
+    const float* pd_offset;
+    const float* verts_gt[2];
+    const float* verts2d_gt[2];
+    const float* cam;
+    const float* jr[2];
+} dir_eval_inputs;
+typedef struct dir_eval_outputs {
+    float *joint_err, *vert_err, *joint2d_err, *vert2d_err, *joints_pd, *joints_gt, *root_err;
+} dir_eval_outputs;
+int dir_eval_metrics_forward(const dir_eval_inputs* in_host, const dir_eval_outputs* out_host, int B, int root_joint,
+                             int use_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -285,8 +285,57 @@ def gen_full():
     save('g7_dir', **out)
 
 
+# ----------------------------------------------------------------------------- G9 eval metric maths
+def gen_eval():
+    """The metric maths is inside apps/eval.py's `if __name__ == '__main__':` block, so it cannot be imported: the
+    loop body (from `with torch.no_grad():` to the first np.concatenate) is extracted from the reference file AT
+    GENERATION TIME and executed on synthetic batches, with the reference's own Jr and xyz2uvd definitions."""
+    import textwrap
+    src = open(os.path.join(REF, 'apps', 'eval.py')).read().split('\n')
+    a = next(i for i, l in enumerate(src) if l.strip() == 'with torch.no_grad():')
+    b = next(i for i, l in enumerate(src) if l.strip().startswith("joints_loss['left'] = np.concatenate"))
+    body = textwrap.dedent('\n'.join(src[a:b]))
+    c0 = next(i for i, l in enumerate(src) if l.startswith('class Jr'))
+    c1 = next(i for i, l in enumerate(src) if l.startswith('class handDataset'))
+    d0 = next(i for i, l in enumerate(src) if l.startswith('def xyz2uvd'))
+    d1 = next(i for i, l in enumerate(src) if l.startswith("if __name__ == '__main__':"))
+    defs = '\n'.join(src[c0:c1] + src[d0:d1])
+    from oracle.golden_inputs import eval_inputs
+    ins = eval_inputs()
+    T = lambda k: torch.from_numpy(ins[k])  # noqa: E731
+    out = {}
+    for root_joint in (0, 9):
+        for scale in (True, False):
+            ns = {'torch': torch, 'np': np, 'tqdm': (lambda x: x)}
+            exec(defs, ns)
+            data = [torch.zeros(ins['cam'].shape[0], 3, 8, 8), None, None, T('verts_gt_left'), None, T('verts_gt_right'), None,
+                    T('verts2d_gt_left'), None, T('verts2d_gt_right'), T('cam')]
+            for i in (2, 4, 6, 8):
+                data[i] = torch.zeros(1)
+            result = [None, None, {'pd_offset': T('pd_offset'), 'pd_mesh_xyz_left': T('verts_pd_left'),
+                                   'pd_mesh_xyz_right': T('verts_pd_right')}]
+            ns.update(dataloader=[tuple(data)], network=lambda *a, **k: (result, {}),
+                      J_regressor={'left': ns['Jr'](T('jreg_left'), device='cpu'), 'right': ns['Jr'](T('jreg_right'), device='cpu')},
+                      opt=types.SimpleNamespace(root_joint=root_joint, scale=scale), stage_num=3, idx=0,
+                      joints_loss={'left': [], 'right': []}, verts_loss={'left': [], 'right': []},
+                      joints_xyz_list={'left': [], 'right': []}, joints_xyz_gt_list={'left': [], 'right': []},
+                      joints_2d_loss={'left': [], 'right': []}, verts_2d_loss={'left': [], 'right': []},
+                      root_loss_list=[], inter_volume_list=[], val_root_list=[])
+            exec(body, ns)
+            tag = 'r%d_s%d.' % (root_joint, int(scale))
+            for side in ('left', 'right'):
+                out[tag + 'joint_err_' + side] = ns['joints_loss'][side][0]
+                out[tag + 'vert_err_' + side] = ns['verts_loss'][side][0]
+                out[tag + 'joint2d_err_' + side] = ns['joints_2d_loss'][side][0]
+                out[tag + 'vert2d_err_' + side] = ns['verts_2d_loss'][side][0]
+                out[tag + 'joints_pd_' + side] = ns['joints_xyz_list'][side][0]
+                out[tag + 'joints_gt_' + side] = ns['joints_xyz_gt_list'][side][0]
+            out[tag + 'root_err'] = ns['root_loss_list'][0]
+    save('g9_eval', **out)
+
+
 GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
-        'stage': gen_stage, 'full': gen_full}
+        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

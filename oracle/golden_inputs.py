@@ -64,3 +64,27 @@ def stage_inputs(S, B=2):
     return img_feat, xyz_l, xyz_r, uv_l, uv_r, para_l, para_r, offset
 
 
+def eval_inputs(B=6):
+    """synthetic batch with the layout of apps/eval.py's dataloader tuple (data[0..10]) and of network(...)[2]"""
+    from oracle import mano as OM
+    out = {}
+    for side in ('left', 'right'):
+        pose, betas = mano_inputs('normal', B)
+        buf = synth.mano_buffers(side, SEED)
+        v, j = OM.mano_forward(buf, pose + synth.synth_input('eval.pose.' + side, (B, 51), SEED) * 0.2, betas, side, None)
+        trans = np.array([[-0.08 if side == 'left' else 0.08, 0.0, 0.75]], np.float32) + \
+            synth.synth_input('eval.trans.' + side, (B, 3), SEED) * np.float32(0.03)
+        out['verts_gt_' + side] = (v + trans[:, None]).astype(np.float32)
+        noise = synth.synth_input('eval.noise.' + side, (B, 778, 3), SEED) * np.float32(0.004)
+        scl = 1.0 + synth.synth_input('eval.scl.' + side, (B, 1, 1), SEED) * np.float32(0.05)
+        out['verts_pd_' + side] = ((v + noise) * scl).astype(np.float32)            # root-relative, wrong scale
+        out['jreg_' + side] = buf['th_J_regressor']
+    cam = np.tile(np.array([[1500., 0, 128.], [0, 1500., 128.], [0, 0, 1.]], np.float32), (B, 1, 1))
+    cam[:, 0, 0] += synth.synth_input('eval.f', (B,), SEED) * 20
+    out['cam'] = cam
+    for side in ('left', 'right'):
+        p = out['verts_gt_' + side] @ cam.transpose(0, 2, 1)
+        out['verts2d_gt_' + side] = (p[..., :2] / p[..., 2:]).astype(np.float32) + \
+            synth.synth_input('eval.v2d.' + side, (B, 778, 2), SEED) * np.float32(0.5)
+    out['pd_offset'] = synth.synth_input('eval.off', (B, 3), SEED)
+    return out

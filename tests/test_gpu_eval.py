@@ -1,0 +1,146 @@
+"""GPU parity of the eval-metric row: dir_eval_metrics_forward / dir_joint_regress_forward through the
+C ABI against the golden the reference's own loop body produced (tests/golden/g9_eval.npz) and against the oracle.
+
+Tolerances (floating point, written here as the task demands): the inputs live in camera space (|z| ~ 0.75 m, fp32 ulp
+6e-8 m = 6e-5 mm) and the scale alignment divides two bone lengths of ~0.09 m, so the reference's own fp32 noise is
+~1e-6 m on 3-D errors and ~2e-3 px on 2-D errors (the numpy oracle differs from the torch golden by exactly that).
+3-D: 2e-6 m (2e-3 mm); 2-D: 5e-3 px.  The fp64 arbitration test shows the kernel is closer to the exact value than that.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import eval_metrics as EM
+
+pytestmark = pytest.mark.gpu
+TOL3D, TOL2D = 2e-6, 5e-3
+
+
+def _inputs(B=6):
+    from oracle.golden_inputs import eval_inputs
+    return eval_inputs(B)
+
+
+def _run(ins, root_joint, scale):
+    from dir_amd.apps.eval import Jr, eval_batch
+    T = lambda k: torch.from_numpy(ins[k]).cuda()  # noqa: E731
+    J = {s: Jr(torch.from_numpy(ins['jreg_' + s])) for s in ('left', 'right')}
+    out = eval_batch(J, {s: T('verts_pd_' + s) for s in ('left', 'right')}, T('pd_offset'),
+                     {s: T('verts_gt_' + s) for s in ('left', 'right')}, {s: T('verts2d_gt_' + s) for s in ('left', 'right')},
+                     T('cam'), root_joint, scale)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}, J
+
+
+@pytest.mark.parametrize('root_joint', [0, 9])
+@pytest.mark.parametrize('scale', [True, False])
+def test_eval_metrics_vs_reference_golden(golden, root_joint, scale):
+    g, ins = golden('g9_eval'), _inputs()
+    out, _ = _run(ins, root_joint, scale)
+    tag = 'r%d_s%d.' % (root_joint, int(scale))
+    for h, side in enumerate(('left', 'right')):
+        for k, tol in (('joint_err', TOL3D), ('vert_err', TOL3D), ('joints_pd', TOL3D), ('joints_gt', TOL3D),
+                       ('joint2d_err', TOL2D), ('vert2d_err', TOL2D)):
+            d = np.abs(out[k][:, h] - g[tag + k + '_' + side]).max()
+            assert d <= tol, (k, side, d)
+    assert np.abs(out['root_err'] - g[tag + 'root_err'][:, 0]).max() <= TOL3D
+
+
+def test_eval_metrics_fp64_arbitration(golden):
+    """the kernel's distance to the exact (float64) value is no larger than the reference's own fp32 noise."""
+    ins = _inputs()
+    ins64 = dict(ins, jr_left=EM.jr_matrix(ins['jreg_left']), jr_right=EM.jr_matrix(ins['jreg_right']))
+    exact = EM.batch_metrics(ins64, 0, True, dtype=np.float64)
+    g = golden('g9_eval')
+    out, _ = _run(ins, 0, True)
+    for h, side in enumerate(('left', 'right')):
+        for k in ('joint_err', 'vert_err', 'joint2d_err', 'vert2d_err'):
+            e_gpu = np.abs(out[k][:, h] - exact[k + '_' + side]).max()
+            e_ref = np.abs(g['r0_s1.' + k + '_' + side] - exact[k + '_' + side]).max()
+            assert e_gpu <= max(1.5 * e_ref, 1e-7), (k, side, e_gpu, e_ref)
+
+
+def test_jr_call_matches_reference_joints(golden):
+    """Jr.__call__ (apps/eval.py:43-44): root-relative GT joints of the golden = Jr(verts_gt) - root."""
+    from dir_amd.apps.eval import Jr
+    g, ins = golden('g9_eval'), _inputs()
+    for side in ('left', 'right'):
+        jr = Jr(torch.from_numpy(ins['jreg_' + side]))
+        assert np.array_equal(jr.J_regressor.cpu().numpy(), EM.jr_matrix(ins['jreg_' + side]))
+        j = jr(torch.from_numpy(ins['verts_gt_' + side]).cuda()).cpu().numpy()
+        assert np.abs((j - j[:, :1]) - g['r0_s1.joints_gt_' + side]).max() <= TOL3D
+        j64 = EM.jr_matrix(ins['jreg_' + side]).astype(np.float64) @ ins['verts_gt_' + side].astype(np.float64)
+        assert np.abs(j - j64).max() <= 6e-8          # one fp32 rounding of the fp64-accumulated dot product
+
+
+def test_eval_identity_and_scale_invariance():
+    """size-independent properties at the eval batch size (256): a prediction equal to the root-relative GT scores 0
+    (up to the camera-space rounding), and with scale alignment a uniformly scaled prediction scores the same."""
+    B = 256
+    ins = _inputs(B)
+    jr = {s: EM.jr_matrix(ins['jreg_' + s]) for s in ('left', 'right')}
+    for s in ('left', 'right'):
+        root = (jr[s].astype(np.float64) @ ins['verts_gt_' + s].astype(np.float64))[:, :1]
+        ins['verts_pd_' + s] = (ins['verts_gt_' + s] - root).astype(np.float32)
+        p = ins['verts_gt_' + s] @ ins['cam'].transpose(0, 2, 1)
+        ins['verts2d_gt_' + s] = (p[..., :2] / p[..., 2:]).astype(np.float32)
+    a, _ = _run(ins, 0, True)
+    assert a['vert_err'].max() <= TOL3D and a['joint_err'].max() <= TOL3D
+    assert a['vert2d_err'].max() <= TOL2D and a['joint2d_err'].max() <= TOL2D
+    for s in ('left', 'right'):
+        ins['verts_pd_' + s] = ins['verts_pd_' + s] * np.float32(1.37)
+    b, _ = _run(ins, 0, True)
+    assert np.abs(a['vert_err'] - b['vert_err']).max() <= TOL3D
+    c, _ = _run(ins, 0, False)
+    assert c['vert_err'].max() > 1e-3                   # without the alignment the 1.37x prediction is off by centimetres
+
+
+def test_eval_accumulator_matches_oracle_summary(tmp_path):
+    """EvalMetrics.update/summarize/save_txt over two ragged batches == oracle.summarize (apps/eval.py:246-306)."""
+    from dir_amd.apps.eval import EvalMetrics, Jr
+    ins = _inputs(10)
+    J = {s: Jr(torch.from_numpy(ins['jreg_' + s])) for s in ('left', 'right')}
+    m = EvalMetrics(J, root_joint=0, scale=True)
+    obatches = []
+    for lo, hi in ((0, 7), (7, 10)):
+        T = lambda k: torch.from_numpy(ins[k][lo:hi])  # noqa: E731
+        data = [None, None, None, T('verts_gt_left'), None, T('verts_gt_right'), None, T('verts2d_gt_left'), None,
+                T('verts2d_gt_right'), T('cam')]
+        result = [None, None, {'pd_offset': T('pd_offset').cuda(), 'pd_mesh_xyz_left': T('verts_pd_left').cuda(),
+                               'pd_mesh_xyz_right': T('verts_pd_right').cuda()}]
+        m.update(result, data)
+        sub = {k: (v[lo:hi] if k not in ('jreg_left', 'jreg_right') else v) for k, v in ins.items()}
+        sub.update(jr_left=EM.jr_matrix(ins['jreg_left']), jr_right=EM.jr_matrix(ins['jreg_right']))
+        obatches.append(EM.batch_metrics(sub, 0, True))
+    s, so = m.summarize(), EM.summarize(obatches)
+    for k in ('joint_mm', 'vert_mm'):
+        for side in ('left', 'right', 'all'):
+            assert abs(s[k][side] - so[k][side]) <= 2e-3
+    for k in ('joint_px', 'vert_px'):
+        for side in ('left', 'right', 'all'):
+            assert abs(s[k][side] - so[k][side]) <= 5e-3
+    assert abs(s['root_mm'] - so['root_mm']) <= 2e-3
+    m.save_txt(str(tmp_path))
+    assert np.loadtxt(str(tmp_path / 'joint_left_error.txt')).shape == (10, 21)
+    assert np.loadtxt(str(tmp_path / 'mesh_left_error.txt')).shape == (10,)
+    assert 'root error:' in m.report()
+
+
+def test_eval_rejects_bad_arguments():
+    from dir_amd import _capi
+    from dir_amd.apps.eval import Jr, eval_batch
+    ins = _inputs(2)
+    J = {s: Jr(torch.from_numpy(ins['jreg_' + s])) for s in ('left', 'right')}
+    T = lambda k: torch.from_numpy(ins[k]).cuda()  # noqa: E731
+    args = [J, {s: T('verts_pd_' + s) for s in ('left', 'right')}, T('pd_offset'), {s: T('verts_gt_' + s) for s in ('left', 'right')},
+            {s: T('verts2d_gt_' + s) for s in ('left', 'right')}, T('cam')]
+    with pytest.raises(_capi.DirHipError):
+        eval_batch(*args, root_joint=21)
+    bad = list(args)
+    bad[5] = T('cam')[:, :2]
+    with pytest.raises(_capi.DirHipError):
+        eval_batch(*bad)
+    bad = list(args)
+    bad[2] = T('pd_offset').cpu()
+    with pytest.raises(_capi.DirHipError):
+        eval_batch(*bad)

@@ -210,3 +210,23 @@ def test_full_dir_matches_reference(golden):
     assert relerr(outs[3]['seg'], g['seg']) < 5e-4
     assert relerr(outs[3]['dense'], g['dense']) < 5e-4
     assert relerr(outs[3]['proj_feat'][:, 0:1280:97], g['proj_feat.slice']) < 5e-4
+
+
+# ------------------------------------------------------------------ G9 eval metric maths (8f rank 1)
+@pytest.mark.parametrize('root_joint', [0, 9])
+@pytest.mark.parametrize('scale', [True, False])
+def test_eval_metrics_match_reference(golden, root_joint, scale):
+    """oracle/eval_metrics.py vs the arrays the reference's own loop body (apps/eval.py:139-241) produced.
+    Tolerance: the reference's fp32 noise on camera-space inputs -- 2e-6 m (3-D), 5e-3 px (2-D); see tests/test_gpu_eval.py."""
+    from oracle import eval_metrics as EM
+    from oracle.golden_inputs import eval_inputs
+    g, ins = golden('g9_eval'), eval_inputs()
+    ins.update(jr_left=EM.jr_matrix(ins['jreg_left']), jr_right=EM.jr_matrix(ins['jreg_right']))
+    out = EM.batch_metrics(ins, root_joint, scale)
+    tag = 'r%d_s%d.' % (root_joint, int(scale))
+    keys = [k for k in g if k.startswith(tag)]
+    assert len(keys) == 13
+    for k in keys:
+        tol = 5e-3 if '2d' in k else 2e-6
+        assert out[k[len(tag):]].shape == g[k].shape
+        assert maxabs(out[k[len(tag):]], g[k]) <= tol, k
