@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, 'build', 'obj')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdir_hip.so')
 ARCH = 'gfx950'
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++20', '-fPIC', '-Wall', '-Wno-unused-function',
          '-fno-gpu-rdc']
 
 

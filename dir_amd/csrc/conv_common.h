@@ -1,0 +1,160 @@
+// Pieces shared by the two implicit-GEMM convolution kernels (conv.hip: 4-wave general kernel; conv_pipe.hip: 8-wave
+// deep-pipelined kernel for the MFMA-bound layers).  gfx950 only.
+#pragma once
+#include "dir_common.h"
+
+#include <type_traits>
+
+namespace dir {
+namespace convk {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned short bf16_t;
+typedef int __attribute__((ext_vector_type(4))) i32x4;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+
+// Buffer load the COMPILER DOES NOT TRACK (inline asm): hipcc's wait-count pass drains every in-flight load at the
+// loop back-edge, which collapses a distance-2 software pipeline to distance 1.  These loads are waited for by hand
+// with counted s_waitcnt vmcnt(N) (wait_stage) so the newest stage stays in flight across the barrier.
+__device__ __forceinline__ u32x4 buffer_load_untracked(i32x4 rsrc, unsigned voff, unsigned soff) {
+    u32x4 v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
+// wait until at most N untracked loads are outstanding; the registers of the stage being released are tied to the
+// statement so no consumer can be scheduled above it
+template <int N, int NA, int NB>
+__device__ __forceinline__ void wait_stage(u32x4 (&a)[NA], u32x4 (&b)[NB]) {
+    static_assert(NA <= 4 && NB <= 4, "stage too large");
+    if constexpr (NA == 4 && NB == 4)
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+    else if constexpr (NA == 4 && NB == 2)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+    else if constexpr (NA == 2 && NB == 4)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
+    else
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
+}
+
+// 16-byte-per-lane LDS-DMA: global -> LDS without a VGPR destination.  `lds` must be wave-uniform; lane L lands at
+// lds + 16*L.  An out-of-range voff writes zeros.  (Kept in a __device__ function: used directly inside the __global__
+// template, the host pass silently drops the kernel stub.)
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// Same transfer, but issued through inline asm so that hipcc's wait-count pass does NOT see it: the compiler would
+// otherwise drain every in-flight DMA (vmcnt(0)) before the next ds_read / barrier, which caps the pipeline at one slab
+// in flight.  No VGPR is written, so the register hazard of an untracked load does not exist here; completion is
+// tracked by hand with counted s_waitcnt vmcnt(N).  M0 (LDS base of the transfer) is saved and restored inside the
+// statement.  `lds_addr` = LDS byte address (wave-uniform).
+__device__ __forceinline__ void lds_dma16_untracked(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory");
+}
+// Variant that leaves M0 pointing at the transfer's LDS base (no save / restore: one SALU write per piece).  gfx9+ DS
+// instructions do not read M0, and nothing else in the kernels that use this touches it; M0 is on the clobber list.
+__device__ __forceinline__ void lds_dma16_m0(i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                 : : "v"(voff), "s"(lds_addr), "s"(rsrc), "s"(soff) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Register-destination loads hidden from the compiler turned out UNSAFE here: hipcc may split / copy the live range of
+// an asm-loaded register (e.g. at the loop header) before the data has landed -> intermittent garbage on large grids.
+// Kept for reference; the deep pipeline is built on LDS-DMA instead (no VGPR destination).
+constexpr bool UNTRACKED = false;
+constexpr int LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Tr;
+template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };    // EPC = elems per 16-B chunk
+template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
+
+struct ConvArgs {
+    const void* x; const void* w; const float* scale; const float* shift;
+    const float* pre_scale; const float* pre_shift; const void* res; void* y;
+    int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
+    int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
+    unsigned x_bytes, w_bytes;          // buffer sizes for the hardware bounds check
+    const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
+                                        // each 64-channel input group; K-slabs that cannot touch a tile are skipped
+};
+
+constexpr int MAX_SLABS = 768;
+
+template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <typename TO> __device__ __forceinline__ float load_res(const TO* p);
+template <> __device__ __forceinline__ float load_res<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_res<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename TI>
+__device__ __forceinline__ void mma_slab(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc);
+template <>
+__device__ __forceinline__ void mma_slab<float>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].x), __uint_as_float(bf[q].x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].y), __uint_as_float(bf[q].y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].z), __uint_as_float(bf[q].z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[q].w), __uint_as_float(bf[q].w), acc, 0, 0, 0);
+    }
+}
+template <>
+__device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
+                                                      __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
+}
+
+// 16-byte vector of output elements (coalesced epilogue)
+template <typename TO> struct OutVec;
+template <> struct OutVec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void unpack(const uint4 t, float (&v)[4]) {
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+    }
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct OutVec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
+    static __device__ __forceinline__ void unpack(const uint4 t, float (&v)[8]) {
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f((bf16_t)(u[e] & 0xffffu)); v[2 * e + 1] = bf2f((bf16_t)(u[e] >> 16)); }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+
+// conv_pipe.hip: returns true if it took the launch (bf16 input, no pre-activation, long reduction, enough tiles)
+bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s);
+
+}  // namespace convk
+}  // namespace dir

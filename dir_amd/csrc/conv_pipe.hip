@@ -1,0 +1,661 @@
+// Deep-pipelined implicit-GEMM convolution for the MFMA-bound layers (bf16 operands, fp32 accumulate): the same
+// maths, operand layout and epilogue as conv.hip, restructured so that the matrix cores never wait inside a K-slab.
+//
+//   * 8 waves (512 threads) per workgroup, one workgroup per CU, block tile 256x128 | 128x128 | 256x64:
+//     twice the rows of conv.hip's largest tile per byte fetched from L2 (the 128x128 2-barrier structure is capped
+//     near 900 TFLOP/s on this chip by L2 -> LDS traffic and by its exposed DMA / ds_read latencies).
+//   * K-slabs (64 bf16 channels = 128 B per row) travel global -> LDS by DMA into a 3-buffer ring, issued THREE
+//     slabs ahead through untracked inline asm and retired with counted s_waitcnt vmcnt(N) -- never vmcnt(0).
+//   * MFMA operands are double-buffered in registers: while the 16 MFMAs of slab k run, the same instruction stream
+//     issues the ds_read_b128 of slab k+1's fragments (first half of the slots) and the DMA pieces of slab k+3
+//     (second half), so one barrier per slab is the only synchronisation and nothing in a slab's MFMA chain
+//     depends on a load of the same iteration.
+//   * K order, XOR swizzle on the DMA source address, hardware-bounds-checked zero padding, sparse-K slab list and
+//     LDS-staged coalesced epilogue are those of conv.hip (bit-identical results: same fp32 accumulation order).
+//
+// Replaces the same reference calls as conv.hip (models/backbone/resnet.py:120-140, models/backbone/hourglass.py:55-70,
+// models/dir.py:57-62,227-241,404-420) for the layers launch_conv_pipe() accepts.
+#include "conv_common.h"
+
+#include <stdlib.h>
+
+namespace dir {
+namespace convk {
+namespace {
+
+// one K-slab of the reduction: tap (ky,kx) of channel slab c0
+struct Slab {
+    int tap, toff, k0;     // tap index, byte offset of (ky,kx,c0) inside the input, element offset inside a weight row
+};
+
+// scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM (conv.hip's epilogue)
+template <typename TO, int MI, int NJ, int WM, int WN>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0, int wm, int wn,
+                                         int tid, int lane) {
+    constexpr int NT = 64 * WM * WN, BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    TO* __restrict__ y = (TO*)a.y;
+    const TO* __restrict__ res = (const TO*)a.res;
+    const bool relu = (a.flags & 1) != 0;
+    float* st = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cl = wn * NJ * 32 + j * 32 + (lane & 31);
+        const int n = n0 + cl;
+        const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+        const float sh = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                st[rl * BN + cl] = fmaf(acc[i][j][r], sc, sh);
+            }
+    }
+    __syncthreads();
+    constexpr int VN = OutVec<TO>::N, CPR = BN / VN;
+    for (int c = tid; c < BM * CPR; c += NT) {
+        const int rl = c / CPR, cc = (c - rl * CPR) * VN;
+        const int m = m0 + rl, n = n0 + cc;
+        if (m >= a.M || n >= a.Cout) continue;
+        float v[VN];
+        const float4* sp = reinterpret_cast<const float4*>(st + rl * BN + cc);
+#pragma unroll
+        for (int q = 0; q < VN / 4; ++q) { const float4 t = sp[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+        if (res) {
+            float rv[VN];
+            OutVec<TO>::load(res + (long long)m * a.res_cs + a.res_co + n, rv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] += rv[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        OutVec<TO>::store(y + (long long)m * a.out_cs + a.out_co + n, v);
+    }
+}
+
+
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) {
+    typedef bf16_t TI;
+    constexpr int NT = 64 * WM * WN;               // threads
+    constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    constexpr int RPP = NT / 8;                    // rows covered by one DMA pass of the whole workgroup
+    constexpr int ACH = BM / RPP, BCH = BN / RPP, NP = ACH + BCH;   // DMA pieces per thread per slab
+    constexpr int ROW = 128;
+    constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int NBUF = 3;
+    constexpr int STAGE_BYTES = BM * BN * 4;
+    constexpr int SMEM = NBUF * BUF_BYTES > STAGE_BYTES ? NBUF * BUF_BYTES : STAGE_BYTES;
+    constexpr int EPC = 8, BK = 64, ES = 2;
+    constexpr int NSLOT = MI * NJ * 4;             // MFMAs per slab per wave
+    constexpr int NREAD = (MI + NJ) * 4;           // ds_read_b128 per slab per wave
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    // XCD-aware tile order (see conv.hip)
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    const TI* __restrict__ x = (const TI*)a.x;
+    const TI* __restrict__ w = (const TI*)a.w;
+    const i32x4 xd = {(int)(unsigned)(unsigned long long)x, (int)(unsigned)((unsigned long long)x >> 32), (int)a.x_bytes, 0x00020000};
+    const i32x4 wd = {(int)(unsigned)(unsigned long long)w, (int)(unsigned)((unsigned long long)w >> 32), (int)a.w_bytes, 0x00020000};
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- per-thread DMA source state: row (tid >> 3) + RPP * i of the A / B tile, 16-byte chunk (tid & 7) ^ swizzle
+    int avoff[ACH];
+    unsigned amask[ACH];
+    unsigned bvoff[BCH];
+    const int col = (tid & 7) ^ ((tid >> 4) & 7);
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int m = m0 + (tid >> 3) + RPP * i;
+        avoff[i] = 0;
+        amask[i] = 0;
+        if (m < a.M) {
+            const int b = m / (a.Ho * a.Wo);
+            const int rem = m - b * (a.Ho * a.Wo);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            avoff[i] = (((b * a.H + iy0) * a.W + ix0) * a.in_cs + a.in_co + col * EPC) * ES;
+            unsigned msk = 0;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx) {
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) msk |= 1u << (ky * a.kw + kx);
+                }
+            amask[i] = msk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int n = n0 + (tid >> 3) + RPP * i;
+        bvoff[i] = n < a.Cout ? (unsigned)((n * a.K + col * EPC) * ES) : OOB;
+    }
+    const int ntaps = a.kh * a.kw;
+
+    // ---- optional sparse-K: ordered list of the slabs whose 64-channel input group can be non-zero for this tile
+    __shared__ int s_list[SPARSE ? MAX_SLABS : 1];
+    __shared__ unsigned char s_flag[SPARSE ? MAX_SLABS : 1];
+    __shared__ int s_nact;
+    int nact = a.nk;
+    if constexpr (SPARSE) {
+        const int hw = a.Ho * a.Wo;
+        const int b = m0 / hw, rem0 = m0 - b * hw;                 // host guarantees hw % BM == 0: one image per tile
+        const int oy0 = rem0 / a.Wo, oy1 = (rem0 + BM - 1) / a.Wo;
+        const bool fullw = BM >= a.Wo;
+        const int ox0 = fullw ? 0 : rem0 - oy0 * a.Wo, ox1 = fullw ? a.Wo - 1 : ox0 + BM - 1;
+        for (int ks = tid; ks < a.nk; ks += NT) {
+            const int cs = ks / ntaps, tap = ks - cs * ntaps, c0 = cs * BK;
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            const int* bb = a.bbox + ((long long)b * a.bbox_groups + c0 / 64) * 4;
+            const int y0 = oy0 * a.stride - a.pad + ky, y1 = oy1 * a.stride - a.pad + ky;
+            const int x0 = ox0 * a.stride - a.pad + kx, x1 = ox1 * a.stride - a.pad + kx;
+            s_flag[ks] = (y1 >= bb[0] && y0 <= bb[1] && x1 >= bb[2] && x0 <= bb[3]) ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int cnt = 0;
+            for (int base = 0; base < a.nk; base += 64) {
+                const int ks = base + lane;
+                const bool f = ks < a.nk && s_flag[ks];
+                const unsigned long long mask = __ballot(f);
+                if (f) {      // packed descriptor: tap | ky << 8 | kx << 12 | channel slab << 16 (no division in the K loop)
+                    const int cs = ks / ntaps, tap = ks - cs * ntaps, ky = tap / a.kw, kx = tap - ky * a.kw;
+                    s_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = tap | (ky << 8) | (kx << 12) | (cs << 16);
+                }
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) s_nact = cnt;
+        }
+        __syncthreads();
+        nact = s_nact;
+    }
+
+    // slab descriptor of the i-th ACTIVE slab.  Dense: an incremental (tap, c0) counter -- no division in the loop.
+    int d_tap = 0, d_ky = 0, d_kx = 0, d_c0 = 0;      // state of the DMA stream (runs 3 slabs ahead of the MFMAs)
+    auto next_slab = [&](int i) -> Slab {
+        Slab s;
+        if constexpr (SPARSE) {
+            const int e = __builtin_amdgcn_readfirstlane(s_list[i < nact ? i : 0]);
+            const int tap = e & 0xff, ky = (e >> 8) & 0xf, kx = (e >> 12) & 0xf, cs = e >> 16;
+            s.tap = tap;
+            s.toff = ((ky * a.W + kx) * a.in_cs + cs * BK) * ES;
+            s.k0 = tap * a.Cin + cs * BK;
+        } else {
+            s.tap = d_tap;
+            s.toff = ((d_ky * a.W + d_kx) * a.in_cs + d_c0) * ES;
+            s.k0 = d_tap * a.Cin + d_c0;
+            ++d_tap;
+            if (++d_kx == a.kw) { d_kx = 0; ++d_ky; }
+            if (d_tap == ntaps) { d_tap = 0; d_ky = 0; d_kx = 0; d_c0 += BK; }
+        }
+        return s;
+    };
+
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    // DMA piece p of slab s into ring buffer `buf`: wave w fills rows 8w..8w+7 of every RPP-row pass (1 KiB each)
+    auto dma_piece = [&](auto PIdx, const Slab& s, unsigned bufaddr, bool live) {
+        constexpr int p = decltype(PIdx)::value;
+        if constexpr (p < ACH) {
+            const bool ok = ((amask[p] >> s.tap) & 1u) && live;
+            lds_dma16_untracked(xd, bufaddr + p * (RPP * ROW), ok ? (unsigned)(avoff[p] + s.toff) : OOB, 0);
+        } else {
+            constexpr int i = p - ACH;
+            lds_dma16_untracked(wd, bufaddr + A_BYTES + i * (RPP * ROW), live ? bvoff[i] : OOB, (unsigned)(s.k0 * ES));
+        }
+    };
+    auto dma_slab = [&](const Slab& s, int buf, bool live) {
+        const unsigned ba = lds_base + buf * BUF_BYTES + wave * 1024;
+        [&]<int... P>(std::integer_sequence<int, P...>) {
+            (dma_piece(std::integral_constant<int, P>{}, s, ba, live), ...);
+        }(std::make_integer_sequence<int, NP>{});
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment addressing (conv.hip): lane (i = lane & 31, h = lane >> 5) reads chunks h*4+q of row i, un-swizzled
+    const int frag_a = (wm * MI * 32 + (lane & 31)) * ROW;
+    const int frag_b = A_BYTES + (wn * NJ * 32 + (lane & 31)) * ROW;
+    int qoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) qoff[q] = (((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4;
+
+    uint4 fa[2][MI][4], fb[2][NJ][4];              // two register sets of MFMA operands
+    // read r (0 .. NREAD-1) of a slab's fragments, q-major so the first MFMAs' operands arrive first
+    auto frag_read = [&](auto Set, auto RIdx, const char* bufp) {
+        constexpr int set = decltype(Set)::value, r = decltype(RIdx)::value;
+        constexpr int q = r / (MI + NJ), t = r - q * (MI + NJ);
+        if constexpr (t < MI) fa[set][t][q] = *reinterpret_cast<const uint4*>(bufp + frag_a + t * 32 * ROW + qoff[q]);
+        else fb[set][t - MI][q] = *reinterpret_cast<const uint4*>(bufp + frag_b + (t - MI) * 32 * ROW + qoff[q]);
+    };
+
+    // ---- prologue: three slabs in flight, the first one's fragments in register set 0
+    {
+        const Slab s0 = next_slab(0);
+        dma_slab(s0, 0, nact > 0);
+        const Slab s1 = next_slab(1);
+        dma_slab(s1, 1, nact > 1);
+        const Slab s2 = next_slab(2);
+        dma_slab(s2, 2, nact > 2);
+        wait_vmcnt<2 * NP>();
+        __syncthreads();
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}, smem), ...);
+        }(std::make_integer_sequence<int, NREAD>{});
+    }
+
+    // iteration ks (fragments of slab ks are in register set P; DMAs of slabs ks+1, ks+2 are in flight):
+    //   wait until only slab ks+2's pieces are outstanding, barrier (everyone's pieces of slab ks+1 have landed and
+    //   everyone's reads of buffer ks % 3 have returned), then MFMA(ks) || ds_read(ks+1) || DMA(ks+3 -> buffer ks % 3)
+    int buf = 0;                                   // ks % 3
+    auto iteration = [&](auto Pc, int ks) {
+        constexpr int P = decltype(Pc)::value;
+        wait_vmcnt<NP>();
+        __syncthreads();
+        const int nb = buf == 2 ? 0 : buf + 1;     // (ks + 1) % 3
+        const char* rbuf = smem + nb * BUF_BYTES;
+        const bool live = ks + 3 < nact;
+        const Slab sd = next_slab(ks + 3);
+        const unsigned ba = lds_base + buf * BUF_BYTES + wave * 1024;
+        // slot plan: MFMA t is followed by RPS fragment reads (slots [0, H)) or DPS DMA pieces (slots [H, NSLOT))
+        constexpr int RPS = (NREAD + NSLOT / 2 - 1) / (NSLOT / 2);
+        constexpr int H = (NREAD + RPS - 1) / RPS;
+        constexpr int DPS = (NP + NSLOT - H - 1) / (NSLOT - H);
+        static_assert(H < NSLOT, "slot plan");
+        [&]<int... T>(std::integer_sequence<int, T...>) {
+            (([&] {
+                 constexpr int t = T;
+                 constexpr int q = t / (MI * NJ), ij = t - q * (MI * NJ), i = ij / NJ, j = ij - i * NJ;
+                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[P][i][q]),
+                                                                     __builtin_bit_cast(bf16x8, fb[P][j][q]), acc[i][j], 0, 0, 0);
+                 if constexpr (t < H) {
+                     [&]<int... R>(std::integer_sequence<int, R...>) {
+                         (([&] {
+                              if constexpr (t * RPS + R < NREAD)
+                                  frag_read(std::integral_constant<int, P ^ 1>{}, std::integral_constant<int, t * RPS + R>{}, rbuf);
+                          }()),
+                          ...);
+                     }(std::make_integer_sequence<int, RPS>{});
+                 } else {
+                     [&]<int... D>(std::integer_sequence<int, D...>) {
+                         (([&] {
+                              if constexpr ((t - H) * DPS + D < NP)
+                                  dma_piece(std::integral_constant<int, (t - H) * DPS + D>{}, sd, ba, live);
+                          }()),
+                          ...);
+                     }(std::make_integer_sequence<int, DPS>{});
+                 }
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, NSLOT>{});
+        buf = nb;
+    };
+    for (int ks = 0; ks < nact; ks += 2) {
+        iteration(std::integral_constant<int, 0>{}, ks);
+        if (ks + 1 < nact) iteration(std::integral_constant<int, 1>{}, ks + 1);
+    }
+    wait_vmcnt<0>();                               // trailing (out-of-range) refills must land before the LDS is reused
+    __syncthreads();
+
+    epilogue<TO, MI, NJ, WM, WN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Halo-reuse variant for stride-1 kh x kw convolutions (every 3x3 on the path).  The pipelined kernel above is bound by
+// the CU's global -> LDS path (measured: 48 KB per slab at ~43 B/clk/CU = 1130 cycles against 1024 MFMA cycles), and 2/3
+// of those bytes are im2col re-reads: the kh*kw taps of one channel slab gather the SAME input pixels, shifted.  Here a
+// tile of BM output pixels is a rectangle of whole image rows (or whole small images); its input halo patch
+// ((rows + kh - 1) x (Wo + kw - 1) pixels x 64 channels, <= 400 rows of 128 B) is DMA'd ONCE per channel slab into a
+// double-buffered LDS patch and every tap reads its MFMA A-operand from the patch at a shifted row.  Per channel slab the
+// CU now fetches ~npr + kh*kw*BN rows instead of kh*kw*(BM + BN): 2.2x fewer bytes for 256x128 tiles.  Zero padding is
+// the hardware bounds check on the patch DMA (no per-tap masks).  The weight slabs keep the 3-deep ring; the next
+// channel slab's patch pieces ride along, one per tap iteration.  fp32 accumulation order is unchanged (bit-identical).
+struct PatchGeom {
+    int PW, PH;      // patch width / height in input pixels (one segment)
+    int nseg;        // segments per tile: 1 (rows of one image) or BM / (Ho*Wo) whole images
+    int seg_px;      // output pixels per segment
+    int npr;         // patch rows in total = nseg * PH * PW  (<= PATCH_MAX_ROWS)
+};
+constexpr int PATCH_MAX_ROWS = 400;
+
+struct KPos {        // position in the (channel slab, tap) stream
+    int ci, tap, ky, kx;
+};
+
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, int PMAX = PATCH_MAX_ROWS>
+__global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a, PatchGeom g) {
+    typedef bf16_t TI;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    constexpr int RPP = NT / 8;                        // rows per DMA pass of the workgroup
+    constexpr int BCH = BN / RPP;                      // weight DMA pieces per thread per slab
+    constexpr int MAXPP = (PMAX + RPP - 1) / RPP;             // patch DMA passes per channel slab
+    constexpr int ROW = 128;
+    constexpr int P_BYTES = PMAX * ROW, B_BYTES = BN * ROW;
+    constexpr int NBUF = 3;
+    constexpr int RING_BYTES = 2 * P_BYTES + NBUF * B_BYTES;
+    constexpr int STAGE_BYTES = BM * BN * 4;
+    constexpr int SMEM = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
+    constexpr int BK = 64, ES = 2;
+    static_assert(BN % RPP == 0, "weight tile rows must be a multiple of the DMA pass");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    __shared__ int s_list[SPARSE ? 64 : 1];            // active channel slabs (sparse-K at (hand, bone) granularity)
+    __shared__ int s_nact;
+
+    const int nwg = a.tiles_m * a.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+
+    const TI* __restrict__ x = (const TI*)a.x;
+    const TI* __restrict__ w = (const TI*)a.w;
+    const i32x4 xd = {(int)(unsigned)(unsigned long long)x, (int)(unsigned)((unsigned long long)x >> 32), (int)a.x_bytes, 0x00020000};
+    const i32x4 wd = {(int)(unsigned)(unsigned long long)w, (int)(unsigned)((unsigned long long)w >> 32), (int)a.w_bytes, 0x00020000};
+    constexpr unsigned OOB = 0x80000000u;
+    const int ntaps = a.kh * a.kw;
+    const int hw = a.Ho * a.Wo;
+    const int b0 = m0 / hw, y0 = (m0 - b0 * hw) / a.Wo;        // the tile starts at the beginning of an image row
+
+    // ---- patch DMA source of this thread: patch row RPP * i + (tid >> 3), chunk (tid & 7) ^ swizzle, channel slab 0
+    unsigned pvoff[MAXPP];
+    const int col = (tid & 7) ^ ((tid >> 4) & 7);
+    const int pseg = g.PH * g.PW;
+#pragma unroll
+    for (int i = 0; i < MAXPP; ++i) {
+        const int prow = RPP * i + (tid >> 3);
+        pvoff[i] = OOB;
+        if (prow < g.npr) {
+            const int seg = prow / pseg, rem = prow - seg * pseg;
+            const int py = rem / g.PW, px = rem - py * g.PW;
+            const int b = g.nseg > 1 ? b0 + seg : b0;
+            const int iy = (g.nseg > 1 ? 0 : y0) + py - a.pad, ix = px - a.pad;
+            if (b < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                pvoff[i] = (unsigned)((((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + col * 8) * ES);
+        }
+    }
+    // passes this wave takes part in (a piece always writes the wave's 8 rows; rows >= npr are zero-filled)
+    const int npr8 = (g.npr + 7) & ~7;
+    const int npw = npr8 > 8 * wave ? (npr8 - 8 * wave + RPP - 1) / RPP : 0;
+    unsigned bvoff[BCH];
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int n = n0 + (tid >> 3) + RPP * i;
+        bvoff[i] = n < a.Cout ? (unsigned)((n * a.K + col * 8) * ES) : OOB;
+    }
+
+    // ---- optional sparse-K: channel slabs (= 64-channel input groups) whose support can touch the tile's rows
+    int ncs = a.Cin / BK;
+    if constexpr (SPARSE) {
+        const int oy1 = y0 + BM / a.Wo - 1;                        // host guarantees one image per tile when sparse
+        if (tid < 64) {
+            int cnt = 0;
+            for (int base = 0; base < ncs; base += 64) {
+                const int cs = base + lane;
+                bool f = false;
+                if (cs < ncs) {
+                    const int* bb = a.bbox + ((long long)b0 * a.bbox_groups + cs) * 4;
+                    f = oy1 + (a.kh - 1 - a.pad) >= bb[0] && y0 - a.pad <= bb[1] && bb[2] <= bb[3];
+                }
+                const unsigned long long mask = __ballot(f);
+                if (f) s_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = cs;
+                cnt += __popcll(mask);
+            }
+            if (lane == 0) s_nact = cnt;
+        }
+        __syncthreads();
+        ncs = s_nact;
+    }
+    const int nslab = ncs * ntaps;
+    auto c0_of = [&](int ci) -> int {                  // first channel of the ci-th active channel slab
+        if constexpr (SPARSE) return __builtin_amdgcn_readfirstlane(s_list[ci < ncs ? ci : 0]) * BK;
+        else return ci * BK;
+    };
+    auto advance = [&](KPos& p) {
+        ++p.tap;
+        if (++p.kx == a.kw) { p.kx = 0; ++p.ky; }
+        if (p.tap == ntaps) { p.tap = 0; p.ky = 0; p.kx = 0; ++p.ci; }
+    };
+
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned bring = lds_base + 2 * P_BYTES + wave * 1024;
+    // weight piece i of the slab at position p into ring buffer `buf`
+    auto dma_b = [&](auto I, const KPos& p, int c0, int buf, bool live) {
+        constexpr int i = decltype(I)::value;
+        lds_dma16_m0(wd, bring + buf * B_BYTES + i * (RPP * ROW), live ? bvoff[i] : OOB, (unsigned)((p.tap * a.Cin + c0) * ES));
+    };
+    // patch piece t (wave-uniform) of the channel slab starting at channel c0 into patch buffer pb
+    // (an if-chain over static indices: a dynamically indexed pvoff[] would be demoted to scratch memory, and the
+    //  scratch load's vmcnt(0) would drain the DMA ring)
+    auto dma_patch = [&](int t, int c0, int pb, bool live) {
+        const unsigned dst = lds_base + pb * P_BYTES + (RPP * t + 8 * wave) * ROW;
+#pragma unroll
+        for (int i = 0; i < MAXPP; ++i)
+            if (t == i) lds_dma16_m0(xd, dst, live ? pvoff[i] : OOB, (unsigned)(c0 * ES));
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- fragment addressing.  A: lane (i = lane & 31, h = lane >> 5) reads chunks h*4+q of the patch row of its output
+    //      pixel shifted by the tap; B: as in conv.hip.  Chunk c of LDS row r sits at position c ^ ((r >> 1) & 7).
+    int pr0[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = wm * MI * 32 + i * 32 + (lane & 31);
+        const int seg = r / g.seg_px, rr = r - seg * g.seg_px;
+        const int y = rr / a.Wo, xx = rr - y * a.Wo;
+        pr0[i] = seg * pseg + y * g.PW + xx;
+    }
+    int hq4[4], qoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        hq4[q] = ((lane >> 5) * 4 + q) << 4;
+        qoff[q] = (((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4;
+    }
+    const int frag_b = (wn * NJ * 32 + (lane & 31)) * ROW;
+
+    uint4 fa[MI][4], fb[NJ][4];
+    auto frag_load = [&](const KPos& p, const char* bbuf) {
+        const int shift = p.ky * g.PW + p.kx;
+        const int pbase = (p.ci & 1) * P_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = pr0[i] + shift;
+                fa[i][q] = *reinterpret_cast<const uint4*>(smem + pbase + row * ROW + (hq4[q] ^ ((row << 3) & 0x70)));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j][q] = *reinterpret_cast<const uint4*>(bbuf + frag_b + j * 32 * ROW + qoff[q]);
+        }
+    };
+
+    // ---- prologue: patch of channel slab 0 and weight slabs 0, 1 (the loop issues slab s+2 during slab s)
+    KPos cur = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
+    {
+        const int c0 = c0_of(0);
+#pragma unroll
+        for (int t = 0; t < MAXPP; ++t)
+            if (t < npw) dma_patch(t, c0, 0, nslab > 0);
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int cb = c0_of(dm.ci);
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (dma_b(std::integral_constant<int, I>{}, dm, cb, sidx, sidx < nslab), ...);
+            }(std::make_integer_sequence<int, BCH>{});
+            advance(dm);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
+
+    // ---- main loop: two wave groups in ping-pong.  Waves w and w + 4 share a SIMD; group 0 = waves 0..3, group 1 = 4..7.
+    // Each slab has a memory phase M (16 ds_read_b128 of the slab's fragments + this wave's DMA pieces of slab s+2) and a
+    // compute phase C (16 MFMAs, nothing else); group 1 runs one phase behind group 0, so on every SIMD one wave is in C
+    // while the other is in M and neither wave's memory instructions ever sit in front of its own MFMAs.
+    //   slot:      2s          2s+1        2s+2
+    //   group 0:   M(s)        C(s)        M(s+1)
+    //   group 1:   C(s-1)      M(s)        C(s)
+    // Slab s must have landed before slot 2s: every wave waits for its own pieces of slab s (everything but the pieces of
+    // slab s+1 it issued last) at the end of slot 2s-1, which is the end of C for group 0 and the end of M for group 1.
+    // Slab s+2 goes into the ring buffer of slab s-1, last read by group 1 in slot 2s-1.
+    const bool grp = wave >= (WM * WN) / 2;
+    if (grp) __builtin_amdgcn_s_barrier();
+    int buf = 0;                                   // s % 3
+    for (int sidx = 0; sidx < nslab; ++sidx) {
+        // ---- M(s)
+        frag_load(cur, smem + 2 * P_BYTES + buf * B_BYTES);
+        const int nb2 = buf == 0 ? 2 : buf - 1;    // (s + 2) % 3
+        const bool pp = cur.tap < npw;
+        if (pp) dma_patch(cur.tap, c0_of(cur.ci + 1), (cur.ci + 1) & 1, cur.ci + 1 < ncs);
+        {
+            const int c0d = c0_of(dm.ci);
+            const bool blive = sidx + 2 < nslab;
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (dma_b(std::integral_constant<int, I>{}, dm, c0d, nb2, blive), ...);
+            }(std::make_integer_sequence<int, BCH>{});
+        }
+        if (grp) {
+            if (pp) wait_vmcnt<BCH + 1>();
+            else wait_vmcnt<BCH>();
+        }
+        __syncthreads();                            // (drains the ds_reads: lgkmcnt(0))
+        // ---- C(s)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]),
+                                                                        __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (!grp) {
+            if (pp) wait_vmcnt<BCH + 1>();
+            else wait_vmcnt<BCH>();
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep the MFMAs above the phase-closing barrier
+        __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
+        advance(cur);
+        advance(dm);
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();        // group 1 executed one more barrier up front
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    epilogue<TO, MI, NJ, WM, WN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+// geometry of the halo patch for BM-pixel tiles; false if the layer does not fit the patch kernel
+static bool patch_geometry(const ConvArgs& a, int bm, PatchGeom* g) {
+    const int ntaps = a.kh * a.kw;
+    if (a.stride != 1 || ntaps < 4 || bm % a.Wo != 0) return false;
+    const int rows = bm / a.Wo;
+    int rows_seg;
+    if (rows <= a.Ho) {
+        if (a.Ho % rows != 0) return false;
+        g->nseg = 1;
+        rows_seg = rows;
+    } else {
+        if (rows % a.Ho != 0) return false;
+        g->nseg = rows / a.Ho;
+        rows_seg = a.Ho;
+    }
+    g->PW = a.Wo + a.kw - 1;
+    g->PH = rows_seg + a.kh - 1;
+    g->seg_px = rows_seg * a.Wo;
+    g->npr = g->nseg * g->PH * g->PW;
+    if (g->npr > PATCH_MAX_ROWS) return false;
+    // one patch piece per tap iteration, the last one at least one iteration before the next channel slab starts
+    if ((g->npr + 63) / 64 > ntaps - 1) return false;
+    return true;
+}
+
+template <typename TO, int MI, int NJ, int WM, int WN>
+void launch_tile(ConvArgs a, hipStream_t s) {
+    constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    dim3 grid(a.tiles_m * a.tiles_n), block(64 * WM * WN);
+    static const int use_patch = getenv("DIR_PATCH") ? atoi(getenv("DIR_PATCH")) : 0;           // halo-reuse kernel: opt-in
+    PatchGeom g;
+    if (use_patch && patch_geometry(a, BM, &g) && (!a.bbox || a.Cin / 64 <= 64)) {
+        if (a.bbox) hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a, g);
+        else hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
+        return;
+    }
+    if (a.bbox) hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a);
+}
+
+}  // namespace
+
+bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s) {
+    // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
+    static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
+    static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
+    if (force == 0 || a.pre_scale || !(a.flags & 4) || a.nk < min_nk) return false;
+    const long long hw = (long long)a.Ho * a.Wo;
+    auto tiles = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
+    int shape = 0;
+    if (force > 0) shape = force;
+    else {
+        // largest tile that still gives (nearly) every CU a workgroup; 64-wide N tile only for Cout <= 64
+        const long long need = (long long)num_cu * 3 / 4;
+        if (a.Cout <= 64) shape = tiles(256, 64) >= need ? 3 : 0;
+        else if (tiles(256, 128) >= need) shape = 1;
+        else if (tiles(128, 128) >= need) shape = 2;
+    }
+    if (shape == 0) return false;
+    const int bm = shape == 2 ? 128 : 256;
+    ConvArgs b = a;
+    if (b.bbox && hw % bm != 0) b.bbox = nullptr;          // sparse-K needs whole tiles inside one image
+#define DIR_PIPE_LAUNCH(MI_, NJ_, WM_, WN_)                                       \
+    do {                                                                          \
+        if (out_f32) launch_tile<float, MI_, NJ_, WM_, WN_>(b, s);                \
+        else launch_tile<bf16_t, MI_, NJ_, WM_, WN_>(b, s);                       \
+    } while (0)
+    if (shape == 1) DIR_PIPE_LAUNCH(2, 2, 4, 2);
+    else if (shape == 2) DIR_PIPE_LAUNCH(2, 1, 2, 4);
+    else DIR_PIPE_LAUNCH(2, 1, 4, 2);
+#undef DIR_PIPE_LAUNCH
+    return true;
+}
+
+}  // namespace convk
+}  // namespace dir

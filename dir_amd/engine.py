@@ -11,6 +11,8 @@ State-dict keys are the reference's (963 keys, tests/golden/manifest_dir.json).
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _capi
@@ -415,6 +417,15 @@ class DirEngine(object):
         _capi.check(_capi.lib().dir_upsample2x_bilinear(_capi.ptr(x), _capi.ptr(out), B, H, W, Cc, out.shape[3], coff,
                                                         _dt(self.dtype), _capi.stream_ptr()), 'dir_upsample2x_bilinear')
 
+    overlap = os.environ.get('DIR_OVERLAP', '1') != '0'     # run the skip branches on a side stream (False: everything on the current stream, e.g. to time kernels alone)
+
+    def _side_stream(self):
+        if not self.overlap:
+            return torch.cuda.current_stream()
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, img, want_proj_feat=True, taps=None):
         """img: float32 NCHW [B,3,256,256] on the GPU.  Returns outs_list exactly like DIR.forward (models/dir.py:521-540);
@@ -425,19 +436,34 @@ class DirEngine(object):
         B = img.shape[0]
         feats = self.bb(img)
         c1, c2, c3, c4 = feats
+        cat4 = torch.empty(B, 16, 16, 2304, device=dev, dtype=dt)
+        cat3 = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
+        # The two skip branches depend on the backbone only.  They run on a side stream so that their convolutions fill the
+        # CUs the latency-bound launches leave idle: skip_layer4 beside init_head / MANO, skip_layer3 beside stage 1's token
+        # path (grid-sample -> P-GCN -> STE -> MANO -> bone_proj: at most 64 workgroups each).  Fork / join is capturable.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        ev_tok = torch.cuda.Event()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.res['skip_layer4'](c3, out=cat4, out_coff=2048)
+            ev_s4 = torch.cuda.Event()
+            ev_s4.record()
         init = self.init_regressor(c4)
         # ---- stage 1 @16x16 (models/dir.py:442-456)
-        cat4 = torch.empty(B, 16, 16, 2304, device=dev, dtype=dt)
         self.upsample_into(c4, cat4, 0)
-        self.res['skip_layer4'](c3, out=cat4, out_coff=2048)
+        main.wait_event(ev_s4)
         enh4_in = torch.empty(B, 16, 16, 512, device=dev, dtype=dt)             # cat(fusion_feat, img_feat)
         self.res['fusion_layer4'](cat4, out=enh4_in, out_coff=0)
+        ev_tok.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev_tok)
+            self.res['skip_layer3'](c2, out=cat3, out_coff=256)
         r4 = self.stage(self.stage4, enh4_in, 512, init, enh4_in, 256, False)
         e4 = self.res['enhance_layer4'](enh4_in)
         # ---- stage 2 @32x32 (models/dir.py:459-471)
-        cat3 = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
         self.upsample_into(e4, cat3, 0)
-        self.res['skip_layer3'](c2, out=cat3, out_coff=256)
+        main.wait_stream(side)
         enh3_in = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
         self.res['fusion_layer3'](cat3, out=enh3_in, out_coff=0)
         r3 = self.stage(self.stage3, enh3_in, 512, r4, enh3_in, 256, want_proj_feat)
