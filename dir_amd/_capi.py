@@ -56,6 +56,10 @@ class InitHeadParams(C.Structure):
                 ('mano_b', C.c_void_p * 2), ('off_w', C.c_void_p), ('off_b', C.c_void_p)]
 
 
+class BoneFusionParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('w_g', 'scale', 'shift')]
+
+
 class EvalInputs(C.Structure):
     _fields_ = [('verts_pd', C.c_void_p * 2), ('pd_offset', C.c_void_p), ('verts_gt', C.c_void_p * 2),
                 ('verts2d_gt', C.c_void_p * 2), ('cam', C.c_void_p), ('jr', C.c_void_p * 2)]
@@ -66,7 +70,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 2          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 3          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -88,6 +92,9 @@ _SIGNATURES = {
     'dir_pgcn_stack_forward_pair': (C.c_int, [C.POINTER(PgcnLayer), C.POINTER(PgcnLayer), _i, _p, _p, _p, _p, _i, _p]),
     'dir_ste_forward': (C.c_int, [C.POINTER(SteParams), _p, _p, _p, _i, _p]),
     'dir_regress_forward': (C.c_int, [C.POINTER(RegressParams), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    'dir_bone_fusion_scratch_bytes': (C.c_size_t, [_i]),
+    'dir_bone_fusion_prepare': (C.c_int, [C.POINTER(BoneFusionParams), _p, _p, _i, _p]),
+    'dir_bone_fusion_forward': (C.c_int, [C.POINTER(BoneFusionParams), _p, _p, _p, _p, _i, _i, C.c_float, _i, _i, _i, _p]),
     'dir_joint_regress_forward': (C.c_int, [_p, _p, _p, _i, _p]),
     'dir_eval_metrics_forward': (C.c_int, [C.POINTER(EvalInputs), C.POINTER(EvalOutputs), _i, _i, _i, _p]),
     'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),

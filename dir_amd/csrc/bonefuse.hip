@@ -1,0 +1,241 @@
+// Factorised bone fusion: Joint2BoneFeature.bone_proj (models/dir.py:132-174) + fusion[0..2] (3x3 conv 2560 -> 256,
+// BatchNorm, ReLU; models/dir.py:57-62) WITHOUT the [B,S,S,2560] bone map.
+//
+// The rasterised operand is rank 2 per bone:  img[p, hb, c] = m(p,hb) * (wa(p,hb) * fa[hb][c] + wb(p,hb) * fb[hb][c]),
+// fa / fb = the 64-channel token features of the bone's two end joints, (m, wa, wb) per-pixel scalars.  Hence
+//
+//   conv(img)[p, n] = sum_tap sum_e  Wgt[p + tap, e] * G[tap, e, n],      e = (hand, bone, end) in [0, 80)
+//   G[tap, (hb, end), n] = sum_c f_end[hb][c] * W[n, tap, hb*64 + c]      (per sample: 80 x 9 x 256 numbers)
+//   Wgt[p, (hb, 0)] = m * wa,  Wgt[p, (hb, 1)] = m * wb
+//
+// i.e. a K = 9 * 80 = 720 reduction instead of K = 23040: 32x fewer MACs than the dense convolution, no 335 MB bone map
+// written and re-read, and no sparsity bookkeeping.  Mathematically identical to the reference; the summation is
+// re-associated, so this path is used in the bf16 throughput mode only (the fp32 parity mode keeps bone_proj + conv).
+//
+//   bone_g_kernel    : G for every sample, exact fp32 MFMA (v_mfma_f32_16x16x4_f32) over the bf16-rounded weights;
+//                      one workgroup per (tap, hand-bone): [B*2 ends, 64] x [64, 256]; written as bf16 pairs (end 0, end 1)
+//   bone_fuse_kernel : one workgroup per (sample, 256-pixel strip, 128 output channels): the strip's halo patch of Wgt
+//                      (<= 400 pixels x 80) is computed ONCE into LDS with bone_proj's own distance / weight formulas
+//                      (bit-identical mask), every tap reads its MFMA A operand from the patch at a shifted row (as
+//                      conv_pipe.hip's halo-reuse kernel), G_tap streams through a double-buffered LDS tile;
+//                      v_mfma_f32_32x32x16_bf16, fp32 accumulate, BN + ReLU + coalesced bf16 NHWC epilogue.
+#include "bone_common.h"
+#include "conv_common.h"
+#include "dir_mfma.h"
+
+namespace dir {
+namespace {
+
+using namespace dir::convk;
+using dir::bone::bone_weights;
+using dir::bone::kChild;
+using dir::bone::kParent;
+
+constexpr int NE = 80;            // bone ends: 2 hands x 20 bones x 2
+constexpr int EP = 88;            // LDS row length in bf16: 176-byte pitch = 11 x 16 B, odd -> conflict-free ds_read_b128
+constexpr int NCOUT = 256;        // fusion.0 output channels
+constexpr int NTAP = 9;
+
+// ---------------------------------------------------------------------------------------------------------------- G
+struct GArgs {
+    const float* w_g;     // [9][40][64][256]
+    const float* emb;     // [B][42][64]
+    unsigned* g;          // [B][9][40][256] words = (bf16 end 0) | (bf16 end 1) << 16
+    int B;
+};
+
+constexpr int G_ROWS = 128, G_LD = 66;      // (sample, end) rows per pass; lda % 32 == 2 (dir_mfma.h)
+
+__global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
+    __shared__ float s_f[G_ROWS * G_LD];
+    const int tap = blockIdx.x / 40, hb = blockIdx.x - tap * 40, hand = hb / 20, bone = hb - hand * 20;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jpar = hand * 21 + kParent[bone], jchi = hand * 21 + kChild[bone];
+    const float* wt = a.w_g + ((long long)(tap * 40 + hb) * 64) * NCOUT;
+    for (int b0 = 0; b0 < a.B; b0 += G_ROWS / 2) {
+        __syncthreads();
+        for (int i = tid; i < G_ROWS * 64; i += 256) {
+            const int r = i >> 6, c = i & 63, b = b0 + (r >> 1);
+            s_f[r * G_LD + c] = b < a.B ? a.emb[((long long)b * 42 + ((r & 1) ? jchi : jpar)) * 64 + c] : 0.f;
+        }
+        __syncthreads();
+        for (int nt = wave; nt < NCOUT / 16; nt += 4) {
+            f32x4 acc[G_ROWS / 16];
+#pragma unroll
+            for (int m = 0; m < G_ROWS / 16; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mfma_tile_f32<64, G_ROWS / 16>(s_f, G_LD, wt, NCOUT, nt * 16, lane, acc);
+            // lane holds column n = nt*16 + (lane & 15), rows m*16 + 4*(lane >> 4) + r: two samples x two ends
+            const int n = nt * 16 + (lane & 15);
+#pragma unroll
+            for (int m = 0; m < G_ROWS / 16; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int b = b0 + m * 8 + 2 * (lane >> 4) + s;
+                    if (b < a.B)
+                        a.g[(((long long)b * NTAP + tap) * 40 + hb) * NCOUT + n] =
+                            (unsigned)f2bf(acc[m][2 * s]) | ((unsigned)f2bf(acc[m][2 * s + 1]) << 16);
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------- fuse
+struct FuseArgs {
+    ConvArgs c;           // epilogue description: scale, shift, y, M, Cout, out_cs, out_co, flags (res = nullptr)
+    const float* uv[2];   // [B][21][2] normalised joint uv, left / right
+    const unsigned* g;
+    int S;
+    float distance;
+    int PW, PH, npr;      // halo patch geometry of one 256-pixel strip
+};
+
+constexpr int FUSE_MAX_ROWS = 400;
+
+__global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
+    constexpr int MI = 2, NJ = 2, WM = 4, WN = 2, NT = 512, BM = 256, BN = 128;
+    constexpr int PITCH = EP * 2;                                   // 176 B
+    constexpr int P_BYTES = FUSE_MAX_ROWS * PITCH, G_BYTES = BN * PITCH;
+    constexpr int STAGE_BYTES = BM * BN * 4;
+    constexpr int SMEM = P_BYTES + 2 * G_BYTES > STAGE_BYTES ? P_BYTES + 2 * G_BYTES : STAGE_BYTES;
+    constexpr int GW = 40 * BN / NT;                                 // G words per thread per tap (10)
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    __shared__ float s_uv[84];
+
+    const int S = a.S, hw = S * S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int tn = blockIdx.x & 1, tm = blockIdx.x >> 1;            // the two N halves of a strip are neighbours (same XCD pair)
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int b = m0 / hw, y0 = (m0 - b * hw) / S;
+
+    // ---- G_tap loader: word (hb, n) -> LDS [n][hb*2 .. hb*2+1]; consecutive threads read consecutive n (coalesced)
+    const unsigned* gsrc = a.g + ((long long)b * NTAP * 40) * NCOUT + n0;
+    unsigned greg[GW];
+    auto g_load = [&](int tap) {
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int w = tid + NT * k, hb = w / BN, n = w - hb * BN;
+            greg[k] = gsrc[((long long)tap * 40 + hb) * NCOUT + n];
+        }
+    };
+    auto g_store = [&](int buf) {
+        char* gb = smem + P_BYTES + buf * G_BYTES;
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int w = tid + NT * k, hb = w / BN, n = w - hb * BN;
+            *reinterpret_cast<unsigned*>(gb + n * PITCH + hb * 4) = greg[k];
+        }
+    };
+    g_load(0);
+
+    // ---- the strip's halo patch of Wgt: rows = (PH x PW) input pixels, 80 bf16 per row
+    if (tid < 84) {
+#pragma clang fp contract(off)
+        const int hand = tid / 42, r = tid - hand * 42;
+        const float v = a.uv[hand][(long long)b * 42 + r];
+        s_uv[tid] = (v + 1.f) / 2.f * (float)S;                      // models/dir.py:150
+    }
+    __syncthreads();
+    for (int i = tid; i < a.npr * 40; i += NT) {
+        const int prow = i / 40, hb = i - prow * 40, hand = hb / 20, bone = hb - hand * 20;
+        const int py = prow / a.PW, px = prow - py * a.PW;
+        const int iy = y0 + py - 1, ix = px - 1;                      // 3x3, pad 1
+        unsigned word = 0;
+        if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+            const float* uv = s_uv + hand * 42;
+            const int pa = kParent[bone], ch = kChild[bone];
+            float wa, wb;
+            bool in;
+            bone_weights((float)ix + 0.5f, (float)iy + 0.5f, uv[2 * pa], uv[2 * pa + 1], uv[2 * ch], uv[2 * ch + 1], a.distance, wa, wb, in);
+            if (in) word = (unsigned)f2bf(wa) | ((unsigned)f2bf(wb) << 16);   // torch.where(mask, v, 0), models/dir.py:172
+        }
+        *reinterpret_cast<unsigned*>(smem + prow * PITCH + hb * 4) = word;
+    }
+    g_store(0);
+    __syncthreads();
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // lane (i = lane & 31, h = lane >> 5): k16-step s reads the 16 bytes at e = s*16 + h*8 of its A / B row
+    int pr0[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = wm * MI * 32 + i * 32 + (lane & 31);
+        const int y = r / S, x = r - y * S;
+        pr0[i] = y * a.PW + x;
+    }
+    const int hoff = (lane >> 5) * 16;
+    const int frag_b = (wn * NJ * 32 + (lane & 31)) * PITCH + hoff;
+
+    for (int tap = 0; tap < NTAP; ++tap) {
+        if (tap + 1 < NTAP) g_load(tap + 1);                          // in flight during this tap's MFMAs
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* gb = smem + P_BYTES + (tap & 1) * G_BYTES + frag_b;
+        const int shift = (ky * a.PW + kx) * PITCH + hoff;
+#pragma unroll
+        for (int s = 0; s < NE / 16; ++s) {
+            uint4 fa[MI], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const uint4*>(smem + pr0[i] * PITCH + shift + s * 32);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const uint4*>(gb + j * 32 * PITCH + s * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+        if (tap + 1 < NTAP) g_store((tap + 1) & 1);                   // buffer (tap+1)&1 was last read in tap-1
+        __syncthreads();
+    }
+
+    ConvArgs c = a.c;
+    epilogue_tile<bf16_t, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
+}  // namespace
+}  // namespace dir
+
+extern "C" size_t dir_bone_fusion_scratch_bytes(int B) { return (size_t)(B > 0 ? B : 0) * dir::NTAP * 40 * dir::NCOUT * 4; }
+
+extern "C" int dir_bone_fusion_prepare(const dir_bone_fusion_params* p, const float* emb, void* scratch, int B, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(p && p->w_g && emb && scratch, "dir_bone_fusion_prepare: null pointer");
+    DIR_REQUIRE(B >= 0, "dir_bone_fusion_prepare: B=%d", B);
+    if (B == 0) return DIR_OK;
+    GArgs ga{p->w_g, emb, (unsigned*)scratch, B};
+    hipLaunchKernelGGL(bone_g_kernel, dim3(NTAP * 40), dim3(256), 0, (hipStream_t)stream, ga);
+    return dir::check_launch("dir_bone_fusion_prepare");
+}
+
+extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const float* uv_left, const float* uv_right,
+                                       const void* scratch, void* y, int B, int S, float distance, int out_cstride,
+                                       int out_coff, int relu, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(p && uv_left && uv_right && scratch && y, "dir_bone_fusion_forward: null pointer");
+    DIR_REQUIRE(B >= 0, "dir_bone_fusion_forward: B=%d", B);
+    if (B == 0) return DIR_OK;
+    DIR_REQUIRE(S > 0 && 256 % S == 0 && (S * S) % 256 == 0, "dir_bone_fusion_forward: S=%d (needs 256 %% S == 0 and S*S %% 256 == 0)", S);
+    const int ocs = out_cstride ? out_cstride : NCOUT;
+    DIR_REQUIRE(ocs % 8 == 0 && out_coff % 8 == 0 && out_coff + NCOUT <= ocs, "dir_bone_fusion_forward: output slice must be 16-byte aligned");
+    const long long M = (long long)B * S * S;
+    DIR_REQUIRE(M < (1ll << 31), "dir_bone_fusion_forward: too many pixels");
+    FuseArgs fa{};
+    fa.c.scale = p->scale; fa.c.shift = p->shift; fa.c.res = nullptr; fa.c.y = y;
+    fa.c.M = (int)M; fa.c.Cout = NCOUT; fa.c.out_cs = ocs; fa.c.out_co = out_coff; fa.c.res_cs = 0; fa.c.res_co = 0;
+    fa.c.flags = (relu ? 1 : 0) | 4;
+    fa.uv[0] = uv_left; fa.uv[1] = uv_right; fa.g = (const unsigned*)scratch; fa.S = S; fa.distance = distance;
+    const int rows = 256 / S;
+    fa.PW = S + 2; fa.PH = rows + 2; fa.npr = fa.PH * fa.PW;
+    DIR_REQUIRE(fa.npr <= FUSE_MAX_ROWS, "dir_bone_fusion_forward: halo patch of %d rows does not fit", fa.npr);
+    hipLaunchKernelGGL(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    return dir::check_launch("dir_bone_fusion_forward");
+}

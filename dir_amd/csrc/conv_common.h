@@ -153,6 +153,54 @@ template <> struct OutVec<bf16_t> {
 };
 
 
+// Epilogue of the 8-wave kernels (conv_pipe.hip, bonefuse.hip): tile of (32*MI*WM) x (32*NJ*WN), wave (wm, wn).
+// scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM (conv.hip's epilogue)
+template <typename TO, int MI, int NJ, int WM, int WN>
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[MI][NJ], char* smem, int m0, int n0, int wm, int wn,
+                                         int tid, int lane) {
+    constexpr int NT = 64 * WM * WN, BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    TO* __restrict__ y = (TO*)a.y;
+    const TO* __restrict__ res = (const TO*)a.res;
+    const bool relu = (a.flags & 1) != 0;
+    float* st = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cl = wn * NJ * 32 + j * 32 + (lane & 31);
+        const int n = n0 + cl;
+        const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+        const float sh = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * MI * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                st[rl * BN + cl] = fmaf(acc[i][j][r], sc, sh);
+            }
+    }
+    __syncthreads();
+    constexpr int VN = OutVec<TO>::N, CPR = BN / VN;
+    for (int c = tid; c < BM * CPR; c += NT) {
+        const int rl = c / CPR, cc = (c - rl * CPR) * VN;
+        const int m = m0 + rl, n = n0 + cc;
+        if (m >= a.M || n >= a.Cout) continue;
+        float v[VN];
+        const float4* sp = reinterpret_cast<const float4*>(st + rl * BN + cc);
+#pragma unroll
+        for (int q = 0; q < VN / 4; ++q) { const float4 t = sp[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+        if (res) {
+            float rv[VN];
+            OutVec<TO>::load(res + (long long)m * a.res_cs + a.res_co + n, rv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] += rv[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        OutVec<TO>::store(y + (long long)m * a.out_cs + a.out_co + n, v);
+    }
+}
+
 // conv_pipe.hip: returns true if it took the launch (bf16 input, no pre-activation, long reduction, enough tiles)
 bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s);
 

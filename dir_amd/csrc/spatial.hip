@@ -5,7 +5,7 @@
 //                            written straight into a channel slice of the concat buffer
 //   dir_init_head_forward    models/dir.py:263-270 (1x1 conv -> sigmoid attention, attention-weighted pooling, Linears)
 //   dir_bone_proj_forward    models/dir.py:132-174 (bone_proj / lineseg_dists) for both hands, NHWC [B,S,S,2560]
-#include "dir_common.h"
+#include "bone_common.h"
 
 namespace {
 
@@ -233,43 +233,14 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ bone_proj
-__constant__ int kParent[20] = {0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0, 17, 18, 19};
-__constant__ int kChild[20] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20};
-
 struct BoneArgs {
     const float* uv[2]; const float* emb; void* out; float* vis; int* bbox;
     int B, S; float distance;
 };
 
-// correctly rounded hypot (products of two floats are exact in double): ATen's CPU kernel (Sleef hypotf_u05) and
-// glibc are correctly rounded, the device libm's hypotf is not, and pixels lying exactly on the capsule boundary
-// flip on a 1-ulp difference.
-__device__ __forceinline__ float hypot_cr(float x, float y) {
-    return (float)sqrt((double)x * (double)x + (double)y * (double)y);
-}
-
-// point-segment distance exactly as lineseg_dists (models/dir.py:132-144): same fp32 op sequence, no FMA
-// contraction, so the `distance < threshold` mask is bit-identical to the reference's.
-__device__ __forceinline__ void bone_weights(float px, float py, float ax, float ay, float bx, float by, float thr,
-                                             float& wa, float& wb, bool& inside) {
-#pragma clang fp contract(off)
-    const float dbx = bx - ax, dby = by - ay;
-    const float len = hypot_cr(dbx, dby);
-    const float dx = dbx / len, dy = dby / len;
-    const float s = (ax - px) * dx + (ay - py) * dy;
-    const float t = (px - bx) * dx + (py - by) * dy;
-    const float h = fmaxf(fmaxf(s, t), 0.f);
-    const float dpx = px - ax, dpy = py - ay;
-    const float c = dpx * dy - dpy * dx;
-    const float dist = hypot_cr(h, c);
-    inside = dist < thr;                                  // NaN (zero-length bone) -> false, like torch.lt
-    // F.pairwise_distance(p, a): || p - a + 1e-6 ||_2  (models/dir.py:164-167)
-    const float eax = px - ax + 1e-6f, eay = py - ay + 1e-6f;
-    const float ebx = px - bx + 1e-6f, eby = py - by + 1e-6f;
-    const float da = sqrtf(eax * eax + eay * eay), db = sqrtf(ebx * ebx + eby * eby);
-    wa = 1.f - da / (da + db);
-    wb = 1.f - db / (da + db);
-}
+using dir::bone::bone_weights;
+using dir::bone::kChild;
+using dir::bone::kParent;
 
 template <typename T>
 __global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
@@ -324,7 +295,7 @@ __global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
     __syncthreads();
     // NHWC write: [b][y][x][hand*1280 + bone*64 + c], 8 channels per thread-item, fully coalesced
     T* orow = (T*)a.out + ((long long)(b * S + y) * S) * 2560;
-    for (int i = tid; i < S * 40 * 8; i += 256) {
+    for (int i = tid; i < (a.out ? S * 40 * 8 : 0); i += 256) {
         const int c8 = i & 7, xhb = i >> 3;
         const int x = xhb / 40, hb = xhb - x * 40, hand = hb / 20, bone = hb - hand * 20;
         const float wa = s_wa[xhb], wb = s_wb[xhb];
@@ -369,6 +340,60 @@ __global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
             }
             Vec<float>::store(vrow + (long long)ch * S * S + x4, out4);
         }
+    }
+}
+
+// proj_feat only (models/dir.py:128,481): vis[b, bone*64 + c, y, x] = left + right, fp32 NCHW.  One workgroup per
+// (sample, bone) owns the 64 consecutive channel planes of that bone (a contiguous 64 * S*S * 4-byte region): the
+// per-pixel (mask * wa, mask * wb) of both hands are computed once into LDS and every plane is streamed out with
+// 16-byte stores.  Same formulas and evaluation order as bone_proj_kernel (bit-identical values).
+__global__ __launch_bounds__(256) void bone_vis_kernel(BoneArgs a) {
+    extern __shared__ float sm[];
+    const int S = a.S, hw = S * S;
+    float* s_w = sm;                          // [2 hands][2 (wa, wb)][hw]; masked pixels hold NaN-free zeros + flag
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(s_w + 4 * hw);   // [2][hw]
+    __shared__ float s_f[2][2][64];           // [hand][end][c]
+    __shared__ float s_uv[2][4];              // [hand][ax, ay, bx, by] in pixel units
+    const int b = blockIdx.x / 20, bone = blockIdx.x - b * 20, tid = threadIdx.x;
+    if (tid < 8) {
+#pragma clang fp contract(off)
+        const int hand = tid >> 2, k = tid & 3, j = (k < 2) ? kParent[bone] : kChild[bone];
+        const float v = a.uv[hand][(long long)b * 42 + 2 * j + (k & 1)];
+        s_uv[hand][k] = (v + 1.f) / 2.f * (float)S;                   // models/dir.py:150
+    }
+    {
+        const int hand = tid >> 7, end = (tid >> 6) & 1, c = tid & 63;
+        s_f[hand][end][c] = a.emb[((long long)b * 42 + hand * 21 + (end ? kChild[bone] : kParent[bone])) * 64 + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * hw; i += 256) {
+        const int hand = i / hw, p = i - hand * hw, y = p / S, x = p - y * S;
+        float wa, wb;
+        bool in;
+        bone_weights((float)x + 0.5f, (float)y + 0.5f, s_uv[hand][0], s_uv[hand][1], s_uv[hand][2], s_uv[hand][3], a.distance, wa, wb, in);
+        s_w[(hand * 2) * hw + p] = wa;
+        s_w[(hand * 2 + 1) * hw + p] = wb;
+        s_in[i] = in ? 1 : 0;
+    }
+    __syncthreads();
+    float* out = a.vis + ((long long)b * 1280 + bone * 64) * hw;
+    for (int i = tid; i < 64 * hw / 4; i += 256) {
+        const int c = i / (hw / 4), p4 = (i - c * (hw / 4)) * 4;
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int hand = 0; hand < 2; ++hand) {
+#pragma clang fp contract(off)
+                const int p = p4 + q;
+                const float v = s_in[hand * hw + p] == 0 ? 0.f
+                                                         : s_f[hand][0][c] * s_w[(hand * 2) * hw + p] + s_f[hand][1][c] * s_w[(hand * 2 + 1) * hw + p];
+                acc = hand == 0 ? v : acc + v;
+            }
+            o[q] = acc;
+        }
+        Vec<float>::store(out + (long long)c * hw + p4, o);
     }
 }
 
@@ -437,13 +462,19 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
 extern "C" int dir_bone_proj_forward(const float* uv_left, const float* uv_right, const float* emb, void* out,
                                      float* vis_nchw, int32_t* group_bbox, int B, int S, float distance, int dtype,
                                      void* stream) {
-    DIR_REQUIRE(uv_left && uv_right && emb && out, "dir_bone_proj_forward: null pointer");
+    DIR_REQUIRE(uv_left && uv_right && emb && (out || vis_nchw), "dir_bone_proj_forward: null pointer (out and vis_nchw may not both be null)");
     DIR_REQUIRE(B > 0 && S > 0 && S <= 64 && S % 4 == 0, "dir_bone_proj_forward: bad shape (S must be a multiple of 4, <= 64)");
     BoneArgs a;
     a.uv[0] = uv_left; a.uv[1] = uv_right; a.emb = emb; a.out = out; a.vis = vis_nchw; a.bbox = group_bbox; a.B = B; a.S = S;
     a.distance = distance;
     const size_t lds = (size_t)(42 * 64 + 2 * S * 40 + 84) * sizeof(float) + (size_t)S * 40;
     hipStream_t s = (hipStream_t)stream;
+    if (!out && S <= 32) {                             // proj_feat only: contiguous per-bone channel planes
+        DIR_REQUIRE(group_bbox == nullptr, "dir_bone_proj_forward: group_bbox needs the NHWC output");
+        const size_t vlds = (size_t)4 * S * S * sizeof(float) + (size_t)2 * S * S;
+        hipLaunchKernelGGL(bone_vis_kernel, dim3(B * 20), dim3(256), vlds, s, a);
+        return dir::check_launch("dir_bone_proj_forward");
+    }
     if (dtype == DIR_DT_F32) hipLaunchKernelGGL((bone_proj_kernel<float>), dim3(B * S), dim3(256), lds, s, a);
     else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((bone_proj_kernel<bf16_t>), dim3(B * S), dim3(256), lds, s, a);
     else DIR_REQUIRE(false, "dir_bone_proj_forward: bad dtype");

@@ -275,6 +275,14 @@ class StageOp(object):
                      pack_mano(sd, p + '.regressor.mano_layer_right', 'right', root_joint, keep))
         s, h = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])
         self.fusion0 = ConvOp(sd[p + '.fusion.0.weight'], dtype, pad=1, scale=s, shift=h, relu=True)
+        self.bone_fusion = None
+        if dtype == torch.bfloat16:
+            # factorised bone fusion (dir_bone_fusion_forward): w_g[tap][hb][c][n] = weight[n, hb*64+c, ky, kx], bf16-rounded
+            w = sd[p + '.fusion.0.weight'].detach().to(torch.bfloat16).float()             # [256, 2560, 3, 3]
+            t = dict(w_g=w.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous(), scale=self.fusion0.scale,
+                     shift=self.fusion0.shift)
+            keep.append(t)
+            self.bone_fusion = _capi.BoneFusionParams(t['w_g'].data_ptr(), t['scale'].data_ptr(), t['shift'].data_ptr())
         self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
 
 
@@ -400,14 +408,36 @@ class DirEngine(object):
                                           _capi.ptr(prev['pd_mano_para_right']), _capi.ptr(prev['pd_offset']),
                                           _capi.ptr(para_l), _capi.ptr(para_r), _capi.ptr(off), _capi.ptr(emb), B, sp),
                     'dir_regress_forward')
+        factorised = st.bone_fusion is not None and self.factorised_fusion
+        if factorised:
+            # bf16 throughput mode: bone_proj + fusion conv as a K = 720 reduction, no [B,S,S,2560] bone map.  The per-sample
+            # G tensors need the token features only: they are computed on the side stream, beside the MANO layer.
+            scratch = torch.empty(L.dir_bone_fusion_scratch_bytes(B), device=dev, dtype=torch.uint8)
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _capi.check(L.dir_bone_fusion_prepare(st.bone_fusion, _capi.ptr(emb), _capi.ptr(scratch), B, _capi.stream_ptr()),
+                            'dir_bone_fusion_prepare')
         res = self.mano_outputs(st.mano, para_l, para_r, off)
-        bone = torch.empty(B, S, S, 2560, device=dev, dtype=self.dtype)
         vis = torch.empty(B, 1280, S, S, device=dev, dtype=F32) if want_vis else None
-        bbox = torch.empty(B, 40, 4, device=dev, dtype=torch.int32)
-        _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
-                                            _capi.ptr(emb), _capi.ptr(bone), _capi.ptr(vis), _capi.ptr(bbox), B, S,
-                                            st.distance, _dt(self.dtype), sp), 'dir_bone_proj_forward')
-        st.fusion3(st.fusion0(bone, bbox=bbox if self.sparse_fusion else None), out=img_out, out_coff=img_coff)
+        if factorised:
+            main.wait_stream(side)
+            fused = torch.empty(B, S, S, 256, device=dev, dtype=self.dtype)
+            _capi.check(L.dir_bone_fusion_forward(st.bone_fusion, _capi.ptr(res['pd_joint_uv_left']),
+                                                  _capi.ptr(res['pd_joint_uv_right']), _capi.ptr(scratch),
+                                                  _capi.ptr(fused), B, S, st.distance, 256, 0, 1, sp), 'dir_bone_fusion_forward')
+            if want_vis:                                        # proj_feat output only (models/dir.py:128,481)
+                _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
+                                                    _capi.ptr(emb), None, _capi.ptr(vis), None, B, S, st.distance,
+                                                    _dt(self.dtype), sp), 'dir_bone_proj_forward')
+            st.fusion3(fused, out=img_out, out_coff=img_coff)
+        else:
+            bone = torch.empty(B, S, S, 2560, device=dev, dtype=self.dtype)
+            bbox = torch.empty(B, 40, 4, device=dev, dtype=torch.int32)
+            _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
+                                                _capi.ptr(emb), _capi.ptr(bone), _capi.ptr(vis), _capi.ptr(bbox), B, S,
+                                                st.distance, _dt(self.dtype), sp), 'dir_bone_proj_forward')
+            st.fusion3(st.fusion0(bone, bbox=bbox if self.sparse_fusion else None), out=img_out, out_coff=img_coff)
         res['joint_feat'] = emb
         res['vis_img_feat'] = vis
         return res
@@ -417,6 +447,7 @@ class DirEngine(object):
         _capi.check(_capi.lib().dir_upsample2x_bilinear(_capi.ptr(x), _capi.ptr(out), B, H, W, Cc, out.shape[3], coff,
                                                         _dt(self.dtype), _capi.stream_ptr()), 'dir_upsample2x_bilinear')
 
+    factorised_fusion = os.environ.get('DIR_FACTORISED_FUSION', '1') != '0'    # bf16 mode: dir_bone_fusion_forward
     overlap = os.environ.get('DIR_OVERLAP', '1') != '0'     # run the skip branches on a side stream (False: everything on the current stream, e.g. to time kernels alone)
 
     def _side_stream(self):

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 2
+#define DIR_ABI_VERSION 3
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -162,7 +162,8 @@ int dir_init_head_forward(const dir_init_head_params* params_host, const void* c
 
 /* a10: Joint2BoneFeature.bone_proj + lineseg_dists (models/dir.py:132-174) for BOTH hands.
  * uv_left/right [B,21,2] in [-1,1]; emb [B,42,64] (tokens 0..20 left, 21..41 right);
- * out NHWC [B,S,S,2560] (channel = hand*1280 + bone*64 + c == torch.cat((left,right),1) of models/dir.py:122);
+ * out NHWC [B,S,S,2560] (channel = hand*1280 + bone*64 + c == torch.cat((left,right),1) of models/dir.py:122); may be
+ * NULL when only vis_nchw is wanted (dir_bone_fusion_forward covers the convolution);
  * vis_nchw (optional) fp32 [B,1280,S,S] = left + right (vis_img_feat / proj_feat, models/dir.py:128,481).
  * The capsule mask `distance < thr` follows the reference's fp32 op order exactly (bit-exact support).
  * group_bbox (optional) int32 [B][40][4]: conservative pixel box (ymin,ymax,xmin,xmax; empty when min > max) outside
@@ -248,6 +249,27 @@ typedef struct dir_regress_params {
 int dir_regress_forward(const dir_regress_params* params_host, const float* tok, const float* prev_para_left,
                         const float* prev_para_right, const float* prev_offset, float* para_left, float* para_right,
                         float* offset, float* emb, int B, void* stream);
+
+/* a10 + a11 fused (bf16 throughput mode): Joint2BoneFeature.bone_proj (models/dir.py:132-174) + fusion[0..2] (3x3 conv
+ * 2560 -> 256 + BatchNorm + ReLU, models/dir.py:57-62) without the [B,S,S,2560] bone map.  The rasterised operand is rank 2
+ * per bone, so conv(img)[p,n] = sum_tap sum_e Wgt[p+tap, e] * G[tap, e, n] with e = (hand, bone, end) in [0,80),
+ * G[tap,(hb,end),n] = sum_c f_end[hb][c] * W[n, hb*64+c, tap] and Wgt = mask * (wa | wb): K = 720 instead of 23040.
+ * Same mathematics as dir_bone_proj_forward + dir_conv2d_forward, re-associated (so the fp32 parity mode keeps those).
+ * Two launches so that the first can overlap the MANO layer (it needs the token features only):
+ *   dir_bone_fusion_prepare : G for every sample from emb [B,42,64] (proj_feat_emb output) into `scratch`
+ *                             (dir_bone_fusion_scratch_bytes(B) bytes of device memory);
+ *   dir_bone_fusion_forward : uv_* [B,21,2] (pd_joint_uv) + scratch -> y, NHWC bf16 [B,S,S,out_cstride], channels
+ *                             [out_coff, out_coff+256).  S in {16, 32, ...} with 256 % S == 0 and S*S % 256 == 0. */
+typedef struct dir_bone_fusion_params {
+    const float* w_g;   /* [9][40][64][256]: fusion.0.weight[n, hb*64 + c, ky, kx] at [ky*3+kx][hb][c][n], rounded to bf16 */
+    const float* scale; /* [256] folded fusion.1 BatchNorm scale            */
+    const float* shift; /* [256] folded BatchNorm shift (+ fusion.0 bias)   */
+} dir_bone_fusion_params;
+size_t dir_bone_fusion_scratch_bytes(int B);
+int dir_bone_fusion_prepare(const dir_bone_fusion_params* params_host, const float* emb, void* scratch, int B, void* stream);
+int dir_bone_fusion_forward(const dir_bone_fusion_params* params_host, const float* uv_left, const float* uv_right,
+                            const void* scratch, void* y, int B, int S, float distance, int out_cstride, int out_coff,
+                            int relu, void* stream);
 
 /* ---- evaluation-metric maths of apps/eval.py --------------------------------------------------
  * f1a: Jr.__call__ (apps/eval.py:43-44): joints[B,21,3] = jr[21,778] @ verts[B,778,3].  `jr` is the Jr-processed

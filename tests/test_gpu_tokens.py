@@ -128,6 +128,11 @@ def test_bone_proj_vs_reference(golden):
             assert np.array_equal(got[:, 1280:] != 0, ref_r != 0)
             assert maxabs(got[:, :1280], ref) < tol and maxabs(got[:, 1280:], ref_r) < tol
             assert maxabs(vis.cpu().numpy(), ref + ref_r) < 2e-6                 # vis is fp32 regardless of dtype
+            vis2 = torch.full((2, 1280, S, S), 3.0, device='cuda')               # proj_feat-only launch (out = NULL)
+            _capi.check(_capi.lib().dir_bone_proj_forward(
+                _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), None, _capi.ptr(vis2), None, 2, S, float(dist),
+                0 if tdt == torch.float32 else 1, _capi.stream_ptr()), 'bone_proj vis only')
+            assert torch.equal(vis, vis2)
 
 
 def stage_sd(S):
@@ -226,3 +231,68 @@ def test_bone_bbox_is_conservative_and_sparse_conv_is_bit_identical(golden):
             _capi.check(_capi.lib().dir_conv2d_sparse_forward(d, _capi.ptr(out), _capi.ptr(w), None, _capi.ptr(shift), None,
                                                               _capi.ptr(sparse), _capi.ptr(bbox), _capi.stream_ptr()), 'sparse')
             assert torch.equal(dense, sparse), 'sparse-K conv differs from dense (S=%d, %s)' % (S, tdt)
+
+
+@pytest.mark.parametrize('S,dist,B', [(16, 1, 3), (32, 2, 2), (32, 2, 5)])
+def test_bone_fusion_factorised_vs_oracle(golden, S, dist, B):
+    """dir_bone_fusion_forward (bone_proj + fusion conv + BN + ReLU as a K = 720 reduction) against the oracle's
+    bone_proj -> conv2d 3x3 -> scale/shift -> ReLU in float64, against the reference's own bone map (g5_bone golden) pushed
+    through the same float64 conv, and against the materialised GPU path (dir_bone_proj_forward + dir_conv2d_forward).
+    Tolerance: bf16 operands (weights, G, pixel weights: 2^-9 each) and a bf16 output -> 1.5e-2 of the output scale."""
+    g = golden('g5_bone')
+    uv0 = g['S%d.uv' % S]                                                        # [2,21,2] from the reference fixture
+    rng = np.random.default_rng(7 + S + B)
+    uv_l = np.concatenate([uv0, uv0[::-1]], 0)[:B] if B <= 4 else np.concatenate([uv0, uv0[::-1], uv0[:1] * 0.7], 0)
+    uv_l = np.ascontiguousarray(uv_l, np.float32)
+    uv_r = uv_l.copy(); uv_r[..., 0] *= -0.9
+    emb = synth.synth_input('bonefuse.emb%d' % S, (B, 42, 64), SEED)
+    w = (rng.standard_normal((256, 2560, 3, 3)) * 0.02).astype(np.float32)
+    w = torch.from_numpy(w).to(torch.bfloat16).float().numpy()                   # the bf16 mode's weights
+    scale = (1 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    shift = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    # oracle, float64
+    img = np.concatenate([OT.bone_proj(uv_l, emb[:, :21], S, dist), OT.bone_proj(uv_r, emb[:, 21:], S, dist)], 1)   # [B,2560,S,S]
+    if B == 2:                                                # left-hand joints == the reference fixture's: same capsule mask
+        assert np.array_equal((img[:, :1280] != 0).reshape(2, 20, 64, S, S).any(2), (g['S%d.y' % S] != 0).reshape(2, 20, 64, S, S).any(2))
+    ref = N.conv2d(img.astype(np.float64), w.astype(np.float64), None, 1, 1)
+    ref = np.maximum(ref * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    # GPU: factorised
+    L = _capi.lib()
+    dw = torch.from_numpy(w).cuda()
+    wg = dw.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous()
+    dsc, dsh = dev(scale), dev(shift)
+    P = _capi.BoneFusionParams(wg.data_ptr(), dsc.data_ptr(), dsh.data_ptr())
+    duv, duvr, demb = dev(uv_l), dev(uv_r), dev(emb)
+    scratch = torch.empty(L.dir_bone_fusion_scratch_bytes(B), device='cuda', dtype=torch.uint8)
+    y = torch.full((B, S, S, 320), 7.0, device='cuda', dtype=torch.bfloat16)      # written into channels [32, 288)
+    _capi.check(L.dir_bone_fusion_prepare(P, _capi.ptr(demb), _capi.ptr(scratch), B, _capi.stream_ptr()), 'bone_fusion_prepare')
+    _capi.check(L.dir_bone_fusion_forward(P, _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(scratch), _capi.ptr(y),
+                                          B, S, float(dist), 320, 32, 1, _capi.stream_ptr()), 'bone_fusion')
+    torch.cuda.synchronize()
+    got = y[..., 32:288].float().cpu().numpy().transpose(0, 3, 1, 2)
+    sc = np.abs(ref).max()
+    assert maxabs(got, ref) <= 1.5e-2 * sc, (maxabs(got, ref), sc)
+    assert float(y[..., :32].float().min()) == 7.0 and float(y[..., 288:].float().max()) == 7.0     # slice untouched outside
+    # GPU: materialised bone map + implicit-GEMM conv (the fp32-mode path, here in bf16)
+    bone = torch.empty(B, S, S, 2560, device='cuda', dtype=torch.bfloat16)
+    _capi.check(L.dir_bone_proj_forward(_capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), _capi.ptr(bone), None, None, B, S,
+                                        float(dist), 1, _capi.stream_ptr()), 'bone_proj')
+    from dir_amd import functional as Fn
+    wp = dw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    y2 = Fn.conv2d_nhwc(bone, wp, 1, 1, scale=dsc, shift=dsh, relu=True).float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert maxabs(got, y2) <= 1.5e-2 * sc
+    # and the factorised result is at least as close to the float64 value as the materialised bf16 path
+    assert maxabs(got, ref) <= 1.25 * maxabs(y2, ref) + 1e-3 * sc
+
+
+def test_bone_fusion_rejects_bad_arguments():
+    L = _capi.lib()
+    z = torch.zeros(16, device='cuda')
+    P = _capi.BoneFusionParams(z.data_ptr(), z.data_ptr(), z.data_ptr())
+    for S, cs, co in ((24, 256, 0), (16, 250, 0), (16, 256, 8)):
+        rc = L.dir_bone_fusion_forward(P, _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), 1, S, 1.0, cs, co, 1, _capi.stream_ptr())
+        assert rc != 0 and b'dir_bone_fusion_forward' in L.dir_last_error()
+    assert L.dir_bone_fusion_forward(P, _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), 0, 16, 1.0, 256, 0, 1,
+                                     _capi.stream_ptr()) == 0                       # empty batch is a no-op
+    assert L.dir_bone_fusion_prepare(P, _capi.ptr(z), _capi.ptr(z), 0, _capi.stream_ptr()) == 0
+    assert L.dir_bone_fusion_scratch_bytes(3) == 3 * 9 * 40 * 256 * 4

@@ -11,14 +11,16 @@ def per_kernel(path, counter, pat):
     T = lambda p: [t for t in tabs if t.startswith(p)][0]  # noqa: E731
     pe, pi, kd, ks = T('rocpd_pmc_event'), T('rocpd_info_pmc'), T('rocpd_kernel_dispatch'), T('rocpd_info_kernel_symbol')
     q = ("select d.id, sum(e.value) from %s e join %s i on e.pmc_id=i.id join %s d on e.event_id=d.event_id "
-         "join %s s on d.kernel_id=s.id where s.kernel_name like ? and i.name=? group by d.id") % (pe, pi, kd, ks)
-    vals = [v for _, v in db.execute(q, ('%' + pat + '%', counter))]
+         "join %s s on d.kernel_id=s.id where (%s) and i.name=? group by d.id") % (
+             pe, pi, kd, ks, ' or '.join('s.kernel_name like ?' for _ in pat))
+    vals = [v for _, v in db.execute(q, tuple('%' + x + '%' for x in pat) + (counter,))]
     return len(vals), sum(vals)
 
 
 if __name__ == '__main__':
     fetch_db, write_db, out = sys.argv[1:4]
-    pat = 'conv_igemm_kernelItt'          # conv_igemm<bf16,bf16,*>
+    # the bf16 -> bf16 convolution family: conv.hip (4-wave) and conv_pipe.hip (8-wave pipelined / halo-reuse) kernels
+    pat = ['conv_igemm_kernelItt', 'conv_pipe_kernelIt', 'conv_patch_kernelIt']
     nf, f = per_kernel(fetch_db, 'FETCH_SIZE', pat)
     nw, w = per_kernel(write_db, 'WRITE_SIZE', pat)
     res = {'kernel': 'conv_igemm<bf16,bf16>', 'launches_fetch_pass': nf, 'launches_write_pass': nw,

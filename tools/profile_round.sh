@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage (on the GPU box, via gpurun): tools/profile_round.sh <tag>      e.g. r01_f
+# kernel trace + the two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command; results under gpurun_out/<tag>/
+tag=$1
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/$tag
+mkdir -p $out
+cmd="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dump-conv"
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $cmd > $out/pmcF.log 2>&1 )
+( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $cmd > $out/pmcW.log 2>&1 )
+cd $R
+python tools/prof_summary.py $(find $out/trace -name "*.db" | head -1) 60 > $out/kernel_stats.txt
+python tools/pmc_traffic.py $(find $out/pmcF -name "*.db" | head -1) $(find $out/pmcW -name "*.db" | head -1) $out/pmc_traffic.json
+grep -h "^conv_igemm\|^{" $out/trace.log > $out/bench_line.txt
+rm -rf $out/trace $out/pmcF $out/pmcW
