@@ -43,7 +43,8 @@ class SteBlock(C.Structure):
 
 class SteParams(C.Structure):
     _fields_ = [('pos_embed', C.c_void_p), ('blocks', SteBlock * 3), ('num_blocks', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('snorm_w', 'snorm_b', 'head_ln_w', 'head_ln_b', 'head_wt', 'head_b')]
+               [(n, C.c_void_p) for n in ('snorm_w', 'snorm_b', 'head_ln_w', 'head_ln_b', 'head_wt', 'head_b')] + \
+               [('weight_dtype', C.c_int32)]
 
 
 class RegressParams(C.Structure):
@@ -70,7 +71,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 3          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 4          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 

@@ -99,6 +99,57 @@ __device__ __forceinline__ void linear_mfma(const float* s_in, int ldi, const fl
     }
 }
 
+// The same Linear on the bf16 matrix cores (bf16 throughput mode = the reference's autocast semantics: nn.Linear in bf16,
+// LayerNorm / softmax / residual stream in fp32).  W is the PyTorch-native [N][K] bf16 matrix: a lane's B operand
+// (column n, 8 consecutive k) is one 16-byte load; the A operand is converted from the fp32 LDS activations on the fly.
+// v_mfma_f32_16x16x32_bf16: A lane (row l&15, k 8*(l>>4)..+7), B lane (col l&15, same k), D as the fp32 variant.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+template <int K, typename F>
+__device__ __forceinline__ void linear_mfma_bf16(const float* s_in, int ldi, const unsigned short* __restrict__ W,
+                                                 const float* __restrict__ bias, int N, int wave, int lane, F store) {
+    const int li = lane & 15, lk = lane >> 4;
+    for (int nt = wave; nt < N / 16; nt += NWAVES) {
+        const int n = nt * 16 + li;
+        bf16x8_t bv[K / 32];
+#pragma unroll
+        for (int kk = 0; kk < K / 32; ++kk) bv[kk] = *reinterpret_cast<const bf16x8_t*>(W + (long long)n * K + kk * 32 + lk * 8);
+        f32x4 acc[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < K / 32; ++kk) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const float2* ap = reinterpret_cast<const float2*>(s_in + (m * 16 + li) * ldi + kk * 32 + lk * 8);   // 8-byte aligned rows
+                bf16x8_t av;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 t = ap[e];
+                    av[2 * e] = (__bf16)t.x;
+                    av[2 * e + 1] = (__bf16)t.y;
+                }
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv[kk], acc[m], 0, 0, 0);
+            }
+        }
+        const float bb = bias[n];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = m * 16 + lk * 4 + r;
+                if (t < NT) store(t, n, acc[m][r] + bb);
+            }
+    }
+}
+
+// WBF16: Linear weights are bf16 [out][in] (dir_ste_params.weight_dtype == DIR_DT_BF16), else fp32 k-major [in][out]
+template <int K, bool WBF16, typename F>
+__device__ __forceinline__ void linear(const float* s_in, int ldi, const float* W, const float* bias, int N, int wave, int lane, F store) {
+    if constexpr (WBF16) linear_mfma_bf16<K>(s_in, ldi, reinterpret_cast<const unsigned short*>(W), bias, N, wave, lane, store);
+    else linear_mfma<K>(s_in, ldi, W, bias, N, wave, lane, store);
+}
+
+template <bool WBF16>
 __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
     __shared__ __attribute__((aligned(16))) float sm[2 * NTP * LDX + NTP * LDQ + HEADS * NTP * LDP];   // 158,592 B
     float* s_x = sm;                      // [48][130] residual stream (rows 42..47: zero padding of the MFMA row tile)
@@ -123,7 +174,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         // ---- attention branch
         layernorm_tokens(s_x, s_n, P.ln1_w, P.ln1_b, 1e-6f, wave, lane);
         __syncthreads();
-        linear_mfma<D>(s_n, LDX, P.qkv_wt, P.qkv_b, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
+        linear<D, WBF16>(s_n, LDX, P.qkv_wt, P.qkv_b, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
         __syncthreads();
         // scores S = q k^T * 32^-0.5 per head on the matrix cores.  qkv column layout is (3, heads, 32) (mixSTE.py:78):
         // q = [0,128), k = [128,256), v = [256,384).  36 tiles of 16x16 (4 heads x 3 x 3), K = 32.
@@ -177,16 +228,16 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
             }
         }
         __syncthreads();
-        linear_mfma<D>(s_n, LDX, P.proj_wt, P.proj_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
+        linear<D, WBF16>(s_n, LDX, P.proj_wt, P.proj_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
         __syncthreads();
         // ---- MLP branch
         layernorm_tokens(s_x, s_n, P.ln2_w, P.ln2_b, 1e-6f, wave, lane);
         __syncthreads();
-        linear_mfma<D>(s_n, LDX, P.fc1_wt, P.fc1_b, 256, wave, lane, [&](int t, int n, float v) {
+        linear<D, WBF16>(s_n, LDX, P.fc1_wt, P.fc1_b, 256, wave, lane, [&](int t, int n, float v) {
             s_big[t * LDH + n] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));          // exact GELU
         });
         __syncthreads();
-        linear_mfma<256>(s_big, LDH, P.fc2_wt, P.fc2_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
+        linear<256, WBF16>(s_big, LDH, P.fc2_wt, P.fc2_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
         __syncthreads();
         // ---- spatial_norm after every block (mixSTE.py:200)
         layernorm_tokens(s_x, s_x, a.p.snorm_w, a.p.snorm_b, 1e-6f, wave, lane);      // in place
@@ -196,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
     layernorm_tokens(s_x, s_n, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, wave, lane);
     __syncthreads();
     float* y = a.y + (long long)b * NT * 64;
-    linear_mfma<D>(s_n, LDX, a.p.head_wt, a.p.head_b, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    linear<D, WBF16>(s_n, LDX, a.p.head_wt, a.p.head_b, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
 }
 
 }  // namespace
@@ -214,6 +265,8 @@ extern "C" int dir_ste_forward(const dir_ste_params* p, const float* x, float* x
     }
     SteArgs a;
     a.p = *p; a.x_in = x; a.x_inout = x_pos_out; a.y = y; a.nblocks = p->num_blocks;
-    hipLaunchKernelGGL(ste_kernel, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    DIR_REQUIRE(p->weight_dtype == DIR_DT_F32 || p->weight_dtype == DIR_DT_BF16, "dir_ste_forward: weight_dtype must be f32 or bf16");
+    if (p->weight_dtype == DIR_DT_BF16) hipLaunchKernelGGL(ste_kernel<true>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ste_kernel<false>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     return dir::check_launch("dir_ste_forward");
 }

@@ -109,17 +109,20 @@ def pack_pgcn(sd, prefix, keep, num_layers=4):
     return arr
 
 
-def pack_ste(sd, prefix, keep, depth=4):
+def pack_ste(sd, prefix, keep, depth=4, weight_dtype=torch.float32):
+    """weight_dtype float32: exact fp32 Linears (k-major weights); bfloat16: bf16 Linears = autocast semantics ([out][in])."""
     def f(k):
         t = sd[prefix + '.' + k].float().contiguous()
         keep.append(t)
         return t.data_ptr()
 
     def ft(k):
-        t = sd[prefix + '.' + k].float().t().contiguous()
+        w = sd[prefix + '.' + k]
+        t = w.float().t().contiguous() if weight_dtype == torch.float32 else w.detach().to(torch.bfloat16).contiguous()
         keep.append(t)
         return t.data_ptr()
     P = _capi.SteParams()
+    P.weight_dtype = _dt(weight_dtype)
     pe = sd[prefix + '.spatial_pos_embed'].float().reshape(42, 128).contiguous()
     keep.append(pe)
     P.pos_embed = pe.data_ptr()
@@ -258,7 +261,7 @@ class StageOp(object):
                                             pack_token_mlp(sd, p + '.pos_emb_right', keep))
         self.gpos = pack_token_mlp(sd, p + '.global_pos_emb', keep)
         self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep), pack_pgcn(sd, p + '.gcn_right', keep))
-        self.ste = pack_ste(sd, p + '.interaction', keep)
+        self.ste = pack_ste(sd, p + '.interaction', keep, weight_dtype=dtype)
         R = _capi.RegressParams()
         t = dict(wt=torch.cat([sd[p + '.regressor.mano_left.weight'].float().t(),
                                sd[p + '.regressor.mano_right.weight'].float().t()], 1).contiguous(),     # [1408][128]

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 3
+#define DIR_ABI_VERSION 4
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -220,7 +220,11 @@ int dir_pgcn_stack_forward_pair(const dir_pgcn_layer* layers_left_host, const di
                                 int num_layers, const float* x_lr, const float* add_lr, float* tokens, float* scratch,
                                 int B, void* stream);
 
-/* a6: STE.forward (transformer/mixSTE.py:194-205) on [B,42,128] -> [B,42,64]; weights k-major ([in][out]). */
+/* a6: STE.forward (transformer/mixSTE.py:194-205) on [B,42,128] -> [B,42,64].
+ * weight_dtype DIR_DT_F32: the six Linear weights per block (*_wt) and head_wt are fp32, k-major ([in][out]); exact fp32.
+ * weight_dtype DIR_DT_BF16: they are bf16 in nn.Linear's own [out][in] layout and the Linears run on the bf16 matrix cores
+ * with fp32 accumulation -- torch.autocast(bfloat16) semantics (BASELINE config 4); LayerNorm, softmax, attention and the
+ * residual stream stay fp32, biases and LayerNorm parameters are fp32 in both modes. */
 typedef struct dir_ste_block {
     const float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc1_wt, *fc1_b, *fc2_wt, *fc2_b;
 } dir_ste_block;
@@ -229,6 +233,7 @@ typedef struct dir_ste_params {
     dir_ste_block blocks[3]; /* STEblocks[1..3]: block 0 is never executed (transformer/mixSTE.py:197) */
     int32_t num_blocks;      /* depth - 1 */
     const float *snorm_w, *snorm_b, *head_ln_w, *head_ln_b, *head_wt /* [128][64] */, *head_b;
+    int32_t weight_dtype;    /* DIR_DT_F32 | DIR_DT_BF16 */
 } dir_ste_params;
 /* x_pos_out (optional): receives x + pos_embed, reproducing the reference's in-place `x += pos` on its input. */
 int dir_ste_forward(const dir_ste_params* params_host, const float* x, float* x_pos_out, float* y, int B,

@@ -296,3 +296,31 @@ def test_bone_fusion_rejects_bad_arguments():
                                      _capi.stream_ptr()) == 0                       # empty batch is a no-op
     assert L.dir_bone_fusion_prepare(P, _capi.ptr(z), _capi.ptr(z), 0, _capi.stream_ptr()) == 0
     assert L.dir_bone_fusion_scratch_bytes(3) == 3 * 9 * 40 * 256 * 4
+
+
+def test_ste_bf16_linears_autocast_semantics(golden):
+    """weight_dtype = bf16: nn.Linear on the bf16 matrix cores (fp32 accumulate), everything else fp32 -- what
+    torch.autocast(bfloat16) does to transformer/mixSTE.py.  Checked against (a) the reference golden within the bf16
+    envelope and (b) an oracle run whose Linear operands are rounded to bf16 the same way (tight)."""
+    g = golden('g3_ste')
+    sdn = synth.synth_state_dict(ste_shapes(''), SEED)
+    sd = {('ste.' + k): torch.from_numpy(v).cuda() for k, v in sdn.items()}
+    keep = []
+    P = engine.pack_ste(sd, 'ste', keep, weight_dtype=torch.bfloat16)
+    x = torch.from_numpy(g['x']).cuda()
+    y = torch.empty(2, 42, 64, device='cuda')
+    _capi.check(_capi.lib().dir_ste_forward(C.byref(P), _capi.ptr(x), None, _capi.ptr(y), 2, _capi.stream_ptr()), 'ste bf16')
+    got = y.cpu().numpy()
+    sc = np.abs(g['y']).max()
+    assert maxabs(got, g['y']) < 2e-2 * sc, (maxabs(got, g['y']), sc)
+
+    def bf(a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+    orig = N.linear                                      # oracle with bf16-rounded Linear operands, fp32 accumulation
+    try:
+        N.linear = lambda xx, w, b=None: orig(bf(xx), bf(w), b)
+        want = OT.ste_forward(g['x'].copy(), N.Params(sdn))
+    finally:
+        N.linear = orig
+    assert maxabs(got, want) < 2e-3 * sc, (maxabs(got, want), sc)
