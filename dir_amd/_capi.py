@@ -96,6 +96,7 @@ _SIGNATURES = {
     'dir_bone_fusion_scratch_bytes': (C.c_size_t, [_i]),
     'dir_bone_fusion_prepare': (C.c_int, [C.POINTER(BoneFusionParams), _p, _p, _i, _p]),
     'dir_bone_fusion_forward': (C.c_int, [C.POINTER(BoneFusionParams), _p, _p, _p, _p, _i, _i, C.c_float, _i, _i, _i, _p]),
+    'dir_gt_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     'dir_joint_regress_forward': (C.c_int, [_p, _p, _p, _i, _p]),
     'dir_eval_metrics_forward': (C.c_int, [C.POINTER(EvalInputs), C.POINTER(EvalOutputs), _i, _i, _i, _p]),
     'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),

@@ -31,33 +31,6 @@ using namespace dir::convk;
 
 namespace {
 
-// pre-activation BN (+ReLU) applied to one 16-byte chunk of input channels starting at channel c
-template <typename TI>
-__device__ __forceinline__ uint4 prologue(uint4 v, const float* ps, const float* pb, int c, bool relu);
-template <>
-__device__ __forceinline__ uint4 prologue<float>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
-    float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        f[e] = fmaf(f[e], ps[c + e], pb[c + e]);
-        if (relu) f[e] = fmaxf(f[e], 0.f);
-    }
-    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
-}
-template <>
-__device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
-    uint32_t u[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float lo = bf2f((bf16_t)(u[e] & 0xffffu)), hi = bf2f((bf16_t)(u[e] >> 16));
-        lo = fmaf(lo, ps[c + 2 * e], pb[c + 2 * e]);
-        hi = fmaf(hi, ps[c + 2 * e + 1], pb[c + 2 * e + 1]);
-        if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        u[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
-    }
-    return make_uint4(u[0], u[1], u[2], u[3]);
-}
-
 // MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
 template <typename TI, typename TO, int MI, int NJ, bool PRE, bool RING>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {

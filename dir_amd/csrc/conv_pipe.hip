@@ -28,7 +28,9 @@ struct Slab {
     int tap, toff, k0;     // tap index, byte offset of (ky,kx,c0) inside the input, element offset inside a weight row
 };
 
-template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE>
+constexpr int PRE_MAX_CIN = 2304;      // pre-activation parameters staged in LDS (fusion_layer4: 2048 + 256 channels)
+
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) {
     typedef bf16_t TI;
     constexpr int NT = 64 * WM * WN;               // threads
@@ -45,6 +47,18 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     constexpr int NREAD = (MI + NJ) * 4;           // ds_read_b128 per slab per wave
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    // PRE: hourglass.Residual's pre-activation BatchNorm + ReLU (models/backbone/hourglass.py:55-70) on the A operand.  The
+    // raw slab still arrives by LDS-DMA; the thread that issued a piece rewrites its own 16-byte chunks in LDS once they have
+    // landed (its counted vmcnt) and before the slab's barrier, so the deep ring is kept.  Parameters live in LDS: a
+    // compiler-tracked global load inside the loop would drain the untracked DMA ring (vmcnt is shared and in order).
+    __shared__ float s_pre[PRE ? 2 * PRE_MAX_CIN : 1];
+    if constexpr (PRE) {
+        for (int i = threadIdx.x; i < a.Cin; i += NT) {
+            s_pre[i] = a.pre_scale[i];
+            s_pre[PRE_MAX_CIN + i] = a.pre_shift[i];
+        }
+        __syncthreads();
+    }
 
     // XCD-aware tile order (see conv.hip)
     const int nwg = a.tiles_m * a.tiles_n;
@@ -200,6 +214,23 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
         else fb[set][t - MI][q] = *reinterpret_cast<const uint4*>(bufp + frag_b + (t - MI) * 32 * ROW + qoff[q]);
     };
 
+    // PRE: (tap, first channel) of the slab whose fragments are read next; dense order (PRE is never sparse)
+    int r_tap = 0, r_c0 = 0;
+    const bool pre_relu = (a.flags & 2) != 0;
+    auto pre_transform = [&](int buf) {
+        if constexpr (PRE) {
+            char* base = smem + buf * BUF_BYTES + wave * 1024 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                if ((amask[i] >> r_tap) & 1u) {                       // zero padding / M tail stay zero: conv pads the ACTIVATED input
+                    uint4* cp = reinterpret_cast<uint4*>(base + i * (RPP * ROW));
+                    *cp = prologue<bf16_t>(*cp, s_pre, s_pre + PRE_MAX_CIN, r_c0 + col * EPC, pre_relu);
+                }
+            }
+            if (++r_tap == ntaps) { r_tap = 0; r_c0 += BK; }
+        }
+    };
+
     // ---- prologue: three slabs in flight, the first one's fragments in register set 0
     {
         const Slab s0 = next_slab(0);
@@ -209,6 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
         const Slab s2 = next_slab(2);
         dma_slab(s2, 2, nact > 2);
         wait_vmcnt<2 * NP>();
+        pre_transform(0);
         __syncthreads();
         [&]<int... R>(std::integer_sequence<int, R...>) {
             (frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, R>{}, smem), ...);
@@ -222,8 +254,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     auto iteration = [&](auto Pc, int ks) {
         constexpr int P = decltype(Pc)::value;
         wait_vmcnt<NP>();
-        __syncthreads();
         const int nb = buf == 2 ? 0 : buf + 1;     // (ks + 1) % 3
+        if (ks + 1 < nact) pre_transform(nb);      // own pieces of slab ks+1 have landed; everyone else's after the barrier
+        __syncthreads();
         const char* rbuf = smem + nb * BUF_BYTES;
         const bool live = ks + 3 < nact;
         const Slab sd = next_slab(ks + 3);
@@ -571,6 +604,12 @@ void launch_tile(ConvArgs a, hipStream_t s) {
         else hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
         return;
     }
+    if constexpr (!(MI == 2 && NJ == 2)) {                // pre-activation variant: the tiles whose ring leaves room for s_pre
+        if (a.pre_scale) {
+            hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a);
+            return;
+        }
+    }
     if (a.bbox) hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a);
 }
@@ -581,7 +620,10 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
     static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
     static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
-    if (force == 0 || a.pre_scale || !(a.flags & 4) || a.nk < min_nk) return false;
+    if (force == 0 || !(a.flags & 4) || a.nk < min_nk) return false;
+    const bool pre = a.pre_scale != nullptr;
+    static const int pre_pipe = getenv("DIR_PIPE_PRE") ? atoi(getenv("DIR_PIPE_PRE")) : 1;     // tuning aid
+    if (pre && (!pre_pipe || a.Cin > PRE_MAX_CIN || a.bbox)) return false;
     const long long hw = (long long)a.Ho * a.Wo;
     auto tiles = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
     int shape = 0;
@@ -590,10 +632,10 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
         // largest tile that still gives (nearly) every CU a workgroup; 64-wide N tile only for Cout <= 64
         const long long need = (long long)num_cu * 3 / 4;
         if (a.Cout <= 64) shape = tiles(256, 64) >= need ? 3 : 0;
-        else if (tiles(256, 128) >= need) shape = 1;
-        else if (tiles(128, 128) >= need) shape = 2;
+        else if (tiles(256, 128) >= need && !pre) shape = 1;
+        else if (tiles(128, 128) >= (pre ? need / 2 : need)) shape = 2;   // the register-staged pre-activation path is slow: accept half-full grids
     }
-    if (shape == 0) return false;
+    if (shape == 0 || (pre && shape == 1)) return false;
     const int bm = shape == 2 ? 128 : 256;
     ConvArgs b = a;
     if (b.bbox && hw % bm != 0) b.bbox = nullptr;          // sparse-K needs whole tiles inside one image

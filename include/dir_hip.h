@@ -303,6 +303,16 @@ typedef struct dir_eval_outputs {
 int dir_eval_metrics_forward(const dir_eval_inputs* in_host, const dir_eval_outputs* out_host, int B, int root_joint,
                              int use_scale, void* stream);
 
+/* f1c: the ground-truth MANO layer, models/manolayer.py:251-323 (ManoLayer.forward; rodrigues_batch :32-48), the
+ * formulation dataset/interhand.py:130-149 uses to synthesise GT.  Tables in the dir_mano_tables packing (comps = the full
+ * [45][45] hands_components, the first `ncomps` rows are used; side / root_palm are ignored: fingertip vertices are
+ * 745,317,444,556,673 for both hands, models/manolayer.py:297).  root_rotation [B,3,3]; pose [B,ncomps] PCA coefficients
+ * (use_pca) or, with ncomps = 0, [B,15,3,3] rotation matrices; shape [B,10]; trans [B,3] / scale [B] optional (NULL);
+ * center_idx -1 = None; verts [B,778,3], joints [B,21,3] (metres). */
+int dir_gt_mano_forward(const dir_mano_tables* tables_host, const float* root_rotation, const float* pose, int ncomps,
+                        const float* shape, const float* trans, const float* scale, int center_idx, int new_skel,
+                        float* verts, float* joints, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

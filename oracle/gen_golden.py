@@ -334,8 +334,38 @@ def gen_eval():
     save('g9_eval', **out)
 
 
+# ----------------------------------------------------------------------------- G10 GT MANO layer (models/manolayer.py)
+def gen_gtmano():
+    """models/manolayer.py::ManoLayer built from a synthetic pickle (written to a temp dir at generation time) with the keys
+    its constructor reads (:106-158); forward on the seeded inputs of golden_inputs.gtmano_inputs."""
+    import pickle
+    import tempfile
+    import scipy.sparse as sp
+    from models.manolayer import ManoLayer as GTManoLayer
+    from oracle.golden_inputs import GTMANO_CASES, gtmano_inputs
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for side in ('left', 'right'):
+            t = synth.synthetic_mano_tables(side, SEED)
+            d = {'hands_components': t['hands_components'], 'J_regressor': sp.csc_matrix(t['J_regressor']),
+                 'J': t['J_regressor'] @ t['v_template'], 'weights': t['weights'], 'posedirs': t['posedirs'],
+                 'v_template': t['v_template'], 'shapedirs': t['shapedirs'], 'hands_mean': t['hands_mean'], 'f': t['f'],
+                 'kintree_table': t['kintree_table']}
+            path = os.path.join(tmp, side + '.pkl')
+            with open(path, 'wb') as f:
+                pickle.dump(d, f)
+            for case in GTMANO_CASES:
+                name, ncomps, center, _, _, new_skel = case
+                layer = GTManoLayer(path, center_idx=center, use_pca=ncomps > 0, new_skel=new_skel)
+                R, pose, shape, trans, scale = gtmano_inputs(case)
+                T = lambda a: None if a is None else torch.from_numpy(a)  # noqa: E731
+                v, j = layer(T(R), T(pose), T(shape), trans=T(trans), scale=T(scale))
+                out['%s.%s.verts' % (side, name)], out['%s.%s.joints' % (side, name)] = v.numpy(), j.numpy()
+    save('g10_gtmano', **out)
+
+
 GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
-        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval}
+        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

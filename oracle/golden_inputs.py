@@ -88,3 +88,27 @@ def eval_inputs(B=6):
             synth.synth_input('eval.v2d.' + side, (B, 778, 2), SEED) * np.float32(0.5)
     out['pd_offset'] = synth.synth_input('eval.off', (B, 3), SEED)
     return out
+
+
+GTMANO_CASES = [('normal', 45, None, False, False, False), ('pca12', 12, None, False, False, False),
+                ('center9_scale', 45, 9, True, True, False), ('center0_notrans', 45, 0, False, False, False),
+                ('rotmat_newskel', 0, None, True, False, True), ('zero_pose', 45, None, False, False, False)]
+
+
+def gtmano_inputs(case, B=5):
+    """inputs of models/manolayer.py::ManoLayer.forward for the case tuple (name, ncomps (0 = rotation matrices), center_idx,
+    with_trans(ignored for 'center0_notrans'), with_scale, new_skel)"""
+    name, ncomps = case[0], case[1]
+    from oracle.gt_mano import rodrigues_batch
+    ax = synth.synth_input('gtmano.root.' + name, (B, 3), SEED) * np.float32(1.2)
+    R = rodrigues_batch(ax.astype(np.float64)).astype(np.float32)
+    if ncomps > 0:
+        pose = synth.synth_input('gtmano.pose.' + name, (B, ncomps), SEED) * np.float32(0.0 if name == 'zero_pose' else 0.8)
+    else:
+        a = synth.synth_input('gtmano.rotpose.' + name, (B * 15, 3), SEED) * np.float32(0.5)
+        pose = rodrigues_batch(a.astype(np.float64)).astype(np.float32).reshape(B, 15, 3, 3)
+    shape = synth.synth_input('gtmano.shape.' + name, (B, 10), SEED)
+    trans = None if name == 'center0_notrans' else (synth.synth_input('gtmano.trans.' + name, (B, 3), SEED) * np.float32(0.1) +
+                                                   np.array([0, 0, 0.7], np.float32))
+    scale = (1 + 0.1 * synth.synth_input('gtmano.scale.' + name, (B,), SEED)).astype(np.float32) if case[4] else None
+    return R, pose, shape, trans, scale

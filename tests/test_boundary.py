@@ -61,6 +61,20 @@ def test_reference_call_signatures():
         PGraphConv(64, 64, adj)
 
 
+def test_next_row_call_signatures():
+    """8f rank 1 mirrors: models/manolayer.py::ManoLayer (:100-105, :251) and apps/eval.py::Jr (:22-44)"""
+    import inspect
+    from dir_amd.apps.eval import Jr
+    from dir_amd.models.manolayer import ManoLayer as GTManoLayer
+    assert list(inspect.signature(GTManoLayer.__init__).parameters)[:5] == ['self', 'manoPath', 'center_idx', 'use_pca', 'new_skel']
+    assert list(inspect.signature(GTManoLayer.forward).parameters) == ['self', 'root_rotation', 'pose', 'shape', 'trans', 'scale']
+    assert list(inspect.signature(Jr.__init__).parameters) == ['self', 'J_regressor', 'device']
+    layer = GTManoLayer.synthetic('left', center_idx=None)
+    assert layer.J_regressor.shape == (16, 778) and layer.hands_components_inv.shape == (45, 45)
+    assert layer.parent == [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14] and layer.get_faces().shape == (1538, 3)
+    assert list(layer.state_dict().keys()) == ['hands_components', 'hands_components_inv']      # the persistent buffers
+
+
 def test_eval_only_and_gpu_only():
     from dir_amd import _capi
     from dir_amd.models.dir import DIR

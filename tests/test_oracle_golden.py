@@ -230,3 +230,20 @@ def test_eval_metrics_match_reference(golden, root_joint, scale):
         tol = 5e-3 if '2d' in k else 2e-6
         assert out[k[len(tag):]].shape == g[k].shape
         assert maxabs(out[k[len(tag):]], g[k]) <= tol, k
+
+
+# ------------------------------------------------------------------ G10 GT MANO layer (8f rank 1)
+def test_gt_mano_matches_reference(golden):
+    """oracle/gt_mano.py vs the reference's models/manolayer.py::ManoLayer outputs (12 cases: PCA 45 / 12, rotation-matrix
+    pose, centring, scale, no translation, new_skel, zero pose; both hands).  1e-7 m = 1e-4 mm."""
+    from oracle import gt_mano as G
+    from oracle.golden_inputs import GTMANO_CASES, gtmano_inputs
+    g = golden('g10_gtmano')
+    assert len([k for k in g if k.endswith('.verts')]) == 12
+    for side in ('left', 'right'):
+        T = G.tables(side)
+        for case in GTMANO_CASES:
+            R, pose, shape, trans, scale = gtmano_inputs(case)
+            v, j = G.gt_mano_forward(T, R, pose, shape, trans, scale, center_idx=case[2], use_pca=case[1] > 0, new_skel=case[5])
+            assert maxabs(v, g['%s.%s.verts' % (side, case[0])]) <= 1e-7, (side, case[0])
+            assert maxabs(j, g['%s.%s.joints' % (side, case[0])]) <= 1e-7, (side, case[0])
