@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-autotune', action='store_true', help='keep the library heuristic for every conv layer')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=64, help='images timed on the CPU baseline')
     ap.add_argument('--cpu-threads', type=int, default=16)
@@ -66,6 +67,8 @@ def main():
     fwd = lambda: eng.forward(img)                # noqa: E731
     outs = fwd()                                  # eager once: allocator warm-up, lazy init
     torch.cuda.synchronize()
+    if not args.no_autotune:
+        eng.autotune(img)                         # per-layer conv kernel variant for this batch size (bit-identical results)
     if args.no_graph:
         step = fwd
     else:
@@ -104,11 +107,11 @@ def main():
         for _ in range(reps):
             eng.forward(img)
         torch.cuda.synchronize()
-        rec = [(t_, f_, e0.elapsed_time(e1)) for t_, f_, e0, e1, _, _ in E.PROFILE]
-        alg_bytes = [nb for t_, _, _, _, _, nb in E.PROFILE if t_ == tag]
+        rec = [(r[0], r[1], r[2].elapsed_time(r[3])) for r in E.PROFILE]
+        alg_bytes = [r[5] for r in E.PROFILE if r[0] == tag]
         if args.dump_conv:
             agg = {}
-            for t_, f_, e0, e1, shp, _ in E.PROFILE:
+            for t_, f_, e0, e1, shp, _, _ in E.PROFILE:
                 a = agg.setdefault((t_, shp), [0, 0.0, 0.0])
                 a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f_
             for (t_, shp), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -168,7 +171,7 @@ def main():
                          '%.1f s' % (n, chunk, nthreads, tc)}
 
     if rank == 0:
-        line = {'metric': 'images/sec at 256x256 bs=64, 3 stage outputs (DIR.forward eval)', 'value': round(value, 1),
+        line = {'metric': 'images/sec at 256x256 bs=%d, 3 stage outputs (DIR.forward eval)' % B, 'value': round(value, 1),
                 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': args.dtype, 'data': 'synthetic',

@@ -418,7 +418,8 @@ template <typename TI, typename TO>
 void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     if constexpr (std::is_same<TI, bf16_t>::value) {
         // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip
-        if (launch_conv_pipe(a0, std::is_same<TO, float>::value, num_cu, s)) return;
+        const bool four_wave = (a0.variant & 15) >= 1 && (a0.variant & 15) <= 4;     // explicit DIR_CONV_VARIANT 1..4 (+16)
+        if (!four_wave && launch_conv_pipe(a0, std::is_same<TO, float>::value, num_cu, s)) return;
     }
     ConvArgs a = a0;
     // tile shape: 64-wide N tile for Cout <= 64 (no half-empty MFMA tiles); 64-tall M tile when the 128-tall grid
@@ -428,12 +429,21 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     static const int force_n64 = getenv("DIR_FORCE_N64") ? atoi(getenv("DIR_FORCE_N64")) : -1;   // tuning aid
     if (!n64 && force_n64 != 0 && ((long long)((a.M + 63) / 64) * ((a.Cout + 127) / 128) <= (long long)num_cu || force_n64 == 1)) n64 = true;
     const int bn = n64 ? 64 : 128;
-    const int tiles_n = (a.Cout + bn - 1) / bn;
+    int tiles_n = (a.Cout + bn - 1) / bn;
     // ... or when the reduction is so short (<= 4 slabs) that the layer is HBM-bound: smaller tiles = more workgroups
     // per CU = more bytes in flight
     const bool m64_auto = (long long)((a.M + 127) / 128) * tiles_n <= (long long)num_cu || a.nk <= 4;
     static const int force_m64 = getenv("DIR_FORCE_M64") ? atoi(getenv("DIR_FORCE_M64")) : -1;   // tuning aid
-    const bool m64 = force_m64 >= 0 ? (force_m64 != 0) : m64_auto;
+    bool m64 = force_m64 >= 0 ? (force_m64 != 0) : m64_auto;
+    int ring_sel = -1;
+    const int var = a.variant & 15;
+    if (var >= 1 && var <= 4) {                            // explicit tile (DIR_CONV_VARIANT): 128x128 | 128x64 | 64x128 | 64x64
+        m64 = var >= 3;
+        n64 = (var == 2 || var == 4);
+        ring_sel = (a.variant & 16) ? 1 : 0;
+    }
+    const int bn2 = n64 ? 64 : 128;
+    tiles_n = (a.Cout + bn2 - 1) / bn2;
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
@@ -441,7 +451,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const bool pre = a.pre_scale != nullptr;
     // 3-buffer ring (two slabs in flight) pays once the reduction is long enough to amortise its two-slab prologue
     static const int ring_min = getenv("DIR_RING_MIN_NK") ? atoi(getenv("DIR_RING_MIN_NK")) : 12;   // tuning aid
-    const bool ring = a.nk >= ring_min;
+    const bool ring = ring_sel >= 0 ? (ring_sel == 1 && a.nk >= 3) : a.nk >= ring_min;
 #define DIR_LAUNCH(MI_, NJ_)                                                                                   \
     do {                                                                                                       \
         if (pre) hipLaunchKernelGGL((conv_igemm_kernel<TI, TO, MI_, NJ_, true, false>), grid, block, 0, s, a);       \
@@ -493,6 +503,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     a.M = (int)M; a.K = d->kh * d->kw * d->Cin; a.nk = a.K / BK;
     a.tiles_m = a.tiles_n = 0;
     a.flags = d->flags & 3;
+    a.variant = (d->flags >> 8) & 0xff;
     DIR_REQUIRE(d->kh * d->kw <= 32, "dir_conv2d_forward: at most 32 taps");
     const long long xb = (long long)d->B * d->H * d->W * in_cs * (f32 ? 4 : 2);
     const long long wb = (long long)d->Cout * a.K * (f32 ? 4 : 2);

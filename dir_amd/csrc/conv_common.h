@@ -87,6 +87,7 @@ struct ConvArgs {
     const float* pre_scale; const float* pre_shift; const void* res; void* y;
     int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
     int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
+    int variant;                        // DIR_CONV_VARIANT code (0 = heuristic)
     unsigned x_bytes, w_bytes;          // buffer sizes for the hardware bounds check
     const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
                                         // each 64-channel input group; K-slabs that cannot touch a tile are skipped

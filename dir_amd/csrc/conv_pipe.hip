@@ -620,14 +620,18 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
     static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
     static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
-    if (force == 0 || !(a.flags & 4) || a.nk < min_nk) return false;
+    const bool explicit_variant = a.variant >= 8 && a.variant <= 10;
+    if (force == 0 || !(a.flags & 4) || (a.nk < min_nk && !explicit_variant)) return false;
     const bool pre = a.pre_scale != nullptr;
     static const int pre_pipe = getenv("DIR_PIPE_PRE") ? atoi(getenv("DIR_PIPE_PRE")) : 1;     // tuning aid
     if (pre && (!pre_pipe || a.Cin > PRE_MAX_CIN || a.bbox)) return false;
     const long long hw = (long long)a.Ho * a.Wo;
     auto tiles = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
     int shape = 0;
-    if (force > 0) shape = force;
+    if (a.variant >= 8 && a.variant <= 10) {               // explicit tile (DIR_CONV_VARIANT)
+        shape = a.variant - 7;
+        if (a.nk < 1 || (pre && shape == 1)) return false;
+    } else if (force > 0) shape = force;
     else {
         // largest tile that still gives (nearly) every CU a workgroup; 64-wide N tile only for Cout <= 64
         const long long need = (long long)num_cu * 3 / 4;

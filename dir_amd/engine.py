@@ -39,6 +39,7 @@ def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
 
 class ConvOp(object):
     """one dir_conv2d_forward call with packed parameters"""
+    default_variant = None        # set during DirEngine.autotune: every layer tries this DIR_CONV_VARIANT
 
     def __init__(self, w_oihw, dtype, stride=1, pad=0, scale=None, shift=None, relu=False, pre=None, pre_relu=False,
                  out_dtype=None):
@@ -53,6 +54,7 @@ class ConvOp(object):
         self.ho = self.wo = 0
         self.in_cs_override = None
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
+        self.variant = {}                                  # batch size -> DIR_CONV_VARIANT code chosen by DirEngine.autotune
 
     def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None):
         B, H, W, cbuf = x.shape
@@ -63,6 +65,8 @@ class ConvOp(object):
         d = ConvDesc(B, H, W, self.cin, self.in_cs_override or cbuf, in_coff, self.cout, out.shape[3], out_coff,
                      residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
                      _dt(self.dtype), _dt(out.dtype), self.flags, self.ho, self.wo)
+        v = ConvOp.default_variant if ConvOp.default_variant is not None else self.variant.get(B, 0)
+        d.flags |= (v & 0xff) << 8
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -83,7 +87,7 @@ class ConvOp(object):
                       + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
             PROFILE.append((tag, 2.0 * B * ho * wo * self.cout * self.alg_k, e0, e1,
                             'M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
-                                                           self.kw, self.stride), nbytes))
+                                                           self.kw, self.stride), nbytes, self))
         return out
 
 
@@ -309,6 +313,7 @@ def run_mano_pair(tables_lr, para_l, para_r, B):
 class DirEngine(object):
     def __init__(self, state_dict, dtype=torch.bfloat16, root_joint=0, device='cuda', sparse_fusion=True):
         assert dtype in (torch.bfloat16, torch.float32)
+        self.tuned_batches = set()
         self.sparse_fusion = sparse_fusion     # skip all-zero (tap, bone) K-slabs in the fusion conv (bit-identical)
         _capi.lib()
         self.dtype, self.device = dtype, torch.device(device)
@@ -459,6 +464,46 @@ class DirEngine(object):
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
+
+    # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 19, 20, 8, 9, 10)
+
+    def autotune(self, img, reps=2):
+        """Pick the convolution kernel variant per layer for this batch size by timing every candidate inside real
+        forwards (HIP events around each conv launch, side stream off, realistic cache state).  All variants accumulate in
+        the same order, so the outputs are bit-identical whatever is chosen; a variant that does not apply to a layer falls
+        back to the heuristic inside the library.  ~12 x (reps+1) eager forwards, once per (engine, batch size)."""
+        global PROFILE
+        B = img.shape[0]
+        saved_overlap, saved_profile = self.overlap, PROFILE
+        self.overlap = False
+        best = {}
+        try:
+            for v in self.CONV_VARIANTS:
+                ConvOp.default_variant = v
+                PROFILE = []
+                self.forward(img)                                  # warm-up (allocator, instruction cache)
+                torch.cuda.synchronize()
+                PROFILE = []
+                for _ in range(reps):
+                    self.forward(img)
+                torch.cuda.synchronize()
+                acc = {}
+                for rec in PROFILE:
+                    op = rec[6]
+                    acc.setdefault(op, []).append(rec[2].elapsed_time(rec[3]))
+                for op, ts in acc.items():
+                    t = min(ts)
+                    if op not in best or t < best[op][0] * 0.97:  # a challenger must win by 3 % (timing noise)
+                        best[op] = (t, v)
+        finally:
+            ConvOp.default_variant = None
+            PROFILE = saved_profile
+            self.overlap = saved_overlap
+        for op, (t, v) in best.items():
+            op.variant[B] = v
+        self.tuned_batches.add(B)
+        return {op: v for op, (t, v) in best.items()}
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, img, want_proj_feat=True, taps=None):

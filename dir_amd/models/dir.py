@@ -145,6 +145,7 @@ class DIR(nn.Module):
         self.coord_weight, self.dense_weight = 10, 1
         self.seg_loss = nn.CrossEntropyLoss(weight=torch.Tensor([.1, 0.45, 0.45]))     # state-dict key seg_loss.weight
         self._engine, self._engine_key = None, None
+        self.autotune = True
 
     def engine(self):
         """(re)pack the parameters when any of them changed (load_state_dict, .to(), in-place edits)."""
@@ -165,6 +166,9 @@ class DIR(nn.Module):
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()
         with torch.cuda.device(x.device), torch.no_grad():
-            outs = eng.forward(_capi.f32c(x))
+            x = _capi.f32c(x)
+            if self.autotune and x.shape[0] not in eng.tuned_batches and not torch.cuda.is_current_stream_capturing():
+                eng.autotune(x)             # once per batch size: per-layer conv kernel choice (bit-identical results)
+            outs = eng.forward(x)
         outs_list = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs]
         return outs_list, {}

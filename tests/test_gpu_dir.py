@@ -155,3 +155,18 @@ def test_engine_odd_batch_sizes(dir_state, dt):
     for B in (3, 5):
         o = eng.forward(five[:B].contiguous())
         assert torch.equal(o[2]['pd_mesh_xyz_right'], ref_v[:B]) and torch.equal(o[3]['seg'], ref_seg[:B]), (B, dt)
+
+
+def test_autotuned_engine_is_bit_identical(dir_state):
+    """DirEngine.autotune only changes WHICH convolution kernel runs per layer; every variant accumulates in the same order,
+    so the whole forward is bit-identical before and after tuning (bf16 mode, batch 4)."""
+    eng = DirEngine(dir_state[0] if isinstance(dir_state, tuple) else dir_state, dtype=torch.bfloat16)
+    img = torch.randn(4, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
+    before = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in eng.forward(img)]
+    chosen = eng.autotune(img, reps=1)
+    assert len(chosen) > 60 and set(chosen.values()) <= set(eng.CONV_VARIANTS)
+    after = eng.forward(img)
+    for o0, o1 in zip(before, after):
+        for k, v in o0.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, o1[k]), k
