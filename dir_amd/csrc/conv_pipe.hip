@@ -30,7 +30,7 @@ struct Slab {
 
 constexpr int PRE_MAX_CIN = 2304;      // pre-activation parameters staged in LDS (fusion_layer4: 2048 + 256 channels)
 
-template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false>
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false, int NBUF = 3>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) {
     typedef bf16_t TI;
     constexpr int NT = 64 * WM * WN;               // threads
@@ -39,7 +39,6 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     constexpr int ACH = BM / RPP, BCH = BN / RPP, NP = ACH + BCH;   // DMA pieces per thread per slab
     constexpr int ROW = 128;
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
-    constexpr int NBUF = 3;
     constexpr int STAGE_BYTES = BM * BN * 4;
     constexpr int SMEM = NBUF * BUF_BYTES > STAGE_BYTES ? NBUF * BUF_BYTES : STAGE_BYTES;
     constexpr int EPC = 8, BK = 64, ES = 2;
@@ -233,13 +232,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
 
     // ---- prologue: three slabs in flight, the first one's fragments in register set 0
     {
-        const Slab s0 = next_slab(0);
-        dma_slab(s0, 0, nact > 0);
-        const Slab s1 = next_slab(1);
-        dma_slab(s1, 1, nact > 1);
-        const Slab s2 = next_slab(2);
-        dma_slab(s2, 2, nact > 2);
-        wait_vmcnt<2 * NP>();
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) {
+            const Slab si = next_slab(i);
+            dma_slab(si, i, nact > i);
+        }
+        wait_vmcnt<(NBUF - 1) * NP>();
         pre_transform(0);
         __syncthreads();
         [&]<int... R>(std::integer_sequence<int, R...>) {
@@ -253,13 +251,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     int buf = 0;                                   // ks % 3
     auto iteration = [&](auto Pc, int ks) {
         constexpr int P = decltype(Pc)::value;
-        wait_vmcnt<NP>();
-        const int nb = buf == 2 ? 0 : buf + 1;     // (ks + 1) % 3
+        wait_vmcnt<(NBUF - 2) * NP>();             // slabs ks+2 .. ks+NBUF-1 may still be in flight
+        const int nb = buf == NBUF - 1 ? 0 : buf + 1;     // (ks + 1) % NBUF
         if (ks + 1 < nact) pre_transform(nb);      // own pieces of slab ks+1 have landed; everyone else's after the barrier
         __syncthreads();
         const char* rbuf = smem + nb * BUF_BYTES;
-        const bool live = ks + 3 < nact;
-        const Slab sd = next_slab(ks + 3);
+        const bool live = ks + NBUF < nact;
+        const Slab sd = next_slab(ks + NBUF);
         const unsigned ba = lds_base + buf * BUF_BYTES + wave * 1024;
         // slot plan: MFMA t is followed by RPS fragment reads (slots [0, H)) or DPS DMA pieces (slots [H, NSLOT))
         constexpr int RPS = (NREAD + NSLOT / 2 - 1) / (NSLOT / 2);

@@ -72,6 +72,31 @@ __global__ void stem_prep_kernel(const float* __restrict__ img, T* __restrict__ 
     }
 }
 
+// Space-to-depth staging of the stem input: out[b][Y][X][16], channel (dy*2 + dx)*4 + c = img[b][c][2Y - 4 + dy][2X - 4 + dx]
+// (zero outside the image and for c = 3).  The 7x7 stride-2 pad-3 stem convolution (models/backbone/resnet.py:244) becomes
+// a 4x4 stride-1 convolution over 2x2 pixel blocks: output (oy, ox) reads blocks Y = oy..oy+3, X = ox..ox+3, and one
+// K-slab of the implicit GEMM is the 128-byte window of 4 blocks x 16 channels of one block row -- K = 4 x 64 = 256
+// instead of the 7 x 64 = 448 of the row-window formulation over single pixels (147 of them non-zero either way).
+template <typename T>
+__global__ void stem_prep_s2d_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int Hs, int Ws) {
+    const long long n = (long long)B * Hs * Ws * 4;                     // one thread per (block, dy*2+dx)
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        long long p = i >> 2;
+        const int X = (int)(p % Ws); p /= Ws;
+        const int Y = (int)(p % Hs);
+        const int b = (int)(p / Hs);
+        const int y = 2 * Y - 4 + (q >> 1), x = 2 * X - 4 + (q & 1);
+        float v[3] = {0.f, 0.f, 0.f};
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = img[((long long)(b * 3 + c) * H + y) * W + x];
+        }
+        T* o = out + i * 4;
+        st<T>(o, v[0]); st<T>(o + 1, v[1]); st<T>(o + 2, v[2]); st<T>(o + 3, 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ maxpool
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
@@ -413,6 +438,17 @@ extern "C" int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int
     else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad);
     else DIR_REQUIRE(false, "dir_stem_prep: bad dtype");
     return dir::check_launch("dir_stem_prep");
+}
+
+extern "C" int dir_stem_prep_s2d(const float* img_nchw, void* out, int B, int H, int W, int Hs, int Ws, int dtype, void* stream) {
+    DIR_REQUIRE(img_nchw && out && B > 0 && H > 0 && W > 0, "dir_stem_prep_s2d: bad args");
+    DIR_REQUIRE(H % 2 == 0 && W % 2 == 0 && Hs >= H / 2 + 3 && Ws >= W / 2 + 3, "dir_stem_prep_s2d: need even H, W and Hs >= H/2+3, Ws >= W/2+3");
+    const long long n = (long long)B * Hs * Ws * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((stem_prep_s2d_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hs, Ws);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_s2d_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hs, Ws);
+    else DIR_REQUIRE(false, "dir_stem_prep_s2d: bad dtype");
+    return dir::check_launch("dir_stem_prep_s2d");
 }
 
 extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {

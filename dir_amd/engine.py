@@ -174,15 +174,25 @@ class BackboneOp(object):
     def __init__(self, sd, p, dtype, device):
         dt = self.dtype = dtype
         self.device = device
-        # one "tap" = an image-row window of kwin pixels x 4 channels (RGB0); zero weights beyond the 7 real taps
-        self.kwin = 8 if dt == torch.float32 else 16
+        # 7x7/2 stem over 2x2 space-to-depth blocks (dir_stem_prep_s2d): a 4x4 stride-1 convolution whose K-slab is a
+        # block-row window of 4 blocks x 16 channels; w'[n][j*16 + (dy*2+dx)*4 + c][r] = w[n, c, 2r+dy-1, 2j+dx-1]
         w = sd[p + '.conv1.weight']                                       # [64,3,7,7]
-        wp = torch.zeros(64, self.kwin * 4, 7, 1, device=w.device, dtype=F32)     # [Cout, Cin', kh, kw=1]
-        for kx in range(7):
-            wp[:, kx * 4:kx * 4 + 3, :, 0] = w[:, :, :, kx]
+        wp = torch.zeros(64, 64, 4, 1, device=w.device, dtype=F32)        # [Cout, Cin', kh, kw=1]
+        for r in range(4):
+            for dy in range(2):
+                ky = 2 * r + dy - 1
+                if not 0 <= ky <= 6:
+                    continue
+                for j in range(4):
+                    for dx in range(2):
+                        kx = 2 * j + dx - 1
+                        if 0 <= kx <= 6:
+                            c0 = j * 16 + (dy * 2 + dx) * 4
+                            wp[:, c0:c0 + 3, r, 0] = w[:, :, ky, kx]
         s, h = bn_fold(sd, p + '.bn1')
-        self.stem = ConvOp(wp, dt, stride=2, pad=0, scale=s, shift=h, relu=True)
+        self.stem = ConvOp(wp, dt, stride=1, pad=0, scale=s, shift=h, relu=True)
         self.stem.ho = self.stem.wo = 128
+        self.stem.in_cs_override = 16
         self.stem.alg_k = 147
         self.layers = []
         for li, n in enumerate((3, 4, 6, 3), start=1):
@@ -205,11 +215,10 @@ class BackboneOp(object):
     def __call__(self, img):
         L, dt, dev = _capi.lib(), self.dtype, self.device
         B = img.shape[0]
-        # 3 blank pixels top/left; wide enough for the last window (column 2*127 + kwin - 1), rows 16-byte aligned
-        Hp, Wp = 262, (272 if self.kwin == 16 else 264)
-        xp = torch.empty(B, Hp, Wp, 4, device=dev, dtype=dt)
-        _capi.check(L.dir_stem_prep(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hp, Wp, 3, _dt(dt), _capi.stream_ptr()),
-                    'dir_stem_prep')
+        Hs, Ws = 131, 132                                                        # blocks Y, X = 0 .. 130 (+1 column: even rows)
+        xp = torch.empty(B, Hs, Ws, 16, device=dev, dtype=dt)
+        _capi.check(L.dir_stem_prep_s2d(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hs, Ws, _dt(dt), _capi.stream_ptr()),
+                    'dir_stem_prep_s2d')
         s1 = self.stem(xp)                                                       # [B,128,128,64]
         x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
         _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),

@@ -142,6 +142,12 @@ int dir_conv2d_sparse_forward(const dir_conv_desc* desc_host, const void* x, con
  * 7x7/s2 stem (models/backbone/resnet.py:176,244) becomes a kh=7,kw=1 implicit GEMM over contiguous pixel windows. */
 int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int W, int Hp, int Wp, int pad, int dtype,
                   void* stream);
+/* The same staging as 2x2 space-to-depth blocks: out [B,Hs,Ws,16] (dtype), channel (dy*2+dx)*4 + c =
+ * img[b][c][2Y-4+dy][2X-4+dx] (zero outside the image / for c = 3); Hs >= H/2+3, Ws >= W/2+3.  The 7x7/2 stem becomes
+ * dir_conv2d_forward with kh=4, kw=1, stride=1, pad=0, Cin=64 (4 blocks x 16 channels), in_cstride=16, Ho=H/2, Wo=W/2 and
+ * weights [Cout][4][1][64] (w[n][r][0][j*16 + (dy*2+dx)*4 + c] = conv1.weight[n, c, 2r+dy-1, 2j+dx-1], zero outside 0..6):
+ * K = 256 per output instead of 448. */
+int dir_stem_prep_s2d(const float* img_nchw, void* out, int B, int H, int W, int Hs, int Ws, int dtype, void* stream);
 /* nn.MaxPool2d(3, 2, 1) (models/backbone/resnet.py:179,247): [B,H,W,C] -> [B,(H+1)/2,(W+1)/2,C] */
 int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 /* nn.Upsample(scale_factor=2, mode='bilinear') (models/dir.py:392,398; align_corners=False): [B,H,W,C] ->
