@@ -83,6 +83,8 @@ _SIGNATURES = {
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'dir_image_normalize_forward': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _p]),
+    'dir_stem_prep_s2d_u8': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

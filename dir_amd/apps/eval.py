@@ -15,6 +15,27 @@ import torch
 
 from .. import _capi
 
+IMG_MEAN, IMG_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # apps/eval.py:49-50
+
+
+def normalize_images(img_u8_bgr):
+    """apps/eval.py:59-61 for a batch: uint8 BGR [B,H,W,3] (cv.imread / cv.resize output) -> float32 RGB NCHW, / 255,
+    ImageNet-normalised; bit-identical to the reference's torch CPU result.  (DirEngine.forward / DIR accept the uint8 batch
+    directly and fuse this into the stem staging.)"""
+    import ctypes as C
+    _capi.require_cuda(img_u8_bgr)
+    if img_u8_bgr.dtype != torch.uint8 or img_u8_bgr.dim() != 4 or img_u8_bgr.shape[3] != 3:
+        raise _capi.DirHipError('normalize_images: expected a uint8 [B,H,W,3] tensor')
+    x = img_u8_bgr.contiguous()
+    B, H, W, _ = x.shape
+    out = torch.empty(B, 3, H, W, device=x.device)
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().dir_image_normalize_forward(_capi.ptr(x), _capi.ptr(out), (C.c_float * 3)(*IMG_MEAN),
+                                                            (C.c_float * 3)(*IMG_STD), B, H, W, _capi.stream_ptr()),
+                    'dir_image_normalize_forward')
+    return out
+
+
 TIP_VERTS = (745, 317, 444, 556, 673)
 NEW_ORDER = (0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20)
 

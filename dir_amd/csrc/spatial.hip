@@ -97,6 +97,47 @@ __global__ void stem_prep_s2d_kernel(const float* __restrict__ img, T* __restric
     }
 }
 
+// ---- SURVEY 8f rank 3 (tensor side of the input pipeline): apps/eval.py:59-61 == dataset/interhand.py:223-225
+//      uint8 BGR HWC -> RGB, / 255, (t - mean) / std, in the reference's fp32 operation order (bit-identical to torch on CPU)
+__device__ __forceinline__ float norm_px(unsigned char v, float mean, float stdv) {
+#pragma clang fp contract(off)
+    return ((float)v / 255.f - mean) / stdv;
+}
+struct NormArgs { float mean[3], stdv[3]; };
+
+__global__ void image_normalize_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, int B, int H, int W, NormArgs nm) {
+    const long long n = (long long)B * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)H * W), p = i - b * H * W;
+        const unsigned char* px = img + i * 3;                                  // B, G, R
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(b * 3 + c) * H * W + p] = norm_px(px[2 - c], nm.mean[c], nm.stdv[c]);
+    }
+}
+
+// the same, fused with the space-to-depth staging of the stem (no fp32 NCHW image in HBM)
+template <typename T>
+__global__ void stem_prep_s2d_u8_kernel(const unsigned char* __restrict__ img, T* __restrict__ out, int B, int H, int W, int Hs, int Ws,
+                                        NormArgs nm) {
+    const long long n = (long long)B * Hs * Ws * 4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i & 3);
+        long long p = i >> 2;
+        const int X = (int)(p % Ws); p /= Ws;
+        const int Y = (int)(p % Hs);
+        const int b = (int)(p / Hs);
+        const int y = 2 * Y - 4 + (q >> 1), x = 2 * X - 4 + (q & 1);
+        float v[3] = {0.f, 0.f, 0.f};
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            const unsigned char* px = img + (((long long)b * H + y) * W + x) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = norm_px(px[2 - c], nm.mean[c], nm.stdv[c]);
+        }
+        T* o = out + i * 4;
+        st<T>(o, v[0]); st<T>(o + 1, v[1]); st<T>(o + 2, v[2]); st<T>(o + 3, 0.f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ maxpool
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
@@ -449,6 +490,41 @@ extern "C" int dir_stem_prep_s2d(const float* img_nchw, void* out, int B, int H,
     else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_s2d_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hs, Ws);
     else DIR_REQUIRE(false, "dir_stem_prep_s2d: bad dtype");
     return dir::check_launch("dir_stem_prep_s2d");
+}
+
+static int norm_args(const float* mean, const float* stdv, NormArgs* nm, const char* who) {
+    DIR_REQUIRE(mean && stdv, "%s: null mean / std (host pointers to 3 floats)", who);
+    for (int c = 0; c < 3; ++c) {
+        DIR_REQUIRE(stdv[c] != 0.f, "%s: std[%d] is zero", who, c);
+        nm->mean[c] = mean[c];
+        nm->stdv[c] = stdv[c];
+    }
+    return DIR_OK;
+}
+
+extern "C" int dir_image_normalize_forward(const uint8_t* img_bgr_hwc, float* out_nchw, const float* mean_host, const float* std_host,
+                                           int B, int H, int W, void* stream) {
+    if (B == 0) return DIR_OK;
+    DIR_REQUIRE(img_bgr_hwc && out_nchw && B > 0 && H > 0 && W > 0, "dir_image_normalize_forward: bad args");
+    NormArgs nm;
+    if (int rc = norm_args(mean_host, std_host, &nm, "dir_image_normalize_forward")) return rc;
+    hipLaunchKernelGGL(image_normalize_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img_bgr_hwc, out_nchw, B, H,
+                       W, nm);
+    return dir::check_launch("dir_image_normalize_forward");
+}
+
+extern "C" int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const float* mean_host, const float* std_host, int B, int H, int W,
+                                    int Hs, int Ws, int dtype, void* stream) {
+    DIR_REQUIRE(img_bgr_hwc && out && B > 0 && H > 0 && W > 0, "dir_stem_prep_s2d_u8: bad args");
+    DIR_REQUIRE(H % 2 == 0 && W % 2 == 0 && Hs >= H / 2 + 3 && Ws >= W / 2 + 3, "dir_stem_prep_s2d_u8: need even H, W and Hs >= H/2+3, Ws >= W/2+3");
+    NormArgs nm;
+    if (int rc = norm_args(mean_host, std_host, &nm, "dir_stem_prep_s2d_u8")) return rc;
+    const long long n = (long long)B * Hs * Ws * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((stem_prep_s2d_u8_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (float*)out, B, H, W, Hs, Ws, nm);
+    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_s2d_u8_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (bf16_t*)out, B, H, W, Hs, Ws, nm);
+    else DIR_REQUIRE(false, "dir_stem_prep_s2d_u8: bad dtype");
+    return dir::check_launch("dir_stem_prep_s2d_u8");
 }
 
 extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {

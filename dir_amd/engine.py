@@ -19,6 +19,8 @@ from . import _capi
 from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
 
 F32 = torch.float32
+IMAGENET_MEAN = (C.c_float * 3)(0.485, 0.456, 0.406)      # apps/eval.py:49-50
+IMAGENET_STD = (C.c_float * 3)(0.229, 0.224, 0.225)
 PROFILE = None     # set to a list to record (kernel tag, algorithmic flops, start event, end event) per conv launch
 
 
@@ -217,8 +219,12 @@ class BackboneOp(object):
         B = img.shape[0]
         Hs, Ws = 131, 132                                                        # blocks Y, X = 0 .. 130 (+1 column: even rows)
         xp = torch.empty(B, Hs, Ws, 16, device=dev, dtype=dt)
-        _capi.check(L.dir_stem_prep_s2d(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hs, Ws, _dt(dt), _capi.stream_ptr()),
-                    'dir_stem_prep_s2d')
+        if img.dtype == torch.uint8:     # [B,256,256,3] BGR as decoded: normalisation fused into the staging (apps/eval.py:59-61)
+            _capi.check(L.dir_stem_prep_s2d_u8(_capi.ptr(img), _capi.ptr(xp), IMAGENET_MEAN, IMAGENET_STD, B, 256, 256, Hs, Ws,
+                                               _dt(dt), _capi.stream_ptr()), 'dir_stem_prep_s2d_u8')
+        else:
+            _capi.check(L.dir_stem_prep_s2d(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, Hs, Ws, _dt(dt), _capi.stream_ptr()),
+                        'dir_stem_prep_s2d')
         s1 = self.stem(xp)                                                       # [B,128,128,64]
         x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
         _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),
@@ -519,7 +525,10 @@ class DirEngine(object):
         """img: float32 NCHW [B,3,256,256] on the GPU.  Returns outs_list exactly like DIR.forward (models/dir.py:521-540);
         tensors are engine-owned buffers (valid until the next forward when run under a captured graph)."""
         _capi.require_cuda(img)
-        assert img.dtype == F32 and img.is_contiguous() and img.shape[1:] == (3, 256, 256)
+        if img.dtype == torch.uint8:     # decoded BGR frames [B,256,256,3]: the reference's normalisation runs inside the stem staging
+            assert img.is_contiguous() and img.shape[1:] == (256, 256, 3)
+        else:
+            assert img.dtype == F32 and img.is_contiguous() and img.shape[1:] == (3, 256, 256)
         dt, dev = self.dtype, self.device
         B = img.shape[0]
         feats = self.bb(img)

@@ -166,7 +166,7 @@ class DIR(nn.Module):
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()
         with torch.cuda.device(x.device), torch.no_grad():
-            x = _capi.f32c(x)
+            x = x.contiguous() if x.dtype == torch.uint8 else _capi.f32c(x)       # uint8 BGR [B,256,256,3]: fused normalisation
             if self.autotune and x.shape[0] not in eng.tuned_batches and not torch.cuda.is_current_stream_capturing():
                 eng.autotune(x)             # once per batch size: per-layer conv kernel choice (bit-identical results)
             outs = eng.forward(x)

@@ -325,6 +325,17 @@ int dir_gt_mano_forward(const dir_mano_tables* tables_host, const float* root_ro
                         const float* shape, const float* trans, const float* scale, int center_idx, int new_skel,
                         float* verts, float* joints, int B, void* stream);
 
+/* f3 (tensor side of the input pipeline): apps/eval.py:59-61 == dataset/interhand.py:223-225 --
+ * uint8 BGR HWC [B,H,W,3] (what cv.imread / cv.resize hand over) -> RGB, / 255, (t - mean) / std -> fp32 NCHW [B,3,H,W],
+ * in the reference's fp32 operation order (bit-identical to the torch CPU result).  mean / std: host pointers to 3 floats
+ * (ImageNet: 0.485 0.456 0.406 / 0.229 0.224 0.225).  JPEG decode and resize stay on the host. */
+int dir_image_normalize_forward(const uint8_t* img_bgr_hwc, float* out_nchw, const float* mean_host, const float* std_host,
+                                int B, int H, int W, void* stream);
+/* the same arithmetic fused into the space-to-depth stem staging (== dir_image_normalize_forward + dir_stem_prep_s2d,
+ * bit for bit, without the fp32 image in HBM) */
+int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const float* mean_host, const float* std_host, int B, int H,
+                         int W, int Hs, int Ws, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

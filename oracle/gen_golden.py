@@ -364,8 +364,39 @@ def gen_gtmano():
     save('g10_gtmano', **out)
 
 
+# ----------------------------------------------------------------------------- G11 input tensor preparation
+def gen_imgprep():
+    """apps/eval.py:59-61 (handDataset.__getitem__), the three statements after cv.resize, extracted from the reference file and
+    executed on a seeded uint8 BGR image batch; cv.cvtColor(BGR2RGB) and torchvision's Normalize are the only stubs (channel
+    flip; (t - mean) / std as torchvision.transforms.functional.normalize computes it)."""
+    import textwrap
+    src = open(os.path.join(REF, 'apps', 'eval.py')).read().split('\n')
+    a = next(i for i, l in enumerate(src) if 'imgTensor = torch.tensor(cv.cvtColor' in l)
+    body = textwrap.dedent('\n'.join(src[a:a + 3]))
+    assert 'normalize_img' in body and 'permute(2, 0, 1)' in body
+
+    class _Norm:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+    cvstub = types.SimpleNamespace(COLOR_BGR2RGB=4, cvtColor=lambda im, code: np.ascontiguousarray(im[..., ::-1]))
+    g = np.random.default_rng(SEED)
+    imgs = g.integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)
+    imgs[0, :4, :4] = 0
+    imgs[0, 4:8, :4] = 255
+    outs = []
+    for im in imgs:
+        ns = {'torch': torch, 'cv': cvstub, 'img': im,
+              'self': types.SimpleNamespace(normalize_img=_Norm([0.485, 0.456, 0.406], [0.229, 0.224, 0.225]))}
+        exec(body, ns)
+        outs.append(ns['imgTensor'].numpy())
+    save('g11_imgprep', img=imgs, y=np.stack(outs))
+
+
 GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
-        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano}
+        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

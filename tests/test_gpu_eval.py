@@ -144,3 +144,40 @@ def test_eval_rejects_bad_arguments():
     bad[2] = T('pd_offset').cpu()
     with pytest.raises(_capi.DirHipError):
         eval_batch(*bad)
+
+
+def test_image_normalize_bit_exact_vs_reference(golden):
+    """8f rank 3, tensor side: dir_image_normalize_forward == the reference's three statements (apps/eval.py:59-61), bit for bit"""
+    from dir_amd.apps.eval import normalize_images
+    g = golden('g11_imgprep')
+    y = normalize_images(torch.from_numpy(g['img']).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), g['y'])
+    from oracle.image_prep import normalize_u8_bgr
+    rng = np.random.default_rng(3)
+    big = rng.integers(0, 256, (5, 64, 96, 3), dtype=np.uint8)                 # other sizes, ragged batch
+    assert np.array_equal(normalize_images(torch.from_numpy(big).cuda()).cpu().numpy(), normalize_u8_bgr(big))
+    with pytest.raises(Exception):
+        normalize_images(torch.zeros(1, 3, 8, 8).cuda())
+
+
+def test_engine_accepts_uint8_frames(golden):
+    """DirEngine.forward on the decoded uint8 BGR batch (normalisation fused into the stem staging) == forward on the
+    reference-normalised float tensor, bit for bit"""
+    import json, os
+    from conftest import GOLDEN
+    from dir_amd import synth
+    from dir_amd.apps.eval import normalize_images
+    from dir_amd.engine import DirEngine
+    with open(os.path.join(GOLDEN, 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
+    eng = DirEngine(sd, dtype=torch.bfloat16)
+    u8 = torch.from_numpy(golden('g11_imgprep')['img']).cuda()
+    a = eng.forward(normalize_images(u8))
+    a = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in a]
+    b = eng.forward(u8)
+    for o0, o1 in zip(a, b):
+        for k, v in o0.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, o1[k]), k

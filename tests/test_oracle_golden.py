@@ -247,3 +247,10 @@ def test_gt_mano_matches_reference(golden):
             v, j = G.gt_mano_forward(T, R, pose, shape, trans, scale, center_idx=case[2], use_pca=case[1] > 0, new_skel=case[5])
             assert maxabs(v, g['%s.%s.verts' % (side, case[0])]) <= 1e-7, (side, case[0])
             assert maxabs(j, g['%s.%s.joints' % (side, case[0])]) <= 1e-7, (side, case[0])
+
+
+# ------------------------------------------------------------------ G11 input tensor preparation (8f rank 3, tensor side)
+def test_image_prep_matches_reference(golden):
+    from oracle.image_prep import normalize_u8_bgr
+    g = golden('g11_imgprep')
+    assert np.array_equal(normalize_u8_bgr(g['img']), g['y'])          # bit-exact: same fp32 operation order
