@@ -34,6 +34,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-autotune', action='store_true', help='keep the library heuristic for every conv layer')
+    ap.add_argument('--autotune-cache', default=None, help='JSON file: load the per-layer variants if it exists, else tune and save '
+                    '(profiling runs use it to keep the exploration out of the trace)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=64, help='images timed on the CPU baseline')
     ap.add_argument('--cpu-threads', type=int, default=16)
@@ -67,8 +69,15 @@ def main():
     fwd = lambda: eng.forward(img)                # noqa: E731
     outs = fwd()                                  # eager once: allocator warm-up, lazy init
     torch.cuda.synchronize()
-    if not args.no_autotune:
-        eng.autotune(img)                         # per-layer conv kernel variant for this batch size (bit-identical results)
+    if not args.no_autotune:                      # per-layer conv kernel variant for this batch size (bit-identical results)
+        if args.autotune_cache and os.path.exists(args.autotune_cache):
+            with open(args.autotune_cache) as f:
+                eng.import_tuning(img, json.load(f))
+        else:
+            eng.autotune(img)
+            if args.autotune_cache and rank == 0:
+                with open(args.autotune_cache, 'w') as f:
+                    json.dump(eng.export_tuning(B), f)
     if args.no_graph:
         step = fwd
     else:

@@ -7,19 +7,20 @@
 // One K-slab = 128 bytes per row for both precisions (32 fp32 / 64 bf16 channels).  A 32x32 MFMA lane
 // (i = lane&31, h = lane>>5) owns the contiguous 64-byte half h of row i of the slab: 4 x ds_read_b128
 // feed 16 x v_mfma_f32_32x32x2_f32 (fp32: exact fmaf chain) or 4 x v_mfma_f32_32x32x16_bf16.  Any
-// bijection of k is legal as long as A and W use the same one.  LDS rows are padded 128 -> 144 B, which
-// makes the ds_read_b128 pattern conflict free (bank step 36 dwords).
+// bijection of k is legal as long as A and W use the same one.
 //
-// Block = 256 threads (2x2 waves); tile (64|128)(M) x (64|128)(N) picked per layer (launch_conv): each wave owns
-// MI x NJ MFMA tiles of 32x32 (up to 64 acc VGPRs).
-// Global -> registers -> LDS, double-buffered LDS + two register stages (prefetch distance 2), one barrier per
-// K-slab.  Loads are hardware-bounds-checked buffer loads (out-of-range offset -> zeros): zero padding and the M / N
-// tails cost a select on a per-row tap bitmask computed once.  The optional pre-activation BatchNorm+ReLU
-// (hourglass.Residual, models/backbone/hourglass.py:55-70) is applied in the register stage.
-// Epilogue: per-channel scale/shift (folded BatchNorm / bias), optional residual add, optional ReLU,
-// optional channel offset/stride so a conv can write straight into a slice of a concat buffer.  The fp32 tile is
-// staged through LDS (reusing the pipeline buffers) so HBM sees 16-byte coalesced row segments for the output and
-// the residual -- the 1x1 bottleneck convs (K = 64..256) are HBM-bound and live or die by this.
+// This file: the general 4-wave kernel.  Block = 256 threads (2x2 waves); tile (64|128)(M) x (64|128)(N) picked per layer
+// (launch_conv, or forced through DIR_CONV_VARIANT); each wave owns MI x NJ MFMA tiles of 32x32 (up to 64 acc VGPRs).
+//   * K-slabs travel global -> LDS by DMA (buffer_load ... lds; hardware bounds check = zero padding and M / N tails), rows
+//     unpadded with an XOR swizzle applied on the SOURCE address so ds_read_b128 is conflict free; 2 LDS buffers, or a
+//     3-buffer ring with two slabs in flight (untracked asm DMA + counted vmcnt) for long reductions.
+//   * The pre-activation variant (hourglass.Residual's BatchNorm+ReLU on the input, models/backbone/hourglass.py:55-70) must
+//     touch the data in registers: global -> registers -> LDS (rows padded 128 -> 144 B), two register stages.
+//   * Short reductions (K <= 512, the HBM-bound 1x1 bottleneck layers) prefetch their residual tile at kernel start.
+//   * Epilogue: per-channel scale/shift (folded BatchNorm / bias), optional residual add, optional ReLU, optional channel
+//     offset/stride so a conv writes straight into a slice of a concat buffer; the fp32 tile is staged through LDS so HBM
+//     sees 16-byte coalesced row segments for output and residual.
+// Layers with K >= 512 and enough tiles go to the 8-wave pipelined kernel of conv_pipe.hip instead (same results).
 //
 // Replaces the ATen/MKL-DNN (cuDNN in the original) calls under models/backbone/resnet.py:120-140,243-255,
 // models/backbone/hourglass.py:10-30,55-70 and models/dir.py:57-62,227-241,404-420.
@@ -140,20 +141,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < ACH; ++i) {
             const bool ok = (amask[i] >> tap) & 1u;
             const unsigned vo = ok ? (unsigned)(avoff[i] + toff) : OOB;
-            if constexpr (PRE || !UNTRACKED) {     // compiler-tracked load (the prologue consumes the data at once)
-                uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
-                if constexpr (PRE) {
-                    if (ok) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
-                }
-                ra[p][i] = __builtin_bit_cast(u32x4, v);
-            } else {
-                ra[p][i] = buffer_load_untracked(xd, vo, 0);
+            uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
+            if constexpr (PRE) {
+                if (ok) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
             }
+            ra[p][i] = __builtin_bit_cast(u32x4, v);
         }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
-            if constexpr (PRE || !UNTRACKED) rb[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[i], k0 * ES, 0));
-            else rb[p][i] = buffer_load_untracked(wd, bvoff[i], (unsigned)(k0 * ES));
+            rb[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[i], k0 * ES, 0));
         }
     };
     auto lstore = [&](auto P, int buf) {

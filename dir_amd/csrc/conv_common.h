@@ -14,29 +14,6 @@ typedef unsigned short bf16_t;
 typedef int __attribute__((ext_vector_type(4))) i32x4;
 typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 
-// Buffer load the COMPILER DOES NOT TRACK (inline asm): hipcc's wait-count pass drains every in-flight load at the
-// loop back-edge, which collapses a distance-2 software pipeline to distance 1.  These loads are waited for by hand
-// with counted s_waitcnt vmcnt(N) (wait_stage) so the newest stage stays in flight across the barrier.
-__device__ __forceinline__ u32x4 buffer_load_untracked(i32x4 rsrc, unsigned voff, unsigned soff) {
-    u32x4 v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-    return v;
-}
-// wait until at most N untracked loads are outstanding; the registers of the stage being released are tied to the
-// statement so no consumer can be scheduled above it
-template <int N, int NA, int NB>
-__device__ __forceinline__ void wait_stage(u32x4 (&a)[NA], u32x4 (&b)[NB]) {
-    static_assert(NA <= 4 && NB <= 4, "stage too large");
-    if constexpr (NA == 4 && NB == 4)
-        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
-    else if constexpr (NA == 4 && NB == 2)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
-    else if constexpr (NA == 2 && NB == 4)
-        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N));
-    else
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N));
-}
-
 // 16-byte-per-lane LDS-DMA: global -> LDS without a VGPR destination.  `lds` must be wave-uniform; lane L lands at
 // lds + 16*L.  An out-of-range voff writes zeros.  (Kept in a __device__ function: used directly inside the __global__
 // template, the host pass silently drops the kernel stub.)
@@ -65,10 +42,10 @@ __device__ __forceinline__ void lds_dma16_m0(i32x4 rsrc, unsigned lds_addr, unsi
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Register-destination loads hidden from the compiler turned out UNSAFE here: hipcc may split / copy the live range of
-// an asm-loaded register (e.g. at the loop header) before the data has landed -> intermittent garbage on large grids.
-// Kept for reference; the deep pipeline is built on LDS-DMA instead (no VGPR destination).
-constexpr bool UNTRACKED = false;
+// NOTE (kept as a warning): hiding REGISTER-destination loads from the compiler (inline-asm buffer_load +
+// hand-counted vmcnt) to deepen the register pipeline is UNSAFE -- hipcc may split / copy the live range of an asm-loaded VGPR
+// before the data has landed (intermittent garbage on full grids; tests/test_gpu_conv.py::
+// test_conv_full_size_chunk_consistency is the regression test).  The deep pipelines here use LDS-DMA (no VGPR destination).
 constexpr int LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

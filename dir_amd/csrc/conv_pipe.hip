@@ -597,7 +597,8 @@ void launch_tile(ConvArgs a, hipStream_t s) {
     dim3 grid(a.tiles_m * a.tiles_n), block(64 * WM * WN);
     static const int use_patch = getenv("DIR_PATCH") ? atoi(getenv("DIR_PATCH")) : 0;           // halo-reuse kernel: opt-in
     PatchGeom g;
-    if (use_patch && patch_geometry(a, BM, &g) && (!a.bbox || a.Cin / 64 <= 64)) {
+    const bool want_patch = use_patch || (a.variant >= 12 && a.variant <= 14);      // DIR_CONV_VARIANT 12..14: halo reuse
+    if (want_patch && !a.pre_scale && patch_geometry(a, BM, &g) && (!a.bbox || a.Cin / 64 <= 64)) {
         if (a.bbox) hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a, g);
         else hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
         return;
@@ -618,7 +619,7 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
     static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
     static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
-    const bool explicit_variant = a.variant >= 8 && a.variant <= 10;
+    const bool explicit_variant = (a.variant >= 8 && a.variant <= 10) || (a.variant >= 12 && a.variant <= 14);
     if (force == 0 || !(a.flags & 4) || (a.nk < min_nk && !explicit_variant)) return false;
     const bool pre = a.pre_scale != nullptr;
     static const int pre_pipe = getenv("DIR_PIPE_PRE") ? atoi(getenv("DIR_PIPE_PRE")) : 1;     // tuning aid
@@ -626,8 +627,8 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     const long long hw = (long long)a.Ho * a.Wo;
     auto tiles = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
     int shape = 0;
-    if (a.variant >= 8 && a.variant <= 10) {               // explicit tile (DIR_CONV_VARIANT)
-        shape = a.variant - 7;
+    if (explicit_variant) {                                // explicit tile (DIR_CONV_VARIANT 8..10, 12..14 = with halo reuse)
+        shape = a.variant >= 12 ? a.variant - 11 : a.variant - 7;
         if (a.nk < 1 || (pre && shape == 1)) return false;
     } else if (force > 0) shape = force;
     else {

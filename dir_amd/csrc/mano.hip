@@ -48,7 +48,6 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     __shared__ float s_c[3];
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
 
     if (tid < 51) s_pose[tid] = a.pose[(size_t)b * a.pose_stride + tid];
     if (tid >= 64 && tid < 74) s_beta[tid - 64] = a.betas[(size_t)b * a.betas_stride + tid - 64];

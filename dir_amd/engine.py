@@ -481,7 +481,7 @@ class DirEngine(object):
         return self._side
 
     # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 19, 20, 8, 9, 10)
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 19, 20, 8, 9, 10, 12, 13, 14)
 
     def autotune(self, img, reps=2):
         """Pick the convolution kernel variant per layer for this batch size by timing every candidate inside real
@@ -518,7 +518,35 @@ class DirEngine(object):
         for op, (t, v) in best.items():
             op.variant[B] = v
         self.tuned_batches.add(B)
+        self._tuned_order = getattr(self, '_tuned_order', {})
+        self._tuned_order[B] = [op for op in best]          # first-call order of one forward: stable for a given engine
         return {op: v for op, (t, v) in best.items()}
+
+    def export_tuning(self, B):
+        """the variants autotune chose for batch size B, in the order the conv layers run (JSON-serialisable)"""
+        return [[op.cout, op.cin, op.kh, op.kw, op.stride, op.variant.get(B, 0)] for op in self._tuned_order[B]]
+
+    def import_tuning(self, img, table):
+        """apply a table produced by export_tuning on an identically built engine (same layer order, checked by shape)"""
+        global PROFILE
+        B = img.shape[0]
+        saved_overlap, saved_profile, self.overlap, PROFILE = self.overlap, PROFILE, False, []
+        try:
+            self.forward(img)
+            torch.cuda.synchronize()
+            ops = []
+            for rec in PROFILE:
+                if rec[6] not in ops:
+                    ops.append(rec[6])
+        finally:
+            PROFILE, self.overlap = saved_profile, saved_overlap
+        if len(ops) != len(table) or any([op.cout, op.cin, op.kh, op.kw, op.stride] != row[:5] for op, row in zip(ops, table)):
+            raise ValueError('tuning table does not match this engine')
+        for op, row in zip(ops, table):
+            op.variant[B] = int(row[5])
+        self.tuned_batches.add(B)
+        self._tuned_order = getattr(self, '_tuned_order', {})
+        self._tuned_order[B] = ops
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, img, want_proj_feat=True, taps=None):

@@ -108,7 +108,8 @@ int dir_mano_forward_pair(const dir_mano_tables* tables_lr_host, const float* co
  * computes the same fp32 accumulation order (bit-identical results); a variant that does not apply to the layer
  * (alignment, pre-activation, grid) silently falls back to the heuristic.  dir_amd.engine times them per layer.
  *   1..4  : 4-wave kernel (conv.hip), tile 128x128 | 128x64 | 64x128 | 64x64 ; +16: 3-buffer DMA ring
- *   8..10 : 8-wave pipelined kernel (conv_pipe.hip), tile 256x128 | 128x128 | 256x64 */
+ *   8..10 : 8-wave pipelined kernel (conv_pipe.hip), tile 256x128 | 128x128 | 256x64
+ *   12..14: the same tiles with halo reuse (stride-1 kh x kw layers whose tile is a rectangle of image rows) */
 #define DIR_CONV_VARIANT(v) (((v) & 0xff) << 8)
 
 typedef struct dir_conv_desc {

@@ -22,7 +22,7 @@ for v in eng.CONV_VARIANTS:
         times.setdefault((r[6], r[4]), {}).setdefault(v, []).append(r[2].elapsed_time(r[3]) * 1e3)
 E.ConvOp.default_variant = None; E.PROFILE = None
 tot_auto = tot_best = 0
-names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x128', 4: '64x64', 17: '128x128r', 18: '128x64r', 19: '64x128r', 20: '64x64r', 8: 'P256x128', 9: 'P128x128', 10: 'P256x64'}
+names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x128', 4: '64x64', 17: '128x128r', 18: '128x64r', 19: '64x128r', 20: '64x64r', 8: 'P256x128', 9: 'P128x128', 10: 'P256x64', 12: 'H256x128', 13: 'H128x128', 14: 'H256x64'}
 for (op, shp), d in times.items():
     m = {v: min(ts) for v, ts in d.items()}
     bv = min(m, key=m.get)

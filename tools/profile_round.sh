@@ -6,7 +6,10 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 mkdir -p $out
-cmd="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dump-conv"
+# the per-layer kernel choice is made once OUTSIDE the profiler and re-used, so the traces hold only the timed configuration
+rm -f /tmp/dir_autotune.json
+python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
+cmd="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dump-conv --autotune-cache /tmp/dir_autotune.json"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $cmd > $out/pmcF.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $cmd > $out/pmcW.log 2>&1 )
