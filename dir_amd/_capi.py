@@ -28,6 +28,10 @@ class ConvDesc(C.Structure):
         'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')]
 
 
+class ConvSrc2(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('H', 'W', 'Cin', 'in_cstride', 'in_coff', 'stride')]
+
+
 class TokenMlp(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w1t', 's1', 'b1', 'w2t', 'b2')]
 
@@ -71,7 +75,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 4          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 5          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -89,6 +93,7 @@ _SIGNATURES = {
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_bone_proj_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _i, _p]),
+    'dir_conv2d_dual_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p]),
     'dir_conv2d_sparse_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),
                                           C.POINTER(TokenMlp), C.POINTER(TokenMlp), _p, _p, _i, _p]),

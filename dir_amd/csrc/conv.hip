@@ -79,6 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     constexpr int ES = (int)sizeof(TI);
     int avoff[ACH];                                  // byte offset of (b, iy0, ix0, chunk) -- may be negative
     unsigned amask[ACH];                             // bit t: tap t of this row is inside the image (and m < M)
+    unsigned avoff2[ACH];                            // second source (1x1, stride2): byte offset of the row's pixel, OOB if m >= M
+    const bool dual = a.x2 != nullptr;
     unsigned bvoff[BCH];
     // row handled by this thread in chunk-group i is (tid >> 3) + 32*i: ((row >> 1) & 7) == (tid >> 4) & 7 for every i
     const int col = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
@@ -100,13 +102,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) msk |= 1u << (ky * a.kw + kx);
                 }
             amask[i] = msk;
-        }
+            if (dual) avoff2[i] = (unsigned)((((b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.in_cs2 + a.in_co2 + col * EPC) * ES);
+        } else if (dual) avoff2[i] = 0x80000000u;
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
         const int n = n0 + (tid >> 3) + 32 * i;
         bvoff[i] = n < a.Cout ? (unsigned)((n * a.K + col * EPC) * ES) : OOB;
     }
+    const TI* __restrict__ x2 = (const TI*)a.x2;
+    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)x2, 0, a.x2_bytes, 0x00020000);
+    const i32x4 x2d = {(int)(unsigned)(unsigned long long)x2, (int)(unsigned)((unsigned long long)x2 >> 32), (int)a.x2_bytes, 0x00020000};
 
     const int ntaps = a.kh * a.kw;
 
@@ -166,6 +172,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // LDS-DMA of one K-slab into buffer `buf`: wave w writes row groups (w + 4*i) * 8 .. +7 (1 KiB each)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto dma = [&](int buf, int ks) {
+        if (ks >= a.nk1) {                               // second source: slab (ks - nk1) of x2's channels, 1x1
+            const int c2 = (ks - a.nk1) * BK;
+            char* sa2 = smem + buf * BUF_BYTES + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) lds_dma16(x2r, sa2 + i * 4096, avoff2[i], (unsigned)(c2 * ES));
+#pragma unroll
+            for (int i = 0; i < BCH; ++i) lds_dma16(wr, sa2 + A_BYTES + i * 4096, bvoff[i], (unsigned)((a.nk1 * BK + c2) * ES));
+            return;
+        }
         const int cs = ks / ntaps, tap = ks - cs * ntaps;
         const int c0 = cs * BK, k0 = tap * a.Cin + c0;
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
@@ -184,6 +199,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
     auto dma_ring = [&](int buf, int ks, bool live) {      // !live: every lane out of range -> zeros, branch-free code
+        if (ks >= a.nk1) {                               // second source (never reached when !live: ks is then 0)
+            const int c2 = (ks - a.nk1) * BK;
+            const unsigned sa2 = lds_base + buf * BUF_BYTES + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) lds_dma16_untracked(x2d, sa2 + i * 4096, live ? avoff2[i] : OOB, (unsigned)(c2 * ES));
+#pragma unroll
+            for (int i = 0; i < BCH; ++i)
+                lds_dma16_untracked(wd, sa2 + A_BYTES + i * 4096, live ? bvoff[i] : OOB, (unsigned)((a.nk1 * BK + c2) * ES));
+            return;
+        }
         const int cs = ks / ntaps, tap = ks - cs * ntaps;
         const int c0 = cs * BK, k0 = tap * a.Cin + c0;
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
@@ -414,7 +439,7 @@ template <typename TI, typename TO>
 void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     if constexpr (std::is_same<TI, bf16_t>::value) {
         // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip
-        const bool four_wave = (a0.variant & 15) >= 1 && (a0.variant & 15) <= 4;     // explicit DIR_CONV_VARIANT 1..4 (+16)
+        const bool four_wave = ((a0.variant & 15) >= 1 && (a0.variant & 15) <= 4) || a0.x2;   // explicit DIR_CONV_VARIANT 1..4 (+16), or a second source
         if (!four_wave && launch_conv_pipe(a0, std::is_same<TO, float>::value, num_cu, s)) return;
     }
     ConvArgs a = a0;
@@ -466,7 +491,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
 
 static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                         const float* pre_scale, const float* pre_shift, const void* residual, void* y,
-                        const int32_t* bbox, void* stream) {
+                        const int32_t* bbox, void* stream, const dir_conv_src2* d2 = nullptr, const void* x2 = nullptr) {
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
@@ -497,6 +522,22 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     const long long M = (long long)d->B * a.Ho * a.Wo;
     DIR_REQUIRE(M < (1ll << 31), "dir_conv2d_forward: too many output pixels");
     a.M = (int)M; a.K = d->kh * d->kw * d->Cin; a.nk = a.K / BK;
+    a.x2 = nullptr; a.x2_bytes = 0; a.H2 = a.W2 = a.in_cs2 = a.in_co2 = a.stride2 = 0; a.nk1 = a.nk;
+    if (d2) {        // second source: 1x1 (strided) convolution over x2 accumulated into the same output tile
+        DIR_REQUIRE(x2 && d2->H > 0 && d2->W > 0 && d2->Cin > 0 && d2->stride > 0, "dir_conv2d_dual_forward: bad second source");
+        DIR_REQUIRE(d2->Cin % BK == 0, "dir_conv2d_dual_forward: Cin2=%d must be a multiple of %d", d2->Cin, BK);
+        DIR_REQUIRE((d2->H - 1) / d2->stride + 1 == a.Ho && (d2->W - 1) / d2->stride + 1 == a.Wo,
+                    "dir_conv2d_dual_forward: the second source does not produce a %dx%d output", a.Ho, a.Wo);
+        const int cs2 = d2->in_cstride ? d2->in_cstride : d2->Cin;
+        DIR_REQUIRE(cs2 % EPC == 0 && d2->in_coff % EPC == 0, "dir_conv2d_dual_forward: second source channel slice must be 16-byte aligned");
+        DIR_REQUIRE(pre_scale == nullptr && bbox == nullptr && scale == nullptr,
+                    "dir_conv2d_dual_forward: scale / pre-activation / sparse-K do not combine with a second source");
+        const long long x2b = (long long)d->B * d2->H * d2->W * cs2 * (f32 ? 4 : 2);
+        DIR_REQUIRE(x2b < (1ll << 31), "dir_conv2d_dual_forward: second source must be < 2 GiB");
+        a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.H2 = d2->H; a.W2 = d2->W; a.in_cs2 = cs2; a.in_co2 = d2->in_coff;
+        a.stride2 = d2->stride;
+        a.K += d2->Cin; a.nk += d2->Cin / BK;
+    }
     a.tiles_m = a.tiles_n = 0;
     a.flags = d->flags & 3;
     a.variant = (d->flags >> 8) & 0xff;
@@ -530,6 +571,12 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
                                   const float* shift, const float* pre_scale, const float* pre_shift,
                                   const void* residual, void* y, void* stream) {
     return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream);
+}
+
+extern "C" int dir_conv2d_dual_forward(const dir_conv_desc* d, const void* x, const dir_conv_src2* d2, const void* x2, const void* w,
+                                       const float* shift, void* y, void* stream) {
+    DIR_REQUIRE(d2, "dir_conv2d_dual_forward: null second-source descriptor");
+    return conv_forward(d, x, w, nullptr, shift, nullptr, nullptr, nullptr, y, nullptr, stream, d2, x2);
 }
 
 extern "C" int dir_conv2d_sparse_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,

@@ -65,6 +65,9 @@ struct ConvArgs {
     int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
     int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
     int variant;                        // DIR_CONV_VARIANT code (0 = heuristic)
+    // optional second source, a 1x1 (strided) convolution accumulated into the same output: K-slabs ks >= nk1 read x2;
+    // weight rows are [kh*kw*Cin | Cin2] (dir_conv2d_dual_forward)
+    const void* x2; unsigned x2_bytes; int H2, W2, in_cs2, in_co2, stride2, nk1;
     unsigned x_bytes, w_bytes;          // buffer sizes for the hardware bounds check
     const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
                                         // each 64-channel input group; K-slabs that cannot touch a tile are skipped

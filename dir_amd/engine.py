@@ -93,6 +93,46 @@ class ConvOp(object):
         return out
 
 
+class DualConvOp(object):
+    """dir_conv2d_dual_forward: a bottleneck's conv3 + BN with the projection shortcut (downsample conv + BN, stride s) folded
+    in as a second K range -- relu(bn3(conv3(y)) + bn_ds(conv_ds(x))) in one launch, the identity tensor never exists
+    (models/backbone/resnet.py:117-119,137-140).  Both BatchNorm scales are multiplied into the weight rows."""
+    default_variant = None
+
+    def __init__(self, w3, s3, h3, wds, sds, hds, stride2, dtype):
+        self.cout, self.cin = w3.shape[0], w3.shape[1]
+        self.cin2, self.stride2, self.dtype = wds.shape[1], stride2, dtype
+        w = torch.cat([w3.float().flatten(1) * s3.float()[:, None], wds.float().flatten(1) * sds.float()[:, None]], 1)
+        self.w = w.contiguous().to(dtype)                                    # [Cout][Cin + Cin2]
+        self.shift = (h3.float() + hds.float()).contiguous()
+        self.kh = self.kw = self.stride = 1
+        self.pre_scale = None
+        self.variant = {}
+
+    def __call__(self, y, x):
+        B, H, W, cbuf = y.shape
+        out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
+        d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, self.cout, 0, 0, 0, 1, 1, 1, 0, _dt(self.dtype), _dt(self.dtype),
+                     CONV_RELU, 0, 0)
+        v = ConvOp.default_variant if ConvOp.default_variant is not None else self.variant.get(B, 0)
+        d.flags |= (v & 0xff) << 8
+        d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _capi.check(_capi.lib().dir_conv2d_dual_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.shift),
+                                                        _capi.ptr(out), _capi.stream_ptr()), 'dir_conv2d_dual_forward')
+        if PROFILE is not None:
+            e1.record()
+            es = y.element_size()
+            tag = 'conv_igemm<%s,%s>' % (('f32', 'f32') if self.dtype == F32 else ('bf16', 'bf16'))
+            m = B * H * W
+            PROFILE.append((tag, 2.0 * m * self.cout * (self.cin + self.cin2), e0, e1,
+                            'M=%d N=%d K=%d+%d dual s%d' % (m, self.cout, self.cin, self.cin2, self.stride2),
+                            (m * self.cin + m * self.cin2 + self.w.numel() + m * self.cout) * es, self))
+        return out
+
+
 def pack_token_mlp(sd, prefix, keep):
     """nn.Sequential(Conv1d(k=1), BatchNorm1d, ReLU, Conv1d(k=1)) -> dir_token_mlp (k-major weights, folded BN)."""
     w1 = sd[prefix + '.0.weight'][:, :, 0]
@@ -170,8 +210,10 @@ def pack_mano(sd, prefix, side, center_idx, keep):
 
 
 class BackboneOp(object):
-    """ResNet-50 pyramid (models/backbone/resnet.py:243-255): stem as a kh=7,kw=1 implicit GEMM over a pre-padded
-    NHWC4 image, maxpool, 16 bottlenecks with BN folded into the conv epilogues and the residual add + ReLU fused."""
+    """ResNet-50 pyramid (models/backbone/resnet.py:243-255): stem as a 4x4 implicit GEMM over 2x2 space-to-depth blocks,
+    maxpool, 16 bottlenecks with BN folded into the conv epilogues, the residual add + ReLU fused, and the four projection
+    shortcuts folded into their block's conv3 as a second K range (dir_conv2d_dual_forward)."""
+    fold_downsample = os.environ.get('DIR_FOLD_DOWNSAMPLE', '1') != '0'
 
     def __init__(self, sd, p, dtype, device):
         dt = self.dtype = dtype
@@ -210,7 +252,10 @@ class BackboneOp(object):
                            c3=ConvOp(sd[q + '.conv3.weight'], dt, scale=s3, shift=h3, relu=True), ds=None)
                 if (q + '.downsample.0.weight') in sd:
                     sd_, hd_ = bn_fold(sd, q + '.downsample.1')
-                    blk['ds'] = ConvOp(sd[q + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
+                    if self.fold_downsample:
+                        blk['dual'] = DualConvOp(sd[q + '.conv3.weight'], s3, h3, sd[q + '.downsample.0.weight'], sd_, hd_, stride, dt)
+                    else:
+                        blk['ds'] = ConvOp(sd[q + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
                 blocks.append(blk)
             self.layers.append(blocks)
 
@@ -232,8 +277,11 @@ class BackboneOp(object):
         feats = []
         for blocks in self.layers:
             for blk in blocks:
-                idn = blk['ds'](x) if blk['ds'] is not None else x
-                x = blk['c3'](blk['c2'](blk['c1'](x)), residual=idn)
+                if 'dual' in blk:                                    # conv3 + projection shortcut in one launch
+                    x = blk['dual'](blk['c2'](blk['c1'](x)), x)
+                else:
+                    idn = blk['ds'](x) if blk['ds'] is not None else x
+                    x = blk['c3'](blk['c2'](blk['c1'](x)), residual=idn)
             feats.append(x)
         return feats
 

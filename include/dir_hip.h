@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 4
+#define DIR_ABI_VERSION 5
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -126,6 +126,18 @@ typedef struct dir_conv_desc {
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
+
+/* A convolution with a SECOND source accumulated into the same output tile:
+ *   y = epilogue( conv(x; kh x kw, stride, pad) + conv1x1(x2; stride2) )
+ * -- ResNet's projection shortcut (`downsample`, models/backbone/resnet.py:137-140 and :117-119) folded into the block's last
+ * convolution, so the identity tensor is neither written nor read back.  w: [Cout][kh*kw*Cin + Cin2] (the second source's
+ * columns appended to every row) with both BatchNorm scales pre-multiplied into the rows; shift = the sum of the two folded
+ * shifts; flags: DIR_CONV_RELU.  x2: NHWC [B, d2->H, d2->W, in_cstride], read at pixels (oy*stride, ox*stride). */
+typedef struct dir_conv_src2 {
+    int32_t H, W, Cin, in_cstride, in_coff, stride;
+} dir_conv_src2;
+int dir_conv2d_dual_forward(const dir_conv_desc* desc, const void* x, const dir_conv_src2* src2, const void* x2, const void* w,
+                            const float* shift, void* y, void* stream);
 
 /* a11 with a10's sparsity: same as dir_conv2d_forward (no prologue), plus group_bbox int32 [B][Cin/64][4] = for every
  * image and every 64-channel input group the pixel box (ymin,ymax,xmin,xmax) outside which that group is exactly zero.

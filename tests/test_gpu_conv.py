@@ -129,3 +129,41 @@ def test_conv_full_size_chunk_consistency(shape, dtype):
     for _ in range(4):
         y = F.conv2d_nhwc(x, w, 1, k // 2)
         assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize('dt,tol', [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize('shape', [(3, 16, 64, 64, 256, 1), (2, 32, 128, 256, 512, 2), (5, 8, 256, 512, 96, 2)])
+def test_dual_source_conv_vs_oracle(dt, tol, shape):
+    """dir_conv2d_dual_forward: relu(conv1x1(y) + conv1x1_stride(x) + shift), the projection shortcut folded into conv3
+    (models/backbone/resnet.py:117-119,137-140), against the float64 composition of the two convolutions."""
+    import ctypes as C
+    from dir_amd import _capi
+    from oracle import nnops as N
+    B, S, c1, c2, cout, stride = shape
+    rng = np.random.default_rng(sum(shape))
+    y = rng.standard_normal((B, c1, S, S)).astype(np.float32)
+    x = rng.standard_normal((B, c2, S * stride, S * stride)).astype(np.float32)
+    w3 = (rng.standard_normal((cout, c1, 1, 1)) * 0.05).astype(np.float32)
+    wd = (rng.standard_normal((cout, c2, 1, 1)) * 0.05).astype(np.float32)
+    shift = rng.standard_normal(cout).astype(np.float32)
+    q = (lambda a: torch.from_numpy(a).to(dt).float().numpy())
+    ref = N.conv2d(q(y).astype(np.float64), q(w3).astype(np.float64), None, 1, 0) + \
+        N.conv2d(q(x).astype(np.float64), q(wd).astype(np.float64), None, stride, 0) + shift[None, :, None, None]
+    ref = np.maximum(ref, 0)
+    yd = torch.from_numpy(y).permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    xd = torch.from_numpy(x).permute(0, 2, 3, 1).contiguous().to(dt).cuda()
+    w = torch.cat([torch.from_numpy(w3).flatten(1), torch.from_numpy(wd).flatten(1)], 1).contiguous().to(dt).cuda()
+    sh = torch.from_numpy(shift).cuda()
+    out = torch.empty(B, S, S, cout, device='cuda', dtype=dt)
+    code = 0 if dt == torch.float32 else 1
+    for variant in (0, 1, 4, 19):
+        out.zero_()
+        d = _capi.ConvDesc(B, S, S, c1, c1, 0, cout, cout, 0, 0, 0, 1, 1, 1, 0, code, code, 1 | (variant << 8), 0, 0)
+        d2 = _capi.ConvSrc2(S * stride, S * stride, c2, c2, 0, stride)
+        _capi.check(_capi.lib().dir_conv2d_dual_forward(d, _capi.ptr(yd), d2, _capi.ptr(xd), _capi.ptr(w), _capi.ptr(sh), _capi.ptr(out),
+                                                        _capi.stream_ptr()), 'dual')
+        got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (variant, np.abs(got - ref).max())
+    d2 = _capi.ConvSrc2(S * stride + 1, S * stride, c2, c2, 0, stride + 1)            # wrong geometry is rejected
+    assert _capi.lib().dir_conv2d_dual_forward(d, _capi.ptr(yd), d2, _capi.ptr(xd), _capi.ptr(w), _capi.ptr(sh), _capi.ptr(out),
+                                               _capi.stream_ptr()) != 0
