@@ -99,7 +99,8 @@ class DualConvOp(object):
     (models/backbone/resnet.py:117-119,137-140).  Both BatchNorm scales are multiplied into the weight rows."""
     default_variant = None
 
-    def __init__(self, w3, s3, h3, wds, sds, hds, stride2, dtype):
+    def __init__(self, w3, s3, h3, wds, sds, hds, stride2, dtype, relu=True):
+        self.relu = relu
         self.cout, self.cin = w3.shape[0], w3.shape[1]
         self.cin2, self.stride2, self.dtype = wds.shape[1], stride2, dtype
         w = torch.cat([w3.float().flatten(1) * s3.float()[:, None], wds.float().flatten(1) * sds.float()[:, None]], 1)
@@ -109,11 +110,12 @@ class DualConvOp(object):
         self.pre_scale = None
         self.variant = {}
 
-    def __call__(self, y, x):
+    def __call__(self, y, x, out=None, out_coff=0):
         B, H, W, cbuf = y.shape
-        out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
-        d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, self.cout, 0, 0, 0, 1, 1, 1, 0, _dt(self.dtype), _dt(self.dtype),
-                     CONV_RELU, 0, 0)
+        if out is None:
+            out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
+        d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, _dt(self.dtype), _dt(self.dtype),
+                     CONV_RELU if self.relu else 0, 0, 0)
         v = ConvOp.default_variant if ConvOp.default_variant is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
@@ -311,8 +313,17 @@ class ResidualOp(object):
         s3, h3 = bn_fold(sd, p + '.bn3', b('conv2'))
         self.c2 = ConvOp(w('conv2'), dtype, pad=1, scale=s3, shift=h3, relu=True)
         self.c3 = ConvOp(w('conv3'), dtype, shift=b('conv3'))
+        # out = conv3(h) + skip_layer(x): the 1x1 skip projection is a second K range of conv3 (dir_conv2d_dual_forward)
+        self.dual = None
+        if self.need_skip and self.fold_skip:
+            one = torch.ones(w('conv3').shape[0], device=w('conv3').device)
+            self.dual = DualConvOp(w('conv3'), one, b('conv3'), w('skip_layer'), one, b('skip_layer'), 1, dtype, relu=False)
+
+    fold_skip = os.environ.get('DIR_FOLD_SKIP', '1') != '0'
 
     def __call__(self, x, out=None, out_coff=0):
+        if self.dual is not None:
+            return self.dual(self.c2(self.c1(x)), x, out=out, out_coff=out_coff)
         res = self.skip(x) if self.need_skip else x
         return self.c3(self.c2(self.c1(x)), out=out, out_coff=out_coff, residual=res)
 
