@@ -33,8 +33,17 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     x /= m; y /= m; z /= m;
 }
 
+// gridDim.z = vertex parts: with 4 parts every workgroup owns 196 vertices (588 floats, 16-byte aligned) of one (sample, hand),
+// recomputes the cheap pose / chain maths, and streams only its quarter of the blend-shape tables -- the 1.3 MB posedirs
+// read per (sample, hand) is spread over four CUs instead of one.  blockDim.x = NTHR (1 part) or PTHR (4 parts).
+constexpr int PART_V = 196, PTHR = 192;
+
 __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     const ManoHand& a = args.h[blockIdx.y];
+    const int nthr = blockDim.x;
+    const int v_lo = gridDim.z > 1 ? blockIdx.z * PART_V : 0;
+    const int v_hi = gridDim.z > 1 ? min(NV, v_lo + PART_V) : NV;
+    const int f_lo = 3 * v_lo, f_hi = 3 * v_hi;          // float range [f_lo, f_hi) of the flattened vertex array
     __shared__ float s_v[NV3P];         // v_shaped -> v_posed -> skinned vertices (in place)
     __shared__ float s_pose[51], s_beta[10], s_cam[3];
     __shared__ float s_full[45];        // axis-angle of the 15 articulated joints
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
         for (int k = 0; k < 45; ++k) acc = fmaf(s_pose[6 + k], a.t.comps[k * 45 + tid], acc);
         s_full[tid] = a.t.hands_mean[tid] + acc;
     }
-    for (int i = tid; i < NV3; i += NTHR) {
+    for (int i = f_lo + tid; i < f_hi; i += nthr) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 10; ++k) acc = fmaf(a.t.shapedirs_t[k * NV3P + i], s_beta[k], acc);
@@ -126,8 +135,9 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     __syncthreads();
 
     // ---- pose blend shapes (manolayer.py:186-187): 584 threads x float4 of the k-major table, 9 loads in flight
-    if (tid < NV3P / 4) {
-        const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + tid;
+    if (f_lo / 4 + tid < (f_hi + 3) / 4) {
+        const int c4 = f_lo / 4 + tid;                    // float4 column (f_lo is a multiple of 12)
+        const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + c4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 9
         for (int k = 0; k < 135; ++k) {
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
             const float w = s_pm[k];
             acc.x = fmaf(p.x, w, acc.x); acc.y = fmaf(p.y, w, acc.y); acc.z = fmaf(p.z, w, acc.z); acc.w = fmaf(p.w, w, acc.w);
         }
-        const int i = 4 * tid;
+        const int i = 4 * c4;
         s_v[i] += acc.x; s_v[i + 1] += acc.y;
         if (i + 2 < NV3) { s_v[i + 2] += acc.z; s_v[i + 3] += acc.w; }
     }
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     __syncthreads();
 
     // ---- linear blend skinning (manolayer.py:236-246): T = sum_k w[v][k] A'[k]; vert = T.[v_posed;1]
-    for (int v = tid; v < NV; v += NTHR) {
+    for (int v = v_lo + tid; v < v_hi; v += nthr) {
         const float4* wp = reinterpret_cast<const float4*>(a.t.weights + 16 * v);
         float w[16];
 #pragma unroll
@@ -224,18 +234,25 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     if (tid < 3) s_c[tid] = a.t.center_idx >= 0 ? s_jtr[3 * a.t.center_idx + tid] : 0.f;   // manolayer.py:261-265
     __syncthreads();
 
+    // with vertex parts: part 0 writes the 16 chain joints, a fingertip joint is written by the part that owns its vertex
+    auto owns_joint = [&](int j) {
+        if (gridDim.z == 1) return true;
+        const int src = kReorderJ[j];
+        const int v = src < 16 ? 0 : kTips[a.t.side][src - 16];
+        return v >= v_lo && v < v_hi;
+    };
     const float sc = s_cam[0], tx = s_cam[1], ty = s_cam[2];
     float* vout = a.verts + (size_t)b * NV3;
-    for (int i = tid; i < NV3; i += NTHR) vout[i] = s_v[i] - s_c[i % 3];
-    if (tid < 63) a.joints[(size_t)b * 63 + tid] = s_jtr[tid] - s_c[tid % 3];
+    for (int i = f_lo + tid; i < f_hi; i += nthr) vout[i] = s_v[i] - s_c[i % 3];
+    if (tid < 63 && owns_joint(tid / 3)) a.joints[(size_t)b * 63 + tid] = s_jtr[tid] - s_c[tid % 3];
     if (a.cam) {   // utils/utils.py:47-63: uv = s * xy + t
         if (a.joint_uv && tid >= 64 && tid < 64 + 42) {
             const int i = tid - 64, j = i >> 1, c = i & 1;
-            a.joint_uv[(size_t)b * 42 + i] = sc * (s_jtr[3 * j + c] - s_c[c]) + (c ? ty : tx);
+            if (owns_joint(j)) a.joint_uv[(size_t)b * 42 + i] = sc * (s_jtr[3 * j + c] - s_c[c]) + (c ? ty : tx);
         }
         if (a.mesh_uv) {
             float* mo = a.mesh_uv + (size_t)b * NV * 2;
-            for (int i = tid; i < NV * 2; i += NTHR) {
+            for (int i = 2 * v_lo + tid; i < 2 * v_hi; i += nthr) {
                 const int v = i >> 1, c = i & 1;
                 mo[i] = sc * (s_v[3 * v + c] - s_c[c]) + (c ? ty : tx);
             }
@@ -244,6 +261,19 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
 }
 
 }  // namespace
+
+// Four vertex parts per (sample, hand) unless the centre joint needs vertices of another part (a fingertip centre or the
+// root_palm wrist) or the batch alone fills the chip.
+static void launch_mano(const ManoArgs& a, int B, int hands, hipStream_t s) {
+    bool split = B * hands < 1024;
+    for (int h = 0; h < hands; ++h) {
+        const dir_mano_tables& t = a.h[h].t;
+        const int c = t.center_idx;
+        if (t.root_palm || (c >= 0 && (c == 4 || c == 8 || c == 12 || c == 16 || c == 20))) split = false;
+    }
+    if (split) hipLaunchKernelGGL(mano_forward_kernel, dim3(B, hands, 4), dim3(PTHR), 0, s, a);
+    else hipLaunchKernelGGL(mano_forward_kernel, dim3(B, hands, 1), dim3(NTHR), 0, s, a);
+}
 
 static int check_hand(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
                       int betas_stride, const float* cam, int cam_stride, float* verts, float* joints) {
@@ -269,7 +299,7 @@ extern "C" int dir_mano_forward(const dir_mano_tables* t, const float* pose, int
     ManoArgs a;
     a.h[0] = ManoHand{*t, pose, pose_stride, betas, betas_stride, cam, cam_stride, verts, joints, joint_uv, mesh_uv, flags_out};
     a.h[1] = a.h[0];
-    hipLaunchKernelGGL(mano_forward_kernel, dim3(B, 1), dim3(NTHR), 0, (hipStream_t)stream, a);
+    launch_mano(a, B, 1, (hipStream_t)stream);
     return dir::check_launch("dir_mano_forward");
 }
 
@@ -288,6 +318,6 @@ extern "C" int dir_mano_forward_pair(const dir_mano_tables* tables_lr, const flo
         a.h[h] = ManoHand{tables_lr[h], pose_lr[h], pose_stride, betas_lr[h], betas_stride, cam, cam_stride, verts_lr[h],
                           joints_lr[h], joint_uv_lr ? joint_uv_lr[h] : nullptr, nullptr, nullptr};
     }
-    hipLaunchKernelGGL(mano_forward_kernel, dim3(B, 2), dim3(NTHR), 0, (hipStream_t)stream, a);
+    launch_mano(a, B, 2, (hipStream_t)stream);
     return dir::check_launch("dir_mano_forward_pair");
 }
