@@ -199,14 +199,15 @@ __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (
     for (int t = 0; t < deg; ++t) w[t] /= sum;
 }
 
-constexpr int PG_BC = 16;   // samples per workgroup = one 16-row MFMA tile
+constexpr int PG_BC = 16;   // samples per workgroup
+constexpr int PG_MT = (PG_BC + 15) / 16, PG_ROWS = PG_MT * 16;   // 16-row MFMA tiles (rows >= PG_BC are zero)
 constexpr int PG_LD = 128 + 2;
 
 // grid (21 nodes, 2 slices of 64 output columns, hands x batch chunks), 256 threads.  A = the node's input rows of 16
 // samples (LDS), B = the node's own W0 / W1 column tiles (k-major in the reference layout [2][21][k][o]); wave w owns
 // output columns slice*64 + 16w .. +15 of both matrices.
 __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
-    __shared__ float s_x[PG_BC * PG_LD];
+    __shared__ float s_x[PG_ROWS * PG_LD];
     const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hand = blockIdx.z / args.nchunk, chunk = blockIdx.z - hand * args.nchunk;
     const PgcnHand& a = args.h[hand];
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
     float wgt[5]; int nidx[5]; int deg = 0;
     if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
     // ---- stage this node's input rows; layers >= 1 finish the previous layer here (mix + bias + BN + ReLU)
-    for (int i = tid; i < PG_BC * 128; i += 256) {
+    for (int i = tid; i < PG_ROWS * 128; i += 256) {
         const int bb = i >> 7, k = i & 127;
         float v = 0.f;
         if (bb < nb) {
@@ -233,18 +234,22 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
     }
     __syncthreads();
     const int n0 = slice * 64 + wave * 16, li = lane & 15, lk = lane >> 4;
-    f32x4 a0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, a1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    dir::mfma_tile_f32<128, 1>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
-    dir::mfma_tile_f32<128, 1>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
+    f32x4 a0[PG_MT], a1[PG_MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int bb = lk * 4 + r;
-        if (bb < nb) {
-            float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
-            hb[n0 + li] = a0[0][r];
-            hb[128 + n0 + li] = a1[0][r];
+    for (int m = 0; m < PG_MT; ++m) a0[m] = a1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
+    dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
+#pragma unroll
+    for (int m = 0; m < PG_MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bb = m * 16 + lk * 4 + r;
+            if (bb < nb) {
+                float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
+                hb[n0 + li] = a0[m][r];
+                hb[128 + n0 + li] = a1[m][r];
+            }
         }
-    }
 }
 
 struct MixHand {
