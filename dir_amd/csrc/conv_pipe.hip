@@ -326,7 +326,9 @@ struct KPos {        // position in the (channel slab, tap) stream
     int ci, tap, ky, kx;
 };
 
-template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, int PMAX = PATCH_MAX_ROWS>
+// PRELOAD (single channel slab, e.g. ResNet layer1's 3x3 64 -> 64): the patch AND every tap's weight slab are fetched in one
+// burst, one barrier, then all kh*kw taps run back to back with no ring, no counted waits and no per-tap barrier.
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRELOAD = false, int PMAX = PATCH_MAX_ROWS>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a, PatchGeom g) {
     typedef bf16_t TI;
     constexpr int NT = 64 * WM * WN;
@@ -336,8 +338,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
     constexpr int MAXPP = (PMAX + RPP - 1) / RPP;             // patch DMA passes per channel slab
     constexpr int ROW = 128;
     constexpr int P_BYTES = PMAX * ROW, B_BYTES = BN * ROW;
-    constexpr int NBUF = 3;
-    constexpr int RING_BYTES = 2 * P_BYTES + NBUF * B_BYTES;
+    constexpr int NBUF = PRELOAD ? 9 : 3;              // PRELOAD: one weight buffer per tap (kh*kw <= 9), one patch buffer
+    constexpr int NPATCH = PRELOAD ? 1 : 2;
+    constexpr int RING_BYTES = NPATCH * P_BYTES + NBUF * B_BYTES;
     constexpr int STAGE_BYTES = BM * BN * 4;
     constexpr int SMEM = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
     constexpr int BK = 64, ES = 2;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
     };
 
     const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-    const unsigned bring = lds_base + 2 * P_BYTES + wave * 1024;
+    const unsigned bring = lds_base + NPATCH * P_BYTES + wave * 1024;
     // weight piece i of the slab at position p into ring buffer `buf`
     auto dma_b = [&](auto I, const KPos& p, int c0, int buf, bool live) {
         constexpr int i = decltype(I)::value;
@@ -486,6 +489,36 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
         }
     };
 
+    if constexpr (PRELOAD) {
+        KPos cur = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < MAXPP; ++t)
+            if (t < npw) dma_patch(t, 0, 0, true);
+        for (int t = 0; t < ntaps; ++t) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                (dma_b(std::integral_constant<int, I>{}, dm, 0, t, true), ...);
+            }(std::make_integer_sequence<int, BCH>{});
+            advance(dm);
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        for (int t = 0; t < ntaps; ++t) {
+            frag_load(cur, smem + NPATCH * P_BYTES + t * B_BYTES);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]),
+                                                                            __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+            advance(cur);
+        }
+        __syncthreads();
+        epilogue_tile<TO, MI, NJ, WM, WN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+        return;
+    }
+
     // ---- prologue: patch of channel slab 0 and weight slabs 0, 1 (the loop issues slab s+2 during slab s)
     KPos cur = {0, 0, 0, 0}, dm = {0, 0, 0, 0};
     {
@@ -520,7 +553,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
     int buf = 0;                                   // s % 3
     for (int sidx = 0; sidx < nslab; ++sidx) {
         // ---- M(s)
-        frag_load(cur, smem + 2 * P_BYTES + buf * B_BYTES);
+        frag_load(cur, smem + NPATCH * P_BYTES + buf * B_BYTES);
         const int nb2 = buf == 0 ? 2 : buf - 1;    // (s + 2) % 3
         const bool pp = cur.tap < npw;
         if (pp) dma_patch(cur.tap, c0_of(cur.ci + 1), (cur.ci + 1) & 1, cur.ci + 1 < ncs);
@@ -599,6 +632,12 @@ void launch_tile(ConvArgs a, hipStream_t s) {
     PatchGeom g;
     const bool want_patch = use_patch || (a.variant >= 12 && a.variant <= 14);      // DIR_CONV_VARIANT 12..14: halo reuse
     if (want_patch && !a.pre_scale && patch_geometry(a, BM, &g) && (!a.bbox || a.Cin / 64 <= 64)) {
+        if constexpr (MI == 2 && NJ == 1 && WM == 4 && WN == 2) {      // 256x64: patch + 9 weight slabs = 125 KB
+            if (!a.bbox && a.Cin == 64 && a.kh * a.kw <= 9) {
+                hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a, g);
+                return;
+            }
+        }
         if (a.bbox) hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a, g);
         else hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
         return;
