@@ -433,11 +433,16 @@ class DirEngine(object):
         s, h = bn_fold(sd, d + '.conv_final.1')
         self.final0 = ConvOp(sd[d + '.conv_final.0.weight'], dt, pad=1, scale=s, shift=h, relu=True)
         self.final3 = ConvOp(sd[d + '.conv_final.3.weight'], dt, shift=sd[d + '.conv_final.3.bias'])
-        self.heads = {}
-        for k in ('seg', 'dense'):
+        # seg / dense heads (models/dir.py:425-433): both read `feat`, so their 3x3 convs run as ONE N = 128 + 128 GEMM and their
+        # 1x1 -> 3 convs as one block-diagonal N = 6 GEMM over the 256 merged channels (identical arithmetic per output)
+        w0, s0, h0, w3, b3 = [], [], [], torch.zeros(6, 256, 1, 1, device=self.device), []
+        for i, k in enumerate(('seg', 'dense')):
             s, h = bn_fold(sd, '%s.%s.1' % (d, k), sd['%s.%s.0.bias' % (d, k)])
-            self.heads[k] = (ConvOp(sd['%s.%s.0.weight' % (d, k)], dt, pad=1, scale=s, shift=h, relu=True),
-                             ConvOp(sd['%s.%s.3.weight' % (d, k)], dt, shift=sd['%s.%s.3.bias' % (d, k)], out_dtype=F32))
+            w0.append(sd['%s.%s.0.weight' % (d, k)]); s0.append(s); h0.append(h)
+            w3[3 * i:3 * i + 3, 128 * i:128 * i + 128] = sd['%s.%s.3.weight' % (d, k)]
+            b3.append(sd['%s.%s.3.bias' % (d, k)])
+        self.heads0 = ConvOp(torch.cat(w0, 0), dt, pad=1, scale=torch.cat(s0), shift=torch.cat(h0), relu=True)
+        self.heads3 = ConvOp(w3, dt, shift=torch.cat(b3), out_dtype=F32)
 
     # ------------------------------------------------------------------------------------------ pieces
     def init_regressor(self, c4):
@@ -654,8 +659,8 @@ class DirEngine(object):
         e3 = self.res['enhance_layer3'](enh3_in)
         # ---- heads (models/dir.py:474-476)
         feat = self.final3(self.final0(e3))
-        seg = self.heads['seg'][1](self.heads['seg'][0](feat))                   # NHWC fp32 [B,32,32,3]
-        dense = self.heads['dense'][1](self.heads['dense'][0](feat))
+        sd6 = self.heads3(self.heads0(feat))                                     # NHWC fp32 [B,32,32,6] = seg | dense
+        seg, dense = sd6[..., :3], sd6[..., 3:]
         if taps is not None:
             taps.update(c1=c1, c2=c2, c3=c3, c4=c4, fusion4=enh4_in[..., :256], proj4=enh4_in[..., 256:], enh4=e4,
                         fusion3=enh3_in[..., :256], proj3=enh3_in[..., 256:], enh3=e3, final=feat,
