@@ -37,7 +37,7 @@ class TokenMlp(C.Structure):
 
 
 class PgcnLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('W', 'e1', 'bias', 'bn_scale', 'bn_shift')] + [('relu', C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ('W', 'e1', 'bias', 'bn_scale', 'bn_shift')] + [('relu', C.c_int32), ('w_dtype', C.c_int32)]
 
 
 class SteBlock(C.Structure):
@@ -75,7 +75,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 5          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 6          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 

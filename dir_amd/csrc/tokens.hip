@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
 
 // --------------------------------------------------------------------------------------------- P-GCN
 struct PgcnHand {
-    const float* W; const float* x_in;          // layer weights [2][21][128][128]; x_in [B][21][128] (layer 0 only)
+    const float* W; const float* x_in;          // layer weights [2][21][128][128] (fp32 [k][o], or bf16 [o][k] when w_bf16); x_in [B][21][128] (layer 0 only)
+    int w_bf16;
     const float* h_prev;                        // [B][21][256] = (h0 | h1) of the previous layer (layers >= 1)
     const float* e1_prev; const float* bias_prev; const float* bns_prev; const float* bnb_prev; int relu_prev;
     float* h_out;                               // [B][21][256]
@@ -237,8 +238,37 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
     f32x4 a0[PG_MT], a1[PG_MT];
 #pragma unroll
     for (int m = 0; m < PG_MT; ++m) a0[m] = a1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
-    dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
+    if (a.w_bf16) {
+        // bf16 throughput mode (torch.autocast semantics for the matmuls of SemGCN/p_graph_conv.py:47-48): W^T as bf16 [o][k], one
+        // 16-byte load per lane and k-step; the A operand is converted from the fp32 LDS rows; fp32 accumulation
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+        const unsigned short* w0 = reinterpret_cast<const unsigned short*>(a.W) + ((long long)j * 128 + n0 + li) * 128 + lk * 8;
+        const unsigned short* w1 = w0 + (long long)NJ * 128 * 128;
+        bf16x8_t b0[4], b1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            b0[kk] = *reinterpret_cast<const bf16x8_t*>(w0 + kk * 32);
+            b1[kk] = *reinterpret_cast<const bf16x8_t*>(w1 + kk * 32);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < PG_MT; ++m) {
+                const float2* ap = reinterpret_cast<const float2*>(s_x + (m * 16 + li) * PG_LD + kk * 32 + lk * 8);
+                bf16x8_t av;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 t = ap[e];
+                    av[2 * e] = (__bf16)t.x;
+                    av[2 * e + 1] = (__bf16)t.y;
+                }
+                a0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0[kk], a0[m], 0, 0, 0);
+                a1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[kk], a1[m], 0, 0, 0);
+            }
+    } else {
+        dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
+        dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
+    }
 #pragma unroll
     for (int m = 0; m < PG_MT; ++m)
 #pragma unroll
@@ -400,9 +430,10 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
             const int hh = h < nh ? h : 0;
             const dir_pgcn_layer& L = layers[hh][l];
             DIR_REQUIRE(L.W && L.e1 && L.bias && L.bn_scale && L.bn_shift, "dir_pgcn_stack_forward: null layer parameter");
+            DIR_REQUIRE(L.w_dtype == DIR_DT_F32 || L.w_dtype == DIR_DT_BF16, "dir_pgcn_stack_forward: w_dtype must be f32 or bf16");
             float* hbuf[2] = {scratch[hh], scratch[hh] + (long long)B * NJ * 256};
             PgcnHand& g = a.h[h];
-            g.W = L.W; g.x_in = x[hh]; g.h_prev = l ? hbuf[(l - 1) & 1] : nullptr;
+            g.W = L.W; g.w_bf16 = L.w_dtype == DIR_DT_BF16; g.x_in = x[hh]; g.h_prev = l ? hbuf[(l - 1) & 1] : nullptr;
             g.e1_prev = l ? layers[hh][l - 1].e1 : nullptr; g.bias_prev = l ? layers[hh][l - 1].bias : nullptr;
             g.bns_prev = l ? layers[hh][l - 1].bn_scale : nullptr; g.bnb_prev = l ? layers[hh][l - 1].bn_shift : nullptr;
             g.relu_prev = l ? layers[hh][l - 1].relu : 0;

@@ -145,15 +145,19 @@ def pack_token_mlp(sd, prefix, keep):
     return _capi.TokenMlp(*(t[k].data_ptr() for k in ('w1t', 's1', 'b1', 'w2t', 'b2')))
 
 
-def pack_pgcn(sd, prefix, keep, num_layers=4):
+def pack_pgcn(sd, prefix, keep, num_layers=4, weight_dtype=torch.float32):
+    """weight_dtype float32: exact fp32 matmuls (reference layout); bfloat16: bf16 matmuls = autocast semantics (W transposed)"""
     arr = (_capi.PgcnLayer * num_layers)()
     for i in range(num_layers):
         p = '%s.gconv_layers.%d' % (prefix, i)
         s, b = bn_fold(sd, p + '.bn')
-        t = dict(W=sd[p + '.gconv.W'].float().contiguous(), e1=sd[p + '.gconv.e_1'].float().reshape(-1).contiguous(),
+        W = sd[p + '.gconv.W']
+        W = W.float().contiguous() if weight_dtype == torch.float32 else W.detach().transpose(2, 3).contiguous().to(torch.bfloat16)
+        t = dict(W=W, e1=sd[p + '.gconv.e_1'].float().reshape(-1).contiguous(),
                  bias=sd[p + '.gconv.bias'].float().contiguous(), s=s, b=b)
         keep.append(t)
-        arr[i] = _capi.PgcnLayer(t['W'].data_ptr(), t['e1'].data_ptr(), t['bias'].data_ptr(), s.data_ptr(), b.data_ptr(), 1)
+        arr[i] = _capi.PgcnLayer(t['W'].data_ptr(), t['e1'].data_ptr(), t['bias'].data_ptr(), s.data_ptr(), b.data_ptr(), 1,
+                                 _dt(weight_dtype))
     return arr
 
 
@@ -338,7 +342,7 @@ class StageOp(object):
         self.pos_emb = (_capi.TokenMlp * 2)(pack_token_mlp(sd, p + '.pos_emb_left', keep),
                                             pack_token_mlp(sd, p + '.pos_emb_right', keep))
         self.gpos = pack_token_mlp(sd, p + '.global_pos_emb', keep)
-        self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep), pack_pgcn(sd, p + '.gcn_right', keep))
+        self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep, weight_dtype=dtype), pack_pgcn(sd, p + '.gcn_right', keep, weight_dtype=dtype))
         self.ste = pack_ste(sd, p + '.interaction', keep, weight_dtype=dtype)
         R = _capi.RegressParams()
         t = dict(wt=torch.cat([sd[p + '.regressor.mano_left.weight'].float().t(),

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 5
+#define DIR_ABI_VERSION 6
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -225,12 +225,15 @@ int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, int C, int 
 
 /* a5: one _GraphConv = PGraphConv + BatchNorm1d(eval) + ReLU (SemGCN/p_graph_conv.py:39-59, SemGCN/p_gcn.py:20-27) */
 typedef struct dir_pgcn_layer {
-    const float* W;        /* [2][21][128][128]  gconv.W  (reference layout)                     */
+    const float* W;        /* gconv.W: w_dtype DIR_DT_F32 -> fp32 [2][21][128 k][128 o] (reference layout, exact fp32 MFMA);
+                              DIR_DT_BF16 -> bf16 [2][21][128 o][128 k] (transposed), bf16 MFMA with fp32 accumulation =
+                              torch.autocast semantics for the two matmuls of SemGCN/p_graph_conv.py:47-48            */
     const float* e1;       /* [40]               gconv.e_1, row-major nonzero order of adj > 0    */
     const float* bias;     /* [128]              gconv.bias                                       */
     const float* bn_scale; /* [128]              gamma / sqrt(var + eps)                          */
     const float* bn_shift; /* [128]              beta - mean * bn_scale                           */
     int32_t relu;          /* 1: ReLU after BN (the _GraphConv of the network); 0: bare PGraphConv (scale 1, shift 0) */
+    int32_t w_dtype;       /* DIR_DT_F32 | DIR_DT_BF16 (layout of W above)                                              */
 } dir_pgcn_layer;
 /* ResSimplePGCN.forward (SemGCN/p_gcn.py:71-73): x [B,21,128] -> out; `add` (optional, [B,21,128]) is added after the
  * last layer (global_pos_emb, models/dir.py:109-110); out rows are out_bstride floats apart so both hands can write

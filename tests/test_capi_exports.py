@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'libdir_hip.so does not export ' + s
     lib.dir_abi_version.restype = ctypes.c_int
-    assert lib.dir_abi_version() == 5
+    assert lib.dir_abi_version() == 6
 
 
 def test_binding_signatures_cover_header():

@@ -324,3 +324,41 @@ def test_ste_bf16_linears_autocast_semantics(golden):
     finally:
         N.linear = orig
     assert maxabs(got, want) < 2e-3 * sc, (maxabs(got, want), sc)
+
+
+def test_pgcn_bf16_matmuls_autocast_semantics(golden):
+    """w_dtype = bf16: the two matmuls of PGraphConv (SemGCN/p_graph_conv.py:47-48) on the bf16 matrix cores with fp32
+    accumulation, everything else (edge softmax, neighbour mix, bias, BatchNorm, ReLU) fp32 -- torch.autocast semantics.
+    Checked against the reference golden within the bf16 envelope and, tightly, against the oracle with the matmul operands
+    rounded to bf16 the same way (per layer input and weights)."""
+    g = golden('g2_pgcn')
+    sdn = synth.synth_state_dict(pgcn_shapes(), SEED)
+    sd = {('gcn.' + k): dev(v) for k, v in sdn.items()}
+    keep = []
+    layers = engine.pack_pgcn(sd, 'gcn', keep, weight_dtype=torch.bfloat16)
+    x = torch.from_numpy(g['x']).cuda()
+    B = x.shape[0]
+    out = torch.empty(B, 21, 128, device='cuda')
+    scratch = torch.empty(2, B, 21, 256, device='cuda')
+    _capi.check(_capi.lib().dir_pgcn_stack_forward(layers, 4, _capi.ptr(x), None, _capi.ptr(out), 21 * 128,
+                                                   _capi.ptr(scratch), B, _capi.stream_ptr()), 'pgcn bf16')
+    got = out.cpu().numpy()
+    sc = np.abs(g['y']).max()
+    assert maxabs(got, g['y']) < 2e-2 * sc, (maxabs(got, g['y']), sc)
+
+    def bf(a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+    orig = OT.pgraphconv
+
+    def rounded(xx, P):
+        class Q(dict):
+            pass
+        P2 = {'W': bf(P['W']), 'e_0': P['e_0'], 'e_1': P['e_1'], 'bias': P['bias']}
+        return orig(bf(xx), P2)
+    try:
+        OT.pgraphconv = rounded
+        want = OT.pgcn_stack(g['x'].copy(), N.Params(sdn))
+    finally:
+        OT.pgraphconv = orig
+    assert maxabs(got, want) < 2e-3 * sc, (maxabs(got, want), sc)
