@@ -13,8 +13,10 @@ cmd="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dump-conv --au
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $cmd > $out/pmcF.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $cmd > $out/pmcW.log 2>&1 )
+( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $out/pmcS -o r -- $cmd > $out/pmcS.log 2>&1 )
 cd $R
 python tools/prof_summary.py $(find $out/trace -name "*.db" | head -1) 60 > $out/kernel_stats.txt
 python tools/pmc_traffic.py $(find $out/pmcF -name "*.db" | head -1) $(find $out/pmcW -name "*.db" | head -1) $out/pmc_traffic.json
+python tools/pmc_per_kernel.py $(find $out/trace -name "*.db" | head -1) $(find $out/pmcF -name "*.db" | head -1) $(find $out/pmcW -name "*.db" | head -1) $(find $out/pmcS -name "*.db" | head -1) > $out/per_kernel.txt 2>&1
 grep -h "^conv_igemm\|^{" $out/trace.log > $out/bench_line.txt
-rm -rf $out/trace $out/pmcF $out/pmcW
+rm -rf $out/trace $out/pmcF $out/pmcW $out/pmcS
