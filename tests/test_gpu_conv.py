@@ -136,7 +136,6 @@ def test_conv_full_size_chunk_consistency(shape, dtype):
 def test_dual_source_conv_vs_oracle(dt, tol, shape):
     """dir_conv2d_dual_forward: relu(conv1x1(y) + conv1x1_stride(x) + shift), the projection shortcut folded into conv3
     (models/backbone/resnet.py:117-119,137-140), against the float64 composition of the two convolutions."""
-    import ctypes as C
     from dir_amd import _capi
     from oracle import nnops as N
     B, S, c1, c2, cout, stride = shape

@@ -2,7 +2,7 @@
 """Average HBM traffic per launch of the dominant kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of
 the bench command.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of a wide
 coalesced read -> doubled; both counters are in KiB.  Writes profiles/<tag>_pmc_traffic.json (read by bench.py)."""
-import json, re, sqlite3, sys
+import json, sqlite3, sys
 
 
 def per_kernel(path, counter, pat):
