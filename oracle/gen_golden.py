@@ -383,7 +383,7 @@ def gen_imgprep():
             return (t - self.mean) / self.std
     cvstub = types.SimpleNamespace(COLOR_BGR2RGB=4, cvtColor=lambda im, code: np.ascontiguousarray(im[..., ::-1]))
     g = np.random.default_rng(SEED)
-    imgs = g.integers(0, 256, (3, 256, 256, 3), dtype=np.uint8)
+    imgs = g.integers(0, 256, (1, 256, 256, 3), dtype=np.uint8)
     imgs[0, :4, :4] = 0
     imgs[0, 4:8, :4] = 255
     outs = []
