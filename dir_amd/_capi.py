@@ -75,7 +75,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 6          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 7          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -89,6 +89,7 @@ _SIGNATURES = {
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_image_normalize_forward': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _p]),
     'dir_stem_prep_s2d_u8': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _i, _i, _i, _p]),
+    'dir_stem_pool_forward': (C.c_int, [_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -215,35 +215,46 @@ def pack_mano(sd, prefix, side, center_idx, keep):
                             -1 if center_idx is None else int(center_idx), 0)
 
 
+def stem_conv_op(w, scale, shift, dtype):
+    """7x7/2 stem over 2x2 space-to-depth blocks (dir_stem_prep_s2d): a 4x4 stride-1 convolution whose K-slab is a block-row
+    window of 4 blocks x 16 channels; w'[n][j*16 + (dy*2+dx)*4 + c][r] = w[n, c, 2r+dy-1, 2j+dx-1]   (w = conv1.weight [64,3,7,7])"""
+    wp = torch.zeros(64, 64, 4, 1, device=w.device, dtype=F32)        # [Cout, Cin', kh, kw=1]
+    for r in range(4):
+        for dy in range(2):
+            ky = 2 * r + dy - 1
+            if not 0 <= ky <= 6:
+                continue
+            for j in range(4):
+                for dx in range(2):
+                    kx = 2 * j + dx - 1
+                    if 0 <= kx <= 6:
+                        c0 = j * 16 + (dy * 2 + dx) * 4
+                        wp[:, c0:c0 + 3, r, 0] = w[:, :, ky, kx]
+    op = ConvOp(wp, dtype, stride=1, pad=0, scale=scale, shift=shift, relu=True)
+    op.ho = op.wo = 128
+    op.in_cs_override = 16
+    op.alg_k = 147
+    return op
+
+
 class BackboneOp(object):
     """ResNet-50 pyramid (models/backbone/resnet.py:243-255): stem as a 4x4 implicit GEMM over 2x2 space-to-depth blocks,
     maxpool, 16 bottlenecks with BN folded into the conv epilogues, the residual add + ReLU fused, and the four projection
     shortcuts folded into their block's conv3 as a second K range (dir_conv2d_dual_forward)."""
     fold_downsample = os.environ.get('DIR_FOLD_DOWNSAMPLE', '1') != '0'
+    fused_stem = os.environ.get('DIR_FUSED_STEM', '1') != '0'       # bf16 mode: conv1 + bn1 + ReLU + maxpool in one launch
 
     def __init__(self, sd, p, dtype, device):
         dt = self.dtype = dtype
         self.device = device
-        # 7x7/2 stem over 2x2 space-to-depth blocks (dir_stem_prep_s2d): a 4x4 stride-1 convolution whose K-slab is a
-        # block-row window of 4 blocks x 16 channels; w'[n][j*16 + (dy*2+dx)*4 + c][r] = w[n, c, 2r+dy-1, 2j+dx-1]
-        w = sd[p + '.conv1.weight']                                       # [64,3,7,7]
-        wp = torch.zeros(64, 64, 4, 1, device=w.device, dtype=F32)        # [Cout, Cin', kh, kw=1]
-        for r in range(4):
-            for dy in range(2):
-                ky = 2 * r + dy - 1
-                if not 0 <= ky <= 6:
-                    continue
-                for j in range(4):
-                    for dx in range(2):
-                        kx = 2 * j + dx - 1
-                        if 0 <= kx <= 6:
-                            c0 = j * 16 + (dy * 2 + dx) * 4
-                            wp[:, c0:c0 + 3, r, 0] = w[:, :, ky, kx]
-        s, h = bn_fold(sd, p + '.bn1')
-        self.stem = ConvOp(wp, dt, stride=1, pad=0, scale=s, shift=h, relu=True)
-        self.stem.ho = self.stem.wo = 128
-        self.stem.in_cs_override = 16
-        self.stem.alg_k = 147
+        # dir_stem_pool_forward: conv1.weight [64,3,7,7] -> bf16 [64][ky 7][kx 8][c 4] (zero for kx = 7, c = 3)
+        w = sd[p + '.conv1.weight']
+        wk = torch.zeros(64, 7, 8, 4, device=w.device, dtype=F32)
+        wk[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        self.stem_w = wk.to(torch.bfloat16).contiguous().to(device)
+        s_, h_ = bn_fold(sd, p + '.bn1')
+        self.stem_scale, self.stem_shift = s_.float().contiguous().to(device), h_.float().contiguous().to(device)
+        self.stem = stem_conv_op(sd[p + '.conv1.weight'], s_, h_, dt)     # staged path (fp32 mode, DIR_FUSED_STEM=0)
         self.layers = []
         for li, n in enumerate((3, 4, 6, 3), start=1):
             blocks = []
@@ -268,6 +279,13 @@ class BackboneOp(object):
     def __call__(self, img):
         L, dt, dev = _capi.lib(), self.dtype, self.device
         B = img.shape[0]
+        if self.fused_stem and dt == torch.bfloat16:
+            x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
+            u8 = img.dtype == torch.uint8
+            _capi.check(L.dir_stem_pool_forward(_capi.ptr(img), 2 if u8 else 0, IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
+                                                _capi.ptr(self.stem_scale), _capi.ptr(self.stem_shift), _capi.ptr(x), B, 256, 256,
+                                                _capi.stream_ptr()), 'dir_stem_pool_forward')
+            return self._layers(x)
         Hs, Ws = 131, 132                                                        # blocks Y, X = 0 .. 130 (+1 column: even rows)
         xp = torch.empty(B, Hs, Ws, 16, device=dev, dtype=dt)
         if img.dtype == torch.uint8:     # [B,256,256,3] BGR as decoded: normalisation fused into the staging (apps/eval.py:59-61)
@@ -280,6 +298,9 @@ class BackboneOp(object):
         x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
         _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),
                     'dir_maxpool3x3s2')
+        return self._layers(x)
+
+    def _layers(self, x):
         feats = []
         for blocks in self.layers:
             for blk in blocks:

@@ -51,3 +51,29 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
                                             _capi.ptr(out), _capi.stream_ptr())
     _capi.check(rc, 'dir_conv2d_forward')
     return out
+
+
+def pack_stem_weight(w_oihw):
+    """conv1.weight [64,3,7,7] -> bf16 [64][ky 7][kx 8][c 4] for dir_stem_pool_forward (zero for kx = 7, c = 3)"""
+    wk = torch.zeros(64, 7, 8, 4, device=w_oihw.device, dtype=torch.float32)
+    wk[:, :, :7, :3] = w_oihw.float().permute(0, 2, 3, 1)
+    return wk.to(torch.bfloat16).contiguous()
+
+
+def stem_pool(img, w_packed, scale, shift, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """models/backbone/resnet.py:244-247 in one launch (bf16 operands): conv1 7x7/s2/p3 + folded bn1 + ReLU + MaxPool2d(3,2,1).
+    img: float32 NCHW [B,3,H,W] (normalised) or uint8 BGR HWC [B,H,W,3] (apps/eval.py:59-61 fused) -> bf16 NHWC [B,H/4,W/4,64]"""
+    import ctypes as C
+    _capi.require_cuda(img)
+    u8 = img.dtype == torch.uint8
+    if u8:
+        B, H, W = img.shape[0], img.shape[1], img.shape[2]
+    else:
+        img = _capi.f32c(img)
+        B, H, W = img.shape[0], img.shape[2], img.shape[3]
+    img = img.contiguous()
+    y = torch.empty(B, H // 4, W // 4, 64, device=img.device, dtype=torch.bfloat16)
+    _capi.check(_capi.lib().dir_stem_pool_forward(_capi.ptr(img), 2 if u8 else 0, (C.c_float * 3)(*mean), (C.c_float * 3)(*std),
+                                                  _capi.ptr(w_packed), _capi.ptr(_capi.f32c(scale)), _capi.ptr(_capi.f32c(shift)),
+                                                  _capi.ptr(y), B, H, W, _capi.stream_ptr()), 'dir_stem_pool_forward')
+    return y

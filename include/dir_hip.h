@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 6
+#define DIR_ABI_VERSION 7
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -102,6 +102,7 @@ int dir_mano_forward_pair(const dir_mano_tables* tables_lr_host, const float* co
  */
 #define DIR_DT_F32 0
 #define DIR_DT_BF16 1
+#define DIR_DT_U8 2 /* input images only (dir_stem_pool_forward) */
 #define DIR_CONV_RELU 1
 #define DIR_CONV_PRE_RELU 2
 /* Optional kernel choice in bits 8..15 of dir_conv_desc.flags (0 = the library's per-layer heuristic).  Every variant
@@ -351,6 +352,15 @@ int dir_image_normalize_forward(const uint8_t* img_bgr_hwc, float* out_nchw, con
  * bit for bit, without the fp32 image in HBM) */
 int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const float* mean_host, const float* std_host, int B, int H,
                          int W, int Hs, int Ws, int dtype, void* stream);
+
+/* a1 (stem), bf16 mode: models/backbone/resnet.py:244-247 -- conv1 7x7/s2/p3 (3->64) + bn1 (eval, folded scale / shift) + ReLU +
+ * MaxPool2d(3,2,1) in ONE launch; with uint8 input also apps/eval.py:59-61 (== dir_image_normalize_forward, bit for bit).
+ * img: DIR_DT_F32 -> fp32 NCHW [B,3,H,W] (normalised), DIR_DT_U8 -> uint8 BGR HWC [B,H,W,3] (mean / std: host pointers to 3
+ * floats, else ignored).  w_packed: bf16 [64][7 ky][8 kx][4 c] = conv1.weight[n][c][ky][kx], zero for kx = 7 and c = 3.
+ * y: bf16 NHWC [B,H/4,W/4,64].  H, W multiples of 4.  Same operand rounding as dir_stem_prep_s2d + dir_conv2d_forward +
+ * dir_maxpool3x3s2 (bf16 operands, fp32 accumulation, bf16 conv output); only the summation order inside K differs. */
+int dir_stem_pool_forward(const void* img, int img_dtype, const float* mean_host, const float* std_host, const void* w_packed,
+                          const float* scale, const float* shift, void* y, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }
