@@ -406,11 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < VN; ++e) v[e] += rv[e];
             }
-            if (relu) {
-#pragma unroll
-                for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            OutVec<TO>::store(y + (long long)m * a.out_cs + a.out_co + n, v);
+            OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
         }
         return;
     }

@@ -49,10 +49,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 constexpr int LDS_STRIDE = 144;   // one K-slab row = 128 data bytes (+16 pad)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);   // round to nearest even
-    return (bf16_t)(u >> 16);
+// fp32 pair -> packed bf16 pair, round to nearest even: one v_cvt_pk_bf16_f32 (gfx950) instead of ~6 integer ops per value
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+// ReLU on a packed bf16 pair: sign bit set = negative int16 -> 0 (v_pk_max_i16)
+__device__ __forceinline__ uint32_t relu2bf(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, v), i16x2_t{0, 0}));
 }
 
 template <typename T> struct Tr;
@@ -116,6 +123,10 @@ template <> struct OutVec<float> {
     static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    static __device__ __forceinline__ void store_act(float* p, const float (&v)[4], bool relu) {
+        *reinterpret_cast<float4*>(p) = relu ? make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f))
+                                             : make_float4(v[0], v[1], v[2], v[3]);
+    }
 };
 template <> struct OutVec<bf16_t> {
     static constexpr int N = 8;
@@ -128,7 +139,14 @@ template <> struct OutVec<bf16_t> {
     static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
         uint32_t u[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+        for (int e = 0; e < 4; ++e) u[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+    // round, then ReLU on the packed pairs (rounding is monotonic and sign-preserving: same result as ReLU in fp32 first)
+    static __device__ __forceinline__ void store_act(bf16_t* p, const float (&v)[8], bool relu) {
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u[e] = pack2bf(v[2 * e], v[2 * e + 1]); if (relu) u[e] = relu2bf(u[e]); }
         *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
     }
 };
@@ -156,7 +174,7 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, cons
         lo = fmaf(lo, ps[c + 2 * e], pb[c + 2 * e]);
         hi = fmaf(hi, ps[c + 2 * e + 1], pb[c + 2 * e + 1]);
         if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        u[e] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        u[e] = pack2bf(lo, hi);
     }
     return make_uint4(u[0], u[1], u[2], u[3]);
 }
@@ -201,11 +219,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
 #pragma unroll
             for (int e = 0; e < VN; ++e) v[e] += rv[e];
         }
-        if (relu) {
-#pragma unroll
-            for (int e = 0; e < VN; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        OutVec<TO>::store(y + (long long)m * a.out_cs + a.out_co + n, v);
+        OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
     }
 }
 
