@@ -49,7 +49,7 @@ constexpr int G_ROWS = 128, G_LD = 66;      // (sample, end) rows per pass; lda 
 __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
     __shared__ float s_f[G_ROWS * G_LD];
     const int tap = blockIdx.x / 40, hb = blockIdx.x - tap * 40, hand = hb / 20, bone = hb - hand * 20;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jpar = hand * 21 + kParent[bone], jchi = hand * 21 + kChild[bone];
     const float* wt = a.w_g + ((long long)(tap * 40 + hb) * 64) * NCOUT;
     for (int b0 = 0; b0 < a.B; b0 += G_ROWS / 2) {

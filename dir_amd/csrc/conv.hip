@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
     const TI* __restrict__ x = (const TI*)a.x;

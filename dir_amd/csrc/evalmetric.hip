@@ -30,7 +30,7 @@ __device__ __forceinline__ float norm3(float x, float y, float z) { return sqrtf
 __global__ __launch_bounds__(256) void joint_regress_kernel(const float* __restrict__ jr, const float* __restrict__ verts,
                                                              float* __restrict__ joints) {
     __shared__ float s_v[NV * 3];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* v = verts + (size_t)b * NV * 3;
     for (int i = tid; i < NV * 3; i += 256) s_v[i] = v[i];
     __syncthreads();
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(dir_eval_input
     __shared__ float s_vg[2][NV * 3], s_vp[2][NV * 3];
     __shared__ float s_jg[2][NJ][3], s_jp[2][NJ][3];       // regressed joints: GT (camera space), prediction (model space)
     __shared__ float s_scale[2], s_cam[9];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int h = 0; h < 2; ++h) {
         const float* g = in.verts_gt[h] + (size_t)b * NV * 3;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
     float* s_feat = sm + 2 * a.HW;      // [3][C]
     __shared__ float s_den[2];
     __shared__ float s_part[4][128];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = a.HW, C = a.C, Ch = a.Ch;
     const T* c4 = (const T*)a.c4 + (long long)b * HW * C;
     // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232); one wave per (hand, pixel) dot product

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
     float* s_n = s_x + NTP * LDX;         // [48][130] LayerNorm output / attention output
     float* s_big = s_n + NTP * LDX;       // [48][386] qkv, later [48][258] MLP hidden
     float* s_p = s_big + NTP * LDQ;       // [4][48][44] attention scores / probabilities (padding: zero columns 42,43)
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int i = tid; i < (NTP - NT) * LDX; i += NTHREADS) { s_x[NT * LDX + i] = 0.f; s_n[NT * LDX + i] = 0.f; }
     for (int i = tid; i < (NTP - NT) * LDQ; i += NTHREADS) s_big[NT * LDQ + i] = 0.f;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
     __shared__ float s_p[NJ * 3], s_q[NJ * 3];
     __shared__ float s_w[NJ * 4];
     __shared__ int s_i[NJ * 4];
-    const int b = blockIdx.x, hand = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, hand = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.S, C = a.C;
     if (tid < NJ) {
         // F.grid_sample, bilinear / zeros / align_corners=False: ix = ((u + 1) * W - 1) / 2
@@ -209,7 +209,7 @@ constexpr int PG_LD = 128 + 2;
 // output columns slice*64 + 16w .. +15 of both matrices.
 __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
     __shared__ float s_x[PG_ROWS * PG_LD];
-    const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hand = blockIdx.z / args.nchunk, chunk = blockIdx.z - hand * args.nchunk;
     const PgcnHand& a = args.h[hand];
     const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
     __shared__ float s_hid[42 * 64];
     __shared__ float s_part[4][128];
     __shared__ float s_off[3], s_red[8][3];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 42 * 64; i += 512) {
         const int hand = i / 1344;
         s_in[hand][i - hand * 1344] = a.tok[(long long)b * 42 * 64 + i];
