@@ -76,6 +76,7 @@ struct ConvArgs {
     // weight rows are [kh*kw*Cin | Cin2] (dir_conv2d_dual_forward)
     const void* x2; unsigned x2_bytes; int H2, W2, in_cs2, in_co2, stride2, nk1;
     unsigned x_bytes, w_bytes;          // buffer sizes for the hardware bounds check
+    unsigned mg_hw, sh_hw, mg_w, sh_w;  // magic multipliers: m / (Ho*Wo) and r / Wo for 0 <= m < 2^31 (set_magic)
     const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
                                         // each 64-channel input group; K-slabs that cannot touch a tile are skipped
 };
@@ -107,6 +108,37 @@ __device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uin
     for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
                                                       __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
+}
+
+
+// Exact unsigned division of n < 2^31 by a launch constant d as one 64-bit multiply and a shift: sh = 31 + ceil(log2 d),
+// mg = ceil(2^sh / d) < 2^32 (Granlund-Montgomery round-up; n * mg < 2^63).  The tile setup of every workgroup decomposes
+// BM output-pixel indices into (image, row, column); with hardware-less integer division that was ~40 VALU instructions each.
+inline void magic_u31(unsigned d, unsigned* mg, unsigned* sh) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    *sh = 31 + l;
+    *mg = (unsigned)(((1ull << *sh) + d - 1) / d);
+}
+inline void set_magic(ConvArgs& a) {
+    magic_u31((unsigned)(a.Ho * a.Wo), &a.mg_hw, &a.sh_hw);
+    magic_u31((unsigned)a.Wo, &a.mg_w, &a.sh_w);
+}
+__device__ __forceinline__ int div_magic(int n, unsigned mg, unsigned sh) { return (int)(((unsigned long long)(unsigned)n * mg) >> sh); }
+
+// output pixel m -> byte offset of its first tap (may be negative) and the bit mask of taps inside the image
+__device__ __forceinline__ void pixel_setup(const ConvArgs& a, int m, int col_bytes, int es, int& voff, unsigned& msk, int& b, int& oy, int& ox) {
+    b = div_magic(m, a.mg_hw, a.sh_hw);
+    const int rem = m - b * (a.Ho * a.Wo);
+    oy = div_magic(rem, a.mg_w, a.sh_w);
+    ox = rem - oy * a.Wo;
+    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+    voff = (((b * a.H + iy0) * a.W + ix0) * a.in_cs + a.in_co) * es + col_bytes;
+    unsigned colbits = 0;
+    for (int kx = 0; kx < a.kw; ++kx) colbits |= (unsigned)(ix0 + kx >= 0 && ix0 + kx < a.W) << kx;
+    msk = 0;
+    for (int ky = 0; ky < a.kh; ++ky)
+        if (iy0 + ky >= 0 && iy0 + ky < a.H) msk |= colbits << (ky * a.kw);
 }
 
 // 16-byte vector of output elements (coalesced epilogue)

@@ -90,18 +90,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
         avoff[i] = 0;
         amask[i] = 0;
         if (m < a.M) {
-            const int b = m / (a.Ho * a.Wo);
-            const int rem = m - b * (a.Ho * a.Wo);
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            avoff[i] = (((b * a.H + iy0) * a.W + ix0) * a.in_cs + a.in_co + col * EPC) * ES;
-            unsigned msk = 0;
-            for (int ky = 0; ky < a.kh; ++ky)
-                for (int kx = 0; kx < a.kw; ++kx) {
-                    const int iy = iy0 + ky, ix = ix0 + kx;
-                    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) msk |= 1u << (ky * a.kw + kx);
-                }
-            amask[i] = msk;
+            int b, oy, ox;
+            pixel_setup(a, m, col * EPC * ES, ES, avoff[i], amask[i], b, oy, ox);
         }
     }
 #pragma unroll
