@@ -1,0 +1,317 @@
+// dir_bottleneck_chain_forward: the HBM-bound tail of one ResNet bottleneck and the head of the next in ONE kernel (bf16 mode)
+//   models/backbone/resnet.py:126-140   block i  : conv2 3x3 (64->64) -> bn2 -> ReLU -> conv3 1x1 (64->256) -> bn3 -> += identity -> ReLU
+//   models/backbone/resnet.py:122-124   block i+1: conv1 1x1 (256->64) -> bn1 -> ReLU                                   (optional)
+// for the layer1 geometry (planes = 64, stride 1).  Unfused, block i moves y1, y2 (64 ch) twice each and the 256-channel map
+// three times (residual read, output write, next conv1 read) = 534 MB at B = 64; these launches run at the practical HBM rate
+// (4.0-4.8 TB/s), so only traffic counts.  Here y2 and the conv1 input never leave the CU: read y1 (+ halo) and the residual,
+// write the block output and the next block's y1 = 334 MB.
+//
+// One persistent 8-wave workgroup per CU walks 8x16-pixel tiles.  conv2's weights (73 KB) sit in LDS for the whole kernel,
+// conv3's and the next conv1's are MFMA A-fragments in registers (each wave owns 32 / 16 output channels), so no weight byte
+// is re-read per tile.  Every GEMM is computed as D[channel][pixel] (weights = A operand): a lane then holds 4 consecutive
+// channels of one pixel, which is what the bf16 NHWC stores, the residual loads and the LDS hand-over to the next GEMM want --
+// no transposition through LDS in any epilogue.  Per tile:
+//   A. conv2: 10x18 halo patch of y1 (LDS, loaded one tile ahead into registers) x w2 (LDS), 36 x v_mfma_f32_32x32x16_bf16 per
+//      wave (wave = 32 pixels x 32 channels), bn2 + ReLU -> y2 (LDS, bf16: same rounding point as the unfused path)
+//   B. conv3 per 64-pixel half: y2 (LDS) x w3 (registers); bn3 + residual + ReLU in place on the T tile (LDS, bf16), which the
+//      residual entered and the block output leaves with coalesced 16-byte accesses (two whole pixels per wave instruction)
+//   C. next conv1 per half: T (LDS) x w1' (registers) on v_mfma_f32_16x16x32_bf16, bn1' + ReLU -> next y1 (HBM)
+// A half's residual registers are re-requested for the next tile as soon as they have been copied to T (a tile of lead time);
+// all global accesses are unconditional (clamped addresses, zero-select at the LDS write) so that the compiler's in-order vmcnt
+// accounting stays exact and no wait covers more than it needs.
+#include "conv_common.h"
+
+namespace dir {
+namespace {
+
+using convk::bf16_t;
+using convk::bf16x8;
+using convk::f32x16;
+using convk::pack2bf;
+using convk::relu2bf;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TH = 8, TW = 16, NPX = TH * TW;            // tile: 8 rows x 16 cols = 128 pixels, pixel P = row * 16 + col
+constexpr int PH = TH + 2, PWD = TW + 2, NPP = PH * PWD;  // halo patch 10 x 18
+constexpr int PPITCH = 144;                               // bytes per patch / y2 pixel: 64 bf16 + 16 (conflict-free 16-lane reads)
+constexpr int W2PITCH = 1168;                             // bytes per w2 row: 576 bf16 + 16
+constexpr int TPITCH = 528;                               // bytes per T pixel: 256 bf16 + 16
+constexpr int NTHR = 512;
+constexpr int NPRE = (NPP * 8 + NTHR - 1) / NTHR;         // 16-byte patch chunks per thread (3)
+
+struct ChainArgs {
+    const bf16_t* y1; const bf16_t* res; bf16_t* out; bf16_t* y1n;
+    const bf16_t* w2; const float* sc2; const float* sh2;
+    const bf16_t* w3; const float* sc3; const float* sh3;
+    const bf16_t* w1n; const float* sc1n; const float* sh1n;
+    int B, H, W, tiles_x, tiles_y, ntiles;
+};
+
+__device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+template <bool HAS_RES, bool HAS_NEXT>
+__global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_w2[64 * W2PITCH];
+    __shared__ __attribute__((aligned(16))) char s_patch[NPP * PPITCH];
+    __shared__ __attribute__((aligned(16))) char s_y2[NPX * PPITCH];
+    __shared__ __attribute__((aligned(16))) char s_t[64 * TPITCH];
+    __shared__ __attribute__((aligned(16))) float s_ss[768];          // sc2 sh2 (64 each) | sc3 sh3 (256 each) | sc1n sh1n (64 each)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;                         // 32x32 MFMA: row / col index, 8-element k group
+    const int l16 = lane & 15, g = lane >> 4;                         // 16x16 MFMA
+
+    // ---- once per workgroup: conv2 weights and the folded BN vectors -> LDS; conv3 / next conv1 weights -> registers
+    for (int c = tid; c < 64 * 72; c += NTHR) {
+        const int row = c / 72, col = c - row * 72;
+        *reinterpret_cast<uint4*>(s_w2 + row * W2PITCH + col * 16) = *reinterpret_cast<const uint4*>(a.w2 + row * 576 + col * 8);
+    }
+    if (tid < 64) { s_ss[tid] = a.sc2[tid]; s_ss[64 + tid] = a.sh2[tid]; }
+    if (tid < 256) { s_ss[128 + tid] = a.sc3[tid]; s_ss[384 + tid] = a.sh3[tid]; }
+    if (HAS_NEXT && tid < 64) { s_ss[640 + tid] = a.sc1n[tid]; s_ss[704 + tid] = a.sh1n[tid]; }
+    bf16x8 w3f[4];                                                    // channel 32 wave + l32, k = 16 s + 8 h
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w3f[s] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * wave + l32) * 64 + 16 * s + 8 * h);
+    bf16x8 w1f[HAS_NEXT ? 8 : 1];                                     // channel 16 (wave >> 1) + l16, k = 32 s + 8 g
+    if constexpr (HAS_NEXT) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) w1f[s] = *reinterpret_cast<const bf16x8*>(a.w1n + (16 * (wave >> 1) + l16) * 256 + 32 * s + 8 * g);
+    }
+
+    // XCD-aware tile order: the 32 workgroups of one XCD walk one contiguous range of tiles (halo rows hit the same L2)
+    const int nblk = gridDim.x;
+    int t0, tstep, tend;
+    if ((nblk & 7) == 0 && a.ntiles % 8 == 0) {
+        const int per = a.ntiles >> 3;
+        t0 = (blockIdx.x & 7) * per + (blockIdx.x >> 3); tstep = nblk >> 3; tend = ((blockIdx.x & 7) + 1) * per;
+    } else { t0 = blockIdx.x; tstep = nblk; tend = a.ntiles; }
+
+    // ---- halo patch prefetch: chunk e = tid + 512 i -> patch pixel e >> 3, 16-byte channel chunk e & 7
+    uint4 pre[NPRE];
+    unsigned okmask = 0;
+    auto origin = [&](int t, int& b, int& y0, int& x0) {
+        const int tx = t % a.tiles_x, r = t / a.tiles_x;
+        b = r / a.tiles_y; y0 = (r - b * a.tiles_y) * TH; x0 = tx * TW;
+    };
+    auto fetch = [&](int t) {
+        int b, y0, x0;
+        origin(t, b, y0, x0);
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int e = tid + NTHR * i, pp = e >> 3, cc = e & 7;
+            const int pr = pp / PWD, pc = pp - pr * PWD;
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            if (e < NPP * 8 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) okmask |= 1u << i;
+            const int iyc = min(max(iy, 0), a.H - 1), ixc = min(max(ix, 0), a.W - 1);
+            pre[i] = *reinterpret_cast<const uint4*>(a.y1 + (((long long)b * a.H + iyc) * a.W + ixc) * 64 + cc * 8);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int e = tid + NTHR * i, pp = e >> 3, cc = e & 7;
+            if (e < NPP * 8)
+                *reinterpret_cast<uint4*>(s_patch + pp * PPITCH + cc * 16) = (okmask >> i) & 1u ? pre[i] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    int t = t0;
+    if (t < tend) fetch(t);
+    // weight fragments landed before the tile loop (no vmcnt wait on them inside it)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(w3f[s]));
+    if constexpr (HAS_NEXT) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(w1f[s]));
+    }
+    if (t < tend) stage();
+    __syncthreads();
+
+    // phase-A roles: wave = (pixel group mt: tile rows 2 mt, 2 mt + 1) x (channel half nt)
+    const int mt = wave >> 1, nt = wave & 1;
+    const int prow = 2 * mt + (l32 >> 4), pcol = l32 & 15;
+    const char* pa_b = s_patch + (prow * PWD + pcol) * PPITCH + 16 * h;       // + ((ky * 18 + kx) * 144 + 32 s)
+    const char* pa_w = s_w2 + (32 * nt + l32) * W2PITCH + 16 * h;             // + (tap * 128 + 32 s)
+
+    // Block output leaves through the T tile ([64 pixels][256 channels] bf16 per half) with COALESCED 16-byte stores: chunk
+    // c = tid + 512 i of a half = pixel c >> 5, channel chunk c & 31, i.e. two whole 512-byte pixels per wave instruction.  The
+    // residual is read straight into the epilogue-B register layout (pixel 64 mg + 32 j + l32, channels 32 wave + 8 q + 4 h .. +4;
+    // 8-byte pieces): measured, the extra LDS round trip + barrier of a coalesced residual costs more than it saves.
+    uint2 xr[2][2][4];
+    auto out_ptr = [&](int mg, int i, int rb, int ry0, int rx0) {
+        const int c = tid + NTHR * i, P = 64 * mg + (c >> 5);
+        return a.out + (((long long)rb * a.H + ry0 + (P >> 4)) * a.W + rx0 + (P & 15)) * 256 + (c & 31) * 8;
+    };
+
+    auto tile = [&](int t) {
+        int b, y0, x0;
+        origin(t, b, y0, x0);
+        const bool more = t + tstep < tend;
+        fetch(more ? t + tstep : t);                                          // consumed at the end of this tile
+        // this tile's residual: in flight during phase A, consumed in the epilogues B.  (Requesting it a tile ahead does not pay on
+        // gfx9: loads and stores share the in-order vmcnt, so waiting for old loads also waits for the wave's recent stores.)
+        if constexpr (HAS_RES) {
+#pragma unroll
+            for (int mg = 0; mg < 2; ++mg)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int P = 64 * mg + 32 * j + l32;
+                    const bf16_t* rp = a.res + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 256 + 32 * wave + 4 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xr[mg][j][q] = *reinterpret_cast<const uint2*>(rp + 8 * q);
+                }
+        }
+
+        // ---- A. conv2 (3x3): D[channel 32][pixel 32] per wave, K = 9 taps x 64 channels
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // operand fragments are read two k-steps ahead of the MFMA that uses them (LDS latency ~ one MFMA)
+            bf16x8 wv[3], pv[3];
+            auto ldfrag = [&](int i, int slot) {
+                const int tap = i >> 2, s = i & 3, ky = tap / 3, kx = tap - 3 * ky;
+                wv[slot] = *reinterpret_cast<const bf16x8*>(pa_w + tap * 128 + 32 * s);
+                pv[slot] = *reinterpret_cast<const bf16x8*>(pa_b + (ky * PWD + kx) * PPITCH + 32 * s);
+            };
+            ldfrag(0, 0);
+            ldfrag(1, 1);
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                if (i + 2 < 36) ldfrag(i + 2, (i + 2) % 3);
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i % 3], pv[i % 3], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // rows (channels) of the 32x32 tile held by this lane: 8 q + 4 h + {0..3}
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * nt + 8 * q + 4 * h;
+                const float4 sc = *reinterpret_cast<const float4*>(s_ss + c0);
+                const float4 sh = *reinterpret_cast<const float4*>(s_ss + 64 + c0);
+                uint2 o;
+                o.x = relu2bf(pack2bf(fmaf(acc[4 * q], sc.x, sh.x), fmaf(acc[4 * q + 1], sc.y, sh.y)));
+                o.y = relu2bf(pack2bf(fmaf(acc[4 * q + 2], sc.z, sh.z), fmaf(acc[4 * q + 3], sc.w, sh.w)));
+                *reinterpret_cast<uint2*>(s_y2 + (32 * mt + l32) * PPITCH + c0 * 2) = o;
+            }
+        }
+        __syncthreads();                                                      // y2 complete; the patch is free
+
+#pragma unroll
+        for (int mg = 0; mg < 2; ++mg) {
+            // ---- B. conv3 (1x1, K = 64): this wave's 32 output channels x the half's 64 pixels
+            f32x16 accb[2];
+            bf16x8 pvb[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    pvb[j][s] = *reinterpret_cast<const bf16x8*>(s_y2 + (64 * mg + 32 * j + l32) * PPITCH + 32 * s + 16 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accb[j][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[s], pvb[j][s], accb[j], 0, 0, 0);
+            // epilogue B -> T: lane = pixel 32 j + l32, channels 32 wave + 8 q + 4 h .. +4
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = 32 * wave + 8 * q + 4 * h;
+                    char* tp = s_t + (32 * j + l32) * TPITCH + c0 * 2;
+                    const float4 sc = *reinterpret_cast<const float4*>(s_ss + 128 + c0);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_ss + 384 + c0);
+                    float v[4] = {fmaf(accb[j][4 * q], sc.x, sh.x), fmaf(accb[j][4 * q + 1], sc.y, sh.y),
+                                  fmaf(accb[j][4 * q + 2], sc.z, sh.z), fmaf(accb[j][4 * q + 3], sc.w, sh.w)};
+                    if constexpr (HAS_RES) {
+                        float rv[4];
+                        unpack4(xr[mg][j][q], rv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    uint2 o;
+                    o.x = relu2bf(pack2bf(v[0], v[1]));
+                    o.y = relu2bf(pack2bf(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(tp) = o;
+                }
+            }
+            __syncthreads();                                                  // T = this half of the block output
+            // block output: coalesced 16-byte stores from T
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = tid + NTHR * i;
+                *reinterpret_cast<uint4*>(out_ptr(mg, i, b, y0, x0)) = *reinterpret_cast<const uint4*>(s_t + (c >> 5) * TPITCH + (c & 31) * 16);
+            }
+            if constexpr (HAS_NEXT) {
+                // ---- C. next block's conv1 (1x1, K = 256): 16 channels (wave >> 1) x two 16-pixel groups
+                const int ct = wave >> 1;
+                f32x4 accc[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) accc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(s_t + (16 * (2 * (wave & 1) + u) + l16) * TPITCH + 64 * s + 16 * g);
+                        accc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], pv, accc[u], 0, 0, 0);
+                    }
+                const int c0 = 16 * ct + 4 * g;
+                const float4 sc = *reinterpret_cast<const float4*>(s_ss + 640 + c0);
+                const float4 sh = *reinterpret_cast<const float4*>(s_ss + 704 + c0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int P = 64 * mg + 16 * (2 * (wave & 1) + u) + l16;
+                    uint2 o;
+                    o.x = relu2bf(pack2bf(fmaf(accc[u][0], sc.x, sh.x), fmaf(accc[u][1], sc.y, sh.y)));
+                    o.y = relu2bf(pack2bf(fmaf(accc[u][2], sc.z, sh.z), fmaf(accc[u][3], sc.w, sh.w)));
+                    *reinterpret_cast<uint2*>(a.y1n + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 64 + c0) = o;
+                }
+            }
+            if (mg == 0) __syncthreads();                                     // T free for the second half
+        }
+        stage();                                                              // next tile's patch (loads issued a whole tile ago)
+        __syncthreads();                                                      // patch visible; y2 free
+    };
+    for (; t < tend; t += tstep) tile(t);
+}
+
+}  // namespace
+}  // namespace dir
+
+extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, void* out, void* y1_next,
+                                            int B, int H, int W, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(p && y1 && out && B > 0, "dir_bottleneck_chain_forward: bad args");
+    DIR_REQUIRE(p->w2 && p->scale2 && p->shift2 && p->w3 && p->scale3 && p->shift3, "dir_bottleneck_chain_forward: missing conv2 / conv3 parameters");
+    DIR_REQUIRE(H > 0 && W > 0 && H % TH == 0 && W % TW == 0, "dir_bottleneck_chain_forward: H must be a multiple of 8 and W of 16");
+    const bool next = y1_next != nullptr;
+    DIR_REQUIRE(!next || (p->w1n && p->scale1n && p->shift1n), "dir_bottleneck_chain_forward: y1_next needs the next conv1 parameters");
+    ChainArgs a;
+    a.y1 = (const convk::bf16_t*)y1; a.res = (const convk::bf16_t*)residual; a.out = (convk::bf16_t*)out; a.y1n = (convk::bf16_t*)y1_next;
+    a.w2 = (const convk::bf16_t*)p->w2; a.sc2 = p->scale2; a.sh2 = p->shift2;
+    a.w3 = (const convk::bf16_t*)p->w3; a.sc3 = p->scale3; a.sh3 = p->shift3;
+    a.w1n = (const convk::bf16_t*)p->w1n; a.sc1n = p->scale1n; a.sh1n = p->shift1n;
+    a.B = B; a.H = H; a.W = W; a.tiles_x = W / TW; a.tiles_y = H / TH;
+    const long long nt = (long long)B * a.tiles_x * a.tiles_y;
+    DIR_REQUIRE(nt < (1ll << 31) && (long long)B * H * W * 256 < (1ll << 40), "dir_bottleneck_chain_forward: too large");
+    a.ntiles = (int)nt;
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0; hipDeviceProp_t pr;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    }
+    const int grid = (int)(nt < num_cu ? nt : num_cu);
+    hipStream_t s = (hipStream_t)stream;
+    const bool res = residual != nullptr;
+    if (res && next) hipLaunchKernelGGL((bneck_chain_kernel<true, true>), dim3(grid), dim3(NTHR), 0, s, a);
+    else if (res) hipLaunchKernelGGL((bneck_chain_kernel<true, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    else if (next) hipLaunchKernelGGL((bneck_chain_kernel<false, true>), dim3(grid), dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((bneck_chain_kernel<false, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    return check_launch("dir_bottleneck_chain_forward");
+}

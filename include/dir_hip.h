@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 7
+#define DIR_ABI_VERSION 8
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -361,6 +361,21 @@ int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const float* mea
  * dir_maxpool3x3s2 (bf16 operands, fp32 accumulation, bf16 conv output); only the summation order inside K differs. */
 int dir_stem_pool_forward(const void* img, int img_dtype, const float* mean_host, const float* std_host, const void* w_packed,
                           const float* scale, const float* shift, void* y, int B, int H, int W, void* stream);
+
+/* a1 (layer1 bottlenecks), bf16 mode: models/backbone/resnet.py:126-140 of block i -- conv2 3x3/s1/p1 (64->64) + bn2 + ReLU +
+ * conv3 1x1 (64->256) + bn3 + identity + ReLU -- and, optionally, :122-124 of block i+1 -- conv1 1x1 (256->64) + bn1 + ReLU --
+ * in one launch: the 64-channel intermediate and the next conv1's input never touch HBM (534 -> 334 MB per block at B = 64).
+ * y1 [B,H,W,64] = ReLU(bn1(conv1(x))) of block i; residual [B,H,W,256] or NULL; out [B,H,W,256]; y1_next [B,H,W,64] or NULL
+ * (then w1n / scale1n / shift1n are ignored); all bf16 NHWC.  H % 8 == 0, W % 16 == 0.  Weights bf16: w2 [64][3][3][64]
+ * (dir_conv2d_forward's packing), w3 [256][64], w1n [64][256]; scale / shift = folded eval BatchNorm, fp32, device pointers.
+ * Same rounding points as the unfused dir_conv2d_forward sequence (bf16 operands, fp32 accumulation, bf16 y2 / out). */
+typedef struct dir_bneck_chain_params {
+    const void* w2; const float* scale2; const float* shift2;
+    const void* w3; const float* scale3; const float* shift3;
+    const void* w1n; const float* scale1n; const float* shift1n;
+} dir_bneck_chain_params;
+int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, void* out, void* y1_next,
+                                 int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }
