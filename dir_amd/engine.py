@@ -215,6 +215,47 @@ def pack_mano(sd, prefix, side, center_idx, keep):
                             -1 if center_idx is None else int(center_idx), 0)
 
 
+class BneckChainOp(object):
+    """dir_bottleneck_chain_forward: conv2 + bn2 + ReLU + conv3 + bn3 + identity + ReLU of a layer1 bottleneck and, optionally,
+    the next block's conv1 + bn1 + ReLU in one launch (models/backbone/resnet.py:122-140).  Built from the blocks' ConvOps;
+    carries the attributes autotune / export_tuning read from a conv op (it has a single kernel: every variant code is a no-op)."""
+
+    def __init__(self, c2, c3, c1n=None):
+        self.c2, self.c3, self.c1n = c2, c3, c1n
+        self.cout, self.cin, self.kh, self.kw, self.stride = c3.cout, c2.cin, 3, 3, 1
+        self.variant = {}
+        self.w3 = c3.w.reshape(c3.cout, c3.cin).contiguous()
+        self.w1n = c1n.w.reshape(c1n.cout, c1n.cin).contiguous() if c1n is not None else None
+        n = (lambda t: None) if c1n is None else _capi.ptr        # noqa: E731
+        self.params = _capi.BneckChainParams(_capi.ptr(c2.w), _capi.ptr(c2.scale), _capi.ptr(c2.shift), _capi.ptr(self.w3),
+                                             _capi.ptr(c3.scale), _capi.ptr(c3.shift), n(self.w1n),
+                                             n(c1n.scale if c1n is not None else None), n(c1n.shift if c1n is not None else None))
+
+    @staticmethod
+    def applies(c2, c3, c1n, dtype):
+        ok = (dtype == torch.bfloat16 and c2.cin == 64 and c2.cout == 64 and c2.kh == 3 and c2.stride == 1 and c3.cin == 64
+              and c3.cout == 256 and c2.scale is not None and c3.scale is not None)
+        return ok and (c1n is None or (c1n.cin == 256 and c1n.cout == 64 and c1n.kh == 1 and c1n.stride == 1))
+
+    def __call__(self, y1, residual):
+        B, H, W, _ = y1.shape
+        out = torch.empty(B, H, W, 256, device=y1.device, dtype=y1.dtype)
+        y1n = torch.empty(B, H, W, 64, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(self.params), _capi.ptr(y1), _capi.ptr(residual), _capi.ptr(out),
+                                                             _capi.ptr(y1n), B, H, W, _capi.stream_ptr()), 'dir_bottleneck_chain_forward')
+        if PROFILE is not None:
+            e1.record()
+            m, nx = B * H * W, self.c1n is not None
+            PROFILE.append(('conv_igemm<bf16,bf16>', 2.0 * m * (64 * 576 + 256 * 64 + (64 * 256 if nx else 0)), e0, e1,
+                            'M=%d chain 3x3(64)+1x1(256)%s' % (m, '+1x1(64)' if nx else ''),
+                            (m * (64 + 256 * (2 if residual is not None else 1) + (64 if nx else 0))
+                             + self.c2.w.numel() + self.w3.numel() + (self.w1n.numel() if nx else 0)) * 2, self))
+        return out, y1n
+
+
 def stem_conv_op(w, scale, shift, dtype):
     """7x7/2 stem over 2x2 space-to-depth blocks (dir_stem_prep_s2d): a 4x4 stride-1 convolution whose K-slab is a block-row
     window of 4 blocks x 16 channels; w'[n][j*16 + (dy*2+dx)*4 + c][r] = w[n, c, 2r+dy-1, 2j+dx-1]   (w = conv1.weight [64,3,7,7])"""
@@ -243,6 +284,7 @@ class BackboneOp(object):
     shortcuts folded into their block's conv3 as a second K range (dir_conv2d_dual_forward)."""
     fold_downsample = os.environ.get('DIR_FOLD_DOWNSAMPLE', '1') != '0'
     fused_stem = os.environ.get('DIR_FUSED_STEM', '1') != '0'       # bf16 mode: conv1 + bn1 + ReLU + maxpool in one launch
+    bneck_chain = os.environ.get('DIR_BNECK_CHAIN', '1') != '0'     # bf16 mode, layer1: conv2 + conv3 (+ next conv1) in one launch
 
     def __init__(self, sd, p, dtype, device):
         dt = self.dtype = dtype
@@ -275,6 +317,13 @@ class BackboneOp(object):
                         blk['ds'] = ConvOp(sd[q + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
                 blocks.append(blk)
             self.layers.append(blocks)
+        # layer1 (HBM-bound): blocks without a projection shortcut run conv2 -> conv3 -> (next block's conv1) as one kernel
+        if self.bneck_chain:
+            l1 = self.layers[0]
+            for i, blk in enumerate(l1):
+                nxt = l1[i + 1]['c1'] if i + 1 < len(l1) else None
+                if 'dual' not in blk and blk['ds'] is None and BneckChainOp.applies(blk['c2'], blk['c3'], nxt, dt):
+                    blk['chain'] = BneckChainOp(blk['c2'], blk['c3'], nxt)
 
     def __call__(self, img):
         L, dt, dev = _capi.lib(), self.dtype, self.device
@@ -303,7 +352,11 @@ class BackboneOp(object):
     def _layers(self, x):
         feats = []
         for blocks in self.layers:
+            y1 = None                                                # conv1 output handed over by the previous block's chain kernel
             for blk in blocks:
+                if 'chain' in blk:
+                    x, y1 = blk['chain'](y1 if y1 is not None else blk['c1'](x), x)
+                    continue
                 if 'dual' in blk:                                    # conv3 + projection shortcut in one launch
                     x = blk['dual'](blk['c2'](blk['c1'](x)), x)
                 else:
