@@ -33,7 +33,7 @@ class ConvSrc2(C.Structure):
 
 
 class BneckChainParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n')]
+    _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n', 'wd')]
 
 
 class TokenMlp(C.Structure):
@@ -93,7 +93,7 @@ _SIGNATURES = {
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_image_normalize_forward': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _p]),
     'dir_stem_prep_s2d_u8': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _i, _i, _i, _p]),
-    'dir_bottleneck_chain_forward': (C.c_int, [C.POINTER(BneckChainParams), _p, _p, _p, _p, _i, _i, _i, _p]),
+    'dir_bottleneck_chain_forward': (C.c_int, [C.POINTER(BneckChainParams), _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_stem_pool_forward': (C.c_int, [_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -1,6 +1,7 @@
 // dir_bottleneck_chain_forward: the HBM-bound tail of one ResNet bottleneck and the head of the next in ONE kernel (bf16 mode)
 //   models/backbone/resnet.py:126-140   block i  : conv2 3x3 (64->64) -> bn2 -> ReLU -> conv3 1x1 (64->256) -> bn3 -> += identity -> ReLU
 //   models/backbone/resnet.py:122-124   block i+1: conv1 1x1 (256->64) -> bn1 -> ReLU                                   (optional)
+//   models/backbone/resnet.py:117-119   block i with a projection shortcut: downsample conv 1x1 (64->256) + BN as 64 more K of conv3's GEMM
 // for the layer1 geometry (planes = 64, stride 1).  Unfused, block i moves y1, y2 (64 ch) twice each and the 256-channel map
 // three times (residual read, output write, next conv1 read) = 534 MB at B = 64; these launches run at the practical HBM rate
 // (4.0-4.8 TB/s), so only traffic counts.  Here y2 and the conv1 input never leave the CU: read y1 (+ halo) and the residual,
@@ -44,6 +45,7 @@ struct ChainArgs {
     const bf16_t* w2; const float* sc2; const float* sh2;
     const bf16_t* w3; const float* sc3; const float* sh3;
     const bf16_t* w1n; const float* sc1n; const float* sh1n;
+    const bf16_t* x2; const bf16_t* wd;                   // projection shortcut: second 64-channel source of conv3's GEMM
     int B, H, W, tiles_x, tiles_y, ntiles;
 };
 
@@ -52,7 +54,7 @@ __device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-template <bool HAS_RES, bool HAS_NEXT>
+template <bool HAS_RES, bool HAS_NEXT, bool HAS_DUAL>
 __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     __shared__ __attribute__((aligned(16))) char s_w2[64 * W2PITCH];
     __shared__ __attribute__((aligned(16))) char s_patch[NPP * PPITCH];
@@ -74,6 +76,11 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     bf16x8 w3f[4];                                                    // channel 32 wave + l32, k = 16 s + 8 h
 #pragma unroll
     for (int s = 0; s < 4; ++s) w3f[s] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * wave + l32) * 64 + 16 * s + 8 * h);
+    bf16x8 wdf[HAS_DUAL ? 4 : 1];                                     // projection weights, same fragment layout as w3f
+    if constexpr (HAS_DUAL) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wdf[s] = *reinterpret_cast<const bf16x8*>(a.wd + (32 * wave + l32) * 64 + 16 * s + 8 * h);
+    }
     bf16x8 w1f[HAS_NEXT ? 8 : 1];                                     // channel 16 (wave >> 1) + l16, k = 32 s + 8 g
     if constexpr (HAS_NEXT) {
 #pragma unroll
@@ -123,6 +130,10 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     // weight fragments landed before the tile loop (no vmcnt wait on them inside it)
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(w3f[s]));
+    if constexpr (HAS_DUAL) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(wdf[s]));
+    }
     if constexpr (HAS_NEXT) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(w1f[s]));
@@ -165,6 +176,17 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                 }
         }
 
+        // projection shortcut input (the block's own input, 64 channels) for this tile: chunk c = tid + 512 i = pixel c >> 3,
+        // 16-byte chunk c & 7; parked in the patch buffer once phase A is done with it
+        uint4 xq[2];
+        if constexpr (HAS_DUAL) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + NTHR * i, P = c >> 3;
+                xq[i] = *reinterpret_cast<const uint4*>(a.x2 + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 64 + (c & 7) * 8);
+            }
+        }
+
         // ---- A. conv2 (3x3): D[channel 32][pixel 32] per wave, K = 9 taps x 64 channels
         {
             f32x16 acc;
@@ -199,6 +221,14 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
             }
         }
         __syncthreads();                                                      // y2 complete; the patch is free
+        if constexpr (HAS_DUAL) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + NTHR * i;
+                *reinterpret_cast<uint4*>(s_patch + (c >> 3) * PPITCH + (c & 7) * 16) = xq[i];
+            }
+            __syncthreads();
+        }
 
 #pragma unroll
         for (int mg = 0; mg < 2; ++mg) {
@@ -218,6 +248,17 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[s], pvb[j][s], accb[j], 0, 0, 0);
+            if constexpr (HAS_DUAL) {                                         // + projection shortcut: K = 64 more, from the parked input tile
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        pvb[j][s] = *reinterpret_cast<const bf16x8*>(s_patch + (64 * mg + 32 * j + l32) * PPITCH + 32 * s + 16 * h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wdf[s], pvb[j][s], accb[j], 0, 0, 0);
+            }
             // epilogue B -> T: lane = pixel 32 j + l32, channels 32 wave + 8 q + 4 h .. +4
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -284,19 +325,22 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
 }  // namespace
 }  // namespace dir
 
-extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, void* out, void* y1_next,
-                                            int B, int H, int W, void* stream) {
+extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
+                                            void* y1_next, int B, int H, int W, void* stream) {
     using namespace dir;
     DIR_REQUIRE(p && y1 && out && B > 0, "dir_bottleneck_chain_forward: bad args");
     DIR_REQUIRE(p->w2 && p->scale2 && p->shift2 && p->w3 && p->scale3 && p->shift3, "dir_bottleneck_chain_forward: missing conv2 / conv3 parameters");
     DIR_REQUIRE(H > 0 && W > 0 && H % TH == 0 && W % TW == 0, "dir_bottleneck_chain_forward: H must be a multiple of 8 and W of 16");
     const bool next = y1_next != nullptr;
+    const bool dual = x2 != nullptr;
+    DIR_REQUIRE(!dual || (p->wd && !residual), "dir_bottleneck_chain_forward: a second source needs wd and excludes the identity residual");
     DIR_REQUIRE(!next || (p->w1n && p->scale1n && p->shift1n), "dir_bottleneck_chain_forward: y1_next needs the next conv1 parameters");
     ChainArgs a;
     a.y1 = (const convk::bf16_t*)y1; a.res = (const convk::bf16_t*)residual; a.out = (convk::bf16_t*)out; a.y1n = (convk::bf16_t*)y1_next;
     a.w2 = (const convk::bf16_t*)p->w2; a.sc2 = p->scale2; a.sh2 = p->shift2;
     a.w3 = (const convk::bf16_t*)p->w3; a.sc3 = p->scale3; a.sh3 = p->shift3;
     a.w1n = (const convk::bf16_t*)p->w1n; a.sc1n = p->scale1n; a.sh1n = p->shift1n;
+    a.x2 = (const convk::bf16_t*)x2; a.wd = (const convk::bf16_t*)p->wd;
     a.B = B; a.H = H; a.W = W; a.tiles_x = W / TW; a.tiles_y = H / TH;
     const long long nt = (long long)B * a.tiles_x * a.tiles_y;
     DIR_REQUIRE(nt < (1ll << 31) && (long long)B * H * W * 256 < (1ll << 40), "dir_bottleneck_chain_forward: too large");
@@ -309,9 +353,11 @@ extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, con
     const int grid = (int)(nt < num_cu ? nt : num_cu);
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
-    if (res && next) hipLaunchKernelGGL((bneck_chain_kernel<true, true>), dim3(grid), dim3(NTHR), 0, s, a);
-    else if (res) hipLaunchKernelGGL((bneck_chain_kernel<true, false>), dim3(grid), dim3(NTHR), 0, s, a);
-    else if (next) hipLaunchKernelGGL((bneck_chain_kernel<false, true>), dim3(grid), dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((bneck_chain_kernel<false, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    if (dual && next) hipLaunchKernelGGL((bneck_chain_kernel<false, true, true>), dim3(grid), dim3(NTHR), 0, s, a);
+    else if (dual) hipLaunchKernelGGL((bneck_chain_kernel<false, false, true>), dim3(grid), dim3(NTHR), 0, s, a);
+    else if (res && next) hipLaunchKernelGGL((bneck_chain_kernel<true, true, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    else if (res) hipLaunchKernelGGL((bneck_chain_kernel<true, false, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    else if (next) hipLaunchKernelGGL((bneck_chain_kernel<false, true, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL((bneck_chain_kernel<false, false, false>), dim3(grid), dim3(NTHR), 0, s, a);
     return check_launch("dir_bottleneck_chain_forward");
 }

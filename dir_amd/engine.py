@@ -220,39 +220,53 @@ class BneckChainOp(object):
     the next block's conv1 + bn1 + ReLU in one launch (models/backbone/resnet.py:122-140).  Built from the blocks' ConvOps;
     carries the attributes autotune / export_tuning read from a conv op (it has a single kernel: every variant code is a no-op)."""
 
-    def __init__(self, c2, c3, c1n=None):
-        self.c2, self.c3, self.c1n = c2, c3, c1n
-        self.cout, self.cin, self.kh, self.kw, self.stride = c3.cout, c2.cin, 3, 3, 1
+    def __init__(self, c2, c3, c1n=None, dual=None):
+        """c3: the block's conv3 ConvOp, or None with dual = DualConvOp (conv3 + projection shortcut, BN scales folded into rows)"""
+        self.c2, self.c3, self.c1n, self.dual = c2, c3, c1n, dual
+        self.cout, self.cin, self.kh, self.kw, self.stride = 256, c2.cin, 3, 3, 1
         self.variant = {}
-        self.w3 = c3.w.reshape(c3.cout, c3.cin).contiguous()
+        dev = c2.w.device
+        if dual is None:
+            self.w3 = c3.w.reshape(c3.cout, c3.cin).contiguous()
+            self.wd, self.s3, self.h3 = None, c3.scale, c3.shift
+        else:
+            self.w3 = dual.w[:, :64].contiguous()
+            self.wd = dual.w[:, 64:].contiguous()
+            self.s3, self.h3 = torch.ones(256, device=dev, dtype=F32), dual.shift
         self.w1n = c1n.w.reshape(c1n.cout, c1n.cin).contiguous() if c1n is not None else None
         n = (lambda t: None) if c1n is None else _capi.ptr        # noqa: E731
         self.params = _capi.BneckChainParams(_capi.ptr(c2.w), _capi.ptr(c2.scale), _capi.ptr(c2.shift), _capi.ptr(self.w3),
-                                             _capi.ptr(c3.scale), _capi.ptr(c3.shift), n(self.w1n),
-                                             n(c1n.scale if c1n is not None else None), n(c1n.shift if c1n is not None else None))
+                                             _capi.ptr(self.s3), _capi.ptr(self.h3), n(self.w1n),
+                                             n(c1n.scale if c1n is not None else None), n(c1n.shift if c1n is not None else None),
+                                             _capi.ptr(self.wd) if self.wd is not None else None)
 
     @staticmethod
-    def applies(c2, c3, c1n, dtype):
-        ok = (dtype == torch.bfloat16 and c2.cin == 64 and c2.cout == 64 and c2.kh == 3 and c2.stride == 1 and c3.cin == 64
-              and c3.cout == 256 and c2.scale is not None and c3.scale is not None)
+    def applies(c2, c3, c1n, dtype, dual=None):
+        ok = dtype == torch.bfloat16 and c2.cin == 64 and c2.cout == 64 and c2.kh == 3 and c2.stride == 1 and c2.scale is not None
+        if dual is None:
+            ok = ok and c3.cin == 64 and c3.cout == 256 and c3.scale is not None
+        else:
+            ok = ok and dual.cin == 64 and dual.cin2 == 64 and dual.cout == 256 and dual.stride2 == 1 and dual.relu
         return ok and (c1n is None or (c1n.cin == 256 and c1n.cout == 64 and c1n.kh == 1 and c1n.stride == 1))
 
-    def __call__(self, y1, residual):
+    def __call__(self, y1, x):
+        """x: the block input -- the identity residual, or (dual) the projection shortcut's source"""
+        residual, x2 = (None, x) if self.dual is not None else (x, None)
         B, H, W, _ = y1.shape
         out = torch.empty(B, H, W, 256, device=y1.device, dtype=y1.dtype)
         y1n = torch.empty(B, H, W, 64, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(self.params), _capi.ptr(y1), _capi.ptr(residual), _capi.ptr(out),
+        _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(self.params), _capi.ptr(y1), _capi.ptr(residual), _capi.ptr(x2), _capi.ptr(out),
                                                              _capi.ptr(y1n), B, H, W, _capi.stream_ptr()), 'dir_bottleneck_chain_forward')
         if PROFILE is not None:
             e1.record()
             m, nx = B * H * W, self.c1n is not None
-            PROFILE.append(('conv_igemm<bf16,bf16>', 2.0 * m * (64 * 576 + 256 * 64 + (64 * 256 if nx else 0)), e0, e1,
+            PROFILE.append(('conv_igemm<bf16,bf16>', 2.0 * m * (64 * 576 + 256 * 64 * (2 if x2 is not None else 1) + (64 * 256 if nx else 0)), e0, e1,
                             'M=%d chain 3x3(64)+1x1(256)%s' % (m, '+1x1(64)' if nx else ''),
-                            (m * (64 + 256 * (2 if residual is not None else 1) + (64 if nx else 0))
-                             + self.c2.w.numel() + self.w3.numel() + (self.w1n.numel() if nx else 0)) * 2, self))
+                            (m * (64 + 256 * (2 if residual is not None else 1) + (64 if nx else 0) + (64 if x2 is not None else 0))
+                             + self.c2.w.numel() + self.w3.numel() * (2 if x2 is not None else 1) + (self.w1n.numel() if nx else 0)) * 2, self))
         return out, y1n
 
 
@@ -322,7 +336,10 @@ class BackboneOp(object):
             l1 = self.layers[0]
             for i, blk in enumerate(l1):
                 nxt = l1[i + 1]['c1'] if i + 1 < len(l1) else None
-                if 'dual' not in blk and blk['ds'] is None and BneckChainOp.applies(blk['c2'], blk['c3'], nxt, dt):
+                if 'dual' in blk:
+                    if BneckChainOp.applies(blk['c2'], None, nxt, dt, dual=blk['dual']):
+                        blk['chain'] = BneckChainOp(blk['c2'], None, nxt, dual=blk['dual'])
+                elif blk['ds'] is None and BneckChainOp.applies(blk['c2'], blk['c3'], nxt, dt):
                     blk['chain'] = BneckChainOp(blk['c2'], blk['c3'], nxt)
 
     def __call__(self, img):

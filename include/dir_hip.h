@@ -373,9 +373,12 @@ typedef struct dir_bneck_chain_params {
     const void* w2; const float* scale2; const float* shift2;
     const void* w3; const float* scale3; const float* shift3;
     const void* w1n; const float* scale1n; const float* shift1n;
+    const void* wd;   /* projection shortcut (models/backbone/resnet.py:117-119), bf16 [256][64]: with x2 != NULL conv3's GEMM gets
+                         64 more K from x2 [B,H,W,64] (the block input).  Both BatchNorm scales must then be folded into w3 / wd
+                         rows, scale3 = 1 and shift3 = shift_bn3 + shift_bn_ds; `residual` must be NULL. */
 } dir_bneck_chain_params;
-int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, void* out, void* y1_next,
-                                 int B, int H, int W, void* stream);
+int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
+                                 void* y1_next, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

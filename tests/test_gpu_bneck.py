@@ -95,6 +95,36 @@ def test_chain_vs_unfused_sequence():
     assert relerr(y1n.float().cpu().numpy(), n1.float().cpu().numpy()) < 1e-2
 
 
+@pytest.mark.parametrize('nxt', [True, False])
+def test_chain_projection_shortcut(nxt):
+    """first block of layer1: conv3 + downsample conv as one GEMM (BN scales folded into the bf16 weight rows, as DualConvOp does)"""
+    B, H, W = 2, 16, 32
+    p = make('bneck.dual', B, H, W)
+    g = lambda n, shp, **k: synth.synth_input('bneck.dual.%s' % n, shp, SEED, **k)  # noqa: E731
+    x0 = bf16_round(g('x0', (B, 64, H, W)))
+    wd = g('wd', (256, 64, 1, 1)) * np.float32(np.sqrt(2.0 / 64))
+    sd, hd = g('sd', (256,), kind='uniform', lo=0.5, hi=1.5), g('hd', (256,)) * np.float32(0.3)
+    w3f = bf16_round(p['w3'].reshape(256, 64) * p['s3'][:, None])            # folded rows, then bf16 (what the kernel multiplies)
+    wdf = bf16_round(wd.reshape(256, 64) * sd[:, None])
+    shift = (p['h3'] + hd).astype(np.float32)
+    aff = lambda t, s, h: t * s.reshape(1, -1, 1, 1) + h.reshape(1, -1, 1, 1)  # noqa: E731
+    y2 = bf16_round(np.maximum(aff(N.conv2d(p['y1'].astype(np.float64), p['w2'].astype(np.float64), None, 1, 1), p['s2'], p['h2']), 0)
+                    .astype(np.float32))
+    o = (N.conv2d(y2.astype(np.float64), w3f.reshape(256, 64, 1, 1).astype(np.float64), None, 1, 0)
+         + N.conv2d(x0.astype(np.float64), wdf.reshape(256, 64, 1, 1).astype(np.float64), None, 1, 0) + shift.reshape(1, -1, 1, 1))
+    ref_out = bf16_round(np.maximum(o, 0).astype(np.float32))
+    out, y1n = F.bottleneck_chain(nhwc(p['y1']), F.pack_conv_weight(dev(p['w2']), BF), dev(p['s2']), dev(p['h2']), dev(w3f).to(BF),
+                                  torch.ones(256, device='cuda'), dev(shift),
+                                  nxt=(dev(p['w1'].reshape(64, 256)).to(BF), dev(p['s1']), dev(p['h1'])) if nxt else None,
+                                  dual=(nhwc(x0), dev(wdf).to(BF)))
+    got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert relerr(got, ref_out) < 1e-2
+    assert np.abs(got - ref_out).max() <= np.abs(ref_out).max() * 2.0 ** -6
+    if nxt:
+        ref1 = np.maximum(aff(N.conv2d(ref_out.astype(np.float64), p['w1'].astype(np.float64), None, 1, 0), p['s1'], p['h1']), 0)
+        assert relerr(y1n.float().cpu().numpy().transpose(0, 3, 1, 2), ref1) < 1.5e-2
+
+
 def test_chain_rejects_bad_shape():
     from dir_amd._capi import DirHipError
     p = make('bneck.bad', 1, 8, 16)
