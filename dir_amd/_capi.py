@@ -33,7 +33,8 @@ class ConvSrc2(C.Structure):
 
 
 class BneckChainParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n', 'wd')]
+    _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n', 'wd')] + [
+        ('n_next', C.c_int32)]
 
 
 class TokenMlp(C.Structure):

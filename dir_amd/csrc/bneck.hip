@@ -54,13 +54,15 @@ __device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-template <bool HAS_RES, bool HAS_NEXT, bool HAS_DUAL>
+// N2: output channels of the fused next conv1 (0 = none, 64 = next layer1 block, 128 = first block of layer2)
+template <bool HAS_RES, int N2, bool HAS_DUAL>
 __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
+    constexpr bool HAS_NEXT = N2 > 0;
     __shared__ __attribute__((aligned(16))) char s_w2[64 * W2PITCH];
     __shared__ __attribute__((aligned(16))) char s_patch[NPP * PPITCH];
     __shared__ __attribute__((aligned(16))) char s_y2[NPX * PPITCH];
     __shared__ __attribute__((aligned(16))) char s_t[64 * TPITCH];
-    __shared__ __attribute__((aligned(16))) float s_ss[768];          // sc2 sh2 (64 each) | sc3 sh3 (256 each) | sc1n sh1n (64 each)
+    __shared__ __attribute__((aligned(16))) float s_ss[896];          // sc2 sh2 (64 each) | sc3 sh3 (256 each) | sc1n sh1n (128 each)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, h = lane >> 5;                         // 32x32 MFMA: row / col index, 8-element k group
     const int l16 = lane & 15, g = lane >> 4;                         // 16x16 MFMA
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     }
     if (tid < 64) { s_ss[tid] = a.sc2[tid]; s_ss[64 + tid] = a.sh2[tid]; }
     if (tid < 256) { s_ss[128 + tid] = a.sc3[tid]; s_ss[384 + tid] = a.sh3[tid]; }
-    if (HAS_NEXT && tid < 64) { s_ss[640 + tid] = a.sc1n[tid]; s_ss[704 + tid] = a.sh1n[tid]; }
+    if (HAS_NEXT && tid < N2) { s_ss[640 + tid] = a.sc1n[tid]; s_ss[768 + tid] = a.sh1n[tid]; }
     bf16x8 w3f[4];                                                    // channel 32 wave + l32, k = 16 s + 8 h
 #pragma unroll
     for (int s = 0; s < 4; ++s) w3f[s] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * wave + l32) * 64 + 16 * s + 8 * h);
@@ -81,10 +83,13 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) wdf[s] = *reinterpret_cast<const bf16x8*>(a.wd + (32 * wave + l32) * 64 + 16 * s + 8 * h);
     }
-    bf16x8 w1f[HAS_NEXT ? 8 : 1];                                     // channel 16 (wave >> 1) + l16, k = 32 s + 8 g
+    // phase-C roles: 16 output channels per wave (N2 = 128: wave; 64: wave >> 1) x NPT 16-pixel groups of the half
+    constexpr int NPT = N2 == 128 ? 4 : 2;
+    const int ct = N2 == 128 ? wave : (wave >> 1), pt0 = N2 == 128 ? 0 : 2 * (wave & 1);
+    bf16x8 w1f[HAS_NEXT ? 8 : 1];                                     // channel 16 ct + l16, k = 32 s + 8 g
     if constexpr (HAS_NEXT) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) w1f[s] = *reinterpret_cast<const bf16x8*>(a.w1n + (16 * (wave >> 1) + l16) * 256 + 32 * s + 8 * g);
+        for (int s = 0; s < 8; ++s) w1f[s] = *reinterpret_cast<const bf16x8*>(a.w1n + (16 * ct + l16) * 256 + 32 * s + 8 * g);
     }
 
     // XCD-aware tile order: the 32 workgroups of one XCD walk one contiguous range of tiles (halo rows hit the same L2)
@@ -290,28 +295,27 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                 *reinterpret_cast<uint4*>(out_ptr(mg, i, b, y0, x0)) = *reinterpret_cast<const uint4*>(s_t + (c >> 5) * TPITCH + (c & 31) * 16);
             }
             if constexpr (HAS_NEXT) {
-                // ---- C. next block's conv1 (1x1, K = 256): 16 channels (wave >> 1) x two 16-pixel groups
-                const int ct = wave >> 1;
-                f32x4 accc[2];
+                // ---- C. next block's conv1 (1x1, K = 256): 16 channels x NPT 16-pixel groups per wave
+                f32x4 accc[NPT];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) accc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < NPT; ++u) accc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(s_t + (16 * (2 * (wave & 1) + u) + l16) * TPITCH + 64 * s + 16 * g);
+                    for (int u = 0; u < NPT; ++u) {
+                        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(s_t + (16 * (pt0 + u) + l16) * TPITCH + 64 * s + 16 * g);
                         accc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], pv, accc[u], 0, 0, 0);
                     }
                 const int c0 = 16 * ct + 4 * g;
                 const float4 sc = *reinterpret_cast<const float4*>(s_ss + 640 + c0);
-                const float4 sh = *reinterpret_cast<const float4*>(s_ss + 704 + c0);
+                const float4 sh = *reinterpret_cast<const float4*>(s_ss + 768 + c0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int P = 64 * mg + 16 * (2 * (wave & 1) + u) + l16;
+                for (int u = 0; u < NPT; ++u) {
+                    const int P = 64 * mg + 16 * (pt0 + u) + l16;
                     uint2 o;
                     o.x = relu2bf(pack2bf(fmaf(accc[u][0], sc.x, sh.x), fmaf(accc[u][1], sc.y, sh.y)));
                     o.y = relu2bf(pack2bf(fmaf(accc[u][2], sc.z, sh.z), fmaf(accc[u][3], sc.w, sh.w)));
-                    *reinterpret_cast<uint2*>(a.y1n + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 64 + c0) = o;
+                    *reinterpret_cast<uint2*>(a.y1n + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * N2 + c0) = o;
                 }
             }
             if (mg == 0) __syncthreads();                                     // T free for the second half
@@ -353,11 +357,12 @@ extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, con
     const int grid = (int)(nt < num_cu ? nt : num_cu);
     hipStream_t s = (hipStream_t)stream;
     const bool res = residual != nullptr;
-    if (dual && next) hipLaunchKernelGGL((bneck_chain_kernel<false, true, true>), dim3(grid), dim3(NTHR), 0, s, a);
-    else if (dual) hipLaunchKernelGGL((bneck_chain_kernel<false, false, true>), dim3(grid), dim3(NTHR), 0, s, a);
-    else if (res && next) hipLaunchKernelGGL((bneck_chain_kernel<true, true, false>), dim3(grid), dim3(NTHR), 0, s, a);
-    else if (res) hipLaunchKernelGGL((bneck_chain_kernel<true, false, false>), dim3(grid), dim3(NTHR), 0, s, a);
-    else if (next) hipLaunchKernelGGL((bneck_chain_kernel<false, true, false>), dim3(grid), dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((bneck_chain_kernel<false, false, false>), dim3(grid), dim3(NTHR), 0, s, a);
+    const int n2 = next ? p->n_next : 0;
+    DIR_REQUIRE(n2 == 0 || n2 == 64 || n2 == 128, "dir_bottleneck_chain_forward: n_next must be 64 or 128");
+#define DIR_CHAIN(RES_, N2_, DUAL_) hipLaunchKernelGGL((bneck_chain_kernel<RES_, N2_, DUAL_>), dim3(grid), dim3(NTHR), 0, s, a)
+    if (dual) { if (n2 == 128) DIR_CHAIN(false, 128, true); else if (n2) DIR_CHAIN(false, 64, true); else DIR_CHAIN(false, 0, true); }
+    else if (res) { if (n2 == 128) DIR_CHAIN(true, 128, false); else if (n2) DIR_CHAIN(true, 64, false); else DIR_CHAIN(true, 0, false); }
+    else { if (n2 == 128) DIR_CHAIN(false, 128, false); else if (n2) DIR_CHAIN(false, 64, false); else DIR_CHAIN(false, 0, false); }
+#undef DIR_CHAIN
     return check_launch("dir_bottleneck_chain_forward");
 }

@@ -238,7 +238,7 @@ class BneckChainOp(object):
         self.params = _capi.BneckChainParams(_capi.ptr(c2.w), _capi.ptr(c2.scale), _capi.ptr(c2.shift), _capi.ptr(self.w3),
                                              _capi.ptr(self.s3), _capi.ptr(self.h3), n(self.w1n),
                                              n(c1n.scale if c1n is not None else None), n(c1n.shift if c1n is not None else None),
-                                             _capi.ptr(self.wd) if self.wd is not None else None)
+                                             _capi.ptr(self.wd) if self.wd is not None else None, c1n.cout if c1n is not None else 0)
 
     @staticmethod
     def applies(c2, c3, c1n, dtype, dual=None):
@@ -247,14 +247,14 @@ class BneckChainOp(object):
             ok = ok and c3.cin == 64 and c3.cout == 256 and c3.scale is not None
         else:
             ok = ok and dual.cin == 64 and dual.cin2 == 64 and dual.cout == 256 and dual.stride2 == 1 and dual.relu
-        return ok and (c1n is None or (c1n.cin == 256 and c1n.cout == 64 and c1n.kh == 1 and c1n.stride == 1))
+        return ok and (c1n is None or (c1n.cin == 256 and c1n.cout in (64, 128) and c1n.kh == 1 and c1n.stride == 1 and c1n.scale is not None))
 
     def __call__(self, y1, x):
         """x: the block input -- the identity residual, or (dual) the projection shortcut's source"""
         residual, x2 = (None, x) if self.dual is not None else (x, None)
         B, H, W, _ = y1.shape
         out = torch.empty(B, H, W, 256, device=y1.device, dtype=y1.dtype)
-        y1n = torch.empty(B, H, W, 64, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
+        y1n = torch.empty(B, H, W, self.c1n.cout, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -263,9 +263,10 @@ class BneckChainOp(object):
         if PROFILE is not None:
             e1.record()
             m, nx = B * H * W, self.c1n is not None
-            PROFILE.append(('conv_igemm<bf16,bf16>', 2.0 * m * (64 * 576 + 256 * 64 * (2 if x2 is not None else 1) + (64 * 256 if nx else 0)), e0, e1,
+            n2 = self.c1n.cout if nx else 0
+            PROFILE.append(('conv_igemm<bf16,bf16>', 2.0 * m * (64 * 576 + 256 * 64 * (2 if x2 is not None else 1) + n2 * 256), e0, e1,
                             'M=%d chain 3x3(64)+1x1(256)%s' % (m, '+1x1(64)' if nx else ''),
-                            (m * (64 + 256 * (2 if residual is not None else 1) + (64 if nx else 0) + (64 if x2 is not None else 0))
+                            (m * (64 + 256 * (2 if residual is not None else 1) + n2 + (64 if x2 is not None else 0))
                              + self.c2.w.numel() + self.w3.numel() * (2 if x2 is not None else 1) + (self.w1n.numel() if nx else 0)) * 2, self))
         return out, y1n
 
@@ -335,7 +336,7 @@ class BackboneOp(object):
         if self.bneck_chain:
             l1 = self.layers[0]
             for i, blk in enumerate(l1):
-                nxt = l1[i + 1]['c1'] if i + 1 < len(l1) else None
+                nxt = l1[i + 1]['c1'] if i + 1 < len(l1) else self.layers[1][0]['c1']      # last block: layer2's first conv1
                 if 'dual' in blk:
                     if BneckChainOp.applies(blk['c2'], None, nxt, dt, dual=blk['dual']):
                         blk['chain'] = BneckChainOp(blk['c2'], None, nxt, dual=blk['dual'])
@@ -368,17 +369,17 @@ class BackboneOp(object):
 
     def _layers(self, x):
         feats = []
+        y1 = None                                                    # conv1 output handed over by the previous block's chain kernel
         for blocks in self.layers:
-            y1 = None                                                # conv1 output handed over by the previous block's chain kernel
             for blk in blocks:
                 if 'chain' in blk:
                     x, y1 = blk['chain'](y1 if y1 is not None else blk['c1'](x), x)
                     continue
                 if 'dual' in blk:                                    # conv3 + projection shortcut in one launch
-                    x = blk['dual'](blk['c2'](blk['c1'](x)), x)
+                    x, y1 = blk['dual'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x), None
                 else:
                     idn = blk['ds'](x) if blk['ds'] is not None else x
-                    x = blk['c3'](blk['c2'](blk['c1'](x)), residual=idn)
+                    x, y1 = blk['c3'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), residual=idn), None
             feats.append(x)
         return feats
 

@@ -87,11 +87,12 @@ def bottleneck_chain(y1, w2, s2, h2, w3, s3, h3, residual=None, nxt=None, dual=N
     _capi.require_cuda(y1)
     B, H, W, _ = y1.shape
     out = torch.empty(B, H, W, 256, device=y1.device, dtype=torch.bfloat16)
-    y1n = torch.empty(B, H, W, 64, device=y1.device, dtype=torch.bfloat16) if nxt is not None else None
+    y1n = torch.empty(B, H, W, nxt[0].shape[0], device=y1.device, dtype=torch.bfloat16) if nxt is not None else None
     keep = [_capi.f32c(t) for t in (s2, h2, s3, h3)] + ([_capi.f32c(nxt[1]), _capi.f32c(nxt[2])] if nxt is not None else [])
     p = _capi.BneckChainParams(_capi.ptr(w2), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(w3), _capi.ptr(keep[2]), _capi.ptr(keep[3]),
                                _capi.ptr(nxt[0]) if nxt is not None else None, _capi.ptr(keep[4]) if nxt is not None else None,
-                               _capi.ptr(keep[5]) if nxt is not None else None, _capi.ptr(dual[1]) if dual is not None else None)
+                               _capi.ptr(keep[5]) if nxt is not None else None, _capi.ptr(dual[1]) if dual is not None else None,
+                               nxt[0].shape[0] if nxt is not None else 0)
     import ctypes as C
     _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(p), _capi.ptr(y1), _capi.ptr(residual) if residual is not None else None,
                                                          _capi.ptr(dual[0]) if dual is not None else None, _capi.ptr(out), _capi.ptr(y1n) if y1n is not None else None, B, H, W,

@@ -365,7 +365,7 @@ int dir_stem_pool_forward(const void* img, int img_dtype, const float* mean_host
 /* a1 (layer1 bottlenecks), bf16 mode: models/backbone/resnet.py:126-140 of block i -- conv2 3x3/s1/p1 (64->64) + bn2 + ReLU +
  * conv3 1x1 (64->256) + bn3 + identity + ReLU -- and, optionally, :122-124 of block i+1 -- conv1 1x1 (256->64) + bn1 + ReLU --
  * in one launch: the 64-channel intermediate and the next conv1's input never touch HBM (534 -> 334 MB per block at B = 64).
- * y1 [B,H,W,64] = ReLU(bn1(conv1(x))) of block i; residual [B,H,W,256] or NULL; out [B,H,W,256]; y1_next [B,H,W,64] or NULL
+ * y1 [B,H,W,64] = ReLU(bn1(conv1(x))) of block i; residual [B,H,W,256] or NULL; out [B,H,W,256]; y1_next [B,H,W,n_next] or NULL
  * (then w1n / scale1n / shift1n are ignored); all bf16 NHWC.  H % 8 == 0, W % 16 == 0.  Weights bf16: w2 [64][3][3][64]
  * (dir_conv2d_forward's packing), w3 [256][64], w1n [64][256]; scale / shift = folded eval BatchNorm, fp32, device pointers.
  * Same rounding points as the unfused dir_conv2d_forward sequence (bf16 operands, fp32 accumulation, bf16 y2 / out). */
@@ -376,6 +376,8 @@ typedef struct dir_bneck_chain_params {
     const void* wd;   /* projection shortcut (models/backbone/resnet.py:117-119), bf16 [256][64]: with x2 != NULL conv3's GEMM gets
                          64 more K from x2 [B,H,W,64] (the block input).  Both BatchNorm scales must then be folded into w3 / wd
                          rows, scale3 = 1 and shift3 = shift_bn3 + shift_bn_ds; `residual` must be NULL. */
+    int32_t n_next;   /* output channels of the fused next conv1: 64 (next layer1 block) or 128 (layer2's first block); y1_next is
+                         [B,H,W,n_next], w1n [n_next][256] */
 } dir_bneck_chain_params;
 int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
                                  void* y1_next, int B, int H, int W, void* stream);

@@ -125,6 +125,24 @@ def test_chain_projection_shortcut(nxt):
         assert relerr(y1n.float().cpu().numpy().transpose(0, 3, 1, 2), ref1) < 1.5e-2
 
 
+def test_chain_next_conv1_128_channels():
+    """last layer1 block -> layer2's first conv1 (256 -> 128)"""
+    B, H, W = 2, 16, 32
+    p = make('bneck.n128', B, H, W)
+    g = lambda n, shp, **k: synth.synth_input('bneck.n128.%s' % n, shp, SEED, **k)  # noqa: E731
+    w1 = bf16_round(g('w1b', (128, 256, 1, 1)) * np.float32(np.sqrt(2.0 / 256)))
+    s1, h1 = g('s1b', (128,), kind='uniform', lo=0.5, hi=1.5), g('h1b', (128,)) * np.float32(0.3)
+    ref_out, _ = oracle_chain(p, True, False)
+    ref1 = np.maximum(N.conv2d(ref_out.astype(np.float64), w1.astype(np.float64), None, 1, 0) * s1.reshape(1, -1, 1, 1)
+                      + h1.reshape(1, -1, 1, 1), 0)
+    out, y1n = F.bottleneck_chain(nhwc(p['y1']), F.pack_conv_weight(dev(p['w2']), BF), dev(p['s2']), dev(p['h2']),
+                                  dev(p['w3'].reshape(256, 64)).to(BF), dev(p['s3']), dev(p['h3']), residual=nhwc(p['res']),
+                                  nxt=(dev(w1.reshape(128, 256)).to(BF), dev(s1), dev(h1)))
+    assert tuple(y1n.shape) == (B, H, W, 128)
+    assert relerr(out.float().cpu().numpy().transpose(0, 3, 1, 2), ref_out) < 1e-2
+    assert relerr(y1n.float().cpu().numpy().transpose(0, 3, 1, 2), ref1) < 1.5e-2
+
+
 def test_chain_rejects_bad_shape():
     from dir_amd._capi import DirHipError
     p = make('bneck.bad', 1, 8, 16)
