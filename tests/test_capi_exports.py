@@ -23,7 +23,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), 'libdir_hip.so does not export ' + s
     lib.dir_abi_version.restype = ctypes.c_int
-    assert lib.dir_abi_version() == 6
+    hdr = open(os.path.join(ROOT, 'include', 'dir_hip.h')).read()
+    declared = int(re.search(r'#define\s+DIR_ABI_VERSION\s+(\d+)', hdr).group(1))
+    from dir_amd import _capi
+    assert lib.dir_abi_version() == declared == _capi.ABI_VERSION      # header, library and ctypes binding agree
 
 
 def test_binding_signatures_cover_header():
