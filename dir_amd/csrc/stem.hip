@@ -97,7 +97,13 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
     const int pcol = U8 ? jj / 3 : jj % PW;
     const int pc = U8 ? 2 - (jj - pcol * 3) : jj / PW;
     const bool pact = tid < 2 * EPR && pcol < PR;
-    int t = blockIdx.x;
+    // XCD-aware tile order (workgroup b runs on XCD b % 8): each XCD walks one contiguous range of tiles, so the halo rows /
+    // columns neighbouring tiles share are fetched into one L2 instead of eight
+    int t, tstep, tend;
+    if ((gridDim.x & 7) == 0 && a.ntiles % 8 == 0) {
+        const int per = a.ntiles >> 3;
+        t = (blockIdx.x & 7) * per + (blockIdx.x >> 3); tstep = gridDim.x >> 3; tend = ((blockIdx.x & 7) + 1) * per;
+    } else { t = blockIdx.x; tstep = gridDim.x; tend = a.ntiles; }
     // raw prefetch registers + validity bits: every load is unconditional (clamped address) so that all 20 are in flight
     // together, and nothing consumes them before the next tile's staging (no wait in front of the MFMA phase)
     typedef typename std::conditional<U8, unsigned char, float>::type raw_t;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
         for (int ky = 0; ky < 7; ++ky) bv[ky] = *reinterpret_cast<const bf16x8*>(bp + ky * PPITCH);
     };
 
-    if (t < a.ntiles) fetch(t);
+    if (t < tend) fetch(t);
     // all weight fragments landed before the tile loop: no vmcnt wait inside the MFMA phase, where the next tile's patch
     // loads are in flight
 #pragma unroll
@@ -154,11 +160,11 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) asm volatile("" ::"v"(wf[mt][ky]));
     __syncthreads();
-    if (t < a.ntiles) stage();
+    if (t < tend) stage();
     __syncthreads();
-    if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);
+    if (t + tstep < tend) fetch(t + tstep);
 
-    for (; t < a.ntiles; t += gridDim.x) {
+    for (; t < tend; t += tstep) {
         int b, py0, px0;
         tile_origin(t, b, py0, px0);
         // ---- conv pixels of this tile
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
         __syncthreads();                                          // s_conv complete, s_patch free
 
         // ---- next tile's patch -> LDS: its loads were issued a whole MFMA phase ago, the previous stores even earlier
-        if (t + (int)gridDim.x < a.ntiles) stage();
+        if (t + tstep < tend) stage();
 
         // ---- 3x3 / s2 max-pool of the tile, 8 channels (16 bytes) per item
         for (int it = tid; it < TP * TP * 8; it += NTHR) {
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
                 }
             *reinterpret_cast<uint4*>(a.y + ((((long long)b * a.Hp + py) * a.Wp + px) * 64 + cg * 8)) = o;
         }
-        if (t + 2 * (int)gridDim.x < a.ntiles) fetch(t + 2 * gridDim.x);   // lands during the next tile's MFMA phase
+        if (t + 2 * tstep < tend) fetch(t + 2 * tstep);   // lands during the next tile's MFMA phase
         __syncthreads();                                          // next patch complete, s_conv free
     }
 }
