@@ -9,6 +9,7 @@
 // the weight fragment prefetched k-major from L2; LayerNorm and softmax reduce with wavefront shuffles (one wave
 // per token / per attention row).  ~36 MFLOP per sample.
 #include "dir_common.h"
+#include <stdlib.h>
 #include "dir_mfma.h"
 
 namespace {
@@ -25,6 +26,7 @@ using dir::f32x4;
 struct SteArgs {
     dir_ste_params p;
     float* x_inout; const float* x_in; float* y; int nblocks;
+    long long* stamps;        // DIR_STE_STAMPS=1: s_memtime at every phase boundary of workgroup 0 (tuning aid, else NULL)
 };
 
 // sum over the 16 lanes of a DPP row (all lanes receive it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror.
@@ -39,6 +41,14 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // LayerNorm over the channel dim (two-pass variance like ATen): 16 lanes per token (channels li, li+16, ...), four
 // tokens per wave, 32 tokens per round.  s_out may alias s_in (every element is read and written by the same lane).
+constexpr int LDB = 136, LDHB = 264;  // bf16 activation rows (elements): [48][128 + 8], [48][256 + 8] -- 16-byte aligned rows whose
+                                      // 16-lane ds_read_b128 (row l & 15) tile all 64 banks
+__device__ __forceinline__ unsigned short f2bf_rne(float f) {
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{f, 0.f}, b2_t)) & 0xffffu);
+}
+template <bool BF16OUT = false>
 __device__ __forceinline__ void layernorm_tokens(const float* s_in, float* s_out, const float* w, const float* b,
                                                  float eps, int wave, int lane) {
     const int li = lane & 15;
@@ -60,7 +70,11 @@ __device__ __forceinline__ void layernorm_tokens(const float* s_in, float* s_out
         const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / D) + eps);
         if (live) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s_out[t * LDX + li + 16 * e] = v[e] * rstd * wv[e] + bv[e];
+            for (int e = 0; e < 8; ++e) {
+                const float o = v[e] * rstd * wv[e] + bv[e];
+                if constexpr (BF16OUT) reinterpret_cast<unsigned short*>(s_out)[t * LDB + li + 16 * e] = f2bf_rne(o);   // the Linear's operand
+                else s_out[t * LDX + li + 16 * e] = o;
+            }
         }
     }
 }
@@ -142,6 +156,59 @@ __device__ __forceinline__ void linear_mfma_bf16(const float* s_in, int ldi, con
     }
 }
 
+// bf16 mode, activations already rounded to bf16 in LDS (by the producer: LayerNorm / attention output / GELU): every A fragment
+// is ONE 16-byte LDS read instead of four 8-byte fp32 reads + conversion, and it is shared by all of the wave's output tiles
+// (tile i = wave + 8 i).  Measured with DIR_STE_STAMPS: the fp32-operand version spent 1.1 us per 16-column tile re-reading the
+// whole [48][K] fp32 activation matrix -- LDS bandwidth, not the weights' L2 latency, bounded the Linears.  Same values reach
+// the matrix cores (one round-to-nearest-even of the same fp32 numbers), so results are bit-identical.
+template <int K, int NTW>
+struct WFrag { bf16x8_t bv[NTW][K / 32]; float bb[NTW]; };
+// all global loads of the wave's weight tiles + bias; issued one phase before gemm_bf16_act needs them (measured with
+// DIR_STE_STAMPS: loaded at the point of use, the first-touch latency of a Linear's weights -- ~2 us, the slowest wave's more --
+// was waited for by the whole workgroup at the next barrier)
+template <int K, int NTW>
+__device__ __forceinline__ void load_wfrag(const float* Wf, const float* __restrict__ bias, int N, int wave, int lane, WFrag<K, NTW>& w) {
+    const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(Wf);
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int n = min(wave + NWAVES * i, N / 16 - 1) * 16 + li;
+#pragma unroll
+        for (int kk = 0; kk < K / 32; ++kk) w.bv[i][kk] = *reinterpret_cast<const bf16x8_t*>(W + (long long)n * K + kk * 32 + lk * 8);
+        w.bb[i] = bias[n];
+    }
+}
+template <int K, int NTW, typename F>
+__device__ __forceinline__ void gemm_bf16_act(const unsigned short* s_a, int lda, const WFrag<K, NTW>& w, int N, int wave, int lane, F store) {
+    const int li = lane & 15, lk = lane >> 4;
+    f32x4 acc[NTW][3];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < K / 32; ++kk)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const bf16x8_t av = *reinterpret_cast<const bf16x8_t*>(s_a + (m * 16 + li) * lda + kk * 32 + lk * 8);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, w.bv[i][kk], acc[i][m], 0, 0, 0);
+        }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int nt = wave + NWAVES * i;
+        if (nt < N / 16) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = m * 16 + lk * 4 + r;
+                    if (t < NT) store(t, nt * 16 + li, acc[i][m][r] + w.bb[i]);
+                }
+        }
+    }
+}
+
 // WBF16: Linear weights are bf16 [out][in] (dir_ste_params.weight_dtype == DIR_DT_BF16), else fp32 k-major [in][out]
 template <int K, bool WBF16, typename F>
 __device__ __forceinline__ void linear(const float* s_in, int ldi, const float* W, const float* bias, int N, int wave, int lane, F store) {
@@ -156,7 +223,14 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
     float* s_n = s_x + NTP * LDX;         // [48][130] LayerNorm output / attention output
     float* s_big = s_n + NTP * LDX;       // [48][386] qkv, later [48][258] MLP hidden
     float* s_p = s_big + NTP * LDQ;       // [4][48][44] attention scores / probabilities (padding: zero columns 42,43)
+    // bf16 mode: the Linear operands live as bf16 -- s_n's space holds [48][136] bf16 (LayerNorm / attention output), the MLP hidden
+    // [48][264] bf16 sits at the start of s_big (free once the attention has consumed q, k, v)
+    unsigned short* s_nb = reinterpret_cast<unsigned short*>(s_n);
+    unsigned short* s_hb = reinterpret_cast<unsigned short*>(s_big);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && b == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
 
     for (int i = tid; i < (NTP - NT) * LDX; i += NTHREADS) { s_x[NT * LDX + i] = 0.f; s_n[NT * LDX + i] = 0.f; }
     for (int i = tid; i < (NTP - NT) * LDQ; i += NTHREADS) s_big[NT * LDQ + i] = 0.f;
@@ -167,15 +241,28 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         s_x[(i >> 7) * LDX + (i & 127)] = v;
         if (a.x_inout) a.x_inout[(long long)b * NT * D + i] = v;        // the reference mutates its input in place
     }
-    __syncthreads();
+    __syncthreads(); stamp();
 
+    // bf16 mode: each Linear's weight fragments are requested one phase ahead (qkv's before LayerNorm 1 / during the previous
+    // block's fc2, proj's before the attention, fc1's before LayerNorm 2, fc2's before fc1's GELU epilogue)
+    WFrag<D, WBF16 ? 3 : 1> wq;
+    WFrag<D, 1> wp, wh;
+    WFrag<D, WBF16 ? 2 : 1> w1;
+    WFrag<256, 1> w2;
+    if constexpr (WBF16) {
+        if (a.nblocks > 0) load_wfrag<D, 3>(a.p.blocks[0].qkv_wt, a.p.blocks[0].qkv_b, 384, wave, lane, wq);
+    }
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const dir_ste_block& P = a.p.blocks[blk];
         // ---- attention branch
-        layernorm_tokens(s_x, s_n, P.ln1_w, P.ln1_b, 1e-6f, wave, lane);
-        __syncthreads();
-        linear<D, WBF16>(s_n, LDX, P.qkv_wt, P.qkv_b, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
-        __syncthreads();
+        layernorm_tokens<WBF16>(s_x, s_n, P.ln1_w, P.ln1_b, 1e-6f, wave, lane);
+        __syncthreads(); stamp();
+        if constexpr (WBF16) {
+            load_wfrag<D, 1>(P.proj_wt, P.proj_b, D, wave, lane, wp);
+            gemm_bf16_act<D, 3>(s_nb, LDB, wq, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
+        }
+        else linear<D, WBF16>(s_n, LDX, P.qkv_wt, P.qkv_b, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
+        __syncthreads(); stamp();
         // scores S = q k^T * 32^-0.5 per head on the matrix cores.  qkv column layout is (3, heads, 32) (mixSTE.py:78):
         // q = [0,128), k = [128,256), v = [256,384).  36 tiles of 16x16 (4 heads x 3 x 3), K = 32.
         const float scale = 0.17677669529663687f;                       // 32 ** -0.5
@@ -196,18 +283,34 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
                 }
             }
         }
-        __syncthreads();
-        if (tid < HEADS * NT) {                                         // softmax: one thread per row, row in registers
-            float* pr = s_p + ((tid / NT) * NTP + tid % NT) * LDP;
-            float v[NT], mx = -INFINITY, sum = 0.f;
+        __syncthreads(); stamp();
+        // softmax: four lanes per row (elements q, q + 4, ...; max / sum through two DPP quad permutes), 128 rows per pass --
+        // every wave works (one thread per row kept 5 of 8 waves idle for ~3 us per block)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { v[j] = pr[j]; mx = fmaxf(mx, v[j]); }
+        for (int pass = 0; pass < 2; ++pass) {
+            const int row = pass * 128 + (tid >> 2), q = tid & 3;
+            const bool live = row < HEADS * NT;
+            float* pr = s_p + (((live ? row : 0) / NT) * NTP + (live ? row : 0) % NT) * LDP;
+            float v[11], mx = -INFINITY, sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { v[j] = expf(v[j] - mx); sum += v[j]; }
+            for (int e = 0; e < 11; ++e) {
+                const int j = q + 4 * e;
+                v[e] = j < NT ? pr[j] : -INFINITY;
+                mx = fmaxf(mx, v[e]);
+            }
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));
+            mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) pr[j] = v[j] / sum;
+            for (int e = 0; e < 11; ++e) { v[e] = q + 4 * e < NT ? expf(v[e] - mx) : 0.f; sum += v[e]; }
+            sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0xB1, 0xF, 0xF, true));
+            sum += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sum), 0x4E, 0xF, 0xF, true));
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 11; ++e)
+                    if (q + 4 * e < NT) pr[q + 4 * e] = v[e] / sum;
+            }
         }
-        __syncthreads();
+        __syncthreads(); stamp();
         // o = P v, heads concatenated (mixSTE.py:94): 24 tiles (4 heads x 3 row tiles x 2 column tiles), K = 44
         // (probability columns 42,43 and v rows 42..47 are zero)
         {
@@ -223,31 +326,55 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = mt * 16 + lk * 4 + r;
-                    if (t < NT) s_n[t * LDX + h * HD + nt * 16 + li] = acc[r];
+                    if (t < NT) {
+                        if constexpr (WBF16) s_nb[t * LDB + h * HD + nt * 16 + li] = f2bf_rne(acc[r]);
+                        else s_n[t * LDX + h * HD + nt * 16 + li] = acc[r];
+                    }
                 }
             }
         }
-        __syncthreads();
-        linear<D, WBF16>(s_n, LDX, P.proj_wt, P.proj_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
-        __syncthreads();
+        __syncthreads(); stamp();
+        auto add_x = [&](int t, int n, float v) { s_x[t * LDX + n] += v; };
+        if constexpr (WBF16) {
+            load_wfrag<D, 2>(P.fc1_wt, P.fc1_b, 256, wave, lane, w1);
+            gemm_bf16_act<D, 1>(s_nb, LDB, wp, D, wave, lane, add_x);
+        }
+        else linear<D, WBF16>(s_n, LDX, P.proj_wt, P.proj_b, D, wave, lane, add_x);
+        __syncthreads(); stamp();
         // ---- MLP branch
-        layernorm_tokens(s_x, s_n, P.ln2_w, P.ln2_b, 1e-6f, wave, lane);
-        __syncthreads();
-        linear<D, WBF16>(s_n, LDX, P.fc1_wt, P.fc1_b, 256, wave, lane, [&](int t, int n, float v) {
-            s_big[t * LDH + n] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));          // exact GELU
-        });
-        __syncthreads();
-        linear<256, WBF16>(s_big, LDH, P.fc2_wt, P.fc2_b, D, wave, lane, [&](int t, int n, float v) { s_x[t * LDX + n] += v; });
-        __syncthreads();
+        layernorm_tokens<WBF16>(s_x, s_n, P.ln2_w, P.ln2_b, 1e-6f, wave, lane);
+        __syncthreads(); stamp();
+        if constexpr (WBF16) {
+            load_wfrag<256, 1>(P.fc2_wt, P.fc2_b, D, wave, lane, w2);
+            gemm_bf16_act<D, 2>(s_nb, LDB, w1, 256, wave, lane, [&](int t, int n, float v) {
+                s_hb[t * LDHB + n] = f2bf_rne(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));          // exact GELU, rounded once for fc2
+            });
+            __syncthreads(); stamp();
+            if (blk + 1 < a.nblocks) load_wfrag<D, 3>(a.p.blocks[blk + 1].qkv_wt, a.p.blocks[blk + 1].qkv_b, 384, wave, lane, wq);
+            else load_wfrag<D, 1>(a.p.head_wt, a.p.head_b, 64, wave, lane, wh);
+            gemm_bf16_act<256, 1>(s_hb, LDHB, w2, D, wave, lane, add_x);
+        } else {
+            linear<D, WBF16>(s_n, LDX, P.fc1_wt, P.fc1_b, 256, wave, lane, [&](int t, int n, float v) {
+                s_big[t * LDH + n] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));          // exact GELU
+            });
+            __syncthreads(); stamp();
+            linear<256, WBF16>(s_big, LDH, P.fc2_wt, P.fc2_b, D, wave, lane, add_x);
+        }
+        __syncthreads(); stamp();
         // ---- spatial_norm after every block (mixSTE.py:200)
         layernorm_tokens(s_x, s_x, a.p.snorm_w, a.p.snorm_b, 1e-6f, wave, lane);      // in place
-        __syncthreads();
+        __syncthreads(); stamp();
     }
     // ---- head: LayerNorm(eps 1e-5) + Linear 128 -> 64 (mixSTE.py:187-190)
-    layernorm_tokens(s_x, s_n, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, wave, lane);
-    __syncthreads();
+    layernorm_tokens<WBF16>(s_x, s_n, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, wave, lane);
+    __syncthreads(); stamp();
     float* y = a.y + (long long)b * NT * 64;
-    linear<D, WBF16>(s_n, LDX, a.p.head_wt, a.p.head_b, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    if constexpr (WBF16) {
+        if (a.nblocks == 0) load_wfrag<D, 1>(a.p.head_wt, a.p.head_b, 64, wave, lane, wh);
+        gemm_bf16_act<D, 1>(s_nb, LDB, wh, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    }
+    else linear<D, WBF16>(s_n, LDX, a.p.head_wt, a.p.head_b, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    stamp();
 }
 
 }  // namespace
@@ -265,8 +392,20 @@ extern "C" int dir_ste_forward(const dir_ste_params* p, const float* x, float* x
     }
     SteArgs a;
     a.p = *p; a.x_in = x; a.x_inout = x_pos_out; a.y = y; a.nblocks = p->num_blocks;
+    a.stamps = nullptr;
+    static const bool want_stamps = getenv("DIR_STE_STAMPS") != nullptr;
+    if (want_stamps && hipMalloc((void**)&a.stamps, 64 * sizeof(long long)) != hipSuccess) a.stamps = nullptr;
     DIR_REQUIRE(p->weight_dtype == DIR_DT_F32 || p->weight_dtype == DIR_DT_BF16, "dir_ste_forward: weight_dtype must be f32 or bf16");
     if (p->weight_dtype == DIR_DT_BF16) hipLaunchKernelGGL(ste_kernel<true>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(ste_kernel<false>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    if (a.stamps) {                                       // tuning aid: phase durations of workgroup 0 in 100 MHz ticks -> stderr
+        long long h[64] = {0};
+        hipStreamSynchronize((hipStream_t)stream);
+        hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
+        hipFree(a.stamps);
+        fprintf(stderr, "ste stamps (us since start):");
+        for (int i = 1; i < 64 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) * 0.01);
+        fprintf(stderr, "\n");
+    }
     return dir::check_launch("dir_ste_forward");
 }
