@@ -215,23 +215,45 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
     const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
     float wgt[5]; int nidx[5]; int deg = 0;
     if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
-    // ---- stage this node's input rows; layers >= 1 finish the previous layer here (mix + bias + BN + ReLU)
-    for (int i = tid; i < PG_ROWS * 128; i += 256) {
-        const int bb = i >> 7, k = i & 127;
-        float v = 0.f;
-        if (bb < nb) {
-            const long long b = b0 + bb;
-            if (!a.h_prev) v = a.x_in[(b * NJ + j) * 128 + k];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        if (t >= deg) { wgt[t] = 0.f; nidx[t] = j; }                           // padded to 5 neighbours: every gather below is unconditional
+    // ---- stage this node's input rows; layers >= 1 finish the previous layer here (mix + bias + BN + ReLU).
+    //      thread = (column k, row parity): rows (tid >> 7) + 2 it.  All 6 x 8 gathers of a thread are independent loads from
+    //      clamped addresses (issued together: one L2 round trip instead of a chain of conditional ones); out-of-range rows are
+    //      zeroed at the LDS write
+    {
+        const int k = tid & 127;
+        float pb = 0.f, ps = 1.f, pn = 0.f;
+        if (a.h_prev) { pb = a.bias_prev[k]; ps = a.bns_prev[k]; pn = a.bnb_prev[k]; }
+        constexpr int NIT = PG_ROWS * 128 / 256;
+        float self[NIT], nb_v[NIT][5];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int bb = (tid >> 7) + 2 * it;
+            const long long b = b0 + min(bb, nb - 1);
+            if (!a.h_prev) self[it] = a.x_in[(b * NJ + j) * 128 + k];
             else {
                 const float* hb = a.h_prev + b * NJ * 256;
-                float acc = 0.f;
-                for (int t = 0; t < deg; ++t) acc = fmaf(wgt[t], hb[nidx[t] * 256 + 128 + k], acc);
-                v = hb[j * 256 + k] + acc + a.bias_prev[k];                     // output_0 + output_1 + bias
-                v = fmaf(v, a.bns_prev[k], a.bnb_prev[k]);                      // BN1d (eval)
-                if (a.relu_prev) v = fmaxf(v, 0.f);
+                self[it] = hb[j * 256 + k];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) nb_v[it][t] = hb[nidx[t] * 256 + 128 + k];
             }
         }
-        s_x[bb * PG_LD + k] = v;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int bb = (tid >> 7) + 2 * it;
+            float v = self[it];
+            if (a.h_prev) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) acc = fmaf(wgt[t], nb_v[it][t], acc);  // padded terms add +0 (same sum as the deg-term chain)
+                v = v + acc + pb;                                               // output_0 + output_1 + bias
+                v = fmaf(v, ps, pn);                                            // BN1d (eval)
+                if (a.relu_prev) v = fmaxf(v, 0.f);
+            }
+            s_x[bb * PG_LD + k] = bb < nb ? v : 0.f;
+        }
     }
     __syncthreads();
     const int n0 = slice * 64 + wave * 16, li = lane & 15, lk = lane >> 4;
