@@ -100,15 +100,38 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
     for (int i = tid; i < (GT_ROWS - NJ) * LDS_H; i += 256) s_hid[NJ * LDS_H + i] = 0.f;
     __syncthreads();
     const T* fb = (const T*)a.feat + (long long)b * S * S * a.fcs + a.fco;
-    for (int i = tid; i < NJ * C; i += 256) {
-        const int j = i / C, c = i - j * C;
-        float acc = 0.f;
+    // bilinear gather: out-of-range taps carry weight 0 and a clamped (valid) pixel, so the 4 loads of an element -- and, unrolled,
+    // of several elements -- are unconditional and in flight together
+    if (C == 256) {                                                      // thread = channel, 21 joints x 4 taps
+        const int c = tid;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int pix = s_i[j * 4 + t];
-            if (pix >= 0) acc += ld<T>(fb + (long long)pix * a.fcs + c) * s_w[j * 4 + t];
+        for (int j0 = 0; j0 < NJ; j0 += 7) {
+            float tv[7][4];
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) tv[jj][t] = ld<T>(fb + (long long)max(s_i[(j0 + jj) * 4 + t], 0) * a.fcs + c);
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (s_i[(j0 + jj) * 4 + t] >= 0) acc += tv[jj][t] * s_w[(j0 + jj) * 4 + t];   // same skip rule / order as before
+                }
+                s_samp[(j0 + jj) * LDS_S + c] = acc;
+            }
         }
-        s_samp[j * LDS_S + c] = acc;
+    } else {
+        for (int i = tid; i < NJ * C; i += 256) {
+            const int j = i / C, c = i - j * C;
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pix = s_i[j * 4 + t];
+                if (pix >= 0) acc += ld<T>(fb + (long long)pix * a.fcs + c) * s_w[j * 4 + t];
+            }
+            s_samp[j * LDS_S + c] = acc;
+        }
     }
     __syncthreads();
     const int li = lane & 15, lk = lane >> 4;
@@ -316,8 +339,12 @@ __global__ __launch_bounds__(128) void pgcn_mix_kernel(MixArgs args) {
     float wgt[5]; int nidx[5]; int deg;
     edge_softmax_row(a.e1, j, wgt, nidx, deg);
     const float* hb = a.h + (long long)b * NJ * 256;
+    float nv[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) nv[t] = hb[(t < deg ? nidx[t] : j) * 256 + 128 + k];          // unconditional: all in flight together
     float acc = 0.f;
-    for (int t = 0; t < deg; ++t) acc = fmaf(wgt[t], hb[nidx[t] * 256 + 128 + k], acc);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc = t < deg ? fmaf(wgt[t], nv[t], acc) : acc;
     float v = hb[j * 256 + k] + acc + a.bias[k];
     v = fmaf(v, a.bns[k], a.bnb[k]);
     if (a.relu) v = fmaxf(v, 0.f);
