@@ -224,19 +224,29 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
     const int HW = a.HW, C = a.C, Ch = a.Ch;
     const T* c4 = (const T*)a.c4 + (long long)b * HW * C;
     // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232); one wave per (hand, pixel) dot product
-    for (int o = wave; o < 2 * HW; o += 8) {
-        const int s = o / HW, px = o - s * HW;
-        const T* h = (const T*)a.h[s] + ((long long)b * HW + px) * a.hcs;
-        const float* w = a.p.attn_w[s];
-        float acc = 0.f;
+    //    (four dot products per pass: their loads are issued together instead of one L2 round trip per (hand, pixel))
+    for (int o0 = wave * 4; o0 < 2 * HW; o0 += 32) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = lane * VN; k < Ch; k += 64 * VN) {
-            float v[VN];
-            Vec<T>::load(h + k, v);
+            float v[4][VN], wv[4][VN];
 #pragma unroll
-            for (int e = 0; e < VN; ++e) acc = fmaf(v[e], w[k + e], acc);
+            for (int u = 0; u < 4; ++u) {
+                const int o = min(o0 + u, 2 * HW - 1), s = o / HW, px = o - s * HW;
+                Vec<T>::load((const T*)a.h[s] + ((long long)b * HW + px) * a.hcs + k, v[u]);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) wv[u][e] = a.p.attn_w[s][k + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[u] = fmaf(v[u][e], wv[u][e], acc[u]);
         }
-        acc = dir::wave_sum(acc);
-        if (lane == 0) s_attn[o] = 1.f / (1.f + expf(-(acc + a.p.attn_b[s])));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t = dir::wave_sum(acc[u]);
+            const int o = o0 + u;
+            if (lane == 0 && o < 2 * HW) s_attn[o] = 1.f / (1.f + expf(-(t + a.p.attn_b[o / HW])));
+        }
     }
     __syncthreads();
     if (tid < 2) {
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
         float fl[VN], fr[VN], fm[VN];
 #pragma unroll
         for (int e = 0; e < VN; ++e) { fl[e] = 0.f; fr[e] = 0.f; fm[e] = 0.f; }
-#pragma unroll 8
+#pragma unroll 16
         for (int px = 0; px < HW; ++px) {
             float v[VN];
             Vec<T>::load(c4 + (long long)px * C + c, v);
@@ -273,7 +283,15 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
         const float* f = s_feat + (o >> 6) * C + ks * kq;
         const float* w = a.p.mano_wt + (long long)(ks * kq) * 128 + o;
         float acc = 0.f;
-        for (int k0 = 0; k0 < kq; k0 += 16) {
+        int k0 = 0;
+        for (; k0 + 64 <= kq; k0 += 64) {                           // 64 loads in flight per thread (was 16: 32 L2 round trips at C = 2048)
+            float wv[64];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) wv[u] = w[(k0 + u) * 128];
+#pragma unroll
+            for (int u = 0; u < 64; ++u) acc = fmaf(f[k0 + u], wv[u], acc);
+        }
+        for (; k0 < kq; k0 += 16) {                                 // kq % 16 == 0 (C % 64 == 0)
             float wv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) wv[u] = w[(k0 + u) * 128];

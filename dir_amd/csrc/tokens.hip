@@ -378,20 +378,24 @@ __global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
         const float* in = s_in[o >> 6] + ks * 352;
         const float* w = a.p.mano_wt + (long long)(ks * 352) * 128 + o;
         float acc = 0.f;
-        for (int k0 = 0; k0 < 352; k0 += 16) {
-            float wv[16];
+        for (int k0 = 0; k0 < 352; k0 += 88) {                      // 88 loads in flight per thread: 4 L2 round trips (was 22)
+            float wv[88];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) wv[u] = w[(k0 + u) * 128];
+            for (int u = 0; u < 88; ++u) wv[u] = w[(k0 + u) * 128];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc = fmaf(in[k0 + u], wv[u], acc);
+            for (int u = 0; u < 88; ++u) acc = fmaf(in[k0 + u], wv[u], acc);
         }
         s_part[ks][o] = acc;
     }
     {   // Linear(2691 -> 3) (models/dir.py:347-348) over cat(tokL, tokR, prev_offset)
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-        for (int k = tid; k < 2688; k += 512) {
-            const float x = k < 1344 ? s_in[0][k] : s_in[1][k - 1344];
-            p0 = fmaf(x, a.p.off_w[k], p0); p1 = fmaf(x, a.p.off_w[2691 + k], p1); p2 = fmaf(x, a.p.off_w[2 * 2691 + k], p2);
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {                            // 2688 = 5.25 x 512: unrolled, all weight loads independent
+            const int k = tid + 512 * it;
+            if (k < 2688) {
+                const float x = k < 1344 ? s_in[0][k] : s_in[1][k - 1344];
+                p0 = fmaf(x, a.p.off_w[k], p0); p1 = fmaf(x, a.p.off_w[2691 + k], p1); p2 = fmaf(x, a.p.off_w[2 * 2691 + k], p2);
+            }
         }
         p0 = dir::wave_sum(p0); p1 = dir::wave_sum(p1); p2 = dir::wave_sum(p2);
         if (lane == 0) { s_red[wave][0] = p0; s_red[wave][1] = p1; s_red[wave][2] = p2; }
