@@ -134,12 +134,12 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     }
     __syncthreads();
 
-    // ---- pose blend shapes (manolayer.py:186-187): 584 threads x float4 of the k-major table, 9 loads in flight
+    // ---- pose blend shapes (manolayer.py:186-187): one float4 column of the k-major table per thread, 27 loads in flight (5 L2 round trips)
     if (f_lo / 4 + tid < (f_hi + 3) / 4) {
         const int c4 = f_lo / 4 + tid;                    // float4 column (f_lo is a multiple of 12)
         const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + c4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 9
+#pragma unroll 27
         for (int k = 0; k < 135; ++k) {
             const float4 p = pd[k * (NV3P / 4)];
             const float w = s_pm[k];
