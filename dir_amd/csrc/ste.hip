@@ -48,6 +48,17 @@ __device__ __forceinline__ unsigned short f2bf_rne(float f) {
     typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
     return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{f, 0.f}, b2_t)) & 0xffffu);
 }
+// bf16 mode only: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding of the GELU output that
+// follows) -- ocml's erff cost 3 us per block in fc1's epilogue (DIR_STE_STAMPS).  The fp32 mode keeps erff.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x), t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.f - p * t * __expf(-ax * ax);
+    return copysignf(e, x);
+}
 template <bool BF16OUT = false>
 __device__ __forceinline__ void layernorm_tokens(const float* s_in, float* s_out, const float* w, const float* b,
                                                  float eps, int wave, int lane) {
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         if constexpr (WBF16) {
             load_wfrag<256, 1>(P.fc2_wt, P.fc2_b, D, wave, lane, w2);
             gemm_bf16_act<D, 2>(s_nb, LDB, w1, 256, wave, lane, [&](int t, int n, float v) {
-                s_hb[t * LDHB + n] = f2bf_rne(0.5f * v * (1.f + erff(v * 0.70710678118654752f)));          // exact GELU, rounded once for fc2
+                s_hb[t * LDHB + n] = f2bf_rne(0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)));       // GELU, rounded once for fc2
             });
             __syncthreads(); stamp();
             if (blk + 1 < a.nblocks) load_wfrag<D, 3>(a.p.blocks[blk + 1].qkv_wt, a.p.blocks[blk + 1].qkv_b, 384, wave, lane, wq);
