@@ -14,6 +14,27 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace dir
 
+namespace dir {
+long long* stamps_begin(const char* kernel) {
+    const char* e = getenv("DIR_STAMPS");
+    if (!e || strcmp(e, kernel) != 0) return nullptr;
+    long long* buf = nullptr;
+    if (hipMalloc((void**)&buf, MAX_STAMPS * sizeof(long long)) != hipSuccess) return nullptr;
+    if (hipMemset(buf, 0, MAX_STAMPS * sizeof(long long)) != hipSuccess) { (void)hipFree(buf); return nullptr; }
+    return buf;
+}
+void stamps_end(const char* kernel, long long* buf, hipStream_t s) {
+    if (!buf) return;
+    long long h[MAX_STAMPS] = {0};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(buf);
+    fprintf(stderr, "%s stamps (ticks since start):", kernel);
+    for (int i = 1; i < MAX_STAMPS && h[i]; ++i) fprintf(stderr, " %lld", h[i] - h[0]);
+    fprintf(stderr, "\n");
+}
+}  // namespace dir
+
 extern "C" int dir_abi_version(void) { return DIR_ABI_VERSION; }
 
 extern "C" const char* dir_last_error(void) { return dir::g_err; }

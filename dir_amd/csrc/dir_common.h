@@ -28,6 +28,13 @@ inline int check_launch(const char* what) {
         }                               \
     } while (0)
 
+// Tuning aid shared by the latency-bound token kernels: with DIR_STAMPS=<kernel name> in the environment the launcher passes a
+// device buffer and thread 0 of workgroup 0 writes s_memtime at every phase boundary; the launcher then prints the phase
+// durations (ticks of the shader clock counter) to stderr.  NULL (the normal case) costs one uniform branch per stamp.
+long long* stamps_begin(const char* kernel);                       // NULL unless DIR_STAMPS names this kernel
+void stamps_end(const char* kernel, long long* buf, hipStream_t s);
+constexpr int MAX_STAMPS = 64;
+
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -9,7 +9,6 @@
 // the weight fragment prefetched k-major from L2; LayerNorm and softmax reduce with wavefront shuffles (one wave
 // per token / per attention row).  ~36 MFLOP per sample.
 #include "dir_common.h"
-#include <stdlib.h>
 #include "dir_mfma.h"
 
 namespace {
@@ -26,7 +25,7 @@ using dir::f32x4;
 struct SteArgs {
     dir_ste_params p;
     float* x_inout; const float* x_in; float* y; int nblocks;
-    long long* stamps;        // DIR_STE_STAMPS=1: s_memtime at every phase boundary of workgroup 0 (tuning aid, else NULL)
+    long long* stamps;        // DIR_STAMPS=ste: s_memtime at every phase boundary of workgroup 0 (tuning aid, else NULL)
 };
 
 // sum over the 16 lanes of a DPP row (all lanes receive it): quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror.
@@ -49,7 +48,7 @@ __device__ __forceinline__ unsigned short f2bf_rne(float f) {
     return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(f2_t{f, 0.f}, b2_t)) & 0xffffu);
 }
 // bf16 mode only: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 rounding of the GELU output that
-// follows) -- ocml's erff cost 3 us per block in fc1's epilogue (DIR_STE_STAMPS).  The fp32 mode keeps erff.
+// follows) -- ocml's erff cost 3 us per block in fc1's epilogue (DIR_STAMPS=ste).  The fp32 mode keeps erff.
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x), t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -169,13 +168,13 @@ __device__ __forceinline__ void linear_mfma_bf16(const float* s_in, int ldi, con
 
 // bf16 mode, activations already rounded to bf16 in LDS (by the producer: LayerNorm / attention output / GELU): every A fragment
 // is ONE 16-byte LDS read instead of four 8-byte fp32 reads + conversion, and it is shared by all of the wave's output tiles
-// (tile i = wave + 8 i).  Measured with DIR_STE_STAMPS: the fp32-operand version spent 1.1 us per 16-column tile re-reading the
+// (tile i = wave + 8 i).  Measured with DIR_STAMPS=ste: the fp32-operand version spent 1.1 us per 16-column tile re-reading the
 // whole [48][K] fp32 activation matrix -- LDS bandwidth, not the weights' L2 latency, bounded the Linears.  Same values reach
 // the matrix cores (one round-to-nearest-even of the same fp32 numbers), so results are bit-identical.
 template <int K, int NTW>
 struct WFrag { bf16x8_t bv[NTW][K / 32]; float bb[NTW]; };
 // all global loads of the wave's weight tiles + bias; issued one phase before gemm_bf16_act needs them (measured with
-// DIR_STE_STAMPS: loaded at the point of use, the first-touch latency of a Linear's weights -- ~2 us, the slowest wave's more --
+// DIR_STAMPS=ste: loaded at the point of use, the first-touch latency of a Linear's weights -- ~2 us, the slowest wave's more --
 // was waited for by the whole workgroup at the next barrier)
 template <int K, int NTW>
 __device__ __forceinline__ void load_wfrag(const float* Wf, const float* __restrict__ bias, int N, int wave, int lane, WFrag<K, NTW>& w) {
@@ -403,20 +402,10 @@ extern "C" int dir_ste_forward(const dir_ste_params* p, const float* x, float* x
     }
     SteArgs a;
     a.p = *p; a.x_in = x; a.x_inout = x_pos_out; a.y = y; a.nblocks = p->num_blocks;
-    a.stamps = nullptr;
-    static const bool want_stamps = getenv("DIR_STE_STAMPS") != nullptr;
-    if (want_stamps && hipMalloc((void**)&a.stamps, 64 * sizeof(long long)) != hipSuccess) a.stamps = nullptr;
+    a.stamps = dir::stamps_begin("ste");
     DIR_REQUIRE(p->weight_dtype == DIR_DT_F32 || p->weight_dtype == DIR_DT_BF16, "dir_ste_forward: weight_dtype must be f32 or bf16");
     if (p->weight_dtype == DIR_DT_BF16) hipLaunchKernelGGL(ste_kernel<true>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(ste_kernel<false>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
-    if (a.stamps) {                                       // tuning aid: phase durations of workgroup 0 in 100 MHz ticks -> stderr
-        long long h[64] = {0};
-        hipStreamSynchronize((hipStream_t)stream);
-        hipMemcpy(h, a.stamps, sizeof(h), hipMemcpyDeviceToHost);
-        hipFree(a.stamps);
-        fprintf(stderr, "ste stamps (us since start):");
-        for (int i = 1; i < 64 && h[i]; ++i) fprintf(stderr, " %.2f", (double)(h[i] - h[0]) * 0.01);
-        fprintf(stderr, "\n");
-    }
+    dir::stamps_end("ste", a.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_ste_forward");
 }

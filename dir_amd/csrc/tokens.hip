@@ -40,31 +40,30 @@ struct GridArgs {
     dir_token_mlp img2joint[2]; dir_token_mlp pos_emb[2]; dir_token_mlp gpos;
     float* x0; float* g;       // [2][B][21][128]
     int B;
+    long long* stamps;         // DIR_STAMPS=grid_tokens (tuning aid, else NULL)
 };
 
 constexpr int GT_ROWS = 32;            // 21 tokens padded to two 16-row MFMA tiles
+constexpr int GT_THR = 512, GT_WAVES = GT_THR / 64;   // one 16-column output tile per wave (8 tiles of the 128-wide MLP layers)
 constexpr int LDS_S = 256 + 2, LDS_H = 128 + 2;
 
-// second Conv1d of a token MLP on the matrix cores: acc[tile][m] += hid[32 x 128] * w2t[128 x 128]; wave w owns the
-// output column tiles w and w + 4
-__device__ __forceinline__ void mlp_out_mfma(const float* s_hid, const dir_token_mlp& m, int wave, int lane,
-                                             f32x4 (&acc)[2][2]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) dir::mfma_tile_f32<128, 2>(s_hid, LDS_H, m.w2t, 128, (wave + 4 * t) * 16, lane, acc[t]);
+// second Conv1d of a token MLP on the matrix cores: acc[m] += hid[32 x 128] * w2t[128 x 128]; wave w owns output column tile w
+__device__ __forceinline__ void mlp_out_mfma(const float* s_hid, const dir_token_mlp& m, int wave, int lane, f32x4 (&acc)[2]) {
+    dir::mfma_tile_f32<128, 2>(s_hid, LDS_H, m.w2t, 128, wave * 16, lane, acc);
 }
 
 // first Conv1d (K = 3) + folded BN + ReLU of the positional MLPs: plain VALU, writes hid[21][128]
 __device__ __forceinline__ void mlp_in3(const float* s_in, const dir_token_mlp& m, float* s_hid, int tid) {
     const int o = tid & 127;
     const float w0 = m.w1t[o], w1 = m.w1t[128 + o], w2 = m.w1t[256 + o], s1 = m.s1[o], b1 = m.b1[o];
-    for (int j = tid >> 7; j < NJ; j += 2) {
+    for (int j = tid >> 7; j < NJ; j += GT_THR / 128) {
         const float h = fmaf(w2, s_in[j * 3 + 2], fmaf(w1, s_in[j * 3 + 1], w0 * s_in[j * 3]));
         s_hid[j * LDS_H + o] = fmaxf(fmaf(h, s1, b1), 0.f);
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
+__global__ __launch_bounds__(GT_THR) void grid_tokens_kernel(GridArgs a) {
     __shared__ float s_samp[GT_ROWS * LDS_S];
     __shared__ float s_hid[GT_ROWS * LDS_H];
     __shared__ float s_p[NJ * 3], s_q[NJ * 3];
@@ -72,6 +71,9 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
     __shared__ int s_i[NJ * 4];
     const int b = blockIdx.x, hand = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = a.S, C = a.C;
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && b == 0 && hand == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     if (tid < NJ) {
         // F.grid_sample, bilinear / zeros / align_corners=False: ix = ((u + 1) * W - 1) / 2
 #pragma clang fp contract(off)
@@ -96,33 +98,37 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
         s_q[i] = hand == 0 ? p - off : p + off;                                   // models/dir.py:106-107
     }
     // padding rows of the MFMA row tiles stay zero for the whole kernel
-    for (int i = tid; i < (GT_ROWS - NJ) * LDS_S; i += 256) s_samp[NJ * LDS_S + i] = 0.f;
-    for (int i = tid; i < (GT_ROWS - NJ) * LDS_H; i += 256) s_hid[NJ * LDS_H + i] = 0.f;
-    __syncthreads();
+    for (int i = tid; i < (GT_ROWS - NJ) * LDS_S; i += GT_THR) s_samp[NJ * LDS_S + i] = 0.f;
+    for (int i = tid; i < (GT_ROWS - NJ) * LDS_H; i += GT_THR) s_hid[NJ * LDS_H + i] = 0.f;
+    __syncthreads(); stamp();
     const T* fb = (const T*)a.feat + (long long)b * S * S * a.fcs + a.fco;
     // bilinear gather: out-of-range taps carry weight 0 and a clamped (valid) pixel, so the 4 loads of an element -- and, unrolled,
     // of several elements -- are unconditional and in flight together
-    if (C == 256) {                                                      // thread = channel, 21 joints x 4 taps
-        const int c = tid;
+    if (C == 256) {                                                      // thread = (channel, joint half): 11 | 10 joints x 4 taps
+        const int c = tid & 255, jb = (tid >> 8) ? 11 : 0, je = (tid >> 8) ? NJ : 11;
 #pragma unroll
-        for (int j0 = 0; j0 < NJ; j0 += 7) {
-            float tv[7][4];
+        for (int j0 = 0; j0 < 12; j0 += 6) {
+            float tv[6][4];
 #pragma unroll
-            for (int jj = 0; jj < 7; ++jj)
+            for (int jj = 0; jj < 6; ++jj) {
+                const int j = min(jb + j0 + jj, je - 1);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) tv[jj][t] = ld<T>(fb + (long long)max(s_i[(j0 + jj) * 4 + t], 0) * a.fcs + c);
+                for (int t = 0; t < 4; ++t) tv[jj][t] = ld<T>(fb + (long long)max(s_i[j * 4 + t], 0) * a.fcs + c);
+            }
 #pragma unroll
-            for (int jj = 0; jj < 7; ++jj) {
-                float acc = 0.f;
+            for (int jj = 0; jj < 6; ++jj) {
+                const int j = jb + j0 + jj;
+                if (j < je) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (s_i[(j0 + jj) * 4 + t] >= 0) acc += tv[jj][t] * s_w[(j0 + jj) * 4 + t];   // same skip rule / order as before
+                    for (int t = 0; t < 4; ++t)
+                        if (s_i[j * 4 + t] >= 0) acc += tv[jj][t] * s_w[j * 4 + t];   // same skip rule / order as before
+                    s_samp[j * LDS_S + c] = acc;
                 }
-                s_samp[(j0 + jj) * LDS_S + c] = acc;
             }
         }
     } else {
-        for (int i = tid; i < NJ * C; i += 256) {
+        for (int i = tid; i < NJ * C; i += GT_THR) {
             const int j = i / C, c = i - j * C;
             float acc = 0.f;
 #pragma unroll
@@ -133,15 +139,14 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
             s_samp[j * LDS_S + c] = acc;
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     const int li = lane & 15, lk = lane >> 4;
     // ---- img2joint: Conv1d 256 -> 128 (+BN+ReLU) on the matrix cores -> hid
     {
         const dir_token_mlp& m = a.img2joint[hand];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        {
             f32x4 h[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            const int n0 = (wave + 4 * t) * 16, n = n0 + li;
+            const int n0 = wave * 16, n = n0 + li;
             dir::mfma_tile_f32<256, 2>(s_samp, LDS_S, m.w1t, 128, n0, lane, h);
             const float s1 = m.s1[n], b1 = m.b1[n];
 #pragma unroll
@@ -153,53 +158,47 @@ __global__ __launch_bounds__(256) void grid_tokens_kernel(GridArgs a) {
                 }
         }
     }
-    __syncthreads();
-    f32x4 acc[2][2];
+    __syncthreads(); stamp();
+    f32x4 acc[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     mlp_out_mfma(s_hid, a.img2joint[hand], wave, lane, acc);
-    __syncthreads();
+    __syncthreads(); stamp();
     // ---- pos_emb: x0 = pos + img (models/dir.py:100) accumulates into the same tiles
     mlp_in3(s_p, a.pos_emb[hand], s_hid, tid);
-    __syncthreads();
+    __syncthreads(); stamp();
     mlp_out_mfma(s_hid, a.pos_emb[hand], wave, lane, acc);
+    const int n = wave * 16 + li;
     float* x0 = a.x0 + ((long long)hand * a.B + b) * NJ * 128;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int n = (wave + 4 * t) * 16 + li;
+    {
         const float b2 = a.img2joint[hand].b2[n] + a.pos_emb[hand].b2[n];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = mt * 16 + lk * 4 + r;
-                if (j < NJ) x0[j * 128 + n] = acc[t][mt][r] + b2;
+                if (j < NJ) x0[j * 128 + n] = acc[mt][r] + b2;
             }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     // ---- global_pos_emb
     mlp_in3(s_q, a.gpos, s_hid, tid);
-    __syncthreads();
+    __syncthreads(); stamp();
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     mlp_out_mfma(s_hid, a.gpos, wave, lane, acc);
     float* gp = a.g + ((long long)hand * a.B + b) * NJ * 128;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int n = (wave + 4 * t) * 16 + li;
+    {
         const float b2 = a.gpos.b2[n];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = mt * 16 + lk * 4 + r;
-                if (j < NJ) gp[j * 128 + n] = acc[t][mt][r] + b2;
+                if (j < NJ) gp[j * 128 + n] = acc[mt][r] + b2;
             }
     }
+    stamp();
 }
 
 // --------------------------------------------------------------------------------------------- P-GCN
@@ -465,9 +464,11 @@ extern "C" int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, 
     a.offset = offset; a.img2joint[0] = img2joint_lr[0]; a.img2joint[1] = img2joint_lr[1];
     a.pos_emb[0] = pos_emb_lr[0]; a.pos_emb[1] = pos_emb_lr[1]; a.gpos = *global_pos_emb; a.x0 = x0; a.g = gpos; a.B = B;
     hipStream_t s = (hipStream_t)stream;
-    if (feat_dtype == DIR_DT_F32) hipLaunchKernelGGL((grid_tokens_kernel<float>), dim3(B, 2), dim3(256), 0, s, a);
-    else if (feat_dtype == DIR_DT_BF16) hipLaunchKernelGGL((grid_tokens_kernel<bf16_t>), dim3(B, 2), dim3(256), 0, s, a);
+    a.stamps = dir::stamps_begin("grid_tokens");
+    if (feat_dtype == DIR_DT_F32) hipLaunchKernelGGL((grid_tokens_kernel<float>), dim3(B, 2), dim3(GT_THR), 0, s, a);
+    else if (feat_dtype == DIR_DT_BF16) hipLaunchKernelGGL((grid_tokens_kernel<bf16_t>), dim3(B, 2), dim3(GT_THR), 0, s, a);
     else DIR_REQUIRE(false, "dir_grid_tokens_forward: bad dtype");
+    dir::stamps_end("grid_tokens", a.stamps, s);
     return dir::check_launch("dir_grid_tokens_forward");
 }
 

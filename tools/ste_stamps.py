@@ -1,6 +1,6 @@
 """Scratch: phase durations inside ste_kernel (DIR_STE_STAMPS=1: s_memtime at every barrier of workgroup 0) at B = 64."""
 import json, os, sys
-os.environ['DIR_STE_STAMPS'] = '1'
+os.environ['DIR_STAMPS'] = 'ste'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ctypes as C
