@@ -23,7 +23,7 @@ struct ManoHand {
     const float* cam; int cam_stride;
     float* verts; float* joints; float* joint_uv; float* mesh_uv; int32_t* flags;
 };
-struct ManoArgs { ManoHand h[2]; };
+struct ManoArgs { ManoHand h[2]; long long* stamps; };   // stamps: DIR_STAMPS=mano (tuning aid, else NULL)
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     // rot6d.py:54-60: v / max(|v|, 1e-8).  No FMA contraction: the robust-6D construction is
@@ -36,9 +36,12 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
 // gridDim.z = vertex parts: with 4 parts every workgroup owns 196 vertices (588 floats, 16-byte aligned) of one (sample, hand),
 // recomputes the cheap pose / chain maths, and streams only its quarter of the blend-shape tables -- the 1.3 MB posedirs
 // read per (sample, hand) is spread over four CUs instead of one.  blockDim.x = NTHR (1 part) or PTHR (4 parts).
-constexpr int PART_V = 196, PTHR = 192;
+constexpr int PART_V = 196, PTHR = 256;   // >= PART_V threads: the skinning loop is one pass per part
 
-__global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
+// THREADS = NTHR (one part) or PTHR (four vertex parts): the launch bound sets the register budget -- under the 640-thread bound the
+// 4-part launches (256 threads) were compiled down to 168 VGPRs and spilled (scratch traffic inside the skinning loop)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
     const ManoHand& a = args.h[blockIdx.y];
     const int nthr = blockDim.x;
     const int v_lo = gridDim.z > 1 ? blockIdx.z * PART_V : 0;
@@ -52,16 +55,19 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
     __shared__ float s_root[9];
     __shared__ float s_J[NJ * 3];
     __shared__ float s_A[NJ * 12];      // global transforms (top 3 rows), th_j joint order
-    __shared__ float s_A2[NJ * 12];     // with the rest-pose joint removed: A' = A - pack(A.[J;0])
+    __shared__ __attribute__((aligned(16))) float s_A2[NJ * 12];     // with the rest-pose joint removed: A' = A - pack(A.[J;0])
     __shared__ float s_jtr[21 * 3];
     __shared__ float s_c[3];
 
     const int b = blockIdx.x, tid = threadIdx.x;
+    int nstamp = 0;
+    auto stamp = [&]() { if (args.stamps && b == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
 
     if (tid < 51) s_pose[tid] = a.pose[(size_t)b * a.pose_stride + tid];
     if (tid >= 64 && tid < 74) s_beta[tid - 64] = a.betas[(size_t)b * a.betas_stride + tid - 64];
     if (tid >= 128 && tid < 131) s_cam[tid - 128] = a.cam ? a.cam[(size_t)b * a.cam_stride + tid - 128] : 0.f;
-    __syncthreads();
+    __syncthreads(); stamp();
 
     // ---- PCA coefficients -> axis angle (manolayer.py:131-144) ; shape blend (manolayer.py:180-182)
     if (tid < 45) {
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
             a.flags[b] = det < 0.f ? 1 : 0;
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
 
     // ---- Rodrigues via quaternion (rodrigues_layer.py:43-54, 15-40)
     if (tid < 15) {
@@ -132,14 +138,14 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
         for (int k = 0; k < 10; ++k) acc = fmaf(a.t.j_shapedirs[o * 10 + k], s_beta[k], acc);
         s_J[o] = acc;
     }
-    __syncthreads();
+    __syncthreads(); stamp();
 
-    // ---- pose blend shapes (manolayer.py:186-187): one float4 column of the k-major table per thread, 27 loads in flight (5 L2 round trips)
+    // ---- pose blend shapes (manolayer.py:186-187): one float4 column of the k-major table per thread, 9 loads in flight
     if (f_lo / 4 + tid < (f_hi + 3) / 4) {
         const int c4 = f_lo / 4 + tid;                    // float4 column (f_lo is a multiple of 12)
         const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + c4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 27
+#pragma unroll 9
         for (int k = 0; k < 135; ++k) {
             const float4 p = pd[k * (NV3P / 4)];
             const float w = s_pm[k];
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
             parent = j;
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     if (tid < NJ) {   // A' = A - pack(A.[J;0])  (manolayer.py:231-234)
         const float* A = s_A + 12 * tid;
         const float j0 = s_J[3 * tid], j1 = s_J[3 * tid + 1], j2 = s_J[3 * tid + 2];
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
             s_A2[12 * tid + 4 * r + 3] = A[4 * r + 3] - (A[4 * r] * j0 + A[4 * r + 1] * j1 + A[4 * r + 2] * j2);
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
 
     // ---- linear blend skinning (manolayer.py:236-246): T = sum_k w[v][k] A'[k]; vert = T.[v_posed;1]
     for (int v = v_lo + tid; v < v_hi; v += nthr) {
@@ -208,16 +214,21 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < 16; ++k) {                       // A'[k] as three 16-byte LDS reads (was 12 scalar reads; same fmaf order)
+            const float4* ak = reinterpret_cast<const float4*>(s_A2 + 12 * k);
 #pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = fmaf(s_A2[12 * k + e], w[k], T[e]);
+            for (int r = 0; r < 3; ++r) {
+                const float4 t4 = ak[r];
+                T[4 * r] = fmaf(t4.x, w[k], T[4 * r]); T[4 * r + 1] = fmaf(t4.y, w[k], T[4 * r + 1]);
+                T[4 * r + 2] = fmaf(t4.z, w[k], T[4 * r + 2]); T[4 * r + 3] = fmaf(t4.w, w[k], T[4 * r + 3]);
+            }
         }
         const float x = s_v[3 * v], y = s_v[3 * v + 1], z = s_v[3 * v + 2];
         s_v[3 * v + 0] = T[0] * x + T[1] * y + T[2] * z + T[3];
         s_v[3 * v + 1] = T[4] * x + T[5] * y + T[6] * z + T[7];
         s_v[3 * v + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
     }
-    __syncthreads();
+    __syncthreads(); stamp();
 
     // ---- joints: 16 chain joints + 5 fingertip vertices, reordered (manolayer.py:247-259)
     if (tid < 21) {
@@ -230,9 +241,9 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
         else { const int v = kTips[a.t.side][src - 16]; x = s_v[3 * v]; y = s_v[3 * v + 1]; z = s_v[3 * v + 2]; }
         s_jtr[3 * tid] = x; s_jtr[3 * tid + 1] = y; s_jtr[3 * tid + 2] = z;
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     if (tid < 3) s_c[tid] = a.t.center_idx >= 0 ? s_jtr[3 * a.t.center_idx + tid] : 0.f;   // manolayer.py:261-265
-    __syncthreads();
+    __syncthreads(); stamp();
 
     // with vertex parts: part 0 writes the 16 chain joints, a fingertip joint is written by the part that owns its vertex
     auto owns_joint = [&](int j) {
@@ -258,21 +269,25 @@ __global__ __launch_bounds__(NTHR) void mano_forward_kernel(ManoArgs args) {
             }
         }
     }
+    stamp();
 }
 
 }  // namespace
 
 // Four vertex parts per (sample, hand) unless the centre joint needs vertices of another part (a fingertip centre or the
 // root_palm wrist) or the batch alone fills the chip.
-static void launch_mano(const ManoArgs& a, int B, int hands, hipStream_t s) {
+static void launch_mano(const ManoArgs& a0, int B, int hands, hipStream_t s) {
+    ManoArgs a = a0;
+    a.stamps = dir::stamps_begin("mano");
     bool split = B * hands < 1024;
     for (int h = 0; h < hands; ++h) {
         const dir_mano_tables& t = a.h[h].t;
         const int c = t.center_idx;
         if (t.root_palm || (c >= 0 && (c == 4 || c == 8 || c == 12 || c == 16 || c == 20))) split = false;
     }
-    if (split) hipLaunchKernelGGL(mano_forward_kernel, dim3(B, hands, 4), dim3(PTHR), 0, s, a);
-    else hipLaunchKernelGGL(mano_forward_kernel, dim3(B, hands, 1), dim3(NTHR), 0, s, a);
+    if (split) hipLaunchKernelGGL(mano_forward_kernel<PTHR>, dim3(B, hands, 4), dim3(PTHR), 0, s, a);
+    else hipLaunchKernelGGL(mano_forward_kernel<NTHR>, dim3(B, hands, 1), dim3(NTHR), 0, s, a);
+    dir::stamps_end("mano", a.stamps, s);
 }
 
 static int check_hand(const dir_mano_tables* t, const float* pose, int pose_stride, const float* betas,
