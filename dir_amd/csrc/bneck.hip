@@ -183,13 +183,11 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
 
         // projection shortcut input (the block's own input, 64 channels) for this tile: chunk c = tid + 512 i = pixel c >> 3,
         // 16-byte chunk c & 7; parked in the patch buffer once phase A is done with it
-        uint4 xq[2];
+        uint4 xq0 = make_uint4(0u, 0u, 0u, 0u), xq1 = xq0;                   // (two scalars: as an array the pair went through scratch)
         if constexpr (HAS_DUAL) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = tid + NTHR * i, P = c >> 3;
-                xq[i] = *reinterpret_cast<const uint4*>(a.x2 + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 64 + (c & 7) * 8);
-            }
+            const int P0 = tid >> 3, P1 = (tid + NTHR) >> 3;
+            xq0 = *reinterpret_cast<const uint4*>(a.x2 + (((long long)b * a.H + y0 + (P0 >> 4)) * a.W + x0 + (P0 & 15)) * 64 + (tid & 7) * 8);
+            xq1 = *reinterpret_cast<const uint4*>(a.x2 + (((long long)b * a.H + y0 + (P1 >> 4)) * a.W + x0 + (P1 & 15)) * 64 + (tid & 7) * 8);
         }
 
         // ---- A. conv2 (3x3): D[channel 32][pixel 32] per wave, K = 9 taps x 64 channels
@@ -227,11 +225,8 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
         }
         __syncthreads();                                                      // y2 complete; the patch is free
         if constexpr (HAS_DUAL) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = tid + NTHR * i;
-                *reinterpret_cast<uint4*>(s_patch + (c >> 3) * PPITCH + (c & 7) * 16) = xq[i];
-            }
+            *reinterpret_cast<uint4*>(s_patch + (tid >> 3) * PPITCH + (tid & 7) * 16) = xq0;
+            *reinterpret_cast<uint4*>(s_patch + ((tid + NTHR) >> 3) * PPITCH + (tid & 7) * 16) = xq1;
             __syncthreads();
         }
 
