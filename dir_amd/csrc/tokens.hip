@@ -356,6 +356,7 @@ struct RegArgs {
     dir_regress_params p;
     const float* tok; const float* prev_para[2]; const float* prev_off;
     float* para[2]; float* off; float* emb;
+    long long* stamps;         // DIR_STAMPS=regress (tuning aid, else NULL)
 };
 
 // one 512-thread workgroup per sample
@@ -365,13 +366,16 @@ __global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
     __shared__ float s_part[4][128];
     __shared__ float s_off[3], s_red[8][3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && b == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     for (int i = tid; i < 42 * 64; i += 512) {
         const int hand = i / 1344;
         s_in[hand][i - hand * 1344] = a.tok[(long long)b * 42 * 64 + i];
     }
     if (tid < 128) s_in[tid >> 6][1344 + (tid & 63)] = a.prev_para[tid >> 6][(long long)b * 64 + (tid & 63)];
     if (tid >= 128 && tid < 131) s_off[tid - 128] = a.prev_off[(long long)b * 3 + tid - 128];
-    __syncthreads();
+    __syncthreads(); stamp();
     {   // Linear(1408 -> 64) x 2 (models/dir.py:350-351): thread = (output o of 128, K quarter), weights k-major
         const int o = tid & 127, ks = tid >> 7;
         const float* in = s_in[o >> 6] + ks * 352;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
         p0 = dir::wave_sum(p0); p1 = dir::wave_sum(p1); p2 = dir::wave_sum(p2);
         if (lane == 0) { s_red[wave][0] = p0; s_red[wave][1] = p1; s_red[wave][2] = p2; }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     if (tid < 128) {
         const int s = tid >> 6, oo = tid & 63;
         a.para[s][(long long)b * 64 + oo] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + a.p.mano_b[s][oo];
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
             s_hid[j * 64 + o] = fmaxf(fmaf(acc, m.s1[o], m.b1[o]), 0.f);
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
 #pragma unroll
     for (int k = 0; k < 64; ++k) wv[k] = m.w2t[k * 64 + o];
 #pragma unroll
@@ -442,6 +446,7 @@ __global__ __launch_bounds__(512) void regress_kernel(RegArgs a) {
             a.emb[((long long)b * 42 + j) * 64 + o] = h[t] + m.b2[o];
         }
     }
+    stamp();
 }
 
 bool mlp_ok(const dir_token_mlp& m) { return m.w1t && m.s1 && m.b1 && m.w2t && m.b2; }
@@ -542,6 +547,8 @@ extern "C" int dir_regress_forward(const dir_regress_params* p, const float* tok
     RegArgs a;
     a.p = *p; a.tok = tok; a.prev_para[0] = prev_para_left; a.prev_para[1] = prev_para_right; a.prev_off = prev_offset;
     a.para[0] = para_left; a.para[1] = para_right; a.off = offset; a.emb = emb;
+    a.stamps = dir::stamps_begin("regress");
     hipLaunchKernelGGL(regress_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, a);
+    dir::stamps_end("regress", a.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_regress_forward");
 }
