@@ -87,6 +87,8 @@ struct FuseArgs {
     int S;
     float distance;
     int PW, PH, npr;      // halo patch geometry of one 256-pixel strip
+    long long* stamps;    // DIR_STAMPS=bone_fuse (tuning aid, else NULL)
+    unsigned mg_npr, sh_npr, mg_pw, sh_pw;   // magic dividers (convk::magic_u31) for npr and PW
 };
 
 constexpr int FUSE_MAX_ROWS = 400;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
     constexpr int GW = 40 * BN / NT;                                 // G words per thread per tap (10)
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     __shared__ float s_uv[84];
+    __shared__ float s_bone[40 * 6];                                // per (hand, bone): ax, ay, bx, by (pixel units), unit direction dx, dy
 
     const int S = a.S, hw = S * S;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
     const int tn = blockIdx.x & 1, tm = blockIdx.x >> 1;            // the two N halves of a strip are neighbours (same XCD pair)
     const int m0 = tm * BM, n0 = tn * BN;
     const int b = m0 / hw, y0 = (m0 - b * hw) / S;
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
 
     // ---- G_tap loader: word (hb, n) -> LDS [n][hb*2 .. hb*2+1]; consecutive threads read consecutive n (coalesced)
     const unsigned* gsrc = a.g + ((long long)b * NTAP * 40) * NCOUT + n0;
@@ -136,24 +142,34 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
         const float v = a.uv[hand][(long long)b * 42 + r];
         s_uv[tid] = (v + 1.f) / 2.f * (float)S;                      // models/dir.py:150
     }
+    __syncthreads(); stamp();
+    // per-bone unit directions once per workgroup, then item i = hb * npr + prow: a wave covers 64 consecutive patch pixels of ONE
+    // bone, so most waves take the early-out of bone_weights_fast as a whole (the capsule touches ~10 % of the patch)
+    if (tid < 40) {
+        const int hand = tid / 20, bone = tid - hand * 20;
+        const float* uv = s_uv + hand * 42;
+        const int pa = kParent[bone], ch = kChild[bone];
+        float dx, dy;
+        dir::bone::bone_dir(uv[2 * pa], uv[2 * pa + 1], uv[2 * ch], uv[2 * ch + 1], dx, dy);
+        float* sb = s_bone + 6 * tid;
+        sb[0] = uv[2 * pa]; sb[1] = uv[2 * pa + 1]; sb[2] = uv[2 * ch]; sb[3] = uv[2 * ch + 1]; sb[4] = dx; sb[5] = dy;
+    }
     __syncthreads();
     for (int i = tid; i < a.npr * 40; i += NT) {
-        const int prow = i / 40, hb = i - prow * 40, hand = hb / 20, bone = hb - hand * 20;
-        const int py = prow / a.PW, px = prow - py * a.PW;
+        const int hb = convk::div_magic(i, a.mg_npr, a.sh_npr), prow = i - hb * a.npr;
+        const int py = convk::div_magic(prow, a.mg_pw, a.sh_pw), px = prow - py * a.PW;
         const int iy = y0 + py - 1, ix = px - 1;                      // 3x3, pad 1
         unsigned word = 0;
         if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
-            const float* uv = s_uv + hand * 42;
-            const int pa = kParent[bone], ch = kChild[bone];
-            float wa, wb;
-            bool in;
-            bone_weights((float)ix + 0.5f, (float)iy + 0.5f, uv[2 * pa], uv[2 * pa + 1], uv[2 * ch], uv[2 * ch + 1], a.distance, wa, wb, in);
-            if (in) word = (unsigned)f2bf(wa) | ((unsigned)f2bf(wb) << 16);   // torch.where(mask, v, 0), models/dir.py:172
+            const float* sb = s_bone + 6 * hb;                        // (the parent / child tables are __constant__: indexed per lane
+            float wa, wb;                                             //  they would be two global loads per item)
+            if (dir::bone::bone_weights_fast((float)ix + 0.5f, (float)iy + 0.5f, sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], a.distance, wa, wb))
+                word = (unsigned)f2bf(wa) | ((unsigned)f2bf(wb) << 16);   // torch.where(mask, v, 0), models/dir.py:172
         }
         *reinterpret_cast<unsigned*>(smem + prow * PITCH + hb * 4) = word;
     }
     g_store(0);
-    __syncthreads();
+    __syncthreads(); stamp();
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -197,8 +213,10 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
         __syncthreads();
     }
 
+    stamp();
     ConvArgs c = a.c;
     epilogue_tile<bf16_t, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
+    stamp();
 }
 
 }  // namespace
@@ -236,6 +254,10 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     const int rows = 256 / S;
     fa.PW = S + 2; fa.PH = rows + 2; fa.npr = fa.PH * fa.PW;
     DIR_REQUIRE(fa.npr <= FUSE_MAX_ROWS, "dir_bone_fusion_forward: halo patch of %d rows does not fit", fa.npr);
+    convk::magic_u31((unsigned)fa.npr, &fa.mg_npr, &fa.sh_npr);
+    convk::magic_u31((unsigned)fa.PW, &fa.mg_pw, &fa.sh_pw);
+    fa.stamps = stamps_begin("bone_fuse");
     hipLaunchKernelGGL(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    stamps_end("bone_fuse", fa.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_forward");
 }
