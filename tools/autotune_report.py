@@ -27,5 +27,5 @@ for (op, shp), d in times.items():
     m = {v: min(ts) for v, ts in d.items()}
     bv = min(m, key=m.get)
     tot_auto += m[0]; tot_best += m[bv]
-    print('%-38s pre=%d auto %6.1f best %-9s %6.1f   ' % (shp, op.pre_scale is not None, m[0], names[bv], m[bv]) + ' '.join('%s:%.0f' % (names[v], m[v]) for v in sorted(m)))
+    print('%-38s pre=%d auto %6.1f best %-9s %6.1f   ' % (shp, getattr(op, 'pre_scale', None) is not None, m[0], names[bv], m[bv]) + ' '.join('%s:%.0f' % (names[v], m[v]) for v in sorted(m)))
 print('sum auto %.1f us, sum best %.1f us' % (tot_auto, tot_best))
