@@ -42,6 +42,7 @@ struct GArgs {
     const float* emb;     // [B][42][64]
     unsigned* g;          // [B][9][40][256] words = (bf16 end 0) | (bf16 end 1) << 16
     int B;
+    long long* stamps;    // DIR_STAMPS=bone_g (tuning aid, else NULL)
 };
 
 constexpr int G_ROWS = 128, G_LD = 66;      // (sample, end) rows per pass; lda % 32 == 2 (dir_mfma.h)
@@ -52,18 +53,35 @@ __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int jpar = hand * 21 + kParent[bone], jchi = hand * 21 + kChild[bone];
     const float* wt = a.w_g + ((long long)(tap * 40 + hb) * 64) * NCOUT;
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && nstamp < MAX_STAMPS) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     for (int b0 = 0; b0 < a.B; b0 += G_ROWS / 2) {
         __syncthreads();
-        for (int i = tid; i < G_ROWS * 64; i += 256) {
-            const int r = i >> 6, c = i & 63, b = b0 + (r >> 1);
-            s_f[r * G_LD + c] = b < a.B ? a.emb[((long long)b * 42 + ((r & 1) ? jchi : jpar)) * 64 + c] : 0.f;
+        // thread = (column c, row quarter): 32 independent loads from clamped addresses, all in flight together (a conditional load
+        // per iteration is a chain of 32 memory round trips: 10 us of this kernel); rows past the batch are zeroed at the LDS write
+        {
+            const int c = tid & 63, r0 = tid >> 6;
+            float v[G_ROWS / 4];
+#pragma unroll
+            for (int k = 0; k < G_ROWS / 4; ++k) {
+                const int r = r0 + 4 * k, b = min(b0 + (r >> 1), a.B - 1);
+                v[k] = a.emb[((long long)b * 42 + ((r & 1) ? jchi : jpar)) * 64 + c];
+            }
+#pragma unroll
+            for (int k = 0; k < G_ROWS / 4; ++k) {
+                const int r = r0 + 4 * k;
+                s_f[r * G_LD + c] = b0 + (r >> 1) < a.B ? v[k] : 0.f;
+            }
         }
-        __syncthreads();
-        for (int nt = wave; nt < NCOUT / 16; nt += 4) {
+        __syncthreads(); stamp();
+        for (int nt = wave + 4 * blockIdx.y; nt < NCOUT / 16; nt += 4 * gridDim.y) {   // grid.y = 2: 720 workgroups of two column tiles
+                                                                                     // per wave balance better over 256 CUs than 360 of four
             f32x4 acc[G_ROWS / 16];
 #pragma unroll
             for (int m = 0; m < G_ROWS / 16; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             mfma_tile_f32<64, G_ROWS / 16>(s_f, G_LD, wt, NCOUT, nt * 16, lane, acc);
+            asm volatile("" :: "v"(acc[0]), "v"(acc[7])); stamp();
             // lane holds column n = nt*16 + (lane & 15), rows m*16 + 4*(lane >> 4) + r: two samples x two ends
             const int n = nt * 16 + (lane & 15);
 #pragma unroll
@@ -229,8 +247,9 @@ extern "C" int dir_bone_fusion_prepare(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(p && p->w_g && emb && scratch, "dir_bone_fusion_prepare: null pointer");
     DIR_REQUIRE(B >= 0, "dir_bone_fusion_prepare: B=%d", B);
     if (B == 0) return DIR_OK;
-    GArgs ga{p->w_g, emb, (unsigned*)scratch, B};
-    hipLaunchKernelGGL(bone_g_kernel, dim3(NTAP * 40), dim3(256), 0, (hipStream_t)stream, ga);
+    GArgs ga{p->w_g, emb, (unsigned*)scratch, B, stamps_begin("bone_g")};
+    hipLaunchKernelGGL(bone_g_kernel, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    stamps_end("bone_g", ga.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_prepare");
 }
 
