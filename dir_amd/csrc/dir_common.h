@@ -42,6 +42,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sum over the 64 lanes on DPP row operations (a few cycles each) + four v_readlane: the shuffle tree above goes through
+// ds_bpermute (~100 cycles per step, six dependent steps).  Different association order than wave_sum (last-ulp differences).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);      // row_half_mirror
+    v += dpp_f32<0x140>(v);      // row_mirror: every lane holds its row-of-16 sum
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

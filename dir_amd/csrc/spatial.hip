@@ -209,6 +209,7 @@ struct InitHeadArgs {
     const void* c4; const void* h[2];
     float* para[2]; float* offset;
     int HW, C, Ch, hcs;
+    long long* stamps;     // DIR_STAMPS=init_head (tuning aid, else NULL)
 };
 
 template <typename T>
@@ -222,39 +223,74 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
     __shared__ float s_part[4][128];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = a.HW, C = a.C, Ch = a.Ch;
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && b == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     const T* c4 = (const T*)a.c4 + (long long)b * HW * C;
-    // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232); one wave per (hand, pixel) dot product
-    //    (four dot products per pass: their loads are issued together instead of one L2 round trip per (hand, pixel))
-    for (int o0 = wave * 4; o0 < 2 * HW; o0 += 32) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = lane * VN; k < Ch; k += 64 * VN) {
-            float v[4][VN], wv[4][VN];
+    // 1) attention logits: 1x1 conv Ch -> 1, sigmoid (models/dir.py:231-232); one wave per (hand, pixel) dot product, lanes over
+    //    channels (1 KB contiguous per load instruction).  Fast path (Ch = 2 x 64 x VN, 2 HW a multiple of 64): a wave owns 2 HW / 8
+    //    consecutive outputs of ONE hand, keeps that hand's weights in registers and issues the loads of sixteen outputs (32 per
+    //    lane) together -- one memory round trip per wave instead of eight; DPP wave sums.  Per-lane fmaf order unchanged (bit-identical).
+    if (Ch == 2 * 64 * VN && (2 * HW) % 128 == 0) {
+        const int per = 2 * HW / 8, o_first = wave * per, s = o_first / HW;
+        float wv[2][VN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int o = min(o0 + u, 2 * HW - 1), s = o / HW, px = o - s * HW;
-                Vec<T>::load((const T*)a.h[s] + ((long long)b * HW + px) * a.hcs + k, v[u]);
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int e = 0; e < VN; ++e) wv[u][e] = a.p.attn_w[s][k + e];
+            for (int e = 0; e < VN; ++e) wv[kk][e] = a.p.attn_w[s][kk * 64 * VN + lane * VN + e];
+        const float bias = a.p.attn_b[s];
+        for (int o0 = o_first; o0 < o_first + per; o0 += 16) {
+            float v[16][2][VN];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int px = o0 + u - s * HW;
+                const T* hp = (const T*)a.h[s] + ((long long)b * HW + px) * a.hcs + lane * VN;
+                Vec<T>::load(hp, v[u][0]);
+                Vec<T>::load(hp + 64 * VN, v[u][1]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 16; ++u) {
+                float acc = 0.f;
 #pragma unroll
-                for (int e = 0; e < VN; ++e) acc[u] = fmaf(v[u][e], wv[u][e], acc[u]);
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc = fmaf(v[u][kk][e], wv[kk][e], acc);
+                const float t = dir::wave_sum_dpp(acc);
+                if (lane == 0) s_attn[o0 + u] = 1.f / (1.f + expf(-(t + bias)));
+            }
         }
+    } else {
+        for (int o0 = wave * 4; o0 < 2 * HW; o0 += 32) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = lane * VN; k < Ch; k += 64 * VN) {
+                float v[4][VN], wv[4][VN];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float t = dir::wave_sum(acc[u]);
-            const int o = o0 + u;
-            if (lane == 0 && o < 2 * HW) s_attn[o] = 1.f / (1.f + expf(-(t + a.p.attn_b[o / HW])));
+                for (int u = 0; u < 4; ++u) {
+                    const int o = min(o0 + u, 2 * HW - 1), s = o / HW, px = o - s * HW;
+                    Vec<T>::load((const T*)a.h[s] + ((long long)b * HW + px) * a.hcs + k, v[u]);
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) wv[u][e] = a.p.attn_w[s][k + e];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < VN; ++e) acc[u] = fmaf(v[u][e], wv[u][e], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t = dir::wave_sum(acc[u]);
+                const int o = o0 + u;
+                if (lane == 0 && o < 2 * HW) s_attn[o] = 1.f / (1.f + expf(-(t + a.p.attn_b[o / HW])));
+            }
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     if (tid < 2) {
         float d = 0.f;
         for (int px = 0; px < HW; ++px) d += s_attn[tid * HW + px];
         s_den[tid] = d + 1e-8f;                                     // models/dir.py:264
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     // 2) attention-weighted pooling and the plain spatial mean (models/dir.py:264-268): VN channels per thread
     for (int c = tid * VN; c < C; c += 512 * VN) {
         float fl[VN], fr[VN], fm[VN];
@@ -275,7 +311,7 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
             s_feat[2 * C + c + e] = fm[e] / (float)HW;
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     // 3) Linears (models/dir.py:268-270).  mano_{left,right}: thread = (output o of 128, K quarter), k-major weights,
     //    16 loads in flight; offset (3 outputs): waves 0..2, lane-strided.
     {
@@ -309,11 +345,12 @@ __global__ __launch_bounds__(512) void init_head_kernel(InitHeadArgs a) {
         acc = dir::wave_sum(acc);
         if (lane == 0) a.offset[(long long)b * 3 + wave] = acc + a.p.off_b[wave];
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     if (tid < 128) {
         const int s = tid >> 6, oo = tid & 63;
         a.para[s][(long long)b * 64 + oo] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid] + a.p.mano_b[s][oo];
     }
+    stamp();
 }
 
 // ------------------------------------------------------------------------------------------ bone_proj
@@ -583,9 +620,11 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
     DIR_REQUIRE(lds <= 60000, "dir_init_head_forward: feature too large for LDS");
     DIR_REQUIRE(C % 64 == 0 && Ch % 8 == 0 && (2 * HW) % 4 == 0 && p->mano_wt, "dir_init_head_forward: need C % 64 == 0, Ch % 8 == 0");
     hipStream_t s = (hipStream_t)stream;
+    a.stamps = dir::stamps_begin("init_head");
     if (dtype == DIR_DT_F32) hipLaunchKernelGGL((init_head_kernel<float>), dim3(B), dim3(512), lds, s, a);
     else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((init_head_kernel<bf16_t>), dim3(B), dim3(512), lds, s, a);
     else DIR_REQUIRE(false, "dir_init_head_forward: bad dtype");
+    dir::stamps_end("init_head", a.stamps, s);
     return dir::check_launch("dir_init_head_forward");
 }
 
