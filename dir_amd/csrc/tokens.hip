@@ -209,7 +209,7 @@ struct PgcnHand {
     const float* e1_prev; const float* bias_prev; const float* bns_prev; const float* bnb_prev; int relu_prev;
     float* h_out;                               // [B][21][256]
 };
-struct PgcnArgs { PgcnHand h[2]; int B; int nchunk; };
+struct PgcnArgs { PgcnHand h[2]; int B; int nchunk; long long* stamps; };   // stamps: DIR_STAMPS=pgcn (tuning aid, else NULL)
 
 __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (&w)[5], int (&idx)[5], int& deg) {
     // row j of softmax(A_1) where A_1 = -9e15 off the skeleton edges (SemGCN/p_graph_conv.py:43-50)
@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
     const int hand = blockIdx.z / args.nchunk, chunk = blockIdx.z - hand * args.nchunk;
     const PgcnHand& a = args.h[hand];
     const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
+    int nstamp = 0;
+    auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     float wgt[5]; int nidx[5]; int deg = 0;
     if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
             s_x[bb * PG_LD + k] = bb < nb ? v : 0.f;
         }
     }
-    __syncthreads();
+    __syncthreads(); stamp();
     const int n0 = slice * 64 + wave * 16, li = lane & 15, lk = lane >> 4;
     f32x4 a0[PG_MT], a1[PG_MT];
 #pragma unroll
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
         dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
         dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
     }
+    asm volatile("" :: "v"(a0[0]), "v"(a1[0])); stamp();
 #pragma unroll
     for (int m = 0; m < PG_MT; ++m)
 #pragma unroll
@@ -324,6 +328,7 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
                 hb[128 + n0 + li] = a1[m][r];
             }
         }
+    stamp();
 }
 
 struct MixHand {
@@ -498,7 +503,9 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
             g.relu_prev = l ? layers[hh][l - 1].relu : 0;
             g.h_out = hbuf[l & 1];
         }
+        a.stamps = dir::stamps_begin("pgcn");
         hipLaunchKernelGGL(pgcn_layer_kernel, dim3(NJ, 2, nh * nchunk), dim3(256), 0, s, a);
+        dir::stamps_end("pgcn", a.stamps, s);
     }
     MixArgs m;
     m.out_bstride = out_bstride;
