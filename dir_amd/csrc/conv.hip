@@ -426,7 +426,16 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     if constexpr (std::is_same<TI, bf16_t>::value) {
         // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip
         const bool four_wave = ((a0.variant & 15) >= 1 && (a0.variant & 15) <= 4) || a0.x2;   // explicit DIR_CONV_VARIANT 1..4 (+16), or a second source
-        if (!four_wave && launch_conv_pipe(a0, std::is_same<TO, float>::value, num_cu, s)) return;
+        if (!four_wave) {
+            ConvArgs ap = a0;
+            ap.stamps = dir::stamps_begin("conv_pipe");
+            const bool taken = launch_conv_pipe(ap, std::is_same<TO, float>::value, num_cu, s);
+            if (ap.stamps) {
+                fprintf(stderr, "conv M=%d N=%d K=%d %s: ", ap.M, ap.Cout, ap.K, taken ? "pipe" : "(not taken)");
+                dir::stamps_end("conv_pipe", ap.stamps, s);
+            }
+            if (taken) return;
+        }
     }
     ConvArgs a = a0;
     // tile shape: 64-wide N tile for Cout <= 64 (no half-empty MFMA tiles); 64-tall M tile when the 128-tall grid
@@ -497,6 +506,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
                 "dir_conv2d_forward: input channel slice must be 16-byte aligned");
     DIR_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "dir_conv2d_forward: pre_scale/pre_shift go together");
     ConvArgs a;
+    a.stamps = nullptr;
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.res = residual; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = in_cs; a.in_co = d->in_coff;

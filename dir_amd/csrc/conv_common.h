@@ -77,6 +77,7 @@ struct ConvArgs {
     const void* x2; unsigned x2_bytes; int H2, W2, in_cs2, in_co2, stride2, nk1;
     unsigned x_bytes, w_bytes;          // buffer sizes for the hardware bounds check
     unsigned mg_hw, sh_hw, mg_w, sh_w;  // magic multipliers: m / (Ho*Wo) and r / Wo for 0 <= m < 2^31 (set_magic)
+    long long* stamps;                  // DIR_STAMPS=conv_pipe (tuning aid, else NULL): phase times of the first / last workgroup
     const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
                                         // each 64-channel input group; K-slabs that cannot touch a tile are skipped
 };

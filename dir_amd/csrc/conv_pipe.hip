@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
+    int nstamp = blockIdx.x == 0 ? 0 : 4;
+    auto stamp = [&]() { if (a.stamps && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
 
@@ -283,14 +286,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
         }(std::make_integer_sequence<int, NSLOT>{});
         buf = nb;
     };
+    stamp();
     for (int ks = 0; ks < nact; ks += 2) {
         iteration(std::integral_constant<int, 0>{}, ks);
         if (ks + 1 < nact) iteration(std::integral_constant<int, 1>{}, ks + 1);
     }
     wait_vmcnt<0>();                               // trailing (out-of-range) refills must land before the LDS is reused
     __syncthreads();
+    stamp();
 
     epilogue_tile<TO, MI, NJ, WM, WN>(a, acc, smem, m0, n0, wm, wn, tid, lane);
+    stamp();
 }
 
 
