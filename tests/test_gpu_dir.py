@@ -170,3 +170,46 @@ def test_autotuned_engine_is_bit_identical(dir_state):
         for k, v in o0.items():
             if torch.is_tensor(v):
                 assert torch.equal(v, o1[k]), k
+
+
+def test_fused_backbone_paths_agree(dir_state):
+    """bf16 mode: the fused stem (dir_stem_pool_forward) and the layer1 chain kernels (dir_bottleneck_chain_forward) against the
+    launch-per-conv path they replace: same rounding points, so the pyramid agrees to bf16 noise and the final joints to well
+    inside the bf16-mode envelope."""
+    from dir_amd import engine as E
+    sd, img = dir_state
+    saved = (E.BackboneOp.fused_stem, E.BackboneOp.bneck_chain)
+    try:
+        E.BackboneOp.fused_stem, E.BackboneOp.bneck_chain = True, True
+        taps_f = {}
+        outs_f = DirEngine(sd, dtype=torch.bfloat16).forward(img, taps=taps_f)
+        E.BackboneOp.fused_stem, E.BackboneOp.bneck_chain = False, False
+        taps_u = {}
+        outs_u = DirEngine(sd, dtype=torch.bfloat16).forward(img, taps=taps_u)
+    finally:
+        E.BackboneOp.fused_stem, E.BackboneOp.bneck_chain = saved
+    torch.cuda.synchronize()
+    for name in ('c1', 'c2', 'c3', 'c4'):
+        e = relerr(taps_f[name].float().cpu().numpy(), taps_u[name].float().cpu().numpy())
+        print('fused vs unfused %s relerr %.3e' % (name, e))
+        assert e < 2e-2, name
+    for side in ('left', 'right'):
+        d = (outs_f[2]['pd_joint_xyz_' + side] - outs_u[2]['pd_joint_xyz_' + side]).norm(dim=-1).mean().item() * 1e3
+        assert d < 0.05, (side, d)         # mm; the bf16 envelope against the reference is ~0.004 mm at this stage
+
+
+def test_engine_uint8_frames_equal_normalised_input(dir_state):
+    """uint8 BGR frames through the fused stem (apps/eval.py:59-61 inside dir_stem_pool_forward) == the float path on the oracle-
+    normalised image, bit for bit"""
+    from oracle import image_prep as IP
+    sd, _ = dir_state
+    rng = np.random.RandomState(11)
+    frames = rng.randint(0, 256, size=(2, 256, 256, 3)).astype(np.uint8)
+    x = torch.from_numpy(IP.normalize_u8_bgr(frames)).cuda()
+    eng = DirEngine(sd, dtype=torch.bfloat16)
+    a = eng.forward(torch.from_numpy(frames).cuda())
+    b = eng.forward(x)
+    torch.cuda.synchronize()
+    for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_uv_left'):
+        assert torch.equal(a[2][k], b[2][k]), k
+    assert torch.equal(a[3]['seg'], b[3]['seg'])
