@@ -44,7 +44,8 @@ struct GridArgs {
 };
 
 constexpr int GT_ROWS = 32;            // 21 tokens padded to two 16-row MFMA tiles
-constexpr int GT_THR = 512, GT_WAVES = GT_THR / 64;   // one 16-column output tile per wave (8 tiles of the 128-wide MLP layers)
+constexpr int GT_THR = 512;             // 8 waves: one 16-column output tile per wave (8 tiles of the 128-wide MLP layers)
+static_assert(GT_THR / 64 == 128 / 16, "grid_tokens: one output tile per wave");
 constexpr int LDS_S = 256 + 2, LDS_H = 128 + 2;
 
 // second Conv1d of a token MLP on the matrix cores: acc[m] += hid[32 x 128] * w2t[128 x 128]; wave w owns output column tile w
