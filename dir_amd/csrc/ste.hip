@@ -278,18 +278,34 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         const float scale = 0.17677669529663687f;                       // 32 ** -0.5
         {
             const int li = lane & 15, lk = lane >> 4;
-            for (int tile = wave; tile < HEADS * 9; tile += NWAVES) {
+            // a wave's tiles (wave, wave + 8, ...: five or four of them) advance together through K: five independent accumulator
+            // chains hide the MFMA latency a single dependent chain of 8 exposes; per tile the k order is unchanged (exact fp32)
+            constexpr int TPW = (HEADS * 9 + NWAVES - 1) / NWAVES;
+            const float* qa[TPW]; const float* kb[TPW];
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = min(wave + NWAVES * i, HEADS * 9 - 1);
                 const int h = tile / 9, mt = (tile - h * 9) / 3, nt = tile - h * 9 - mt * 3;
-                const float* qa = s_big + (mt * 16 + li) * LDQ + h * HD + lk;
-                const float* kb = s_big + (nt * 16 + li) * LDQ + 128 + h * HD + lk;
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                qa[i] = s_big + (mt * 16 + li) * LDQ + h * HD + lk;
+                kb[i] = s_big + (nt * 16 + li) * LDQ + 128 + h * HD + lk;
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
-                for (int kk = 0; kk < HD / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[4 * kk], kb[4 * kk], acc, 0, 0, 0);
-                const int col = nt * 16 + li;
-                if (col < KP) {
+            for (int kk = 0; kk < HD / 4; ++kk)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        s_p[(h * NTP + mt * 16 + lk * 4 + r) * LDP + col] = col < NT ? acc[r] * scale : 0.f;
+                for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[i][4 * kk], kb[i][4 * kk], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = wave + NWAVES * i;
+                if (tile < HEADS * 9) {
+                    const int h = tile / 9, mt = (tile - h * 9) / 3, nt = tile - h * 9 - mt * 3;
+                    const int col = nt * 16 + li;
+                    if (col < KP) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            s_p[(h * NTP + mt * 16 + lk * 4 + r) * LDP + col] = col < NT ? acc[i][r] * scale : 0.f;
+                    }
                 }
             }
         }
@@ -325,20 +341,29 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
         // (probability columns 42,43 and v rows 42..47 are zero)
         {
             const int li = lane & 15, lk = lane >> 4;
-            for (int tile = wave; tile < HEADS * 6; tile += NWAVES) {
-                const int h = tile / 6, mt = (tile - h * 6) >> 1, nt = tile & 1;
-                const float* pa = s_p + (h * NTP + mt * 16 + li) * LDP + lk;
-                const float* vb = s_big + lk * LDQ + 256 + h * HD + nt * 16 + li;
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            constexpr int TPW = HEADS * 6 / NWAVES;                     // 3 tiles per wave, advanced together (independent chains)
+            const float* pa[TPW]; const float* vb[TPW];
+            f32x4 acc[TPW];
 #pragma unroll
-                for (int kk = 0; kk < KP / 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * kk], vb[4 * kk * LDQ], acc, 0, 0, 0);
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = wave + NWAVES * i, h = tile / 6, mt = (tile - h * 6) >> 1, nt = tile & 1;
+                pa[i] = s_p + (h * NTP + mt * 16 + li) * LDP + lk;
+                vb[i] = s_big + lk * LDQ + 256 + h * HD + nt * 16 + li;
+                acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kk = 0; kk < KP / 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[i][4 * kk], vb[i][4 * kk * LDQ], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = wave + NWAVES * i, h = tile / 6, mt = (tile - h * 6) >> 1, nt = tile & 1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int t = mt * 16 + lk * 4 + r;
                     if (t < NT) {
-                        if constexpr (WBF16) s_nb[t * LDB + h * HD + nt * 16 + li] = f2bf_rne(acc[r]);
-                        else s_n[t * LDX + h * HD + nt * 16 + li] = acc[r];
+                        if constexpr (WBF16) s_nb[t * LDB + h * HD + nt * 16 + li] = f2bf_rne(acc[i][r]);
+                        else s_n[t * LDX + h * HD + nt * 16 + li] = acc[i][r];
                     }
                 }
             }
