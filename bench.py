@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--inflight', type=int, default=2, help='forwards in flight per GPU (engine.ForwardPipeline: one captured graph + '
+                    'stream + input batch per slot, steps alternate between them); 1 = one graph replayed back to back')
     ap.add_argument('--no-autotune', action='store_true', help='keep the library heuristic for every conv layer')
     ap.add_argument('--autotune-cache', default=None, help='JSON file: load the per-layer variants if it exists, else tune and save '
                     '(profiling runs use it to keep the exploration out of the trace)')
@@ -78,13 +80,37 @@ def main():
             if args.autotune_cache and rank == 0:
                 with open(args.autotune_cache, 'w') as f:
                     json.dump(eng.export_tuning(B), f)
+    serial_ms = None
     if args.no_graph:
         step = fwd
-    else:
+        args.inflight = 1
+    elif args.inflight <= 1:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             outs = fwd()
         step = graph.replay
+    else:
+        # steps alternate between `inflight` slots (own stream, graph, synthetic input batch; shared weights): step k's forward
+        # overlaps step k-1's.  Every step is still one whole B-image forward; the timed region is closed by a device-wide sync.
+        imgs = [img] + [torch.randn(B, 3, 256, 256, device=dev, generator=g) for _ in range(args.inflight - 1)]
+        pipe = E.ForwardPipeline(eng, imgs)
+        outs = pipe.outs[0]
+        counter = [0]
+
+        def step():
+            pipe.launch(counter[0] % args.inflight, after_current_stream=False)
+            counter[0] += 1
+
+        def one_slot():
+            pipe.launch(0, after_current_stream=False)
+        for _ in range(3):
+            one_slot()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            one_slot()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - t0) / 10 * 1e3      # same graphs, one forward at a time (reported beside `value`)
 
     def barrier():
         D.barrier(dev)
@@ -186,7 +212,8 @@ def main():
                 'dtype': args.dtype, 'data': 'synthetic',
                 'config': {'workload': 'BASELINE configs[1]: batch 64 synthetic 256x256 per GPU, ResNet-50 + init '
                                        'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads',
-                           'batch_per_gpu': B, 'graph': not args.no_graph, 'weights': 'synthetic (dir_amd.synth seed 1234)',
+                           'batch_per_gpu': B, 'graph': not args.no_graph, 'forwards_in_flight': args.inflight,
+                           'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3), 'weights': 'synthetic (dir_amd.synth seed 1234)',
                            'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite},
                 'roofline': roof, 'cpu_baseline': cpu}
         print(json.dumps(line))

@@ -213,3 +213,42 @@ def test_engine_uint8_frames_equal_normalised_input(dir_state):
     for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_uv_left'):
         assert torch.equal(a[2][k], b[2][k]), k
     assert torch.equal(a[3]['seg'], b[3]['seg'])
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_forward_pipeline_is_bit_identical(dir_state, dt):
+    """engine.ForwardPipeline: two captured forwards in flight on two streams (refilled inputs, interleaved launches) return
+    exactly what one forward at a time returns -- images are independent (models/dir.py:513-540, eval mode), the slots share
+    nothing but the weights."""
+    from dir_amd.engine import ForwardPipeline
+    sd, img = dir_state
+    eng = DirEngine(sd, dtype=dt)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    batches = [img] + [torch.randn(img.shape, device='cuda', generator=g) for _ in range(3)]
+    keys = ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_uv_right', 'pd_offset')
+    want = []
+    for x in batches:
+        o = eng.forward(x)
+        torch.cuda.synchronize()
+        want.append(([{k: o[s][k].clone() for k in keys} for s in range(3)], o[3]['seg'].clone(), o[3]['proj_feat'].clone()))
+    slots = [torch.empty_like(img), torch.empty_like(img)]
+    pipe = ForwardPipeline(eng, slots)
+    assert len(pipe) == 2
+    for rnd in range(3):                                  # several rounds: every slot is reused with new contents
+        order = [(0, (2 * rnd) % 4), (1, (2 * rnd + 1) % 4)]
+        for slot, bi in order:
+            slots[slot].copy_(batches[bi])                # refill on the current stream; launch() orders the replay after it
+            pipe.launch(slot)
+        for slot, bi in reversed(order):
+            o = pipe.wait(slot)
+            stages, seg, pf = want[bi]
+            for s in range(3):
+                for k in keys:
+                    assert torch.equal(o[s][k], stages[s][k]), (rnd, slot, s, k)
+            assert torch.equal(o[3]['seg'], seg) and torch.equal(o[3]['proj_feat'], pf)
+    # stream-ordered hand-over (no host wait)
+    slots[0].copy_(batches[3]); pipe.launch(0)
+    o = pipe.outputs(0)
+    got = o[2]['pd_mesh_xyz_left'].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want[3][0][2]['pd_mesh_xyz_left'])

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, via gpurun): tools/profile_round.sh <tag>      e.g. r01_f
+# (one forward in flight: uncontended kernel durations, as in the live roofline pass of bench.py)
 # kernel trace + the two PMC passes (FETCH_SIZE, WRITE_SIZE) of the bench command; results under gpurun_out/<tag>/
 tag=$1
 export TMPDIR=/tmp
@@ -9,7 +10,7 @@ mkdir -p $out
 # the per-layer kernel choice is made once OUTSIDE the profiler and re-used, so the traces hold only the timed configuration
 rm -f /tmp/dir_autotune.json
 python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
-cmd="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --dump-conv --autotune-cache /tmp/dir_autotune.json"
+cmd="python $R/bench.py --inflight 1 --steps 10 --warmup 3 --no-cpu-baseline --dump-conv --autotune-cache /tmp/dir_autotune.json"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $cmd > $out/pmcF.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $cmd > $out/pmcW.log 2>&1 )
