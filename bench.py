@@ -146,11 +146,12 @@ def main():
         alg_bytes = [r[5] for r in E.PROFILE if r[0] == tag]
         if args.dump_conv:
             agg = {}
-            for t_, f_, e0, e1, shp, _, _ in E.PROFILE:
-                a = agg.setdefault((t_, shp), [0, 0.0, 0.0])
-                a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f_
-            for (t_, shp), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                sys.stderr.write('%-24s %-40s x%-3d %8.3f ms/step %8.1f TFLOP/s\n' % (t_, shp, n // reps, ms / reps, fl / ms / 1e9))
+            for t_, f_, e0, e1, shp, by_, _ in E.PROFILE:
+                a = agg.setdefault((t_, shp), [0, 0.0, 0.0, 0.0])
+                a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f_; a[3] += by_
+            for (t_, shp), (n, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                sys.stderr.write('%-24s %-40s x%-3d %8.3f ms/step %8.1f TFLOP/s %8.1f GB/s\n' % (t_, shp, n // reps, ms / reps, fl / ms / 1e9, by / ms / 1e6))
+        E_PROFILE = E.PROFILE
         E.PROFILE = None
         dom = [(f_, ms) for t_, f_, ms in rec if t_ == tag]
         n_launch = len(dom) // reps
@@ -176,7 +177,22 @@ def main():
         else:
             head = {'bound': 'mfma', 'kernel': tag, 'achieved': round(achieved / 1e12, 2), 'peak': PEAK[args.dtype] / 1e12,
                     'unit': 'TFLOP/s', 'frac': round(frac_mfma, 4)}
-        roof = dict(head, traffic=traffic, traffic_source=traffic_src, frac_mfma=round(frac_mfma, 4), frac_hbm=round(frac_hbm, 4),
+        # the same launches split by arithmetic intensity against the machine balance (peak FLOP/s : peak B/s): each class priced
+        # against the roof that bounds it
+        balance = PEAK[args.dtype] / HBM_PEAK
+        cls = {'hbm': [0, 0.0, 0.0, 0.0], 'mfma': [0, 0.0, 0.0, 0.0]}
+        for r, ms in zip([r for r in E_PROFILE if r[0] == tag], [ms for t_, _, ms in rec if t_ == tag]):
+            c = cls['hbm' if r[1] / r[5] < balance else 'mfma']
+            c[0] += 1; c[1] += ms; c[2] += r[1]; c[3] += r[5]
+        by_class = {}
+        for k, (n, ms, fl, by) in cls.items():
+            if n:
+                ach = (by if k == 'hbm' else fl) / (ms * 1e-3)
+                pk = HBM_PEAK if k == 'hbm' else PEAK[args.dtype]
+                by_class[k] = {'launches_per_step': n // reps, 'ms_per_step': round(ms / reps, 3),
+                               'achieved': round(ach / (1e9 if k == 'hbm' else 1e12), 1), 'unit': 'GB/s' if k == 'hbm' else 'TFLOP/s',
+                               'frac': round(ach / pk, 4)}
+        roof = dict(head, by_class=by_class, traffic=traffic, traffic_source=traffic_src, frac_mfma=round(frac_mfma, 4), frac_hbm=round(frac_hbm, 4),
                     achieved_tflops=round(achieved / 1e12, 2), achieved_gbps=round(hbm_rate / 1e9, 1),
                     alg_bytes_per_launch=round(bytes_per_launch),
                     launches_per_step=n_launch, avg_launch_us=round(ms_per_launch * 1e3, 2),
