@@ -171,3 +171,15 @@ def synth_input(name, shape, seed=1234, kind='normal', lo=-1.0, hi=1.0, scale=1.
     if kind == 'normal':
         return (g.normal(0, 1, shape) * scale).astype(np.float32)
     return g.uniform(lo, hi, shape).astype(np.float32)
+
+
+def loss_faces(side, seed=1234):
+    """Triangle table for the mesh losses (models/loss.py): the synthetic `f` with its few degenerate rows (a random index drawn
+    twice) repaired -- on a zero-area triangle the reference's normal is normalised rounding noise, so nothing can be pinned."""
+    f = np.array(synthetic_mano_tables(side, seed)['f'], np.int64)
+    for i in range(f.shape[0]):
+        a, b, c = f[i]
+        if a == b or a == c or b == c:
+            f[i] = [a, (a + 1 + i % 7) % 778, (a + 9 + i % 11) % 778]
+    assert not ((f[:, 0] == f[:, 1]) | (f[:, 0] == f[:, 2]) | (f[:, 1] == f[:, 2])).any()
+    return f

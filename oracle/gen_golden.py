@@ -395,8 +395,91 @@ def gen_imgprep():
     save('g11_imgprep', img=imgs, y=np.stack(outs))
 
 
+# ----------------------------------------------------------------------------- G8 training objective (forward)
+def gen_loss():
+    """The loss block is inline in DIR.forward (models/dir.py:542-594) and runs only in training mode: the reference model is run
+    with .train() (batch-statistics BN) on seeded input, once with placeholder targets to obtain its predictions, then with targets
+    built AROUND those predictions (small and large residuals: both SmoothL1 branches) -- the fixture holds that second pass's
+    predictions, targets and the 42 loss scalars.  Faces: synth.loss_faces (the synthetic MANO triangles with the degenerate rows repaired; regenerated by the tests)."""
+    from models.dir import DIR
+    net = DIR(21, 'unused', 0)
+    load_synth(net)
+    net.train()
+    for side in ('left', 'right'):      # non-degenerate triangles (synth.loss_faces); the forward pass never reads the faces
+        fc = torch.from_numpy(synth.loss_faces(side, SEED))
+        getattr(net, 'normal_loss_' + side).face = fc
+        getattr(net, 'edge_loss_' + side).face = fc
+    B = 2
+    img = torch.from_numpy(synth.synth_input('loss.img', (B, 3, 256, 256), SEED))
+    rng = np.random.RandomState(77)
+
+    def targets_around(outs):
+        t, m = {}, {}
+        last = outs[2]
+        for side in ('left', 'right'):
+            c = rng.normal(0, 0.05, (B, 1, 3)).astype(np.float32)
+            m['center_' + side] = torch.from_numpy(c)
+            for key, pk, n in (('joint_3d_', 'pd_joint_xyz_', 21), ('mesh_3d_', 'pd_mesh_xyz_', 778)):
+                p = last[pk + side].detach().numpy()
+                noise = np.where(rng.rand(B, n, 3) < 0.5, rng.normal(0, 0.0005, (B, n, 3)), rng.normal(0, 0.01, (B, n, 3)))
+                t[key + side] = torch.from_numpy((p + c + noise).astype(np.float32))
+            for key, pk, n in (('joint_2d_', 'pd_joint_uv_', 21), ('mesh_2d_', 'pd_mesh_uv_', 778)):
+                p = (last[pk + side] if pk + side in last else None)
+                p = p.detach().numpy() if p is not None else np.zeros((B, n, 2), np.float32)
+                noise = np.where(rng.rand(B, n, 2) < 0.5, rng.normal(0, 0.004, (B, n, 2)), rng.normal(0, 0.05, (B, n, 2)))
+                uvd = np.concatenate([p + noise, rng.normal(0, 1, (B, n, 1))], axis=2)
+                t[key + side] = torch.from_numpy(uvd.astype(np.float32))
+        seg_lo = rng.randint(0, 3, (B, 1, 16, 16))
+        seg = np.repeat(np.repeat(seg_lo, 16, axis=2), 16, axis=3).astype(np.uint8)
+        flip = rng.rand(B, 1, 256, 256) < 0.02
+        seg = np.where(flip, rng.randint(0, 3, seg.shape), seg).astype(np.uint8)
+        dense_lo = rng.randint(0, 256, (B, 3, 64, 64))
+        dense = np.repeat(np.repeat(dense_lo, 4, axis=2), 4, axis=3).astype(np.uint8)
+        t['seg'] = torch.from_numpy(seg.astype(np.float32))
+        t['dense'] = torch.from_numpy(dense.astype(np.float32) / np.float32(255.0))
+        return t, m, seg, dense
+
+    captured = {}
+
+    def grab(mod, args, out):
+        captured.setdefault(mod, []).append(out)
+    h0 = net.init_regressor.register_forward_hook(grab)
+    h1 = net.decoder.register_forward_hook(grab)
+    zeros_t = {k + s: torch.zeros(B, n, 3) for s in ('left', 'right')
+               for k, n in (('joint_2d_', 21), ('mesh_2d_', 778), ('joint_3d_', 21), ('mesh_3d_', 778))}
+    zeros_t.update(seg=torch.zeros(B, 1, 256, 256), dense=torch.zeros(B, 3, 256, 256))
+    zeros_m = {'center_left': torch.zeros(B, 1, 3), 'center_right': torch.zeros(B, 1, 3)}
+    with torch.no_grad():
+        net({'img': img}, zeros_t, zeros_m)
+    iter0 = [captured[net.init_regressor][0]] + captured[net.decoder][0]['result_list']
+    target, meta, seg_u8, dense_u8 = targets_around(iter0)
+    captured.clear()
+    with torch.no_grad():
+        outs, loss = net({'img': img}, target, meta)
+    h0.remove(); h1.remove()
+    iter_outs = [captured[net.init_regressor][0]] + captured[net.decoder][0]['result_list']
+    assert len(loss) == 42, len(loss)
+    out = {'gt_seg_u8': seg_u8, 'gt_dense_u8': dense_u8}
+    for k, v in target.items():
+        if k not in ('seg', 'dense'):
+            out['gt_' + k] = v
+    for k, v in meta.items():
+        out['gt_' + k] = v
+    for i, o in enumerate(iter_outs):
+        for k in ('pd_joint_uv_', 'pd_mesh_uv_', 'pd_joint_xyz_', 'pd_mesh_xyz_'):
+            for side in ('left', 'right'):
+                out['s%d.%s%s' % (i, k, side)] = o[k + side]
+        out['s%d.pd_offset' % i] = o['pd_offset']
+    out['seg'] = outs[3]['seg']
+    out['dense'] = outs[3]['dense']
+    for k, v in loss.items():
+        out['loss.' + k] = np.float64(float(v))
+        print('   %-20s %.6f' % (k, float(v)))
+    save('g8_loss', **out)
+
+
 GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
-        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep}
+        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

@@ -32,3 +32,18 @@ def maxabs(a, b):
 def relerr(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def loss_case(g):
+    """inputs of the G8 fixture in the shape oracle.losses / dir_amd.models.loss take them: (per-stage prediction dicts, ground
+    truth dict, (faces_left, faces_right), seg logits, dense prediction, gt seg [B,1,256,256] f32, gt dense [B,3,256,256] f32)"""
+    from dir_amd import synth
+    preds = []
+    for i in range(3):
+        d = {k.split('.', 1)[1]: g[k] for k in g if k.startswith('s%d.' % i)}
+        preds.append(d)
+    gt = {k[3:]: g[k] for k in g if k.startswith('gt_') and not k.endswith('_u8')}
+    faces = tuple(synth.loss_faces(side, 1234) for side in ('left', 'right'))
+    gt_seg = g['gt_seg_u8'].astype(np.float32)
+    gt_dense = g['gt_dense_u8'].astype(np.float32) / np.float32(255.0)
+    return preds, gt, faces, g['seg'], g['dense'], gt_seg, gt_dense

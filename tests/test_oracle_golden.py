@@ -254,3 +254,35 @@ def test_image_prep_matches_reference(golden):
     from oracle.image_prep import normalize_u8_bgr
     g = golden('g11_imgprep')
     assert np.array_equal(normalize_u8_bgr(g['img']), g['y'])          # bit-exact: same fp32 operation order
+
+
+# ------------------------------------------------------------------ G8 training objective, forward (a13)
+def test_losses_match_reference(golden):
+    """oracle/losses.py against the 42 scalars of the reference's own DIR.forward in training mode (models/dir.py:542-594)"""
+    from conftest import loss_case
+    from oracle import losses as OL
+    g = golden('g8_loss')
+    preds, gt, faces, seg, dense, gt_seg, gt_dense = loss_case(g)
+    got = dict(OL.dense_losses(seg, dense, gt_seg, gt_dense))
+    for i in range(3):
+        for k, v in OL.stage_losses(preds[i], gt, faces).items():
+            got['%s_%d' % (k, i)] = v
+    want = {k[5:]: float(g[k]) for k in g if k.startswith('loss.')}
+    assert set(got) == set(want) and len(want) == 42
+    for k in sorted(want):
+        assert abs(got[k] - want[k]) <= 2e-6 * max(1.0, abs(want[k])) + 1e-5 * abs(want[k]), (k, got[k], want[k])
+
+
+def test_loss_interpolation_matches_torch():
+    """the two F.interpolate modes of models/dir.py:565-566 at sizes where the taps are not the trivial half-half ones"""
+    import torch
+    import torch.nn.functional as F
+    from oracle import losses as OL
+    rng = np.random.RandomState(3)
+    for H, S in ((256, 32), (96, 32), (100, 16)):
+        x = rng.rand(2, 3, H, H).astype(np.float32)
+        want = F.interpolate(torch.from_numpy(x), (S, S), mode='bilinear').numpy()
+        assert maxabs(OL.interpolate_bilinear(x, S), want) < 2e-7
+        lab = rng.randint(0, 3, (2, 1, H, H)).astype(np.float32)
+        want = F.interpolate(torch.from_numpy(lab), (S, S), mode='nearest').numpy()
+        assert np.array_equal(OL.interpolate_nearest(lab, S), want)
