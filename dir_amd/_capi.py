@@ -75,12 +75,23 @@ class EvalInputs(C.Structure):
                 ('verts2d_gt', C.c_void_p * 2), ('cam', C.c_void_p), ('jr', C.c_void_p * 2)]
 
 
+class LossPred(C.Structure):
+    _fields_ = [('joint_uv', C.c_void_p * 2), ('mesh_uv', C.c_void_p * 2), ('joint_xyz', C.c_void_p * 2),
+                ('mesh_xyz', C.c_void_p * 2), ('offset', C.c_void_p)]
+
+
+class LossTarget(C.Structure):
+    _fields_ = [('joint_2d', C.c_void_p * 2), ('mesh_2d', C.c_void_p * 2), ('joint_3d', C.c_void_p * 2),
+                ('mesh_3d', C.c_void_p * 2), ('center', C.c_void_p * 2), ('faces', C.c_void_p * 2),
+                ('c2', C.c_int32), ('n_faces', C.c_int32)]
+
+
 class EvalOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('joint_err', 'vert_err', 'joint2d_err', 'vert2d_err', 'joints_pd', 'joints_gt',
                                           'root_err')]
 
 
-ABI_VERSION = 8          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 9          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -94,6 +105,9 @@ _SIGNATURES = {
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_image_normalize_forward': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _p]),
     'dir_stem_prep_s2d_u8': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _i, _i, _i, _p]),
+    'dir_stage_losses_forward': (C.c_int, [C.POINTER(LossPred), C.POINTER(LossTarget), C.c_float, _p, _p, _i, _p]),
+    'dir_dense_losses_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_dense_losses_forward': (C.c_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.c_float, _p, C.c_longlong, _p, _i, _i, _i, _i, _p]),
     'dir_bottleneck_chain_forward': (C.c_int, [C.POINTER(BneckChainParams), _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_stem_pool_forward': (C.c_int, [_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),

@@ -1,0 +1,389 @@
+// SURVEY 8a row a13 / 8f rank 2 (forward half): the training objective of the reference, models/dir.py:542-594, as device kernels.
+//   * stage_loss_kernel: the 13 terms of one refinement stage (models/dir.py:571-592) -- SmoothL1 with the 0.01 knee
+//     (models/loss.py:68-85) on joint / mesh uv and on the /0.15-normalised joint / mesh xyz, EdgeLengthLoss (:41-60) and
+//     NormalVectorLoss (:11-33) over the 1538 MANO triangles, SmoothL1 on the inter-hand offset.  One workgroup per (sample,
+//     hand): both normalised meshes staged once in LDS (18.7 KB), triangles gathered from LDS, per-sample partial sums written to a
+//     scratch table and reduced over the batch in a fixed order by a second tiny launch (deterministic; no float atomics).
+//   * dense_pixel_kernel / lovasz_kernel / dense_final_kernel: models/dir.py:562-569 -- F.interpolate (nearest labels, bilinear
+//     dense map), class-weighted cross entropy, SmoothL1 on the dense map, and lovasz_softmax (models/lovasz_loss.py:155-202) on the
+//     raw logits exactly as the reference calls it.  The descending sort of the per-class errors is rocPRIM's segmented radix sort
+//     (a library primitive, like a plain library GEMM); the Jaccard scan runs one workgroup per class with a carried prefix.
+// Elementwise arithmetic is fp32 in the reference's operation order (contraction off); sums accumulate in fp64.
+// HBM-bound and tiny: 2 x (778 x 5 + ...) floats per sample and stage.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "dir_common.h"
+
+namespace dir {
+namespace {
+
+constexpr int NV = 778, NJ = 21, LT = 256, NTERM = 13;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum of v over the workgroup (every thread gets it); s_red: NW doubles
+template <int NW> __device__ __forceinline__ double block_sum_d(double v, double* s_red, int tid) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += s_red[w];
+    return t;
+}
+
+// models/loss.py:74-81 for one element
+__device__ __forceinline__ float smooth_l1_term(float x, float y) {
+#pragma clang fp contract(off)
+    const float z = x - y, az = fabsf(z);
+    return az < 0.01f ? 0.5f * (z * z) : 0.01f * (az - 0.005f);
+}
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) {
+#pragma clang fp contract(off)
+    return V3{a.x - b.x, a.y - b.y, a.z - b.z};
+}
+__device__ __forceinline__ float sumsq(V3 a) {
+#pragma clang fp contract(off)
+    return a.x * a.x + a.y * a.y + a.z * a.z;
+}
+__device__ __forceinline__ V3 normalize(V3 a) {           // F.normalize(p=2, eps=1e-12)
+    const float n = fmaxf(sqrtf(sumsq(a)), 1e-12f);
+    return V3{a.x / n, a.y / n, a.z / n};
+}
+__device__ __forceinline__ float dot(V3 a, V3 b) {
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+#pragma clang fp contract(off)
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+struct StageArgs {
+    dir_loss_pred p;
+    dir_loss_target g;
+    double* scratch;      // [B][NTERM]
+    int B;
+};
+
+// slots: 0,1 joint uv L/R; 2,3 mesh uv; 4,5 joint xyz; 6,7 mesh xyz; 8,9 edge; 10,11 normal; 12 offset
+__global__ __launch_bounds__(LT) void stage_loss_kernel(StageArgs a) {
+    __shared__ float s_pm[NV * 3], s_gm[NV * 3];
+    __shared__ double s_red[LT / 64];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const float* cen = a.g.center[h] + (size_t)b * 3;
+    const float c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    double* out = a.scratch + (size_t)b * NTERM;
+    // ---- mesh xyz: pred / 0.15 vs (gt - center) / 0.15 (models/dir.py:556-560,576-577), kept in LDS for the triangle terms
+    double acc = 0;
+    {
+        const float* pm = a.p.mesh_xyz[h] + (size_t)b * NV * 3;
+        const float* gm = a.g.mesh_3d[h] + (size_t)b * NV * 3;
+        for (int i = tid; i < NV * 3; i += LT) {
+            const int c = i % 3;
+            const float x = pm[i] / 0.15f, y = (gm[i] - (c == 0 ? c0 : c == 1 ? c1 : c2)) / 0.15f;
+            s_pm[i] = x; s_gm[i] = y;
+            acc += (double)smooth_l1_term(x, y);
+        }
+    }
+    double t = block_sum_d<LT / 64>(acc, s_red, tid);        // (also the barrier that publishes s_pm / s_gm)
+    if (tid == 0) out[6 + h] = t / (NV * 3);
+    // ---- joint xyz
+    acc = 0;
+    if (tid < NJ * 3) {
+        const int c = tid % 3;
+        const float x = a.p.joint_xyz[h][(size_t)b * NJ * 3 + tid] / 0.15f;
+        const float y = (a.g.joint_3d[h][(size_t)b * NJ * 3 + tid] - (c == 0 ? c0 : c == 1 ? c1 : c2)) / 0.15f;
+        acc = (double)smooth_l1_term(x, y);
+    }
+    t = block_sum_d<LT / 64>(acc, s_red, tid);
+    if (tid == 0) out[4 + h] = t / (NJ * 3);
+    // ---- joint uv / mesh uv against the first two columns of the [.., c2] targets
+    acc = 0;
+    if (tid < NJ * 2) {
+        const int j = tid >> 1, c = tid & 1;
+        acc = (double)smooth_l1_term(a.p.joint_uv[h][(size_t)b * NJ * 2 + tid], a.g.joint_2d[h][((size_t)b * NJ + j) * a.g.c2 + c]);
+    }
+    t = block_sum_d<LT / 64>(acc, s_red, tid);
+    if (tid == 0) out[0 + h] = t / (NJ * 2);
+    acc = 0;
+    for (int i = tid; i < NV * 2; i += LT) {
+        const int v = i >> 1, c = i & 1;
+        acc += (double)smooth_l1_term(a.p.mesh_uv[h][(size_t)b * NV * 2 + i], a.g.mesh_2d[h][((size_t)b * NV + v) * a.g.c2 + c]);
+    }
+    t = block_sum_d<LT / 64>(acc, s_red, tid);
+    if (tid == 0) out[2 + h] = t / (NV * 2);
+    // ---- triangles: edge lengths (models/loss.py:46-60) and normals (:16-33)
+    double e_acc = 0, n_acc = 0;
+    const int32_t* face = a.g.faces[h];
+    for (int f = tid; f < a.g.n_faces; f += LT) {
+        const int i0 = face[f * 3], i1 = face[f * 3 + 1], i2 = face[f * 3 + 2];
+        const V3 p0 = ld3(s_pm + i0 * 3), p1 = ld3(s_pm + i1 * 3), p2 = ld3(s_pm + i2 * 3);
+        const V3 g0 = ld3(s_gm + i0 * 3), g1 = ld3(s_gm + i1 * 3), g2 = ld3(s_gm + i2 * 3);
+        {
+            const float d1o = sqrtf(sumsq(sub(p0, p1)) + 1e-12f), d2o = sqrtf(sumsq(sub(p0, p2)) + 1e-12f), d3o = sqrtf(sumsq(sub(p1, p2)) + 1e-12f);
+            const float d1g = sqrtf(sumsq(sub(g0, g1)) + 1e-12f), d2g = sqrtf(sumsq(sub(g0, g2)) + 1e-12f), d3g = sqrtf(sumsq(sub(g1, g2)) + 1e-12f);
+            e_acc += (double)fabsf(d1o - d1g) + (double)fabsf(d2o - d2g) + (double)fabsf(d3o - d3g);
+        }
+        {
+            const V3 v1o = normalize(sub(p1, p0)), v2o = normalize(sub(p2, p0)), v3o = normalize(sub(p2, p1));
+            const V3 v1g = normalize(sub(g1, g0)), v2g = normalize(sub(g2, g0));
+            const V3 ng = normalize(cross(v1g, v2g));
+            n_acc += (double)fabsf(dot(v1o, ng)) + (double)fabsf(dot(v2o, ng)) + (double)fabsf(dot(v3o, ng));
+        }
+    }
+    t = block_sum_d<LT / 64>(e_acc, s_red, tid);
+    if (tid == 0) out[8 + h] = t / (3.0 * a.g.n_faces);
+    t = block_sum_d<LT / 64>(n_acc, s_red, tid);
+    if (tid == 0) out[10 + h] = t / (3.0 * a.g.n_faces);
+    // ---- offset (models/dir.py:561,591-592): (center_right - center_left) / 0.15
+    if (h == 0) {
+        acc = 0;
+        if (tid < 3) {
+            const float y = (a.g.center[1][(size_t)b * 3 + tid] - a.g.center[0][(size_t)b * 3 + tid]) / 0.15f;
+            acc = (double)smooth_l1_term(a.p.offset[(size_t)b * 3 + tid], y);
+        }
+        acc = wave_sum_d(acc);
+        if (tid == 0) out[12] = acc / 3.0;
+    }
+}
+
+// batch means in a fixed order: term k = weight_k * sum_b scratch[b][k] / B
+__global__ __launch_bounds__(64) void stage_reduce_kernel(const double* __restrict__ scratch, float* __restrict__ out, int B, float coord_weight) {
+    const int k = threadIdx.x;
+    if (k >= NTERM) return;
+    double s = 0;
+    for (int b = 0; b < B; ++b) s += scratch[(size_t)b * NTERM + k];
+    const double w = (k < 8 || k == 12) ? (double)coord_weight : (k < 10 ? 1.0 : 0.1);
+    out[k] = (float)(s / B * w);
+}
+
+// ------------------------------------------------------------------------------------------------ seg / dense / lovasz
+struct DenseArgs {
+    const float* seg; const float* dense; const float* gt_seg; const float* gt_dense;
+    float* keys; unsigned char* vals;       // [3][P]
+    double* partial;                        // [nwg][6]: sum w nll, sum w, dense smooth-l1 sum, fg count of class 0..2
+    int B, S, H, W, P, chunks;
+    float cw[3];
+};
+
+__global__ __launch_bounds__(LT) void dense_pixel_kernel(DenseArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double s_red[LT / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, S = a.S, pix = blockIdx.x * LT + tid;
+    const bool ok = pix < S * S;
+    const int oy = ok ? pix / S : 0, ox = ok ? pix - oy * S : 0;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if (ok) {
+        // F.interpolate(nearest): source index floor(dst * in / out) (models/dir.py:565)
+        const int sy = min((int)floorf(oy * ((float)a.H / S)), a.H - 1), sx = min((int)floorf(ox * ((float)a.W / S)), a.W - 1);
+        int lab = (int)a.gt_seg[((size_t)b * a.H + sy) * a.W + sx];
+        lab = lab < 0 ? 0 : lab > 2 ? 2 : lab;
+        const size_t plane = (size_t)S * S;
+        const float* sg = a.seg + (size_t)b * 3 * plane + pix;
+        const float l0 = sg[0], l1 = sg[plane], l2 = sg[2 * plane];
+        // weighted cross entropy (models/dir.py:511,567)
+        const double m = fmax((double)l0, fmax((double)l1, (double)l2));
+        const double lse = m + log(exp(l0 - m) + exp(l1 - m) + exp(l2 - m));
+        const double nll = lse - (double)(lab == 0 ? l0 : lab == 1 ? l1 : l2);
+        const double w = a.cw[lab];
+        v[0] = w * nll; v[1] = w;
+        // lovasz errors |fg - logit| per class (models/lovasz_loss.py:184-193; the reference passes raw logits)
+        const size_t p = (size_t)b * plane + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float fg = lab == c ? 1.f : 0.f, lc = c == 0 ? l0 : c == 1 ? l1 : l2;
+            a.keys[(size_t)c * a.P + p] = fabsf(fg - lc);
+            a.vals[(size_t)c * a.P + p] = lab == c;
+            v[3 + c] = lab == c;
+        }
+        // F.interpolate(bilinear, align_corners=False) of the dense target (models/dir.py:566) + SmoothL1
+        const float fy = fmaxf((oy + 0.5f) * ((float)a.H / S) - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * ((float)a.W / S) - 0.5f, 0.f);
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx), y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
+        const float wy1 = fy - y0, wy0 = 1.f - wy1, wx1 = fx - x0, wx0 = 1.f - wx1;
+        for (int c = 0; c < 3; ++c) {
+            const float* gd = a.gt_dense + ((size_t)b * 3 + c) * a.H * a.W;
+            const float r0 = wx0 * gd[(size_t)y0 * a.W + x0] + wx1 * gd[(size_t)y0 * a.W + x1];
+            const float r1 = wx0 * gd[(size_t)y1 * a.W + x0] + wx1 * gd[(size_t)y1 * a.W + x1];
+            const float t = wy0 * r0 + wy1 * r1;
+            v[2] += (double)smooth_l1_term(a.dense[((size_t)b * 3 + c) * plane + pix], t);
+        }
+    }
+    double* out = a.partial + ((size_t)b * a.chunks + blockIdx.x) * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double t = block_sum_d<LT / 64>(v[k], s_red, tid);
+        if (tid == 0) out[k] = t;
+    }
+}
+
+constexpr int LV_T = 1024;
+// one workgroup per class: loss_c = sum_i err_sorted[i] * (J_i - J_{i-1}), J_i = 1 - (G - cumfg_i) / (G + cumbg_i)
+// (models/lovasz_loss.py:19-31,194-197); result[c] = loss, result[3 + c] = G (0 -> class absent, skipped by 'present')
+__global__ __launch_bounds__(LV_T) void lovasz_kernel(const float* __restrict__ keys, const unsigned char* __restrict__ vals,
+                                                      const double* __restrict__ partial, int nwg, int P, double* __restrict__ result) {
+    __shared__ double s_red[LV_T / 64];
+    __shared__ int s_wsum[LV_T / 64];
+    __shared__ double s_prevJ;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double G = 0;
+    for (int i = 0; i < nwg; ++i) G += partial[(size_t)i * 6 + 3 + c];           // same order in every thread: identical value
+    const float* e = keys + (size_t)c * P;
+    const unsigned char* fgv = vals + (size_t)c * P;
+    long long carry = 0;                      // foreground count before this chunk
+    double prevJ = 0, acc = 0;                // J of the last element of the previous chunk (J_{-1} := 0: jaccard[0] is kept)
+    for (int base = 0; base < P; base += LV_T) {
+        const int i = base + tid;
+        const int fg = i < P ? (int)fgv[i] : 0;
+        // inclusive scan of fg over the chunk
+        int x = fg;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < LV_T / 64; ++w) {
+            const int s = s_wsum[w];
+            if (w < wave) woff += s;
+            total += s;
+        }
+        const long long cumfg = carry + woff + x;
+        const long long cumbg = (long long)(i + 1) - cumfg;
+        double J = 0;
+        if (i < P) J = 1.0 - (G - (double)cumfg) / (G + (double)cumbg);
+        // J of the previous element: lane - 1, or the previous wave's last lane, or the previous chunk's last element
+        double Jm = __shfl_up(J, 1, 64);
+        if (lane == 63) s_red[wave] = J;
+        __syncthreads();
+        if (lane == 0) Jm = wave == 0 ? prevJ : s_red[wave - 1];
+        if (i < P) acc += (double)e[i] * (J - Jm);
+        if (tid == LV_T - 1) s_prevJ = J;
+        __syncthreads();
+        prevJ = s_prevJ;
+        carry += total;
+    }
+    const double t = block_sum_d<LV_T / 64>(acc, s_red, tid);
+    if (tid == 0) { result[c] = t; result[3 + c] = G; }
+}
+
+__global__ void dense_final_kernel(const double* __restrict__ partial, int chunks, int B, int S, const double* __restrict__ lov,
+                                   float dense_weight, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double wn = 0, w = 0, dsum = 0;
+    for (int b = 0; b < B; ++b) {
+        double d = 0;
+        for (int k = 0; k < chunks; ++k) {
+            const double* p = partial + ((size_t)b * chunks + k) * 6;
+            wn += p[0]; w += p[1]; d += p[2];
+        }
+        dsum += d / (3.0 * S * S);              // SmoothL1Loss: per-sample mean, then the batch mean
+    }
+    double ls = 0; int n = 0;
+    for (int c = 0; c < 3; ++c)
+        if (lov[3 + c] > 0) { ls += lov[c]; ++n; }
+    out[0] = (float)(wn / w * 0.1 * dense_weight);
+    out[1] = (float)(dsum / B * dense_weight);
+    out[2] = (float)((n ? ls / n : 0.0) * 0.1 * dense_weight);
+}
+
+// workspace carve-up (all offsets 256-byte aligned)
+struct DenseWs { size_t keys_in, keys_out, vals_in, vals_out, offs, partial, lov, temp, temp_bytes, total; };
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+int dense_ws(int B, int S, DenseWs& w) {
+    const size_t P = (size_t)B * S * S;
+    const int chunks = (S * S + LT - 1) / LT;
+    size_t o = 0;
+    w.keys_in = o; o = al(o + 3 * P * 4);
+    w.keys_out = o; o = al(o + 3 * P * 4);
+    w.vals_in = o; o = al(o + 3 * P);
+    w.vals_out = o; o = al(o + 3 * P);
+    w.offs = o; o = al(o + 4 * sizeof(int));
+    w.partial = o; o = al(o + (size_t)B * chunks * 6 * sizeof(double));
+    w.lov = o; o = al(o + 6 * sizeof(double));
+    size_t tb = 0;
+    const hipError_t e = rocprim::segmented_radix_sort_pairs_desc((void*)nullptr, tb, (const float*)nullptr, (float*)nullptr,
+                                                                  (const unsigned char*)nullptr, (unsigned char*)nullptr, (unsigned)(3 * P), 3u,
+                                                                  (const int*)nullptr, (const int*)nullptr, 0, 32, (hipStream_t)0);
+    if (e != hipSuccess) return -1;
+    w.temp = o; w.temp_bytes = tb; o = al(o + tb);
+    w.total = o;
+    return 0;
+}
+
+__global__ void fill_offsets_kernel(int* offs, int P) {
+    if (threadIdx.x < 4) offs[threadIdx.x] = threadIdx.x * P;
+}
+
+}  // namespace
+}  // namespace dir
+
+extern "C" int dir_stage_losses_forward(const dir_loss_pred* pred_host, const dir_loss_target* gt_host, float coord_weight,
+                                        double* scratch, float* out13, int B, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(pred_host && gt_host && scratch && out13, "dir_stage_losses_forward: null pointer");
+    DIR_REQUIRE(B > 0 && gt_host->c2 >= 2 && gt_host->n_faces > 0, "dir_stage_losses_forward: bad arguments");
+    for (int h = 0; h < 2; ++h)
+        DIR_REQUIRE(pred_host->joint_uv[h] && pred_host->mesh_uv[h] && pred_host->joint_xyz[h] && pred_host->mesh_xyz[h] &&
+                    gt_host->joint_2d[h] && gt_host->mesh_2d[h] && gt_host->joint_3d[h] && gt_host->mesh_3d[h] && gt_host->center[h] &&
+                    gt_host->faces[h], "dir_stage_losses_forward: null tensor");
+    DIR_REQUIRE(pred_host->offset, "dir_stage_losses_forward: null offset");
+    StageArgs a;
+    a.p = *pred_host; a.g = *gt_host; a.scratch = scratch; a.B = B;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(stage_loss_kernel, dim3(B, 2), dim3(LT), 0, s, a);
+    hipLaunchKernelGGL(stage_reduce_kernel, dim3(1), dim3(64), 0, s, scratch, out13, B, coord_weight);
+    return check_launch("dir_stage_losses_forward");
+}
+
+extern "C" long long dir_dense_losses_workspace_bytes(int B, int S) {
+    using namespace dir;
+    if (B <= 0 || S <= 0) return -1;
+    DenseWs w;
+    if (dense_ws(B, S, w)) return -1;
+    return (long long)w.total;
+}
+
+extern "C" int dir_dense_losses_forward(const float* seg_logits, const float* dense_pred, const float* gt_seg, const float* gt_dense,
+                                        const float* class_weight_host, float dense_weight, void* workspace, long long workspace_bytes,
+                                        float* out3, int B, int S, int H, int W, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(seg_logits && dense_pred && gt_seg && gt_dense && class_weight_host && workspace && out3,
+                "dir_dense_losses_forward: null pointer");
+    DIR_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && (long long)B * S * S * 3 < (1ll << 31), "dir_dense_losses_forward: bad shape");
+    DenseWs w;
+    DIR_REQUIRE(dense_ws(B, S, w) == 0, "dir_dense_losses_forward: rocPRIM size query failed");
+    DIR_REQUIRE(workspace_bytes >= (long long)w.total, "dir_dense_losses_forward: workspace too small (%lld < %zu)", workspace_bytes, w.total);
+    char* ws = (char*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    DenseArgs a;
+    a.seg = seg_logits; a.dense = dense_pred; a.gt_seg = gt_seg; a.gt_dense = gt_dense;
+    a.keys = (float*)(ws + w.keys_in); a.vals = (unsigned char*)(ws + w.vals_in); a.partial = (double*)(ws + w.partial);
+    a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT;
+    for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
+    hipLaunchKernelGGL(dense_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
+    hipLaunchKernelGGL(fill_offsets_kernel, dim3(1), dim3(64), 0, s, (int*)(ws + w.offs), a.P);
+    size_t tb = w.temp_bytes;
+    const int* offs = (const int*)(ws + w.offs);
+    const hipError_t e = rocprim::segmented_radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const float*)a.keys, (float*)(ws + w.keys_out),
+                                                                  (const unsigned char*)a.vals, (unsigned char*)(ws + w.vals_out),
+                                                                  (unsigned)(3 * a.P), 3u, offs, offs + 1, 0, 32, s);
+    DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_forward: rocPRIM sort: %s", hipGetErrorString(e));
+    double* lov = (double*)(ws + w.lov);
+    hipLaunchKernelGGL(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const float*)(ws + w.keys_out), (const unsigned char*)(ws + w.vals_out),
+                       (const double*)a.partial, B * a.chunks, a.P, lov);
+    hipLaunchKernelGGL(dense_final_kernel, dim3(1), dim3(64), 0, s, (const double*)a.partial, a.chunks, B, S, (const double*)lov, dense_weight, out3);
+    return check_launch("dir_dense_losses_forward");
+}

@@ -1,0 +1,109 @@
+"""Host-side mirror of the reference's training objective (forward values), on libdir_hip.so.
+
+  DirLoss.__call__      models/dir.py:542-594   the loss block of DIR.forward: same inputs (the per-stage output dicts incl.
+                                                pd_mesh_uv_*, the decoder's seg / dense maps, `target`, `meta_info`), same 42 keys
+                                                ('seg', 'dense', 'lovasz', 'joint_left_uv_0', ..., 'offset_2'), same weights
+                                                (coord_weight 10, dense_weight 1, class weights .1/.45/.45)
+  stage_losses          models/dir.py:571-592   one dir_stage_losses_forward launch pair per stage (13 terms)
+  dense_losses          models/dir.py:562-569   dir_dense_losses_forward (interpolate + CE + SmoothL1 + Lovasz)
+The modules behind them in the reference: models/loss.py (SmoothL1Loss, EdgeLengthLoss, NormalVectorLoss),
+models/lovasz_loss.py (lovasz_softmax).  Forward only: there is no backward pass in this build, the values serve validation-loss
+monitoring and as the pinned target for the training work.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _capi
+
+STAGE_KEYS = ('joint_left_uv', 'joint_right_uv', 'mesh_left_uv', 'mesh_right_uv', 'joint_left_xyz', 'joint_right_xyz',
+              'mesh_left_xyz', 'mesh_right_xyz', 'edge_left', 'edge_right', 'normal_left', 'normal_right', 'offset')
+SIDES = ('left', 'right')
+
+
+def _pair(d, prefix):
+    ts = [_capi.f32c(d[prefix + s]) for s in SIDES]
+    return ts, (C.c_void_p * 2)(*[_capi.ptr(t) for t in ts])
+
+
+def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
+    """pred: one entry of iter_outs (pd_joint_uv_*, pd_mesh_uv_*, pd_joint_xyz_*, pd_mesh_xyz_*, pd_offset); target: joint_2d_*,
+    mesh_2d_* [B,N,>=2], joint_3d_*, mesh_3d_*; meta_info: center_* [B,1,3]; faces: (left, right) int tensors [F,3].
+    Returns a float32 tensor of the 13 terms in STAGE_KEYS order (on the GPU, no host synchronisation)."""
+    keep = []
+    p, g = _capi.LossPred(), _capi.LossTarget()
+    for field, prefix in (('joint_uv', 'pd_joint_uv_'), ('mesh_uv', 'pd_mesh_uv_'), ('joint_xyz', 'pd_joint_xyz_'),
+                          ('mesh_xyz', 'pd_mesh_xyz_')):
+        ts, arr = _pair(pred, prefix)
+        keep += ts
+        setattr(p, field, arr)
+    off = _capi.f32c(pred['pd_offset'])
+    keep.append(off)
+    p.offset = _capi.ptr(off)
+    for field, prefix in (('joint_2d', 'joint_2d_'), ('mesh_2d', 'mesh_2d_'), ('joint_3d', 'joint_3d_'), ('mesh_3d', 'mesh_3d_')):
+        ts, arr = _pair(target, prefix)
+        keep += ts
+        setattr(g, field, arr)
+    ts, arr = _pair(meta_info, 'center_')
+    keep += ts
+    g.center = arr
+    B = off.shape[0]
+    c2 = keep[9].shape[-1]                       # joint_2d_left
+    for t in keep[9:13]:
+        if t.shape[-1] != c2:
+            raise _capi.DirHipError('stage_losses: the 2-D targets must share their last dimension')
+    fs = [f.to(device=off.device, dtype=torch.int32).contiguous() for f in faces]
+    if fs[0].shape != fs[1].shape or fs[0].dim() != 2 or fs[0].shape[1] != 3:
+        raise _capi.DirHipError('stage_losses: faces must be two [F,3] tables of the same size')
+    g.faces = (C.c_void_p * 2)(*[_capi.ptr(f) for f in fs])
+    g.c2, g.n_faces = int(c2), int(fs[0].shape[0])
+    _capi.require_cuda(*keep)
+    scratch = torch.empty(B * 13, device=off.device, dtype=torch.float64)
+    out = torch.empty(13, device=off.device, dtype=torch.float32)
+    with torch.cuda.device(off.device):
+        _capi.check(_capi.lib().dir_stage_losses_forward(C.byref(p), C.byref(g), float(coord_weight), _capi.ptr(scratch),
+                                                         _capi.ptr(out), B, _capi.stream_ptr()), 'dir_stage_losses_forward')
+    return out
+
+
+def dense_losses(seg_logits, dense_pred, gt_seg, gt_dense, class_weight=(0.1, 0.45, 0.45), dense_weight=1.0):
+    """models/dir.py:562-569 -> float32 tensor (seg, dense, lovasz) on the GPU"""
+    seg, dense, gs, gd = (_capi.f32c(t) for t in (seg_logits, dense_pred, gt_seg, gt_dense))
+    _capi.require_cuda(seg, dense, gs, gd)
+    B, Cc, S, S2 = seg.shape
+    if Cc != 3 or S != S2 or dense.shape != seg.shape or gs.shape[:2] != (B, 1) or gd.shape[:2] != (B, 3) or gs.shape[2:] != gd.shape[2:]:
+        raise _capi.DirHipError('dense_losses: expected seg / dense [B,3,S,S], gt_seg [B,1,H,W], gt_dense [B,3,H,W]')
+    H, W = gs.shape[2:]
+    L = _capi.lib()
+    with torch.cuda.device(seg.device):
+        nbytes = L.dir_dense_losses_workspace_bytes(B, S)
+        if nbytes < 0:
+            raise _capi.DirHipError('dir_dense_losses_workspace_bytes failed')
+        ws = torch.empty(nbytes, device=seg.device, dtype=torch.uint8)
+        out = torch.empty(3, device=seg.device, dtype=torch.float32)
+        _capi.check(L.dir_dense_losses_forward(_capi.ptr(seg), _capi.ptr(dense), _capi.ptr(gs), _capi.ptr(gd),
+                                               (C.c_float * 3)(*class_weight), float(dense_weight), _capi.ptr(ws), nbytes,
+                                               _capi.ptr(out), B, S, H, W, _capi.stream_ptr()), 'dir_dense_losses_forward')
+    return out
+
+
+class DirLoss(object):
+    """The loss block of DIR.forward (models/dir.py:505-511 for the weights, :542-594 for the terms)."""
+
+    def __init__(self, faces_left, faces_right, coord_weight=10.0, dense_weight=1.0, class_weight=(0.1, 0.45, 0.45)):
+        self.faces = (torch.as_tensor(faces_left), torch.as_tensor(faces_right))
+        self.coord_weight, self.dense_weight, self.class_weight = coord_weight, dense_weight, tuple(class_weight)
+
+    def __call__(self, iter_outs, decode_list, target, meta_info):
+        """iter_outs: the per-stage dicts; decode_list: {'seg', 'dense'}.  Returns {name: 0-d tensor} with the reference's keys."""
+        loss = {}
+        d = dense_losses(decode_list['seg'], decode_list['dense'], target['seg'], target['dense'], self.class_weight,
+                         self.dense_weight)
+        loss['seg'], loss['dense'], loss['lovasz'] = d[0], d[1], d[2]
+        for index, out in enumerate(iter_outs):
+            t = stage_losses(out, target, meta_info, self.faces, self.coord_weight)
+            for i, k in enumerate(STAGE_KEYS):
+                if k == 'offset' and out.get('pd_offset') is None:
+                    continue
+                loss['%s_%d' % (k, index)] = t[i]
+        return loss

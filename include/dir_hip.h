@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 8
+#define DIR_ABI_VERSION 9
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -381,6 +381,39 @@ typedef struct dir_bneck_chain_params {
 } dir_bneck_chain_params;
 int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
                                  void* y1_next, int B, int H, int W, void* stream);
+
+/* a13 / 8f rank 2, forward half: the training objective, models/dir.py:542-594 (SmoothL1Loss models/loss.py:63-93, EdgeLengthLoss
+ * :36-60, NormalVectorLoss :6-33, nn.CrossEntropyLoss(weight), lovasz_softmax models/lovasz_loss.py:155-202).  Forward values
+ * only (the backward pass is not built).  All tensors fp32, device pointers, index 0 = left hand, 1 = right hand. */
+typedef struct dir_loss_pred {      /* one entry of iter_outs (models/dir.py:519,571) */
+    const float* joint_uv[2];       /* pd_joint_uv_*  [B,21,2] */
+    const float* mesh_uv[2];        /* pd_mesh_uv_*   [B,778,2] (dir_mano_forward's optional output) */
+    const float* joint_xyz[2];      /* pd_joint_xyz_* [B,21,3] metres */
+    const float* mesh_xyz[2];       /* pd_mesh_xyz_*  [B,778,3] metres */
+    const float* offset;            /* pd_offset      [B,3] */
+} dir_loss_pred;
+typedef struct dir_loss_target {    /* target / meta_info of models/dir.py:543-554 */
+    const float* joint_2d[2];       /* joint_2d_* [B,21,c2]: the first two columns are used (:572) */
+    const float* mesh_2d[2];        /* mesh_2d_*  [B,778,c2] */
+    const float* joint_3d[2];       /* joint_3d_* [B,21,3] metres */
+    const float* mesh_3d[2];        /* mesh_3d_*  [B,778,3] metres */
+    const float* center[2];         /* center_*   [B,3] */
+    const int32_t* faces[2];        /* ManoLayer.th_faces [n_faces,3] */
+    int32_t c2, n_faces;
+} dir_loss_target;
+/* The 13 terms of one stage (models/dir.py:571-592) in this order: joint_left_uv, joint_right_uv, mesh_left_uv, mesh_right_uv,
+ * joint_left_xyz, joint_right_xyz, mesh_left_xyz, mesh_right_xyz, edge_left, edge_right, normal_left (x0.1), normal_right (x0.1),
+ * offset; SmoothL1 terms x coord_weight (the reference's 10).  scratch: B*13 doubles (device); out13: 13 floats (device). */
+int dir_stage_losses_forward(const dir_loss_pred* pred_host, const dir_loss_target* gt_host, float coord_weight, double* scratch,
+                             float* out13, int B, void* stream);
+/* models/dir.py:562-569: seg (weighted cross entropy x0.1), dense (SmoothL1), lovasz (x0.1), each x dense_weight -> out3.
+ * seg_logits / dense_pred [B,3,S,S]; gt_seg [B,1,H,W] labels 0..2 stored as floats (F.interpolate nearest -> .long());
+ * gt_dense [B,3,H,W] (F.interpolate bilinear).  class_weight_host: 3 floats (0.1, 0.45, 0.45).  workspace: device bytes,
+ * dir_dense_losses_workspace_bytes(B, S) of them (sort keys / values and rocPRIM's temporary storage). */
+long long dir_dense_losses_workspace_bytes(int B, int S);
+int dir_dense_losses_forward(const float* seg_logits, const float* dense_pred, const float* gt_seg, const float* gt_dense,
+                             const float* class_weight_host, float dense_weight, void* workspace, long long workspace_bytes,
+                             float* out3, int B, int S, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }
