@@ -76,7 +76,7 @@ class EvalInputs(C.Structure):
 
 
 class LossPred(C.Structure):
-    _fields_ = [('joint_uv', C.c_void_p * 2), ('mesh_uv', C.c_void_p * 2), ('joint_xyz', C.c_void_p * 2),
+    _fields_ = [('joint_uv', C.c_void_p * 2), ('mesh_uv', C.c_void_p * 2), ('proj', C.c_void_p * 2), ('joint_xyz', C.c_void_p * 2),
                 ('mesh_xyz', C.c_void_p * 2), ('offset', C.c_void_p)]
 
 

@@ -6,8 +6,8 @@
 //     scratch table and reduced over the batch in a fixed order by a second tiny launch (deterministic; no float atomics).
 //   * dense_pixel_kernel / lovasz_kernel / dense_final_kernel: models/dir.py:562-569 -- F.interpolate (nearest labels, bilinear
 //     dense map), class-weighted cross entropy, SmoothL1 on the dense map, and lovasz_softmax (models/lovasz_loss.py:155-202) on the
-//     raw logits exactly as the reference calls it.  The descending sort of the per-class errors is rocPRIM's segmented radix sort
-//     (a library primitive, like a plain library GEMM); the Jaccard scan runs one workgroup per class with a carried prefix.
+//     raw logits exactly as the reference calls it.  The descending sort of the per-class errors is ONE rocPRIM device radix sort over
+//     composite (class, error) keys (a library primitive, like a plain library GEMM); the Jaccard scan runs one workgroup per class with a carried prefix.
 // Elementwise arithmetic is fp32 in the reference's operation order (contraction off); sums accumulate in fp64.
 // HBM-bound and tiny: 2 x (778 x 5 + ...) floats per sample and stage.
 #include <cstring>
@@ -43,6 +43,12 @@ __device__ __forceinline__ float smooth_l1_term(float x, float y) {
 #pragma clang fp contract(off)
     const float z = x - y, az = fabsf(z);
     return az < 0.01f ? 0.5f * (z * z) : 0.01f * (az - 0.005f);
+}
+
+// utils/utils.py:47-63 (projection_batch_xy): scale * xyz[..., :2] + trans2d
+__device__ __forceinline__ float project_xy(float scale, float trans, float x) {
+#pragma clang fp contract(off)
+    return scale * x + trans;
 }
 
 struct V3 { float x, y, z; };
@@ -118,7 +124,10 @@ __global__ __launch_bounds__(LT) void stage_loss_kernel(StageArgs a) {
     acc = 0;
     for (int i = tid; i < NV * 2; i += LT) {
         const int v = i >> 1, c = i & 1;
-        acc += (double)smooth_l1_term(a.p.mesh_uv[h][(size_t)b * NV * 2 + i], a.g.mesh_2d[h][((size_t)b * NV + v) * a.g.c2 + c]);
+        float x;
+        if (a.p.mesh_uv[h]) x = a.p.mesh_uv[h][(size_t)b * NV * 2 + i];
+        else x = project_xy(a.p.proj[h][(size_t)b * 3], a.p.proj[h][(size_t)b * 3 + 1 + c], a.p.mesh_xyz[h][((size_t)b * NV + v) * 3 + c]);
+        acc += (double)smooth_l1_term(x, a.g.mesh_2d[h][((size_t)b * NV + v) * a.g.c2 + c]);
     }
     t = block_sum_d<LT / 64>(acc, s_red, tid);
     if (tid == 0) out[2 + h] = t / (NV * 2);
@@ -157,20 +166,20 @@ __global__ __launch_bounds__(LT) void stage_loss_kernel(StageArgs a) {
     }
 }
 
-// batch means in a fixed order: term k = weight_k * sum_b scratch[b][k] / B
-__global__ __launch_bounds__(64) void stage_reduce_kernel(const double* __restrict__ scratch, float* __restrict__ out, int B, float coord_weight) {
-    const int k = threadIdx.x;
-    if (k >= NTERM) return;
+// batch means: wave k owns term k (lanes stride over the samples, fixed-shape reduction tree): term k = weight_k * sum_b scratch[b][k] / B
+__global__ __launch_bounds__(64 * NTERM) void stage_reduce_kernel(const double* __restrict__ scratch, float* __restrict__ out, int B, float coord_weight) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double s = 0;
-    for (int b = 0; b < B; ++b) s += scratch[(size_t)b * NTERM + k];
+    for (int b = lane; b < B; b += 64) s += scratch[(size_t)b * NTERM + k];
+    s = wave_sum_d(s);
     const double w = (k < 8 || k == 12) ? (double)coord_weight : (k < 10 ? 1.0 : 0.1);
-    out[k] = (float)(s / B * w);
+    if (lane == 0) out[k] = (float)(s / B * w);
 }
 
 // ------------------------------------------------------------------------------------------------ seg / dense / lovasz
 struct DenseArgs {
     const float* seg; const float* dense; const float* gt_seg; const float* gt_dense;
-    float* keys; unsigned char* vals;       // [3][P]
+    unsigned long long* keys; unsigned char* vals;       // [3][P]: (2 - class) << 32 | bits of the (non-negative) error -- ONE device-wide descending sort orders class 0 | 1 | 2, each by error
     double* partial;                        // [nwg][6]: sum w nll, sum w, dense smooth-l1 sum, fg count of class 0..2
     int B, S, H, W, P, chunks;
     float cw[3];
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(LT) void dense_pixel_kernel(DenseArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float fg = lab == c ? 1.f : 0.f, lc = c == 0 ? l0 : c == 1 ? l1 : l2;
-            a.keys[(size_t)c * a.P + p] = fabsf(fg - lc);
+            a.keys[(size_t)c * a.P + p] = ((unsigned long long)(2 - c) << 32) | (unsigned long long)__float_as_uint(fabsf(fg - lc));
             a.vals[(size_t)c * a.P + p] = lab == c;
             v[3 + c] = lab == c;
         }
@@ -226,10 +235,12 @@ __global__ __launch_bounds__(LT) void dense_pixel_kernel(DenseArgs a) {
     }
 }
 
-constexpr int LV_T = 1024;
+constexpr int LV_T = 1024, LV_E = 8;
 // one workgroup per class: loss_c = sum_i err_sorted[i] * (J_i - J_{i-1}), J_i = 1 - (G - cumfg_i) / (G + cumbg_i)
-// (models/lovasz_loss.py:19-31,194-197); result[c] = loss, result[3 + c] = G (0 -> class absent, skipped by 'present')
-__global__ __launch_bounds__(LV_T) void lovasz_kernel(const float* __restrict__ keys, const unsigned char* __restrict__ vals,
+// (models/lovasz_loss.py:19-31,194-197); result[c] = loss, result[3 + c] = G (0 -> class absent, skipped by 'present').
+// A thread owns LV_E consecutive sorted elements per pass (local scan), the wave / workgroup scans run on the thread totals and the
+// running foreground count and last J are carried from pass to pass.
+__global__ __launch_bounds__(LV_T) void lovasz_kernel(const unsigned long long* __restrict__ keys, const unsigned char* __restrict__ vals,
                                                       const double* __restrict__ partial, int nwg, int P, double* __restrict__ result) {
     __shared__ double s_red[LV_T / 64];
     __shared__ int s_wsum[LV_T / 64];
@@ -237,15 +248,22 @@ __global__ __launch_bounds__(LV_T) void lovasz_kernel(const float* __restrict__ 
     const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double G = 0;
     for (int i = 0; i < nwg; ++i) G += partial[(size_t)i * 6 + 3 + c];           // same order in every thread: identical value
-    const float* e = keys + (size_t)c * P;
+    const unsigned long long* e = keys + (size_t)c * P;
     const unsigned char* fgv = vals + (size_t)c * P;
-    long long carry = 0;                      // foreground count before this chunk
-    double prevJ = 0, acc = 0;                // J of the last element of the previous chunk (J_{-1} := 0: jaccard[0] is kept)
-    for (int base = 0; base < P; base += LV_T) {
-        const int i = base + tid;
-        const int fg = i < P ? (int)fgv[i] : 0;
-        // inclusive scan of fg over the chunk
-        int x = fg;
+    long long carry = 0;                      // foreground count before this pass
+    double prevJ = 0, acc = 0;                // J of the last element of the previous pass (J_{-1} := 0: jaccard[0] is kept)
+    for (int base = 0; base < P; base += LV_T * LV_E) {
+        const int i0 = base + tid * LV_E;
+        int fg[LV_E]; float er[LV_E];
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < LV_E; ++k) {
+            const bool ok = i0 + k < P;
+            fg[k] = ok ? (int)fgv[ok ? i0 + k : 0] : 0;
+            er[k] = ok ? __uint_as_float((unsigned)e[ok ? i0 + k : 0]) : 0.f;
+            mine += fg[k];
+        }
+        int x = mine;                         // inclusive scan of the thread totals
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(x, o, 64);
@@ -256,21 +274,29 @@ __global__ __launch_bounds__(LV_T) void lovasz_kernel(const float* __restrict__ 
         int woff = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < LV_T / 64; ++w) {
-            const int s = s_wsum[w];
-            if (w < wave) woff += s;
-            total += s;
+            const int sw = s_wsum[w];
+            if (w < wave) woff += sw;
+            total += sw;
         }
-        const long long cumfg = carry + woff + x;
-        const long long cumbg = (long long)(i + 1) - cumfg;
-        double J = 0;
-        if (i < P) J = 1.0 - (G - (double)cumfg) / (G + (double)cumbg);
-        // J of the previous element: lane - 1, or the previous wave's last lane, or the previous chunk's last element
-        double Jm = __shfl_up(J, 1, 64);
-        if (lane == 63) s_red[wave] = J;
+        long long cum = carry + woff + x - mine;          // foreground count before this thread's first element
+        double J[LV_E];
+#pragma unroll
+        for (int k = 0; k < LV_E; ++k) {
+            cum += fg[k];
+            const long long cumbg = (long long)(i0 + k + 1) - cum;
+            J[k] = i0 + k < P ? 1.0 - (G - (double)cum) / (G + (double)cumbg) : 0.0;
+        }
+        // J of the element before this thread's first one: previous lane's last, previous wave's last, or the previous pass's last
+        double Jm = __shfl_up(J[LV_E - 1], 1, 64);
+        if (lane == 63) s_red[wave] = J[LV_E - 1];
         __syncthreads();
         if (lane == 0) Jm = wave == 0 ? prevJ : s_red[wave - 1];
-        if (i < P) acc += (double)e[i] * (J - Jm);
-        if (tid == LV_T - 1) s_prevJ = J;
+#pragma unroll
+        for (int k = 0; k < LV_E; ++k) {
+            if (i0 + k < P) acc += (double)er[k] * (J[k] - Jm);
+            Jm = J[k];
+        }
+        if (tid == LV_T - 1) s_prevJ = J[LV_E - 1];
         __syncthreads();
         prevJ = s_prevJ;
         carry += total;
@@ -279,11 +305,12 @@ __global__ __launch_bounds__(LV_T) void lovasz_kernel(const float* __restrict__ 
     if (tid == 0) { result[c] = t; result[3 + c] = G; }
 }
 
-__global__ void dense_final_kernel(const double* __restrict__ partial, int chunks, int B, int S, const double* __restrict__ lov,
-                                   float dense_weight, float* __restrict__ out) {
-    if (threadIdx.x != 0) return;
+// one wave: lanes stride over the per-workgroup partials, fixed-shape reduction tree (deterministic)
+__global__ __launch_bounds__(64) void dense_final_kernel(const double* __restrict__ partial, int chunks, int B, int S, const double* __restrict__ lov,
+                                                          float dense_weight, float* __restrict__ out) {
+    const int lane = threadIdx.x;
     double wn = 0, w = 0, dsum = 0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = lane; b < B; b += 64) {
         double d = 0;
         for (int k = 0; k < chunks; ++k) {
             const double* p = partial + ((size_t)b * chunks + k) * 6;
@@ -291,6 +318,8 @@ __global__ void dense_final_kernel(const double* __restrict__ partial, int chunk
         }
         dsum += d / (3.0 * S * S);              // SmoothL1Loss: per-sample mean, then the batch mean
     }
+    wn = wave_sum_d(wn); w = wave_sum_d(w); dsum = wave_sum_d(dsum);
+    if (lane != 0) return;
     double ls = 0; int n = 0;
     for (int c = 0; c < 3; ++c)
         if (lov[3 + c] > 0) { ls += lov[c]; ++n; }
@@ -300,31 +329,26 @@ __global__ void dense_final_kernel(const double* __restrict__ partial, int chunk
 }
 
 // workspace carve-up (all offsets 256-byte aligned)
-struct DenseWs { size_t keys_in, keys_out, vals_in, vals_out, offs, partial, lov, temp, temp_bytes, total; };
+struct DenseWs { size_t keys_in, keys_out, vals_in, vals_out, partial, lov, temp, temp_bytes, total; };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+constexpr unsigned KEY_BITS = 34;            // 32 bits of error + 2 bits of class
 int dense_ws(int B, int S, DenseWs& w) {
     const size_t P = (size_t)B * S * S;
     const int chunks = (S * S + LT - 1) / LT;
     size_t o = 0;
-    w.keys_in = o; o = al(o + 3 * P * 4);
-    w.keys_out = o; o = al(o + 3 * P * 4);
+    w.keys_in = o; o = al(o + 3 * P * 8);
+    w.keys_out = o; o = al(o + 3 * P * 8);
     w.vals_in = o; o = al(o + 3 * P);
     w.vals_out = o; o = al(o + 3 * P);
-    w.offs = o; o = al(o + 4 * sizeof(int));
     w.partial = o; o = al(o + (size_t)B * chunks * 6 * sizeof(double));
     w.lov = o; o = al(o + 6 * sizeof(double));
     size_t tb = 0;
-    const hipError_t e = rocprim::segmented_radix_sort_pairs_desc((void*)nullptr, tb, (const float*)nullptr, (float*)nullptr,
-                                                                  (const unsigned char*)nullptr, (unsigned char*)nullptr, (unsigned)(3 * P), 3u,
-                                                                  (const int*)nullptr, (const int*)nullptr, 0, 32, (hipStream_t)0);
+    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                        (const unsigned char*)nullptr, (unsigned char*)nullptr, 3 * P, 0u, KEY_BITS, (hipStream_t)0);
     if (e != hipSuccess) return -1;
     w.temp = o; w.temp_bytes = tb; o = al(o + tb);
     w.total = o;
     return 0;
-}
-
-__global__ void fill_offsets_kernel(int* offs, int P) {
-    if (threadIdx.x < 4) offs[threadIdx.x] = threadIdx.x * P;
 }
 
 }  // namespace
@@ -336,7 +360,7 @@ extern "C" int dir_stage_losses_forward(const dir_loss_pred* pred_host, const di
     DIR_REQUIRE(pred_host && gt_host && scratch && out13, "dir_stage_losses_forward: null pointer");
     DIR_REQUIRE(B > 0 && gt_host->c2 >= 2 && gt_host->n_faces > 0, "dir_stage_losses_forward: bad arguments");
     for (int h = 0; h < 2; ++h)
-        DIR_REQUIRE(pred_host->joint_uv[h] && pred_host->mesh_uv[h] && pred_host->joint_xyz[h] && pred_host->mesh_xyz[h] &&
+        DIR_REQUIRE(pred_host->joint_uv[h] && (pred_host->mesh_uv[h] || pred_host->proj[h]) && pred_host->joint_xyz[h] && pred_host->mesh_xyz[h] &&
                     gt_host->joint_2d[h] && gt_host->mesh_2d[h] && gt_host->joint_3d[h] && gt_host->mesh_3d[h] && gt_host->center[h] &&
                     gt_host->faces[h], "dir_stage_losses_forward: null tensor");
     DIR_REQUIRE(pred_host->offset, "dir_stage_losses_forward: null offset");
@@ -344,7 +368,7 @@ extern "C" int dir_stage_losses_forward(const dir_loss_pred* pred_host, const di
     a.p = *pred_host; a.g = *gt_host; a.scratch = scratch; a.B = B;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(stage_loss_kernel, dim3(B, 2), dim3(LT), 0, s, a);
-    hipLaunchKernelGGL(stage_reduce_kernel, dim3(1), dim3(64), 0, s, scratch, out13, B, coord_weight);
+    hipLaunchKernelGGL(stage_reduce_kernel, dim3(1), dim3(64 * NTERM), 0, s, scratch, out13, B, coord_weight);
     return check_launch("dir_stage_losses_forward");
 }
 
@@ -370,19 +394,16 @@ extern "C" int dir_dense_losses_forward(const float* seg_logits, const float* de
     hipStream_t s = (hipStream_t)stream;
     DenseArgs a;
     a.seg = seg_logits; a.dense = dense_pred; a.gt_seg = gt_seg; a.gt_dense = gt_dense;
-    a.keys = (float*)(ws + w.keys_in); a.vals = (unsigned char*)(ws + w.vals_in); a.partial = (double*)(ws + w.partial);
+    a.keys = (unsigned long long*)(ws + w.keys_in); a.vals = (unsigned char*)(ws + w.vals_in); a.partial = (double*)(ws + w.partial);
     a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT;
     for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
     hipLaunchKernelGGL(dense_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
-    hipLaunchKernelGGL(fill_offsets_kernel, dim3(1), dim3(64), 0, s, (int*)(ws + w.offs), a.P);
     size_t tb = w.temp_bytes;
-    const int* offs = (const int*)(ws + w.offs);
-    const hipError_t e = rocprim::segmented_radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const float*)a.keys, (float*)(ws + w.keys_out),
-                                                                  (const unsigned char*)a.vals, (unsigned char*)(ws + w.vals_out),
-                                                                  (unsigned)(3 * a.P), 3u, offs, offs + 1, 0, 32, s);
+    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const unsigned long long*)a.keys, (unsigned long long*)(ws + w.keys_out),
+                                                        (const unsigned char*)a.vals, (unsigned char*)(ws + w.vals_out), (size_t)3 * a.P, 0u, KEY_BITS, s);
     DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_forward: rocPRIM sort: %s", hipGetErrorString(e));
     double* lov = (double*)(ws + w.lov);
-    hipLaunchKernelGGL(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const float*)(ws + w.keys_out), (const unsigned char*)(ws + w.vals_out),
+    hipLaunchKernelGGL(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned char*)(ws + w.vals_out),
                        (const double*)a.partial, B * a.chunks, a.P, lov);
     hipLaunchKernelGGL(dense_final_kernel, dim3(1), dim3(64), 0, s, (const double*)a.partial, a.chunks, B, S, (const double*)lov, dense_weight, out3);
     return check_launch("dir_dense_losses_forward");

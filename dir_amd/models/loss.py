@@ -27,16 +27,19 @@ def _pair(d, prefix):
 
 
 def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
-    """pred: one entry of iter_outs (pd_joint_uv_*, pd_mesh_uv_*, pd_joint_xyz_*, pd_mesh_xyz_*, pd_offset); target: joint_2d_*,
+    """pred: one entry of iter_outs (pd_joint_uv_*, pd_mesh_uv_* or pd_proj_*, pd_joint_xyz_*, pd_mesh_xyz_*, pd_offset); target: joint_2d_*,
     mesh_2d_* [B,N,>=2], joint_3d_*, mesh_3d_*; meta_info: center_* [B,1,3]; faces: (left, right) int tensors [F,3].
     Returns a float32 tensor of the 13 terms in STAGE_KEYS order (on the GPU, no host synchronisation)."""
     keep = []
     p, g = _capi.LossPred(), _capi.LossTarget()
-    for field, prefix in (('joint_uv', 'pd_joint_uv_'), ('mesh_uv', 'pd_mesh_uv_'), ('joint_xyz', 'pd_joint_xyz_'),
-                          ('mesh_xyz', 'pd_mesh_xyz_')):
+    for field, prefix in (('joint_uv', 'pd_joint_uv_'), ('joint_xyz', 'pd_joint_xyz_'), ('mesh_xyz', 'pd_mesh_xyz_')):
         ts, arr = _pair(pred, prefix)
         keep += ts
         setattr(p, field, arr)
+    # pd_mesh_uv_* is an output of the reference's regressors that only this loss reads (models/dir.py:278-280,574-575); the
+    # engine's stage dicts carry pd_proj_* instead and the kernel projects the mesh itself
+    extra, arr = _pair(pred, 'pd_mesh_uv_' if 'pd_mesh_uv_left' in pred else 'pd_proj_')
+    setattr(p, 'mesh_uv' if 'pd_mesh_uv_left' in pred else 'proj', arr)
     off = _capi.f32c(pred['pd_offset'])
     keep.append(off)
     p.offset = _capi.ptr(off)
@@ -48,8 +51,8 @@ def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
     keep += ts
     g.center = arr
     B = off.shape[0]
-    c2 = keep[9].shape[-1]                       # joint_2d_left
-    for t in keep[9:13]:
+    c2 = keep[7].shape[-1]                       # joint_2d_left
+    for t in keep[7:11]:
         if t.shape[-1] != c2:
             raise _capi.DirHipError('stage_losses: the 2-D targets must share their last dimension')
     fs = [f.to(device=off.device, dtype=torch.int32).contiguous() for f in faces]
@@ -57,7 +60,7 @@ def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
         raise _capi.DirHipError('stage_losses: faces must be two [F,3] tables of the same size')
     g.faces = (C.c_void_p * 2)(*[_capi.ptr(f) for f in fs])
     g.c2, g.n_faces = int(c2), int(fs[0].shape[0])
-    _capi.require_cuda(*keep)
+    _capi.require_cuda(*(keep + extra))
     scratch = torch.empty(B * 13, device=off.device, dtype=torch.float64)
     out = torch.empty(13, device=off.device, dtype=torch.float32)
     with torch.cuda.device(off.device):

@@ -387,7 +387,9 @@ int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1
  * only (the backward pass is not built).  All tensors fp32, device pointers, index 0 = left hand, 1 = right hand. */
 typedef struct dir_loss_pred {      /* one entry of iter_outs (models/dir.py:519,571) */
     const float* joint_uv[2];       /* pd_joint_uv_*  [B,21,2] */
-    const float* mesh_uv[2];        /* pd_mesh_uv_*   [B,778,2] (dir_mano_forward's optional output) */
+    const float* mesh_uv[2];        /* pd_mesh_uv_*   [B,778,2] (dir_mano_forward's optional output), or NULL: then computed here */
+    const float* proj[2];           /* pd_proj_* [B,3] = (scale, tx, ty): mesh_uv = scale * mesh_xyz[..., :2] + t (utils/utils.py:47-63,
+                                       models/dir.py:278-280,359-361); read only where mesh_uv is NULL */
     const float* joint_xyz[2];      /* pd_joint_xyz_* [B,21,3] metres */
     const float* mesh_xyz[2];       /* pd_mesh_xyz_*  [B,778,3] metres */
     const float* offset;            /* pd_offset      [B,3] */

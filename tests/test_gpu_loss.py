@@ -115,3 +115,60 @@ def test_loss_argument_errors():
                         torch.zeros(2, 3, 64, 64).cuda())
     with pytest.raises(_capi.DirHipError):
         ML.stage_losses({k: torch.from_numpy(v) for k, v in pred.items()}, target, meta, faces)      # CPU tensors: no fallback
+
+
+def test_projection_inside_the_kernel_equals_mesh_uv_input():
+    """pd_mesh_uv_* absent -> the kernel applies utils/utils.py:47-63 to pd_mesh_xyz_* / pd_proj_* itself: same 13 values"""
+    rng = np.random.RandomState(5)
+    B = 6
+    pred, gt = _random_stage(rng, B)
+    faces = [torch.from_numpy(synth.loss_faces(s)) for s in ('left', 'right')]
+    for side in ('left', 'right'):
+        proj = np.concatenate([rng.uniform(2, 6, (B, 1)), rng.normal(0, 0.2, (B, 2))], axis=1).astype(np.float32)
+        pred['pd_proj_' + side] = proj
+        pred['pd_mesh_uv_' + side] = (proj[:, None, :1] * pred['pd_mesh_xyz_' + side][..., :2] + proj[:, None, 1:]).astype(np.float32)
+        gt['mesh_2d_' + side][..., :2] = pred['pd_mesh_uv_' + side] + rng.normal(0, 0.01, (B, 778, 2)).astype(np.float32)
+    target = cuda({k: v for k, v in gt.items() if not k.startswith('center')})
+    meta = cuda({k: v for k, v in gt.items() if k.startswith('center')})
+    a = ML.stage_losses(cuda(pred), target, meta, faces)
+    b = ML.stage_losses(cuda({k: v for k, v in pred.items() if 'mesh_uv' not in k}), target, meta, faces)
+    assert torch.equal(a, b)
+
+
+def test_validation_loss_on_engine_outputs():
+    """DirEngine.forward -> DirLoss on its output dicts (fp32 engine) == the oracle's objective on the same tensors"""
+    import json
+    import os
+    from conftest import GOLDEN
+    from dir_amd.engine import DirEngine
+    with open(os.path.join(GOLDEN, 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
+    B = 3
+    img = torch.from_numpy(synth.synth_input('loss.img', (B, 3, 256, 256), 1234)).cuda()
+    outs = DirEngine(sd, dtype=torch.float32).forward(img, want_proj_feat=False)
+    rng = np.random.RandomState(9)
+    _, gt = _random_stage(rng, B)
+    last = outs[2]
+    for side in ('left', 'right'):
+        for tag, n in (('joint', 21), ('mesh', 778)):
+            gt['%s_3d_%s' % (tag, side)] = (last['pd_%s_xyz_%s' % (tag, side)].cpu().numpy() + gt['center_' + side]
+                                            + rng.normal(0, 0.003, (B, n, 3))).astype(np.float32)
+    gt_seg = rng.randint(0, 3, (B, 1, 256, 256)).astype(np.float32)
+    gt_dense = rng.uniform(0, 1, (B, 3, 256, 256)).astype(np.float32)
+    faces = tuple(synth.loss_faces(s) for s in ('left', 'right'))
+    target = cuda({k: v for k, v in gt.items() if not k.startswith('center')})
+    target.update(seg=torch.from_numpy(gt_seg).cuda(), dense=torch.from_numpy(gt_dense).cuda())
+    meta = cuda({k: v for k, v in gt.items() if k.startswith('center')})
+    loss = ML.DirLoss(*[torch.from_numpy(f) for f in faces])(outs[:3], outs[3], target, meta)
+    assert len(loss) == 42
+    want = dict(OL.dense_losses(outs[3]['seg'].cpu().numpy(), outs[3]['dense'].cpu().numpy(), gt_seg, gt_dense))
+    for i in range(3):
+        p = {k: v.cpu().numpy() for k, v in outs[i].items() if v is not None}
+        for side in ('left', 'right'):
+            pr = p['pd_proj_' + side]
+            p['pd_mesh_uv_' + side] = (pr[:, None, :1] * p['pd_mesh_xyz_' + side][..., :2] + pr[:, None, 1:]).astype(np.float32)
+        for k, v in OL.stage_losses(p, gt, faces).items():
+            want['%s_%d' % (k, i)] = v
+    for k in sorted(want):
+        assert close(float(loss[k]), want[k]), (k, float(loss[k]), want[k])
