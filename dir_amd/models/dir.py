@@ -159,10 +159,18 @@ class DIR(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def objective(self, outs_list, target, meta_info):
+        """The loss block of the reference's forward (models/dir.py:542-594) evaluated on eval-mode outputs: the same 42 keys
+        and weights (coord_weight 10, dense_weight 1, seg class weights .1/.45/.45), forward values only (validation loss)."""
+        from .loss import DirLoss
+        crit = DirLoss(self.init_regressor.mano_layer_left.th_faces, self.init_regressor.mano_layer_right.th_faces)
+        return crit(outs_list[:3], outs_list[3], target, meta_info)
+
     def forward(self, input, target, meta_info):
         if self.training:
-            raise NotImplementedError('dir_amd implements DIR.forward in eval mode (inference hot path); the loss block '
-                                      'of models/dir.py:542-594 is not built yet -- call .eval()')
+            raise NotImplementedError('dir_amd implements DIR.forward in eval mode (inference hot path): training-mode '
+                                      'BatchNorm and the backward pass are not built -- call .eval(); the loss block of '
+                                      'models/dir.py:542-594 is available as forward values, see DIR.objective()')
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()
         with torch.cuda.device(x.device), torch.no_grad():

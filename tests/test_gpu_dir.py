@@ -128,6 +128,22 @@ def test_dir_module_dropin(golden, dir_state):
     y = st.interaction(t)
     assert maxabs(y.cpu().numpy(), OT.ste_forward(t0.cpu().numpy(), Ps)) < 3e-5
     assert maxabs(t.cpu().numpy(), t0.cpu().numpy() + Ps['spatial_pos_embed']) < 1e-7      # in-place `x += pos`
+    # the loss block (models/dir.py:542-594) on the eval-mode outputs: the reference's 42 keys
+    rng = np.random.RandomState(2)
+    target, meta = {}, {}
+    for side in ('left', 'right'):
+        meta['center_' + side] = torch.from_numpy(rng.normal(0, 0.05, (2, 1, 3)).astype(np.float32)).cuda()
+        for tag, n in (('joint', 21), ('mesh', 778)):
+            target['%s_3d_%s' % (tag, side)] = outs[2]['pd_%s_xyz_%s' % (tag, side)] + meta['center_' + side]
+            target['%s_2d_%s' % (tag, side)] = torch.from_numpy(rng.uniform(-1, 1, (2, n, 3)).astype(np.float32)).cuda()
+    target['seg'] = torch.from_numpy(rng.randint(0, 3, (2, 1, 256, 256)).astype(np.float32)).cuda()
+    target['dense'] = torch.from_numpy(rng.uniform(0, 1, (2, 3, 256, 256)).astype(np.float32)).cuda()
+    objective = net.objective(outs, target, meta)
+    assert len(objective) == 42 and all(np.isfinite(float(v)) for v in objective.values())
+    assert float(objective['mesh_left_xyz_2']) < 1e-6 and float(objective['edge_right_2']) < 1e-6       # targets == stage-2 predictions
+    assert float(objective['mesh_left_xyz_0']) > float(objective['mesh_left_xyz_2'])
+    with pytest.raises(NotImplementedError):
+        net.train()({'img': img}, target, meta)
 
 
 def test_sparse_fusion_is_bit_identical(dir_state):
