@@ -105,6 +105,8 @@ _SIGNATURES = {
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_image_normalize_forward': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _p]),
     'dir_stem_prep_s2d_u8': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _i, _i, _i, _p]),
+    'dir_adamw_step': (C.c_int, [_p, _p, _p, _p, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_longlong, _p]),
     'dir_stage_losses_forward': (C.c_int, [C.POINTER(LossPred), C.POINTER(LossTarget), C.c_float, _p, _p, _i, _p]),
     'dir_dense_losses_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_dense_losses_forward': (C.c_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.c_float, _p, C.c_longlong, _p, _i, _i, _i, _i, _p]),

@@ -417,6 +417,12 @@ int dir_dense_losses_forward(const float* seg_logits, const float* dense_pred, c
                              const float* class_weight_host, float dense_weight, void* workspace, long long workspace_bytes,
                              float* out3, int B, int S, int H, int W, void* stream);
 
+/* 8f rank 2, optimiser: train.py:227 `optim.AdamW(params, lr)` (torch defaults betas (0.9, 0.999), eps 1e-8, weight_decay 0.01) as one
+ * launch over flat fp32 buffers of n elements (16-byte aligned): decoupled weight decay, bias-corrected moments, torch's fp32
+ * operation order.  step = 1-based update count (the value torch keeps in state['step'] AFTER this update). */
+int dir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, long long step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,3 +286,27 @@ def test_loss_interpolation_matches_torch():
         lab = rng.randint(0, 3, (2, 1, H, H)).astype(np.float32)
         want = F.interpolate(torch.from_numpy(lab), (S, S), mode='nearest').numpy()
         assert np.array_equal(OL.interpolate_nearest(lab, S), want)
+
+
+# ------------------------------------------------------------------ optimiser (8f rank 2): pinned against torch itself
+def test_adamw_oracle_matches_torch():
+    """train.py:227-230: the numpy restatement against torch.optim.AdamW + CosineAnnealingLR (the reference's dependency)"""
+    import torch
+    from oracle import optim as OO
+    rng = np.random.RandomState(0)
+    p0 = rng.normal(0, 0.1, (37, 19)).astype(np.float32)
+    w = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.AdamW([{'params': [w], 'initial_lr': 1e-3}], 1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=6, eta_min=0)
+    p, m, v = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    for step in range(1, 8):
+        g = (rng.normal(0, 1, p0.shape) * 10.0 ** rng.randint(-4, 1)).astype(np.float32)
+        lr = opt.param_groups[0]['lr']
+        assert abs(lr - OO.cosine_lr(1e-3, step - 1, 6)) < 1e-12
+        w.grad = torch.from_numpy(g.copy())
+        opt.step()
+        sch.step()
+        p, m, v = OO.adamw_step(p, g, m, v, step, lr)
+        assert relerr(p, w.detach().numpy()) < 2e-7, step
+        st = opt.state[w]
+        assert relerr(m, st['exp_avg'].numpy()) < 2e-7 and relerr(v, st['exp_avg_sq'].numpy()) < 2e-7
