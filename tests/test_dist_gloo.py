@@ -58,3 +58,33 @@ def test_shard_range_partitions():
             cuts = [shard_range(n, r, w) for r in range(w)]
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from dir_amd import dist as D
+    D.init_from_env('gloo')
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(1000, generator=g)
+    D.average_gradients(flat, bucket_elems=384)             # three pieces, the last one ragged
+    q.put((rank, flat.tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_gradient_average_world2():
+    """training DP: the flat gradient bucket is summed over the ranks and divided by the world size, bucket by bucket"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (torch.randn(1000, generator=torch.Generator().manual_seed(100)) + torch.randn(1000, generator=torch.Generator().manual_seed(101))) / 2
+    assert torch.allclose(torch.tensor(res[0]), want, atol=1e-7) and res[0] == res[1]
+    from dir_amd import dist as D
+    one = torch.ones(5)
+    assert D.average_gradients(one) is one and float(one.sum()) == 5.0      # single process: untouched
