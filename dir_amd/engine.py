@@ -631,7 +631,14 @@ class DirEngine(object):
                                                         _dt(self.dtype), _capi.stream_ptr()), 'dir_upsample2x_bilinear')
 
     factorised_fusion = os.environ.get('DIR_FACTORISED_FUSION', '1') != '0'    # bf16 mode: dir_bone_fusion_forward
-    overlap = os.environ.get('DIR_OVERLAP', '1') != '0'     # run the skip branches on a side stream (False: everything on the current stream, e.g. to time kernels alone)
+    # Side-stream fork / join inside one forward (skip branches + the fusion's G tensors beside the token path): OFF by default.
+    # With it on, B = 64 forwards were not reproducible: consumers of the init stage's outputs read stale cache lines of whatever
+    # the allocator block held before (256-byte chunks of an earlier tensor), in eager mode and under graph replay alike; any join
+    # before the consumer, or a host synchronise, hides it, and the kernels involved are race-free in isolation
+    # (tools/race_hunt.py, tools/race_hunt2.py).  Not root-caused (a kernel-to-kernel cache-coherence effect once two hardware
+    # queues are active); since two whole forwards in flight (ForwardPipeline: disjoint memory per slot, one stream each) fill the
+    # same idle CUs better -- 2.44 ms per forward against 2.51 ms with the side stream -- the single-stream forward is the default.
+    overlap = os.environ.get('DIR_OVERLAP', '0') == '1'
 
     def _side_stream(self):
         if not self.overlap:
@@ -723,9 +730,9 @@ class DirEngine(object):
         c1, c2, c3, c4 = feats
         cat4 = torch.empty(B, 16, 16, 2304, device=dev, dtype=dt)
         cat3 = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
-        # The two skip branches depend on the backbone only.  They run on a side stream so that their convolutions fill the
-        # CUs the latency-bound launches leave idle: skip_layer4 beside init_head / MANO, skip_layer3 beside stage 1's token
-        # path (grid-sample -> P-GCN -> STE -> MANO -> bone_proj: at most 64 workgroups each).  Fork / join is capturable.
+        # The two skip branches depend on the backbone only.  With `overlap` (off by default, see the class attribute) they run on
+        # a side stream: skip_layer4 beside init_head / MANO, skip_layer3 beside stage 1's token path.  Otherwise `side` is the
+        # current stream and the waits below are no-ops.
         main = torch.cuda.current_stream()
         side = self._side_stream()
         ev_tok = torch.cuda.Event()
@@ -776,7 +783,7 @@ class ForwardPipeline(object):
     tensor and activation / output buffers (the weights are the engine's, shared).  Images are independent
     (models/dir.py:513-540 has no cross-sample op in eval mode), so two batches can overlap freely: the low-occupancy token
     kernels (64-336 workgroups) and every kernel's ramp / drain of one forward run under the convolutions of the other.
-    Measured at B = 64, bf16: 2.99 ms per forward with one in flight, 2.50 ms with two (three: 2.77 ms -- cache and LDS
+    Measured at B = 64, bf16: 2.93 ms per forward with one in flight, 2.44 ms with two (three: slower -- cache and LDS
     contention), `tools/two_stream_test.py`.
 
         pipe = ForwardPipeline(eng, [img_a, img_b])      # the caller owns (and refills) the slot inputs
