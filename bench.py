@@ -98,11 +98,11 @@ def main():
         counter = [0]
 
         def step():
-            pipe.launch(counter[0] % args.inflight, after_current_stream=False)
+            pipe.launch(counter[0] % args.inflight)
             counter[0] += 1
 
         def one_slot():
-            pipe.launch(0, after_current_stream=False)
+            pipe.launch(0)
         for _ in range(3):
             one_slot()
         torch.cuda.synchronize()

@@ -18,7 +18,14 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdir_hip.so')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++20', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-fno-gpu-rdc']
+         '-fno-gpu-rdc',
+         # No packed-FP32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  Measured on MI355X ("Packed FP32
+         # beside another kernel"): a wave executing them while waves of certain OTHER kernels (e.g. the 64x128 ring variant of the
+         # MFMA convolution) are resident on the same CU gets wrong LOW-half results -- never alone, never in LDS / VGPR / memory
+         # canaries, only when two streams' kernels really overlap.  With the feature off the same overlap is bit-exact, at no
+         # measurable cost (the bf16 epilogues keep v_cvt_pk_bf16_f32 / v_pk_max_i16, which are other features).
+         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+FLAGS += os.environ.get('DIR_HIPCC_EXTRA', '').split()       # tuning / debugging aid (changing it needs --force)
 
 
 def hipcc():
@@ -41,8 +48,9 @@ def _compile(src, force):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    err = '\n'.join(l for l in r.stderr.splitlines() if 'is not a recognized feature for this target' not in l)   # the host pass of the feature flag
+    if err.strip():
+        sys.stderr.write(err + '\n')
     return obj, True
 
 

@@ -632,12 +632,8 @@ class DirEngine(object):
 
     factorised_fusion = os.environ.get('DIR_FACTORISED_FUSION', '1') != '0'    # bf16 mode: dir_bone_fusion_forward
     # Side-stream fork / join inside one forward (skip branches + the fusion's G tensors beside the token path): OFF by default.
-    # With it on, B = 64 forwards were not reproducible: consumers of the init stage's outputs read stale cache lines of whatever
-    # the allocator block held before (256-byte chunks of an earlier tensor), in eager mode and under graph replay alike; any join
-    # before the consumer, or a host synchronise, hides it, and the kernels involved are race-free in isolation
-    # (tools/race_hunt.py, tools/race_hunt2.py).  Not root-caused (a kernel-to-kernel cache-coherence effect once two hardware
-    # queues are active); since two whole forwards in flight (ForwardPipeline: disjoint memory per slot, one stream each) fill the
-    # same idle CUs better -- 2.44 ms per forward against 2.51 ms with the side stream -- the single-stream forward is the default.
+    # It is how the packed-FP32 hazard was found ("Packed FP32 beside another kernel"; fixed at build level), and with
+    # two whole forwards in flight (ForwardPipeline) it no longer pays: 2.44 ms per forward without it against 2.51 ms with it.
     overlap = os.environ.get('DIR_OVERLAP', '0') == '1'
 
     def _side_stream(self):
@@ -786,9 +782,9 @@ class ForwardPipeline(object):
     Measured at B = 64, bf16: 2.93 ms per forward with one in flight, 2.44 ms with two (three: slower -- cache and LDS
     contention), `tools/two_stream_test.py`.
 
-        pipe = ForwardPipeline(eng, [img_a, img_b])      # the caller owns (and refills) the slot inputs
-        pipe.launch(0); pipe.launch(1)
-        outs = pipe.wait(0)                               # valid until slot 0 is launched again
+        pipe = ForwardPipeline(eng, [img_a, img_b])      # static input tensor per slot
+        pipe.refill(0, batch0); pipe.launch(0); pipe.refill(1, batch1); pipe.launch(1)
+        outs = pipe.wait(0)                               # host wait; valid until slot 0 is launched again
 
     Results are bit-identical to `eng.forward(img)`: the same kernels on the same inputs, only scheduled side by side."""
 
@@ -813,21 +809,21 @@ class ForwardPipeline(object):
     def __len__(self):
         return len(self.graphs)
 
-    def launch(self, slot, after_current_stream=True):
-        """Replays slot's forward on its stream.  after_current_stream: order it after the work already queued on the caller's
-        current stream (the refill of `imgs[slot]`)."""
+    def refill(self, slot, batch):
+        """Copies `batch` into the slot's input ON THE SLOT'S STREAM (ordered before its next launch by stream order alone).
+        `batch` must be complete from the host's point of view (pinned host memory, or device memory produced before a host
+        synchronise): every hand-over of the pipeline is stream order or a host wait, no cross-stream event edges."""
+        with torch.cuda.stream(self.streams[slot]):
+            self.imgs[slot].copy_(batch, non_blocking=True)
+
+    def launch(self, slot):
+        """Replays slot's forward on its stream (after whatever `refill` queued there)."""
         s = self.streams[slot]
-        if after_current_stream:
-            s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self.graphs[slot].replay()
             self.done[slot].record(s)
 
-    def outputs(self, slot):
-        """Stream-ordered hand-over: the caller's current stream waits for slot's forward; no host synchronisation."""
-        torch.cuda.current_stream().wait_event(self.done[slot])
-        return self.outs[slot]
-
     def wait(self, slot):
+        """Host wait for slot's forward; returns its outs_list (valid until the slot is launched again)."""
         self.done[slot].synchronize()
         return self.outs[slot]

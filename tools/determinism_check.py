@@ -26,8 +26,8 @@ if os.environ.get('NO_OVERLAP'): eng.overlap = False
 print('overlap', eng.overlap, 'factorised', eng.factorised_fusion)
 base = [snap(eng.forward(im)) for im in imgs]
 torch.cuda.synchronize()
-for trial in range(2):
-    eng.autotune(imgs[0])
+for trial in range(int(os.environ.get('TRIALS', '2'))):
+    if not os.environ.get('NO_TUNE'): eng.autotune(imgs[0])
     tuned = [snap(eng.forward(im)) for im in imgs]
     torch.cuda.synchronize()
     bad = [same(t, b) for t, b in zip(tuned, base)]
@@ -36,15 +36,24 @@ for trial in range(2):
         table = eng.export_tuning(B)
         json.dump(table, open(os.path.join(ROOT, 'gpurun_out', 'bad_tuning_%d.json' % trial), 'w'))
     pipe = E.ForwardPipeline(eng, imgs)
-    for rep in range(10):
-        pipe.launch(0, False); pipe.launch(1, False)
+    for rep in range(int(os.environ.get('REPS', '10'))):
+        pipe.launch(0); pipe.launch(1)
         o = [snap(pipe.wait(s)) for s in (0, 1)]
         bad = [same(x, t) for x, t in zip(o, tuned)]
         if any(bad):
             print('   rep %d: concurrent slots vs tuned eager: %s' % (rep, bad))
+    src = [im.clone() for im in imgs]
+    for rep in range(10):                      # refill on the slot's own stream, host wait for the results
+        for s in (0, 1):
+            pipe.refill(s, src[s]); pipe.launch(s)
+        o = [snap(pipe.wait(s)) for s in (0, 1)]
+        torch.cuda.synchronize()
+        bad = [same(x, t) for x, t in zip(o, tuned)]
+        if any(bad):
+            print('   rep %d: refill + launch vs tuned eager: %s' % (rep, bad))
     for rep in range(3):
         for s in (0, 1):
-            pipe.launch(s, False)
+            pipe.launch(s)
             x = snap(pipe.wait(s))
             b = same(x, tuned[s])
             if b:
