@@ -128,6 +128,21 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
     finite = bool(torch.isfinite(outs[2]['pd_mesh_xyz_left']).all())
+    # overlapped execution must not change results: every slot's outputs from the timed (overlapping) replays against the same
+    # slot replayed alone (this is the check that exposed the packed-FP32 hazard)
+    reproducible = None
+    if not args.no_graph and args.inflight > 1:
+        def snap(o):
+            return [o[i][k].clone() for i in range(3) for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_uv_left', 'pd_offset')] + [o[3]['seg'].clone()]
+        for s_ in range(args.inflight):
+            pipe.launch(s_)
+        torch.cuda.synchronize()
+        overlapped = [snap(pipe.outs[s_]) for s_ in range(args.inflight)]
+        reproducible = True
+        for s_ in range(args.inflight):
+            pipe.launch(s_)
+            alone = snap(pipe.wait(s_))
+            reproducible = reproducible and all(torch.equal(a, b) for a, b in zip(overlapped[s_], alone))
 
     # ---- roofline of the dominant kernel: HIP events around every conv launch, eager, same stream
     roof = None
@@ -230,7 +245,8 @@ def main():
                                        'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads',
                            'batch_per_gpu': B, 'graph': not args.no_graph, 'forwards_in_flight': args.inflight,
                            'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3), 'weights': 'synthetic (dir_amd.synth seed 1234)',
-                           'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite},
+                           'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite,
+                           'overlapped_equals_one_at_a_time': reproducible},
                 'roofline': roof, 'cpu_baseline': cpu}
         print(json.dumps(line))
     if world > 1:
