@@ -32,7 +32,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 
 // The VALU work per conv output is what bounds this kernel (75.8 M outputs at B = 64), so the epilogue and the pooling run on
-// packed instructions: v_pk_fma_f32 (scale / shift), v_cvt_pk_bf16_f32 (round to nearest even, = convk::f2bf on finite values),
+// packed instructions: v_cvt_pk_bf16_f32 (round to nearest even, = convk::f2bf on finite values),
 // and ReLU / max as v_pk_max_i16 on the bf16 bit patterns (sign bit set -> negative int16 -> 0; non-negative bf16 order = int16 order).
 __device__ __forceinline__ unsigned pack_bf16(f32x2 v) {
     const bf16x2 b = __builtin_convertvector(v, bf16x2);
