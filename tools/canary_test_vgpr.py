@@ -1,4 +1,4 @@
-"""Scratch: LDS canary beside the suspected aggressor (skip4.dual, conv variant 19 = 64x128 tile with the 3-buffer DMA ring)."""
+"""Scratch (build first: hipcc --offload-arch=gfx950 -O3 -fPIC -shared -o tools/_ubench/canary_vgpr.so tools/canary_vgpr.hip): VGPR canary beside the suspected aggressor (skip4.dual, conv variant 19 = 64x128 tile with the 3-buffer DMA ring)."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

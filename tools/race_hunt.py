@@ -1,4 +1,5 @@
-"""Scratch: which tensor of the init stage diverges first when the skip branch runs on the side stream?"""
+"""Scratch: which tensor of the init stage diverges first when the skip branch runs on the side stream (DIR_OVERLAP semantics)?
+Part of the packed-FP32 hunt; with the library built as it is now this prints an empty histogram."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
