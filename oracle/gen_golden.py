@@ -478,8 +478,67 @@ def gen_loss():
     save('g8_loss', **out)
 
 
+# ----------------------------------------------------------------------------- G12 gradients of the training objective
+def gen_loss_grad():
+    """d(sum of the 42 terms) / d(predictions): torch autograd through the reference's own loss modules (models/loss.py,
+    models/lovasz_loss.py, nn.CrossEntropyLoss) composed as models/dir.py:562-592 composes them -- the composition is checked here
+    against the 42 forward values G8 holds from the reference's DIR.forward -- on the G8 predictions as leaf tensors (pd_mesh_uv is
+    its own leaf: the projection's chain rule is the caller's).  Run after `loss`."""
+    import torch.nn.functional as F
+    from models.loss import EdgeLengthLoss, NormalVectorLoss, SmoothL1Loss
+    from models.lovasz_loss import lovasz_softmax
+    g = dict(np.load(os.path.join(OUT, 'g8_loss.npz')))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    faces = {s_: synth.loss_faces(s_, SEED) for s_ in ('left', 'right')}
+    l1 = SmoothL1Loss()
+    edge = {s_: EdgeLengthLoss(faces[s_]) for s_ in faces}
+    normal = {s_: NormalVectorLoss(faces[s_]) for s_ in faces}
+    ce = nn.CrossEntropyLoss(weight=torch.Tensor([.1, 0.45, 0.45]))
+    leaves, loss = {}, {}
+
+    def leaf(name):
+        t = T(g[name]).clone().requires_grad_(True)
+        leaves[name] = t
+        return t
+    seg, dense = leaf('seg'), leaf('dense')
+    gt_seg = T(g['gt_seg_u8'].astype(np.float32))
+    gt_dense = T(g['gt_dense_u8'].astype(np.float32) / np.float32(255.0))
+    S = seg.shape[-1]
+    lab = F.interpolate(gt_seg, (S, S), mode='nearest').long().squeeze(1)
+    dd = F.interpolate(gt_dense, (S, S), mode='bilinear')
+    loss['seg'] = ce(seg, lab) * 0.1
+    loss['dense'] = l1(dense, dd)
+    loss['lovasz'] = lovasz_softmax(seg, lab) * 0.1
+    cl, cr = T(g['gt_center_left']), T(g['gt_center_right'])
+    cen = {'left': cl, 'right': cr}
+    gt_off = (cr - cl) / 0.15
+    for i in range(3):
+        for s_ in ('left', 'right'):
+            gj = (T(g['gt_joint_3d_' + s_]) - cen[s_]) / 0.15
+            gm = (T(g['gt_mesh_3d_' + s_]) - cen[s_]) / 0.15
+            loss['joint_%s_uv_%d' % (s_, i)] = l1(leaf('s%d.pd_joint_uv_%s' % (i, s_)), T(g['gt_joint_2d_' + s_])[:, :, :2]) * 10
+            loss['mesh_%s_uv_%d' % (s_, i)] = l1(leaf('s%d.pd_mesh_uv_%s' % (i, s_)), T(g['gt_mesh_2d_' + s_])[:, :, :2]) * 10
+            jp = leaf('s%d.pd_joint_xyz_%s' % (i, s_)) / 0.15
+            mp = leaf('s%d.pd_mesh_xyz_%s' % (i, s_)) / 0.15
+            loss['joint_%s_xyz_%d' % (s_, i)] = l1(jp, gj) * 10
+            loss['mesh_%s_xyz_%d' % (s_, i)] = l1(mp, gm) * 10
+            loss['edge_%s_%d' % (s_, i)] = edge[s_](mp, gm).mean()
+            loss['normal_%s_%d' % (s_, i)] = normal[s_](mp, gm).mean() * 0.1
+        loss['offset_%d' % i] = l1(leaf('s%d.pd_offset' % i), gt_off.squeeze(1)) * 10
+    assert len(loss) == 42
+    for k, v in loss.items():
+        want = float(g['loss.' + k])
+        assert abs(float(v) - want) <= 1e-6 * max(1.0, abs(want)), (k, float(v), want)     # same composition as DIR.forward
+    sum(loss.values()).backward()
+    out = {'grad.' + k: v.grad for k, v in leaves.items()}
+    for k, v in out.items():
+        assert v is not None and bool(torch.isfinite(v).all()), k
+    print('   %d gradient tensors, |g|max %.3e' % (len(out), max(float(v.abs().max()) for v in out.values())))
+    save('g12_loss_grad', **out)
+
+
 GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
-        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss}
+        'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

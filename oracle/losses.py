@@ -139,3 +139,98 @@ def dense_losses(seg_logits, dense_pred, gt_seg, gt_dense, class_weight=(0.1, 0.
     return {'seg': cross_entropy_weighted(seg_logits, lab, class_weight) * 0.1 * dense_weight,
             'dense': smooth_l1(dense_pred, dd) * dense_weight,
             'lovasz': lovasz_softmax(seg_logits, lab) * 0.1 * dense_weight}
+
+
+# ----------------------------------------------------------------------------- gradients (what autograd gives on the reference's modules)
+def smooth_l1_grad(x, y, scale=1.0):
+    """d(scale * smooth_l1(x, y)) / dx: z inside the knee, 0.01 sign(z) outside (models/loss.py:74-81), / (features * batch)"""
+    B = x.shape[0]
+    z = (x.reshape(B, -1).astype(F32) - y.reshape(B, -1).astype(F32)).astype(np.float64)
+    g = np.where(np.abs(z) < 0.01, z, 0.01 * np.sign(z))
+    return (g * (scale / (z.shape[1] * B))).reshape(x.shape)
+
+
+def edge_length_grad(out, gt, face, scale=1.0):
+    """d(scale * edge_length_loss) / d out"""
+    out64, gt64 = out.astype(np.float64), gt.astype(np.float64)
+    B, F = out.shape[0], face.shape[0]
+    g = np.zeros_like(out64)
+    for a, b in ((0, 1), (0, 2), (1, 2)):
+        ia, ib = face[:, a], face[:, b]
+        e = out64[:, ia] - out64[:, ib]
+        d = np.sqrt((e * e).sum(2) + 1e-12)
+        eg = gt64[:, ia] - gt64[:, ib]
+        dg = np.sqrt((eg * eg).sum(2) + 1e-12)
+        c = (np.sign(d - dg) / d)[..., None] * e * (scale / (B * 3 * F))
+        for bi in range(B):
+            np.add.at(g[bi], ia, c[bi])
+            np.add.at(g[bi], ib, -c[bi])
+    return g
+
+
+def normal_vector_grad(out, gt, face, scale=1.0):
+    """d(scale * normal_vector_loss) / d out: cos = |v_hat . n|, d cos / d e = sign(v_hat . n) (n - (v_hat . n) v_hat) / |e|"""
+    out64, gt64 = out.astype(np.float64), gt.astype(np.float64)
+    B, F = out.shape[0], face.shape[0]
+    f0, f1, f2 = face[:, 0], face[:, 1], face[:, 2]
+
+    def nrm(v):
+        return v / np.maximum(np.sqrt((v * v).sum(2, keepdims=True)), 1e-12)
+    n = nrm(np.cross(nrm(gt64[:, f1] - gt64[:, f0]), nrm(gt64[:, f2] - gt64[:, f0]), axis=2))
+    g = np.zeros_like(out64)
+    for hi, lo in ((f1, f0), (f2, f0), (f2, f1)):
+        e = out64[:, hi] - out64[:, lo]
+        ln = np.maximum(np.sqrt((e * e).sum(2, keepdims=True)), 1e-12)
+        v = e / ln
+        dot = (v * n).sum(2, keepdims=True)
+        c = np.sign(dot) * (n - dot * v) / ln * (scale / (B * 3 * F))
+        for bi in range(B):
+            np.add.at(g[bi], hi, c[bi])
+            np.add.at(g[bi], lo, -c[bi])
+    return g
+
+
+def stage_loss_grads(pred, gt, faces, coord_weight=10.0):
+    """gradients of the sum of one stage's 13 terms w.r.t. pd_joint_uv / pd_mesh_uv / pd_joint_xyz / pd_mesh_xyz (per hand) and
+    pd_offset (pd_mesh_uv taken as an independent input)"""
+    out = {}
+    gt_off = ((gt['center_right'] - gt['center_left']).astype(F32) / F32(0.15)).astype(F32)
+    for side, face in zip(('left', 'right'), faces):
+        c = gt['center_' + side].astype(F32)
+        gj = ((gt['joint_3d_' + side].astype(F32) - c) / F32(0.15)).astype(F32)
+        gm = ((gt['mesh_3d_' + side].astype(F32) - c) / F32(0.15)).astype(F32)
+        pj = (pred['pd_joint_xyz_' + side].astype(F32) / F32(0.15)).astype(F32)
+        pm = (pred['pd_mesh_xyz_' + side].astype(F32) / F32(0.15)).astype(F32)
+        out['pd_joint_uv_' + side] = smooth_l1_grad(pred['pd_joint_uv_' + side], gt['joint_2d_' + side][:, :, :2], coord_weight)
+        out['pd_mesh_uv_' + side] = smooth_l1_grad(pred['pd_mesh_uv_' + side], gt['mesh_2d_' + side][:, :, :2], coord_weight)
+        out['pd_joint_xyz_' + side] = smooth_l1_grad(pj, gj, coord_weight) / 0.15
+        out['pd_mesh_xyz_' + side] = (smooth_l1_grad(pm, gm, coord_weight) + edge_length_grad(pm, gm, face)
+                                      + normal_vector_grad(pm, gm, face, 0.1)) / 0.15
+    out['pd_offset'] = smooth_l1_grad(pred['pd_offset'], gt_off[:, 0], coord_weight)
+    return out
+
+
+def dense_loss_grads(seg_logits, dense_pred, gt_seg, gt_dense, class_weight=(0.1, 0.45, 0.45), dense_weight=1.0):
+    """gradients of seg + dense + lovasz w.r.t. the seg logits and the dense prediction"""
+    B, C, S, _ = seg_logits.shape
+    lab = interpolate_nearest(gt_seg, S).astype(np.int64)[:, 0]
+    dd = interpolate_bilinear(gt_dense, S)
+    x = seg_logits.transpose(0, 2, 3, 1).reshape(-1, C).astype(np.float64)
+    y = lab.reshape(-1)
+    p = np.exp(x - x.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
+    w = np.asarray(class_weight, np.float64)[y]
+    gce = p.copy(); gce[np.arange(len(y)), y] -= 1.0
+    gce *= (w / w.sum())[:, None] * 0.1 * dense_weight
+    glov = np.zeros_like(x)
+    present = [c for c in range(C) if (y == c).any()]
+    for c in present:
+        fg = (y == c).astype(np.float64)
+        err = np.abs(fg - x[:, c].astype(F32).astype(np.float64))
+        perm = np.argsort(-err.astype(F32), kind='stable')
+        fs = fg[perm]
+        gts = fs.sum()
+        jac = 1.0 - (gts - np.cumsum(fs)) / (gts + np.cumsum(1.0 - fs))
+        jac[1:] = jac[1:] - jac[:-1]
+        glov[perm, c] = np.sign(x[perm, c] - fs) * jac * (0.1 * dense_weight / len(present))
+    gseg = (gce + glov).reshape(B, S, S, C).transpose(0, 3, 1, 2)
+    return {'seg': gseg, 'dense': smooth_l1_grad(dense_pred, dd, dense_weight)}

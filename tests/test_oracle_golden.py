@@ -310,3 +310,19 @@ def test_adamw_oracle_matches_torch():
         assert relerr(p, w.detach().numpy()) < 2e-7, step
         st = opt.state[w]
         assert relerr(m, st['exp_avg'].numpy()) < 2e-7 and relerr(v, st['exp_avg_sq'].numpy()) < 2e-7
+
+
+def test_loss_gradients_match_autograd(golden):
+    """oracle/losses.py gradients against torch autograd through the reference's loss modules (G12, oracle/gen_golden.py gen_loss_grad)"""
+    from conftest import loss_case
+    from oracle import losses as OL
+    g, gg = golden('g8_loss'), golden('g12_loss_grad')
+    preds, gt, faces, seg, dense, gt_seg, gt_dense = loss_case(g)
+    d = OL.dense_loss_grads(seg, dense, gt_seg, gt_dense)
+    # the reference side is fp32 autograd; its Lovasz term differences J_i - J_{i-1} (~1e-5) carry fp32 cancellation noise
+    for k, tol in (('seg', 1e-4), ('dense', 2e-5)):
+        assert maxabs(d[k], gg['grad.' + k]) <= tol * np.abs(gg['grad.' + k]).max(), k
+    for i in range(3):
+        for k, v in OL.stage_loss_grads(preds[i], gt, faces).items():
+            want = gg['grad.s%d.%s' % (i, k)]
+            assert maxabs(v, want) <= 2e-5 * np.abs(want).max(), (i, k, maxabs(v, want), np.abs(want).max())
