@@ -86,12 +86,17 @@ class LossTarget(C.Structure):
                 ('c2', C.c_int32), ('n_faces', C.c_int32)]
 
 
+class LossPredGrad(C.Structure):
+    _fields_ = [('joint_uv', C.c_void_p * 2), ('mesh_uv', C.c_void_p * 2), ('joint_xyz', C.c_void_p * 2),
+                ('mesh_xyz', C.c_void_p * 2), ('offset', C.c_void_p)]
+
+
 class EvalOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('joint_err', 'vert_err', 'joint2d_err', 'vert2d_err', 'joints_pd', 'joints_gt',
                                           'root_err')]
 
 
-ABI_VERSION = 9          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 10          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -107,6 +112,10 @@ _SIGNATURES = {
     'dir_stem_prep_s2d_u8': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _i, _i, _i, _p]),
     'dir_adamw_step': (C.c_int, [_p, _p, _p, _p, C.c_longlong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_longlong, _p]),
+    'dir_stage_losses_backward': (C.c_int, [C.POINTER(LossPred), C.POINTER(LossTarget), C.c_float, _p, C.POINTER(C.c_void_p * 2),
+                                            C.POINTER(C.c_void_p * 2), C.POINTER(LossPredGrad), _i, _p]),
+    'dir_dense_losses_backward_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_dense_losses_backward': (C.c_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.c_float, _p, _p, C.c_longlong, _p, _p, _i, _i, _i, _i, _p]),
     'dir_stage_losses_forward': (C.c_int, [C.POINTER(LossPred), C.POINTER(LossTarget), C.c_float, _p, _p, _i, _p]),
     'dir_dense_losses_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_dense_losses_forward': (C.c_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.c_float, _p, C.c_longlong, _p, _i, _i, _i, _i, _p]),

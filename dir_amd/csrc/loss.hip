@@ -354,6 +354,358 @@ int dense_ws(int B, int S, DenseWs& w) {
 }  // namespace
 }  // namespace dir
 
+
+// ================================================================================================ backward (gradients w.r.t. the predictions)
+namespace dir {
+namespace {
+
+__device__ __forceinline__ float sgn(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+// d smooth_l1_term / d x (models/loss.py:74-81 under autograd: z inside the knee, 0.01 sign(z) outside)
+__device__ __forceinline__ float smooth_l1_dterm(float x, float y) {
+#pragma clang fp contract(off)
+    const float z = x - y;
+    return fabsf(z) < 0.01f ? z : 0.01f * sgn(z);
+}
+
+struct StageBwdArgs {
+    dir_loss_pred p;
+    dir_loss_target g;
+    dir_loss_pred_grad o;
+    const float* gout;          // [13] upstream gradients (NULL: ones)
+    const int32_t* vf_off[2];   // CSR vertex -> (face * 3 + corner) lists: offsets [NV + 1]
+    const int32_t* vf_idx[2];   // entries [3 F]
+    float coord_weight;
+    int B;
+};
+
+// One workgroup per (sample, hand).  Phase 1: every triangle's edge-length and normal-vector gradient contributions to its three
+// corners go to LDS (9 floats per triangle); phase 2: every vertex sums its corners in CSR order (deterministic, no atomics), adds the
+// SmoothL1 term and applies the 1 / 0.15 of the normalisation.
+__global__ __launch_bounds__(LT) void stage_loss_bwd_kernel(StageBwdArgs a) {
+    extern __shared__ float s_dyn[];
+    float* s_pm = s_dyn;                 // [NV * 3]
+    float* s_gm = s_pm + NV * 3;         // [NV * 3]
+    float* s_fg = s_gm + NV * 3;         // [F * 9]
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, F = a.g.n_faces;
+    const float* cen = a.g.center[h] + (size_t)b * 3;
+    const float c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    auto gk = [&](int k) { return a.gout ? a.gout[k] : 1.f; };
+    const float invB = 1.f / (float)a.B;
+    {
+        const float* pm = a.p.mesh_xyz[h] + (size_t)b * NV * 3;
+        const float* gm = a.g.mesh_3d[h] + (size_t)b * NV * 3;
+        for (int i = tid; i < NV * 3; i += LT) {
+            const int c = i % 3;
+            s_pm[i] = pm[i] / 0.15f;
+            s_gm[i] = (gm[i] - (c == 0 ? c0 : c == 1 ? c1 : c2)) / 0.15f;
+        }
+    }
+    __syncthreads();
+    const float ke = gk(8 + h) * invB / (3.f * F), kn = gk(10 + h) * 0.1f * invB / (3.f * F);
+    const int32_t* face = a.g.faces[h];
+    for (int f = tid; f < F; f += LT) {
+        const int idx[3] = {face[f * 3], face[f * 3 + 1], face[f * 3 + 2]};
+        V3 p[3], g[3], acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { p[c] = ld3(s_pm + idx[c] * 3); g[c] = ld3(s_gm + idx[c] * 3); acc[c] = V3{0.f, 0.f, 0.f}; }
+        const V3 n = normalize(cross(normalize(sub(g[1], g[0])), normalize(sub(g[2], g[0]))));
+        auto add = [&](int c, V3 v, float sc) { acc[c].x += sc * v.x; acc[c].y += sc * v.y; acc[c].z += sc * v.z; };
+        const int ea[3] = {0, 0, 1}, eb[3] = {1, 2, 2};               // edge pairs of EdgeLengthLoss; NormalVectorLoss: (hi, lo) = (eb, ea)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const V3 d = sub(p[ea[e]], p[eb[e]]);
+            const float len = sqrtf(sumsq(d) + 1e-12f), leng = sqrtf(sumsq(sub(g[ea[e]], g[eb[e]])) + 1e-12f);
+            const float s = sgn(len - leng) / len * ke;
+            add(ea[e], d, s); add(eb[e], d, -s);
+            const V3 ev = sub(p[eb[e]], p[ea[e]]);                    // hi - lo
+            const float ln = fmaxf(sqrtf(sumsq(ev)), 1e-12f);
+            const V3 v = V3{ev.x / ln, ev.y / ln, ev.z / ln};
+            const float dt = dot(v, n), sc = sgn(dt) / ln * kn;
+            const V3 t = V3{n.x - dt * v.x, n.y - dt * v.y, n.z - dt * v.z};
+            add(eb[e], t, sc); add(ea[e], t, -sc);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s_fg[(f * 3 + c) * 3] = acc[c].x; s_fg[(f * 3 + c) * 3 + 1] = acc[c].y; s_fg[(f * 3 + c) * 3 + 2] = acc[c].z; }
+    }
+    __syncthreads();
+    const float km = gk(6 + h) * a.coord_weight * invB / (NV * 3.f);
+    float* gmx = a.o.mesh_xyz[h] + (size_t)b * NV * 3;
+    for (int v = tid; v < NV; v += LT) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int e = a.vf_off[h][v]; e < a.vf_off[h][v + 1]; ++e) {
+            const int k = a.vf_idx[h][e] * 3;
+            sx += s_fg[k]; sy += s_fg[k + 1]; sz += s_fg[k + 2];
+        }
+        sx += km * smooth_l1_dterm(s_pm[3 * v], s_gm[3 * v]);
+        sy += km * smooth_l1_dterm(s_pm[3 * v + 1], s_gm[3 * v + 1]);
+        sz += km * smooth_l1_dterm(s_pm[3 * v + 2], s_gm[3 * v + 2]);
+        gmx[3 * v] = sx / 0.15f; gmx[3 * v + 1] = sy / 0.15f; gmx[3 * v + 2] = sz / 0.15f;
+    }
+    // joints, uv, offset: plain SmoothL1 gradients
+    if (tid < NJ * 3) {
+        const int c = tid % 3;
+        const float x = a.p.joint_xyz[h][(size_t)b * NJ * 3 + tid] / 0.15f;
+        const float y = (a.g.joint_3d[h][(size_t)b * NJ * 3 + tid] - (c == 0 ? c0 : c == 1 ? c1 : c2)) / 0.15f;
+        a.o.joint_xyz[h][(size_t)b * NJ * 3 + tid] = gk(4 + h) * a.coord_weight * invB / (NJ * 3.f) * smooth_l1_dterm(x, y) / 0.15f;
+    }
+    if (tid < NJ * 2) {
+        const int j = tid >> 1, c = tid & 1;
+        a.o.joint_uv[h][(size_t)b * NJ * 2 + tid] = gk(0 + h) * a.coord_weight * invB / (NJ * 2.f) *
+            smooth_l1_dterm(a.p.joint_uv[h][(size_t)b * NJ * 2 + tid], a.g.joint_2d[h][((size_t)b * NJ + j) * a.g.c2 + c]);
+    }
+    for (int i = tid; i < NV * 2; i += LT) {
+        const int v = i >> 1, c = i & 1;
+        a.o.mesh_uv[h][(size_t)b * NV * 2 + i] = gk(2 + h) * a.coord_weight * invB / (NV * 2.f) *
+            smooth_l1_dterm(a.p.mesh_uv[h][(size_t)b * NV * 2 + i], a.g.mesh_2d[h][((size_t)b * NV + v) * a.g.c2 + c]);
+    }
+    if (h == 0 && tid < 3) {
+        const float y = (a.g.center[1][(size_t)b * 3 + tid] - a.g.center[0][(size_t)b * 3 + tid]) / 0.15f;
+        a.o.offset[(size_t)b * 3 + tid] = gk(12) * a.coord_weight * invB / 3.f * smooth_l1_dterm(a.p.offset[(size_t)b * 3 + tid], y);
+    }
+}
+
+// ---- seg / dense / lovasz
+struct DenseBwdArgs {
+    const float* seg; const float* dense; const float* gt_seg; const float* gt_dense;
+    unsigned long long* keys; unsigned* vals;      // [3][P]: composite (class, error) keys; values = pixel index | fg << 31
+    double* partial;                                // [nwg][4]: sum of class weights, fg count of class 0..2
+    unsigned char* label;                           // [P]
+    float* gdense;
+    const float* gout;                              // [3] upstream gradients (NULL: ones)
+    int B, S, H, W, P, chunks;
+    float cw[3], dense_weight;
+};
+
+__global__ __launch_bounds__(LT) void dense_bwd_pixel_kernel(DenseBwdArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double s_red[LT / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, S = a.S, pix = blockIdx.x * LT + tid;
+    const bool ok = pix < S * S;
+    const int oy = ok ? pix / S : 0, ox = ok ? pix - oy * S : 0;
+    double v[4] = {0, 0, 0, 0};
+    if (ok) {
+        const int sy = min((int)floorf(oy * ((float)a.H / S)), a.H - 1), sx = min((int)floorf(ox * ((float)a.W / S)), a.W - 1);
+        int lab = (int)a.gt_seg[((size_t)b * a.H + sy) * a.W + sx];
+        lab = lab < 0 ? 0 : lab > 2 ? 2 : lab;
+        const size_t plane = (size_t)S * S, p = (size_t)b * plane + pix;
+        a.label[p] = (unsigned char)lab;
+        v[0] = a.cw[lab];
+        const float* sg = a.seg + (size_t)b * 3 * plane + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float fg = lab == c ? 1.f : 0.f;
+            a.keys[(size_t)c * a.P + p] = ((unsigned long long)(2 - c) << 32) | (unsigned long long)__float_as_uint(fabsf(fg - sg[c * plane]));
+            a.vals[(size_t)c * a.P + p] = (unsigned)p | (lab == c ? 0x80000000u : 0u);
+            v[1 + c] = lab == c;
+        }
+        // dense SmoothL1 gradient (target = bilinear F.interpolate of the GT map, as in the forward)
+        const float fy = fmaxf((oy + 0.5f) * ((float)a.H / S) - 0.5f, 0.f), fx = fmaxf((ox + 0.5f) * ((float)a.W / S) - 0.5f, 0.f);
+        const int y0 = (int)floorf(fy), x0 = (int)floorf(fx), y1 = min(y0 + 1, a.H - 1), x1 = min(x0 + 1, a.W - 1);
+        const float wy1 = fy - y0, wy0 = 1.f - wy1, wx1 = fx - x0, wx0 = 1.f - wx1;
+        const float kd = (a.gout ? a.gout[1] : 1.f) * a.dense_weight / ((float)a.B * 3.f * S * S);
+        for (int c = 0; c < 3; ++c) {
+            const float* gd = a.gt_dense + ((size_t)b * 3 + c) * a.H * a.W;
+            const float r0 = wx0 * gd[(size_t)y0 * a.W + x0] + wx1 * gd[(size_t)y0 * a.W + x1];
+            const float r1 = wx0 * gd[(size_t)y1 * a.W + x0] + wx1 * gd[(size_t)y1 * a.W + x1];
+            const float t = wy0 * r0 + wy1 * r1;
+            const size_t o = ((size_t)b * 3 + c) * plane + pix;
+            a.gdense[o] = kd * smooth_l1_dterm(a.dense[o], t);
+        }
+    }
+    double* out = a.partial + ((size_t)b * a.chunks + blockIdx.x) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double t = block_sum_d<LT / 64>(v[k], s_red, tid);
+        if (tid == 0) out[k] = t;
+    }
+}
+
+// same scan as lovasz_kernel; writes d loss_c / d logit = sign(logit - fg) (J_i - J_{i-1}) at the element's pixel
+__global__ __launch_bounds__(LV_T) void lovasz_bwd_kernel(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                          const float* __restrict__ seg, const double* __restrict__ partial, int nwg, int P,
+                                                          int plane, float* __restrict__ glov, double* __restrict__ result) {
+    __shared__ double s_red[LV_T / 64];
+    __shared__ int s_wsum[LV_T / 64];
+    __shared__ double s_prevJ;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double G = 0, W = 0;
+    for (int i = 0; i < nwg; ++i) { G += partial[(size_t)i * 4 + 1 + c]; W += partial[(size_t)i * 4]; }
+    if (tid == 0) { result[c] = G; if (c == 0) result[3] = W; }
+    const unsigned* vv = vals + (size_t)c * P;
+    long long carry = 0;
+    double prevJ = 0;
+    for (int base = 0; base < P; base += LV_T * LV_E) {
+        const int i0 = base + tid * LV_E;
+        int fg[LV_E]; unsigned px[LV_E];
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < LV_E; ++k) {
+            const bool ok = i0 + k < P;
+            const unsigned v = ok ? vv[i0 + k] : 0u;
+            fg[k] = ok ? (int)(v >> 31) : 0;
+            px[k] = v & 0x7fffffffu;
+            mine += fg[k];
+        }
+        int x = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < LV_T / 64; ++w) {
+            const int sw = s_wsum[w];
+            if (w < wave) woff += sw;
+            total += sw;
+        }
+        long long cum = carry + woff + x - mine;
+        double J[LV_E];
+#pragma unroll
+        for (int k = 0; k < LV_E; ++k) {
+            cum += fg[k];
+            const long long cumbg = (long long)(i0 + k + 1) - cum;
+            J[k] = i0 + k < P ? 1.0 - (G - (double)cum) / (G + (double)cumbg) : 0.0;
+        }
+        double Jm = __shfl_up(J[LV_E - 1], 1, 64);
+        if (lane == 63) s_red[wave] = J[LV_E - 1];
+        __syncthreads();
+        if (lane == 0) Jm = wave == 0 ? prevJ : s_red[wave - 1];
+#pragma unroll
+        for (int k = 0; k < LV_E; ++k) {
+            if (i0 + k < P) {
+                const unsigned p = px[k];
+                const int bb = p / plane, pix = p - bb * plane;
+                const float lg = seg[((size_t)bb * 3 + c) * plane + pix];
+                glov[(size_t)c * P + p] = sgn(lg - (float)fg[k]) * (float)(J[k] - Jm);
+            }
+            Jm = J[k];
+        }
+        if (tid == LV_T - 1) s_prevJ = J[LV_E - 1];
+        __syncthreads();
+        prevJ = s_prevJ;
+        carry += total;
+    }
+}
+
+// grad_seg[b][c][pix] = g_seg 0.1 dw w[y] (softmax_c - [c == y]) / sum w  +  g_lov 0.1 dw / n_present * glov[c][p]
+__global__ __launch_bounds__(LT) void dense_bwd_final_kernel(DenseBwdArgs a, const float* __restrict__ glov, const double* __restrict__ result,
+                                                             float* __restrict__ gseg) {
+    const int b = blockIdx.y, pix = blockIdx.x * LT + threadIdx.x, S = a.S;
+    if (pix >= S * S) return;
+    const size_t plane = (size_t)S * S, p = (size_t)b * plane + pix;
+    const int lab = a.label[p];
+    const float* sg = a.seg + (size_t)b * 3 * plane + pix;
+    const double l0 = sg[0], l1 = sg[plane], l2 = sg[2 * plane];
+    const double m = fmax(l0, fmax(l1, l2));
+    const double e0 = exp(l0 - m), e1 = exp(l1 - m), e2 = exp(l2 - m), es = e0 + e1 + e2;
+    int npres = 0;
+    for (int c = 0; c < 3; ++c) npres += result[c] > 0;
+    const double kce = (double)(a.gout ? a.gout[0] : 1.f) * 0.1 * a.dense_weight * a.cw[lab] / result[3];
+    const double klv = npres ? (double)(a.gout ? a.gout[2] : 1.f) * 0.1 * a.dense_weight / npres : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double sm = (c == 0 ? e0 : c == 1 ? e1 : e2) / es;
+        const double gl = result[c] > 0 ? (double)glov[(size_t)c * a.P + p] : 0.0;
+        gseg[((size_t)b * 3 + c) * plane + pix] = (float)(kce * (sm - (lab == c ? 1.0 : 0.0)) + klv * gl);
+    }
+}
+
+struct DenseBwdWs { size_t keys_in, keys_out, vals_in, vals_out, partial, result, label, glov, temp, temp_bytes, total; };
+int dense_bwd_ws(int B, int S, DenseBwdWs& w) {
+    const size_t P = (size_t)B * S * S;
+    const int chunks = (S * S + LT - 1) / LT;
+    size_t o = 0;
+    w.keys_in = o; o = al(o + 3 * P * 8);
+    w.keys_out = o; o = al(o + 3 * P * 8);
+    w.vals_in = o; o = al(o + 3 * P * 4);
+    w.vals_out = o; o = al(o + 3 * P * 4);
+    w.partial = o; o = al(o + (size_t)B * chunks * 4 * sizeof(double));
+    w.result = o; o = al(o + 4 * sizeof(double));
+    w.label = o; o = al(o + P);
+    w.glov = o; o = al(o + 3 * P * 4);
+    size_t tb = 0;
+    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                                        (const unsigned*)nullptr, (unsigned*)nullptr, 3 * P, 0u, KEY_BITS, (hipStream_t)0);
+    if (e != hipSuccess) return -1;
+    w.temp = o; w.temp_bytes = tb; o = al(o + tb);
+    w.total = o;
+    return 0;
+}
+
+}  // namespace
+}  // namespace dir
+
+extern "C" int dir_stage_losses_backward(const dir_loss_pred* pred_host, const dir_loss_target* gt_host, float coord_weight,
+                                         const float* grad_out13, const int32_t* const* vert_face_offsets, const int32_t* const* vert_face_index,
+                                         const dir_loss_pred_grad* grads_host, int B, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(pred_host && gt_host && grads_host && vert_face_offsets && vert_face_index, "dir_stage_losses_backward: null pointer");
+    DIR_REQUIRE(B > 0 && gt_host->c2 >= 2 && gt_host->n_faces > 0, "dir_stage_losses_backward: bad arguments");
+    for (int h = 0; h < 2; ++h)
+        DIR_REQUIRE(pred_host->joint_uv[h] && pred_host->mesh_uv[h] && pred_host->joint_xyz[h] && pred_host->mesh_xyz[h] &&
+                    gt_host->joint_2d[h] && gt_host->mesh_2d[h] && gt_host->joint_3d[h] && gt_host->mesh_3d[h] && gt_host->center[h] &&
+                    gt_host->faces[h] && grads_host->joint_uv[h] && grads_host->mesh_uv[h] && grads_host->joint_xyz[h] &&
+                    grads_host->mesh_xyz[h] && vert_face_offsets[h] && vert_face_index[h],
+                    "dir_stage_losses_backward: null tensor (pd_mesh_uv must be given: it is a leaf of this gradient)");
+    DIR_REQUIRE(pred_host->offset && grads_host->offset, "dir_stage_losses_backward: null offset");
+    const size_t lds = ((size_t)2 * NV * 3 + (size_t)gt_host->n_faces * 9) * sizeof(float);
+    DIR_REQUIRE(lds <= 150 * 1024, "dir_stage_losses_backward: too many faces for LDS (%d)", gt_host->n_faces);
+    StageBwdArgs a;
+    a.p = *pred_host; a.g = *gt_host; a.o = *grads_host; a.gout = grad_out13; a.coord_weight = coord_weight; a.B = B;
+    for (int h = 0; h < 2; ++h) { a.vf_off[h] = vert_face_offsets[h]; a.vf_idx[h] = vert_face_index[h]; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        DIR_REQUIRE(hipFuncSetAttribute((const void*)stage_loss_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess,
+                    "dir_stage_losses_backward: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stage_loss_bwd_kernel, dim3(B, 2), dim3(LT), lds, (hipStream_t)stream, a);
+    return check_launch("dir_stage_losses_backward");
+}
+
+extern "C" long long dir_dense_losses_backward_workspace_bytes(int B, int S) {
+    using namespace dir;
+    if (B <= 0 || S <= 0) return -1;
+    DenseBwdWs w;
+    if (dense_bwd_ws(B, S, w)) return -1;
+    return (long long)w.total;
+}
+
+extern "C" int dir_dense_losses_backward(const float* seg_logits, const float* dense_pred, const float* gt_seg, const float* gt_dense,
+                                         const float* class_weight_host, float dense_weight, const float* grad_out3, void* workspace,
+                                         long long workspace_bytes, float* grad_seg, float* grad_dense, int B, int S, int H, int W,
+                                         void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(seg_logits && dense_pred && gt_seg && gt_dense && class_weight_host && workspace && grad_seg && grad_dense,
+                "dir_dense_losses_backward: null pointer");
+    DIR_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && (long long)B * S * S * 3 < (1ll << 31), "dir_dense_losses_backward: bad shape");
+    DenseBwdWs w;
+    DIR_REQUIRE(dense_bwd_ws(B, S, w) == 0, "dir_dense_losses_backward: rocPRIM size query failed");
+    DIR_REQUIRE(workspace_bytes >= (long long)w.total, "dir_dense_losses_backward: workspace too small (%lld < %zu)", workspace_bytes, w.total);
+    char* ws = (char*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    DenseBwdArgs a;
+    a.seg = seg_logits; a.dense = dense_pred; a.gt_seg = gt_seg; a.gt_dense = gt_dense; a.gdense = grad_dense; a.gout = grad_out3;
+    a.keys = (unsigned long long*)(ws + w.keys_in); a.vals = (unsigned*)(ws + w.vals_in); a.partial = (double*)(ws + w.partial);
+    a.label = (unsigned char*)(ws + w.label);
+    a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT; a.dense_weight = dense_weight;
+    for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
+    hipLaunchKernelGGL(dense_bwd_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
+    size_t tb = w.temp_bytes;
+    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const unsigned long long*)a.keys, (unsigned long long*)(ws + w.keys_out),
+                                                        (const unsigned*)a.vals, (unsigned*)(ws + w.vals_out), (size_t)3 * a.P, 0u, KEY_BITS, s);
+    DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_backward: rocPRIM sort: %s", hipGetErrorString(e));
+    double* result = (double*)(ws + w.result);
+    float* glov = (float*)(ws + w.glov);
+    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned*)(ws + w.vals_out),
+                       seg_logits, (const double*)a.partial, B * a.chunks, a.P, S * S, glov, result);
+    hipLaunchKernelGGL(dense_bwd_final_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a, (const float*)glov, (const double*)result, grad_seg);
+    return check_launch("dir_dense_losses_backward");
+}
+
 extern "C" int dir_stage_losses_forward(const dir_loss_pred* pred_host, const dir_loss_target* gt_host, float coord_weight,
                                         double* scratch, float* out13, int B, void* stream) {
     using namespace dir;

@@ -110,3 +110,77 @@ class DirLoss(object):
                     continue
                 loss['%s_%d' % (k, index)] = t[i]
         return loss
+
+
+# ----------------------------------------------------------------------------------------------- gradients w.r.t. the predictions
+def vertex_face_csr(faces, n_vertices=778):
+    """CSR lists vertex -> (face * 3 + corner) of a [F,3] triangle table (int32 tensors on the faces' device): the order in which
+    dir_stage_losses_backward sums a vertex's triangle contributions."""
+    f = faces.to(torch.int64).reshape(-1).cpu()
+    order = torch.argsort(f, stable=True)
+    counts = torch.bincount(f, minlength=n_vertices)
+    off = torch.zeros(n_vertices + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(counts, 0)
+    return off.to(torch.int32).to(faces.device), order.to(torch.int32).to(faces.device)
+
+
+def stage_loss_grads(pred, target, meta_info, faces, coord_weight=10.0, grad_out=None, csr=None):
+    """Gradients of sum_k grad_out[k] * term_k (grad_out None = ones) of one stage w.r.t. pd_joint_uv_*, pd_mesh_uv_*, pd_joint_xyz_*,
+    pd_mesh_xyz_* and pd_offset -- what autograd returns through the reference's loss modules.  pd_mesh_uv_* must be in `pred` (it
+    is an independent input of this gradient).  Returns a dict with the prediction keys."""
+    keep, p, g, o = [], _capi.LossPred(), _capi.LossTarget(), _capi.LossPredGrad()
+    out = {}
+    for field, prefix in (('joint_uv', 'pd_joint_uv_'), ('mesh_uv', 'pd_mesh_uv_'), ('joint_xyz', 'pd_joint_xyz_'), ('mesh_xyz', 'pd_mesh_xyz_')):
+        ts, arr = _pair(pred, prefix)
+        keep += ts
+        setattr(p, field, arr)
+        gs = [torch.empty_like(t) for t in ts]
+        setattr(o, field, (C.c_void_p * 2)(*[_capi.ptr(t) for t in gs]))
+        for s_, t in zip(SIDES, gs):
+            out[prefix + s_] = t
+    off = _capi.f32c(pred['pd_offset'])
+    p.offset = _capi.ptr(off)
+    out['pd_offset'] = torch.empty_like(off)
+    o.offset = _capi.ptr(out['pd_offset'])
+    for field, prefix in (('joint_2d', 'joint_2d_'), ('mesh_2d', 'mesh_2d_'), ('joint_3d', 'joint_3d_'), ('mesh_3d', 'mesh_3d_')):
+        ts, arr = _pair(target, prefix)
+        keep += ts
+        setattr(g, field, arr)
+    ts, arr = _pair(meta_info, 'center_')
+    keep += ts
+    g.center = arr
+    _capi.require_cuda(*(keep + [off]))
+    fs = [f.to(device=off.device, dtype=torch.int32).contiguous() for f in faces]
+    g.faces = (C.c_void_p * 2)(*[_capi.ptr(f) for f in fs])
+    g.c2, g.n_faces = int(keep[8].shape[-1]), int(fs[0].shape[0])
+    csr = csr if csr is not None else [vertex_face_csr(f) for f in fs]
+    offs = (C.c_void_p * 2)(*[_capi.ptr(c[0]) for c in csr])
+    idxs = (C.c_void_p * 2)(*[_capi.ptr(c[1]) for c in csr])
+    go = None if grad_out is None else _capi.f32c(grad_out)
+    with torch.cuda.device(off.device):
+        _capi.check(_capi.lib().dir_stage_losses_backward(C.byref(p), C.byref(g), float(coord_weight), None if go is None else _capi.ptr(go),
+                                                          C.byref(offs), C.byref(idxs), C.byref(o), off.shape[0], _capi.stream_ptr()),
+                    'dir_stage_losses_backward')
+    return out
+
+
+def dense_loss_grads(seg_logits, dense_pred, gt_seg, gt_dense, class_weight=(0.1, 0.45, 0.45), dense_weight=1.0, grad_out=None):
+    """Gradients of grad_out . (seg, dense, lovasz) w.r.t. the seg logits and the dense prediction -> (grad_seg, grad_dense)"""
+    seg, dense, gs, gd = (_capi.f32c(t) for t in (seg_logits, dense_pred, gt_seg, gt_dense))
+    _capi.require_cuda(seg, dense, gs, gd)
+    B, Cc, S, S2 = seg.shape
+    if Cc != 3 or S != S2 or dense.shape != seg.shape or gs.shape[:2] != (B, 1) or gd.shape[:2] != (B, 3) or gs.shape[2:] != gd.shape[2:]:
+        raise _capi.DirHipError('dense_loss_grads: expected seg / dense [B,3,S,S], gt_seg [B,1,H,W], gt_dense [B,3,H,W]')
+    H, W = gs.shape[2:]
+    L = _capi.lib()
+    go = None if grad_out is None else _capi.f32c(grad_out)
+    with torch.cuda.device(seg.device):
+        nbytes = L.dir_dense_losses_backward_workspace_bytes(B, S)
+        if nbytes < 0:
+            raise _capi.DirHipError('dir_dense_losses_backward_workspace_bytes failed')
+        ws = torch.empty(nbytes, device=seg.device, dtype=torch.uint8)
+        gseg, gdense = torch.empty_like(seg), torch.empty_like(dense)
+        _capi.check(L.dir_dense_losses_backward(_capi.ptr(seg), _capi.ptr(dense), _capi.ptr(gs), _capi.ptr(gd), (C.c_float * 3)(*class_weight),
+                                                float(dense_weight), None if go is None else _capi.ptr(go), _capi.ptr(ws), nbytes,
+                                                _capi.ptr(gseg), _capi.ptr(gdense), B, S, H, W, _capi.stream_ptr()), 'dir_dense_losses_backward')
+    return gseg, gdense

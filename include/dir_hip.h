@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 9
+#define DIR_ABI_VERSION 10
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -422,6 +422,24 @@ int dir_dense_losses_forward(const float* seg_logits, const float* dense_pred, c
  * operation order.  step = 1-based update count (the value torch keeps in state['step'] AFTER this update). */
 int dir_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, double lr, double beta1,
                    double beta2, double eps, double weight_decay, long long step, void* stream);
+
+/* a13 backward, first step of the training backward pass (8f rank 2): gradients of (sum_k grad_out[k] * term_k) w.r.t. the predictions
+ * the terms read -- what autograd gives through models/loss.py / models/lovasz_loss.py / nn.CrossEntropyLoss as models/dir.py:562-592
+ * composes them.  grad_out: device pointer to the upstream gradients of the 13 (3) terms in forward order, or NULL for ones.
+ * pd_mesh_uv is an independent input here (pred->mesh_uv must be given; the projection's chain rule is the caller's).
+ * vert_face_offsets[h] [779] / vert_face_index[h] [3 n_faces]: CSR lists vertex -> (face * 3 + corner) of faces[h] (int32, device):
+ * vertex gradients are summed in that order, without atomics (deterministic). */
+typedef struct dir_loss_pred_grad {
+    float* joint_uv[2]; float* mesh_uv[2]; float* joint_xyz[2]; float* mesh_xyz[2]; float* offset;     /* same shapes as dir_loss_pred */
+} dir_loss_pred_grad;
+int dir_stage_losses_backward(const dir_loss_pred* pred_host, const dir_loss_target* gt_host, float coord_weight, const float* grad_out13,
+                              const int32_t* const* vert_face_offsets, const int32_t* const* vert_face_index,
+                              const dir_loss_pred_grad* grads_host, int B, void* stream);
+long long dir_dense_losses_backward_workspace_bytes(int B, int S);
+/* grad_seg / grad_dense: [B,3,S,S] fp32 */
+int dir_dense_losses_backward(const float* seg_logits, const float* dense_pred, const float* gt_seg, const float* gt_dense,
+                              const float* class_weight_host, float dense_weight, const float* grad_out3, void* workspace,
+                              long long workspace_bytes, float* grad_seg, float* grad_dense, int B, int S, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -172,3 +172,54 @@ def test_validation_loss_on_engine_outputs():
             want['%s_%d' % (k, i)] = v
     for k in sorted(want):
         assert close(float(loss[k]), want[k]), (k, float(loss[k]), want[k])
+
+
+# ----------------------------------------------------------------------------------------------- gradients
+def test_loss_gradients_match_autograd_golden(golden):
+    """dir_stage_losses_backward / dir_dense_losses_backward against torch autograd through the reference's loss modules (G12)"""
+    g, gg = golden('g8_loss'), golden('g12_loss_grad')
+    preds, gt, faces, seg, dense, gt_seg, gt_dense = loss_case(g)
+    target = cuda({k: v for k, v in gt.items() if not k.startswith('center')})
+    meta = cuda({k: v for k, v in gt.items() if k.startswith('center')})
+    ft = [torch.from_numpy(f) for f in faces]
+    gs, gd = ML.dense_loss_grads(*(torch.from_numpy(t).cuda() for t in (seg, dense, gt_seg, gt_dense)))
+    for got, k, tol in ((gs, 'seg', 1e-4), (gd, 'dense', 2e-5)):      # fp32 autograd's Lovasz differences carry cancellation noise
+        want = gg['grad.' + k]
+        assert np.abs(got.cpu().numpy() - want).max() <= tol * np.abs(want).max(), k
+    worst = 0.0
+    for i in range(3):
+        for k, v in ML.stage_loss_grads(cuda(preds[i]), target, meta, ft).items():
+            want = gg['grad.s%d.%s' % (i, k)]
+            e = np.abs(v.cpu().numpy() - want).max() / np.abs(want).max()
+            worst = max(worst, e)
+            assert e <= 2e-5, (i, k, e)
+    print('gradients vs autograd: worst error %.2e of the tensor maximum' % worst)
+
+
+@pytest.mark.parametrize('B', [1, 7, 64])
+def test_loss_gradients_vs_oracle(B):
+    rng = np.random.RandomState(200 + B)
+    pred, gt = _random_stage(rng, B)
+    for side in ('left', 'right'):
+        pred['pd_mesh_uv_' + side] = pred['pd_mesh_uv_' + side]
+    faces = tuple(synth.loss_faces(s) for s in ('left', 'right'))
+    want = OL.stage_loss_grads(pred, gt, faces)
+    target = cuda({k: v for k, v in gt.items() if not k.startswith('center')})
+    meta = cuda({k: v for k, v in gt.items() if k.startswith('center')})
+    got = ML.stage_loss_grads(cuda(pred), target, meta, [torch.from_numpy(f) for f in faces])
+    for k, w in want.items():
+        assert np.abs(got[k].cpu().numpy() - w).max() <= 2e-5 * np.abs(w).max(), k
+    # upstream gradients: linear in grad_out
+    go = torch.from_numpy(rng.uniform(0.5, 2.0, 13).astype(np.float32)).cuda()
+    got2 = ML.stage_loss_grads(cuda(pred), target, meta, [torch.from_numpy(f) for f in faces], grad_out=go)
+    k = 'pd_joint_uv_left'
+    assert torch.allclose(got2[k], got[k] * go[0], rtol=1e-6, atol=0)
+    S, H = 32, 96
+    seg = rng.normal(0, 1.5, (B, 3, S, S)).astype(np.float32)
+    dense = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    gt_seg = rng.choice((0, 2) if B == 7 else (0, 1, 2), size=(B, 1, H, H)).astype(np.float32)      # B = 7: class 1 absent
+    gt_dense = rng.uniform(0, 1, (B, 3, H, H)).astype(np.float32)
+    want = OL.dense_loss_grads(seg, dense, gt_seg, gt_dense)
+    gs, gd = ML.dense_loss_grads(*(torch.from_numpy(t).cuda() for t in (seg, dense, gt_seg, gt_dense)))
+    assert np.abs(gs.cpu().numpy() - want['seg']).max() <= 2e-5 * np.abs(want['seg']).max()
+    assert np.abs(gd.cpu().numpy() - want['dense']).max() <= 2e-5 * np.abs(want['dense']).max()
