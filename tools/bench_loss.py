@@ -30,6 +30,10 @@ for B in (32, 64, 256):
     gs = torch.randint(0, 3, (B, 1, 256, 256), device='cuda').float(); gd = torch.rand(B, 3, 256, 256, device='cuda')
     t_stage = timeit(lambda: ML.stage_losses(p, target, meta, faces))
     t_dense = timeit(lambda: ML.dense_losses(seg, dense, gs, gd))
+    csr = [ML.vertex_face_csr(f) for f in faces]
+    t_sb = timeit(lambda: ML.stage_loss_grads(p, target, meta, faces, csr=csr))
+    t_db = timeit(lambda: ML.dense_loss_grads(seg, dense, gs, gd))
+    print('B=%3d  backward: stage gradients %.1f us, dense + lovasz gradients %.1f us' % (B, t_sb, t_db))
     # algorithmic bytes: stage = both hands' pred + gt meshes (xyz + uv), joints; dense = logits + sampled gt + sort traffic
     stage_bytes = B * 2 * (778 * (3 + 2 + 3 + 3) + 21 * (3 + 2 + 3 + 3)) * 4
     print('B=%3d  stage losses %.1f us (%.1f MB algorithmic, %.0f GB/s)   dense + lovasz %.1f us' % (
