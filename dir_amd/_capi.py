@@ -96,7 +96,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 10          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 12          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -105,6 +105,8 @@ _SIGNATURES = {
     'dir_abi_version': (C.c_int, []),
     'dir_last_error': (C.c_char_p, []),
     'dir_device_info': (C.c_int, [C.c_char_p, _i, C.POINTER(C.c_int)]),
+    'dir_launch_log_reset': (None, []),
+    'dir_launch_log_get': (C.c_int, [C.c_char_p, _i]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -139,13 +141,56 @@ _SIGNATURES = {
     'dir_gt_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     'dir_joint_regress_forward': (C.c_int, [_p, _p, _p, _i, _p]),
     'dir_eval_metrics_forward': (C.c_int, [C.POINTER(EvalInputs), C.POINTER(EvalOutputs), _i, _i, _i, _p]),
-    'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _p]),
+    'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
 
 
+# ---- live per-launch measurement (bench.py roofline, DirEngine.autotune).  With PROFILE set to a list, lib() hands out a proxy that
+# brackets every entry point that launches kernels with HIP events on the current stream and appends one record per call:
+#   {'api': entry point, 'kernels': "name,name" as rocprofv3 reports them (dir_launch_log_get), 'e0' / 'e1': events,
+#    + whatever the caller announced for this call with annotate(): 'flops', 'bytes' (algorithmic work), 'shape', 'op'}
+PROFILE = None
+_pending = {}
+_NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get',
+               'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes')
+
+
+def annotate(**kw):
+    """algorithmic work / label of the NEXT library call (ignored unless PROFILE is a list)"""
+    if PROFILE is not None:
+        _pending.update(kw)
+
+
+class _ProfLib(object):
+    def __init__(self, l):
+        self._l = l
+
+    def __getattr__(self, name):
+        fn = getattr(self._l, name)
+        if name in _NO_PROFILE:
+            return fn
+        import torch
+
+        def call(*args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._l.dir_launch_log_reset()
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            buf = C.create_string_buffer(1024)
+            self._l.dir_launch_log_get(buf, 1024)
+            rec = dict(_pending, api=name, kernels=buf.value.decode(), e0=e0, e1=e1)
+            _pending.clear()
+            PROFILE.append(rec)
+            return rc
+        return call
+
+
 def lib():
     global _lib
+    if _lib is not None and PROFILE is not None:
+        return _ProfLib(_lib)
     if _lib is None:
         import torch  # noqa: F401  (maps torch's libamdhip64 first)
         if not os.path.exists(LIB_PATH):
@@ -158,7 +203,7 @@ def lib():
         if l.dir_abi_version() != ABI_VERSION:
             raise DirHipError('libdir_hip.so ABI version %d != %d' % (l.dir_abi_version(), ABI_VERSION))
         _lib = l
-    return _lib
+    return _ProfLib(_lib) if PROFILE is not None else _lib
 
 
 def check(rc, what):

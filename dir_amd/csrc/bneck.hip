@@ -354,7 +354,7 @@ extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, con
     const bool res = residual != nullptr;
     const int n2 = next ? p->n_next : 0;
     DIR_REQUIRE(n2 == 0 || n2 == 64 || n2 == 128, "dir_bottleneck_chain_forward: n_next must be 64 or 128");
-#define DIR_CHAIN(RES_, N2_, DUAL_) hipLaunchKernelGGL((bneck_chain_kernel<RES_, N2_, DUAL_>), dim3(grid), dim3(NTHR), 0, s, a)
+#define DIR_CHAIN(RES_, N2_, DUAL_) DIR_LAUNCH((bneck_chain_kernel<RES_, N2_, DUAL_>), dim3(grid), dim3(NTHR), 0, s, a)
     if (dual) { if (n2 == 128) DIR_CHAIN(false, 128, true); else if (n2) DIR_CHAIN(false, 64, true); else DIR_CHAIN(false, 0, true); }
     else if (res) { if (n2 == 128) DIR_CHAIN(true, 128, false); else if (n2) DIR_CHAIN(true, 64, false); else DIR_CHAIN(true, 0, false); }
     else { if (n2 == 128) DIR_CHAIN(false, 128, false); else if (n2) DIR_CHAIN(false, 64, false); else DIR_CHAIN(false, 0, false); }

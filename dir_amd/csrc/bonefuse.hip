@@ -248,7 +248,7 @@ extern "C" int dir_bone_fusion_prepare(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(B >= 0, "dir_bone_fusion_prepare: B=%d", B);
     if (B == 0) return DIR_OK;
     GArgs ga{p->w_g, emb, (unsigned*)scratch, B, stamps_begin("bone_g")};
-    hipLaunchKernelGGL(bone_g_kernel, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    DIR_LAUNCH(bone_g_kernel, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
     stamps_end("bone_g", ga.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_prepare");
 }
@@ -276,7 +276,7 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     convk::magic_u31((unsigned)fa.npr, &fa.mg_npr, &fa.sh_npr);
     convk::magic_u31((unsigned)fa.PW, &fa.mg_pw, &fa.sh_pw);
     fa.stamps = stamps_begin("bone_fuse");
-    hipLaunchKernelGGL(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    DIR_LAUNCH(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
     stamps_end("bone_fuse", fa.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_forward");
 }

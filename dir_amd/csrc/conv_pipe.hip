@@ -630,22 +630,22 @@ void launch_tile(ConvArgs a, hipStream_t s) {
     if (want_patch && !a.pre_scale && patch_geometry(a, BM, &g) && (!a.bbox || a.Cin / 64 <= 64)) {
         if constexpr (MI == 2 && NJ == 1 && WM == 4 && WN == 2) {      // 256x64: patch + 9 weight slabs = 125 KB
             if (!a.bbox && a.Cin == 64 && a.kh * a.kw <= 9) {
-                hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a, g);
+                DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a, g);
                 return;
             }
         }
-        if (a.bbox) hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a, g);
-        else hipLaunchKernelGGL((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
+        if (a.bbox) DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a, g);
+        else DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
         return;
     }
     if constexpr (!(MI == 2 && NJ == 2)) {                // pre-activation variant: the tiles whose ring leaves room for s_pre
         if (a.pre_scale) {
-            hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a);
+            DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a);
             return;
         }
     }
-    if (a.bbox) hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_pipe_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a);
+    if (a.bbox) DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a);
+    else DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a);
 }
 
 }  // namespace

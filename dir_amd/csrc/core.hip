@@ -35,6 +35,33 @@ void stamps_end(const char* kernel, long long* buf, hipStream_t s) {
 }
 }  // namespace dir
 
+namespace dir {
+// launch log of the calling thread: the last LOG_MAX kernel names since dir_launch_log_reset()
+constexpr int LOG_MAX = 32;
+static thread_local const char* g_log[LOG_MAX];
+static thread_local int g_nlog = 0;
+void note_kernel(const char* name) {
+    if (g_nlog < LOG_MAX) g_log[g_nlog] = name;
+    ++g_nlog;
+}
+}  // namespace dir
+
+extern "C" void dir_launch_log_reset(void) { dir::g_nlog = 0; }
+
+extern "C" int dir_launch_log_get(char* buf_host, int len) {
+    // names as written at the launch site, template arguments dropped: "conv_pipe_kernel,pgcn_layer_kernel,..."
+    int pos = 0;
+    const int n = dir::g_nlog < dir::LOG_MAX ? dir::g_nlog : dir::LOG_MAX;
+    for (int i = 0; i < n && buf_host && len > 0; ++i) {
+        const char* s = dir::g_log[i];
+        while (*s == '(' || *s == ' ') ++s;
+        if (i && pos < len - 1) buf_host[pos++] = ',';
+        for (; *s && *s != '<' && *s != ')' && *s != ' ' && pos < len - 1; ++s) buf_host[pos++] = *s;
+    }
+    if (buf_host && len > 0) buf_host[pos] = 0;
+    return dir::g_nlog;
+}
+
 extern "C" int dir_abi_version(void) { return DIR_ABI_VERSION; }
 
 extern "C" const char* dir_last_error(void) { return dir::g_err; }

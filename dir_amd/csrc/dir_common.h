@@ -11,6 +11,16 @@ namespace dir {
 
 void set_error(const char* fmt, ...);
 
+// Launch log (measurement aid, dir_launch_log_* in include/dir_hip.h): every kernel launch of the library records its kernel's name
+// for the calling thread, so that a per-call HIP-event timing (bench.py's live roofline) can be labelled with the kernel
+// symbol rocprofv3 reports for it.  One pointer store per launch.
+void note_kernel(const char* name);
+#define DIR_LAUNCH(kernel, ...)                   \
+    do {                                          \
+        ::dir::note_kernel(#kernel);              \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);  \
+    } while (0)
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

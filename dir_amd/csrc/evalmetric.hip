@@ -163,7 +163,7 @@ extern "C" int dir_joint_regress_forward(const float* jr, const float* verts, fl
     DIR_REQUIRE(B >= 0, "dir_joint_regress_forward: B=%d", B);
     if (B == 0) return DIR_OK;
     DIR_REQUIRE(jr && verts && joints, "dir_joint_regress_forward: null pointer");
-    dir::joint_regress_kernel<<<B, 256, 0, (hipStream_t)stream>>>(jr, verts, joints);
+    DIR_LAUNCH(dir::joint_regress_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, jr, verts, joints);
     return dir::check_launch("dir_joint_regress_forward");
 }
 
@@ -178,6 +178,6 @@ extern "C" int dir_eval_metrics_forward(const dir_eval_inputs* in, const dir_eva
     DIR_REQUIRE(in->cam && in->pd_offset, "dir_eval_metrics_forward: null cam / pd_offset");
     DIR_REQUIRE(!out->vert2d_err || (in->verts2d_gt[0] && in->verts2d_gt[1]),
                 "dir_eval_metrics_forward: vert2d_err requested without verts2d_gt");
-    dir::eval_metrics_kernel<<<B, dir::EV_THREADS, 0, (hipStream_t)stream>>>(*in, *out, root_joint, use_scale);
+    DIR_LAUNCH(dir::eval_metrics_kernel, dim3(B), dim3(dir::EV_THREADS), 0, (hipStream_t)stream, *in, *out, root_joint, use_scale);
     return dir::check_launch("dir_eval_metrics_forward");
 }

@@ -210,6 +210,6 @@ extern "C" int dir_gt_mano_forward(const dir_mano_tables* t, const float* root_r
     DIR_REQUIRE(((uintptr_t)t->posedirs_t & 15) == 0 && ((uintptr_t)t->weights & 15) == 0,
                 "dir_gt_mano_forward: posedirs_t / weights must be 16-byte aligned");
     GtArgs a{*t, root_rotation, pose, shape, trans, scale, verts, joints, ncomps, center_idx, new_skel};
-    hipLaunchKernelGGL(gt_mano_kernel, dim3(B), dim3(NTHR), 0, (hipStream_t)stream, a);
+    DIR_LAUNCH(gt_mano_kernel, dim3(B), dim3(NTHR), 0, (hipStream_t)stream, a);
     return dir::check_launch("dir_gt_mano_forward");
 }

@@ -662,7 +662,7 @@ extern "C" int dir_stage_losses_backward(const dir_loss_pred* pred_host, const d
                     "dir_stage_losses_backward: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    hipLaunchKernelGGL(stage_loss_bwd_kernel, dim3(B, 2), dim3(LT), lds, (hipStream_t)stream, a);
+    DIR_LAUNCH(stage_loss_bwd_kernel, dim3(B, 2), dim3(LT), lds, (hipStream_t)stream, a);
     return check_launch("dir_stage_losses_backward");
 }
 
@@ -693,16 +693,16 @@ extern "C" int dir_dense_losses_backward(const float* seg_logits, const float* d
     a.label = (unsigned char*)(ws + w.label);
     a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT; a.dense_weight = dense_weight;
     for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
-    hipLaunchKernelGGL(dense_bwd_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
+    DIR_LAUNCH(dense_bwd_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
     size_t tb = w.temp_bytes;
     const hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const unsigned long long*)a.keys, (unsigned long long*)(ws + w.keys_out),
                                                         (const unsigned*)a.vals, (unsigned*)(ws + w.vals_out), (size_t)3 * a.P, 0u, KEY_BITS, s);
     DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_backward: rocPRIM sort: %s", hipGetErrorString(e));
     double* result = (double*)(ws + w.result);
     float* glov = (float*)(ws + w.glov);
-    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned*)(ws + w.vals_out),
+    DIR_LAUNCH(lovasz_bwd_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned*)(ws + w.vals_out),
                        seg_logits, (const double*)a.partial, B * a.chunks, a.P, S * S, glov, result);
-    hipLaunchKernelGGL(dense_bwd_final_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a, (const float*)glov, (const double*)result, grad_seg);
+    DIR_LAUNCH(dense_bwd_final_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a, (const float*)glov, (const double*)result, grad_seg);
     return check_launch("dir_dense_losses_backward");
 }
 
@@ -719,8 +719,8 @@ extern "C" int dir_stage_losses_forward(const dir_loss_pred* pred_host, const di
     StageArgs a;
     a.p = *pred_host; a.g = *gt_host; a.scratch = scratch; a.B = B;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(stage_loss_kernel, dim3(B, 2), dim3(LT), 0, s, a);
-    hipLaunchKernelGGL(stage_reduce_kernel, dim3(1), dim3(64 * NTERM), 0, s, scratch, out13, B, coord_weight);
+    DIR_LAUNCH(stage_loss_kernel, dim3(B, 2), dim3(LT), 0, s, a);
+    DIR_LAUNCH(stage_reduce_kernel, dim3(1), dim3(64 * NTERM), 0, s, scratch, out13, B, coord_weight);
     return check_launch("dir_stage_losses_forward");
 }
 
@@ -749,14 +749,14 @@ extern "C" int dir_dense_losses_forward(const float* seg_logits, const float* de
     a.keys = (unsigned long long*)(ws + w.keys_in); a.vals = (unsigned char*)(ws + w.vals_in); a.partial = (double*)(ws + w.partial);
     a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT;
     for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
-    hipLaunchKernelGGL(dense_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
+    DIR_LAUNCH(dense_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
     size_t tb = w.temp_bytes;
     const hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const unsigned long long*)a.keys, (unsigned long long*)(ws + w.keys_out),
                                                         (const unsigned char*)a.vals, (unsigned char*)(ws + w.vals_out), (size_t)3 * a.P, 0u, KEY_BITS, s);
     DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_forward: rocPRIM sort: %s", hipGetErrorString(e));
     double* lov = (double*)(ws + w.lov);
-    hipLaunchKernelGGL(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned char*)(ws + w.vals_out),
+    DIR_LAUNCH(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned char*)(ws + w.vals_out),
                        (const double*)a.partial, B * a.chunks, a.P, lov);
-    hipLaunchKernelGGL(dense_final_kernel, dim3(1), dim3(64), 0, s, (const double*)a.partial, a.chunks, B, S, (const double*)lov, dense_weight, out3);
+    DIR_LAUNCH(dense_final_kernel, dim3(1), dim3(64), 0, s, (const double*)a.partial, a.chunks, B, S, (const double*)lov, dense_weight, out3);
     return check_launch("dir_dense_losses_forward");
 }

@@ -78,6 +78,6 @@ extern "C" int dir_adamw_step(float* param, const float* grad, float* exp_avg, f
     long long blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;                 // 16 workgroups per CU, grid-stride beyond
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    DIR_LAUNCH(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("dir_adamw_step");
 }

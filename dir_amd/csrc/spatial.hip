@@ -530,8 +530,8 @@ extern "C" int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int
     DIR_REQUIRE(img_nchw && out && B > 0 && H > 0 && W > 0 && Hp >= H + pad && Wp >= W + pad, "dir_stem_prep: bad args");
     const long long n = (long long)B * Hp * Wp;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((stem_prep_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hp, Wp, pad);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((stem_prep_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hp, Wp, pad);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((stem_prep_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad);
     else DIR_REQUIRE(false, "dir_stem_prep: bad dtype");
     return dir::check_launch("dir_stem_prep");
 }
@@ -541,8 +541,8 @@ extern "C" int dir_stem_prep_s2d(const float* img_nchw, void* out, int B, int H,
     DIR_REQUIRE(H % 2 == 0 && W % 2 == 0 && Hs >= H / 2 + 3 && Ws >= W / 2 + 3, "dir_stem_prep_s2d: need even H, W and Hs >= H/2+3, Ws >= W/2+3");
     const long long n = (long long)B * Hs * Ws * 4;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((stem_prep_s2d_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hs, Ws);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_s2d_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hs, Ws);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((stem_prep_s2d_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hs, Ws);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((stem_prep_s2d_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hs, Ws);
     else DIR_REQUIRE(false, "dir_stem_prep_s2d: bad dtype");
     return dir::check_launch("dir_stem_prep_s2d");
 }
@@ -563,7 +563,7 @@ extern "C" int dir_image_normalize_forward(const uint8_t* img_bgr_hwc, float* ou
     DIR_REQUIRE(img_bgr_hwc && out_nchw && B > 0 && H > 0 && W > 0, "dir_image_normalize_forward: bad args");
     NormArgs nm;
     if (int rc = norm_args(mean_host, std_host, &nm, "dir_image_normalize_forward")) return rc;
-    hipLaunchKernelGGL(image_normalize_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img_bgr_hwc, out_nchw, B, H,
+    DIR_LAUNCH(image_normalize_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, img_bgr_hwc, out_nchw, B, H,
                        W, nm);
     return dir::check_launch("dir_image_normalize_forward");
 }
@@ -576,8 +576,8 @@ extern "C" int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const
     if (int rc = norm_args(mean_host, std_host, &nm, "dir_stem_prep_s2d_u8")) return rc;
     const long long n = (long long)B * Hs * Ws * 4;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((stem_prep_s2d_u8_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (float*)out, B, H, W, Hs, Ws, nm);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((stem_prep_s2d_u8_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (bf16_t*)out, B, H, W, Hs, Ws, nm);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((stem_prep_s2d_u8_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (float*)out, B, H, W, Hs, Ws, nm);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((stem_prep_s2d_u8_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (bf16_t*)out, B, H, W, Hs, Ws, nm);
     else DIR_REQUIRE(false, "dir_stem_prep_s2d_u8: bad dtype");
     return dir::check_launch("dir_stem_prep_s2d_u8");
 }
@@ -588,8 +588,8 @@ extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long n = (long long)B * Ho * Wo * (C / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((maxpool_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((maxpool_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((maxpool_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((maxpool_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
     else DIR_REQUIRE(false, "dir_maxpool3x3s2: bad dtype");
     return dir::check_launch("dir_maxpool3x3s2");
 }
@@ -601,8 +601,8 @@ extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int
     DIR_REQUIRE(C % 8 == 0 && ocs % 8 == 0 && out_coff % 8 == 0, "dir_upsample2x_bilinear: channel counts/offsets must be multiples of 8");
     const long long n = (long long)B * 4 * H * W * (C / 4);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((upsample_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((upsample_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((upsample_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((upsample_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
     else DIR_REQUIRE(false, "dir_upsample2x_bilinear: bad dtype");
     return dir::check_launch("dir_upsample2x_bilinear");
 }
@@ -621,8 +621,8 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
     DIR_REQUIRE(C % 64 == 0 && Ch % 8 == 0 && (2 * HW) % 4 == 0 && p->mano_wt, "dir_init_head_forward: need C % 64 == 0, Ch % 8 == 0");
     hipStream_t s = (hipStream_t)stream;
     a.stamps = dir::stamps_begin("init_head");
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((init_head_kernel<float>), dim3(B), dim3(512), lds, s, a);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((init_head_kernel<bf16_t>), dim3(B), dim3(512), lds, s, a);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((init_head_kernel<float>), dim3(B), dim3(512), lds, s, a);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((init_head_kernel<bf16_t>), dim3(B), dim3(512), lds, s, a);
     else DIR_REQUIRE(false, "dir_init_head_forward: bad dtype");
     dir::stamps_end("init_head", a.stamps, s);
     return dir::check_launch("dir_init_head_forward");
@@ -641,11 +641,11 @@ extern "C" int dir_bone_proj_forward(const float* uv_left, const float* uv_right
     if (!out && S <= 32) {                             // proj_feat only: contiguous per-bone channel planes
         DIR_REQUIRE(group_bbox == nullptr, "dir_bone_proj_forward: group_bbox needs the NHWC output");
         const size_t vlds = (size_t)4 * S * S * sizeof(float) + (size_t)2 * S * S;
-        hipLaunchKernelGGL(bone_vis_kernel, dim3(B * 20), dim3(256), vlds, s, a);
+        DIR_LAUNCH(bone_vis_kernel, dim3(B * 20), dim3(256), vlds, s, a);
         return dir::check_launch("dir_bone_proj_forward");
     }
-    if (dtype == DIR_DT_F32) hipLaunchKernelGGL((bone_proj_kernel<float>), dim3(B * S), dim3(256), lds, s, a);
-    else if (dtype == DIR_DT_BF16) hipLaunchKernelGGL((bone_proj_kernel<bf16_t>), dim3(B * S), dim3(256), lds, s, a);
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((bone_proj_kernel<float>), dim3(B * S), dim3(256), lds, s, a);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((bone_proj_kernel<bf16_t>), dim3(B * S), dim3(256), lds, s, a);
     else DIR_REQUIRE(false, "dir_bone_proj_forward: bad dtype");
     return dir::check_launch("dir_bone_proj_forward");
 }

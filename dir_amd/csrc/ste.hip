@@ -429,8 +429,8 @@ extern "C" int dir_ste_forward(const dir_ste_params* p, const float* x, float* x
     a.p = *p; a.x_in = x; a.x_inout = x_pos_out; a.y = y; a.nblocks = p->num_blocks;
     a.stamps = dir::stamps_begin("ste");
     DIR_REQUIRE(p->weight_dtype == DIR_DT_F32 || p->weight_dtype == DIR_DT_BF16, "dir_ste_forward: weight_dtype must be f32 or bf16");
-    if (p->weight_dtype == DIR_DT_BF16) hipLaunchKernelGGL(ste_kernel<true>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(ste_kernel<false>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    if (p->weight_dtype == DIR_DT_BF16) DIR_LAUNCH(ste_kernel<true>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    else DIR_LAUNCH(ste_kernel<false>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     dir::stamps_end("ste", a.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_ste_forward");
 }

@@ -263,7 +263,7 @@ extern "C" int dir_stem_pool_forward(const void* img, int img_dtype, const float
     }
     const int grid = (int)(nt < 2ll * num_cu ? nt : 2ll * num_cu);
     hipStream_t s = (hipStream_t)stream;
-    if (img_dtype == DIR_DT_U8) hipLaunchKernelGGL((stem_pool_kernel<true>), dim3(grid), dim3(NTHR), 0, s, a);
-    else hipLaunchKernelGGL((stem_pool_kernel<false>), dim3(grid), dim3(NTHR), 0, s, a);
+    if (img_dtype == DIR_DT_U8) DIR_LAUNCH((stem_pool_kernel<true>), dim3(grid), dim3(NTHR), 0, s, a);
+    else DIR_LAUNCH((stem_pool_kernel<false>), dim3(grid), dim3(NTHR), 0, s, a);
     return check_launch("dir_stem_pool_forward");
 }

@@ -476,8 +476,8 @@ extern "C" int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, 
     a.pos_emb[0] = pos_emb_lr[0]; a.pos_emb[1] = pos_emb_lr[1]; a.gpos = *global_pos_emb; a.x0 = x0; a.g = gpos; a.B = B;
     hipStream_t s = (hipStream_t)stream;
     a.stamps = dir::stamps_begin("grid_tokens");
-    if (feat_dtype == DIR_DT_F32) hipLaunchKernelGGL((grid_tokens_kernel<float>), dim3(B, 2), dim3(GT_THR), 0, s, a);
-    else if (feat_dtype == DIR_DT_BF16) hipLaunchKernelGGL((grid_tokens_kernel<bf16_t>), dim3(B, 2), dim3(GT_THR), 0, s, a);
+    if (feat_dtype == DIR_DT_F32) DIR_LAUNCH((grid_tokens_kernel<float>), dim3(B, 2), dim3(GT_THR), 0, s, a);
+    else if (feat_dtype == DIR_DT_BF16) DIR_LAUNCH((grid_tokens_kernel<bf16_t>), dim3(B, 2), dim3(GT_THR), 0, s, a);
     else DIR_REQUIRE(false, "dir_grid_tokens_forward: bad dtype");
     dir::stamps_end("grid_tokens", a.stamps, s);
     return dir::check_launch("dir_grid_tokens_forward");
@@ -505,7 +505,7 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
             g.h_out = hbuf[l & 1];
         }
         a.stamps = dir::stamps_begin("pgcn");
-        hipLaunchKernelGGL(pgcn_layer_kernel, dim3(NJ, 2, nh * nchunk), dim3(256), 0, s, a);
+        DIR_LAUNCH(pgcn_layer_kernel, dim3(NJ, 2, nh * nchunk), dim3(256), 0, s, a);
         dir::stamps_end("pgcn", a.stamps, s);
     }
     MixArgs m;
@@ -516,7 +516,7 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
         float* hb = scratch[hh] + (((num_layers - 1) & 1) ? (long long)B * NJ * 256 : 0);
         m.h[h] = MixHand{hb, L.e1, L.bias, L.bn_scale, L.bn_shift, add ? add[hh] : nullptr, out[hh], L.relu};
     }
-    hipLaunchKernelGGL(pgcn_mix_kernel, dim3(B, NJ, nh), dim3(128), 0, s, m);
+    DIR_LAUNCH(pgcn_mix_kernel, dim3(B, NJ, nh), dim3(128), 0, s, m);
     return dir::check_launch("dir_pgcn_stack_forward");
 }
 
@@ -556,7 +556,7 @@ extern "C" int dir_regress_forward(const dir_regress_params* p, const float* tok
     a.p = *p; a.tok = tok; a.prev_para[0] = prev_para_left; a.prev_para[1] = prev_para_right; a.prev_off = prev_offset;
     a.para[0] = para_left; a.para[1] = para_right; a.off = offset; a.emb = emb;
     a.stamps = dir::stamps_begin("regress");
-    hipLaunchKernelGGL(regress_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, a);
+    DIR_LAUNCH(regress_kernel, dim3(B), dim3(512), 0, (hipStream_t)stream, a);
     dir::stamps_end("regress", a.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_regress_forward");
 }

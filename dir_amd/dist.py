@@ -89,3 +89,27 @@ def average_gradients(flat_grad, bucket_elems=64 << 20):
         w.wait()
     flat.div_(world)
     return flat_grad
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(script_argv, nproc, env=None, timeout=None):
+    """Run `python <script_argv...>` as `nproc` ranks of ONE node through torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1 with a free port) and return its exit code: the same command line the driver uses for N > 1, so that a bare
+    `python bench.py --gpus N` produces N ranks by itself.  Every rank sees RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*."""
+    import subprocess
+    import sys
+    e = dict(os.environ if env is None else env)
+    e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC only on this stack (RCCL needs it)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(int(nproc)),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port())] + list(script_argv)
+    return subprocess.run(cmd, env=e, timeout=timeout).returncode

@@ -10,8 +10,8 @@ on torch's current stream so the whole forward can be captured in a HIP graph (t
 State-dict keys are the reference's (963 keys, tests/golden/manifest_dir.json).
 """
 import ctypes as C
-
 import os
+import threading
 
 import torch
 
@@ -21,7 +21,19 @@ from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
 F32 = torch.float32
 IMAGENET_MEAN = (C.c_float * 3)(0.485, 0.456, 0.406)      # apps/eval.py:49-50
 IMAGENET_STD = (C.c_float * 3)(0.229, 0.224, 0.225)
-PROFILE = None     # set to a list to record (kernel tag, algorithmic flops, start event, end event) per conv launch
+# Live per-launch measurement: set _capi.PROFILE to a list and every library call is bracketed by HIP events and recorded with the
+# kernel names it launched plus the algorithmic work announced here with _capi.annotate() (bench.py roofline, DirEngine.autotune).
+_TLS = threading.local()      # .variant: DIR_CONV_VARIANT every conv of THIS thread is forced to (autotune); per thread, not global
+
+
+def _forced_variant():
+    return getattr(_TLS, 'variant', None)
+
+
+def _ann(family, flops, nbytes, shape):
+    """algorithmic work of the next library call (minimum HBM bytes = inputs + parameters + outputs once)"""
+    if _capi.PROFILE is not None:
+        _capi.annotate(family=family, flops=float(flops), bytes=float(nbytes), shape=shape)
 
 
 def _dt(dtype):
@@ -41,8 +53,6 @@ def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
 
 class ConvOp(object):
     """one dir_conv2d_forward call with packed parameters"""
-    default_variant = None        # set during DirEngine.autotune: every layer tries this DIR_CONV_VARIANT
-
     def __init__(self, w_oihw, dtype, stride=1, pad=0, scale=None, shift=None, relu=False, pre=None, pre_relu=False,
                  out_dtype=None):
         self.w = w_oihw.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
@@ -67,11 +77,15 @@ class ConvOp(object):
         d = ConvDesc(B, H, W, self.cin, self.in_cs_override or cbuf, in_coff, self.cout, out.shape[3], out_coff,
                      residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
                      _dt(self.dtype), _dt(out.dtype), self.flags, self.ho, self.wo)
-        v = ConvOp.default_variant if ConvOp.default_variant is not None else self.variant.get(B, 0)
+        v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
-        if PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        if _capi.PROFILE is not None:
+            nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
+                      + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
+            _capi.annotate(family='conv', flops=2.0 * B * ho * wo * self.cout * self.alg_k, bytes=nbytes, op=self,
+                           dtype='f32' if self.dtype == F32 else 'bf16',
+                           shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
+                                                              self.kw, self.stride))
         if bbox is not None:
             rc = _capi.lib().dir_conv2d_sparse_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
                                                        _capi.ptr(self.shift), _capi.ptr(residual), _capi.ptr(out),
@@ -82,14 +96,6 @@ class ConvOp(object):
                                                 _capi.ptr(self.pre_shift), _capi.ptr(residual), _capi.ptr(out),
                                                 _capi.stream_ptr())
         _capi.check(rc, 'dir_conv2d_forward')
-        if PROFILE is not None:
-            e1.record()
-            tag = 'conv_igemm<%s,%s>' % ('f32' if self.dtype == F32 else 'bf16', 'f32' if out.dtype == F32 else 'bf16')
-            nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
-                      + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
-            PROFILE.append((tag, 2.0 * B * ho * wo * self.cout * self.alg_k, e0, e1,
-                            'M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
-                                                           self.kw, self.stride), nbytes, self))
         return out
 
 
@@ -97,8 +103,6 @@ class DualConvOp(object):
     """dir_conv2d_dual_forward: a bottleneck's conv3 + BN with the projection shortcut (downsample conv + BN, stride s) folded
     in as a second K range -- relu(bn3(conv3(y)) + bn_ds(conv_ds(x))) in one launch, the identity tensor never exists
     (models/backbone/resnet.py:117-119,137-140).  Both BatchNorm scales are multiplied into the weight rows."""
-    default_variant = None
-
     def __init__(self, w3, s3, h3, wds, sds, hds, stride2, dtype, relu=True):
         self.relu = relu
         self.cout, self.cin = w3.shape[0], w3.shape[1]
@@ -116,22 +120,17 @@ class DualConvOp(object):
             out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
         d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, _dt(self.dtype), _dt(self.dtype),
                      CONV_RELU if self.relu else 0, 0, 0)
-        v = ConvOp.default_variant if ConvOp.default_variant is not None else self.variant.get(B, 0)
+        v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
-        if PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        if _capi.PROFILE is not None:
+            es, m = y.element_size(), B * H * W
+            _capi.annotate(family='conv', flops=2.0 * m * self.cout * (self.cin + self.cin2), op=self,
+                           bytes=(m * self.cin + m * self.cin2 + self.w.numel() + m * self.cout) * es,
+                           dtype='f32' if self.dtype == F32 else 'bf16',
+                           shape='M=%d N=%d K=%d+%d dual s%d' % (m, self.cout, self.cin, self.cin2, self.stride2))
         _capi.check(_capi.lib().dir_conv2d_dual_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.shift),
                                                         _capi.ptr(out), _capi.stream_ptr()), 'dir_conv2d_dual_forward')
-        if PROFILE is not None:
-            e1.record()
-            es = y.element_size()
-            tag = 'conv_igemm<%s,%s>' % (('f32', 'f32') if self.dtype == F32 else ('bf16', 'bf16'))
-            m = B * H * W
-            PROFILE.append((tag, 2.0 * m * self.cout * (self.cin + self.cin2), e0, e1,
-                            'M=%d N=%d K=%d+%d dual s%d' % (m, self.cout, self.cin, self.cin2, self.stride2),
-                            (m * self.cin + m * self.cin2 + self.w.numel() + m * self.cout) * es, self))
         return out
 
 
@@ -255,19 +254,15 @@ class BneckChainOp(object):
         B, H, W, _ = y1.shape
         out = torch.empty(B, H, W, 256, device=y1.device, dtype=y1.dtype)
         y1n = torch.empty(B, H, W, self.c1n.cout, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
-        if PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(self.params), _capi.ptr(y1), _capi.ptr(residual), _capi.ptr(x2), _capi.ptr(out),
-                                                             _capi.ptr(y1n), B, H, W, _capi.stream_ptr()), 'dir_bottleneck_chain_forward')
-        if PROFILE is not None:
-            e1.record()
+        if _capi.PROFILE is not None:
             m, nx = B * H * W, self.c1n is not None
             n2 = self.c1n.cout if nx else 0
-            PROFILE.append(('conv_igemm<bf16,bf16>', 2.0 * m * (64 * 576 + 256 * 64 * (2 if x2 is not None else 1) + n2 * 256), e0, e1,
-                            'M=%d chain 3x3(64)+1x1(256)%s' % (m, '+1x1(64)' if nx else ''),
-                            (m * (64 + 256 * (2 if residual is not None else 1) + n2 + (64 if x2 is not None else 0))
-                             + self.c2.w.numel() + self.w3.numel() * (2 if x2 is not None else 1) + (self.w1n.numel() if nx else 0)) * 2, self))
+            _capi.annotate(family='conv', flops=2.0 * m * (64 * 576 + 256 * 64 * (2 if x2 is not None else 1) + n2 * 256), op=self, dtype='bf16',
+                           shape='M=%d chain 3x3(64)+1x1(256)%s' % (m, '+1x1(%d)' % n2 if nx else ''),
+                           bytes=(m * (64 + 256 * (2 if residual is not None else 1) + n2 + (64 if x2 is not None else 0))
+                                  + self.c2.w.numel() + self.w3.numel() * (2 if x2 is not None else 1) + (self.w1n.numel() if nx else 0)) * 2)
+        _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(self.params), _capi.ptr(y1), _capi.ptr(residual), _capi.ptr(x2), _capi.ptr(out),
+                                                             _capi.ptr(y1n), B, H, W, _capi.stream_ptr()), 'dir_bottleneck_chain_forward')
         return out, y1n
 
 
@@ -349,12 +344,15 @@ class BackboneOp(object):
         if self.fused_stem and dt == torch.bfloat16:
             x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
             u8 = img.dtype == torch.uint8
+            _ann('stem', 2.0 * B * 128 * 128 * 64 * 147, img.numel() * img.element_size() + x.numel() * 2 + self.stem_w.numel() * 2,
+                 'B=%d 7x7/2 conv + bn + relu + maxpool' % B)
             _capi.check(L.dir_stem_pool_forward(_capi.ptr(img), 2 if u8 else 0, IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
                                                 _capi.ptr(self.stem_scale), _capi.ptr(self.stem_shift), _capi.ptr(x), B, 256, 256,
                                                 _capi.stream_ptr()), 'dir_stem_pool_forward')
             return self._layers(x)
         Hs, Ws = 131, 132                                                        # blocks Y, X = 0 .. 130 (+1 column: even rows)
         xp = torch.empty(B, Hs, Ws, 16, device=dev, dtype=dt)
+        _ann('stem', 0, img.numel() * img.element_size() + xp.numel() * xp.element_size(), 'B=%d space-to-depth staging' % B)
         if img.dtype == torch.uint8:     # [B,256,256,3] BGR as decoded: normalisation fused into the staging (apps/eval.py:59-61)
             _capi.check(L.dir_stem_prep_s2d_u8(_capi.ptr(img), _capi.ptr(xp), IMAGENET_MEAN, IMAGENET_STD, B, 256, 256, Hs, Ws,
                                                _dt(dt), _capi.stream_ptr()), 'dir_stem_prep_s2d_u8')
@@ -363,6 +361,7 @@ class BackboneOp(object):
                         'dir_stem_prep_s2d')
         s1 = self.stem(xp)                                                       # [B,128,128,64]
         x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
+        _ann('stem', 0, (s1.numel() + x.numel()) * x.element_size(), 'B=%d maxpool 3x3/2' % B)
         _capi.check(L.dir_maxpool3x3s2(_capi.ptr(s1), _capi.ptr(x), B, 128, 128, 64, _dt(dt), _capi.stream_ptr()),
                     'dir_maxpool3x3s2')
         return self._layers(x)
@@ -463,19 +462,23 @@ class StageOp(object):
         self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
 
 
-def run_mano_pair(tables_lr, para_l, para_r, B):
+def run_mano_pair(tables_lr, para_l, para_r, B, flags=None):
     """MANO + projection for both hands in one launch, straight out of the 64-wide parameter vectors
-    (pose = para[:, :51], betas = para[:, 51:61], cam = para[:, 61:64]; models/dir.py:272-280)."""
+    (pose = para[:, :51], betas = para[:, 51:61], cam = para[:, 61:64]; models/dir.py:272-280).  flags: optional int32 [2, B],
+    set to 1 where the 6D root rotation has det < 0 (the reference asserts there, rot6d.py:50)."""
     dev = para_l.device
     out = [[torch.empty(B, 778, 3, device=dev, dtype=F32), torch.empty(B, 21, 3, device=dev, dtype=F32),
             torch.empty(B, 21, 2, device=dev, dtype=F32)] for _ in range(2)]
     P2 = C.c_void_p * 2
     base = (para_l.data_ptr(), para_r.data_ptr())
     tabs = (_capi.ManoTables * 2)(tables_lr[0], tables_lr[1])
+    _ann('mano', 2.0 * B * 1.2e6, 2 * B * (64 + 778 * 3 + 21 * 3 + 21 * 2) * 4 + 2 * (145 * 2336 + 2334 + 778 * 16 + 16 * 33 + 45 * 46) * 4,
+         'B=%d x 2 hands (rot6d + PCA + blend shapes + LBS + projection)' % B)
     rc = _capi.lib().dir_mano_forward_pair(
         tabs, P2(base[0], base[1]), 64, P2(base[0] + 51 * 4, base[1] + 51 * 4), 64, P2(base[0] + 61 * 4, base[1] + 61 * 4), 64,
         P2(out[0][0].data_ptr(), out[1][0].data_ptr()), P2(out[0][1].data_ptr(), out[1][1].data_ptr()),
-        P2(out[0][2].data_ptr(), out[1][2].data_ptr()), B, _capi.stream_ptr())
+        P2(out[0][2].data_ptr(), out[1][2].data_ptr()),
+        None if flags is None else P2(flags[0].data_ptr(), flags[1].data_ptr()), B, _capi.stream_ptr())
     _capi.check(rc, 'dir_mano_forward_pair')
     return out
 
@@ -550,15 +553,18 @@ class DirEngine(object):
         para_l = torch.empty(B, 64, device=dev, dtype=F32)
         para_r = torch.empty(B, 64, device=dev, dtype=F32)
         off = torch.empty(B, 3, device=dev, dtype=F32)
+        npx = c4.shape[1] * c4.shape[2]
+        _ann('init_head', 2.0 * B * (2 * npx * ch + 2 * npx * c4.shape[3] + c4.shape[3] * 128),
+             (c4.numel() + hh.numel()) * esz + (c4.shape[3] * 128 + 2 * ch + 131 * 3) * 4 + B * 131 * 4, 'B=%d attention pooling + 3 Linears' % B)
         _capi.check(L.dir_init_head_forward(self.init_head, _capi.ptr(c4), C.c_void_p(hh.data_ptr()),
                                             C.c_void_p(hh.data_ptr() + ch * esz), 2 * ch, _capi.ptr(para_l),
                                             _capi.ptr(para_r), _capi.ptr(off), B, c4.shape[1] * c4.shape[2], c4.shape[3],
                                             ch, _dt(self.dtype), _capi.stream_ptr()), 'dir_init_head_forward')
-        return self.mano_outputs(self.init_mano, para_l, para_r, off)
+        return self.mano_outputs(self.init_mano, para_l, para_r, off, self._flags[0] if self._flags is not None else None)
 
-    def mano_outputs(self, tables, para_l, para_r, off):
+    def mano_outputs(self, tables, para_l, para_r, off, flags=None):
         B = para_l.shape[0]
-        (vl, jl, uvl), (vr, jr, uvr) = run_mano_pair(tables, para_l, para_r, B)
+        (vl, jl, uvl), (vr, jr, uvr) = run_mano_pair(tables, para_l, para_r, B, flags)
         return {'pd_offset': off, 'pd_mano_para_left': para_l, 'pd_mano_para_right': para_r,
                 'pd_proj_left': para_l[:, 61:64], 'pd_proj_right': para_r[:, 61:64],
                 'pd_mesh_xyz_left': vl, 'pd_mesh_xyz_right': vr, 'pd_joint_xyz_left': jl, 'pd_joint_xyz_right': jr,
@@ -572,6 +578,10 @@ class DirEngine(object):
         sp = _capi.stream_ptr()
         x0 = torch.empty(2, B, 21, 128, device=dev, dtype=F32)
         gp = torch.empty(2, B, 21, 128, device=dev, dtype=F32)
+        es = feat_buf.element_size()
+        mlp = lambda cin: cin * 128 + 128 * 128          # noqa: E731  (Conv1d cin->128, Conv1d 128->128)
+        _ann('grid_tokens', 2.0 * 2 * B * 21 * (mlp(256) + 2 * mlp(3)), 2 * B * 21 * 4 * 256 * es + (2 * mlp(256) + 3 * mlp(3)) * 4 + 4 * B * 21 * 128 * 4,
+             'B=%d S=%d bilinear gather + 3 token MLPs, 2 hands' % (B, S))
         _capi.check(L.dir_grid_tokens_forward(
             _capi.ptr(feat_buf), _dt(self.dtype), S, 256, feat_cs, 0, _capi.ptr(prev['pd_joint_uv_left']),
             _capi.ptr(prev['pd_joint_uv_right']), _capi.ptr(prev['pd_joint_xyz_left']),
@@ -579,14 +589,22 @@ class DirEngine(object):
             C.byref(st.gpos), _capi.ptr(x0), _capi.ptr(gp), B, sp), 'dir_grid_tokens_forward')
         tok = torch.empty(B, 42, 128, device=dev, dtype=F32)
         scratch = torch.empty(4, B, 21, 256, device=dev, dtype=F32)
+        wes = 2 if self.dtype == torch.bfloat16 else 4
+        _ann('pgcn', 2.0 * 4 * 2 * B * 21 * 2 * 128 * 128, 4 * 2 * (2 * 21 * 128 * 128 * wes + 2 * B * 21 * 128 * 4),
+             'B=%d 4 layers x 2 hands (per-node W0/W1 %s + neighbour mix + BN + ReLU)' % (B, 'bf16' if wes == 2 else 'f32'))
         _capi.check(L.dir_pgcn_stack_forward_pair(st.gcn[0], st.gcn[1], 4, _capi.ptr(x0), _capi.ptr(gp), _capi.ptr(tok),
                                                   _capi.ptr(scratch), B, sp), 'dir_pgcn_stack_forward_pair')
         y = torch.empty(B, 42, 64, device=dev, dtype=F32)
+        blk = 42 * 128 * 384 + 4 * 2 * 42 * 42 * 32 + 42 * 128 * 128 + 2 * 42 * 128 * 256
+        _ann('ste', 2.0 * B * (3 * blk + 42 * 128 * 64), B * 42 * (128 + 64) * 4 + (3 * (128 * 384 + 128 * 128 + 2 * 128 * 256) + 128 * 64) * wes,
+             'B=%d 42 tokens x 128, 3 blocks + head' % B)
         _capi.check(L.dir_ste_forward(C.byref(st.ste), _capi.ptr(tok), None, _capi.ptr(y), B, sp), 'dir_ste_forward')
         para_l = torch.empty(B, 64, device=dev, dtype=F32)
         para_r = torch.empty(B, 64, device=dev, dtype=F32)
         off = torch.empty(B, 3, device=dev, dtype=F32)
         emb = torch.empty(B, 42, 64, device=dev, dtype=F32)
+        _ann('regress', 2.0 * B * (2 * 1408 * 64 + 2691 * 3 + 42 * 2 * 64 * 64), (2 * 1408 * 64 + 2691 * 3 + 2 * 64 * 64) * 4 + B * (42 * 64 * 2 + 2 * 64 * 2 + 6) * 4,
+             'B=%d 2 x Linear 1408->64 + Linear 2691->3 + proj_feat_emb' % B)
         _capi.check(L.dir_regress_forward(C.byref(st.reg), _capi.ptr(y), _capi.ptr(prev['pd_mano_para_left']),
                                           _capi.ptr(prev['pd_mano_para_right']), _capi.ptr(prev['pd_offset']),
                                           _capi.ptr(para_l), _capi.ptr(para_r), _capi.ptr(off), _capi.ptr(emb), B, sp),
@@ -599,17 +617,22 @@ class DirEngine(object):
             main, side = torch.cuda.current_stream(), self._side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                _ann('bone_fusion', 2.0 * B * 9 * 80 * 64 * 256, 9 * 40 * 64 * 256 * 4 + B * 42 * 64 * 4 + B * 9 * 80 * 256 * 4,
+                     'B=%d G = f_end . W (9 taps x 80 bone ends x 256)' % B)
                 _capi.check(L.dir_bone_fusion_prepare(st.bone_fusion, _capi.ptr(emb), _capi.ptr(scratch), B, _capi.stream_ptr()),
                             'dir_bone_fusion_prepare')
-        res = self.mano_outputs(st.mano, para_l, para_r, off)
+        res = self.mano_outputs(st.mano, para_l, para_r, off, self._flags[1 if st is self.stage4 else 2] if self._flags is not None else None)
         vis = torch.empty(B, 1280, S, S, device=dev, dtype=F32) if want_vis else None
         if factorised:
             main.wait_stream(side)
             fused = torch.empty(B, S, S, 256, device=dev, dtype=self.dtype)
+            _ann('bone_fusion', 2.0 * B * S * S * 256 * 720, B * 9 * 80 * 256 * 4 + B * S * S * 256 * 2 + B * 42 * 2 * 4,
+                 'B=%d S=%d factorised bone_proj + 3x3 fusion conv (K=720)' % (B, S))
             _capi.check(L.dir_bone_fusion_forward(st.bone_fusion, _capi.ptr(res['pd_joint_uv_left']),
                                                   _capi.ptr(res['pd_joint_uv_right']), _capi.ptr(scratch),
                                                   _capi.ptr(fused), B, S, st.distance, 256, 0, 1, sp), 'dir_bone_fusion_forward')
             if want_vis:                                        # proj_feat output only (models/dir.py:128,481)
+                _ann('proj_feat', 30.0 * B * S * S * 40, B * 1280 * S * S * 4 + B * 42 * 64 * 4, 'B=%d S=%d proj_feat output (fp32 NCHW)' % (B, S))
                 _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
                                                     _capi.ptr(emb), None, _capi.ptr(vis), None, B, S, st.distance,
                                                     _dt(self.dtype), sp), 'dir_bone_proj_forward')
@@ -617,6 +640,8 @@ class DirEngine(object):
         else:
             bone = torch.empty(B, S, S, 2560, device=dev, dtype=self.dtype)
             bbox = torch.empty(B, 40, 4, device=dev, dtype=torch.int32)
+            _ann('bone_proj', 30.0 * B * S * S * 40, bone.numel() * bone.element_size() + (B * 1280 * S * S * 4 if want_vis else 0) + B * 42 * 64 * 4,
+                 'B=%d S=%d materialised bone map' % (B, S))
             _capi.check(L.dir_bone_proj_forward(_capi.ptr(res['pd_joint_uv_left']), _capi.ptr(res['pd_joint_uv_right']),
                                                 _capi.ptr(emb), _capi.ptr(bone), _capi.ptr(vis), _capi.ptr(bbox), B, S,
                                                 st.distance, _dt(self.dtype), sp), 'dir_bone_proj_forward')
@@ -627,6 +652,7 @@ class DirEngine(object):
 
     def upsample_into(self, x, out, coff):
         B, H, W, Cc = x.shape
+        _ann('upsample', 0, 5 * x.numel() * x.element_size(), 'B=%d %dx%dx%d -> 2x' % (B, H, W, Cc))
         _capi.check(_capi.lib().dir_upsample2x_bilinear(_capi.ptr(x), _capi.ptr(out), B, H, W, Cc, out.shape[3], coff,
                                                         _dt(self.dtype), _capi.stream_ptr()), 'dir_upsample2x_bilinear')
 
@@ -643,40 +669,44 @@ class DirEngine(object):
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
-    # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 19, 20, 8, 9, 10, 12, 13, 14)
+    # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic.  (Code 19, the
+    # 64x128 tile on the 3-buffer ring, is not offered: see conv.hip, DIR_RING_64x128.)
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14)
+
+    def _profiled_forwards(self, img, n):
+        """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""
+        _capi.PROFILE = []
+        try:
+            for _ in range(n):
+                self.forward(img)
+            torch.cuda.synchronize()
+            return [r for r in _capi.PROFILE if r.get('op') is not None]
+        finally:
+            _capi.PROFILE = None
 
     def autotune(self, img, reps=2):
         """Pick the convolution kernel variant per layer for this batch size by timing every candidate inside real
         forwards (HIP events around each conv launch, side stream off, realistic cache state).  All variants accumulate in
         the same order, so the outputs are bit-identical whatever is chosen; a variant that does not apply to a layer falls
-        back to the heuristic inside the library.  ~12 x (reps+1) eager forwards, once per (engine, batch size)."""
-        global PROFILE
+        back to the heuristic inside the library.  ~14 x (reps+1) eager forwards, once per (engine, batch size)."""
         B = img.shape[0]
-        saved_overlap, saved_profile = self.overlap, PROFILE
+        saved_overlap, saved_profile = self.overlap, _capi.PROFILE
         self.overlap = False
         best = {}
         try:
             for v in self.CONV_VARIANTS:
-                ConvOp.default_variant = v
-                PROFILE = []
-                self.forward(img)                                  # warm-up (allocator, instruction cache)
-                torch.cuda.synchronize()
-                PROFILE = []
-                for _ in range(reps):
-                    self.forward(img)
-                torch.cuda.synchronize()
+                _TLS.variant = v
+                self._profiled_forwards(img, 1)                    # warm-up (allocator, instruction cache)
                 acc = {}
-                for rec in PROFILE:
-                    op = rec[6]
-                    acc.setdefault(op, []).append(rec[2].elapsed_time(rec[3]))
+                for rec in self._profiled_forwards(img, reps):
+                    acc.setdefault(rec['op'], []).append(rec['e0'].elapsed_time(rec['e1']))
                 for op, ts in acc.items():
                     t = min(ts)
                     if op not in best or t < best[op][0] * 0.97:  # a challenger must win by 3 % (timing noise)
                         best[op] = (t, v)
         finally:
-            ConvOp.default_variant = None
-            PROFILE = saved_profile
+            _TLS.variant = None
+            _capi.PROFILE = saved_profile
             self.overlap = saved_overlap
         for op, (t, v) in best.items():
             op.variant[B] = v
@@ -691,18 +721,15 @@ class DirEngine(object):
 
     def import_tuning(self, img, table):
         """apply a table produced by export_tuning on an identically built engine (same layer order, checked by shape)"""
-        global PROFILE
         B = img.shape[0]
-        saved_overlap, saved_profile, self.overlap, PROFILE = self.overlap, PROFILE, False, []
+        saved_overlap, saved_profile, self.overlap = self.overlap, _capi.PROFILE, False
         try:
-            self.forward(img)
-            torch.cuda.synchronize()
             ops = []
-            for rec in PROFILE:
-                if rec[6] not in ops:
-                    ops.append(rec[6])
+            for rec in self._profiled_forwards(img, 1):
+                if rec['op'] not in ops:
+                    ops.append(rec['op'])
         finally:
-            PROFILE, self.overlap = saved_profile, saved_overlap
+            _capi.PROFILE, self.overlap = saved_profile, saved_overlap
         if len(ops) != len(table) or any([op.cout, op.cin, op.kh, op.kw, op.stride] != row[:5] for op, row in zip(ops, table)):
             raise ValueError('tuning table does not match this engine')
         for op, row in zip(ops, table):
@@ -711,11 +738,55 @@ class DirEngine(object):
         self._tuned_order = getattr(self, '_tuned_order', {})
         self._tuned_order[B] = ops
 
+    pending_tuning = None          # {batch size: export_tuning table} handed over by DIR.engine() when the weights were re-packed
+
+    def export_all_tuning(self):
+        return {B: self.export_tuning(B) for B in getattr(self, '_tuned_order', {})}
+
+    def tune_for(self, img):
+        """Make sure batch size img.shape[0] has a kernel choice: a table handed over from the previous engine, else the variants of
+        the nearest batch size already tuned (the ragged last batch of an evaluation loader must not cost 45 forwards), else a
+        timed autotune."""
+        B = img.shape[0]
+        if B in self.tuned_batches:
+            return
+        if self.pending_tuning and B in self.pending_tuning:
+            try:
+                self.import_tuning(img, self.pending_tuning[B])
+                return
+            except ValueError:
+                pass
+        order = getattr(self, '_tuned_order', {})
+        if order:
+            self.copy_tuning(min(order, key=lambda b: abs(b - B)), B)
+        else:
+            self.autotune(img)
+
+    def copy_tuning(self, B_from, B_to):
+        """reuse the variants tuned for batch size B_from at batch size B_to (e.g. the ragged last batch of an evaluation loader:
+        the choice is bit-identical by construction, so only speed is at stake)"""
+        for op in self._tuned_order.get(B_from, []):
+            op.variant[B_to] = op.variant.get(B_from, 0)
+        self._tuned_order[B_to] = self._tuned_order[B_from]
+        self.tuned_batches.add(B_to)
+
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, img, want_proj_feat=True, taps=None):
+    _flags = None
+
+    def forward(self, img, want_proj_feat=True, taps=None, reflection_flags=None):
         """img: float32 NCHW [B,3,256,256] on the GPU.  Returns outs_list exactly like DIR.forward (models/dir.py:521-540);
-        tensors are engine-owned buffers (valid until the next forward when run under a captured graph)."""
+        tensors are engine-owned buffers (valid until the next forward when run under a captured graph).
+        reflection_flags: optional int32 tensor [3 stages, 2 hands, B]; an entry is set to 1 where the predicted 6D root rotation
+        is a reflection (det < 0) -- where the reference's `assert` fires (rot6d.py:50).  The caller decides when to look (a host
+        read); dir_amd.models.dir.DIR.forward does, and raises AssertionError like the reference."""
         _capi.require_cuda(img)
+        self._flags = reflection_flags
+        try:
+            return self._forward(img, want_proj_feat, taps)
+        finally:
+            self._flags = None
+
+    def _forward(self, img, want_proj_feat, taps):
         if img.dtype == torch.uint8:     # decoded BGR frames [B,256,256,3]: the reference's normalisation runs inside the stem staging
             assert img.is_contiguous() and img.shape[1:] == (256, 256, 3)
         else:

@@ -144,18 +144,40 @@ class DIR(nn.Module):
         self.decoder = FusionJointInterIterDecoder(self.joint_num, mano_path, root_joint)
         self.coord_weight, self.dense_weight = 10, 1
         self.seg_loss = nn.CrossEntropyLoss(weight=torch.Tensor([.1, 0.45, 0.45]))     # state-dict key seg_loss.weight
-        self._engine, self._engine_key = None, None
+        self._engine, self._engine_key, self._sd_tensors = None, None, None
         self.autotune = True
 
+    def _tensors(self):
+        """parameters and buffers in state-dict order, listed once (re-listed after _apply / load_state_dict / refresh())"""
+        if self._sd_tensors is None:
+            self._sd_tensors = list(self.state_dict(keep_vars=True).values())
+        return self._sd_tensors
+
+    def refresh(self):
+        """forget the packed engine: the next forward re-packs the parameters (needed only after out-of-band edits that bump neither
+        a tensor's version counter nor its storage, e.g. writes through a raw pointer)"""
+        self._sd_tensors, self._engine_key = None, None
+
+    def _apply(self, fn, *args, **kw):               # .cuda() / .to() / .float(): storages change
+        self._sd_tensors = None
+        return super()._apply(fn, *args, **kw)
+
+    def load_state_dict(self, *args, **kw):
+        self._sd_tensors = None
+        return super().load_state_dict(*args, **kw)
+
     def engine(self):
-        """(re)pack the parameters when any of them changed (load_state_dict, .to(), in-place edits)."""
-        key = (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        """(re)pack the parameters when any of them changed (load_state_dict, .to(), in-place edits, optimiser steps)."""
+        key = (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self._tensors())
         if key != self._engine_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             dev = next(self.parameters()).device
             if dev.type != 'cuda':
                 raise _capi.DirHipError('DIR runs on the GPU only: call .cuda() first (no CPU fallback exists)')
+            tuned = self._engine.export_all_tuning() if self._engine is not None else None
             self._engine = DirEngine(sd, dtype=self.compute_dtype, root_joint=self.root_joint, device=dev)
+            if tuned:
+                self._engine.pending_tuning = tuned      # same architecture, new weights: the kernel choices carry over
             self._engine_key = key
         return self._engine
 
@@ -176,7 +198,13 @@ class DIR(nn.Module):
         with torch.cuda.device(x.device), torch.no_grad():
             x = x.contiguous() if x.dtype == torch.uint8 else _capi.f32c(x)       # uint8 BGR [B,256,256,3]: fused normalisation
             if self.autotune and x.shape[0] not in eng.tuned_batches and not torch.cuda.is_current_stream_capturing():
-                eng.autotune(x)             # once per batch size: per-layer conv kernel choice (bit-identical results)
-            outs = eng.forward(x)
+                eng.tune_for(x)             # per-layer conv kernel choice (bit-identical results): timed once, re-used for other batch sizes
+            flags = torch.zeros(3, 2, x.shape[0], device=x.device, dtype=torch.int32)
+            outs = eng.forward(x, reflection_flags=flags)
+            # manopth's robust 6D -> rotation asserts det > 0 over the batch (rot6d.py:50, a host synchronisation in the reference
+            # too); a stage whose predicted root rotation is a reflection raises exactly there
+            if not torch.cuda.is_current_stream_capturing() and int(flags.sum().item()) != 0:
+                raise AssertionError('robust_compute_rotation_matrix_from_ortho6d: det < 0 (rot6d.py:50) in stage(s) %s'
+                                     % sorted(set(torch.nonzero(flags.sum((1, 2))).flatten().tolist())))
         outs_list = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs]
         return outs_list, {}

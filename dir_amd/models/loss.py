@@ -21,49 +21,90 @@ STAGE_KEYS = ('joint_left_uv', 'joint_right_uv', 'mesh_left_uv', 'mesh_right_uv'
 SIDES = ('left', 'right')
 
 
-def _pair(d, prefix):
-    ts = [_capi.f32c(d[prefix + s]) for s in SIDES]
+def _pair(d, prefix, dev=None):
+    ts = [_capi.f32c(d[prefix + s] if dev is None else d[prefix + s].to(dev)) for s in SIDES]
     return ts, (C.c_void_p * 2)(*[_capi.ptr(t) for t in ts])
 
 
-def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
-    """pred: one entry of iter_outs (pd_joint_uv_*, pd_mesh_uv_* or pd_proj_*, pd_joint_xyz_*, pd_mesh_xyz_*, pd_offset); target: joint_2d_*,
-    mesh_2d_* [B,N,>=2], joint_3d_*, mesh_3d_*; meta_info: center_* [B,1,3]; faces: (left, right) int tensors [F,3].
-    Returns a float32 tensor of the 13 terms in STAGE_KEYS order (on the GPU, no host synchronisation)."""
+_FACES_OK = {}
+
+
+def _check_faces(faces, dev, n_vertices=778):
+    """two [F,3] int tables of the same size with indices in [0, n_vertices): an index out of range would read out of bounds on the
+    device.  The range check costs a host round trip, so it is done once per table (keyed on storage and version)."""
+    fs = [torch.as_tensor(f).to(device=dev, dtype=torch.int32).contiguous() for f in faces]
+    if fs[0].shape != fs[1].shape or fs[0].dim() != 2 or fs[0].shape[1] != 3:
+        raise _capi.DirHipError('stage losses: faces must be two [F,3] tables of the same size')
+    for f, src in zip(fs, faces):
+        key = (src.data_ptr(), src._version, tuple(src.shape)) if torch.is_tensor(src) else None
+        if key is None or key not in _FACES_OK:
+            if f.numel() and (int(f.min()) < 0 or int(f.max()) >= n_vertices):
+                raise _capi.DirHipError('stage losses: face index outside [0, %d)' % n_vertices)
+            if key is not None:
+                _FACES_OK[key] = True
+    return fs
+
+
+def _marshal_stage(pred, target, meta_info, faces, mesh_uv_required):
+    """Shared argument marshalling / validation of dir_stage_losses_forward and _backward.  Targets and meta_info are moved to the
+    predictions' device (the reference calls .cuda() on them, models/dir.py:543-560).  Returns (LossPred, LossTarget, keep-alive list,
+    pd_offset tensor or None when the stage has no offset, B, faces)."""
     keep = []
     p, g = _capi.LossPred(), _capi.LossTarget()
+    dev = pred['pd_joint_uv_left'].device
     for field, prefix in (('joint_uv', 'pd_joint_uv_'), ('joint_xyz', 'pd_joint_xyz_'), ('mesh_xyz', 'pd_mesh_xyz_')):
         ts, arr = _pair(pred, prefix)
         keep += ts
         setattr(p, field, arr)
     # pd_mesh_uv_* is an output of the reference's regressors that only this loss reads (models/dir.py:278-280,574-575); the
-    # engine's stage dicts carry pd_proj_* instead and the kernel projects the mesh itself
-    extra, arr = _pair(pred, 'pd_mesh_uv_' if 'pd_mesh_uv_left' in pred else 'pd_proj_')
-    setattr(p, 'mesh_uv' if 'pd_mesh_uv_left' in pred else 'proj', arr)
-    off = _capi.f32c(pred['pd_offset'])
+    # engine's stage dicts carry pd_proj_* instead and the forward kernel projects the mesh itself
+    if 'pd_mesh_uv_left' in pred:
+        ts, arr = _pair(pred, 'pd_mesh_uv_')
+        p.mesh_uv = arr
+    elif mesh_uv_required:
+        raise _capi.DirHipError('stage loss gradients: pd_mesh_uv_* must be in the stage dict (it is an independent input of the gradient)')
+    else:
+        ts, arr = _pair(pred, 'pd_proj_')
+        p.proj = arr
+    keep += ts
+    B = keep[0].shape[0]
+    has_off = pred.get('pd_offset') is not None                      # models/dir.py:589: the offset term exists only if predicted
+    off = _capi.f32c(pred['pd_offset']) if has_off else torch.zeros(B, 3, device=dev)
     keep.append(off)
     p.offset = _capi.ptr(off)
+    t2d = []
     for field, prefix in (('joint_2d', 'joint_2d_'), ('mesh_2d', 'mesh_2d_'), ('joint_3d', 'joint_3d_'), ('mesh_3d', 'mesh_3d_')):
-        ts, arr = _pair(target, prefix)
+        ts, arr = _pair(target, prefix, dev)
         keep += ts
         setattr(g, field, arr)
-    ts, arr = _pair(meta_info, 'center_')
+        if field.endswith('2d'):
+            t2d += ts
+    ts, arr = _pair(meta_info, 'center_', dev)
     keep += ts
     g.center = arr
-    B = off.shape[0]
-    c2 = keep[7].shape[-1]                       # joint_2d_left
-    for t in keep[7:11]:
-        if t.shape[-1] != c2:
-            raise _capi.DirHipError('stage_losses: the 2-D targets must share their last dimension')
-    fs = [f.to(device=off.device, dtype=torch.int32).contiguous() for f in faces]
-    if fs[0].shape != fs[1].shape or fs[0].dim() != 2 or fs[0].shape[1] != 3:
-        raise _capi.DirHipError('stage_losses: faces must be two [F,3] tables of the same size')
+    c2 = t2d[0].shape[-1]
+    if any(t.shape[-1] != c2 for t in t2d) or c2 < 2:
+        raise _capi.DirHipError('stage losses: the 2-D targets must share their last dimension (>= 2)')
+    if any(t.shape[0] != B for t in keep):
+        raise _capi.DirHipError('stage losses: batch size mismatch between predictions and targets')
+    fs = _check_faces(faces, dev)
+    keep += fs
     g.faces = (C.c_void_p * 2)(*[_capi.ptr(f) for f in fs])
     g.c2, g.n_faces = int(c2), int(fs[0].shape[0])
-    _capi.require_cuda(*(keep + extra))
-    scratch = torch.empty(B * 13, device=off.device, dtype=torch.float64)
-    out = torch.empty(13, device=off.device, dtype=torch.float32)
-    with torch.cuda.device(off.device):
+    _capi.require_cuda(*keep)
+    return p, g, keep, (off if has_off else None), B, fs
+
+
+def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
+    """pred: one entry of iter_outs (pd_joint_uv_*, pd_mesh_uv_* or pd_proj_*, pd_joint_xyz_*, pd_mesh_xyz_*, pd_offset); target: joint_2d_*,
+    mesh_2d_* [B,N,>=2], joint_3d_*, mesh_3d_*; meta_info: center_* [B,1,3]; faces: (left, right) int tensors [F,3].
+    Returns a float32 tensor of the 13 terms in STAGE_KEYS order (on the GPU, no host synchronisation); the last one (offset) is
+    meaningless when the stage predicts no offset (DirLoss drops the key, like the reference)."""
+    p, g, keep, off, B, _ = _marshal_stage(pred, target, meta_info, faces, False)
+    dev = keep[0].device
+    scratch = torch.empty(B * 13, device=dev, dtype=torch.float64)
+    out = torch.empty(13, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
         _capi.check(_capi.lib().dir_stage_losses_forward(C.byref(p), C.byref(g), float(coord_weight), _capi.ptr(scratch),
                                                          _capi.ptr(out), B, _capi.stream_ptr()), 'dir_stage_losses_forward')
     return out
@@ -71,7 +112,8 @@ def stage_losses(pred, target, meta_info, faces, coord_weight=10.0):
 
 def dense_losses(seg_logits, dense_pred, gt_seg, gt_dense, class_weight=(0.1, 0.45, 0.45), dense_weight=1.0):
     """models/dir.py:562-569 -> float32 tensor (seg, dense, lovasz) on the GPU"""
-    seg, dense, gs, gd = (_capi.f32c(t) for t in (seg_logits, dense_pred, gt_seg, gt_dense))
+    seg, dense = _capi.f32c(seg_logits), _capi.f32c(dense_pred)
+    gs, gd = _capi.f32c(gt_seg.to(seg.device)), _capi.f32c(gt_dense.to(seg.device))      # the reference: target[...].cuda()
     _capi.require_cuda(seg, dense, gs, gd)
     B, Cc, S, S2 = seg.shape
     if Cc != 3 or S != S2 or dense.shape != seg.shape or gs.shape[:2] != (B, 1) or gd.shape[:2] != (B, 3) or gs.shape[2:] != gd.shape[2:]:
@@ -128,31 +170,19 @@ def stage_loss_grads(pred, target, meta_info, faces, coord_weight=10.0, grad_out
     """Gradients of sum_k grad_out[k] * term_k (grad_out None = ones) of one stage w.r.t. pd_joint_uv_*, pd_mesh_uv_*, pd_joint_xyz_*,
     pd_mesh_xyz_* and pd_offset -- what autograd returns through the reference's loss modules.  pd_mesh_uv_* must be in `pred` (it
     is an independent input of this gradient).  Returns a dict with the prediction keys."""
-    keep, p, g, o = [], _capi.LossPred(), _capi.LossTarget(), _capi.LossPredGrad()
+    p, g, keep, off, B, fs = _marshal_stage(pred, target, meta_info, faces, True)
+    o = _capi.LossPredGrad()
     out = {}
     for field, prefix in (('joint_uv', 'pd_joint_uv_'), ('mesh_uv', 'pd_mesh_uv_'), ('joint_xyz', 'pd_joint_xyz_'), ('mesh_xyz', 'pd_mesh_xyz_')):
-        ts, arr = _pair(pred, prefix)
-        keep += ts
-        setattr(p, field, arr)
-        gs = [torch.empty_like(t) for t in ts]
+        gs = [torch.empty_like(_capi.f32c(pred[prefix + s_])) for s_ in SIDES]
         setattr(o, field, (C.c_void_p * 2)(*[_capi.ptr(t) for t in gs]))
         for s_, t in zip(SIDES, gs):
             out[prefix + s_] = t
-    off = _capi.f32c(pred['pd_offset'])
-    p.offset = _capi.ptr(off)
-    out['pd_offset'] = torch.empty_like(off)
-    o.offset = _capi.ptr(out['pd_offset'])
-    for field, prefix in (('joint_2d', 'joint_2d_'), ('mesh_2d', 'mesh_2d_'), ('joint_3d', 'joint_3d_'), ('mesh_3d', 'mesh_3d_')):
-        ts, arr = _pair(target, prefix)
-        keep += ts
-        setattr(g, field, arr)
-    ts, arr = _pair(meta_info, 'center_')
-    keep += ts
-    g.center = arr
-    _capi.require_cuda(*(keep + [off]))
-    fs = [f.to(device=off.device, dtype=torch.int32).contiguous() for f in faces]
-    g.faces = (C.c_void_p * 2)(*[_capi.ptr(f) for f in fs])
-    g.c2, g.n_faces = int(keep[8].shape[-1]), int(fs[0].shape[0])
+    goff = torch.empty(B, 3, device=keep[0].device)
+    o.offset = _capi.ptr(goff)
+    if off is not None:
+        out['pd_offset'] = goff
+    off = keep[0]                     # device anchor below
     csr = csr if csr is not None else [vertex_face_csr(f) for f in fs]
     offs = (C.c_void_p * 2)(*[_capi.ptr(c[0]) for c in csr])
     idxs = (C.c_void_p * 2)(*[_capi.ptr(c[1]) for c in csr])
@@ -166,7 +196,8 @@ def stage_loss_grads(pred, target, meta_info, faces, coord_weight=10.0, grad_out
 
 def dense_loss_grads(seg_logits, dense_pred, gt_seg, gt_dense, class_weight=(0.1, 0.45, 0.45), dense_weight=1.0, grad_out=None):
     """Gradients of grad_out . (seg, dense, lovasz) w.r.t. the seg logits and the dense prediction -> (grad_seg, grad_dense)"""
-    seg, dense, gs, gd = (_capi.f32c(t) for t in (seg_logits, dense_pred, gt_seg, gt_dense))
+    seg, dense = _capi.f32c(seg_logits), _capi.f32c(dense_pred)
+    gs, gd = _capi.f32c(gt_seg.to(seg.device)), _capi.f32c(gt_dense.to(seg.device))
     _capi.require_cuda(seg, dense, gs, gd)
     B, Cc, S, S2 = seg.shape
     if Cc != 3 or S != S2 or dense.shape != seg.shape or gs.shape[:2] != (B, 1) or gd.shape[:2] != (B, 3) or gs.shape[2:] != gd.shape[2:]:

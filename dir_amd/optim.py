@@ -50,24 +50,55 @@ class FlatAdamW(object):
         self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         self.param_groups = [dict(self.defaults, **self.extra)]      # schedulers write param_groups[0]['lr']
         self.step_count = 0
+        self.active = [True] * len(self.params)
+        self._ranges = [(0, n)]
 
-    def zero_grad(self):
+    def set_inactive(self, params):
+        """Parameters that never receive a gradient (torch.optim.AdamW skips `p.grad is None`: no state, no weight decay -- in the
+        reference e.g. interaction.STEblocks.0.*, never executed, transformer/mixSTE.py:197, and the dead e_0 of every PGraphConv):
+        step() leaves their slots alone and state_dict() omits them, as torch does."""
+        ids = {id(p) for p in params}
+        self.active = [a and id(p) not in ids for a, p in zip(self.active, self.params)]
+        self._ranges, cur = [], None
+        ends = self.offsets[1:] + [self.numel]
+        for a, o, e in zip(self.active, self.offsets, ends):
+            if a:
+                cur = (cur[0], e) if cur is not None and cur[1] == o else (o, e)
+                if self._ranges and self._ranges[-1][0] == cur[0]:
+                    self._ranges[-1] = cur
+                else:
+                    self._ranges.append(cur)
+            else:
+                cur = None
+
+    def zero_grad(self, set_to_none=False):
+        # the gradients live in flat_grad (the all-reduce bucket): they are zeroed in place, never detached
         self.flat_grad.zero_()
 
     def step(self):
         g = self.param_groups[0]
         self.step_count += 1
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
+                raise _capi.DirHipError('FlatAdamW: a parameter\'s .grad no longer aliases flat_grad (zero_grad(set_to_none=True) on the '
+                                        'model, or .grad reassigned): use FlatAdamW.zero_grad()')
         with torch.cuda.device(self.flat_param.device):
-            _capi.check(_capi.lib().dir_adamw_step(_capi.ptr(self.flat_param), _capi.ptr(self.flat_grad), _capi.ptr(self.exp_avg),
-                                                   _capi.ptr(self.exp_avg_sq), self.numel, float(g['lr']), float(g['betas'][0]),
-                                                   float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
-                                                   self.step_count, _capi.stream_ptr()), 'dir_adamw_step')
+            for a, b in self._ranges:
+                off = lambda t: _capi.C.c_void_p(t.data_ptr() + 4 * a)       # noqa: E731
+                _capi.check(_capi.lib().dir_adamw_step(off(self.flat_param), off(self.flat_grad), off(self.exp_avg), off(self.exp_avg_sq),
+                                                       b - a, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                                       float(g['weight_decay']), self.step_count, _capi.stream_ptr()), 'dir_adamw_step')
+        # the kernel writes through raw pointers: bump every parameter's version counter as an in-place torch op would, so that
+        # caches keyed on (data_ptr, _version) -- DIR.engine()'s packed weights -- see the update
+        torch._C._increment_version(self.params)
 
     # ---- torch.optim.Optimizer.state_dict() layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [0..]}]}
     def state_dict(self):
         state = {}
         if self.step_count > 0:
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                if not self.active[i]:
+                    continue
                 sl = slice(o, o + p.numel())
                 state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.exp_avg[sl].view(p.shape).clone(),
                             'exp_avg_sq': self.exp_avg_sq[sl].view(p.shape).clone()}

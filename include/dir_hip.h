@@ -29,12 +29,17 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 10
+#define DIR_ABI_VERSION 12
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
 /* number of visible HIP devices, and the gcnArchName of device 0 copied into buf (host). */
 int dir_device_info(char* arch_host, int arch_len, int* num_cu_host);
+/* Measurement aid (bench.py's live roofline): the library notes the name of every kernel it launches for the calling thread.
+ * dir_launch_log_reset() clears the note pad; dir_launch_log_get() copies the names launched since then into buf_host as a
+ * comma-separated list (kernel names as rocprofv3 reports them, template arguments dropped) and returns how many there were. */
+void dir_launch_log_reset(void);
+int dir_launch_log_get(char* buf_host, int len);
 
 /* ------------------------------------------------------------------------------------------------
  * a8 + a9: MANO forward + weak-perspective projection
@@ -79,11 +84,12 @@ int dir_mano_forward(const dir_mano_tables* tables_host, const float* pose, int 
                      int B, void* stream);
 
 /* Both hands of one stage in ONE launch (grid = B x 2).  tables_lr[2] = {left, right}; the *_lr arguments are HOST
- * arrays of two device pointers.  cam_lr / joint_uv_lr may be NULL. */
+ * arrays of two device pointers.  cam_lr / joint_uv_lr / flags_lr may be NULL; flags_lr[h] = int32[B] as flags_out above
+ * (the reflection check of rot6d.py:50 that DIR.forward turns into the reference's AssertionError). */
 int dir_mano_forward_pair(const dir_mano_tables* tables_lr_host, const float* const* pose_lr_host, int pose_stride,
                           const float* const* betas_lr_host, int betas_stride, const float* const* cam_lr_host,
                           int cam_stride, float* const* verts_lr_host, float* const* joints_lr_host,
-                          float* const* joint_uv_lr_host, int B, void* stream);
+                          float* const* joint_uv_lr_host, int32_t* const* flags_lr_host, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores

@@ -92,3 +92,31 @@ def test_csr_adjacency_constants_match_edge_order(golden):
     order = golden('g2_pgcn')['edge_order']
     rows = [r for r in range(21) for _ in range(off[r + 1] - off[r])]
     assert np.array_equal(np.stack([rows, idx], 1), order)
+
+
+def test_reference_import_lines_resolve_through_the_compat_shim():
+    """apps/eval.py:15-19 and models/dir.py:7-15 import `models.dir`, `models.manolayer`, `SemGCN.*`, `transformer.mixSTE`,
+    `manopth.manolayer` as top-level packages: with dir_amd/compat on sys.path those lines work unchanged and give the mirrors."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from models.dir import DIR
+from models.manolayer import ManoLayer
+from models.backbone.hourglass import Residual
+from models.backbone.resnet import resnet50 as ResNet50
+from SemGCN.utils import adj_mx_from_edges, get_sketch_setting
+from SemGCN.p_gcn import ResSimplePGCN
+from SemGCN.p_graph_conv import PGraphConv
+from transformer.mixSTE import STE
+from manopth.manolayer import ManoLayer as ObmanManoLayer
+import dir_amd.models.dir, dir_amd.manopth.manolayer, dir_amd.models.manolayer
+assert DIR is dir_amd.models.dir.DIR and ObmanManoLayer is dir_amd.manopth.manolayer.ManoLayer
+assert ManoLayer is dir_amd.models.manolayer.ManoLayer
+assert ResNet50().inplanes == 2048
+print("ok")
+''' % (root, os.path.join(root, 'dir_amd', 'compat'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr

@@ -88,3 +88,36 @@ def test_gradient_average_world2():
     from dir_amd import dist as D
     one = torch.ones(5)
     assert D.average_gradients(one) is one and float(one.sum()) == 5.0      # single process: untouched
+
+
+def test_spawn_ranks_launcher(tmp_path):
+    """the launcher path a bare `python bench.py --gpus N` takes (dir_amd.dist.spawn_ranks -> torch.distributed.run, 127.0.0.1):
+    2 ranks on CPU with gloo"""
+    import json
+    import sys
+    from dir_amd import dist as D
+    out = tmp_path / 'probe.json'
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'rank_probe.py')
+    rc = D.spawn_ranks([script, str(out)], 2, timeout=300)
+    assert rc == 0
+    got = json.loads(out.read_text())
+    assert got == {'world': 2, 'sum': 3.0, 'gathered': [float(i) for i in range(10)], 'dist_world': 2}
+    assert sys.executable
+
+
+def test_bench_refuses_a_world_it_cannot_build():
+    """`python bench.py --gpus 2` must never come back with a 1-rank line: without two visible GPUs (this box has none) it exits
+    non-zero with a message; with WORLD_SIZE in the environment that contradicts --gpus it does so too"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and 'needs 2 visible GPUs' in r.stderr and '"metric"' not in r.stdout
+    env2 = dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0'], env=env2,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and 'WORLD_SIZE=2' in r.stderr and '"metric"' not in r.stdout

@@ -30,6 +30,10 @@ def dir_state():
     return sd, img
 
 
+# bf16 mode, feature-map slices vs the reference (G7), relative to the slice's maximum: 2x the values measured on MI355X
+BF16_SLICE_BOUND = {'c1': 6e-2, 'c2': 6e-2, 'c3': 6e-2, 'c4': 6e-2, 'fusion4': 6e-2, 'enh3': 6e-2, 'final': 6e-2, 'seg': 0.1}
+
+
 def nchw(t):
     return t.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
 
@@ -53,7 +57,9 @@ def test_engine_fp32_vs_reference_golden(golden, dir_state):
             assert maxabs(outs[i][k].cpu().numpy(), g['s%d.%s' % (i, k)]) < 5e-4, (i, k)
         assert outs[i]['pd_rel_joint'] is None
     print('fp32 engine: worst |xyz - reference| = %.3e m (%.2e mm)' % (worst, worst * 1e3))
-    assert worst < 5e-6
+    # north_star: joint / vertex positions within 1e-4 mm = 1e-7 m of the reference; measured 7.5e-8 .. 8.9e-8 m.  The gate leaves
+    # the summation-order slack of the convolutions (ATen sums in a different order) and nothing else.
+    assert worst < 1.5e-7
     assert relerr(outs[3]['seg'].cpu().numpy(), g['seg']) < 5e-4
     assert relerr(outs[3]['dense'].cpu().numpy(), g['dense']) < 5e-4
     pf = outs[3]['proj_feat'].cpu().numpy()
@@ -72,15 +78,19 @@ def test_engine_bf16_envelope(golden, dir_state):
     for name in ('c1', 'c2', 'c3', 'c4', 'fusion4', 'enh3', 'final'):
         e = relerr(nchw(taps[name])[:, :4], g[name + '.slice'])
         print('bf16 %s slice relerr %.3e' % (name, e))
-        assert e < 6e-2, name
+        assert e < BF16_SLICE_BOUND[name], name      # 2x the measured value (profiles/r02_bf16_envelope.txt)
     mpjpe = []
     for i in range(3):
         for side in ('left', 'right'):
             d = outs[i]['pd_joint_xyz_' + side].cpu().numpy() - g['s%d.pd_joint_xyz_%s' % (i, side)]
             mpjpe.append(float(np.sqrt((d ** 2).sum(-1)).mean()) * 1e3)
     print('bf16 engine: mean per-joint position error vs reference per stage/hand (mm):', np.round(mpjpe, 4))
-    assert max(mpjpe) < 1.0           # random-weight envelope; see module docstring
-    assert relerr(outs[3]['seg'].cpu().numpy(), g['seg']) < 0.1
+    # measured envelope on these random weights: init stage 0.12 mm (the init regression reads bf16 c4 with |c4| ~ 2e2), refined
+    # stages 0.001 - 0.004 mm (they re-regress from fp32 tokens)
+    assert max(mpjpe[:2]) < 0.25 and max(mpjpe[2:]) < 0.01, mpjpe
+    e = relerr(outs[3]['seg'].cpu().numpy(), g['seg'])
+    print('bf16 seg relerr %.3e' % e)
+    assert e < BF16_SLICE_BOUND['seg']
 
 
 def test_engine_batch_independence(dir_state):
@@ -109,7 +119,7 @@ def test_dir_module_dropin(golden, dir_state):
                                       'pd_joint_xyz_left', 'pd_joint_xyz_right', 'pd_proj_left', 'pd_proj_right',
                                       'pd_offset', 'pd_rel_joint'])
     assert sorted(outs[3]) == ['dense', 'proj_feat', 'seg']
-    assert maxabs(outs[2]['pd_mesh_xyz_left'].cpu().numpy(), g['s2.pd_mesh_xyz_left']) < 5e-6
+    assert maxabs(outs[2]['pd_mesh_xyz_left'].cpu().numpy(), g['s2.pd_mesh_xyz_left']) < 1.5e-7
     assert outs[3]['seg'].shape == (2, 3, 32, 32) and outs[3]['proj_feat'].shape == (2, 1280, 32, 32)
     # sub-module drop-ins on the same weights
     c1, c2, c3, c4 = net.backbone(img)
@@ -319,7 +329,29 @@ def test_full_size_batch_64_rows_equal_the_golden_pinned_small_batch(golden, dir
                         print('   stage %d %-20s max abs diff %.3e' % (s, k, d))
         if dt == torch.float32:
             assert torch.equal(o[3]['seg'][[5, 63]], want_seg)
-            assert maxabs(o[2]['pd_mesh_xyz_left'][[5, 63]].cpu().numpy(), g['s2.pd_mesh_xyz_left']) < 5e-6
+            assert maxabs(o[2]['pd_mesh_xyz_left'][[5, 63]].cpu().numpy(), g['s2.pd_mesh_xyz_left']) < 1.5e-7
     if dt != torch.float32:
         print('bf16 B=64 rows vs B=2 run: worst abs difference %.3e' % worst)
         assert worst < 2e-3
+
+
+def test_batch_128_rows_equal_the_golden_pinned_small_batch(golden, dir_state):
+    """BASELINE configs[2]'s batch size (128; the dataset and checkpoint of that config are not available here): the golden images
+    at rows 0 and 127 of a batch of 126 others equal the B = 2 run bit for bit in fp32 mode -- and through it the reference."""
+    sd, img = dir_state
+    g = golden('g7_dir')
+    eng = DirEngine(sd, dtype=torch.float32)
+    small = eng.forward(img)
+    want = {k: small[2][k].clone() for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_uv_left')}
+    big = torch.randn(128, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(128))
+    big[0], big[127] = img[0], img[1]
+    o = eng.forward(big)
+    torch.cuda.synchronize()
+    for k, v in want.items():
+        assert torch.equal(o[2][k][[0, 127]], v), k
+    assert maxabs(o[2]['pd_mesh_xyz_left'][[0, 127]].cpu().numpy(), g['s2.pd_mesh_xyz_left']) < 1.5e-7
+    e16 = DirEngine(sd, dtype=torch.bfloat16)
+    o16 = e16.forward(big)
+    torch.cuda.synchronize()
+    d = (o16[2]['pd_joint_xyz_left'][[0, 127]].cpu().numpy() - g['s2.pd_joint_xyz_left'])
+    assert float(np.sqrt((d ** 2).sum(-1)).mean()) * 1e3 < 0.01           # mm, the refined-stage bf16 envelope

@@ -118,3 +118,57 @@ def test_adamw_argument_errors():
     assert L.dir_adamw_step(_capi.ptr(p), _capi.ptr(p), _capi.ptr(p), _capi.ptr(p), 16, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 0, None) != 0
     with pytest.raises(_capi.DirHipError):
         DO.FlatAdamW([torch.nn.Parameter(torch.zeros(4))])       # CPU parameters: no fallback
+
+
+def test_step_bumps_versions_and_skips_inactive_parameters():
+    """(1) the kernel writes parameters through raw pointers: step() must bump every parameter's version counter like torch's
+    in-place ops do, or caches keyed on (data_ptr, _version) -- DIR.engine() -- keep serving stale weights.  (2) parameters that
+    never get a gradient (torch: `p.grad is None`, e.g. the never-executed STE block 0) take no weight decay and have no state,
+    exactly like torch.optim.AdamW; (3) detached gradients are an error, not a silent decay-only step."""
+    rng = np.random.RandomState(3)
+    ref_p = make_params(rng, 'cpu')
+    our_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    dead = (1, 4)                                                   # indices that never receive a gradient
+    ref = torch.optim.AdamW(ref_p, 1e-2)
+    our = DO.FlatAdamW(our_p, 1e-2)
+    our.set_inactive([our_p[i] for i in dead])
+    v0 = [p._version for p in our_p]
+    for _ in range(3):
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i in dead:
+                continue
+            g = rng.normal(0, 1, a.shape).astype(np.float32)
+            a.grad = torch.from_numpy(g.copy())
+            b.grad.copy_(torch.from_numpy(g))
+        ref.step(); our.step()
+    assert all(p._version > v for p, v in zip(our_p, v0))
+    for i, (a, b) in enumerate(zip(ref_p, our_p)):
+        assert relerr(b.detach().cpu().numpy(), a.detach().numpy()) < 2e-7, i       # dead ones: untouched on both sides
+    assert sorted(our.state_dict()['state']) == sorted(ref.state_dict()['state']) == [0, 2, 3, 5]
+    our_p[0].grad = None                                            # what model.zero_grad(set_to_none=True) does
+    with pytest.raises(DO._capi.DirHipError):
+        our.step()
+
+
+def test_dir_module_sees_an_optimiser_step():
+    """train.py:87 validates after optimiser steps: DIR.forward must run the UPDATED weights"""
+    import json
+    from conftest import GOLDEN
+    from dir_amd import synth
+    from dir_amd.models.dir import DIR
+    with open(os.path.join(GOLDEN, 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
+    net = DIR(21, './misc/mano', 0)
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    net.autotune = False
+    img = torch.from_numpy(synth.synth_input('dir.img', (1, 3, 256, 256), 1234)).cuda()
+    a = net({'img': img}, None, None)[0][2]['pd_mesh_xyz_left'].clone()
+    opt = DO.FlatAdamW([p for p in net.parameters() if p.requires_grad], 1e-2)
+    opt.flat_grad.fill_(1.0)
+    opt.step()
+    b = net({'img': img}, None, None)[0][2]['pd_mesh_xyz_left'].clone()
+    assert not torch.equal(a, b)
+    c = net({'img': img}, None, None)[0][2]['pd_mesh_xyz_left']
+    assert torch.equal(b, c)                                        # and the re-packed engine is cached again

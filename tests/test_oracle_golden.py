@@ -326,3 +326,22 @@ def test_loss_gradients_match_autograd(golden):
         for k, v in OL.stage_loss_grads(preds[i], gt, faces).items():
             want = gg['grad.s%d.%s' % (i, k)]
             assert maxabs(v, want) <= 2e-5 * np.abs(want).max(), (i, k, maxabs(v, want), np.abs(want).max())
+
+
+def test_stock_torch_dense_ops_equal_the_numpy_oracle():
+    """bench.py's second CPU baseline swaps the oracle's dense operators for stock torch CPU kernels (oracle/torch_ops.py): the
+    swapped forward must be the same function (fp32 summation-order noise only), and the swap must be undone afterwards"""
+    from oracle import nnops as N_
+    from oracle.torch_ops import stock_torch_dense_ops
+    sd = synth.synth_state_dict(shapes_of('manifest_dir.json'), SEED)
+    img = synth.synth_input('dir.img', (1, 3, 256, 256), SEED)
+    a = dir_forward(sd, img)
+    conv_before = N_.conv2d
+    with stock_torch_dense_ops(2):
+        assert N_.conv2d is not conv_before
+        b = dir_forward(sd, img)
+    assert N_.conv2d is conv_before
+    for i in range(3):
+        for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_uv_right'):
+            assert maxabs(a[i][k], b[i][k]) < 2e-6, (i, k)
+    assert relerr(a[3]['seg'], b[3]['seg']) < 1e-3 and relerr(a[3]['proj_feat'], b[3]['proj_feat']) < 1e-3
