@@ -236,7 +236,10 @@ def main():
             step2()
         r2 = timed_regions(step2, args.steps, 3, sync, float, sync)
         d2 = statistics.median(r2)
-        no_pf = {'images_per_sec': round(B * args.steps / d2, 1), 'ms_per_step': round(d2 / args.steps * 1e3, 3)}
+        r3 = timed_regions(step, args.steps, 3, sync, float, sync)          # the headline pipeline again, right after: same clocks
+        d3 = statistics.median(r3)
+        no_pf = {'images_per_sec': round(B * args.steps / d2, 1), 'ms_per_step': round(d2 / args.steps * 1e3, 3),
+                 'with_proj_feat_measured_right_after_ms_per_step': round(d3 / args.steps * 1e3, 3)}
         del pipe2
 
     # ---- roofline: HIP events around every library call, eager, same stream
@@ -345,7 +348,7 @@ def main():
         from oracle.dir_forward import dir_forward
         from oracle.torch_ops import stock_torch_dense_ops
         from threadpoolctl import threadpool_limits
-        ncpu = os.cpu_count() or 1
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         nthreads = min(args.cpu_threads, ncpu)
         n, chunk = args.cpu_sample, 8
         ximg = img[:min(max(n, 64), B)].cpu().numpy()
@@ -355,10 +358,12 @@ def main():
             for i in range(0, n, chunk):
                 dir_forward(sd_np, ximg[i % len(ximg):i % len(ximg) + chunk])
             tc = time.perf_counter() - t0
+        # torch's CPU kernels at every hardware thread of this box were measured 20x SLOWER than at 16 (256 threads: 0.6 images/s at
+        # B = 64, 0.013 at B = 1 -- oversubscribed oneDNN thread pool), so the torch leg runs at the numpy leg's thread count too
         tor = {}
-        with stock_torch_dense_ops(ncpu):
+        with stock_torch_dense_ops(nthreads):
             dir_forward(sd_np, ximg[:2])
-            for bb, nrep in ((1, 4), (min(64, len(ximg)), 1)):
+            for bb, nrep in ((1, 2), (min(64, len(ximg)), 1)):
                 t0 = time.perf_counter()
                 for _ in range(nrep):
                     dir_forward(sd_np, ximg[:bb])
@@ -367,7 +372,7 @@ def main():
         cpu = {'value': round(n / tc, 3), 'unit': 'images/sec', 'cores': int(nthreads), 'kind': 'port', 'os_cpu_count': int(ncpu),
                'sample': '%d images in chunks of %d, fp32 forward of oracle/dir_forward.py (numpy + OpenBLAS, %d threads), '
                          '%.1f s' % (n, chunk, nthreads, tc),
-               'torch_ops': dict(tor, threads=int(ncpu), note='oracle/dir_forward.py with conv / BN / pool / upsample / linear on stock torch '
+               'torch_ops': dict(tor, threads=int(nthreads), note='oracle/dir_forward.py with conv / BN / pool / upsample / linear on stock torch '
                                  'CPU kernels (oracle/torch_ops.py); token path numpy')}
 
     if rank == 0:

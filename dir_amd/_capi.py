@@ -37,6 +37,10 @@ class BneckChainParams(C.Structure):
         ('n_next', C.c_int32)]
 
 
+class BneckTailParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('wstream', 'scale3', 'shift3', 'scale1n', 'shift1n')] + [('planes', C.c_int32), ('n_next', C.c_int32)]
+
+
 class TokenMlp(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w1t', 's1', 'b1', 'w2t', 'b2')]
 
@@ -96,7 +100,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 12          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 13          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -122,6 +126,7 @@ _SIGNATURES = {
     'dir_dense_losses_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_dense_losses_forward': (C.c_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.c_float, _p, C.c_longlong, _p, _i, _i, _i, _i, _p]),
     'dir_bottleneck_chain_forward': (C.c_int, [C.POINTER(BneckChainParams), _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'dir_bottleneck_tail_forward': (C.c_int, [C.POINTER(BneckTailParams), _p, _p, _p, _p, C.c_longlong, _p]),
     'dir_stem_pool_forward': (C.c_int, [_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -1,0 +1,312 @@
+// dir_bottleneck_tail_forward: the 1x1 tail of one ResNet bottleneck and the 1x1 head of the next in ONE kernel (bf16 mode), for the
+// layer2 / layer3 geometry (planes P = 128 / 256, block width C4 = 4 P = 512 / 1024):
+//   models/backbone/resnet.py:132-140   block i  : conv3 1x1 (P -> 4P) -> bn3 -> += identity -> ReLU            -> out   (HBM)
+//   models/backbone/resnet.py:122-124   block i+1: conv1 1x1 (4P -> N2) -> bn1 -> ReLU                           -> y1n   (HBM)
+// Unfused, the block output (the widest tensor of the layer: 67 MB at 32x32x512, B = 64) is written by conv3 and read back by the
+// next conv1; both launches stream (K <= 1024), so only bytes count: y2 + identity + out + (out again) + y1n = 235 MB per block at
+// layer2 against 168 MB here (layer3: 117 -> 84 MB), and one launch (ramp, first-load latency, drain) instead of two -- at layer3's
+// M = 16 384 the two launches are latency-bound at 2.1 - 2.6 TB/s.
+//
+// One persistent 8-wave workgroup per CU walks 64-pixel tiles (1x1 convolutions: a tile is any 64 consecutive NHW pixels).  Both
+// GEMMs are computed as D[channel][pixel] (weights = MFMA A operand): a lane holds 4 consecutive channels of a pixel -- what the
+// bf16 NHWC stores, the residual loads and the LDS hand-over between the GEMMs want (bneck.hip).  The weights do not fit on the
+// CU (w3 + w1n = 256 KB at layer2, 1 MB at layer3): every wave STREAMS its own slice from L2 into a register ring, fragment by
+// fragment, in exactly the order its MFMAs consume them -- the host packs them in that order (dir_amd/engine.py::pack_tail_stream),
+// so a fragment is one coalesced 1 KB load per wave and no weight byte goes through LDS.  The block output is processed in
+// 512-channel halves (NH = C4 / 512) so that the T tile ([64 px][512 ch] bf16, 65 KB) fits in LDS at layer3 too; the next conv1
+// accumulates over the halves in registers.  Per unit (tile, half):
+//   B. conv3:  y2 tile (LDS) x this wave's 64 output channels (stream), bn3 + residual + ReLU -> T (LDS, bf16: the rounding point
+//      of the unfused path); the residual sits in registers since the previous unit's epilogue (a unit of lead time)
+//   -  T -> HBM with coalesced 16-byte stores (block output)
+//   C. next conv1: T (LDS) x this wave's N2 / 8 output channels (stream), accumulated over the halves; after the last half
+//      bn1 + ReLU -> y1n (HBM)
+// The next tile's y2 rows are requested at the top of a tile and parked in LDS at its end.
+#include "conv_common.h"
+
+namespace dir {
+namespace {
+
+using convk::bf16_t;
+using convk::bf16x8;
+using convk::f32x16;
+using convk::pack2bf;
+using convk::relu2bf;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TM = 64;                 // pixels per tile
+constexpr int HC = 512;                // channels per half of the block output
+constexpr int NTHR = 512;
+constexpr int TPITCH = HC * 2 + 16;    // bytes per T pixel
+
+struct TailArgs {
+    const bf16_t* y2; const bf16_t* res; bf16_t* out; bf16_t* y1n;
+    const uint4* wstream;              // [NH][8 waves][NBF + NCF fragments][64 lanes] x 16 bytes
+    const float* sc3; const float* sh3; const float* sc1n; const float* sh1n;
+    int ntiles; unsigned y2_bytes;
+};
+
+__device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// P: planes (K of conv3); N2: output channels of the next conv1 (128: 16 per wave on v_mfma_f32_16x16x32_bf16; 256: 32 per wave
+// on v_mfma_f32_32x32x16_bf16)
+template <int P, int N2>
+__global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
+    constexpr int C4 = 4 * P, NH = C4 / HC;
+    constexpr int YROW = P * 2;                         // bytes per y2 pixel (unpadded: 16-byte chunk c of row r sits at c ^ (r & 15))
+    constexpr int GRP = P == 256 ? 4 : 8;               // weight fragments per ring group (1 KB each per wave): register budget
+    constexpr int KBS = P / 16;                         // k-steps of conv3
+    constexpr int NBF = 2 * KBS;                        // phase-B fragments per unit: (channel block of 32, k-step), channel-block-major
+    constexpr bool C16 = N2 == 128;                     // phase C on 16x16x32 (16 channels per wave) or 32x32x16 (32 per wave)
+    constexpr int NCF = C16 ? HC / 32 : HC / 16;        // phase-C fragments per unit (K = 512 per half)
+    constexpr int NF = NBF + NCF, NG = NF / GRP;        // fragments / ring groups per unit
+    static_assert(NF % GRP == 0 && C4 % HC == 0 && (N2 == 128 || N2 == 256), "tail_chain_kernel: unsupported geometry");
+    constexpr int YCH = TM * (P / 8) / NTHR;            // 16-byte y2 chunks per thread (2 | 4) = 1 KB LDS-DMA pieces per wave
+    __shared__ __attribute__((aligned(16))) char s_t[TM * TPITCH];
+    __shared__ __attribute__((aligned(16))) char s_y2[2][TM * YROW];
+    __shared__ __attribute__((aligned(16))) float s_ss[2 * C4 + 2 * N2];     // sc3 | sh3 | sc1n | sh1n
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5, l16 = lane & 15, g16 = lane >> 4;
+
+    for (int i = tid; i < C4; i += NTHR) { s_ss[i] = a.sc3[i]; s_ss[C4 + i] = a.sh3[i]; }
+    for (int i = tid; i < N2; i += NTHR) { s_ss[2 * C4 + i] = a.sc1n[i]; s_ss[2 * C4 + N2 + i] = a.sh1n[i]; }
+
+    const int tstep = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= a.ntiles) return;
+
+    // ---- y2 rows of a tile: global -> LDS by DMA (no registers: the prefetch of the next tile is in flight for a whole tile).  Piece i of
+    //      wave w fills LDS bytes [(8 i + w) KB, +1 KB) of the buffer: lane l lands on 16-byte slot s = (8 i + w) * 64 + l = (pixel
+    //      s / (P/8), position s % (P/8)) and fetches the chunk that belongs there under the XOR swizzle (conflict-free ds_read_b128)
+    const convk::i32x4 yd = {(int)(unsigned)(unsigned long long)a.y2, (int)(unsigned)((unsigned long long)a.y2 >> 32), (int)a.y2_bytes, 0x00020000};
+    const unsigned y2_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)&s_y2[0][0];
+    auto y2_dma = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < YCH; ++i) {
+            const int slot = (8 * i + wave) * 64 + lane, px = slot / (P / 8), pos = slot % (P / 8);
+            const unsigned voff = (unsigned)(((long long)tile * TM + px) * YROW) + (unsigned)((pos ^ (px & 15)) * 16);
+            convk::lds_dma16_m0(yd, y2_lds + buf * (TM * YROW) + (8 * i + wave) * 1024, voff, 0);
+        }
+    };
+    // ---- residual of a unit in the epilogue-B layout: pixel 32 pb + l32, channels half*512 + 64 wave + 32 cb + 8 q + 4 h .. +4
+    uint2 xr[2][2][4];
+    auto res_fetch = [&](int tile, int half) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const bf16_t* rp = a.res + ((long long)tile * TM + 32 * pb + l32) * C4 + half * HC + 64 * wave + 4 * h;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xr[cb][pb][q] = *reinterpret_cast<const uint2*>(rp + 32 * cb + 8 * q);
+        }
+    };
+    // ---- weight stream of this wave: fragment f of half hf at wstream[((hf * 8 + wave) * NF + f) * 64 + lane]
+    bf16x8 ring[2][GRP];
+    auto ring_load = [&](auto Slot, int hf, int grp) {
+        constexpr int slot = decltype(Slot)::value;
+        const uint4* p = a.wstream + ((long long)(hf * 8 + wave) * NF + grp * GRP) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) ring[slot][i] = __builtin_bit_cast(bf16x8, p[i * 64]);
+    };
+
+    y2_dma(t, 0);
+    ring_load(std::integral_constant<int, 0>{}, 0, 0);
+    res_fetch(t, 0);
+    convk::wait_vmcnt<0>();
+    __syncthreads();
+    int ybuf = 0;
+
+    f32x16 accb[2];                                      // conv3: [pixel block] of the current channel block
+    f32x16 accc32[C16 ? 1 : 2];                          // next conv1, 32x32 path: [pixel block]
+    f32x4 accc16[C16 ? 4 : 1];                           // next conv1, 16x16 path: [16-pixel group]
+    // activation (MFMA B) operands of a fragment step, read from LDS one step ahead of the MFMAs that use them
+    constexpr int NOP = C16 ? 4 : 2;
+    bf16x8 bop[2][NOP];
+    const char* ycur = s_y2[0];
+    auto act_read = [&](auto F, auto Set) {
+        constexpr int f = decltype(F)::value, set = decltype(Set)::value;
+        if constexpr (f < NBF) {                         // conv3: y2[pixel 32 pb + l32][16 ks + 8 h ..]
+            constexpr int ks = f % KBS;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+                bop[set][pb] = *reinterpret_cast<const bf16x8*>(ycur + (32 * pb + l32) * YROW + (((2 * ks + h) ^ (l32 & 15)) << 4));
+        } else {
+            constexpr int fc = f - NBF;
+            if constexpr (C16) {                         // T[pixel 16 u + l16][32 fc + 8 g ..]
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bop[set][u] = *reinterpret_cast<const bf16x8*>(s_t + (16 * u + l16) * TPITCH + 64 * fc + 16 * g16);
+            } else {                                     // T[pixel 32 pb + l32][16 fc + 8 h ..]
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) bop[set][pb] = *reinterpret_cast<const bf16x8*>(s_t + (32 * pb + l32) * TPITCH + 32 * fc + 16 * h);
+            }
+        }
+    };
+
+    for (; t < a.ntiles; t += tstep) {
+        const bool more = t + tstep < a.ntiles;
+        if (more) y2_dma(t + tstep, ybuf ^ 1);           // lands during this tile; published by the tile's last barrier
+        ycur = s_y2[ybuf];
+#pragma nounroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const bool last_half = hf == NH - 1;
+            if (hf == 0) {
+                if constexpr (C16) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) accc16[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accc32[pb][r] = 0.f;
+                }
+            }
+            act_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            // the unit's fragments, group by group; the next group (of this unit, or group 0 of the next unit) is requested first
+            [&]<int... G>(std::integer_sequence<int, G...>) {
+                (([&] {
+                     constexpr int grp = G, slot = G & 1;
+                     if constexpr (grp + 1 < NG) ring_load(std::integral_constant<int, slot ^ 1>{}, hf, grp + 1);
+                     else ring_load(std::integral_constant<int, slot ^ 1>{}, last_half ? 0 : hf + 1, 0);     // NG is even: slot 0 again
+                     [&]<int... I>(std::integer_sequence<int, I...>) {
+                         (([&] {
+                              constexpr int f = grp * GRP + I, set = f & 1;
+                              // operands of the next step (not across the phase boundary: T does not exist yet; not across the unit)
+                              if constexpr (f + 1 < NF && f + 1 != NBF) act_read(std::integral_constant<int, f + 1>{}, std::integral_constant<int, set ^ 1>{});
+                              if constexpr (f < NBF) {
+                                  // ---- B. conv3: fragment (channel block cb, k-step ks), channel-block-major: two accumulators live
+                                  constexpr int cb = f / KBS, ks = f - cb * KBS;
+                                  if constexpr (ks == 0) {
+#pragma unroll
+                                      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                                          for (int r = 0; r < 16; ++r) accb[pb][r] = 0.f;
+                                  }
+#pragma unroll
+                                  for (int pb = 0; pb < 2; ++pb)
+                                      accb[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set][pb], accb[pb], 0, 0, 0);
+                                  if constexpr (ks == KBS - 1) {
+                                      // ---- epilogue B of this channel block -> T: bn3 + residual + ReLU, bf16
+#pragma unroll
+                                      for (int q = 0; q < 4; ++q) {
+                                          const int cl = 64 * wave + 32 * cb + 8 * q + 4 * h;                  // channel inside the half
+                                          const float4 sc = *reinterpret_cast<const float4*>(s_ss + hf * HC + cl);
+                                          const float4 sh = *reinterpret_cast<const float4*>(s_ss + C4 + hf * HC + cl);
+#pragma unroll
+                                          for (int pb = 0; pb < 2; ++pb) {
+                                              float v[4] = {fmaf(accb[pb][4 * q], sc.x, sh.x), fmaf(accb[pb][4 * q + 1], sc.y, sh.y),
+                                                            fmaf(accb[pb][4 * q + 2], sc.z, sh.z), fmaf(accb[pb][4 * q + 3], sc.w, sh.w)};
+                                              float rv[4];
+                                              unpack4(xr[cb][pb][q], rv);
+#pragma unroll
+                                              for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                                              uint2 o;
+                                              o.x = relu2bf(pack2bf(v[0], v[1]));
+                                              o.y = relu2bf(pack2bf(v[2], v[3]));
+                                              *reinterpret_cast<uint2*>(s_t + (32 * pb + l32) * TPITCH + cl * 2) = o;
+                                          }
+                                          __builtin_amdgcn_sched_barrier(0);          // keep the (sc, sh) reads of later q's out of this one's registers
+                                      }
+                                  }
+                                  if constexpr (f == NBF - 1) {
+                                      __syncthreads();                               // T = this half of the block output; every wave is done with y2
+                                      act_read(std::integral_constant<int, NBF>{}, std::integral_constant<int, set ^ 1>{});
+                                      // residual of the NEXT unit into the registers just consumed (a unit of lead time)
+                                      if (!last_half) res_fetch(t, hf + 1);
+                                      else if (more) res_fetch(t + tstep, 0);
+                                      // block output: coalesced 16-byte stores from T (chunk c = pixel c >> 6, 16-byte chunk c & 63)
+#pragma unroll
+                                      for (int i = 0; i < TM * (HC / 8) / NTHR; ++i) {
+                                          const int c = tid + NTHR * i;
+                                          *reinterpret_cast<uint4*>(a.out + ((long long)t * TM + (c >> 6)) * C4 + hf * HC + (c & 63) * 8) =
+                                              *reinterpret_cast<const uint4*>(s_t + (c >> 6) * TPITCH + (c & 63) * 16);
+                                          if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                                      }
+                                  }
+                              } else {
+                                  // ---- C. next conv1 over this half's 512 input channels
+                                  if constexpr (C16) {
+#pragma unroll
+                                      for (int u = 0; u < 4; ++u)
+                                          accc16[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[slot][I], bop[set][u], accc16[u], 0, 0, 0);
+                                  } else {
+#pragma unroll
+                                      for (int pb = 0; pb < 2; ++pb)
+                                          accc32[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set][pb], accc32[pb], 0, 0, 0);
+                                  }
+                              }
+                              // the next tile's y2 DMA is the oldest thing this wave can still have in flight: everything but the ring
+                              // group requested at the top of this (last) group has to be back before the closing barrier publishes it
+                              if constexpr (f == NF - 1) convk::wait_vmcnt<GRP>();
+                              __builtin_amdgcn_sched_barrier(0);
+                          }()),
+                          ...);
+                     }(std::make_integer_sequence<int, GRP>{});
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, NG>{});
+            if (last_half) {
+                // ---- epilogue C: bn1 + ReLU -> next y1
+                if constexpr (C16) {
+                    const int c0 = 16 * wave + 4 * g16;
+                    const float4 sc = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + c0);
+                    const float4 sh = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + N2 + c0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        uint2 o;
+                        o.x = relu2bf(pack2bf(fmaf(accc16[u][0], sc.x, sh.x), fmaf(accc16[u][1], sc.y, sh.y)));
+                        o.y = relu2bf(pack2bf(fmaf(accc16[u][2], sc.z, sh.z), fmaf(accc16[u][3], sc.w, sh.w)));
+                        *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TM + 16 * u + l16) * N2 + c0) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c0 = 32 * wave + 8 * q + 4 * h;
+                            const float4 sc = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + c0);
+                            const float4 sh = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + N2 + c0);
+                            uint2 o;
+                            o.x = relu2bf(pack2bf(fmaf(accc32[pb][4 * q], sc.x, sh.x), fmaf(accc32[pb][4 * q + 1], sc.y, sh.y)));
+                            o.y = relu2bf(pack2bf(fmaf(accc32[pb][4 * q + 2], sc.z, sh.z), fmaf(accc32[pb][4 * q + 3], sc.w, sh.w)));
+                            *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TM + 32 * pb + l32) * N2 + c0) = o;
+                        }
+                }
+            }
+            __syncthreads();                             // T is free for the next unit; the next tile's y2 rows are visible
+        }
+        ybuf ^= 1;
+    }
+}
+
+}  // namespace
+}  // namespace dir
+
+extern "C" int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const void* y2, const void* residual, void* out, void* y1_next,
+                                           long long M, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(p && y2 && residual && out && y1_next, "dir_bottleneck_tail_forward: null pointer");
+    DIR_REQUIRE(p->wstream && p->scale3 && p->shift3 && p->scale1n && p->shift1n, "dir_bottleneck_tail_forward: missing parameters");
+    DIR_REQUIRE(M > 0 && M % TM == 0 && M / TM < (1ll << 31), "dir_bottleneck_tail_forward: M must be a positive multiple of 64");
+    TailArgs a;
+    a.y2 = (const convk::bf16_t*)y2; a.res = (const convk::bf16_t*)residual; a.out = (convk::bf16_t*)out; a.y1n = (convk::bf16_t*)y1_next;
+    a.wstream = (const uint4*)p->wstream; a.sc3 = p->scale3; a.sh3 = p->shift3; a.sc1n = p->scale1n; a.sh1n = p->shift1n;
+    a.ntiles = (int)(M / TM);
+    DIR_REQUIRE(M * p->planes * 2 < (1ll << 31), "dir_bottleneck_tail_forward: y2 must be < 2 GiB (32-bit buffer offsets)");
+    a.y2_bytes = (unsigned)(M * p->planes * 2);
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0; hipDeviceProp_t pr;
+        num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    }
+    const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
+    hipStream_t s = (hipStream_t)stream;
+#define DIR_TAIL(P_, N2_) DIR_LAUNCH((tail_chain_kernel<P_, N2_>), dim3(grid), dim3(NTHR), 0, s, a)
+    if (p->planes == 128 && p->n_next == 128) DIR_TAIL(128, 128);
+    else if (p->planes == 128 && p->n_next == 256) DIR_TAIL(128, 256);
+    else if (p->planes == 256 && p->n_next == 256) DIR_TAIL(256, 256);
+    else DIR_REQUIRE(false, "dir_bottleneck_tail_forward: (planes, n_next) must be (128,128), (128,256) or (256,256)");
+#undef DIR_TAIL
+    return check_launch("dir_bottleneck_tail_forward");
+}

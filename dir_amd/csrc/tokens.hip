@@ -210,7 +210,6 @@ struct PgcnHand {
     const float* e1_prev; const float* bias_prev; const float* bns_prev; const float* bnb_prev; int relu_prev;
     float* h_out;                               // [B][21][256]
 };
-struct PgcnArgs { PgcnHand h[2]; int B; int nchunk; long long* stamps; };   // stamps: DIR_STAMPS=pgcn (tuning aid, else NULL)
 
 __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (&w)[5], int (&idx)[5], int& deg) {
     // row j of softmax(A_1) where A_1 = -9e15 off the skeleton edges (SemGCN/p_graph_conv.py:43-50)
@@ -223,86 +222,134 @@ __device__ __forceinline__ void edge_softmax_row(const float* e1, int j, float (
     for (int t = 0; t < deg; ++t) w[t] /= sum;
 }
 
-constexpr int PG_BC = 16;   // samples per workgroup
-constexpr int PG_MT = (PG_BC + 15) / 16, PG_ROWS = PG_MT * 16;   // 16-row MFMA tiles (rows >= PG_BC are zero)
+constexpr int PG_BC = 16;   // samples per chunk (one 16-row MFMA tile)
 constexpr int PG_LD = 128 + 2;
+constexpr int PG_T = 512;   // 8 waves: wave w owns output columns 32 (w & 3) .. +31 of W0 (w < 4) or W1 (w >= 4)
+constexpr int PG_MAXSPLIT = 8;
 
-// grid (21 nodes, 2 slices of 64 output columns, hands x batch chunks), 256 threads.  A = the node's input rows of 16
-// samples (LDS), B = the node's own W0 / W1 column tiles (k-major in the reference layout [2][21][k][o]); wave w owns
-// output columns slice*64 + 16w .. +15 of both matrices.
-__global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
-    __shared__ float s_x[PG_ROWS * PG_LD];
-    const int j = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hand = blockIdx.z / args.nchunk, chunk = blockIdx.z - hand * args.nchunk;
+struct PgcnArgs {
+    PgcnHand h[2];
+    int B, nchunk;       // batch, 16-sample chunks
+    int npairs, npp;     // (node, hand) pairs = 21 * hands; workgroups per pair (each takes chunks c, c + npp, ...)
+    long long* stamps;   // DIR_STAMPS=pgcn (tuning aid, else NULL)
+};
+
+// One workgroup = one (node j, hand) pair and every npp-th 16-sample chunk of the batch.
+//   * The node's W0[j] | W1[j] (bf16: 64 KB, fp32: 128 KB) are fetched ONCE per workgroup, straight into MFMA B-operand registers
+//     (wave w: 32 of the 256 output columns, every k), and stay there for all of the workgroup's chunks.  The npp workgroups of
+//     a pair sit on the same XCD (blockIdx -> XCD is round robin), so their concurrent fetches of the same 64 KB merge in that
+//     XCD's L2: each weight byte leaves HBM once per launch (the previous grid -- (node, 64-column slice, hand, chunk) -- pulled
+//     it through up to eight L2s: 4x the algorithmic traffic in the PMC counters).
+//   * Layers >= 1 finish the previous layer in the prologue: per (sample, 4 channels) one thread gathers the node's own h0 row
+//     and its <= 5 neighbours' h1 rows with 16-byte loads (all six independent, from clamped addresses), applies the softmax-ed
+//     edge weights (row j of A_1, from LDS), bias, BatchNorm, ReLU and writes the MFMA A tile to LDS.  The next chunk's
+//     gathers are issued before the current chunk's MFMAs.
+//   * Arithmetic per output element is that of the previous kernel (same fmaf chain, same k order): results are bit-identical.
+template <bool WBF16>
+__global__ __launch_bounds__(PG_T) void pgcn_node_kernel(PgcnArgs args) {
+    __shared__ float s_x[2][PG_BC * PG_LD];
+    __shared__ float s_adj[8];                 // row j of softmax(A_1) of the previous layer, padded to 5 (+ pad)
+    __shared__ int s_nidx[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pi = slot / args.npp, c0 = slot - pi * args.npp;
+    const int p = xcd + 8 * pi;
+    if (p >= args.npairs) return;
+    const int hand = p / NJ, j = p - hand * NJ;
     const PgcnHand& a = args.h[hand];
-    const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
     int nstamp = 0;
-    auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
     stamp();
-    float wgt[5]; int nidx[5]; int deg = 0;
-    if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
+
+    // ---- this wave's weight fragments -> registers (in flight while the first chunk is gathered and mixed)
+    const int half = wave >> 2, ncol0 = (wave & 3) * 32, li = lane & 15, lk = lane >> 4;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+    bf16x8_t bw[WBF16 ? 2 : 1][WBF16 ? 4 : 1];
+    float bv[WBF16 ? 1 : 2][WBF16 ? 1 : 32];
+    if constexpr (WBF16) {          // W^T as bf16 [2][21][o][k]: one 16-byte load per lane and k-step
+        const unsigned short* w = reinterpret_cast<const unsigned short*>(a.W) + (((long long)half * NJ + j) * 128 + ncol0 + li) * 128 + lk * 8;
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
-        if (t >= deg) { wgt[t] = 0.f; nidx[t] = j; }                           // padded to 5 neighbours: every gather below is unconditional
-    // ---- stage this node's input rows; layers >= 1 finish the previous layer here (mix + bias + BN + ReLU).
-    //      thread = (column k, row parity): rows (tid >> 7) + 2 it.  All 6 x 8 gathers of a thread are independent loads from
-    //      clamped addresses (issued together: one L2 round trip instead of a chain of conditional ones); out-of-range rows are
-    //      zeroed at the LDS write
-    {
-        const int k = tid & 127;
-        float pb = 0.f, ps = 1.f, pn = 0.f;
-        if (a.h_prev) { pb = a.bias_prev[k]; ps = a.bns_prev[k]; pn = a.bnb_prev[k]; }
-        constexpr int NIT = PG_ROWS * 128 / 256;
-        float self[NIT], nb_v[NIT][5];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int bb = (tid >> 7) + 2 * it;
-            const long long b = b0 + min(bb, nb - 1);
-            if (!a.h_prev) self[it] = a.x_in[(b * NJ + j) * 128 + k];
-            else {
-                const float* hb = a.h_prev + b * NJ * 256;
-                self[it] = hb[j * 256 + k];
+            for (int kk = 0; kk < 4; ++kk) bw[t][kk] = *reinterpret_cast<const bf16x8_t*>(w + t * 16 * 128 + kk * 32);
+    } else {                        // fp32 [2][21][k][o] (the reference layout)
+        const float* w = a.W + ((long long)half * NJ + j) * 128 * 128 + ncol0 + li;
 #pragma unroll
-                for (int t = 0; t < 5; ++t) nb_v[it][t] = hb[nidx[t] * 256 + 128 + k];
-            }
-        }
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int bb = (tid >> 7) + 2 * it;
-            float v = self[it];
-            if (a.h_prev) {
-                float acc = 0.f;
-#pragma unroll
-                for (int t = 0; t < 5; ++t) acc = fmaf(wgt[t], nb_v[it][t], acc);  // padded terms add +0 (same sum as the deg-term chain)
-                v = v + acc + pb;                                               // output_0 + output_1 + bias
-                v = fmaf(v, ps, pn);                                            // BN1d (eval)
-                if (a.relu_prev) v = fmaxf(v, 0.f);
-            }
-            s_x[bb * PG_LD + k] = bb < nb ? v : 0.f;
-        }
+            for (int kk = 0; kk < 32; ++kk) bv[t][kk] = w[(4 * kk + lk) * 128 + t * 16];
     }
-    __syncthreads(); stamp();
-    const int n0 = slice * 64 + wave * 16, li = lane & 15, lk = lane >> 4;
-    f32x4 a0[PG_MT], a1[PG_MT];
+
+    // ---- adjacency row (LDS) and the per-channel epilogue constants of the previous layer
+    if (tid == 0) {
+        float wgt[5]; int nidx[5]; int deg = 0;
+        if (a.h_prev) edge_softmax_row(a.e1_prev, j, wgt, nidx, deg);
 #pragma unroll
-    for (int m = 0; m < PG_MT; ++m) a0[m] = a1[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.w_bf16) {
-        // bf16 throughput mode (torch.autocast semantics for the matmuls of SemGCN/p_graph_conv.py:47-48): W^T as bf16 [o][k], one
-        // 16-byte load per lane and k-step; the A operand is converted from the fp32 LDS rows; fp32 accumulation
-        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-        const unsigned short* w0 = reinterpret_cast<const unsigned short*>(a.W) + ((long long)j * 128 + n0 + li) * 128 + lk * 8;
-        const unsigned short* w1 = w0 + (long long)NJ * 128 * 128;
-        bf16x8_t b0[4], b1[4];
+        for (int t = 0; t < 5; ++t) { s_adj[t] = t < deg ? wgt[t] : 0.f; s_nidx[t] = t < deg ? nidx[t] : j; }   // padded: every gather is unconditional
+    }
+    const int bb = tid >> 5, cq = (tid & 31) * 4;          // mix role: sample bb of the chunk, channels cq .. cq+3
+    float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), ps = make_float4(1.f, 1.f, 1.f, 1.f), pn = pb;
+    if (a.h_prev) {
+        pb = *reinterpret_cast<const float4*>(a.bias_prev + cq);
+        ps = *reinterpret_cast<const float4*>(a.bns_prev + cq);
+        pn = *reinterpret_cast<const float4*>(a.bnb_prev + cq);
+    }
+    __syncthreads();
+    float wgt[5]; int nidx[5];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            b0[kk] = *reinterpret_cast<const bf16x8_t*>(w0 + kk * 32);
-            b1[kk] = *reinterpret_cast<const bf16x8_t*>(w1 + kk * 32);
+    for (int t = 0; t < 5; ++t) { wgt[t] = s_adj[t]; nidx[t] = s_nidx[t]; }
+
+    float4 self, nbv[5];
+    auto gather = [&](int chunk) {
+        const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
+        const long long b = b0 + min(bb, nb - 1);
+        if (!a.h_prev) self = *reinterpret_cast<const float4*>(a.x_in + (b * NJ + j) * 128 + cq);
+        else {
+            const float* hb = a.h_prev + b * NJ * 256;
+            self = *reinterpret_cast<const float4*>(hb + j * 256 + cq);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) nbv[t] = *reinterpret_cast<const float4*>(hb + nidx[t] * 256 + 128 + cq);
         }
+    };
+    auto mix1 = [&](float sv, float n0, float n1, float n2, float n3, float n4, float b_, float s_, float h_) -> float {
+        float acc = 0.f;
+        acc = fmaf(wgt[0], n0, acc); acc = fmaf(wgt[1], n1, acc); acc = fmaf(wgt[2], n2, acc);
+        acc = fmaf(wgt[3], n3, acc); acc = fmaf(wgt[4], n4, acc);           // padded terms add +0 (same sum as the deg-term chain)
+        float v = sv + acc + b_;                                            // output_0 + output_1 + bias
+        v = fmaf(v, s_, h_);                                                // BN1d (eval)
+        return a.relu_prev ? fmaxf(v, 0.f) : v;
+    };
+    auto mix_store = [&](int chunk, int buf) {
+        const int nb = min(PG_BC, args.B - chunk * PG_BC);
+        float4 v = self;
+        if (a.h_prev) {
+            v.x = mix1(self.x, nbv[0].x, nbv[1].x, nbv[2].x, nbv[3].x, nbv[4].x, pb.x, ps.x, pn.x);
+            v.y = mix1(self.y, nbv[0].y, nbv[1].y, nbv[2].y, nbv[3].y, nbv[4].y, pb.y, ps.y, pn.y);
+            v.z = mix1(self.z, nbv[0].z, nbv[1].z, nbv[2].z, nbv[3].z, nbv[4].z, pb.z, ps.z, pn.z);
+            v.w = mix1(self.w, nbv[0].w, nbv[1].w, nbv[2].w, nbv[3].w, nbv[4].w, pb.w, ps.w, pn.w);
+        }
+        if (bb >= nb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = s_x[buf] + bb * PG_LD + cq;                               // row pitch 130 floats: 8-byte aligned
+        *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+    };
+
+    int buf = 0;
+    if (c0 < args.nchunk) gather(c0);
+    stamp();
+    for (int chunk = c0; chunk < args.nchunk; chunk += args.npp, buf ^= 1) {
+        mix_store(chunk, buf);
+        __syncthreads();                       // the A tile of this chunk is complete (and the other buffer is free again)
+        if (chunk + args.npp < args.nchunk) gather(chunk + args.npp);
+        const float* sx = s_x[buf];
+        f32x4 acc[2];
+        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (WBF16) {
+            // bf16 throughput mode (torch.autocast semantics for the matmuls of SemGCN/p_graph_conv.py:47-48): the A operand is
+            // converted from the fp32 LDS rows; fp32 accumulation
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int m = 0; m < PG_MT; ++m) {
-                const float2* ap = reinterpret_cast<const float2*>(s_x + (m * 16 + li) * PG_LD + kk * 32 + lk * 8);
+            for (int kk = 0; kk < 4; ++kk) {
+                const float2* ap = reinterpret_cast<const float2*>(sx + li * PG_LD + kk * 32 + lk * 8);
                 bf16x8_t av;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -310,25 +357,29 @@ __global__ __launch_bounds__(256) void pgcn_layer_kernel(PgcnArgs args) {
                     av[2 * e] = (__bf16)t.x;
                     av[2 * e + 1] = (__bf16)t.y;
                 }
-                a0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b0[kk], a0[m], 0, 0, 0);
-                a1[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[kk], a1[m], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[0][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[1][kk], acc[1], 0, 0, 0);
             }
-    } else {
-        dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)j * 128) * 128, 128, n0, lane, a0);          // x W0[j]
-        dir::mfma_tile_f32<128, PG_MT>(s_x, PG_LD, a.W + ((long long)(NJ + j) * 128) * 128, 128, n0, lane, a1);   // x W1[j]
-    }
-    asm volatile("" :: "v"(a0[0]), "v"(a1[0])); stamp();
+        } else {
+            const float* ap = sx + li * PG_LD + lk;
 #pragma unroll
-    for (int m = 0; m < PG_MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int bb = m * 16 + lk * 4 + r;
-            if (bb < nb) {
-                float* hb = a.h_out + ((long long)(b0 + bb) * NJ + j) * 256;
-                hb[n0 + li] = a0[m][r];
-                hb[128 + n0 + li] = a1[m][r];
+            for (int kk = 0; kk < 32; ++kk) {
+                const float av = ap[4 * kk];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[0][kk], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[1][kk], acc[1], 0, 0, 0);
             }
         }
+        const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = lk * 4 + r;
+            if (row < nb) {
+                float* hb = a.h_out + ((long long)(b0 + row) * NJ + j) * 256 + half * 128 + ncol0 + li;
+                hb[0] = acc[0][r];
+                hb[16] = acc[1][r];
+            }
+        }
+    }
     stamp();
 }
 
@@ -336,25 +387,43 @@ struct MixHand {
     const float* h; const float* e1; const float* bias; const float* bns; const float* bnb;
     const float* add; float* out; int relu;
 };
-struct MixArgs { MixHand h[2]; long long out_bstride; };
-// finishes the last layer: out[b][j][:] = relu(bn(h0 + A1 h1 + bias)) (+ add).  grid (B, 21, hands)
-__global__ __launch_bounds__(128) void pgcn_mix_kernel(MixArgs args) {
-    const MixHand& a = args.h[blockIdx.z];
-    const int b = blockIdx.x, j = blockIdx.y, k = threadIdx.x;
+struct MixArgs { MixHand h[2]; long long out_bstride; int B; };
+// finishes the last layer: out[b][j][:] = relu(bn(h0 + A1 h1 + bias)) (+ add).  One thread per (sample, node, 4 channels): six
+// independent 16-byte gathers, one 16-byte store; grid (ceil(B * 21 * 32 / 256), hands)
+__global__ __launch_bounds__(256) void pgcn_mix_kernel(MixArgs args) {
+    const MixHand& a = args.h[blockIdx.y];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int cq = (g & 31) * 4, bj = g >> 5;
+    if (bj >= args.B * NJ) return;
+    const int b = bj / NJ, j = bj - b * NJ;
     float wgt[5]; int nidx[5]; int deg;
     edge_softmax_row(a.e1, j, wgt, nidx, deg);
     const float* hb = a.h + (long long)b * NJ * 256;
-    float nv[5];
+    float4 nv[5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) nv[t] = hb[(t < deg ? nidx[t] : j) * 256 + 128 + k];          // unconditional: all in flight together
-    float acc = 0.f;
+    for (int t = 0; t < 5; ++t) nv[t] = *reinterpret_cast<const float4*>(hb + (t < deg ? nidx[t] : j) * 256 + 128 + cq);   // unconditional
+    const float4 self = *reinterpret_cast<const float4*>(hb + j * 256 + cq);
+    const float4 bi = *reinterpret_cast<const float4*>(a.bias + cq), sc = *reinterpret_cast<const float4*>(a.bns + cq),
+                 sh = *reinterpret_cast<const float4*>(a.bnb + cq);
+    float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.add) ad = *reinterpret_cast<const float4*>(a.add + ((long long)b * NJ + j) * 128 + cq);
+    auto one = [&](float sv, float n0, float n1, float n2, float n3, float n4, float b_, float s_, float h_, float ad_) -> float {
+        float acc = 0.f;
+        const float n[5] = {n0, n1, n2, n3, n4};
 #pragma unroll
-    for (int t = 0; t < 5; ++t) acc = t < deg ? fmaf(wgt[t], nv[t], acc) : acc;
-    float v = hb[j * 256 + k] + acc + a.bias[k];
-    v = fmaf(v, a.bns[k], a.bnb[k]);
-    if (a.relu) v = fmaxf(v, 0.f);
-    if (a.add) v += a.add[((long long)b * NJ + j) * 128 + k];
-    a.out[(long long)b * args.out_bstride + j * 128 + k] = v;
+        for (int t = 0; t < 5; ++t) acc = t < deg ? fmaf(wgt[t], n[t], acc) : acc;
+        float v = sv + acc + b_;
+        v = fmaf(v, s_, h_);
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.add) v += ad_;
+        return v;
+    };
+    float4 o;
+    o.x = one(self.x, nv[0].x, nv[1].x, nv[2].x, nv[3].x, nv[4].x, bi.x, sc.x, sh.x, ad.x);
+    o.y = one(self.y, nv[0].y, nv[1].y, nv[2].y, nv[3].y, nv[4].y, bi.y, sc.y, sh.y, ad.y);
+    o.z = one(self.z, nv[0].z, nv[1].z, nv[2].z, nv[3].z, nv[4].z, bi.z, sc.z, sh.z, ad.z);
+    o.w = one(self.w, nv[0].w, nv[1].w, nv[2].w, nv[3].w, nv[4].w, bi.w, sc.w, sh.w, ad.w);
+    *reinterpret_cast<float4*>(a.out + (long long)b * args.out_bstride + j * 128 + cq) = o;
 }
 
 // --------------------------------------------------------------------------------------------- regressor
@@ -488,9 +557,11 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
                     hipStream_t s) {
     DIR_REQUIRE(num_layers >= 1 && B > 0 && out_bstride >= NJ * 128, "dir_pgcn_stack_forward: bad arguments");
     const int nchunk = (B + PG_BC - 1) / PG_BC;
+    bool wbf16 = false;
     for (int l = 0; l < num_layers; ++l) {
         PgcnArgs a;
         a.B = B; a.nchunk = nchunk;
+        a.npairs = NJ * nh; a.npp = nchunk < PG_MAXSPLIT ? nchunk : PG_MAXSPLIT;
         for (int h = 0; h < 2; ++h) {
             const int hh = h < nh ? h : 0;
             const dir_pgcn_layer& L = layers[hh][l];
@@ -503,20 +574,25 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
             g.bns_prev = l ? layers[hh][l - 1].bn_scale : nullptr; g.bnb_prev = l ? layers[hh][l - 1].bn_shift : nullptr;
             g.relu_prev = l ? layers[hh][l - 1].relu : 0;
             g.h_out = hbuf[l & 1];
+            if (h == 0) wbf16 = g.w_bf16 != 0;
+            DIR_REQUIRE((g.w_bf16 != 0) == wbf16, "dir_pgcn_stack_forward: both hands must use the same weight dtype");
         }
         a.stamps = dir::stamps_begin("pgcn");
-        DIR_LAUNCH(pgcn_layer_kernel, dim3(NJ, 2, nh * nchunk), dim3(256), 0, s, a);
+        const int per_xcd = (a.npairs + 7) / 8;                   // pairs xcd, xcd + 8, ... on XCD `xcd`
+        const dim3 grid(8 * per_xcd * a.npp);
+        if (wbf16) DIR_LAUNCH(pgcn_node_kernel<true>, grid, dim3(PG_T), 0, s, a);
+        else DIR_LAUNCH(pgcn_node_kernel<false>, grid, dim3(PG_T), 0, s, a);
         dir::stamps_end("pgcn", a.stamps, s);
     }
     MixArgs m;
-    m.out_bstride = out_bstride;
+    m.out_bstride = out_bstride; m.B = B;
     for (int h = 0; h < 2; ++h) {
         const int hh = h < nh ? h : 0;
         const dir_pgcn_layer& L = layers[hh][num_layers - 1];
         float* hb = scratch[hh] + (((num_layers - 1) & 1) ? (long long)B * NJ * 256 : 0);
         m.h[h] = MixHand{hb, L.e1, L.bias, L.bn_scale, L.bn_shift, add ? add[hh] : nullptr, out[hh], L.relu};
     }
-    DIR_LAUNCH(pgcn_mix_kernel, dim3(B, NJ, nh), dim3(128), 0, s, m);
+    DIR_LAUNCH(pgcn_mix_kernel, dim3((B * NJ * 32 + 255) / 256, nh), dim3(256), 0, s, m);
     return dir::check_launch("dir_pgcn_stack_forward");
 }
 

@@ -266,6 +266,72 @@ class BneckChainOp(object):
         return out, y1n
 
 
+def pack_tail_stream(w3, w1n):
+    """dir_bottleneck_tail_forward's weight stream (include/dir_hip.h): conv3.weight [4P, P] and the next conv1.weight [N2, 4P]
+    as bf16 MFMA A-operand fragments in the order the kernel's waves consume them, [4P/512][8][NBF + NCF][64 lanes][8]."""
+    w3 = w3.detach().float().reshape(w3.shape[0], -1)
+    w1n = w1n.detach().float().reshape(w1n.shape[0], -1)
+    C4, P = w3.shape
+    N2 = w1n.shape[0]
+    assert w1n.shape[1] == C4 and C4 == 4 * P and C4 % 512 == 0 and N2 in (128, 256)
+    dev = w3.device
+    lane = torch.arange(64, device=dev)
+    l32, h, l16, g16 = lane & 31, lane >> 5, lane & 15, lane >> 4
+    e = torch.arange(8, device=dev)
+    KBS = P // 16
+    out = []
+    for hf in range(C4 // 512):
+        for w in range(8):
+            for cb in range(2):
+                for ks in range(KBS):
+                    ch = hf * 512 + 64 * w + 32 * cb + l32
+                    k0 = 16 * ks + 8 * h
+                    out.append(w3[ch[:, None], k0[:, None] + e])
+            if N2 == 128:
+                for fc in range(16):
+                    out.append(w1n[(16 * w + l16)[:, None], (hf * 512 + 32 * fc + 8 * g16)[:, None] + e])
+            else:
+                for fc in range(32):
+                    out.append(w1n[(32 * w + l32)[:, None], (hf * 512 + 16 * fc + 8 * h)[:, None] + e])
+    return torch.stack(out).to(torch.bfloat16).contiguous()
+
+
+class BneckTailOp(object):
+    """dir_bottleneck_tail_forward: conv3 + bn3 + identity + ReLU of a layer2 / layer3 bottleneck and the next block's conv1 + bn1 +
+    ReLU in one launch (models/backbone/resnet.py:132-140,122-124): the block output is written once and not read back.  Built from
+    the blocks' ConvOps; carries the attributes autotune / export_tuning read from a conv op (single kernel: variant codes are no-ops)."""
+    GEOMETRIES = ((128, 128), (128, 256), (256, 256))
+
+    def __init__(self, c3, c1n):
+        self.c3, self.c1n = c3, c1n
+        self.cout, self.cin, self.kh, self.kw, self.stride = c3.cout, c3.cin, 1, 1, 1
+        self.variant = {}
+        self.stream = pack_tail_stream(c3.w.reshape(c3.cout, c3.cin), c1n.w.reshape(c1n.cout, c1n.cin))
+        self.params = _capi.BneckTailParams(_capi.ptr(self.stream), _capi.ptr(c3.scale), _capi.ptr(c3.shift), _capi.ptr(c1n.scale),
+                                            _capi.ptr(c1n.shift), c3.cin, c1n.cout)
+
+    @staticmethod
+    def applies(c3, c1n, dtype):
+        return (dtype == torch.bfloat16 and c3.kh == 1 and c3.stride == 1 and c3.scale is not None and c3.cout == 4 * c3.cin
+                and c1n.kh == 1 and c1n.stride == 1 and c1n.cin == c3.cout and c1n.scale is not None and c1n.pre_scale is None
+                and (c3.cin, c1n.cout) in BneckTailOp.GEOMETRIES)
+
+    def __call__(self, y2, x):
+        """y2: conv2's output [B,H,W,P]; x: the block input [B,H,W,4P] (identity residual) -> (block output, next y1)"""
+        B, H, W, P = y2.shape
+        M = B * H * W
+        out = torch.empty(B, H, W, self.c3.cout, device=y2.device, dtype=y2.dtype)
+        y1n = torch.empty(B, H, W, self.c1n.cout, device=y2.device, dtype=y2.dtype)
+        if _capi.PROFILE is not None:
+            c4, n2 = self.c3.cout, self.c1n.cout
+            _capi.annotate(family='conv', flops=2.0 * M * (P * c4 + c4 * n2), op=self, dtype='bf16',
+                           shape='M=%d tail 1x1(%d->%d)+res+1x1(->%d)' % (M, P, c4, n2),
+                           bytes=(M * (P + 2 * c4 + n2) + c4 * P + n2 * c4) * 2)
+        _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(self.params), _capi.ptr(y2), _capi.ptr(x), _capi.ptr(out), _capi.ptr(y1n),
+                                                            M, _capi.stream_ptr()), 'dir_bottleneck_tail_forward')
+        return out, y1n
+
+
 def stem_conv_op(w, scale, shift, dtype):
     """7x7/2 stem over 2x2 space-to-depth blocks (dir_stem_prep_s2d): a 4x4 stride-1 convolution whose K-slab is a block-row
     window of 4 blocks x 16 channels; w'[n][j*16 + (dy*2+dx)*4 + c][r] = w[n, c, 2r+dy-1, 2j+dx-1]   (w = conv1.weight [64,3,7,7])"""
@@ -295,6 +361,7 @@ class BackboneOp(object):
     fold_downsample = os.environ.get('DIR_FOLD_DOWNSAMPLE', '1') != '0'
     fused_stem = os.environ.get('DIR_FUSED_STEM', '1') != '0'       # bf16 mode: conv1 + bn1 + ReLU + maxpool in one launch
     bneck_chain = os.environ.get('DIR_BNECK_CHAIN', '1') != '0'     # bf16 mode, layer1: conv2 + conv3 (+ next conv1) in one launch
+    bneck_tail = os.environ.get('DIR_BNECK_TAIL', '1') != '0'       # bf16 mode, layer2 / layer3: conv3 + residual + next conv1 in one launch
 
     def __init__(self, sd, p, dtype, device):
         dt = self.dtype = dtype
@@ -338,6 +405,17 @@ class BackboneOp(object):
                 elif blk['ds'] is None and BneckChainOp.applies(blk['c2'], blk['c3'], nxt, dt):
                     blk['chain'] = BneckChainOp(blk['c2'], blk['c3'], nxt)
 
+        # layer2 / layer3 (HBM- / latency-bound 1x1 convs): identity blocks hand their output to the next block's conv1 on chip
+        if self.bneck_tail:
+            for li in (1, 2):
+                blocks = self.layers[li]
+                for i, blk in enumerate(blocks):
+                    if 'dual' in blk or blk['ds'] is not None or 'chain' in blk:
+                        continue
+                    nxt = blocks[i + 1]['c1'] if i + 1 < len(blocks) else self.layers[li + 1][0]['c1']
+                    if BneckTailOp.applies(blk['c3'], nxt, dt):
+                        blk['tail'] = BneckTailOp(blk['c3'], nxt)
+
     def __call__(self, img):
         L, dt, dev = _capi.lib(), self.dtype, self.device
         B = img.shape[0]
@@ -374,7 +452,9 @@ class BackboneOp(object):
                 if 'chain' in blk:
                     x, y1 = blk['chain'](y1 if y1 is not None else blk['c1'](x), x)
                     continue
-                if 'dual' in blk:                                    # conv3 + projection shortcut in one launch
+                if 'tail' in blk and (x.shape[0] * x.shape[1] * x.shape[2]) % 64 == 0:
+                    x, y1 = blk['tail'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x)
+                elif 'dual' in blk:                                  # conv3 + projection shortcut in one launch
                     x, y1 = blk['dual'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x), None
                 else:
                     idn = blk['ds'](x) if blk['ds'] is not None else x

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 12
+#define DIR_ABI_VERSION 13
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -387,6 +387,28 @@ typedef struct dir_bneck_chain_params {
 } dir_bneck_chain_params;
 int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
                                  void* y1_next, int B, int H, int W, void* stream);
+
+/* a1, layer2 / layer3 geometry (planes P = 128 | 256): the 1x1 TAIL of a bottleneck and the 1x1 HEAD of the next one in one launch
+ *   models/backbone/resnet.py:132-140   out = relu(bn3(conv3(y2)) + identity)            conv3: 1x1, P -> 4P
+ *   models/backbone/resnet.py:122-124   y1_next = relu(bn1'(conv1'(out)))                conv1': 1x1, 4P -> n_next
+ * bf16 NHWC: y2 [M][P], residual [M][4P] (the block input), out [M][4P], y1_next [M][n_next]; M = B*H*W pixels, a multiple of 64
+ * (1x1 convolutions: the image geometry does not matter).  The block output is written once and never read back.
+ * wstream: both weight matrices as bf16 MFMA A-operand fragments in the order the kernel's waves consume them (16 bytes per lane,
+ * 1 KB per fragment), [4P/512 halves][8 waves][NBF + NCF fragments][64 lanes][8 bf16]:
+ *   conv3 fragment f < NBF = P/8        channel block cb = f / (P/16), k-step ks = f % (P/16): lane l holds
+ *                                       w3[half*512 + 64*wave + 32*cb + (l & 31)][16*ks + 8*(l >> 5) .. +8]
+ *   conv1' fragment fc (n_next = 256)   NCF = 32: w1n[32*wave + (l & 31)][half*512 + 16*fc + 8*(l >> 5) .. +8]
+ *   conv1' fragment fc (n_next = 128)   NCF = 16: w1n[16*wave + (l & 15)][half*512 + 32*fc + 8*(l >> 4) .. +8]
+ * (dir_amd/engine.py::pack_tail_stream builds it).  scale / shift: the folded eval-mode BatchNorms, fp32. */
+typedef struct dir_bneck_tail_params {
+    const void* wstream;
+    const float* scale3; const float* shift3;      /* [4P]     */
+    const float* scale1n; const float* shift1n;    /* [n_next] */
+    int32_t planes;   /* P: 128 | 256 */
+    int32_t n_next;   /* 128 | 256 (P = 128), 256 (P = 256) */
+} dir_bneck_tail_params;
+int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const void* y2, const void* residual, void* out, void* y1_next,
+                                long long M, void* stream);
 
 /* a13 / 8f rank 2, forward half: the training objective, models/dir.py:542-594 (SmoothL1Loss models/loss.py:63-93, EdgeLengthLoss
  * :36-60, NormalVectorLoss :6-33, nn.CrossEntropyLoss(weight), lovasz_softmax models/lovasz_loss.py:155-202).  Forward values

@@ -31,7 +31,8 @@ def dir_state():
 
 
 # bf16 mode, feature-map slices vs the reference (G7), relative to the slice's maximum: 2x the values measured on MI355X
-BF16_SLICE_BOUND = {'c1': 6e-2, 'c2': 6e-2, 'c3': 6e-2, 'c4': 6e-2, 'fusion4': 6e-2, 'enh3': 6e-2, 'final': 6e-2, 'seg': 0.1}
+# (measured: c1 7.9e-3, c2 1.17e-2, c3 2.81e-2, c4 3.25e-2, fusion4 8.9e-3, enh3 1.16e-2, final 1.37e-2, seg 2.5e-2)
+BF16_SLICE_BOUND = {'c1': 1.6e-2, 'c2': 2.4e-2, 'c3': 5.7e-2, 'c4': 6.5e-2, 'fusion4': 1.8e-2, 'enh3': 2.4e-2, 'final': 2.8e-2, 'seg': 5e-2}
 
 
 def nchw(t):
