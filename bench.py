@@ -226,7 +226,7 @@ def main():
     #      reads).  Reported beside the headline, never as `value`.
     no_pf = None
     if rank == 0 and world == 1 and pipe is not None and not args.no_proj_feat_variant:
-        pipe2 = E.ForwardPipeline(eng, pipe.imgs, want_proj_feat=False)
+        pipe2 = E.ForwardPipeline(eng, pipe.imgs, want_proj_feat=False, streams=pipe.streams)      # same hardware queues as the headline pipeline
         c2 = [0]
 
         def step2():

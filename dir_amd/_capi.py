@@ -100,7 +100,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 13          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 14          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -133,6 +133,7 @@ _SIGNATURES = {
     'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_bone_proj_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _i, _p]),
     'dir_conv2d_dual_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p]),
+    'dir_conv1x1_stream_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_conv2d_sparse_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),
                                           C.POINTER(TokenMlp), C.POINTER(TokenMlp), _p, _p, _i, _p]),

@@ -51,6 +51,27 @@ def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
     return scale.float().contiguous(), shift.float().contiguous()
 
 
+STREAM_VARIANT = 21      # DIR_CONV_VARIANT code: dir_conv1x1_stream_forward (1x1, bf16, Cout % 128 == 0), chosen per layer by autotune
+
+
+def pack_stream_weights(w_nk):
+    """dir_conv1x1_stream_forward's weight stream (include/dir_hip.h) from W [Cout, K] (K = Cin, or Cin + Cin2 for two sources):
+    bf16 [Cout/NWG][4 waves][K/64][4 k-steps][NCB][64 lanes][8]."""
+    w = w_nk.detach().float()
+    N, K = w.shape
+    assert N % 128 == 0 and K % 64 == 0
+    ncb = 2 if N % 256 == 0 else 1
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    l32, h = lane & 31, lane >> 5
+    e = torch.arange(8, device=dev)
+    g, wv, c, ks, cb = torch.meshgrid(torch.arange(N // (128 * ncb), device=dev), torch.arange(4, device=dev), torch.arange(K // 64, device=dev),
+                                      torch.arange(4, device=dev), torch.arange(ncb, device=dev), indexing='ij')
+    row = (g * (128 * ncb) + (wv * ncb + cb) * 32)[..., None] + l32                    # [G,4,nk,4,ncb,64]
+    k0 = (64 * c + 16 * ks)[..., None] + 8 * h
+    return w[row[..., None], k0[..., None] + e].to(torch.bfloat16).contiguous()
+
+
 class ConvOp(object):
     """one dir_conv2d_forward call with packed parameters"""
     def __init__(self, w_oihw, dtype, stride=1, pad=0, scale=None, shift=None, relu=False, pre=None, pre_relu=False,
@@ -67,6 +88,11 @@ class ConvOp(object):
         self.in_cs_override = None
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
         self.variant = {}                                  # batch size -> DIR_CONV_VARIANT code chosen by DirEngine.autotune
+        # streaming alternative for the HBM-bound 1x1 layers (dir_conv1x1_stream_forward), taken when autotune prefers it
+        self.w_stream = None
+        if (dtype == torch.bfloat16 and self.out_dtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and stride == 1 and pad == 0
+                and self.cin % 64 == 0 and self.cout % 128 == 0 and self.cin <= 2304):
+            self.w_stream = pack_stream_weights(self.w.reshape(self.cout, self.cin))
 
     def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None):
         B, H, W, cbuf = x.shape
@@ -86,6 +112,12 @@ class ConvOp(object):
                            dtype='f32' if self.dtype == F32 else 'bf16',
                            shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
                                                               self.kw, self.stride))
+        if v == STREAM_VARIANT and self.w_stream is not None and residual is None and bbox is None and out.dtype == torch.bfloat16:
+            d.flags &= 0xff
+            _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(x), None, None, _capi.ptr(self.w_stream), _capi.ptr(self.scale),
+                                                               _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
+                                                               _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
+            return out
         if bbox is not None:
             rc = _capi.lib().dir_conv2d_sparse_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
                                                        _capi.ptr(self.shift), _capi.ptr(residual), _capi.ptr(out),
@@ -113,6 +145,9 @@ class DualConvOp(object):
         self.kh = self.kw = self.stride = 1
         self.pre_scale = None
         self.variant = {}
+        self.w_stream = None
+        if dtype == torch.bfloat16 and self.cin % 64 == 0 and self.cin2 % 64 == 0 and self.cout % 128 == 0:
+            self.w_stream = pack_stream_weights(self.w)
 
     def __call__(self, y, x, out=None, out_coff=0):
         B, H, W, cbuf = y.shape
@@ -129,6 +164,11 @@ class DualConvOp(object):
                            bytes=(m * self.cin + m * self.cin2 + self.w.numel() + m * self.cout) * es,
                            dtype='f32' if self.dtype == F32 else 'bf16',
                            shape='M=%d N=%d K=%d+%d dual s%d' % (m, self.cout, self.cin, self.cin2, self.stride2))
+        if v == STREAM_VARIANT and self.w_stream is not None:
+            d.flags &= 0xff
+            _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w_stream), None, _capi.ptr(self.shift),
+                                                               None, None, _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
+            return out
         _capi.check(_capi.lib().dir_conv2d_dual_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.shift),
                                                         _capi.ptr(out), _capi.stream_ptr()), 'dir_conv2d_dual_forward')
         return out
@@ -751,7 +791,7 @@ class DirEngine(object):
 
     # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic.  (Code 19, the
     # 64x128 tile on the 3-buffer ring, is not offered: see conv.hip, DIR_RING_64x128.)
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14)
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14, STREAM_VARIANT)
 
     def _profiled_forwards(self, img, n):
         """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""
@@ -939,13 +979,16 @@ class ForwardPipeline(object):
 
     Results are bit-identical to `eng.forward(img)`: the same kernels on the same inputs, only scheduled side by side."""
 
-    def __init__(self, eng, imgs, want_proj_feat=True):
-        assert len(imgs) >= 1
+    def __init__(self, eng, imgs, want_proj_feat=True, streams=None):
+        """streams: optional list of torch streams to run the slots on (one per slot).  HIP multiplexes streams onto a handful of
+        hardware queues; two slots whose streams share a queue do not overlap at all, so a second pipeline on the same engine
+        should re-use the first one's streams (bench.py's proj_feat-less variant does)."""
+        assert len(imgs) >= 1 and (streams is None or len(streams) == len(imgs))
         self.eng, self.imgs = eng, list(imgs)
         self.streams, self.graphs, self.outs, self.done = [], [], [], []
         cur = torch.cuda.current_stream()
-        for img in self.imgs:
-            s = torch.cuda.Stream(device=eng.device)
+        for i, img in enumerate(self.imgs):
+            s = streams[i] if streams is not None else torch.cuda.Stream(device=eng.device)
             s.wait_stream(cur)
             with torch.cuda.stream(s):
                 eng.forward(img, want_proj_feat)          # eager once on this stream: allocator warm-up before the capture

@@ -116,3 +116,27 @@ def bottleneck_tail(y2, w3, s3, h3, residual, w1n, s1n, h1n):
     _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(p), _capi.ptr(y2.contiguous()), _capi.ptr(residual.contiguous()), _capi.ptr(out),
                                                         _capi.ptr(y1n), B * H * W, _capi.stream_ptr()), 'dir_bottleneck_tail_forward')
     return out, y1n
+
+
+def conv1x1_stream(x, w_nk, scale=None, shift=None, relu=False, pre_scale=None, pre_shift=None, pre_relu=False, x2=None, stride2=1,
+                   out=None, out_coff=0, in_coff=0, cin=None):
+    """dir_conv1x1_stream_forward: y = act(scale * (x[..., in_coff:in_coff+cin] . W1^T + x2[::stride2, ::stride2] . W2^T) + shift), bf16 NHWC.
+    w_nk: fp32/bf16 [Cout, cin (+ Cin2)] (second source's columns appended)"""
+    from .engine import pack_stream_weights
+    _capi.require_cuda(x, x2, out)
+    B, H, W, cbuf = x.shape
+    Cout, K = w_nk.shape
+    cin2 = x2.shape[3] if x2 is not None else 0
+    cin = cin if cin is not None else K - cin2
+    assert cin + cin2 == K
+    ws = pack_stream_weights(w_nk)
+    if out is None:
+        out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.bfloat16)
+    d = ConvDesc(B, H, W, cin, cbuf, in_coff, Cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, DT_BF16, DT_BF16,
+                 (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0))
+    d2 = _capi.ConvSrc2(x2.shape[1], x2.shape[2], cin2, x2.shape[3], 0, stride2) if x2 is not None else None
+    keep = [None if t is None else _capi.f32c(t) for t in (scale, shift, pre_scale, pre_shift)]
+    _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(x), d2, _capi.ptr(x2), _capi.ptr(ws), _capi.ptr(keep[0]), _capi.ptr(keep[1]),
+                                                       _capi.ptr(keep[2]), _capi.ptr(keep[3]), _capi.ptr(out), _capi.stream_ptr()),
+                'dir_conv1x1_stream_forward')
+    return out

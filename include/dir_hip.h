@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 13
+#define DIR_ABI_VERSION 14
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -145,6 +145,21 @@ typedef struct dir_conv_src2 {
 } dir_conv_src2;
 int dir_conv2d_dual_forward(const dir_conv_desc* desc, const void* x, const dir_conv_src2* src2, const void* x2, const void* w,
                             const float* shift, void* y, void* stream);
+
+/* The HBM-bound 1x1 convolutions (bf16 in / out, stride 1) as a streaming kernel: small synchronous workgroups (128 pixels x
+ * 128 | 256 output channels), several per CU, activations global -> registers -> LDS two K-chunks ahead, weights straight
+ * into MFMA operand registers from a stream packed in consumption order.  Same mathematics as dir_conv2d_forward /
+ * dir_conv2d_dual_forward for kh = kw = 1 (models/backbone/hourglass.py:55-70 conv1 with its pre-activation and conv3 + skip_layer;
+ * models/backbone/resnet.py:117-140 conv1 / conv3 + projection shortcut): y = act(scale * (x . W1^T + x2 . W2^T) + shift), with
+ * the optional pre-activation relu(x * pre_scale + pre_shift) on the FIRST source only.  No residual input.
+ * desc: kh = kw = stride = 1, pad = 0, Cin % 64 == 0, Cout % 128 == 0, bf16; src2 / x2 optional (1x1, stride src2->stride).
+ * w_stream: bf16 [Cout / NWG][4 waves][K / 64 chunks][4 k-steps][NCB][64 lanes][8] with NWG = 256, NCB = 2 when Cout % 256 == 0,
+ * else NWG = 128, NCB = 1; lane l of fragment (chunk c, k-step ks, block cb) of wave w in N-chunk g holds
+ *   W[g*NWG + (w*NCB + cb)*32 + (l & 31)][64*c + 16*ks + 8*(l >> 5) .. +8],   W = [W1 | W2] along K
+ * (dir_amd/engine.py::pack_stream_weights). */
+int dir_conv1x1_stream_forward(const dir_conv_desc* desc, const void* x, const dir_conv_src2* src2, const void* x2,
+                               const void* w_stream, const float* scale, const float* shift, const float* pre_scale,
+                               const float* pre_shift, void* y, void* stream);
 
 /* a11 with a10's sparsity: same as dir_conv2d_forward (no prologue), plus group_bbox int32 [B][Cin/64][4] = for every
  * image and every 64-channel input group the pixel box (ymin,ymax,xmin,xmax) outside which that group is exactly zero.

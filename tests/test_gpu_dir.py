@@ -191,7 +191,7 @@ def test_autotuned_engine_is_bit_identical(dir_state):
     img = torch.randn(4, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(5))
     before = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()} for o in eng.forward(img)]
     chosen = eng.autotune(img, reps=1)
-    assert len(chosen) > 60 and set(chosen.values()) <= set(eng.CONV_VARIANTS)
+    assert len(chosen) > 50 and set(chosen.values()) <= set(eng.CONV_VARIANTS)      # every conv-family op of one forward
     after = eng.forward(img)
     for o0, o1 in zip(before, after):
         for k, v in o0.items():

@@ -1,6 +1,8 @@
 """GPU parity (a1, layer2 / layer3 bottlenecks): dir_bottleneck_tail_forward -- conv3 1x1 + bn3 + identity + ReLU of block i and
 conv1 1x1 + bn1 + ReLU of block i+1 in one launch (models/backbone/resnet.py:122-124,132-140) -- vs the numpy oracle with the same
-bf16 rounding points, and vs the unfused dir_conv2d_forward pair it replaces (bit for bit: same MFMA k order, same epilogue)."""
+bf16 rounding points, and vs the unfused dir_conv2d_forward pair it replaces (same rounding points; the GEMMs are computed
+transposed, D[channel][pixel], so the fp32 sums may differ in the last bit and an output that sits on a bf16 rounding boundary by
+one bf16 ulp)."""
 import numpy as np
 import pytest
 import torch
@@ -73,7 +75,7 @@ def test_tail_matches_oracle(geom, shape):
 
 
 @pytest.mark.parametrize('geom', GEOM)
-def test_tail_equals_the_unfused_pair_bit_for_bit(geom):
+def test_tail_vs_the_unfused_pair_full_size(geom):
     """full-size: B = 64 at the layer's resolution (65 536 / 16 384 pixels: 4 / 1 tiles per workgroup on 256 CUs)"""
     P, N2 = geom
     B, H, W = (64, 32, 32) if P == 128 else (64, 16, 16)
@@ -83,8 +85,11 @@ def test_tail_equals_the_unfused_pair_bit_for_bit(geom):
     o = F.conv2d_nhwc(y2, F.pack_conv_weight(dev(p['w3']), BF), 1, 0, dev(p['s3']), dev(p['h3']), relu=True, residual=res)
     n1 = F.conv2d_nhwc(o, F.pack_conv_weight(dev(p['w1']), BF), 1, 0, dev(p['s1']), dev(p['h1']), relu=True)
     torch.cuda.synchronize()
-    assert torch.equal(out, o)
-    assert torch.equal(y1n, n1)
+    d = (out.float() - o.float()).abs()
+    print('tail vs unfused: %.4f %% of the block outputs differ, max %.3e' % (100 * float((d > 0).float().mean()), float(d.max())))
+    assert float(d.max()) <= float(o.float().abs().max()) * 2.0 ** -6     # at most a bf16 ulp of the output scale
+    assert float((d > 0).float().mean()) < 0.02
+    assert relerr(y1n.float().cpu().numpy(), n1.float().cpu().numpy()) < 1e-2
     # and a second launch on the same inputs reproduces itself (persistent workgroups, DMA double buffer, register ring)
     out2, y1n2 = run_fused(p)
     assert torch.equal(out, out2) and torch.equal(y1n, y1n2)
