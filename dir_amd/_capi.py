@@ -38,7 +38,7 @@ class BneckChainParams(C.Structure):
 
 
 class BneckTailParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('wstream', 'scale3', 'shift3', 'scale1n', 'shift1n')] + [('planes', C.c_int32), ('n_next', C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ('wstream', 'scale3', 'shift3', 'scale1n', 'shift1n')] + [('planes', C.c_int32), ('n_next', C.c_int32), ('waves', C.c_int32)]
 
 
 class TokenMlp(C.Structure):
@@ -100,7 +100,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 14          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 15          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 

@@ -33,6 +33,25 @@ using convk::pack2bf;
 using convk::relu2bf;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// The activations are touched once per launch; the weight stream is re-read by every workgroup.  DIR_TAIL_NT (compile-time A/B
+// switch) marks the residual loads and block-output stores non-temporal so that they do not push the weights out of L2.
+// MEASURED AND REJECTED (r02): 46.6 -> 71.0 us at layer2, 34.7 -> 44.6 us at layer3 -- the tensors a layer reads were written by the
+// previous launch and sit in the 256 MB Infinity Cache; a non-temporal access gives that up.  Off.
+#ifndef DIR_TAIL_NT
+#define DIR_TAIL_NT 0
+#endif
+#if DIR_TAIL_NT
+typedef unsigned __attribute__((ext_vector_type(2))) u32x2_t;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4_t;
+__device__ __forceinline__ uint2 nt_load2(const uint2* p) { const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p)); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void nt_store4(uint4 v, uint4* p) { __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(p)); }
+#define NT_LOAD(p) nt_load2(p)
+#define NT_STORE(v, p) nt_store4(v, p)
+#else
+#define NT_LOAD(p) (*(p))
+#define NT_STORE(v, p) (*(p) = (v))
+#endif
+
 constexpr int TM = 64;                 // pixels per tile
 constexpr int HC = 512;                // channels per half of the block output
 constexpr int NTHR = 512;
@@ -99,7 +118,7 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xr[cb][pb][q] = *reinterpret_cast<const uint2*>(rp + 32 * cb + 8 * q);
+                for (int q = 0; q < 4; ++q) xr[cb][pb][q] = NT_LOAD(reinterpret_cast<const uint2*>(rp + 32 * cb + 8 * q));
         }
     };
     // ---- weight stream of this wave: fragment f of half hf at wstream[((hf * 8 + wave) * NF + f) * 64 + lane]
@@ -219,8 +238,8 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
 #pragma unroll
                                       for (int i = 0; i < TM * (HC / 8) / NTHR; ++i) {
                                           const int c = tid + NTHR * i;
-                                          *reinterpret_cast<uint4*>(a.out + ((long long)t * TM + (c >> 6)) * C4 + hf * HC + (c & 63) * 8) =
-                                              *reinterpret_cast<const uint4*>(s_t + (c >> 6) * TPITCH + (c & 63) * 16);
+                                          NT_STORE(*reinterpret_cast<const uint4*>(s_t + (c >> 6) * TPITCH + (c & 63) * 16),
+                                                   reinterpret_cast<uint4*>(a.out + ((long long)t * TM + (c >> 6)) * C4 + hf * HC + (c & 63) * 8));
                                           if (i & 1) __builtin_amdgcn_sched_barrier(0);
                                       }
                                   }
@@ -280,6 +299,187 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Thin variant (layer3 geometry at moderate batch: M = 16 384 pixels = one 64-pixel tile per CU, so the persistent fat workgroup
+// above has nothing to overlap its own latencies with): 4 waves, 32-pixel tiles, <= 76 KB of LDS -- TWO workgroups per CU, each
+// in a different phase.  Same phases and arithmetic; a wave owns 128 conv3 channels per half (4 blocks, one accumulator live at a
+// time) and N2 / 4 channels of the next conv1 on v_mfma_f32_32x32x16_bf16.  The weight stream is packed for 4 waves
+// (dir_amd/engine.py::pack_tail_stream(..., waves=4)).
+constexpr int TTM = 32, TTHR = 256;
+
+template <int P, int N2>
+__global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
+    constexpr int C4 = 4 * P, NH = C4 / HC;
+    constexpr int YROW = P * 2;
+    constexpr int GRP = 8;
+    constexpr int KBS = P / 16;
+    constexpr int NBF = 4 * KBS;                        // (channel block of 32, k-step), channel-block-major
+    constexpr int NCC = N2 / 128;                       // 32-channel blocks of the next conv1 per wave
+    constexpr int NCF = 32 * NCC;                       // (k-step, channel block), k-step-major
+    constexpr int NF = NBF + NCF, NG = NF / GRP;
+    static_assert(NF % GRP == 0 && NG % 2 == 0 && C4 % HC == 0 && (N2 == 128 || N2 == 256), "tail_thin_kernel: unsupported geometry");
+    constexpr int YCH = TTM * (P / 8) / TTHR;           // 1 KB LDS-DMA pieces per wave (2 | 4)
+    __shared__ __attribute__((aligned(16))) char s_t[TTM * TPITCH];
+    __shared__ __attribute__((aligned(16))) char s_y2[2][TTM * YROW];
+    __shared__ __attribute__((aligned(16))) float s_ss[2 * C4 + 2 * N2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+
+    for (int i = tid; i < C4; i += TTHR) { s_ss[i] = a.sc3[i]; s_ss[C4 + i] = a.sh3[i]; }
+    for (int i = tid; i < N2; i += TTHR) { s_ss[2 * C4 + i] = a.sc1n[i]; s_ss[2 * C4 + N2 + i] = a.sh1n[i]; }
+
+    const int tstep = gridDim.x;
+    int t = blockIdx.x;
+    if (t >= a.ntiles) return;
+
+    const convk::i32x4 yd = {(int)(unsigned)(unsigned long long)a.y2, (int)(unsigned)((unsigned long long)a.y2 >> 32), (int)a.y2_bytes, 0x00020000};
+    const unsigned y2_lds = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)&s_y2[0][0];
+    auto y2_dma = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < YCH; ++i) {
+            const int slot = (4 * i + wave) * 64 + lane, px = slot / (P / 8), pos = slot % (P / 8);
+            const unsigned voff = (unsigned)(((long long)tile * TTM + px) * YROW) + (unsigned)((pos ^ (px & 15)) * 16);
+            convk::lds_dma16_m0(yd, y2_lds + buf * (TTM * YROW) + (4 * i + wave) * 1024, voff, 0);
+        }
+    };
+    // residual of a unit: pixel l32, channels half*512 + 128 wave + 32 cb + 8 q + 4 h .. +4
+    uint2 xr[4][4];
+    auto res_fetch = [&](int tile, int half) {
+        const bf16_t* rp = a.res + ((long long)tile * TTM + l32) * C4 + half * HC + 128 * wave + 4 * h;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[cb][q] = NT_LOAD(reinterpret_cast<const uint2*>(rp + 32 * cb + 8 * q));
+    };
+    bf16x8 ring[2][GRP];
+    auto ring_load = [&](auto Slot, int hf, int grp) {
+        constexpr int slot = decltype(Slot)::value;
+        const uint4* p = a.wstream + ((long long)(hf * 4 + wave) * NF + grp * GRP) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < GRP; ++i) ring[slot][i] = __builtin_bit_cast(bf16x8, p[i * 64]);
+    };
+
+    y2_dma(t, 0);
+    ring_load(std::integral_constant<int, 0>{}, 0, 0);
+    res_fetch(t, 0);
+    convk::wait_vmcnt<0>();
+    __syncthreads();
+    int ybuf = 0;
+
+    f32x16 accb;
+    f32x16 accc[NCC];
+    bf16x8 bop[2];
+    const char* ycur = s_y2[0];
+    auto act_read = [&](auto F, auto Set) {
+        constexpr int f = decltype(F)::value, set = decltype(Set)::value;
+        if constexpr (f < NBF) {
+            constexpr int ks = f % KBS;
+            bop[set] = *reinterpret_cast<const bf16x8*>(ycur + l32 * YROW + (((2 * ks + h) ^ (l32 & 15)) << 4));
+        } else {
+            constexpr int ks = (f - NBF) / NCC;
+            bop[set] = *reinterpret_cast<const bf16x8*>(s_t + l32 * TPITCH + 32 * ks + 16 * h);
+        }
+    };
+
+    for (; t < a.ntiles; t += tstep) {
+        const bool more = t + tstep < a.ntiles;
+        if (more) y2_dma(t + tstep, ybuf ^ 1);
+        ycur = s_y2[ybuf];
+#pragma nounroll
+        for (int hf = 0; hf < NH; ++hf) {
+            const bool last_half = hf == NH - 1;
+            if (hf == 0) {
+#pragma unroll
+                for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accc[cc][r] = 0.f;
+            }
+            act_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            [&]<int... G>(std::integer_sequence<int, G...>) {
+                (([&] {
+                     constexpr int grp = G, slot = G & 1;
+                     if constexpr (grp + 1 < NG) ring_load(std::integral_constant<int, slot ^ 1>{}, hf, grp + 1);
+                     else ring_load(std::integral_constant<int, slot ^ 1>{}, last_half ? 0 : hf + 1, 0);
+                     [&]<int... I>(std::integer_sequence<int, I...>) {
+                         (([&] {
+                              constexpr int f = grp * GRP + I;
+                              // operand of the next step, unless it is the same LDS vector (phase C: NCC fragments share a k-step) or
+                              // would cross the phase boundary (T does not exist yet) / the unit
+                              constexpr bool same_next = f >= NBF && f + 1 < NF && (f - NBF) / NCC == (f + 1 - NBF) / NCC;
+                              constexpr int set = f < NBF ? (f & 1) : ((((f - NBF) / NCC) + NBF) & 1);
+                              if constexpr (f + 1 < NF && f + 1 != NBF && !same_next)
+                                  act_read(std::integral_constant<int, f + 1>{}, std::integral_constant<int, set ^ 1>{});
+                              if constexpr (f < NBF) {
+                                  constexpr int cb = f / KBS, ks = f - cb * KBS;
+                                  if constexpr (ks == 0) {
+#pragma unroll
+                                      for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+                                  }
+                                  accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set], accb, 0, 0, 0);
+                                  if constexpr (ks == KBS - 1) {
+#pragma unroll
+                                      for (int q = 0; q < 4; ++q) {
+                                          const int cl = 128 * wave + 32 * cb + 8 * q + 4 * h;
+                                          const float4 sc = *reinterpret_cast<const float4*>(s_ss + hf * HC + cl);
+                                          const float4 sh = *reinterpret_cast<const float4*>(s_ss + C4 + hf * HC + cl);
+                                          float v[4] = {fmaf(accb[4 * q], sc.x, sh.x), fmaf(accb[4 * q + 1], sc.y, sh.y),
+                                                        fmaf(accb[4 * q + 2], sc.z, sh.z), fmaf(accb[4 * q + 3], sc.w, sh.w)};
+                                          float rv[4];
+                                          unpack4(xr[cb][q], rv);
+#pragma unroll
+                                          for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                                          uint2 o;
+                                          o.x = relu2bf(pack2bf(v[0], v[1]));
+                                          o.y = relu2bf(pack2bf(v[2], v[3]));
+                                          *reinterpret_cast<uint2*>(s_t + l32 * TPITCH + cl * 2) = o;
+                                      }
+                                  }
+                                  if constexpr (f == NBF - 1) {
+                                      __syncthreads();
+                                      act_read(std::integral_constant<int, NBF>{}, std::integral_constant<int, (NBF & 1)>{});
+                                      if (!last_half) res_fetch(t, hf + 1);
+                                      else if (more) res_fetch(t + tstep, 0);
+#pragma unroll
+                                      for (int i = 0; i < TTM * (HC / 8) / TTHR; ++i) {
+                                          const int c = tid + TTHR * i;
+                                          NT_STORE(*reinterpret_cast<const uint4*>(s_t + (c >> 6) * TPITCH + (c & 63) * 16),
+                                                   reinterpret_cast<uint4*>(a.out + ((long long)t * TTM + (c >> 6)) * C4 + hf * HC + (c & 63) * 8));
+                                          if (i & 1) __builtin_amdgcn_sched_barrier(0);
+                                      }
+                                  }
+                              } else {
+                                  constexpr int cc = (f - NBF) % NCC;
+                                  accc[cc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set], accc[cc], 0, 0, 0);
+                              }
+                              if constexpr (f == NF - 1) convk::wait_vmcnt<GRP>();
+                              __builtin_amdgcn_sched_barrier(0);
+                          }()),
+                          ...);
+                     }(std::make_integer_sequence<int, GRP>{});
+                 }()),
+                 ...);
+            }(std::make_integer_sequence<int, NG>{});
+            if (last_half) {
+#pragma unroll
+                for (int cc = 0; cc < NCC; ++cc)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c0 = (N2 / 4) * wave + 32 * cc + 8 * q + 4 * h;
+                        const float4 sc = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + c0);
+                        const float4 sh = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + N2 + c0);
+                        uint2 o;
+                        o.x = relu2bf(pack2bf(fmaf(accc[cc][4 * q], sc.x, sh.x), fmaf(accc[cc][4 * q + 1], sc.y, sh.y)));
+                        o.y = relu2bf(pack2bf(fmaf(accc[cc][4 * q + 2], sc.z, sh.z), fmaf(accc[cc][4 * q + 3], sc.w, sh.w)));
+                        *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TTM + l32) * N2 + c0) = o;
+                    }
+            }
+            __syncthreads();
+        }
+        ybuf ^= 1;
+    }
+}
+
 }  // namespace
 }  // namespace dir
 
@@ -289,6 +489,7 @@ extern "C" int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const
     DIR_REQUIRE(p && y2 && residual && out && y1_next, "dir_bottleneck_tail_forward: null pointer");
     DIR_REQUIRE(p->wstream && p->scale3 && p->shift3 && p->scale1n && p->shift1n, "dir_bottleneck_tail_forward: missing parameters");
     DIR_REQUIRE(M > 0 && M % TM == 0 && M / TM < (1ll << 31), "dir_bottleneck_tail_forward: M must be a positive multiple of 64");
+    DIR_REQUIRE(p->waves == 8 || p->waves == 4, "dir_bottleneck_tail_forward: the stream must be packed for 8 or 4 waves");
     TailArgs a;
     a.y2 = (const convk::bf16_t*)y2; a.res = (const convk::bf16_t*)residual; a.out = (convk::bf16_t*)out; a.y1n = (convk::bf16_t*)y1_next;
     a.wstream = (const uint4*)p->wstream; a.sc3 = p->scale3; a.sh3 = p->shift3; a.sc1n = p->scale1n; a.sh1n = p->shift1n;
@@ -300,8 +501,19 @@ extern "C" int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const
         int dev = 0; hipDeviceProp_t pr;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
     }
-    const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
     hipStream_t s = (hipStream_t)stream;
+    if (p->waves == 4) {               // thin variant: 32-pixel tiles, two workgroups per CU
+        a.ntiles = (int)(M / TTM);
+        const int grid4 = a.ntiles < 2 * num_cu ? a.ntiles : 2 * num_cu;
+#define DIR_TAIL4(P_, N2_) DIR_LAUNCH((tail_thin_kernel<P_, N2_>), dim3(grid4), dim3(TTHR), 0, s, a)
+        if (p->planes == 128 && p->n_next == 128) DIR_TAIL4(128, 128);
+        else if (p->planes == 128 && p->n_next == 256) DIR_TAIL4(128, 256);
+        else if (p->planes == 256 && p->n_next == 256) DIR_TAIL4(256, 256);
+        else DIR_REQUIRE(false, "dir_bottleneck_tail_forward: (planes, n_next) must be (128,128), (128,256) or (256,256)");
+#undef DIR_TAIL4
+        return check_launch("dir_bottleneck_tail_forward");
+    }
+    const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
 #define DIR_TAIL(P_, N2_) DIR_LAUNCH((tail_chain_kernel<P_, N2_>), dim3(grid), dim3(NTHR), 0, s, a)
     if (p->planes == 128 && p->n_next == 128) DIR_TAIL(128, 128);
     else if (p->planes == 128 && p->n_next == 256) DIR_TAIL(128, 256);

@@ -306,9 +306,10 @@ class BneckChainOp(object):
         return out, y1n
 
 
-def pack_tail_stream(w3, w1n):
+def pack_tail_stream(w3, w1n, waves=8):
     """dir_bottleneck_tail_forward's weight stream (include/dir_hip.h): conv3.weight [4P, P] and the next conv1.weight [N2, 4P]
-    as bf16 MFMA A-operand fragments in the order the kernel's waves consume them, [4P/512][8][NBF + NCF][64 lanes][8]."""
+    as bf16 MFMA A-operand fragments in the order the kernel's waves consume them, [4P/512][waves][NBF + NCF][64 lanes][8]
+    (waves = 8: 64-pixel tiles, one workgroup per CU; waves = 4: the thin variant, 32-pixel tiles, two workgroups per CU)."""
     w3 = w3.detach().float().reshape(w3.shape[0], -1)
     w1n = w1n.detach().float().reshape(w1n.shape[0], -1)
     C4, P = w3.shape
@@ -320,6 +321,17 @@ def pack_tail_stream(w3, w1n):
     e = torch.arange(8, device=dev)
     KBS = P // 16
     out = []
+    if waves == 4:
+        ncc = N2 // 128
+        for hf in range(C4 // 512):
+            for w in range(4):
+                for cb in range(4):
+                    for ks in range(KBS):
+                        out.append(w3[(hf * 512 + 128 * w + 32 * cb + l32)[:, None], (16 * ks + 8 * h)[:, None] + e])
+                for ks in range(32):
+                    for cc in range(ncc):
+                        out.append(w1n[((N2 // 4) * w + 32 * cc + l32)[:, None], (hf * 512 + 16 * ks + 8 * h)[:, None] + e])
+        return torch.stack(out).to(torch.bfloat16).contiguous()
     for hf in range(C4 // 512):
         for w in range(8):
             for cb in range(2):
@@ -341,14 +353,18 @@ class BneckTailOp(object):
     ReLU in one launch (models/backbone/resnet.py:132-140,122-124): the block output is written once and not read back.  Built from
     the blocks' ConvOps; carries the attributes autotune / export_tuning read from a conv op (single kernel: variant codes are no-ops)."""
     GEOMETRIES = ((128, 128), (128, 256), (256, 256))
+    # the thin variant is built and parity-tested but measured slower at every size (layer3, B = 64: 41.8 vs 34.7 us; it streams the
+    # weights twice as often): off unless DIR_TAIL_THIN_MAX_TILES says otherwise
+    THIN_MAX_TILES = int(os.environ.get('DIR_TAIL_THIN_MAX_TILES', '0'))
+    force_waves = int(os.environ.get('DIR_TAIL_WAVES', '0'))
 
     def __init__(self, c3, c1n):
         self.c3, self.c1n = c3, c1n
         self.cout, self.cin, self.kh, self.kw, self.stride = c3.cout, c3.cin, 1, 1, 1
         self.variant = {}
-        self.stream = pack_tail_stream(c3.w.reshape(c3.cout, c3.cin), c1n.w.reshape(c1n.cout, c1n.cin))
-        self.params = _capi.BneckTailParams(_capi.ptr(self.stream), _capi.ptr(c3.scale), _capi.ptr(c3.shift), _capi.ptr(c1n.scale),
-                                            _capi.ptr(c1n.shift), c3.cin, c1n.cout)
+        self.stream = {n: pack_tail_stream(c3.w.reshape(c3.cout, c3.cin), c1n.w.reshape(c1n.cout, c1n.cin), n) for n in (8, 4)}
+        self.params = {n: _capi.BneckTailParams(_capi.ptr(self.stream[n]), _capi.ptr(c3.scale), _capi.ptr(c3.shift), _capi.ptr(c1n.scale),
+                                                _capi.ptr(c1n.shift), c3.cin, c1n.cout, n) for n in (8, 4)}
 
     @staticmethod
     def applies(c3, c1n, dtype):
@@ -367,7 +383,9 @@ class BneckTailOp(object):
             _capi.annotate(family='conv', flops=2.0 * M * (P * c4 + c4 * n2), op=self, dtype='bf16',
                            shape='M=%d tail 1x1(%d->%d)+res+1x1(->%d)' % (M, P, c4, n2),
                            bytes=(M * (P + 2 * c4 + n2) + c4 * P + n2 * c4) * 2)
-        _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(self.params), _capi.ptr(y2), _capi.ptr(x), _capi.ptr(out), _capi.ptr(y1n),
+        # thin variant (32-pixel tiles, two workgroups per CU) while the fat one would leave workgroups with a single tile
+        waves = self.force_waves or (4 if M // 64 <= self.THIN_MAX_TILES else 8)
+        _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(self.params[waves]), _capi.ptr(y2), _capi.ptr(x), _capi.ptr(out), _capi.ptr(y1n),
                                                             M, _capi.stream_ptr()), 'dir_bottleneck_tail_forward')
         return out, y1n
 

@@ -100,7 +100,7 @@ def bottleneck_chain(y1, w2, s2, h2, w3, s3, h3, residual=None, nxt=None, dual=N
     return out, y1n
 
 
-def bottleneck_tail(y2, w3, s3, h3, residual, w1n, s1n, h1n):
+def bottleneck_tail(y2, w3, s3, h3, residual, w1n, s1n, h1n, waves=8):
     """models/backbone/resnet.py:132-140 (+ :122-124 of the next block) in one launch, layer2 / layer3 geometry, bf16 NHWC.
     y2 [B,H,W,P]; w3 [4P,P]; residual [B,H,W,4P] (the block input); w1n [N2,4P]  ->  (out [B,H,W,4P], y1_next [B,H,W,N2])"""
     import ctypes as C
@@ -108,11 +108,11 @@ def bottleneck_tail(y2, w3, s3, h3, residual, w1n, s1n, h1n):
     _capi.require_cuda(y2, residual)
     B, H, W, P = y2.shape
     C4, N2 = w3.shape[0], w1n.shape[0]
-    stream = pack_tail_stream(w3, w1n)
+    stream = pack_tail_stream(w3, w1n, waves)
     keep = [_capi.f32c(t) for t in (s3, h3, s1n, h1n)]
     out = torch.empty(B, H, W, C4, device=y2.device, dtype=torch.bfloat16)
     y1n = torch.empty(B, H, W, N2, device=y2.device, dtype=torch.bfloat16)
-    p = _capi.BneckTailParams(_capi.ptr(stream), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(keep[2]), _capi.ptr(keep[3]), P, N2)
+    p = _capi.BneckTailParams(_capi.ptr(stream), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(keep[2]), _capi.ptr(keep[3]), P, N2, waves)
     _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(p), _capi.ptr(y2.contiguous()), _capi.ptr(residual.contiguous()), _capi.ptr(out),
                                                         _capi.ptr(y1n), B * H * W, _capi.stream_ptr()), 'dir_bottleneck_tail_forward')
     return out, y1n

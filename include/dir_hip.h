@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 14
+#define DIR_ABI_VERSION 15
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -421,6 +421,11 @@ typedef struct dir_bneck_tail_params {
     const float* scale1n; const float* shift1n;    /* [n_next] */
     int32_t planes;   /* P: 128 | 256 */
     int32_t n_next;   /* 128 | 256 (P = 128), 256 (P = 256) */
+    int32_t waves;    /* 8: the layout above (64-pixel tiles, one workgroup per CU).  4: the thin variant (32-pixel tiles, two
+                         workgroups per CU, for M <~ 64 pixels x CUs): [halves][4 waves][P/4 + 32*(n_next/128) fragments][64][8] with
+                         conv3 fragment f < P/4: cb = f / (P/16), ks = f % (P/16): w3[half*512 + 128*wave + 32*cb + (l&31)][16*ks + 8*(l>>5)..],
+                         conv1' fragment fc: ks = fc / (n_next/128), cc = fc % (n_next/128):
+                         w1n[(n_next/4)*wave + 32*cc + (l&31)][half*512 + 16*ks + 8*(l>>5)..] */
 } dir_bneck_tail_params;
 int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const void* y2, const void* residual, void* out, void* y1_next,
                                 long long M, void* stream);

@@ -50,21 +50,22 @@ def oracle_tail(p):
     return out, y1n
 
 
-def run_fused(p):
+def run_fused(p, waves=8):
     C4, P = p['w3'].shape[:2]
     N2 = p['w1'].shape[0]
     return F.bottleneck_tail(nhwc(p['y2']), dev(p['w3'].reshape(C4, P)), dev(p['s3']), dev(p['h3']), nhwc(p['res']),
-                             dev(p['w1'].reshape(N2, C4)), dev(p['s1']), dev(p['h1']))
+                             dev(p['w1'].reshape(N2, C4)), dev(p['s1']), dev(p['h1']), waves=waves)
 
 
+@pytest.mark.parametrize('waves', [8, 4])
 @pytest.mark.parametrize('geom', GEOM)
 @pytest.mark.parametrize('shape', [(1, 8, 8), (2, 16, 16), (3, 32, 32)])
-def test_tail_matches_oracle(geom, shape):
-    """one tile, fewer tiles than CUs, and several tiles per workgroup"""
+def test_tail_matches_oracle(geom, shape, waves):
+    """one tile, fewer tiles than CUs, and several tiles per workgroup; both workgroup shapes (8 waves x 64 pixels, 4 waves x 32)"""
     (P, N2), (B, H, W) = geom, shape
     p = make('tail.%d_%d.%d_%d_%d' % (geom + shape), B, H, W, P, N2)
     ref_out, ref_y1n = oracle_tail(p)
-    out, y1n = run_fused(p)
+    out, y1n = run_fused(p, waves)
     got = out.float().cpu().numpy().transpose(0, 3, 1, 2)
     assert relerr(got, ref_out) < 1e-2                     # bf16 output: one ulp of the output scale
     d = np.abs(got - ref_out)
@@ -74,13 +75,14 @@ def test_tail_matches_oracle(geom, shape):
     assert relerr(got1, ref_y1n) < 1.5e-2                  # its input (the block output) may differ from the oracle's by a bf16 ulp
 
 
+@pytest.mark.parametrize('waves', [8, 4])
 @pytest.mark.parametrize('geom', GEOM)
-def test_tail_vs_the_unfused_pair_full_size(geom):
+def test_tail_vs_the_unfused_pair_full_size(geom, waves):
     """full-size: B = 64 at the layer's resolution (65 536 / 16 384 pixels: 4 / 1 tiles per workgroup on 256 CUs)"""
     P, N2 = geom
     B, H, W = (64, 32, 32) if P == 128 else (64, 16, 16)
     p = make('tail.full.%d_%d' % geom, B, H, W, P, N2)
-    out, y1n = run_fused(p)
+    out, y1n = run_fused(p, waves)
     y2, res = nhwc(p['y2']), nhwc(p['res'])
     o = F.conv2d_nhwc(y2, F.pack_conv_weight(dev(p['w3']), BF), 1, 0, dev(p['s3']), dev(p['h3']), relu=True, residual=res)
     n1 = F.conv2d_nhwc(o, F.pack_conv_weight(dev(p['w1']), BF), 1, 0, dev(p['s1']), dev(p['h1']), relu=True)
@@ -91,7 +93,7 @@ def test_tail_vs_the_unfused_pair_full_size(geom):
     assert float((d > 0).float().mean()) < 0.02
     assert relerr(y1n.float().cpu().numpy(), n1.float().cpu().numpy()) < 1e-2
     # and a second launch on the same inputs reproduces itself (persistent workgroups, DMA double buffer, register ring)
-    out2, y1n2 = run_fused(p)
+    out2, y1n2 = run_fused(p, waves)
     assert torch.equal(out, out2) and torch.equal(y1n, y1n2)
 
 

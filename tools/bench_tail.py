@@ -37,21 +37,21 @@ for P, N2, HW in ((128, 128, 32), (128, 256, 32), (256, 256, 16)):
     import ctypes as C
     from dir_amd import _capi
     from dir_amd.engine import pack_tail_stream
-    stream = pack_tail_stream(w3, w1)
+    streams = {n: pack_tail_stream(w3, w1, n) for n in (8, 4)}
     out = torch.empty(B, HW, HW, C4, device='cuda', dtype=BF)
     y1n = torch.empty(B, HW, HW, N2, device='cuda', dtype=BF)
-    p = _capi.BneckTailParams(_capi.ptr(stream), _capi.ptr(s3), _capi.ptr(h3), _capi.ptr(s1), _capi.ptr(h1), P, N2)
+    ps = {n: _capi.BneckTailParams(_capi.ptr(streams[n]), _capi.ptr(s3), _capi.ptr(h3), _capi.ptr(s1), _capi.ptr(h1), P, N2, n) for n in (8, 4)}
 
-    def fused():
-        _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(p), _capi.ptr(y2), _capi.ptr(res), _capi.ptr(out), _capi.ptr(y1n),
+    def fused(n=8):
+        _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(ps[n]), _capi.ptr(y2), _capi.ptr(res), _capi.ptr(out), _capi.ptr(y1n),
                                                             B * HW * HW, _capi.stream_ptr()), 'tail')
 
     def unfused():
         o = F.conv2d_nhwc(y2, w3p, 1, 0, s3, h3, relu=True, residual=res)
         F.conv2d_nhwc(o, w1p, 1, 0, s1, h1, relu=True)
     M = B * HW * HW
-    tf, tu = timeit(fused), timeit(unfused)
+    tf, tu, t4 = timeit(fused), timeit(unfused), timeit(lambda: fused(4))
     bf = (M * (P + 2 * C4 + N2) + C4 * P + N2 * C4) * 2
     bu = bf + M * C4 * 2
-    print('P=%d N2=%d M=%d: fused %.1f us (%.2f TB/s of %.1f MB)   unfused pair %.1f us (%.2f TB/s of %.1f MB)   L2 weight stream %.0f MB'
-          % (P, N2, M, tf, bf / tf / 1e6, bf / 1e6, tu, bu / tu / 1e6, bu / 1e6, M / 64 * (C4 * P + N2 * C4) * 2 / 1e6))
+    print('P=%d N2=%d M=%d: fused 8-wave %.1f us (%.2f TB/s of %.1f MB)   4-wave thin %.1f us (%.2f TB/s)   unfused pair %.1f us (%.2f TB/s of %.1f MB)'
+          % (P, N2, M, tf, bf / tf / 1e6, bf / 1e6, t4, bf / t4 / 1e6, tu, bu / tu / 1e6, bu / 1e6))

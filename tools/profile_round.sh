@@ -9,8 +9,8 @@ out=$R/gpurun_out/$tag
 mkdir -p $out
 # the per-layer kernel choice is made once OUTSIDE the profiler and re-used, so the traces hold only the timed configuration
 rm -f /tmp/dir_autotune.json
-python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
-cmd="python $R/bench.py --inflight 1 --steps 10 --warmup 3 --no-cpu-baseline --dump-conv --autotune-cache /tmp/dir_autotune.json"
+python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-proj-feat-variant --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
+cmd="python $R/bench.py --inflight 1 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-proj-feat-variant --dump-conv --autotune-cache /tmp/dir_autotune.json"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $cmd > $out/pmcF.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $cmd > $out/pmcW.log 2>&1 )
@@ -19,5 +19,5 @@ cd $R
 python tools/prof_summary.py $(find $out/trace -name "*.db" | head -1) 60 > $out/kernel_stats.txt
 python tools/pmc_traffic.py $(find $out/pmcF -name "*.db" | head -1) $(find $out/pmcW -name "*.db" | head -1) $out/pmc_traffic.json
 python tools/pmc_per_kernel.py $(find $out/trace -name "*.db" | head -1) $(find $out/pmcF -name "*.db" | head -1) $(find $out/pmcW -name "*.db" | head -1) $(find $out/pmcS -name "*.db" | head -1) > $out/per_kernel.txt 2>&1
-grep -h "^conv_igemm\|^{" $out/trace.log > $out/bench_line.txt
+grep -h "_kernel \|^{" $out/trace.log > $out/bench_line.txt
 rm -rf $out/trace $out/pmcF $out/pmcW $out/pmcS
