@@ -1,0 +1,245 @@
+"""Input side of the evaluation loop: the prepared InterHand2.6M split on disk -> batches on the GPU.
+
+  layout            dataset/prepare_data.py:123-166   <data_path>/<split>/img/<idx>.jpg   256x256 crop written by cv.imwrite
+                                                      <data_path>/<split>/anno/<idx>.pkl  {'camera': {'R','t','camera'},
+                                                                                           'mano_params': {'left'|'right': {'R','pose','shape','trans'}}}
+  InterHandSplit    dataset/interhand.py:31-105       InterHand_dataset.__getitem__: image + annotation of one index
+  frame decode      apps/eval.py:56-58                cv.imread -> (cv.resize to 256, the identity on the prepared crops) -> BGR uint8
+  DecodeRing                                          what the reference leaves to DataLoader(num_workers=8): decode processes fill a
+                                                      ring of pinned uint8 batches [B,256,256,3]; the uint8 batch goes to the GPU as it
+                                                      is (4x fewer bytes than the float tensor) and the normalisation of apps/eval.py:
+                                                      59-61 happens inside the stem kernel (dir_stem_pool_forward)
+  gt_batch          dataset/interhand.py:62-95        ground-truth vertices / joints: the GT MANO layer on the whole batch on the GPU
+                                                      (dir_gt_mano_forward) instead of per sample on a CPU worker, then the camera
+                                                      transform and projection
+JPEG decoding is libjpeg-turbo through PIL (cv.imread uses the same library with the same defaults: integer slow DCT, fancy
+upsampling).  cv2 is not installed where this was written, so the equality of the two decoders' pixels is not pinned by a fixture
+("parity unpinned" for the decode step; everything after the uint8 frame is pinned by G11 / G9 / G10).  `resize_bilinear_u8`
+restates cv.resize(INTER_LINEAR) on uint8 (OpenCV's 11-bit fixed-point coefficients) for frames that are not already 256x256; on the
+prepared split it is never taken.
+"""
+import glob
+import os
+import pickle
+import queue
+
+import numpy as np
+import torch
+
+IMG_SIZE = 256          # dataset/dataset_utils.py:5
+
+
+def resize_bilinear_u8(img, wo, ho):
+    """cv.resize(img, (wo, ho)) for uint8 HxWxC, INTER_LINEAR: half-pixel centres, coefficients quantised to 2^-11, the horizontal pass
+    kept at full precision, one rounding at the end (OpenCV's HResizeLinear / VResizeLinear for 8-bit images)."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    if (w, h) == (wo, ho):
+        return img.copy()
+
+    def taps(n_in, n_out):
+        scale = n_in / float(n_out)
+        src = (np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5
+        i0 = np.floor(src).astype(np.int64)
+        f = (src - i0).astype(np.float32)
+        neg = i0 < 0
+        i0[neg], f[neg] = 0, 0.0
+        over = i0 >= n_in - 1
+        i0[over], f[over] = n_in - 1, 0.0
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        c1 = np.rint(f * 2048.0).astype(np.int64)            # saturate_cast<short>(f * INTER_RESIZE_COEF_SCALE)
+        return i0, i1, 2048 - c1, c1
+    x0, x1, a0, a1 = taps(w, wo)
+    y0, y1, b0, b1 = taps(h, ho)
+    src = img.astype(np.int64)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None] if img.ndim == 3 else src[:, x0] * a0[None] + src[:, x1] * a1[None]
+    top, bot = rows[y0], rows[y1]
+    bb0 = b0.reshape((-1, 1, 1) if img.ndim == 3 else (-1, 1))
+    bb1 = b1.reshape((-1, 1, 1) if img.ndim == 3 else (-1, 1))
+    out = (((bb0 * (top >> 4)) >> 16) + ((bb1 * (bot >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def decode_bgr(path, size=IMG_SIZE):
+    """cv.imread(path) (+ cv.resize to size x size when needed): uint8 BGR [size, size, 3]"""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'))
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    return bgr if bgr.shape[:2] == (size, size) else resize_bilinear_u8(bgr, size, size)
+
+
+class InterHandSplit(object):
+    """the prepared split on disk (dataset/interhand.py:31-47): len() = number of annotation files; frame(i) / anno(i) read one index"""
+
+    def __init__(self, data_path, split='test'):
+        assert split in ('train', 'test', 'val')
+        self.data_path, self.split = data_path, split
+        self.size = len(glob.glob(os.path.join(data_path, split, 'anno', '*.pkl')))
+
+    def __len__(self):
+        return self.size
+
+    def img_path(self, idx):
+        return os.path.join(self.data_path, self.split, 'img', '%d.jpg' % idx)
+
+    def frame(self, idx):
+        return decode_bgr(self.img_path(idx))
+
+    def anno(self, idx):
+        """-> 31 + 2 x 67 float32 numbers: camera R (9) | t (3) | K (9) | per hand (left, right): root R (9) | pose (45) | shape (10) | trans (3)"""
+        with open(os.path.join(self.data_path, self.split, 'anno', '%d.pkl' % idx), 'rb') as f:
+            d = pickle.load(f, encoding='latin1')
+        cam = d['camera']
+        parts = [np.asarray(cam['R'], np.float32).reshape(9), np.asarray(cam['t'], np.float32).reshape(3),
+                 np.asarray(cam['camera'], np.float32).reshape(9)]
+        for side in ('left', 'right'):
+            p = d['mano_params'][side]
+            pose = np.asarray(p['pose'], np.float32).reshape(-1)
+            assert pose.size == 45, 'the prepared split stores 45 PCA coefficients per hand (dataset/prepare_data.py:100)'
+            parts += [np.asarray(p['R'], np.float32).reshape(9), pose, np.asarray(p['shape'], np.float32).reshape(10),
+                      np.asarray(p['trans'], np.float32).reshape(3)]
+        return np.concatenate(parts)
+
+
+ANNO_FLOATS = 21 + 2 * 67
+
+
+def _decode_worker(data_path, split, tasks, done, frames, annos):
+    """decode process: (slot, first index, count) -> frames[slot][:count], annos[slot][:count]"""
+    torch.set_num_threads(1)
+    ds = InterHandSplit(data_path, split)
+    fr, an = [f.numpy() for f in frames], [a.numpy() for a in annos]
+    while True:
+        t = tasks.get()
+        if t is None:
+            return
+        slot, part, idxs = t
+        try:
+            for j, idx in idxs:
+                fr[slot][j] = ds.frame(idx)
+                an[slot][j] = ds.anno(idx)
+            done.put((slot, part, None))
+        except Exception as e:          # noqa: BLE001  (reported to the consumer, which raises)
+            done.put((slot, part, repr(e)))
+
+
+class DecodeRing(object):
+    """Batches of decoded frames from `workers` processes through a ring of `depth` shared, page-locked host buffers.
+
+        ring = DecodeRing(data_path, 'test', batch_size=256)
+        for frames_u8, annos, n in ring:          # pinned uint8 [B,256,256,3], float32 [B,155]; the first n rows are valid
+            pipe.refill(slot, frames_u8[:n]) ...
+    A batch is split over all workers (so one batch's latency is 1/workers of its decode time); the next `depth - 1` batches are
+    decoded while the caller consumes the current one.  The buffers are shared memory registered with the HIP runtime
+    (cudaHostRegister), so the host -> device copy is an asynchronous DMA from where the decoders wrote."""
+
+    def __init__(self, data_path, split='test', batch_size=256, workers=8, depth=3, indices=None, pin=True):
+        import torch.multiprocessing as mp
+        self.ds = InterHandSplit(data_path, split)
+        self.indices = list(range(len(self.ds))) if indices is None else list(indices)
+        self.bs, self.depth, self.workers = batch_size, depth, max(1, workers)
+        self.frames = [torch.zeros(batch_size, IMG_SIZE, IMG_SIZE, 3, dtype=torch.uint8).share_memory_() for _ in range(depth)]
+        self.annos = [torch.zeros(batch_size, ANNO_FLOATS, dtype=torch.float32).share_memory_() for _ in range(depth)]
+        self.pinned = False
+        if pin and torch.cuda.is_available():
+            rt = torch.cuda.cudart()
+            self.pinned = all(int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0 for t in self.frames + self.annos)
+        ctx = mp.get_context('spawn')
+        self.tasks, self.done = ctx.Queue(), ctx.Queue()
+        self.procs = [ctx.Process(target=_decode_worker, args=(data_path, split, self.tasks, self.done, self.frames, self.annos), daemon=True)
+                      for _ in range(self.workers)]
+        for p in self.procs:
+            p.start()
+
+    def __len__(self):
+        return (len(self.indices) + self.bs - 1) // self.bs
+
+    def _submit(self, b, slot):
+        idxs = list(enumerate(self.indices[b * self.bs:(b + 1) * self.bs]))
+        parts = [idxs[w::self.workers] for w in range(self.workers) if idxs[w::self.workers]]
+        for k, part in enumerate(parts):
+            self.tasks.put((slot, k, part))
+        return len(parts), len(idxs)
+
+    def __iter__(self):
+        nb = len(self)
+        pending = {}
+        for b in range(min(self.depth - 1, nb)):
+            pending[b] = self._submit(b, b % self.depth)
+        for b in range(nb):
+            nxt = b + self.depth - 1
+            if nxt < nb:
+                pending[nxt] = self._submit(nxt, nxt % self.depth)
+            slot = b % self.depth
+            nparts, n = pending.pop(b)
+            got = 0
+            stash = []
+            while got < nparts:
+                try:
+                    s, k, err = self.done.get(timeout=600)
+                except queue.Empty:
+                    raise RuntimeError('DecodeRing: decode workers made no progress for 600 s')
+                if err is not None:
+                    raise RuntimeError('DecodeRing: decode failed: ' + err)
+                if s == slot:
+                    got += 1
+                else:
+                    stash.append((s, k, err))
+            for item in stash:              # completions of later batches: put back for their turn
+                self.done.put(item)
+            yield self.frames[slot], self.annos[slot], n
+
+    def close(self):
+        for _ in self.procs:
+            self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=10)
+        if self.pinned:
+            rt = torch.cuda.cudart()
+            for t in self.frames + self.annos:
+                rt.cudaHostUnregister(t.data_ptr())
+            self.pinned = False
+
+
+def gt_batch(mano_layer, annos):
+    """dataset/interhand.py:62-95 for a batch: annos float32 [n,155] on the GPU (InterHandSplit.anno layout); mano_layer = {'left','right'}
+    GT layers (dir_amd.models.manolayer.ManoLayer, center_idx=None).  Returns the dataloader tuple entries of apps/eval.py:63-78 after
+    the image: (joints_left, verts_left, joints_right, verts_right, joints2d_left, verts2d_left, joints2d_right, verts2d_right, cam)."""
+    n = annos.shape[0]
+    R = annos[:, 0:9].reshape(n, 3, 3)
+    T = annos[:, 9:12].reshape(n, 1, 3)
+    K = annos[:, 12:21].reshape(n, 3, 3).contiguous()
+    out = {}
+    for h, side in enumerate(('left', 'right')):
+        o = 21 + 67 * h
+        root = annos[:, o:o + 9].reshape(n, 3, 3).contiguous()
+        pose, shape, trans = annos[:, o + 9:o + 54].contiguous(), annos[:, o + 54:o + 64].contiguous(), annos[:, o + 64:o + 67].contiguous()
+        v, j = mano_layer[side](root, pose, shape, trans=trans)
+        v = torch.baddbmm(T, v, R.transpose(1, 2))            # handV @ R.T + T
+        j = torch.baddbmm(T, j, R.transpose(1, 2))
+        v2 = torch.bmm(v, K.transpose(1, 2))
+        j2 = torch.bmm(j, K.transpose(1, 2))
+        out[side] = (j, v, j2[..., :2] / j2[..., 2:], v2[..., :2] / v2[..., 2:])
+    (jl, vl, j2l, v2l), (jr, vr, j2r, v2r) = out['left'], out['right']
+    return jl, vl, jr, vr, j2l, v2l, j2r, v2r, K
+
+
+def gt_layers_from_checkpoint(state, device='cuda'):
+    """The two ground-truth MANO layers (apps/eval.py:110-113) built from the MANO buffers the published checkpoint already carries
+    (init_regressor.mano_layer_{left,right}.th_*) -- no licensed pickle needed.  The checkpoint's left shapedirs are
+    already the `fix_shape`-corrected ones (models/dir.py:306-309 ran before it was saved), i.e. what dataset/interhand.py:19-22
+    applies to the GT layer."""
+    from ..models.manolayer import ManoLayer
+    layers = {}
+    for side in ('left', 'right'):
+        p = 'init_regressor.mano_layer_%s.' % side
+        g = lambda k: state[p + k].detach().cpu().float().numpy()  # noqa: E731
+        comps = g('th_selected_comps')
+        t = dict(hands_components=comps, hands_mean=g('th_hands_mean').reshape(45), J_regressor=g('th_J_regressor'),
+                 weights=g('th_weights'), posedirs=g('th_posedirs'), v_template=g('th_v_template').reshape(778, 3),
+                 shapedirs=g('th_shapedirs'), f=state[p + 'th_faces'].cpu().numpy() if (p + 'th_faces') in state else np.zeros((1538, 3), np.int64),
+                 kintree_table=np.array([[4294967295, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14], list(range(16))], dtype=np.int64))
+        t['J'] = t['J_regressor'] @ t['v_template']
+        layers[side] = ManoLayer(None, center_idx=None, _tables=t).to(device)
+    return layers

@@ -5,8 +5,10 @@
                                        per-sample errors stay on the GPU until summarize()/save_txt(), which reduce and
                                        format exactly like :246-306 (numpy float32 means, *1000 for mm, '%.3f' files)
   evaluate        apps/eval.py:137-241 the loop: network(...) -> metrics.update(...)
-Dataset, checkpoint download and MANO pkl loading are out of scope (SURVEY.md 8 'out'): the caller supplies the batches
-(the reference's dataloader tuple layout) and the two [16,778] joint regressors.
+  evaluate_from_disk / main   apps/eval.py:88-136  the command line (`python -m dir_amd.apps.eval --model DIR.pth --data_path ... --bs 256
+                                       --root_joint 0`): checkpoint -> DIR, the prepared split from disk through dir_amd.apps.dataset
+                                       (decode ring -> uint8 frames -> two forwards in flight), GT on the GPU, the same report / files
+The licensed MANO pickle is not needed: the checkpoint carries the MANO buffers (dataset.gt_layers_from_checkpoint).
 """
 import os
 
@@ -171,3 +173,86 @@ def evaluate(network, dataloader, J_regressor, root_joint=0, scale=True, stage_n
             result, _ = network({'img': data[0].cuda()}, None, None)
             m.update(result, data)
     return m
+
+
+def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joint=0, scale=True, split='test', workers=8,
+                       stage_num=3, indices=None, progress=None):
+    """apps/eval.py:121-241 from the prepared split on disk, at pipeline speed: decode processes (dataset.DecodeRing) -> pinned uint8
+    batches -> two forwards in flight (engine.ForwardPipeline over uint8 input slots; the normalisation runs inside the stem kernel,
+    proj_feat is not produced: the evaluation never reads it) -> GT MANO + metrics on the GPU.  `eng`: a DirEngine.
+    Returns (EvalMetrics, {'images', 'seconds', 'images_per_sec'})."""
+    import time
+    from ..engine import ForwardPipeline
+    from .dataset import IMG_SIZE, DecodeRing, gt_batch
+    dev = eng.device
+    ring = DecodeRing(data_path, split, bs, workers=workers, indices=indices)
+    m = EvalMetrics(J_regressor, root_joint, scale, stage_num)
+    slots = [torch.zeros(bs, IMG_SIZE, IMG_SIZE, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+    pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
+    pending = [None, None]
+
+    def finish(slot):
+        n, annos = pending[slot]
+        outs = pipe.wait(slot)
+        res = [{k: (v[:n] if torch.is_tensor(v) else v) for k, v in o.items()} for o in outs[:3]]
+        gt = gt_batch(mano_layer, annos[:n])
+        m.update(res, (None,) * 2 + gt)          # data[0] image / data[1] mask are not read by the metric maths (apps/eval.py:151-241)
+        pending[slot] = None
+
+    t0, seen = time.perf_counter(), 0
+    try:
+        for k, (frames, annos, n) in enumerate(ring):
+            slot = k % 2
+            if pending[slot] is not None:
+                finish(slot)
+            pipe.refill(slot, frames)                                  # async DMA from the ring's page-locked buffer, on the slot's stream
+            with torch.cuda.stream(pipe.streams[slot]):
+                annos_dev = annos.to(dev, non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record()
+            pipe.launch(slot)
+            pending[slot] = (n, annos_dev)
+            copied.synchronize()                                       # the ring may hand this buffer back to the decoders
+            seen += n
+            if progress:
+                progress(seen)
+        for slot in (0, 1):
+            if pending[slot] is not None:
+                finish(slot)
+        torch.cuda.synchronize(dev)
+    finally:
+        ring.close()
+    dt = time.perf_counter() - t0
+    return m, {'images': seen, 'seconds': dt, 'images_per_sec': seen / dt if dt > 0 else 0.0}
+
+
+def main(argv=None):
+    """python -m dir_amd.apps.eval: the reference's command line (apps/eval.py:88-94) and outputs (:272-306)"""
+    import argparse
+    from ..engine import DirEngine
+    from .dataset import gt_layers_from_checkpoint
+    ap = argparse.ArgumentParser(description='InterHand2.6M evaluation of a DIR checkpoint on MI355X (apps/eval.py of the reference)')
+    ap.add_argument('--model', type=str, default='./DIR.pth')
+    ap.add_argument('--data_path', type=str, default='./data/interhand2.6m/')
+    ap.add_argument('--bs', type=int, default=256)
+    ap.add_argument('--root_joint', type=int, default=0)              # 0 wrist, 9 middle MCP
+    ap.add_argument('--scale', type=lambda v: str(v).lower() not in ('0', 'false', 'no'), default=True)
+    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16', help='bf16 feature maps (throughput mode) or exact fp32 (parity mode)')
+    ap.add_argument('--workers', type=int, default=8)
+    ap.add_argument('--result_dir', type=str, default='./result/DIR-PoseEmb-Wrist')
+    opt = ap.parse_args(argv)
+    state = torch.load(opt.model, map_location='cpu', weights_only=False)
+    state = state['net'] if isinstance(state, dict) and 'net' in state else state
+    eng = DirEngine(state, dtype=torch.bfloat16 if opt.dtype == 'bf16' else torch.float32, root_joint=0)     # apps/eval.py:104: DIR(21, './misc/mano')
+    mano_layer = gt_layers_from_checkpoint(state)
+    J_regressor = {s: Jr(mano_layer[s].J_regressor) for s in ('left', 'right')}
+    m, rate = evaluate_from_disk(eng, opt.data_path, J_regressor, mano_layer, bs=opt.bs, root_joint=opt.root_joint, scale=opt.scale,
+                                 workers=opt.workers)
+    m.save_txt(opt.result_dir)
+    print(m.report())
+    print('%d images in %.1f s: %.0f images/s from files' % (rate['images'], rate['seconds'], rate['images_per_sec']))
+    return m
+
+
+if __name__ == '__main__':
+    main()

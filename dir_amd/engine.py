@@ -57,7 +57,8 @@ STREAM_VARIANT = 21      # DIR_CONV_VARIANT code: dir_conv1x1_stream_forward (1x
 def pack_stream_weights(w_nk):
     """dir_conv1x1_stream_forward's weight stream (include/dir_hip.h) from W [Cout, K] (K = Cin, or Cin + Cin2 for two sources):
     bf16 [Cout/NWG][4 waves][K/64][4 k-steps][NCB][64 lanes][8]."""
-    w = w_nk.detach().float()
+    out_dev = w_nk.device
+    w = w_nk.detach().float().cpu()
     N, K = w.shape
     assert N % 128 == 0 and K % 64 == 0
     ncb = 2 if N % 256 == 0 else 1
@@ -69,7 +70,7 @@ def pack_stream_weights(w_nk):
                                       torch.arange(4, device=dev), torch.arange(ncb, device=dev), indexing='ij')
     row = (g * (128 * ncb) + (wv * ncb + cb) * 32)[..., None] + l32                    # [G,4,nk,4,ncb,64]
     k0 = (64 * c + 16 * ks)[..., None] + 8 * h
-    return w[row[..., None], k0[..., None] + e].to(torch.bfloat16).contiguous()
+    return w[row[..., None], k0[..., None] + e].to(torch.bfloat16).contiguous().to(out_dev)
 
 
 class ConvOp(object):
@@ -310,8 +311,9 @@ def pack_tail_stream(w3, w1n, waves=8):
     """dir_bottleneck_tail_forward's weight stream (include/dir_hip.h): conv3.weight [4P, P] and the next conv1.weight [N2, 4P]
     as bf16 MFMA A-operand fragments in the order the kernel's waves consume them, [4P/512][waves][NBF + NCF][64 lanes][8]
     (waves = 8: 64-pixel tiles, one workgroup per CU; waves = 4: the thin variant, 32-pixel tiles, two workgroups per CU)."""
-    w3 = w3.detach().float().reshape(w3.shape[0], -1)
-    w1n = w1n.detach().float().reshape(w1n.shape[0], -1)
+    out_dev = w3.device
+    w3 = w3.detach().float().reshape(w3.shape[0], -1).cpu()        # packed on the host: hundreds of small gathers, once per engine
+    w1n = w1n.detach().float().reshape(w1n.shape[0], -1).cpu()
     C4, P = w3.shape
     N2 = w1n.shape[0]
     assert w1n.shape[1] == C4 and C4 == 4 * P and C4 % 512 == 0 and N2 in (128, 256)
@@ -331,7 +333,7 @@ def pack_tail_stream(w3, w1n, waves=8):
                 for ks in range(32):
                     for cc in range(ncc):
                         out.append(w1n[((N2 // 4) * w + 32 * cc + l32)[:, None], (hf * 512 + 16 * ks + 8 * h)[:, None] + e])
-        return torch.stack(out).to(torch.bfloat16).contiguous()
+        return torch.stack(out).to(torch.bfloat16).contiguous().to(out_dev)
     for hf in range(C4 // 512):
         for w in range(8):
             for cb in range(2):
@@ -345,7 +347,7 @@ def pack_tail_stream(w3, w1n, waves=8):
             else:
                 for fc in range(32):
                     out.append(w1n[(32 * w + l32)[:, None], (hf * 512 + 16 * fc + 8 * h)[:, None] + e])
-    return torch.stack(out).to(torch.bfloat16).contiguous()
+    return torch.stack(out).to(torch.bfloat16).contiguous().to(out_dev)
 
 
 class BneckTailOp(object):

@@ -1,0 +1,39 @@
+"""Sustained images/s of the evaluation loop FROM FILES (JPEG decode on the host cores -> uint8 frames -> two forwards in flight ->
+GT MANO + metrics on the GPU), on a synthetic split in the reference's layout.  python tools/bench_fromdisk.py [n_images] [bs] [workers]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'helpers'))
+from fake_split import write_split  # noqa: E402
+from dir_amd import synth  # noqa: E402
+from dir_amd.apps import dataset as DS  # noqa: E402
+from dir_amd.apps import eval as EV  # noqa: E402
+from dir_amd.engine import DirEngine  # noqa: E402
+
+if __name__ == '__main__':
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    workers = [int(w) for w in sys.argv[3].split(',')] if len(sys.argv) > 3 else [8, 16, 32, 64]
+    with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    state = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
+    with tempfile.TemporaryDirectory() as d:
+        t0 = time.perf_counter()
+        write_split(d, 256, seed=1)
+        print('wrote 256 synthetic 256x256 JPEGs + annotations in %.1f s (re-used cyclically as a %d-image split)' % (time.perf_counter() - t0, n))
+        eng = DirEngine(state, dtype=torch.bfloat16)
+        mano = DS.gt_layers_from_checkpoint(state)
+        jreg = {s: EV.Jr(mano[s].J_regressor) for s in ('left', 'right')}
+        idx = [i % 256 for i in range(n)]
+        eng.autotune(torch.randn(bs, 3, 256, 256, device='cuda'))
+        for w in workers:
+            m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx)
+            print('workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))

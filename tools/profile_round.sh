@@ -12,9 +12,12 @@ rm -f /tmp/dir_autotune.json
 python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-proj-feat-variant --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
 cmd="python $R/bench.py --inflight 1 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-proj-feat-variant --dump-conv --autotune-cache /tmp/dir_autotune.json"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
-( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $cmd > $out/pmcF.log 2>&1 )
-( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $cmd > $out/pmcW.log 2>&1 )
-( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $out/pmcS -o r -- $cmd > $out/pmcS.log 2>&1 )
+# counter passes: the same kernels launched eagerly (--no-graph) -- under --pmc the HIP-graph RNG bookkeeping kernel of torch.cuda.graph
+# segfaulted inside the profiler on this stack (r02); counters are per dispatch, so graph or no graph makes no difference to them
+pcmd="python $R/bench.py --no-graph --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-proj-feat-variant --autotune-cache /tmp/dir_autotune.json"
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $pcmd > $out/pmcF.log 2>&1 )
+( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $pcmd > $out/pmcW.log 2>&1 )
+( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $out/pmcS -o r -- $pcmd > $out/pmcS.log 2>&1 )
 cd $R
 python tools/prof_summary.py $(find $out/trace -name "*.db" | head -1) 60 > $out/kernel_stats.txt
 python tools/pmc_traffic.py $(find $out/pmcF -name "*.db" | head -1) $(find $out/pmcW -name "*.db" | head -1) $out/pmc_traffic.json
