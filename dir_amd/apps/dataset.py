@@ -110,6 +110,7 @@ def _decode_worker(data_path, split, tasks, done, frames, annos):
     torch.set_num_threads(1)
     ds = InterHandSplit(data_path, split)
     fr, an = [f.numpy() for f in frames], [a.numpy() for a in annos]
+    done.put((-1, -1, None))            # ready (the interpreter and its imports are up)
     while True:
         t = tasks.get()
         if t is None:
@@ -151,6 +152,9 @@ class DecodeRing(object):
                       for _ in range(self.workers)]
         for p in self.procs:
             p.start()
+        for _ in self.procs:             # wait until every decoder is up: a spawned interpreter takes seconds to import
+            s_, _, err = self.done.get(timeout=600)
+            assert s_ == -1 and err is None
 
     def __len__(self):
         return (len(self.indices) + self.bs - 1) // self.bs

@@ -216,7 +216,7 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
             seen += n
             if progress:
                 progress(seen)
-        for slot in (0, 1):
+        for slot in ((k + 1) % 2, k % 2) if seen else ():              # flush in launch order: the older slot first
             if pending[slot] is not None:
                 finish(slot)
         torch.cuda.synchronize(dev)

@@ -140,3 +140,30 @@ def conv1x1_stream(x, w_nk, scale=None, shift=None, relu=False, pre_scale=None, 
                                                        _capi.ptr(keep[2]), _capi.ptr(keep[3]), _capi.ptr(out), _capi.stream_ptr()),
                 'dir_conv1x1_stream_forward')
     return out
+
+
+def mano_backward(tables_lr, para_lr, g_verts=None, g_joints=None, g_joint_uv=None, g_mesh_uv=None):
+    """dir_mano_backward_pair on 64-vectors (pose 51 | betas 10 | cam 3, models/dir.py:352-363).  tables_lr: list of _capi.ManoTables
+    (1 or 2 hands); para_lr: list of fp32 [B,64] tensors; g_*: lists of cotangent tensors (or None).  Returns the list of g_para [B,64]."""
+    import ctypes as C
+    hands = len(para_lr)
+    B = para_lr[0].shape[0]
+    para = [_capi.f32c(p) for p in para_lr]
+    _capi.require_cuda(*para)
+    P = C.c_void_p * hands
+
+    def arr(ts, off=0):
+        if ts is None:
+            return None
+        keep.extend(t for t in ts if t is not None)
+        return P(*[(None if t is None else t.data_ptr() + off) for t in ts])
+    keep = []
+    gs = [[None if g is None else _capi.f32c(t) for t in (g if g is not None else [None] * hands)] for g in (g_verts, g_joints, g_joint_uv, g_mesh_uv)]
+    out = [torch.zeros(B, 64, device=para[0].device) for _ in range(hands)]
+    tabs = (_capi.ManoTables * hands)(*tables_lr)
+    _capi.check(_capi.lib().dir_mano_backward_pair(
+        tabs, arr(para), 64, arr(para, 51 * 4), 64, arr(para, 61 * 4), 64,
+        arr(gs[0]) if g_verts is not None else None, arr(gs[1]) if g_joints is not None else None,
+        arr(gs[2]) if g_joint_uv is not None else None, arr(gs[3]) if g_mesh_uv is not None else None,
+        arr(out), 64, arr(out, 51 * 4), 64, arr(out, 61 * 4), 64, hands, B, _capi.stream_ptr()), 'dir_mano_backward_pair')
+    return out

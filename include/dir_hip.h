@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 15
+#define DIR_ABI_VERSION 16
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -90,6 +90,19 @@ int dir_mano_forward_pair(const dir_mano_tables* tables_lr_host, const float* co
                           const float* const* betas_lr_host, int betas_stride, const float* const* cam_lr_host,
                           int cam_stride, float* const* verts_lr_host, float* const* joints_lr_host,
                           float* const* joint_uv_lr_host, int32_t* const* flags_lr_host, int B, void* stream);
+
+/* SURVEY 8f rank 2, backward pass, first link behind the loss gradients: the gradient of
+ *   <g_verts, verts> + <g_joints, joints> + <g_joint_uv, joint_uv> + <g_mesh_uv, mesh_uv>
+ * w.r.t. pose [B,51], betas [B,10] and cam [B,3] of dir_mano_forward -- what torch autograd computes through
+ * manopth/manopth/manolayer.py:110-270 and utils/utils.py:47-63 in the reference's training step (train.py:66-70).
+ * The *_lr arguments are HOST arrays of `hands` (1 or 2) device pointers; any g_* input may be NULL (or hold NULL) = no
+ * contribution.  Inputs as for the forward (the forward is recomputed, nothing has to be saved).  Deterministic (no atomics). */
+int dir_mano_backward_pair(const dir_mano_tables* tables_lr_host, const float* const* pose_lr_host, int pose_stride,
+                           const float* const* betas_lr_host, int betas_stride, const float* const* cam_lr_host, int cam_stride,
+                           const float* const* g_verts_lr_host, const float* const* g_joints_lr_host,
+                           const float* const* g_joint_uv_lr_host, const float* const* g_mesh_uv_lr_host,
+                           float* const* g_pose_lr_host, int g_pose_stride, float* const* g_betas_lr_host, int g_betas_stride,
+                           float* const* g_cam_lr_host, int g_cam_stride, int hands, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores

@@ -537,7 +537,34 @@ def gen_loss_grad():
     save('g12_loss_grad', **out)
 
 
-GENS = {'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G13 gradients through the MANO layer + projection
+def gen_mano_grad():
+    """torch autograd through the reference's own manopth ManoLayer (manopth/manopth/manolayer.py:110-270) and projection_batch_xy
+    (utils/utils.py:47-63), composed as RegressorOffset.forward does (models/dir.py:352-363): d <cotangents, outputs> / d para[64]"""
+    from manopth.manolayer import ManoLayer
+    from utils.utils import projection_batch_xy
+    from oracle.golden_inputs import MANO_GRAD_CASES, mano_grad_inputs
+    out = {}
+    for side in ('left', 'right'):
+        for case, center in MANO_GRAD_CASES:
+            layer = ManoLayer(root_rot_mode='6D', joint_rot_mode='axisang', use_pca=True, mano_root='unused', side=side, ncomps=45,
+                              center_idx=(None if center < 0 else center), flat_hand_mean=False, robust_rot=True)
+            para_np, cot = mano_grad_inputs(case, side)
+            para = torch.from_numpy(para_np).requires_grad_(True)
+            pose, beta, cam = torch.split(para, [51, 10, 3], dim=-1)
+            verts, joints = layer(pose, beta)
+            juv = projection_batch_xy(cam[:, 0], cam[:, 1:], joints)
+            muv = projection_batch_xy(cam[:, 0], cam[:, 1:], verts)
+            tag = '%s_%s_c%d' % (side, case, center)
+            for sel in ('all', 'verts', 'joints', 'joint_uv', 'mesh_uv'):
+                terms = {'verts': verts, 'joints': joints, 'joint_uv': juv, 'mesh_uv': muv}
+                L = sum((terms[k] * torch.from_numpy(cot[k])).sum() for k in terms if sel in ('all', k))
+                g, = torch.autograd.grad(L, para, retain_graph=True)
+                out['%s.%s' % (tag, sel)] = g
+    save('g13_mano_grad', **out)
+
+
+GENS = {'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

@@ -112,3 +112,18 @@ def gtmano_inputs(case, B=5):
                                                    np.array([0, 0, 0.7], np.float32))
     scale = (1 + 0.1 * synth.synth_input('gtmano.scale.' + name, (B,), SEED)).astype(np.float32) if case[4] else None
     return R, pose, shape, trans, scale
+
+
+MANO_GRAD_CASES = [('normal', 0), ('normal', 9), ('normal', -1), ('large', 0), ('zero_pose', 0)]
+
+
+def mano_grad_inputs(case, side, B=3):
+    """64-vectors (pose 51 | betas 10 | cam 3) and cotangents of the four outputs a regressor derives from them (models/dir.py:352-363)"""
+    pose, betas = mano_inputs(case, B)
+    cam = synth.synth_input('manograd.cam.%s.%s' % (case, side), (B, 3), SEED) * np.float32(0.3) + np.array([1.2, 0.0, 0.0], np.float32)
+    para = np.concatenate([pose, betas, cam], 1).astype(np.float32)
+    cot = {'verts': synth.synth_input('manograd.gv.%s.%s' % (case, side), (B, 778, 3), SEED),
+           'joints': synth.synth_input('manograd.gj.%s.%s' % (case, side), (B, 21, 3), SEED),
+           'joint_uv': synth.synth_input('manograd.gju.%s.%s' % (case, side), (B, 21, 2), SEED),
+           'mesh_uv': synth.synth_input('manograd.gmu.%s.%s' % (case, side), (B, 778, 2), SEED)}
+    return para, cot

@@ -29,6 +29,12 @@ if __name__ == '__main__':
         t0 = time.perf_counter()
         write_split(d, 256, seed=1)
         print('wrote 256 synthetic 256x256 JPEGs + annotations in %.1f s (re-used cyclically as a %d-image split)' % (time.perf_counter() - t0, n))
+        print('host cores usable by this process: %d (os.cpu_count() = %d)' % (len(os.sched_getaffinity(0)), os.cpu_count()))
+        t0 = time.perf_counter()
+        ds = DS.InterHandSplit(d)
+        for i in range(64):
+            ds.frame(i)
+        print('one process decodes %.0f frames/s' % (64 / (time.perf_counter() - t0)))
         eng = DirEngine(state, dtype=torch.bfloat16)
         mano = DS.gt_layers_from_checkpoint(state)
         jreg = {s: EV.Jr(mano[s].J_regressor) for s in ('left', 'right')}
