@@ -167,3 +167,17 @@ def mano_backward(tables_lr, para_lr, g_verts=None, g_joints=None, g_joint_uv=No
         arr(gs[2]) if g_joint_uv is not None else None, arr(gs[3]) if g_mesh_uv is not None else None,
         arr(out), 64, arr(out, 51 * 4), 64, arr(out, 61 * 4), 64, hands, B, _capi.stream_ptr()), 'dir_mano_backward_pair')
     return out
+
+
+def regress_backward(w_left, w_right, w_offset, tok, prev_para_left, prev_para_right, prev_offset, g_para_left, g_para_right, g_offset):
+    """dir_regress_backward -> dict of the six parameter gradients (nn.Linear layout) and g_tok [B,42,64]"""
+    ts = [_capi.f32c(t) for t in (w_left, w_right, w_offset, tok, prev_para_left, prev_para_right, prev_offset.reshape(-1, 3), g_para_left, g_para_right, g_offset)]
+    _capi.require_cuda(*ts)
+    B, dev = ts[3].shape[0], ts[3].device
+    out = {'mano_left.weight': torch.empty(64, 1408, device=dev), 'mano_left.bias': torch.empty(64, device=dev),
+           'mano_right.weight': torch.empty(64, 1408, device=dev), 'mano_right.bias': torch.empty(64, device=dev),
+           'offset.weight': torch.empty(3, 2691, device=dev), 'offset.bias': torch.empty(3, device=dev), 'tok': torch.empty(B, 42, 64, device=dev)}
+    _capi.check(_capi.lib().dir_regress_backward(*[_capi.ptr(t) for t in ts], _capi.ptr(out['mano_left.weight']), _capi.ptr(out['mano_left.bias']),
+                                                 _capi.ptr(out['mano_right.weight']), _capi.ptr(out['mano_right.bias']), _capi.ptr(out['offset.weight']),
+                                                 _capi.ptr(out['offset.bias']), _capi.ptr(out['tok']), B, _capi.stream_ptr()), 'dir_regress_backward')
+    return out

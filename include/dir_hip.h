@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 16
+#define DIR_ABI_VERSION 17
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -103,6 +103,16 @@ int dir_mano_backward_pair(const dir_mano_tables* tables_lr_host, const float* c
                            const float* const* g_joint_uv_lr_host, const float* const* g_mesh_uv_lr_host,
                            float* const* g_pose_lr_host, int g_pose_stride, float* const* g_betas_lr_host, int g_betas_stride,
                            float* const* g_cam_lr_host, int g_cam_stride, int hands, int B, void* stream);
+
+/* Backward of RegressorOffset's three Linears (models/dir.py:339-351).  w_left / w_right [64][1408], w_offset [3][2691]: the
+ * nn.Linear weights in their own layout; tok [B,42,64] = the STE head output (tokens 0..20 left); prev_* the previous stage's
+ * (detached) mano_para [B,64] / offset [B,3]; g_para_* [B,64], g_offset [B,3]: gradients w.r.t. the Linears' outputs.
+ * Outputs (gw_* / gb_* in the parameters' layout, written not accumulated; all six or none) and g_tok [B,42,64] (optional). */
+int dir_regress_backward(const float* w_left, const float* w_right, const float* w_offset, const float* tok,
+                         const float* prev_para_left, const float* prev_para_right, const float* prev_offset,
+                         const float* g_para_left, const float* g_para_right, const float* g_offset,
+                         float* gw_left, float* gb_left, float* gw_right, float* gb_right, float* gw_offset, float* gb_offset,
+                         float* g_tok, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores

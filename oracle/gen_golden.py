@@ -564,7 +564,39 @@ def gen_mano_grad():
     save('g13_mano_grad', **out)
 
 
-GENS = {'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G14 gradients through RegressorOffset
+def gen_regress_grad():
+    """torch autograd through the reference's RegressorOffset (models/dir.py:312-381: three Linears -> two manopth layers -> four
+    projections): d <cotangents, outputs> / d (sampled features, the six Linear parameters)."""
+    from models.dir import RegressorOffset
+    from oracle.golden_inputs import REGRESS_OUT_KEYS, regress_grad_inputs
+    net = RegressorOffset(21 * 64, 'unused', 0)
+    load_synth(net)              # (the synthetic Linear weights give O(1) parameters: the MANO layers are driven well away from the rest pose)
+    ins, cot = regress_grad_inputs()
+    t = {k: torch.from_numpy(v) for k, v in ins.items()}
+    fl, fr = t['feat_l'].requires_grad_(True), t['feat_r'].requires_grad_(True)
+    out = net(fl, fr, t['para_l'], t['para_r'], t['offset'])
+    L = sum((out[k] * torch.from_numpy(cot[k])).sum() for k in REGRESS_OUT_KEYS)
+    params = {'mano_left.weight': net.mano_left.weight, 'mano_left.bias': net.mano_left.bias, 'mano_right.weight': net.mano_right.weight,
+              'mano_right.bias': net.mano_right.bias, 'offset.weight': net.offset.weight, 'offset.bias': net.offset.bias}
+    gs = torch.autograd.grad(L, [fl, fr] + list(params.values()))
+    res = {'grad.feat_l': gs[0], 'grad.feat_r': gs[1]}
+    for k, g in zip(params, gs[2:]):          # the two [64,1408] weight gradients: every 4th column + row / column sums (fixture size)
+        if g.dim() == 1 or g.shape[0] == 3:
+            res['grad.' + k] = g
+        else:
+            res['grad.' + k + '.cols4'] = g[:, ::4].contiguous()
+            res['grad.' + k + '.rowsum'] = g.double().sum(1)
+            res['grad.' + k + '.colsum'] = g.double().sum(0)
+    res.update({'out.pd_mano_para_left': out['pd_mano_para_left'].detach(), 'out.pd_mano_para_right': out['pd_mano_para_right'].detach(),
+                'out.pd_offset': out['pd_offset'].detach()})
+    shapes = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(OUT, 'manifest_regressor.json'), 'w') as f:
+        json.dump(shapes, f, indent=0)
+    save('g14_regress_grad', **res)
+
+
+GENS = {'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

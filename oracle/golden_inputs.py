@@ -127,3 +127,19 @@ def mano_grad_inputs(case, side, B=3):
            'joint_uv': synth.synth_input('manograd.gju.%s.%s' % (case, side), (B, 21, 2), SEED),
            'mesh_uv': synth.synth_input('manograd.gmu.%s.%s' % (case, side), (B, 778, 2), SEED)}
     return para, cot
+
+
+REGRESS_OUT_KEYS = ('pd_offset', 'pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_uv_left', 'pd_mesh_uv_right', 'pd_joint_xyz_left',
+                    'pd_joint_xyz_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right')
+
+
+def regress_grad_inputs(B=4):
+    """inputs of RegressorOffset.forward (models/dir.py:339) and cotangents of the outputs the training objective reads (:571-592)"""
+    g = lambda n, shp: synth.synth_input('regressgrad.' + n, shp, SEED)  # noqa: E731
+    ins = dict(feat_l=g('fl', (B, 21, 64)), feat_r=g('fr', (B, 21, 64)), para_l=g('pl', (B, 64)) * np.float32(0.3), para_r=g('pr', (B, 64)) * np.float32(0.3),
+               offset=g('off', (B, 1, 3)))
+    shp = {'pd_offset': (B, 3)}
+    for s_ in ('left', 'right'):
+        shp.update({'pd_joint_uv_' + s_: (B, 21, 2), 'pd_mesh_uv_' + s_: (B, 778, 2), 'pd_joint_xyz_' + s_: (B, 21, 3), 'pd_mesh_xyz_' + s_: (B, 778, 3)})
+    cot = {k: g('cot.' + k, shp[k]) for k in REGRESS_OUT_KEYS}
+    return ins, cot

@@ -87,3 +87,63 @@ def test_mano_backward_without_projection():
                                                       p[:, :51], p[:, 51:61], 'right', 9), para.astype(np.float64), (cot['verts'], cot['joints']))
     got = out.cpu().numpy()
     assert np.abs(got[:, :61] - ref[:, :61]).max() / np.abs(ref).max() < 1e-5 and float(np.abs(got[:, 61:]).max()) == 0.0
+
+
+def test_regressor_backward_chain_vs_reference_autograd(golden):
+    """G14 = torch autograd through the reference's RegressorOffset (three Linears -> two MANO layers -> four projections).  HIP chain:
+    dir_regress_forward -> dir_mano_backward_pair (cotangents of the MANO outputs -> g mano_para) -> dir_regress_backward (parameter
+    gradients in nn.Linear layout + the gradient w.r.t. the joint tokens)."""
+    import ctypes as C
+    import json
+    import os
+    from conftest import GOLDEN, maxabs
+    from dir_amd import _capi
+    from oracle import nnops as N
+    from oracle import tokens as OT
+    from oracle.golden_inputs import regress_grad_inputs
+    g = golden('g14_regress_grad')
+    with open(os.path.join(GOLDEN, 'manifest_regressor.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sdn = synth.synth_state_dict(shapes, SEED)
+    sd = {('r.' + k): dev(v) for k, v in sdn.items()}
+    keep = []
+    Ts = [engine.pack_mano(sd, 'r.mano_layer_left', 'left', 0, keep), engine.pack_mano(sd, 'r.mano_layer_right', 'right', 0, keep)]
+    ins, cot = regress_grad_inputs()
+    B = ins['feat_l'].shape[0]
+    tok = dev(np.concatenate([ins['feat_l'], ins['feat_r']], 1))
+    # forward of the three Linears on the GPU: the regressor kernel of the engine (k-major packed weights)
+    R = _capi.RegressParams()
+    t = dict(wt=torch.cat([sd['r.mano_left.weight'].t(), sd['r.mano_right.weight'].t()], 1).contiguous(), bl=sd['r.mano_left.bias'], br=sd['r.mano_right.bias'],
+             wo=sd['r.offset.weight'], bo=sd['r.offset.bias'])
+    R.mano_wt, R.mano_b[0], R.mano_b[1], R.off_w, R.off_b = t['wt'].data_ptr(), t['bl'].data_ptr(), t['br'].data_ptr(), t['wo'].data_ptr(), t['bo'].data_ptr()
+    zero = {k: torch.zeros(64 if k != 'w2t' else 64 * 64, device='cuda') for k in ('w1t', 's1', 'b1', 'w2t', 'b2')}
+    zero['w1t'] = torch.zeros(64 * 64, device='cuda')
+    R.emb = _capi.TokenMlp(*(zero[k].data_ptr() for k in ('w1t', 's1', 'b1', 'w2t', 'b2')))
+    pl, pr, off, emb = (torch.empty(B, 64, device='cuda'), torch.empty(B, 64, device='cuda'), torch.empty(B, 3, device='cuda'), torch.empty(B, 42, 64, device='cuda'))
+    dpl, dpr, doff = dev(ins['para_l']), dev(ins['para_r']), dev(ins['offset'].reshape(B, 3))
+    _capi.check(_capi.lib().dir_regress_forward(C.byref(R), _capi.ptr(tok), _capi.ptr(dpl), _capi.ptr(dpr), _capi.ptr(doff), _capi.ptr(pl), _capi.ptr(pr),
+                                                _capi.ptr(off), _capi.ptr(emb), B, _capi.stream_ptr()), 'regress')
+    assert maxabs(pl.cpu().numpy(), g['out.pd_mano_para_left']) < 2e-5 and maxabs(off.cpu().numpy(), g['out.pd_offset']) < 2e-5
+    gp = F.mano_backward(Ts, [pl, pr], g_verts=[dev(cot['pd_mesh_xyz_left']), dev(cot['pd_mesh_xyz_right'])],
+                         g_joints=[dev(cot['pd_joint_xyz_left']), dev(cot['pd_joint_xyz_right'])],
+                         g_joint_uv=[dev(cot['pd_joint_uv_left']), dev(cot['pd_joint_uv_right'])],
+                         g_mesh_uv=[dev(cot['pd_mesh_uv_left']), dev(cot['pd_mesh_uv_right'])])
+    got = F.regress_backward(sd['r.mano_left.weight'], sd['r.mano_right.weight'], sd['r.offset.weight'], tok, dpl, dpr, doff, gp[0], gp[1],
+                             dev(cot['pd_offset']))
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / np.abs(b).max())  # noqa: E731
+    gt = got['tok'].cpu().numpy()
+    worst = max(rel(gt[:, :21], g['grad.feat_l']), rel(gt[:, 21:], g['grad.feat_r']))
+    for k in ('mano_left.bias', 'mano_right.bias', 'offset.weight', 'offset.bias'):
+        worst = max(worst, rel(got[k].cpu().numpy(), g['grad.' + k]))
+    for k in ('mano_left.weight', 'mano_right.weight'):
+        w = got[k].cpu().numpy()
+        worst = max(worst, rel(w[:, ::4], g['grad.' + k + '.cols4']), rel(w.astype(np.float64).sum(1), g['grad.' + k + '.rowsum']),
+                    rel(w.astype(np.float64).sum(0), g['grad.' + k + '.colsum']))
+    print('regressor backward chain vs torch autograd through the reference: worst %.2e of each gradient maximum' % worst)
+    assert worst < 1e-5
+    # and against the float64 oracle (analytic Linears + central differences through MANO)
+    from oracle import grad as OG
+    P = N.Params(sdn)
+    ref = OG.regressor_vjp(P, OT.mano_bufs(P, 'left'), OT.mano_bufs(P, 'right'), ins['feat_l'], ins['feat_r'], ins['para_l'], ins['para_r'], ins['offset'], cot)
+    assert rel(gp[0].cpu().numpy(), ref['g_para_left']) < 1e-5 and rel(got['mano_left.weight'].cpu().numpy(), ref['mano_left.weight']) < 1e-5
+    assert rel(gt[:, 21:], ref['feat_r']) < 1e-5

@@ -345,3 +345,45 @@ def test_stock_torch_dense_ops_equal_the_numpy_oracle():
         for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_uv_right'):
             assert maxabs(a[i][k], b[i][k]) < 2e-6, (i, k)
     assert relerr(a[3]['seg'], b[3]['seg']) < 1e-3 and relerr(a[3]['proj_feat'], b[3]['proj_feat']) < 1e-3
+
+
+# ------------------------------------------------------------------ G13 / G14 gradients (backward pass)
+def test_mano_gradient_oracle_matches_reference_autograd(golden):
+    """oracle/grad.py (central differences in float64 on the numpy forward) vs torch autograd through the reference's manopth layer"""
+    from oracle import grad as OG
+    from oracle.golden_inputs import MANO_GRAD_CASES, mano_grad_inputs
+    g = golden('g13_mano_grad')
+    for side in ('left', 'right'):
+        buf = synth.mano_buffers(side, SEED)
+        for case, center in MANO_GRAD_CASES[:3]:
+            para, cot = mano_grad_inputs(case, side)
+            for sel in ('all', 'joint_uv'):
+                kw = {('g_' + k): cot[k] for k in cot if sel in ('all', k)}
+                got = OG.mano_vjp(buf, para.astype(np.float64), side, None if center < 0 else center, **kw)
+                ref = g['%s_%s_c%d.%s' % (side, case, center, sel)]
+                assert maxabs(got, ref) < 1e-6 * np.abs(ref).max(), (side, case, center, sel)
+
+
+def regressor_fixture():
+    shapes = shapes_of('manifest_regressor.json')
+    return synth.synth_state_dict(shapes, SEED)
+
+
+def test_regressor_gradient_oracle_matches_reference_autograd(golden):
+    from oracle import grad as OG
+    from oracle.golden_inputs import regress_grad_inputs
+    g = golden('g14_regress_grad')
+    sd = regressor_fixture()
+    P = N.Params(sd)
+    ins, cot = regress_grad_inputs()
+    out = OT.regressor_offset(ins['feat_l'], ins['feat_r'], ins['para_l'], ins['para_r'], ins['offset'], P, OT.mano_bufs(P, 'left'), OT.mano_bufs(P, 'right'))
+    assert maxabs(out['pd_mano_para_left'], g['out.pd_mano_para_left']) < 1e-5 and maxabs(out['pd_offset'], g['out.pd_offset']) < 1e-5
+    got = OG.regressor_vjp(P, OT.mano_bufs(P, 'left'), OT.mano_bufs(P, 'right'), ins['feat_l'], ins['feat_r'], ins['para_l'], ins['para_r'],
+                           ins['offset'], cot)
+    for k in ('feat_l', 'feat_r', 'mano_left.bias', 'mano_right.bias', 'offset.weight', 'offset.bias'):
+        assert maxabs(got[k], g['grad.' + k]) < 2e-6 * np.abs(g['grad.' + k]).max(), k
+    for k in ('mano_left.weight', 'mano_right.weight'):
+        ref = g['grad.' + k + '.cols4']
+        assert maxabs(got[k][:, ::4], ref) < 2e-6 * np.abs(ref).max(), k
+        assert maxabs(got[k].sum(1), g['grad.' + k + '.rowsum']) < 2e-6 * np.abs(g['grad.' + k + '.rowsum']).max()
+        assert maxabs(got[k].sum(0), g['grad.' + k + '.colsum']) < 2e-6 * np.abs(g['grad.' + k + '.colsum']).max()
