@@ -41,6 +41,11 @@ class BneckTailParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('wstream', 'scale3', 'shift3', 'scale1n', 'shift1n')] + [('planes', C.c_int32), ('n_next', C.c_int32), ('waves', C.c_int32)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'trans_a', 'trans_b', 'accumulate', 'batch')] + \
+               [(n, C.c_int64) for n in ('stride_a', 'stride_b', 'stride_c')]
+
+
 class TokenMlp(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w1t', 's1', 'b1', 'w2t', 'b2')]
 
@@ -100,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 17          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 18          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -150,6 +155,16 @@ _SIGNATURES = {
     'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p]),
     'dir_mano_backward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     'dir_regress_backward': (C.c_int, [_p] * 17 + [_i, _p]),
+    'dir_gemm_f32': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p]),
+    'dir_colsum_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
+    'dir_layernorm_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _p]),
+    'dir_layernorm_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'dir_gelu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),
+    'dir_gelu_backward': (C.c_int, [_p, _p, _p, C.c_longlong, _p]),
+    'dir_attention_forward': (C.c_int, [_p, _p, _p, _i, _i, _i, C.c_float, _p]),
+    'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
+    'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p]),
+    'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
 

@@ -1,0 +1,361 @@
+// Building blocks of the backward pass over the joint-token path (reference: train.py:66-70 runs
+// torch autograd through transformer/mixSTE.py, SemGCN/p_graph_conv.py and the nn.Conv1d / nn.Linear / nn.LayerNorm / nn.BatchNorm1d
+// modules of models/dir.py:19-130).  The token path is ~0.1 GFLOP per image: these are plain, exact-fp32, deterministic kernels
+// (fixed summation orders, no atomics) -- correctness and reproducibility first; they are composed by dir_amd/train/*.py.
+//
+//   dir_gemm_f32              C = op(A) op(B) (+ bias | + C), batched / strided, exact fp32 on v_mfma_f32_16x16x4_f32
+//   dir_colsum_f32            bias gradients: column sums of a [R, N] matrix
+//   dir_layernorm_forward / _backward    nn.LayerNorm over the last dimension (mixSTE.py:177: eps 1e-6; head: 1e-5)
+//   dir_gelu_forward / _backward         exact-erf GELU (mixSTE.py:12,27)
+//   dir_attention_forward / _backward    softmax(q k^T * scale) v per (sample, head) (mixSTE.py:76-97)
+//   dir_bn_train_forward / _backward     BatchNorm1d / 2d in training mode over [R rows, C channels] (batch statistics, running update)
+#include "dir_common.h"
+#include "dir_mfma.h"
+
+#include <math.h>
+
+namespace {
+
+using dir::f32x4;
+
+// ------------------------------------------------------------------------------------------------------------------ GEMM
+struct GemmArgs {
+    const float* A; const float* B; const float* bias; float* C;
+    int M, N, K, lda, ldb, ldc, ta, tb, accumulate;
+    long long sA, sB, sC;
+};
+constexpr int GT = 64, GK = 16, GLD = GK + 1;      // 64 x 64 tile, K step 16; LDS rows padded (17 floats: conflict-free column reads)
+
+// 256 threads = 4 waves; wave w owns rows 16w .. 16w+15 of the tile and all 64 columns (4 accumulators of 16x16).
+// A tile [64][16] (row m, k) and B tile stored transposed [64][16] (column n, k): both MFMA operands read along k.
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
+    __shared__ float s_a[GT * GLD], s_b[GT * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const float* A = a.A + blockIdx.z * a.sA;
+    const float* B = a.B + blockIdx.z * a.sB;
+    float* C = a.C + blockIdx.z * a.sC;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4;
+    for (int k0 = 0; k0 < a.K; k0 += GK) {
+        // stage: 64 x 16 elements of each operand, 4 per thread; the faster-varying thread index follows the contiguous dimension
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            int r, k;
+            if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }          // A[m][k] (ta = 0) or A[k][m] (ta = 1)
+            const int m = m0 + r, kk = k0 + k;
+            float v = 0.f;
+            if (m < a.M && kk < a.K) v = a.ta ? A[(long long)kk * a.lda + m] : A[(long long)m * a.lda + kk];
+            s_a[r * GLD + k] = v;
+            int c, k2;
+            if (a.tb) { k2 = e & 15; c = e >> 4; } else { c = e & 63; k2 = e >> 6; }        // B[k][n] (tb = 0) or B[n][k] (tb = 1)
+            const int n = n0 + c, kb = k0 + k2;
+            float w = 0.f;
+            if (n < a.N && kb < a.K) w = a.tb ? B[(long long)n * a.ldb + kb] : B[(long long)kb * a.ldb + n];
+            s_b[c * GLD + k2] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            const float av = s_a[(16 * wave + li) * GLD + 4 * ks + lk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bv = s_b[(16 * j + li) * GLD + 4 * ks + lk];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D layout: lane holds column n0 + 16 j + li, rows m0 + 16 wave + 4 lk + r
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * j + li;
+        if (n >= a.N) continue;
+        const float bz = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * lk + r;
+            if (m >= a.M) continue;
+            float* p = C + (long long)m * a.ldc + n;
+            *p = a.accumulate ? *p + (acc[j][r] + bz) : acc[j][r] + bz;
+        }
+    }
+}
+
+// column sums of X [R, N] (row stride ld): one thread per column, rows in order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int R, int N, int ld, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) acc += x[(long long)r * ld + n];
+    out[n] = accumulate ? out[n] + acc : acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row, C <= 256 (4 values per lane).  Statistics as torch: mean, biased variance (two passes in registers).
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                                                           int R, int C, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* xr = x + (long long)row * C;
+    float v[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; v[i] = c < C ? xr[c] : 0.f; s += v[i]; }
+    const float mu = dir::wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; const float d = c < C ? v[i] - mu : 0.f; q += d * d; }
+    const float rs = 1.f / sqrtf(dir::wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = lane + 64 * i; if (c < C) y[(long long)row * C + c] = (v[i] - mu) * rs * w[c] + b[c]; }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+// g x = rstd (g^ - mean(g^) - x^ mean(g^ x^)), g^ = g y * w
+__global__ __launch_bounds__(256) void layernorm_bwd_x_kernel(const float* gy, const float* x, const float* w, const float* mean, const float* rstd,
+                                                             float* gx, int R, int C, int accumulate) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float mu = mean[row], rs = rstd[row];
+    float gh[4], xh[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        gh[i] = c < C ? gy[(long long)row * C + c] * w[c] : 0.f;
+        xh[i] = c < C ? (x[(long long)row * C + c] - mu) * rs : 0.f;
+        s1 += gh[i]; s2 += gh[i] * xh[i];
+    }
+    s1 = dir::wave_sum(s1) / C; s2 = dir::wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) { float* p = gx + (long long)row * C + c; const float v = rs * (gh[i] - s1 - xh[i] * s2); *p = accumulate ? *p + v : v; }
+    }
+}
+// g w[c] = sum_rows g y x^ ; g b[c] = sum_rows g y : one thread per column, rows in order
+__global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const float* gy, const float* x, const float* mean, const float* rstd, float* gw, float* gb,
+                                                              int R, int C, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float aw = 0.f, ab = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float g = gy[(long long)r * C + c];
+        aw = fmaf(g, (x[(long long)r * C + c] - mean[r]) * rstd[r], aw);
+        ab += g;
+    }
+    gw[c] = accumulate ? gw[c] + aw : aw;
+    gb[c] = accumulate ? gb[c] + ab : ab;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ GELU (exact erf)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* x, float* y, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* gy, const float* x, float* gx, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const float v = x[i];
+        const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+        const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
+        gx[i] = gy[i] * (cdf + v * pdf);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ attention
+// qkv [B, T, 3, H, D] (nn.Linear output of mixSTE.py:77), T <= 64, D = 32.  One workgroup per (sample, head).
+constexpr int AT = 64, AD = 32;
+struct AttnArgs { const float* qkv; float* probs; float* out; const float* gout; float* gqkv; int B, T, H; float scale; };
+
+__global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs a) {
+    __shared__ float s_q[AT * (AD + 1)], s_k[AT * (AD + 1)], s_v[AT * (AD + 1)], s_p[AT * (AT + 1)];
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H, tid = threadIdx.x, T = a.T, C = a.H * AD;
+    for (int e = tid; e < T * AD; e += 256) {
+        const int t = e / AD, d = e - t * AD;
+        const float* p = a.qkv + ((long long)(b * T + t) * 3) * C + h * AD + d;
+        s_q[t * (AD + 1) + d] = p[0]; s_k[t * (AD + 1) + d] = p[C]; s_v[t * (AD + 1) + d] = p[2 * C];
+    }
+    __syncthreads();
+    for (int e = tid; e < T * T; e += 256) {
+        const int i = e / T, j = e - i * T;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < AD; ++d) acc = fmaf(s_q[i * (AD + 1) + d], s_k[j * (AD + 1) + d], acc);
+        s_p[i * (AT + 1) + j] = acc * a.scale;
+    }
+    __syncthreads();
+    if (tid < T) {            // softmax of row tid (max-subtracted, as torch)
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) mx = fmaxf(mx, s_p[tid * (AT + 1) + j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { const float ev = expf(s_p[tid * (AT + 1) + j] - mx); s_p[tid * (AT + 1) + j] = ev; sum += ev; }
+        for (int j = 0; j < T; ++j) s_p[tid * (AT + 1) + j] /= sum;
+    }
+    __syncthreads();
+    if (a.probs)
+        for (int e = tid; e < T * T; e += 256) a.probs[((long long)(b * a.H + h) * T + e / T) * T + e % T] = s_p[(e / T) * (AT + 1) + e % T];
+    for (int e = tid; e < T * AD; e += 256) {
+        const int i = e / AD, d = e - i * AD;
+        float acc = 0.f;
+        for (int j = 0; j < T; ++j) acc = fmaf(s_p[i * (AT + 1) + j], s_v[j * (AD + 1) + d], acc);
+        a.out[(long long)(b * T + i) * C + h * AD + d] = acc;            // (attn @ v).transpose(1, 2).reshape(B, N, C)
+    }
+}
+
+// g v = P^T g o ; g P = g o v^T ; g S = P (g P - rowsum(g P P)) ; g q = g S k scale ; g k = g S^T q scale
+__global__ __launch_bounds__(256) void attention_bwd_kernel(AttnArgs a) {
+    __shared__ float s_q[AT * (AD + 1)], s_k[AT * (AD + 1)], s_v[AT * (AD + 1)], s_go[AT * (AD + 1)], s_p[AT * (AT + 1)], s_gs[AT * (AT + 1)];
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H, tid = threadIdx.x, T = a.T, C = a.H * AD;
+    for (int e = tid; e < T * AD; e += 256) {
+        const int t = e / AD, d = e - t * AD;
+        const float* p = a.qkv + ((long long)(b * T + t) * 3) * C + h * AD + d;
+        s_q[t * (AD + 1) + d] = p[0]; s_k[t * (AD + 1) + d] = p[C]; s_v[t * (AD + 1) + d] = p[2 * C];
+        s_go[t * (AD + 1) + d] = a.gout[(long long)(b * T + t) * C + h * AD + d];
+    }
+    for (int e = tid; e < T * T; e += 256) s_p[(e / T) * (AT + 1) + e % T] = a.probs[((long long)(b * a.H + h) * T + e / T) * T + e % T];
+    __syncthreads();
+    for (int e = tid; e < T * T; e += 256) {          // g P
+        const int i = e / T, j = e - i * T;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < AD; ++d) acc = fmaf(s_go[i * (AD + 1) + d], s_v[j * (AD + 1) + d], acc);
+        s_gs[i * (AT + 1) + j] = acc;
+    }
+    __syncthreads();
+    if (tid < T) {            // softmax backward, row tid; the scale of S = q k^T * scale folded in
+        float dot = 0.f;
+        for (int j = 0; j < T; ++j) dot = fmaf(s_gs[tid * (AT + 1) + j], s_p[tid * (AT + 1) + j], dot);
+        for (int j = 0; j < T; ++j) s_gs[tid * (AT + 1) + j] = s_p[tid * (AT + 1) + j] * (s_gs[tid * (AT + 1) + j] - dot) * a.scale;
+    }
+    __syncthreads();
+    for (int e = tid; e < T * AD; e += 256) {
+        const int i = e / AD, d = e - i * AD;
+        float gq = 0.f, gk = 0.f, gv = 0.f;
+        for (int j = 0; j < T; ++j) {
+            gq = fmaf(s_gs[i * (AT + 1) + j], s_k[j * (AD + 1) + d], gq);
+            gk = fmaf(s_gs[j * (AT + 1) + i], s_q[j * (AD + 1) + d], gk);
+            gv = fmaf(s_p[j * (AT + 1) + i], s_go[j * (AD + 1) + d], gv);
+        }
+        float* p = a.gqkv + ((long long)(b * T + i) * 3) * C + h * AD + d;
+        p[0] = gq; p[C] = gk; p[2 * C] = gv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ BatchNorm (training)
+// x [R, C] (channels last: rows = samples x positions).  One thread per channel, rows in order (R is small on the token path).
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
+                                                          float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(long long)r * ld + c];
+    const float mu = s / R;
+    float q = 0.f;
+    for (int r = 0; r < R; ++r) { const float d = x[(long long)r * ld + c] - mu; q = fmaf(d, d, q); }
+    const float var = q / R, rs = 1.f / sqrtf(var + eps);
+    const float g = w ? w[c] : 1.f, be = b ? b[c] : 0.f;
+    for (int r = 0; r < R; ++r) y[(long long)r * ld + c] = (x[(long long)r * ld + c] - mu) * rs * g + be;
+    save_mean[c] = mu; save_rstd[c] = rs;
+    if (running_mean) {       // torch: running = (1 - momentum) running + momentum stat, with the UNBIASED variance
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (R > 1 ? q / (R - 1) : var);
+    }
+}
+// g x = w rstd (g y - mean(g y) - x^ mean(g y x^)) ; g w = sum g y x^ ; g b = sum g y
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd,
+                                                          float* gx, float* gw, float* gb, int R, int C, int ld) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = save_mean[c], rs = save_rstd[c], g = w ? w[c] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float gv = gy[(long long)r * ld + c];
+        s1 += gv; s2 = fmaf(gv, (x[(long long)r * ld + c] - mu) * rs, s2);
+    }
+    if (gw) gw[c] = s2;
+    if (gb) gb[c] = s1;
+    const float m1 = s1 / R, m2 = s2 / R;
+    if (gx)
+        for (int r = 0; r < R; ++r)
+            gx[(long long)r * ld + c] = g * rs * (gy[(long long)r * ld + c] - m1 - (x[(long long)r * ld + c] - mu) * rs * m2);
+}
+
+}  // namespace
+
+extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(d && A && B && C, "dir_gemm_f32: null pointer");
+    DIR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->lda > 0 && d->ldb > 0 && d->ldc >= d->N, "dir_gemm_f32: bad shape");
+    GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c};
+    DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, d->batch), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("dir_gemm_f32");
+}
+
+extern "C" int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, int accumulate, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && out && R > 0 && N > 0 && ld >= N, "dir_colsum_f32: bad arguments");
+    DIR_LAUNCH(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, R, N, ld, accumulate);
+    return check_launch("dir_colsum_f32");
+}
+
+extern "C" int dir_layernorm_forward(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int R, int C, float eps, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && w && b && y && mean && rstd && R > 0 && C > 0 && C <= 256, "dir_layernorm_forward: bad arguments (C <= 256)");
+    DIR_LAUNCH(layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mean, rstd, R, C, eps);
+    return check_launch("dir_layernorm_forward");
+}
+
+extern "C" int dir_layernorm_backward(const float* gy, const float* x, const float* w, const float* mean, const float* rstd, float* gx, float* gw, float* gb,
+                                      int R, int C, int accumulate_x, int accumulate_wb, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && w && mean && rstd && R > 0 && C > 0 && C <= 256, "dir_layernorm_backward: bad arguments (C <= 256)");
+    if (gx) DIR_LAUNCH(layernorm_bwd_x_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, gy, x, w, mean, rstd, gx, R, C, accumulate_x);
+    if (gw && gb) DIR_LAUNCH(layernorm_bwd_wb_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, x, mean, rstd, gw, gb, R, C, accumulate_wb);
+    return check_launch("dir_layernorm_backward");
+}
+
+extern "C" int dir_gelu_forward(const float* x, float* y, long long n, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && y && n > 0, "dir_gelu_forward: bad arguments");
+    DIR_LAUNCH(gelu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return check_launch("dir_gelu_forward");
+}
+extern "C" int dir_gelu_backward(const float* gy, const float* x, float* gx, long long n, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && gx && n > 0, "dir_gelu_backward: bad arguments");
+    DIR_LAUNCH(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, n);
+    return check_launch("dir_gelu_backward");
+}
+
+extern "C" int dir_attention_forward(const float* qkv, float* probs, float* out, int B, int T, int H, float scale, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(qkv && out && B > 0 && T > 0 && T <= AT && H > 0, "dir_attention_forward: bad arguments (T <= 64, head dim 32)");
+    AttnArgs a{qkv, probs, out, nullptr, nullptr, B, T, H, scale};
+    DIR_LAUNCH(attention_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("dir_attention_forward");
+}
+extern "C" int dir_attention_backward(const float* qkv, const float* probs, const float* gout, float* gqkv, int B, int T, int H, float scale, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(qkv && probs && gout && gqkv && B > 0 && T > 0 && T <= AT && H > 0, "dir_attention_backward: bad arguments");
+    AttnArgs a{qkv, const_cast<float*>(probs), nullptr, gout, gqkv, B, T, H, scale};
+    DIR_LAUNCH(attention_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("dir_attention_backward");
+}
+
+extern "C" int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
+                                    float* running_var, int R, int C, int ld, float eps, float momentum, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && y && save_mean && save_rstd && R > 0 && C > 0 && ld >= C && ((running_mean == nullptr) == (running_var == nullptr)),
+                "dir_bn_train_forward: bad arguments");
+    DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum);
+    return check_launch("dir_bn_train_forward");
+}
+extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd, float* gx, float* gw,
+                                     float* gb, int R, int C, int ld, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_train_backward: bad arguments");
+    DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, x, w, save_mean, save_rstd, gx, gw, gb, R, C, ld);
+    return check_launch("dir_bn_train_backward");
+}

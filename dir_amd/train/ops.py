@@ -1,0 +1,131 @@
+"""Thin tensor front ends of the training building blocks of libdir_hip.so (include/dir_hip.h: dir_gemm_f32, dir_layernorm_*, dir_gelu_*,
+dir_attention_*, dir_bn_train_*).  Plumbing only: shapes, strides, output allocation -- every arithmetic step is a library call."""
+import torch
+
+from .. import _capi
+from .._capi import GemmDesc
+
+F32 = torch.float32
+
+
+def _chk(*ts):
+    _capi.require_cuda(*ts)
+    for t in ts:
+        assert t is None or (t.dtype == F32 and t.is_contiguous()), 'fp32 contiguous tensors'
+
+
+def gemm(A, B, ta=False, tb=False, bias=None, out=None, accumulate=False):
+    """out (+)= op(A) op(B) (+ bias).  A, B: 2-D, or 3-D with a shared leading batch dimension (a 2-D operand is broadcast)."""
+    _chk(A, B, bias, out)
+    batch = max(A.shape[0] if A.dim() == 3 else 1, B.shape[0] if B.dim() == 3 else 1)
+    a2, b2 = A.shape[-2:], B.shape[-2:]
+    M, K = (a2[1], a2[0]) if ta else (a2[0], a2[1])
+    K2, N = (b2[1], b2[0]) if tb else (b2[0], b2[1])
+    assert K == K2, (A.shape, B.shape, ta, tb)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((batch, M, N) if batch > 1 or A.dim() == 3 or B.dim() == 3 else (M, N), device=A.device, dtype=F32)
+    d = GemmDesc(M, N, K, a2[1], b2[1], N, int(ta), int(tb), int(accumulate), batch,
+                 a2[0] * a2[1] if A.dim() == 3 else 0, b2[0] * b2[1] if B.dim() == 3 else 0, M * N if out.dim() == 3 else 0)
+    assert out.shape[-2:] == (M, N) and (batch == 1 or out.dim() == 3)
+    _capi.check(_capi.lib().dir_gemm_f32(d, _capi.ptr(A), _capi.ptr(B), _capi.ptr(bias), _capi.ptr(out), _capi.stream_ptr()), 'dir_gemm_f32')
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """column sums of a 2-D tensor (bias gradients)"""
+    _chk(x, out)
+    R, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=F32)
+    _capi.check(_capi.lib().dir_colsum_f32(_capi.ptr(x), _capi.ptr(out), R, N, N, int(accumulate), _capi.stream_ptr()), 'dir_colsum_f32')
+    return out
+
+
+def linear_fwd(x, W, b, out=None, accumulate=False):
+    """nn.Linear on rows: x [R,K], W [N,K] -> [R,N] (accumulate: added onto `out`, e.g. a residual trunk)"""
+    return gemm(x, W, tb=True, bias=b, out=out, accumulate=accumulate)
+
+
+def linear_bwd(gy, x, W, gW=None, gb=None, accumulate=False, need_gx=True):
+    """-> (g x [R,K] or None, g W [N,K], g b [N]); accumulate: parameter gradients are added to gW / gb (shared parameters)"""
+    gx = gemm(gy, W) if need_gx else None
+    gW = gemm(gy, x, ta=True, out=gW, accumulate=accumulate and gW is not None)
+    gb = colsum(gy, out=gb, accumulate=accumulate and gb is not None)
+    return gx, gW, gb
+
+
+def layernorm_fwd(x, w, b, eps):
+    _chk(x, w, b)
+    R, C = x.shape
+    y, mean, rstd = torch.empty_like(x), torch.empty(R, device=x.device), torch.empty(R, device=x.device)
+    _capi.check(_capi.lib().dir_layernorm_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(mean), _capi.ptr(rstd), R, C, float(eps),
+                                                  _capi.stream_ptr()), 'dir_layernorm_forward')
+    return y, (mean, rstd)
+
+
+def layernorm_bwd(gy, x, w, stats, gx=None, gw=None, gb=None, accumulate_x=False, accumulate_wb=False):
+    """g x is written into (or, accumulate_x, added onto) gx; g w / g b likewise"""
+    _chk(gy, x, w, gx, gw, gb)
+    R, C = x.shape
+    if gx is None:
+        gx = torch.empty_like(x)
+        accumulate_x = False
+    if gw is None:
+        gw, gb, accumulate_wb = torch.empty(C, device=x.device), torch.empty(C, device=x.device), False
+    _capi.check(_capi.lib().dir_layernorm_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(gx),
+                                                   _capi.ptr(gw), _capi.ptr(gb), R, C, int(accumulate_x), int(accumulate_wb), _capi.stream_ptr()),
+                'dir_layernorm_backward')
+    return gx, gw, gb
+
+
+def gelu_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    _capi.check(_capi.lib().dir_gelu_forward(_capi.ptr(x), _capi.ptr(y), x.numel(), _capi.stream_ptr()), 'dir_gelu_forward')
+    return y
+
+
+def gelu_bwd(gy, x):
+    _chk(gy, x)
+    gx = torch.empty_like(x)
+    _capi.check(_capi.lib().dir_gelu_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(gx), x.numel(), _capi.stream_ptr()), 'dir_gelu_backward')
+    return gx
+
+
+def attention_fwd(qkv, B, T, H, scale, save_probs=True):
+    """qkv [B*T, 3*H*32] -> (out [B*T, H*32], probs [B,H,T,T] or None)"""
+    _chk(qkv)
+    out = torch.empty(B * T, H * 32, device=qkv.device)
+    probs = torch.empty(B, H, T, T, device=qkv.device) if save_probs else None
+    _capi.check(_capi.lib().dir_attention_forward(_capi.ptr(qkv), _capi.ptr(probs), _capi.ptr(out), B, T, H, float(scale), _capi.stream_ptr()),
+                'dir_attention_forward')
+    return out, probs
+
+
+def attention_bwd(qkv, probs, gout, B, T, H, scale):
+    _chk(qkv, probs, gout)
+    gqkv = torch.empty_like(qkv)
+    _capi.check(_capi.lib().dir_attention_backward(_capi.ptr(qkv), _capi.ptr(probs), _capi.ptr(gout), _capi.ptr(gqkv), B, T, H, float(scale),
+                                                   _capi.stream_ptr()), 'dir_attention_backward')
+    return gqkv
+
+
+def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """BatchNorm in training mode over x [R, C] (channels last).  -> (y, (save_mean, save_rstd)); running statistics updated in place"""
+    _chk(x, w, b, running_mean, running_var)
+    R, C = x.shape
+    y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    _capi.check(_capi.lib().dir_bn_train_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
+                                                 _capi.ptr(running_var), R, C, C, float(eps), float(momentum), _capi.stream_ptr()), 'dir_bn_train_forward')
+    return y, (sm, sr)
+
+
+def bn_train_bwd(gy, x, w, stats, need_gx=True):
+    _chk(gy, x, w)
+    R, C = x.shape
+    gx = torch.empty_like(x) if need_gx else None
+    gw, gb = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    _capi.check(_capi.lib().dir_bn_train_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(gx),
+                                                  _capi.ptr(gw), _capi.ptr(gb), R, C, C, _capi.stream_ptr()), 'dir_bn_train_backward')
+    return gx, gw, gb

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 17
+#define DIR_ABI_VERSION 18
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -113,6 +113,41 @@ int dir_regress_backward(const float* w_left, const float* w_right, const float*
                          const float* g_para_left, const float* g_para_right, const float* g_offset,
                          float* gw_left, float* gb_left, float* gw_right, float* gb_right, float* gw_offset, float* gb_offset,
                          float* g_tok, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * building blocks of the backward pass over the joint-token path (train.py:66-70 runs torch autograd through
+ * transformer/mixSTE.py, SemGCN/p_graph_conv.py and the Conv1d / Linear / LayerNorm / BatchNorm1d modules of models/dir.py:19-130).
+ * Exact fp32, deterministic (fixed summation orders, no atomics); composed on the host by dir_amd/train/.
+ */
+/* C[b] (+)= op(A[b]) op(B[b]) (+ bias[n]):  op(X) = X or X^T; row-major, leading dimensions in elements, `batch` problems
+ * `stride_*` elements apart.  trans_a = 0: A is [M][K]; 1: A is [K][M].  trans_b = 0: B is [K][N]; 1: B is [N][K] (nn.Linear weight).
+ * accumulate != 0: C += product + bias (a residual branch lands on its trunk in place).  v_mfma_f32_16x16x4_f32: exact fp32
+ * products, k ascending. */
+typedef struct dir_gemm_desc {
+    int32_t M, N, K, lda, ldb, ldc, trans_a, trans_b, accumulate, batch;
+    int64_t stride_a, stride_b, stride_c;
+} dir_gemm_desc;
+int dir_gemm_f32(const dir_gemm_desc* desc_host, const float* A, const float* B, const float* bias, float* C, void* stream);
+/* out[n] (+)= sum_r x[r][n]: bias gradients */
+int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, int accumulate, void* stream);
+/* nn.LayerNorm over the last dimension of x [R][C] (C <= 256); mean / rstd [R] are saved for the backward */
+int dir_layernorm_forward(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int R, int C, float eps, void* stream);
+int dir_layernorm_backward(const float* gy, const float* x, const float* w, const float* mean, const float* rstd, float* gx, float* gw,
+                           float* gb, int R, int C, int accumulate_x, int accumulate_wb, void* stream);
+/* nn.GELU() (exact erf form; transformer/mixSTE.py:12,27) */
+int dir_gelu_forward(const float* x, float* y, long long n, void* stream);
+int dir_gelu_backward(const float* gy, const float* x, float* gx, long long n, void* stream);
+/* Attention.forward without the two Linears (transformer/mixSTE.py:76-97): qkv [B][T][3][H][32] -> out [B][T][H*32] =
+ * softmax(q k^T * scale) v per (sample, head); probs [B][H][T][T] is saved for the backward (may be NULL in inference).  T <= 64. */
+int dir_attention_forward(const float* qkv, float* probs, float* out, int B, int T, int H, float scale, void* stream);
+int dir_attention_backward(const float* qkv, const float* probs, const float* gout, float* gqkv, int B, int T, int H, float scale, void* stream);
+/* BatchNorm in TRAINING mode over x [R][C] with row stride ld (channels last: R = samples x positions): batch mean and biased
+ * variance, y = (x - mean) * rstd * w + b, running statistics updated with `momentum` and the unbiased variance (torch semantics);
+ * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional). */
+int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
+                         float* running_var, int R, int C, int ld, float eps, float momentum, void* stream);
+int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd, float* gx, float* gw,
+                          float* gb, int R, int C, int ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores

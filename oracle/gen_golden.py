@@ -596,7 +596,40 @@ def gen_regress_grad():
     save('g14_regress_grad', **res)
 
 
-GENS = {'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G15 gradients through STE
+def compact_grads(named, step=16):
+    """fixture-size form of a set of parameter gradients: small tensors whole; matrices as every `step`-th column + row / column sums"""
+    res = {}
+    for k, g in named.items():
+        if g.dim() < 2 or g.numel() <= 8192:
+            res['grad.' + k] = g
+        else:
+            g2 = g.reshape(g.shape[0], -1)
+            res['grad.' + k + '.cols%d' % step] = g2[:, ::step].contiguous()
+            res['grad.' + k + '.rowsum'] = g2.double().sum(1)
+            res['grad.' + k + '.colsum'] = g2.double().sum(0)
+    return res
+
+
+def gen_ste_grad():
+    """torch autograd through the reference's STE (transformer/mixSTE.py:159-205): d <gy, STE(x)> / d (x, every parameter)"""
+    from transformer.mixSTE import STE
+    net = STE(num_joints=42, in_chans=128, out_dim=64, depth=4)
+    load_synth(net)
+    x0 = torch.from_numpy(synth.synth_input('stegrad.x', (3, 42, 128), SEED))
+    gy = torch.from_numpy(synth.synth_input('stegrad.gy', (3, 42, 64), SEED))
+    x = x0.clone().requires_grad_(True)
+    y = net(x + 0.0)                      # (+ 0: the forward adds the positional embedding in place)
+    params = {k: v for k, v in net.named_parameters()}
+    gs = torch.autograd.grad((y * gy).sum(), [x] + list(params.values()), allow_unused=True)
+    unused = [k for k, g in zip(params, gs[1:]) if g is None]
+    assert all(k.startswith('STEblocks.0.') for k in unused) and len(unused) == 12      # block 0 is never executed (:197)
+    res = {'y': y.detach(), 'grad.x': gs[0]}
+    res.update(compact_grads({k: g for k, g in zip(params, gs[1:]) if g is not None}))
+    save('g15_ste_grad', **res)
+
+
+GENS = {'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

@@ -47,3 +47,39 @@ def loss_case(g):
     gt_seg = g['gt_seg_u8'].astype(np.float32)
     gt_dense = g['gt_dense_u8'].astype(np.float32) / np.float32(255.0)
     return preds, gt, faces, g['seg'], g['dense'], gt_seg, gt_dense
+
+
+def check_compact_grads(got, g, tol, prefix='grad.'):
+    """compare {key: gradient array} with a fixture written by oracle/gen_golden.py::compact_grads (small tensors whole; matrices as every
+    n-th column + float64 row / column sums).  Returns the worst error relative to each gradient's maximum; asserts it is < tol."""
+    worst = 0.0
+    keys = set()
+    for k in g:
+        if not k.startswith(prefix):
+            continue
+        name = k[len(prefix):]
+        for suf in ('.rowsum', '.colsum'):
+            if name.endswith(suf):
+                name = name[:-len(suf)]
+        if '.cols' in name and name.rsplit('.cols', 1)[1].isdigit():
+            name = name.rsplit('.cols', 1)[0]
+        keys.add(name)
+    for name in sorted(keys):
+        if name not in got:
+            continue
+        a = np.asarray(got[name], np.float64)
+        if prefix + name in g:
+            ref = g[prefix + name]
+            e = np.abs(a.reshape(ref.shape) - ref).max() / (np.abs(ref).max() + 1e-30)
+        else:
+            a2 = a.reshape(a.shape[0], -1)
+            ck = [k for k in g if k.startswith(prefix + name + '.cols')][0]
+            step = int(ck.rsplit('.cols', 1)[1])
+            # the sums are compared on the scale of the L1 norms of the rows / columns they sum: a gradient that flows out of a
+            # LayerNorm has (exactly) zero channel sum, so some of these sums are pure cancellation
+            e = max(np.abs(a2[:, ::step] - g[ck]).max() / (np.abs(g[ck]).max() + 1e-30),
+                    np.abs(a2.sum(1) - g[prefix + name + '.rowsum']).max() / (np.abs(a2).sum(1).max() + 1e-30),
+                    np.abs(a2.sum(0) - g[prefix + name + '.colsum']).max() / (np.abs(a2).sum(0).max() + 1e-30))
+        worst = max(worst, float(e))
+        assert e < tol, (name, float(e))
+    return worst

@@ -1,0 +1,142 @@
+"""GPU parity of the training building blocks (dir_gemm_f32, dir_layernorm_*, dir_gelu_*, dir_attention_*, dir_bn_train_*) against numpy in
+float64, and of the composed STE forward + backward (dir_amd/train/ste.py) against G15 = torch autograd through the reference's STE
+(transformer/mixSTE.py:159-205) and the analytic oracle (oracle/ste_grad.py).  fp32 kernels: 1e-5 of each tensor's maximum."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_compact_grads, maxabs
+from dir_amd import synth
+from dir_amd.train import ops as O
+from dir_amd.train import ste as STE
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rel(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a.detach().cpu().numpy().astype(np.float64).reshape(b.shape) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(126, 384, 128, 0, 1), (384, 128, 126, 1, 0), (126, 128, 384, 0, 0), (1, 5376, 3, 0, 0), (70, 65, 17, 1, 1),
+                                        (2688, 256, 128, 0, 1)])
+def test_gemm(M, N, K, ta, tb):
+    rng = np.random.RandomState(M + N)
+    A = rng.normal(0, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.normal(0, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.normal(0, 1, N).astype(np.float32)
+    ref = (A.T if ta else A).astype(np.float64) @ (B.T if tb else B).astype(np.float64)
+    got = O.gemm(dev(A), dev(B), bool(ta), bool(tb), bias=dev(bias))
+    assert rel(got, ref + bias) < 2e-6
+    C0 = rng.normal(0, 1, (M, N)).astype(np.float32)
+    out = dev(C0)
+    O.gemm(dev(A), dev(B), bool(ta), bool(tb), out=out, accumulate=True)
+    assert rel(out, ref + C0) < 2e-6
+    assert torch.equal(O.gemm(dev(A), dev(B), bool(ta), bool(tb)), O.gemm(dev(A), dev(B), bool(ta), bool(tb)))          # deterministic
+
+
+def test_gemm_batched():
+    rng = np.random.RandomState(3)
+    A, B = rng.normal(0, 1, (21, 48, 128)).astype(np.float32), rng.normal(0, 1, (21, 128, 128)).astype(np.float32)
+    got = O.gemm(dev(A), dev(B))
+    assert rel(got, A.astype(np.float64) @ B.astype(np.float64)) < 2e-6
+    got = O.gemm(dev(A), dev(B[0]), tb=True)                        # shared second operand
+    assert rel(got, A.astype(np.float64) @ B[0].astype(np.float64).T) < 2e-6
+
+
+def test_layernorm_gelu_bn():
+    rng = np.random.RandomState(7)
+    for R, C, eps in ((126, 128, 1e-6), (5, 64, 1e-5), (300, 256, 1e-5)):
+        x, w, b, gy = (rng.normal(0, 1, s).astype(np.float32) for s in ((R, C), (C,), (C,), (R, C)))
+        x64 = x.astype(np.float64)
+        mu, var = x64.mean(1, keepdims=True), x64.var(1, keepdims=True)
+        xh = (x64 - mu) / np.sqrt(var + eps)
+        y, st = O.layernorm_fwd(dev(x), dev(w), dev(b), eps)
+        assert rel(y, xh * w + b) < 2e-6
+        gh = gy.astype(np.float64) * w
+        gx_ref = (gh - gh.mean(1, keepdims=True) - xh * (gh * xh).mean(1, keepdims=True)) / np.sqrt(var + eps)
+        gx, gw, gb = O.layernorm_bwd(dev(gy), dev(x), dev(w), st)
+        assert rel(gx, gx_ref) < 5e-6 and rel(gw, (gy * xh).sum(0)) < 5e-6 and rel(gb, gy.astype(np.float64).sum(0)) < 5e-6
+        base = dev(rng.normal(0, 1, (R, C)))
+        keep = base.clone()
+        O.layernorm_bwd(dev(gy), dev(x), dev(w), st, gx=base, accumulate_x=True)
+        assert rel(base, gx_ref + keep.cpu().numpy()) < 5e-6
+        # BatchNorm, training mode, against torch's own module on the CPU (statistics, running update, gradients)
+        bn = torch.nn.BatchNorm1d(C).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy(w)); bn.bias.copy_(torch.from_numpy(b))
+        xt = torch.from_numpy(x).requires_grad_(True)
+        yt = bn(xt)
+        yt.backward(torch.from_numpy(gy))
+        rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        y, st = O.bn_train_fwd(dev(x), dev(w), dev(b), rm, rv)
+        assert rel(y, yt.detach().numpy()) < 5e-6 and rel(rm, bn.running_mean.numpy()) < 5e-6 and rel(rv, bn.running_var.numpy()) < 5e-6
+        gx, gw, gb = O.bn_train_bwd(dev(gy), dev(x), dev(w), st)
+        assert rel(gx, xt.grad.numpy()) < 2e-5 and rel(gw, bn.weight.grad.numpy()) < 5e-6 and rel(gb, bn.bias.grad.numpy()) < 5e-6
+    from scipy.special import erf
+    h = rng.normal(0, 2, (77, 256)).astype(np.float32)
+    g = rng.normal(0, 1, (77, 256)).astype(np.float32)
+    h64 = h.astype(np.float64)
+    assert rel(O.gelu_fwd(dev(h)), 0.5 * h64 * (1 + erf(h64 / np.sqrt(2)))) < 2e-6
+    assert rel(O.gelu_bwd(dev(g), dev(h)), g * (0.5 * (1 + erf(h64 / np.sqrt(2))) + h64 * np.exp(-0.5 * h64 ** 2) / np.sqrt(2 * np.pi))) < 2e-6
+
+
+def test_attention():
+    rng = np.random.RandomState(9)
+    B, T, H, D = 3, 42, 4, 32
+    qkv = rng.normal(0, 1, (B, T, 3, H, D)).astype(np.float32)
+    go = rng.normal(0, 1, (B, T, H * D)).astype(np.float32)
+    q, k, v = (qkv.astype(np.float64).transpose(2, 0, 3, 1, 4)[j] for j in range(3))
+    S = q @ k.transpose(0, 1, 3, 2) * D ** -0.5
+    P = np.exp(S - S.max(-1, keepdims=True)); P /= P.sum(-1, keepdims=True)
+    o = (P @ v).transpose(0, 2, 1, 3).reshape(B, T, H * D)
+    out, probs = O.attention_fwd(dev(qkv.reshape(B * T, -1)), B, T, H, D ** -0.5)
+    assert rel(out, o) < 3e-6 and rel(probs, P) < 3e-6
+    g = go.astype(np.float64).reshape(B, T, H, D).transpose(0, 2, 1, 3)
+    gv, gP = P.transpose(0, 1, 3, 2) @ g, g @ v.transpose(0, 1, 3, 2)
+    gS = P * (gP - (gP * P).sum(-1, keepdims=True)) * D ** -0.5
+    ref = np.stack([gS @ k, gS.transpose(0, 1, 3, 2) @ q, gv]).transpose(1, 3, 0, 2, 4).reshape(B * T, 3 * H * D)
+    assert rel(O.attention_bwd(dev(qkv.reshape(B * T, -1)), probs, dev(go.reshape(B * T, -1)), B, T, H, D ** -0.5), ref) < 5e-6
+
+
+def ste_params():
+    import json
+    import os
+    shapes = {'spatial_pos_embed': (1, 42, 128), 'spatial_norm.weight': (128,), 'spatial_norm.bias': (128,),
+              'head.0.weight': (128,), 'head.0.bias': (128,), 'head.1.weight': (64, 128), 'head.1.bias': (64,)}
+    for i in range(4):
+        p = 'STEblocks.%d.' % i
+        shapes.update({p + 'norm1.weight': (128,), p + 'norm1.bias': (128,), p + 'norm2.weight': (128,), p + 'norm2.bias': (128,),
+                       p + 'attn.qkv.weight': (384, 128), p + 'attn.qkv.bias': (384,), p + 'attn.proj.weight': (128, 128), p + 'attn.proj.bias': (128,),
+                       p + 'mlp.fc1.weight': (256, 128), p + 'mlp.fc1.bias': (256,), p + 'mlp.fc2.weight': (128, 256), p + 'mlp.fc2.bias': (128,)})
+    return synth.synth_state_dict(shapes, SEED)
+
+
+def test_ste_forward_backward_vs_reference_autograd(golden):
+    g = golden('g15_ste_grad')
+    sdn = ste_params()
+    P = {k: dev(v) for k, v in sdn.items()}
+    x = dev(synth.synth_input('stegrad.x', (3, 42, 128), SEED))
+    gy = dev(synth.synth_input('stegrad.gy', (3, 42, 64), SEED))
+    y, ctx = STE.ste_forward(P, x)
+    assert maxabs(y.cpu().numpy(), g['y']) < 3e-5
+    gx, G = STE.ste_backward(P, ctx, gy)
+    assert rel(gx, g['grad.x']) < 1e-5
+    assert not any(k.startswith('STEblocks.0.') for k in G) and len(G) == 43
+    worst = check_compact_grads({k: v.cpu().numpy() for k, v in G.items()}, g, 1e-5)
+    print('STE backward vs torch autograd through the reference: worst %.2e' % worst)
+    # and the analytic float64 oracle at another batch size
+    from oracle.ste_grad import ste_forward_backward
+    rng = np.random.RandomState(4)
+    x2, gy2 = rng.normal(0, 1, (7, 42, 128)).astype(np.float32), rng.normal(0, 1, (7, 42, 64)).astype(np.float32)
+    yr, gxr, Gr = ste_forward_backward(sdn, x2, gy2)
+    y2, ctx2 = STE.ste_forward(P, dev(x2))
+    gx2, G2 = STE.ste_backward(P, ctx2, dev(gy2))
+    assert rel(y2, yr) < 1e-5 and rel(gx2, gxr) < 1e-5
+    for k in Gr:
+        assert rel(G2[k], Gr[k]) < 1e-5, k

@@ -387,3 +387,17 @@ def test_regressor_gradient_oracle_matches_reference_autograd(golden):
         assert maxabs(got[k][:, ::4], ref) < 2e-6 * np.abs(ref).max(), k
         assert maxabs(got[k].sum(1), g['grad.' + k + '.rowsum']) < 2e-6 * np.abs(g['grad.' + k + '.rowsum']).max()
         assert maxabs(got[k].sum(0), g['grad.' + k + '.colsum']) < 2e-6 * np.abs(g['grad.' + k + '.colsum']).max()
+
+
+def test_ste_gradient_oracle_matches_reference_autograd(golden):
+    from conftest import check_compact_grads
+    from oracle.ste_grad import ste_forward_backward
+    g = golden('g15_ste_grad')
+    sd = synth.synth_state_dict(ste_shapes(), SEED)
+    x, gy = synth.synth_input('stegrad.x', (3, 42, 128), SEED), synth.synth_input('stegrad.gy', (3, 42, 64), SEED)
+    y, gx, G = ste_forward_backward(sd, x, gy)
+    assert maxabs(y, g['y']) < 3e-5
+    assert maxabs(gx, g['grad.x']) < 2e-5 * np.abs(g['grad.x']).max()
+    assert not any(k.startswith('STEblocks.0.') for k in G)                  # never executed: no gradient (mixSTE.py:197)
+    worst = check_compact_grads(G, g, 2e-5)
+    assert worst < 2e-5 and len(G) == 12 * 3 + 7
