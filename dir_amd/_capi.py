@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 18          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 19          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -165,6 +165,10 @@ _SIGNATURES = {
     'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p]),
     'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'dir_relu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),
+    'dir_relu_backward': (C.c_int, [_p, _p, _p, C.c_longlong, _p]),
+    'dir_pgcn_adjacency_forward': (C.c_int, [_p, _p, _p]),
+    'dir_pgcn_adjacency_backward': (C.c_int, [_p, _p, _p, _p, _p, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
 }
 

@@ -282,6 +282,59 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, cons
             gx[(long long)r * ld + c] = g * rs * (gy[(long long)r * ld + c] - m1 - (x[(long long)r * ld + c] - mu) * rs * m2);
 }
 
+// ------------------------------------------------------------------------------------------------------------------ ReLU
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const float* x, float* y, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* gy, const float* y, float* gx, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) gx[i] = y[i] > 0.f ? gy[i] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ P-GCN adjacency
+// A_1 = row-softmax of the skeleton mask filled with e_1 (SemGCN/p_graph_conv.py:43-50); the 40 edges in row-major nonzero order.
+__constant__ int kAdjOff[22] = {0, 5, 7, 9, 11, 12, 14, 16, 18, 19, 21, 23, 25, 26, 28, 30, 32, 33, 35, 37, 39, 40};
+__constant__ int kAdjIdx[40] = {1, 5, 9, 13, 17, 0, 2, 1, 3, 2, 4, 3, 0, 6, 5, 7, 6, 8, 7, 0,
+                                10, 9, 11, 10, 12, 11, 0, 14, 13, 15, 14, 16, 15, 0, 18, 17, 19, 18, 20, 19};
+__global__ __launch_bounds__(64) void pgcn_adj_fwd_kernel(const float* e1, float* A) {      // A [21][21], one thread per row
+    const int j = threadIdx.x;
+    if (j >= 21) return;
+    for (int k = 0; k < 21; ++k) A[j * 21 + k] = 0.f;
+    const int o0 = kAdjOff[j], deg = kAdjOff[j + 1] - o0;
+    float mx = -INFINITY, sum = 0.f;
+    for (int t = 0; t < deg; ++t) mx = fmaxf(mx, e1[o0 + t]);
+    for (int t = 0; t < deg; ++t) sum += expf(e1[o0 + t] - mx);
+    for (int t = 0; t < deg; ++t) A[j * 21 + kAdjIdx[o0 + t]] = expf(e1[o0 + t] - mx) / sum;
+}
+// g A_1[j][k] = sum_b <g z[b][j], h1[b][k]> on the 40 edges (one wave per edge, samples in order), then the softmax chain rule per
+// row: g e_1[edge] = A (g A - sum_row g A A).  grid = 1 workgroup of 40 waves would exceed 1024 threads: 40 workgroups + a tail kernel.
+__global__ __launch_bounds__(64) void pgcn_adj_bwd_edge_kernel(const float* gz, const float* h1, float* gA_edge, int B) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    int j = 0;
+    while (kAdjOff[j + 1] <= e) ++j;
+    const int k = kAdjIdx[e];
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* g = gz + ((long long)b * 21 + j) * 128;
+        const float* h = h1 + ((long long)b * 21 + k) * 128;
+        acc = fmaf(g[lane], h[lane], acc);
+        acc = fmaf(g[lane + 64], h[lane + 64], acc);
+    }
+    acc = dir::wave_sum(acc);
+    if (lane == 0) gA_edge[e] = acc;
+}
+__global__ __launch_bounds__(64) void pgcn_adj_bwd_softmax_kernel(const float* e1, const float* gA_edge, float* ge1) {
+    const int j = threadIdx.x;
+    if (j >= 21) return;
+    const int o0 = kAdjOff[j], deg = kAdjOff[j + 1] - o0;
+    float mx = -INFINITY, sum = 0.f, p[5], dot = 0.f;
+    for (int t = 0; t < deg; ++t) mx = fmaxf(mx, e1[o0 + t]);
+    for (int t = 0; t < deg; ++t) { p[t] = expf(e1[o0 + t] - mx); sum += p[t]; }
+    for (int t = 0; t < deg; ++t) { p[t] /= sum; dot = fmaf(gA_edge[o0 + t], p[t], dot); }
+    for (int t = 0; t < deg; ++t) ge1[o0 + t] = p[t] * (gA_edge[o0 + t] - dot);
+}
+
 }  // namespace
 
 extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* stream) {
@@ -358,4 +411,30 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
     DIR_REQUIRE(gy && x && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_train_backward: bad arguments");
     DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, x, w, save_mean, save_rstd, gx, gw, gb, R, C, ld);
     return check_launch("dir_bn_train_backward");
+}
+
+extern "C" int dir_relu_forward(const float* x, float* y, long long n, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && y && n > 0, "dir_relu_forward: bad arguments");
+    DIR_LAUNCH(relu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return check_launch("dir_relu_forward");
+}
+extern "C" int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && y && gx && n > 0, "dir_relu_backward: bad arguments");
+    DIR_LAUNCH(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy, y, gx, n);
+    return check_launch("dir_relu_backward");
+}
+extern "C" int dir_pgcn_adjacency_forward(const float* e1, float* A, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(e1 && A, "dir_pgcn_adjacency_forward: null pointer");
+    DIR_LAUNCH(pgcn_adj_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e1, A);
+    return check_launch("dir_pgcn_adjacency_forward");
+}
+extern "C" int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h1, float* scratch40, float* g_e1, int B, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(e1 && gz && h1 && scratch40 && g_e1 && B > 0, "dir_pgcn_adjacency_backward: bad arguments");
+    DIR_LAUNCH(pgcn_adj_bwd_edge_kernel, dim3(40), dim3(64), 0, (hipStream_t)stream, gz, h1, scratch40, B);
+    DIR_LAUNCH(pgcn_adj_bwd_softmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e1, scratch40, g_e1);
+    return check_launch("dir_pgcn_adjacency_backward");
 }

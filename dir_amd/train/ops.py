@@ -129,3 +129,44 @@ def bn_train_bwd(gy, x, w, stats, need_gx=True):
     _capi.check(_capi.lib().dir_bn_train_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(gx),
                                                   _capi.ptr(gw), _capi.ptr(gb), R, C, C, _capi.stream_ptr()), 'dir_bn_train_backward')
     return gx, gw, gb
+
+
+def gemm_strided(A, B, C, M, N, K, lda, ldb, ldc, ta=False, tb=False, batch=1, sa=0, sb=0, sc=0, a_off=0, b_off=0, c_off=0, bias=None,
+                 accumulate=False):
+    """dir_gemm_f32 with explicit leading dimensions / batch strides / element offsets into the three buffers (views that torch would
+    have to copy: node j of a [B,21,C] tensor is the matrix at offset j*C with row pitch 21*C)"""
+    import ctypes as Ct
+    _chk(A, B, C, bias)
+    d = GemmDesc(M, N, K, lda, ldb, ldc, int(ta), int(tb), int(accumulate), batch, sa, sb, sc)
+    p = lambda t, off: Ct.c_void_p(t.data_ptr() + 4 * off)  # noqa: E731
+    _capi.check(_capi.lib().dir_gemm_f32(d, p(A, a_off), p(B, b_off), _capi.ptr(bias), p(C, c_off), _capi.stream_ptr()), 'dir_gemm_f32')
+    return C
+
+
+def relu_fwd(x):
+    _chk(x)
+    y = torch.empty_like(x)
+    _capi.check(_capi.lib().dir_relu_forward(_capi.ptr(x), _capi.ptr(y), x.numel(), _capi.stream_ptr()), 'dir_relu_forward')
+    return y
+
+
+def relu_bwd(gy, y):
+    _chk(gy, y)
+    gx = torch.empty_like(y)
+    _capi.check(_capi.lib().dir_relu_backward(_capi.ptr(gy), _capi.ptr(y), _capi.ptr(gx), y.numel(), _capi.stream_ptr()), 'dir_relu_backward')
+    return gx
+
+
+def pgcn_adjacency(e1):
+    _chk(e1)
+    A = torch.empty(21, 21, device=e1.device)
+    _capi.check(_capi.lib().dir_pgcn_adjacency_forward(_capi.ptr(e1), _capi.ptr(A), _capi.stream_ptr()), 'dir_pgcn_adjacency_forward')
+    return A
+
+
+def pgcn_adjacency_bwd(e1, gz, h1):
+    _chk(e1, gz, h1)
+    scratch, ge = torch.empty(40, device=e1.device), torch.empty_like(e1)
+    _capi.check(_capi.lib().dir_pgcn_adjacency_backward(_capi.ptr(e1), _capi.ptr(gz), _capi.ptr(h1), _capi.ptr(scratch), _capi.ptr(ge), gz.shape[0],
+                                                        _capi.stream_ptr()), 'dir_pgcn_adjacency_backward')
+    return ge

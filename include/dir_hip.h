@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 18
+#define DIR_ABI_VERSION 19
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -148,6 +148,13 @@ int dir_bn_train_forward(const float* x, const float* w, const float* b, float* 
                          float* running_var, int R, int C, int ld, float eps, float momentum, void* stream);
 int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd, float* gx, float* gw,
                           float* gb, int R, int C, int ld, void* stream);
+int dir_relu_forward(const float* x, float* y, long long n, void* stream);
+int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, void* stream);   /* g x = y > 0 ? g y : 0 */
+/* PGraphConv's adjacency (SemGCN/p_graph_conv.py:43-50): A_1 [21][21] = row-softmax of the hand-skeleton mask filled with e_1 [40]
+ * (row-major nonzero order); backward: g e_1 from g z [B,21,128] (gradient of the layer's pre-BatchNorm output) and h1 = x W_1 [B,21,128]
+ * (g A_1[j][k] = sum_b <g z[b][j], h1[b][k]> on the edges, then the softmax chain rule).  scratch40: 40 floats. */
+int dir_pgcn_adjacency_forward(const float* e1, float* A, void* stream);
+int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h1, float* scratch40, float* g_e1, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a1 / a2 / a3 / a11: 2-D convolution as an implicit GEMM on the matrix cores

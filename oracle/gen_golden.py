@@ -604,7 +604,7 @@ def compact_grads(named, step=16):
         if g.dim() < 2 or g.numel() <= 8192:
             res['grad.' + k] = g
         else:
-            g2 = g.reshape(g.shape[0], -1)
+            g2 = g.reshape(-1, g.shape[-1])
             res['grad.' + k + '.cols%d' % step] = g2[:, ::step].contiguous()
             res['grad.' + k + '.rowsum'] = g2.double().sum(1)
             res['grad.' + k + '.colsum'] = g2.double().sum(0)
@@ -629,7 +629,30 @@ def gen_ste_grad():
     save('g15_ste_grad', **res)
 
 
-GENS = {'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G16 gradients through the P-GCN stack (training mode)
+def gen_pgcn_grad():
+    """torch autograd through the reference's ResSimplePGCN in TRAINING mode (batch-statistics BatchNorm1d, SemGCN/p_gcn.py:20-27,64-73)"""
+    from SemGCN.p_gcn import ResSimplePGCN
+    from SemGCN.utils import adj_mx_from_edges, get_sketch_setting
+    adj = adj_mx_from_edges(21, get_sketch_setting(), sparse=False, eye=False)
+    net = ResSimplePGCN(adj, 128, num_layers=4)
+    load_synth(net)
+    net.train()
+    x0 = torch.from_numpy(synth.synth_input('pgcngrad.x', (5, 21, 128), SEED))
+    gy = torch.from_numpy(synth.synth_input('pgcngrad.gy', (5, 21, 128), SEED))
+    x = x0.clone().requires_grad_(True)
+    y = net(x)
+    params = {k: v for k, v in net.named_parameters()}
+    gs = torch.autograd.grad((y * gy).sum(), [x] + list(params.values()))
+    res = {'y': y.detach(), 'grad.x': gs[0]}
+    res.update(compact_grads(dict(zip(params, gs[1:])), step=32))
+    for k, v in net.state_dict().items():
+        if 'running_' in k:
+            res['after.' + k] = v
+    save('g16_pgcn_grad', **res)
+
+
+GENS = {'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

@@ -140,3 +140,44 @@ def test_ste_forward_backward_vs_reference_autograd(golden):
     assert rel(y2, yr) < 1e-5 and rel(gx2, gxr) < 1e-5
     for k in Gr:
         assert rel(G2[k], Gr[k]) < 1e-5, k
+
+
+def pgcn_params():
+    s = {}
+    for i in range(4):
+        p = 'gconv_layers.%d.' % i
+        s.update({p + 'gconv.W': (2, 21, 128, 128), p + 'gconv.e_0': (1, 21), p + 'gconv.e_1': (1, 40), p + 'gconv.bias': (128,), p + 'bn.weight': (128,),
+                  p + 'bn.bias': (128,), p + 'bn.running_mean': (128,), p + 'bn.running_var': (128,), p + 'bn.num_batches_tracked': ()})
+    return synth.synth_state_dict(s, SEED)
+
+
+def test_pgcn_train_forward_backward_vs_reference_autograd(golden):
+    """ResSimplePGCN in training mode (batch-statistics BatchNorm1d): G16 = torch autograd through the reference's own modules"""
+    from dir_amd.train import pgcn as PG
+    from oracle.pgcn_grad import pgcn_train_forward_backward
+    g = golden('g16_pgcn_grad')
+    sdn = pgcn_params()
+    P = {k: dev(v) for k, v in sdn.items() if np.asarray(v).dtype.kind == 'f'}
+    x = dev(synth.synth_input('pgcngrad.x', (5, 21, 128), SEED))
+    gy = dev(synth.synth_input('pgcngrad.gy', (5, 21, 128), SEED))
+    y, ctx = PG.pgcn_forward(P, x)
+    assert rel(y, g['y']) < 1e-5
+    for k in g:
+        if k.startswith('after.') and 'running' in k:
+            assert rel(P[k[6:]], g[k]) < 1e-5, k                               # running statistics updated like torch (momentum 0.1, unbiased var)
+    gx, G = PG.pgcn_backward(P, ctx, gy)
+    assert rel(gx, g['grad.x']) < 2e-5
+    Gn = {k: (v.cpu().numpy().reshape(2 * 21 * 128, 128) if k.endswith('gconv.W') else v.cpu().numpy()) for k, v in G.items()}
+    worst = check_compact_grads(Gn, g, 2e-5, zero_suffixes=('gconv.bias', 'gconv.e_0'))
+    print('P-GCN (training mode) backward vs torch autograd through the reference: worst %.2e' % worst)
+    # the float64 oracle at a batch size that is not a multiple of anything
+    rng = np.random.RandomState(2)
+    x2, gy2 = rng.normal(0, 1, (13, 21, 128)).astype(np.float32), rng.normal(0, 1, (13, 21, 128)).astype(np.float32)
+    yr, gxr, Gr, _ = pgcn_train_forward_backward(sdn, x2, gy2)
+    P2 = {k: dev(v) for k, v in sdn.items() if np.asarray(v).dtype.kind == 'f'}
+    y2, ctx2 = PG.pgcn_forward(P2, dev(x2))
+    gx2, G2 = PG.pgcn_backward(P2, ctx2, dev(gy2))
+    assert rel(y2, yr) < 1e-5 and rel(gx2, gxr) < 2e-5
+    for k in Gr:
+        if not k.endswith(('gconv.bias', 'gconv.e_0')):
+            assert rel(G2[k], Gr[k]) < 2e-5, k

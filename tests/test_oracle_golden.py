@@ -401,3 +401,18 @@ def test_ste_gradient_oracle_matches_reference_autograd(golden):
     assert not any(k.startswith('STEblocks.0.') for k in G)                  # never executed: no gradient (mixSTE.py:197)
     worst = check_compact_grads(G, g, 2e-5)
     assert worst < 2e-5 and len(G) == 12 * 3 + 7
+
+
+def test_pgcn_train_gradient_oracle_matches_reference_autograd(golden):
+    from conftest import check_compact_grads
+    from oracle.pgcn_grad import pgcn_train_forward_backward
+    g = golden('g16_pgcn_grad')
+    sd = synth.synth_state_dict(_pgcn_shapes(), SEED)
+    x, gy = synth.synth_input('pgcngrad.x', (5, 21, 128), SEED), synth.synth_input('pgcngrad.gy', (5, 21, 128), SEED)
+    y, gx, G, running = pgcn_train_forward_backward(sd, x, gy)
+    assert maxabs(y, g['y']) < 2e-5 * np.abs(g['y']).max()
+    assert maxabs(gx, g['grad.x']) < 3e-5 * np.abs(g['grad.x']).max()
+    G = {k: (v.reshape(2 * 21 * 128, 128) if k.endswith('gconv.W') else v) for k, v in G.items()}
+    assert check_compact_grads(G, g, 3e-5, zero_suffixes=('gconv.bias', 'gconv.e_0')) < 3e-5
+    for k, v in running.items():
+        assert maxabs(v, g['after.' + k]) < 1e-5 * max(1.0, np.abs(g['after.' + k]).max()), k
