@@ -335,6 +335,69 @@ __global__ __launch_bounds__(64) void pgcn_adj_bwd_softmax_kernel(const float* e
     for (int t = 0; t < deg; ++t) ge1[o0 + t] = p[t] * (gA_edge[o0 + t] - dot);
 }
 
+// ------------------------------------------------------------------------------------------------------------------ grid sample
+// F.grid_sample(feat, uv[:, None], bilinear, zeros padding, align_corners False) at 21 joints (models/dir.py:198): feat NHWC fp32
+// [B,S,S,C]; rows [B*21, C] (token-major).  Backward w.r.t. feat only (uv comes in detached, models/dir.py:447-453).
+struct GridArgs2 { const float* feat; const float* uv; float* rows; const float* grows[2]; const float* uvs[2]; float* gfeat; int B, S, C, hands; };
+
+__device__ __forceinline__ void bilinear_taps(float u, float v, int S, int (&ix)[4], int (&iy)[4], float (&w)[4]) {
+#pragma clang fp contract(off)
+    const float fx = ((u + 1.f) * S - 1.f) / 2.f, fy = ((v + 1.f) * S - 1.f) / 2.f;
+    const float x0 = floorf(fx), y0 = floorf(fy), x1 = x0 + 1.f, y1 = y0 + 1.f;
+    const float wx[4] = {x1 - fx, fx - x0, x1 - fx, fx - x0}, wy[4] = {y1 - fy, y1 - fy, fy - y0, fy - y0};
+    const float xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const bool ok = xs[t] >= 0.f && xs[t] <= (float)(S - 1) && ys[t] >= 0.f && ys[t] <= (float)(S - 1);
+        ix[t] = ok ? (int)xs[t] : 0; iy[t] = ok ? (int)ys[t] : 0;
+        w[t] = ok ? wx[t] * wy[t] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void grid_rows_fwd_kernel(GridArgs2 a) {          // grid (B*21), thread = channel
+    const int bj = blockIdx.x, b = bj / 21;
+    int ix[4], iy[4]; float w[4];
+    bilinear_taps(a.uv[2 * bj], a.uv[2 * bj + 1], a.S, ix, iy, w);
+    for (int c = threadIdx.x; c < a.C; c += 256) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc += a.feat[(((long long)b * a.S + iy[t]) * a.S + ix[t]) * a.C + c] * w[t];
+        a.rows[(long long)bj * a.C + c] = acc;
+    }
+}
+// g feat[b][pixel][c] += w g rows[b*21 + j][c]: one thread per (sample, channel) walks the hands' 21 x 4 taps in order (deterministic;
+// two joints, or the two hands' samplers, may hit the same pixel).  g feat must be zero on entry.
+__global__ __launch_bounds__(256) void grid_rows_bwd_kernel(GridArgs2 a) {          // grid (B, ceil(C / 256))
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= a.C) return;
+    for (int h = 0; h < a.hands; ++h)
+        for (int j = 0; j < 21; ++j) {
+            const int bj = b * 21 + j;
+            int ix[4], iy[4]; float w[4];
+            bilinear_taps(a.uvs[h][2 * bj], a.uvs[h][2 * bj + 1], a.S, ix, iy, w);
+            const float g = a.grows[h][(long long)bj * a.C + c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (w[t] != 0.f) { float* p = a.gfeat + (((long long)b * a.S + iy[t]) * a.S + ix[t]) * a.C + c; *p = fmaf(w[t], g, *p); }
+        }
+}
+
+// dst += alpha src (gradient accumulation of shared modules: global_pos_emb / proj_feat_emb run once per hand, models/dir.py:106-107,118-119)
+__global__ __launch_bounds__(256) void axpy_kernel(float* dst, const float* src, long long n, float alpha) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = fmaf(alpha, src[i], dst[i]);
+}
+// token-path inputs of a stage (models/dir.py:97-98,106-107): pos = xyz / 0.15; gpos = xyz / 0.15 -+ offset / 2 (left -, right +)
+__global__ __launch_bounds__(256) void stage_positions_kernel(const float* xyz_l, const float* xyz_r, const float* offset, float* pos_l, float* pos_r,
+                                                              float* gpos_l, float* gpos_r, int n) {      // n = B * 63
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / 63, c = i % 3;
+    const float o = offset[3 * b + c] / 2.f;
+    const float l = xyz_l[i] / 0.15f, r = xyz_r[i] / 0.15f;
+    pos_l[i] = l; pos_r[i] = r; gpos_l[i] = l - o; gpos_r[i] = r + o;
+}
+
 }  // namespace
 
 extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* stream) {
@@ -437,4 +500,40 @@ extern "C" int dir_pgcn_adjacency_backward(const float* e1, const float* gz, con
     DIR_LAUNCH(pgcn_adj_bwd_edge_kernel, dim3(40), dim3(64), 0, (hipStream_t)stream, gz, h1, scratch40, B);
     DIR_LAUNCH(pgcn_adj_bwd_softmax_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, e1, scratch40, g_e1);
     return check_launch("dir_pgcn_adjacency_backward");
+}
+
+extern "C" int dir_grid_rows_forward(const float* feat_nhwc, const float* uv, float* rows, int B, int S, int C, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(feat_nhwc && uv && rows && B > 0 && S > 0 && C > 0, "dir_grid_rows_forward: bad arguments");
+    GridArgs2 a{};
+    a.feat = feat_nhwc; a.uv = uv; a.rows = rows; a.B = B; a.S = S; a.C = C;
+    DIR_LAUNCH(grid_rows_fwd_kernel, dim3(B * 21), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("dir_grid_rows_forward");
+}
+extern "C" int dir_grid_rows_backward(const float* const* g_rows_h, const float* const* uv_h, int hands, float* g_feat_nhwc, int B, int S, int C,
+                                      int zero_first, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(g_rows_h && uv_h && g_feat_nhwc && (hands == 1 || hands == 2) && B > 0 && S > 0 && C > 0, "dir_grid_rows_backward: bad arguments");
+    GridArgs2 a{};
+    for (int h = 0; h < hands; ++h) { DIR_REQUIRE(g_rows_h[h] && uv_h[h], "dir_grid_rows_backward: null hand"); a.grows[h] = g_rows_h[h]; a.uvs[h] = uv_h[h]; }
+    a.gfeat = g_feat_nhwc; a.B = B; a.S = S; a.C = C; a.hands = hands;
+    hipStream_t s = (hipStream_t)stream;
+    if (zero_first && hipMemsetAsync(g_feat_nhwc, 0, (size_t)B * S * S * C * sizeof(float), s) != hipSuccess) { set_error("dir_grid_rows_backward: memset failed"); return DIR_E_LAUNCH; }
+    DIR_LAUNCH(grid_rows_bwd_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, s, a);
+    return check_launch("dir_grid_rows_backward");
+}
+
+extern "C" int dir_axpy_f32(float* dst, const float* src, long long n, float alpha, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(dst && src && n > 0, "dir_axpy_f32: bad arguments");
+    DIR_LAUNCH(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, alpha);
+    return check_launch("dir_axpy_f32");
+}
+extern "C" int dir_stage_positions(const float* xyz_left, const float* xyz_right, const float* offset, float* pos_left, float* pos_right,
+                                   float* gpos_left, float* gpos_right, int B, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(xyz_left && xyz_right && offset && pos_left && pos_right && gpos_left && gpos_right && B > 0, "dir_stage_positions: bad arguments");
+    DIR_LAUNCH(stage_positions_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz_left, xyz_right, offset, pos_left, pos_right,
+               gpos_left, gpos_right, B * 63);
+    return check_launch("dir_stage_positions");
 }

@@ -170,3 +170,43 @@ def pgcn_adjacency_bwd(e1, gz, h1):
     _capi.check(_capi.lib().dir_pgcn_adjacency_backward(_capi.ptr(e1), _capi.ptr(gz), _capi.ptr(h1), _capi.ptr(scratch), _capi.ptr(ge), gz.shape[0],
                                                         _capi.stream_ptr()), 'dir_pgcn_adjacency_backward')
     return ge
+
+
+def grid_rows_fwd(feat_nhwc, uv):
+    """[B,S,S,C], uv [B,21,2] -> [B*21, C]"""
+    _chk(feat_nhwc, uv)
+    B, S, _, C = feat_nhwc.shape
+    rows = torch.empty(B * 21, C, device=uv.device)
+    _capi.check(_capi.lib().dir_grid_rows_forward(_capi.ptr(feat_nhwc), _capi.ptr(uv), _capi.ptr(rows), B, S, C, _capi.stream_ptr()), 'dir_grid_rows_forward')
+    return rows
+
+
+def grid_rows_bwd(g_rows_list, uv_list, B, S, C, out=None):
+    """sum over the samplers (hands) -> g feat NHWC [B,S,S,C] (written; or added onto `out`)"""
+    import ctypes as Ct
+    _chk(*(list(g_rows_list) + list(uv_list)))
+    n = len(g_rows_list)
+    zero = out is None
+    if out is None:
+        out = torch.empty(B, S, S, C, device=uv_list[0].device)
+    P = Ct.c_void_p * n
+    _capi.check(_capi.lib().dir_grid_rows_backward(P(*[t.data_ptr() for t in g_rows_list]), P(*[t.data_ptr() for t in uv_list]), n, _capi.ptr(out), B, S, C,
+                                                   int(zero), _capi.stream_ptr()), 'dir_grid_rows_backward')
+    return out
+
+
+def axpy(dst, src, alpha=1.0):
+    """dst += alpha src (both contiguous, same size)"""
+    _chk(dst, src)
+    assert dst.numel() == src.numel()
+    _capi.check(_capi.lib().dir_axpy_f32(_capi.ptr(dst), _capi.ptr(src), dst.numel(), float(alpha), _capi.stream_ptr()), 'dir_axpy_f32')
+    return dst
+
+
+def stage_positions(xyz_l, xyz_r, offset):
+    _chk(xyz_l, xyz_r, offset)
+    B = xyz_l.shape[0]
+    outs = [torch.empty(B * 21, 3, device=xyz_l.device) for _ in range(4)]
+    _capi.check(_capi.lib().dir_stage_positions(_capi.ptr(xyz_l), _capi.ptr(xyz_r), _capi.ptr(offset), *[_capi.ptr(o) for o in outs], B, _capi.stream_ptr()),
+                'dir_stage_positions')
+    return outs

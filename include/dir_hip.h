@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 19
+#define DIR_ABI_VERSION 20
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -153,6 +153,20 @@ int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, v
 /* PGraphConv's adjacency (SemGCN/p_graph_conv.py:43-50): A_1 [21][21] = row-softmax of the hand-skeleton mask filled with e_1 [40]
  * (row-major nonzero order); backward: g e_1 from g z [B,21,128] (gradient of the layer's pre-BatchNorm output) and h1 = x W_1 [B,21,128]
  * (g A_1[j][k] = sum_b <g z[b][j], h1[b][k]> on the edges, then the softmax chain rule).  scratch40: 40 floats. */
+/* ImgFeature2JointFeature's sampler in training form (models/dir.py:197-198): F.grid_sample(bilinear, zeros, align_corners False) of
+ * feat NHWC fp32 [B,S,S,C] at uv [B,21,2] -> rows [B*21][C]; backward w.r.t. feat only (uv arrives detached, models/dir.py:447-453):
+ * g feat += sum over `hands` samplers (g_rows_h / uv_h: host arrays of device pointers); zero_first != 0 clears g feat before.
+ * Deterministic: the taps of a (sample, channel) are applied in a fixed order by one thread. */
+int dir_grid_rows_forward(const float* feat_nhwc, const float* uv, float* rows, int B, int S, int C, void* stream);
+int dir_grid_rows_backward(const float* const* g_rows_h_host, const float* const* uv_h_host, int hands, float* g_feat_nhwc, int B, int S, int C,
+                           int zero_first, void* stream);
+/* dst += alpha * src, n floats (gradient accumulation of the modules a stage runs once per hand: global_pos_emb, proj_feat_emb,
+ * models/dir.py:106-107,118-119). */
+int dir_axpy_f32(float* dst, const float* src, long long n, float alpha, void* stream);
+/* Joint2BoneFeature's token inputs (models/dir.py:97-98,106-107): pos = xyz / 0.15, gpos_left = xyz_left / 0.15 - offset / 2,
+ * gpos_right = xyz_right / 0.15 + offset / 2; xyz [B,21,3], offset [B,3], outputs [B*21,3]. */
+int dir_stage_positions(const float* xyz_left, const float* xyz_right, const float* offset, float* pos_left, float* pos_right,
+                        float* gpos_left, float* gpos_right, int B, void* stream);
 int dir_pgcn_adjacency_forward(const float* e1, float* A, void* stream);
 int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h1, float* scratch40, float* g_e1, int B, void* stream);
 

@@ -601,6 +601,8 @@ def compact_grads(named, step=16):
     """fixture-size form of a set of parameter gradients: small tensors whole; matrices as every `step`-th column + row / column sums"""
     res = {}
     for k, g in named.items():
+        while g.dim() > 2 and g.shape[-1] == 1:             # Conv1d k=1 weights [out, in, 1]
+            g = g.squeeze(-1)
         if g.dim() < 2 or g.numel() <= 8192:
             res['grad.' + k] = g
         else:
@@ -652,7 +654,47 @@ def gen_pgcn_grad():
     save('g16_pgcn_grad', **res)
 
 
-GENS = {'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G17 gradients through one stage's token half (training mode)
+STAGE_GRAD_COT = ('pd_offset', 'pd_mano_para_left', 'pd_mano_para_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left',
+                  'pd_joint_xyz_right', 'pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_uv_left', 'pd_mesh_uv_right')
+
+
+def gen_stage_grad():
+    """torch autograd through the reference's Joint2BoneFeature.forward (models/dir.py:86-116) in TRAINING mode: L = sum <cot_k, result_k>
+    over the regressor's outputs + <cot, STE output>; gradients w.r.t. img_feat and every parameter on the token path"""
+    from models.dir import Joint2BoneFeature
+    from oracle.golden_inputs import stage_grad_inputs
+    S = 16
+    net = Joint2BoneFeature(256, 128, 64, 21, S, 'unused', 0, distance=1)
+    load_synth(net)
+    net.train()
+    ins, cot = stage_grad_inputs(S)
+    ins = [torch.from_numpy(a) for a in ins]
+    feat = ins[0].clone().requires_grad_(True)
+    tap = {}
+    net.interaction.register_forward_hook(lambda m, a, o: tap.__setitem__('ste', o))
+    result, feats = net(feat, *ins[1:])
+    L = (tap['ste'] * torch.from_numpy(cot['joint_feat'])).sum()
+    for k in STAGE_GRAD_COT:
+        L = L + (result[k] * torch.from_numpy(cot[k])).sum()
+    params = {k: v for k, v in net.named_parameters() if not (k.startswith('proj_feat_emb') or k.startswith('fusion'))}
+    gs = torch.autograd.grad(L, [feat] + list(params.values()), allow_unused=True)
+    res = {('out.' + k): result[k].detach() for k in STAGE_GRAD_COT}
+    res['out.joint_feat'] = tap['ste'].detach()
+    res['gfeat.ch4'] = gs[0][:, ::4].contiguous()               # every 4th channel + the channel sums of the gradient into fusion_feat
+    res['gfeat.chsum'] = gs[0].double().sum(1)
+    res['gfeat.abssum'] = gs[0].double().abs().sum(1)
+    named = {k: g for k, g in zip(params, gs[1:]) if g is not None}
+    unused = sorted(k for k, g in zip(params, gs[1:]) if g is None)
+    print('   parameters without gradient:', unused)
+    res.update(compact_grads(named, step=32))
+    for k, v in net.state_dict().items():
+        if 'running_' in k and not (k.startswith('proj_feat_emb') or k.startswith('fusion')):
+            res['after.' + k] = v
+    save('g17_stage_grad', **res)
+
+
+GENS = {'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

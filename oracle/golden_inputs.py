@@ -143,3 +143,15 @@ def regress_grad_inputs(B=4):
         shp.update({'pd_joint_uv_' + s_: (B, 21, 2), 'pd_mesh_uv_' + s_: (B, 778, 2), 'pd_joint_xyz_' + s_: (B, 21, 3), 'pd_mesh_xyz_' + s_: (B, 778, 3)})
     cot = {k: g('cot.' + k, shp[k]) for k in REGRESS_OUT_KEYS}
     return ins, cot
+
+
+def stage_grad_inputs(S=16, B=4):
+    """G17: stage inputs (as stage_inputs) + the cotangents of the stage's outputs"""
+    ins = stage_inputs(S, B)
+    shapes = {'pd_offset': (B, 3), 'joint_feat': (B, 42, 64)}
+    for s in ('left', 'right'):
+        shapes.update({'pd_mano_para_' + s: (B, 64), 'pd_mesh_xyz_' + s: (B, 778, 3), 'pd_joint_xyz_' + s: (B, 21, 3),
+                       'pd_joint_uv_' + s: (B, 21, 2), 'pd_mesh_uv_' + s: (B, 778, 2)})
+    cot = {k: synth.synth_input('stagegrad.' + k, shp, SEED) for k, shp in shapes.items()}
+    cot['joint_feat'] = cot['joint_feat'] * np.float32(0.05)
+    return ins, cot

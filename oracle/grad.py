@@ -61,6 +61,8 @@ def regressor_vjp(P, mano_l, mano_r, feat_l, feat_r, para_l, para_r, offset, cot
     for side, p, buf in (('left', pl, mano_l), ('right', pr, mano_r)):
         g_para[side] = mano_vjp(buf, p, side, root_joint, cot.get('pd_mesh_xyz_' + side), cot.get('pd_joint_xyz_' + side),
                                 cot.get('pd_joint_uv_' + side), cot.get('pd_mesh_uv_' + side))
+        if cot.get('pd_mano_para_' + side) is not None:                 # the 64-vector is itself an output (the next stage's input, :366-367)
+            g_para[side] = g_para[side] + f8(cot['pd_mano_para_' + side])
     g_off = f8(cot['pd_offset']) if cot.get('pd_offset') is not None else np.zeros((B, 3))
     n = fl.shape[1]
     return {'feat_l': (g_para['left'] @ Wl[:, :n] + g_off @ Wo[:, :n]).reshape(feat_l.shape),

@@ -69,6 +69,8 @@ def check_compact_grads(got, g, tol, prefix='grad.', zero_suffixes=()):
         if name not in got:
             continue
         a = np.asarray(got[name], np.float64)
+        while a.ndim > 2 and a.shape[-1] == 1:              # Conv1d k=1 weights [out, in, 1]
+            a = a[..., 0]
         if any(name.endswith(z) for z in zero_suffixes):
             # analytically zero (e.g. a bias in front of a training-mode BatchNorm, which subtracts the batch mean): both sides hold
             # rounding noise only
@@ -78,7 +80,7 @@ def check_compact_grads(got, g, tol, prefix='grad.', zero_suffixes=()):
             ref = g[prefix + name]
             e = np.abs(a.reshape(ref.shape) - ref).max() / (np.abs(ref).max() + 1e-30)
         else:
-            a2 = a.reshape(a.shape[0], -1)
+            a2 = a.reshape(-1, a.shape[-1])
             ck = [k for k in g if k.startswith(prefix + name + '.cols')][0]
             step = int(ck.rsplit('.cols', 1)[1])
             # the sums are compared on the scale of the L1 norms of the rows / columns they sum: a gradient that flows out of a

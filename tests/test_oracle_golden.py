@@ -416,3 +416,32 @@ def test_pgcn_train_gradient_oracle_matches_reference_autograd(golden):
     assert check_compact_grads(G, g, 3e-5, zero_suffixes=('gconv.bias', 'gconv.e_0')) < 3e-5
     for k, v in running.items():
         assert maxabs(v, g['after.' + k]) < 1e-5 * max(1.0, np.abs(g['after.' + k]).max()), k
+
+
+# ------------------------------------------------------------------ G17 gradients through one stage's token half (training mode)
+STAGE_ZERO_GRADS = ('gconv.bias', 'gconv.e_0', 'filters.0.bias', 'pos_emb_left.0.bias', 'pos_emb_right.0.bias', 'global_pos_emb.0.bias')
+MANO_KEYS = ('th_selected_comps', 'th_hands_mean', 'th_shapedirs', 'th_posedirs', 'th_v_template', 'th_J_regressor', 'th_weights')
+
+
+def test_stage_token_gradient_oracle_matches_reference_autograd(golden):
+    """the float64 chain rule through sampler -> token MLPs -> P-GCN -> STE -> RegressorOffset -> MANO (oracle/stage_grad.py) against torch
+    autograd through the reference's Joint2BoneFeature in training mode"""
+    from conftest import check_compact_grads
+    from oracle.golden_inputs import stage_grad_inputs
+    from oracle.stage_grad import stage_token_grads
+    g = golden('g17_stage_grad')
+    sd = synth.synth_state_dict(shapes_of('manifest_stage16.json'), SEED)
+    ins, cot = stage_grad_inputs(16)
+    mano = [{k: sd['regressor.mano_layer_%s.%s' % (s, k)] for k in MANO_KEYS} for s in ('left', 'right')]
+    tok, g_feat, G, running = stage_token_grads(sd, mano[0], mano[1], *ins, cot)
+    assert maxabs(tok, g['out.joint_feat']) < 2e-5 * np.abs(g['out.joint_feat']).max()
+    gm = np.abs(g['gfeat.ch4']).max()
+    assert maxabs(g_feat[:, ::4], g['gfeat.ch4']) < 3e-5 * gm
+    assert maxabs(g_feat.sum(1), g['gfeat.chsum']) < 3e-5 * g['gfeat.abssum'].max()
+    G = {k: (v.reshape(2 * 21 * 128, 128) if k.endswith('gconv.W') else v) for k, v in G.items()}
+    worst = check_compact_grads(G, g, 5e-5, zero_suffixes=STAGE_ZERO_GRADS)
+    n_ref = len({k for k in g if k.startswith('grad.')})
+    assert n_ref > 100 and worst < 5e-5
+    for k, v in running.items():
+        assert maxabs(v, g['after.' + k]) < 1e-5 * max(1.0, np.abs(g['after.' + k]).max()), k
+    assert len(running) == 2 * (2 + 2 + 8) + 2
