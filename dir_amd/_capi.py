@@ -152,7 +152,7 @@ _SIGNATURES = {
     'dir_gt_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     'dir_joint_regress_forward': (C.c_int, [_p, _p, _p, _i, _p]),
     'dir_eval_metrics_forward': (C.c_int, [C.POINTER(EvalInputs), C.POINTER(EvalOutputs), _i, _i, _i, _p]),
-    'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _i, _p]),
+    'dir_mano_forward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
     'dir_mano_backward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     'dir_regress_backward': (C.c_int, [_p] * 17 + [_i, _p]),
     'dir_gemm_f32': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p]),

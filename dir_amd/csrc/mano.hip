@@ -321,7 +321,7 @@ extern "C" int dir_mano_forward(const dir_mano_tables* t, const float* pose, int
 extern "C" int dir_mano_forward_pair(const dir_mano_tables* tables_lr, const float* const* pose_lr, int pose_stride,
                                      const float* const* betas_lr, int betas_stride, const float* const* cam_lr,
                                      int cam_stride, float* const* verts_lr, float* const* joints_lr,
-                                     float* const* joint_uv_lr, int32_t* const* flags_lr, int B, void* stream) {
+                                     float* const* joint_uv_lr, float* const* mesh_uv_lr, int32_t* const* flags_lr, int B, void* stream) {
     if (B == 0) return DIR_OK;
     DIR_REQUIRE(B > 0 && tables_lr && pose_lr && betas_lr && verts_lr && joints_lr, "dir_mano_forward_pair: bad arguments");
     ManoArgs a;
@@ -331,7 +331,7 @@ extern "C" int dir_mano_forward_pair(const dir_mano_tables* tables_lr, const flo
                             joints_lr[h]);
         if (rc) return rc;
         a.h[h] = ManoHand{tables_lr[h], pose_lr[h], pose_stride, betas_lr[h], betas_stride, cam, cam_stride, verts_lr[h],
-                          joints_lr[h], joint_uv_lr ? joint_uv_lr[h] : nullptr, nullptr, flags_lr ? flags_lr[h] : nullptr};
+                          joints_lr[h], joint_uv_lr ? joint_uv_lr[h] : nullptr, mesh_uv_lr ? mesh_uv_lr[h] : nullptr, flags_lr ? flags_lr[h] : nullptr};
     }
     launch_mano(a, B, 2, (hipStream_t)stream);
     return dir::check_launch("dir_mano_forward_pair");

@@ -602,13 +602,17 @@ class StageOp(object):
         self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
 
 
-def run_mano_pair(tables_lr, para_l, para_r, B, flags=None):
+def run_mano_pair(tables_lr, para_l, para_r, B, flags=None, mesh_uv=False):
     """MANO + projection for both hands in one launch, straight out of the 64-wide parameter vectors
     (pose = para[:, :51], betas = para[:, 51:61], cam = para[:, 61:64]; models/dir.py:272-280).  flags: optional int32 [2, B],
-    set to 1 where the 6D root rotation has det < 0 (the reference asserts there, rot6d.py:50)."""
+    set to 1 where the 6D root rotation has det < 0 (the reference asserts there, rot6d.py:50).  mesh_uv: also return pd_mesh_uv
+    [B,778,2] per hand (fourth entry), which only the training loss reads."""
     dev = para_l.device
     out = [[torch.empty(B, 778, 3, device=dev, dtype=F32), torch.empty(B, 21, 3, device=dev, dtype=F32),
             torch.empty(B, 21, 2, device=dev, dtype=F32)] for _ in range(2)]
+    if mesh_uv:
+        for o in out:
+            o.append(torch.empty(B, 778, 2, device=dev, dtype=F32))
     P2 = C.c_void_p * 2
     base = (para_l.data_ptr(), para_r.data_ptr())
     tabs = (_capi.ManoTables * 2)(tables_lr[0], tables_lr[1])
@@ -617,7 +621,7 @@ def run_mano_pair(tables_lr, para_l, para_r, B, flags=None):
     rc = _capi.lib().dir_mano_forward_pair(
         tabs, P2(base[0], base[1]), 64, P2(base[0] + 51 * 4, base[1] + 51 * 4), 64, P2(base[0] + 61 * 4, base[1] + 61 * 4), 64,
         P2(out[0][0].data_ptr(), out[1][0].data_ptr()), P2(out[0][1].data_ptr(), out[1][1].data_ptr()),
-        P2(out[0][2].data_ptr(), out[1][2].data_ptr()),
+        P2(out[0][2].data_ptr(), out[1][2].data_ptr()), P2(out[0][3].data_ptr(), out[1][3].data_ptr()) if mesh_uv else None,
         None if flags is None else P2(flags[0].data_ptr(), flags[1].data_ptr()), B, _capi.stream_ptr())
     _capi.check(rc, 'dir_mano_forward_pair')
     return out
@@ -811,7 +815,11 @@ class DirEngine(object):
 
     # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic.  (Code 19, the
     # 64x128 tile on the 3-buffer ring, is not offered: see conv.hip, DIR_RING_64x128.)
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14, STREAM_VARIANT)
+    # These all accumulate in the same order (outputs bit-identical whichever is chosen).  The streaming 1x1 kernel (STREAM_VARIANT,
+    # stream.hip) feeds the MFMA its k-slots in another order, so its bf16 outputs differ from the others' in the last bit: the
+    # autotuner offers it only on request (DIR_STREAM_1X1=1) -- by default the per-layer choice, which depends on timing, cannot
+    # change a single output bit.  Measured gain when offered: ~8 us on each of the two 512->128 @32x32 Residual conv1 layers.
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14) + ((STREAM_VARIANT,) if os.environ.get('DIR_STREAM_1X1') == '1' else ())
 
     def _profiled_forwards(self, img, n):
         """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""

@@ -9,8 +9,7 @@ the backward, every arithmetic step a libdir_hip.so kernel (dir_amd/train/ops.py
         feat   fusion_feat NHWC fp32 [B,S,S,C]
         prev   the previous stage's outputs, all entering detached (models/dir.py:447-453): 'pd_joint_xyz_left/right' [B,21,3],
                'pd_joint_uv_left/right' [B,21,2], 'pd_mano_para_left/right' [B,64], 'pd_offset' [B,3]
-        out    'pd_offset', 'pd_mano_para_*', 'pd_mesh_xyz_*', 'pd_joint_xyz_*', 'pd_joint_uv_*', 'pd_mesh_uv_*' (computed from
-               joint/mesh xyz by the MANO kernel's projection) and 'joint_feat' [B,42,64] (the STE output the image half re-embeds,
+        out    'pd_offset', 'pd_mano_para_*', 'pd_mesh_xyz_*', 'pd_joint_xyz_*', 'pd_joint_uv_*', 'pd_mesh_uv_*' and 'joint_feat' [B,42,64] (the STE output the image half re-embeds,
                models/dir.py:118-119)
     g_feat, grads = stage_tokens_backward(P, mano_tables_lr, ctx, cot, g_joint_feat=None)
         cot    cotangents of out: any of 'pd_offset' [B,3], 'pd_mano_para_left/right' [B,64], 'pd_mesh_xyz_*', 'pd_joint_xyz_*',
@@ -113,12 +112,12 @@ def stage_tokens_forward(P, mano_tables_lr, feat_nhwc, prev):
     off = torch.empty(B, 3, device=dev)
     O.gemm_strided(tok, W, off, B, 3, 2 * NJ * TOK, 2 * NJ * TOK, W.shape[1], 3, tb=True, bias=b)
     O.gemm_strided(poff, W, off, B, 3, 3, 3, W.shape[1], 3, tb=True, b_off=2 * NJ * TOK, accumulate=True)
-    mano = E.run_mano_pair(mano_tables_lr, para[0], para[1], B)
+    mano = E.run_mano_pair(mano_tables_lr, para[0], para[1], B, mesh_uv=True)
     ctx['para'] = para
     out = {'pd_offset': off, 'joint_feat': tok}
     for h, s in enumerate(SIDES):
         out['pd_mano_para_' + s] = para[h]
-        out['pd_mesh_xyz_' + s], out['pd_joint_xyz_' + s], out['pd_joint_uv_' + s] = mano[h]
+        out['pd_mesh_xyz_' + s], out['pd_joint_xyz_' + s], out['pd_joint_uv_' + s], out['pd_mesh_uv_' + s] = mano[h]
     return out, ctx
 
 

@@ -1,0 +1,46 @@
+"""Where the backward pass meets the optimiser: the gradients dir_amd/train/* returns are added into the `.grad` views of
+dir_amd.optim.FlatAdamW (one contiguous fp32 buffer in parameter order = the bucket `dir_amd.dist.average_gradients` all-reduces,
+SURVEY.md 8e), and one training step of a refinement stage's token half is composed from the library calls:
+
+    stage_tokens_forward -> dir_stage_losses_backward (the 13 loss terms' gradients w.r.t. the predictions, models/dir.py:543-591)
+    -> stage_tokens_backward -> add_grads -> [average_gradients] -> FlatAdamW.step            (train.py:62-70 for this part of the net)
+
+The image half (backbone, decoder convolutions, bone_proj, fusion) has no backward yet: its parameters receive no gradient here.
+"""
+import torch
+
+from . import ops as O
+from . import stage as TS
+from .. import dist as D
+from ..models import loss as L
+
+
+def add_grads(named_params, prefix, grads):
+    """named_params: {full name -> nn.Parameter whose .grad is a view of FlatAdamW.flat_grad}; grads: {key relative to prefix -> tensor}.
+    .grad += gradient, one dir_axpy_f32 per tensor (a parameter used twice accumulates, like autograd)."""
+    for k, g in grads.items():
+        p = named_params[prefix + k]
+        assert p.grad is not None and p.grad.numel() == g.numel(), prefix + k
+        O.axpy(p.grad, g.contiguous())
+
+
+def inactive_parameters(named_params):
+    """the parameters torch leaves without a gradient on the token path (never-executed STE block 0, transformer/mixSTE.py:197):
+    FlatAdamW.set_inactive() keeps AdamW from decaying them, as torch.optim.AdamW skips `grad is None`.  (PGraphConv's e_0 does get a
+    gradient in the reference -- identically zero -- so it stays active and decays, like there.)"""
+    return [p for k, p in named_params.items() if '.interaction.STEblocks.0.' in '.' + k]
+
+
+def token_stage_train_step(named_params, prefix, mano_tables_lr, feat_nhwc, prev, target, meta_info, faces, optimizer, coord_weight=10.0,
+                           g_joint_feat=None):
+    """one optimisation step of the token half of the stage whose parameters are named `prefix + key`.
+    -> (stage outputs, g fusion_feat NHWC): the gradient the image half would continue from."""
+    P = {k[len(prefix):]: (v.data if isinstance(v, torch.nn.Parameter) else v) for k, v in named_params.items() if k.startswith(prefix)}
+    out, ctx = TS.stage_tokens_forward(P, mano_tables_lr, feat_nhwc, prev)
+    cot = L.stage_loss_grads(out, target, meta_info, faces, coord_weight)
+    g_feat, G = TS.stage_tokens_backward(P, mano_tables_lr, ctx, cot, g_joint_feat)
+    optimizer.zero_grad()
+    add_grads(named_params, prefix, G)
+    D.average_gradients(optimizer.flat_grad)
+    optimizer.step()
+    return out, g_feat

@@ -84,12 +84,14 @@ int dir_mano_forward(const dir_mano_tables* tables_host, const float* pose, int 
                      int B, void* stream);
 
 /* Both hands of one stage in ONE launch (grid = B x 2).  tables_lr[2] = {left, right}; the *_lr arguments are HOST
- * arrays of two device pointers.  cam_lr / joint_uv_lr / flags_lr may be NULL; flags_lr[h] = int32[B] as flags_out above
+ * arrays of two device pointers.  cam_lr / joint_uv_lr / mesh_uv_lr / flags_lr may be NULL (mesh_uv_lr: pd_mesh_uv_* [B,778,2], which only
+ * the training loss reads, models/dir.py:278-280,574-575); flags_lr[h] = int32[B] as flags_out above
  * (the reflection check of rot6d.py:50 that DIR.forward turns into the reference's AssertionError). */
 int dir_mano_forward_pair(const dir_mano_tables* tables_lr_host, const float* const* pose_lr_host, int pose_stride,
                           const float* const* betas_lr_host, int betas_stride, const float* const* cam_lr_host,
                           int cam_stride, float* const* verts_lr_host, float* const* joints_lr_host,
-                          float* const* joint_uv_lr_host, int32_t* const* flags_lr_host, int B, void* stream);
+                          float* const* joint_uv_lr_host, float* const* mesh_uv_lr_host, int32_t* const* flags_lr_host, int B,
+                          void* stream);
 
 /* SURVEY 8f rank 2, backward pass, first link behind the loss gradients: the gradient of
  *   <g_verts, verts> + <g_joints, joints> + <g_joint_uv, joint_uv> + <g_mesh_uv, mesh_uv>

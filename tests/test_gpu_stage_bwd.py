@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ZERO = ('gconv.bias', 'gconv.e_0', 'filters.0.bias', 'pos_emb_left.0.bias', 'pos_emb_right.0.bias', 'global_pos_emb.0.bias')
 MANO_KEYS = ('th_selected_comps', 'th_hands_mean', 'th_shapedirs', 'th_posedirs', 'th_v_template', 'th_J_regressor', 'th_weights')
 OUT_KEYS = ('pd_offset', 'pd_mano_para_left', 'pd_mano_para_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left',
-            'pd_joint_xyz_right', 'pd_joint_uv_left', 'pd_joint_uv_right')
+            'pd_joint_xyz_right', 'pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_uv_left', 'pd_mesh_uv_right')
 
 
 def setup(B):
@@ -114,3 +114,54 @@ def test_grid_rows_roundtrip():
     gf = O.grid_rows_bwd([g], [uv], B, S, C)
     lhs, rhs = (rows.double() * g.double()).sum(), (feat.double() * gf.double()).sum()
     assert abs(float(lhs - rhs)) < 1e-6 * float(rows.double().abs().mul(g.double().abs()).sum())
+
+
+def test_token_stage_train_step_feeds_flat_adamw():
+    """loss gradients -> stage backward -> FlatAdamW.flat_grad (the data-parallel bucket) -> AdamW step, all through library calls:
+    the bucket holds exactly the stage gradients, parameters without gradient (STE block 0, buffers) stay put, the rest move by
+    lr * sign(g) (Adam's first step) + decoupled decay"""
+    from dir_amd.optim import FlatAdamW
+    from dir_amd.train import step as TSTEP
+    B = 4
+    sd, P, tabs, keep, ins, cot, feat, prev, dv = setup(B)
+    params = {'decoder.projecter_4.' + k: torch.nn.Parameter(v.clone()) for k, v in P.items() if 'running_' not in k and 'num_batches' not in k
+              and 'mano_layer' not in k and k != 'img_gird'}
+    named = dict(params)
+    for k, v in P.items():
+        if 'decoder.projecter_4.' + k not in named:
+            named['decoder.projecter_4.' + k] = v.clone()                      # buffers (running statistics, MANO tables)
+    opt = FlatAdamW(list(params.values()), lr=1e-4)
+    # the image half (proj_feat_emb, fusion) has no backward yet: kept out of this step, like parameters torch leaves with grad None
+    opt.set_inactive(TSTEP.inactive_parameters(params) + [p for k, p in params.items() if '.proj_feat_emb.' in k or '.fusion.' in k])
+    before = {k: p.detach().clone() for k, p in params.items()}
+    rng = np.random.RandomState(3)
+    target, meta = {}, {}
+    for s in ('left', 'right'):
+        target['joint_2d_' + s] = dv(rng.uniform(0, 256, (B, 21, 2)).astype(np.float32))
+        target['mesh_2d_' + s] = dv(rng.uniform(0, 256, (B, 778, 2)).astype(np.float32))
+        target['joint_3d_' + s] = dv(rng.normal(0, 0.05, (B, 21, 3)).astype(np.float32))
+        target['mesh_3d_' + s] = dv(rng.normal(0, 0.05, (B, 778, 3)).astype(np.float32))
+        meta['center_' + s] = dv(rng.normal(0, 0.1, (B, 1, 3)).astype(np.float32))
+    faces = [dv(synth.mano_buffers(s, SEED)['th_faces'].astype(np.int64)) for s in ('left', 'right')]
+    # reference gradients of the same step, computed without the optimiser
+    Pd = {k[len('decoder.projecter_4.'):]: (v.data.clone() if isinstance(v, torch.nn.Parameter) else v.clone()) for k, v in named.items()}
+    from dir_amd.models import loss as L
+    out0, ctx0 = TS.stage_tokens_forward(Pd, tabs, feat, prev)
+    G0 = TS.stage_tokens_backward(Pd, tabs, ctx0, L.stage_loss_grads(out0, target, meta, faces))[1]
+    out, g_feat = TSTEP.token_stage_train_step(named, 'decoder.projecter_4.', tabs, feat, prev, target, meta, faces, opt)
+    assert torch.equal(out['pd_mesh_xyz_left'], out0['pd_mesh_xyz_left'])
+    moved = 0
+    for k, p in params.items():
+        rel = k[len('decoder.projecter_4.'):]
+        if rel in G0:
+            assert torch.equal(p.grad.reshape(-1), G0[rel].reshape(-1)), k              # the bucket holds the stage gradient, bit for bit
+            big = G0[rel].reshape(p.shape).abs() > 1e-6                        # >> Adam's eps 1e-8
+            if big.any():
+                d = (before[k] * (1 - 1e-4 * 1e-2) - p.detach())[big] / 1e-4           # = sign(g) * |g| / (|g| + eps) ~ sign(g)
+                assert (d * torch.sign(G0[rel].reshape(p.shape)[big]) > 0.5).all(), k
+                moved += 1
+        else:
+            assert torch.equal(p.detach(), before[k]), k                                # no gradient: untouched (no decay either)
+            assert 'STEblocks.0.' in k or 'proj_feat_emb' in k or 'fusion' in k, k
+    assert moved > 100
+    print('token-stage train step: %d parameter tensors updated through flat_grad (%d floats in the bucket)' % (moved, opt.flat_grad.numel()))

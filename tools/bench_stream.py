@@ -48,7 +48,7 @@ for name, HW, Cin, Cout, pre, Cin2, s2 in LAYERS:
         call = lambda: op(x)  # noqa: E731
         nbytes = (M * (Cin + Cout) + op.w.numel()) * 2
     best = None
-    for v in E.DirEngine.CONV_VARIANTS:
+    for v in tuple(v for v in E.DirEngine.CONV_VARIANTS if v != E.STREAM_VARIANT) + (E.STREAM_VARIANT,):
         E._TLS.variant = v
         t = timeit(call)
         if v == E.STREAM_VARIANT:
