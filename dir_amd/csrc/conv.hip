@@ -32,8 +32,10 @@ using namespace dir::convk;
 
 namespace {
 
+constexpr long long SPLITK_COUNTER_BYTES = 16384;      // head of a split-K workspace: one arrival counter per output tile (<= 4096 tiles)
+
 // MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
-template <typename TI, typename TO, int MI, int NJ, bool PRE, bool RING>
+template <typename TI, typename TO, int MI, int NJ, bool PRE, bool RING, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // DMA: K-slabs go global -> LDS directly (buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS image of a
     // wave-level DMA is lane-linear (8 rows x 128 B per instruction), so rows are unpadded and the bank-conflict-free
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // layout the coalesced epilogue uses, so both trips overlap (16-32 VGPRs held across a loop of at most 8 slabs).
     constexpr int RVN = OutVec<TO>::N, RCPR = BN / RVN, RCH = BM * RCPR / 256;
     uint4 rpre[sizeof(TO) == 2 ? RCH : 1];
-    const bool respre = a.res != nullptr && (a.flags & 4) && a.nk <= 8 && sizeof(TO) == 2;
+    const bool respre = !SPLIT && a.res != nullptr && (a.flags & 4) && a.nk <= 8 && sizeof(TO) == 2;
     if (respre) {
         const TO* __restrict__ resp = (const TO*)a.res;
 #pragma unroll
@@ -263,7 +265,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
         nact = s_nact;
     }
-    auto slab = [&](int i) { return sparse ? (int)s_list[i] : i; };
+    int kbeg = 0;
+    if constexpr (SPLIT) {                   // this workgroup's contiguous share of the K-slabs
+        const int z = blockIdx.y;
+        kbeg = (int)((long long)a.nk * z / a.splits);
+        nact = (int)((long long)a.nk * (z + 1) / a.splits) - kbeg;
+    }
+    auto slab = [&](int i) { return sparse ? (int)s_list[i] : kbeg + i; };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
 
@@ -355,6 +363,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
     }
 
+    if constexpr (SPLIT) {
+        // Partial tile -> workspace ([element][thread]: every store instruction of a wave is one contiguous 256-byte row), then one
+        // counter per tile decides who finishes: the last workgroup to arrive re-reads ALL partials in split order, so the sum does
+        // not depend on the arrival order.  The partials cross XCDs (one L2 each): they are written and read as relaxed AGENT-scope
+        // atomics (sc1 accesses that go through to the device-coherent level) and ordered by hand -- every wave drains its stores
+        // (vmcnt(0)), the workgroup meets at a barrier, then one lane bumps the counter.  (Agent-scope FENCES are correct too but
+        // write back / invalidate the whole L2 per workgroup: measured 12 us per extra split on the 128-tile layers.)
+        constexpr int NE = MI * NJ * 16;
+        float* part = a.ws_part + ((long long)blockIdx.y * nwg + bid) * (NE * 256);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(part + ((i * NJ + j) * 16 + e) * 256 + tid, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) s_last = __hip_atomic_fetch_add(&a.ws_cnt[bid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.splits - 1);
+        __syncthreads();
+        if (!s_last) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int z = 0; z < a.splits; ++z) {
+            const float* pz = a.ws_part + ((long long)z * nwg + bid) * (NE * 256);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[i][j][e] += __hip_atomic_load(pz + ((i * NJ + j) * 16 + e) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) __hip_atomic_store(&a.ws_cnt[bid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     TO* __restrict__ y = (TO*)a.y;
     const TO* __restrict__ res = (const TO*)a.res;
@@ -423,6 +471,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
 template <typename TI, typename TO>
 void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
+    if (a0.splits > 1) {                                   // dir_conv2d_splitk_forward: 128x128 tiles, 2-buffer loop
+        if constexpr (std::is_same<TI, bf16_t>::value && std::is_same<TO, bf16_t>::value) {
+            ConvArgs a = a0;
+            a.tiles_m = (a.M + 127) / 128;
+            a.tiles_n = (a.Cout + 127) / 128;
+            dim3 grid(a.tiles_m * a.tiles_n, a.splits), block(256);
+            if (a.pre_scale) DIR_LAUNCH((conv_igemm_kernel<TI, TO, 2, 2, true, false, true>), grid, block, 0, s, a);
+            else DIR_LAUNCH((conv_igemm_kernel<TI, TO, 2, 2, false, false, true>), grid, block, 0, s, a);
+        }
+        return;
+    }
     if constexpr (std::is_same<TI, bf16_t>::value) {
         // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip
         const bool four_wave = ((a0.variant & 15) >= 1 && (a0.variant & 15) <= 4) || a0.x2;   // explicit DIR_CONV_VARIANT 1..4 (+16), or a second source
@@ -491,7 +550,8 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
 
 static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                         const float* pre_scale, const float* pre_shift, const void* residual, void* y,
-                        const int32_t* bbox, void* stream, const dir_conv_src2* d2 = nullptr, const void* x2 = nullptr) {
+                        const int32_t* bbox, void* stream, const dir_conv_src2* d2 = nullptr, const void* x2 = nullptr,
+                        int splits = 0, void* workspace = nullptr, long long workspace_bytes = 0) {
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
@@ -562,6 +622,16 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
         hipDeviceProp_t p;
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
     }
+    a.splits = 0; a.ws_part = nullptr; a.ws_cnt = nullptr;
+    if (splits > 1) {
+        DIR_REQUIRE(!f32 && d->out_dtype == DIR_DT_BF16 && vec && bbox == nullptr, "dir_conv2d_splitk_forward: bf16 -> bf16 layers with 16-byte aligned output rows only");
+        DIR_REQUIRE(splits <= a.nk && splits <= 16, "dir_conv2d_splitk_forward: splits must be <= min(16, K / 64)");
+        const long long tiles = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+        const long long need = SPLITK_COUNTER_BYTES + (long long)splits * tiles * 128 * 128 * 4;
+        DIR_REQUIRE(workspace && workspace_bytes >= need && tiles * 4 <= SPLITK_COUNTER_BYTES && ((uintptr_t)workspace & 15) == 0,
+                    "dir_conv2d_splitk_forward: workspace of %lld bytes needed (dir_conv2d_splitk_workspace_bytes), 16-byte aligned", need);
+        a.splits = splits; a.ws_cnt = (unsigned*)workspace; a.ws_part = (float*)((char*)workspace + SPLITK_COUNTER_BYTES);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (f32) launch_conv<float, float>(a, num_cu, s);
     else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
@@ -573,6 +643,24 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
                                   const float* shift, const float* pre_scale, const float* pre_shift,
                                   const void* residual, void* y, void* stream) {
     return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream);
+}
+
+extern "C" long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits) {
+    if (!d || splits < 1) return -1;
+    const int Ho = d->Ho > 0 ? d->Ho : (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    const int Wo = d->Wo > 0 ? d->Wo : (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    const long long M = (long long)d->B * Ho * Wo;
+    const long long tiles = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    if (tiles * 4 > SPLITK_COUNTER_BYTES) return -1;
+    return SPLITK_COUNTER_BYTES + (long long)splits * tiles * 128 * 128 * 4;
+}
+
+extern "C" int dir_conv2d_splitk_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                                         const float* pre_scale, const float* pre_shift, const void* residual, void* y, int splits,
+                                         void* workspace, long long workspace_bytes, void* stream) {
+    DIR_REQUIRE(splits >= 1, "dir_conv2d_splitk_forward: splits must be >= 1");
+    return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream, nullptr, nullptr, splits, workspace,
+                        workspace_bytes);
 }
 
 extern "C" int dir_conv2d_dual_forward(const dir_conv_desc* d, const void* x, const dir_conv_src2* d2, const void* x2, const void* w,

@@ -80,6 +80,10 @@ struct ConvArgs {
     long long* stamps;                  // DIR_STAMPS=conv_pipe (tuning aid, else NULL): phase times of the first / last workgroup
     const int* bbox; int bbox_groups;   // optional [B][bbox_groups][4] = ymin,ymax,xmin,xmax of the non-zero support of
                                         // each 64-channel input group; K-slabs that cannot touch a tile are skipped
+    // split-K (dir_conv2d_splitk_forward): `splits` workgroups (blockIdx.y) share one output tile, each reducing a contiguous range
+    // of K-slabs; raw fp32 partial tiles go to ws_part [split][tile][128*128], the last workgroup to arrive at ws_cnt[tile] sums
+    // them in split order (deterministic) and runs the epilogue.  0 / 1 = off.
+    int splits; float* ws_part; unsigned* ws_cnt;
 };
 
 constexpr int MAX_SLABS = 768;

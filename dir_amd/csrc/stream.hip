@@ -17,7 +17,8 @@
 //     (dir_amd/engine.py::pack_stream_weights) and a fragment is one coalesced 1 KB load a chunk ahead, L2-resident;
 //   * the pre-activation BatchNorm + ReLU is applied in registers on the way to LDS; the epilogue (scale, shift, ReLU) writes
 //     8-byte pieces -- a lane holds 4 consecutive channels of a pixel (bneck.hip).
-// fp32 accumulation in the K order of the tiled kernels; results agree with them to the last-bit noise of the transposed MFMA.
+// fp32 accumulation in the K order AND the k-slot assignment of the tiled kernels (MFMA q of a 64-channel chunk multiplies channels
+// 8q..8q+7 in lanes 0-31 and 32+8q..32+8q+7 in lanes 32-63, conv.hip): the sums are the same fp32 chains, the outputs bit-identical.
 #include "conv_common.h"
 
 namespace dir {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
                 const int row = 32 * pb + l32;
-                bv[pb] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4));
+                bv[pb] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + (((ks + 4 * h) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)

@@ -69,7 +69,7 @@ def pack_stream_weights(w_nk):
     g, wv, c, ks, cb = torch.meshgrid(torch.arange(N // (128 * ncb), device=dev), torch.arange(4, device=dev), torch.arange(K // 64, device=dev),
                                       torch.arange(4, device=dev), torch.arange(ncb, device=dev), indexing='ij')
     row = (g * (128 * ncb) + (wv * ncb + cb) * 32)[..., None] + l32                    # [G,4,nk,4,ncb,64]
-    k0 = (64 * c + 16 * ks)[..., None] + 8 * h
+    k0 = (64 * c + 8 * ks)[..., None] + 32 * h            # the k-slot assignment of conv.hip's MFMAs (bit-identical sums)
     return w[row[..., None], k0[..., None] + e].to(torch.bfloat16).contiguous().to(out_dev)
 
 
@@ -89,6 +89,7 @@ class ConvOp(object):
         self.in_cs_override = None
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
         self.variant = {}                                  # batch size -> DIR_CONV_VARIANT code chosen by DirEngine.autotune
+        self.split, self._ws = {}, {}                      # batch size -> split-K factor; (B, S, stream) -> workspace
         # streaming alternative for the HBM-bound 1x1 layers (dir_conv1x1_stream_forward), taken when autotune prefers it
         self.w_stream = None
         if (dtype == torch.bfloat16 and self.out_dtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and stride == 1 and pad == 0
@@ -119,6 +120,15 @@ class ConvOp(object):
                                                                _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
                                                                _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
             return out
+        S = self.splits(B, ho, wo) if (bbox is None and out.dtype == torch.bfloat16 and self.dtype == torch.bfloat16) else 1
+        if S > 1 and (_forced_variant() in (None, 0)):
+            d.flags &= 0xff
+            ws = self._splitk_ws(d, S, B, x.device)
+            _capi.check(_capi.lib().dir_conv2d_splitk_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale), _capi.ptr(self.shift),
+                                                              _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift), _capi.ptr(residual),
+                                                              _capi.ptr(out), S, _capi.ptr(ws), ws.numel(), _capi.stream_ptr()),
+                        'dir_conv2d_splitk_forward')
+            return out
         if bbox is not None:
             rc = _capi.lib().dir_conv2d_sparse_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
                                                        _capi.ptr(self.shift), _capi.ptr(residual), _capi.ptr(out),
@@ -130,6 +140,37 @@ class ConvOp(object):
                                                 _capi.stream_ptr())
         _capi.check(rc, 'dir_conv2d_forward')
         return out
+
+
+    # ---- split-K (dir_conv2d_splitk_forward) for layers whose M x Cout grid of 128x128 tiles covers at most half of the 256 CUs at
+    # this batch size (ResNet layer4 at 8x8, the decoder's 16x16 Residual blocks).  OFF by default: measured at B = 64
+    # (tools/bench_splitk.py) it wins only on the 2304 -> 128 pre-activation 1x1 (46 -> 39 us) and ties on layer4's 3x3 (36 -> 34 us); every
+    # other candidate is slower than its best tiled variant -- each extra split costs 3 - 5 us of partial-tile traffic through the
+    # device-coherent level -- and its sums are not bit-identical to the tiled kernels'.  DIR_SPLITK=1 enables the shape heuristic
+    # (shapes only, never timing); op.split[B] = S forces a factor.
+    SPLITK = os.environ.get('DIR_SPLITK', '0') == '1'
+
+    def splits(self, B, ho, wo):
+        S = self.split.get(B)
+        if S is None:
+            S = 1
+            tiles = -(-(B * ho * wo) // 128) * -(-self.cout // 128)
+            nk = self.kh * self.kw * self.cin // 64
+            if ConvOp.SPLITK and self.cout % 8 == 0 and tiles <= 128 and nk >= 8:
+                S = max(1, min(16, nk // 4, -(-512 // tiles)))
+            self.split[B] = S
+        return S
+
+    def _splitk_ws(self, d, S, B, dev):
+        key = (B, S, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = _capi.lib().dir_conv2d_splitk_workspace_bytes(d, S)
+            assert n > 0
+            ws = torch.empty(n, dtype=torch.uint8, device=dev)
+            ws[:16384].zero_()                             # the arrival counters; the kernel leaves them zero
+            self._ws[key] = ws
+        return ws
 
 
 class DualConvOp(object):
@@ -815,11 +856,10 @@ class DirEngine(object):
 
     # kernel variants a layer can be forced to (include/dir_hip.h: DIR_CONV_VARIANT); 0 = the library's heuristic.  (Code 19, the
     # 64x128 tile on the 3-buffer ring, is not offered: see conv.hip, DIR_RING_64x128.)
-    # These all accumulate in the same order (outputs bit-identical whichever is chosen).  The streaming 1x1 kernel (STREAM_VARIANT,
-    # stream.hip) feeds the MFMA its k-slots in another order, so its bf16 outputs differ from the others' in the last bit: the
-    # autotuner offers it only on request (DIR_STREAM_1X1=1) -- by default the per-layer choice, which depends on timing, cannot
-    # change a single output bit.  Measured gain when offered: ~8 us on each of the two 512->128 @32x32 Residual conv1 layers.
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14) + ((STREAM_VARIANT,) if os.environ.get('DIR_STREAM_1X1') == '1' else ())
+    # All of them -- including the streaming 1x1 kernel (STREAM_VARIANT, stream.hip), which feeds the MFMA the same k-slots in the
+    # same order as the tiled kernels -- accumulate identically: outputs are bit-identical whichever is chosen
+    # (tools/check_stream_layers.py, tests/test_gpu_dir.py::test_autotuned_engine_is_bit_identical).
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 12, 13, 14, STREAM_VARIANT)
 
     def _profiled_forwards(self, img, n):
         """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""

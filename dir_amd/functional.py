@@ -21,8 +21,10 @@ def pack_conv_weight(w_oihw, dtype=torch.float32):
 
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
-                res_coff=0):
-    """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf]."""
+                res_coff=0, splits=1, workspace=None):
+    """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
+    splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
+    if None)."""
     _capi.require_cuda(x, w_ohwi, scale, shift, residual, pre_scale, pre_shift, out)
     assert x.is_contiguous() and w_ohwi.is_contiguous() and x.dim() == 4
     B, H, W, cbuf = x.shape
@@ -46,6 +48,14 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
                  residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, _dt(x), _dt(out),
                  (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0))
     with torch.cuda.device(x.device):
+        if splits > 1:
+            if workspace is None:
+                workspace = torch.zeros(_capi.lib().dir_conv2d_splitk_workspace_bytes(d, splits), dtype=torch.uint8, device=x.device)
+            _capi.check(_capi.lib().dir_conv2d_splitk_forward(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift),
+                                                              _capi.ptr(pre_scale), _capi.ptr(pre_shift), _capi.ptr(residual), _capi.ptr(out),
+                                                              splits, _capi.ptr(workspace), workspace.numel(), _capi.stream_ptr()),
+                        'dir_conv2d_splitk_forward')
+            return out
         rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift),
                                             _capi.ptr(pre_scale), _capi.ptr(pre_shift), _capi.ptr(residual),
                                             _capi.ptr(out), _capi.stream_ptr())

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 20
+#define DIR_ABI_VERSION 21
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -214,6 +214,18 @@ typedef struct dir_conv_desc {
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
+
+/* dir_conv2d_forward with the reduction split over `splits` workgroups per output tile (bf16 -> bf16 layers whose M x Cout grid is too
+ * small to fill 256 CUs at the benchmark batch: ResNet layer4 at 8x8, the decoder's 16x16 Residual blocks).  128x128 tiles; every
+ * workgroup reduces a contiguous range of K-slabs and writes its raw fp32 partial tile to the workspace; the LAST one to arrive at the
+ * tile's counter sums all partials in split order -- so the result does not depend on the arrival order -- and runs the usual epilogue
+ * (scale / shift, residual, ReLU).  The summation order differs from the unsplit kernels': outputs agree to bf16 rounding, not bit for
+ * bit.  workspace: dir_conv2d_splitk_workspace_bytes(d, splits) bytes, 16-byte aligned, its first 16 KiB ZERO before the first use (the
+ * kernel leaves them zero); one workspace must not be shared by launches that can run concurrently.  splits == 1 = dir_conv2d_forward. */
+long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits);
+int dir_conv2d_splitk_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                              const float* pre_scale, const float* pre_shift, const void* residual, void* y, int splits,
+                              void* workspace, long long workspace_bytes, void* stream);
 
 /* A convolution with a SECOND source accumulated into the same output tile:
  *   y = epilogue( conv(x; kh x kw, stride, pad) + conv1x1(x2; stride2) )
