@@ -23,7 +23,7 @@ struct ManoHand {
     const float* cam; int cam_stride;
     float* verts; float* joints; float* joint_uv; float* mesh_uv; int32_t* flags;
 };
-struct ManoArgs { ManoHand h[2]; long long* stamps; };   // stamps: DIR_STAMPS=mano (tuning aid, else NULL)
+struct ManoArgs { ManoHand h[2]; long long* stamps; int B, hands, parts; };   // stamps: DIR_STAMPS=mano (tuning aid, else NULL)
 
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     // rot6d.py:54-60: v / max(|v|, 1e-8).  No FMA contraction: the robust-6D construction is
@@ -33,7 +33,10 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     x /= m; y /= m; z /= m;
 }
 
-// gridDim.z = vertex parts: with 4 parts every workgroup owns 196 vertices (588 floats, 16-byte aligned) of one (sample, hand),
+// XCD-aware 1-D grid: a (hand, vertex part) combination lives on ONE XCD (8 / (hands * parts) XCDs each, samples dealt among them), so
+// each XCD's L2 holds only that combination's slice of the blend-shape tables -- with hands = 2, parts = 4 exactly one slice per XCD.
+// (The former (B, hands, parts) grid put every combination on every XCD: 24 MB of table traffic per launch for 2.8 MB of tables.)
+// parts = vertex parts: with 4 parts every workgroup owns 196 vertices (588 floats, 16-byte aligned) of one (sample, hand),
 // recomputes the cheap pose / chain maths, and streams only its quarter of the blend-shape tables -- the 1.3 MB posedirs
 // read per (sample, hand) is spread over four CUs instead of one.  blockDim.x = NTHR (1 part) or PTHR (4 parts).
 constexpr int PART_V = 196, PTHR = 256;   // >= PART_V threads: the skinning loop is one pass per part
@@ -42,10 +45,15 @@ constexpr int PART_V = 196, PTHR = 256;   // >= PART_V threads: the skinning loo
 // 4-part launches (256 threads) were compiled down to 168 VGPRs and spilled (scratch traffic inside the skinning loop)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
-    const ManoHand& a = args.h[blockIdx.y];
+    const int combos = args.hands * args.parts, rep = 8 / combos;      // combos in {1, 2, 4, 8}
+    const int xcd = blockIdx.x & 7, combo = xcd / rep;
+    const int b = (blockIdx.x >> 3) * rep + (xcd - combo * rep);
+    if (b >= args.B) return;
+    const int hand = combo / args.parts, part = combo - hand * args.parts;
+    const ManoHand& a = args.h[hand];
     const int nthr = blockDim.x;
-    const int v_lo = gridDim.z > 1 ? blockIdx.z * PART_V : 0;
-    const int v_hi = gridDim.z > 1 ? min(NV, v_lo + PART_V) : NV;
+    const int v_lo = args.parts > 1 ? part * PART_V : 0;
+    const int v_hi = args.parts > 1 ? min(NV, v_lo + PART_V) : NV;
     const int f_lo = 3 * v_lo, f_hi = 3 * v_hi;          // float range [f_lo, f_hi) of the flattened vertex array
     __shared__ float s_v[NV3P];         // v_shaped -> v_posed -> skinned vertices (in place)
     __shared__ float s_pose[51], s_beta[10], s_cam[3];
@@ -59,9 +67,9 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
     __shared__ float s_jtr[21 * 3];
     __shared__ float s_c[3];
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     int nstamp = 0;
-    auto stamp = [&]() { if (args.stamps && b == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && tid == 0) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
     stamp();
 
     if (tid < 51) s_pose[tid] = a.pose[(size_t)b * a.pose_stride + tid];
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
 
     // with vertex parts: part 0 writes the 16 chain joints, a fingertip joint is written by the part that owns its vertex
     auto owns_joint = [&](int j) {
-        if (gridDim.z == 1) return true;
+        if (args.parts == 1) return true;
         const int src = kReorderJ[j];
         const int v = src < 16 ? 0 : kTips[a.t.side][src - 16];
         return v >= v_lo && v < v_hi;
@@ -285,8 +293,11 @@ static void launch_mano(const ManoArgs& a0, int B, int hands, hipStream_t s) {
         const int c = t.center_idx;
         if (t.root_palm || (c >= 0 && (c == 4 || c == 8 || c == 12 || c == 16 || c == 20))) split = false;
     }
-    if (split) DIR_LAUNCH(mano_forward_kernel<PTHR>, dim3(B, hands, 4), dim3(PTHR), 0, s, a);
-    else DIR_LAUNCH(mano_forward_kernel<NTHR>, dim3(B, hands, 1), dim3(NTHR), 0, s, a);
+    a.B = B; a.hands = hands; a.parts = split ? 4 : 1;
+    const int rep = 8 / (hands * a.parts);
+    const dim3 grid(8 * ((B + rep - 1) / rep));
+    if (split) DIR_LAUNCH(mano_forward_kernel<PTHR>, grid, dim3(PTHR), 0, s, a);
+    else DIR_LAUNCH(mano_forward_kernel<NTHR>, grid, dim3(NTHR), 0, s, a);
     dir::stamps_end("mano", a.stamps, s);
 }
 

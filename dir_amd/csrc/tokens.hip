@@ -253,9 +253,12 @@ __global__ __launch_bounds__(PG_T) void pgcn_node_kernel(PgcnArgs args) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int pi = slot / args.npp, c0 = slot - pi * args.npp;
-    const int p = xcd + 8 * pi;
-    if (p >= args.npairs) return;
-    const int hand = p / NJ, j = p - hand * NJ;
+    // XCD -> (hand, contiguous range of nodes): the joints are numbered finger by finger, so most of a node's graph neighbours are
+    // produced and consumed under the same L2 (round-robin pairs re-fetched every h1 row through ~3 L2s: 1.8x the algorithmic bytes)
+    const int nh = args.npairs / NJ, groups = 8 / nh;       // nh = 1: 8 node groups; nh = 2: XCDs 0-3 left hand, 4-7 right hand
+    const int hand = xcd / groups, g = xcd - hand * groups;
+    const int j = (NJ * g) / groups + pi;
+    if (j >= (NJ * (g + 1)) / groups) return;
     const PgcnHand& a = args.h[hand];
     int nstamp = 0;
     auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
@@ -578,7 +581,7 @@ static int pgcn_run(const dir_pgcn_layer* const* layers, int nh, int num_layers,
             DIR_REQUIRE((g.w_bf16 != 0) == wbf16, "dir_pgcn_stack_forward: both hands must use the same weight dtype");
         }
         a.stamps = dir::stamps_begin("pgcn");
-        const int per_xcd = (a.npairs + 7) / 8;                   // pairs xcd, xcd + 8, ... on XCD `xcd`
+        const int per_xcd = (NJ + 8 / nh - 1) / (8 / nh);         // nodes per XCD group (kernel: XCD -> hand, node range)
         const dim3 grid(8 * per_xcd * a.npp);
         if (wbf16) DIR_LAUNCH(pgcn_node_kernel<true>, grid, dim3(PG_T), 0, s, a);
         else DIR_LAUNCH(pgcn_node_kernel<false>, grid, dim3(PG_T), 0, s, a);
