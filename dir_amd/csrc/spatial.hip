@@ -172,34 +172,46 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
 }
 
 // ------------------------------------------------------------------------------------------ upsample
+// One thread = one INPUT pixel x one 16-byte channel vector -> its 2x2 output quad: the quad's four bilinear footprints lie inside the
+// pixel's 3x3 neighbourhood, so 9 vector loads (clamped addresses, all independent) serve 4 output vectors instead of 16, and the
+// index arithmetic is 32-bit.  Every output is computed with the reference's own expressions (ATen area_pixel_compute_source_index,
+// align_corners=False: src = max((dst + 0.5) * 0.5 - 0.5, 0)) -- bit-identical to the one-thread-per-output form it replaces.
 template <typename T>
-__global__ void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int ocs, int oco) {
+__global__ __launch_bounds__(256) void upsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int ocs, int oco) {
     constexpr int VN = Vec<T>::N;
-    const int Ho = 2 * H, Wo = 2 * W, CV = C / VN;
-    const long long n = (long long)B * Ho * Wo * CV;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CV) * VN;
-        long long p = i / CV;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int b = (int)(p / Ho);
-        // src = (dst + 0.5) * 0.5 - 0.5, clamped at 0 (ATen area_pixel_compute_source_index, align_corners=False)
-        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-        const float ly = sy - y0, lx = sx - x0;
-        const T* base = x + (long long)b * H * W * C + c;
-        float v00[VN], v01[VN], v10[VN], v11[VN], o[VN];
-        Vec<T>::load(base + ((long long)y0 * W + x0) * C, v00);
-        Vec<T>::load(base + ((long long)y0 * W + x1) * C, v01);
-        Vec<T>::load(base + ((long long)y1 * W + x0) * C, v10);
-        Vec<T>::load(base + ((long long)y1 * W + x1) * C, v11);
+    const unsigned CV = C / VN, n = (unsigned)B * H * W * CV;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const unsigned cv = i % CV, p = i / CV;
+    const int ix = (int)(p % (unsigned)W), q = (int)(p / (unsigned)W), iy = q % H, b = q / H;
+    const int c = (int)cv * VN, Wo = 2 * W;
+    const T* base = x + (long long)b * H * W * C + c;
+    float v[3][3][VN];
 #pragma unroll
-        for (int e = 0; e < VN; ++e) {
-            const float top = v00[e] * (1.f - lx) + v01[e] * lx, bot = v10[e] * (1.f - lx) + v11[e] * lx;
-            o[e] = top * (1.f - ly) + bot * ly;
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            Vec<T>::load(base + ((long long)min(max(iy - 1 + r, 0), H - 1) * W + min(max(ix - 1 + t, 0), W - 1)) * C, v[r][t]);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int oy = 2 * iy + dy;
+        const float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f);
+        const float ly = sy - (int)sy;                  // 0.75 (rows iy-1, iy) for dy = 0, 0.25 (rows iy, iy+1) for dy = 1; 0 on a clamped border
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ox = 2 * ix + dx;
+            const float sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f);
+            const float lx = sx - (int)sx;
+            // footprint rows (dy, dy + 1) and columns (dx, dx + 1) of the loaded 3 x 3: on a clamped border the reference's second
+            // row / column carries weight 0 (first output row) or is the same clamped pixel (last one) -- the same values either way
+            float o[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float top = v[dy][dx][e] * (1.f - lx) + v[dy][dx + 1][e] * lx, bot = v[dy + 1][dx][e] * (1.f - lx) + v[dy + 1][dx + 1][e] * lx;
+                o[e] = top * (1.f - ly) + bot * ly;
+            }
+            Vec<T>::store(y + ((long long)(b * 2 * H + oy) * Wo + ox) * ocs + oco + c, o);
         }
-        Vec<T>::store(y + ((long long)(b * Ho + oy) * Wo + ox) * ocs + oco + c, o);
     }
 }
 
@@ -599,10 +611,12 @@ extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int
     DIR_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "dir_upsample2x_bilinear: bad args");
     const int ocs = out_cstride ? out_cstride : C;
     DIR_REQUIRE(C % 8 == 0 && ocs % 8 == 0 && out_coff % 8 == 0, "dir_upsample2x_bilinear: channel counts/offsets must be multiples of 8");
-    const long long n = (long long)B * 4 * H * W * (C / 4);
+    const long long n = (long long)B * H * W * (C / (dtype == DIR_DT_F32 ? 4 : 8));        // one thread per input pixel and 16-byte channel vector
+    DIR_REQUIRE(n < (1ll << 31), "dir_upsample2x_bilinear: too many elements");
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == DIR_DT_F32) DIR_LAUNCH((upsample_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
-    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((upsample_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((upsample_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((upsample_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
     else DIR_REQUIRE(false, "dir_upsample2x_bilinear: bad dtype");
     return dir::check_launch("dir_upsample2x_bilinear");
 }
