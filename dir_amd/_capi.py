@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 21          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 22          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -171,6 +171,8 @@ _SIGNATURES = {
     'dir_pgcn_adjacency_backward': (C.c_int, [_p, _p, _p, _p, _p, _i, _p]),
     'dir_conv2d_splitk_workspace_bytes': (C.c_longlong, [C.POINTER(ConvDesc), _i]),
     'dir_conv2d_splitk_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, C.c_longlong, _p]),
+    'dir_conv2d_wgrad_workspace_bytes': (C.c_longlong, [C.POINTER(ConvDesc)]),
+    'dir_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, _p]),
     'dir_axpy_f32': (C.c_int, [_p, _p, C.c_longlong, C.c_float, _p]),
     'dir_stage_positions': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'dir_grid_rows_forward': (C.c_int, [_p, _p, _p, _i, _i, _i, _p]),

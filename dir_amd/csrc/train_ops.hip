@@ -398,6 +398,81 @@ __global__ __launch_bounds__(256) void stage_positions_kernel(const float* xyz_l
     pos_l[i] = l; pos_r[i] = r; gpos_l[i] = l - o; gpos_r[i] = r + o;
 }
 
+// ------------------------------------------------------------------------------------------------------------------ conv wgrad
+// d loss / d W of nn.Conv2d (NHWC activations, weights [Cout][kh][kw][Cin]):  gW[co][tap][ci] = sum_m gy[m][co] * x[pixel(m, tap)][ci]
+// -- per tap a GEMM  gy^T [Cout x M] . X_tap [M x Cin]  whose reduction runs over the M = B*Ho*Wo output pixels.  Grid (ci tile x co
+// tile, tap, pixel chunk): a workgroup reduces one contiguous chunk of pixels into a 64 x 64 tile (exact fp32 products on
+// v_mfma_f32_16x16x4_f32, the tile layout of gemm_f32_kernel); with more than one chunk the partial tiles go to a workspace and
+// wgrad_reduce_kernel adds them in chunk order (deterministic, no atomics).
+struct WgradArgs {
+    const float* x; const float* gy; float* out;        // out: gw, or the workspace [chunks][Cout][taps][Cin]
+    int B, H, W, Cin, in_cs, in_co, Cout, gy_cs, gy_co, kh, kw, stride, pad, Ho, Wo, M, chunk, tiles_ci;
+};
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    __shared__ float s_a[GT * GLD], s_b[GT * GLD];
+    __shared__ long long s_row[GK];                      // element offset of the input pixel of each of the 16 reduction rows, -1 = padding
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci, tap = blockIdx.y, ch = blockIdx.z;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const int co0 = tco * GT, ci0 = tci * GT;
+    const int m_beg = ch * a.chunk, m_end = min(a.M, m_beg + a.chunk);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4;
+    for (int k0 = m_beg; k0 < m_end; k0 += GK) {
+        if (tid < GK) {
+            const int m = k0 + tid;
+            long long off = -1;
+            if (m < m_end) {
+                const int b = m / (a.Ho * a.Wo), r = m - b * a.Ho * a.Wo, oy = r / a.Wo, ox = r - oy * a.Wo;
+                const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = (((long long)b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co;
+            }
+            s_row[tid] = off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, c = e & 63, k = e >> 6;           // 64 channels (contiguous in memory) x 16 pixels
+            const int m = k0 + k;
+            float v = 0.f, w = 0.f;
+            if (m < m_end && co0 + c < a.Cout) v = a.gy[(long long)m * a.gy_cs + a.gy_co + co0 + c];
+            const long long ro = s_row[k];
+            if (ro >= 0 && ci0 + c < a.Cin) w = a.x[ro + ci0 + c];
+            s_a[c * GLD + k] = v;
+            s_b[c * GLD + k] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            const float av = s_a[(16 * wave + li) * GLD + 4 * ks + lk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_b[(16 * j + li) * GLD + 4 * ks + lk], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int taps = a.kh * a.kw;
+    float* out = a.out + (long long)ch * a.Cout * taps * a.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + 16 * j + li;
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 16 * wave + 4 * lk + r;
+            if (co < a.Cout) out[((long long)co * taps + tap) * a.Cin + ci] = acc[j][r];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* gw, long long n, int chunks, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? gw[i] : 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long long)c * n + i];
+    gw[i] = s;
+}
+
 }  // namespace
 
 extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* stream) {
@@ -536,4 +611,50 @@ extern "C" int dir_stage_positions(const float* xyz_left, const float* xyz_right
     DIR_LAUNCH(stage_positions_kernel, dim3((B * 63 + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz_left, xyz_right, offset, pos_left, pos_right,
                gpos_left, gpos_right, B * 63);
     return check_launch("dir_stage_positions");
+}
+
+static int wgrad_chunks(const dir_conv_desc* d, long long M) {
+    const long long per = (long long)((d->Cin + GT - 1) / GT) * ((d->Cout + GT - 1) / GT) * d->kh * d->kw;
+    long long c = (1024 + per - 1) / per;                 // >= ~1024 workgroups in flight
+    const long long cmax = (M + 2047) / 2048;             // but at least 2048 pixels per chunk
+    if (c > cmax) c = cmax;
+    return (int)(c < 1 ? 1 : c);
+}
+extern "C" long long dir_conv2d_wgrad_workspace_bytes(const dir_conv_desc* d) {
+    if (!d) return -1;
+    const int Ho = d->Ho > 0 ? d->Ho : (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    const int Wo = d->Wo > 0 ? d->Wo : (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    const long long M = (long long)d->B * Ho * Wo;
+    const int c = wgrad_chunks(d, M);
+    return c > 1 ? (long long)c * d->Cout * d->kh * d->kw * d->Cin * 4 : 0;
+}
+extern "C" int dir_conv2d_wgrad_f32(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                                    long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(d && x && gy && gw, "dir_conv2d_wgrad_f32: null pointer");
+    DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0,
+                "dir_conv2d_wgrad_f32: bad geometry");
+    WgradArgs a;
+    a.x = x; a.gy = gy; a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.in_cs = d->in_cstride ? d->in_cstride : d->Cin; a.in_co = d->in_coff;
+    a.Cout = d->Cout; a.gy_cs = d->out_cstride ? d->out_cstride : d->Cout; a.gy_co = d->out_coff;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = d->Ho > 0 ? d->Ho : (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    a.Wo = d->Wo > 0 ? d->Wo : (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    DIR_REQUIRE(a.Ho > 0 && a.Wo > 0, "dir_conv2d_wgrad_f32: empty output");
+    const long long M = (long long)d->B * a.Ho * a.Wo;
+    DIR_REQUIRE(M < (1ll << 31), "dir_conv2d_wgrad_f32: too many output pixels");
+    a.M = (int)M;
+    const int chunks = wgrad_chunks(d, M);
+    const long long n = (long long)d->Cout * d->kh * d->kw * d->Cin;
+    DIR_REQUIRE(chunks == 1 || (workspace && workspace_bytes >= (long long)chunks * n * 4), "dir_conv2d_wgrad_f32: workspace too small (dir_conv2d_wgrad_workspace_bytes)");
+    a.chunk = (int)(((M + chunks - 1) / chunks + GK - 1) / GK * GK);
+    a.tiles_ci = (d->Cin + GT - 1) / GT;
+    const bool direct = chunks == 1 && !accumulate;
+    DIR_REQUIRE(direct || workspace, "dir_conv2d_wgrad_f32: accumulate needs a workspace of at least the weight size");
+    DIR_REQUIRE(direct || workspace_bytes >= (long long)chunks * n * 4, "dir_conv2d_wgrad_f32: workspace too small");
+    a.out = direct ? gw : workspace;
+    hipStream_t s = (hipStream_t)stream;
+    DIR_LAUNCH(conv_wgrad_kernel, dim3(a.tiles_ci * ((d->Cout + GT - 1) / GT), d->kh * d->kw, chunks), dim3(256), 0, s, a);
+    if (!direct) DIR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, gw, n, chunks, accumulate);
+    return check_launch("dir_conv2d_wgrad_f32");
 }

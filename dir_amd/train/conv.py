@@ -1,0 +1,74 @@
+"""nn.Conv2d in training form on libdir_hip.so: fp32 NHWC forward (dir_conv2d_forward, exact-fp32 matrix cores) and its two gradients.
+
+    y = conv_fwd(x, w, bias, stride, pad)                      x [B,H,W,Cin], w [Cout,kh,kw,Cin] (pack_conv_weight layout), y [B,Ho,Wo,Cout]
+    gx, gw, gb = conv_bwd(x, w, gy, stride, pad, need_gx)      what autograd returns for nn.Conv2d (models/backbone/resnet.py:23-40,
+                                                               models/backbone/hourglass.py:14, models/dir.py:58-61,229-232,404-419)
+* weight gradient: dir_conv2d_wgrad_f32 (train_ops.hip), bias gradient: dir_colsum_f32;
+* data gradient: the transposed convolution is the SAME forward kernel run on gy with the flipped, (Cin <-> Cout)-transposed weights
+  and padding k - 1 - pad; for stride 2, gy is first spread onto the even positions of a zero [2 Ho, 2 Wo] map.  The flips, the zero
+  insertion and the channel padding to the kernel's 32-channel granularity are copies -- no arithmetic happens outside the library.
+"""
+import torch
+
+from . import ops as O
+from .. import _capi
+from .. import functional as F
+
+
+def conv_fwd(x, w, bias=None, stride=1, pad=0):
+    cin = w.shape[3]
+    if cin % 32:                                           # the 3-channel image: channels padded to the kernel's K granularity
+        x, w = _pad_last(x, 32), _pad_last(w, 32)
+    return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=bias)
+
+
+def _pad_last(t, mult):
+    c = t.shape[-1]
+    if c % mult == 0:
+        return t
+    out = torch.zeros(*t.shape[:-1], (c + mult - 1) // mult * mult, device=t.device, dtype=t.dtype)
+    out[..., :c] = t
+    return out
+
+
+def conv_dgrad(w, gy, stride, pad, H, W):
+    """d loss / d x [B,H,W,Cin] of y = conv(x, w, stride, pad) from gy [B,Ho,Wo,Cout]"""
+    Cout, kh, kw, Cin = w.shape
+    assert kh == kw and stride in (1, 2)
+    wt = _pad_last(w.flip(1, 2).permute(3, 1, 2, 0).contiguous(), 32)          # [Cin][kh][kw][Cout (padded)]
+    g = gy
+    if stride == 2:
+        B, Ho, Wo, _ = gy.shape
+        g = torch.zeros(B, 2 * Ho, 2 * Wo, Cout, device=gy.device)
+        g[:, ::2, ::2] = gy
+    g = _pad_last(g.contiguous(), 32)
+    gx = F.conv2d_nhwc(g, wt, stride=1, pad=kh - 1 - pad)
+    if gx.shape[1] != H or gx.shape[2] != W:               # odd H / W under stride 2
+        assert gx.shape[1] >= H and gx.shape[2] >= W
+        gx = gx[:, :H, :W].contiguous()
+    return gx
+
+
+def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
+    Cout, kh, kw, Cin = w_shape
+    B, H, W, cs = x.shape
+    O._chk(x, gy, out)
+    d = _capi.ConvDesc(B, H, W, Cin, cs, 0, Cout, gy.shape[3], 0, 0, 0, kh, kw, stride, pad, _capi.DT_F32, _capi.DT_F32, 0)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(Cout, kh, kw, Cin, device=x.device)
+    n = _capi.lib().dir_conv2d_wgrad_workspace_bytes(d)
+    if accumulate:
+        n = max(n, out.numel() * 4)
+    ws = torch.empty(max(n, 4) // 4, device=x.device)
+    _capi.check(_capi.lib().dir_conv2d_wgrad_f32(d, _capi.ptr(x), _capi.ptr(gy), _capi.ptr(out), int(accumulate), _capi.ptr(ws), n,
+                                                 _capi.stream_ptr()), 'dir_conv2d_wgrad_f32')
+    return out
+
+
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True):
+    gy = gy.contiguous()
+    gw = conv_wgrad(x, gy, w.shape, stride, pad)
+    gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None
+    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2]) if need_gx else None
+    return gx, gw, gb

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 21
+#define DIR_ABI_VERSION 22
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -226,6 +226,17 @@ long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits);
 int dir_conv2d_splitk_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                               const float* pre_scale, const float* pre_shift, const void* residual, void* y, int splits,
                               void* workspace, long long workspace_bytes, void* stream);
+
+/* d loss / d weight of nn.Conv2d in fp32 (train.py:68 runs autograd through every Conv2d of models/backbone/resnet.py,
+ * models/backbone/hourglass.py and models/dir.py): d = the FORWARD geometry (in_cstride / in_coff address x, out_cstride / out_coff address
+ * gy), x NHWC [B,H,W,*], gy NHWC [B,Ho,Wo,*], gw [Cout][kh][kw][Cin] (the layout dir_conv2d_forward reads); accumulate != 0 adds to gw.
+ * The reduction over the B*Ho*Wo output pixels is cut into chunks whose partial tiles are added in chunk order (deterministic).
+ * workspace: dir_conv2d_wgrad_workspace_bytes(d) bytes (0 = none needed unless accumulate, then the weight size).
+ * The data gradient needs no kernel of its own: it is dir_conv2d_forward on gy with the flipped, transposed weights (zeros inserted
+ * between the rows / columns of gy for stride 2), dir_amd/train/conv.py. */
+long long dir_conv2d_wgrad_workspace_bytes(const dir_conv_desc* d);
+int dir_conv2d_wgrad_f32(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                         long long workspace_bytes, void* stream);
 
 /* A convolution with a SECOND source accumulated into the same output tile:
  *   y = epilogue( conv(x; kh x kw, stride, pad) + conv1x1(x2; stride2) )
