@@ -163,8 +163,9 @@ _SIGNATURES = {
     'dir_gelu_backward': (C.c_int, [_p, _p, _p, C.c_longlong, _p]),
     'dir_attention_forward': (C.c_int, [_p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
-    'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p]),
-    'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p, C.c_longlong, _p]),
+    'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_relu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),
     'dir_relu_backward': (C.c_int, [_p, _p, _p, C.c_longlong, _p]),
     'dir_pgcn_adjacency_forward': (C.c_int, [_p, _p, _p]),

@@ -282,6 +282,71 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, cons
             gx[(long long)r * ld + c] = g * rs * (gy[(long long)r * ld + c] - m1 - (x[(long long)r * ld + c] - mu) * rs * m2);
 }
 
+// Large R (BatchNorm2d over feature maps: R = B*H*W up to 10^6 rows): the column reductions are cut into row chunks -- a workgroup =
+// 64 channels x 4 row lanes over one chunk, lanes combined in a fixed order -- and a per-channel finalise adds the chunk partials in
+// chunk order: deterministic, no atomics.  Same formulas as the one-thread-per-channel kernels above (two-pass variance).
+constexpr int BN_CHUNK_ROWS = 1024, BN_SMALL_R = 2048;
+// mode 0: p1 = sum x | mode 1: p1 = sum (x - mu)^2 | mode 2: p1 = sum gy, p2 = sum gy (x - mu) rs
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const float* gy, const float* mu, const float* rs, float* p1, float* p2,
+                                                        int R, int C, int ld, int mode) {
+    __shared__ float s1[4][64], s2[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, ch = blockIdx.y;
+    const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        const float m = mode ? mu[c] : 0.f, k = mode == 2 ? rs[c] : 0.f;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float v = x[(long long)r * ld + c];
+            if (mode == 0) a += v;
+            else if (mode == 1) { const float d = v - m; a = fmaf(d, d, a); }
+            else { const float g = gy[(long long)r * ld + c]; a += g; b = fmaf(g, (v - m) * k, b); }
+        }
+    }
+    s1[rl][cl] = a; s2[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        p1[(long long)ch * C + c] = ((s1[0][cl] + s1[1][cl]) + s1[2][cl]) + s1[3][cl];
+        if (mode == 2) p2[(long long)ch * C + c] = ((s2[0][cl] + s2[1][cl]) + s2[2][cl]) + s2[3][cl];
+    }
+}
+__global__ __launch_bounds__(256) void bn_colsum_chunks_kernel(const float* p, float* out, int chunks, int C, float scale) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += p[(long long)k * C + c];
+    out[c] = s * scale;
+}
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* p, const float* mean, float* save_mean, float* save_rstd, float* running_mean,
+                                                               float* running_var, int chunks, int R, int C, float eps, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float q = 0.f;
+    for (int k = 0; k < chunks; ++k) q += p[(long long)k * C + c];
+    const float mu = mean[c], var = q / R;
+    save_mean[c] = mu; save_rstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (R > 1 ? q / (R - 1) : var);
+    }
+}
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* x, const float* w, const float* b, const float* mu, const float* rs, float* y,
+                                                          long long n, int C, int ld) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const long long o = (i / C) * ld + c;
+    y[o] = (x[o] - mu[c]) * rs[c] * (w ? w[c] : 1.f) + (b ? b[c] : 0.f);
+}
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* gy, const float* x, const float* w, const float* mu, const float* rs, const float* s1,
+                                                          const float* s2, float* gx, long long n, int R, int C, int ld) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const long long o = (i / C) * ld + c;
+    const float m1 = s1[c] / R, m2 = s2[c] / R;
+    gx[o] = (w ? w[c] : 1.f) * rs[c] * (gy[o] - m1 - (x[o] - mu[c]) * rs[c] * m2);
+}
+
 // ------------------------------------------------------------------------------------------------------------------ ReLU
 __global__ __launch_bounds__(256) void relu_fwd_kernel(const float* x, float* y, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -535,19 +600,57 @@ extern "C" int dir_attention_backward(const float* qkv, const float* probs, cons
     return check_launch("dir_attention_backward");
 }
 
+extern "C" long long dir_bn_train_workspace_bytes(int R, int C) {
+    if (R <= 0 || C <= 0) return -1;
+    if (R <= BN_SMALL_R) return 0;
+    const long long chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    return (2 * chunks + 2) * C * 4;
+}
 extern "C" int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
-                                    float* running_var, int R, int C, int ld, float eps, float momentum, void* stream) {
+                                    float* running_var, int R, int C, int ld, float eps, float momentum, float* workspace, long long workspace_bytes,
+                                    void* stream) {
     using namespace dir;
     DIR_REQUIRE(x && y && save_mean && save_rstd && R > 0 && C > 0 && ld >= C && ((running_mean == nullptr) == (running_var == nullptr)),
                 "dir_bn_train_forward: bad arguments");
-    DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum);
+    hipStream_t s = (hipStream_t)stream;
+    if (R <= BN_SMALL_R) {
+        DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum);
+        return check_launch("dir_bn_train_forward");
+    }
+    DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_forward: workspace too small (dir_bn_train_workspace_bytes)");
+    const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    float* part = workspace;
+    const dim3 pg((C + 63) / 64, chunks), cg((C + 255) / 256);
+    DIR_LAUNCH(bn_partial_kernel, pg, dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, (float*)nullptr, R, C, ld, 0);
+    DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)part, save_mean, chunks, C, 1.f / R);
+    DIR_LAUNCH(bn_partial_kernel, pg, dim3(256), 0, s, x, (const float*)nullptr, (const float*)save_mean, (const float*)nullptr, part, (float*)nullptr, R, C, ld, 1);
+    DIR_LAUNCH(bn_stats_finalize_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)save_mean, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
+    const long long n = (long long)R * C;
+    DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld);
     return check_launch("dir_bn_train_forward");
 }
 extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd, float* gx, float* gw,
-                                     float* gb, int R, int C, int ld, void* stream) {
+                                     float* gb, int R, int C, int ld, float* workspace, long long workspace_bytes, void* stream) {
     using namespace dir;
     DIR_REQUIRE(gy && x && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_train_backward: bad arguments");
-    DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, x, w, save_mean, save_rstd, gx, gw, gb, R, C, ld);
+    hipStream_t s = (hipStream_t)stream;
+    if (R <= BN_SMALL_R) {
+        DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gy, x, w, save_mean, save_rstd, gx, gw, gb, R, C, ld);
+        return check_launch("dir_bn_train_backward");
+    }
+    DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_backward: workspace too small (dir_bn_train_workspace_bytes)");
+    const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    float* p1 = workspace; float* p2 = p1 + (long long)chunks * C; float* t1 = p2 + (long long)chunks * C; float* t2 = t1 + C;
+    const dim3 pg((C + 63) / 64, chunks), cg((C + 255) / 256);
+    DIR_LAUNCH(bn_partial_kernel, pg, dim3(256), 0, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2);
+    DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p1, t1, chunks, C, 1.f);
+    DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p2, t2, chunks, C, 1.f);
+    if (gb && hipMemcpyAsync(gb, t1, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("dir_bn_train_backward: copy failed"); return DIR_E_LAUNCH; }
+    if (gw && hipMemcpyAsync(gw, t2, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("dir_bn_train_backward: copy failed"); return DIR_E_LAUNCH; }
+    if (gx) {
+        const long long n = (long long)R * C;
+        DIR_LAUNCH(bn_apply_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, x, w, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, n, R, C, ld);
+    }
     return check_launch("dir_bn_train_backward");
 }
 

@@ -1,0 +1,126 @@
+"""The two residual blocks of the image half in TRAINING form (batch-statistics BatchNorm2d), forward + backward from libdir_hip.so:
+
+    Bottleneck   models/backbone/resnet.py:86-142    conv1x1 - bn - relu - conv3x3(stride) - bn - relu - conv1x1 - bn (+ downsample(x)) - relu
+    Residual     models/backbone/hourglass.py:33-70  bn - relu - conv1x1 - bn - relu - conv3x3 - bn - relu - conv1x1 (+ skip_layer(x) | x)
+
+P: {state-dict key relative to the block -> fp32 cuda tensor, reference layouts (conv weights OIHW)}; running statistics in P are
+updated like nn.BatchNorm2d does.  Activations NHWC fp32.  y, ctx = *_forward(P, x);  gx, grads = *_backward(P, ctx, gy) with grads in the
+reference layouts.  Every arithmetic step is a library call (dir_conv2d_forward, dir_conv2d_wgrad_f32, dir_bn_train_*, dir_relu_*,
+dir_axpy_f32, dir_colsum_f32).
+"""
+from . import conv as TC
+from . import ops as O
+
+
+def _ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def _oihw(g):
+    return g.permute(0, 3, 1, 2).contiguous()
+
+
+def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5):
+    C = x.shape[-1]
+    y, st = O.bn_train_fwd(x.view(-1, C), P[pre + 'weight'], P[pre + 'bias'], P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum)
+    return y.view(x.shape), (x, st)
+
+
+def bn_bwd(P, pre, saved, gy, G):
+    x, st = saved
+    C = x.shape[-1]
+    gx, G[pre + 'weight'], G[pre + 'bias'] = O.bn_train_bwd(gy.contiguous().view(-1, C), x.view(-1, C), P[pre + 'weight'], st)
+    return gx.view(x.shape)
+
+
+def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True):
+    w = _ohwi(P[key + 'weight'])
+    has_bias = (key + 'bias') in P
+    gx, gw, gb = TC.conv_bwd(x, w, gy, stride, pad, need_gx=need_gx, has_bias=has_bias)
+    G[key + 'weight'] = _oihw(gw)
+    if has_bias:
+        G[key + 'bias'] = gb
+    return gx
+
+
+# ------------------------------------------------------------------------------------------------------------------------ Bottleneck
+def bottleneck_forward(P, x, stride=1):
+    ctx = {'x': x, 'stride': stride}
+    h = TC.conv_fwd(x, _ohwi(P['conv1.weight']))
+    h, ctx['bn1'] = bn_fwd(P, 'bn1.', h)
+    a1 = O.relu_fwd(h)
+    h = TC.conv_fwd(a1, _ohwi(P['conv2.weight']), None, stride, 1)
+    h, ctx['bn2'] = bn_fwd(P, 'bn2.', h)
+    a2 = O.relu_fwd(h)
+    h = TC.conv_fwd(a2, _ohwi(P['conv3.weight']))
+    out, ctx['bn3'] = bn_fwd(P, 'bn3.', h)
+    if 'downsample.0.weight' in P:
+        idn = TC.conv_fwd(x, _ohwi(P['downsample.0.weight']), None, stride, 0)
+        idn, ctx['bnd'] = bn_fwd(P, 'downsample.1.', idn)
+    else:
+        idn = x
+    O.axpy(out, idn)                                        # out += identity (resnet.py:139)
+    y = O.relu_fwd(out)
+    ctx.update(a1=a1, a2=a2, y=y)
+    return y, ctx
+
+
+def bottleneck_backward(P, ctx, gy, need_gx=True):
+    G = {}
+    x, stride = ctx['x'], ctx['stride']
+    g = O.relu_bwd(gy.contiguous(), ctx['y'])               # gradient of (bn3 out + identity)
+    g3 = bn_bwd(P, 'bn3.', ctx['bn3'], g, G)
+    g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G)
+    g2 = bn_bwd(P, 'bn2.', ctx['bn2'], O.relu_bwd(g2, ctx['a2']), G)
+    g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G)
+    g1 = bn_bwd(P, 'bn1.', ctx['bn1'], O.relu_bwd(g1, ctx['a1']), G)
+    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx)
+    if 'downsample.0.weight' in P:
+        gd = bn_bwd(P, 'downsample.1.', ctx['bnd'], g, G)
+        gxd = _conv_bwd(P, 'downsample.0.', x, gd, stride, 0, G, need_gx=need_gx)
+        if need_gx:
+            O.axpy(gx, gxd)
+    elif need_gx:
+        O.axpy(gx, g)
+    return gx, G
+
+
+# -------------------------------------------------------------------------------------------------------------------------- Residual
+def residual_forward(P, x):
+    ctx = {'x': x}
+    h, ctx['bn1'] = bn_fwd(P, 'bn1.', x)
+    a0 = O.relu_fwd(h)
+    h = TC.conv_fwd(a0, _ohwi(P['conv1.conv.weight']), P['conv1.conv.bias'])
+    h, ctx['bn2'] = bn_fwd(P, 'bn2.', h)
+    a1 = O.relu_fwd(h)
+    h = TC.conv_fwd(a1, _ohwi(P['conv2.conv.weight']), P['conv2.conv.bias'], 1, 1)
+    h, ctx['bn3'] = bn_fwd(P, 'bn3.', h)
+    a2 = O.relu_fwd(h)
+    y = TC.conv_fwd(a2, _ohwi(P['conv3.conv.weight']), P['conv3.conv.bias'])
+    need_skip = P['skip_layer.conv.weight'].shape[0] != P['skip_layer.conv.weight'].shape[1]          # hourglass.py:49-52
+    if need_skip:
+        O.axpy(y, TC.conv_fwd(x, _ohwi(P['skip_layer.conv.weight']), P['skip_layer.conv.bias']))
+    else:
+        O.axpy(y, x)
+    ctx.update(a0=a0, a1=a1, a2=a2, need_skip=need_skip)
+    return y, ctx
+
+
+def residual_backward(P, ctx, gy, need_gx=True):
+    G = {}
+    x = ctx['x']
+    gy = gy.contiguous()
+    g = _conv_bwd(P, 'conv3.conv.', ctx['a2'], gy, 1, 0, G)
+    g = bn_bwd(P, 'bn3.', ctx['bn3'], O.relu_bwd(g, ctx['a2']), G)
+    g = _conv_bwd(P, 'conv2.conv.', ctx['a1'], g, 1, 1, G)
+    g = bn_bwd(P, 'bn2.', ctx['bn2'], O.relu_bwd(g, ctx['a1']), G)
+    g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G)
+    gx = bn_bwd(P, 'bn1.', ctx['bn1'], O.relu_bwd(g, ctx['a0']), G)
+    if ctx['need_skip']:
+        gs = _conv_bwd(P, 'skip_layer.conv.', x, gy, 1, 0, G, need_gx=need_gx)
+        if need_gx:
+            O.axpy(gx, gs)
+    else:
+        # an unused skip_layer keeps its parameters without gradient, like torch (hourglass.py:56-59)
+        O.axpy(gx, gy)
+    return gx, G

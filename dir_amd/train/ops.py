@@ -111,13 +111,20 @@ def attention_bwd(qkv, probs, gout, B, T, H, scale):
     return gqkv
 
 
+def _bn_ws(R, C, dev):
+    n = _capi.lib().dir_bn_train_workspace_bytes(R, C)
+    return (torch.empty(n // 4, device=dev) if n > 0 else None), n
+
+
 def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     """BatchNorm in training mode over x [R, C] (channels last).  -> (y, (save_mean, save_rstd)); running statistics updated in place"""
     _chk(x, w, b, running_mean, running_var)
     R, C = x.shape
     y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    ws, n = _bn_ws(R, C, x.device)
     _capi.check(_capi.lib().dir_bn_train_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
-                                                 _capi.ptr(running_var), R, C, C, float(eps), float(momentum), _capi.stream_ptr()), 'dir_bn_train_forward')
+                                                 _capi.ptr(running_var), R, C, C, float(eps), float(momentum), _capi.ptr(ws), n, _capi.stream_ptr()),
+                'dir_bn_train_forward')
     return y, (sm, sr)
 
 
@@ -126,8 +133,9 @@ def bn_train_bwd(gy, x, w, stats, need_gx=True):
     R, C = x.shape
     gx = torch.empty_like(x) if need_gx else None
     gw, gb = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    ws, n = _bn_ws(R, C, x.device)
     _capi.check(_capi.lib().dir_bn_train_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(gx),
-                                                  _capi.ptr(gw), _capi.ptr(gb), R, C, C, _capi.stream_ptr()), 'dir_bn_train_backward')
+                                                  _capi.ptr(gw), _capi.ptr(gb), R, C, C, _capi.ptr(ws), n, _capi.stream_ptr()), 'dir_bn_train_backward')
     return gx, gw, gb
 
 

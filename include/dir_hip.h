@@ -145,11 +145,15 @@ int dir_attention_forward(const float* qkv, float* probs, float* out, int B, int
 int dir_attention_backward(const float* qkv, const float* probs, const float* gout, float* gqkv, int B, int T, int H, float scale, void* stream);
 /* BatchNorm in TRAINING mode over x [R][C] with row stride ld (channels last: R = samples x positions): batch mean and biased
  * variance, y = (x - mean) * rstd * w + b, running statistics updated with `momentum` and the unbiased variance (torch semantics);
- * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional). */
+ * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional).  R <= 2048 (the token path): one
+ * thread per channel walks the rows in order, no workspace.  Larger R (BatchNorm2d over feature maps): the column reductions are cut
+ * into 1024-row chunks whose partials are added in chunk order (deterministic); workspace of dir_bn_train_workspace_bytes(R, C). */
+long long dir_bn_train_workspace_bytes(int R, int C);
 int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
-                         float* running_var, int R, int C, int ld, float eps, float momentum, void* stream);
+                         float* running_var, int R, int C, int ld, float eps, float momentum, float* workspace, long long workspace_bytes,
+                         void* stream);
 int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd, float* gx, float* gw,
-                          float* gb, int R, int C, int ld, void* stream);
+                          float* gb, int R, int C, int ld, float* workspace, long long workspace_bytes, void* stream);
 int dir_relu_forward(const float* x, float* y, long long n, void* stream);
 int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, void* stream);   /* g x = y > 0 ? g y : 0 */
 /* PGraphConv's adjacency (SemGCN/p_graph_conv.py:43-50): A_1 [21][21] = row-softmax of the hand-skeleton mask filled with e_1 [40]

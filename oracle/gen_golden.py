@@ -606,7 +606,7 @@ def compact_grads(named, step=16):
         if g.dim() < 2 or g.numel() <= 8192:
             res['grad.' + k] = g
         else:
-            g2 = g.reshape(-1, g.shape[-1])
+            g2 = g.reshape(g.shape[0], -1) if (g.dim() == 4 and g.shape[-1] <= 7) else g.reshape(-1, g.shape[-1])     # conv OIHW -> [O, I*kh*kw]
             res['grad.' + k + '.cols%d' % step] = g2[:, ::step].contiguous()
             res['grad.' + k + '.rowsum'] = g2.double().sum(1)
             res['grad.' + k + '.colsum'] = g2.double().sum(0)
@@ -694,7 +694,54 @@ def gen_stage_grad():
     save('g17_stage_grad', **res)
 
 
-GENS = {'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G18 / G19 gradients through the image half's residual blocks
+BLOCK_CASES = {  # name: (kind, constructor arguments, input shape NCHW)
+    'bneck_plain': ('bottleneck', dict(inplanes=256, planes=64, stride=1, downsample=False), (3, 256, 16, 16)),
+    'bneck_down': ('bottleneck', dict(inplanes=256, planes=128, stride=2, downsample=True), (3, 256, 16, 16)),
+    'res_skip': ('residual', dict(inp_dim=512, out_dim=256), (3, 512, 16, 16)),
+    'res_same': ('residual', dict(inp_dim=256, out_dim=256), (3, 256, 16, 16)),
+}
+
+
+def make_block(kind, kw):
+    if kind == 'bottleneck':
+        from models.backbone.resnet import Bottleneck, conv1x1
+        ds = None
+        if kw['downsample']:
+            ds = torch.nn.Sequential(conv1x1(kw['inplanes'], kw['planes'] * 4, kw['stride']), torch.nn.BatchNorm2d(kw['planes'] * 4))
+        return Bottleneck(kw['inplanes'], kw['planes'], kw['stride'], ds)
+    from models.backbone.hourglass import Residual
+    return Residual(kw['inp_dim'], kw['out_dim'])
+
+
+def gen_block_grad():
+    """torch autograd through the reference's Bottleneck (models/backbone/resnet.py:86-142) and Residual (models/backbone/hourglass.py:33-70)
+    in TRAINING mode (batch-statistics BatchNorm2d): d <gy, block(x)> / d (x, every parameter), and the running statistics after"""
+    shapes_all = {}
+    for name, (kind, kw, xs) in BLOCK_CASES.items():
+        net = make_block(kind, kw)
+        shapes_all[name] = {k: list(v) for k, v in load_synth(net).items()}
+        net.train()
+        x0 = torch.from_numpy(synth.synth_input('blockgrad.%s.x' % name, xs, SEED))
+        x = x0.clone().requires_grad_(True)
+        y = net(x + 0.0)                                   # (+ 0: the blocks end in in-place ops on views of their input chain)
+        gy = torch.from_numpy(synth.synth_input('blockgrad.%s.gy' % name, tuple(y.shape), SEED))
+        params = {k: v for k, v in net.named_parameters()}
+        gs = torch.autograd.grad((y * gy).sum(), [x] + list(params.values()), allow_unused=True)
+        res = {'y.ch8': y.detach()[:, ::8].contiguous(), 'y.chsum': y.detach().double().sum(1),
+               'gx.ch8': gs[0][:, ::8].contiguous(), 'gx.chsum': gs[0].double().sum(1), 'gx.abssum': gs[0].double().abs().sum(1)}
+        named = {k: g for k, g in zip(params, gs[1:]) if g is not None}
+        print('   %s: parameters without gradient: %s' % (name, sorted(k for k, g in zip(params, gs[1:]) if g is None)))
+        res.update(compact_grads(named, step=16))
+        for k, v in net.state_dict().items():
+            if 'running_' in k:
+                res['after.' + k] = v
+        save('g18_block_grad_' + name, **res)
+    with open(os.path.join(OUT, 'manifest_blocks.json'), 'w') as f:
+        json.dump(shapes_all, f, indent=0)
+
+
+GENS = {'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

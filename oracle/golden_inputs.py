@@ -155,3 +155,18 @@ def stage_grad_inputs(S=16, B=4):
     cot = {k: synth.synth_input('stagegrad.' + k, shp, SEED) for k, shp in shapes.items()}
     cot['joint_feat'] = cot['joint_feat'] * np.float32(0.05)
     return ins, cot
+
+
+BLOCK_GRAD_CASES = {  # name: (kind, stride, input shape NCHW, output shape NCHW)       (oracle/gen_golden.py::BLOCK_CASES)
+    'bneck_plain': ('bottleneck', 1, (3, 256, 16, 16), (3, 256, 16, 16)),
+    'bneck_down': ('bottleneck', 2, (3, 256, 16, 16), (3, 512, 8, 8)),
+    'res_skip': ('residual', 1, (3, 512, 16, 16), (3, 256, 16, 16)),
+    'res_same': ('residual', 1, (3, 256, 16, 16), (3, 256, 16, 16)),
+}
+
+
+def block_grad_inputs(name, batch=None):
+    kind, stride, xs, ys = BLOCK_GRAD_CASES[name]
+    if batch is not None:
+        xs, ys = (batch,) + xs[1:], (batch,) + ys[1:]
+    return synth.synth_input('blockgrad.%s.x' % name, xs, SEED), synth.synth_input('blockgrad.%s.gy' % name, ys, SEED)

@@ -80,7 +80,7 @@ def check_compact_grads(got, g, tol, prefix='grad.', zero_suffixes=()):
             ref = g[prefix + name]
             e = np.abs(a.reshape(ref.shape) - ref).max() / (np.abs(ref).max() + 1e-30)
         else:
-            a2 = a.reshape(-1, a.shape[-1])
+            a2 = a.reshape(a.shape[0], -1) if (a.ndim == 4 and a.shape[-1] <= 7) else a.reshape(-1, a.shape[-1])       # conv OIHW -> [O, I*kh*kw]
             ck = [k for k in g if k.startswith(prefix + name + '.cols')][0]
             step = int(ck.rsplit('.cols', 1)[1])
             # the sums are compared on the scale of the L1 norms of the rows / columns they sum: a gradient that flows out of a

@@ -16,9 +16,10 @@ from oracle.dir_forward import dir_forward
 SEED = 1234
 
 
-def shapes_of(name):
+def shapes_of(name, key=None):
     with open(os.path.join(GOLDEN, name)) as f:
-        return {k: tuple(v) for k, v in json.load(f).items()}
+        d = json.load(f)
+    return {k: tuple(v) for k, v in (d if key is None else d[key]).items()}
 
 
 def sub_shapes(shapes, prefix):
@@ -445,3 +446,27 @@ def test_stage_token_gradient_oracle_matches_reference_autograd(golden):
     for k, v in running.items():
         assert maxabs(v, g['after.' + k]) < 1e-5 * max(1.0, np.abs(g['after.' + k]).max()), k
     assert len(running) == 2 * (2 + 2 + 8) + 2
+
+
+# ------------------------------------------------------------------ G18 gradients through the image half's residual blocks (training mode)
+BLOCK_ZERO = ('conv1.conv.bias', 'conv2.conv.bias')        # a conv bias in front of a training-mode BatchNorm: analytically zero gradient
+
+
+@pytest.mark.parametrize('name', ['bneck_plain', 'bneck_down', 'res_skip', 'res_same'])
+def test_block_gradient_oracle_matches_reference_autograd(golden, name):
+    from conftest import check_compact_grads
+    from oracle import block_grad as OB
+    from oracle.golden_inputs import BLOCK_GRAD_CASES, block_grad_inputs
+    g = golden('g18_block_grad_' + name)
+    kind, stride = BLOCK_GRAD_CASES[name][:2]
+    sd = synth.synth_state_dict(shapes_of('manifest_blocks.json', name), SEED)
+    x, gy = block_grad_inputs(name)
+    y, gx, G, R = OB.bottleneck(sd, x, gy, stride) if kind == 'bottleneck' else OB.residual(sd, x, gy)
+    assert maxabs(y[:, ::8], g['y.ch8']) < 2e-5 * np.abs(g['y.ch8']).max()
+    assert maxabs(gx[:, ::8], g['gx.ch8']) < 3e-5 * np.abs(g['gx.ch8']).max()
+    assert maxabs(gx.sum(1), g['gx.chsum']) < 3e-5 * g['gx.abssum'].max()
+    assert check_compact_grads(G, g, 5e-5, zero_suffixes=BLOCK_ZERO) < 5e-5
+    if kind == 'residual':
+        assert ('skip_layer.conv.weight' in G) == (name != 'res_same')      # an unused skip_layer gets no gradient (hourglass.py:56-59)
+    for k, v in R.items():
+        assert maxabs(v, g['after.' + k]) < 1e-5 * max(1.0, np.abs(g['after.' + k]).max()), k
