@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 22          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 23          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -174,6 +174,12 @@ _SIGNATURES = {
     'dir_conv2d_splitk_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, C.c_longlong, _p]),
     'dir_conv2d_wgrad_workspace_bytes': (C.c_longlong, [C.POINTER(ConvDesc)]),
     'dir_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, _p]),
+    'dir_maxpool3x3s2_backward': (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    'dir_upsample2x_bilinear_backward': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'dir_attn_pool_forward': (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'dir_attn_pool_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    'dir_bone_proj_backward_scratch_bytes': (C.c_longlong, [_i, _i]),
+    'dir_bone_proj_backward': (C.c_int, [_p, _p, _p, _i, _i, C.c_float, _p, _p, _p, _i, _i, _i, _p]),
     'dir_axpy_f32': (C.c_int, [_p, _p, C.c_longlong, C.c_float, _p]),
     'dir_stage_positions': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'dir_grid_rows_forward': (C.c_int, [_p, _p, _p, _i, _i, _i, _p]),

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 22
+#define DIR_ABI_VERSION 23
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -166,6 +166,26 @@ int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, v
 int dir_grid_rows_forward(const float* feat_nhwc, const float* uv, float* rows, int B, int S, int C, void* stream);
 int dir_grid_rows_backward(const float* const* g_rows_h_host, const float* const* uv_h_host, int hands, float* g_feat_nhwc, int B, int S, int C,
                            int zero_first, void* stream);
+/* Backward pass, image half: the spatial operators between the convolutions (fp32 NHWC, deterministic gather forms).
+ * dir_maxpool3x3s2_backward: nn.MaxPool2d(3,2,1) (models/backbone/resnet.py:247): g x from x [B,H,W,C] and g y [B,Ho,Wo,C]; the gradient of a
+ *   window goes to its FIRST maximum in (ky, kx) order, as ATen's max_pool2d_with_indices picks it.
+ * dir_upsample2x_bilinear_backward: nn.Upsample(2, bilinear) (models/dir.py:392,398): g x [B,H,W,C] from g y [B,2H,2W,*] (channel slice
+ *   gy_coff .. +C of rows of gy_cstride floats: the upsampled map is one half of a concatenation).
+ * dir_attn_pool_forward / _backward: InitRegressor's pooling (models/dir.py:263-270): attn = sigmoid(logit [B,HW]);
+ *   pooled [B,C] = sum_p feat[p,c] attn[p] / (sum_p attn[p] + 1e-8); mean [B,C] = feat.mean over the pixels.  Backward: g feat (written, or
+ *   added with accumulate != 0) from g pooled and g mean (either may be NULL), g logit [B,HW] (optional).
+ * dir_bone_proj_backward: Joint2BoneFeature.bone_proj (models/dir.py:146-174) for `hands` hands: from g img [B,S,S,*] (channel
+ *   (hand*20 + bone)*64 + c at offset img_coff of rows of img_cstride floats) the gradients w.r.t. the re-embedded joint features
+ *   emb [B,42,64] (-> g_emb [B,42,64]) and the joint uv [B,21,2] per hand (-> g_uv_lr, optional).  The capsule mask and the weights are
+ *   recomputed with the forward's own arithmetic; scratch: dir_bone_proj_backward_scratch_bytes(B, hands). */
+int dir_maxpool3x3s2_backward(const float* x, const float* gy, float* gx, int B, int H, int W, int C, void* stream);
+int dir_upsample2x_bilinear_backward(const float* gy, float* gx, int B, int H, int W, int C, int gy_cstride, int gy_coff, void* stream);
+int dir_attn_pool_forward(const float* feat, const float* logit, float* attn, float* pooled, float* mean, int B, int HW, int C, void* stream);
+int dir_attn_pool_backward(const float* feat, const float* attn, const float* pooled, const float* g_pooled, const float* g_mean, float* g_feat,
+                           float* g_logit, int B, int HW, int C, int accumulate, void* stream);
+long long dir_bone_proj_backward_scratch_bytes(int B, int hands);
+int dir_bone_proj_backward(const float* const* uv_lr_host, const float* emb, const float* g_img, int img_cstride, int img_coff, float distance,
+                           float* g_emb, float* const* g_uv_lr_host, float* scratch, int B, int S, int hands, void* stream);
 /* dst += alpha * src, n floats (gradient accumulation of the modules a stage runs once per hand: global_pos_emb, proj_feat_emb,
  * models/dir.py:106-107,118-119). */
 int dir_axpy_f32(float* dst, const float* src, long long n, float alpha, void* stream);

@@ -741,7 +741,25 @@ def gen_block_grad():
         json.dump(shapes_all, f, indent=0)
 
 
-GENS = {'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G19 gradients through bone_proj
+def gen_bone_grad():
+    """torch autograd through the reference's Joint2BoneFeature.bone_proj (models/dir.py:146-174): d <g, img> / d (joint_uv, joint_feat)"""
+    from models.dir import Joint2BoneFeature
+    from oracle.golden_inputs import bone_grad_inputs
+    res = {}
+    for S, dist in ((16, 1), (32, 2)):
+        net = Joint2BoneFeature(256, 128, 64, 21, S, 'unused', 0, distance=dist)
+        uv, feat, g = [torch.from_numpy(a) for a in bone_grad_inputs(S)]
+        uv, feat = uv.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        img = net.bone_proj(uv, feat)                                      # [B, 1280, S, S]
+        gu, gf = torch.autograd.grad((img * g).sum(), [uv, feat])
+        res['S%d.g_uv' % S], res['S%d.g_feat' % S] = gu, gf
+        res['S%d.img.sum' % S] = img.detach().double().sum((2, 3))
+        print('   S=%d: mask covers %.3f of the map, |g uv| max %.3e' % (S, float((img.detach() != 0).float().mean()), float(gu.abs().max())))
+    save('g19_bone_grad', **res)
+
+
+GENS = {'bone_grad': gen_bone_grad, 'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

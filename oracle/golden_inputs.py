@@ -170,3 +170,9 @@ def block_grad_inputs(name, batch=None):
     if batch is not None:
         xs, ys = (batch,) + xs[1:], (batch,) + ys[1:]
     return synth.synth_input('blockgrad.%s.x' % name, xs, SEED), synth.synth_input('blockgrad.%s.gy' % name, ys, SEED)
+
+
+def bone_grad_inputs(S, B=3):
+    """G19: one hand's joint uv [B,21,2], re-embedded joint features [B,21,64], cotangent of the rasterised map [B,1280,S,S]"""
+    p = 'bonegrad%d.' % S
+    return bone_uv(p + 'uv', B, S), synth.synth_input(p + 'feat', (B, 21, 64), SEED), synth.synth_input(p + 'g', (B, 1280, S, S), SEED)

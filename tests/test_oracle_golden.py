@@ -470,3 +470,15 @@ def test_block_gradient_oracle_matches_reference_autograd(golden, name):
         assert ('skip_layer.conv.weight' in G) == (name != 'res_same')      # an unused skip_layer gets no gradient (hourglass.py:56-59)
     for k, v in R.items():
         assert maxabs(v, g['after.' + k]) < 1e-5 * max(1.0, np.abs(g['after.' + k]).max()), k
+
+
+# ------------------------------------------------------------------ G19 gradients through bone_proj
+@pytest.mark.parametrize('S,dist', [(16, 1), (32, 2)])
+def test_bone_proj_gradient_oracle_matches_reference_autograd(golden, S, dist):
+    from oracle.golden_inputs import bone_grad_inputs
+    from oracle.spatial_grad import bone_proj_backward
+    g = golden('g19_bone_grad')
+    uv, feat, gi = bone_grad_inputs(S)
+    g_uv, g_feat = bone_proj_backward(uv, feat, gi, S, dist)
+    assert maxabs(g_feat, g['S%d.g_feat' % S]) < 2e-5 * np.abs(g['S%d.g_feat' % S]).max()
+    assert maxabs(g_uv, g['S%d.g_uv' % S]) < 1e-4 * np.abs(g['S%d.g_uv' % S]).max()     # the fp32 side divides by (d_a + d_b)^2 near the joints
