@@ -1,0 +1,236 @@
+"""DIR.forward in TRAINING mode and the gradient of the summed training objective w.r.t. every parameter -- what
+`outs_list, loss = model(inputs, targets, meta_infos); sum(loss.values()).backward()` (train.py:66-68) computes -- composed from
+libdir_hip.so kernels: dir_amd/train/{conv,blocks,spatial,stage,ste,pgcn,ops}.py, the loss gradients of dir_amd/models/loss.py and the
+MANO / regressor backward.  fp32, NHWC, batch-statistics BatchNorm everywhere (running statistics in P are updated), deterministic.
+
+    outs, ctx = forward(P, img_nchw, mano)            P: {DIR state-dict key -> fp32 cuda tensor, reference layouts}
+    loss = losses(outs, target, meta_info, faces)     the 42 terms (dir_amd.models.loss.DirLoss)
+    grads = backward(P, ctx, outs, target, meta_info, faces, mano)     {parameter key -> gradient of sum(loss)}
+
+The reference's `.detach()` cuts (models/dir.py:447-453,463-469) are structural here: a stage receives the previous stage's outputs as
+plain inputs.  This path is correctness-first (an exact-fp32 64x64-tile GEMM for the weight gradients, the inference convolution kernel
+in its fp32 mode for everything else); it is not on the benchmarked path.
+"""
+import torch
+
+from . import blocks as TB
+from . import conv as TC
+from . import ops as O
+from . import spatial as SP
+from . import stage as TS
+from .. import engine as E
+from ..models import loss as L
+
+SIDES = ('left', 'right')
+LAYERS = (3, 4, 6, 3)
+
+
+def sub(P, pre):
+    n = len(pre)
+    return {k[n:]: v for k, v in P.items() if k.startswith(pre)}
+
+
+def put(G, pre, g):
+    for k, v in g.items():
+        G[pre + k] = v
+
+
+def mano_tables(P, pre, keep):
+    """(left, right) dir_mano_tables of the two ManoLayers under `pre` ('init_regressor.' / 'decoder.projecter_4.regressor.')"""
+    return [E.pack_mano(P, pre + 'mano_layer_' + s, s, 0, keep) for s in SIDES]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------ pieces
+def _stem_forward(P, img):
+    """conv1 7x7/2 (no bias) through the engine's space-to-depth form (dir_stem_prep_s2d + a 4x4 stride-1 implicit GEMM, engine.stem_conv_op)"""
+    from .. import _capi
+    B = img.shape[0]
+    op = E.stem_conv_op(P['backbone.conv1.weight'], None, None, torch.float32)
+    op.flags = 0                                           # raw convolution: BatchNorm (batch statistics) and ReLU follow as their own steps
+    xp = torch.empty(B, 131, 132, 16, device=img.device)
+    _capi.check(_capi.lib().dir_stem_prep_s2d(_capi.ptr(img), _capi.ptr(xp), B, 256, 256, 131, 132, _capi.DT_F32, _capi.stream_ptr()), 'dir_stem_prep_s2d')
+    return op(xp)
+
+
+def _cbr_forward(P, pre, x, k):
+    """Sequential(Conv2d(k, pad k//2), BatchNorm2d, ReLU, Conv2d(1)) -- conv_final, seg, dense, attention_*, fusion (models/dir.py:57-62,227-241,404-419)"""
+    w0 = TB._ohwi(P[pre + '0.weight'])
+    h = TC.conv_fwd(x, w0, P.get(pre + '0.bias'), 1, k // 2)
+    n, s_bn = TB.bn_fwd(P, pre + '1.', h)
+    a = O.relu_fwd(n)
+    y = TC.conv_fwd(a, TB._ohwi(P[pre + '3.weight']), P.get(pre + '3.bias'))
+    return y, dict(x=x, bn=s_bn, a=a, k=k)
+
+
+def _cbr_backward(P, pre, s, gy, G, need_gx=True):
+    g = TB._conv_bwd(P, pre + '3.', s['a'], gy, 1, 0, G)
+    g = TB.bn_bwd(P, pre + '1.', s['bn'], O.relu_bwd(g, s['a']), G)
+    return TB._conv_bwd(P, pre + '0.', s['x'], g, 1, s['k'] // 2, G, need_gx=need_gx)
+
+
+def _stage_image_forward(P, pre, tok, uv_l, uv_r, S, distance):
+    """re-embedding + bone rasterisation + fusion conv of a stage (models/dir.py:118-122)"""
+    B = tok.shape[0]
+    Ps = sub(P, pre)
+    emb = torch.empty(B, 42, 64, device=tok.device)
+    ctx_emb = []
+    for h in range(2):                                     # proj_feat_emb runs once per hand (shared module, two BatchNorm calls)
+        rows = tok[:, 21 * h:21 * (h + 1)].contiguous().view(B * 21, 64)
+        y, c = TS.mlp_forward(Ps, 'proj_feat_emb.', rows)
+        emb[:, 21 * h:21 * (h + 1)] = y.view(B, 21, 64)
+        ctx_emb.append(c)
+    bone = SP.bone_proj_fwd(uv_l, uv_r, emb, S, distance)
+    img_feat, c_fus = _cbr_forward(P, pre + 'fusion.', bone, 3)
+    return img_feat, dict(emb=emb, ctx_emb=ctx_emb, fus=c_fus, uv=(uv_l, uv_r), S=S, distance=distance)
+
+
+def _stage_image_backward(P, pre, s, g_img_feat, G):
+    """-> (g joint_feat [B,42,64], g uv_left, g uv_right)"""
+    B = s['emb'].shape[0]
+    g_bone = _cbr_backward(P, pre + 'fusion.', s['fus'], g_img_feat, G)
+    g_emb, gul, gur = SP.bone_proj_bwd(s['uv'][0], s['uv'][1], s['emb'], g_bone, s['S'], s['distance'])
+    Ps, Gs = sub(P, pre), {}
+    g_tok = torch.empty(B, 42, 64, device=g_emb.device)
+    for h in range(2):
+        g_rows = TS.mlp_backward(Ps, 'proj_feat_emb.', s['ctx_emb'][h], g_emb[:, 21 * h:21 * (h + 1)].contiguous().view(B * 21, 64), Gs, need_gx=True)
+        g_tok[:, 21 * h:21 * (h + 1)] = g_rows.view(B, 21, 64)
+    put(G, pre, Gs)
+    return g_tok, gul, gur
+
+
+# ----------------------------------------------------------------------------------------------------------------------------- forward
+def forward(P, img, keep=None):
+    """img NCHW fp32 [B,3,256,256] -> (outs: the three stage dicts + {'seg', 'dense'} NCHW, ctx)"""
+    keep = [] if keep is None else keep
+    B = img.shape[0]
+    dev = img.device
+    ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)
+    # ---- backbone (models/backbone/resnet.py:243-255)
+    h = _stem_forward(P, img)
+    n, ctx['bn1'] = TB.bn_fwd(P, 'backbone.bn1.', h)
+    a = O.relu_fwd(n)
+    x = SP.maxpool_fwd(a)
+    ctx['stem'] = (a, x)
+    feats, ctx['blocks'] = [], []
+    for li, nb in enumerate(LAYERS):
+        for bi in range(nb):
+            pre = 'backbone.layer%d.%d.' % (li + 1, bi)
+            x, c = TB.bottleneck_forward(sub(P, pre), x, 2 if (bi == 0 and li > 0) else 1)
+            ctx['blocks'].append((pre, c))
+        feats.append(x)
+    c1, c2, c3, c4 = feats
+    # ---- InitRegressor (models/dir.py:260-305)
+    init, ctx['init'] = {}, {}
+    pooled = []
+    for h_i, s in enumerate(SIDES):
+        logit, c_att = _cbr_forward(P, 'init_regressor.attention_%s.' % s, c4, 3)             # [B,8,8,1]; the Sigmoid lives in the pooling kernel
+        p, attn, mean = SP.attn_pool_fwd(c4, logit.reshape(B, 64).contiguous(), want_mean=(h_i == 0))
+        ctx['init'][s] = dict(att=c_att, attn=attn, pooled=p)
+        pooled.append(p)
+        if h_i == 0:
+            ctx['init']['mean'] = mean
+    init['pd_offset'] = O.linear_fwd(ctx['init']['mean'], P['init_regressor.offset.weight'], P['init_regressor.offset.bias'])
+    para = [O.linear_fwd(pooled[i], P['init_regressor.mano_%s.weight' % s], P['init_regressor.mano_%s.bias' % s]) for i, s in enumerate(SIDES)]
+    tabs0 = mano_tables(P, 'init_regressor.', keep)
+    mano = E.run_mano_pair(tabs0, para[0], para[1], B, mesh_uv=True)
+    for i, s in enumerate(SIDES):
+        init['pd_mano_para_' + s] = para[i]
+        init['pd_mesh_xyz_' + s], init['pd_joint_xyz_' + s], init['pd_joint_uv_' + s], init['pd_mesh_uv_' + s] = mano[i]
+    ctx['init'].update(para=para, tabs=tabs0)
+    # ---- decoder (models/dir.py:437-483)
+    outs = [init]
+    prev, feat_lo, skip_src = init, c4, (c3, c2)
+    ctx['dec'] = []
+    for si, (tag, S, dist) in enumerate((('4', 16, 1), ('3', 32, 2))):
+        d = {}
+        Cup = feat_lo.shape[3]
+        skip, d['skip'] = TB.residual_forward(sub(P, 'decoder.skip_layer%s.' % tag), skip_src[si])
+        cat = torch.empty(B, S, S, Cup + 256, device=dev)
+        SP.upsample_fwd(feat_lo, out=cat, out_coff=0)
+        cat[..., Cup:] = skip
+        fusion_feat, d['fusion'] = TB.residual_forward(sub(P, 'decoder.fusion_layer%s.' % tag), cat)
+        pre = 'decoder.projecter_%s.' % tag
+        tabs = mano_tables(P, pre + 'regressor.', keep)
+        res, d['tok'] = TS.stage_tokens_forward(sub(P, pre), tabs, fusion_feat, prev)
+        img_feat, d['img'] = _stage_image_forward(P, pre, res['joint_feat'], res['pd_joint_uv_left'], res['pd_joint_uv_right'], S, dist)
+        enh_in = torch.cat((fusion_feat, img_feat), dim=3)
+        feat_lo, d['enh'] = TB.residual_forward(sub(P, 'decoder.enhance_layer%s.' % tag), enh_in)
+        d.update(tabs=tabs, Cup=Cup, S=S)
+        ctx['dec'].append(d)
+        outs.append(res)
+        prev = res
+    feat, ctx['final'] = _cbr_forward(P, 'decoder.conv_final.', feat_lo, 3)
+    seg, ctx['seg'] = _cbr_forward(P, 'decoder.seg.', feat, 3)
+    dense, ctx['dense'] = _cbr_forward(P, 'decoder.dense.', feat, 3)
+    outs.append({'seg': seg.permute(0, 3, 1, 2).contiguous(), 'dense': dense.permute(0, 3, 1, 2).contiguous()})
+    ctx.update(feats=feats)
+    return outs, ctx
+
+
+def losses(outs, target, meta_info, faces):
+    return L.DirLoss(faces[0], faces[1])(outs[:3], outs[3], target, meta_info)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------- backward
+def backward(P, ctx, outs, target, meta_info, faces):
+    """gradient of sum(loss) (all 42 terms with weight 1, train.py:68) -> {parameter key: gradient}"""
+    G = {}
+    B = ctx['img'].shape[0]
+    c1, c2, c3, c4 = ctx['feats']
+    g_seg, g_dense = L.dense_loss_grads(outs[3]['seg'], outs[3]['dense'], target['seg'], target['dense'])
+    g_feat = _cbr_backward(P, 'decoder.seg.', ctx['seg'], g_seg.permute(0, 2, 3, 1).contiguous(), G)
+    O.axpy(g_feat, _cbr_backward(P, 'decoder.dense.', ctx['dense'], g_dense.permute(0, 2, 3, 1).contiguous(), G))
+    g_lo = _cbr_backward(P, 'decoder.conv_final.', ctx['final'], g_feat, G)                      # gradient of enhance_layer3's output
+    g_skip_src = [None, None]
+    for si in (1, 0):
+        tag, d = ('4', '3')[si], ctx['dec'][si]
+        pre = 'decoder.projecter_%s.' % tag
+        S, Cup = d['S'], d['Cup']
+        g_enh_in, g = TB.residual_backward(sub(P, 'decoder.enhance_layer%s.' % tag), d['enh'], g_lo)
+        put(G, 'decoder.enhance_layer%s.' % tag, g)
+        g_fusion = g_enh_in[..., :256].contiguous()
+        g_tok, gul, gur = _stage_image_backward(P, pre, d['img'], g_enh_in[..., 256:].contiguous(), G)
+        cot = L.stage_loss_grads(outs[si + 1], target, meta_info, faces)
+        O.axpy(cot['pd_joint_uv_left'], gul)                                                     # bone_proj reads the stage's own (not detached) uv
+        O.axpy(cot['pd_joint_uv_right'], gur)
+        g_samp, g = TS.stage_tokens_backward(sub(P, pre), d['tabs'], d['tok'], cot, g_joint_feat=g_tok)
+        put(G, pre, g)
+        O.axpy(g_fusion, g_samp)
+        g_cat, g = TB.residual_backward(sub(P, 'decoder.fusion_layer%s.' % tag), d['fusion'], g_fusion)
+        put(G, 'decoder.fusion_layer%s.' % tag, g)
+        g_lo = SP.upsample_bwd(g_cat, Cup, 0)                                                    # -> enhance_layer4's output (si = 1) or c4 (si = 0)
+        g_src, g = TB.residual_backward(sub(P, 'decoder.skip_layer%s.' % tag), d['skip'], g_cat[..., Cup:].contiguous())
+        put(G, 'decoder.skip_layer%s.' % tag, g)
+        g_skip_src[si] = g_src                                                                    # gradient into c3 (si = 0) / c2 (si = 1)
+    g_c4 = g_lo
+    # ---- InitRegressor
+    ci = ctx['init']
+    cot = L.stage_loss_grads(outs[0], target, meta_info, faces)
+    from .. import functional as F
+    g_para = F.mano_backward(list(ci['tabs']), ci['para'], g_verts=[cot['pd_mesh_xyz_' + s] for s in SIDES], g_joints=[cot['pd_joint_xyz_' + s] for s in SIDES],
+                             g_joint_uv=[cot['pd_joint_uv_' + s] for s in SIDES], g_mesh_uv=[cot['pd_mesh_uv_' + s] for s in SIDES])
+    g_mean, G['init_regressor.offset.weight'], G['init_regressor.offset.bias'] = O.linear_bwd(cot['pd_offset'].contiguous(), ci['mean'], P['init_regressor.offset.weight'])
+    for i, s in enumerate(SIDES):
+        g_pool, G['init_regressor.mano_%s.weight' % s], G['init_regressor.mano_%s.bias' % s] = O.linear_bwd(g_para[i], ci[s]['pooled'], P['init_regressor.mano_%s.weight' % s])
+        _, g_logit = SP.attn_pool_bwd(c4, ci[s]['attn'], ci[s]['pooled'], g_pool, g_mean if i == 0 else None, g_feat=g_c4)
+        O.axpy(g_c4, _cbr_backward(P, 'init_regressor.attention_%s.' % s, ci[s]['att'], g_logit.view(B, 8, 8, 1), G))
+    # ---- backbone
+    g_feats = [None, g_skip_src[1], g_skip_src[0], g_c4]                                         # c1 has no consumer besides layer2
+    g = None
+    bi_end = len(ctx['blocks'])
+    for li in (3, 2, 1, 0):
+        if g is None:
+            g = g_feats[li]
+        elif g_feats[li] is not None:
+            O.axpy(g, g_feats[li])
+        for _ in range(LAYERS[li]):
+            bi_end -= 1
+            pre, c = ctx['blocks'][bi_end]
+            g, gb = TB.bottleneck_backward(sub(P, pre), c, g)
+            put(G, pre, gb)
+    a, x_pool = ctx['stem']
+    g = SP.maxpool_bwd(a, g)
+    g = TB.bn_bwd(P, 'backbone.bn1.', ctx['bn1'], O.relu_bwd(g, a), G)
+    img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
+    G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
+    return G

@@ -759,7 +759,92 @@ def gen_bone_grad():
     save('g19_bone_grad', **res)
 
 
-GENS = {'bone_grad': gen_bone_grad, 'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
+# ----------------------------------------------------------------------------- G20 the whole training step's gradient
+def gen_full_grad():
+    """sum(loss.values()).backward() through the reference's own DIR in training mode (train.py:66-68) on G8's input, targets and faces.
+    With random weights the network is badly conditioned (seg logits ~ 1e5, BatchNorm backward cancels most of its input), so the fp32
+    gradient carries visible evaluation noise: the fixture holds the gradient of the SAME graph evaluated in float64 (compact form) and,
+    per parameter, how far the reference's own fp32 evaluation is from it ('ref32_err.<key>', relative to the gradient's maximum) --
+    the yardstick for any other fp32 implementation."""
+    from models.dir import DIR
+    g8 = np.load(os.path.join(OUT, 'g8_loss.npz'))
+
+    def run(dtype):
+        net = DIR(21, 'unused', 0)
+        load_synth(net)
+        net.train()
+        for side in ('left', 'right'):
+            fc = torch.from_numpy(synth.loss_faces(side, SEED))
+            getattr(net, 'normal_loss_' + side).face = fc
+            getattr(net, 'edge_loss_' + side).face = fc
+        net = net.to(dtype)
+        for m in net.modules():                            # plain tensor attributes (PGraphConv's adjacency, the loss modules' tables) follow
+            for name, val in list(vars(m).items()):
+                if torch.is_tensor(val) and val.dtype == torch.float32:
+                    setattr(m, name, val.to(dtype))
+        img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).to(dtype)
+        target = {k[3:]: torch.from_numpy(g8[k]).to(dtype) for k in g8.files if k.startswith('gt_') and not k.endswith('_u8') and 'center' not in k}
+        target['seg'] = torch.from_numpy(g8['gt_seg_u8'].astype(np.float32)).to(dtype)
+        target['dense'] = torch.from_numpy(g8['gt_dense_u8'].astype(np.float32) / np.float32(255.0)).to(dtype)
+        meta = {k[3:]: torch.from_numpy(g8[k]).to(dtype) for k in g8.files if k.startswith('gt_center')}
+        keep_float = torch.Tensor.float
+        if dtype == torch.float64:                         # lovasz_loss.py:193 builds its foreground mask with .float(): promoted for the float64 pass
+            torch.Tensor.float = lambda self, *a, **k: self.double()
+        captured = {}
+        h0 = net.init_regressor.register_forward_hook(lambda m, a, o: captured.__setitem__('init', o))
+        h1 = net.decoder.register_forward_hook(lambda m, a, o: captured.__setitem__('dec', o))
+        inter = {}
+        try:
+            outs, loss = net({'img': img}, target, meta)
+            assert len(loss) == 42
+            stages = [captured['init']] + captured['dec']['result_list']
+            for i, st in enumerate(stages):                # gradients at the stage outputs: localise a mismatch without the whole net
+                for k in ('pd_mano_para_left', 'pd_mano_para_right', 'pd_mesh_xyz_left', 'pd_joint_uv_left', 'pd_offset'):
+                    st[k].retain_grad()
+                    inter['s%d.%s' % (i, k)] = st[k]
+            total = sum(loss[k] for k in loss)
+            total.backward()
+        finally:
+            torch.Tensor.float = keep_float
+            h0.remove(); h1.remove()
+        net.inter = {k: v.grad for k, v in inter.items()}
+        return net, loss, total
+    net, loss, total = run(torch.float32)
+    for k, v in loss.items():                              # the same pass G8 pinned (batch-statistics BN: independent of the running statistics)
+        assert abs(float(v) - float(g8['loss.' + k])) <= 2e-5 * max(1.0, abs(float(g8['loss.' + k]))), (k, float(v), float(g8['loss.' + k]))
+    named = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    none = sorted(k for k, p in net.named_parameters() if p.grad is None)
+    print('   %d parameters with gradient, %d without: %s ...' % (len(named), len(none), none[:6]))
+    net64, loss64, total64 = run(torch.float64)
+    named64 = {k: p.grad for k, p in net64.named_parameters() if p.grad is not None}
+    res = {'total': total.detach(), 'total64': total64.detach()}
+    res.update({'inter.' + k: v.float() for k, v in net64.inter.items()})
+    errs = []
+    for k in named:
+        e = float((named[k].double() - named64[k]).abs().max() / (named64[k].abs().max() + 1e-300))
+        res['ref32_err.' + k] = np.float64(e)
+        errs.append((e, k))
+    errs.sort(reverse=True)
+    print('   reference fp32 vs float64 evaluation of its own gradient: median %.2e, worst %s' % (errs[len(errs) // 2][0], errs[:5]))
+    res.update({k: (v.float() if torch.is_tensor(v) else v) for k, v in compact_grads_sized(named64).items()})       # fp32 storage: the yardstick is ~1e-2
+    for k, v in net.state_dict().items():
+        if 'running_' in k:
+            res['after.' + k] = v
+    res['none'] = np.array(none)
+    save('g20_full_grad', **res)
+
+
+def compact_grads_sized(named):
+    """compact_grads with the column step growing with the tensor: <= ~1024 sampled values per row block"""
+    res = {}
+    for k, g in named.items():
+        n = g.numel()
+        step = 16 if n <= (1 << 16) else 64 if n <= (1 << 20) else 512
+        res.update(compact_grads({k: g}, step=step))
+    return res
+
+
+GENS = {'full_grad': gen_full_grad, 'bone_grad': gen_bone_grad, 'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 
 if __name__ == '__main__':

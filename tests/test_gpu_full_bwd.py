@@ -1,0 +1,91 @@
+"""The whole training step's gradient on the GPU (dir_amd/train/net.py: DIR.forward in training mode + the gradient of the summed objective
+w.r.t. all 556 trained parameters, every arithmetic step a libdir_hip.so kernel) against
+  G8   the reference's own training-mode DIR.forward: predictions and the 42 loss terms, and
+  G20  `sum(loss.values()).backward()` through the reference's DIR (train.py:66-68) on the same input, evaluated in float64 (compact
+       form), the parameters torch leaves without gradient, the BatchNorm running statistics after the pass, and -- per parameter --
+       how far the reference's OWN fp32 evaluation of that gradient is from the float64 one.
+With synthetic random weights the network is badly conditioned (seg logits ~ 1e5; every training-mode BatchNorm backward cancels most of
+its input): the reference's fp32 gradient is only good to a median 1.3e-2 of each tensor's maximum.  That noise is the yardstick here:
+any wiring error shows up as O(1) (a dangling table pointer did: 180 %), while each component is pinned to 1e-5 .. 1e-6 on
+well-conditioned data by its own test (G13-G19).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dir_amd import synth
+from dir_amd.train import net as TN
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+HERE = os.path.dirname(os.path.abspath(__file__))
+ZERO = ('conv1.conv.bias', 'conv2.conv.bias', 'fusion.0.bias', 'attention_left.0.bias', 'attention_right.0.bias', 'seg.0.bias', 'dense.0.bias',
+        'filters.0.bias', 'pos_emb_left.0.bias', 'pos_emb_right.0.bias', 'global_pos_emb.0.bias', 'proj_feat_emb.0.bias', 'gconv.bias', 'gconv.e_0')
+
+
+def test_full_training_step_gradient_vs_reference(golden):
+    from conftest import loss_case
+    g8, g20 = golden('g8_loss'), golden('g20_full_grad')
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if 'num_batches' not in k}
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+    keep = []
+    outs, ctx = TN.forward(P, img, keep)
+    # ---- forward: the reference's training-mode predictions and loss terms (G8)
+    worst_f = 0.0
+    for i in range(3):
+        for k in ('pd_joint_uv_', 'pd_mesh_uv_', 'pd_joint_xyz_', 'pd_mesh_xyz_'):
+            for s in ('left', 'right'):
+                ref = g8['s%d.%s%s' % (i, k, s)]
+                worst_f = max(worst_f, float(np.abs(outs[i][k + s].cpu().numpy() - ref).max()))
+    assert worst_f < 2e-5, worst_f
+    assert np.abs(outs[3]['seg'].cpu().numpy() - g8['seg']).max() < 2e-4 * np.abs(g8['seg']).max()
+    loss = TN.losses(outs, target, meta, fc)
+    assert len(loss) == 42
+    for k, v in loss.items():
+        assert abs(float(v) - float(g8['loss.' + k])) < 5e-5 * max(1.0, abs(float(g8['loss.' + k]))), k
+    total = sum(float(v) for v in loss.values())
+    assert abs(total - float(g20['total'])) < 5e-5 * abs(float(g20['total']))
+    # ---- backward
+    G = TN.backward(P, ctx, outs, target, meta, fc)
+    none = set(str(k) for k in g20['none'])
+    trained = {k for k in shapes if not any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight')) and k not in none}
+    assert set(G) == trained, (sorted(trained - set(G))[:8], sorted(set(G) - trained)[:8])
+    errs, ratio = [], []
+    for k, v in G.items():
+        if any(k.endswith(z) for z in ZERO):
+            continue
+        a = v.cpu().numpy().astype(np.float64)
+        while a.ndim > 2 and a.shape[-1] == 1:
+            a = a[..., 0]
+        if 'grad.' + k in g20:
+            ref = g20['grad.' + k]
+            e = np.abs(a.reshape(ref.shape) - ref).max() / (np.abs(ref).max() + 1e-30)
+        else:
+            a2 = a.reshape(a.shape[0], -1) if (a.ndim == 4 and a.shape[-1] <= 7) else a.reshape(-1, a.shape[-1])
+            ck = [q for q in g20 if q.startswith('grad.' + k + '.cols')][0]
+            e = np.abs(a2[:, ::int(ck.rsplit('.cols', 1)[1])] - g20[ck]).max() / (np.abs(g20[ck]).max() + 1e-30)
+        r = float(g20['ref32_err.' + k])
+        errs.append(float(e)); ratio.append((float(e) / (r + 2e-5), k, float(e), r))
+        assert e < 25 * r + 5e-4, (k, float(e), r)        # within the reference's own fp32 evaluation noise of this tensor
+    med_ours, med_ref = float(np.median(errs)), float(np.median([float(g20[k]) for k in g20 if k.startswith('ref32_err.')]))
+    assert med_ours < 2 * med_ref, (med_ours, med_ref)
+    ratio.sort(reverse=True)
+    worst = ratio[0]
+    for k in g20:
+        if k.startswith('after.'):
+            e = float(np.abs(P[k[6:]].cpu().numpy() - g20[k]).max())
+            assert e < 1e-4 * max(1.0, float(np.abs(g20[k]).max())), (k, e)        # batch variances of K = 18 432 fp32 sums
+    print('full training step: %d parameter gradients; median error vs the float64 reference gradient %.2e (the reference\'s own fp32: %.2e); '
+          'largest ratio to the reference noise %.1f (%s: %.2e vs %.2e); forward worst %.2e' % (len(G), med_ours, med_ref, worst[0], worst[1], worst[2], worst[3], worst_f))
