@@ -44,3 +44,20 @@ def token_stage_train_step(named_params, prefix, mano_tables_lr, feat_nhwc, prev
     D.average_gradients(optimizer.flat_grad)
     optimizer.step()
     return out, g_feat
+
+
+def train_step(named_params, buffers, img, target, meta_info, faces, optimizer):
+    """One optimisation step of the whole network (train.py:64-70: zero_grad, forward, sum(loss).backward(), optimizer.step):
+    named_params {DIR state-dict key -> nn.Parameter registered with `optimizer` (FlatAdamW)}, buffers {key -> tensor} (BatchNorm running
+    statistics -- updated in place --, MANO tables).  Returns the 42 loss terms."""
+    from . import net as TN
+    P = {k: v.data for k, v in named_params.items()}
+    P.update(buffers)
+    outs, ctx = TN.forward(P, img)
+    loss = TN.losses(outs, target, meta_info, faces)
+    G = TN.backward(P, ctx, outs, target, meta_info, faces)
+    optimizer.zero_grad()
+    add_grads(named_params, '', G)
+    D.average_gradients(optimizer.flat_grad)
+    optimizer.step()
+    return loss

@@ -89,3 +89,39 @@ def test_full_training_step_gradient_vs_reference(golden):
             assert e < 1e-4 * max(1.0, float(np.abs(g20[k]).max())), (k, e)        # batch variances of K = 18 432 fp32 sums
     print('full training step: %d parameter gradients; median error vs the float64 reference gradient %.2e (the reference\'s own fp32: %.2e); '
           'largest ratio to the reference noise %.1f (%s: %.2e vs %.2e); forward worst %.2e' % (len(G), med_ours, med_ref, worst[0], worst[1], worst[2], worst[3], worst_f))
+
+
+def test_whole_network_train_steps_reduce_the_objective():
+    """three optimisation steps through dir_amd.train.step.train_step (forward, backward, flat gradient bucket, one AdamW launch): the summed
+    objective of the SAME batch goes down, the parameters torch would leave untouched stay put, every other parameter moves"""
+    from conftest import loss_case
+    from dir_amd.optim import FlatAdamW
+    from dir_amd.train import step as TSTEP
+    g8 = dict(np.load(os.path.join(HERE, 'golden', 'g8_loss.npz')))
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+    is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
+    params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
+    buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
+    opt = FlatAdamW(list(params.values()), lr=2e-5)
+    dead = [p for k, p in params.items() if k.startswith('backbone.fc.') or '.interaction.STEblocks.0.' in k]
+    opt.set_inactive(dead)
+    before = {k: p.detach().clone() for k, p in params.items()}
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+    totals = []
+    for _ in range(3):
+        loss = TSTEP.train_step(params, buffers, img, target, meta, fc, opt)
+        totals.append(sum(float(v) for v in loss.values()))
+    assert abs(totals[0] - sum(float(g8[k]) for k in g8 if k.startswith('loss.'))) < 1e-3 * totals[0]       # step 0 is evaluated at the golden weights
+    assert totals[2] < totals[1] < totals[0], totals
+    moved = sum(int(not torch.equal(p.detach(), before[k])) for k, p in params.items())
+    assert moved == len(params) - len(dead)
+    assert all(torch.equal(p.detach(), before[k]) for k, p in params.items() if any(p is d for d in dead))
+    print('whole-network training steps: objective %s, %d parameter tensors updated' % (' -> '.join('%.4f' % t for t in totals), moved))
