@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 23          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 24          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16 = 0, 1
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -156,7 +156,8 @@ _SIGNATURES = {
     'dir_mano_backward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     'dir_regress_backward': (C.c_int, [_p] * 17 + [_i, _p]),
     'dir_gemm_f32': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p]),
-    'dir_colsum_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _p]),
+    'dir_colsum_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_colsum_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_layernorm_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _p]),
     'dir_layernorm_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     'dir_gelu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),

@@ -38,7 +38,9 @@ def colsum(x, out=None, accumulate=False):
     R, N = x.shape
     if out is None:
         out = torch.empty(N, device=x.device, dtype=F32)
-    _capi.check(_capi.lib().dir_colsum_f32(_capi.ptr(x), _capi.ptr(out), R, N, N, int(accumulate), _capi.stream_ptr()), 'dir_colsum_f32')
+    n = _capi.lib().dir_colsum_workspace_bytes(R, N)
+    ws = torch.empty(n // 4, device=x.device) if n > 0 else None
+    _capi.check(_capi.lib().dir_colsum_f32(_capi.ptr(x), _capi.ptr(out), R, N, N, int(accumulate), _capi.ptr(ws), n, _capi.stream_ptr()), 'dir_colsum_f32')
     return out
 
 

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 23
+#define DIR_ABI_VERSION 24
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -130,8 +130,10 @@ typedef struct dir_gemm_desc {
     int64_t stride_a, stride_b, stride_c;
 } dir_gemm_desc;
 int dir_gemm_f32(const dir_gemm_desc* desc_host, const float* A, const float* B, const float* bias, float* C, void* stream);
-/* out[n] (+)= sum_r x[r][n]: bias gradients */
-int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, int accumulate, void* stream);
+/* out[n] (+)= sum_r x[r][n]: bias gradients.  R > 512: 1024-row chunk partials added in chunk order; workspace of
+ * dir_colsum_workspace_bytes(R, N) bytes (0 for R <= 512). */
+long long dir_colsum_workspace_bytes(int R, int N);
+int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, int accumulate, float* workspace, long long workspace_bytes, void* stream);
 /* nn.LayerNorm over the last dimension of x [R][C] (C <= 256); mean / rstd [R] are saved for the backward */
 int dir_layernorm_forward(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int R, int C, float eps, void* stream);
 int dir_layernorm_backward(const float* gy, const float* x, const float* w, const float* mean, const float* rstd, float* gx, float* gw,
@@ -145,7 +147,7 @@ int dir_attention_forward(const float* qkv, float* probs, float* out, int B, int
 int dir_attention_backward(const float* qkv, const float* probs, const float* gout, float* gqkv, int B, int T, int H, float scale, void* stream);
 /* BatchNorm in TRAINING mode over x [R][C] with row stride ld (channels last: R = samples x positions): batch mean and biased
  * variance, y = (x - mean) * rstd * w + b, running statistics updated with `momentum` and the unbiased variance (torch semantics);
- * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional).  R <= 2048 (the token path): one
+ * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional).  R <= 512: one
  * thread per channel walks the rows in order, no workspace.  Larger R (BatchNorm2d over feature maps): the column reductions are cut
  * into 1024-row chunks whose partials are added in chunk order (deterministic); workspace of dir_bn_train_workspace_bytes(R, C). */
 long long dir_bn_train_workspace_bytes(int R, int C);

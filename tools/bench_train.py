@@ -1,0 +1,52 @@
+"""Time of one whole-network training step (dir_amd.train.step.train_step: training-mode forward, 42-term objective, backward, flat gradient
+bucket, AdamW) at BASELINE config 3's per-GPU batch (32), synthetic data, 1 GPU.  This path is correctness-first (not tuned); the number is a
+baseline for the rounds that tune it.  usage: bench_train.py [batch] [steps]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dir_amd import _capi, synth  # noqa: E402
+from dir_amd.optim import FlatAdamW  # noqa: E402
+from dir_amd.train import step as TSTEP  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
+    shapes = {k: tuple(v) for k, v in json.load(f).items()}
+sd = synth.synth_state_dict(shapes, 1234)
+is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
+params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
+buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
+opt = FlatAdamW(list(params.values()), lr=1e-5)
+opt.set_inactive([p for k, p in params.items() if k.startswith('backbone.fc.') or '.interaction.STEblocks.0.' in k])
+rng = np.random.RandomState(0)
+dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+img = dv(synth.synth_input('train.img', (B, 3, 256, 256), 1234))
+target, meta = {}, {}
+for s in ('left', 'right'):
+    target['joint_2d_' + s] = dv(rng.uniform(-1, 1, (B, 21, 3)).astype(np.float32))
+    target['mesh_2d_' + s] = dv(rng.uniform(-1, 1, (B, 778, 3)).astype(np.float32))
+    target['joint_3d_' + s] = dv(rng.normal(0, 0.05, (B, 21, 3)).astype(np.float32))
+    target['mesh_3d_' + s] = dv(rng.normal(0, 0.05, (B, 778, 3)).astype(np.float32))
+    meta['center_' + s] = dv(rng.normal(0, 0.1, (B, 1, 3)).astype(np.float32))
+target['seg'] = dv(rng.randint(0, 3, (B, 1, 256, 256)).astype(np.float32))
+target['dense'] = dv(rng.rand(B, 3, 256, 256).astype(np.float32))
+faces = tuple(dv(synth.loss_faces(s, 1234).astype(np.int64)) for s in ('left', 'right'))
+times, totals = [], []
+for i in range(steps + 1):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _capi.PROFILE = [] if i == steps else None
+    loss = TSTEP.train_step(params, buffers, img, target, meta, faces, opt)
+    torch.cuda.synchronize()
+    times.append(time.time() - t0)
+    totals.append(sum(float(v) for v in loss.values()))
+prof, _capi.PROFILE = _capi.PROFILE, None
+print('batch %d: train step %s s (first includes allocator warm-up); objective %s' % (B, ' '.join('%.3f' % t for t in times), ' -> '.join('%.3f' % t for t in totals)))
+print('peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 2 ** 30))
