@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, cons
 // Large R (BatchNorm2d over feature maps: R = B*H*W up to 10^6 rows): the column reductions are cut into row chunks -- a workgroup =
 // 64 channels x 4 row lanes over one chunk, lanes combined in a fixed order -- and a per-channel finalise adds the chunk partials in
 // chunk order: deterministic, no atomics.  Same formulas as the one-thread-per-channel kernels above (two-pass variance).
-constexpr int BN_CHUNK_ROWS = 1024, BN_SMALL_R = 512;
+constexpr int BN_CHUNK_ROWS = 256, BN_SMALL_R = 512;
 // mode 0: p1 = sum x | mode 1: p1 = sum (x - mu)^2 | mode 2: p1 = sum gy, p2 = sum gy (x - mu) rs
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const float* gy, const float* mu, const float* rs, float* p1, float* p2,
                                                         int R, int C, int ld, int mode) {
@@ -561,7 +561,7 @@ extern "C" int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, 
         DIR_LAUNCH(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x, out, R, N, ld, accumulate);
         return check_launch("dir_colsum_f32");
     }
-    // tall matrices (bias gradients of the convolutions: R = B*Ho*Wo): 1024-row chunk partials, added in chunk order
+    // tall matrices (bias gradients of the convolutions: R = B*Ho*Wo): 256-row chunk partials, added in chunk order
     DIR_REQUIRE(workspace && workspace_bytes >= dir_colsum_workspace_bytes(R, N), "dir_colsum_f32: workspace too small (dir_colsum_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     DIR_LAUNCH(bn_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace,

@@ -130,7 +130,7 @@ typedef struct dir_gemm_desc {
     int64_t stride_a, stride_b, stride_c;
 } dir_gemm_desc;
 int dir_gemm_f32(const dir_gemm_desc* desc_host, const float* A, const float* B, const float* bias, float* C, void* stream);
-/* out[n] (+)= sum_r x[r][n]: bias gradients.  R > 512: 1024-row chunk partials added in chunk order; workspace of
+/* out[n] (+)= sum_r x[r][n]: bias gradients.  R > 512: 256-row chunk partials added in chunk order; workspace of
  * dir_colsum_workspace_bytes(R, N) bytes (0 for R <= 512). */
 long long dir_colsum_workspace_bytes(int R, int N);
 int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, int accumulate, float* workspace, long long workspace_bytes, void* stream);
@@ -149,7 +149,7 @@ int dir_attention_backward(const float* qkv, const float* probs, const float* go
  * variance, y = (x - mean) * rstd * w + b, running statistics updated with `momentum` and the unbiased variance (torch semantics);
  * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional).  R <= 512: one
  * thread per channel walks the rows in order, no workspace.  Larger R (BatchNorm2d over feature maps): the column reductions are cut
- * into 1024-row chunks whose partials are added in chunk order (deterministic); workspace of dir_bn_train_workspace_bytes(R, C). */
+ * into 256-row chunks whose partials are added in chunk order (deterministic); workspace of dir_bn_train_workspace_bytes(R, C). */
 long long dir_bn_train_workspace_bytes(int R, int C);
 int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
                          float* running_var, int R, int C, int ld, float eps, float momentum, float* workspace, long long workspace_bytes,
