@@ -132,6 +132,28 @@ class FusionJointInterIterDecoder(nn.Module):
         self.seg, self.dense = head(), head()
 
 
+class _TrainObjective(torch.autograd.Function):
+    """the whole training-mode forward + objective as ONE autograd node over the parameters: forward = dir_amd.train.net.forward + losses,
+    backward = dir_amd.train.net.backward with the upstream gradient of each of the 42 terms"""
+    @staticmethod
+    def forward(ctx, box, img, target, meta_info, faces, buffers, keys, *params):
+        from ..train import net as TN
+        P = {k: p.detach() for k, p in zip(keys, params)}
+        P.update(buffers)
+        outs, c = TN.forward(P, img)
+        loss = TN.losses(outs, target, meta_info, faces)
+        ctx.saved = (P, c, outs, target, meta_info, faces, keys, list(loss))
+        box['outs'], box['keys'] = outs, list(loss)
+        return torch.stack([loss[k].reshape(()) for k in loss])
+
+    @staticmethod
+    def backward(ctx, g_vec):
+        from ..train import net as TN
+        P, c, outs, target, meta_info, faces, keys, lkeys = ctx.saved
+        G = TN.backward(P, c, outs, target, meta_info, faces, grad_out={k: g_vec[i] for i, k in enumerate(lkeys)})
+        return (None,) * 7 + tuple(G.get(k) for k in keys)
+
+
 class DIR(nn.Module):
     def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16):
         super().__init__()
@@ -188,11 +210,34 @@ class DIR(nn.Module):
         crit = DirLoss(self.init_regressor.mano_layer_left.th_faces, self.init_regressor.mano_layer_right.th_faces)
         return crit(outs_list[:3], outs_list[3], target, meta_info)
 
+    def _forward_train(self, input, target, meta_info):
+        """Training mode (train.py:66-68 runs `outs_list, loss = model(inputs, targets, meta_infos); sum(loss[k] ...).backward()`): the
+        fp32 training forward of dir_amd/train/net.py (batch-statistics BatchNorm, running statistics updated) and the 42 loss terms as
+        0-d tensors attached to the parameters through one autograd node whose backward is dir_amd.train.net.backward -- `.backward()`
+        on any combination of the terms fills `.grad` of every trained parameter like the reference does."""
+        from ..train import net as TN
+        x = _capi.f32c(input['img'].cuda())
+        named = [(k, p) for k, p in self.named_parameters()]
+        buffers = {k: b for k, b in self.named_buffers() if 'num_batches_tracked' not in k}
+        faces = (self.init_regressor.mano_layer_left.th_faces, self.init_regressor.mano_layer_right.th_faces)
+        box = {}
+        vec = _TrainObjective.apply(box, x, target, meta_info, faces, buffers, [k for k, _ in named], *[p for _, p in named])
+        with torch.no_grad():
+            for k, b in self.named_buffers():
+                if k.endswith('num_batches_tracked'):
+                    b += 1                                          # nn.BatchNorm bookkeeping (momentum is not None: unused by the maths)
+        loss = {k: vec[i] for i, k in enumerate(box['keys'])}
+        outs = box['outs']
+        outs_list = [{k: o.get(k) for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left',
+                                             'pd_joint_xyz_right', 'pd_offset')} for o in outs[:3]]
+        for o, d in zip(outs[:3], outs_list):
+            d['pd_proj_left'], d['pd_proj_right'], d['pd_rel_joint'] = o['pd_mano_para_left'][:, 61:], o['pd_mano_para_right'][:, 61:], None
+        outs_list.append({'dense': outs[3]['dense'], 'seg': outs[3]['seg'], 'proj_feat': None})
+        return outs_list, loss
+
     def forward(self, input, target, meta_info):
         if self.training:
-            raise NotImplementedError('dir_amd implements DIR.forward in eval mode (inference hot path): training-mode '
-                                      'BatchNorm and the backward pass are not built -- call .eval(); the loss block of '
-                                      'models/dir.py:542-594 is available as forward values, see DIR.objective()')
+            return self._forward_train(input, target, meta_info)
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()
         with torch.cuda.device(x.device), torch.no_grad():

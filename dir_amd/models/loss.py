@@ -7,8 +7,8 @@
   stage_losses          models/dir.py:571-592   one dir_stage_losses_forward launch pair per stage (13 terms)
   dense_losses          models/dir.py:562-569   dir_dense_losses_forward (interpolate + CE + SmoothL1 + Lovasz)
 The modules behind them in the reference: models/loss.py (SmoothL1Loss, EdgeLengthLoss, NormalVectorLoss),
-models/lovasz_loss.py (lovasz_softmax).  Forward only: there is no backward pass in this build, the values serve validation-loss
-monitoring and as the pinned target for the training work.
+models/lovasz_loss.py (lovasz_softmax).  Their gradients w.r.t. the predictions: stage_loss_grads / dense_loss_grads below (dir_stage_losses_backward,
+dir_dense_losses_backward); the network behind the predictions: dir_amd/train/.
 """
 import ctypes as C
 

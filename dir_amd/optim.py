@@ -8,7 +8,8 @@
 The parameters are moved into ONE contiguous fp32 buffer (each tensor becomes a view of it), gradients into a second one
 (`.grad` of each parameter is a view), the two Adam moments are flat as well: `step()` is a single dir_adamw_step launch over
 all of them, and `flat_grad` is the bucket a data-parallel all-reduce would reduce in one call.
-There is no backward pass in this build: the caller fills the gradient views.
+The gradient views are filled by dir_amd.train (train/step.py::train_step, or `.backward()` on the losses of the mirror DIR in
+training mode).
 """
 import math
 

@@ -172,12 +172,24 @@ def losses(outs, target, meta_info, faces):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------- backward
-def backward(P, ctx, outs, target, meta_info, faces):
-    """gradient of sum(loss) (all 42 terms with weight 1, train.py:68) -> {parameter key: gradient}"""
+def _term_weights(grad_out):
+    """grad_out: None (every term weight 1: `sum(loss.values()).backward()`, train.py:68) or {loss key: 0-d tensor / float} -- the upstream
+    gradient of each of the 42 terms -> (dense 3-vector or None, [three 13-vectors or None])"""
+    if grad_out is None:
+        return None, [None, None, None]
+    dev = next(v for v in grad_out.values() if torch.is_tensor(v)).device
+    f = lambda k: (grad_out[k].to(dev).float().reshape(()) if k in grad_out and grad_out[k] is not None else torch.zeros((), device=dev))  # noqa: E731
+    dense = torch.stack([f('seg'), f('dense'), f('lovasz')])
+    return dense, [torch.stack([f('%s_%d' % (k, i)) for k in L.STAGE_KEYS]) for i in range(3)]
+
+
+def backward(P, ctx, outs, target, meta_info, faces, grad_out=None):
+    """gradient of sum_k grad_out[k] * loss[k] (grad_out None: all 42 terms with weight 1, train.py:68) -> {parameter key: gradient}"""
     G = {}
+    w_dense, w_stage = _term_weights(grad_out)
     B = ctx['img'].shape[0]
     c1, c2, c3, c4 = ctx['feats']
-    g_seg, g_dense = L.dense_loss_grads(outs[3]['seg'], outs[3]['dense'], target['seg'], target['dense'])
+    g_seg, g_dense = L.dense_loss_grads(outs[3]['seg'], outs[3]['dense'], target['seg'], target['dense'], grad_out=w_dense)
     g_feat = _cbr_backward(P, 'decoder.seg.', ctx['seg'], g_seg.permute(0, 2, 3, 1).contiguous(), G)
     O.axpy(g_feat, _cbr_backward(P, 'decoder.dense.', ctx['dense'], g_dense.permute(0, 2, 3, 1).contiguous(), G))
     g_lo = _cbr_backward(P, 'decoder.conv_final.', ctx['final'], g_feat, G)                      # gradient of enhance_layer3's output
@@ -190,7 +202,7 @@ def backward(P, ctx, outs, target, meta_info, faces):
         put(G, 'decoder.enhance_layer%s.' % tag, g)
         g_fusion = g_enh_in[..., :256].contiguous()
         g_tok, gul, gur = _stage_image_backward(P, pre, d['img'], g_enh_in[..., 256:].contiguous(), G)
-        cot = L.stage_loss_grads(outs[si + 1], target, meta_info, faces)
+        cot = L.stage_loss_grads(outs[si + 1], target, meta_info, faces, grad_out=w_stage[si + 1])
         O.axpy(cot['pd_joint_uv_left'], gul)                                                     # bone_proj reads the stage's own (not detached) uv
         O.axpy(cot['pd_joint_uv_right'], gur)
         g_samp, g = TS.stage_tokens_backward(sub(P, pre), d['tabs'], d['tok'], cot, g_joint_feat=g_tok)
@@ -205,7 +217,7 @@ def backward(P, ctx, outs, target, meta_info, faces):
     g_c4 = g_lo
     # ---- InitRegressor
     ci = ctx['init']
-    cot = L.stage_loss_grads(outs[0], target, meta_info, faces)
+    cot = L.stage_loss_grads(outs[0], target, meta_info, faces, grad_out=w_stage[0])
     from .. import functional as F
     g_para = F.mano_backward(list(ci['tabs']), ci['para'], g_verts=[cot['pd_mesh_xyz_' + s] for s in SIDES], g_joints=[cot['pd_joint_xyz_' + s] for s in SIDES],
                              g_joint_uv=[cot['pd_joint_uv_' + s] for s in SIDES], g_mesh_uv=[cot['pd_mesh_uv_' + s] for s in SIDES])

@@ -5,7 +5,7 @@ SURVEY.md 8e), and one training step of a refinement stage's token half is compo
     stage_tokens_forward -> dir_stage_losses_backward (the 13 loss terms' gradients w.r.t. the predictions, models/dir.py:543-591)
     -> stage_tokens_backward -> add_grads -> [average_gradients] -> FlatAdamW.step            (train.py:62-70 for this part of the net)
 
-The image half (backbone, decoder convolutions, bone_proj, fusion) has no backward yet: its parameters receive no gradient here.
+token_stage_train_step covers the token half of one stage (image-half parameters receive no gradient there); train_step the whole network.
 """
 import torch
 

@@ -561,8 +561,8 @@ int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const void* y2, 
                                 long long M, void* stream);
 
 /* a13 / 8f rank 2, forward half: the training objective, models/dir.py:542-594 (SmoothL1Loss models/loss.py:63-93, EdgeLengthLoss
- * :36-60, NormalVectorLoss :6-33, nn.CrossEntropyLoss(weight), lovasz_softmax models/lovasz_loss.py:155-202).  Forward values
- * only (the backward pass is not built).  All tensors fp32, device pointers, index 0 = left hand, 1 = right hand. */
+ * :36-60, NormalVectorLoss :6-33, nn.CrossEntropyLoss(weight), lovasz_softmax models/lovasz_loss.py:155-202).  Forward values;
+ * the gradients w.r.t. the predictions are dir_stage_losses_backward / dir_dense_losses_backward below.  All tensors fp32, device pointers, index 0 = left hand, 1 = right hand. */
 typedef struct dir_loss_pred {      /* one entry of iter_outs (models/dir.py:519,571) */
     const float* joint_uv[2];       /* pd_joint_uv_*  [B,21,2] */
     const float* mesh_uv[2];        /* pd_mesh_uv_*   [B,778,2] (dir_mano_forward's optional output), or NULL: then computed here */

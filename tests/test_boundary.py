@@ -75,12 +75,14 @@ def test_next_row_call_signatures():
     assert list(layer.state_dict().keys()) == ['hands_components', 'hands_components_inv']      # the persistent buffers
 
 
-def test_eval_only_and_gpu_only():
-    from dir_amd import _capi
+def test_gpu_only_in_both_modes():
+    """no CPU fallback: eval and training mode alike refuse to run without the GPU (the reference calls .cuda() itself, models/dir.py:514)"""
     from dir_amd.models.dir import DIR
     net = DIR(21, 'unused', 0)
-    with pytest.raises(NotImplementedError):
-        net.train()({'img': torch.zeros(1, 3, 256, 256)}, None, None)
+    for mode in (net.train, net.eval):
+        with pytest.raises((RuntimeError, AssertionError, Exception)) as e:
+            mode()({'img': torch.zeros(1, 3, 256, 256)}, None, None)
+        assert not isinstance(e.value, NotImplementedError)
 
 
 def test_csr_adjacency_constants_match_edge_order(golden):

@@ -125,3 +125,57 @@ def test_whole_network_train_steps_reduce_the_objective():
     assert moved == len(params) - len(dead)
     assert all(torch.equal(p.detach(), before[k]) for k, p in params.items() if any(p is d for d in dead))
     print('whole-network training steps: objective %s, %d parameter tensors updated' % (' -> '.join('%.4f' % t for t in totals), moved))
+
+
+def test_mirror_module_runs_the_reference_training_lines(golden):
+    """train.py:64-70 verbatim on the mirror: model.train(); optimizer.zero_grad(); outs_list, loss = model(inputs, targets, meta_infos);
+    sum(loss[k] for k in loss).backward(); optimizer.step() -- with a stock torch.optim.AdamW.  The 42 terms equal G8, the parameter
+    gradients are those of dir_amd.train.net.backward (same kernels: bit for bit), parameters without gradient keep .grad None, the
+    BatchNorm buffers advance, and the eval-mode engine re-packs the updated weights."""
+    from conftest import loss_case
+    from dir_amd.models.dir import DIR
+    g8 = golden('g8_loss')
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+    net = DIR(21, 'unused', 0)
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=True)
+    net = net.cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    for m, f in zip((net.init_regressor.mano_layer_left, net.init_regressor.mano_layer_right), faces):     # non-degenerate triangles, as in G8
+        m.th_faces.copy_(torch.from_numpy(f.astype(np.int64)).to(m.th_faces.dtype))
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED))
+    target = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in gt.items() if 'center' not in k}       # CPU tensors, like a DataLoader's
+    target.update(seg=torch.from_numpy(gt_seg), dense=torch.from_numpy(gt_dense))
+    meta = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in gt.items() if 'center' in k}
+    # reference gradients through the functional path on copies of the same tensors
+    P = {k: v.detach().clone() for k, v in net.state_dict().items() if 'num_batches' not in k}
+    outs0, ctx0 = TN.forward(P, img.cuda())
+    dv = lambda a: a.cuda()  # noqa: E731
+    fc = tuple(m.th_faces for m in (net.init_regressor.mano_layer_left, net.init_regressor.mano_layer_right))
+    G0 = TN.backward(P, ctx0, outs0, {k: dv(v) for k, v in target.items()}, {k: dv(v) for k, v in meta.items()}, fc)
+    optimizer = torch.optim.AdamW([{'params': net.parameters(), 'initial_lr': 1e-5}], lr=1e-5)              # train.py:227
+    net.train()
+    rm_before = net.backbone.bn1.running_mean.clone()
+    optimizer.zero_grad()
+    outs_list, loss = net({'img': img}, target, meta)
+    assert len(loss) == 42 and len(outs_list) == 4
+    for k, v in loss.items():
+        assert abs(float(v) - float(g8['loss.' + k])) < 5e-5 * max(1.0, abs(float(g8['loss.' + k]))), k
+    sum(loss[k] for k in loss).backward()
+    n_grad = 0
+    for k, p in net.named_parameters():
+        if k in G0:
+            assert p.grad is not None and torch.equal(p.grad, G0[k].reshape(p.shape)), k
+            n_grad += 1
+        else:
+            assert p.grad is None, k
+    assert n_grad == 556
+    assert not torch.equal(net.backbone.bn1.running_mean, rm_before) and int(net.backbone.bn1.num_batches_tracked) == 1
+    w_before = net.decoder.conv_final[0].weight.detach().clone()
+    optimizer.step()
+    assert not torch.equal(net.decoder.conv_final[0].weight.detach(), w_before)
+    net.eval()
+    with torch.no_grad():
+        outs_eval, _ = net({'img': img}, None, None)
+    assert torch.isfinite(outs_eval[2]['pd_mesh_xyz_left']).all()

@@ -131,7 +131,8 @@ def test_token_stage_train_step_feeds_flat_adamw():
         if 'decoder.projecter_4.' + k not in named:
             named['decoder.projecter_4.' + k] = v.clone()                      # buffers (running statistics, MANO tables)
     opt = FlatAdamW(list(params.values()), lr=1e-4)
-    # the image half (proj_feat_emb, fusion) has no backward yet: kept out of this step, like parameters torch leaves with grad None
+    # token_stage_train_step covers the token half only: the image half's parameters are kept out of this step, like parameters torch
+    # leaves with grad None (the whole network: dir_amd.train.step.train_step, tests/test_gpu_full_bwd.py)
     opt.set_inactive(TSTEP.inactive_parameters(params) + [p for k, p in params.items() if '.proj_feat_emb.' in k or '.fusion.' in k])
     before = {k: p.detach().clone() for k, p in params.items()}
     rng = np.random.RandomState(3)
