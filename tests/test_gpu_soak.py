@@ -1,0 +1,45 @@
+"""Foreign kernels beside a running forward (the 64x128 three-buffer-ring convolution tile once corrupted packed-FP32 instructions
+of OTHER kernels resident on the same CU; that tile is no longer selected unless DIR_RING_64x128=1).  A torch fused-multiply-add kernel --
+compiled by someone else, free to use v_pk_fma_f32 -- runs on a second stream while forwards replay on the slot's stream: both sides
+must reproduce their stand-alone results bit for bit, every round."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dir_amd import synth
+from dir_amd.engine import DirEngine, ForwardPipeline
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides():
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
+    eng = DirEngine(sd, dtype=torch.bfloat16)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    img = torch.randn(64, 3, 256, 256, device='cuda', generator=gen)
+    pipe = ForwardPipeline(eng, [img])
+    pipe.launch(0)
+    o = pipe.wait(0)
+    keys = ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset')
+    ref = [o[s][k].clone() for s in range(3) for k in keys] + [o[3]['seg'].clone()]
+    a, b, c = (torch.randn(1 << 24, device='cuda', generator=gen) for _ in range(3))
+    want = torch.addcmul(c, a, b)                       # a * b + c: one fused multiply-add per element
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rnd in range(8):
+        pipe.launch(0)
+        outs = []
+        with torch.cuda.stream(side):
+            for _ in range(40):                          # ~ the duration of the forward
+                outs.append(torch.addcmul(c, a, b))
+        o = pipe.wait(0)
+        side.synchronize()
+        got = [o[s][k] for s in range(3) for k in keys] + [o[3]['seg']]
+        assert all(torch.equal(x, y) for x, y in zip(got, ref)), 'forward changed beside a foreign kernel (round %d)' % rnd
+        assert all(torch.equal(x, want) for x in outs), 'foreign kernel corrupted beside the forward (round %d)' % rnd
