@@ -1,4 +1,6 @@
-"""Time of one whole-network training step (dir_amd.train.step.train_step: training-mode forward, 42-term objective, backward, flat gradient
+"""(Under `python -m torch.distributed.run --nproc-per-node N tools/bench_train.py`: one rank per GPU, each with its own synthetic batch,
+gradients averaged by dist.average_gradients over RCCL -- BASELINE config 3's data-parallel set-up; rank 0 prints the aggregate.)
+Time of one whole-network training step (dir_amd.train.step.train_step: training-mode forward, 42-term objective, backward, flat gradient
 bucket, AdamW) at BASELINE config 3's per-GPU batch (32), synthetic data, 1 GPU.  This path is correctness-first (not tuned); the number is a
 baseline for the rounds that tune it.  usage: bench_train.py [batch] [steps]"""
 import json
@@ -15,6 +17,10 @@ from dir_amd import _capi, synth  # noqa: E402
 from dir_amd.optim import FlatAdamW  # noqa: E402
 from dir_amd.train import step as TSTEP  # noqa: E402
 
+from dir_amd import dist as D  # noqa: E402
+local = int(os.environ.get('LOCAL_RANK', '0'))
+torch.cuda.set_device(local)
+rank, world, _ = D.init_from_env('nccl', torch.device('cuda', local))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
@@ -25,9 +31,9 @@ params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()
 buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
 opt = FlatAdamW(list(params.values()), lr=1e-5)
 opt.set_inactive([p for k, p in params.items() if k.startswith('backbone.fc.') or '.interaction.STEblocks.0.' in k])
-rng = np.random.RandomState(0)
+rng = np.random.RandomState(rank)
 dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-img = dv(synth.synth_input('train.img', (B, 3, 256, 256), 1234))
+img = dv(synth.synth_input('train.img.%d' % rank, (B, 3, 256, 256), 1234))
 target, meta = {}, {}
 for s in ('left', 'right'):
     target['joint_2d_' + s] = dv(rng.uniform(-1, 1, (B, 21, 3)).astype(np.float32))
@@ -48,5 +54,12 @@ for i in range(steps + 1):
     times.append(time.time() - t0)
     totals.append(sum(float(v) for v in loss.values()))
 prof, _capi.PROFILE = _capi.PROFILE, None
-print('batch %d: train step %s s (first includes allocator warm-up); objective %s' % (B, ' '.join('%.3f' % t for t in times), ' -> '.join('%.3f' % t for t in totals)))
-print('peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 2 ** 30))
+if rank == 0:
+    print('batch %d x %d rank(s): train step %s s (first includes allocator warm-up); objective on rank 0 %s; %.0f images/s aggregate'
+          % (B, world, ' '.join('%.3f' % t for t in times), ' -> '.join('%.3f' % t for t in totals), B * world / min(times)))
+    print('peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 2 ** 30))
+if world > 1:
+    flat = opt.flat_param.clone()
+    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.MAX)
+    assert torch.equal(flat, opt.flat_param), 'ranks diverged: the averaged gradients / AdamW steps are not identical across ranks'
+    torch.distributed.destroy_process_group()
