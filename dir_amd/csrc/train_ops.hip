@@ -309,6 +309,43 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const f
         if (mode == 2) p2[(long long)ch * C + c] = ((s2[0][cl] + s2[1][cl]) + s2[2][cl]) + s2[3][cl];
     }
 }
+// the same partial sums with 16-byte loads: 256 threads = 16 channel quads (64 channels) x 16 row lanes; lanes combined in order
+__global__ __launch_bounds__(256) void bn_partial4_kernel(const float* x, const float* gy, const float* mu, const float* rs, float* p1, float* p2,
+                                                         int R, int C, int ld, int mode) {
+    __shared__ float4 s1[16][16], s2[16][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 64 + cq * 4, ch = blockIdx.y;
+    const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (c < C) {
+        const float4 m = mode ? *reinterpret_cast<const float4*>(mu + c) : a;
+        const float4 k = mode == 2 ? *reinterpret_cast<const float4*>(rs + c) : a;
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long long)r * ld + c);
+            if (mode == 0) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+            else if (mode == 1) {
+                const float dx = v.x - m.x, dy = v.y - m.y, dz = v.z - m.z, dw = v.w - m.w;
+                a.x = fmaf(dx, dx, a.x); a.y = fmaf(dy, dy, a.y); a.z = fmaf(dz, dz, a.z); a.w = fmaf(dw, dw, a.w);
+            } else {
+                const float4 g = *reinterpret_cast<const float4*>(gy + (long long)r * ld + c);
+                a.x += g.x; a.y += g.y; a.z += g.z; a.w += g.w;
+                b.x = fmaf(g.x, (v.x - m.x) * k.x, b.x); b.y = fmaf(g.y, (v.y - m.y) * k.y, b.y);
+                b.z = fmaf(g.z, (v.z - m.z) * k.z, b.z); b.w = fmaf(g.w, (v.w - m.w) * k.w, b.w);
+            }
+        }
+    }
+    s1[rl][cq] = a; s2[rl][cq] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float4 t = s1[0][cq], u = s2[0][cq];
+        for (int l = 1; l < 16; ++l) {
+            const float4 q = s1[l][cq], w = s2[l][cq];
+            t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+            u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+        }
+        *reinterpret_cast<float4*>(p1 + (long long)ch * C + c) = t;
+        if (mode == 2) *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
+    }
+}
 __global__ __launch_bounds__(256) void bn_colsum_chunks_kernel(const float* p, float* out, int chunks, int C, float scale) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -538,6 +575,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
     gw[i] = s;
 }
 
+static void launch_bn_partial(dim3 grid, hipStream_t s, const float* x, const float* gy, const float* mu, const float* rs, float* p1, float* p2, int R, int C, int ld,
+                              int mode) {
+    const bool vec = C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && (!gy || ((uintptr_t)gy & 15) == 0) && ((uintptr_t)p1 & 15) == 0 &&
+                     (!p2 || ((uintptr_t)p2 & 15) == 0) && (!mu || ((uintptr_t)mu & 15) == 0) && (!rs || ((uintptr_t)rs & 15) == 0);
+    if (vec) DIR_LAUNCH(bn_partial4_kernel, grid, dim3(256), 0, s, x, gy, mu, rs, p1, p2, R, C, ld, mode);
+    else DIR_LAUNCH(bn_partial_kernel, grid, dim3(256), 0, s, x, gy, mu, rs, p1, p2, R, C, ld, mode);
+}
+
 }  // namespace
 
 extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, void* stream) {
@@ -564,8 +609,7 @@ extern "C" int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, 
     // tall matrices (bias gradients of the convolutions: R = B*Ho*Wo): 256-row chunk partials, added in chunk order
     DIR_REQUIRE(workspace && workspace_bytes >= dir_colsum_workspace_bytes(R, N), "dir_colsum_f32: workspace too small (dir_colsum_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
-    DIR_LAUNCH(bn_partial_kernel, dim3((N + 63) / 64, chunks), dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, workspace,
-               (float*)nullptr, R, N, ld, 0);
+    launch_bn_partial(dim3((N + 63) / 64, chunks), s, x, nullptr, nullptr, nullptr, workspace, nullptr, R, N, ld, 0);
     DIR_LAUNCH(wgrad_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, out, (long long)N, chunks, accumulate);
     return check_launch("dir_colsum_f32");
 }
@@ -635,9 +679,9 @@ extern "C" int dir_bn_train_forward(const float* x, const float* w, const float*
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* part = workspace;
     const dim3 pg((C + 63) / 64, chunks), cg((C + 255) / 256);
-    DIR_LAUNCH(bn_partial_kernel, pg, dim3(256), 0, s, x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, part, (float*)nullptr, R, C, ld, 0);
+    launch_bn_partial(pg, s, x, nullptr, nullptr, nullptr, part, nullptr, R, C, ld, 0);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)part, save_mean, chunks, C, 1.f / R);
-    DIR_LAUNCH(bn_partial_kernel, pg, dim3(256), 0, s, x, (const float*)nullptr, (const float*)save_mean, (const float*)nullptr, part, (float*)nullptr, R, C, ld, 1);
+    launch_bn_partial(pg, s, x, nullptr, save_mean, nullptr, part, nullptr, R, C, ld, 1);
     DIR_LAUNCH(bn_stats_finalize_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)save_mean, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
     const long long n = (long long)R * C;
     DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld);
@@ -656,7 +700,7 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* p1 = workspace; float* p2 = p1 + (long long)chunks * C; float* t1 = p2 + (long long)chunks * C; float* t2 = t1 + C;
     const dim3 pg((C + 63) / 64, chunks), cg((C + 255) / 256);
-    DIR_LAUNCH(bn_partial_kernel, pg, dim3(256), 0, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2);
+    launch_bn_partial(pg, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p1, t1, chunks, C, 1.f);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p2, t2, chunks, C, 1.f);
     if (gb && hipMemcpyAsync(gb, t1, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("dir_bn_train_backward: copy failed"); return DIR_E_LAUNCH; }
