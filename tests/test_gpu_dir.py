@@ -153,8 +153,10 @@ def test_dir_module_dropin(golden, dir_state):
     assert len(objective) == 42 and all(np.isfinite(float(v)) for v in objective.values())
     assert float(objective['mesh_left_xyz_2']) < 1e-6 and float(objective['edge_right_2']) < 1e-6       # targets == stage-2 predictions
     assert float(objective['mesh_left_xyz_0']) > float(objective['mesh_left_xyz_2'])
-    with pytest.raises(NotImplementedError):
-        net.train()({'img': img}, target, meta)
+    # training mode (train.py:66-68): the same 42 keys as tensors on an autograd node (tests/test_gpu_full_bwd.py pins the gradients)
+    outs_t, loss_t = net.train()({'img': img}, target, meta)
+    assert set(loss_t) == set(objective) and len(outs_t) == 4 and all(v.requires_grad for v in loss_t.values())
+    net.eval()
 
 
 def test_sparse_fusion_is_bit_identical(dir_state):
