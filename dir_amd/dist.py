@@ -84,10 +84,13 @@ def average_gradients(flat_grad, bucket_elems=64 << 20):
         return flat_grad
     world = dist.get_world_size()
     flat = flat_grad.view(-1)
-    works = [dist.all_reduce(flat[i:i + bucket_elems], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), bucket_elems)]
+    avg = dist.get_backend() == 'nccl'                    # RCCL averages inside the collective; gloo (CPU tests) sums, then one division
+    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    works = [dist.all_reduce(flat[i:i + bucket_elems], op=op, async_op=True) for i in range(0, flat.numel(), bucket_elems)]
     for w in works:
         w.wait()
-    flat.div_(world)
+    if not avg:
+        flat.div_(world)
     return flat_grad
 
 

@@ -16,3 +16,18 @@ def test_two_ranks_shard_and_gather_bit_identical(tmp_path):
     assert D.spawn_ranks([script, str(out)], 2, timeout=900) == 0
     got = json.loads(out.read_text())
     assert got == {'world': 2, 'bit_identical': True}
+
+
+@pytest.mark.gpu
+def test_two_rank_data_parallel_train_step(tmp_path):
+    """BASELINE config 3's set-up in small: two ranks, each its own batch, gradients averaged in FlatAdamW.flat_grad by
+    dist.average_gradients, one AdamW launch each.  (gloo group so that it also runs with both ranks on ONE GPU; RCCL on a multi-GPU node
+    is the same call.)  Both ranks end with bit-identical parameters; they equal a single process stepping on the hand-averaged
+    gradients of the two batches (AdamW's first step moves every weight by ~lr: agreement to a small fraction of that)."""
+    from dir_amd import dist as D
+    out = tmp_path / 'dp.json'
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'two_rank_train.py')
+    assert D.spawn_ranks([script, str(out)], 2, timeout=900) == 0
+    got = json.loads(out.read_text())
+    assert got['world'] == 2 and got['same_across_ranks'] is True
+    assert got['max_abs_diff_to_single_process'] < 0.02 * got['lr'], got
