@@ -134,19 +134,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_x_kernel(const float* gy, c
         if (c < C) { float* p = gx + (long long)row * C + c; const float v = rs * (gh[i] - s1 - xh[i] * s2); *p = accumulate ? *p + v : v; }
     }
 }
-// g w[c] = sum_rows g y x^ ; g b[c] = sum_rows g y : one thread per column, rows in order
+// g w[c] = sum_rows g y x^ ; g b[c] = sum_rows g y : a workgroup = 16 columns x 16 row lanes (lane l takes rows l, l + 16, ...), the lanes'
+// partial sums added in lane order (deterministic)
 __global__ __launch_bounds__(256) void layernorm_bwd_wb_kernel(const float* gy, const float* x, const float* mean, const float* rstd, float* gw, float* gb,
                                                               int R, int C, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float s_w[16][17], s_b[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     float aw = 0.f, ab = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float g = gy[(long long)r * C + c];
-        aw = fmaf(g, (x[(long long)r * C + c] - mean[r]) * rstd[r], aw);
-        ab += g;
+    if (c < C)
+        for (int r = rl; r < R; r += 16) {
+            const float g = gy[(long long)r * C + c];
+            aw = fmaf(g, (x[(long long)r * C + c] - mean[r]) * rstd[r], aw);
+            ab += g;
+        }
+    s_w[rl][cl] = aw; s_b[rl][cl] = ab;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float tw = 0.f, tb = 0.f;
+        for (int l = 0; l < 16; ++l) { tw += s_w[l][cl]; tb += s_b[l][cl]; }
+        gw[c] = accumulate ? gw[c] + tw : tw;
+        gb[c] = accumulate ? gb[c] + tb : tb;
     }
-    gw[c] = accumulate ? gw[c] + aw : aw;
-    gb[c] = accumulate ? gb[c] + ab : ab;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ GELU (exact erf)
@@ -346,19 +354,29 @@ __global__ __launch_bounds__(256) void bn_partial4_kernel(const float* x, const 
         if (mode == 2) *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
     }
 }
+// sums of the chunk partials: a workgroup = 16 channels x 16 lanes (lane l adds chunks l, l + 16, ... in order; lanes combined in lane order)
+__device__ __forceinline__ float chunk_sum16(const float* p, int chunks, int C, int c, float (&s)[16][17]) {
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float a = 0.f;
+    if (c < C) for (int k = rl; k < chunks; k += 16) a += p[(long long)k * C + c];
+    s[rl][cl] = a;
+    __syncthreads();
+    float t = 0.f;
+    for (int l = 0; l < 16; ++l) t += s[l][cl];
+    return t;
+}
 __global__ __launch_bounds__(256) void bn_colsum_chunks_kernel(const float* p, float* out, int chunks, int C, float scale) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += p[(long long)k * C + c];
-    out[c] = s * scale;
+    __shared__ float s[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float t = chunk_sum16(p, chunks, C, c, s);
+    if ((threadIdx.x >> 4) == 0 && c < C) out[c] = t * scale;
 }
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* p, const float* mean, float* save_mean, float* save_rstd, float* running_mean,
                                                                float* running_var, int chunks, int R, int C, float eps, float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float q = 0.f;
-    for (int k = 0; k < chunks; ++k) q += p[(long long)k * C + c];
+    __shared__ float s[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float q = chunk_sum16(p, chunks, C, c, s);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
     const float mu = mean[c], var = q / R;
     save_mean[c] = mu; save_rstd[c] = 1.f / sqrtf(var + eps);
     if (running_mean) {
@@ -567,6 +585,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
 }
+// The same reduction for 16-byte-aligned channel counts (every convolution of the path except the 3-channel stem and the 1- / 3-output
+// heads): 32 pixels per step, both operands fetched with float4 loads into registers ONE STEP AHEAD of the MFMAs that consume the
+// previous step (software pipeline: global latency hidden behind 32 MFMAs per wave), pixel -> address arithmetic per thread.
+constexpr int WK = 32, WLD = WK + 1;
+__global__ __launch_bounds__(256) void conv_wgrad4_kernel(WgradArgs a) {
+    __shared__ float s_a[GT * WLD], s_b[GT * WLD];       // [channel][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tci = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci, tap = blockIdx.y, ch = blockIdx.z;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const int co0 = tco * GT, ci0 = tci * GT;
+    const int m_beg = ch * a.chunk, m_end = min(a.M, m_beg + a.chunk);
+    const int pl = tid >> 4, cq = (tid & 15) * 4;         // loader role: pixels pl, pl + 16 of the step; channels cq .. cq + 3 of the tile
+    const bool co_ok = co0 + cq < a.Cout, ci_ok = ci0 + cq < a.Cin;      // (channel counts are multiples of 4: a quad is all in or all out)
+    const int hw = a.Ho * a.Wo;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = k0 + pl + 16 * h;
+            ra[h] = make_float4(0.f, 0.f, 0.f, 0.f); rb[h] = ra[h];
+            if (m < m_end) {
+                if (co_ok) ra[h] = *reinterpret_cast<const float4*>(a.gy + (long long)m * a.gy_cs + a.gy_co + co0 + cq);
+                const int b = m / hw, r = m - b * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
+                const int iy = oy * a.stride - a.pad + ky, ix = ox * a.stride - a.pad + kx;
+                if (ci_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    rb[h] = *reinterpret_cast<const float4*>(a.x + (((long long)b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + ci0 + cq);
+            }
+        }
+    };
+    const int li = lane & 15, lk = lane >> 4;
+    gload(m_beg);
+    for (int k0 = m_beg; k0 < m_end; k0 += WK) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int px = pl + 16 * h;
+            s_a[(cq + 0) * WLD + px] = ra[h].x; s_a[(cq + 1) * WLD + px] = ra[h].y; s_a[(cq + 2) * WLD + px] = ra[h].z; s_a[(cq + 3) * WLD + px] = ra[h].w;
+            s_b[(cq + 0) * WLD + px] = rb[h].x; s_b[(cq + 1) * WLD + px] = rb[h].y; s_b[(cq + 2) * WLD + px] = rb[h].z; s_b[(cq + 3) * WLD + px] = rb[h].w;
+        }
+        __syncthreads();
+        gload(k0 + WK);                                   // next step's operands (all zeros past the chunk's end)
+#pragma unroll
+        for (int ks = 0; ks < WK / 4; ++ks) {
+            const float av = s_a[(16 * wave + li) * WLD + 4 * ks + lk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_b[(16 * j + li) * WLD + 4 * ks + lk], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int taps = a.kh * a.kw;
+    float* out = a.out + (long long)ch * a.Cout * taps * a.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + 16 * j + li;
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 16 * wave + 4 * lk + r;
+            if (co < a.Cout) out[((long long)co * taps + tap) * a.Cin + ci] = acc[j][r];
+        }
+    }
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, float* gw, long long n, int chunks, int accumulate) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -610,7 +692,8 @@ extern "C" int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, 
     DIR_REQUIRE(workspace && workspace_bytes >= dir_colsum_workspace_bytes(R, N), "dir_colsum_f32: workspace too small (dir_colsum_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     launch_bn_partial(dim3((N + 63) / 64, chunks), s, x, nullptr, nullptr, nullptr, workspace, nullptr, R, N, ld, 0);
-    DIR_LAUNCH(wgrad_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, out, (long long)N, chunks, accumulate);
+    if (accumulate) DIR_LAUNCH(wgrad_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, out, (long long)N, chunks, accumulate);
+    else DIR_LAUNCH(bn_colsum_chunks_kernel, dim3((N + 15) / 16), dim3(256), 0, s, (const float*)workspace, out, chunks, N, 1.f);
     return check_launch("dir_colsum_f32");
 }
 
@@ -626,7 +709,7 @@ extern "C" int dir_layernorm_backward(const float* gy, const float* x, const flo
     using namespace dir;
     DIR_REQUIRE(gy && x && w && mean && rstd && R > 0 && C > 0 && C <= 256, "dir_layernorm_backward: bad arguments (C <= 256)");
     if (gx) DIR_LAUNCH(layernorm_bwd_x_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, gy, x, w, mean, rstd, gx, R, C, accumulate_x);
-    if (gw && gb) DIR_LAUNCH(layernorm_bwd_wb_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gy, x, mean, rstd, gw, gb, R, C, accumulate_wb);
+    if (gw && gb) DIR_LAUNCH(layernorm_bwd_wb_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, gy, x, mean, rstd, gw, gb, R, C, accumulate_wb);
     return check_launch("dir_layernorm_backward");
 }
 
@@ -678,7 +761,7 @@ extern "C" int dir_bn_train_forward(const float* x, const float* w, const float*
     DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_forward: workspace too small (dir_bn_train_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* part = workspace;
-    const dim3 pg((C + 63) / 64, chunks), cg((C + 255) / 256);
+    const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
     launch_bn_partial(pg, s, x, nullptr, nullptr, nullptr, part, nullptr, R, C, ld, 0);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)part, save_mean, chunks, C, 1.f / R);
     launch_bn_partial(pg, s, x, nullptr, save_mean, nullptr, part, nullptr, R, C, ld, 1);
@@ -699,7 +782,7 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
     DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_backward: workspace too small (dir_bn_train_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* p1 = workspace; float* p2 = p1 + (long long)chunks * C; float* t1 = p2 + (long long)chunks * C; float* t2 = t1 + C;
-    const dim3 pg((C + 63) / 64, chunks), cg((C + 255) / 256);
+    const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
     launch_bn_partial(pg, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p1, t1, chunks, C, 1.f);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p2, t2, chunks, C, 1.f);
@@ -815,7 +898,13 @@ extern "C" int dir_conv2d_wgrad_f32(const dir_conv_desc* d, const float* x, cons
     DIR_REQUIRE(direct || workspace_bytes >= (long long)chunks * n * 4, "dir_conv2d_wgrad_f32: workspace too small");
     a.out = direct ? gw : workspace;
     hipStream_t s = (hipStream_t)stream;
-    DIR_LAUNCH(conv_wgrad_kernel, dim3(a.tiles_ci * ((d->Cout + GT - 1) / GT), d->kh * d->kw, chunks), dim3(256), 0, s, a);
+    const bool vec4 = d->Cin % 4 == 0 && d->Cout % 4 == 0 && a.in_cs % 4 == 0 && a.in_co % 4 == 0 && a.gy_cs % 4 == 0 && a.gy_co % 4 == 0 &&
+                      ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0;
+    const dim3 wgrid(a.tiles_ci * ((d->Cout + GT - 1) / GT), d->kh * d->kw, chunks);
+    if (vec4) {
+        a.chunk = (a.chunk + WK - 1) / WK * WK;           // whole 32-pixel steps per chunk
+        DIR_LAUNCH(conv_wgrad4_kernel, wgrid, dim3(256), 0, s, a);
+    } else DIR_LAUNCH(conv_wgrad_kernel, wgrid, dim3(256), 0, s, a);
     if (!direct) DIR_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, gw, n, chunks, accumulate);
     return check_launch("dir_conv2d_wgrad_f32");
 }
