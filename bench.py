@@ -28,6 +28,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One HIP hardware queue per forward in flight: the runtime multiplexes streams onto GPU_MAX_HW_QUEUES queues (default 4, one of them
+# the null stream's), and two pipeline slots that share a queue do not overlap at all (measured: 4 slots on 4 queues 2.48 ms per step,
+# on 8 queues 2.23 ms).  Must be set before the runtime initialises; an explicit setting of the user wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 ALG_GFLOP_PER_IMAGE = 36.80                     # BASELINE.md section 2 (reference, torch flop counter)
@@ -44,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--inflight', type=int, default=2, help='forwards in flight per GPU (engine.ForwardPipeline: one captured graph + '
+    ap.add_argument('--inflight', type=int, default=4, help='forwards in flight per GPU (engine.ForwardPipeline: one captured graph + '
                     'stream + input batch per slot, steps alternate between them); 1 = one graph replayed back to back')
     ap.add_argument('--no-autotune', action='store_true', help='keep the library heuristic for every conv layer')
     ap.add_argument('--autotune-cache', default=None, help='JSON file: load the per-layer variants if it exists, else tune and save '
@@ -383,6 +387,7 @@ def main():
                 'config': {'workload': 'BASELINE configs[1]: batch 64 synthetic 256x256 per GPU, ResNet-50 + init '
                                        'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads',
                            'batch_per_gpu': B, 'graph': not args.no_graph, 'forwards_in_flight': args.inflight,
+                           'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                            'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3), 'weights': 'synthetic (dir_amd.synth seed 1234)',
                            'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite,
                            'overlapped_equals_one_at_a_time': reproducible, 'world_size_observed': world_observed,

@@ -1049,7 +1049,8 @@ class ForwardPipeline(object):
 
     def __init__(self, eng, imgs, want_proj_feat=True, streams=None):
         """streams: optional list of torch streams to run the slots on (one per slot).  HIP multiplexes streams onto a handful of
-        hardware queues; two slots whose streams share a queue do not overlap at all, so a second pipeline on the same engine
+        hardware queues (GPU_MAX_HW_QUEUES, default 4 including the null stream's: set it to 8 before the runtime starts for four
+        slots, as bench.py does); two slots whose streams share a queue do not overlap at all, so a second pipeline on the same engine
         should re-use the first one's streams (bench.py's proj_feat-less variant does)."""
         assert len(imgs) >= 1 and (streams is None or len(streams) == len(imgs))
         self.eng, self.imgs = eng, list(imgs)
