@@ -872,6 +872,9 @@ class DirEngine(object):
         finally:
             _capi.PROFILE = None
 
+    # margin by which an 8-wave one-workgroup-per-CU variant (pipe / patch) must beat the best 4-wave variant in isolation (A/B aid)
+    PIPE_MARGIN = float(os.environ.get('DIR_TUNE_PIPE_MARGIN', '0.03'))
+
     def autotune(self, img, reps=2):
         """Pick the convolution kernel variant per layer for this batch size by timing every candidate inside real
         forwards (HIP events around each conv launch, side stream off, realistic cache state).  All variants accumulate in
@@ -890,7 +893,8 @@ class DirEngine(object):
                     acc.setdefault(rec['op'], []).append(rec['e0'].elapsed_time(rec['e1']))
                 for op, ts in acc.items():
                     t = min(ts)
-                    if op not in best or t < best[op][0] * 0.97:  # a challenger must win by 3 % (timing noise)
+                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 12, 13, 14) else 0.03
+                    if op not in best or t < best[op][0] * (1.0 - margin):  # a challenger must win by 3 % (timing noise)
                         best[op] = (t, v)
         finally:
             _TLS.variant = None
