@@ -43,3 +43,28 @@ def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides():
         got = [o[s][k] for s in range(3) for k in keys] + [o[3]['seg']]
         assert all(torch.equal(x, y) for x, y in zip(got, ref)), 'forward changed beside a foreign kernel (round %d)' % rnd
         assert all(torch.equal(x, want) for x in outs), 'foreign kernel corrupted beside the forward (round %d)' % rnd
+
+
+def test_four_forwards_in_flight_reproduce_the_one_at_a_time_results():
+    """bench.py's default concurrency (four pipeline slots): every slot, every round, equals its stand-alone result bit for bit"""
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
+    eng = DirEngine(sd, dtype=torch.bfloat16)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    imgs = [torch.randn(64, 3, 256, 256, device='cuda', generator=gen) for _ in range(4)]
+    eng.autotune(imgs[0])
+    pipe = ForwardPipeline(eng, imgs)
+    keys = ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset')
+    ref = []
+    for s in range(4):                                   # one at a time
+        pipe.launch(s)
+        o = pipe.wait(s)
+        ref.append([o[i][k].clone() for i in range(3) for k in keys] + [o[3]['seg'].clone(), o[3]['proj_feat'].clone()])
+    for rnd in range(5):
+        for s in range(4):
+            pipe.launch(s)
+        for s in range(4):
+            o = pipe.wait(s)
+            got = [o[i][k] for i in range(3) for k in keys] + [o[3]['seg'], o[3]['proj_feat']]
+            assert all(torch.equal(a, b) for a, b in zip(got, ref[s])), (rnd, s)
