@@ -874,6 +874,7 @@ class DirEngine(object):
 
     # margin by which an 8-wave one-workgroup-per-CU variant (pipe / patch) must beat the best 4-wave variant in isolation (A/B aid)
     PIPE_MARGIN = float(os.environ.get('DIR_TUNE_PIPE_MARGIN', '0.03'))
+    STREAM_MARGIN = float(os.environ.get('DIR_TUNE_STREAM_MARGIN', '0.03'))     # same for the streaming 1x1 kernel (negative: preferred even when slower alone)
 
     def autotune(self, img, reps=2):
         """Pick the convolution kernel variant per layer for this batch size by timing every candidate inside real
@@ -893,7 +894,7 @@ class DirEngine(object):
                     acc.setdefault(rec['op'], []).append(rec['e0'].elapsed_time(rec['e1']))
                 for op, ts in acc.items():
                     t = min(ts)
-                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 12, 13, 14) else 0.03
+                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 12, 13, 14) else self.STREAM_MARGIN if v == STREAM_VARIANT else 0.03
                     if op not in best or t < best[op][0] * (1.0 - margin):  # a challenger must win by 3 % (timing noise)
                         best[op] = (t, v)
         finally:
