@@ -36,7 +36,6 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 ALG_GFLOP_PER_IMAGE = 36.80                     # BASELINE.md section 2 (reference, torch flop counter)
 HBM_PEAK = 8.0e12                               # bytes/s, same guide
-CONV_KERNELS = ('conv_pipe_kernel', 'conv_igemm_kernel', 'conv_patch_kernel', 'bneck_chain_kernel', 'tail_chain_kernel')
 
 
 def parse_args(argv=None):
@@ -283,8 +282,10 @@ def main():
         pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
         if pm and args.dtype == 'bf16' and B == 64:
             with open(pm[-1]) as f:
-                traffic = round(json.load(f)['hbm_bytes_per_launch'])
-            traffic_src = os.path.relpath(pm[-1], ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)'
+                pj = json.load(f)
+            traffic = round(pj['hbm_bytes_per_launch'])
+            traffic_src = (os.path.relpath(pm[-1], ROOT) + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at HEAD %s; a tracked '
+                           'file, not re-measured inside this run: counters need their own rocprofv3 passes)' % pj.get('head', 'unrecorded'))
         # the conv family spans both regimes (K <= 512 1x1 layers stream, the 3x3 layers compute): price the aggregate
         # against both roofs and report the one it sits closer to as the binding one
         frac_mfma, frac_hbm = achieved / PEAK[args.dtype], hbm_rate / HBM_PEAK
@@ -373,7 +374,17 @@ def main():
                     dir_forward(sd_np, ximg[:bb])
                 tt = time.perf_counter() - t0
                 tor['B=%d' % bb] = {'images_per_sec': round(bb * nrep / tt, 3), 'seconds': round(tt, 2), 'forwards': nrep}
+        cpu_model = None
+        try:
+            with open('/proc/cpuinfo') as f:
+                cpu_model = next((ln.split(':', 1)[1].strip() for ln in f if ln.startswith('model name')), None)
+        except OSError:
+            pass
         cpu = {'value': round(n / tc, 3), 'unit': 'images/sec', 'cores': int(nthreads), 'kind': 'port', 'os_cpu_count': int(ncpu),
+               'cpu_model': cpu_model,
+               'thread_policy': 'min(--cpu-threads=%d, cores this process may run on=%d): OpenBLAS / oneDNN at every hardware thread of the box '
+                                'oversubscribe and run 4-20x slower (measured r02: 64 threads 1.1 img/s, 256 threads 0.6) -- pass --cpu-threads N to '
+                                'change it' % (args.cpu_threads, ncpu),
                'sample': '%d images in chunks of %d, fp32 forward of oracle/dir_forward.py (numpy + OpenBLAS, %d threads), '
                          '%.1f s' % (n, chunk, nthreads, tc),
                'torch_ops': dict(tor, threads=int(nthreads), note='oracle/dir_forward.py with conv / BN / pool / upsample / linear on stock torch '

@@ -116,6 +116,7 @@ _SIGNATURES = {
     'dir_device_info': (C.c_int, [C.c_char_p, _i, C.POINTER(C.c_int)]),
     'dir_launch_log_reset': (None, []),
     'dir_launch_log_get': (C.c_int, [C.c_char_p, _i]),
+    'dir_launch_log_note': (None, [C.c_char_p, C.c_longlong]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -195,7 +196,7 @@ _SIGNATURES = {
 #    + whatever the caller announced for this call with annotate(): 'flops', 'bytes' (algorithmic work), 'shape', 'op'}
 PROFILE = None
 _pending = {}
-_NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get',
+_NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
                'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes')
 
 

@@ -168,7 +168,7 @@ def mano_backward(tables_lr, para_lr, g_verts=None, g_joints=None, g_joint_uv=No
         keep.extend(t for t in ts if t is not None)
         return P(*[(None if t is None else t.data_ptr() + off) for t in ts])
     keep = []
-    gs = [[None if g is None else _capi.f32c(t) for t in (g if g is not None else [None] * hands)] for g in (g_verts, g_joints, g_joint_uv, g_mesh_uv)]
+    gs = [[None if t is None else _capi.f32c(t) for t in (g if g is not None else [None] * hands)] for g in (g_verts, g_joints, g_joint_uv, g_mesh_uv)]   # a hand without a cotangent: NULL pointer
     out = [torch.zeros(B, 64, device=para[0].device) for _ in range(hands)]
     tabs = (_capi.ManoTables * hands)(*tables_lr)
     _capi.check(_capi.lib().dir_mano_backward_pair(

@@ -3,8 +3,9 @@ tree and state-dict keys (963 keys; a reference checkpoint's ['net'] loads with 
 signature and output structure (models/dir.py:513-540).  The classes below are parameter containers; DIR.forward runs
 the whole eval-mode path through dir_amd.engine.DirEngine, i.e. through libdir_hip.so (include/dir_hip.h).
 
-Scope: inference.  `self.training == True` raises NotImplementedError (loss block + backward are row
-8f.2, "next").  `compute_dtype` selects bf16 feature maps (BASELINE config 2, default) or exact-fp32 MFMA convs.
+Scope: eval mode = the benchmarked hot path (DirEngine); `self.training == True` runs the fp32 training forward of
+dir_amd/train/net.py and returns the 42 loss terms attached to the parameters (row 8f.2: `sum(loss.values()).backward()` fills `.grad`).
+`compute_dtype` selects bf16 feature maps (BASELINE config 2, default), exact-fp32 MFMA convs, or the f16x3 split-precision mode.
 """
 import torch
 import torch.nn as nn
@@ -170,10 +171,17 @@ class DIR(nn.Module):
         self.autotune = True
 
     def _tensors(self):
-        """parameters and buffers in state-dict order, listed once (re-listed after _apply / load_state_dict / refresh())"""
+        """parameters and buffers in state-dict order.  What is cached is the list of SLOTS -- (the owning module's _parameters / _buffers
+        dict, name) -- not the tensor objects: every call looks the current tensor of each slot up again, so `model.backbone.float()`,
+        `.to()` on a sub-module or `bn.running_mean = t` (which replace tensor objects without going through DIR._apply) are seen.  The
+        slot list itself is rebuilt after _apply / load_state_dict / refresh()."""
         if self._sd_tensors is None:
-            self._sd_tensors = list(self.state_dict(keep_vars=True).values())
-        return self._sd_tensors
+            slots = []
+            for mod in self.modules():
+                slots += [(mod._parameters, k) for k, v in mod._parameters.items() if v is not None]
+                slots += [(mod._buffers, k) for k, v in mod._buffers.items() if v is not None and k not in mod._non_persistent_buffers_set]
+            self._sd_tensors = slots
+        return [d[k] for d, k in self._sd_tensors]
 
     def refresh(self):
         """forget the packed engine: the next forward re-packs the parameters (needed only after out-of-band edits that bump neither
@@ -224,15 +232,17 @@ class DIR(nn.Module):
         vec = _TrainObjective.apply(box, x, target, meta_info, faces, buffers, [k for k, _ in named], *[p for _, p in named])
         with torch.no_grad():
             for k, b in self.named_buffers():
-                if k.endswith('num_batches_tracked'):
-                    b += 1                                          # nn.BatchNorm bookkeeping (momentum is not None: unused by the maths)
+                if k.endswith('num_batches_tracked'):               # nn.BatchNorm bookkeeping (momentum is not None: unused by the maths):
+                    # one count per BatchNorm CALL -- global_pos_emb and proj_feat_emb are shared modules the reference calls once per
+                    # hand (models/dir.py:106-107,118-119), so theirs advance by 2 per forward
+                    b += 2 if ('.global_pos_emb.' in k or '.proj_feat_emb.' in k) else 1
         loss = {k: vec[i] for i, k in enumerate(box['keys'])}
         outs = box['outs']
         outs_list = [{k: o.get(k) for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left',
                                              'pd_joint_xyz_right', 'pd_offset')} for o in outs[:3]]
         for o, d in zip(outs[:3], outs_list):
             d['pd_proj_left'], d['pd_proj_right'], d['pd_rel_joint'] = o['pd_mano_para_left'][:, 61:], o['pd_mano_para_right'][:, 61:], None
-        outs_list.append({'dense': outs[3]['dense'], 'seg': outs[3]['seg'], 'proj_feat': None})
+        outs_list.append({'dense': outs[3]['dense'], 'seg': outs[3]['seg'], 'proj_feat': outs[3].get('proj_feat')})    # models/dir.py:536-540
         return outs_list, loss
 
     def forward(self, input, target, meta_info):

@@ -26,22 +26,20 @@ def _pair(d, prefix, dev=None):
     return ts, (C.c_void_p * 2)(*[_capi.ptr(t) for t in ts])
 
 
-_FACES_OK = {}
-
-
 def _check_faces(faces, dev, n_vertices=778):
     """two [F,3] int tables of the same size with indices in [0, n_vertices): an index out of range would read out of bounds on the
-    device.  The range check costs a host round trip, so it is done once per table (keyed on storage and version)."""
+    device.  The range check costs a host round trip, so it is done once per table OBJECT and version: the verdict is stored on the
+    tensor itself (an address-keyed cache would be fooled by a freed-and-reused allocation, and would grow without bound)."""
     fs = [torch.as_tensor(f).to(device=dev, dtype=torch.int32).contiguous() for f in faces]
     if fs[0].shape != fs[1].shape or fs[0].dim() != 2 or fs[0].shape[1] != 3:
         raise _capi.DirHipError('stage losses: faces must be two [F,3] tables of the same size')
     for f, src in zip(fs, faces):
-        key = (src.data_ptr(), src._version, tuple(src.shape)) if torch.is_tensor(src) else None
-        if key is None or key not in _FACES_OK:
+        tag = (src._version, n_vertices) if torch.is_tensor(src) else None
+        if tag is None or getattr(src, '_dir_faces_checked', None) != tag:
             if f.numel() and (int(f.min()) < 0 or int(f.max()) >= n_vertices):
                 raise _capi.DirHipError('stage losses: face index outside [0, %d)' % n_vertices)
-            if key is not None:
-                _FACES_OK[key] = True
+            if tag is not None:
+                src._dir_faces_checked = tag
     return fs
 
 

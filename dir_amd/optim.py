@@ -56,7 +56,8 @@ class FlatAdamW(object):
 
     def set_inactive(self, params):
         """Parameters that never receive a gradient (torch.optim.AdamW skips `p.grad is None`: no state, no weight decay -- in the
-        reference e.g. interaction.STEblocks.0.*, never executed, transformer/mixSTE.py:197, and the dead e_0 of every PGraphConv):
+        reference backbone.fc.* and interaction.STEblocks.0.*, never executed; NOT PGraphConv's e_0, whose gradient is a zero TENSOR there and
+        which therefore decays -- dir_amd.train.step.inactive_parameters() is the authoritative list):
         step() leaves their slots alone and state_dict() omits them, as torch does."""
         ids = {id(p) for p in params}
         self.active = [a and id(p) not in ids for a, p in zip(self.active, self.params)]

@@ -68,7 +68,7 @@ def _cbr_backward(P, pre, s, gy, G, need_gx=True):
     return TB._conv_bwd(P, pre + '0.', s['x'], g, 1, s['k'] // 2, G, need_gx=need_gx)
 
 
-def _stage_image_forward(P, pre, tok, uv_l, uv_r, S, distance):
+def _stage_image_forward(P, pre, tok, uv_l, uv_r, S, distance, want_vis=False):
     """re-embedding + bone rasterisation + fusion conv of a stage (models/dir.py:118-122)"""
     B = tok.shape[0]
     Ps = sub(P, pre)
@@ -79,9 +79,12 @@ def _stage_image_forward(P, pre, tok, uv_l, uv_r, S, distance):
         y, c = TS.mlp_forward(Ps, 'proj_feat_emb.', rows)
         emb[:, 21 * h:21 * (h + 1)] = y.view(B, 21, 64)
         ctx_emb.append(c)
-    bone = SP.bone_proj_fwd(uv_l, uv_r, emb, S, distance)
+    bone = SP.bone_proj_fwd(uv_l, uv_r, emb, S, distance, want_vis=want_vis)
+    vis = None
+    if want_vis:
+        bone, vis = bone
     img_feat, c_fus = _cbr_forward(P, pre + 'fusion.', bone, 3)
-    return img_feat, dict(emb=emb, ctx_emb=ctx_emb, fus=c_fus, uv=(uv_l, uv_r), S=S, distance=distance)
+    return img_feat, dict(emb=emb, ctx_emb=ctx_emb, fus=c_fus, uv=(uv_l, uv_r), S=S, distance=distance, vis=vis)
 
 
 def _stage_image_backward(P, pre, s, g_img_feat, G):
@@ -152,7 +155,8 @@ def forward(P, img, keep=None):
         pre = 'decoder.projecter_%s.' % tag
         tabs = mano_tables(P, pre + 'regressor.', keep)
         res, d['tok'] = TS.stage_tokens_forward(sub(P, pre), tabs, fusion_feat, prev)
-        img_feat, d['img'] = _stage_image_forward(P, pre, res['joint_feat'], res['pd_joint_uv_left'], res['pd_joint_uv_right'], S, dist)
+        img_feat, d['img'] = _stage_image_forward(P, pre, res['joint_feat'], res['pd_joint_uv_left'], res['pd_joint_uv_right'], S, dist,
+                                                  want_vis=(si == 1))            # the last stage's map is an output (models/dir.py:481)
         enh_in = torch.cat((fusion_feat, img_feat), dim=3)
         feat_lo, d['enh'] = TB.residual_forward(sub(P, 'decoder.enhance_layer%s.' % tag), enh_in)
         d.update(tabs=tabs, Cup=Cup, S=S)
@@ -162,7 +166,8 @@ def forward(P, img, keep=None):
     feat, ctx['final'] = _cbr_forward(P, 'decoder.conv_final.', feat_lo, 3)
     seg, ctx['seg'] = _cbr_forward(P, 'decoder.seg.', feat, 3)
     dense, ctx['dense'] = _cbr_forward(P, 'decoder.dense.', feat, 3)
-    outs.append({'seg': seg.permute(0, 3, 1, 2).contiguous(), 'dense': dense.permute(0, 3, 1, 2).contiguous()})
+    outs.append({'seg': seg.permute(0, 3, 1, 2).contiguous(), 'dense': dense.permute(0, 3, 1, 2).contiguous(),
+                 'proj_feat': ctx['dec'][1]['img']['vis']})
     ctx.update(feats=feats)
     return outs, ctx
 

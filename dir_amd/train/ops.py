@@ -127,6 +127,11 @@ def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentu
     _capi.check(_capi.lib().dir_bn_train_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
                                                  _capi.ptr(running_var), R, C, C, float(eps), float(momentum), _capi.ptr(ws), n, _capi.stream_ptr()),
                 'dir_bn_train_forward')
+    # the kernel wrote the running statistics through raw pointers: bump their version counters as an in-place torch op would, so that
+    # caches keyed on (data_ptr, _version) -- DIR.engine()'s packed eval weights -- see the update (FlatAdamW.step does the same)
+    written = [t for t in (running_mean, running_var) if t is not None]
+    if written:
+        torch._C._increment_version(written)
     return y, (sm, sr)
 
 

@@ -66,13 +66,15 @@ def attn_pool_bwd(feat, attn, pooled, g_pooled, g_mean=None, g_feat=None, need_l
     return g_feat, g_logit
 
 
-def bone_proj_fwd(uv_l, uv_r, emb, S, distance):
-    """-> NHWC fp32 [B,S,S,2560] (dir_bone_proj_forward)"""
+def bone_proj_fwd(uv_l, uv_r, emb, S, distance, want_vis=False):
+    """-> NHWC fp32 [B,S,S,2560] (dir_bone_proj_forward); want_vis: also `vis_img_feat` = left + right maps, NCHW fp32 [B,1280,S,S]
+    (models/dir.py:128, returned as outs_list[3]['proj_feat'], models/dir.py:481)"""
     B = emb.shape[0]
     out = torch.empty(B, S, S, 2560, device=emb.device)
-    _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(uv_l), _capi.ptr(uv_r), _capi.ptr(emb), _capi.ptr(out), None, None, B, S, float(distance),
+    vis = torch.empty(B, 1280, S, S, device=emb.device) if want_vis else None
+    _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(uv_l), _capi.ptr(uv_r), _capi.ptr(emb), _capi.ptr(out), _capi.ptr(vis), None, B, S, float(distance),
                                                   _capi.DT_F32, _capi.stream_ptr()), 'dir_bone_proj_forward')
-    return out
+    return (out, vis) if want_vis else out
 
 
 def bone_proj_bwd(uv_l, uv_r, emb, g_img, S, distance, coff=0):

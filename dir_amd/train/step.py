@@ -25,10 +25,14 @@ def add_grads(named_params, prefix, grads):
 
 
 def inactive_parameters(named_params):
-    """the parameters torch leaves without a gradient on the token path (never-executed STE block 0, transformer/mixSTE.py:197):
-    FlatAdamW.set_inactive() keeps AdamW from decaying them, as torch.optim.AdamW skips `grad is None`.  (PGraphConv's e_0 does get a
-    gradient in the reference -- identically zero -- so it stays active and decays, like there.)"""
-    return [p for k, p in named_params.items() if '.interaction.STEblocks.0.' in '.' + k]
+    """THE list of parameters torch leaves with `grad is None` after `sum(loss.values()).backward()` on the reference network (so
+    torch.optim.AdamW neither updates nor decays them; FlatAdamW.set_inactive() reproduces that and omits them from state_dict()):
+      * `backbone.fc.*`                       -- ResNet's classifier, never called (models/backbone/resnet.py:243-255 returns the pyramid);
+      * `*.interaction.STEblocks.0.*`         -- the first STE block, skipped by the loop (transformer/mixSTE.py:197).
+    PGraphConv's `e_0` is NOT in the list: it enters the graph through a one-entry softmax row (SemGCN/p_graph_conv.py:45-48), so torch hands
+    it an identically-zero gradient tensor and AdamW still applies weight decay to it -- it stays active here too.  Works for the whole
+    state dict and for any sub-tree of it (tests, tools/bench_train.py and train_step's callers all use this one function)."""
+    return [p for k, p in named_params.items() if ('.' + k).startswith('.backbone.fc.') or '.interaction.STEblocks.0.' in '.' + k]
 
 
 def token_stage_train_step(named_params, prefix, mano_tables_lr, feat_nhwc, prev, target, meta_info, faces, optimizer, coord_weight=10.0,

@@ -40,6 +40,9 @@ int dir_device_info(char* arch_host, int arch_len, int* num_cu_host);
  * comma-separated list (kernel names as rocprofv3 reports them, template arguments dropped) and returns how many there were. */
 void dir_launch_log_reset(void);
 int dir_launch_log_get(char* buf_host, int len);
+/* as if `times` launches of kernel `name` had been noted: the counter dir_launch_log_get() returns SATURATES at INT_MAX (a serving process
+ * never resets it), only the first 32 names since the last reset are kept.  Used by the CPU tests; launches nothing. */
+void dir_launch_log_note(const char* name, long long times);
 
 /* ------------------------------------------------------------------------------------------------
  * a8 + a9: MANO forward + weak-perspective projection
@@ -247,7 +250,12 @@ int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void
  * tile's counter sums all partials in split order -- so the result does not depend on the arrival order -- and runs the usual epilogue
  * (scale / shift, residual, ReLU).  The summation order differs from the unsplit kernels': outputs agree to bf16 rounding, not bit for
  * bit.  workspace: dir_conv2d_splitk_workspace_bytes(d, splits) bytes, 16-byte aligned, its first 16 KiB ZERO before the first use (the
- * kernel leaves them zero); one workspace must not be shared by launches that can run concurrently.  splits == 1 = dir_conv2d_forward. */
+ * kernel leaves them zero); one workspace must not be shared by launches that can run concurrently.  splits == 1 = dir_conv2d_forward.
+ * EXPERIMENTAL, off by default (DIR_SPLITK=1 / ConvOp.split): the cross-workgroup hand-over publishes the partial tiles as relaxed
+ * agent-scope atomic stores that are drained (s_waitcnt vmcnt(0)) before a relaxed ticket increment -- sufficient on gfx950, where a
+ * completed sc1 store is visible device-wide, but NOT a release / acquire pair in the HIP memory model (a formal release on the ticket
+ * costs an L2 write-back per workgroup: +12 us per split, which erases the gain).  Measured no faster than the tiled kernels at the
+ * benchmark batch; kept for small-batch latency experiments, covered by tests/test_gpu_splitk.py (incl. a many-iteration stress case). */
 long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits);
 int dir_conv2d_splitk_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                               const float* pre_scale, const float* pre_shift, const void* residual, void* y, int splits,

@@ -44,3 +44,28 @@ def test_product_path_has_no_cpu_fallback():
         m(torch.zeros(2, 51), torch.zeros(2, 10))
     with pytest.raises(NotImplementedError):
         ManoLayer(root_rot_mode='axisang', use_pca=True, ncomps=45)
+
+
+def test_launch_log_counter_saturates_instead_of_overflowing():
+    """the per-thread launch counter is only reset by profiling code; a serving process crosses 2^31 launches in days.  It
+    must saturate (not wrap negative and index the 32-entry name table out of bounds)."""
+    import torch  # noqa: F401
+    from dir_amd import build
+    lib = ctypes.CDLL(build.build(verbose=False))
+    lib.dir_launch_log_note.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    lib.dir_launch_log_note.restype = None
+    lib.dir_launch_log_get.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.dir_launch_log_get.restype = ctypes.c_int
+    buf = ctypes.create_string_buffer(4096)
+    lib.dir_launch_log_reset()
+    lib.dir_launch_log_note(b'(alpha_kernel<1, 2>)', 3)
+    assert lib.dir_launch_log_get(buf, 4096) == 3 and buf.value == b'alpha_kernel,alpha_kernel,alpha_kernel'
+    lib.dir_launch_log_note(b'beta_kernel', 100)                      # past the 32-entry table: counted, names beyond 32 dropped
+    assert lib.dir_launch_log_get(buf, 4096) == 103 and buf.value.count(b',') == 31
+    lib.dir_launch_log_note(b'beta_kernel', 1 << 40)                  # far past INT_MAX
+    n = lib.dir_launch_log_get(buf, 4096)
+    assert n == 2 ** 31 - 1 and buf.value.count(b',') == 31
+    lib.dir_launch_log_note(b'beta_kernel', 5)                        # stays saturated, table untouched
+    assert lib.dir_launch_log_get(buf, 4096) == 2 ** 31 - 1
+    lib.dir_launch_log_reset()
+    assert lib.dir_launch_log_get(buf, 4096) == 0 and buf.value == b''

@@ -105,7 +105,7 @@ def test_whole_network_train_steps_reduce_the_objective():
     params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
     buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
     opt = FlatAdamW(list(params.values()), lr=2e-5)
-    dead = [p for k, p in params.items() if k.startswith('backbone.fc.') or '.interaction.STEblocks.0.' in k]
+    dead = TSTEP.inactive_parameters(params)
     opt.set_inactive(dead)
     before = {k: p.detach().clone() for k, p in params.items()}
     img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()

@@ -71,3 +71,27 @@ def test_splitk_rejects_bad_workspace():
         F.conv2d_nhwc(x, w, splits=2, workspace=torch.zeros(1024, dtype=torch.uint8, device='cuda'))
     with pytest.raises(_capi.DirHipError):
         F.conv2d_nhwc(x, w, splits=2)                                                # K = 64: one slab cannot be shared by two workgroups
+
+
+def test_splitk_stress_many_launches_two_streams():
+    """the partial-tile hand-over rests on drained sc1 stores + a relaxed ticket, not on a formal release / acquire pair.  Stress
+    it: 300 launches per stream on two concurrent streams (own workspace each, as the API requires), every result bit-identical to the
+    first."""
+    torch.manual_seed(7)
+    B, H, Cin, Cout, k, S = 64, 8, 512, 512, 3, 4
+    x = torch.randn(B, H, H, Cin, device='cuda').to(torch.bfloat16)
+    w = (torch.randn(Cout, k, k, Cin, device='cuda') * (k * k * Cin) ** -0.5).to(torch.bfloat16)
+    d = _capi.ConvDesc(B, H, H, Cin, Cin, 0, Cout, Cout, 0, 0, 0, k, k, 1, 1, _capi.DT_BF16, _capi.DT_BF16, 0)
+    nbytes = _capi.lib().dir_conv2d_splitk_workspace_bytes(d, S)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    wss = [torch.zeros(nbytes, dtype=torch.uint8, device='cuda') for _ in streams]
+    ref = F.conv2d_nhwc(x, w, pad=1, relu=True, splits=S, workspace=torch.zeros(nbytes, dtype=torch.uint8, device='cuda')).clone()
+    torch.cuda.synchronize()
+    bad = torch.zeros(2, dtype=torch.int64, device='cuda')
+    for it in range(300):
+        for i, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                o = F.conv2d_nhwc(x, w, pad=1, relu=True, splits=S, workspace=wss[i])
+                bad[i] += (o != ref).sum()
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0, 0], bad.tolist()

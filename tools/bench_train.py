@@ -30,7 +30,7 @@ is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer',
 params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
 buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
 opt = FlatAdamW(list(params.values()), lr=1e-5)
-opt.set_inactive([p for k, p in params.items() if k.startswith('backbone.fc.') or '.interaction.STEblocks.0.' in k])
+opt.set_inactive(TSTEP.inactive_parameters(params))
 rng = np.random.RandomState(rank)
 dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
 img = dv(synth.synth_input('train.img.%d' % rank, (B, 3, 256, 256), 1234))
