@@ -25,7 +25,7 @@ class ManoTables(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'B', 'H', 'W', 'Cin', 'in_cstride', 'in_coff', 'Cout', 'out_cstride', 'out_coff', 'res_cstride', 'res_coff',
-        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')]
+        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')] + [('in_scale', C.c_float)]
 
 
 class ConvSrc2(C.Structure):
@@ -105,8 +105,8 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 24          # DIR_ABI_VERSION (include/dir_hip.h)
-DT_F32, DT_BF16 = 0, 1
+ABI_VERSION = 25          # DIR_ABI_VERSION (include/dir_hip.h)
+DT_F32, DT_BF16, DT_F16X3 = 0, 1, 3
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
 _p, _i = C.c_void_p, C.c_int
@@ -139,6 +139,7 @@ _SIGNATURES = {
     'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_bone_proj_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _i, _p]),
     'dir_conv2d_dual_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p]),
+    'dir_conv2d_dual_scaled_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p, _p]),
     'dir_conv1x1_stream_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_conv2d_sparse_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),

@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // wave-level DMA is lane-linear (8 rows x 128 B per instruction), so rows are unpadded and the bank-conflict-free
     // layout is obtained by XOR-swizzling the 16-byte chunk index on the SOURCE address: chunk c of row r lives at
     // position c ^ ((r >> 1) & 7).  The prologue variant must touch the data in registers and keeps the staged path.
-    constexpr bool DMA = !PRE;
+    // f16x3 (fp32 tensors, split-precision arithmetic): the activations are split into f16 hi / lo parts on their way into LDS, so that
+    // mode always takes the register-staged path, with or without the pre-activation
+    constexpr bool X3 = std::is_same<TI, f16x3_t>::value;
+    constexpr bool DMA = !PRE && !X3;
     constexpr int ROW = DMA ? 128 : LDS_STRIDE;
     constexpr int BM = 64 * MI, BN = 64 * NJ;
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
@@ -129,6 +132,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     auto gload = [&](auto P, int ks) {
         constexpr int p = decltype(P)::value;
+        if (ks >= a.nk1) {                               // second source (f16x3 only on this path): slab (ks - nk1) of x2's channels, 1x1
+            const int c2 = (ks - a.nk1) * BK;
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x2r, avoff2[i], c2 * ES, 0));
+                if constexpr (X3) v = split_f16x3(v, a.a_scale);
+                ra[p][i] = __builtin_bit_cast(u32x4, v);
+            }
+#pragma unroll
+            for (int i = 0; i < BCH; ++i)
+                rb[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[i], (a.nk1 * BK + c2) * ES, 0));
+            return;
+        }
         // K order: channel slab outer, taps inner -- consecutive slabs touch the same pixels' cache lines (shifted
         // by one tap), so the im2col re-reads hit L1/L2 instead of re-streaming the feature map once per tap
         const int cs = ks / ntaps, tap = ks - cs * ntaps;
@@ -143,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             if constexpr (PRE) {
                 if (ok) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
             }
+            if constexpr (X3) v = split_f16x3(v, a.a_scale);                    // {hi01, hi23, lo01, lo23}
             ra[p][i] = __builtin_bit_cast(u32x4, v);
         }
 #pragma unroll
@@ -155,8 +172,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         char* sa = smem + buf * BUF_BYTES;
         char* sb = sa + A_BYTES;
         const int off0 = (tid >> 3) * LDS_STRIDE + col * 16;
+        if constexpr (X3) {
+            // LDS row of a 32-channel slab = [hi: 32 f16 | lo: 32 f16] (the layout the host packs the weights in): this thread's four
+            // channels are 8 bytes of each half
+            const int offa = (tid >> 3) * LDS_STRIDE + col * 8;
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(sa + off0 + 32 * i * LDS_STRIDE) = ra[p][i];
+            for (int i = 0; i < ACH; ++i) {
+                *reinterpret_cast<uint2*>(sa + offa + 32 * i * LDS_STRIDE) = make_uint2(ra[p][i].x, ra[p][i].y);
+                *reinterpret_cast<uint2*>(sa + offa + 64 + 32 * i * LDS_STRIDE) = make_uint2(ra[p][i].z, ra[p][i].w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) *reinterpret_cast<u32x4*>(sa + off0 + 32 * i * LDS_STRIDE) = ra[p][i];
+        }
 #pragma unroll
         for (int i = 0; i < BCH; ++i) *reinterpret_cast<u32x4*>(sb + off0 + 32 * i * LDS_STRIDE) = rb[p][i];
     };
@@ -225,10 +253,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // fragment addressing: lane (i = lane & 31, h = lane >> 5) reads the 64-byte half h of row i
-    const int frag_off = (lane & 31) * ROW + (DMA ? 0 : (lane >> 5) * 64);
+    // (f16x3: fragment q = 2*s + part reads the 16 bytes of k16-step s, half h, of the row's hi (part 0) or lo (part 1) half)
+    const int frag_off = (lane & 31) * ROW + (DMA || X3 ? 0 : (lane >> 5) * 64);
     int qoff[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) qoff[q] = DMA ? ((((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4) : q * 16;
+    for (int q = 0; q < 4; ++q)
+        qoff[q] = X3 ? 32 * (q >> 1) + 16 * (lane >> 5) + 64 * (q & 1) : DMA ? ((((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4) : q * 16;
 
     // ---- optional sparse-K: compact, ordered list of the K-slabs whose input group can be non-zero for this tile
     __shared__ short s_list[MAX_SLABS];
@@ -555,8 +585,9 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
-    const bool f32 = d->in_dtype == DIR_DT_F32;
-    DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16, "dir_conv2d_forward: in_dtype must be f32 or bf16");
+    const bool x3 = d->in_dtype == DIR_DT_F16X3;                 // fp32 tensors, split-precision arithmetic: sizes / alignment as fp32
+    const bool f32 = d->in_dtype == DIR_DT_F32 || x3;
+    DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16, "dir_conv2d_forward: in_dtype must be f32, bf16 or f16x3");
     DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == DIR_DT_BF16, "dir_conv2d_forward: bad out_dtype");
     DIR_REQUIRE(!(f32 && d->out_dtype == DIR_DT_BF16), "dir_conv2d_forward: f32 in / bf16 out not built");
     const int BK = f32 ? 32 : 64, EPC = f32 ? 4 : 8;
@@ -591,8 +622,8 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
                     "dir_conv2d_dual_forward: the second source does not produce a %dx%d output", a.Ho, a.Wo);
         const int cs2 = d2->in_cstride ? d2->in_cstride : d2->Cin;
         DIR_REQUIRE(cs2 % EPC == 0 && d2->in_coff % EPC == 0, "dir_conv2d_dual_forward: second source channel slice must be 16-byte aligned");
-        DIR_REQUIRE(pre_scale == nullptr && bbox == nullptr && scale == nullptr,
-                    "dir_conv2d_dual_forward: scale / pre-activation / sparse-K do not combine with a second source");
+        DIR_REQUIRE(pre_scale == nullptr && bbox == nullptr,
+                    "dir_conv2d_dual_forward: pre-activation / sparse-K do not combine with a second source");
         const long long x2b = (long long)d->B * d2->H * d2->W * cs2 * (f32 ? 4 : 2);
         DIR_REQUIRE(x2b < (1ll << 31), "dir_conv2d_dual_forward: second source must be < 2 GiB");
         a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.H2 = d2->H; a.W2 = d2->W; a.in_cs2 = cs2; a.in_co2 = d2->in_coff;
@@ -603,6 +634,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     set_magic(a);
     a.flags = d->flags & 3;
     a.variant = (d->flags >> 8) & 0xff;
+    a.a_scale = (x3 && d->in_scale > 0.f) ? d->in_scale : 1.f;
     DIR_REQUIRE(d->kh * d->kw <= 32, "dir_conv2d_forward: at most 32 taps");
     const long long xb = (long long)d->B * d->H * d->W * in_cs * (f32 ? 4 : 2);
     const long long wb = (long long)d->Cout * a.K * (f32 ? 4 : 2);
@@ -633,7 +665,8 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
         a.splits = splits; a.ws_cnt = (unsigned*)workspace; a.ws_part = (float*)((char*)workspace + SPLITK_COUNTER_BYTES);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (f32) launch_conv<float, float>(a, num_cu, s);
+    if (x3) launch_conv<f16x3_t, float>(a, num_cu, s);
+    else if (f32) launch_conv<float, float>(a, num_cu, s);
     else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
     else launch_conv<bf16_t, float>(a, num_cu, s);
     return dir::check_launch("dir_conv2d_forward");
@@ -667,6 +700,12 @@ extern "C" int dir_conv2d_dual_forward(const dir_conv_desc* d, const void* x, co
                                        const float* shift, void* y, void* stream) {
     DIR_REQUIRE(d2, "dir_conv2d_dual_forward: null second-source descriptor");
     return conv_forward(d, x, w, nullptr, shift, nullptr, nullptr, nullptr, y, nullptr, stream, d2, x2);
+}
+
+extern "C" int dir_conv2d_dual_scaled_forward(const dir_conv_desc* d, const void* x, const dir_conv_src2* d2, const void* x2, const void* w,
+                                              const float* scale, const float* shift, void* y, void* stream) {
+    DIR_REQUIRE(d2, "dir_conv2d_dual_scaled_forward: null second-source descriptor");
+    return conv_forward(d, x, w, scale, shift, nullptr, nullptr, nullptr, y, nullptr, stream, d2, x2);
 }
 
 extern "C" int dir_conv2d_sparse_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,

@@ -62,9 +62,33 @@ __device__ __forceinline__ uint32_t relu2bf(uint32_t v) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, v), i16x2_t{0, 0}));
 }
 
+// f16x3 "split precision" operand tag (DIR_DT_F16X3): tensors are fp32 in memory, every product a*w is evaluated as
+//   hi(a)*hi(w) + lo(a)*hi(w) + hi(a)*lo(w),   hi(x) = f16(x), lo(x) = f16(x - hi(x))           (3 x v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// hi + lo carries 22 significant bits (the dropped lo*lo and residual terms are ~2^-22 |a w|), against 24 for the exact fp32 MFMA at
+// 1/5.3 of its matrix-core time.  The matrix cores honour f16 denormal inputs (tools/ubench_f16_denorm.hip), so lo needs no scaling for
+// |a| >= 2^-14 ~ 6e-5 * 2^11; the WEIGHTS are pre-scaled per output channel by a power of two on the host (max |w| -> [2^12, 2^13)) so
+// that their lo parts are normal numbers, and split there: the weight "tensor" of this mode is [Cout][kh][kw][Cin/32][hi 32 | lo 32]
+// f16 -- byte for byte the size and addressing of the fp32 tensor it replaces.  Activations are split when a K-slab is staged into LDS.
+struct f16x3_t { float v; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
 template <typename T> struct Tr;
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };    // EPC = elems per 16-B chunk
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
+template <> struct Tr<f16x3_t> { static constexpr int EPC = 4, BK = 32; };
+
+// four fp32 values, times the power of two s, clamped to the f16 range -> {hi01, hi23, lo01, lo23} as packed f16 pairs (round to
+// nearest even both times)
+__device__ __forceinline__ uint4 split_f16x3(const uint4 v, const float s) {
+    constexpr float FMAX = 65504.f;
+    const f32x2_t a = {__builtin_amdgcn_fmed3f(__uint_as_float(v.x) * s, -FMAX, FMAX), __builtin_amdgcn_fmed3f(__uint_as_float(v.y) * s, -FMAX, FMAX)};
+    const f32x2_t b = {__builtin_amdgcn_fmed3f(__uint_as_float(v.z) * s, -FMAX, FMAX), __builtin_amdgcn_fmed3f(__uint_as_float(v.w) * s, -FMAX, FMAX)};
+    const f16x2_t ha = __builtin_convertvector(a, f16x2_t), hb = __builtin_convertvector(b, f16x2_t);
+    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
+    const f16x2_t la = __builtin_convertvector(ra, f16x2_t), lb = __builtin_convertvector(rb, f16x2_t);
+    return make_uint4(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb), __builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
 
 struct ConvArgs {
     const void* x; const void* w; const float* scale; const float* shift;
@@ -72,6 +96,7 @@ struct ConvArgs {
     int B, H, W, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
     int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
     int variant;                        // DIR_CONV_VARIANT code (0 = heuristic)
+    float a_scale;                      // f16x3: power of two applied to the activations before the hi / lo split (dir_conv_desc.in_scale)
     // optional second source, a 1x1 (strided) convolution accumulated into the same output: K-slabs ks >= nk1 read x2;
     // weight rows are [kh*kw*Cin | Cin2] (dir_conv2d_dual_forward)
     const void* x2; unsigned x2_bytes; int H2, W2, in_cs2, in_co2, stride2, nk1;
@@ -113,6 +138,18 @@ __device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uin
     for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
                                                       __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
+}
+// f16x3: fragment q = 2*s + part of a 32-channel slab: k16-step s in {0, 1}, part 0 = hi, 1 = lo (both operands laid out alike)
+template <>
+__device__ __forceinline__ void mma_slab<f16x3_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, af[2 * s]), al = __builtin_bit_cast(f16x8, af[2 * s + 1]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, bf[2 * s]), bl = __builtin_bit_cast(f16x8, bf[2 * s + 1]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    }
 }
 
 
@@ -202,6 +239,8 @@ __device__ __forceinline__ uint4 prologue<float>(uint4 v, const float* ps, const
     }
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
+template <>
+__device__ __forceinline__ uint4 prologue<f16x3_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue<float>(v, ps, pb, c, relu); }
 template <>
 __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
     uint32_t u[4] = {v.x, v.y, v.z, v.w};

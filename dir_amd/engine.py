@@ -10,13 +10,14 @@ on torch's current stream so the whole forward can be captured in a HIP graph (t
 State-dict keys are the reference's (963 keys, tests/golden/manifest_dir.json).
 """
 import ctypes as C
+import math
 import os
 import threading
 
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X3, DT_F32, ConvDesc
 
 F32 = torch.float32
 IMAGENET_MEAN = (C.c_float * 3)(0.485, 0.456, 0.406)      # apps/eval.py:49-50
@@ -28,6 +29,12 @@ _TLS = threading.local()      # .variant: DIR_CONV_VARIANT every conv of THIS th
 
 def _forced_variant():
     return getattr(_TLS, 'variant', None)
+
+
+def _packing_arith():
+    """'f16x3' while a DirEngine(dtype=float32, arith='f16x3') packs its parameters (per thread): every fp32 convolution built meanwhile
+    takes the split-precision arithmetic (include/dir_hip.h: DIR_DT_F16X3), else None"""
+    return getattr(_TLS, 'arith', None)
 
 
 def _ann(family, flops, nbytes, shape):
@@ -76,11 +83,18 @@ def pack_stream_weights(w_nk):
 class ConvOp(object):
     """one dir_conv2d_forward call with packed parameters"""
     def __init__(self, w_oihw, dtype, stride=1, pad=0, scale=None, shift=None, relu=False, pre=None, pre_relu=False,
-                 out_dtype=None):
+                 out_dtype=None, arith=None):
         self.w = w_oihw.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
         self.cout, self.kh, self.kw, self.cin = self.w.shape
         self.stride, self.pad, self.dtype = stride, pad, dtype
         self.out_dtype = out_dtype or dtype
+        self.arith = (arith or _packing_arith()) if dtype == torch.float32 else None
+        self.in_code = DT_F16X3 if self.arith == 'f16x3' else _dt(dtype)
+        self.in_scale = 1.0                # f16x3: power of two applied to the activations before the split (set_in_scale / DirEngine.calibrate)
+        if self.arith == 'f16x3':          # fp32 tensors, f16 hi / lo split arithmetic: weights split + pre-scaled here, 1 / p_n into the scale
+            from .functional import pack_f16x3_weights
+            self.w, scale = pack_f16x3_weights(self.w.reshape(self.cout, -1), scale)
+            self.scale0 = scale.float().contiguous()          # the epilogue scale at in_scale = 1
         self.scale = None if scale is None else scale.float().contiguous()
         self.shift = None if shift is None else shift.float().contiguous()
         self.pre_scale, self.pre_shift = (None, None) if pre is None else (pre[0].contiguous(), pre[1].contiguous())
@@ -96,22 +110,37 @@ class ConvOp(object):
                 and self.cin % 64 == 0 and self.cout % 128 == 0 and self.cin <= 2304):
             self.w_stream = pack_stream_weights(self.w.reshape(self.cout, self.cin))
 
+    def set_in_scale(self, s):
+        """f16x3: multiply the activations by the power of two `s` before the hi / lo split; 1 / s goes into the epilogue scale (exact)"""
+        assert self.arith == 'f16x3' and s > 0 and math.frexp(s)[0] == 0.5
+        self.in_scale = float(s)
+        self.scale.copy_(self.scale0 / s)
+
+    def _calibrate(self, xs):
+        """DirEngine.calibrate: pick in_scale from this batch -- the largest |activation| the layer reads lands in [2^9, 2^10)"""
+        amax = max(float(t.abs().max()) for t in xs)
+        if self.pre_scale is not None:     # the split sees relu(x * ps + pb): bound it by |x| max * |ps| max + |pb| max
+            amax = amax * float(self.pre_scale.abs().max()) + float(self.pre_shift.abs().max())
+        self.set_in_scale(2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0)
+
     def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None):
         B, H, W, cbuf = x.shape
+        if self.arith == 'f16x3' and getattr(_TLS, 'calibrating', False):
+            self._calibrate([x[..., in_coff:in_coff + self.cin]] if self.in_cs_override is None else [x])
         ho = self.ho or (H + 2 * self.pad - self.kh) // self.stride + 1
         wo = self.wo or (W + 2 * self.pad - self.kw) // self.stride + 1
         if out is None:
             out = torch.empty(B, ho, wo, self.cout, device=x.device, dtype=self.out_dtype)
         d = ConvDesc(B, H, W, self.cin, self.in_cs_override or cbuf, in_coff, self.cout, out.shape[3], out_coff,
                      residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
-                     _dt(self.dtype), _dt(out.dtype), self.flags, self.ho, self.wo)
+                     self.in_code, _dt(out.dtype), self.flags, self.ho, self.wo, self.in_scale)
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         if _capi.PROFILE is not None:
             nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
                       + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
             _capi.annotate(family='conv', flops=2.0 * B * ho * wo * self.cout * self.alg_k, bytes=nbytes, op=self,
-                           dtype='f32' if self.dtype == F32 else 'bf16',
+                           dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),
                            shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
                                                               self.kw, self.stride))
         if v == STREAM_VARIANT and self.w_stream is not None and residual is None and bbox is None and out.dtype == torch.bfloat16:
@@ -183,6 +212,13 @@ class DualConvOp(object):
         self.cin2, self.stride2, self.dtype = wds.shape[1], stride2, dtype
         w = torch.cat([w3.float().flatten(1) * s3.float()[:, None], wds.float().flatten(1) * sds.float()[:, None]], 1)
         self.w = w.contiguous().to(dtype)                                    # [Cout][Cin + Cin2]
+        self.arith = _packing_arith() if dtype == torch.float32 else None
+        self.scale = None
+        if self.arith == 'f16x3':          # split-precision rows; their power-of-two prescale comes back out through a scale vector
+            from .functional import pack_f16x3_weights
+            self.w, self.scale = pack_f16x3_weights(self.w)
+            self.scale0 = self.scale.clone()
+        self.in_scale = 1.0
         self.shift = (h3.float() + hds.float()).contiguous()
         self.kh = self.kw = self.stride = 1
         self.pre_scale = None
@@ -191,12 +227,17 @@ class DualConvOp(object):
         if dtype == torch.bfloat16 and self.cin % 64 == 0 and self.cin2 % 64 == 0 and self.cout % 128 == 0:
             self.w_stream = pack_stream_weights(self.w)
 
+    set_in_scale = ConvOp.set_in_scale
+    pre_scale = None
+
     def __call__(self, y, x, out=None, out_coff=0):
         B, H, W, cbuf = y.shape
+        if self.arith == 'f16x3' and getattr(_TLS, 'calibrating', False):
+            ConvOp._calibrate(self, [y[..., :self.cin], x[..., :self.cin2]])
         if out is None:
             out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
-        d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, _dt(self.dtype), _dt(self.dtype),
-                     CONV_RELU if self.relu else 0, 0, 0)
+        d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0,
+                     DT_F16X3 if self.arith == 'f16x3' else _dt(self.dtype), _dt(self.dtype), CONV_RELU if self.relu else 0, 0, 0, self.in_scale)
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
@@ -204,12 +245,17 @@ class DualConvOp(object):
             es, m = y.element_size(), B * H * W
             _capi.annotate(family='conv', flops=2.0 * m * self.cout * (self.cin + self.cin2), op=self,
                            bytes=(m * self.cin + m * self.cin2 + self.w.numel() + m * self.cout) * es,
-                           dtype='f32' if self.dtype == F32 else 'bf16',
+                           dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),
                            shape='M=%d N=%d K=%d+%d dual s%d' % (m, self.cout, self.cin, self.cin2, self.stride2))
         if v == STREAM_VARIANT and self.w_stream is not None:
             d.flags &= 0xff
             _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w_stream), None, _capi.ptr(self.shift),
                                                                None, None, _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
+            return out
+        if self.scale is not None:
+            _capi.check(_capi.lib().dir_conv2d_dual_scaled_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
+                                                                   _capi.ptr(self.shift), _capi.ptr(out), _capi.stream_ptr()),
+                        'dir_conv2d_dual_scaled_forward')
             return out
         _capi.check(_capi.lib().dir_conv2d_dual_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.shift),
                                                         _capi.ptr(out), _capi.stream_ptr()), 'dir_conv2d_dual_forward')
@@ -669,15 +715,25 @@ def run_mano_pair(tables_lr, para_l, para_r, B, flags=None, mesh_uv=False):
 
 
 class DirEngine(object):
-    def __init__(self, state_dict, dtype=torch.bfloat16, root_joint=0, device='cuda', sparse_fusion=True):
+    def __init__(self, state_dict, dtype=torch.bfloat16, root_joint=0, device='cuda', sparse_fusion=True, arith=None):
+        """dtype bfloat16: the throughput mode (BASELINE config 2); float32: fp32 feature maps, exact fp32 matrix-core arithmetic
+        everywhere (the parity mode of rounds 1-2); float32 with arith='f16x3': the same fp32 feature maps and token path, the
+        convolutions on the f16 matrix cores in split precision (3 products per multiply, DIR_DT_F16X3) -- meets the same 1e-4 mm
+        budget several times faster."""
         assert dtype in (torch.bfloat16, torch.float32)
+        assert arith in (None, 'f16x3') and (arith is None or dtype == torch.float32)
+        self.arith = arith
         self.tuned_batches = set()
         self.sparse_fusion = sparse_fusion     # skip all-zero (tap, bone) K-slabs in the fusion conv (bit-identical)
         _capi.lib()
         self.dtype, self.device = dtype, torch.device(device)
         sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
         self.keep = []
-        self._pack(sd, root_joint)
+        _TLS.arith = arith
+        try:
+            self._pack(sd, root_joint)
+        finally:
+            _TLS.arith = None
 
     # ------------------------------------------------------------------------------------------ packing
     def _pack(self, sd, root_joint):
@@ -962,6 +1018,26 @@ class DirEngine(object):
             op.variant[B_to] = op.variant.get(B_from, 0)
         self._tuned_order[B_to] = self._tuned_order[B_from]
         self.tuned_batches.add(B_to)
+
+    # ------------------------------------------------------------------------------------------ f16x3 calibration
+    calibrated = False
+
+    def calibrate(self, img):
+        """arith='f16x3' only: one eager forward on `img` during which every convolution records the largest |activation| it reads and
+        sets its power-of-two input scale so that this maximum lands in [2^9, 2^10) of the f16 range (include/dir_hip.h: in_scale): 64x
+        headroom before values saturate at 65504, full 22-bit operand accuracy down to max / 4096.  Each layer is re-scaled BEFORE it
+        runs, so the activations further down are already those of the calibrated network.  Host synchronisations: not capturable; call
+        it once per engine on a representative batch (DIR.forward and bench.py do, on the first batch they see).  Without it in_scale is
+        1 everywhere: correct for activations inside [2^-3, 65504), saturating beyond."""
+        if self.arith != 'f16x3':
+            return
+        _TLS.calibrating = True
+        try:
+            self.forward(img)
+            torch.cuda.synchronize(self.device)
+        finally:
+            _TLS.calibrating = False
+        self.calibrated = True
 
     # ------------------------------------------------------------------------------------------ forward
     _flags = None

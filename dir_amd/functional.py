@@ -3,7 +3,7 @@ Feature maps are NHWC torch tensors (float32 or bfloat16) on the GPU."""
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X3, DT_F32, ConvDesc
 
 
 def _dt(t):
@@ -19,12 +19,32 @@ def pack_conv_weight(w_oihw, dtype=torch.float32):
     return w_oihw.detach().permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
+def pack_f16x3_weights(w_rows, scale=None):
+    """The weight operand of DIR_DT_F16X3 (include/dir_hip.h) from fp32 rows [Cout, K] (K % 32 == 0; K = kh*kw*Cin of an OHWI tensor, or
+    [kh*kw*Cin | Cin2] of a dual convolution): every row is scaled by a power of two p_n so that max |w_n| p_n lies in [2^12, 2^13)
+    (exact), split into hi = f16(w p) and lo = f16(w p - hi) and stored per 32-column slab as [32 hi | 32 lo].
+    -> (float16 tensor [Cout, K/32, 2, 32] -- the bytes of the fp32 tensor it replaces --, scale / p as fp32 [Cout])"""
+    w = w_rows.detach().float()
+    Cout, K = w.shape
+    assert K % 32 == 0
+    amax = w.abs().amax(1)
+    _, e = torch.frexp(amax)                                 # amax = m * 2^e, m in [0.5, 1)
+    e = torch.where(amax > 0, e, torch.full_like(e, 13)).clamp(-100, 100)
+    p = torch.ldexp(torch.ones_like(amax), 13 - e)           # amax * p in [2^12, 2^13)
+    ws = w * p[:, None]                                      # exact: a power of two
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    packed = torch.stack([hi.view(Cout, K // 32, 32), lo.view(Cout, K // 32, 32)], 2).contiguous()
+    sc = (torch.ones_like(p) if scale is None else scale.detach().float().to(p.device)) / p
+    return packed, sc.contiguous()
+
+
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
-                res_coff=0, splits=1, workspace=None):
+                res_coff=0, splits=1, workspace=None, arith=None, variant=0):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
-    if None)."""
+    if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
     _capi.require_cuda(x, w_ohwi, scale, shift, residual, pre_scale, pre_shift, out)
     assert x.is_contiguous() and w_ohwi.is_contiguous() and x.dim() == 4
     B, H, W, cbuf = x.shape
@@ -32,6 +52,18 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
     if cin is None:
         cin = Cin
     assert cin == Cin and w_ohwi.dtype == x.dtype
+    assert arith in (None, 'f16x3')
+    in_scale = 0.0
+    if arith == 'f16x3':
+        assert x.dtype == torch.float32 and splits == 1
+        w_ohwi, scale = pack_f16x3_weights(w_ohwi.reshape(Cout, -1), scale)
+        # input scale as DirEngine.calibrate picks it: the largest |activation| the split sees lands in [2^9, 2^10)
+        import math
+        amax = float(x[..., in_coff:in_coff + Cin].abs().max())
+        if pre_scale is not None:
+            amax = amax * float(pre_scale.abs().max()) + float(pre_shift.abs().max())
+        in_scale = 2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0
+        scale = scale / in_scale
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     if out is None:
@@ -45,8 +77,8 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
     for v in (pre_scale, pre_shift):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cin and v.is_contiguous())
     d = ConvDesc(B, H, W, Cin, cbuf, in_coff, Cout, out.shape[3], out_coff,
-                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, _dt(x), _dt(out),
-                 (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0))
+                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, DT_F16X3 if arith == 'f16x3' else _dt(x), _dt(out),
+                 (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0) | ((variant & 0xff) << 8), 0, 0, in_scale)      # variant: DIR_CONV_VARIANT code
     with torch.cuda.device(x.device):
         if splits > 1:
             if workspace is None:

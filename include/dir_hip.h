@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 24
+#define DIR_ABI_VERSION 25
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -219,6 +219,20 @@ int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h
 #define DIR_DT_F32 0
 #define DIR_DT_BF16 1
 #define DIR_DT_U8 2 /* input images only (dir_stem_pool_forward) */
+/* dir_conv2d_* only, as in_dtype (out_dtype = DIR_DT_F32): "split precision".  Tensors are fp32 in memory; every product a*w is
+ * evaluated on the f16 matrix cores as hi(a)*hi(w) + lo(a)*hi(w) + hi(a)*lo(w) with hi(x) = f16(x), lo(x) = f16(x - hi(x)) and fp32
+ * accumulation: 22 significant bits per operand (error ~2^-22 |a w| per product, below the fp32 accumulation noise of any K >= 8
+ * reduction) at 3 instead of 16 matrix-core cycles per product of the exact fp32 path.  This is the mode that meets the 1e-4 mm parity
+ * budget at several times the fp32 mode's speed.  The caller passes the WEIGHTS already split:
+ *   w = f16 [Cout][kh][kw][Cin/32][2][32]   (per 32-channel slab: 32 hi values, then the 32 lo values; the same bytes / addressing as
+ *                                            the fp32 tensor [Cout][kh][kw][Cin]; for dir_conv2d_dual_* the rows are [kh*kw*Cin | Cin2])
+ * of the weights PRE-SCALED per output channel n by a power of two p_n chosen so that max |w_n| p_n lies in [2^12, 2^13) (their lo
+ * parts are then normal f16 numbers), with 1 / p_n folded into scale[n] (dir_amd/functional.py::pack_f16x3_weights).  The ACTIVATIONS
+ * are split inside the kernel after multiplication by dir_conv_desc.in_scale, a power of two the caller picks per layer so that the
+ * layer's typical maximum lands near 2^9 (dir_amd/engine.py::DirEngine.calibrate): 64x headroom below the f16 maximum 65504 (beyond it
+ * values saturate), full 22-bit accuracy down to max / 4096, below that an absolute floor of 2^-25 / in_scale per element (f16 denormal
+ * lo parts, which the matrix cores honour: tools/ubench_f16_denorm.hip).  Cin % 32 == 0 as for fp32. */
+#define DIR_DT_F16X3 3
 #define DIR_CONV_RELU 1
 #define DIR_CONV_PRE_RELU 2
 /* Optional kernel choice in bits 8..15 of dir_conv_desc.flags (0 = the library's per-layer heuristic).  Every variant
@@ -238,6 +252,9 @@ typedef struct dir_conv_desc {
     int32_t in_dtype, out_dtype; /* DIR_DT_*; residual is read in out_dtype */
     int32_t flags;               /* DIR_CONV_* */
     int32_t Ho, Wo;              /* 0 = (H + 2*pad - kh)/stride + 1 ; set explicitly for the pre-padded stem image */
+    float in_scale;              /* DIR_DT_F16X3 only (0 = 1): a power of two the activations (after the pre-activation, both sources of a
+                                    dual convolution) are multiplied by before the f16 hi / lo split, to centre them in the f16 range;
+                                    the caller folds 1 / in_scale into scale[].  Scaled values are clamped to +-65504 (no inf / nan). */
 } dir_conv_desc;
 
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
@@ -283,6 +300,10 @@ typedef struct dir_conv_src2 {
 } dir_conv_src2;
 int dir_conv2d_dual_forward(const dir_conv_desc* desc, const void* x, const dir_conv_src2* src2, const void* x2, const void* w,
                             const float* shift, void* y, void* stream);
+/* the same with a per-output-channel scale applied to the SUM of both sources before the shift (needed by DIR_DT_F16X3, whose weight
+ * rows carry a power-of-two prescale; scale may be NULL = dir_conv2d_dual_forward) */
+int dir_conv2d_dual_scaled_forward(const dir_conv_desc* desc, const void* x, const dir_conv_src2* src2, const void* x2, const void* w,
+                                   const float* scale, const float* shift, void* y, void* stream);
 
 /* The HBM-bound 1x1 convolutions (bf16 in / out, stride 1) as a streaming kernel: small synchronous workgroups (128 pixels x
  * 128 | 256 output channels), several per CU, activations global -> registers -> LDS two K-chunks ahead, weights straight

@@ -39,10 +39,14 @@ def nchw(t):
     return t.float().permute(0, 3, 1, 2).contiguous().cpu().numpy()
 
 
-def test_engine_fp32_vs_reference_golden(golden, dir_state):
+@pytest.mark.parametrize('arith', [None, 'f16x3'])
+def test_engine_fp32_vs_reference_golden(golden, dir_state, arith):
+    """the two modes that meet north_star's 1e-4 mm: exact fp32 matrix-core arithmetic, and the split-precision convolutions
+    (DIR_DT_F16X3: f16 hi / lo operands, 3 products per multiply, fp32 accumulation) on the same fp32 feature maps / token path"""
     g = golden('g7_dir')
     sd, img = dir_state
-    eng = DirEngine(sd, dtype=torch.float32)
+    eng = DirEngine(sd, dtype=torch.float32, arith=arith)
+    eng.calibrate(img)                      # f16x3: per-layer power-of-two input scales from this batch (no-op otherwise)
     taps = {}
     outs = eng.forward(img, taps=taps)
     torch.cuda.synchronize()
@@ -57,7 +61,7 @@ def test_engine_fp32_vs_reference_golden(golden, dir_state):
         for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_proj_left', 'pd_proj_right', 'pd_offset'):
             assert maxabs(outs[i][k].cpu().numpy(), g['s%d.%s' % (i, k)]) < 5e-4, (i, k)
         assert outs[i]['pd_rel_joint'] is None
-    print('fp32 engine: worst |xyz - reference| = %.3e m (%.2e mm)' % (worst, worst * 1e3))
+    print('fp32 engine (arith=%s): worst |xyz - reference| = %.3e m (%.2e mm)' % (arith, worst, worst * 1e3))
     # north_star: joint / vertex positions within 1e-4 mm = 1e-7 m of the reference: the gate IS that tolerance (measured 7.5e-8 m)
     assert worst < 1e-7
     assert relerr(outs[3]['seg'].cpu().numpy(), g['seg']) < 5e-4
