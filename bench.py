@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 # on 8 queues 2.23 ms).  Must be set before the runtime initialises; an explicit setting of the user wins.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}        # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK = {'bf16': 2.5e15, 'f32': 157.3e12,         # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+        'f16x3': 2.5e15 / 3}                     # split precision: three f16 MFMAs (dense f16 peak = bf16's) per algorithmic product
 ALG_GFLOP_PER_IMAGE = 36.80                     # BASELINE.md section 2 (reference, torch flop counter)
 HBM_PEAK = 8.0e12                               # bytes/s, same guide
 
@@ -246,8 +247,7 @@ def main():
         del pipe2
 
     # ---- roofline: HIP events around every library call, eager, same stream
-    roof = None
-    if rank == 0:
+    def live_roofline(eng, img, dtype_key, ms_per_step, with_traffic=True):
         eng.overlap = False                       # per-kernel durations: no concurrent side-stream launches
         reps = 3
         _capi.PROFILE = []
@@ -280,7 +280,7 @@ def main():
         traffic, traffic_src = None, None
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
-        if pm and args.dtype == 'bf16' and B == 64:
+        if pm and dtype_key == 'bf16' and B == 64 and with_traffic:
             with open(pm[-1]) as f:
                 pj = json.load(f)
             traffic = round(pj['hbm_bytes_per_launch'])
@@ -288,17 +288,17 @@ def main():
                            'file, not re-measured inside this run: counters need their own rocprofv3 passes)' % pj.get('head', 'unrecorded'))
         # the conv family spans both regimes (K <= 512 1x1 layers stream, the 3x3 layers compute): price the aggregate
         # against both roofs and report the one it sits closer to as the binding one
-        frac_mfma, frac_hbm = achieved / PEAK[args.dtype], hbm_rate / HBM_PEAK
+        frac_mfma, frac_hbm = achieved / PEAK[dtype_key], hbm_rate / HBM_PEAK
         fam = 'conv family: ' + ' + '.join(sorted({k for r in conv for k in r['kernels'].split(',')}))
         if frac_hbm >= frac_mfma:
             head = {'bound': 'hbm', 'kernel': fam, 'achieved': round(hbm_rate / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': round(frac_hbm, 4)}
         else:
-            head = {'bound': 'mfma', 'kernel': fam, 'achieved': round(achieved / 1e12, 2), 'peak': PEAK[args.dtype] / 1e12,
+            head = {'bound': 'mfma', 'kernel': fam, 'achieved': round(achieved / 1e12, 2), 'peak': PEAK[dtype_key] / 1e12,
                     'unit': 'TFLOP/s', 'frac': round(frac_mfma, 4)}
         # the same launches split by arithmetic intensity against the machine balance (peak FLOP/s : peak B/s): each class priced
         # against the roof that bounds it
-        balance = PEAK[args.dtype] / HBM_PEAK
+        balance = PEAK[dtype_key] / HBM_PEAK
         cls = {'hbm': [0, 0.0, 0.0, 0.0], 'mfma': [0, 0.0, 0.0, 0.0]}
         for r in conv:
             c = cls['hbm' if r['flops'] / r['bytes'] < balance else 'mfma']
@@ -307,12 +307,12 @@ def main():
         for k, (n, ms, fl, by) in cls.items():
             if n:
                 ach = (by if k == 'hbm' else fl) / (ms * 1e-3)
-                pk = HBM_PEAK if k == 'hbm' else PEAK[args.dtype]
+                pk = HBM_PEAK if k == 'hbm' else PEAK[dtype_key]
                 by_class[k] = {'launches_per_step': n // reps, 'ms_per_step': round(ms / reps, 3),
                                'achieved': round(ach / (1e9 if k == 'hbm' else 1e12), 1), 'unit': 'GB/s' if k == 'hbm' else 'TFLOP/s',
                                'frac': round(ach / pk, 4)}
         executed = sum(r.get('flops', 0.0) for r in recs) / reps
-        roof = dict(head, by_class=by_class, traffic=traffic, traffic_source=traffic_src, frac_mfma=round(frac_mfma, 4), frac_hbm=round(frac_hbm, 4),
+        return dict(head, by_class=by_class, traffic=traffic, traffic_source=traffic_src, frac_mfma=round(frac_mfma, 4), frac_hbm=round(frac_hbm, 4),
                     achieved_tflops=round(achieved / 1e12, 2), achieved_gbps=round(hbm_rate / 1e9, 1),
                     alg_bytes_per_launch=round(bytes_per_launch),
                     launches_per_step=n_launch, avg_launch_us=round(ms_per_launch * 1e3, 2),
@@ -323,7 +323,10 @@ def main():
                     # fast the reference's arithmetic would have to run to keep up -- not a utilisation)
                     executed_tflops=round(executed / (ms_per_step * 1e-3) / 1e12, 2),
                     effective_reference_tflops=round(ALG_GFLOP_PER_IMAGE * 1e9 * B / (ms_per_step * 1e-3) / 1e12, 2),
-                    kernels=kernel_table(recs, reps, args.dtype))
+                    kernels=kernel_table(recs, reps, dtype_key))
+
+
+    roof = live_roofline(eng, img, args.dtype, ms_per_step) if rank == 0 else None
 
     # ---- fp32 exact-parity mode (the mode that meets the 1e-4 mm budget, tests/test_gpu_dir.py): one graph, a few steps
     fp32 = None
@@ -342,6 +345,42 @@ def main():
         fp32 = {'images_per_sec': round(B * 5 / d32, 1), 'ms_per_step': round(d32 / 5 * 1e3, 3), 'steps': 5, 'regions': 3,
                 'note': 'DirEngine(dtype=float32): exact fp32 MFMA everywhere, the mode the 1e-4 mm parity tests run; one forward in flight'}
         del g32, eng32
+
+    # ---- split-precision parity mode (DirEngine(dtype=float32, arith='f16x3'): fp32 feature maps and token path, convolutions on the
+    #      f16 matrix cores with hi / lo operands, 3 products per multiply): the 1e-4 mm tests pass in it as in the exact-fp32 mode
+    #      (tests/test_gpu_dir.py::test_engine_fp32_vs_reference_golden[f16x3]); first-class sub-record with its own roofline
+    parity = None
+    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_fp32_mode and not args.no_graph:
+        engx = E.DirEngine(sd, dtype=torch.float32, device=dev, arith='f16x3')
+        engx.calibrate(img)
+        engx.forward(img)
+        sync()
+        if not args.no_autotune:
+            engx.autotune(img)
+        nslot = max(1, min(args.inflight, 4))
+        imgs_x = [img] + [torch.randn(B, 3, 256, 256, device=dev, generator=g) for _ in range(nslot - 1)]
+        pipex = E.ForwardPipeline(engx, imgs_x)
+        cx = [0]
+
+        def stepx():
+            pipex.launch(cx[0] % nslot)
+            cx[0] += 1
+        for _ in range(3):
+            pipex.launch(0)
+        sync()
+        r1 = timed_regions(lambda: pipex.launch(0), 5, 3, sync, float, sync)
+        for _ in range(args.warmup):
+            stepx()
+        rx = timed_regions(stepx, 10, 3, sync, float, sync)
+        dx, d1 = statistics.median(rx), statistics.median(r1)
+        parity = {'images_per_sec': round(B * 10 / dx, 1), 'ms_per_step': round(dx / 10 * 1e3, 3), 'steps': 10, 'regions': 3,
+                  'forwards_in_flight': nslot, 'ms_per_forward_one_in_flight': round(d1 / 5 * 1e3, 3), 'dtype': 'f16x3',
+                  'speedup_over_fp32_mode': None if fp32 is None else round(fp32['ms_per_step'] / (dx / 10 * 1e3), 2),
+                  'note': "DirEngine(dtype=float32, arith='f16x3'): fp32 feature maps / token path, every convolution product as three f16 "
+                          'MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulate); meets the 1e-4 mm budget like fp32_mode (8.0e-8 m vs the reference '
+                          'golden); roofline priced against the dense f16 peak / 3',
+                  'roofline': live_roofline(engx, img, 'f16x3', dx / 10 * 1e3, with_traffic=False)}
+        del pipex, engx
 
     # ---- CPU baselines on the host cores (rank 0, single-GPU runs only), bounded samples:
     #   port        the numpy oracle (CPU restatement of the reference).  OpenBLAS is pinned to the thread count that serves these
@@ -405,7 +444,7 @@ def main():
                            'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
-                'roofline': roof, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'without_proj_feat': no_pf}
+                'roofline': roof, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'without_proj_feat': no_pf}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -76,7 +76,7 @@ class InitHeadParams(C.Structure):
 
 
 class BoneFusionParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('w_g', 'scale', 'shift')]
+    _fields_ = [(n, C.c_void_p) for n in ('w_g', 'scale', 'shift')] + [('exact_f32', C.c_int32)]
 
 
 class EvalInputs(C.Structure):

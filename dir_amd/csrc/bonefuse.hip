@@ -40,13 +40,14 @@ constexpr int NTAP = 9;
 struct GArgs {
     const float* w_g;     // [9][40][64][256]
     const float* emb;     // [B][42][64]
-    unsigned* g;          // [B][9][40][256] words = (bf16 end 0) | (bf16 end 1) << 16
+    unsigned* g;          // [B][9][40][256] words = (bf16 end 0) | (bf16 end 1) << 16;  F32: float2 (end 0, end 1) instead
     int B;
     long long* stamps;    // DIR_STAMPS=bone_g (tuning aid, else NULL)
 };
 
 constexpr int G_ROWS = 128, G_LD = 66;      // (sample, end) rows per pass; lda % 32 == 2 (dir_mfma.h)
 
+template <bool F32>
 __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
     __shared__ float s_f[G_ROWS * G_LD];
     const int tap = blockIdx.x / 40, hb = blockIdx.x - tap * 40, hand = hb / 20, bone = hb - hand * 20;
@@ -89,9 +90,11 @@ __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const int b = b0 + m * 8 + 2 * (lane >> 4) + s;
-                    if (b < a.B)
-                        a.g[(((long long)b * NTAP + tap) * 40 + hb) * NCOUT + n] =
-                            (unsigned)f2bf(acc[m][2 * s]) | ((unsigned)f2bf(acc[m][2 * s + 1]) << 16);
+                    if (b < a.B) {
+                        const long long o = (((long long)b * NTAP + tap) * 40 + hb) * NCOUT + n;
+                        if constexpr (F32) reinterpret_cast<float2*>(a.g)[o] = make_float2(acc[m][2 * s], acc[m][2 * s + 1]);
+                        else a.g[o] = (unsigned)f2bf(acc[m][2 * s]) | ((unsigned)f2bf(acc[m][2 * s + 1]) << 16);
+                    }
                 }
         }
     }
@@ -237,10 +240,134 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
     stamp();
 }
 
+
+// ---------------------------------------------------------------------------------------------------- fuse, exact fp32
+// The same factorisation with fp32 operands on the exact fp32 matrix cores (v_mfma_f32_32x32x2_f32: products exact, fp32 accumulate)
+// for the parity modes (DirEngine(dtype=float32)): no rounding of Wgt, G or the weights, so the only difference from the reference's
+// bone_proj + conv3x3 is the association of the sum -- fp32 rounding noise, like any other summation order.  One workgroup per
+// (sample, 128-pixel strip, 128 output channels); patch rows and G tile rows are 80 floats at a 336-byte pitch (21 x 16 B: conflict-free
+// ds_read_b128); MFMA step t consumes e = t from lanes 0-31 and e = 40 + t from lanes 32-63 (any bijection of the reduction index is
+// legal as long as both operands use it), so every lane reads ITS 40 values as ten 16-byte loads per tap.
+constexpr int F32_PITCH = 336, F32_MAX_ROWS = 208, F32_BM = 128;
+
+__global__ __launch_bounds__(512, 1) void bone_fuse_f32_kernel(FuseArgs a) {
+    constexpr int MI = 1, NJ = 2, WM = 4, WN = 2, NT = 512, BM = F32_BM, BN = 128;
+    constexpr int P_BYTES = F32_MAX_ROWS * F32_PITCH, G_BYTES = BN * F32_PITCH;
+    constexpr int STAGE_BYTES = BM * BN * 4;
+    constexpr int SMEM = P_BYTES + 2 * G_BYTES > STAGE_BYTES ? P_BYTES + 2 * G_BYTES : STAGE_BYTES;
+    constexpr int GW = 40 * BN / NT;                                 // G float2 words per thread per tap (10)
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    __shared__ float s_uv[84];
+    __shared__ float s_bone[40 * 6];
+
+    const int S = a.S, hw = S * S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int tn = blockIdx.x & 1, tm = blockIdx.x >> 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int b = m0 / hw, y0 = (m0 - b * hw) / S;
+
+    const float2* gsrc = reinterpret_cast<const float2*>(a.g) + ((long long)b * NTAP * 40) * NCOUT + n0;
+    float2 greg[GW];
+    auto g_load = [&](int tap) {
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int w = tid + NT * k, hb = w / BN, n = w - hb * BN;
+            greg[k] = gsrc[((long long)tap * 40 + hb) * NCOUT + n];
+        }
+    };
+    auto g_store = [&](int buf) {
+        char* gb = smem + P_BYTES + buf * G_BYTES;
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            const int w = tid + NT * k, hb = w / BN, n = w - hb * BN;
+            *reinterpret_cast<float2*>(gb + n * F32_PITCH + hb * 8) = greg[k];
+        }
+    };
+    g_load(0);
+
+    if (tid < 84) {
+#pragma clang fp contract(off)
+        const int hand = tid / 42, r = tid - hand * 42;
+        const float v = a.uv[hand][(long long)b * 42 + r];
+        s_uv[tid] = (v + 1.f) / 2.f * (float)S;                      // models/dir.py:150
+    }
+    __syncthreads();
+    if (tid < 40) {
+        const int hand = tid / 20, bone = tid - hand * 20;
+        const float* uv = s_uv + hand * 42;
+        const int pa = kParent[bone], ch = kChild[bone];
+        float dx, dy;
+        dir::bone::bone_dir(uv[2 * pa], uv[2 * pa + 1], uv[2 * ch], uv[2 * ch + 1], dx, dy);
+        float* sb = s_bone + 6 * tid;
+        sb[0] = uv[2 * pa]; sb[1] = uv[2 * pa + 1]; sb[2] = uv[2 * ch]; sb[3] = uv[2 * ch + 1]; sb[4] = dx; sb[5] = dy;
+    }
+    __syncthreads();
+    for (int i = tid; i < a.npr * 40; i += NT) {
+        const int hb = convk::div_magic(i, a.mg_npr, a.sh_npr), prow = i - hb * a.npr;
+        const int py = convk::div_magic(prow, a.mg_pw, a.sh_pw), px = prow - py * a.PW;
+        const int iy = y0 + py - 1, ix = px - 1;                      // 3x3, pad 1
+        float2 word = make_float2(0.f, 0.f);
+        if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+            const float* sb = s_bone + 6 * hb;
+            float wa, wb;
+            if (dir::bone::bone_weights_fast((float)ix + 0.5f, (float)iy + 0.5f, sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], a.distance, wa, wb))
+                word = make_float2(wa, wb);                            // torch.where(mask, v, 0), models/dir.py:172
+        }
+        *reinterpret_cast<float2*>(smem + prow * F32_PITCH + hb * 8) = word;
+    }
+    g_store(0);
+    __syncthreads();
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int pr0;
+    {
+        const int r = wm * 32 + (lane & 31);
+        const int y = r / S, x = r - y * S;
+        pr0 = y * a.PW + x;
+    }
+    const int hoff = (lane >> 5) * 160;                               // this lane's 40 of the 80 reduction indices
+    const int frag_b = (wn * NJ * 32 + (lane & 31)) * F32_PITCH + hoff;
+
+    for (int tap = 0; tap < NTAP; ++tap) {
+        if (tap + 1 < NTAP) g_load(tap + 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* gb = smem + P_BYTES + (tap & 1) * G_BYTES + frag_b;
+        const char* pa = smem + (pr0 + ky * a.PW + kx) * F32_PITCH + hoff;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const float4 fa = *reinterpret_cast<const float4*>(pa + q * 16);
+            float4 fb[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const float4*>(gb + j * 32 * F32_PITCH + q * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[0][j], 0, 0, 0);
+            }
+        }
+        if (tap + 1 < NTAP) g_store((tap + 1) & 1);
+        __syncthreads();
+    }
+    ConvArgs c = a.c;
+    epilogue_tile<float, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
 }  // namespace
 }  // namespace dir
 
-extern "C" size_t dir_bone_fusion_scratch_bytes(int B) { return (size_t)(B > 0 ? B : 0) * dir::NTAP * 40 * dir::NCOUT * 4; }
+// (sized for the exact-fp32 variant, float2 per (tap, hand-bone, channel); the bf16 variant uses the first half)
+extern "C" size_t dir_bone_fusion_scratch_bytes(int B) { return (size_t)(B > 0 ? B : 0) * dir::NTAP * 40 * dir::NCOUT * 8; }
 
 extern "C" int dir_bone_fusion_prepare(const dir_bone_fusion_params* p, const float* emb, void* scratch, int B, void* stream) {
     using namespace dir;
@@ -248,7 +375,8 @@ extern "C" int dir_bone_fusion_prepare(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(B >= 0, "dir_bone_fusion_prepare: B=%d", B);
     if (B == 0) return DIR_OK;
     GArgs ga{p->w_g, emb, (unsigned*)scratch, B, stamps_begin("bone_g")};
-    DIR_LAUNCH(bone_g_kernel, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    if (p->exact_f32) DIR_LAUNCH(bone_g_kernel<true>, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    else DIR_LAUNCH(bone_g_kernel<false>, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
     stamps_end("bone_g", ga.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_prepare");
 }
@@ -263,6 +391,7 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(S > 0 && 256 % S == 0 && (S * S) % 256 == 0, "dir_bone_fusion_forward: S=%d (needs 256 %% S == 0 and S*S %% 256 == 0)", S);
     const int ocs = out_cstride ? out_cstride : NCOUT;
     DIR_REQUIRE(ocs % 8 == 0 && out_coff % 8 == 0 && out_coff + NCOUT <= ocs, "dir_bone_fusion_forward: output slice must be 16-byte aligned");
+    const int strip = p->exact_f32 ? F32_BM : 256;                     // output pixels per workgroup
     const long long M = (long long)B * S * S;
     DIR_REQUIRE(M < (1ll << 31), "dir_bone_fusion_forward: too many pixels");
     FuseArgs fa{};
@@ -270,13 +399,15 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     fa.c.M = (int)M; fa.c.Cout = NCOUT; fa.c.out_cs = ocs; fa.c.out_co = out_coff; fa.c.res_cs = 0; fa.c.res_co = 0;
     fa.c.flags = (relu ? 1 : 0) | 4;
     fa.uv[0] = uv_left; fa.uv[1] = uv_right; fa.g = (const unsigned*)scratch; fa.S = S; fa.distance = distance;
-    const int rows = 256 / S;
+    DIR_REQUIRE(strip % S == 0, "dir_bone_fusion_forward: S=%d does not divide the %d-pixel strip", S, strip);
+    const int rows = strip / S;
     fa.PW = S + 2; fa.PH = rows + 2; fa.npr = fa.PH * fa.PW;
-    DIR_REQUIRE(fa.npr <= FUSE_MAX_ROWS, "dir_bone_fusion_forward: halo patch of %d rows does not fit", fa.npr);
+    DIR_REQUIRE(fa.npr <= (p->exact_f32 ? F32_MAX_ROWS : FUSE_MAX_ROWS), "dir_bone_fusion_forward: halo patch of %d rows does not fit", fa.npr);
     convk::magic_u31((unsigned)fa.npr, &fa.mg_npr, &fa.sh_npr);
     convk::magic_u31((unsigned)fa.PW, &fa.mg_pw, &fa.sh_pw);
     fa.stamps = stamps_begin("bone_fuse");
-    DIR_LAUNCH(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    if (p->exact_f32) DIR_LAUNCH(bone_fuse_f32_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    else DIR_LAUNCH(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
     stamps_end("bone_fuse", fa.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_forward");
 }

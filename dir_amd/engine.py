@@ -679,13 +679,16 @@ class StageOp(object):
         s, h = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])
         self.fusion0 = ConvOp(sd[p + '.fusion.0.weight'], dtype, pad=1, scale=s, shift=h, relu=True)
         self.bone_fusion = None
-        if dtype == torch.bfloat16:
-            # factorised bone fusion (dir_bone_fusion_forward): w_g[tap][hb][c][n] = weight[n, hb*64+c, ky, kx], bf16-rounded
-            w = sd[p + '.fusion.0.weight'].detach().to(torch.bfloat16).float()             # [256, 2560, 3, 3]
-            t = dict(w_g=w.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous(), scale=self.fusion0.scale,
-                     shift=self.fusion0.shift)
+        if dtype == torch.bfloat16 or _packing_arith() == 'f16x3':
+            # factorised bone fusion (dir_bone_fusion_forward): w_g[tap][hb][c][n] = weight[n, hb*64+c, ky, kx]; bf16 mode: rounded to
+            # bf16, bf16 matrix cores; f16x3 parity mode: unrounded, everything on the exact fp32 matrix cores (exact_f32 = 1)
+            exact = dtype == torch.float32
+            w = sd[p + '.fusion.0.weight'].detach()
+            w = w.float() if exact else w.to(torch.bfloat16).float()                          # [256, 2560, 3, 3]
+            s_f, h_f = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])                   # (fusion0.scale carries the f16x3 prescale)
+            t = dict(w_g=w.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous(), scale=s_f.to(w.device), shift=h_f.to(w.device))
             keep.append(t)
-            self.bone_fusion = _capi.BoneFusionParams(t['w_g'].data_ptr(), t['scale'].data_ptr(), t['shift'].data_ptr())
+            self.bone_fusion = _capi.BoneFusionParams(t['w_g'].data_ptr(), t['scale'].data_ptr(), t['shift'].data_ptr(), 1 if exact else 0)
         self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
 
 
@@ -858,7 +861,7 @@ class DirEngine(object):
             main, side = torch.cuda.current_stream(), self._side_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                _ann('bone_fusion', 2.0 * B * 9 * 80 * 64 * 256, 9 * 40 * 64 * 256 * 4 + B * 42 * 64 * 4 + B * 9 * 80 * 256 * 4,
+                _ann('bone_fusion', 2.0 * B * 9 * 80 * 64 * 256, 9 * 40 * 64 * 256 * 4 + B * 42 * 64 * 4 + B * 9 * 80 * 256 * (4 if self.dtype == F32 else 2),
                      'B=%d G = f_end . W (9 taps x 80 bone ends x 256)' % B)
                 _capi.check(L.dir_bone_fusion_prepare(st.bone_fusion, _capi.ptr(emb), _capi.ptr(scratch), B, _capi.stream_ptr()),
                             'dir_bone_fusion_prepare')
@@ -867,7 +870,7 @@ class DirEngine(object):
         if factorised:
             main.wait_stream(side)
             fused = torch.empty(B, S, S, 256, device=dev, dtype=self.dtype)
-            _ann('bone_fusion', 2.0 * B * S * S * 256 * 720, B * 9 * 80 * 256 * 4 + B * S * S * 256 * 2 + B * 42 * 2 * 4,
+            _ann('bone_fusion', 2.0 * B * S * S * 256 * 720, (B * 9 * 80 * 256 + B * S * S * 256) * (4 if self.dtype == F32 else 2) + B * 42 * 2 * 4,
                  'B=%d S=%d factorised bone_proj + 3x3 fusion conv (K=720)' % (B, S))
             _capi.check(L.dir_bone_fusion_forward(st.bone_fusion, _capi.ptr(res['pd_joint_uv_left']),
                                                   _capi.ptr(res['pd_joint_uv_right']), _capi.ptr(scratch),

@@ -472,12 +472,16 @@ int dir_regress_forward(const dir_regress_params* params_host, const float* tok,
  * Two launches so that the first can overlap the MANO layer (it needs the token features only):
  *   dir_bone_fusion_prepare : G for every sample from emb [B,42,64] (proj_feat_emb output) into `scratch`
  *                             (dir_bone_fusion_scratch_bytes(B) bytes of device memory);
- *   dir_bone_fusion_forward : uv_* [B,21,2] (pd_joint_uv) + scratch -> y, NHWC bf16 [B,S,S,out_cstride], channels
- *                             [out_coff, out_coff+256).  S in {16, 32, ...} with 256 % S == 0 and S*S % 256 == 0. */
+ *   dir_bone_fusion_forward : uv_* [B,21,2] (pd_joint_uv) + scratch -> y, NHWC bf16 (fp32 with exact_f32) [B,S,S,out_cstride],
+ *                             channels [out_coff, out_coff+256).  S in {16, 32, ...} with 256 % S == 0 and S*S % 256 == 0
+ *                             (exact_f32: 128 % S == 0). */
 typedef struct dir_bone_fusion_params {
     const float* w_g;   /* [9][40][64][256]: fusion.0.weight[n, hb*64 + c, ky, kx] at [ky*3+kx][hb][c][n], rounded to bf16 */
     const float* scale; /* [256] folded fusion.1 BatchNorm scale            */
     const float* shift; /* [256] folded BatchNorm shift (+ fusion.0 bias)   */
+    int32_t exact_f32;  /* 0: bf16 operands (w_g rounded to bf16 by the caller, G and Wgt rounded to bf16, y bf16) -- the throughput mode;
+                           1: everything fp32 on the exact fp32 matrix cores (w_g unrounded, y NHWC fp32) -- the parity modes: differs from
+                           bone_proj + conv3x3 only by the association of the sum (fp32 rounding noise)                                   */
 } dir_bone_fusion_params;
 size_t dir_bone_fusion_scratch_bytes(int B);
 int dir_bone_fusion_prepare(const dir_bone_fusion_params* params_host, const float* emb, void* scratch, int B, void* stream);

@@ -284,6 +284,50 @@ def test_bone_fusion_factorised_vs_oracle(golden, S, dist, B):
     # and the factorised result is at least as close to the float64 value as the materialised bf16 path
     assert maxabs(got, ref) <= 1.25 * maxabs(y2, ref) + 1e-3 * sc
 
+@pytest.mark.parametrize('S,dist,B', [(16, 1, 2), (32, 2, 2), (32, 2, 5)])
+def test_bone_fusion_exact_fp32_vs_oracle(golden, S, dist, B):
+    """dir_bone_fusion_* with exact_f32 = 1 (the f16x3 parity mode's fusion path): unrounded weights, fp32 G and pixel weights, exact fp32
+    matrix cores.  Against the float64 composition bone_proj -> conv3x3 -> scale / shift -> ReLU: 5e-6 of the output scale (the
+    materialised exact-fp32 convolution of the same operands, K = 23040, sits at the same distance: both are fp32 summations of the same
+    products in different orders)."""
+    g = golden('g5_bone')
+    uv0 = g['S%d.uv' % S]
+    rng = np.random.default_rng(17 + S + B)
+    uv_l = np.concatenate([uv0, uv0[::-1]], 0)[:B] if B <= 4 else np.concatenate([uv0, uv0[::-1], uv0[:1] * 0.7], 0)
+    uv_l = np.ascontiguousarray(uv_l, np.float32)
+    uv_r = uv_l.copy(); uv_r[..., 0] *= -0.9
+    emb = synth.synth_input('bonefuse.emb%d' % S, (B, 42, 64), SEED)
+    w = (rng.standard_normal((256, 2560, 3, 3)) * 0.02).astype(np.float32)
+    scale = (1 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    shift = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    img = np.concatenate([OT.bone_proj(uv_l, emb[:, :21], S, dist), OT.bone_proj(uv_r, emb[:, 21:], S, dist)], 1)   # [B,2560,S,S]
+    ref = N.conv2d(img.astype(np.float64), w.astype(np.float64), None, 1, 1)
+    ref = np.maximum(ref * scale[None, :, None, None] + shift[None, :, None, None], 0)
+    L = _capi.lib()
+    dw = torch.from_numpy(w).cuda()
+    wg = dw.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous()
+    dsc, dsh = dev(scale), dev(shift)
+    P = _capi.BoneFusionParams(wg.data_ptr(), dsc.data_ptr(), dsh.data_ptr(), 1)
+    duv, duvr, demb = dev(uv_l), dev(uv_r), dev(emb)
+    scratch = torch.empty(L.dir_bone_fusion_scratch_bytes(B), device='cuda', dtype=torch.uint8)
+    y = torch.full((B, S, S, 320), 7.0, device='cuda')                            # written into channels [32, 288)
+    _capi.check(L.dir_bone_fusion_prepare(P, _capi.ptr(demb), _capi.ptr(scratch), B, _capi.stream_ptr()), 'bone_fusion_prepare')
+    _capi.check(L.dir_bone_fusion_forward(P, _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(scratch), _capi.ptr(y),
+                                          B, S, float(dist), 320, 32, 1, _capi.stream_ptr()), 'bone_fusion')
+    torch.cuda.synchronize()
+    got = y[..., 32:288].cpu().numpy().transpose(0, 3, 1, 2)
+    sc = np.abs(ref).max()
+    print('exact-fp32 factorised fusion S=%d B=%d: %.2e of the output scale' % (S, B, maxabs(got, ref) / sc))
+    assert maxabs(got, ref) <= 5e-6 * sc, (maxabs(got, ref), sc)
+    assert float(y[..., :32].min()) == 7.0 and float(y[..., 288:].max()) == 7.0     # slice untouched outside
+    bone = torch.empty(B, S, S, 2560, device='cuda')
+    _capi.check(L.dir_bone_proj_forward(_capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(demb), _capi.ptr(bone), None, None, B, S,
+                                        float(dist), 0, _capi.stream_ptr()), 'bone_proj')
+    from dir_amd import functional as Fn
+    y2 = Fn.conv2d_nhwc(bone, dw.permute(0, 2, 3, 1).contiguous(), 1, 1, scale=dsc, shift=dsh, relu=True).cpu().numpy().transpose(0, 3, 1, 2)
+    print('   materialised exact-fp32 conv: %.2e' % (maxabs(y2, ref) / sc))
+    assert maxabs(got, ref) <= 2.0 * maxabs(y2, ref) + 1e-6 * sc
+
 
 def test_bone_fusion_rejects_bad_arguments():
     L = _capi.lib()
@@ -295,7 +339,7 @@ def test_bone_fusion_rejects_bad_arguments():
     assert L.dir_bone_fusion_forward(P, _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), _capi.ptr(z), 0, 16, 1.0, 256, 0, 1,
                                      _capi.stream_ptr()) == 0                       # empty batch is a no-op
     assert L.dir_bone_fusion_prepare(P, _capi.ptr(z), _capi.ptr(z), 0, _capi.stream_ptr()) == 0
-    assert L.dir_bone_fusion_scratch_bytes(3) == 3 * 9 * 40 * 256 * 4
+    assert L.dir_bone_fusion_scratch_bytes(3) == 3 * 9 * 40 * 256 * 8      # float2 per (tap, hand-bone, channel): sized for exact_f32
 
 
 def test_ste_bf16_linears_autocast_semantics(golden):
