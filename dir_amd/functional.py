@@ -27,10 +27,10 @@ def pack_f16x3_weights(w_rows, scale=None):
     w = w_rows.detach().float()
     Cout, K = w.shape
     assert K % 32 == 0
-    amax = w.abs().amax(1)
+    amax = w.abs().amax(1).cpu()                             # exponents on the host: the device's frexp / ldexp are not exact
     _, e = torch.frexp(amax)                                 # amax = m * 2^e, m in [0.5, 1)
     e = torch.where(amax > 0, e, torch.full_like(e, 13)).clamp(-100, 100)
-    p = torch.ldexp(torch.ones_like(amax), 13 - e)           # amax * p in [2^12, 2^13)
+    p = torch.pow(torch.tensor(2.0, dtype=torch.float64), (13 - e).double()).float().to(w.device)     # amax * p in [2^12, 2^13)
     ws = w * p[:, None]                                      # exact: a power of two
     hi = ws.half()
     lo = (ws - hi.float()).half()
