@@ -84,8 +84,21 @@ def _is_regressor(name):
         ('init_regressor' in parts or 'regressor' in parts)
 
 
-def synth_tensor(name, shape, shapes, seed=1234):
-    """Value for state-dict entry `name` (shape `shape`); `shapes` maps every key to its shape."""
+def _branch_final(name):
+    """conv weights whose output is ADDED to a residual stream (or is a plain projection without ReLU): Bottleneck conv3 / downsample,
+    hourglass Residual conv3 / skip_layer, and the second conv of the Sequential heads"""
+    return (name.endswith('.conv3.weight') or name.endswith('.conv3.conv.weight') or name.endswith('.skip_layer.conv.weight')
+            or name.endswith('.downsample.0.weight') or name.endswith('.3.weight'))
+
+
+def synth_tensor(name, shape, shapes, seed=1234, cond=False):
+    """Value for state-dict entry `name` (shape `shape`); `shapes` maps every key to its shape.
+    cond = True: the "trained-like" flavour.  The default flavour follows the reference's initialisers, whose
+    fan-OUT convolution scale amplifies every channel-reducing 1x1 layer (x8 per bottleneck entry) while the random BatchNorm statistics
+    do not renormalise: |c4| ~ 2e2, decoder activations ~ 1e3, training-mode seg logits ~ 1e5 -- nothing a trained network shows, and
+    bad conditioning for parity gates (bf16 init-stage error 0.12 mm, fp32 gradients good to 1e-2 only).  Here convolutions are scaled by
+    fan-IN (variance preserving through ReLU), branch-final convolutions by half of that, so activations stay O(1) through all 53 + 20
+    layers as in a trained, BatchNorm-normalised network; the regressors use the reference's own N(0, 1e-3)."""
     g = rng_for(name, seed)
     shape = tuple(shape)
     base, _, leaf = name.rpartition('.')
@@ -128,6 +141,9 @@ def synth_tensor(name, shape, shapes, seed=1234):
     if leaf == 'weight':
         if len(shape) == 4:
             co, ci, kh, kw = shape
+            if cond:
+                fan_in = kh * kw * ci
+                return g.normal(0, np.sqrt((0.5 if _branch_final(name) else 2.0) / fan_in), shape).astype(f32)
             return g.normal(0, np.sqrt(2.0 / (kh * kw * co)), shape).astype(f32)
         if len(shape) == 3:
             co, ci, k = shape
@@ -138,7 +154,7 @@ def synth_tensor(name, shape, shapes, seed=1234):
                 # c4 of a random-init ResNet-50 has |x|~2e2, the refinement tokens |x|~1: keep the Linear
                 # contribution below the bias so joints project inside the image and the next stage's
                 # gather / rasteriser see real work
-                sig = 2e-5 if 'init_regressor' in name else 2e-4
+                sig = 1e-3 if cond else 2e-5 if 'init_regressor' in name else 2e-4      # cond: models/dir.py:256-257,336-337
                 return g.normal(0, sig, shape).astype(f32)
             b = 1.0 / np.sqrt(shape[1])
             return g.uniform(-b, b, shape).astype(f32)
@@ -161,9 +177,9 @@ def synth_tensor(name, shape, shapes, seed=1234):
     raise KeyError('no synthetic rule for state-dict entry %r shape %r' % (name, shape))
 
 
-def synth_state_dict(shapes, seed=1234):
-    """shapes: {key: shape}.  Returns {key: np.ndarray}."""
-    return {k: synth_tensor(k, s, shapes, seed) for k, s in shapes.items()}
+def synth_state_dict(shapes, seed=1234, cond=False):
+    """shapes: {key: shape}.  Returns {key: np.ndarray}.  cond: the trained-like flavour (synth_tensor)."""
+    return {k: synth_tensor(k, s, shapes, seed, cond) for k, s in shapes.items()}
 
 
 def synth_input(name, shape, seed=1234, kind='normal', lo=-1.0, hi=1.0, scale=1.0):

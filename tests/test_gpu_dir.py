@@ -361,3 +361,47 @@ def test_batch_128_rows_equal_the_golden_pinned_small_batch(golden, dir_state):
     torch.cuda.synchronize()
     d = (o16[2]['pd_joint_xyz_left'][[0, 127]].cpu().numpy() - g['s2.pd_joint_xyz_left'])
     assert float(np.sqrt((d ** 2).sum(-1)).mean()) * 1e3 < 0.01           # mm, the refined-stage bf16 envelope
+
+
+# ---------------------------------------------------------------------------------------------------------------- trained-like weights (G7c)
+@pytest.fixture(scope='module')
+def dir_state_cond():
+    with open(os.path.join(GOLDEN, 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, SEED, cond=True).items()}
+    img = torch.from_numpy(synth.synth_input('dir.img', (2, 3, 256, 256), SEED)).cuda()
+    return sd, img
+
+
+@pytest.mark.parametrize('mode', ['f32', 'f16x3', 'bf16'])
+def test_engine_vs_reference_golden_trained_like_weights(golden, dir_state_cond, mode):
+    """G7c is the reference's own forward on well-conditioned synthetic parameters (activations O(1) in every layer, as a
+    trained BatchNorm network has; dir_amd.synth cond=True).  Both parity modes are held to north_star's 1e-4 mm on it, and the bf16
+    throughput mode to BASELINE's MPJPE budget at the stage MPJPE is computed from."""
+    g = golden('g7c_dir')
+    sd, img = dir_state_cond
+    eng = DirEngine(sd, dtype=torch.bfloat16 if mode == 'bf16' else torch.float32, arith='f16x3' if mode == 'f16x3' else None)
+    eng.calibrate(img)
+    outs = eng.forward(img)
+    torch.cuda.synchronize()
+    worst, mpjpe = 0.0, []
+    for i in range(3):
+        for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right'):
+            worst = max(worst, maxabs(outs[i][k].cpu().numpy(), g['s%d.%s' % (i, k)]))
+        for side in ('left', 'right'):
+            d = outs[i]['pd_joint_xyz_' + side].cpu().numpy() - g['s%d.pd_joint_xyz_%s' % (i, side)]
+            mpjpe.append(float(np.sqrt((d ** 2).sum(-1)).mean()) * 1e3)
+    print('%s engine on trained-like weights: worst |xyz - reference| = %.3e m; mean per-joint error per stage / hand (mm): %s'
+          % (mode, worst, np.round(mpjpe, 5)))
+    if mode == 'bf16':
+        # BASELINE.json: "MPJPE within 0.01 mm" -- MPJPE is computed from the LAST stage (apps/eval.py:170-172 read result[-1]); measured
+        # 0.0024 / 0.0048 mm.  The earlier stages are reported and bounded at 2x their measured values: stage 1 0.003 / 0.006 mm; the init
+        # stage 0.036 / 0.050 mm -- it regresses straight from c4 through N(0, 1e-3) Linears, and c4 carries the bf16 backbone's own
+        # rounding (2^-9 per operand through 53 layers, ~1e-2 relative), trained-like conditioning or not.
+        assert max(mpjpe[4:]) < 0.01, mpjpe
+        assert max(mpjpe[2:4]) < 0.012 and max(mpjpe[:2]) < 0.1, mpjpe
+        assert relerr(outs[3]['seg'].cpu().numpy(), g['seg']) < 5e-2
+    else:
+        assert worst < 1e-7, worst                            # north_star: 1e-4 mm
+        assert relerr(outs[3]['seg'].cpu().numpy(), g['seg']) < 5e-4
+        assert relerr(outs[3]['dense'].cpu().numpy(), g['dense']) < 5e-4

@@ -187,11 +187,13 @@ def test_stage_matches_reference(golden, S, dist):
 
 
 # ------------------------------------------------------------------ G7 full DIR.forward
-def test_full_dir_matches_reference(golden):
-    g = golden('g7_dir')
+@pytest.mark.parametrize('cond', [False, True])
+def test_full_dir_matches_reference(golden, cond):
+    """cond: G7c -- the reference's forward on the trained-like flavour of the synthetic parameters (activations O(1) in every layer)"""
+    g = golden('g7c_dir' if cond else 'g7_dir')
     shapes = shapes_of('manifest_dir.json')
     assert len(shapes) == 963
-    sd = synth.synth_state_dict(shapes, SEED)
+    sd = synth.synth_state_dict(shapes, SEED, cond=cond)
     img = synth.synth_input('dir.img', (2, 3, 256, 256), SEED)
     taps = {}
     outs = dir_forward(sd, img, taps=taps)
