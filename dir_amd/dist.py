@@ -94,6 +94,69 @@ def average_gradients(flat_grad, bucket_elems=64 << 20):
     return flat_grad
 
 
+class GradientBucketer(object):
+    """The same exchange as average_gradients, overlapped with the backward pass: the flat gradient buffer is cut
+    into buckets at parameter boundaries, walking the parameters from the LAST to the first -- the order in which the backward pass
+    finishes them (heads, decoder stages, InitRegressor, backbone layer4 .. stem) -- and a bucket's all-reduce is issued the moment its
+    last gradient has been written (`mark_ready`), asynchronously: on RCCL the collective runs on the process group's own stream
+    behind an event of the compute stream, so it overlaps the rest of the backward; `finish()` issues whatever is left (parameters that
+    never receive a gradient) and waits.  Every element is reduced exactly once, by one all-reduce over the same ranks as in
+    average_gradients: with two ranks the result is bit-identical to the unbucketed path (tests/test_dist_gloo.py).
+
+        b = GradientBucketer(opt.flat_grad, opt.offsets, [p.numel() for p in opt.params])      # once
+        b.begin(); ...backward...: b.mark_ready([parameter indices whose .grad is final]); ...; b.finish()"""
+
+    def __init__(self, flat_grad, offsets, numels, bucket_elems=16 << 20):
+        self.flat = flat_grad.view(-1)
+        n = len(offsets)
+        ends = list(offsets[1:]) + [self.flat.numel()]
+        self.buckets, self.bucket_of = [], [0] * n           # bucket = [start, end, parameter indices]; built from the last parameter down
+        cur = None
+        for i in range(n - 1, -1, -1):
+            if cur is None:
+                cur = [offsets[i], ends[i], []]
+            cur[0] = offsets[i]
+            cur[2].append(i)
+            self.bucket_of[i] = len(self.buckets)
+            if cur[1] - cur[0] >= bucket_elems:
+                self.buckets.append(cur)
+                cur = None
+        if cur is not None:
+            self.buckets.append(cur)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.begin()
+
+    def begin(self):
+        self.pending = [set(b[2]) for b in self.buckets]
+        self.works, self.issued = [], [False] * len(self.buckets)
+
+    def _issue(self, bi):
+        if self.issued[bi]:
+            return
+        self.issued[bi] = True
+        if self.world > 1:
+            avg = dist.get_backend() == 'nccl'
+            a, e = self.buckets[bi][0], self.buckets[bi][1]
+            self.works.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True))
+
+    def mark_ready(self, indices):
+        """the gradients of these parameters (indices into the optimiser's parameter list) are final"""
+        for i in indices:
+            bi = self.bucket_of[i]
+            self.pending[bi].discard(i)
+            if not self.pending[bi]:
+                self._issue(bi)
+
+    def finish(self):
+        for bi in range(len(self.buckets)):
+            self._issue(bi)
+        for w in self.works:
+            w.wait()
+        if self.world > 1 and dist.get_backend() != 'nccl':
+            self.flat.div_(self.world)                        # gloo sums; same single division as average_gradients
+        self.works = []
+
+
 def free_port():
     import socket
     s = socket.socket()

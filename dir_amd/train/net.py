@@ -188,9 +188,14 @@ def _term_weights(grad_out):
     return dense, [torch.stack([f('%s_%d' % (k, i)) for k in L.STAGE_KEYS]) for i in range(3)]
 
 
-def backward(P, ctx, outs, target, meta_info, faces, grad_out=None):
-    """gradient of sum_k grad_out[k] * loss[k] (grad_out None: all 42 terms with weight 1, train.py:68) -> {parameter key: gradient}"""
+def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
+    """gradient of sum_k grad_out[k] * loss[k] (grad_out None: all 42 terms with weight 1, train.py:68) -> {parameter key: gradient}.
+    flush: optional callable(G), called whenever a group of modules has been finished -- every key present in G at that point is FINAL
+    (each parameter's gradient is written once, after all its uses), which lets the caller move gradients into the data-parallel
+    bucket and start its all-reduce while the rest of the backward pass runs (dir_amd/train/step.py)."""
     G = {}
+    if flush is None:
+        flush = lambda g: None      # noqa: E731
     w_dense, w_stage = _term_weights(grad_out)
     B = ctx['img'].shape[0]
     c1, c2, c3, c4 = ctx['feats']
@@ -198,6 +203,7 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None):
     g_feat = _cbr_backward(P, 'decoder.seg.', ctx['seg'], g_seg.permute(0, 2, 3, 1).contiguous(), G)
     O.axpy(g_feat, _cbr_backward(P, 'decoder.dense.', ctx['dense'], g_dense.permute(0, 2, 3, 1).contiguous(), G))
     g_lo = _cbr_backward(P, 'decoder.conv_final.', ctx['final'], g_feat, G)                      # gradient of enhance_layer3's output
+    flush(G)
     g_skip_src = [None, None]
     for si in (1, 0):
         tag, d = ('4', '3')[si], ctx['dec'][si]
@@ -219,6 +225,7 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None):
         g_src, g = TB.residual_backward(sub(P, 'decoder.skip_layer%s.' % tag), d['skip'], g_cat[..., Cup:].contiguous())
         put(G, 'decoder.skip_layer%s.' % tag, g)
         g_skip_src[si] = g_src                                                                    # gradient into c3 (si = 0) / c2 (si = 1)
+        flush(G)
     g_c4 = g_lo
     # ---- InitRegressor
     ci = ctx['init']
@@ -231,6 +238,7 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None):
         g_pool, G['init_regressor.mano_%s.weight' % s], G['init_regressor.mano_%s.bias' % s] = O.linear_bwd(g_para[i], ci[s]['pooled'], P['init_regressor.mano_%s.weight' % s])
         _, g_logit = SP.attn_pool_bwd(c4, ci[s]['attn'], ci[s]['pooled'], g_pool, g_mean if i == 0 else None, g_feat=g_c4)
         O.axpy(g_c4, _cbr_backward(P, 'init_regressor.attention_%s.' % s, ci[s]['att'], g_logit.view(B, 8, 8, 1), G))
+    flush(G)
     # ---- backbone
     g_feats = [None, g_skip_src[1], g_skip_src[0], g_c4]                                         # c1 has no consumer besides layer2
     g = None
@@ -245,9 +253,11 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None):
             pre, c = ctx['blocks'][bi_end]
             g, gb = TB.bottleneck_backward(sub(P, pre), c, g)
             put(G, pre, gb)
+        flush(G)
     a, x_pool = ctx['stem']
     g = SP.maxpool_bwd(a, g)
     g = TB.bn_bwd(P, 'backbone.bn1.', ctx['bn1'], O.relu_bwd(g, a), G)
     img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
     G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
+    flush(G)
     return G

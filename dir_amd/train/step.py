@@ -50,18 +50,40 @@ def token_stage_train_step(named_params, prefix, mano_tables_lr, feat_nhwc, prev
     return out, g_feat
 
 
-def train_step(named_params, buffers, img, target, meta_info, faces, optimizer):
+def train_step(named_params, buffers, img, target, meta_info, faces, optimizer, overlap_allreduce=True):
     """One optimisation step of the whole network (train.py:64-70: zero_grad, forward, sum(loss).backward(), optimizer.step):
     named_params {DIR state-dict key -> nn.Parameter registered with `optimizer` (FlatAdamW)}, buffers {key -> tensor} (BatchNorm running
-    statistics -- updated in place --, MANO tables).  Returns the 42 loss terms."""
+    statistics -- updated in place --, MANO tables).  Returns the 42 loss terms.  overlap_allreduce: bucketed gradient exchange issued
+    during the backward pass (default) or one exchange after it (the round-2 path; same result, bit-identical for two ranks)."""
     from . import net as TN
     P = {k: v.data for k, v in named_params.items()}
     P.update(buffers)
     outs, ctx = TN.forward(P, img)
     loss = TN.losses(outs, target, meta_info, faces)
-    G = TN.backward(P, ctx, outs, target, meta_info, faces)
     optimizer.zero_grad()
-    add_grads(named_params, '', G)
-    D.average_gradients(optimizer.flat_grad)
+    if not overlap_allreduce:
+        G = TN.backward(P, ctx, outs, target, meta_info, faces)
+        add_grads(named_params, '', G)
+        D.average_gradients(optimizer.flat_grad)
+        optimizer.step()
+        return loss
+    # gradients move into the flat bucket as the backward pass finishes them, last layers first, and every bucket's all-reduce is issued
+    # as soon as it is complete (dist.GradientBucketer): the exchange of the heads / decoder overlaps the backbone's backward
+    bucketer = getattr(optimizer, '_bucketer', None)
+    if bucketer is None:
+        bucketer = optimizer._bucketer = D.GradientBucketer(optimizer.flat_grad, optimizer.offsets, [p.numel() for p in optimizer.params])
+    index = getattr(optimizer, '_index_of', None)
+    if index is None:
+        index = optimizer._index_of = {id(p): i for i, p in enumerate(optimizer.params)}
+    bucketer.begin()
+    done = set()
+
+    def flush(G):
+        new = [k for k in G if k not in done]
+        add_grads(named_params, '', {k: G[k] for k in new})
+        done.update(new)
+        bucketer.mark_ready([index[id(named_params[k])] for k in new])
+    TN.backward(P, ctx, outs, target, meta_info, faces, flush=flush)
+    bucketer.finish()
     optimizer.step()
     return loss

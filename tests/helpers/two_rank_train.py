@@ -31,7 +31,7 @@ def fresh():
     params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).to(dev)) for k, v in sd.items() if not is_buf(k)}
     buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
     opt = FlatAdamW(list(params.values()), lr=1e-5)
-    opt.set_inactive([p for k, p in params.items() if k.startswith('backbone.fc.') or '.interaction.STEblocks.0.' in k])
+    opt.set_inactive(TSTEP.inactive_parameters(params))
     return params, buffers, opt
 
 
@@ -54,12 +54,17 @@ def batch(r, B=2):
 faces = tuple(torch.from_numpy(synth.loss_faces(s, 1234).astype(np.int64)).to(dev) for s in ('left', 'right'))
 params, buffers, opt = fresh()
 img, target, meta = batch(rank)
-TSTEP.train_step(params, buffers, img, target, meta, faces, opt)          # forward, backward, all-reduce (mean), AdamW
+TSTEP.train_step(params, buffers, img, target, meta, faces, opt)          # forward, backward with the bucketed all-reduce (mean) overlapped, AdamW
 mine = opt.flat_param.clone()
+# the round-2 path (one exchange after the whole backward) from the same starting point: bit-identical parameters
+params_u, buffers_u, opt_u = fresh()
+TSTEP.train_step(params_u, buffers_u, img, target, meta, faces, opt_u, overlap_allreduce=False)
+bucketed_equals_unbucketed = bool(torch.equal(opt_u.flat_param, mine))
+n_buckets = len(opt._bucketer.buckets)
 other = mine.clone()
 torch.distributed.broadcast(other, src=0)
 same_across_ranks = bool(torch.equal(mine, other))
-result = {'world': world, 'same_across_ranks': same_across_ranks}
+result = {'world': world, 'same_across_ranks': same_across_ranks, 'bucketed_equals_unbucketed': bucketed_equals_unbucketed, 'buckets': n_buckets}
 if rank == 0:
     # one process: both ranks' gradients from the same starting point, averaged by hand, one AdamW step
     p1, b1, o1 = fresh()

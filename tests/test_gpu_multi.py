@@ -30,4 +30,5 @@ def test_two_rank_data_parallel_train_step(tmp_path):
     assert D.spawn_ranks([script, str(out)], 2, timeout=900) == 0
     got = json.loads(out.read_text())
     assert got['world'] == 2 and got['same_across_ranks'] is True
+    assert got['bucketed_equals_unbucketed'] is True and got['buckets'] >= 4, got      # gradient exchange overlapped with the backward: same bits
     assert got['max_abs_diff_to_single_process'] < 0.02 * got['lr'], got
