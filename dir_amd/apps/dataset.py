@@ -15,8 +15,18 @@
 JPEG decoding is libjpeg-turbo through PIL (cv.imread uses the same library with the same defaults: integer slow DCT, fancy
 upsampling).  cv2 is not installed where this was written, so the equality of the two decoders' pixels is not pinned by a fixture
 ("parity unpinned" for the decode step; everything after the uint8 frame is pinned by G11 / G9 / G10).  `resize_bilinear_u8`
-restates cv.resize(INTER_LINEAR) on uint8 (OpenCV's 11-bit fixed-point coefficients) for frames that are not already 256x256; on the
-prepared split it is never taken.
+restates cv.resize(INTER_LINEAR) on uint8 (OpenCV's 11-bit fixed-point coefficients, and its INTER_AREA fast path for an exact 2x
+decimation) for frames that are not already 256x256; it is held to a scalar restatement of the published OpenCV algorithm
+(oracle/resize.py) and to hand-worked vectors (tests/test_dataset.py) -- residual risk: the library's SIMD paths are written to be
+bit-equal to its scalar code, but that, like the decoder, is not checkable without the library.  On the prepared split the resize is
+never taken.
+
+  prepared uint8 split (`write_u8_shards` / `ShardRing`)   an explicit SECOND form of the prepared split, made once by
+                                                      `python -m dir_amd.apps.dataset prepare-u8 <data_path> <split>` next to
+                                                      dataset/prepare_data.py's output: <split>/u8/frames_%05d.npy (uint8
+                                                      [n,256,256,3], the decoded BGR crops) + annos_%05d.npy (float32 [n,155]) +
+                                                      index.json.  JPEG decode is the from-files bottleneck (9.5 k images/s on 12
+                                                      cores against ~28 k on the GPU); the shards are read back at memory-copy speed.
 """
 import glob
 import os
@@ -36,12 +46,16 @@ def resize_bilinear_u8(img, wo, ho):
     h, w = img.shape[:2]
     if (w, h) == (wo, ho):
         return img.copy()
+    if w == 2 * wo and h == 2 * ho:
+        # cv::resize switches INTER_LINEAR to the INTER_AREA fast path for an exact 2x decimation: 2x2 box average, (sum + 2) >> 2
+        s = img.astype(np.int32)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
 
     def taps(n_in, n_out):
         scale = n_in / float(n_out)
-        src = (np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5
+        src = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)     # the library computes fx in float
         i0 = np.floor(src).astype(np.int64)
-        f = (src - i0).astype(np.float32)
+        f = (src - i0.astype(np.float32)).astype(np.float32)
         neg = i0 < 0
         i0[neg], f[neg] = 0, 0.0
         over = i0 >= n_in - 1
@@ -247,3 +261,92 @@ def gt_layers_from_checkpoint(state, device='cuda'):
         t['J'] = t['J_regressor'] @ t['v_template']
         layers[side] = ManoLayer(None, center_idx=None, _tables=t).to(device)
     return layers
+
+
+# ------------------------------------------------------------------------------------------------- prepared uint8 split
+U8_DIR = 'u8'
+
+
+def write_u8_shards(data_path, split='test', shard_size=2048, workers=8, progress=None):
+    """One-off preparation step next to dataset/prepare_data.py:123-166: decode every <split>/img/<idx>.jpg exactly as `decode_bgr` does
+    and store the uint8 BGR crops + the packed annotations in shards of `shard_size` images under <split>/u8/.  Returns the image count."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+    ds = InterHandSplit(data_path, split)
+    out = os.path.join(data_path, split, U8_DIR)
+    os.makedirs(out, exist_ok=True)
+    n = len(ds)
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:      # libjpeg releases the GIL
+        for s0 in range(0, n, shard_size):
+            idx = list(range(s0, min(n, s0 + shard_size)))
+            frames = np.stack(list(ex.map(ds.frame, idx)))
+            annos = np.stack([ds.anno(i) for i in idx])
+            np.save(os.path.join(out, 'frames_%05d.npy' % (s0 // shard_size)), frames)
+            np.save(os.path.join(out, 'annos_%05d.npy' % (s0 // shard_size)), annos)
+            if progress:
+                progress(idx[-1] + 1)
+    with open(os.path.join(out, 'index.json'), 'w') as f:
+        json.dump({'count': n, 'shard_size': shard_size, 'image_size': IMG_SIZE, 'layout': 'uint8 BGR [n,256,256,3] / float32 [n,%d]' % ANNO_FLOATS}, f)
+    return n
+
+
+class ShardRing(object):
+    """DecodeRing's interface over the prepared uint8 split: batches are gathered from memory-mapped shards into a ring of page-locked
+    host buffers by a few copy threads (numpy copies release the GIL), `depth - 1` batches ahead of the consumer."""
+
+    def __init__(self, data_path, split='test', batch_size=256, workers=4, depth=3, indices=None, pin=True):
+        import json
+        self.dir = os.path.join(data_path, split, U8_DIR)
+        with open(os.path.join(self.dir, 'index.json')) as f:
+            meta = json.load(f)
+        self.count, self.ss = int(meta['count']), int(meta['shard_size'])
+        nsh = (self.count + self.ss - 1) // self.ss
+        self.fr = [np.load(os.path.join(self.dir, 'frames_%05d.npy' % i), mmap_mode='r') for i in range(nsh)]
+        self.an = [np.load(os.path.join(self.dir, 'annos_%05d.npy' % i), mmap_mode='r') for i in range(nsh)]
+        self.indices = list(range(self.count)) if indices is None else list(indices)
+        self.bs, self.depth, self.workers = batch_size, depth, max(1, workers)
+        pinned = pin and torch.cuda.is_available()
+        self.frames = [torch.zeros(batch_size, IMG_SIZE, IMG_SIZE, 3, dtype=torch.uint8, pin_memory=pinned) for _ in range(depth)]
+        self.annos = [torch.zeros(batch_size, ANNO_FLOATS, dtype=torch.float32, pin_memory=pinned) for _ in range(depth)]
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=self.workers)
+
+    def __len__(self):
+        return (len(self.indices) + self.bs - 1) // self.bs
+
+    def _fill(self, slot, rows):
+        fr, an = self.frames[slot].numpy(), self.annos[slot].numpy()
+        for j, idx in rows:
+            sh, r = divmod(idx, self.ss)
+            fr[j] = self.fr[sh][r]
+            an[j] = self.an[sh][r]
+
+    def _submit(self, b, slot):
+        rows = list(enumerate(self.indices[b * self.bs:(b + 1) * self.bs]))
+        futs = [self.pool.submit(self._fill, slot, rows[w::self.workers]) for w in range(self.workers) if rows[w::self.workers]]
+        return futs, len(rows)
+
+    def __iter__(self):
+        nb = len(self)
+        pending = {b: self._submit(b, b % self.depth) for b in range(min(self.depth - 1, nb))}
+        for b in range(nb):
+            nxt = b + self.depth - 1
+            if nxt < nb:
+                pending[nxt] = self._submit(nxt, nxt % self.depth)
+            futs, n = pending.pop(b)
+            for f in futs:
+                f.result()
+            yield self.frames[b % self.depth], self.annos[b % self.depth], n
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+if __name__ == '__main__':
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == 'prepare-u8':
+        split = sys.argv[3] if len(sys.argv) > 3 else 'test'
+        n = write_u8_shards(sys.argv[2], split, progress=lambda k: print('\r%d' % k, end='', flush=True))
+        print('\nwrote %d frames under %s' % (n, os.path.join(sys.argv[2], split, U8_DIR)))
+    else:
+        print('usage: python -m dir_amd.apps.dataset prepare-u8 <data_path> [split]')

@@ -176,16 +176,17 @@ def evaluate(network, dataloader, J_regressor, root_joint=0, scale=True, stage_n
 
 
 def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joint=0, scale=True, split='test', workers=8,
-                       stage_num=3, indices=None, progress=None):
+                       stage_num=3, indices=None, progress=None, source='jpeg'):
     """apps/eval.py:121-241 from the prepared split on disk, at pipeline speed: decode processes (dataset.DecodeRing) -> pinned uint8
     batches -> two forwards in flight (engine.ForwardPipeline over uint8 input slots; the normalisation runs inside the stem kernel,
     proj_feat is not produced: the evaluation never reads it) -> GT MANO + metrics on the GPU.  `eng`: a DirEngine.
     Returns (EvalMetrics, {'images', 'seconds', 'images_per_sec'})."""
     import time
     from ..engine import ForwardPipeline
-    from .dataset import IMG_SIZE, DecodeRing, gt_batch
+    from .dataset import IMG_SIZE, DecodeRing, ShardRing, gt_batch
     dev = eng.device
-    ring = DecodeRing(data_path, split, bs, workers=workers, indices=indices)
+    assert source in ('jpeg', 'u8')      # 'u8': the prepared uint8 split (dataset.write_u8_shards): no JPEG decode in the loop
+    ring = (DecodeRing if source == 'jpeg' else ShardRing)(data_path, split, bs, workers=workers, indices=indices)
     m = EvalMetrics(J_regressor, root_joint, scale, stage_num)
     slots = [torch.zeros(bs, IMG_SIZE, IMG_SIZE, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
     pipe = ForwardPipeline(eng, slots, want_proj_feat=False)

@@ -63,3 +63,49 @@ def test_decode_ring_yields_every_frame_in_order(tmp_path, bs, workers):
         assert seen == 10 and len(ring) == (10 + bs - 1) // bs
     finally:
         ring.close()
+
+
+def test_resize_matches_the_scalar_restatement_of_opencv_and_hand_worked_vectors():
+    """`resize_bilinear_u8` against oracle/resize.py (scalar loops following the published OpenCV 8-bit INTER_LINEAR:
+    float32 source coordinates, cvRound(f * 2048) coefficients, the >> 4 / >> 16 / (+2) >> 2 fixed-point cast, the INTER_AREA fast path of an
+    exact 2x decimation) and against vectors worked out by hand from those formulas."""
+    from oracle.resize import cv_resize_linear_u8
+    rng = np.random.RandomState(3)
+    for (h, w, ho, wo) in [(7, 5, 11, 9), (16, 12, 8, 6), (9, 9, 20, 3), (10, 13, 4, 31), (5, 4, 5, 9), (33, 21, 16, 16), (3, 3, 7, 7)]:
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        assert np.array_equal(DS.resize_bilinear_u8(img, wo, ho), cv_resize_linear_u8(img, wo, ho)), (h, w, ho, wo)
+    gray = rng.randint(0, 256, (6, 10)).astype(np.uint8)
+    assert np.array_equal(DS.resize_bilinear_u8(gray, 7, 9), cv_resize_linear_u8(gray, 7, 9))
+    # 1 x 4 -> 1 x 8 (vertical taps b0 = 2048, b1 = 0).  By hand: dx = 1: fx = 0.25 -> a = (1536, 512): 100 * 512 = 51200; >> 4 = 3200;
+    # (2048 * 3200) >> 16 = 100; (100 + 2) >> 2 = 25.  dx = 5: 200 * 1536 + 255 * 512 = 437760; >> 4 = 27360; * 2048 >> 16 = 855; 857 >> 2 = 214
+    # (the exact value is 213.75).  dx = 6: 200 * 512 + 255 * 1536 = 494080 -> 30880 -> 965 -> 967 >> 2 = 241 (241.25).  Ends clamp to the border pixel.
+    row = np.array([[0, 100, 200, 255]], np.uint8)
+    assert DS.resize_bilinear_u8(row, 8, 1).tolist() == [[0, 25, 75, 125, 175, 214, 241, 255]]
+    # the truncation inside the fixed-point cast: 3 -> 5 columns of [1, 2, 4]: dx = 1: fx = (1.5 * 0.6 - 0.5) = 0.4 -> cvRound(819.2) = 819:
+    # 1 * 1229 + 2 * 819 = 2867; >> 4 = 179; * 2048 >> 16 = 5; (5 + 2) >> 2 = 1 (exact 1.4); dx = 2: fx = 1.0 -> sx = 1, f = 0: 2.
+    # dx = 3: fx = 1.6 -> 0.6 -> cvRound(1228.8) = 1229: 2 * 819 + 4 * 1229 = 6554; >> 4 = 409; * 2048 >> 16 = 12; 14 >> 2 = 3 (exact 3.2)
+    assert DS.resize_bilinear_u8(np.array([[1, 2, 4]], np.uint8), 5, 1).tolist() == [[1, 1, 2, 3, 4]]
+    # exact 2x decimation: cv::resize switches to the area fast path: (1 + 2 + 3 + 5 + 2) >> 2 = 3 (bilinear at the centre would give 2.75 -> 3 too;
+    # (0 + 0 + 0 + 3 + 2) >> 2 = 1 where the 11-bit bilinear path gives (3 * 0.25 = 0.75 ->) 1; (255 + 255 + 254 + 255 + 2) >> 2 = 255)
+    assert DS.resize_bilinear_u8(np.array([[1, 2], [3, 5]], np.uint8), 1, 1).tolist() == [[3]]
+    assert DS.resize_bilinear_u8(np.array([[0, 0, 255, 255], [0, 3, 254, 255]], np.uint8), 2, 1).tolist() == [[1, 255]]
+
+
+@pytest.mark.parametrize('bs', [4, 7])
+def test_u8_shards_round_trip(tmp_path, bs):
+    """the prepared uint8 split: `write_u8_shards` stores exactly what `decode_bgr` / `anno` return, ShardRing yields every frame in order
+    (ragged last batch, shard boundary inside a batch, an index list that revisits frames)"""
+    write_split(str(tmp_path), 10, seed=5)
+    ds = DS.InterHandSplit(str(tmp_path))
+    assert DS.write_u8_shards(str(tmp_path), 'test', shard_size=4, workers=2) == 10
+    idx = list(range(10)) + [3, 9, 0]
+    ring = DS.ShardRing(str(tmp_path), 'test', batch_size=bs, workers=2, depth=3, indices=idx, pin=False)
+    try:
+        seen = 0
+        for frames, annos, n in ring:
+            for j in range(n):
+                assert np.array_equal(frames[j].numpy(), ds.frame(idx[seen + j])) and np.array_equal(annos[j].numpy(), ds.anno(idx[seen + j]))
+            seen += n
+        assert seen == len(idx) and len(ring) == (len(idx) + bs - 1) // bs
+    finally:
+        ring.close()

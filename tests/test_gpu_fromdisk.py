@@ -52,6 +52,11 @@ def test_evaluate_from_disk_equals_the_plain_loop(tmp_path, state):
     for k in a:
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k          # same kernels on the same pixels: bit-identical
     assert a['joints_loss_left'].shape == (n, 21) and np.isfinite(a['root_loss']).all()
+    # the prepared uint8 split (no JPEG decode in the loop): the same frames, so the same numbers bit for bit
+    DS.write_u8_shards(str(tmp_path), 'test', shard_size=4, workers=2)
+    m8, rate8 = EV.evaluate_from_disk(eng, str(tmp_path), jreg, mano, bs=bs, root_joint=0, scale=True, workers=2, source='u8')
+    a8 = m8.arrays()
+    assert rate8['images'] == n and all(np.array_equal(a8[k], b[k]) for k in b)
 
 
 def test_command_line(tmp_path, state, capsys):

@@ -43,3 +43,10 @@ if __name__ == '__main__':
         for w in workers:
             m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx)
             print('workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))
+        # the prepared uint8 split (dataset.write_u8_shards): the same loop without the JPEG decode
+        t0 = time.perf_counter()
+        DS.write_u8_shards(d, 'test', shard_size=128, workers=8)
+        print('prepared uint8 shards of the 256 frames in %.1f s' % (time.perf_counter() - t0))
+        for w in (2, 4, 8):
+            m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source='u8')
+            print('u8 shards, %d copy threads  bs %d: %d images in %.2f s = %.0f images/s from files' % (w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))
