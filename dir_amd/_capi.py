@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdir_hip.so')
+LIB_PATH = os.environ.get('DIR_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdir_hip.so')      # DIR_LIB_PATH: investigation builds only (build.py)
 _lib = None
 
 

@@ -25,6 +25,12 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++20', '-fPIC', '-Wall', '-Wno-
          # canaries, only when two streams' kernels really overlap.  With the feature off the same overlap is bit-exact, at no
          # measurable cost (the bf16 epilogues keep v_cvt_pk_bf16_f32 / v_pk_max_i16, which are other features).
          '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+if os.environ.get('DIR_PACKED_FP32') == '1':
+    # investigation aid (tools/pkfp32_repro.hip, tools/aggressor_test.py): the library WITH packed-FP32 instructions, built beside the
+    # product library as lib/libdir_hip_pk.so from its own object directory; never loaded unless DIR_LIB_PATH points at it
+    FLAGS = [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')]
+    OBJ = os.path.join(HERE, 'build', 'obj_pk')
+    LIB = os.path.join(LIBDIR, 'libdir_hip_pk.so')
 FLAGS += os.environ.get('DIR_HIPCC_EXTRA', '').split()       # tuning / debugging aid (changing it needs --force)
 
 
