@@ -32,3 +32,17 @@ def test_two_rank_data_parallel_train_step(tmp_path):
     assert got['world'] == 2 and got['same_across_ranks'] is True
     assert got['bucketed_equals_unbucketed'] is True and got['buckets'] >= 4, got      # gradient exchange overlapped with the backward: same bits
     assert got['max_abs_diff_to_single_process'] < 0.02 * got['lr'], got
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_beside_replayed_forwards(tmp_path):
+    """RCCL's all-reduce kernels (not built with this library's no-packed-FP32 flag) on the process group's stream while
+    forwards replay on the slot's stream -- both sides reproduce their stand-alone results.  RCCL refuses two ranks on one device, so this
+    needs two GPUs (the driver's multi-GPU tier); on a 1-GPU box the foreign-kernel soak of tests/test_gpu_soak.py is what runs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    from dir_amd import dist as D
+    out = tmp_path / 'soak.json'
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'two_rank_rccl_soak.py')
+    assert D.spawn_ranks([script, str(out)], 2, timeout=900) == 0
+    assert json.loads(out.read_text()) == {'world': 2, 'forward_bit_identical': True, 'allreduce_exact': True}
