@@ -773,6 +773,12 @@ class DirEngine(object):
             'skip_layer4', 'fusion_layer4', 'enhance_layer4', 'skip_layer3', 'fusion_layer3', 'enhance_layer3')}
         self.stage4 = StageOp(sd, d + '.projecter_4', 16, 1, dt, root_joint, keep)
         self.stage3 = StageOp(sd, d + '.projecter_3', 32, 2, dt, root_joint, keep)
+        # f4: further refinement iterations at 32x32 (no reference counterpart; dir_amd.models.dir.FusionJointInterIterDecoder extra_stages)
+        self.stages_x, self.res_x = [], []
+        while ('%s.projecter_x.%d.fusion.0.weight' % (d, len(self.stages_x))) in sd:
+            i = len(self.stages_x)
+            self.stages_x.append(StageOp(sd, '%s.projecter_x.%d' % (d, i), 32, 2, dt, root_joint, keep))
+            self.res_x.append(ResidualOp(sd, '%s.enhance_layer_x.%d' % (d, i), dt))
         s, h = bn_fold(sd, d + '.conv_final.1')
         self.final0 = ConvOp(sd[d + '.conv_final.0.weight'], dt, pad=1, scale=s, shift=h, relu=True)
         self.final3 = ConvOp(sd[d + '.conv_final.3.weight'], dt, shift=sd[d + '.conv_final.3.bias'])
@@ -865,7 +871,7 @@ class DirEngine(object):
                      'B=%d G = f_end . W (9 taps x 80 bone ends x 256)' % B)
                 _capi.check(L.dir_bone_fusion_prepare(st.bone_fusion, _capi.ptr(emb), _capi.ptr(scratch), B, _capi.stream_ptr()),
                             'dir_bone_fusion_prepare')
-        res = self.mano_outputs(st.mano, para_l, para_r, off, self._flags[1 if st is self.stage4 else 2] if self._flags is not None else None)
+        res = self.mano_outputs(st.mano, para_l, para_r, off, self._flags[self._stage_index(st)] if self._flags is not None else None)
         vis = torch.empty(B, 1280, S, S, device=dev, dtype=F32) if want_vis else None
         if factorised:
             main.wait_stream(side)
@@ -893,6 +899,10 @@ class DirEngine(object):
         res['joint_feat'] = emb
         res['vis_img_feat'] = vis
         return res
+
+    def _stage_index(self, st):
+        """position of the stage's dict in outs_list (0 = the init regression)"""
+        return 1 if st is self.stage4 else 2 if st is self.stage3 else 3 + self.stages_x.index(st)
 
     def upsample_into(self, x, out, coff):
         B, H, W, Cc = x.shape
@@ -1048,7 +1058,7 @@ class DirEngine(object):
     def forward(self, img, want_proj_feat=True, taps=None, reflection_flags=None):
         """img: float32 NCHW [B,3,256,256] on the GPU.  Returns outs_list exactly like DIR.forward (models/dir.py:521-540);
         tensors are engine-owned buffers (valid until the next forward when run under a captured graph).
-        reflection_flags: optional int32 tensor [3 stages, 2 hands, B]; an entry is set to 1 where the predicted 6D root rotation
+        reflection_flags: optional int32 tensor [3 (+ extra) stages, 2 hands, B]; an entry is set to 1 where the predicted 6D root rotation
         is a reflection (det < 0) -- where the reference's `assert` fires (rot6d.py:50).  The caller decides when to look (a host
         read); dir_amd.models.dir.DIR.forward does, and raises AssertionError like the reference."""
         _capi.require_cuda(img)
@@ -1097,8 +1107,18 @@ class DirEngine(object):
         main.wait_stream(side)
         enh3_in = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
         self.res['fusion_layer3'](cat3, out=enh3_in, out_coff=0)
-        r3 = self.stage(self.stage3, enh3_in, 512, r4, enh3_in, 256, want_proj_feat)
-        e3 = self.res['enhance_layer3'](enh3_in)
+        nx = len(self.stages_x)
+        r3 = self.stage(self.stage3, enh3_in, 512, r4, enh3_in, 256, want_proj_feat and nx == 0)
+        # f4: every further iteration reads the running 32x32 map from channels [0, 256) of its own cat buffer (written there by the
+        # previous enhance Residual) and appends its img_feat to channels [256, 512)
+        extra, buf, prev = [], enh3_in, r3
+        for i in range(nx):
+            nxt = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
+            (self.res['enhance_layer3'] if i == 0 else self.res_x[i - 1])(buf, out=nxt, out_coff=0)
+            prev = self.stage(self.stages_x[i], nxt, 512, prev, nxt, 256, want_proj_feat and i == nx - 1)
+            extra.append(prev)
+            buf = nxt
+        e3 = (self.res['enhance_layer3'] if nx == 0 else self.res_x[nx - 1])(buf)
         # ---- heads (models/dir.py:474-476)
         feat = self.final3(self.final0(e3))
         sd6 = self.heads3(self.heads0(feat))                                     # NHWC fp32 [B,32,32,6] = seg | dense
@@ -1108,12 +1128,12 @@ class DirEngine(object):
                         fusion3=enh3_in[..., :256], proj3=enh3_in[..., 256:], enh3=e3, final=feat,
                         skip4=cat4[..., 2048:])
         outs = []
-        for o in (init, r4, r3):
+        for o in [init, r4, r3] + extra:
             outs.append({k: o[k] for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_xyz_left',
                                            'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right',
                                            'pd_proj_left', 'pd_proj_right', 'pd_offset', 'pd_rel_joint')})
         outs.append({'dense': dense.permute(0, 3, 1, 2), 'seg': seg.permute(0, 3, 1, 2),
-                     'proj_feat': r3['vis_img_feat']})
+                     'proj_feat': (extra[-1] if extra else r3)['vis_img_feat']})
         return outs
 
 

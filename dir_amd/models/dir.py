@@ -112,7 +112,7 @@ class InitRegressor(nn.Module):
 
 
 class FusionJointInterIterDecoder(nn.Module):
-    def __init__(self, joint_num, mano_pth, root_joint, inDim=[2048, 1024, 512, 256], fDim=[256, 256, 256, 256]):
+    def __init__(self, joint_num, mano_pth, root_joint, inDim=[2048, 1024, 512, 256], fDim=[256, 256, 256, 256], extra_stages=0):
         super().__init__()
         self.up4 = nn.Upsample(scale_factor=2, mode='bilinear')
         self.skip_layer4 = Residual(inDim[1], fDim[0])
@@ -131,6 +131,12 @@ class FusionJointInterIterDecoder(nn.Module):
             return nn.Sequential(nn.Conv2d(fDim[3], fDim[3] // 2, 3, 1, 1), nn.BatchNorm2d(fDim[3] // 2), nn.ReLU(),
                                  nn.Conv2d(fDim[3] // 2, 3, 1, 1))
         self.seg, self.dense = head(), head()
+        # f4 (no reference counterpart): N further refinement iterations at the final 32x32 resolution, each with its
+        # own Joint2BoneFeature (like projecter_3) and Residual 512 -> 256 (like enhance_layer3); keys decoder.projecter_x.<i>.* /
+        # decoder.enhance_layer_x.<i>.*.  With 0 (the default) the module tree and its 963 keys are exactly the reference's.
+        if extra_stages:
+            self.projecter_x = nn.ModuleList(Joint2BoneFeature(fDim[2], 128, 64, joint_num, 32, mano_pth, root_joint, distance=2) for _ in range(extra_stages))
+            self.enhance_layer_x = nn.ModuleList(Residual(fDim[2] * 2, fDim[2]) for _ in range(extra_stages))
 
 
 class _TrainObjective(torch.autograd.Function):
@@ -156,15 +162,19 @@ class _TrainObjective(torch.autograd.Function):
 
 
 class DIR(nn.Module):
-    def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16):
+    def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16, extra_stages=0, arith=None):
+        """extra_stages / arith are this build's extensions (defaults = the reference's network): extra_stages = N more refinement iterations at
+        32x32 (config 5's "5 refinement iters" = extra_stages 2; outs_list then carries 3 + N stage dicts before the dense / seg dict; eval
+        mode only); arith = 'f16x3' with compute_dtype float32: the split-precision parity mode (DirEngine)."""
         super().__init__()
+        self.extra_stages, self.arith = int(extra_stages), arith
         self.joint_num = joint_num
         self.root_joint = root_joint
         self.compute_dtype = compute_dtype
         self.backbone = ResNet50()        # ImageNet weights are a download in the reference (models/dir.py:490-498)
         self.mesh_sample_num = joint_num
         self.init_regressor = InitRegressor(self.backbone.inplanes, mano_path, root_joint)
-        self.decoder = FusionJointInterIterDecoder(self.joint_num, mano_path, root_joint)
+        self.decoder = FusionJointInterIterDecoder(self.joint_num, mano_path, root_joint, extra_stages=self.extra_stages)
         self.coord_weight, self.dense_weight = 10, 1
         self.seg_loss = nn.CrossEntropyLoss(weight=torch.Tensor([.1, 0.45, 0.45]))     # state-dict key seg_loss.weight
         self._engine, self._engine_key, self._sd_tensors = None, None, None
@@ -198,14 +208,14 @@ class DIR(nn.Module):
 
     def engine(self):
         """(re)pack the parameters when any of them changed (load_state_dict, .to(), in-place edits, optimiser steps)."""
-        key = (self.compute_dtype,) + tuple((t.data_ptr(), t._version) for t in self._tensors())
+        key = (self.compute_dtype, self.arith) + tuple((t.data_ptr(), t._version) for t in self._tensors())
         if key != self._engine_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             dev = next(self.parameters()).device
             if dev.type != 'cuda':
                 raise _capi.DirHipError('DIR runs on the GPU only: call .cuda() first (no CPU fallback exists)')
             tuned = self._engine.export_all_tuning() if self._engine is not None else None
-            self._engine = DirEngine(sd, dtype=self.compute_dtype, root_joint=self.root_joint, device=dev)
+            self._engine = DirEngine(sd, dtype=self.compute_dtype, root_joint=self.root_joint, device=dev, arith=self.arith)
             if tuned:
                 self._engine.pending_tuning = tuned      # same architecture, new weights: the kernel choices carry over
             self._engine_key = key
@@ -247,14 +257,18 @@ class DIR(nn.Module):
 
     def forward(self, input, target, meta_info):
         if self.training:
+            if self.extra_stages:
+                raise NotImplementedError('extra_stages (no reference counterpart) is built for inference only; training covers the reference network')
             return self._forward_train(input, target, meta_info)
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()
         with torch.cuda.device(x.device), torch.no_grad():
             x = x.contiguous() if x.dtype == torch.uint8 else _capi.f32c(x)       # uint8 BGR [B,256,256,3]: fused normalisation
+            if not eng.calibrated and eng.arith == 'f16x3' and not torch.cuda.is_current_stream_capturing():
+                eng.calibrate(x if x.dtype != torch.uint8 else x)          # f16x3: per-layer power-of-two input scales from the first batch seen
             if self.autotune and x.shape[0] not in eng.tuned_batches and not torch.cuda.is_current_stream_capturing():
                 eng.tune_for(x)             # per-layer conv kernel choice (bit-identical results): timed once, re-used for other batch sizes
-            flags = torch.zeros(3, 2, x.shape[0], device=x.device, dtype=torch.int32)
+            flags = torch.zeros(3 + self.extra_stages, 2, x.shape[0], device=x.device, dtype=torch.int32)
             outs = eng.forward(x, reflection_flags=flags)
             # manopth's robust 6D -> rotation asserts det > 0 over the batch (rot6d.py:50, a host synchronisation in the reference
             # too); a stage whose predicted root rotation is a reflection raises exactly there

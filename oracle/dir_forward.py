@@ -86,6 +86,18 @@ def decoder(feats, init, P, root_joint=0, taps=None):
             taps['proj%d' % lvl], taps['enh%d' % lvl] = ft['img_feat'], x
         outs.append(dict(res, **ft))
         prev = res
+    # f4 (no reference counterpart -- the reference hard-wires the two stages above, models/dir.py:395,401): N more
+    # refinement iterations at the final 32x32 resolution, each with its own parameters: projecter_x.<i> (a Joint2BoneFeature like
+    # projecter_3) on the running feature map, then enhance_layer_x.<i> (a Residual 512 -> 256 like enhance_layer3) on cat(map, img_feat)
+    i = 0
+    while ('projecter_x.%d.fusion.0.weight' % i) in P:
+        res, ft = stage_forward(P.sub('projecter_x.%d' % i), 32, 2, x,
+                                prev['pd_joint_xyz_left'], prev['pd_joint_xyz_right'], prev['pd_joint_uv_left'], prev['pd_joint_uv_right'],
+                                prev['pd_mano_para_left'], prev['pd_mano_para_right'], prev['pd_offset'][:, None, :], root_joint)
+        x = residual(np.concatenate([x, ft['img_feat']], 1), P.sub('enhance_layer_x.%d' % i))
+        outs.append(dict(res, **ft))
+        prev = res
+        i += 1
     feat = seq_head(x, P.sub('conv_final'), bias0=False)
     if taps is not None:
         taps['final'] = feat

@@ -405,3 +405,41 @@ def test_engine_vs_reference_golden_trained_like_weights(golden, dir_state_cond,
         assert worst < 1e-7, worst                            # north_star: 1e-4 mm
         assert relerr(outs[3]['seg'].cpu().numpy(), g['seg']) < 5e-4
         assert relerr(outs[3]['dense'].cpu().numpy(), g['dense']) < 5e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------- f4: N refinement iterations
+@pytest.mark.parametrize('mode', ['f32', 'f16x3', 'bf16'])
+def test_extra_refinement_stages_vs_oracle(mode):
+    """SURVEY.md 8f rank 4 (config 5: "5 refinement iters"): dir_amd.models.dir.DIR(extra_stages=2) -- two further Joint2BoneFeature + Residual
+    iterations at 32x32 with their own parameters -- against the numpy oracle extended the same way (oracle/dir_forward.py).  The reference has
+    no such network (models/dir.py:395,401 hard-wire two stages): parity is pinned to the oracle only, whose stage / Residual functions are the
+    ones the reference goldens G6 / G7 hold.  5 stage dicts + the dense / seg dict; proj_feat comes from the LAST stage."""
+    from dir_amd.models.dir import DIR
+    from oracle.dir_forward import dir_forward
+    net = DIR(21, './misc/mano', 0, extra_stages=2, compute_dtype=torch.bfloat16 if mode == 'bf16' else torch.float32,
+              arith='f16x3' if mode == 'f16x3' else None)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert len(shapes) == 963 + 2 * 240
+    sd_np = synth.synth_state_dict(shapes, SEED, cond=True)
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}, strict=True)
+    net = net.cuda().eval()
+    net.autotune = False
+    img = synth.synth_input('dir.img', (2, 3, 256, 256), SEED)
+    ref = dir_forward(sd_np, img)
+    outs, loss = net({'img': torch.from_numpy(img)}, None, None)
+    assert loss == {} and len(outs) == 6 and len(ref) == 6 and sorted(outs[5]) == ['dense', 'proj_feat', 'seg']
+    worst, mpjpe = 0.0, []
+    for i in range(5):
+        for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right'):
+            worst = max(worst, maxabs(outs[i][k].cpu().numpy(), ref[i][k]))
+        d = outs[i]['pd_joint_xyz_left'].cpu().numpy() - ref[i]['pd_joint_xyz_left']
+        mpjpe.append(float(np.sqrt((d ** 2).sum(-1)).mean()) * 1e3)
+    print('%s, 5 stage outputs: worst |xyz - oracle| %.3e m; mean per-joint error per stage (mm) %s' % (mode, worst, np.round(mpjpe, 5)))
+    assert not torch.equal(outs[4]['pd_mesh_xyz_left'], outs[2]['pd_mesh_xyz_left'])          # the extra stages do refine
+    if mode == 'bf16':
+        assert max(mpjpe[1:]) < 0.012 and mpjpe[0] < 0.1, mpjpe
+    else:
+        assert worst < 1.25e-7, worst                    # vs the numpy oracle (itself up to 3e-8 m from a torch evaluation)
+        assert relerr(outs[5]['seg'].cpu().numpy(), ref[5]['seg']) < 5e-4
+        pf = outs[5]['proj_feat'].cpu().numpy()
+        assert relerr(pf[:, 0:1280:97], ref[5]['proj_feat'][:, 0:1280:97]) < 5e-4
