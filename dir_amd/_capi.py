@@ -106,7 +106,7 @@ class EvalOutputs(C.Structure):
 
 
 ABI_VERSION = 25          # DIR_ABI_VERSION (include/dir_hip.h)
-DT_F32, DT_BF16, DT_F16X3 = 0, 1, 3
+DT_F32, DT_BF16, DT_F16X3, DT_F16X1 = 0, 1, 3, 4
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
 _p, _i = C.c_void_p, C.c_int

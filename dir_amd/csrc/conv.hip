@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // position c ^ ((r >> 1) & 7).  The prologue variant must touch the data in registers and keeps the staged path.
     // f16x3 (fp32 tensors, split-precision arithmetic): the activations are split into f16 hi / lo parts on their way into LDS, so that
     // mode always takes the register-staged path, with or without the pre-activation
-    constexpr bool X3 = std::is_same<TI, f16x3_t>::value;
+    constexpr bool X1 = std::is_same<TI, f16x1_t>::value;            // hi parts only: same staging and LDS layout
+    constexpr bool X3 = std::is_same<TI, f16x3_t>::value || X1;
     constexpr bool DMA = !PRE && !X3;
     constexpr int ROW = DMA ? 128 : LDS_STRIDE;
     constexpr int BM = 64 * MI, BN = 64 * NJ;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < ACH; ++i) {
                 uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x2r, avoff2[i], c2 * ES, 0));
-                if constexpr (X3) v = split_f16x3(v, a.a_scale);
+                if constexpr (X1) v = split_f16x1(v, a.a_scale); else if constexpr (X3) v = split_f16x3(v, a.a_scale);
                 ra[p][i] = __builtin_bit_cast(u32x4, v);
             }
 #pragma unroll
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             if constexpr (PRE) {
                 if (ok) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
             }
-            if constexpr (X3) v = split_f16x3(v, a.a_scale);                    // {hi01, hi23, lo01, lo23}
+            if constexpr (X1) v = split_f16x1(v, a.a_scale); else if constexpr (X3) v = split_f16x3(v, a.a_scale);                    // {hi01, hi23, lo01, lo23}
             ra[p][i] = __builtin_bit_cast(u32x4, v);
         }
 #pragma unroll
@@ -585,7 +586,8 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
-    const bool x3 = d->in_dtype == DIR_DT_F16X3;                 // fp32 tensors, split-precision arithmetic: sizes / alignment as fp32
+    const bool x1 = d->in_dtype == DIR_DT_F16X1;
+    const bool x3 = d->in_dtype == DIR_DT_F16X3 || x1;           // fp32 tensors, f16 arithmetic (split precision / hi only): sizes / alignment as fp32
     const bool f32 = d->in_dtype == DIR_DT_F32 || x3;
     DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16, "dir_conv2d_forward: in_dtype must be f32, bf16 or f16x3");
     DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == DIR_DT_BF16, "dir_conv2d_forward: bad out_dtype");
@@ -665,7 +667,8 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
         a.splits = splits; a.ws_cnt = (unsigned*)workspace; a.ws_part = (float*)((char*)workspace + SPLITK_COUNTER_BYTES);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (x3) launch_conv<f16x3_t, float>(a, num_cu, s);
+    if (x1) launch_conv<f16x1_t, float>(a, num_cu, s);
+    else if (x3) launch_conv<f16x3_t, float>(a, num_cu, s);
     else if (f32) launch_conv<float, float>(a, num_cu, s);
     else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
     else launch_conv<bf16_t, float>(a, num_cu, s);

@@ -70,13 +70,26 @@ __device__ __forceinline__ uint32_t relu2bf(uint32_t v) {
 // that their lo parts are normal numbers, and split there: the weight "tensor" of this mode is [Cout][kh][kw][Cin/32][hi 32 | lo 32]
 // f16 -- byte for byte the size and addressing of the fp32 tensor it replaces.  Activations are split when a K-slab is staged into LDS.
 struct f16x3_t { float v; };
+// f16x1 (DIR_DT_F16X1): the same data path with the hi parts only -- ONE f16 MFMA per product, operands rounded to f16 (11 significant
+// bits, 8x finer than bf16), fp32 accumulation: what torch.autocast(float16) does to a convolution, on fp32 tensors.  The "fp16 MFMA path"
+// of BASELINE config 5; weights come in the f16x3 packing (their lo halves are simply not read into the products).
+struct f16x1_t { float v; };
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+// hi parts only (f16x1): {hi01, hi23, 0, 0}
+__device__ __forceinline__ uint4 split_f16x1(const uint4 v, const float s) {
+    constexpr float FMAX = 65504.f;
+    const f32x2_t a = {__builtin_amdgcn_fmed3f(__uint_as_float(v.x) * s, -FMAX, FMAX), __builtin_amdgcn_fmed3f(__uint_as_float(v.y) * s, -FMAX, FMAX)};
+    const f32x2_t b = {__builtin_amdgcn_fmed3f(__uint_as_float(v.z) * s, -FMAX, FMAX), __builtin_amdgcn_fmed3f(__uint_as_float(v.w) * s, -FMAX, FMAX)};
+    return make_uint4(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2_t)), __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2_t)), 0u, 0u);
+}
 
 template <typename T> struct Tr;
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };    // EPC = elems per 16-B chunk
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 template <> struct Tr<f16x3_t> { static constexpr int EPC = 4, BK = 32; };
+template <> struct Tr<f16x1_t> { static constexpr int EPC = 4, BK = 32; };
 
 // four fp32 values, times the power of two s, clamped to the f16 range -> {hi01, hi23, lo01, lo23} as packed f16 pairs (round to
 // nearest even both times)
@@ -138,6 +151,13 @@ __device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uin
     for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
                                                       __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
+}
+// f16x1: the hi fragments only
+template <>
+__device__ __forceinline__ void mma_slab<f16x1_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[2 * s]), __builtin_bit_cast(f16x8, bf[2 * s]), acc, 0, 0, 0);
 }
 // f16x3: fragment q = 2*s + part of a 32-channel slab: k16-step s in {0, 1}, part 0 = hi, 1 = lo (both operands laid out alike)
 template <>
@@ -241,6 +261,8 @@ __device__ __forceinline__ uint4 prologue<float>(uint4 v, const float* ps, const
 }
 template <>
 __device__ __forceinline__ uint4 prologue<f16x3_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue<float>(v, ps, pb, c, relu); }
+template <>
+__device__ __forceinline__ uint4 prologue<f16x1_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue<float>(v, ps, pb, c, relu); }
 template <>
 __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
     uint32_t u[4] = {v.x, v.y, v.z, v.w};

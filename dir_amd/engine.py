@@ -17,7 +17,7 @@ import threading
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X3, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X3, DT_F32, ConvDesc
 
 F32 = torch.float32
 IMAGENET_MEAN = (C.c_float * 3)(0.485, 0.456, 0.406)      # apps/eval.py:49-50
@@ -89,9 +89,9 @@ class ConvOp(object):
         self.stride, self.pad, self.dtype = stride, pad, dtype
         self.out_dtype = out_dtype or dtype
         self.arith = (arith or _packing_arith()) if dtype == torch.float32 else None
-        self.in_code = DT_F16X3 if self.arith == 'f16x3' else _dt(dtype)
+        self.in_code = DT_F16X3 if self.arith == 'f16x3' else DT_F16X1 if self.arith == 'f16' else _dt(dtype)
         self.in_scale = 1.0                # f16x3: power of two applied to the activations before the split (set_in_scale / DirEngine.calibrate)
-        if self.arith == 'f16x3':          # fp32 tensors, f16 hi / lo split arithmetic: weights split + pre-scaled here, 1 / p_n into the scale
+        if self.arith in ('f16x3', 'f16'):  # fp32 tensors, f16 hi / lo split arithmetic ('f16': hi only): weights split + pre-scaled here, 1 / p_n into the scale
             from .functional import pack_f16x3_weights
             self.w, scale = pack_f16x3_weights(self.w.reshape(self.cout, -1), scale)
             self.scale0 = scale.float().contiguous()          # the epilogue scale at in_scale = 1
@@ -112,7 +112,7 @@ class ConvOp(object):
 
     def set_in_scale(self, s):
         """f16x3: multiply the activations by the power of two `s` before the hi / lo split; 1 / s goes into the epilogue scale (exact)"""
-        assert self.arith == 'f16x3' and s > 0 and math.frexp(s)[0] == 0.5
+        assert self.arith in ('f16x3', 'f16') and s > 0 and math.frexp(s)[0] == 0.5
         self.in_scale = float(s)
         self.scale.copy_(self.scale0 / s)
 
@@ -125,7 +125,7 @@ class ConvOp(object):
 
     def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None):
         B, H, W, cbuf = x.shape
-        if self.arith == 'f16x3' and getattr(_TLS, 'calibrating', False):
+        if self.arith is not None and getattr(_TLS, 'calibrating', False):
             self._calibrate([x[..., in_coff:in_coff + self.cin]] if self.in_cs_override is None else [x])
         ho = self.ho or (H + 2 * self.pad - self.kh) // self.stride + 1
         wo = self.wo or (W + 2 * self.pad - self.kw) // self.stride + 1
@@ -214,7 +214,7 @@ class DualConvOp(object):
         self.w = w.contiguous().to(dtype)                                    # [Cout][Cin + Cin2]
         self.arith = _packing_arith() if dtype == torch.float32 else None
         self.scale = None
-        if self.arith == 'f16x3':          # split-precision rows; their power-of-two prescale comes back out through a scale vector
+        if self.arith is not None:         # split-precision rows; their power-of-two prescale comes back out through a scale vector
             from .functional import pack_f16x3_weights
             self.w, self.scale = pack_f16x3_weights(self.w)
             self.scale0 = self.scale.clone()
@@ -232,12 +232,13 @@ class DualConvOp(object):
 
     def __call__(self, y, x, out=None, out_coff=0):
         B, H, W, cbuf = y.shape
-        if self.arith == 'f16x3' and getattr(_TLS, 'calibrating', False):
+        if self.arith is not None and getattr(_TLS, 'calibrating', False):
             ConvOp._calibrate(self, [y[..., :self.cin], x[..., :self.cin2]])
         if out is None:
             out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
         d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0,
-                     DT_F16X3 if self.arith == 'f16x3' else _dt(self.dtype), _dt(self.dtype), CONV_RELU if self.relu else 0, 0, 0, self.in_scale)
+                     DT_F16X3 if self.arith == 'f16x3' else DT_F16X1 if self.arith == 'f16' else _dt(self.dtype), _dt(self.dtype),
+                     CONV_RELU if self.relu else 0, 0, 0, self.in_scale)
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
@@ -679,7 +680,7 @@ class StageOp(object):
         s, h = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])
         self.fusion0 = ConvOp(sd[p + '.fusion.0.weight'], dtype, pad=1, scale=s, shift=h, relu=True)
         self.bone_fusion = None
-        if dtype == torch.bfloat16 or _packing_arith() == 'f16x3':
+        if dtype == torch.bfloat16 or _packing_arith() is not None:
             # factorised bone fusion (dir_bone_fusion_forward): w_g[tap][hb][c][n] = weight[n, hb*64+c, ky, kx]; bf16 mode: rounded to
             # bf16, bf16 matrix cores; f16x3 parity mode: unrounded, everything on the exact fp32 matrix cores (exact_f32 = 1)
             exact = dtype == torch.float32
@@ -724,7 +725,7 @@ class DirEngine(object):
         convolutions on the f16 matrix cores in split precision (3 products per multiply, DIR_DT_F16X3) -- meets the same 1e-4 mm
         budget several times faster."""
         assert dtype in (torch.bfloat16, torch.float32)
-        assert arith in (None, 'f16x3') and (arith is None or dtype == torch.float32)
+        assert arith in (None, 'f16x3', 'f16') and (arith is None or dtype == torch.float32)     # 'f16': one f16 MFMA per product (DIR_DT_F16X1)
         self.arith = arith
         self.tuned_batches = set()
         self.sparse_fusion = sparse_fusion     # skip all-zero (tap, bone) K-slabs in the fusion conv (bit-identical)
@@ -1042,7 +1043,7 @@ class DirEngine(object):
         runs, so the activations further down are already those of the calibrated network.  Host synchronisations: not capturable; call
         it once per engine on a representative batch (DIR.forward and bench.py do, on the first batch they see).  Without it in_scale is
         1 everywhere: correct for activations inside [2^-3, 65504), saturating beyond."""
-        if self.arith != 'f16x3':
+        if self.arith is None:
             return
         _TLS.calibrating = True
         try:

@@ -3,7 +3,7 @@ Feature maps are NHWC torch tensors (float32 or bfloat16) on the GPU."""
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X3, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X3, DT_F32, ConvDesc
 
 
 def _dt(t):
@@ -52,9 +52,9 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
     if cin is None:
         cin = Cin
     assert cin == Cin and w_ohwi.dtype == x.dtype
-    assert arith in (None, 'f16x3')
+    assert arith in (None, 'f16x3', 'f16')               # 'f16': the hi parts only (DIR_DT_F16X1), same packing
     in_scale = 0.0
-    if arith == 'f16x3':
+    if arith is not None:
         assert x.dtype == torch.float32 and splits == 1
         w_ohwi, scale = pack_f16x3_weights(w_ohwi.reshape(Cout, -1), scale)
         # input scale as DirEngine.calibrate picks it: the largest |activation| the split sees lands in [2^9, 2^10)
@@ -77,7 +77,7 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
     for v in (pre_scale, pre_shift):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cin and v.is_contiguous())
     d = ConvDesc(B, H, W, Cin, cbuf, in_coff, Cout, out.shape[3], out_coff,
-                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, DT_F16X3 if arith == 'f16x3' else _dt(x), _dt(out),
+                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, DT_F16X3 if arith == 'f16x3' else DT_F16X1 if arith == 'f16' else _dt(x), _dt(out),
                  (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0) | ((variant & 0xff) << 8), 0, 0, in_scale)      # variant: DIR_CONV_VARIANT code
     with torch.cuda.device(x.device):
         if splits > 1:

@@ -233,6 +233,9 @@ int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h
  * values saturate), full 22-bit accuracy down to max / 4096, below that an absolute floor of 2^-25 / in_scale per element (f16 denormal
  * lo parts, which the matrix cores honour: tools/ubench_f16_denorm.hip).  Cin % 32 == 0 as for fp32. */
 #define DIR_DT_F16X3 3
+/* the same operands and packing with the hi parts only: ONE f16 MFMA per product (operands rounded to f16, fp32 accumulation) -- the
+ * arithmetic of torch.autocast(float16) on fp32 tensors, 8x finer than bf16; the "fp16 MFMA path" of BASELINE config 5 */
+#define DIR_DT_F16X1 4
 #define DIR_CONV_RELU 1
 #define DIR_CONV_PRE_RELU 2
 /* Optional kernel choice in bits 8..15 of dir_conv_desc.flags (0 = the library's per-layer heuristic).  Every variant

@@ -159,3 +159,32 @@ def test_f16x3_full_size_chunk_consistency(shape):
     assert torch.isfinite(ref).all()
     for _ in range(3):
         assert torch.equal(F.conv2d_nhwc(x, w, 1, k // 2, arith='f16x3'), ref)
+
+
+@pytest.mark.parametrize('case', CASES[:4])
+def test_f16_hi_only_conv(case):
+    """DIR_DT_F16X1, the "fp16 MFMA path": one f16 MFMA per product on the same fp32 tensors and packing.  Against the float64 convolution
+    of the operands ROUNDED to f16 the way the kernel rounds them (activations and pre-scaled weights: exact powers of two cancel), only
+    fp32 accumulation noise remains (5e-6); against the unrounded operands the error is the f16 rounding itself, a few 1e-4 of the output
+    scale -- several times below bf16 operands'."""
+    B, H, W, Ci, Co, k, s, p = case
+    tag = 'conv.%s' % '_'.join(map(str, case))
+    x = synth.synth_input(tag + '.x', (B, Ci, H, W), SEED)
+    w = synth.synth_input(tag + '.w', (Co, Ci, k, k), SEED) * np.float32(np.sqrt(2.0 / (k * k * Ci)))
+    dx = torch.from_numpy(to_nhwc(x)).cuda()
+    dw = F.pack_conv_weight(torch.from_numpy(w).cuda(), torch.float32)
+    y = F.conv2d_nhwc(dx, dw, s, p, arith='f16').cpu().numpy().transpose(0, 3, 1, 2)
+    ref = N.conv2d(x.astype(np.float64), w.astype(np.float64), None, s, p)
+    # the kernel's roundings: x * in_scale -> f16 ; w * p_n -> f16 (both scales are powers of two: rounding commutes with them up to range)
+    import math
+    sx = 2.0 ** (10 - math.frexp(float(np.abs(x).max()))[1])
+    xr = (torch.from_numpy(x * np.float32(sx)).half().double().numpy()) / sx
+    amax = np.abs(w).reshape(Co, -1).max(1)
+    pw = 2.0 ** (13 - np.frexp(amax)[1])
+    wr = (torch.from_numpy(w * pw[:, None, None, None].astype(np.float32)).half().double().numpy()) / pw[:, None, None, None]
+    ref_r = N.conv2d(xr, wr, None, s, p)
+    e_r, e_x = relerr(y, ref_r), relerr(y, ref)
+    xb, wb = torch.from_numpy(x).to(torch.bfloat16).double().numpy(), torch.from_numpy(w).to(torch.bfloat16).double().numpy()
+    e_bf = relerr(N.conv2d(xb, wb, None, s, p), ref)
+    print('%s: f16 arithmetic vs f16-rounded operands %.2e, vs exact operands %.2e (bf16 operands: %.2e)' % (tag, e_r, e_x, e_bf))
+    assert e_r < 5e-6 and e_x < 1.5e-3 and e_x < 0.5 * e_bf
