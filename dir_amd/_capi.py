@@ -106,7 +106,7 @@ class EvalOutputs(C.Structure):
 
 
 ABI_VERSION = 25          # DIR_ABI_VERSION (include/dir_hip.h)
-DT_F32, DT_BF16, DT_F16X3, DT_F16X1 = 0, 1, 3, 4
+DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
 _p, _i = C.c_void_p, C.c_int
@@ -118,6 +118,7 @@ _SIGNATURES = {
     'dir_launch_log_get': (C.c_int, [C.c_char_p, _i]),
     'dir_launch_log_note': (None, [C.c_char_p, C.c_longlong]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'dir_split_f16_forward': (C.c_int, [_p, _p, C.c_longlong, _i, _i, _i, _p, _p, _i, C.c_float, _i, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_image_normalize_forward': (C.c_int, [_p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _i, _p]),

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // mode always takes the register-staged path, with or without the pre-activation
     constexpr bool X1 = std::is_same<TI, f16x1_t>::value;            // hi parts only: same staging and LDS layout
     constexpr bool X3 = std::is_same<TI, f16x3_t>::value || X1;
+    // pre-split activations (dir_split_f16_forward): the hi | lo row layout of X3, but delivered by DMA like bf16 rows
+    constexpr bool XP = std::is_same<TI, f16x3p_t>::value || std::is_same<TI, f16x1p_t>::value;
     constexpr bool DMA = !PRE && !X3;
     constexpr int ROW = DMA ? 128 : LDS_STRIDE;
     constexpr int BM = 64 * MI, BN = 64 * NJ;
@@ -259,7 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     int qoff[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        qoff[q] = X3 ? 32 * (q >> 1) + 16 * (lane >> 5) + 64 * (q & 1) : DMA ? ((((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4) : q * 16;
+        qoff[q] = X3 ? 32 * (q >> 1) + 16 * (lane >> 5) + 64 * (q & 1)
+                  : XP ? ((((2 * (q >> 1) + (lane >> 5)) + 4 * (q & 1)) ^ ((lane >> 1) & 7)) << 4)      // chunk (2s + h) of the hi half, + 4 for the lo half, swizzled
+                  : DMA ? ((((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4) : q * 16;
 
     // ---- optional sparse-K: compact, ordered list of the K-slabs whose input group can be non-zero for this tile
     __shared__ short s_list[MAX_SLABS];
@@ -586,8 +590,10 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
-    const bool x1 = d->in_dtype == DIR_DT_F16X1;
-    const bool x3 = d->in_dtype == DIR_DT_F16X3 || x1;           // fp32 tensors, f16 arithmetic (split precision / hi only): sizes / alignment as fp32
+    const bool xp = d->in_dtype == DIR_DT_F16X3P || d->in_dtype == DIR_DT_F16X1P;      // activations pre-split by dir_split_f16_forward
+    const bool x1 = d->in_dtype == DIR_DT_F16X1 || d->in_dtype == DIR_DT_F16X1P;
+    const bool x3 = d->in_dtype == DIR_DT_F16X3 || d->in_dtype == DIR_DT_F16X3P || x1;   // fp32-sized tensors, f16 arithmetic (split precision / hi only)
+    DIR_REQUIRE(!(xp && pre_scale), "dir_conv2d_forward: pre-split activations carry their pre-activation already (dir_split_f16_forward)");
     const bool f32 = d->in_dtype == DIR_DT_F32 || x3;
     DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16, "dir_conv2d_forward: in_dtype must be f32, bf16 or f16x3");
     DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == DIR_DT_BF16, "dir_conv2d_forward: bad out_dtype");
@@ -636,7 +642,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     set_magic(a);
     a.flags = d->flags & 3;
     a.variant = (d->flags >> 8) & 0xff;
-    a.a_scale = (x3 && d->in_scale > 0.f) ? d->in_scale : 1.f;
+    a.a_scale = (x3 && !xp && d->in_scale > 0.f) ? d->in_scale : 1.f;
     DIR_REQUIRE(d->kh * d->kw <= 32, "dir_conv2d_forward: at most 32 taps");
     const long long xb = (long long)d->B * d->H * d->W * in_cs * (f32 ? 4 : 2);
     const long long wb = (long long)d->Cout * a.K * (f32 ? 4 : 2);
@@ -667,12 +673,51 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
         a.splits = splits; a.ws_cnt = (unsigned*)workspace; a.ws_part = (float*)((char*)workspace + SPLITK_COUNTER_BYTES);
     }
     hipStream_t s = (hipStream_t)stream;
-    if (x1) launch_conv<f16x1_t, float>(a, num_cu, s);
+    if (xp && x1) launch_conv<f16x1p_t, float>(a, num_cu, s);
+    else if (xp) launch_conv<f16x3p_t, float>(a, num_cu, s);
+    else if (x1) launch_conv<f16x1_t, float>(a, num_cu, s);
     else if (x3) launch_conv<f16x3_t, float>(a, num_cu, s);
     else if (f32) launch_conv<float, float>(a, num_cu, s);
     else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
     else launch_conv<bf16_t, float>(a, num_cu, s);
     return dir::check_launch("dir_conv2d_forward");
+}
+
+
+// ---- dir_split_f16_forward: fp32 NHWC channel slice -> [pixel][C/32][hi 32 | lo 32] f16, times in_scale, optional pre-activation
+namespace {
+struct SplitArgs {
+    const float* x; uint4* y; const float* ps; const float* pb;
+    long long nchunk;          // pixels * C / 4
+    int C4, cs, co, relu, hi_only;
+    float s;
+};
+__global__ __launch_bounds__(256) void split_f16_kernel(SplitArgs a) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.nchunk; i += (long long)gridDim.x * 256) {
+        const long long pix = i / a.C4;
+        const int c4 = (int)(i - pix * a.C4);                          // 4-channel chunk inside the pixel
+        uint4 v = *reinterpret_cast<const uint4*>(a.x + pix * a.cs + a.co + 4 * c4);
+        if (a.ps) v = prologue<float>(v, a.ps, a.pb, 4 * c4, a.relu != 0);
+        const uint4 sp = a.hi_only ? split_f16x1(v, a.s) : split_f16x3(v, a.s);
+        // slab = 8 chunks (32 channels) = 128 bytes: hi parts at bytes [0, 64), lo parts at [64, 128); this chunk's 8 bytes at 8 * (c4 & 7)
+        char* row = reinterpret_cast<char*>(a.y) + (pix * a.C4 + (c4 & ~7)) * 16;
+        *reinterpret_cast<uint2*>(row + 8 * (c4 & 7)) = make_uint2(sp.x, sp.y);
+        *reinterpret_cast<uint2*>(row + 64 + 8 * (c4 & 7)) = make_uint2(sp.z, sp.w);
+    }
+}
+}  // namespace
+
+extern "C" int dir_split_f16_forward(const float* x, void* y, long long pixels, int C, int in_cstride, int in_coff, const float* pre_scale,
+                                     const float* pre_shift, int pre_relu, float in_scale, int hi_only, void* stream) {
+    DIR_REQUIRE(x && y && pixels >= 0 && C > 0 && C % 32 == 0, "dir_split_f16_forward: bad arguments (C must be a multiple of 32)");
+    const int cs = in_cstride ? in_cstride : C;
+    DIR_REQUIRE(cs % 4 == 0 && in_coff % 4 == 0 && in_coff + C <= cs, "dir_split_f16_forward: channel slice must be 16-byte aligned");
+    DIR_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr), "dir_split_f16_forward: pre_scale / pre_shift go together");
+    if (pixels == 0) return DIR_OK;
+    SplitArgs a{x, (uint4*)y, pre_scale, pre_shift, pixels * (C / 4), C / 4, cs, in_coff, pre_relu, hi_only, in_scale > 0.f ? in_scale : 1.f};
+    const long long blocks = (a.nchunk + 255) / 256;
+    DIR_LAUNCH(split_f16_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, a);
+    return dir::check_launch("dir_split_f16_forward");
 }
 
 extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale,

@@ -85,11 +85,19 @@ __device__ __forceinline__ uint4 split_f16x1(const uint4 v, const float s) {
     return make_uint4(__builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2_t)), __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2_t)), 0u, 0u);
 }
 
+// f16x3p / f16x1p (DIR_DT_F16X3P / F16X1P): the ACTIVATIONS arrive pre-split too -- dir_split_f16_forward wrote them once as
+// [pixel][C/32][hi 32 | lo 32] f16 (the bytes and addressing of the fp32 tensor), already multiplied by in_scale and through the
+// pre-activation -- so both operands travel global -> LDS by DMA like the bf16 path (no register staging, no conversion per N tile).
+struct f16x3p_t { float v; };
+struct f16x1p_t { float v; };
+
 template <typename T> struct Tr;
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };    // EPC = elems per 16-B chunk
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 template <> struct Tr<f16x3_t> { static constexpr int EPC = 4, BK = 32; };
 template <> struct Tr<f16x1_t> { static constexpr int EPC = 4, BK = 32; };
+template <> struct Tr<f16x3p_t> { static constexpr int EPC = 4, BK = 32; };
+template <> struct Tr<f16x1p_t> { static constexpr int EPC = 4, BK = 32; };
 
 // four fp32 values, times the power of two s, clamped to the f16 range -> {hi01, hi23, lo01, lo23} as packed f16 pairs (round to
 // nearest even both times)
@@ -152,6 +160,10 @@ __device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uin
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
                                                       __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
 }
+template <>
+__device__ __forceinline__ void mma_slab<f16x3p_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc);
+template <>
+__device__ __forceinline__ void mma_slab<f16x1p_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc);
 // f16x1: the hi fragments only
 template <>
 __device__ __forceinline__ void mma_slab<f16x1_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
@@ -171,6 +183,10 @@ __device__ __forceinline__ void mma_slab<f16x3_t>(const uint4 (&af)[4], const ui
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
     }
 }
+template <>
+__device__ __forceinline__ void mma_slab<f16x3p_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) { mma_slab<f16x3_t>(af, bf, acc); }
+template <>
+__device__ __forceinline__ void mma_slab<f16x1p_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) { mma_slab<f16x1_t>(af, bf, acc); }
 
 
 // Exact unsigned division of n < 2^31 by a launch constant d as one 64-bit multiply and a shift: sh = 31 + ceil(log2 d),
@@ -263,6 +279,10 @@ template <>
 __device__ __forceinline__ uint4 prologue<f16x3_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue<float>(v, ps, pb, c, relu); }
 template <>
 __device__ __forceinline__ uint4 prologue<f16x1_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue<float>(v, ps, pb, c, relu); }
+template <>
+__device__ __forceinline__ uint4 prologue<f16x3p_t>(uint4 v, const float*, const float*, int, bool) { return v; }      // (never instantiated with PRE)
+template <>
+__device__ __forceinline__ uint4 prologue<f16x1p_t>(uint4 v, const float*, const float*, int, bool) { return v; }
 template <>
 __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
     uint32_t u[4] = {v.x, v.y, v.z, v.w};

@@ -17,7 +17,7 @@ import threading
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X3, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X1P, DT_F16X3, DT_F16X3P, DT_F32, ConvDesc
 
 F32 = torch.float32
 IMAGENET_MEAN = (C.c_float * 3)(0.485, 0.456, 0.406)      # apps/eval.py:49-50
@@ -101,6 +101,11 @@ class ConvOp(object):
         self.flags = (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0)
         self.ho = self.wo = 0
         self.in_cs_override = None
+        # f16 arithmetic modes: layers whose activations are worth splitting ONCE (dir_split_f16_forward) so that both operands go global ->
+        # LDS by DMA: every 3x3 (each input pixel is read by 9 taps and by every output-channel tile) and the 1x1 layers with >= 4
+        # output-channel tiles; the rest (HBM-bound 1x1 layers with one or two tiles) keep converting while staging.  DIR_PRESPLIT=0|1|2: never / rule / always
+        self.presplit = self.arith is not None and (ConvOp.PRESPLIT == 2 or (ConvOp.PRESPLIT == 1 and (
+            self.kh * self.kw >= 9 or (self.cout >= 512 and self.cin >= 128))))
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
         self.variant = {}                                  # batch size -> DIR_CONV_VARIANT code chosen by DirEngine.autotune
         self.split, self._ws = {}, {}                      # batch size -> split-K factor; (B, S, stream) -> workspace
@@ -109,6 +114,8 @@ class ConvOp(object):
         if (dtype == torch.bfloat16 and self.out_dtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and stride == 1 and pad == 0
                 and self.cin % 64 == 0 and self.cout % 128 == 0 and self.cin <= 2304):
             self.w_stream = pack_stream_weights(self.w.reshape(self.cout, self.cin))
+
+    PRESPLIT = int(os.environ.get('DIR_PRESPLIT', '1'))
 
     def set_in_scale(self, s):
         """f16x3: multiply the activations by the power of two `s` before the hi / lo split; 1 / s goes into the epilogue scale (exact)"""
@@ -131,9 +138,21 @@ class ConvOp(object):
         wo = self.wo or (W + 2 * self.pad - self.kw) // self.stride + 1
         if out is None:
             out = torch.empty(B, ho, wo, self.cout, device=x.device, dtype=self.out_dtype)
-        d = ConvDesc(B, H, W, self.cin, self.in_cs_override or cbuf, in_coff, self.cout, out.shape[3], out_coff,
+        pre_scale, pre_shift, flags, in_code, in_cs = self.pre_scale, self.pre_shift, self.flags, self.in_code, self.in_cs_override or cbuf
+        if self.presplit and self.in_cs_override is None and bbox is None:
+            # the activations' hi | lo split (with in_scale and the pre-activation) as its own HBM-bound pass; the convolution then reads
+            # both operands by DMA (DIR_DT_F16X3P / F16X1P)
+            xs = torch.empty(B, H, W, self.cin, device=x.device, dtype=F32)
+            _ann('split_f16', 0, 2 * xs.numel() * 4, 'M=%d C=%d fp32 -> f16 hi | lo' % (B * H * W, self.cin))
+            _capi.check(_capi.lib().dir_split_f16_forward(_capi.ptr(x), _capi.ptr(xs), B * H * W, self.cin, cbuf, in_coff, _capi.ptr(pre_scale), _capi.ptr(pre_shift),
+                                                          1 if (flags & CONV_PRE_RELU) else 0, self.in_scale, 1 if self.arith == 'f16' else 0, _capi.stream_ptr()),
+                        'dir_split_f16_forward')
+            x, in_cs, in_coff, pre_scale, pre_shift = xs, self.cin, 0, None, None
+            flags &= ~CONV_PRE_RELU
+            in_code = DT_F16X1P if self.arith == 'f16' else DT_F16X3P
+        d = ConvDesc(B, H, W, self.cin, in_cs, in_coff, self.cout, out.shape[3], out_coff,
                      residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
-                     self.in_code, _dt(out.dtype), self.flags, self.ho, self.wo, self.in_scale)
+                     in_code, _dt(out.dtype), flags, self.ho, self.wo, self.in_scale)
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         if _capi.PROFILE is not None:
@@ -164,8 +183,8 @@ class ConvOp(object):
                                                        _capi.ptr(bbox), _capi.stream_ptr())
         else:
             rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(self.w), _capi.ptr(self.scale),
-                                                _capi.ptr(self.shift), _capi.ptr(self.pre_scale),
-                                                _capi.ptr(self.pre_shift), _capi.ptr(residual), _capi.ptr(out),
+                                                _capi.ptr(self.shift), _capi.ptr(pre_scale),
+                                                _capi.ptr(pre_shift), _capi.ptr(residual), _capi.ptr(out),
                                                 _capi.stream_ptr())
         _capi.check(rc, 'dir_conv2d_forward')
         return out

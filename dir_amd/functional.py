@@ -3,7 +3,7 @@ Feature maps are NHWC torch tensors (float32 or bfloat16) on the GPU."""
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X3, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X1P, DT_F16X3, DT_F16X3P, DT_F32, ConvDesc
 
 
 def _dt(t):
@@ -39,9 +39,23 @@ def pack_f16x3_weights(w_rows, scale=None):
     return packed, sc.contiguous()
 
 
+def split_f16(x, C, in_coff=0, pre_scale=None, pre_shift=None, pre_relu=False, in_scale=1.0, hi_only=False, out=None):
+    """dir_split_f16_forward: channels [in_coff, in_coff + C) of the fp32 NHWC tensor x -> the pre-split operand of DIR_DT_F16X3P / F16X1P
+    (a float32-TYPED tensor [B,H,W,C] whose bytes are f16 hi | lo slabs)"""
+    _capi.require_cuda(x, pre_scale, pre_shift, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and C % 32 == 0
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (C,), device=x.device, dtype=torch.float32)
+    pixels = x.numel() // x.shape[-1]
+    with torch.cuda.device(x.device):
+        _capi.check(_capi.lib().dir_split_f16_forward(_capi.ptr(x), _capi.ptr(out), pixels, C, x.shape[-1], in_coff, _capi.ptr(pre_scale), _capi.ptr(pre_shift),
+                                                      int(bool(pre_relu)), float(in_scale), int(bool(hi_only)), _capi.stream_ptr()), 'dir_split_f16_forward')
+    return out
+
+
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
-                res_coff=0, splits=1, workspace=None, arith=None, variant=0):
+                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
     if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
@@ -64,6 +78,9 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
             amax = amax * float(pre_scale.abs().max()) + float(pre_shift.abs().max())
         in_scale = 2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0
         scale = scale / in_scale
+        if presplit:     # activations split ONCE by dir_split_f16_forward (pre-activation and in_scale applied there), both operands by DMA
+            xs = split_f16(x, Cin, in_coff, pre_scale, pre_shift, pre_relu, in_scale, hi_only=(arith == 'f16'))
+            x, cbuf, in_coff, pre_scale, pre_shift, pre_relu = xs, Cin, 0, None, None, False
     Ho = (H + 2 * pad - kh) // stride + 1
     Wo = (W + 2 * pad - kw) // stride + 1
     if out is None:
@@ -77,7 +94,7 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
     for v in (pre_scale, pre_shift):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cin and v.is_contiguous())
     d = ConvDesc(B, H, W, Cin, cbuf, in_coff, Cout, out.shape[3], out_coff,
-                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, DT_F16X3 if arith == 'f16x3' else DT_F16X1 if arith == 'f16' else _dt(x), _dt(out),
+                 residual.shape[3] if residual is not None else 0, res_coff, kh, kw, stride, pad, (DT_F16X3P if presplit else DT_F16X3) if arith == 'f16x3' else (DT_F16X1P if presplit else DT_F16X1) if arith == 'f16' else _dt(x), _dt(out),
                  (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0) | ((variant & 0xff) << 8), 0, 0, in_scale)      # variant: DIR_CONV_VARIANT code
     with torch.cuda.device(x.device):
         if splits > 1:

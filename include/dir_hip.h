@@ -236,6 +236,13 @@ int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h
 /* the same operands and packing with the hi parts only: ONE f16 MFMA per product (operands rounded to f16, fp32 accumulation) -- the
  * arithmetic of torch.autocast(float16) on fp32 tensors, 8x finer than bf16; the "fp16 MFMA path" of BASELINE config 5 */
 #define DIR_DT_F16X1 4
+/* F16X3 / F16X1 with the ACTIVATIONS pre-split as well: x is what dir_split_f16_forward wrote ([pixel][Cin/32][32 hi | 32 lo] f16, the
+ * bytes and addressing of an fp32 tensor with in_cstride = Cin, in_coff = 0), already multiplied by in_scale and through the
+ * pre-activation (so pre_scale / pre_shift must be NULL here and in_scale is ignored; 1 / in_scale still belongs in scale[]).  Both
+ * operands then travel global -> LDS by DMA and nothing is converted per output tile: the form for layers with a long reduction or many
+ * output-channel tiles. */
+#define DIR_DT_F16X3P 5
+#define DIR_DT_F16X1P 6
 #define DIR_CONV_RELU 1
 #define DIR_CONV_PRE_RELU 2
 /* Optional kernel choice in bits 8..15 of dir_conv_desc.flags (0 = the library's per-layer heuristic).  Every variant
@@ -263,6 +270,12 @@ typedef struct dir_conv_desc {
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
+
+/* fp32 NHWC channel slice x[pixel][in_cstride] (channels [in_coff, in_coff + C)) -> y = the pre-split operand of DIR_DT_F16X3P / F16X1P:
+ * v = x (* pre_scale + pre_shift, ReLU if pre_relu: the pre-activation of hourglass.Residual) * in_scale, clamped to +-65504, stored per
+ * 32-channel slab as 32 hi = f16(v) then 32 lo = f16(v - hi) (lo = 0 with hi_only).  y: pixels * C * 4 bytes.  C % 32 == 0. */
+int dir_split_f16_forward(const float* x, void* y, long long pixels, int C, int in_cstride, int in_coff, const float* pre_scale,
+                          const float* pre_shift, int pre_relu, float in_scale, int hi_only, void* stream);
 
 /* dir_conv2d_forward with the reduction split over `splits` workgroups per output tile (bf16 -> bf16 layers whose M x Cout grid is too
  * small to fill 256 CUs at the benchmark batch: ResNet layer4 at 8x8, the decoder's 16x16 Residual blocks).  128x128 tiles; every

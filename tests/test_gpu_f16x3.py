@@ -50,6 +50,12 @@ def test_f16x3_conv_matches_float64_oracle(case):
         y = F.conv2d_nhwc(dx, dw, s, p, sc, sh, relu=True, arith='f16x3', variant=variant)
         e3 = relerr(y.cpu().numpy().transpose(0, 3, 1, 2), ref)
         assert e3 < TOL, (variant, e3)
+    for variant in (0, 1, 2, 3, 4, 17, 18, 20):                        # activations pre-split (DIR_DT_F16X3P): DMA path, incl. the 3-buffer ring tiles
+        yp = F.conv2d_nhwc(dx, dw, s, p, sc, sh, relu=True, arith='f16x3', variant=variant, presplit=True)
+        ep = relerr(yp.cpu().numpy().transpose(0, 3, 1, 2), ref)
+        assert ep < TOL, ('presplit', variant, ep)
+        if variant == 0:
+            assert torch.equal(yp, F.conv2d_nhwc(dx, dw, s, p, sc, sh, relu=True, arith='f16x3', variant=0))      # same operands, same order: same bits
     e32 = relerr(F.conv2d_nhwc(dx, dw, s, p, sc, sh, relu=True).cpu().numpy().transpose(0, 3, 1, 2), ref)
     print('%s: f16x3 %.2e  exact fp32 %.2e  (of the output scale)' % (tag, e3, e32))
     assert e3 < 4 * e32 + 2e-7
@@ -93,6 +99,10 @@ def test_f16x3_prologue_residual_and_concat_slices():
     e = relerr(got[..., 32:].transpose(0, 3, 1, 2), ref)
     print('f16x3 prologue + residual: %.2e' % e)
     assert e < TOL
+    out2 = torch.full((B, H, W, Co + 32), 7.0, device='cuda')          # the same through the pre-split pass (pre-activation applied there)
+    F.conv2d_nhwc(dx, dw, 1, 1, None, torch.from_numpy(bias).cuda(), residual=dres, pre_scale=torch.from_numpy(ps).cuda(),
+                  pre_shift=torch.from_numpy(pb).cuda(), pre_relu=True, out=out2, out_coff=32, in_coff=64, cin=Ci, arith='f16x3', presplit=True)
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize('shape', [(3, 16, 64, 64, 256, 1), (2, 32, 128, 256, 512, 2), (5, 8, 256, 512, 96, 2)])
