@@ -55,6 +55,7 @@ def parse_args(argv=None):
                     '(profiling runs use it to keep the exploration out of the trace)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
+    ap.add_argument('--no-train', action='store_true', help='skip the training-step sub-record (batch 32, fp32)')
     ap.add_argument('--no-proj-feat-variant', action='store_true', help='skip the serving variant without the proj_feat output')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images timed on the numpy CPU baseline')
     ap.add_argument('--cpu-threads', type=int, default=16)
@@ -388,6 +389,51 @@ def main():
                           'rounded to f16 (one MFMA per product, fp32 accumulate); all three stages within 0.01 mm of the reference on trained-like '
                           'weights (init 0.007 mm, refined 0.0003 - 0.001 mm; bf16: 0.05 / 0.005); roofline priced against the dense f16 peak')
 
+    # ---- training step (BASELINE config 4's per-GPU batch: 32 images, fp32, the whole network: forward in training mode, 42-term
+    #      objective, backward, flat gradient bucket, one AdamW launch -- dir_amd/train/step.py); rank 0, single-GPU runs only
+    train = None
+    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_train:
+        from dir_amd.optim import FlatAdamW
+        from dir_amd.train import step as TSTEP
+        torch.cuda.empty_cache()
+        TB = 32
+        is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
+        tparams = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in sd.items() if not is_buf(k)}
+        tbuf = {k: v.clone().to(dev) for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
+        topt = FlatAdamW(list(tparams.values()), lr=1e-5)
+        topt.set_inactive(TSTEP.inactive_parameters(tparams))
+        rng = np.random.RandomState(0)
+        dv = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev)  # noqa: E731
+        timg = torch.randn(TB, 3, 256, 256, device=dev, generator=g)
+        ttar, tmeta = {}, {}
+        for s_ in ('left', 'right'):
+            ttar['joint_2d_' + s_] = dv(rng.uniform(-1, 1, (TB, 21, 3)).astype(np.float32))
+            ttar['mesh_2d_' + s_] = dv(rng.uniform(-1, 1, (TB, 778, 3)).astype(np.float32))
+            ttar['joint_3d_' + s_] = dv(rng.normal(0, 0.05, (TB, 21, 3)).astype(np.float32))
+            ttar['mesh_3d_' + s_] = dv(rng.normal(0, 0.05, (TB, 778, 3)).astype(np.float32))
+            tmeta['center_' + s_] = dv(rng.normal(0, 0.1, (TB, 1, 3)).astype(np.float32))
+        ttar['seg'] = dv(rng.randint(0, 3, (TB, 1, 256, 256)).astype(np.float32))
+        ttar['dense'] = dv(rng.rand(TB, 3, 256, 256).astype(np.float32))
+        tfaces = tuple(dv(synth.loss_faces(s_, 1234).astype(np.int64)) for s_ in ('left', 'right'))
+        tt, objective = [], []
+        for i in range(4):
+            sync()
+            t0 = time.perf_counter()
+            tl = TSTEP.train_step(tparams, tbuf, timg, ttar, tmeta, tfaces, topt)
+            sync()
+            tt.append(time.perf_counter() - t0)
+            objective.append(round(sum(float(v) for v in tl.values()), 4))
+        best = min(tt[1:])
+        # executed arithmetic: forward 36.8 GFLOP per image (all convolutions materialised in training) + data and weight gradients = 3x
+        train = {'batch_per_gpu': TB, 'seconds_per_step': round(best, 4), 'images_per_sec': round(TB / best, 1), 'steps_timed': 3,
+                 'objective_per_step': objective, 'dtype': 'f32',
+                 'algorithmic_tflops': round(3 * ALG_GFLOP_PER_IMAGE * 1e9 * TB / best / 1e12, 2), 'peak_tflops': PEAK['f32'] / 1e12,
+                 'frac_of_fp32_mfma_peak': round(3 * ALG_GFLOP_PER_IMAGE * 1e9 * TB / best / PEAK['f32'], 4),
+                 'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                 'note': 'dir_amd.train.step.train_step on one GPU (no exchange partner): exact-fp32 kernels, correctness-first, eager (about 4000 launches per step)'}
+        del tparams, tbuf, topt
+        torch.cuda.empty_cache()
+
     # ---- CPU baselines on the host cores (rank 0, single-GPU runs only), bounded samples:
     #   port        the numpy oracle (CPU restatement of the reference).  OpenBLAS is pinned to the thread count that serves these
     #               GEMM sizes best on the box (measured: 8-16 threads 4.2 img/s, 32 threads 2.4, 64 threads 1.1 -- oversubscription)
@@ -450,7 +496,7 @@ def main():
                            'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
-                'roofline': roof, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'without_proj_feat': no_pf}
+                'roofline': roof, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
