@@ -171,6 +171,28 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
     }
 }
 
+// ------------------------------------------------------------------------------------------ add (nearest-upsampled) -- HRNet fuse layers
+// acc[b, y, x, c] = act(acc[b, y, x, c] + src[b, y / f, x / f, c]): the sum of an HRNet fuse layer, one term at a time (f = 1: a plain add)
+template <typename T>
+__global__ __launch_bounds__(256) void add_upsampled_kernel(T* __restrict__ acc, const T* __restrict__ src, int B, int H, int W, int C, int f, int relu) {
+    constexpr int VN = Vec<T>::N;
+    const long long n = (long long)B * H * W * (C / VN);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % (C / VN));
+        long long p = i / (C / VN);
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        float a[VN], s[VN];
+        T* ap = acc + (((long long)b * H + y) * W + x) * C + cv * VN;
+        Vec<T>::load(ap, a);
+        Vec<T>::load(src + (((long long)b * (H / f) + y / f) * (W / f) + x / f) * C + cv * VN, s);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { a[e] += s[e]; if (relu) a[e] = fmaxf(a[e], 0.f); }
+        Vec<T>::store(ap, a);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ upsample
 // One thread = one INPUT pixel x one 16-byte channel vector -> its 2x2 output quad: the quad's four bilinear footprints lie inside the
 // pixel's 3x3 neighbourhood, so 9 vector loads (clamped addresses, all independent) serve 4 output vectors instead of 16, and the
@@ -604,6 +626,17 @@ extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((maxpool_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
     else DIR_REQUIRE(false, "dir_maxpool3x3s2: bad dtype");
     return dir::check_launch("dir_maxpool3x3s2");
+}
+
+extern "C" int dir_add_upsampled(void* acc, const void* src, int B, int H, int W, int C, int factor, int relu, int dtype, void* stream) {
+    DIR_REQUIRE(acc && src && B > 0 && H > 0 && W > 0 && C > 0 && factor >= 1, "dir_add_upsampled: bad args");
+    DIR_REQUIRE(C % 8 == 0 && H % factor == 0 && W % factor == 0, "dir_add_upsampled: C must be a multiple of 8, H and W multiples of the factor");
+    const long long n = (long long)B * H * W * (C / (dtype == DIR_DT_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((add_upsampled_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (float*)acc, (const float*)src, B, H, W, C, factor, relu);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((add_upsampled_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)acc, (const bf16_t*)src, B, H, W, C, factor, relu);
+    else DIR_REQUIRE(false, "dir_add_upsampled: bad dtype");
+    return dir::check_launch("dir_add_upsampled");
 }
 
 extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, int out_cstride,

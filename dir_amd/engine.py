@@ -642,6 +642,156 @@ def backbone_standalone(module, x, compute_dtype=torch.float32):
     return [f.permute(0, 3, 1, 2).float() for f in feats]
 
 
+# ------------------------------------------------------------------------------------------------------------- HRNet-W48 (f4)
+def _padc(c):
+    """physical channel count of a logical width: the convolution kernels reduce in 64-channel (bf16) / 32-channel (fp32) slabs and the
+    HRNet widths 48 and 96 are neither: 48 -> 64, 96 -> 128 (zero weights / zero BatchNorm scale and shift on the padding: exact zeros)"""
+    return (c + 63) // 64 * 64
+
+
+def _pad_conv_bn(sd, conv_key, bn_prefix, dtype, stride=1, relu=True):
+    """Conv2d(bias=False) + BatchNorm2d (+ ReLU) with both channel dimensions padded to _padc"""
+    w = sd[conv_key]
+    co, ci, kh, kw = w.shape
+    wp = torch.zeros(_padc(co), _padc(ci), kh, kw, device=w.device, dtype=torch.float32)
+    wp[:co, :ci] = w.float()
+    sc, sh = bn_fold(sd, bn_prefix)
+    scp, shp = torch.zeros(_padc(co), device=w.device), torch.zeros(_padc(co), device=w.device)
+    scp[:co], shp[:co] = sc.to(w.device), sh.to(w.device)
+    return ConvOp(wp, dtype, stride=stride, pad=kh // 2, scale=scp, shift=shp, relu=relu)
+
+
+class HRNetOp(object):
+    """HRNet-W48 pyramid (dir_amd/models/backbone/hrnet.py; SURVEY.md 8f rank 4, no reference counterpart) on the same convolution entry
+    points as the ResNet: every Conv + BN (+ ReLU, + residual) is one dir_conv2d_forward (layer1's projection shortcut folded as in
+    BackboneOp), a fuse layer's sum is accumulated term by term -- the strided-conv terms through the convolution's residual input, the
+    identity / upsampled terms by dir_add_upsampled (nearest x 2^(j-i), the ReLU on the last term).  Returns [c1, c2, c3, c4] NHWC."""
+    WIDTHS = (48, 96, 192, 384)
+    MODULES = ((2, 1), (3, 4), (4, 3))
+
+    def __init__(self, sd, p, dtype, device):
+        dt = self.dtype = dtype
+        self.device = device
+        # stem conv1 (3x3 / 2 on 3 channels): over the zero-bordered NHWC4 image of dir_stem_prep as a kh = 3, kw = 1 reduction over windows
+        # of 16 pixels x 4 channels (weights zero beyond the 3 x 3 real ones): K = 192 instead of 9 x 64
+        w = sd[p + '.conv1.weight'].float()
+        wp = torch.zeros(64, 64, 3, 1, device=w.device)
+        for j in range(3):
+            wp[:, 4 * j:4 * j + 3, :, 0] = w[:, :, :, j]
+        s1, h1 = bn_fold(sd, p + '.bn1')
+        self.conv1 = ConvOp(wp, dt, stride=2, pad=0, scale=s1, shift=h1, relu=True)
+        self.conv1.ho = self.conv1.wo = 0          # set per call (H / 2)
+        self.conv1.in_cs_override = 4
+        self.conv1.alg_k = 27
+        s2, h2 = bn_fold(sd, p + '.bn2')
+        self.conv2 = ConvOp(sd[p + '.conv2.weight'], dt, stride=2, pad=1, scale=s2, shift=h2, relu=True)
+        self.layer1 = []
+        for b in range(4):
+            q = '%s.layer1.%d' % (p, b)
+            sa, ha = bn_fold(sd, q + '.bn1'); sb, hb = bn_fold(sd, q + '.bn2'); sc, hc = bn_fold(sd, q + '.bn3')
+            blk = dict(c1=ConvOp(sd[q + '.conv1.weight'], dt, scale=sa, shift=ha, relu=True),
+                       c2=ConvOp(sd[q + '.conv2.weight'], dt, pad=1, scale=sb, shift=hb, relu=True))
+            if (q + '.downsample.0.weight') in sd:
+                sd_, hd_ = bn_fold(sd, q + '.downsample.1')
+                blk['dual'] = DualConvOp(sd[q + '.conv3.weight'], sc, hc, sd[q + '.downsample.0.weight'], sd_, hd_, 1, dt)
+            else:
+                blk['c3'] = ConvOp(sd[q + '.conv3.weight'], dt, scale=sc, shift=hc, relu=True)
+            self.layer1.append(blk)
+        self.trans = {(1, 0): _pad_conv_bn(sd, p + '.transition1.0.0.weight', p + '.transition1.0.1', dt),
+                      (1, 1): _pad_conv_bn(sd, p + '.transition1.1.0.weight', p + '.transition1.1.1', dt, stride=2),
+                      (2, 2): _pad_conv_bn(sd, p + '.transition2.0.weight', p + '.transition2.1', dt, stride=2),
+                      (3, 3): _pad_conv_bn(sd, p + '.transition3.0.weight', p + '.transition3.1', dt, stride=2)}
+        self.stages = []
+        for st, n in self.MODULES:
+            mods = []
+            for m in range(n):
+                q = '%s.stage%d.%d' % (p, st, m)
+                branches = [[(_pad_conv_bn(sd, '%s.branches.%d.%d.conv1.weight' % (q, b, k), '%s.branches.%d.%d.bn1' % (q, b, k), dt),
+                              _pad_conv_bn(sd, '%s.branches.%d.%d.conv2.weight' % (q, b, k), '%s.branches.%d.%d.bn2' % (q, b, k), dt))
+                             for k in range(4)] for b in range(st)]
+                fuse = {}
+                for i in range(st):
+                    for j in range(st):
+                        f = '%s.fuse_layers.%d.%d' % (q, i, j)
+                        if j > i:
+                            fuse[(i, j)] = [_pad_conv_bn(sd, f + '.0.weight', f + '.1', dt, relu=False)]
+                        elif j < i:
+                            fuse[(i, j)] = [_pad_conv_bn(sd, '%s.%d.0.weight' % (f, t), '%s.%d.1' % (f, t), dt, stride=2, relu=(t < i - j - 1))
+                                            for t in range(i - j)]
+                mods.append((branches, fuse))
+            self.stages.append(mods)
+        self.incre = [_pad_conv_bn(sd, '%s.incre.%d.0.weight' % (p, b), '%s.incre.%d.1' % (p, b), dt) for b in range(4)]
+
+    def _add(self, acc, src, factor, relu):
+        B, H, W, Cc = acc.shape
+        _ann('hr_fuse', 0, (2 * acc.numel() + src.numel()) * acc.element_size(), 'add %dx%dx%d (x%d)' % (H, W, Cc, factor))
+        _capi.check(_capi.lib().dir_add_upsampled(_capi.ptr(acc), _capi.ptr(src), B, H, W, Cc, factor, 1 if relu else 0, _dt(self.dtype),
+                                                  _capi.stream_ptr()), 'dir_add_upsampled')
+
+    def _module(self, xs, mod):
+        branches, fuse = mod
+        nb = len(xs)
+        ys = []
+        for b in range(nb):
+            y = xs[b]
+            for c1, c2 in branches[b]:
+                y = c2(c1(y), residual=y)                     # relu(bn2(conv2(.)) + x): the epilogue adds the residual before the ReLU
+            ys.append(y)
+        outs = []
+        for i in range(nb):
+            acc = None
+            for j in range(nb):
+                last = j == nb - 1
+                if j == i:
+                    if acc is None:
+                        acc = ys[j].clone()                  # (a copy: the branch output also feeds the other fuse rows)
+                    else:
+                        self._add(acc, ys[j], 1, last)
+                elif j > i:
+                    self._add(acc, fuse[(i, j)][0](ys[j]), 2 ** (j - i), last)
+                else:
+                    t = ys[j]
+                    chain = fuse[(i, j)]
+                    for op in chain[:-1]:
+                        t = op(t)
+                    acc = chain[-1](t) if acc is None else chain[-1](t, residual=acc)
+            outs.append(acc)
+        return outs
+
+    def __call__(self, img):
+        L, dt, dev = _capi.lib(), self.dtype, self.device
+        assert img.dtype == F32, 'the HRNet path takes the normalised float image (NCHW)'
+        B, _, H, W = img.shape
+        Hp, Wp = H + 2, W + 2
+        xp = torch.empty(B, Hp, Wp, 4, device=dev, dtype=dt)
+        _ann('stem', 0, img.numel() * 4 + xp.numel() * xp.element_size(), 'B=%d NHWC4 staging' % B)
+        _capi.check(L.dir_stem_prep(_capi.ptr(img), _capi.ptr(xp), B, H, W, Hp, Wp, 1, _dt(dt), _capi.stream_ptr()), 'dir_stem_prep')
+        self.conv1.ho, self.conv1.wo = H // 2, W // 2
+        x = self.conv2(self.conv1(xp))
+        for blk in self.layer1:
+            y = blk['c2'](blk['c1'](x))
+            x = blk['dual'](y, x) if 'dual' in blk else blk['c3'](y, residual=x)
+        xs = [self.trans[(1, 0)](x), self.trans[(1, 1)](x)]
+        for si, (st, n) in enumerate(self.MODULES):
+            if st > 2:
+                xs = xs + [self.trans[(st - 1, st - 1)](xs[-1])]
+            for mod in self.stages[si]:
+                xs = self._module(xs, mod)
+        return [self.incre[b](xs[b]) for b in range(4)]
+
+
+def hrnet_standalone(module, x, compute_dtype=torch.float32):
+    """HRNetW48.forward of the mirror module: NCHW float32 in, [c1..c4] NCHW float32 out."""
+    _capi.require_cuda(x)
+    if module.training:
+        raise NotImplementedError('the HRNet backbone (no reference counterpart) is built for inference: call .eval()')
+    sd = {'b.' + k: v.detach() for k, v in module.state_dict().items()}
+    op = HRNetOp(sd, 'b', compute_dtype, x.device)
+    with torch.cuda.device(x.device):
+        feats = op(_capi.f32c(x.detach()))
+    return [f.permute(0, 3, 1, 2).float() for f in feats]
+
+
 class ResidualOp(object):
     """hourglass.Residual (models/backbone/hourglass.py:33-70), all convs carry a bias"""
 
@@ -761,7 +911,8 @@ class DirEngine(object):
     # ------------------------------------------------------------------------------------------ packing
     def _pack(self, sd, root_joint):
         dt, keep = self.dtype, self.keep
-        self.bb = BackboneOp(sd, 'backbone', dt, self.device)
+        hr = 'backbone.stage4.0.fuse_layers.0.1.0.weight' in sd              # f4: HRNet-W48 instead of ResNet-50 (no reference counterpart)
+        self.bb = HRNetOp(sd, 'backbone', dt, self.device) if hr else BackboneOp(sd, 'backbone', dt, self.device)
         # InitRegressor
         p = 'init_regressor'
         H = _capi.InitHeadParams()

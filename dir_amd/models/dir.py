@@ -162,7 +162,7 @@ class _TrainObjective(torch.autograd.Function):
 
 
 class DIR(nn.Module):
-    def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16, extra_stages=0, arith=None):
+    def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16, extra_stages=0, arith=None, backbone='resnet50'):
         """extra_stages / arith are this build's extensions (defaults = the reference's network): extra_stages = N more refinement iterations at
         32x32 (config 5's "5 refinement iters" = extra_stages 2; outs_list then carries 3 + N stage dicts before the dense / seg dict; eval
         mode only); arith = 'f16x3' with compute_dtype float32: the split-precision parity mode (DirEngine)."""
@@ -171,7 +171,13 @@ class DIR(nn.Module):
         self.joint_num = joint_num
         self.root_joint = root_joint
         self.compute_dtype = compute_dtype
-        self.backbone = ResNet50()        # ImageNet weights are a download in the reference (models/dir.py:490-498)
+        assert backbone in ('resnet50', 'hrnet_w48')
+        if backbone == 'hrnet_w48':       # BASELINE config 5; no reference counterpart (dir_amd/models/backbone/hrnet.py); inference only
+            from .backbone.hrnet import hrnet_w48
+            self.backbone = hrnet_w48()
+        else:
+            self.backbone = ResNet50()    # ImageNet weights are a download in the reference (models/dir.py:490-498)
+        self.backbone_name = backbone
         self.mesh_sample_num = joint_num
         self.init_regressor = InitRegressor(self.backbone.inplanes, mano_path, root_joint)
         self.decoder = FusionJointInterIterDecoder(self.joint_num, mano_path, root_joint, extra_stages=self.extra_stages)
@@ -257,7 +263,7 @@ class DIR(nn.Module):
 
     def forward(self, input, target, meta_info):
         if self.training:
-            if self.extra_stages:
+            if self.extra_stages or self.backbone_name != 'resnet50':
                 raise NotImplementedError('extra_stages (no reference counterpart) is built for inference only; training covers the reference network')
             return self._forward_train(input, target, meta_info)
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)

@@ -125,6 +125,10 @@ def synth_tensor(name, shape, shapes, seed=1234, cond=False):
                                                  or base.endswith('head.0'))
     if is_bn or is_ln:
         if leaf == 'weight':
+            if cond and (('.branches.' in name and '.bn2.' in name) or '.fuse_layers.' in name):
+                # HRNet-W48 (f4): 32 BasicBlocks in sequence per branch and 8 fuse sums -- residual branches and fused terms enter with a small
+                # gain (what zero-init-residual training leaves behind), or the trained-like flavour would not stay O(1)
+                return g.uniform(0.15, 0.3, shape).astype(f32)
             return g.uniform(0.8, 1.2, shape).astype(f32)
         return g.normal(0, 0.1, shape).astype(f32)
     if leaf == 'W':  # PGraphConv per-node weights [2,J,Cin,Cout], xavier_uniform gain 1.414

@@ -364,6 +364,9 @@ int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dty
  * channels [out_coff, out_coff+C) of y [B,2H,2W,out_cstride] (out_cstride 0 = C) */
 int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, int out_cstride, int out_coff,
                             int dtype, void* stream);
+/* f4 (HRNet fuse layers; no reference counterpart): acc [B,H,W,C] = act(acc + nearest_upsample(src [B,H/f,W/f,C], f)), in place, one term
+ * of `y = y + fuse_layers[i][j](x[j])` at a time; factor 1 = a plain add; relu != 0 on the last term (the fuse layer's ReLU). */
+int dir_add_upsampled(void* acc, const void* src, int B, int H, int W, int C, int factor, int relu, int dtype, void* stream);
 
 /* InitRegressor tail (models/dir.py:263-270): 1x1 conv Ch->1 + sigmoid attention, attention-weighted pooling
  * of c4 (+1e-8), plain mean, Linear C->64 (left, right) and C->3 (offset). */

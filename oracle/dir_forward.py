@@ -113,7 +113,11 @@ def dir_forward(sd, img, root_joint=0, dtype=np.float32, taps=None):
     """DIR.forward(eval) -> outs_list (len 4) exactly as models/dir.py:521-540 (pd_rel_joint=None)."""
     P = N.Params(sd, '', dtype)
     img = np.asarray(img).astype(dtype)
-    feats = resnet50(img, P.sub('backbone'), taps)
+    if 'backbone.stage4.0.fuse_layers.0.1.0.weight' in P:          # f4: the HRNet-W48 backbone (oracle/hrnet.py; no reference counterpart)
+        from .hrnet import hrnet_w48
+        feats = hrnet_w48(img, P.sub('backbone'))
+    else:
+        feats = resnet50(img, P.sub('backbone'), taps)
     if taps is not None:
         taps.update(c1=feats[0], c2=feats[1], c3=feats[2], c4=feats[3])
     init = init_regressor(feats[3], P.sub('init_regressor'), root_joint)
