@@ -25,7 +25,7 @@ class ManoTables(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'B', 'H', 'W', 'Cin', 'in_cstride', 'in_coff', 'Cout', 'out_cstride', 'out_coff', 'res_cstride', 'res_coff',
-        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')] + [('in_scale', C.c_float)]
+        'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')] + [('in_scale', C.c_float), ('out_split_scale', C.c_float)]
 
 
 class ConvSrc2(C.Structure):

@@ -479,6 +479,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < VN; ++e) v[e] += rv[e];
             }
+            if constexpr (std::is_same<TO, float>::value) {
+                if (a.out_split_scale > 0.f) { store_split4(y, m, n, a.Cout, v, relu, a.out_split_scale, a.out_split_hi_only != 0); continue; }
+            }
             OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
         }
         return;
@@ -643,6 +646,12 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     a.flags = d->flags & 3;
     a.variant = (d->flags >> 8) & 0xff;
     a.a_scale = (x3 && !xp && d->in_scale > 0.f) ? d->in_scale : 1.f;
+    a.out_split_scale = 0.f; a.out_split_hi_only = 0;
+    if (d->out_split_scale != 0.f) {        // > 0: hi | lo; < 0: hi only, scale = |value|
+        DIR_REQUIRE(d->out_dtype == DIR_DT_F32 && d->Cout % 32 == 0 && out_cs == d->Cout && d->out_coff == 0,
+                    "dir_conv2d_forward: out_split_scale needs an fp32 output that is a whole tensor with Cout %% 32 == 0");
+        a.out_split_scale = fabsf(d->out_split_scale); a.out_split_hi_only = d->out_split_scale < 0.f;
+    }
     DIR_REQUIRE(d->kh * d->kw <= 32, "dir_conv2d_forward: at most 32 taps");
     const long long xb = (long long)d->B * d->H * d->W * in_cs * (f32 ? 4 : 2);
     const long long wb = (long long)d->Cout * a.K * (f32 ? 4 : 2);
@@ -656,6 +665,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     const bool vec = d->Cout % epo == 0 && out_cs % epo == 0 && d->out_coff % epo == 0 &&
                      (residual == nullptr || (res_cs % epo == 0 && d->res_coff % epo == 0));
     if (vec) a.flags |= 4;
+    DIR_REQUIRE(a.out_split_scale == 0.f || vec, "dir_conv2d_forward: out_split_scale needs 16-byte aligned output / residual rows");
     static int num_cu = 0;
     if (num_cu == 0) {
         int dev = 0;

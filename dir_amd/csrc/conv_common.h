@@ -118,6 +118,8 @@ struct ConvArgs {
     int kh, kw, stride, pad, Ho, Wo, M, K, nk, tiles_m, tiles_n, flags;
     int variant;                        // DIR_CONV_VARIANT code (0 = heuristic)
     float a_scale;                      // f16x3: power of two applied to the activations before the hi / lo split (dir_conv_desc.in_scale)
+    float out_split_scale;              // > 0 (fp32 outputs only): write y as the NEXT convolution's pre-split operand ([pixel][Cout/32][hi 32 | lo 32]
+    int out_split_hi_only;              //   f16 of act(y) * out_split_scale; dir_conv_desc.out_split_scale) instead of fp32 -- the same bytes, no pass
     // optional second source, a 1x1 (strided) convolution accumulated into the same output: K-slabs ks >= nk1 read x2;
     // weight rows are [kh*kw*Cin | Cin2] (dir_conv2d_dual_forward)
     const void* x2; unsigned x2_bytes; int H2, W2, in_cs2, in_co2, stride2, nk1;
@@ -238,6 +240,16 @@ template <> struct OutVec<float> {
                                              : make_float4(v[0], v[1], v[2], v[3]);
     }
 };
+// four consecutive output channels n .. n+3 of pixel m as the pre-split operand of the next convolution (out_cs == Cout, out_co == 0)
+__device__ __forceinline__ void store_split4(float* y, long long m, int n, int Cout, const float (&v)[4], bool relu, float s, bool hi_only) {
+    uint4 t = relu ? make_uint4(__float_as_uint(fmaxf(v[0], 0.f)), __float_as_uint(fmaxf(v[1], 0.f)), __float_as_uint(fmaxf(v[2], 0.f)), __float_as_uint(fmaxf(v[3], 0.f)))
+                   : make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    const uint4 sp = hi_only ? split_f16x1(t, s) : split_f16x3(t, s);
+    char* row = reinterpret_cast<char*>(y) + (m * Cout + (n & ~31)) * 4;
+    *reinterpret_cast<uint2*>(row + 2 * (n & 31)) = make_uint2(sp.x, sp.y);
+    *reinterpret_cast<uint2*>(row + 64 + 2 * (n & 31)) = make_uint2(sp.z, sp.w);
+}
+
 template <> struct OutVec<bf16_t> {
     static constexpr int N = 8;
     static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
@@ -336,6 +348,9 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
             OutVec<TO>::load(res + (long long)m * a.res_cs + a.res_co + n, rv);
 #pragma unroll
             for (int e = 0; e < VN; ++e) v[e] += rv[e];
+        }
+        if constexpr (std::is_same<TO, float>::value) {
+            if (a.out_split_scale > 0.f) { store_split4(y, m, n, a.Cout, v, relu, a.out_split_scale, a.out_split_hi_only != 0); continue; }
         }
         OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
     }

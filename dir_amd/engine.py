@@ -106,6 +106,7 @@ class ConvOp(object):
         # output-channel tiles; the rest (HBM-bound 1x1 layers with one or two tiles) keep converting while staging.  DIR_PRESPLIT=0|1|2: never / rule / always
         self.presplit = self.arith is not None and (ConvOp.PRESPLIT == 2 or (ConvOp.PRESPLIT == 1 and (
             self.kh * self.kw >= 9 or (self.cout >= 512 and self.cin >= 128))))
+        self.split_consumer = None                         # f16 arithmetic modes: the ONE convolution reading this op's whole output (link_split)
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
         self.variant = {}                                  # batch size -> DIR_CONV_VARIANT code chosen by DirEngine.autotune
         self.split, self._ws = {}, {}                      # batch size -> split-K factor; (B, S, stream) -> workspace
@@ -116,6 +117,15 @@ class ConvOp(object):
             self.w_stream = pack_stream_weights(self.w.reshape(self.cout, self.cin))
 
     PRESPLIT = int(os.environ.get('DIR_PRESPLIT', '1'))
+    OUT_SPLIT = os.environ.get('DIR_OUT_SPLIT', '1') != '0'      # producers write the next convolution's pre-split operand (link_split)
+
+    def link_split(self, consumer):
+        """f16 arithmetic modes: declare that `consumer` (a ConvOp without pre-activation) is the ONLY reader of this convolution's whole fp32
+        output: the epilogue then writes that tensor directly as the consumer's pre-split operand (f16 hi | lo slabs times the consumer's
+        in_scale -- the same bytes as fp32), and the consumer takes the two-operand DMA path without a dir_split_f16_forward pass."""
+        if (self.arith is not None and isinstance(consumer, ConvOp) and consumer.arith == self.arith and consumer.pre_scale is None
+                and consumer.in_cs_override is None and self.cout == consumer.cin and self.cout % 32 == 0 and self.out_dtype == F32):
+            self.split_consumer = consumer
 
     def set_in_scale(self, s):
         """f16x3: multiply the activations by the power of two `s` before the hi / lo split; 1 / s goes into the epilogue scale (exact)"""
@@ -136,10 +146,15 @@ class ConvOp(object):
             self._calibrate([x[..., in_coff:in_coff + self.cin]] if self.in_cs_override is None else [x])
         ho = self.ho or (H + 2 * self.pad - self.kh) // self.stride + 1
         wo = self.wo or (W + 2 * self.pad - self.kw) // self.stride + 1
+        out_given, residual_ok = out, True
         if out is None:
             out = torch.empty(B, ho, wo, self.cout, device=x.device, dtype=self.out_dtype)
         pre_scale, pre_shift, flags, in_code, in_cs = self.pre_scale, self.pre_shift, self.flags, self.in_code, self.in_cs_override or cbuf
-        if self.presplit and self.in_cs_override is None and bbox is None:
+        if getattr(x, '_dir_split', False):
+            # the producer's epilogue already wrote this tensor as f16 hi | lo slabs scaled by OUR in_scale (link_split): straight to the DMA path
+            assert in_coff == 0 and cbuf == self.cin and pre_scale is None and bbox is None
+            in_code = DT_F16X1P if self.arith == 'f16' else DT_F16X3P
+        elif self.presplit and self.in_cs_override is None and bbox is None:
             # the activations' hi | lo split (with in_scale and the pre-activation) as its own HBM-bound pass; the convolution then reads
             # both operands by DMA (DIR_DT_F16X3P / F16X1P)
             xs = torch.empty(B, H, W, self.cin, device=x.device, dtype=F32)
@@ -153,6 +168,11 @@ class ConvOp(object):
         d = ConvDesc(B, H, W, self.cin, in_cs, in_coff, self.cout, out.shape[3], out_coff,
                      residual.shape[3] if residual is not None else 0, res_coff, self.kh, self.kw, self.stride, self.pad,
                      in_code, _dt(out.dtype), flags, self.ho, self.wo, self.in_scale)
+        cons = self.split_consumer
+        write_split = (cons is not None and out_given is None and residual_ok and not getattr(_TLS, 'calibrating', False)
+                       and not getattr(_TLS, 'no_out_split', False) and ConvOp.OUT_SPLIT)
+        if write_split:      # the only reader is the next convolution: write its pre-split operand instead of fp32 (same bytes, no split pass)
+            d.out_split_scale = -cons.in_scale if cons.arith == 'f16' else cons.in_scale
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
         d.flags |= (v & 0xff) << 8
         if _capi.PROFILE is not None:
@@ -187,6 +207,8 @@ class ConvOp(object):
                                                 _capi.ptr(pre_shift), _capi.ptr(residual), _capi.ptr(out),
                                                 _capi.stream_ptr())
         _capi.check(rc, 'dir_conv2d_forward')
+        if write_split:
+            out._dir_split = True
         return out
 
 
@@ -559,6 +581,9 @@ class BackboneOp(object):
                         blk['dual'] = DualConvOp(sd[q + '.conv3.weight'], s3, h3, sd[q + '.downsample.0.weight'], sd_, hd_, stride, dt)
                     else:
                         blk['ds'] = ConvOp(sd[q + '.downsample.0.weight'], dt, stride=stride, scale=sd_, shift=hd_)
+                blk['c1'].link_split(blk['c2'])
+                if 'dual' not in blk and blk['ds'] is None:
+                    blk['c2'].link_split(blk['c3'])
                 blocks.append(blk)
             self.layers.append(blocks)
         # layer1 (HBM-bound): blocks without a projection shortcut run conv2 -> conv3 -> (next block's conv1) as one kernel
@@ -696,6 +721,9 @@ class HRNetOp(object):
                 blk['dual'] = DualConvOp(sd[q + '.conv3.weight'], sc, hc, sd[q + '.downsample.0.weight'], sd_, hd_, 1, dt)
             else:
                 blk['c3'] = ConvOp(sd[q + '.conv3.weight'], dt, scale=sc, shift=hc, relu=True)
+            blk['c1'].link_split(blk['c2'])
+            if 'c3' in blk:
+                blk['c2'].link_split(blk['c3'])
             self.layer1.append(blk)
         self.trans = {(1, 0): _pad_conv_bn(sd, p + '.transition1.0.0.weight', p + '.transition1.0.1', dt),
                       (1, 1): _pad_conv_bn(sd, p + '.transition1.1.0.weight', p + '.transition1.1.1', dt, stride=2),
@@ -709,6 +737,9 @@ class HRNetOp(object):
                 branches = [[(_pad_conv_bn(sd, '%s.branches.%d.%d.conv1.weight' % (q, b, k), '%s.branches.%d.%d.bn1' % (q, b, k), dt),
                               _pad_conv_bn(sd, '%s.branches.%d.%d.conv2.weight' % (q, b, k), '%s.branches.%d.%d.bn2' % (q, b, k), dt))
                              for k in range(4)] for b in range(st)]
+                for br in branches:
+                    for c1, c2 in br:
+                        c1.link_split(c2)
                 fuse = {}
                 for i in range(st):
                     for j in range(st):
@@ -810,6 +841,9 @@ class ResidualOp(object):
         if self.need_skip and self.fold_skip:
             one = torch.ones(w('conv3').shape[0], device=w('conv3').device)
             self.dual = DualConvOp(w('conv3'), one, b('conv3'), w('skip_layer'), one, b('skip_layer'), 1, dtype, relu=False)
+        self.c1.link_split(self.c2)
+        if self.dual is None:
+            self.c2.link_split(self.c3)
 
     fold_skip = os.environ.get('DIR_FOLD_SKIP', '1') != '0'
 
@@ -963,6 +997,9 @@ class DirEngine(object):
             b3.append(sd['%s.%s.3.bias' % (d, k)])
         self.heads0 = ConvOp(torch.cat(w0, 0), dt, pad=1, scale=torch.cat(s0), shift=torch.cat(h0), relu=True)
         self.heads3 = ConvOp(w3, dt, shift=torch.cat(b3), out_dtype=F32)
+        self.final0.link_split(self.final3)
+        self.final3.link_split(self.heads0)
+        self.heads0.link_split(self.heads3)
 
     # ------------------------------------------------------------------------------------------ pieces
     def init_regressor(self, c4):
@@ -1234,10 +1271,12 @@ class DirEngine(object):
         read); dir_amd.models.dir.DIR.forward does, and raises AssertionError like the reference."""
         _capi.require_cuda(img)
         self._flags = reflection_flags
+        _TLS.no_out_split = taps is not None          # the taps are read as fp32 maps
         try:
             return self._forward(img, want_proj_feat, taps)
         finally:
             self._flags = None
+            _TLS.no_out_split = False
 
     def _forward(self, img, want_proj_feat, taps):
         if img.dtype == torch.uint8:     # decoded BGR frames [B,256,256,3]: the reference's normalisation runs inside the stem staging

@@ -265,6 +265,10 @@ typedef struct dir_conv_desc {
     float in_scale;              /* DIR_DT_F16X3 only (0 = 1): a power of two the activations (after the pre-activation, both sources of a
                                     dual convolution) are multiplied by before the f16 hi / lo split, to centre them in the f16 range;
                                     the caller folds 1 / in_scale into scale[].  Scaled values are clamped to +-65504 (no inf / nan). */
+    float out_split_scale;       /* 0: y as declared by out_dtype.  != 0 (fp32 outputs that are whole tensors, Cout % 32 == 0): y is written as the pre-split
+                                    operand of the NEXT convolution (DIR_DT_F16X3P / F16X1P) instead -- act(result) * |out_split_scale| as f16 hi | lo
+                                    slabs (negative: hi only), the same bytes as the fp32 tensor, so that consumer needs no dir_split_f16_forward pass.
+                                    |out_split_scale| = the consumer's in_scale. */
 } dir_conv_desc;
 
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
