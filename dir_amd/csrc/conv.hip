@@ -520,13 +520,15 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
         }
         return;
     }
-    if constexpr (std::is_same<TI, bf16_t>::value) {
-        // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip
+    constexpr int XM = std::is_same<TI, f16x3p_t>::value ? 3 : std::is_same<TI, f16x1p_t>::value ? 1 : 0;
+    if constexpr (std::is_same<TI, bf16_t>::value || XM != 0) {
+        // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip (bf16, or both operands
+        // pre-split f16)
         const bool four_wave = ((a0.variant & 15) >= 1 && (a0.variant & 15) <= 4) || a0.x2;   // explicit DIR_CONV_VARIANT 1..4 (+16), or a second source
         if (!four_wave) {
             ConvArgs ap = a0;
             ap.stamps = dir::stamps_begin("conv_pipe");
-            const bool taken = launch_conv_pipe(ap, std::is_same<TO, float>::value, num_cu, s);
+            const bool taken = launch_conv_pipe(ap, std::is_same<TO, float>::value, num_cu, s, XM);
             if (ap.stamps) {
                 fprintf(stderr, "conv M=%d N=%d K=%d %s: ", ap.M, ap.Cout, ap.K, taken ? "pipe" : "(not taken)");
                 dir::stamps_end("conv_pipe", ap.stamps, s);

@@ -30,9 +30,12 @@ struct Slab {
 
 constexpr int PRE_MAX_CIN = 2304;      // pre-activation parameters staged in LDS (fusion_layer4: 2048 + 256 channels)
 
-template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false, int NBUF = 3>
+// XM: 0 = bf16 operands; 3 / 1 = both operands pre-split f16 hi | lo slabs (DIR_DT_F16X3P / F16X1P: 32 channels per 128-byte row, three / one
+// v_mfma_f32_32x32x16_f16 per product and k16-step) -- the same ring, the same slot plan with 6 / 2 instead of 4 MFMAs per tile and slab
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false, int NBUF = 3, int XM = 0>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) {
     typedef bf16_t TI;
+    static_assert(XM == 0 || (!SPARSE && !PRE && std::is_same<TO, float>::value), "pre-split operands: dense, no pre-activation, fp32 output");
     constexpr int NT = 64 * WM * WN;               // threads
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
     constexpr int RPP = NT / 8;                    // rows covered by one DMA pass of the whole workgroup
@@ -41,8 +44,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int STAGE_BYTES = BM * BN * 4;
     constexpr int SMEM = NBUF * BUF_BYTES > STAGE_BYTES ? NBUF * BUF_BYTES : STAGE_BYTES;
-    constexpr int EPC = 8, BK = 64, ES = 2;
-    constexpr int NSLOT = MI * NJ * 4;             // MFMAs per slab per wave
+    constexpr int EPC = XM ? 4 : 8, BK = XM ? 32 : 64, ES = XM ? 4 : 2;      // (pre-split rows are addressed like the fp32 tensor they replace)
+    constexpr int NM = XM == 3 ? 6 : XM == 1 ? 2 : 4;                        // MFMAs per 32x32 tile and slab
+    constexpr int NSLOT = MI * NJ * NM;            // MFMAs per slab per wave
     constexpr int NREAD = (MI + NJ) * 4;           // ds_read_b128 per slab per wave
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the DMA pass");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -195,7 +199,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
     const int frag_b = A_BYTES + (wn * NJ * 32 + (lane & 31)) * ROW;
     int qoff[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) qoff[q] = (((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4;
+    for (int q = 0; q < 4; ++q)
+        qoff[q] = XM ? ((((2 * (q >> 1) + (lane >> 5)) + 4 * (q & 1)) ^ ((lane >> 1) & 7)) << 4)      // q = 2s + part: chunk 2s + h of the hi (lo: + 4) half
+                     : ((((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) << 4);
 
     uint4 fa[2][MI][4], fb[2][NJ][4];              // two register sets of MFMA operands
     // read r (0 .. NREAD-1) of a slab's fragments, q-major so the first MFMAs' operands arrive first
@@ -261,8 +267,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
             (([&] {
                  constexpr int t = T;
                  constexpr int q = t / (MI * NJ), ij = t - q * (MI * NJ), i = ij / NJ, j = ij - i * NJ;
-                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[P][i][q]),
-                                                                     __builtin_bit_cast(bf16x8, fb[P][j][q]), acc[i][j], 0, 0, 0);
+                 if constexpr (XM == 0) {
+                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[P][i][q]),
+                                                                         __builtin_bit_cast(bf16x8, fb[P][j][q]), acc[i][j], 0, 0, 0);
+                 } else {           // q counts (k16-step, product): hi*hi, lo*hi, hi*lo (XM = 3) or hi*hi only (XM = 1)
+                     constexpr int ks16 = XM == 3 ? q / 3 : q, part = XM == 3 ? q % 3 : 0;
+                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[P][i][2 * ks16 + (part == 1)]),
+                                                                        __builtin_bit_cast(f16x8, fb[P][j][2 * ks16 + (part == 2)]), acc[i][j], 0, 0, 0);
+                 }
                  if constexpr (t < H) {
                      [&]<int... R>(std::integer_sequence<int, R...>) {
                          (([&] {
@@ -618,12 +630,16 @@ static bool patch_geometry(const ConvArgs& a, int bm, PatchGeom* g) {
     return true;
 }
 
-template <typename TO, int MI, int NJ, int WM, int WN>
+template <typename TO, int MI, int NJ, int WM, int WN, int XM = 0>
 void launch_tile(ConvArgs a, hipStream_t s) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     dim3 grid(a.tiles_m * a.tiles_n), block(64 * WM * WN);
+    if constexpr (XM != 0) {
+        DIR_LAUNCH((conv_pipe_kernel<float, MI, NJ, WM, WN, false, false, 3, XM>), grid, block, 0, s, a);
+        return;
+    }
     static const int use_patch = getenv("DIR_PATCH") ? atoi(getenv("DIR_PATCH")) : 0;           // halo-reuse kernel: opt-in
     PatchGeom g;
     const bool want_patch = use_patch || (a.variant >= 12 && a.variant <= 14);      // DIR_CONV_VARIANT 12..14: halo reuse
@@ -650,11 +666,12 @@ void launch_tile(ConvArgs a, hipStream_t s) {
 
 }  // namespace
 
-bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s) {
+bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s, int xm) {
     // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
     static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
     static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
-    const bool explicit_variant = (a.variant >= 8 && a.variant <= 10) || (a.variant >= 12 && a.variant <= 14);
+    const bool explicit_variant = (a.variant >= 8 && a.variant <= 10) || (!xm && a.variant >= 12 && a.variant <= 14);
+    if (xm && (a.pre_scale || a.bbox || !out_f32)) return false;
     if (force == 0 || !(a.flags & 4) || (a.nk < min_nk && !explicit_variant)) return false;
     const bool pre = a.pre_scale != nullptr;
     static const int pre_pipe = getenv("DIR_PIPE_PRE") ? atoi(getenv("DIR_PIPE_PRE")) : 1;     // tuning aid
@@ -679,7 +696,9 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     if (b.bbox && hw % bm != 0) b.bbox = nullptr;          // sparse-K needs whole tiles inside one image
 #define DIR_PIPE_LAUNCH(MI_, NJ_, WM_, WN_)                                       \
     do {                                                                          \
-        if (out_f32) launch_tile<float, MI_, NJ_, WM_, WN_>(b, s);                \
+        if (xm == 3) launch_tile<float, MI_, NJ_, WM_, WN_, 3>(b, s);             \
+        else if (xm == 1) launch_tile<float, MI_, NJ_, WM_, WN_, 1>(b, s);        \
+        else if (out_f32) launch_tile<float, MI_, NJ_, WM_, WN_>(b, s);           \
         else launch_tile<bf16_t, MI_, NJ_, WM_, WN_>(b, s);                       \
     } while (0)
     if (shape == 1) DIR_PIPE_LAUNCH(2, 2, 4, 2);

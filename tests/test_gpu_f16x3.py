@@ -50,7 +50,8 @@ def test_f16x3_conv_matches_float64_oracle(case):
         y = F.conv2d_nhwc(dx, dw, s, p, sc, sh, relu=True, arith='f16x3', variant=variant)
         e3 = relerr(y.cpu().numpy().transpose(0, 3, 1, 2), ref)
         assert e3 < TOL, (variant, e3)
-    for variant in (0, 1, 2, 3, 4, 17, 18, 20):                        # activations pre-split (DIR_DT_F16X3P): DMA path, incl. the 3-buffer ring tiles
+    for variant in (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10):              # activations pre-split (DIR_DT_F16X3P): DMA path, incl. the 3-buffer ring tiles and
+                                                                       # the 8-wave pipelined kernel (conv_pipe.hip, XM = 3)
         yp = F.conv2d_nhwc(dx, dw, s, p, sc, sh, relu=True, arith='f16x3', variant=variant, presplit=True)
         ep = relerr(yp.cpu().numpy().transpose(0, 3, 1, 2), ref)
         assert ep < TOL, ('presplit', variant, ep)
