@@ -119,6 +119,7 @@ _SIGNATURES = {
     'dir_launch_log_note': (None, [C.c_char_p, C.c_longlong]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),
     'dir_split_f16_forward': (C.c_int, [_p, _p, C.c_longlong, _i, _i, _i, _p, _p, _i, C.c_float, _i, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

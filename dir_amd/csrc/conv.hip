@@ -719,6 +719,40 @@ __global__ __launch_bounds__(256) void split_f16_kernel(SplitArgs a) {
 }
 }  // namespace
 
+// ---- dir_pack_f16x3_weights: the host packing of dir_amd/functional.py::pack_f16x3_weights as one launch (weights that change every
+//      optimiser step): one workgroup per output channel: max |w|, the power of two p with max |w| p in [2^12, 2^13), hi | lo slabs, 1 / p
+namespace {
+__global__ __launch_bounds__(256) void pack_f16x3_kernel(const float* __restrict__ w, uint4* __restrict__ out, float* __restrict__ scale_out,
+                                                         const float* __restrict__ scale_in, int K) {
+    __shared__ float s_max[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* row = w + (long long)n * K;
+    float m = 0.f;
+    for (int k = tid; k < K; k += 256) m = fmaxf(m, fabsf(row[k]));
+    m = dir::wave_max(m);
+    if ((tid & 63) == 0) s_max[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    // m = f * 2^(E - 127), f in [1, 2)  ->  p = 2^(12 - (E - 127)): exponent field 266 - E (clamped; an all-zero row takes p = 1)
+    const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
+    const float p = (m > 0.f && E >= 13u && E <= 253u) ? __uint_as_float((266u - E) << 23) : 1.f;
+    if (tid == 0) scale_out[n] = (scale_in ? scale_in[n] : 1.f) / p;
+    for (int c4 = tid; c4 < K / 4; c4 += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * c4);
+        const uint4 sp = split_f16x3(v, p);
+        char* slab = reinterpret_cast<char*>(out) + ((long long)n * K + 4 * (c4 & ~7)) * 4;
+        *reinterpret_cast<uint2*>(slab + 8 * (c4 & 7)) = make_uint2(sp.x, sp.y);
+        *reinterpret_cast<uint2*>(slab + 64 + 8 * (c4 & 7)) = make_uint2(sp.z, sp.w);
+    }
+}
+}  // namespace
+
+extern "C" int dir_pack_f16x3_weights(const float* w, void* packed, float* scale_out, const float* scale_in, int N, int K, void* stream) {
+    DIR_REQUIRE(w && packed && scale_out && N > 0 && K > 0 && K % 32 == 0, "dir_pack_f16x3_weights: bad arguments (K must be a multiple of 32)");
+    DIR_LAUNCH(pack_f16x3_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, w, (uint4*)packed, scale_out, scale_in, K);
+    return dir::check_launch("dir_pack_f16x3_weights");
+}
+
 extern "C" int dir_split_f16_forward(const float* x, void* y, long long pixels, int C, int in_cstride, int in_coff, const float* pre_scale,
                                      const float* pre_shift, int pre_relu, float in_scale, int hi_only, void* stream) {
     DIR_REQUIRE(x && y && pixels >= 0 && C > 0 && C % 32 == 0, "dir_split_f16_forward: bad arguments (C must be a multiple of 32)");

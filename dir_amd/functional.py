@@ -39,6 +39,20 @@ def pack_f16x3_weights(w_rows, scale=None):
     return packed, sc.contiguous()
 
 
+def pack_f16x3_weights_device(w_rows, scale=None):
+    """pack_f16x3_weights without leaving the GPU (dir_pack_f16x3_weights: one launch, no host synchronisation) -- for weights that change
+    every optimiser step.  Same result, bit for bit."""
+    w = _capi.f32c(w_rows.detach())
+    _capi.require_cuda(w, scale)
+    N, K = w.shape
+    packed = torch.empty(N, K // 32, 2, 32, device=w.device, dtype=torch.float16)
+    sc = torch.empty(N, device=w.device, dtype=torch.float32)
+    with torch.cuda.device(w.device):
+        _capi.check(_capi.lib().dir_pack_f16x3_weights(_capi.ptr(w), _capi.ptr(packed), _capi.ptr(sc), _capi.ptr(scale), N, K, _capi.stream_ptr()),
+                    'dir_pack_f16x3_weights')
+    return packed, sc
+
+
 def split_f16(x, C, in_coff=0, pre_scale=None, pre_shift=None, pre_relu=False, in_scale=1.0, hi_only=False, out=None):
     """dir_split_f16_forward: channels [in_coff, in_coff + C) of the fp32 NHWC tensor x -> the pre-split operand of DIR_DT_F16X3P / F16X1P
     (a float32-TYPED tensor [B,H,W,C] whose bytes are f16 hi | lo slabs)"""
@@ -53,9 +67,18 @@ def split_f16(x, C, in_coff=0, pre_scale=None, pre_shift=None, pre_relu=False, i
     return out
 
 
+def pow2_in_scale(x, pre_scale=None, pre_shift=None):
+    """the power of two that puts the largest |activation| of x (through an optional pre-activation) at [2^9, 2^10) -- a host synchronisation"""
+    import math
+    amax = float(x.abs().max())
+    if pre_scale is not None:
+        amax = amax * float(pre_scale.abs().max()) + float(pre_shift.abs().max())
+    return 2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0
+
+
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
-                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False):
+                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
     if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
@@ -67,16 +90,14 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
         cin = Cin
     assert cin == Cin and w_ohwi.dtype == x.dtype
     assert arith in (None, 'f16x3', 'f16')               # 'f16': the hi parts only (DIR_DT_F16X1), same packing
-    in_scale = 0.0
+    if arith is None:
+        in_scale = 0.0
     if arith is not None:
         assert x.dtype == torch.float32 and splits == 1
-        w_ohwi, scale = pack_f16x3_weights(w_ohwi.reshape(Cout, -1), scale)
-        # input scale as DirEngine.calibrate picks it: the largest |activation| the split sees lands in [2^9, 2^10)
-        import math
-        amax = float(x[..., in_coff:in_coff + Cin].abs().max())
-        if pre_scale is not None:
-            amax = amax * float(pre_scale.abs().max()) + float(pre_shift.abs().max())
-        in_scale = 2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0
+        w_ohwi, scale = (pack_f16x3_weights_device if device_pack else pack_f16x3_weights)(w_ohwi.reshape(Cout, -1), scale)
+        if in_scale is None:
+            # input scale as DirEngine.calibrate picks it: the largest |activation| the split sees lands in [2^9, 2^10)  (host synchronisation)
+            in_scale = pow2_in_scale(x[..., in_coff:in_coff + Cin], pre_scale, pre_shift)
         scale = scale / in_scale
         if presplit:     # activations split ONCE by dir_split_f16_forward (pre-activation and in_scale applied there), both operands by DMA
             xs = split_f16(x, Cin, in_coff, pre_scale, pre_shift, pre_relu, in_scale, hi_only=(arith == 'f16'))

@@ -8,18 +8,57 @@
   and padding k - 1 - pad; for stride 2, gy is first spread onto the even positions of a zero [2 Ho, 2 Wo] map.  The flips, the zero
   insertion and the channel padding to the kernel's 32-channel granularity are copies -- no arithmetic happens outside the library.
 """
+import os
+
 import torch
 
 from . import ops as O
 from .. import _capi
 from .. import functional as F
 
+# Arithmetic of the forward and data-gradient convolutions: 'f16x3' = the split-precision f16 matrix-core path (DIR_DT_F16X3: ~2^-22 per
+# product, below fp32 accumulation noise; 2.5x the exact kernel's speed), 'f32' = exact fp32 MFMA (rounds 1-2).  DIR_TRAIN_ARITH overrides.
+ARITH = os.environ.get('DIR_TRAIN_ARITH', 'f16x3')
+# The split needs one power-of-two input scale per call site (include/dir_hip.h: in_scale).  Measuring it costs a host synchronisation, so it
+# is measured on the FIRST step (and again every RECALIBRATE steps: gradient magnitudes drift as the loss falls) and re-used in between: the
+# convolution calls of a training step happen in a fixed order, so the call counter identifies the site.  64x headroom + saturation at the
+# f16 maximum make a stale scale a (bounded) precision loss, never an inf / nan.
+RECALIBRATE = int(os.environ.get('DIR_TRAIN_RECALIBRATE', '50'))
+_scales, _state = [], {'call': 0, 'step': 0}
+
+
+def begin_step():
+    """called by dir_amd.train.net.forward at the start of every training step"""
+    _state['call'] = 0
+    _state['step'] += 1
+    if RECALIBRATE > 0 and _state['step'] % RECALIBRATE == 1 and _state['step'] > 1:
+        del _scales[:]
+
+
+def _site_scale(x):
+    i = _state['call']
+    _state['call'] += 1
+    if i < len(_scales) and _scales[i][0] == tuple(x.shape):
+        return _scales[i][1]
+    s = F.pow2_in_scale(x)
+    del _scales[i:]
+    _scales.append((tuple(x.shape), s))
+    return s
+
+
+def _conv(x, w, stride, pad, shift=None):
+    if ARITH != 'f16x3':
+        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift)
+    kh = w.shape[1]
+    return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=_site_scale(x), device_pack=True,
+                         presplit=(kh >= 3 or (w.shape[0] >= 512 and w.shape[3] >= 128)))
+
 
 def conv_fwd(x, w, bias=None, stride=1, pad=0):
     cin = w.shape[3]
     if cin % 32:                                           # the 3-channel image: channels padded to the kernel's K granularity
         x, w = _pad_last(x, 32), _pad_last(w, 32)
-    return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=bias)
+    return _conv(x, w, stride, pad, bias)
 
 
 def _pad_last(t, mult):
@@ -42,7 +81,7 @@ def conv_dgrad(w, gy, stride, pad, H, W):
         g = torch.zeros(B, 2 * Ho, 2 * Wo, Cout, device=gy.device)
         g[:, ::2, ::2] = gy
     g = _pad_last(g.contiguous(), 32)
-    gx = F.conv2d_nhwc(g, wt, stride=1, pad=kh - 1 - pad)
+    gx = _conv(g, wt, 1, kh - 1 - pad)
     if gx.shape[1] != H or gx.shape[2] != W:               # odd H / W under stride 2
         assert gx.shape[1] >= H and gx.shape[2] >= W
         gx = gx[:, :H, :W].contiguous()

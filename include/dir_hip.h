@@ -281,6 +281,11 @@ int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void
 int dir_split_f16_forward(const float* x, void* y, long long pixels, int C, int in_cstride, int in_coff, const float* pre_scale,
                           const float* pre_shift, int pre_relu, float in_scale, int hi_only, void* stream);
 
+/* The weight operand of DIR_DT_F16X3 (above) from fp32 rows w [N][K] (K % 32 == 0) in one launch, for weights that change every step
+ * (training): packed = f16 [N][K/32][2][32], scale_out[n] = (scale_in ? scale_in[n] : 1) / p_n.  Same result as the host packing of
+ * dir_amd/functional.py::pack_f16x3_weights (tests/test_gpu_f16x3.py). */
+int dir_pack_f16x3_weights(const float* w, void* packed, float* scale_out, const float* scale_in, int N, int K, void* stream);
+
 /* dir_conv2d_forward with the reduction split over `splits` workgroups per output tile (bf16 -> bf16 layers whose M x Cout grid is too
  * small to fill 256 CUs at the benchmark batch: ResNet layer4 at 8x8, the decoder's 16x16 Residual blocks).  128x128 tiles; every
  * workgroup reduces a contiguous range of K-slabs and writes its raw fp32 partial tile to the workspace; the LAST one to arrive at the

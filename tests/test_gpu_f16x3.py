@@ -199,3 +199,14 @@ def test_f16_hi_only_conv(case):
     e_bf = relerr(N.conv2d(xb, wb, None, s, p), ref)
     print('%s: f16 arithmetic vs f16-rounded operands %.2e, vs exact operands %.2e (bf16 operands: %.2e)' % (tag, e_r, e_x, e_bf))
     assert e_r < 5e-6 and e_x < 1.5e-3 and e_x < 0.5 * e_bf
+
+
+def test_device_weight_packing_equals_host_packing():
+    """dir_pack_f16x3_weights (one launch, for weights that change every optimiser step) == functional.pack_f16x3_weights, bit for bit"""
+    torch.manual_seed(1)
+    w = torch.randn(70, 9 * 64, device='cuda') * torch.logspace(-5, 3, 70, device='cuda')[:, None]
+    w[5] = 0
+    sc_in = torch.rand(70, device='cuda') + 0.5
+    ph, sh = F.pack_f16x3_weights(w, sc_in)
+    pd, sd = F.pack_f16x3_weights_device(w, sc_in)
+    assert torch.equal(ph.view(torch.int16), pd.view(torch.int16)) and torch.equal(sh, sd)
