@@ -120,6 +120,8 @@ _SIGNATURES = {
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),
+    'dir_gemm_f32_splitk_workspace_bytes': (C.c_longlong, [C.POINTER(GemmDesc)]),
+    'dir_gemm_f32_splitk': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p, C.c_longlong, _p]),
     'dir_split_f16_forward': (C.c_int, [_p, _p, C.c_longlong, _i, _i, _i, _p, _p, _i, C.c_float, _i, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
@@ -201,7 +203,8 @@ _SIGNATURES = {
 PROFILE = None
 _pending = {}
 _NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
-               'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes')
+               'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes',
+               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes')
 
 
 def annotate(**kw):

@@ -23,6 +23,7 @@ struct GemmArgs {
     const float* A; const float* B; const float* bias; float* C;
     int M, N, K, lda, ldb, ldc, ta, tb, accumulate;
     long long sA, sB, sC;
+    int kchunk; float* part;        // split-K (dir_gemm_f32_splitk): blockIdx.z = K chunk, raw partial tiles to part [chunk][M][N]
 };
 constexpr int GT = 64, GK = 16, GLD = GK + 1;      // 64 x 64 tile, K step 16; LDS rows padded (17 floats: conflict-free column reads)
 
@@ -32,14 +33,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     __shared__ float s_a[GT * GLD], s_b[GT * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
-    const float* A = a.A + blockIdx.z * a.sA;
-    const float* B = a.B + blockIdx.z * a.sB;
-    float* C = a.C + blockIdx.z * a.sC;
+    const bool split = a.part != nullptr;
+    const float* A = a.A + (split ? 0 : blockIdx.z * a.sA);
+    const float* B = a.B + (split ? 0 : blockIdx.z * a.sB);
+    float* C = a.C + (split ? 0 : blockIdx.z * a.sC);
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lk = lane >> 4;
-    for (int k0 = 0; k0 < a.K; k0 += GK) {
+    const int kbeg = split ? blockIdx.z * a.kchunk : 0, kend = split ? min(a.K, kbeg + a.kchunk) : a.K;
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
         // stage: 64 x 16 elements of each operand, 4 per thread; the faster-varying thread index follows the contiguous dimension
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -48,13 +51,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }          // A[m][k] (ta = 0) or A[k][m] (ta = 1)
             const int m = m0 + r, kk = k0 + k;
             float v = 0.f;
-            if (m < a.M && kk < a.K) v = a.ta ? A[(long long)kk * a.lda + m] : A[(long long)m * a.lda + kk];
+            if (m < a.M && kk < kend) v = a.ta ? A[(long long)kk * a.lda + m] : A[(long long)m * a.lda + kk];
             s_a[r * GLD + k] = v;
             int c, k2;
             if (a.tb) { k2 = e & 15; c = e >> 4; } else { c = e & 63; k2 = e >> 6; }        // B[k][n] (tb = 0) or B[n][k] (tb = 1)
             const int n = n0 + c, kb = k0 + k2;
             float w = 0.f;
-            if (n < a.N && kb < a.K) w = a.tb ? B[(long long)n * a.ldb + kb] : B[(long long)kb * a.ldb + n];
+            if (n < a.N && kb < kend) w = a.tb ? B[(long long)n * a.ldb + kb] : B[(long long)kb * a.ldb + n];
             s_b[c * GLD + k2] = w;
         }
         __syncthreads();
@@ -79,10 +82,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 16 * wave + 4 * lk + r;
             if (m >= a.M) continue;
+            if (split) { a.part[((long long)blockIdx.z * a.M + m) * a.N + n] = acc[j][r]; continue; }
             float* p = C + (long long)m * a.ldc + n;
             *p = a.accumulate ? *p + (acc[j][r] + bz) : acc[j][r] + bz;
         }
     }
+}
+
+// split-K second pass: C[m][n] = (accumulate ? C : 0) + (sum over the chunks IN ORDER of part[chunk][m][n]) + bias[n]   (deterministic)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* part, const float* bias, float* C, int M, int N, int ldc, int chunks, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * N) return;
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long long)c * M * N + i];
+    s += bias ? bias[n] : 0.f;
+    float* p = C + (long long)m * ldc + n;
+    *p = accumulate ? *p + s : s;
 }
 
 // column sums of X [R, N] (row stride ld): one thread per column, rows in order
@@ -671,9 +687,33 @@ extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float*
     using namespace dir;
     DIR_REQUIRE(d && A && B && C, "dir_gemm_f32: null pointer");
     DIR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->lda > 0 && d->ldb > 0 && d->ldc >= d->N, "dir_gemm_f32: bad shape");
-    GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c};
+    GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c, 0, nullptr};
     DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, d->batch), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("dir_gemm_f32");
+}
+
+// Tall reductions with a small output (the weight gradients of the token path's Linear layers: gW [<= 384 x <= 256] = gy^T x over K = B * 21 .. 42
+// rows): a 64 x 64 tile per workgroup walks K in steps of 16 with two barriers and a memory round trip each -- 84 dependent steps on four
+// workgroups.  Split the reduction into chunks of 64 (one workgroup each: hundreds of workgroups, 4 steps each), partial tiles to a workspace,
+// summed in chunk order by a second launch.
+constexpr int GEMM_SPLIT_CHUNK = 64;
+extern "C" long long dir_gemm_f32_splitk_workspace_bytes(const dir_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return -1;
+    return (long long)((d->K + GEMM_SPLIT_CHUNK - 1) / GEMM_SPLIT_CHUNK) * d->M * d->N * 4;
+}
+extern "C" int dir_gemm_f32_splitk(const dir_gemm_desc* d, const float* A, const float* B, const float* bias, float* C, float* workspace,
+                                   long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(d && A && B && C && workspace, "dir_gemm_f32_splitk: null pointer");
+    DIR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch == 1 && d->lda > 0 && d->ldb > 0 && d->ldc >= d->N, "dir_gemm_f32_splitk: bad shape (batch must be 1)");
+    DIR_REQUIRE(workspace_bytes >= dir_gemm_f32_splitk_workspace_bytes(d), "dir_gemm_f32_splitk: workspace too small (dir_gemm_f32_splitk_workspace_bytes)");
+    const int chunks = (d->K + GEMM_SPLIT_CHUNK - 1) / GEMM_SPLIT_CHUNK;
+    GemmArgs a{A, B, nullptr, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, 0, 0, 0, 0, GEMM_SPLIT_CHUNK, workspace};
+    hipStream_t s = (hipStream_t)stream;
+    DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, chunks), dim3(256), 0, s, a);
+    DIR_LAUNCH(gemm_splitk_reduce_kernel, dim3((unsigned)(((long long)d->M * d->N + 255) / 256)), dim3(256), 0, s, (const float*)workspace, bias, C, d->M, d->N,
+               d->ldc, chunks, d->accumulate);
+    return check_launch("dir_gemm_f32_splitk");
 }
 
 extern "C" long long dir_colsum_workspace_bytes(int R, int N) {

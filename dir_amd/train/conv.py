@@ -100,6 +100,9 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     if accumulate:
         n = max(n, out.numel() * 4)
     ws = torch.empty(max(n, 4) // 4, device=x.device)
+    if _capi.PROFILE is not None:
+        _capi.annotate(family='wgrad', flops=2.0 * B * gy.shape[1] * gy.shape[2] * Cout * kh * kw * Cin, bytes=4.0 * (x.numel() + gy.numel() + Cout * kh * kw * Cin),
+                       shape='wgrad M=%d Cout=%d Cin=%d k%d s%d' % (B * gy.shape[1] * gy.shape[2], Cout, Cin, kh, stride))
     _capi.check(_capi.lib().dir_conv2d_wgrad_f32(d, _capi.ptr(x), _capi.ptr(gy), _capi.ptr(out), int(accumulate), _capi.ptr(ws), n,
                                                  _capi.stream_ptr()), 'dir_conv2d_wgrad_f32')
     return out

@@ -28,6 +28,15 @@ def gemm(A, B, ta=False, tb=False, bias=None, out=None, accumulate=False):
     d = GemmDesc(M, N, K, a2[1], b2[1], N, int(ta), int(tb), int(accumulate), batch,
                  a2[0] * a2[1] if A.dim() == 3 else 0, b2[0] * b2[1] if B.dim() == 3 else 0, M * N if out.dim() == 3 else 0)
     assert out.shape[-2:] == (M, N) and (batch == 1 or out.dim() == 3)
+    if _capi.PROFILE is not None:
+        _capi.annotate(family='gemm', flops=2.0 * batch * M * N * K, bytes=4.0 * batch * (M * K + K * N + M * N), shape='gemm M=%d N=%d K=%d batch=%d ta=%d tb=%d' % (M, N, K, batch, ta, tb))
+    if batch == 1 and K >= 512 and ((M + 63) // 64) * ((N + 63) // 64) <= 32:
+        # a tall reduction into a small output (Linear weight gradients over B * 21 .. 42 token rows): K chunks on separate workgroups
+        n = _capi.lib().dir_gemm_f32_splitk_workspace_bytes(d)
+        ws = torch.empty(n // 4, device=A.device)
+        _capi.check(_capi.lib().dir_gemm_f32_splitk(d, _capi.ptr(A), _capi.ptr(B), _capi.ptr(bias), _capi.ptr(out), _capi.ptr(ws), n, _capi.stream_ptr()),
+                    'dir_gemm_f32_splitk')
+        return out
     _capi.check(_capi.lib().dir_gemm_f32(d, _capi.ptr(A), _capi.ptr(B), _capi.ptr(bias), _capi.ptr(out), _capi.stream_ptr()), 'dir_gemm_f32')
     return out
 

@@ -133,6 +133,12 @@ typedef struct dir_gemm_desc {
     int64_t stride_a, stride_b, stride_c;
 } dir_gemm_desc;
 int dir_gemm_f32(const dir_gemm_desc* desc_host, const float* A, const float* B, const float* bias, float* C, void* stream);
+/* the same product (batch == 1) with the reduction cut into chunks of 64, one workgroup per (tile, chunk), partial tiles summed in chunk order by a
+ * second launch (deterministic): for tall reductions with a small output -- the Linear weight gradients of the token path (K = rows = B * 21 .. 42).
+ * Not bit-identical to dir_gemm_f32 (another summation order); workspace of dir_gemm_f32_splitk_workspace_bytes(d) bytes. */
+long long dir_gemm_f32_splitk_workspace_bytes(const dir_gemm_desc* desc_host);
+int dir_gemm_f32_splitk(const dir_gemm_desc* desc_host, const float* A, const float* B, const float* bias, float* C, float* workspace,
+                        long long workspace_bytes, void* stream);
 /* out[n] (+)= sum_r x[r][n]: bias gradients.  R > 512: 256-row chunk partials added in chunk order; workspace of
  * dir_colsum_workspace_bytes(R, N) bytes (0 for R <= 512). */
 long long dir_colsum_workspace_bytes(int R, int N);

@@ -58,6 +58,15 @@ if rank == 0:
     print('batch %d x %d rank(s): train step %s s (first includes allocator warm-up); objective on rank 0 %s; %.0f images/s aggregate'
           % (B, world, ' '.join('%.3f' % t for t in times), ' -> '.join('%.3f' % t for t in totals), B * world / min(times)))
     print('peak memory %.1f GB' % (torch.cuda.max_memory_allocated() / 2 ** 30))
+    agg = {}
+    for r in prof or []:
+        k = (r['api'], r.get('shape', ''))
+        a = agg.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += r['e0'].elapsed_time(r['e1']); a[2] += r.get('flops', 0.0)
+    tot = sum(a[1] for a in agg.values())
+    print('library calls of the last step: %.1f ms of events in %d calls; top by time:' % (tot, sum(a[0] for a in agg.values())))
+    for (api, shape), (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOP', '28'))]:
+        print('  %-34s %-52s x%-4d %8.3f ms %8.1f TFLOP/s' % (api, shape, n, ms, fl / ms / 1e9 if ms > 0 else 0))
 if world > 1:
     flat = opt.flat_param.clone()
     torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.MAX)
