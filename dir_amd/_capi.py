@@ -122,6 +122,7 @@ _SIGNATURES = {
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),
     'dir_gemm_f32_splitk_workspace_bytes': (C.c_longlong, [C.POINTER(GemmDesc)]),
     'dir_gemm_f32_splitk': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p, C.c_longlong, _p]),
+    'dir_axpy_multi_f32': (C.c_int, [_p, _p, _p, _i, C.c_float, _p]),
     'dir_split_f16_forward': (C.c_int, [_p, _p, C.c_longlong, _i, _i, _i, _p, _p, _i, C.c_float, _i, _p]),
     'dir_stem_prep': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_stem_prep_s2d': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

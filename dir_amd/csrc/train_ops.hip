@@ -601,6 +601,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
 }
+
+// The same for a convolution with very few input channels (the 7x7 / 2 stem on the 3-channel image): taps and channels are flattened into ONE
+// column index j = tap * Cin + c (147 columns = 3 tiles) instead of a 64-wide channel tile per tap that is 95 % padding.  Grid (column tile x
+// co tile, 1, pixel chunk); output element [co][j] is the weight layout [Cout][kh][kw][Cin] itself.
+__global__ __launch_bounds__(256) void conv_wgrad_flatk_kernel(WgradArgs a) {
+    __shared__ float s_a[GT * GLD], s_b[GT * GLD];
+    __shared__ int s_pix[GK * 3];                        // per reduction row: image base index b * H, iy0, ix0 (iy0 = INT_MIN/2: no pixel)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KC = a.kh * a.kw * a.Cin;
+    const int tj = blockIdx.x % a.tiles_ci, tco = blockIdx.x / a.tiles_ci, ch = blockIdx.z;
+    const int co0 = tco * GT, j0 = tj * GT;
+    const int m_beg = ch * a.chunk, m_end = min(a.M, m_beg + a.chunk);
+    // this thread's column (fixed over the loop): tap and channel
+    const int jc = j0 + (tid & 63);
+    const int tap = jc / a.Cin, cc = jc - tap * a.Cin, ky = tap / a.kw, kx = tap - ky * a.kw;
+    const bool col_ok = jc < KC;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4;
+    for (int k0 = m_beg; k0 < m_end; k0 += GK) {
+        if (tid < GK) {
+            const int m = k0 + tid;
+            int bh = 0, iy0 = -(1 << 29), ix0 = 0;
+            if (m < m_end) {
+                const int b = m / (a.Ho * a.Wo), r = m - b * a.Ho * a.Wo, oy = r / a.Wo, ox = r - oy * a.Wo;
+                bh = b * a.H; iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
+            }
+            s_pix[3 * tid] = bh; s_pix[3 * tid + 1] = iy0; s_pix[3 * tid + 2] = ix0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, c = e & 63, k = e >> 6;           // column c (gy channel / flattened (tap, channel)) x 16 pixels
+            const int m = k0 + k;
+            float v = 0.f, w = 0.f;
+            if (m < m_end && co0 + c < a.Cout) v = a.gy[(long long)m * a.gy_cs + a.gy_co + co0 + c];
+            const int iy = s_pix[3 * k + 1] + ky, ix = s_pix[3 * k + 2] + kx;
+            if (col_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) w = a.x[((long long)(s_pix[3 * k] + iy) * a.W + ix) * a.in_cs + a.in_co + cc];
+            s_a[c * GLD + k] = v;
+            s_b[c * GLD + k] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ++ks) {
+            const float av = s_a[(16 * wave + li) * GLD + 4 * ks + lk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_b[(16 * j + li) * GLD + 4 * ks + lk], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* out = a.out + (long long)ch * a.Cout * KC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int jj = j0 + 16 * j + li;
+        if (jj >= KC) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 16 * wave + 4 * lk + r;
+            if (co < a.Cout) out[(long long)co * KC + jj] = acc[j][r];
+        }
+    }
+}
 // The same reduction for 16-byte-aligned channel counts (every convolution of the path except the 3-channel stem and the 1- / 3-output
 // heads): 32 pixels per step, both operands fetched with float4 loads into registers ONE STEP AHEAD of the MFMAs that consume the
 // previous step (software pipeline: global latency hidden behind 32 MFMAs per wave), pixel -> address arithmetic per thread.
@@ -882,6 +945,34 @@ extern "C" int dir_grid_rows_backward(const float* const* g_rows_h, const float*
     return check_launch("dir_grid_rows_backward");
 }
 
+// dst_t += alpha * src_t for up to AXPY_MULTI tensors in ONE launch (the table travels in the kernel arguments): moving the 556 parameter
+// gradients of a training step into the flat all-reduce bucket was 556 launches of a few microseconds each
+namespace {
+constexpr int AXPY_MULTI = 40, AXPY_BLOCKS = 32;
+struct AxpyTable { float* dst[AXPY_MULTI]; const float* src[AXPY_MULTI]; long long n[AXPY_MULTI]; };
+__global__ __launch_bounds__(256) void axpy_multi_kernel(AxpyTable t, float alpha) {
+    const int k = blockIdx.x / AXPY_BLOCKS, b = blockIdx.x - k * AXPY_BLOCKS;
+    float* d = t.dst[k];
+    const float* s = t.src[k];
+    const long long n = t.n[k];
+    for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += (long long)AXPY_BLOCKS * 256) d[i] += alpha * s[i];
+}
+}  // namespace
+extern "C" int dir_axpy_multi_f32(float* const* dst_host, const float* const* src_host, const long long* n_host, int count, float alpha, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(count >= 0 && (count == 0 || (dst_host && src_host && n_host)), "dir_axpy_multi_f32: bad arguments");
+    for (int base = 0; base < count; base += AXPY_MULTI) {
+        AxpyTable t;
+        const int m = count - base < AXPY_MULTI ? count - base : AXPY_MULTI;
+        for (int k = 0; k < m; ++k) {
+            DIR_REQUIRE(dst_host[base + k] && src_host[base + k] && n_host[base + k] >= 0, "dir_axpy_multi_f32: null tensor %d", base + k);
+            t.dst[k] = dst_host[base + k]; t.src[k] = src_host[base + k]; t.n[k] = n_host[base + k];
+        }
+        DIR_LAUNCH(axpy_multi_kernel, dim3(m * AXPY_BLOCKS), dim3(256), 0, (hipStream_t)stream, t, alpha);
+    }
+    return check_launch("dir_axpy_multi_f32");
+}
+
 extern "C" int dir_axpy_f32(float* dst, const float* src, long long n, float alpha, void* stream) {
     using namespace dir;
     DIR_REQUIRE(dst && src && n > 0, "dir_axpy_f32: bad arguments");
@@ -897,8 +988,10 @@ extern "C" int dir_stage_positions(const float* xyz_left, const float* xyz_right
     return check_launch("dir_stage_positions");
 }
 
+static bool wgrad_flatk(const dir_conv_desc* d) { return d->Cin < 16 && d->kh * d->kw > 1; }      // few input channels: flatten (tap, channel)
 static int wgrad_chunks(const dir_conv_desc* d, long long M) {
-    const long long per = (long long)((d->Cin + GT - 1) / GT) * ((d->Cout + GT - 1) / GT) * d->kh * d->kw;
+    const long long per = wgrad_flatk(d) ? (long long)((d->kh * d->kw * d->Cin + GT - 1) / GT) * ((d->Cout + GT - 1) / GT)
+                                         : (long long)((d->Cin + GT - 1) / GT) * ((d->Cout + GT - 1) / GT) * d->kh * d->kw;
     long long c = (1024 + per - 1) / per;                 // >= ~1024 workgroups in flight
     const long long cmax = (M + 2047) / 2048;             // but at least 2048 pixels per chunk
     if (c > cmax) c = cmax;
@@ -941,7 +1034,10 @@ extern "C" int dir_conv2d_wgrad_f32(const dir_conv_desc* d, const float* x, cons
     const bool vec4 = d->Cin % 4 == 0 && d->Cout % 4 == 0 && a.in_cs % 4 == 0 && a.in_co % 4 == 0 && a.gy_cs % 4 == 0 && a.gy_co % 4 == 0 &&
                       ((uintptr_t)x & 15) == 0 && ((uintptr_t)gy & 15) == 0;
     const dim3 wgrid(a.tiles_ci * ((d->Cout + GT - 1) / GT), d->kh * d->kw, chunks);
-    if (vec4) {
+    if (wgrad_flatk(d)) {
+        a.tiles_ci = (d->kh * d->kw * d->Cin + GT - 1) / GT;
+        DIR_LAUNCH(conv_wgrad_flatk_kernel, dim3(a.tiles_ci * ((d->Cout + GT - 1) / GT), 1, chunks), dim3(256), 0, s, a);
+    } else if (vec4) {
         a.chunk = (a.chunk + WK - 1) / WK * WK;           // whole 32-pixel steps per chunk
         DIR_LAUNCH(conv_wgrad4_kernel, wgrid, dim3(256), 0, s, a);
     } else DIR_LAUNCH(conv_wgrad_kernel, wgrid, dim3(256), 0, s, a);

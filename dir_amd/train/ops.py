@@ -227,6 +227,21 @@ def axpy(dst, src, alpha=1.0):
     return dst
 
 
+def axpy_multi(dsts, srcs, alpha=1.0):
+    """dst_t += alpha src_t for lists of tensors, ~len / 40 launches (dir_axpy_multi_f32)"""
+    import ctypes as C
+    n = len(dsts)
+    if n == 0:
+        return
+    srcs = [s.contiguous() for s in srcs]
+    _chk(*dsts)
+    _chk(*srcs)
+    assert all(d.numel() == s.numel() for d, s in zip(dsts, srcs))
+    P, L = C.c_void_p * n, C.c_longlong * n
+    _capi.check(_capi.lib().dir_axpy_multi_f32(P(*[d.data_ptr() for d in dsts]), P(*[s.data_ptr() for s in srcs]), L(*[d.numel() for d in dsts]), n,
+                                               float(alpha), _capi.stream_ptr()), 'dir_axpy_multi_f32')
+
+
 def stage_positions(xyz_l, xyz_r, offset):
     _chk(xyz_l, xyz_r, offset)
     B = xyz_l.shape[0]

@@ -18,10 +18,13 @@ from ..models import loss as L
 def add_grads(named_params, prefix, grads):
     """named_params: {full name -> nn.Parameter whose .grad is a view of FlatAdamW.flat_grad}; grads: {key relative to prefix -> tensor}.
     .grad += gradient, one dir_axpy_f32 per tensor (a parameter used twice accumulates, like autograd)."""
+    dsts, srcs = [], []
     for k, g in grads.items():
         p = named_params[prefix + k]
         assert p.grad is not None and p.grad.numel() == g.numel(), prefix + k
-        O.axpy(p.grad, g.contiguous())
+        dsts.append(p.grad)
+        srcs.append(g)
+    O.axpy_multi(dsts, srcs)          # one launch per 40 tensors (a shared parameter appears once per dict: its uses were summed upstream)
 
 
 def inactive_parameters(named_params):

@@ -200,6 +200,9 @@ int dir_bone_proj_backward(const float* const* uv_lr_host, const float* emb, con
 /* dst += alpha * src, n floats (gradient accumulation of the modules a stage runs once per hand: global_pos_emb, proj_feat_emb,
  * models/dir.py:106-107,118-119). */
 int dir_axpy_f32(float* dst, const float* src, long long n, float alpha, void* stream);
+/* dst_t += alpha * src_t for `count` tensors (host arrays of device pointers and element counts) in count / 40 launches: the gradients of a
+ * training step into the flat all-reduce bucket (dir_amd/train/step.py::add_grads) */
+int dir_axpy_multi_f32(float* const* dst_host, const float* const* src_host, const long long* n_host, int count, float alpha, void* stream);
 /* Joint2BoneFeature's token inputs (models/dir.py:97-98,106-107): pos = xyz / 0.15, gpos_left = xyz_left / 0.15 - offset / 2,
  * gpos_right = xyz_right / 0.15 + offset / 2; xyz [B,21,3], offset [B,3], outputs [B*21,3]. */
 int dir_stage_positions(const float* xyz_left, const float* xyz_right, const float* offset, float* pos_left, float* pos_right,
