@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 25          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 26          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -183,6 +183,8 @@ _SIGNATURES = {
     'dir_conv2d_splitk_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, C.c_longlong, _p]),
     'dir_conv2d_wgrad_workspace_bytes': (C.c_longlong, [C.POINTER(ConvDesc)]),
     'dir_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, _p]),
+    'dir_conv2d_wgrad_f16x3_workspace_bytes': (C.c_longlong, [C.POINTER(ConvDesc)]),
+    'dir_conv2d_wgrad_f16x3': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, C.c_float, C.c_float, _p]),
     'dir_maxpool3x3s2_backward': (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear_backward': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_attn_pool_forward': (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
@@ -205,7 +207,7 @@ PROFILE = None
 _pending = {}
 _NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
                'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes',
-               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes')
+               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
 
 
 def annotate(**kw):

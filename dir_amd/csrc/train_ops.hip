@@ -993,7 +993,7 @@ static int wgrad_chunks(const dir_conv_desc* d, long long M) {
     const long long per = wgrad_flatk(d) ? (long long)((d->kh * d->kw * d->Cin + GT - 1) / GT) * ((d->Cout + GT - 1) / GT)
                                          : (long long)((d->Cin + GT - 1) / GT) * ((d->Cout + GT - 1) / GT) * d->kh * d->kw;
     long long c = (1024 + per - 1) / per;                 // >= ~1024 workgroups in flight
-    const long long cmax = (M + 2047) / 2048;             // but at least 2048 pixels per chunk
+    const long long cmax = (M + 255) / 256;               // but at least 256 pixels (16 steps) per chunk
     if (c > cmax) c = cmax;
     return (int)(c < 1 ? 1 : c);
 }

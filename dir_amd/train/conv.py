@@ -19,6 +19,7 @@ from .. import functional as F
 # Arithmetic of the forward and data-gradient convolutions: 'f16x3' = the split-precision f16 matrix-core path (DIR_DT_F16X3: ~2^-22 per
 # product, below fp32 accumulation noise; 2.5x the exact kernel's speed), 'f32' = exact fp32 MFMA (rounds 1-2).  DIR_TRAIN_ARITH overrides.
 ARITH = os.environ.get('DIR_TRAIN_ARITH', 'f16x3')
+WGRAD_ARITH = os.environ.get('DIR_TRAIN_WGRAD_ARITH', ARITH)          # the weight gradient's arithmetic (dir_conv2d_wgrad_f16x3 | _f32)
 # The split needs one power-of-two input scale per call site (include/dir_hip.h: in_scale).  Measuring it costs a host synchronisation, so it
 # is measured on the FIRST step (and again every RECALIBRATE steps: gradient magnitudes drift as the loss falls) and re-used in between: the
 # convolution calls of a training step happen in a fixed order, so the call counter identifies the site.  64x headroom + saturation at the
@@ -96,6 +97,20 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty(Cout, kh, kw, Cin, device=x.device)
+    # split-precision kernel for every layer wide enough to fill its 64-channel tiles (the 3-channel stem and the 1- / 3- / 6-channel heads keep
+    # the exact fp32 kernel); one power-of-two scale per operand and call site, cached like the forward's (_site_scale)
+    if WGRAD_ARITH == 'f16x3' and Cin % 4 == 0 and Cout % 4 == 0 and cs % 4 == 0 and gy.shape[3] % 4 == 0 and Cin >= 32 and Cout >= 32:
+        sx, sg = _site_scale(x), _site_scale(gy)
+        n = _capi.lib().dir_conv2d_wgrad_f16x3_workspace_bytes(d)
+        if accumulate:
+            n = max(n, out.numel() * 4)
+        ws = torch.empty(max(n, 4) // 4, device=x.device)
+        if _capi.PROFILE is not None:
+            _capi.annotate(family='wgrad', flops=2.0 * B * gy.shape[1] * gy.shape[2] * Cout * kh * kw * Cin, bytes=4.0 * (x.numel() + gy.numel() + Cout * kh * kw * Cin),
+                           shape='wgrad M=%d Cout=%d Cin=%d k%d s%d' % (B * gy.shape[1] * gy.shape[2], Cout, Cin, kh, stride))
+        _capi.check(_capi.lib().dir_conv2d_wgrad_f16x3(d, _capi.ptr(x), _capi.ptr(gy), _capi.ptr(out), int(accumulate), _capi.ptr(ws), n, sx, sg,
+                                                       _capi.stream_ptr()), 'dir_conv2d_wgrad_f16x3')
+        return out
     n = _capi.lib().dir_conv2d_wgrad_workspace_bytes(d)
     if accumulate:
         n = max(n, out.numel() * 4)

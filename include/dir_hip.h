@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 25
+#define DIR_ABI_VERSION 26
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -322,6 +322,16 @@ int dir_conv2d_splitk_forward(const dir_conv_desc* d, const void* x, const void*
 long long dir_conv2d_wgrad_workspace_bytes(const dir_conv_desc* d);
 int dir_conv2d_wgrad_f32(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
                          long long workspace_bytes, void* stream);
+
+/* The same weight gradient on the f16 matrix cores in split precision (the arithmetic of DIR_DT_F16X3: every product gy * x as hi*hi + lo*hi +
+ * hi*lo of the operands' f16 hi / lo halves, fp32 accumulation; ~2^-22 per product).  x_scale / gy_scale: powers of two by which x / gy are
+ * multiplied before the split (the largest |value| belongs near 2^9 .. 2^10: dir_amd.functional.pow2_in_scale; values saturate at the f16
+ * maximum, never inf / nan); 1 / (x_scale * gy_scale) is applied to the result.  Same geometry descriptor, result layout, chunked
+ * deterministic pixel reduction and accumulate semantics as dir_conv2d_wgrad_f32; channel counts, strides and offsets must be multiples of 4
+ * (DIR_E_ARG otherwise: use dir_conv2d_wgrad_f32).  workspace: dir_conv2d_wgrad_f16x3_workspace_bytes(d). */
+long long dir_conv2d_wgrad_f16x3_workspace_bytes(const dir_conv_desc* d);
+int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                           long long workspace_bytes, float x_scale, float gy_scale, void* stream);
 
 /* A convolution with a SECOND source accumulated into the same output tile:
  *   y = epilogue( conv(x; kh x kw, stride, pad) + conv1x1(x2; stride2) )

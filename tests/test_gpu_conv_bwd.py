@@ -50,3 +50,45 @@ def test_conv_backward_matches_autograd(case):
     acc = gw.clone()
     TC.conv_wgrad(x, gy.permute(0, 2, 3, 1).contiguous(), w.shape, stride, pad, out=acc, accumulate=True)
     assert (acc - 2 * gw).abs().max() <= 1e-6 * gw.abs().max()
+
+
+X3_CASES = [  # B, H, Cin, Cout, k, stride, pad, |gy| scale
+    (8, 32, 128, 128, 3, 1, 1, 1.0),      # 128 x 128 tiles, several pixel chunks
+    (4, 16, 192, 64, 1, 1, 0, 3e-7),      # 64 x 128 tiles with a ragged second tile; tiny gradients (the scale does the work)
+    (3, 17, 36, 260, 3, 2, 1, 40.0),      # odd map, stride 2, ragged tiles on both sides
+    (16, 32, 2560, 256, 3, 1, 1, 1e-3),   # the bone-fusion convolution's shape (models/dir.py:57-62)
+]
+
+
+@pytest.mark.parametrize('case', X3_CASES)
+def test_split_precision_weight_gradient_vs_float64(case):
+    """dir_conv2d_wgrad_f16x3 against the float64 gradient: as close as the exact fp32 kernel (both are bound by fp32 accumulation)"""
+    B, H, Cin, Cout, k, stride, pad, gs = case
+    torch.manual_seed(sum(int(v) for v in case[:7]))
+    x = torch.randn(B, H, H, Cin, device='cuda') * 3.0
+    Ho = (H + 2 * pad - k) // stride + 1
+    gy = torch.randn(B, Ho, Ho, Cout, device='cuda') * gs
+    wr = torch.zeros(Cout, Cin, k, k, device='cuda', dtype=torch.float64, requires_grad=True)
+    yr = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wr, None, stride=stride, padding=pad)
+    yr.backward(gy.permute(0, 3, 1, 2).double())
+    ref = wr.grad.permute(0, 2, 3, 1)
+    saved = TC.WGRAD_ARITH
+    try:
+        TC.WGRAD_ARITH = 'f16x3'
+        g3 = TC.conv_wgrad(x, gy, (Cout, k, k, Cin), stride, pad)
+        g3b = TC.conv_wgrad(x, gy, (Cout, k, k, Cin), stride, pad)
+        TC.WGRAD_ARITH = 'f32'
+        g1 = TC.conv_wgrad(x, gy, (Cout, k, k, Cin), stride, pad)
+    finally:
+        TC.WGRAD_ARITH = saved
+    assert torch.equal(g3, g3b)                            # deterministic
+    e3 = float((g3.double() - ref).abs().max() / ref.abs().max())
+    e1 = float((g1.double() - ref).abs().max() / ref.abs().max())
+    assert e3 < max(2.0 * e1, 2e-6), (e3, e1)
+    acc = g3.clone()
+    TC.WGRAD_ARITH = 'f16x3'
+    try:
+        TC.conv_wgrad(x, gy, (Cout, k, k, Cin), stride, pad, out=acc, accumulate=True)
+    finally:
+        TC.WGRAD_ARITH = saved
+    assert (acc - 2 * g3).abs().max() <= 1e-6 * g3.abs().max()
