@@ -13,6 +13,7 @@
 #include "dir_mfma.h"
 
 #include <math.h>
+#include <initializer_list>
 
 namespace {
 
@@ -269,8 +270,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------------------------ BatchNorm (training)
 // x [R, C] (channels last: rows = samples x positions).  One thread per channel, rows in order (R is small on the token path).
+// the BatchNorm output as every kernel here forms it (the ReLU mask of the backward pass re-computes exactly this value from x)
+__device__ __forceinline__ float bn_value(float x, float mu, float rs, float g, float be) { return fmaf((x - mu) * rs, g, be); }
 __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
-                                                          float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum) {
+                                                          float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum, int relu) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* x, const
     for (int r = 0; r < R; ++r) { const float d = x[(long long)r * ld + c] - mu; q = fmaf(d, d, q); }
     const float var = q / R, rs = 1.f / sqrtf(var + eps);
     const float g = w ? w[c] : 1.f, be = b ? b[c] : 0.f;
-    for (int r = 0; r < R; ++r) y[(long long)r * ld + c] = (x[(long long)r * ld + c] - mu) * rs * g + be;
+    for (int r = 0; r < R; ++r) { const float v = bn_value(x[(long long)r * ld + c], mu, rs, g, be); y[(long long)r * ld + c] = relu ? fmaxf(v, 0.f) : v; }
     save_mean[c] = mu; save_rstd[c] = rs;
     if (running_mean) {       // torch: running = (1 - momentum) running + momentum stat, with the UNBIASED variance
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
@@ -288,22 +291,26 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* x, const
     }
 }
 // g x = w rstd (g y - mean(g y) - x^ mean(g y x^)) ; g w = sum g y x^ ; g b = sum g y
-__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd,
-                                                          float* gx, float* gw, float* gb, int R, int C, int ld) {
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                                                          float* gx, float* gw, float* gb, int R, int C, int ld, int relu) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const float mu = save_mean[c], rs = save_rstd[c], g = w ? w[c] : 1.f;
+    const float mu = save_mean[c], rs = save_rstd[c], g = w ? w[c] : 1.f, be = b ? b[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     for (int r = 0; r < R; ++r) {
-        const float gv = gy[(long long)r * ld + c];
+        float gv = gy[(long long)r * ld + c];
+        if (relu && !(bn_value(x[(long long)r * ld + c], mu, rs, g, be) > 0.f)) gv = 0.f;
         s1 += gv; s2 = fmaf(gv, (x[(long long)r * ld + c] - mu) * rs, s2);
     }
     if (gw) gw[c] = s2;
     if (gb) gb[c] = s1;
     const float m1 = s1 / R, m2 = s2 / R;
     if (gx)
-        for (int r = 0; r < R; ++r)
-            gx[(long long)r * ld + c] = g * rs * (gy[(long long)r * ld + c] - m1 - (x[(long long)r * ld + c] - mu) * rs * m2);
+        for (int r = 0; r < R; ++r) {
+            float gv = gy[(long long)r * ld + c];
+            if (relu && !(bn_value(x[(long long)r * ld + c], mu, rs, g, be) > 0.f)) gv = 0.f;
+            gx[(long long)r * ld + c] = g * rs * (gv - m1 - (x[(long long)r * ld + c] - mu) * rs * m2);
+        }
 }
 
 // Large R (BatchNorm2d over feature maps: R = B*H*W up to 10^6 rows): the column reductions are cut into row chunks -- a workgroup =
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* gy, cons
 constexpr int BN_CHUNK_ROWS = 256, BN_SMALL_R = 512;
 // mode 0: p1 = sum x | mode 1: p1 = sum (x - mu)^2 | mode 2: p1 = sum gy, p2 = sum gy (x - mu) rs
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const float* gy, const float* mu, const float* rs, float* p1, float* p2,
-                                                        int R, int C, int ld, int mode) {
+                                                        int R, int C, int ld, int mode, const float* w = nullptr, const float* be = nullptr, int relu = 0) {
     __shared__ float s1[4][64], s2[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl, ch = blockIdx.y;
     const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
@@ -323,7 +330,11 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* x, const f
             const float v = x[(long long)r * ld + c];
             if (mode == 0) a += v;
             else if (mode == 1) { const float d = v - m; a = fmaf(d, d, a); }
-            else { const float g = gy[(long long)r * ld + c]; a += g; b = fmaf(g, (v - m) * k, b); }
+            else {
+                float g = gy[(long long)r * ld + c];
+                if (relu && !(bn_value(v, m, k, w ? w[c] : 1.f, be ? be[c] : 0.f) > 0.f)) g = 0.f;
+                a += g; b = fmaf(g, (v - m) * k, b);
+            }
         }
     }
     s1[rl][cl] = a; s2[rl][cl] = b;
@@ -401,21 +412,191 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* p, 
     }
 }
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* x, const float* w, const float* b, const float* mu, const float* rs, float* y,
-                                                          long long n, int C, int ld) {
+                                                          long long n, int C, int ld, int relu) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
     const long long o = (i / C) * ld + c;
-    y[o] = (x[o] - mu[c]) * rs[c] * (w ? w[c] : 1.f) + (b ? b[c] : 0.f);
+    const float v = bn_value(x[o], mu[c], rs[c], w ? w[c] : 1.f, b ? b[c] : 0.f);
+    y[o] = relu ? fmaxf(v, 0.f) : v;
 }
-__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* gy, const float* x, const float* w, const float* mu, const float* rs, const float* s1,
-                                                          const float* s2, float* gx, long long n, int R, int C, int ld) {
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* gy, const float* x, const float* w, const float* b, const float* mu, const float* rs,
+                                                          const float* s1, const float* s2, float* gx, long long n, int R, int C, int ld, int relu) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
     const long long o = (i / C) * ld + c;
-    const float m1 = s1[c] / R, m2 = s2[c] / R;
-    gx[o] = (w ? w[c] : 1.f) * rs[c] * (gy[o] - m1 - (x[o] - mu[c]) * rs[c] * m2);
+    const float m1 = s1[c] / R, m2 = s2[c] / R, g = w ? w[c] : 1.f;
+    float gv = gy[o];
+    if (relu && !(bn_value(x[o], mu[c], rs[c], g, b ? b[c] : 0.f) > 0.f)) gv = 0.f;
+    gx[o] = g * rs[c] * (gv - m1 - (x[o] - mu[c]) * rs[c] * m2);
+}
+
+// ---- 16-byte versions for C % 4 == 0 (every BatchNorm2d of the path).  Forward statistics in ONE pass over HBM: a workgroup (64 channels x
+// one 256-row chunk) forms the chunk's column sums, then the squared deviations from the CHUNK mean on a second read that hits L2 (a chunk
+// is 64 KB); the finalise kernel combines the chunks exactly: var = sum_k [M2_k + n_k (mean_k - mean)^2] / R, in chunk order.
+__global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p1, float* p2, int R, int C, int ld) {
+    __shared__ float4 s1[16][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 64 + cq * 4, ch = blockIdx.y;
+    const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
+    const bool on = c < C;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on)
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long long)r * ld + c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    s1[rl][cq] = a;
+    __syncthreads();
+    float4 t = s1[0][cq];
+    for (int l = 1; l < 16; ++l) { const float4 q = s1[l][cq]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+    __syncthreads();
+    const float inv = 1.f / (r1 - r0);
+    const float4 m = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on)
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long long)r * ld + c);
+            const float dx = v.x - m.x, dy = v.y - m.y, dz = v.z - m.z, dw = v.w - m.w;
+            b.x = fmaf(dx, dx, b.x); b.y = fmaf(dy, dy, b.y); b.z = fmaf(dz, dz, b.z); b.w = fmaf(dw, dw, b.w);
+        }
+    s1[rl][cq] = b;
+    __syncthreads();
+    if (rl == 0 && on) {
+        float4 u = s1[0][cq];
+        for (int l = 1; l < 16; ++l) { const float4 q = s1[l][cq]; u.x += q.x; u.y += q.y; u.z += q.z; u.w += q.w; }
+        *reinterpret_cast<float4*>(p1 + (long long)ch * C + c) = t;
+        *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
+    }
+}
+__global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, const float* p2, float* save_mean, float* save_rstd, float* running_mean,
+                                                              float* running_var, int chunks, int R, int C, float eps, float momentum) {
+    __shared__ float s[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    const float mu = chunk_sum16(p1, chunks, C, c, s) / R;
+    __syncthreads();
+    float a = 0.f;
+    if (c < C)
+        for (int k = rl; k < chunks; k += 16) {
+            const int nk = min(BN_CHUNK_ROWS, R - k * BN_CHUNK_ROWS);
+            const float d = p1[(long long)k * C + c] / nk - mu;
+            a += fmaf((float)nk * d, d, p2[(long long)k * C + c]);
+        }
+    s[rl][cl] = a;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    float q = 0.f;
+    for (int l = 0; l < 16; ++l) q += s[l][cl];
+    const float var = q / R;
+    save_mean[c] = mu; save_rstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (R > 1 ? q / (R - 1) : var);
+    }
+}
+// one thread = 4 channels of 4 rows
+__global__ __launch_bounds__(256) void bn_apply_fwd4_kernel(const float* x, const float* w, const float* b, const float* mu, const float* rs, float* y,
+                                                           int R, int C, int ld, int relu) {
+    const int cq = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(i % cq) * 4;
+    const long long r0 = (i / cq) * 4;
+    if (r0 >= R) return;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 m = *reinterpret_cast<const float4*>(mu + c), k = *reinterpret_cast<const float4*>(rs + c);
+    const float4 g = w ? *reinterpret_cast<const float4*>(w + c) : one, be = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long r = r0 + e;
+        if (r >= R) break;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        float4 o = make_float4(bn_value(v.x, m.x, k.x, g.x, be.x), bn_value(v.y, m.y, k.y, g.y, be.y), bn_value(v.z, m.z, k.z, g.z, be.z),
+                               bn_value(v.w, m.w, k.w, g.w, be.w));
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        *reinterpret_cast<float4*>(y + r * ld + c) = o;
+    }
+}
+// backward partial sums (the vec4 form of bn_partial_kernel's mode 2) with the ReLU mask re-computed from x
+__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, const float* gy, const float* w, const float* b, const float* mu, const float* rs,
+                                                             float* p1, float* p2, int R, int C, int ld, int relu) {
+    __shared__ float4 s1[16][16], s2[16][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 64 + cq * 4, ch = blockIdx.y;
+    const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
+    if (c < C) {
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 m = *reinterpret_cast<const float4*>(mu + c), k = *reinterpret_cast<const float4*>(rs + c);
+        const float4 g = w ? *reinterpret_cast<const float4*>(w + c) : one, be = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (long long)r * ld + c);
+            float4 q = *reinterpret_cast<const float4*>(gy + (long long)r * ld + c);
+            if (relu) {
+                if (!(bn_value(v.x, m.x, k.x, g.x, be.x) > 0.f)) q.x = 0.f;
+                if (!(bn_value(v.y, m.y, k.y, g.y, be.y) > 0.f)) q.y = 0.f;
+                if (!(bn_value(v.z, m.z, k.z, g.z, be.z) > 0.f)) q.z = 0.f;
+                if (!(bn_value(v.w, m.w, k.w, g.w, be.w) > 0.f)) q.w = 0.f;
+            }
+            a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+            bb.x = fmaf(q.x, (v.x - m.x) * k.x, bb.x); bb.y = fmaf(q.y, (v.y - m.y) * k.y, bb.y);
+            bb.z = fmaf(q.z, (v.z - m.z) * k.z, bb.z); bb.w = fmaf(q.w, (v.w - m.w) * k.w, bb.w);
+        }
+    }
+    s1[rl][cq] = a; s2[rl][cq] = bb;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float4 t = s1[0][cq], u = s2[0][cq];
+        for (int l = 1; l < 16; ++l) {
+            const float4 q = s1[l][cq], z = s2[l][cq];
+            t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+            u.x += z.x; u.y += z.y; u.z += z.z; u.w += z.w;
+        }
+        *reinterpret_cast<float4*>(p1 + (long long)ch * C + c) = t;
+        *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
+    }
+}
+// both column sums of the backward pass in one launch: t1 = g b, t2 = g w (also kept for the apply kernel)
+__global__ __launch_bounds__(256) void bn_bwd_combine_kernel(const float* p1, const float* p2, float* t1, float* t2, float* gb, float* gw, int chunks, int C) {
+    __shared__ float s[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float a = chunk_sum16(p1, chunks, C, c, s);
+    __syncthreads();
+    const float b = chunk_sum16(p2, chunks, C, c, s);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
+    t1[c] = a; t2[c] = b;
+    if (gb) gb[c] = a;
+    if (gw) gw[c] = b;
+}
+__global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, const float* x, const float* w, const float* b, const float* mu, const float* rs,
+                                                           const float* s1, const float* s2, float* gx, int R, int C, int ld, int relu) {
+    const int cq = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(i % cq) * 4;
+    const long long r0 = (i / cq) * 4;
+    if (r0 >= R) return;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 m = *reinterpret_cast<const float4*>(mu + c), k = *reinterpret_cast<const float4*>(rs + c);
+    const float4 g = w ? *reinterpret_cast<const float4*>(w + c) : one, be = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+    const float4 a1 = *reinterpret_cast<const float4*>(s1 + c), a2 = *reinterpret_cast<const float4*>(s2 + c);
+    const float4 m1 = make_float4(a1.x / R, a1.y / R, a1.z / R, a1.w / R), m2 = make_float4(a2.x / R, a2.y / R, a2.z / R, a2.w / R);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long r = r0 + e;
+        if (r >= R) break;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        float4 q = *reinterpret_cast<const float4*>(gy + r * ld + c);
+        if (relu) {
+            if (!(bn_value(v.x, m.x, k.x, g.x, be.x) > 0.f)) q.x = 0.f;
+            if (!(bn_value(v.y, m.y, k.y, g.y, be.y) > 0.f)) q.y = 0.f;
+            if (!(bn_value(v.z, m.z, k.z, g.z, be.z) > 0.f)) q.z = 0.f;
+            if (!(bn_value(v.w, m.w, k.w, g.w, be.w) > 0.f)) q.w = 0.f;
+        }
+        float4 o;
+        o.x = g.x * k.x * (q.x - m1.x - (v.x - m.x) * k.x * m2.x);
+        o.y = g.y * k.y * (q.y - m1.y - (v.y - m.y) * k.y * m2.y);
+        o.z = g.z * k.z * (q.z - m1.z - (v.z - m.z) * k.z * m2.z);
+        o.w = g.w * k.w * (q.w - m1.w - (v.w - m.w) * k.w * m2.w);
+        *reinterpret_cast<float4*>(gx + r * ld + c) = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ ReLU
@@ -737,11 +918,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, fl
 }
 
 static void launch_bn_partial(dim3 grid, hipStream_t s, const float* x, const float* gy, const float* mu, const float* rs, float* p1, float* p2, int R, int C, int ld,
-                              int mode) {
+                              int mode, const float* w = nullptr, const float* be = nullptr, int relu = 0) {
+    if (relu) {                                            // (backward sums through a ReLU mask: the scalar kernel carries it)
+        DIR_LAUNCH(bn_partial_kernel, grid, dim3(256), 0, s, x, gy, mu, rs, p1, p2, R, C, ld, mode, w, be, relu);
+        return;
+    }
     const bool vec = C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && (!gy || ((uintptr_t)gy & 15) == 0) && ((uintptr_t)p1 & 15) == 0 &&
                      (!p2 || ((uintptr_t)p2 & 15) == 0) && (!mu || ((uintptr_t)mu & 15) == 0) && (!rs || ((uintptr_t)rs & 15) == 0);
     if (vec) DIR_LAUNCH(bn_partial4_kernel, grid, dim3(256), 0, s, x, gy, mu, rs, p1, p2, R, C, ld, mode);
-    else DIR_LAUNCH(bn_partial_kernel, grid, dim3(256), 0, s, x, gy, mu, rs, p1, p2, R, C, ld, mode);
+    else DIR_LAUNCH(bn_partial_kernel, grid, dim3(256), 0, s, x, gy, mu, rs, p1, p2, R, C, ld, mode, (const float*)nullptr, (const float*)nullptr, 0);
 }
 
 }  // namespace
@@ -850,50 +1035,67 @@ extern "C" long long dir_bn_train_workspace_bytes(int R, int C) {
     const long long chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     return (2 * chunks + 2) * C * 4;
 }
+static bool bn_vec4(int C, int ld, std::initializer_list<const void*> ps) {
+    if (C % 4 || ld % 4) return false;
+    for (const void* q : ps) if (q && ((uintptr_t)q & 15)) return false;
+    return true;
+}
 extern "C" int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
-                                    float* running_var, int R, int C, int ld, float eps, float momentum, float* workspace, long long workspace_bytes,
-                                    void* stream) {
+                                    float* running_var, int R, int C, int ld, float eps, float momentum, int relu, float* workspace,
+                                    long long workspace_bytes, void* stream) {
     using namespace dir;
     DIR_REQUIRE(x && y && save_mean && save_rstd && R > 0 && C > 0 && ld >= C && ((running_mean == nullptr) == (running_var == nullptr)),
                 "dir_bn_train_forward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (R <= BN_SMALL_R) {
-        DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum);
+        DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum, relu);
         return check_launch("dir_bn_train_forward");
     }
     DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_forward: workspace too small (dir_bn_train_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* part = workspace;
     const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
+    if (bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, workspace})) {
+        float* p2 = part + (long long)chunks * C;
+        DIR_LAUNCH(bn_stats4_kernel, pg, dim3(256), 0, s, x, part, p2, R, C, ld);
+        DIR_LAUNCH(bn_stats_combine_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)p2, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
+        const long long nt = (long long)((R + 3) / 4) * (C / 4);
+        DIR_LAUNCH(bn_apply_fwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, R, C, ld, relu);
+        return check_launch("dir_bn_train_forward");
+    }
     launch_bn_partial(pg, s, x, nullptr, nullptr, nullptr, part, nullptr, R, C, ld, 0);
     DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)part, save_mean, chunks, C, 1.f / R);
     launch_bn_partial(pg, s, x, nullptr, save_mean, nullptr, part, nullptr, R, C, ld, 1);
     DIR_LAUNCH(bn_stats_finalize_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)save_mean, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
     const long long n = (long long)R * C;
-    DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld);
+    DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld, relu);
     return check_launch("dir_bn_train_forward");
 }
-extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* save_mean, const float* save_rstd, float* gx, float* gw,
-                                     float* gb, int R, int C, int ld, float* workspace, long long workspace_bytes, void* stream) {
+extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
+                                     float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream) {
     using namespace dir;
     DIR_REQUIRE(gy && x && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_train_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (R <= BN_SMALL_R) {
-        DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gy, x, w, save_mean, save_rstd, gx, gw, gb, R, C, ld);
+        DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, gx, gw, gb, R, C, ld, relu);
         return check_launch("dir_bn_train_backward");
     }
     DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_backward: workspace too small (dir_bn_train_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* p1 = workspace; float* p2 = p1 + (long long)chunks * C; float* t1 = p2 + (long long)chunks * C; float* t2 = t1 + C;
     const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
-    launch_bn_partial(pg, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2);
-    DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p1, t1, chunks, C, 1.f);
-    DIR_LAUNCH(bn_colsum_chunks_kernel, cg, dim3(256), 0, s, (const float*)p2, t2, chunks, C, 1.f);
-    if (gb && hipMemcpyAsync(gb, t1, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("dir_bn_train_backward: copy failed"); return DIR_E_LAUNCH; }
-    if (gw && hipMemcpyAsync(gw, t2, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("dir_bn_train_backward: copy failed"); return DIR_E_LAUNCH; }
+    const bool vec = bn_vec4(C, ld, {x, gy, gx, w, b, save_mean, save_rstd, workspace});
+    if (vec) DIR_LAUNCH(bn_bwd_partial4_kernel, pg, dim3(256), 0, s, x, gy, w, b, save_mean, save_rstd, p1, p2, R, C, ld, relu);
+    else launch_bn_partial(pg, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2, w, b, relu);
+    DIR_LAUNCH(bn_bwd_combine_kernel, cg, dim3(256), 0, s, (const float*)p1, (const float*)p2, t1, t2, gb, gw, chunks, C);
     if (gx) {
-        const long long n = (long long)R * C;
-        DIR_LAUNCH(bn_apply_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, x, w, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, n, R, C, ld);
+        if (vec) {
+            const long long nt = (long long)((R + 3) / 4) * (C / 4);
+            DIR_LAUNCH(bn_apply_bwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, R, C, ld, relu);
+        } else {
+            const long long n = (long long)R * C;
+            DIR_LAUNCH(bn_apply_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, n, R, C, ld, relu);
+        }
     }
     return check_launch("dir_bn_train_backward");
 }

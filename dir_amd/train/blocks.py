@@ -20,16 +20,18 @@ def _oihw(g):
     return g.permute(0, 3, 1, 2).contiguous()
 
 
-def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5):
+def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5, relu=False):
+    """BatchNorm2d in training mode; relu=True: the nn.ReLU that follows it in the same launch (bn_bwd(..., relu=True) undoes both)"""
     C = x.shape[-1]
-    y, st = O.bn_train_fwd(x.view(-1, C), P[pre + 'weight'], P[pre + 'bias'], P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum)
+    y, st = O.bn_train_fwd(x.view(-1, C), P[pre + 'weight'], P[pre + 'bias'], P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum,
+                           relu=relu)
     return y.view(x.shape), (x, st)
 
 
-def bn_bwd(P, pre, saved, gy, G):
+def bn_bwd(P, pre, saved, gy, G, relu=False):
     x, st = saved
     C = x.shape[-1]
-    gx, G[pre + 'weight'], G[pre + 'bias'] = O.bn_train_bwd(gy.contiguous().view(-1, C), x.view(-1, C), P[pre + 'weight'], st)
+    gx, G[pre + 'weight'], G[pre + 'bias'] = O.bn_train_bwd(gy.contiguous().view(-1, C), x.view(-1, C), P[pre + 'weight'], st, b=P[pre + 'bias'], relu=relu)
     return gx.view(x.shape)
 
 
@@ -47,11 +49,9 @@ def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True):
 def bottleneck_forward(P, x, stride=1):
     ctx = {'x': x, 'stride': stride}
     h = TC.conv_fwd(x, _ohwi(P['conv1.weight']))
-    h, ctx['bn1'] = bn_fwd(P, 'bn1.', h)
-    a1 = O.relu_fwd(h)
+    a1, ctx['bn1'] = bn_fwd(P, 'bn1.', h, relu=True)
     h = TC.conv_fwd(a1, _ohwi(P['conv2.weight']), None, stride, 1)
-    h, ctx['bn2'] = bn_fwd(P, 'bn2.', h)
-    a2 = O.relu_fwd(h)
+    a2, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
     h = TC.conv_fwd(a2, _ohwi(P['conv3.weight']))
     out, ctx['bn3'] = bn_fwd(P, 'bn3.', h)
     if 'downsample.0.weight' in P:
@@ -71,9 +71,9 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
     g = O.relu_bwd(gy.contiguous(), ctx['y'])               # gradient of (bn3 out + identity)
     g3 = bn_bwd(P, 'bn3.', ctx['bn3'], g, G)
     g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G)
-    g2 = bn_bwd(P, 'bn2.', ctx['bn2'], O.relu_bwd(g2, ctx['a2']), G)
+    g2 = bn_bwd(P, 'bn2.', ctx['bn2'], g2, G, relu=True)
     g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G)
-    g1 = bn_bwd(P, 'bn1.', ctx['bn1'], O.relu_bwd(g1, ctx['a1']), G)
+    g1 = bn_bwd(P, 'bn1.', ctx['bn1'], g1, G, relu=True)
     gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx)
     if 'downsample.0.weight' in P:
         gd = bn_bwd(P, 'downsample.1.', ctx['bnd'], g, G)
@@ -88,14 +88,11 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
 # -------------------------------------------------------------------------------------------------------------------------- Residual
 def residual_forward(P, x):
     ctx = {'x': x}
-    h, ctx['bn1'] = bn_fwd(P, 'bn1.', x)
-    a0 = O.relu_fwd(h)
+    a0, ctx['bn1'] = bn_fwd(P, 'bn1.', x, relu=True)
     h = TC.conv_fwd(a0, _ohwi(P['conv1.conv.weight']), P['conv1.conv.bias'])
-    h, ctx['bn2'] = bn_fwd(P, 'bn2.', h)
-    a1 = O.relu_fwd(h)
+    a1, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
     h = TC.conv_fwd(a1, _ohwi(P['conv2.conv.weight']), P['conv2.conv.bias'], 1, 1)
-    h, ctx['bn3'] = bn_fwd(P, 'bn3.', h)
-    a2 = O.relu_fwd(h)
+    a2, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True)
     y = TC.conv_fwd(a2, _ohwi(P['conv3.conv.weight']), P['conv3.conv.bias'])
     need_skip = P['skip_layer.conv.weight'].shape[0] != P['skip_layer.conv.weight'].shape[1]          # hourglass.py:49-52
     if need_skip:
@@ -111,11 +108,11 @@ def residual_backward(P, ctx, gy, need_gx=True):
     x = ctx['x']
     gy = gy.contiguous()
     g = _conv_bwd(P, 'conv3.conv.', ctx['a2'], gy, 1, 0, G)
-    g = bn_bwd(P, 'bn3.', ctx['bn3'], O.relu_bwd(g, ctx['a2']), G)
+    g = bn_bwd(P, 'bn3.', ctx['bn3'], g, G, relu=True)
     g = _conv_bwd(P, 'conv2.conv.', ctx['a1'], g, 1, 1, G)
-    g = bn_bwd(P, 'bn2.', ctx['bn2'], O.relu_bwd(g, ctx['a1']), G)
+    g = bn_bwd(P, 'bn2.', ctx['bn2'], g, G, relu=True)
     g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G)
-    gx = bn_bwd(P, 'bn1.', ctx['bn1'], O.relu_bwd(g, ctx['a0']), G)
+    gx = bn_bwd(P, 'bn1.', ctx['bn1'], g, G, relu=True)
     if ctx['need_skip']:
         gs = _conv_bwd(P, 'skip_layer.conv.', x, gy, 1, 0, G, need_gx=need_gx)
         if need_gx:

@@ -56,15 +56,14 @@ def _cbr_forward(P, pre, x, k):
     """Sequential(Conv2d(k, pad k//2), BatchNorm2d, ReLU, Conv2d(1)) -- conv_final, seg, dense, attention_*, fusion (models/dir.py:57-62,227-241,404-419)"""
     w0 = TB._ohwi(P[pre + '0.weight'])
     h = TC.conv_fwd(x, w0, P.get(pre + '0.bias'), 1, k // 2)
-    n, s_bn = TB.bn_fwd(P, pre + '1.', h)
-    a = O.relu_fwd(n)
+    a, s_bn = TB.bn_fwd(P, pre + '1.', h, relu=True)
     y = TC.conv_fwd(a, TB._ohwi(P[pre + '3.weight']), P.get(pre + '3.bias'))
     return y, dict(x=x, bn=s_bn, a=a, k=k)
 
 
 def _cbr_backward(P, pre, s, gy, G, need_gx=True):
     g = TB._conv_bwd(P, pre + '3.', s['a'], gy, 1, 0, G)
-    g = TB.bn_bwd(P, pre + '1.', s['bn'], O.relu_bwd(g, s['a']), G)
+    g = TB.bn_bwd(P, pre + '1.', s['bn'], g, G, relu=True)
     return TB._conv_bwd(P, pre + '0.', s['x'], g, 1, s['k'] // 2, G, need_gx=need_gx)
 
 
@@ -111,8 +110,7 @@ def forward(P, img, keep=None):
     ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)
     # ---- backbone (models/backbone/resnet.py:243-255)
     h = _stem_forward(P, img)
-    n, ctx['bn1'] = TB.bn_fwd(P, 'backbone.bn1.', h)
-    a = O.relu_fwd(n)
+    a, ctx['bn1'] = TB.bn_fwd(P, 'backbone.bn1.', h, relu=True)
     x = SP.maxpool_fwd(a)
     ctx['stem'] = (a, x)
     feats, ctx['blocks'] = [], []
@@ -257,7 +255,7 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
         flush(G)
     a, x_pool = ctx['stem']
     g = SP.maxpool_bwd(a, g)
-    g = TB.bn_bwd(P, 'backbone.bn1.', ctx['bn1'], O.relu_bwd(g, a), G)
+    g = TB.bn_bwd(P, 'backbone.bn1.', ctx['bn1'], g, G, relu=True)
     img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
     G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
     flush(G)

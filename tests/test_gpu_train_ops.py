@@ -181,3 +181,32 @@ def test_pgcn_train_forward_backward_vs_reference_autograd(golden):
     for k in Gr:
         if not k.endswith(('gconv.bias', 'gconv.e_0')):
             assert rel(G2[k], Gr[k]) < 2e-5, k
+
+
+@pytest.mark.parametrize('R,C', [(300, 128), (5000, 64), (70000, 256), (4097, 6), (1537, 36)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_batchnorm_relu_fused(R, C, relu):
+    """dir_bn_train_forward / _backward (one-thread-per-channel, scalar chunked and 16-byte chunked paths), plain and with the fused ReLU,
+    against torch's BatchNorm1d (+ ReLU) in float64 on the CPU"""
+    rng = np.random.RandomState(R + C)
+    x = (rng.normal(0, 1, (R, C)) * rng.uniform(0.5, 3, C) + rng.normal(0, 2, C)).astype(np.float32)
+    w, b, gy = rng.normal(0, 1, C).astype(np.float32), rng.normal(0, 0.5, C).astype(np.float32), rng.normal(0, 1, (R, C)).astype(np.float32)
+    bn = torch.nn.BatchNorm1d(C).double().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(w)); bn.bias.copy_(torch.from_numpy(b))
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    yt = bn(xt)
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    y, st = O.bn_train_fwd(dev(x), dev(w), dev(b), rm, rv, relu=relu)
+    yref = torch.relu(yt) if relu else yt
+    assert rel(y, yref.detach().numpy()) < 5e-6 and rel(rm, bn.running_mean.numpy()) < 5e-6 and rel(rv, bn.running_var.numpy()) < 5e-6
+    # the ReLU's gradient mask is the fp32 forward's (an element within rounding of zero may sit on the other side in float64): the reference
+    # differentiates BatchNorm in float64 under THAT mask, which is what autograd does with the fp32 forward's saved output
+    mask = (y > 0).double().cpu() if relu else torch.ones(R, C, dtype=torch.float64)
+    if relu:
+        assert float((mask - (yt.detach() > 0).double()).abs().mean()) < 1e-5
+    yt.backward(torch.from_numpy(gy).double() * mask)
+    gx, gw, gb = O.bn_train_bwd(dev(gy), dev(x), dev(w), st, b=dev(b), relu=relu)
+    assert rel(gx, xt.grad.numpy()) < 3e-5 and rel(gw, bn.weight.grad.numpy()) < 1e-5 and rel(gb, bn.bias.grad.numpy()) < 1e-5
+    y2, _ = O.bn_train_fwd(dev(x), dev(w), dev(b), relu=relu)
+    assert torch.equal(y, y2)
