@@ -1150,14 +1150,25 @@ extern "C" int dir_grid_rows_backward(const float* const* g_rows_h, const float*
 // dst_t += alpha * src_t for up to AXPY_MULTI tensors in ONE launch (the table travels in the kernel arguments): moving the 556 parameter
 // gradients of a training step into the flat all-reduce bucket was 556 launches of a few microseconds each
 namespace {
-constexpr int AXPY_MULTI = 40, AXPY_BLOCKS = 32;
-struct AxpyTable { float* dst[AXPY_MULTI]; const float* src[AXPY_MULTI]; long long n[AXPY_MULTI]; };
-__global__ __launch_bounds__(256) void axpy_multi_kernel(AxpyTable t, float alpha) {
-    const int k = blockIdx.x / AXPY_BLOCKS, b = blockIdx.x - k * AXPY_BLOCKS;
+constexpr int AXPY_MULTI = 40, AXPY_CHUNK = 8192;      // tensors per launch; elements per workgroup (a tensor gets ceil(n / chunk) of them)
+struct AxpyTable { float* dst[AXPY_MULTI]; const float* src[AXPY_MULTI]; long long n[AXPY_MULTI]; int first[AXPY_MULTI + 1]; };
+__global__ __launch_bounds__(256) void axpy_multi_kernel(AxpyTable t, float alpha, int count) {
+    int k = 0;
+    while (k + 1 < count && (int)blockIdx.x >= t.first[k + 1]) ++k;          // <= 40 uniform (scalar) comparisons
     float* d = t.dst[k];
     const float* s = t.src[k];
-    const long long n = t.n[k];
-    for (long long i = (long long)b * 256 + threadIdx.x; i < n; i += (long long)AXPY_BLOCKS * 256) d[i] += alpha * s[i];
+    const long long n = t.n[k], i0 = (long long)(blockIdx.x - t.first[k]) * AXPY_CHUNK, i1 = min(n, i0 + AXPY_CHUNK);
+    if ((((uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+        for (long long i = i0 + threadIdx.x * 4; i + 3 < i1; i += 1024) {
+            float4 a = *reinterpret_cast<float4*>(d + i);
+            const float4 b = *reinterpret_cast<const float4*>(s + i);
+            a.x += alpha * b.x; a.y += alpha * b.y; a.z += alpha * b.z; a.w += alpha * b.w;
+            *reinterpret_cast<float4*>(d + i) = a;
+        }
+        for (long long i = i0 + ((i1 - i0) & ~3ll) + threadIdx.x; i < i1; i += 256) d[i] += alpha * s[i];
+    } else {
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) d[i] += alpha * s[i];
+    }
 }
 }  // namespace
 extern "C" int dir_axpy_multi_f32(float* const* dst_host, const float* const* src_host, const long long* n_host, int count, float alpha, void* stream) {
@@ -1166,11 +1177,16 @@ extern "C" int dir_axpy_multi_f32(float* const* dst_host, const float* const* sr
     for (int base = 0; base < count; base += AXPY_MULTI) {
         AxpyTable t;
         const int m = count - base < AXPY_MULTI ? count - base : AXPY_MULTI;
+        long long blocks = 0;
         for (int k = 0; k < m; ++k) {
             DIR_REQUIRE(dst_host[base + k] && src_host[base + k] && n_host[base + k] >= 0, "dir_axpy_multi_f32: null tensor %d", base + k);
             t.dst[k] = dst_host[base + k]; t.src[k] = src_host[base + k]; t.n[k] = n_host[base + k];
+            t.first[k] = (int)blocks;
+            blocks += (n_host[base + k] + AXPY_CHUNK - 1) / AXPY_CHUNK;
+            DIR_REQUIRE(blocks < (1ll << 30), "dir_axpy_multi_f32: too many elements");
         }
-        DIR_LAUNCH(axpy_multi_kernel, dim3(m * AXPY_BLOCKS), dim3(256), 0, (hipStream_t)stream, t, alpha);
+        t.first[m] = (int)blocks;
+        if (blocks > 0) DIR_LAUNCH(axpy_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t, alpha, m);
     }
     return check_launch("dir_axpy_multi_f32");
 }

@@ -126,6 +126,9 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
                                                               splits, _capi.ptr(workspace), workspace.numel(), _capi.stream_ptr()),
                         'dir_conv2d_splitk_forward')
             return out
+        if _capi.PROFILE is not None:
+            _capi.annotate(family='conv', flops=2.0 * B * Ho * Wo * Cout * kh * kw * Cin, bytes=float(x.numel() * x.element_size() + out.numel() * out.element_size()),
+                           shape='conv M=%d N=%d K=%d k%d s%d %s' % (B * Ho * Wo, Cout, kh * kw * Cin, kh, stride, arith or str(x.dtype)[6:]))
         rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift),
                                             _capi.ptr(pre_scale), _capi.ptr(pre_shift), _capi.ptr(residual),
                                             _capi.ptr(out), _capi.stream_ptr())

@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 from dir_amd import dist as D  # noqa: E402
 from dir_amd import synth  # noqa: E402
 from dir_amd.optim import FlatAdamW  # noqa: E402
+from dir_amd.train import conv as TC  # noqa: E402
 from dir_amd.train import net as TN  # noqa: E402
 from dir_amd.train import step as TSTEP  # noqa: E402
 
@@ -73,6 +74,7 @@ if rank == 0:
         P = {k: v.data for k, v in p1.items()}
         P.update({k: v.clone() for k, v in b1.items()})
         i2, t2, m2 = batch(r)
+        del TC._scales[:]                                   # the split-precision operand scales are calibrated on a rank's own first batch: do the same here
         outs, ctx = TN.forward(P, i2)
         G = TN.backward(P, ctx, outs, t2, m2, faces)
         o1.zero_grad()

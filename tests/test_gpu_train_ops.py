@@ -210,3 +210,19 @@ def test_batchnorm_relu_fused(R, C, relu):
     assert rel(gx, xt.grad.numpy()) < 3e-5 and rel(gw, bn.weight.grad.numpy()) < 1e-5 and rel(gb, bn.bias.grad.numpy()) < 1e-5
     y2, _ = O.bn_train_fwd(dev(x), dev(w), dev(b), relu=relu)
     assert torch.equal(y, y2)
+
+
+def test_axpy_multi_matches_per_tensor_axpy():
+    """dir_axpy_multi_f32 (work split by elements: one huge tensor beside hundreds of tiny ones, odd lengths, unaligned views)"""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    sizes = [37748736 // 8, 3, 64, 1, 8192, 8193, 100003] + [64 + 7 * i for i in range(90)]
+    pool = torch.randn(sum(sizes) + len(sizes), device='cuda', generator=g)
+    dsts, srcs, o = [], [], 0
+    for i, n in enumerate(sizes):
+        dsts.append(pool[o + (i & 1):o + (i & 1) + n])                     # every other view starts off a 16-byte boundary
+        srcs.append(torch.randn(n, device='cuda', generator=g))
+        o += n + 1
+    want = [d + 0.25 * s_ for d, s_ in zip(dsts, srcs)]
+    O.axpy_multi(dsts, srcs, 0.25)
+    for d, w_ in zip(dsts, want):
+        assert float((d - w_).abs().max()) <= 2.4e-7 * float(w_.abs().max())            # (the kernel's multiply-add is fused)
