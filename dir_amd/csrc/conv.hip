@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int m = m0 + (tid >> 3) + 32 * i;
         avoff[i] = 0;
         amask[i] = 0;
+        avoff2[i] = 0x80000000u;
         if (m < a.M) {
             int b, oy, ox;
             pixel_setup(a, m, col * EPC * ES, ES, avoff[i], amask[i], b, oy, ox);
@@ -135,46 +136,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     auto gload = [&](auto P, int ks) {
         constexpr int p = decltype(P)::value;
-        if (ks >= a.nk1) {                               // second source (f16x3 only on this path): slab (ks - nk1) of x2's channels, 1x1
-            const int c2 = (ks - a.nk1) * BK;
-#pragma unroll
-            for (int i = 0; i < ACH; ++i) {
-                uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(x2r, avoff2[i], c2 * ES, 0));
-                if constexpr (X1) v = split_f16x1(v, a.a_scale); else if constexpr (X3) v = split_f16x3(v, a.a_scale);
-                ra[p][i] = __builtin_bit_cast(u32x4, v);
-            }
-#pragma unroll
-            for (int i = 0; i < BCH; ++i)
-                rb[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[i], (a.nk1 * BK + c2) * ES, 0));
-            return;
-        }
-        // K order: channel slab outer, taps inner -- consecutive slabs touch the same pixels' cache lines (shifted
+        // ONE straight-line load sequence for both sources (descriptor / offsets chosen by scalar selects): loads on two sides of a branch
+        // make hipcc wait for all of them (vmcnt(0)) at the first use.  Second source (ks >= nk1): slab (ks - nk1) of x2's channels, 1x1.
+        // K order of the first source: channel slab outer, taps inner -- consecutive slabs touch the same pixels' cache lines (shifted
         // by one tap), so the im2col re-reads hit L1/L2 instead of re-streaming the feature map once per tap
-        const int cs = ks / ntaps, tap = ks - cs * ntaps;
-        const int c0 = cs * BK, k0 = tap * a.Cin + c0;
+        const bool second = ks >= a.nk1;
+        const int c2 = (ks - a.nk1) * BK;
+        const int cs = ks / ntaps, tap = second ? 0 : ks - cs * ntaps;
+        const int c0 = cs * BK, k0 = second ? a.nk1 * BK + c2 : tap * a.Cin + c0;
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
         const int toff = ((ky * a.W + kx) * a.in_cs + c0) * ES;
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? x2 : x), 0, second ? a.x2_bytes : a.x_bytes, 0x00020000);
+        const int asoff = second ? c2 * ES : 0;
 #pragma unroll
         for (int i = 0; i < ACH; ++i) {
             const bool ok = (amask[i] >> tap) & 1u;
-            const unsigned vo = ok ? (unsigned)(avoff[i] + toff) : OOB;
-            uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, 0, 0));
-            if constexpr (PRE) {
-                if (ok) v = prologue<TI>(v, a.pre_scale, a.pre_shift, c0 + col * EPC, pre_relu);
-            }
-            if constexpr (X1) v = split_f16x1(v, a.a_scale); else if constexpr (X3) v = split_f16x3(v, a.a_scale);                    // {hi01, hi23, lo01, lo23}
-            ra[p][i] = __builtin_bit_cast(u32x4, v);
-        }
+            const unsigned vo = second ? avoff2[i] : ok ? (unsigned)(avoff[i] + toff) : OOB;
+            ra[p][i] = __builtin_amdgcn_raw_buffer_load_b128(ar, vo, asoff, 0);     // RAW: transformed when written to LDS (stage_value), so
+        }                                                                           // that nothing waits for the load inside this function
 #pragma unroll
         for (int i = 0; i < BCH; ++i) {
             rb[p][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, bvoff[i], k0 * ES, 0));
         }
     };
-    auto lstore = [&](auto P, int buf) {
+    // the pre-activation and the f16 hi / lo split of a staged A chunk of slab ks, applied on its way from the register stage to LDS
+    auto stage_value = [&](u32x4 r, int i, int ks) -> uint4 {
+        uint4 v = __builtin_bit_cast(uint4, r);
+        if constexpr (PRE) {
+            if (ks < a.nk1) {
+                const int cs = ks / ntaps, tap = ks - cs * ntaps;
+                if ((amask[i] >> tap) & 1u) v = prologue<TI>(v, a.pre_scale, a.pre_shift, cs * BK + col * EPC, pre_relu);
+            }
+        }
+        if constexpr (X1) v = split_f16x1(v, a.a_scale); else if constexpr (X3) v = split_f16x3(v, a.a_scale);                        // {hi01, hi23, lo01, lo23}
+        return v;
+    };
+    auto lstore = [&](auto P, int buf, int ks) {
         constexpr int p = decltype(P)::value;
         char* sa = smem + buf * BUF_BYTES;
         char* sb = sa + A_BYTES;
         const int off0 = (tid >> 3) * LDS_STRIDE + col * 16;
+        if constexpr (PRE || X3) {
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) ra[p][i] = __builtin_bit_cast(u32x4, stage_value(ra[p][i], i, ks));
+        }
         if constexpr (X3) {
             // LDS row of a 32-channel slab = [hi: 32 f16 | lo: 32 f16] (the layout the host packs the weights in): this thread's four
             // channels are 8 bytes of each half
@@ -315,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         constexpr int p = decltype(P)::value;
         using Q = std::integral_constant<int, p ^ 1>;
         if constexpr (!DMA) {
-            if (ks + 2 < nact) gload(P, slab(ks + 2));
+            gload(P, slab(min(ks + 2, nact - 1)));     // ALWAYS issued (past the end: a re-read that is never stored): under a branch hipcc cannot
+                                                       // count the loads in flight and drains them all (vmcnt(0)) before the register stage is used
         }
         const char* sa = smem + p * BUF_BYTES + (wm * MI * 32) * ROW + frag_off;
         const char* sb = smem + p * BUF_BYTES + A_BYTES + (wn * NJ * 32) * ROW + frag_off;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) mma_slab<TI>(af[i], bfr[j], acc[i][j]);
         if constexpr (!DMA) {
-            if (ks + 1 < nact) lstore(Q{}, p ^ 1);
+            if (ks + 1 < nact) lstore(Q{}, p ^ 1, slab(ks + 1));
         } else {
             __builtin_amdgcn_sched_barrier(0);      // keep the DMA drain + barrier BELOW the MFMAs it overlaps with
         }
@@ -386,9 +392,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     } else {
         if (nact > 0) {
             gload(P0{}, slab(0));
-            lstore(P0{}, 0);
+            lstore(P0{}, 0, slab(0));
+            gload(P1{}, slab(nact > 1 ? 1 : 0));
         }
-        if (nact > 1) gload(P1{}, slab(1));
     }
     if constexpr (!RING3) {
         __syncthreads();
