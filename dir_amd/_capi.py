@@ -76,7 +76,7 @@ class InitHeadParams(C.Structure):
 
 
 class BoneFusionParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('w_g', 'scale', 'shift')] + [('exact_f32', C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ('w_g', 'scale', 'shift')] + [('exact_f32', C.c_int32), ('g_scale', C.c_float)]
 
 
 class EvalInputs(C.Structure):
@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 27          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 28          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 

@@ -110,6 +110,8 @@ struct FuseArgs {
     int PW, PH, npr;      // halo patch geometry of one 256-pixel strip
     long long* stamps;    // DIR_STAMPS=bone_fuse (tuning aid, else NULL)
     unsigned mg_npr, sh_npr, mg_pw, sh_pw;   // magic dividers (convk::magic_u31) for npr and PW
+    float g_scale;        // split-precision variant: power of two applied to G before the f16 hi / lo split
+    unsigned mg_pr8, sh_pr8;                 // and the divider for ceil(npr / 8)
 };
 
 constexpr int FUSE_MAX_ROWS = 400;
@@ -363,6 +365,147 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_f32_kernel(FuseArgs a) {
     epilogue_tile<float, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
 }
 
+// ------------------------------------------------------------------------------------------------- fuse, split precision
+// The fp32 factorisation above on the f16 matrix cores: both operands (bone weights in [0, 1] times 2^10; G times the calibrated power of two
+// g_scale) are split into f16 hi + lo when they are written to LDS and every product is hi*hi + lo*hi + hi*lo with fp32 accumulation -- the
+// arithmetic of DIR_DT_F16X3 (conv_common.h), ~2^-22 per product, i.e. the same distance from the reference's bone_proj + conv3x3 as the
+// exact kernel (fp32 summation noise) at a tenth of its matrix-core time (15 v_mfma_f32_32x32x16_f16 instead of 40 v_mfma_f32_32x32x2_f32 per
+// tile and tap).  Rows are [80 hi | 80 lo] f16 at the same 336-byte pitch (conflict-free ds_read_b128); reduction index e = 2 hb + end.
+// LDS writes: lanes vary (row & 7, hb & 3) fastest -- 32 distinct banks per ds_write_b32 -- instead of one row per lane (8-way conflicts).
+constexpr float X3_WSCALE = 1024.f;
+__device__ __forceinline__ void split2(float x, float y, float s, unsigned& hi, unsigned& lo) {
+    constexpr float FMAX = 65504.f;
+    const convk::f32x2_t v = {__builtin_amdgcn_fmed3f(x * s, -FMAX, FMAX), __builtin_amdgcn_fmed3f(y * s, -FMAX, FMAX)};
+    const convk::f16x2_t h = __builtin_convertvector(v, convk::f16x2_t);
+    const convk::f32x2_t r = v - __builtin_convertvector(h, convk::f32x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, convk::f16x2_t));
+}
+__global__ __launch_bounds__(512, 1) void bone_fuse_x3_kernel(FuseArgs a) {
+    constexpr int MI = 1, NJ = 2, WM = 4, WN = 2, NT = 512, BM = F32_BM, BN = 128;
+    constexpr int P_BYTES = F32_MAX_ROWS * F32_PITCH, G_BYTES = BN * F32_PITCH;
+    constexpr int STAGE_BYTES = BM * BN * 4;
+    constexpr int SMEM = P_BYTES + 2 * G_BYTES > STAGE_BYTES ? P_BYTES + 2 * G_BYTES : STAGE_BYTES;
+    constexpr int GW = 40 * BN / NT;                                 // G float2 words per thread per tap (10)
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    __shared__ float s_uv[84];
+    __shared__ float s_bone[40 * 6];
+
+    const int S = a.S, hw = S * S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int tn = blockIdx.x & 1, tm = blockIdx.x >> 1;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int b = m0 / hw, y0 = (m0 - b * hw) / S;
+
+    // G word k of this thread: channel n = 8 * ((tid >> 5) & 15) + (tid & 7), hand-bone hb = 4 k + ((tid >> 3) & 3)
+    const int gn = 8 * ((tid >> 5) & 15) + (tid & 7), ghb = (tid >> 3) & 3;
+    const float2* gsrc = reinterpret_cast<const float2*>(a.g) + ((long long)b * NTAP * 40) * NCOUT + n0 + gn;
+    float2 greg[GW];
+    auto g_load = [&](int tap) {
+#pragma unroll
+        for (int k = 0; k < GW; ++k) greg[k] = gsrc[((long long)tap * 40 + 4 * k + ghb) * NCOUT];
+    };
+    auto g_store = [&](int buf) {
+        char* gb = smem + P_BYTES + buf * G_BYTES + gn * F32_PITCH + ghb * 4;
+#pragma unroll
+        for (int k = 0; k < GW; ++k) {
+            unsigned hi, lo;
+            split2(greg[k].x, greg[k].y, a.g_scale, hi, lo);
+            *reinterpret_cast<unsigned*>(gb + 16 * k) = hi;
+            *reinterpret_cast<unsigned*>(gb + 160 + 16 * k) = lo;
+        }
+    };
+    g_load(0);
+
+    if (tid < 84) {
+#pragma clang fp contract(off)
+        const int hand = tid / 42, r = tid - hand * 42;
+        const float v = a.uv[hand][(long long)b * 42 + r];
+        s_uv[tid] = (v + 1.f) / 2.f * (float)S;                      // models/dir.py:150
+    }
+    __syncthreads();
+    if (tid < 40) {
+        const int hand = tid / 20, bone = tid - hand * 20;
+        const float* uv = s_uv + hand * 42;
+        const int pa = kParent[bone], ch = kChild[bone];
+        float dx, dy;
+        dir::bone::bone_dir(uv[2 * pa], uv[2 * pa + 1], uv[2 * ch], uv[2 * ch + 1], dx, dy);
+        float* sb = s_bone + 6 * tid;
+        sb[0] = uv[2 * pa]; sb[1] = uv[2 * pa + 1]; sb[2] = uv[2 * ch]; sb[3] = uv[2 * ch + 1]; sb[4] = dx; sb[5] = dy;
+    }
+    __syncthreads();
+    const int pr8 = (a.npr + 7) >> 3;
+    for (int i = tid; i < pr8 * 320; i += NT) {                      // i = ((hq * pr8 + rg) * 4 + c) * 8 + r: patch row 8 rg + r, hand-bone 4 hq + c
+        const int rest = i >> 5, hq = convk::div_magic(rest, a.mg_pr8, a.sh_pr8), rg = rest - hq * pr8;
+        const int prow = 8 * rg + (i & 7), hb = 4 * hq + ((i >> 3) & 3);
+        if (prow >= a.npr) continue;
+        const int py = convk::div_magic(prow, a.mg_pw, a.sh_pw), px = prow - py * a.PW;
+        const int iy = y0 + py - 1, ix = px - 1;                      // 3x3, pad 1
+        float wa = 0.f, wb = 0.f;
+        if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+            const float* sb = s_bone + 6 * hb;
+            float ta, tb;
+            if (dir::bone::bone_weights_fast((float)ix + 0.5f, (float)iy + 0.5f, sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], a.distance, ta, tb)) {
+                wa = ta; wb = tb;                                      // torch.where(mask, v, 0), models/dir.py:172
+            }
+        }
+        unsigned hi, lo;
+        split2(wa, wb, X3_WSCALE, hi, lo);
+        char* pp = smem + prow * F32_PITCH + hb * 4;
+        *reinterpret_cast<unsigned*>(pp) = hi;
+        *reinterpret_cast<unsigned*>(pp + 160) = lo;
+    }
+    g_store(0);
+    __syncthreads();
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int pr0;
+    {
+        const int r = wm * 32 + (lane & 31);
+        const int y = r / S, x = r - y * S;
+        pr0 = y * a.PW + x;
+    }
+    const int hoff = (lane >> 5) * 16;                                // k16-step s: this lane's 8 reduction indices at byte 32 s + 16 h
+    const int frag_b = (wn * NJ * 32 + (lane & 31)) * F32_PITCH + hoff;
+
+    for (int tap = 0; tap < NTAP; ++tap) {
+        if (tap + 1 < NTAP) g_load(tap + 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const char* gb = smem + P_BYTES + (tap & 1) * G_BYTES + frag_b;
+        const char* pa = smem + (pr0 + ky * a.PW + kx) * F32_PITCH + hoff;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const convk::f16x8 ah = *reinterpret_cast<const convk::f16x8*>(pa + q * 32), al = *reinterpret_cast<const convk::f16x8*>(pa + 160 + q * 32);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const convk::f16x8 bh = *reinterpret_cast<const convk::f16x8*>(gb + j * 32 * F32_PITCH + q * 32);
+                const convk::f16x8 bl = *reinterpret_cast<const convk::f16x8*>(gb + j * 32 * F32_PITCH + 160 + q * 32);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][j], 0, 0, 0);
+            }
+        }
+        if (tap + 1 < NTAP) g_store((tap + 1) & 1);
+        __syncthreads();
+    }
+    const float inv = 1.f / (X3_WSCALE * a.g_scale);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] *= inv;
+    ConvArgs c = a.c;
+    epilogue_tile<float, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
+}
+
 }  // namespace
 }  // namespace dir
 
@@ -406,7 +549,13 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     convk::magic_u31((unsigned)fa.npr, &fa.mg_npr, &fa.sh_npr);
     convk::magic_u31((unsigned)fa.PW, &fa.mg_pw, &fa.sh_pw);
     fa.stamps = stamps_begin("bone_fuse");
-    if (p->exact_f32) DIR_LAUNCH(bone_fuse_f32_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    fa.g_scale = p->exact_f32 ? p->g_scale : 0.f;
+    convk::magic_u31((unsigned)((fa.npr + 7) >> 3), &fa.mg_pr8, &fa.sh_pr8);
+    if (p->exact_f32 && fa.g_scale > 0.f) {
+        int e;
+        DIR_REQUIRE(frexpf(fa.g_scale, &e) == 0.5f, "dir_bone_fusion_forward: g_scale must be a power of two");
+        DIR_LAUNCH(bone_fuse_x3_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    } else if (p->exact_f32) DIR_LAUNCH(bone_fuse_f32_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
     else DIR_LAUNCH(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
     stamps_end("bone_fuse", fa.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_forward");

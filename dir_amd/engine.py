@@ -885,7 +885,8 @@ class StageOp(object):
         self.bone_fusion = None
         if dtype == torch.bfloat16 or _packing_arith() is not None:
             # factorised bone fusion (dir_bone_fusion_forward): w_g[tap][hb][c][n] = weight[n, hb*64+c, ky, kx]; bf16 mode: rounded to
-            # bf16, bf16 matrix cores; f16x3 parity mode: unrounded, everything on the exact fp32 matrix cores (exact_f32 = 1)
+            # bf16, bf16 matrix cores; f16 arithmetic modes: unrounded fp32 operands (exact_f32 = 1), on the exact fp32 matrix cores until
+            # DirEngine.calibrate has measured G (g_scale = 0), in split precision on the f16 matrix cores afterwards
             exact = dtype == torch.float32
             w = sd[p + '.fusion.0.weight'].detach()
             w = w.float() if exact else w.to(torch.bfloat16).float()                          # [256, 2560, 3, 3]
@@ -1083,6 +1084,10 @@ class DirEngine(object):
         vis = torch.empty(B, 1280, S, S, device=dev, dtype=F32) if want_vis else None
         if factorised:
             main.wait_stream(side)
+            if self.arith is not None and getattr(_TLS, 'calibrating', False):
+                # split-precision fusion (dir_bone_fusion_params.g_scale): the largest |G| of this batch lands in [2^9, 2^10) of the f16 range
+                amax = float(scratch.view(F32)[:B * 9 * 40 * 256 * 2].abs().max())
+                st.bone_fusion.g_scale = 2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0
             fused = torch.empty(B, S, S, 256, device=dev, dtype=self.dtype)
             _ann('bone_fusion', 2.0 * B * S * S * 256 * 720, (B * 9 * 80 * 256 + B * S * S * 256) * (4 if self.dtype == F32 else 2) + B * 42 * 2 * 4,
                  'B=%d S=%d factorised bone_proj + 3x3 fusion conv (K=720)' % (B, S))

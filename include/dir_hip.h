@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 27
+#define DIR_ABI_VERSION 28
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -532,6 +532,9 @@ typedef struct dir_bone_fusion_params {
     int32_t exact_f32;  /* 0: bf16 operands (w_g rounded to bf16 by the caller, G and Wgt rounded to bf16, y bf16) -- the throughput mode;
                            1: everything fp32 on the exact fp32 matrix cores (w_g unrounded, y NHWC fp32) -- the parity modes: differs from
                            bone_proj + conv3x3 only by the association of the sum (fp32 rounding noise)                                   */
+    float g_scale;      /* exact_f32 only.  0: the exact fp32 matrix cores.  A power of two > 0: split precision on the f16 matrix cores (the
+                           arithmetic of DIR_DT_F16X3: hi*hi + lo*hi + hi*lo per product, ~2^-22) -- G is multiplied by g_scale before its f16
+                           hi / lo split (the largest |G| belongs near 2^9 .. 2^10: DirEngine.calibrate; values saturate, never inf / nan)      */
 } dir_bone_fusion_params;
 size_t dir_bone_fusion_scratch_bytes(int B);
 int dir_bone_fusion_prepare(const dir_bone_fusion_params* params_host, const float* emb, void* scratch, int B, void* stream);

@@ -327,6 +327,21 @@ def test_bone_fusion_exact_fp32_vs_oracle(golden, S, dist, B):
     y2 = Fn.conv2d_nhwc(bone, dw.permute(0, 2, 3, 1).contiguous(), 1, 1, scale=dsc, shift=dsh, relu=True).cpu().numpy().transpose(0, 3, 1, 2)
     print('   materialised exact-fp32 conv: %.2e' % (maxabs(y2, ref) / sc))
     assert maxabs(got, ref) <= 2.0 * maxabs(y2, ref) + 1e-6 * sc
+    # split precision on the f16 matrix cores (g_scale > 0): the same distance from float64 as the exact kernel
+    import math
+    amax = float(scratch.view(torch.float32)[:B * 9 * 40 * 256 * 2].abs().max())
+    P.g_scale = 2.0 ** (10 - math.frexp(amax)[1])
+    y3 = torch.full((B, S, S, 320), 7.0, device='cuda')
+    _capi.check(L.dir_bone_fusion_forward(P, _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(scratch), _capi.ptr(y3),
+                                          B, S, float(dist), 320, 32, 1, _capi.stream_ptr()), 'bone_fusion')
+    torch.cuda.synchronize()
+    got3 = y3[..., 32:288].cpu().numpy().transpose(0, 3, 1, 2)
+    print('   split-precision factorised fusion (g_scale 2^%d): %.2e' % (math.frexp(P.g_scale)[1] - 1, maxabs(got3, ref) / sc))
+    assert maxabs(got3, ref) <= 5e-6 * sc, (maxabs(got3, ref), sc)
+    assert float(y3[..., :32].min()) == 7.0 and float(y3[..., 288:].max()) == 7.0
+    P.g_scale = 3.0                                                                # not a power of two
+    assert L.dir_bone_fusion_forward(P, _capi.ptr(duv), _capi.ptr(duvr), _capi.ptr(scratch), _capi.ptr(y3), B, S, float(dist), 320, 32, 1,
+                                     _capi.stream_ptr()) != 0
 
 
 def test_bone_fusion_rejects_bad_arguments():
