@@ -138,23 +138,19 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
     auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
     stamp();
 
-    // ---- G_tap loader: word (hb, n) -> LDS [n][hb*2 .. hb*2+1]; consecutive threads read consecutive n (coalesced)
-    const unsigned* gsrc = a.g + ((long long)b * NTAP * 40) * NCOUT + n0;
+    // ---- G_tap loader: word (hb, n) -> LDS [n][hb*2 .. hb*2+1].  A wave covers 16 consecutive n x 2 hb x 2 (64-byte global segments); in
+    //      LDS (rows 44 dwords apart) that is at most two lanes per bank for a ds_write_b32 -- free -- where one row per lane was 8-way
+    const int gn = 16 * ((tid >> 5) & 7) + (tid & 15), ghb = ((tid >> 8) << 1) | ((tid >> 4) & 1);      // word k: n = gn, hb = 4 k + ghb
+    const unsigned* gsrc = a.g + ((long long)b * NTAP * 40) * NCOUT + n0 + gn;
     unsigned greg[GW];
     auto g_load = [&](int tap) {
 #pragma unroll
-        for (int k = 0; k < GW; ++k) {
-            const int w = tid + NT * k, hb = w / BN, n = w - hb * BN;
-            greg[k] = gsrc[((long long)tap * 40 + hb) * NCOUT + n];
-        }
+        for (int k = 0; k < GW; ++k) greg[k] = gsrc[((long long)tap * 40 + 4 * k + ghb) * NCOUT];
     };
     auto g_store = [&](int buf) {
-        char* gb = smem + P_BYTES + buf * G_BYTES;
+        char* gb = smem + P_BYTES + buf * G_BYTES + gn * PITCH + ghb * 4;
 #pragma unroll
-        for (int k = 0; k < GW; ++k) {
-            const int w = tid + NT * k, hb = w / BN, n = w - hb * BN;
-            *reinterpret_cast<unsigned*>(gb + n * PITCH + hb * 4) = greg[k];
-        }
+        for (int k = 0; k < GW; ++k) *reinterpret_cast<unsigned*>(gb + 16 * k) = greg[k];
     };
     g_load(0);
 
@@ -178,8 +174,11 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
         sb[0] = uv[2 * pa]; sb[1] = uv[2 * pa + 1]; sb[2] = uv[2 * ch]; sb[3] = uv[2 * ch + 1]; sb[4] = dx; sb[5] = dy;
     }
     __syncthreads();
-    for (int i = tid; i < a.npr * 40; i += NT) {
-        const int hb = convk::div_magic(i, a.mg_npr, a.sh_npr), prow = i - hb * a.npr;
+    const int pr8 = (a.npr + 7) >> 3;
+    for (int i = tid; i < pr8 * 320; i += NT) {                      // i = ((hq * pr8 + rg) * 4 + c) * 8 + r: patch row 8 rg + r, hand-bone 4 hq + c:
+        const int rest = i >> 5, hq = convk::div_magic(rest, a.mg_pr8, a.sh_pr8), rg = rest - hq * pr8;      // 32 distinct LDS banks per 32 lanes
+        const int prow = 8 * rg + (i & 7), hb = 4 * hq + ((i >> 3) & 3);
+        if (prow >= a.npr) continue;
         const int py = convk::div_magic(prow, a.mg_pw, a.sh_pw), px = prow - py * a.PW;
         const int iy = y0 + py - 1, ix = px - 1;                      // 3x3, pad 1
         unsigned word = 0;
