@@ -26,12 +26,15 @@ struct GemmArgs {
     long long sA, sB, sC;
     int kchunk; float* part;        // split-K (dir_gemm_f32_splitk): blockIdx.z = K chunk, raw partial tiles to part [chunk][M][N]
 };
-constexpr int GT = 64, GK = 16, GLD = GK + 1;      // 64 x 64 tile, K step 16; LDS rows padded (17 floats: conflict-free column reads)
+constexpr int GT = 64, GK = 16, GLD = GK + 1;      // 64 x 64 tile, K step 16 (the weight-gradient kernels below); LDS rows padded (17 floats)
+constexpr int MK = 32, MLD = MK + 1;               // K step of gemm_f32_kernel
 
 // 256 threads = 4 waves; wave w owns rows 16w .. 16w+15 of the tile and all 64 columns (4 accumulators of 16x16).
-// A tile [64][16] (row m, k) and B tile stored transposed [64][16] (column n, k): both MFMA operands read along k.
+// A tile [64][32] (row m, k) and B tile stored transposed [64][32] (column n, k): both MFMA operands read along k.  The operands of step
+// k + 1 are requested (unconditional loads from clamped addresses, masked when stored: 16 loads in flight per thread instead of 16
+// serialised conditional ones) before the 32 MFMAs of step k; the k order of the MFMAs is that of the first version (bit-identical sums).
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
-    __shared__ float s_a[GT * GLD], s_b[GT * GLD];
+    __shared__ float s_a[GT * MLD], s_b[GT * MLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
     const bool split = a.part != nullptr;
@@ -43,31 +46,51 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lk = lane >> 4;
     const int kbeg = split ? blockIdx.z * a.kchunk : 0, kend = split ? min(a.K, kbeg + a.kchunk) : a.K;
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        // stage: 64 x 16 elements of each operand, 4 per thread; the faster-varying thread index follows the contiguous dimension
+    // stage: 64 x 32 elements of each operand, 8 per thread; the faster-varying thread index follows the contiguous dimension
+    float ra[8], rb[8];
+    unsigned oka = 0, okb = 0;
+    auto gload = [&](int k0) {
+        oka = okb = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
             int r, k;
-            if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 15; r = e >> 4; }          // A[m][k] (ta = 0) or A[k][m] (ta = 1)
+            if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 31; r = e >> 5; }          // A[m][k] (ta = 0) or A[k][m] (ta = 1)
             const int m = m0 + r, kk = k0 + k;
-            float v = 0.f;
-            if (m < a.M && kk < kend) v = a.ta ? A[(long long)kk * a.lda + m] : A[(long long)m * a.lda + kk];
-            s_a[r * GLD + k] = v;
+            oka |= (m < a.M && kk < kend ? 1u : 0u) << i;
+            const int mc = min(m, a.M - 1), kc = min(kk, kend - 1);
+            ra[i] = a.ta ? A[(long long)kc * a.lda + mc] : A[(long long)mc * a.lda + kc];
             int c, k2;
-            if (a.tb) { k2 = e & 15; c = e >> 4; } else { c = e & 63; k2 = e >> 6; }        // B[k][n] (tb = 0) or B[n][k] (tb = 1)
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 63; k2 = e >> 6; }        // B[k][n] (tb = 0) or B[n][k] (tb = 1)
             const int n = n0 + c, kb = k0 + k2;
-            float w = 0.f;
-            if (n < a.N && kb < kend) w = a.tb ? B[(long long)n * a.ldb + kb] : B[(long long)kb * a.ldb + n];
-            s_b[c * GLD + k2] = w;
+            okb |= (n < a.N && kb < kend ? 1u : 0u) << i;
+            const int nc = min(n, a.N - 1), kbc = min(kb, kend - 1);
+            rb[i] = a.tb ? B[(long long)nc * a.ldb + kbc] : B[(long long)kbc * a.ldb + nc];
         }
-        __syncthreads();
+    };
+    auto lstore = [&]() {
 #pragma unroll
-        for (int ks = 0; ks < GK / 4; ++ks) {
-            const float av = s_a[(16 * wave + li) * GLD + 4 * ks + lk];
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int r, k;
+            if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 31; r = e >> 5; }
+            s_a[r * MLD + k] = (oka >> i) & 1u ? ra[i] : 0.f;
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 63; k2 = e >> 6; }
+            s_b[c * MLD + k2] = (okb >> i) & 1u ? rb[i] : 0.f;
+        }
+    };
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += MK) {
+        lstore();
+        __syncthreads();
+        gload(min(k0 + MK, kend - 1));                   // always issued (past the end: clamped re-reads that are never stored)
+#pragma unroll
+        for (int ks = 0; ks < MK / 4; ++ks) {
+            const float av = s_a[(16 * wave + li) * MLD + 4 * ks + lk];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float bv = s_b[(16 * j + li) * GLD + 4 * ks + lk];
+                const float bv = s_b[(16 * j + li) * MLD + 4 * ks + lk];
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
             }
         }

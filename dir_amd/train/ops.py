@@ -165,6 +165,16 @@ def gemm_strided(A, B, C, M, N, K, lda, ldb, ldc, ta=False, tb=False, batch=1, s
     _chk(A, B, C, bias)
     d = GemmDesc(M, N, K, lda, ldb, ldc, int(ta), int(tb), int(accumulate), batch, sa, sb, sc)
     p = lambda t, off: Ct.c_void_p(t.data_ptr() + 4 * off)  # noqa: E731
+    if _capi.PROFILE is not None:
+        _capi.annotate(family='gemm', flops=2.0 * batch * M * N * K, bytes=4.0 * batch * (M * K + K * N + M * N),
+                       shape='gemm_strided M=%d N=%d K=%d batch=%d ta=%d tb=%d' % (M, N, K, batch, ta, tb))
+    if batch == 1 and K >= 512 and ((M + 63) // 64) * ((N + 63) // 64) <= 32:
+        # a long reduction into a small output (the regressors' Linear layers over 1344 / 2688 inputs): K chunks on separate workgroups
+        n = _capi.lib().dir_gemm_f32_splitk_workspace_bytes(d)
+        ws = torch.empty(n // 4, device=A.device)
+        _capi.check(_capi.lib().dir_gemm_f32_splitk(d, p(A, a_off), p(B, b_off), _capi.ptr(bias), p(C, c_off), _capi.ptr(ws), n, _capi.stream_ptr()),
+                    'dir_gemm_f32_splitk')
+        return C
     _capi.check(_capi.lib().dir_gemm_f32(d, p(A, a_off), p(B, b_off), _capi.ptr(bias), p(C, c_off), _capi.stream_ptr()), 'dir_gemm_f32')
     return C
 
