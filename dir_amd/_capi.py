@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 28          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 29          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -173,7 +173,7 @@ _SIGNATURES = {
     'dir_attention_forward': (C.c_int, [_p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
-    'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, C.c_longlong, _p]),
+    'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
     'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_relu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),
     'dir_relu_backward': (C.c_int, [_p, _p, _p, C.c_longlong, _p]),

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(AttnArgs a) {
 // the BatchNorm output as every kernel here forms it (the ReLU mask of the backward pass re-computes exactly this value from x)
 __device__ __forceinline__ float bn_value(float x, float mu, float rs, float g, float be) { return fmaf((x - mu) * rs, g, be); }
 __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
-                                                          float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum, int relu) {
+                                                          float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum, int relu, const float* res) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
@@ -306,7 +306,11 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* x, const
     for (int r = 0; r < R; ++r) { const float d = x[(long long)r * ld + c] - mu; q = fmaf(d, d, q); }
     const float var = q / R, rs = 1.f / sqrtf(var + eps);
     const float g = w ? w[c] : 1.f, be = b ? b[c] : 0.f;
-    for (int r = 0; r < R; ++r) { const float v = bn_value(x[(long long)r * ld + c], mu, rs, g, be); y[(long long)r * ld + c] = relu ? fmaxf(v, 0.f) : v; }
+    for (int r = 0; r < R; ++r) {
+        float v = bn_value(x[(long long)r * ld + c], mu, rs, g, be);
+        if (res) v += res[(long long)r * ld + c];
+        y[(long long)r * ld + c] = relu ? fmaxf(v, 0.f) : v;
+    }
     save_mean[c] = mu; save_rstd[c] = rs;
     if (running_mean) {       // torch: running = (1 - momentum) running + momentum stat, with the UNBIASED variance
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
@@ -435,12 +439,13 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* p, 
     }
 }
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* x, const float* w, const float* b, const float* mu, const float* rs, float* y,
-                                                          long long n, int C, int ld, int relu) {
+                                                          long long n, int C, int ld, int relu, const float* res) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int c = (int)(i % C);
     const long long o = (i / C) * ld + c;
-    const float v = bn_value(x[o], mu[c], rs[c], w ? w[c] : 1.f, b ? b[c] : 0.f);
+    float v = bn_value(x[o], mu[c], rs[c], w ? w[c] : 1.f, b ? b[c] : 0.f);
+    if (res) v += res[o];
     y[o] = relu ? fmaxf(v, 0.f) : v;
 }
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* gy, const float* x, const float* w, const float* b, const float* mu, const float* rs,
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, 
 }
 // one thread = 4 channels of 4 rows
 __global__ __launch_bounds__(256) void bn_apply_fwd4_kernel(const float* x, const float* w, const float* b, const float* mu, const float* rs, float* y,
-                                                           int R, int C, int ld, int relu) {
+                                                           int R, int C, int ld, int relu, const float* res) {
     const int cq = C >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(i % cq) * 4;
@@ -535,6 +540,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd4_kernel(const float* x, cons
         const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
         float4 o = make_float4(bn_value(v.x, m.x, k.x, g.x, be.x), bn_value(v.y, m.y, k.y, g.y, be.y), bn_value(v.z, m.z, k.z, g.z, be.z),
                                bn_value(v.w, m.w, k.w, g.w, be.w));
+        if (res) { const float4 q = *reinterpret_cast<const float4*>(res + r * ld + c); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
         *reinterpret_cast<float4*>(y + r * ld + c) = o;
     }
@@ -1064,26 +1070,26 @@ static bool bn_vec4(int C, int ld, std::initializer_list<const void*> ps) {
     return true;
 }
 extern "C" int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
-                                    float* running_var, int R, int C, int ld, float eps, float momentum, int relu, float* workspace,
-                                    long long workspace_bytes, void* stream) {
+                                    float* running_var, int R, int C, int ld, float eps, float momentum, int relu, const float* residual,
+                                    float* workspace, long long workspace_bytes, void* stream) {
     using namespace dir;
     DIR_REQUIRE(x && y && save_mean && save_rstd && R > 0 && C > 0 && ld >= C && ((running_mean == nullptr) == (running_var == nullptr)),
                 "dir_bn_train_forward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (R <= BN_SMALL_R) {
-        DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum, relu);
+        DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum, relu, residual);
         return check_launch("dir_bn_train_forward");
     }
     DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_forward: workspace too small (dir_bn_train_workspace_bytes)");
     const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
     float* part = workspace;
     const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
-    if (bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, workspace})) {
+    if (bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, workspace, residual})) {
         float* p2 = part + (long long)chunks * C;
         DIR_LAUNCH(bn_stats4_kernel, pg, dim3(256), 0, s, x, part, p2, R, C, ld);
         DIR_LAUNCH(bn_stats_combine_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)p2, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
         const long long nt = (long long)((R + 3) / 4) * (C / 4);
-        DIR_LAUNCH(bn_apply_fwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, R, C, ld, relu);
+        DIR_LAUNCH(bn_apply_fwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, R, C, ld, relu, residual);
         return check_launch("dir_bn_train_forward");
     }
     launch_bn_partial(pg, s, x, nullptr, nullptr, nullptr, part, nullptr, R, C, ld, 0);
@@ -1091,7 +1097,7 @@ extern "C" int dir_bn_train_forward(const float* x, const float* w, const float*
     launch_bn_partial(pg, s, x, nullptr, save_mean, nullptr, part, nullptr, R, C, ld, 1);
     DIR_LAUNCH(bn_stats_finalize_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)save_mean, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
     const long long n = (long long)R * C;
-    DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld, relu);
+    DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld, relu, residual);
     return check_launch("dir_bn_train_forward");
 }
 extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,

@@ -20,11 +20,12 @@ def _oihw(g):
     return g.permute(0, 3, 1, 2).contiguous()
 
 
-def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5, relu=False):
-    """BatchNorm2d in training mode; relu=True: the nn.ReLU that follows it in the same launch (bn_bwd(..., relu=True) undoes both)"""
+def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5, relu=False, residual=None):
+    """BatchNorm2d in training mode; relu=True: the nn.ReLU that follows it in the same launch (bn_bwd(..., relu=True) undoes both);
+    residual: added before that ReLU (a bottleneck's tail; its backward masks with the saved output: relu_bwd, then bn_bwd(relu=False))"""
     C = x.shape[-1]
     y, st = O.bn_train_fwd(x.view(-1, C), P[pre + 'weight'], P[pre + 'bias'], P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum,
-                           relu=relu)
+                           relu=relu, residual=None if residual is None else residual.contiguous().view(-1, C))
     return y.view(x.shape), (x, st)
 
 
@@ -53,14 +54,12 @@ def bottleneck_forward(P, x, stride=1):
     h = TC.conv_fwd(a1, _ohwi(P['conv2.weight']), None, stride, 1)
     a2, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
     h = TC.conv_fwd(a2, _ohwi(P['conv3.weight']))
-    out, ctx['bn3'] = bn_fwd(P, 'bn3.', h)
     if 'downsample.0.weight' in P:
         idn = TC.conv_fwd(x, _ohwi(P['downsample.0.weight']), None, stride, 0)
         idn, ctx['bnd'] = bn_fwd(P, 'downsample.1.', idn)
     else:
         idn = x
-    O.axpy(out, idn)                                        # out += identity (resnet.py:139)
-    y = O.relu_fwd(out)
+    y, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True, residual=idn)                   # relu(bn3(.) + identity) (resnet.py:136-140), one launch
     ctx.update(a1=a1, a2=a2, y=y)
     return y, ctx
 

@@ -127,15 +127,16 @@ def _bn_ws(R, C, dev):
     return (torch.empty(n // 4, device=dev) if n > 0 else None), n
 
 
-def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=False):
+def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=False, residual=None):
     """BatchNorm in training mode over x [R, C] (channels last).  -> (y, (save_mean, save_rstd)); running statistics updated in place.
     relu=True: y = max(BatchNorm(x), 0) in the same launch (bn_train_bwd(..., b=b, relu=True) re-computes the mask from x)"""
-    _chk(x, w, b, running_mean, running_var)
+    _chk(x, w, b, running_mean, running_var, residual)
+    assert residual is None or residual.shape == x.shape
     R, C = x.shape
     y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
     ws, n = _bn_ws(R, C, x.device)
     _capi.check(_capi.lib().dir_bn_train_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
-                                                 _capi.ptr(running_var), R, C, C, float(eps), float(momentum), int(relu), _capi.ptr(ws), n, _capi.stream_ptr()),
+                                                 _capi.ptr(running_var), R, C, C, float(eps), float(momentum), int(relu), _capi.ptr(residual), _capi.ptr(ws), n, _capi.stream_ptr()),
                 'dir_bn_train_forward')
     # the kernel wrote the running statistics through raw pointers: bump their version counters as an in-place torch op would, so that
     # caches keyed on (data_ptr, _version) -- DIR.engine()'s packed eval weights -- see the update (FlatAdamW.step does the same)

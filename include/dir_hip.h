@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 28
+#define DIR_ABI_VERSION 29
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -158,14 +158,16 @@ int dir_attention_backward(const float* qkv, const float* probs, const float* go
  * variance, y = (x - mean) * rstd * w + b, running statistics updated with `momentum` and the unbiased variance (torch semantics);
  * save_mean / save_rstd [C] feed the backward, which returns g x (optional), g w, g b (optional).  relu != 0 fuses the nn.ReLU that follows
  * the BatchNorm on the path (models/backbone/resnet.py:122-131, hourglass.py:58-66): the forward writes max(y, 0) and the backward masks gy
- * where the re-computed y is not positive (same expression, same mask as the forward's; it therefore also needs b).  R <= 512: one
+ * where the re-computed y is not positive (same expression, same mask as the forward's; it therefore also needs b).  residual (forward,
+ * optional, [R][C] with the same row stride): added before the ReLU -- the tail of a ResNet bottleneck, relu(bn3(.) + identity)
+ * (models/backbone/resnet.py:136-140); the backward of THAT form masks with the saved output instead (dir_relu_backward) and passes relu = 0.  R <= 512: one
  * thread per channel walks the rows in order, no workspace.  Larger R (BatchNorm2d over feature maps): the column reductions are cut
  * into 256-row chunks whose partials are combined in chunk order (deterministic; the variance as sum_k [M2_k + n_k (mean_k - mean)^2] / R,
  * one pass over HBM); workspace of dir_bn_train_workspace_bytes(R, C). */
 long long dir_bn_train_workspace_bytes(int R, int C);
 int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
-                         float* running_var, int R, int C, int ld, float eps, float momentum, int relu, float* workspace,
-                         long long workspace_bytes, void* stream);
+                         float* running_var, int R, int C, int ld, float eps, float momentum, int relu, const float* residual,
+                         float* workspace, long long workspace_bytes, void* stream);
 int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                           float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
 int dir_relu_forward(const float* x, float* y, long long n, void* stream);

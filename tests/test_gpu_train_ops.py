@@ -210,6 +210,11 @@ def test_batchnorm_relu_fused(R, C, relu):
     assert rel(gx, xt.grad.numpy()) < 3e-5 and rel(gw, bn.weight.grad.numpy()) < 1e-5 and rel(gb, bn.bias.grad.numpy()) < 1e-5
     y2, _ = O.bn_train_fwd(dev(x), dev(w), dev(b), relu=relu)
     assert torch.equal(y, y2)
+    # residual added before the ReLU (a bottleneck's tail): relu(bn(x) + res)
+    res = rng.normal(0, 1, (R, C)).astype(np.float32)
+    y3, _ = O.bn_train_fwd(dev(x), dev(w), dev(b), relu=relu, residual=dev(res))
+    want = yt.detach() + torch.from_numpy(res).double()
+    assert rel(y3, (torch.relu(want) if relu else want).numpy()) < 5e-6
 
 
 def test_axpy_multi_matches_per_tensor_axpy():
