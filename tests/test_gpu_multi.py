@@ -2,6 +2,7 @@
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -46,3 +47,22 @@ def test_rccl_allreduce_beside_replayed_forwards(tmp_path):
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'two_rank_rccl_soak.py')
     assert D.spawn_ranks([script, str(out)], 2, timeout=900) == 0
     assert json.loads(out.read_text()) == {'world': 2, 'forward_bit_identical': True, 'allreduce_exact': True}
+
+
+@pytest.mark.gpu
+def test_training_steps_at_config_3_per_gpu_batch(tmp_path):
+    """BASELINE configs[3]'s per-GPU workload as a test (not only a bench line): batch 32, 256x256, the whole network -- training-mode forward,
+    42-term objective, backward, flat bucket, AdamW -- four steps through tools/bench_train.py in its own process: the objective is finite and
+    falls monotonically on the fixed synthetic batch (lr 1e-5), and a step stays far inside the round-2 time (0.088 s)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'bench_train.py'), '32', '3'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('batch 32')][0]
+    times = [float(t) for t in re.search(r'train step ([\d. ]+) s', line).group(1).split()]
+    obj = [float(t) for t in re.search(r'objective on rank 0 ([\d.\- >]+);', line).group(1).split(' -> ')]
+    assert len(obj) == 4 and all(np.isfinite(obj)) and all(b < a for a, b in zip(obj, obj[1:])), obj
+    assert min(times) < 0.08, times
