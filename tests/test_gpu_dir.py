@@ -175,12 +175,17 @@ def test_sparse_fusion_is_bit_identical(dir_state):
         assert torch.equal(a[3]['seg'], b[3]['seg']) and torch.equal(a[3]['proj_feat'], b[3]['proj_feat'])
 
 
-@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32, 'f16x3'])
 def test_engine_odd_batch_sizes(dir_state, dt):
-    """ragged sizes: B = 1, 3, 5 (M tails in every conv, partial P-GCN sample chunks) equal the per-image results."""
+    """ragged sizes: B = 1, 3, 5 (M tails in every conv, partial P-GCN sample chunks) equal the per-image results.  ('f16x3': the
+    split-precision parity mode, operand scales calibrated once -- they are per layer, not per sample.)"""
     sd, img = dir_state
-    eng = DirEngine(sd, dtype=dt)
     five = torch.cat([img, img.flip(0), img[:1] * 0.5], 0).contiguous()
+    if dt == 'f16x3':
+        eng = DirEngine(sd, dtype=torch.float32, arith='f16x3')
+        eng.calibrate(five)
+    else:
+        eng = DirEngine(sd, dtype=dt)
     ref = [eng.forward(five[i:i + 1].contiguous()) for i in range(5)]
     ref_v = torch.cat([r[2]['pd_mesh_xyz_right'].clone() for r in ref], 0)
     ref_seg = torch.cat([r[3]['seg'].clone() for r in ref], 0)
@@ -280,7 +285,7 @@ def test_forward_pipeline_is_bit_identical(dir_state, dt):
             assert torch.equal(o[3]['seg'], seg) and torch.equal(o[3]['proj_feat'], pf)
 
 
-@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, 'f16x3'])
 def test_full_size_batch_64_rows_equal_the_golden_pinned_small_batch(golden, dir_state, dt):
     """BASELINE configs[1] (B = 64), the size the oracle cannot finish in seconds: the two golden images sit at rows 5 and 63 of a
     batch of 62 other images.  Samples are independent (eval-mode BN), so those rows must equal the B = 2 run -- which the golden
@@ -289,7 +294,12 @@ def test_full_size_batch_64_rows_equal_the_golden_pinned_small_batch(golden, dir
     from dir_amd.engine import ForwardPipeline
     sd, img = dir_state
     g = golden('g7_dir')
-    eng = DirEngine(sd, dtype=dt)
+    if dt == 'f16x3':              # the split-precision parity mode (bench.py's parity_mode_f16x3): fp32 tensors, operand scales calibrated once
+        eng = DirEngine(sd, dtype=torch.float32, arith='f16x3')
+        eng.calibrate(img)
+        dt = torch.float32
+    else:
+        eng = DirEngine(sd, dtype=dt)
     small = eng.forward(img)
     torch.cuda.synchronize()
     keys = ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_uv_right', 'pd_offset')
