@@ -37,6 +37,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // switch) marks the residual loads and block-output stores non-temporal so that they do not push the weights out of L2.
 // MEASURED AND REJECTED (r02): 46.6 -> 71.0 us at layer2, 34.7 -> 44.6 us at layer3 -- the tensors a layer reads were written by the
 // previous launch and sit in the 256 MB Infinity Cache; a non-temporal access gives that up.  Off.
+#ifndef DIR_TAIL_RES16
+#define DIR_TAIL_RES16 1
+#endif
 #ifndef DIR_TAIL_NT
 #define DIR_TAIL_NT 0
 #endif
@@ -110,6 +113,21 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
         }
     };
     // ---- residual of a unit in the epilogue-B layout: pixel 32 pb + l32, channels half*512 + 64 wave + 32 cb + 8 q + 4 h .. +4
+#if DIR_TAIL_RES16
+    // fetched as 16-byte chunks -- lane half h takes channels 16 j + 8 h .. + 8 of each 32-channel block -- and turned into the accumulator
+    // layout at the point of use by swapping 8 bytes per chunk with the partner lane (v_permlane32_swap): half the load instructions,
+    // 32 contiguous bytes per pixel row and instruction instead of 16
+    uint4 xr[2][2][2];
+    auto res_fetch = [&](int tile, int half) {
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const bf16_t* rp = a.res + ((long long)tile * TM + 32 * pb + l32) * C4 + half * HC + 64 * wave + 8 * h;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xr[cb][pb][j] = *reinterpret_cast<const uint4*>(rp + 32 * cb + 16 * j);
+        }
+#else
     uint2 xr[2][2][4];
     auto res_fetch = [&](int tile, int half) {
 #pragma unroll
@@ -120,6 +138,7 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xr[cb][pb][q] = NT_LOAD(reinterpret_cast<const uint2*>(rp + 32 * cb + 8 * q));
         }
+#endif
     };
     // ---- weight stream of this wave: fragment f of half hf at wstream[((hf * 8 + wave) * NF + f) * 64 + lane]
     bf16x8 ring[2][GRP];
@@ -217,7 +236,16 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
                                               float v[4] = {fmaf(accb[pb][4 * q], sc.x, sh.x), fmaf(accb[pb][4 * q + 1], sc.y, sh.y),
                                                             fmaf(accb[pb][4 * q + 2], sc.z, sh.z), fmaf(accb[pb][4 * q + 3], sc.w, sh.w)};
                                               float rv[4];
+#if DIR_TAIL_RES16
+                                              {   // (q even, q odd) = swap(lower 8 bytes, upper 8 bytes) of chunk q / 2, dword by dword
+                                                  const uint4 c = xr[cb][pb][q >> 1];
+                                                  const auto sx = __builtin_amdgcn_permlane32_swap(c.x, c.z, false, false);
+                                                  const auto sy = __builtin_amdgcn_permlane32_swap(c.y, c.w, false, false);
+                                                  unpack4(make_uint2(sx[q & 1], sy[q & 1]), rv);
+                                              }
+#else
                                               unpack4(xr[cb][pb][q], rv);
+#endif
 #pragma unroll
                                               for (int e = 0; e < 4; ++e) v[e] += rv[e];
                                               uint2 o;
