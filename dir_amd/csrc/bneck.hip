@@ -22,6 +22,10 @@
 // accounting stays exact and no wait covers more than it needs.
 #include "conv_common.h"
 
+#ifndef DIR_BNECK_RES16
+#define DIR_BNECK_RES16 1      // A/B switch: the residual as 16-byte chunks + v_permlane32_swap (1) or as 8-byte pieces in the accumulator layout (0)
+#endif
+
 namespace dir {
 namespace {
 
@@ -156,7 +160,13 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     // c = tid + 512 i of a half = pixel c >> 5, channel chunk c & 31, i.e. two whole 512-byte pixels per wave instruction.  The
     // residual is read straight into the epilogue-B register layout (pixel 64 mg + 32 j + l32, channels 32 wave + 8 q + 4 h .. +4;
     // 8-byte pieces): measured, the extra LDS round trip + barrier of a coalesced residual costs more than it saves.
+    // Since round 3 as 16-byte chunks (lane half h: channels 16 jj + 8 h .. + 8), swapped into the accumulator layout with
+    // v_permlane32_swap where they are used: half the load instructions (tail.hip, same change).
+#if DIR_BNECK_RES16
+    uint4 xr[2][2][2];
+#else
     uint2 xr[2][2][4];
+#endif
     auto out_ptr = [&](int mg, int i, int rb, int ry0, int rx0) {
         const int c = tid + NTHR * i, P = 64 * mg + (c >> 5);
         return a.out + (((long long)rb * a.H + ry0 + (P >> 4)) * a.W + rx0 + (P & 15)) * 256 + (c & 31) * 8;
@@ -175,9 +185,15 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int P = 64 * mg + 32 * j + l32;
+#if DIR_BNECK_RES16
+                    const bf16_t* rp = a.res + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 256 + 32 * wave + 8 * h;
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) xr[mg][j][jj] = *reinterpret_cast<const uint4*>(rp + 16 * jj);
+#else
                     const bf16_t* rp = a.res + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * 256 + 32 * wave + 4 * h;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xr[mg][j][q] = *reinterpret_cast<const uint2*>(rp + 8 * q);
+#endif
                 }
         }
 
@@ -272,7 +288,14 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                                   fmaf(accb[j][4 * q + 2], sc.z, sh.z), fmaf(accb[j][4 * q + 3], sc.w, sh.w)};
                     if constexpr (HAS_RES) {
                         float rv[4];
+#if DIR_BNECK_RES16
+                        const uint4 c = xr[mg][j][q >> 1];            // (q even, q odd) = swap(lower 8 bytes, upper 8 bytes) with the partner lane
+                        const auto sx = __builtin_amdgcn_permlane32_swap(c.x, c.z, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(c.y, c.w, false, false);
+                        unpack4(make_uint2(sx[q & 1], sy[q & 1]), rv);
+#else
                         unpack4(xr[mg][j][q], rv);
+#endif
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rv[e];
                     }
