@@ -308,17 +308,30 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
                     }
                 } else {
 #pragma unroll
-                    for (int pb = 0; pb < 2; ++pb)
+                    for (int pb = 0; pb < 2; ++pb) {
+                        uint2 o[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const int c0 = 32 * wave + 8 * q + 4 * h;
                             const float4 sc = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + c0);
                             const float4 sh = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + N2 + c0);
-                            uint2 o;
-                            o.x = relu2bf(pack2bf(fmaf(accc32[pb][4 * q], sc.x, sh.x), fmaf(accc32[pb][4 * q + 1], sc.y, sh.y)));
-                            o.y = relu2bf(pack2bf(fmaf(accc32[pb][4 * q + 2], sc.z, sh.z), fmaf(accc32[pb][4 * q + 3], sc.w, sh.w)));
-                            *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TM + 32 * pb + l32) * N2 + c0) = o;
+                            o[q].x = relu2bf(pack2bf(fmaf(accc32[pb][4 * q], sc.x, sh.x), fmaf(accc32[pb][4 * q + 1], sc.y, sh.y)));
+                            o[q].y = relu2bf(pack2bf(fmaf(accc32[pb][4 * q + 2], sc.z, sh.z), fmaf(accc32[pb][4 * q + 3], sc.w, sh.w)));
                         }
+#if DIR_TAIL_RES16
+                        // the residual fetch's swap in reverse: lane half h ends up with channels 16 j + 8 h .. + 8 -- one 16-byte store per j
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const auto dx = __builtin_amdgcn_permlane32_swap(o[2 * j].x, o[2 * j + 1].x, false, false);
+                            const auto dy = __builtin_amdgcn_permlane32_swap(o[2 * j].y, o[2 * j + 1].y, false, false);
+                            *reinterpret_cast<uint4*>(a.y1n + ((long long)t * TM + 32 * pb + l32) * N2 + 32 * wave + 16 * j + 8 * h) = make_uint4(dx[0], dy[0], dx[1], dy[1]);
+                        }
+#else
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TM + 32 * pb + l32) * N2 + 32 * wave + 8 * q + 4 * h) = o[q];
+#endif
+                    }
                 }
             }
             __syncthreads();                             // T is free for the next unit; the next tile's y2 rows are visible
