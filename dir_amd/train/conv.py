@@ -1,9 +1,11 @@
-"""nn.Conv2d in training form on libdir_hip.so: fp32 NHWC forward (dir_conv2d_forward, exact-fp32 matrix cores) and its two gradients.
+"""nn.Conv2d in training form on libdir_hip.so: fp32 NHWC forward (dir_conv2d_forward; split precision f16x3 by default, exact fp32 with
+DIR_TRAIN_ARITH=f32) and its two gradients.
 
     y = conv_fwd(x, w, bias, stride, pad)                      x [B,H,W,Cin], w [Cout,kh,kw,Cin] (pack_conv_weight layout), y [B,Ho,Wo,Cout]
     gx, gw, gb = conv_bwd(x, w, gy, stride, pad, need_gx)      what autograd returns for nn.Conv2d (models/backbone/resnet.py:23-40,
                                                                models/backbone/hourglass.py:14, models/dir.py:58-61,229-232,404-419)
-* weight gradient: dir_conv2d_wgrad_f32 (train_ops.hip), bias gradient: dir_colsum_f32;
+* weight gradient: dir_conv2d_wgrad_f16x3 (wgrad_x3.hip; layers with >= 32 channels on both sides) or dir_conv2d_wgrad_f32 (train_ops.hip: the
+  3-channel stem, the 1- / 3- / 6-channel heads, DIR_TRAIN_WGRAD_ARITH=f32), bias gradient: dir_colsum_f32;
 * data gradient: the transposed convolution is the SAME forward kernel run on gy with the flipped, (Cin <-> Cout)-transposed weights
   and padding k - 1 - pad; for stride 2, gy is first spread onto the even positions of a zero [2 Ho, 2 Wo] map.  The flips, the zero
   insertion and the channel padding to the kernel's 32-channel granularity are copies -- no arithmetic happens outside the library.

@@ -8,8 +8,9 @@ MANO / regressor backward.  fp32, NHWC, batch-statistics BatchNorm everywhere (r
     grads = backward(P, ctx, outs, target, meta_info, faces, mano)     {parameter key -> gradient of sum(loss)}
 
 The reference's `.detach()` cuts (models/dir.py:447-453,463-469) are structural here: a stage receives the previous stage's outputs as
-plain inputs.  This path is correctness-first (an exact-fp32 64x64-tile GEMM for the weight gradients, the inference convolution kernel
-in its fp32 mode for everything else); it is not on the benchmarked path.
+plain inputs.  Arithmetic (round 3): fp32 tensors; the convolutions' forward, data gradient and weight gradient in split precision on the
+f16 matrix cores (dir_amd/train/conv.py: DIR_TRAIN_ARITH / DIR_TRAIN_WGRAD_ARITH = f16x3, 'f32' switches the exact kernels back), everything
+else exact fp32; BatchNorm + ReLU (+ the bottleneck's residual) one launch each way.  bench.py times a step as its train_step sub-record.
 """
 import torch
 
