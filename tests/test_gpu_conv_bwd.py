@@ -92,3 +92,25 @@ def test_split_precision_weight_gradient_vs_float64(case):
     finally:
         TC.WGRAD_ARITH = saved
     assert (acc - 2 * g3).abs().max() <= 1e-6 * g3.abs().max()
+
+
+def test_split_precision_weight_gradient_rejects_bad_arguments():
+    """dir_conv2d_wgrad_f16x3: scales that are not powers of two, channel counts that are not multiples of 4 and a short workspace are
+    argument errors (DIR_E_ARG with a message), never a launch"""
+    from dir_amd import _capi
+    L = _capi.lib()
+    x = torch.randn(2, 8, 8, 64, device='cuda')
+    gy = torch.randn(2, 8, 8, 64, device='cuda')
+    gw = torch.empty(64, 1, 1, 64, device='cuda')
+    d = _capi.ConvDesc(2, 8, 8, 64, 64, 0, 64, 64, 0, 0, 0, 1, 1, 1, 0, _capi.DT_F32, _capi.DT_F32, 0)
+    ws = torch.empty(max(L.dir_conv2d_wgrad_f16x3_workspace_bytes(d), 4) // 4, device='cuda')
+
+    def call(desc, sx, sg, nbytes, acc=0):
+        return L.dir_conv2d_wgrad_f16x3(desc, _capi.ptr(x), _capi.ptr(gy), _capi.ptr(gw), acc, _capi.ptr(ws), nbytes, sx, sg, _capi.stream_ptr())
+    assert call(d, 1.0, 1.0, ws.numel() * 4) == 0
+    assert call(d, 3.0, 1.0, ws.numel() * 4) != 0 and b'powers of two' in L.dir_last_error()
+    assert call(d, 1.0, 0.0, ws.numel() * 4) != 0
+    assert call(d, 1.0, 1.0, 0, acc=1) != 0 and b'workspace' in L.dir_last_error()
+    d2 = _capi.ConvDesc(2, 8, 8, 62, 64, 0, 64, 64, 0, 0, 0, 1, 1, 1, 0, _capi.DT_F32, _capi.DT_F32, 0)
+    assert call(d2, 1.0, 1.0, ws.numel() * 4) != 0 and b'multiples of 4' in L.dir_last_error()
+    torch.cuda.synchronize()
