@@ -65,6 +65,7 @@ struct StemArgs {
     const void* img; const bf16x8* w; const float* scale; const float* shift; bf16_t* y;
     int B, H, W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, ntiles;
     NormArgs nm;
+    long long* stamps;      // DIR_STAMPS=stem (tuning aid, else NULL): workgroup 0, one stamp per phase of its first tiles
 };
 
 template <bool U8>
@@ -75,6 +76,9 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
     __shared__ __attribute__((aligned(16))) float s_ss[128];
     __shared__ bf16_t s_lut[U8 ? 3 * 256 : 1];          // uint8 input: bf16(norm_px(v, mean[c], std[c])) per (c, v)
     const int g = lane >> 4, li = lane & 15;
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
     if (tid < 64) { s_ss[tid] = a.scale[tid]; s_ss[64 + tid] = a.shift[tid]; }
     if constexpr (U8) {
 #pragma unroll
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
     if (t < tend) stage();
     __syncthreads();
     if (t + tstep < tend) fetch(t + tstep);
+    stamp();
 
     for (; t < tend; t += tstep) {
         int b, py0, px0;
@@ -205,9 +210,11 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
             }
         }
         __syncthreads();                                          // s_conv complete, s_patch free
+        stamp();
 
         // ---- next tile's patch -> LDS: its loads were issued a whole MFMA phase ago, the previous stores even earlier
         if (t + tstep < tend) stage();
+        stamp();
 
         // ---- 3x3 / s2 max-pool of the tile, 8 channels (16 bytes) per item
         for (int it = tid; it < TP * TP * 8; it += NTHR) {
@@ -224,8 +231,10 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
                 }
             *reinterpret_cast<uint4*>(a.y + ((((long long)b * a.Hp + py) * a.Wp + px) * 64 + cg * 8)) = o;
         }
+        stamp();
         if (t + 2 * tstep < tend) fetch(t + 2 * tstep);   // lands during the next tile's MFMA phase
         __syncthreads();                                          // next patch complete, s_conv free
+        stamp();
     }
 }
 
@@ -263,7 +272,9 @@ extern "C" int dir_stem_pool_forward(const void* img, int img_dtype, const float
     }
     const int grid = (int)(nt < 2ll * num_cu ? nt : 2ll * num_cu);
     hipStream_t s = (hipStream_t)stream;
+    a.stamps = dir::stamps_begin("stem");
     if (img_dtype == DIR_DT_U8) DIR_LAUNCH((stem_pool_kernel<true>), dim3(grid), dim3(NTHR), 0, s, a);
     else DIR_LAUNCH((stem_pool_kernel<false>), dim3(grid), dim3(NTHR), 0, s, a);
+    dir::stamps_end("stem", a.stamps, s);
     return check_launch("dir_stem_pool_forward");
 }
