@@ -59,13 +59,13 @@ for name, H, Ci, Co, k, s, res, cnt, pre in L:
     sc, sh = torch.ones(Co, device='cuda'), torch.zeros(Co, device='cuda')
     p = k // 2
     for i in range(3):
-        F.conv2d_nhwc(xs[i % NROT], w, s, p, scale=sc, shift=sh, relu=True, residual=rs[i % NROT], out=ys[i % NROT])
+        F.conv2d_nhwc(xs[i % NROT], w, s, p, scale=sc, shift=sh, relu=True, residual=rs[i % NROT], out=ys[i % NROT], variant=int(os.environ.get("VARIANT", 0)))
     torch.cuda.synchronize()
     n = 12
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(n):
-        F.conv2d_nhwc(xs[i % NROT], w, s, p, scale=sc, shift=sh, relu=True, residual=rs[i % NROT], out=ys[i % NROT])
+        F.conv2d_nhwc(xs[i % NROT], w, s, p, scale=sc, shift=sh, relu=True, residual=rs[i % NROT], out=ys[i % NROT], variant=int(os.environ.get("VARIANT", 0)))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
