@@ -532,6 +532,36 @@ __global__ __launch_bounds__(256) void bone_vis_kernel(BoneArgs a) {
     }
     __syncthreads();
     float* out = a.vis + ((long long)b * 1280 + bone * 64) * hw;
+    const int Q = hw >> 2;                                            // pixel quads per plane
+    if (Q <= 256 && 256 % Q == 0) {
+        // S = 16 / 32: a thread owns ONE pixel quad for every channel it visits: its eight (mask, wa, wb) values live in registers and
+        // the channel loop reads only the four broadcast feature values per plane from LDS (was ~10 LDS reads per output element); the
+        // arithmetic -- two products and a sum per hand with contraction off, masked pixels exactly 0 -- is that of the loop below
+        const int p4 = (tid % Q) * 4, cstep = 256 / Q;
+        float wa[2][4], wb[2][4];
+        bool in[2][4];
+#pragma unroll
+        for (int hand = 0; hand < 2; ++hand)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wa[hand][q] = s_w[(hand * 2) * hw + p4 + q];
+                wb[hand][q] = s_w[(hand * 2 + 1) * hw + p4 + q];
+                in[hand][q] = s_in[hand * hw + p4 + q] != 0;
+            }
+        for (int c = tid / Q; c < 64; c += cstep) {
+            const float f00 = s_f[0][0][c], f01 = s_f[0][1][c], f10 = s_f[1][0][c], f11 = s_f[1][1][c];
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma clang fp contract(off)
+                const float v0 = in[0][q] ? f00 * wa[0][q] + f01 * wb[0][q] : 0.f;
+                const float v1 = in[1][q] ? f10 * wa[1][q] + f11 * wb[1][q] : 0.f;
+                o[q] = v0 + v1;
+            }
+            Vec<float>::store(out + (long long)c * hw + p4, o);
+        }
+        return;
+    }
     for (int i = tid; i < 64 * hw / 4; i += 256) {
         const int c = i / (hw / 4), p4 = (i - c * (hw / 4)) * 4;
         float o[4];
