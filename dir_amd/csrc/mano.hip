@@ -9,6 +9,8 @@
 // per call there, one launch here.
 #include "dir_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int NV = 778, NV3 = 2334, NV3P = 2336, NJ = 16, NTHR = 640;   // table rows padded to 2336 floats (16-B aligned)
@@ -43,56 +45,77 @@ constexpr int PART_V = 196, PTHR = 256;   // >= PART_V threads: the skinning loo
 
 // THREADS = NTHR (one part) or PTHR (four vertex parts): the launch bound sets the register budget -- under the 640-thread bound the
 // 4-part launches (256 threads) were compiled down to 168 VGPRs and spilled (scratch traffic inside the skinning loop)
-template <int THREADS>
+// SPW = samples per workgroup (same hand, same vertex part): every table value (shape / pose blend shapes, skinning weights) is loaded
+// ONCE and applied to SPW samples -- at B = 64 the launch is bound by the L2 -> CU traffic of the per-workgroup table streams (512
+// workgroups x 315 KB), which SPW divides; the per-sample arithmetic and its order are unchanged (bit-identical results).
+template <int THREADS, int SPW>
 __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
     const int combos = args.hands * args.parts, rep = 8 / combos;      // combos in {1, 2, 4, 8}
     const int xcd = blockIdx.x & 7, combo = xcd / rep;
-    const int b = (blockIdx.x >> 3) * rep + (xcd - combo * rep);
-    if (b >= args.B) return;
+    const int bg = (blockIdx.x >> 3) * rep + (xcd - combo * rep);      // sample group
+    if (bg * SPW >= args.B) return;
     const int hand = combo / args.parts, part = combo - hand * args.parts;
     const ManoHand& a = args.h[hand];
     const int nthr = blockDim.x;
     const int v_lo = args.parts > 1 ? part * PART_V : 0;
     const int v_hi = args.parts > 1 ? min(NV, v_lo + PART_V) : NV;
     const int f_lo = 3 * v_lo, f_hi = 3 * v_hi;          // float range [f_lo, f_hi) of the flattened vertex array
-    __shared__ float s_v[NV3P];         // v_shaped -> v_posed -> skinned vertices (in place)
-    __shared__ float s_pose[51], s_beta[10], s_cam[3];
-    __shared__ float s_full[45];        // axis-angle of the 15 articulated joints
-    __shared__ float s_rot[15 * 9];     // rotation matrices (row major)
-    __shared__ float s_pm[135];         // pose map = R - I
-    __shared__ float s_root[9];
-    __shared__ float s_J[NJ * 3];
-    __shared__ float s_A[NJ * 12];      // global transforms (top 3 rows), th_j joint order
-    __shared__ __attribute__((aligned(16))) float s_A2[NJ * 12];     // with the rest-pose joint removed: A' = A - pack(A.[J;0])
-    __shared__ float s_jtr[21 * 3];
-    __shared__ float s_c[3];
+    __shared__ float s_v[SPW][NV3P];         // v_shaped -> v_posed -> skinned vertices (in place)
+    __shared__ float s_pose[SPW][51], s_beta[SPW][10], s_cam[SPW][3];
+    __shared__ float s_full[SPW][45];        // axis-angle of the 15 articulated joints
+    __shared__ float s_rot[SPW][15 * 9];     // rotation matrices (row major)
+    __shared__ float s_pm[SPW][135];         // pose map = R - I
+    __shared__ float s_root[SPW][9];
+    __shared__ float s_J[SPW][NJ * 3];
+    __shared__ float s_A[SPW][NJ * 12];      // global transforms (top 3 rows), th_j joint order
+    __shared__ __attribute__((aligned(16))) float s_A2[SPW][NJ * 12];     // with the rest-pose joint removed: A' = A - pack(A.[J;0])
+    __shared__ float s_jtr[SPW][21 * 3];
+    __shared__ float s_c[SPW][3];
 
     const int tid = threadIdx.x;
     int nstamp = 0;
     auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && tid == 0) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
     stamp();
+    // sample s of the group: index bs(s); a group's tail beyond B re-computes sample B - 1 and writes nothing
+    auto bs = [&](int s_) { return min(bg * SPW + s_, args.B - 1); };
+    auto live = [&](int s_) { return bg * SPW + s_ < args.B; };
 
-    if (tid < 51) s_pose[tid] = a.pose[(size_t)b * a.pose_stride + tid];
-    if (tid >= 64 && tid < 74) s_beta[tid - 64] = a.betas[(size_t)b * a.betas_stride + tid - 64];
-    if (tid >= 128 && tid < 131) s_cam[tid - 128] = a.cam ? a.cam[(size_t)b * a.cam_stride + tid - 128] : 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < SPW; ++s_) {
+        const size_t b = (size_t)bs(s_);
+        if (tid < 51) s_pose[s_][tid] = a.pose[b * a.pose_stride + tid];
+        if (tid >= 64 && tid < 74) s_beta[s_][tid - 64] = a.betas[b * a.betas_stride + tid - 64];
+        if (tid >= 128 && tid < 131) s_cam[s_][tid - 128] = a.cam ? a.cam[b * a.cam_stride + tid - 128] : 0.f;
+    }
     __syncthreads(); stamp();
 
     // ---- PCA coefficients -> axis angle (manolayer.py:131-144) ; shape blend (manolayer.py:180-182)
-    if (tid < 45) {
-        float acc = 0.f;
-        for (int k = 0; k < 45; ++k) acc = fmaf(s_pose[6 + k], a.t.comps[k * 45 + tid], acc);
-        s_full[tid] = a.t.hands_mean[tid] + acc;
-    }
-    for (int i = f_lo + tid; i < f_hi; i += nthr) {
-        float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc = fmaf(a.t.shapedirs_t[k * NV3P + i], s_beta[k], acc);
-        s_v[i] = acc + a.t.v_template[i];
+    for (int s_ = 0; s_ < SPW; ++s_)
+        if (tid < 45) {
+            float acc = 0.f;
+            for (int k = 0; k < 45; ++k) acc = fmaf(s_pose[s_][6 + k], a.t.comps[k * 45 + tid], acc);
+            s_full[s_][tid] = a.t.hands_mean[tid] + acc;
+        }
+    for (int i = f_lo + tid; i < f_hi; i += nthr) {
+        float acc[SPW];
+#pragma unroll
+        for (int s_ = 0; s_ < SPW; ++s_) acc[s_] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            const float sd = a.t.shapedirs_t[k * NV3P + i];
+#pragma unroll
+            for (int s_ = 0; s_ < SPW; ++s_) acc[s_] = fmaf(sd, s_beta[s_][k], acc[s_]);
+        }
+        const float vt = a.t.v_template[i];
+#pragma unroll
+        for (int s_ = 0; s_ < SPW; ++s_) s_v[s_][i] = acc[s_] + vt;
     }
-    if (tid == 64) {
+    if (tid >= 64 && tid < 64 + SPW) {
         // robust 6D -> rotation (rot6d.py:26-51): columns (x', y', z)
 #pragma clang fp contract(off)
-        float x0 = s_pose[0], x1 = s_pose[1], x2 = s_pose[2], y0 = s_pose[3], y1 = s_pose[4], y2 = s_pose[5];
+        const int s_ = tid - 64;
+        float x0 = s_pose[s_][0], x1 = s_pose[s_][1], x2 = s_pose[s_][2], y0 = s_pose[s_][3], y1 = s_pose[s_][4], y2 = s_pose[s_][5];
         normalize3(x0, x1, x2);
         normalize3(y0, y1, y2);
         float m0 = x0 + y0, m1 = x1 + y1, m2 = x2 + y2;
@@ -105,20 +128,22 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
         normalize3(y0, y1, y2);
         float z0 = x1 * y2 - x2 * y1, z1 = x2 * y0 - x0 * y2, z2 = x0 * y1 - x1 * y0;
         normalize3(z0, z1, z2);
-        s_root[0] = x0; s_root[1] = y0; s_root[2] = z0;
-        s_root[3] = x1; s_root[4] = y1; s_root[5] = z1;
-        s_root[6] = x2; s_root[7] = y2; s_root[8] = z2;
-        if (a.flags) {
+        float* R = s_root[s_];
+        R[0] = x0; R[1] = y0; R[2] = z0;
+        R[3] = x1; R[4] = y1; R[5] = z1;
+        R[6] = x2; R[7] = y2; R[8] = z2;
+        if (a.flags && live(s_)) {
             float det = x0 * (y1 * z2 - z1 * y2) - y0 * (x1 * z2 - z1 * x2) + z0 * (x1 * y2 - y1 * x2);
-            a.flags[b] = det < 0.f ? 1 : 0;
+            a.flags[bs(s_)] = det < 0.f ? 1 : 0;
         }
     }
     __syncthreads(); stamp();
 
     // ---- Rodrigues via quaternion (rodrigues_layer.py:43-54, 15-40)
-    if (tid < 15) {
+    if (tid < 15 * SPW) {
 #pragma clang fp contract(off)
-        float vx = s_full[3 * tid], vy = s_full[3 * tid + 1], vz = s_full[3 * tid + 2];
+        const int s_ = tid / 15, jt = tid - 15 * s_;
+        float vx = s_full[s_][3 * jt], vy = s_full[s_][3 * jt + 1], vz = s_full[s_][3 * jt + 2];
         float ex = vx + 1e-8f, ey = vy + 1e-8f, ez = vz + 1e-8f;
         float angle = sqrtf(ex * ex + ey * ey + ez * ez);
         float ax = vx / angle, ay = vy / angle, az = vz / angle;
@@ -129,22 +154,25 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
         w /= qn; x /= qn; y /= qn; z /= qn;
         float w2 = w * w, x2 = x * x, y2 = y * y, z2 = z * z;
         float wx = w * x, wy = w * y, wz = w * z, xy = x * y, xz = x * z, yz = y * z;
-        float* R = s_rot + 9 * tid;
+        float* R = s_rot[s_] + 9 * jt;
         R[0] = w2 + x2 - y2 - z2; R[1] = 2 * xy - 2 * wz;     R[2] = 2 * wy + 2 * xz;
         R[3] = 2 * wz + 2 * xy;   R[4] = w2 - x2 + y2 - z2;   R[5] = 2 * yz - 2 * wx;
         R[6] = 2 * xz - 2 * wy;   R[7] = 2 * wx + 2 * yz;     R[8] = w2 - x2 - y2 + z2;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) s_pm[9 * tid + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        for (int e = 0; e < 9; ++e) s_pm[s_][9 * jt + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
     }
     // ---- joint regression from the shaped template (manolayer.py:183).  J = Jreg (v_template + shapedirs beta) is
     //      linear in beta: j_template = Jreg v_template [16,3] and j_shapedirs = Jreg shapedirs [16,3,10] are folded once
     //      at pack time (fp64), replacing 48 dot products of length 778 per sample by 48 of length 10.
     if (tid >= 128 && tid < 128 + NJ * 3) {
         const int o = tid - 128;
-        float acc = a.t.j_template[o];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc = fmaf(a.t.j_shapedirs[o * 10 + k], s_beta[k], acc);
-        s_J[o] = acc;
+        for (int s_ = 0; s_ < SPW; ++s_) {
+            float acc = a.t.j_template[o];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc = fmaf(a.t.j_shapedirs[o * 10 + k], s_beta[s_][k], acc);
+            s_J[s_][o] = acc;
+        }
     }
     __syncthreads(); stamp();
 
@@ -152,35 +180,45 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
     if (f_lo / 4 + tid < (f_hi + 3) / 4) {
         const int c4 = f_lo / 4 + tid;                    // float4 column (f_lo is a multiple of 12)
         const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + c4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 acc[SPW];
+#pragma unroll
+        for (int s_ = 0; s_ < SPW; ++s_) acc[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 9
         for (int k = 0; k < 135; ++k) {
             const float4 p = pd[k * (NV3P / 4)];
-            const float w = s_pm[k];
-            acc.x = fmaf(p.x, w, acc.x); acc.y = fmaf(p.y, w, acc.y); acc.z = fmaf(p.z, w, acc.z); acc.w = fmaf(p.w, w, acc.w);
+#pragma unroll
+            for (int s_ = 0; s_ < SPW; ++s_) {
+                const float w = s_pm[s_][k];
+                acc[s_].x = fmaf(p.x, w, acc[s_].x); acc[s_].y = fmaf(p.y, w, acc[s_].y);
+                acc[s_].z = fmaf(p.z, w, acc[s_].z); acc[s_].w = fmaf(p.w, w, acc[s_].w);
+            }
         }
         const int i = 4 * c4;
-        s_v[i] += acc.x; s_v[i + 1] += acc.y;
-        if (i + 2 < NV3) { s_v[i + 2] += acc.z; s_v[i + 3] += acc.w; }
+#pragma unroll
+        for (int s_ = 0; s_ < SPW; ++s_) {
+            s_v[s_][i] += acc[s_].x; s_v[s_][i + 1] += acc[s_].y;
+            if (i + 2 < NV3) { s_v[s_][i + 2] += acc[s_].z; s_v[s_][i + 3] += acc[s_].w; }
+        }
     }
     // ---- kinematic chain (manolayer.py:192-229): finger f owns joints 1+3f, 2+3f, 3+3f
-    if (tid < 5) {
+    if (tid < 5 * SPW) {
+        const int s_ = tid / 5, fg = tid - 5 * s_;
         float A[12];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            A[4 * r + 0] = s_root[3 * r + 0]; A[4 * r + 1] = s_root[3 * r + 1]; A[4 * r + 2] = s_root[3 * r + 2];
-            A[4 * r + 3] = s_J[r];
+            A[4 * r + 0] = s_root[s_][3 * r + 0]; A[4 * r + 1] = s_root[s_][3 * r + 1]; A[4 * r + 2] = s_root[s_][3 * r + 2];
+            A[4 * r + 3] = s_J[s_][r];
         }
-        if (tid == 0) {
+        if (fg == 0) {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) s_A[e] = A[e];
+            for (int e = 0; e < 12; ++e) s_A[s_][e] = A[e];
         }
         int parent = 0;
         for (int l = 0; l < 3; ++l) {
-            const int j = 1 + 3 * tid + l;
-            const float* R = s_rot + 9 * (j - 1);
-            const float t0 = s_J[3 * j] - s_J[3 * parent], t1 = s_J[3 * j + 1] - s_J[3 * parent + 1],
-                        t2 = s_J[3 * j + 2] - s_J[3 * parent + 2];
+            const int j = 1 + 3 * fg + l;
+            const float* R = s_rot[s_] + 9 * (j - 1);
+            const float t0 = s_J[s_][3 * j] - s_J[s_][3 * parent], t1 = s_J[s_][3 * j + 1] - s_J[s_][3 * parent + 1],
+                        t2 = s_J[s_][3 * j + 2] - s_J[s_][3 * parent + 2];
             float N[12];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -191,20 +229,21 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
                 N[4 * r + 3] = a0 * t0 + a1 * t1 + a2 * t2 + a3;
             }
 #pragma unroll
-            for (int e = 0; e < 12; ++e) { A[e] = N[e]; s_A[12 * j + e] = N[e]; }
+            for (int e = 0; e < 12; ++e) { A[e] = N[e]; s_A[s_][12 * j + e] = N[e]; }
             parent = j;
         }
     }
     __syncthreads(); stamp();
-    if (tid < NJ) {   // A' = A - pack(A.[J;0])  (manolayer.py:231-234)
-        const float* A = s_A + 12 * tid;
-        const float j0 = s_J[3 * tid], j1 = s_J[3 * tid + 1], j2 = s_J[3 * tid + 2];
+    if (tid < NJ * SPW) {   // A' = A - pack(A.[J;0])  (manolayer.py:231-234)
+        const int s_ = tid / NJ, jt = tid - NJ * s_;
+        const float* A = s_A[s_] + 12 * jt;
+        const float j0 = s_J[s_][3 * jt], j1 = s_J[s_][3 * jt + 1], j2 = s_J[s_][3 * jt + 2];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            s_A2[12 * tid + 4 * r + 0] = A[4 * r + 0];
-            s_A2[12 * tid + 4 * r + 1] = A[4 * r + 1];
-            s_A2[12 * tid + 4 * r + 2] = A[4 * r + 2];
-            s_A2[12 * tid + 4 * r + 3] = A[4 * r + 3] - (A[4 * r] * j0 + A[4 * r + 1] * j1 + A[4 * r + 2] * j2);
+            s_A2[s_][12 * jt + 4 * r + 0] = A[4 * r + 0];
+            s_A2[s_][12 * jt + 4 * r + 1] = A[4 * r + 1];
+            s_A2[s_][12 * jt + 4 * r + 2] = A[4 * r + 2];
+            s_A2[s_][12 * jt + 4 * r + 3] = A[4 * r + 3] - (A[4 * r] * j0 + A[4 * r + 1] * j1 + A[4 * r + 2] * j2);
         }
     }
     __syncthreads(); stamp();
@@ -218,39 +257,44 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
             float4 t4 = wp[q];
             w[4 * q] = t4.x; w[4 * q + 1] = t4.y; w[4 * q + 2] = t4.z; w[4 * q + 3] = t4.w;
         }
-        float T[12];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+        for (int s_ = 0; s_ < SPW; ++s_) {
+            float T[12];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {                       // A'[k] as three 16-byte LDS reads (was 12 scalar reads; same fmaf order)
-            const float4* ak = reinterpret_cast<const float4*>(s_A2 + 12 * k);
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float4 t4 = ak[r];
-                T[4 * r] = fmaf(t4.x, w[k], T[4 * r]); T[4 * r + 1] = fmaf(t4.y, w[k], T[4 * r + 1]);
-                T[4 * r + 2] = fmaf(t4.z, w[k], T[4 * r + 2]); T[4 * r + 3] = fmaf(t4.w, w[k], T[4 * r + 3]);
+            for (int k = 0; k < 16; ++k) {                       // A'[k] as three 16-byte LDS reads (was 12 scalar reads; same fmaf order)
+                const float4* ak = reinterpret_cast<const float4*>(s_A2[s_] + 12 * k);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float4 t4 = ak[r];
+                    T[4 * r] = fmaf(t4.x, w[k], T[4 * r]); T[4 * r + 1] = fmaf(t4.y, w[k], T[4 * r + 1]);
+                    T[4 * r + 2] = fmaf(t4.z, w[k], T[4 * r + 2]); T[4 * r + 3] = fmaf(t4.w, w[k], T[4 * r + 3]);
+                }
             }
+            const float x = s_v[s_][3 * v], y = s_v[s_][3 * v + 1], z = s_v[s_][3 * v + 2];
+            s_v[s_][3 * v + 0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+            s_v[s_][3 * v + 1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+            s_v[s_][3 * v + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
         }
-        const float x = s_v[3 * v], y = s_v[3 * v + 1], z = s_v[3 * v + 2];
-        s_v[3 * v + 0] = T[0] * x + T[1] * y + T[2] * z + T[3];
-        s_v[3 * v + 1] = T[4] * x + T[5] * y + T[6] * z + T[7];
-        s_v[3 * v + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
     }
     __syncthreads(); stamp();
 
     // ---- joints: 16 chain joints + 5 fingertip vertices, reordered (manolayer.py:247-259)
-    if (tid < 21) {
-        const int src = kReorderJ[tid];
+    if (tid < 21 * SPW) {
+        const int s_ = tid / 21, jt = tid - 21 * s_;
+        const int src = kReorderJ[jt];
+        const float* sv = s_v[s_];
         float x, y, z;
         if (src == 0 && a.t.root_palm) {
-            x = (s_v[3 * 95] + s_v[3 * 22]) / 2; y = (s_v[3 * 95 + 1] + s_v[3 * 22 + 1]) / 2;
-            z = (s_v[3 * 95 + 2] + s_v[3 * 22 + 2]) / 2;
-        } else if (src < 16) { x = s_A[12 * src + 3]; y = s_A[12 * src + 7]; z = s_A[12 * src + 11]; }
-        else { const int v = kTips[a.t.side][src - 16]; x = s_v[3 * v]; y = s_v[3 * v + 1]; z = s_v[3 * v + 2]; }
-        s_jtr[3 * tid] = x; s_jtr[3 * tid + 1] = y; s_jtr[3 * tid + 2] = z;
+            x = (sv[3 * 95] + sv[3 * 22]) / 2; y = (sv[3 * 95 + 1] + sv[3 * 22 + 1]) / 2;
+            z = (sv[3 * 95 + 2] + sv[3 * 22 + 2]) / 2;
+        } else if (src < 16) { x = s_A[s_][12 * src + 3]; y = s_A[s_][12 * src + 7]; z = s_A[s_][12 * src + 11]; }
+        else { const int v = kTips[a.t.side][src - 16]; x = sv[3 * v]; y = sv[3 * v + 1]; z = sv[3 * v + 2]; }
+        s_jtr[s_][3 * jt] = x; s_jtr[s_][3 * jt + 1] = y; s_jtr[s_][3 * jt + 2] = z;
     }
     __syncthreads(); stamp();
-    if (tid < 3) s_c[tid] = a.t.center_idx >= 0 ? s_jtr[3 * a.t.center_idx + tid] : 0.f;   // manolayer.py:261-265
+    if (tid < 3 * SPW) { const int s_ = tid / 3, c = tid - 3 * s_; s_c[s_][c] = a.t.center_idx >= 0 ? s_jtr[s_][3 * a.t.center_idx + c] : 0.f; }   // manolayer.py:261-265
     __syncthreads(); stamp();
 
     // with vertex parts: part 0 writes the 16 chain joints, a fingertip joint is written by the part that owns its vertex
@@ -260,20 +304,25 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
         const int v = src < 16 ? 0 : kTips[a.t.side][src - 16];
         return v >= v_lo && v < v_hi;
     };
-    const float sc = s_cam[0], tx = s_cam[1], ty = s_cam[2];
-    float* vout = a.verts + (size_t)b * NV3;
-    for (int i = f_lo + tid; i < f_hi; i += nthr) vout[i] = s_v[i] - s_c[i % 3];
-    if (tid < 63 && owns_joint(tid / 3)) a.joints[(size_t)b * 63 + tid] = s_jtr[tid] - s_c[tid % 3];
-    if (a.cam) {   // utils/utils.py:47-63: uv = s * xy + t
-        if (a.joint_uv && tid >= 64 && tid < 64 + 42) {
-            const int i = tid - 64, j = i >> 1, c = i & 1;
-            if (owns_joint(j)) a.joint_uv[(size_t)b * 42 + i] = sc * (s_jtr[3 * j + c] - s_c[c]) + (c ? ty : tx);
-        }
-        if (a.mesh_uv) {
-            float* mo = a.mesh_uv + (size_t)b * NV * 2;
-            for (int i = 2 * v_lo + tid; i < 2 * v_hi; i += nthr) {
-                const int v = i >> 1, c = i & 1;
-                mo[i] = sc * (s_v[3 * v + c] - s_c[c]) + (c ? ty : tx);
+#pragma unroll
+    for (int s_ = 0; s_ < SPW; ++s_) {
+        if (!live(s_)) continue;
+        const size_t b = (size_t)bs(s_);
+        const float sc = s_cam[s_][0], tx = s_cam[s_][1], ty = s_cam[s_][2];
+        float* vout = a.verts + b * NV3;
+        for (int i = f_lo + tid; i < f_hi; i += nthr) vout[i] = s_v[s_][i] - s_c[s_][i % 3];
+        if (tid < 63 && owns_joint(tid / 3)) a.joints[b * 63 + tid] = s_jtr[s_][tid] - s_c[s_][tid % 3];
+        if (a.cam) {   // utils/utils.py:47-63: uv = s * xy + t
+            if (a.joint_uv && tid >= 64 && tid < 64 + 42) {
+                const int i = tid - 64, j = i >> 1, c = i & 1;
+                if (owns_joint(j)) a.joint_uv[b * 42 + i] = sc * (s_jtr[s_][3 * j + c] - s_c[s_][c]) + (c ? ty : tx);
+            }
+            if (a.mesh_uv) {
+                float* mo = a.mesh_uv + b * NV * 2;
+                for (int i = 2 * v_lo + tid; i < 2 * v_hi; i += nthr) {
+                    const int v = i >> 1, c = i & 1;
+                    mo[i] = sc * (s_v[s_][3 * v + c] - s_c[s_][c]) + (c ? ty : tx);
+                }
             }
         }
     }
@@ -295,9 +344,15 @@ static void launch_mano(const ManoArgs& a0, int B, int hands, hipStream_t s) {
     }
     a.B = B; a.hands = hands; a.parts = split ? 4 : 1;
     const int rep = 8 / (hands * a.parts);
-    const dim3 grid(8 * ((B + rep - 1) / rep));
-    if (split) DIR_LAUNCH(mano_forward_kernel<PTHR>, grid, dim3(PTHR), 0, s, a);
-    else DIR_LAUNCH(mano_forward_kernel<NTHR>, grid, dim3(NTHR), 0, s, a);
+    // samples per workgroup (table values shared): DIR_MANO_SPW = 1 | 2 | 4 (tuning aid); default 2 once the batch gives every CU a group
+    static const int spw_env = getenv("DIR_MANO_SPW") ? atoi(getenv("DIR_MANO_SPW")) : 0;
+    const int spw = !split ? 1 : spw_env == 1 || spw_env == 2 || spw_env == 4 ? spw_env : (B * hands * 4 >= 512 ? 2 : 1);
+    const int groups = (B + spw - 1) / spw;
+    const dim3 grid(8 * ((groups + rep - 1) / rep));
+    if (!split) DIR_LAUNCH((mano_forward_kernel<NTHR, 1>), grid, dim3(NTHR), 0, s, a);
+    else if (spw == 4) DIR_LAUNCH((mano_forward_kernel<PTHR, 4>), grid, dim3(PTHR), 0, s, a);
+    else if (spw == 2) DIR_LAUNCH((mano_forward_kernel<PTHR, 2>), grid, dim3(PTHR), 0, s, a);
+    else DIR_LAUNCH((mano_forward_kernel<PTHR, 1>), grid, dim3(PTHR), 0, s, a);
     dir::stamps_end("mano", a.stamps, s);
 }
 
