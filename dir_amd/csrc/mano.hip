@@ -176,14 +176,14 @@ __global__ __launch_bounds__(THREADS) void mano_forward_kernel(ManoArgs args) {
     }
     __syncthreads(); stamp();
 
-    // ---- pose blend shapes (manolayer.py:186-187): one float4 column of the k-major table per thread, 9 loads in flight
+    // ---- pose blend shapes (manolayer.py:186-187): one float4 column of the k-major table per thread, 27 loads in flight
     if (f_lo / 4 + tid < (f_hi + 3) / 4) {
         const int c4 = f_lo / 4 + tid;                    // float4 column (f_lo is a multiple of 12)
         const float4* pd = reinterpret_cast<const float4*>(a.t.posedirs_t) + c4;
         float4 acc[SPW];
 #pragma unroll
         for (int s_ = 0; s_ < SPW; ++s_) acc[s_] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 9
+#pragma unroll 27
         for (int k = 0; k < 135; ++k) {
             const float4 p = pd[k * (NV3P / 4)];
 #pragma unroll
@@ -344,9 +344,11 @@ static void launch_mano(const ManoArgs& a0, int B, int hands, hipStream_t s) {
     }
     a.B = B; a.hands = hands; a.parts = split ? 4 : 1;
     const int rep = 8 / (hands * a.parts);
-    // samples per workgroup (table values shared): DIR_MANO_SPW = 1 | 2 | 4 (tuning aid); default 2 once the batch gives every CU a group
+    // samples per workgroup (table values shared): DIR_MANO_SPW = 1 | 2 | 4 (tuning aid).  Default 1: with the tables hot in L2 two samples per
+    // workgroup are 22 % faster (21.9 -> 17.0 us, back-to-back launches), but inside a forward the tables come from the Infinity Cache and
+    // the launch is bound by loads in flight per CU -- 24 us either way, 32 us with two samples and the shallower unroll (measured in-engine)
     static const int spw_env = getenv("DIR_MANO_SPW") ? atoi(getenv("DIR_MANO_SPW")) : 0;
-    const int spw = !split ? 1 : spw_env == 1 || spw_env == 2 || spw_env == 4 ? spw_env : (B * hands * 4 >= 512 ? 2 : 1);
+    const int spw = !split ? 1 : spw_env == 2 || spw_env == 4 ? spw_env : 1;
     const int groups = (B + spw - 1) / spw;
     const dim3 grid(8 * ((groups + rep - 1) / rep));
     if (!split) DIR_LAUNCH((mano_forward_kernel<NTHR, 1>), grid, dim3(NTHR), 0, s, a);
