@@ -27,15 +27,36 @@ WGRAD_ARITH = os.environ.get('DIR_TRAIN_WGRAD_ARITH', ARITH)          # the weig
 # convolution calls of a training step happen in a fixed order, so the call counter identifies the site.  64x headroom + saturation at the
 # f16 maximum make a stale scale a (bounded) precision loss, never an inf / nan.
 RECALIBRATE = int(os.environ.get('DIR_TRAIN_RECALIBRATE', '50'))
+# (A step's backward must follow its own forward before another model's forward starts: the cache bound by begin_step stays active until
+# the next begin_step.)
+# one cache per trained model (keyed by the storage of its first parameter: stable across steps for FlatAdamW views and nn.Parameters alike), so
+# that two networks stepped in one process do not recalibrate each other; a handful of models at most (least recently used one dropped)
+_caches, _MAX_CACHES = {}, 8
 _scales, _state = [], {'call': 0, 'step': 0}
 
 
-def begin_step():
-    """called by dir_amd.train.net.forward at the start of every training step"""
+def begin_step(key=None):
+    """called by dir_amd.train.net.forward at the start of every training step; `key` identifies the model being stepped"""
+    global _scales, _state
+    if key not in _caches:
+        if len(_caches) >= _MAX_CACHES:
+            _caches.pop(next(iter(_caches)))
+        _caches[key] = ([], {'call': 0, 'step': 0})
+    else:
+        _caches[key] = _caches.pop(key)                    # most recently used last
+    _scales, _state = _caches[key]
     _state['call'] = 0
     _state['step'] += 1
     if RECALIBRATE > 0 and _state['step'] % RECALIBRATE == 1 and _state['step'] > 1:
         del _scales[:]
+
+
+def reset_scales():
+    """forget every cached operand scale (the next step of each model calibrates again on the batch it sees)"""
+    _caches.clear()
+    del _scales[:]
+    _state['call'] = 0
+    _state['step'] = 0
 
 
 def _site_scale(x):

@@ -105,7 +105,7 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
 def forward(P, img, keep=None):
     """img NCHW fp32 [B,3,256,256] -> (outs: the three stage dicts + {'seg', 'dense'} NCHW, ctx)"""
     keep = [] if keep is None else keep
-    TC.begin_step()
+    TC.begin_step(next(iter(P.values())).data_ptr() if len(P) else None)       # operand-scale cache of THIS model (dir_amd/train/conv.py)
     B = img.shape[0]
     dev = img.device
     ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)

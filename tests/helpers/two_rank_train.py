@@ -74,7 +74,7 @@ if rank == 0:
         P = {k: v.data for k, v in p1.items()}
         P.update({k: v.clone() for k, v in b1.items()})
         i2, t2, m2 = batch(r)
-        del TC._scales[:]                                   # the split-precision operand scales are calibrated on a rank's own first batch: do the same here
+        TC.reset_scales()                                   # the split-precision operand scales are calibrated on a rank's own first batch: do the same here
         outs, ctx = TN.forward(P, i2)
         G = TN.backward(P, ctx, outs, t2, m2, faces)
         o1.zero_grad()
