@@ -530,6 +530,9 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     if constexpr (std::is_same<TI, bf16_t>::value || XM != 0) {
         // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip (bf16, or both operands
         // pre-split f16)
+        if constexpr (XM == 0) {
+            if (a0.variant == 11 && launch_conv_big(a0, std::is_same<TO, float>::value, s)) return;      // DIR_CONV_VARIANT 11: 256 x 256 block tile
+        }
         const bool four_wave = ((a0.variant & 15) >= 1 && (a0.variant & 15) <= 4) || a0.x2;   // explicit DIR_CONV_VARIANT 1..4 (+16), or a second source
         if (!four_wave) {
             ConvArgs ap = a0;

@@ -356,6 +356,8 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
     }
 }
 
+// conv_big.hip (DIR_CONV_VARIANT 11, the 256 x 256 block tile): returns true if it took the launch
+bool launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t s);
 // conv_pipe.hip: returns true if it took the launch (bf16 input, no pre-activation, long reduction, enough tiles)
 bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s, int xm = 0);      // xm 3 / 1: both operands pre-split f16 (F16X3P / F16X1P)
 
