@@ -19,6 +19,10 @@
 
 #include <stdlib.h>
 
+#ifndef DIR_P15_NBUF
+#define DIR_P15_NBUF 3
+#endif
+
 namespace dir {
 namespace convk {
 namespace {
@@ -670,7 +674,7 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
     static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
     static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
-    const bool explicit_variant = (a.variant >= 8 && a.variant <= 10) || (!xm && a.variant >= 12 && a.variant <= 14);
+    const bool explicit_variant = (a.variant >= 8 && a.variant <= 10) || (!xm && a.variant >= 12 && a.variant <= 15);
     if (xm && (a.pre_scale || a.bbox || !out_f32)) return false;
     if (force == 0 || !(a.flags & 4) || (a.nk < min_nk && !explicit_variant)) return false;
     const bool pre = a.pre_scale != nullptr;
@@ -682,6 +686,22 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     if (explicit_variant) {                                // explicit tile (DIR_CONV_VARIANT 8..10, 12..14 = with halo reuse)
         shape = a.variant >= 12 ? a.variant - 11 : a.variant - 7;
         if (a.nk < 1 || (pre && shape == 1)) return false;
+        if (a.variant == 15) {
+            // DIR_CONV_VARIANT 15: 128 x 64 tile on EIGHT waves (32 x 32 wave tiles) -- the small-M layers (8 x 8 / 16 x 16 maps: 256 such
+            // tiles at B = 64) otherwise run on four waves, one per SIMD, with nothing to hide a wave's fragment-read latency behind.
+            // Ring depth DIR_P15_NBUF: 3 .. 6 measured equal (layer4 3x3: 33-35 us), so the shallow one, which lets two workgroups share a CU
+            if (a.bbox || xm) return false;
+            ConvArgs b = a;
+            b.tiles_m = (b.M + 127) / 128;
+            b.tiles_n = (b.Cout + 63) / 64;
+            const dim3 grid(b.tiles_m * b.tiles_n), block(512);
+            if (pre) {
+                if (out_f32) DIR_LAUNCH((conv_pipe_kernel<float, 1, 1, 4, 2, false, true, DIR_P15_NBUF>), grid, block, 0, s, b);
+                else DIR_LAUNCH((conv_pipe_kernel<bf16_t, 1, 1, 4, 2, false, true, DIR_P15_NBUF>), grid, block, 0, s, b);
+            } else if (out_f32) DIR_LAUNCH((conv_pipe_kernel<float, 1, 1, 4, 2, false, false, DIR_P15_NBUF>), grid, block, 0, s, b);
+            else DIR_LAUNCH((conv_pipe_kernel<bf16_t, 1, 1, 4, 2, false, false, DIR_P15_NBUF>), grid, block, 0, s, b);
+            return true;
+        }
     } else if (force > 0) shape = force;
     else {
         // largest tile that still gives (nearly) every CU a workgroup; 64-wide N tile only for Cout <= 64

@@ -1141,7 +1141,7 @@ class DirEngine(object):
     # All of them -- including the streaming 1x1 kernel (STREAM_VARIANT, stream.hip), which feeds the MFMA the same k-slots in the
     # same order as the tiled kernels -- accumulate identically: outputs are bit-identical whichever is chosen
     # (tools/check_stream_layers.py, tests/test_gpu_dir.py::test_autotuned_engine_is_bit_identical).
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, STREAM_VARIANT)
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15, STREAM_VARIANT)
 
     def _profiled_forwards(self, img, n):
         """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""
@@ -1179,7 +1179,7 @@ class DirEngine(object):
                     acc.setdefault(rec['op'], []).append(rec['e0'].elapsed_time(rec['e1']))
                 for op, ts in acc.items():
                     t = min(ts)
-                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 11, 12, 13, 14) else self.STREAM_MARGIN if v == STREAM_VARIANT else 0.03
+                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 11, 12, 13, 14, 15) else self.STREAM_MARGIN if v == STREAM_VARIANT else 0.03
                     if op not in best or t < best[op][0] * (1.0 - margin):  # a challenger must win by 3 % (timing noise)
                         best[op] = (t, v)
         finally:

@@ -133,8 +133,9 @@ def test_conv_full_size_chunk_consistency(shape, dtype):
 
 @pytest.mark.parametrize('shape', [(16, 32, 256, 256, 3, 1), (8, 32, 512, 384, 1, 1), (9, 30, 128, 200, 3, 2), (64, 32, 256, 256, 3, 1)])
 @pytest.mark.parametrize('odt', [torch.bfloat16, torch.float32])
-def test_big_tile_variant_is_bit_identical(shape, odt):
-    """DIR_CONV_VARIANT 11 (conv_big.hip, 256 x 256 block tile): the same K order and fp32 accumulation order as the 4-wave kernel, so the
+@pytest.mark.parametrize('pre', [False, True])
+def test_big_tile_variant_is_bit_identical(shape, odt, pre):
+    """DIR_CONV_VARIANT 11 (conv_big.hip, 256 x 256 block tile) and 15 (conv_pipe.hip, 128 x 64 tile on eight waves, deep ring): the same K order and fp32 accumulation order as the 4-wave kernel, so the
     same bits -- whole and ragged tiles in both directions, stride 2, scale / shift / residual / ReLU, bf16 and fp32 outputs, a channel-slice output."""
     B, H, Ci, Co, k, stride = shape
     g = torch.Generator(device='cuda').manual_seed(sum(shape))
@@ -144,14 +145,16 @@ def test_big_tile_variant_is_bit_identical(shape, odt):
     sh = torch.randn(Co, device='cuda', generator=g)
     Ho = (H + 2 * (k // 2) - k) // stride + 1
     res = torch.randn(B, Ho, Ho, Co, device='cuda', generator=g).to(odt)
+    ps, pb = torch.rand(Ci, device='cuda', generator=g) + 0.5, torch.randn(Ci, device='cuda', generator=g) * 0.5     # (pre-activation: 11 falls back)
     outs = []
-    for variant in (1, 11):
+    for variant in (1, 11, 15):
         out = torch.full((B, Ho, Ho, Co + 8), 3.0, device='cuda', dtype=odt)
-        F.conv2d_nhwc(x, w, stride, k // 2, sc, sh, relu=True, residual=res, out=out, out_coff=8, variant=variant)
+        F.conv2d_nhwc(x, w, stride, k // 2, sc, sh, relu=True, residual=res, out=out, out_coff=8, variant=variant,
+                      pre_scale=ps if pre else None, pre_shift=pb if pre else None, pre_relu=pre)
         outs.append(out)
     assert torch.isfinite(outs[0].float()).all() and float(outs[0][..., 8:].float().abs().max()) > 0.5
-    assert torch.equal(outs[0], outs[1])
-    assert bool((outs[1][..., :8] == 3.0).all())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert bool((outs[1][..., :8] == 3.0).all()) and bool((outs[2][..., :8] == 3.0).all())
 
 
 @pytest.mark.parametrize('dt,tol', [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])

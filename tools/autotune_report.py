@@ -24,7 +24,7 @@ for v in eng.CONV_VARIANTS:
         times.setdefault(k, {}).setdefault(v, []).append(r['e0'].elapsed_time(r['e1']) * 1e3)
 E._TLS.variant = None
 names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x128', 4: '64x64', 17: '128x128r', 18: '128x64r', 19: '64x128r', 20: '64x64r', 8: 'P256x128', 9: 'P128x128',
-         10: 'P256x64', 11: 'B256x256', 12: 'H256x128', 13: 'H128x128', 14: 'H256x64', E.STREAM_VARIANT: 'stream'}
+         10: 'P256x64', 11: 'B256x256', 12: 'H256x128', 13: 'H128x128', 14: 'H256x64', 15: 'P128x64', E.STREAM_VARIANT: 'stream'}
 tot_auto = tot_best = 0
 for k in order:
     m = {v: min(ts) for v, ts in times[k].items()}
