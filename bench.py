@@ -54,6 +54,7 @@ def parse_args(argv=None):
     ap.add_argument('--autotune-cache', default=None, help='JSON file: load the per-layer variants if it exists, else tune and save '
                     '(profiling runs use it to keep the exploration out of the trace)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi socket power probe (7 s, outside the timed regions)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
     ap.add_argument('--no-train', action='store_true', help='skip the training-step sub-record (batch 32, fp32)')
     ap.add_argument('--no-proj-feat-variant', action='store_true', help='skip the serving variant without the proj_feat output')
@@ -61,6 +62,56 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-threads', type=int, default=16)
     ap.add_argument('--dump-conv', action='store_true', help='print per-shape timings of every library call (stderr)')
     return ap.parse_args(argv)
+
+
+def smi_sample():
+    """socket power (W), shader clock (MHz), power cap (W) of the visible GPU from `rocm-smi --json`, or None (no rocm-smi / no permission)"""
+    import subprocess
+    try:
+        r = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower', '--json'], capture_output=True, text=True, timeout=10)
+        d = next(iter(json.loads(r.stdout.strip().splitlines()[-1]).values()))
+        num = lambda v: float(''.join(c for c in str(v) if c.isdigit() or c == '.'))                      # noqa: E731
+        return {'w': num(next(v for k, v in d.items() if 'Package Power (W)' in k and 'Max' not in k)),
+                'sclk': num(d.get('sclk clock speed:', '0')), 'cap': num(d.get('Max Graphics Package Power (W)', '0'))}
+    except Exception:
+        return None
+
+
+def power_probe(step, sync, seconds, steps_per_burst):
+    """Runs `step` back to back for `seconds` (outside every timed region) while a thread samples rocm-smi; the first second is dropped
+    (the SMU's power reading is an average).  Returns the median socket power / shader clock, or None when rocm-smi gives nothing."""
+    import threading
+    idle = smi_sample()
+    if idle is None:
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        t0 = time.perf_counter()
+        while not stop.is_set():
+            v = smi_sample()
+            if v is not None and time.perf_counter() - t0 > 1.0:
+                samples.append(v)
+            stop.wait(0.25)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(steps_per_burst):
+            step()
+        sync()
+        n += steps_per_burst
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    if not samples:
+        return None
+    w = statistics.median(v['w'] for v in samples)
+    return {'socket_w': w, 'cap_w': idle['cap'], 'frac_of_cap': round(w / idle['cap'], 3) if idle['cap'] else None,
+            'sclk_mhz': statistics.median(v['sclk'] for v in samples), 'idle_w_before': idle['w'], 'samples': len(samples),
+            'ms_per_step_during_probe': round(dt / n * 1e3, 3), 'joules_per_step': round(w * dt / n, 3),
+            'source': 'rocm-smi --showpower --showclocks, median of samples taken while the timed loop ran again for %.0f s' % seconds}
 
 
 def timed_regions(step, steps, repeats, barrier, max_over_ranks, sync):
@@ -226,6 +277,14 @@ def main():
             pipe.launch(s_)
             alone = snap(pipe.wait(s_))
             reproducible = reproducible and all(torch.equal(a, b) for a, b in zip(overlapped[s_], alone))
+
+    # ---- socket power while the same loop runs (after the timed regions; four forwards in flight sit at the package power cap: DESIGN.md 9)
+    power = None
+    if rank == 0 and world == 1 and not args.no_power:
+        power = power_probe(step, sync, 4.0, 50)
+        if power is not None and pipe is not None:
+            p1 = power_probe(one_slot, sync, 3.0, 20)
+            power['one_in_flight'] = None if p1 is None else {k: p1[k] for k in ('socket_w', 'sclk_mhz', 'ms_per_step_during_probe', 'joules_per_step')}
 
     # ---- serving variant: the same step without the proj_feat output (335 MB of fp32 per step that apps/eval.py:170-172 never
     #      reads).  Reported beside the headline, never as `value`.
@@ -497,7 +556,7 @@ def main():
                            'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
-                'roofline': roof, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf}
+                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
