@@ -53,6 +53,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-autotune', action='store_true', help='keep the library heuristic for every conv layer')
     ap.add_argument('--autotune-cache', default=None, help='JSON file: load the per-layer variants if it exists, else tune and save '
                     '(profiling runs use it to keep the exploration out of the trace)')
+    ap.add_argument('--tuning', choices=['throughput', 'time'], default='throughput',
+                    help='per-layer conv kernel table of the timed graphs: throughput = dir_amd/tuning/ (fewest joules per launch: the socket power '
+                         'cap is what bounds several forwards in flight, DESIGN.md 9) when it matches this engine, else the live time-tuned choice')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi socket power probe (7 s, outside the timed regions)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
@@ -64,37 +67,15 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def smi_sample():
-    """socket power (W), shader clock (MHz), power cap (W) of the visible GPU from `rocm-smi --json`, or None (no rocm-smi / no permission)"""
-    import subprocess
-    try:
-        r = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower', '--json'], capture_output=True, text=True, timeout=10)
-        d = next(iter(json.loads(r.stdout.strip().splitlines()[-1]).values()))
-        num = lambda v: float(''.join(c for c in str(v) if c.isdigit() or c == '.'))                      # noqa: E731
-        return {'w': num(next(v for k, v in d.items() if 'Package Power (W)' in k and 'Max' not in k)),
-                'sclk': num(d.get('sclk clock speed:', '0')), 'cap': num(d.get('Max Graphics Package Power (W)', '0'))}
-    except Exception:
-        return None
-
-
 def power_probe(step, sync, seconds, steps_per_burst):
-    """Runs `step` back to back for `seconds` (outside every timed region) while a thread samples rocm-smi; the first second is dropped
-    (the SMU's power reading is an average).  Returns the median socket power / shader clock, or None when rocm-smi gives nothing."""
-    import threading
-    idle = smi_sample()
+    """Runs `step` back to back for `seconds` (outside every timed region) while a thread samples rocm-smi (dir_amd/power.py); the first
+    second is dropped (the SMU's power reading is an average).  Returns the median socket power / shader clock, or None when rocm-smi
+    gives nothing."""
+    from dir_amd import power as P
+    idle = P.smi_sample()
     if idle is None:
         return None
-    samples, stop = [], threading.Event()
-
-    def sampler():
-        t0 = time.perf_counter()
-        while not stop.is_set():
-            v = smi_sample()
-            if v is not None and time.perf_counter() - t0 > 1.0:
-                samples.append(v)
-            stop.wait(0.25)
-    th = threading.Thread(target=sampler, daemon=True)
-    th.start()
+    smp = P.Sampler(skip=1.0, period=0.25).start()
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < seconds:
@@ -103,13 +84,12 @@ def power_probe(step, sync, seconds, steps_per_burst):
         sync()
         n += steps_per_burst
     dt = time.perf_counter() - t0
-    stop.set()
-    th.join()
+    samples = smp.stop()
     if not samples:
         return None
-    w = statistics.median(v['w'] for v in samples)
+    w = P.median(samples, 'w')
     return {'socket_w': w, 'cap_w': idle['cap'], 'frac_of_cap': round(w / idle['cap'], 3) if idle['cap'] else None,
-            'sclk_mhz': statistics.median(v['sclk'] for v in samples), 'idle_w_before': idle['w'], 'samples': len(samples),
+            'sclk_mhz': P.median(samples, 'sclk'), 'w_before_probe': idle['w'], 'samples': len(samples),
             'ms_per_step_during_probe': round(dt / n * 1e3, 3), 'joules_per_step': round(w * dt / n, 3),
             'source': 'rocm-smi --showpower --showclocks, median of samples taken while the timed loop ran again for %.0f s' % seconds}
 
@@ -219,8 +199,33 @@ def main():
             if args.autotune_cache and rank == 0:
                 with open(args.autotune_cache, 'w') as f:
                     json.dump(eng.export_tuning(B), f)
-    serial_ms = None
+    serial_ms, serial_tp_ms = None, None
     pipe = None
+    # Two kernel tables, the same bits out of both (checked below): the TIME-tuned one just made serves one forward at a time (latency); the timed
+    # graphs take the THROUGHPUT table (dir_amd/tuning/, made by tools/energy_tune.py: fewest joules above idle per launch) when it matches.
+    lat_graph, lat_outs, conv_tuning = None, None, 'time (live autotune)' if not args.no_autotune else 'library heuristic'
+    if not args.no_graph and args.inflight > 1:
+        lat_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(lat_graph):
+            lat_outs = fwd()
+        for _ in range(3):
+            lat_graph.replay()
+        sync()
+        ser = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                lat_graph.replay()
+            sync()
+            ser.append((time.perf_counter() - t0) / 10 * 1e3)
+        serial_ms = statistics.median(ser)      # one forward at a time, time-tuned kernels (reported beside `value`)
+    t_time = None
+    if args.tuning == 'throughput' and not args.no_autotune:
+        t_time = eng.export_tuning(B)
+        meta = eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
+        if meta is not None:
+            conv_tuning = 'throughput table dir_amd/tuning/gfx950_%s_b%d_throughput.json (HEAD %s, %d layers differ from the time-tuned choice)' % (
+                args.dtype, B, meta.get('head', '?'), meta.get('changed_vs_time_tuned', -1))
     if args.no_graph:
         step = fwd
         args.inflight = 1
@@ -247,13 +252,13 @@ def main():
             one_slot()
         sync()
         ser = []
-        for _ in range(5):
+        for _ in range(3):
             t0 = time.perf_counter()
             for _ in range(10):
                 one_slot()
             sync()
             ser.append((time.perf_counter() - t0) / 10 * 1e3)
-        serial_ms = statistics.median(ser)      # same graphs, one forward at a time (reported beside `value`)
+        serial_tp_ms = statistics.median(ser)   # the timed graphs, one forward at a time
 
     for _ in range(args.warmup):
         step()
@@ -277,13 +282,20 @@ def main():
             pipe.launch(s_)
             alone = snap(pipe.wait(s_))
             reproducible = reproducible and all(torch.equal(a, b) for a, b in zip(overlapped[s_], alone))
+    tunings_equal = None
+    if pipe is not None and lat_graph is not None:        # slot 0 and the latency graph read the same images: both kernel tables, the same bits
+        lat_graph.replay()
+        pipe.launch(0)
+        a_, b_ = snap(lat_outs), snap(pipe.wait(0))
+        sync()
+        tunings_equal = all(torch.equal(x_, y_) for x_, y_ in zip(a_, b_))
 
     # ---- socket power while the same loop runs (after the timed regions; four forwards in flight sit at the package power cap: DESIGN.md 9)
     power = None
     if rank == 0 and world == 1 and not args.no_power:
         power = power_probe(step, sync, 4.0, 50)
         if power is not None and pipe is not None:
-            p1 = power_probe(one_slot, sync, 3.0, 20)
+            p1 = power_probe(lat_graph.replay if lat_graph is not None else one_slot, sync, 3.0, 20)
             power['one_in_flight'] = None if p1 is None else {k: p1[k] for k in ('socket_w', 'sclk_mhz', 'ms_per_step_during_probe', 'joules_per_step')}
 
     # ---- serving variant: the same step without the proj_feat output (335 MB of fp32 per step that apps/eval.py:170-172 never
@@ -387,6 +399,17 @@ def main():
 
 
     roof = live_roofline(eng, img, args.dtype, ms_per_step) if rank == 0 else None
+    if roof is not None and t_time is not None and conv_tuning.startswith('throughput'):
+        # the same pass with the TIME-tuned table: the throughput table trades per-kernel duration (one forward alone) for joules, so its launches
+        # look slower one at a time than the kernels can run
+        eng.import_tuning(img, t_time)
+        dump, args.dump_conv = args.dump_conv, False
+        rt = live_roofline(eng, img, args.dtype, ms_per_step, with_traffic=False)
+        args.dump_conv = dump
+        roof['time_tuned_table'] = {k: rt[k] for k in ('frac_mfma', 'frac_hbm', 'by_class', 'all_conv_ms_per_step', 'avg_launch_us')}
+        roof['note_tables'] = ('kernel durations above: the table of the timed graphs (throughput); time_tuned_table: the same launches with '
+                               'the per-layer fastest variant (what one forward at a time runs)')
+        eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
 
     # ---- fp32 exact-parity mode (the mode that meets the 1e-4 mm budget, tests/test_gpu_dir.py): one graph, a few steps
     fp32 = None
@@ -550,7 +573,9 @@ def main():
                                        'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads',
                            'batch_per_gpu': B, 'graph': not args.no_graph, 'forwards_in_flight': args.inflight,
                            'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
-                           'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3), 'weights': 'synthetic (dir_amd.synth seed 1234)',
+                           'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3),
+                           'ms_per_forward_one_in_flight_timed_graphs': None if serial_tp_ms is None else round(serial_tp_ms, 3),
+                           'conv_tuning': conv_tuning, 'tunings_bit_identical': tunings_equal, 'weights': 'synthetic (dir_amd.synth seed 1234)',
                            'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite,
                            'overlapped_equals_one_at_a_time': reproducible, 'world_size_observed': world_observed,
                            'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',

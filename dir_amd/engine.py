@@ -11,6 +11,7 @@ State-dict keys are the reference's (963 keys, tests/golden/manifest_dir.json).
 """
 import ctypes as C
 import math
+import json
 import os
 import threading
 
@@ -149,6 +150,8 @@ class ConvOp(object):
         out_given, residual_ok = out, True
         if out is None:
             out = torch.empty(B, ho, wo, self.cout, device=x.device, dtype=self.out_dtype)
+        if getattr(_TLS, 'capture', None) is not None:       # tools/energy_tune.py: this call, replayable (bf16 engines: no split hand-over)
+            _TLS.capture.append((self, (x,), dict(out=out, out_coff=out_coff, in_coff=in_coff, residual=residual, res_coff=res_coff, bbox=bbox)))
         pre_scale, pre_shift, flags, in_code, in_cs = self.pre_scale, self.pre_shift, self.flags, self.in_code, self.in_cs_override or cbuf
         if getattr(x, '_dir_split', False):
             # the producer's epilogue already wrote this tensor as f16 hi | lo slabs scaled by OUR in_scale (link_split): straight to the DMA path
@@ -277,6 +280,8 @@ class DualConvOp(object):
             ConvOp._calibrate(self, [y[..., :self.cin], x[..., :self.cin2]])
         if out is None:
             out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
+        if getattr(_TLS, 'capture', None) is not None:
+            _TLS.capture.append((self, (y, x), dict(out=out, out_coff=out_coff)))
         d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0,
                      DT_F16X3 if self.arith == 'f16x3' else DT_F16X1 if self.arith == 'f16' else _dt(self.dtype), _dt(self.dtype),
                      CONV_RELU if self.relu else 0, 0, 0, self.in_scale)
@@ -1192,6 +1197,103 @@ class DirEngine(object):
         self._tuned_order = getattr(self, '_tuned_order', {})
         self._tuned_order[B] = [op for op in best]          # first-call order of one forward: stable for a given engine
         return {op: v for op, (t, v) in best.items()}
+
+    def autotune_energy(self, img, seconds=0.8, slack=2.6, idle_w=None, log=None):
+        """The per-layer kernel choice for THROUGHPUT with several forwards in flight.  Four bs-64 forwards in flight run the socket at its
+        power cap (1.3-1.4 kW of 1.4 kW, 2.9 J per forward), so what raises images/s is the variant that costs the fewest joules
+        above idle, not the one that finishes first alone: typically a larger tile on fewer CUs (less L2 -> LDS and LDS -> register traffic
+        per MFMA), the idle CUs being filled by the other forwards.  Every convolution call of one forward is captured and replayed back to
+        back on its real tensors, per variant, for `seconds` while rocm-smi is sampled (dir_amd/power.py); the choice minimises
+        time x (power - idle power) among the variants within `slack` x the fastest.  ~50 calls x ~10 variants x seconds: 5-8 minutes -- run it
+        once per (GPU model, batch size) and keep export_tuning()'s table (dir_amd/tuning/, load_tuning_table).  Results stay bit-identical
+        (same argument as autotune).  One forward alone gets ~10 % slower with this table: latency-bound callers keep autotune()."""
+        import time as _time
+        from . import power
+        B = img.shape[0]
+        if B not in getattr(self, '_tuned_order', {}):
+            self.autotune(img)                                         # the time-tuned choice first: op order, and the fallback for every op not replayed here
+        if power.smi_sample() is None:
+            raise RuntimeError('autotune_energy: rocm-smi gives no power reading on this machine')
+        saved_overlap, self.overlap = self.overlap, False
+        torch.cuda.synchronize(self.device)
+        if idle_w is None:
+            idle_w = power.IDLE_W       # (the reading is a moving average with a time constant near a second: an "idle" sample taken here would still carry load)
+        rows = []
+        try:
+            _TLS.capture = []
+            self.forward(img)
+            torch.cuda.synchronize(self.device)
+            calls, _TLS.capture = _TLS.capture, None
+            seen = set()
+            for op, args, kw in calls:
+                if id(op) in seen:                                     # an op called twice per forward keeps one choice: the first call's
+                    continue
+                seen.add(id(op))
+                times = {}
+                for v in self.CONV_VARIANTS:
+                    if v in self.TUNE_EXCLUDE:
+                        continue
+                    _TLS.variant = v
+                    for _ in range(3):
+                        op(*args, **kw)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        op(*args, **kw)
+                    e1.record()
+                    torch.cuda.synchronize(self.device)
+                    times[v] = e0.elapsed_time(e1) / 10 * 1e3
+                tb = min(times.values())
+                row = {}
+                for v, us in times.items():
+                    if us > slack * tb:
+                        continue
+                    _TLS.variant = v
+                    smp = power.Sampler(skip=0.6 * seconds, period=0.03).start()       # the first 60 % still carries the previous variant's level
+                    t0, n = _time.perf_counter(), 0
+                    while _time.perf_counter() - t0 < seconds:
+                        for _ in range(100):
+                            op(*args, **kw)
+                        torch.cuda.synchronize(self.device)
+                        n += 100
+                    dt = _time.perf_counter() - t0
+                    w = power.median(smp.stop(), 'w')
+                    if w == w:                                         # (NaN: no sample landed in the window -- variant not rated)
+                        row[v] = (dt / n * 1e6, w)
+                _TLS.variant = None
+                if not row:
+                    continue
+                best = min(row, key=lambda v: row[v][0] * max(row[v][1] - idle_w, 1.0))
+                fastest = min(row, key=lambda v: row[v][0])
+                op.variant[B] = best
+                rows.append(dict(cout=op.cout, cin=getattr(op, 'cin', 0), kh=getattr(op, 'kh', 1), stride=getattr(op, 'stride', 1), chosen=best,
+                                 us=round(row[best][0], 1), w=round(row[best][1]), fastest=fastest, fastest_us=round(row[fastest][0], 1),
+                                 fastest_w=round(row[fastest][1])))
+                if log is not None:
+                    log(rows[-1])
+        finally:
+            _TLS.capture, _TLS.variant = None, None
+            self.overlap = saved_overlap
+        return {'idle_w': idle_w, 'layers': rows}
+
+    TUNING_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning')
+
+    def load_tuning_table(self, img, name):
+        """Apply dir_amd/tuning/<name>.json (written by tools/energy_tune.py from export_tuning) if it was made for this batch size and an
+        identically built engine; returns the table's meta dict, or None when there is no such table / it does not match (the caller then
+        keeps whatever autotune chose)."""
+        path = os.path.join(self.TUNING_DIR, name + '.json')
+        if not os.path.exists(path):
+            return None
+        with open(path) as f:
+            t = json.load(f)
+        if t.get('batch') != img.shape[0] or any(int(r[5]) not in self.CONV_VARIANTS for r in t['table']):
+            return None
+        try:
+            self.import_tuning(img, t['table'])
+        except ValueError:
+            return None
+        return t.get('meta', {})
 
     def export_tuning(self, B):
         """the variants autotune chose for batch size B, in the order the conv layers run (JSON-serialisable)"""
