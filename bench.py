@@ -407,6 +407,10 @@ def main():
         rt = live_roofline(eng, img, args.dtype, ms_per_step, with_traffic=False)
         args.dump_conv = dump
         roof['time_tuned_table'] = {k: rt[k] for k in ('frac_mfma', 'frac_hbm', 'by_class', 'all_conv_ms_per_step', 'avg_launch_us')}
+        fl_step = roof['alg_gflop_per_launch'] * 1e9 * roof['launches_per_step']
+        roof['overlapped'] = {'achieved': round(fl_step / (ms_per_step * 1e-3) / 1e12, 2), 'unit': 'TFLOP/s', 'frac': round(fl_step / (ms_per_step * 1e-3) / PEAK[args.dtype], 4),
+                              'note': "the family's algorithmic FLOPs of one step over the whole timed step (%d forwards in flight: its launches overlap "
+                                      "other forwards' kernels, so per-launch durations do not add up to the step)" % args.inflight}
         roof['note_tables'] = ('kernel durations above: the table of the timed graphs (throughput); time_tuned_table: the same launches with '
                                'the per-layer fastest variant (what one forward at a time runs)')
         eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))

@@ -1198,7 +1198,7 @@ class DirEngine(object):
         self._tuned_order[B] = [op for op in best]          # first-call order of one forward: stable for a given engine
         return {op: v for op, (t, v) in best.items()}
 
-    def autotune_energy(self, img, seconds=0.8, slack=2.6, idle_w=None, log=None):
+    def autotune_energy(self, img, seconds=0.8, slack=2.6, idle_w=None, log=None, max_calls=None):
         """The per-layer kernel choice for THROUGHPUT with several forwards in flight.  Four bs-64 forwards in flight run the socket at its
         power cap (1.3-1.4 kW of 1.4 kW, 2.9 J per forward), so what raises images/s is the variant that costs the fewest joules
         above idle, not the one that finishes first alone: typically a larger tile on fewer CUs (less L2 -> LDS and LDS -> register traffic
@@ -1225,7 +1225,7 @@ class DirEngine(object):
             torch.cuda.synchronize(self.device)
             calls, _TLS.capture = _TLS.capture, None
             seen = set()
-            for op, args, kw in calls:
+            for op, args, kw in (calls if max_calls is None else calls[:max_calls]):      # (max_calls: tests rate the first few calls only)
                 if id(op) in seen:                                     # an op called twice per forward keeps one choice: the first call's
                     continue
                 seen.add(id(op))

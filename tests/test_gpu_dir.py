@@ -209,6 +209,44 @@ def test_autotuned_engine_is_bit_identical(dir_state):
                 assert torch.equal(v, o1[k]), k
 
 
+def test_shipped_throughput_table_applies_and_is_bit_identical(dir_state):
+    """dir_amd/tuning/gfx950_bf16_b64_throughput.json (tools/energy_tune.py: per layer the variant with the fewest joules above idle) must
+    match the engine the library builds today -- same conv ops in the same order, variants it still offers -- and, like every kernel choice,
+    leave all outputs bit-identical; at another batch size it does not apply."""
+    eng = DirEngine(dir_state[0] if isinstance(dir_state, tuple) else dir_state, dtype=torch.bfloat16)
+    img = torch.randn(64, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(6))
+    before = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items() if k != 'proj_feat'} for o in eng.forward(img)]
+    meta = eng.load_tuning_table(img, 'gfx950_bf16_b64_throughput')
+    assert meta is not None and meta['changed_vs_time_tuned'] > 10
+    table = eng.export_tuning(64)
+    assert len({r[5] for r in table}) >= 4                       # a real mix of tiles, not one variant everywhere
+    after = eng.forward(img)
+    for o0, o1 in zip(before, after):
+        for k, v in o0.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, o1[k]), k
+    assert eng.load_tuning_table(img[:4].contiguous(), 'gfx950_bf16_b64_throughput') is None
+    assert eng.load_tuning_table(img, 'no_such_table') is None
+
+
+def test_energy_autotune_rates_variants_by_power(dir_state):
+    """DirEngine.autotune_energy on the first three conv calls of a small batch: every rated call gets a variant the library offers, the
+    report carries time and socket power of the chosen and of the fastest variant, outputs stay bit-identical.  Needs rocm-smi."""
+    from dir_amd import power
+    if power.smi_sample() is None:
+        pytest.skip('rocm-smi gives no power reading here')
+    eng = DirEngine(dir_state[0] if isinstance(dir_state, tuple) else dir_state, dtype=torch.bfloat16)
+    img = torch.randn(8, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(7))
+    ref = eng.forward(img)
+    ref = [ref[2]['pd_mesh_xyz_left'].clone(), ref[3]['seg'].clone()]
+    rep = eng.autotune_energy(img, seconds=0.15, max_calls=3)
+    assert len(rep['layers']) == 3
+    for r in rep['layers']:
+        assert r['chosen'] in eng.CONV_VARIANTS and r['fastest'] in eng.CONV_VARIANTS and r['w'] > 100 and r['us'] >= r['fastest_us'] * 0.95
+    out = eng.forward(img)
+    assert torch.equal(ref[0], out[2]['pd_mesh_xyz_left']) and torch.equal(ref[1], out[3]['seg'])
+
+
 def test_fused_backbone_paths_agree(dir_state):
     """bf16 mode: the fused stem (dir_stem_pool_forward) and the layer1 chain kernels (dir_bottleneck_chain_forward) against the
     launch-per-conv path they replace: same rounding points, so the pyramid agrees to bf16 noise and the final joints to well

@@ -1,0 +1,25 @@
+"""The shipped kernel-choice tables (dir_amd/tuning/*.json) are well-formed: CPU-side schema check; that a table matches the engine and keeps
+the outputs bit-identical is a GPU test (tests/test_gpu_dir.py::test_shipped_throughput_table_applies_and_is_bit_identical)."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tuning_tables_are_well_formed():
+    from dir_amd.engine import DirEngine
+    paths = sorted(glob.glob(os.path.join(ROOT, 'dir_amd', 'tuning', '*.json')))
+    assert paths, 'no tuning table shipped'
+    for p in paths:
+        with open(p) as f:
+            t = json.load(f)
+        assert isinstance(t['batch'], int) and t['dtype'] in ('bf16',) and os.path.basename(p) == 'gfx950_%s_b%d_throughput.json' % (t['dtype'], t['batch'])
+        assert len(t['table']) >= 50 and len(t['table']) == len(t['time_tuned_table'])
+        for row, row_t in zip(t['table'], t['time_tuned_table']):
+            assert len(row) == 6 and row[:5] == row_t[:5] and all(isinstance(v, int) for v in row)
+            assert row[5] in DirEngine.CONV_VARIANTS and row_t[5] in DirEngine.CONV_VARIANTS
+        m = t['meta']
+        assert m['objective'].startswith('time x (socket power - idle power)') and m['idle_w'] > 100
+        for r in m['layers']:                       # the measurement the choice was made from travels with the table
+            assert r['chosen'] in DirEngine.CONV_VARIANTS and r['us'] > 0 and r['w'] > r['us'] * 0 + 100
