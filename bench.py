@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument('--tuning', choices=['throughput', 'time'], default='throughput',
                     help='per-layer conv kernel table of the timed graphs: throughput = dir_amd/tuning/ (fewest joules per launch: the socket power '
                          'cap is what bounds several forwards in flight, DESIGN.md 9) when it matches this engine, else the live time-tuned choice')
+    ap.add_argument('--no-time-table-pass', action='store_true', help='skip the second per-launch pass with the time-tuned table (profiling runs: keeps the traces to the timed configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi socket power probe (7 s, outside the timed regions)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
@@ -399,7 +400,7 @@ def main():
 
 
     roof = live_roofline(eng, img, args.dtype, ms_per_step) if rank == 0 else None
-    if roof is not None and t_time is not None and conv_tuning.startswith('throughput'):
+    if roof is not None and t_time is not None and conv_tuning.startswith('throughput') and not args.no_time_table_pass:
         # the same pass with the TIME-tuned table: the throughput table trades per-kernel duration (one forward alone) for joules, so its launches
         # look slower one at a time than the kernels can run
         eng.import_tuning(img, t_time)
