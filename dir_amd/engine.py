@@ -141,8 +141,9 @@ class ConvOp(object):
             amax = amax * float(self.pre_scale.abs().max()) + float(self.pre_shift.abs().max())
         self.set_in_scale(2.0 ** (10 - math.frexp(amax)[1]) if amax > 0 and math.isfinite(amax) else 1.0)
 
-    def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None):
+    def __call__(self, x, out=None, out_coff=0, in_coff=0, residual=None, res_coff=0, bbox=None, _replay_split=None):
         B, H, W, cbuf = x.shape
+        x_arg, in_coff_arg = x, in_coff
         if self.arith is not None and getattr(_TLS, 'calibrating', False):
             self._calibrate([x[..., in_coff:in_coff + self.cin]] if self.in_cs_override is None else [x])
         ho = self.ho or (H + 2 * self.pad - self.kh) // self.stride + 1
@@ -150,8 +151,6 @@ class ConvOp(object):
         out_given, residual_ok = out, True
         if out is None:
             out = torch.empty(B, ho, wo, self.cout, device=x.device, dtype=self.out_dtype)
-        if getattr(_TLS, 'capture', None) is not None:       # tools/energy_tune.py: this call, replayable (bf16 engines: no split hand-over)
-            _TLS.capture.append((self, (x,), dict(out=out, out_coff=out_coff, in_coff=in_coff, residual=residual, res_coff=res_coff, bbox=bbox)))
         pre_scale, pre_shift, flags, in_code, in_cs = self.pre_scale, self.pre_shift, self.flags, self.in_code, self.in_cs_override or cbuf
         if getattr(x, '_dir_split', False):
             # the producer's epilogue already wrote this tensor as f16 hi | lo slabs scaled by OUR in_scale (link_split): straight to the DMA path
@@ -174,6 +173,11 @@ class ConvOp(object):
         cons = self.split_consumer
         write_split = (cons is not None and out_given is None and residual_ok and not getattr(_TLS, 'calibrating', False)
                        and not getattr(_TLS, 'no_out_split', False) and ConvOp.OUT_SPLIT)
+        if _replay_split is not None:
+            write_split = _replay_split
+        if getattr(_TLS, 'capture', None) is not None:       # autotune_energy: this call, replayable (same output buffer, same hand-over format)
+            _TLS.capture.append((self, (x_arg,), dict(out=out, out_coff=out_coff, in_coff=in_coff_arg, residual=residual, res_coff=res_coff, bbox=bbox,
+                                                  _replay_split=write_split)))
         if write_split:      # the only reader is the next convolution: write its pre-split operand instead of fp32 (same bytes, no split pass)
             d.out_split_scale = -cons.in_scale if cons.arith == 'f16' else cons.in_scale
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)

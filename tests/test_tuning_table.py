@@ -14,7 +14,7 @@ def test_tuning_tables_are_well_formed():
     for p in paths:
         with open(p) as f:
             t = json.load(f)
-        assert isinstance(t['batch'], int) and t['dtype'] in ('bf16',) and os.path.basename(p) == 'gfx950_%s_b%d_throughput.json' % (t['dtype'], t['batch'])
+        assert isinstance(t['batch'], int) and t['dtype'] in ('bf16', 'f16x3', 'f16') and os.path.basename(p) == 'gfx950_%s_b%d_throughput.json' % (t['dtype'], t['batch'])
         assert len(t['table']) >= 50 and len(t['table']) == len(t['time_tuned_table'])
         for row, row_t in zip(t['table'], t['time_tuned_table']):
             assert len(row) == 6 and row[:5] == row_t[:5] and all(isinstance(v, int) for v in row)

@@ -11,14 +11,17 @@ from dir_amd import engine as E, synth, power
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 0.8
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-NAME = 'gfx950_bf16_b64_throughput'
+MODE = os.environ.get('MODE', 'bf16')          # bf16 | f16x3 | f16 (the fp32-tensor modes: DirEngine(dtype=float32, arith=MODE))
+NAME = 'gfx950_%s_b64_throughput' % MODE
 shapes = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json'))).items()}
 sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
-eng = E.DirEngine(sd, dtype=torch.bfloat16)
+eng = E.DirEngine(sd, dtype=torch.bfloat16) if MODE == 'bf16' else E.DirEngine(sd, dtype=torch.float32, arith=MODE)
 B, NSLOT = 64, 4
 g = torch.Generator(device='cuda').manual_seed(0)
 imgs = [torch.randn(B, 3, 256, 256, device='cuda', generator=g) for _ in range(NSLOT)]
 img = imgs[0]
+if MODE != 'bf16':
+    eng.calibrate(img)
 ref = eng.forward(img)
 ref = [ref[i]['pd_mesh_xyz_left'].clone() for i in range(3)] + [ref[3]['seg'].clone()]
 eng.autotune(img)
@@ -35,7 +38,7 @@ meta = {'made_by': 'tools/energy_tune.py %.2f' % SECS, 'objective': 'time x (soc
         'device': torch.cuda.get_device_name(0), 'idle_w': rep['idle_w'], 'head': head, 'weights': 'dir_amd.synth seed 1234 (the choice depends on shapes only)',
         'changed_vs_time_tuned': sum(1 for a, b in zip(t_time, t_energy) if a[5] != b[5]), 'layers': rep['layers']}
 os.makedirs(os.path.join(ROOT, 'gpurun_out', 'tuning'), exist_ok=True)
-json.dump({'batch': B, 'dtype': 'bf16', 'meta': meta, 'table': t_energy, 'time_tuned_table': t_time},
+json.dump({'batch': B, 'dtype': MODE, 'meta': meta, 'table': t_energy, 'time_tuned_table': t_time},
           open(os.path.join(ROOT, 'gpurun_out', 'tuning', NAME + '.json'), 'w'), indent=0)
 
 STREAMS = [torch.cuda.Stream() for _ in range(NSLOT)]
