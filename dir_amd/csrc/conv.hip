@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    int tm, tn;
+    tile_of(a, bid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -571,6 +572,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
+    choose_tile_order(a, std::is_same<TI, bf16_t>::value ? 2 : 4);
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     const bool pre = a.pre_scale != nullptr;
     // 3-buffer ring (two slabs in flight) pays once the reduction is long enough to amortise its two-slab prologue

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    int tm, tn;
+    tile_of(a, bid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -206,6 +207,7 @@ bool launch_conv_big(const ConvArgs& a0, bool out_f32, hipStream_t s) {
     ConvArgs a = a0;
     a.tiles_m = (a.M + 255) / 256;
     a.tiles_n = (a.Cout + 255) / 256;
+    choose_tile_order(a, 2);
     const dim3 grid(a.tiles_m * a.tiles_n), block(512);
     if (out_f32) DIR_LAUNCH((conv_big_kernel<float>), grid, block, 0, s, a);
     else DIR_LAUNCH((conv_big_kernel<bf16_t>), grid, block, 0, s, a);

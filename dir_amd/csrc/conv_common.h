@@ -356,6 +356,30 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
     }
 }
 
+// Tile order of a launch (flags bit 8).  The XCD-aware remap hands every XCD one contiguous range of nwg / 8 tiles.  Row-major (tn fastest) makes
+// that range whole ROWS of tiles: the XCD streams every weight row through its 4 MB L2 but only its own pixels; column-major makes it whole
+// COLUMNS: every pixel, its own weight rows.  The order with fewer unique operand bytes per XCD is taken (column-major only when it saves a
+// fifth): the attention conv at B = 64 (16 x 16 tiles, 75 MB of weights, 17 MB of activations) goes from 77 MB to 26 MB per XCD.
+constexpr int CONV_COL_MAJOR = 8;
+inline void choose_tile_order(ConvArgs& a, int es) {
+    a.flags &= ~CONV_COL_MAJOR;
+    static const int forced = getenv("DIR_TILE_ORDER") ? atoi(getenv("DIR_TILE_ORDER")) : -1;      // tuning aid: 0 = always row-major, 1 = always column-major
+    if (a.bbox || a.tiles_m <= 0 || a.tiles_n <= 0 || forced == 0) return;
+    if (forced == 1) { a.flags |= CONV_COL_MAJOR; return; }
+    const double nwg = (double)a.tiles_m * a.tiles_n, per = (nwg + 7.0) / 8.0;
+    const double abytes = (double)a.B * a.H * a.W * a.Cin * es + (a.x2 ? (double)a.x2_bytes : 0.0), wbytes = (double)a.Cout * a.K * es;
+    auto frac = [](double num, double den) { const double f = num / den; return f < 1.0 ? f : 1.0; };
+    auto ceil_div = [](double x, double y) { const long long q = (long long)(x / y); return (double)(q * y < x ? q + 1 : q); };
+    const double cost_row = abytes * frac(ceil_div(per, a.tiles_n), a.tiles_m) + wbytes * frac(per, a.tiles_n);
+    const double cost_col = wbytes * frac(ceil_div(per, a.tiles_m), a.tiles_n) + abytes * frac(per, a.tiles_m);
+    if (cost_col < 0.8 * cost_row) a.flags |= CONV_COL_MAJOR;
+}
+// (tm, tn) of workgroup `bid` (after the XCD remap)
+__device__ __forceinline__ void tile_of(const ConvArgs& a, int bid, int& tm, int& tn) {
+    if (a.flags & CONV_COL_MAJOR) { tn = bid / a.tiles_m; tm = bid - tn * a.tiles_m; }
+    else { tm = bid / a.tiles_n; tn = bid - tm * a.tiles_n; }
+}
+
 // conv_big.hip (DIR_CONV_VARIANT 11, the 256 x 256 block tile): returns true if it took the launch
 bool launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t s);
 // conv_pipe.hip: returns true if it took the launch (bf16 input, no pre-activation, long reduction, enough tiles)

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    int tm, tn;
+    tile_of(a, bid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / a.tiles_n, tn = bid - tm * a.tiles_n;
+    int tm, tn;
+    tile_of(a, bid, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -639,6 +641,7 @@ void launch_tile(ConvArgs a, hipStream_t s) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
+    choose_tile_order(a, XM ? 4 : 2);
     dim3 grid(a.tiles_m * a.tiles_n), block(64 * WM * WN);
     if constexpr (XM != 0) {
         DIR_LAUNCH((conv_pipe_kernel<float, MI, NJ, WM, WN, false, false, 3, XM>), grid, block, 0, s, a);
@@ -694,6 +697,7 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
             ConvArgs b = a;
             b.tiles_m = (b.M + 127) / 128;
             b.tiles_n = (b.Cout + 63) / 64;
+            choose_tile_order(b, 2);
             const dim3 grid(b.tiles_m * b.tiles_n), block(512);
             if (pre) {
                 if (out_f32) DIR_LAUNCH((conv_pipe_kernel<float, 1, 1, 4, 2, false, true, DIR_P15_NBUF>), grid, block, 0, s, b);
