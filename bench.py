@@ -400,6 +400,14 @@ def main():
 
 
     roof = live_roofline(eng, img, args.dtype, ms_per_step) if rank == 0 else None
+    if roof is not None and args.dtype == 'bf16':
+        # what the board sustains on random bf16 data before its power / current limits pull the clock down (tools/ubench_energy.py):
+        # the guide's 2.5 PFLOP/s is reached on all-zero operands only.  Reported beside `peak`, never instead of it.
+        pl = {'mfma_operands_in_registers_tflops': 1790.0, 'mfma_with_64x64_wave_tile_operand_traffic_tflops': 1310.0, 'hbm_read_tbps': 5.15,
+              'source': 'tools/ubench_energy.py on 1x MI355X (1.33 kW at 1.77 GHz; 2.48 PFLOP/s at 0.97 kW on zeros)'}
+        if 'mfma' in roof.get('by_class', {}):
+            pl['by_class_mfma_frac_of_operand_traffic_ceiling'] = round(roof['by_class']['mfma']['achieved'] / 1310.0, 3)
+        roof['power_limited_ceilings'] = pl
     if roof is not None and t_time is not None and conv_tuning.startswith('throughput') and not args.no_time_table_pass:
         # the same pass with the TIME-tuned table: the throughput table trades per-kernel duration (one forward alone) for joules, so its launches
         # look slower one at a time than the kernels can run
