@@ -39,3 +39,10 @@ def test_four_wave_kernel_only():
 
 def test_small_tiles_forced():
     _run({'DIR_PIPE': '0', 'DIR_FORCE_M64': '1', 'DIR_FORCE_N64': '1', 'DIR_RING_MIN_NK': '1'})
+
+
+@pytest.mark.parametrize('pipe', ['0', '1', '2'])
+def test_column_major_tile_order_forced(pipe):
+    """DIR_TILE_ORDER=1: every launch maps workgroups to tiles column-major (the order the library picks itself only where the weights outweigh
+    the activations per XCD, conv_common.h: choose_tile_order) -- ragged tiles in both directions, channel slices, residuals, second sources."""
+    _run({'DIR_TILE_ORDER': '1', 'DIR_PIPE': pipe, 'DIR_PIPE_MIN_NK': '1'})
