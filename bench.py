@@ -200,7 +200,7 @@ def main():
             if args.autotune_cache and rank == 0:
                 with open(args.autotune_cache, 'w') as f:
                     json.dump(eng.export_tuning(B), f)
-    serial_ms, serial_tp_ms = None, None
+    serial_ms, serial_tp_ms, table_check = None, None, None
     pipe = None
     # Two kernel tables, the same bits out of both (checked below): the TIME-tuned one just made serves one forward at a time (latency); the timed
     # graphs take the THROUGHPUT table (dir_amd/tuning/, made by tools/energy_tune.py: fewest joules above idle per launch) when it matches.
@@ -240,6 +240,30 @@ def main():
         # overlaps step k-1's.  Every step is still one whole B-image forward; the timed region is closed by a device-wide sync.
         imgs = [img] + [torch.randn(B, 3, 256, 256, device=dev, generator=g) for _ in range(args.inflight - 1)]
         pipe = E.ForwardPipeline(eng, imgs)
+        table_check = None
+        if t_time is not None and conv_tuning.startswith('throughput'):
+            # The shipped table was measured on another box: check it here before it carries the timed regions.  Both tables' graphs on the same
+            # streams, 3 x 20 steps each; the time-tuned graphs take over if the table does not pay on this machine (another power cap, ...).
+            def quick(p_):
+                k_ = [0]
+
+                def st_():
+                    p_.launch(k_[0] % args.inflight)
+                    k_[0] += 1
+                for _ in range(2 * args.inflight):
+                    st_()
+                sync()
+                return statistics.median(timed_regions(st_, 20, 3, sync, float, sync)) / 20 * 1e3
+            q_tp = quick(pipe)
+            eng.import_tuning(img, t_time)
+            pipe_t = E.ForwardPipeline(eng, imgs, streams=pipe.streams)
+            q_t = quick(pipe_t)
+            table_check = {'throughput_table_ms_per_step': round(q_tp, 3), 'time_tuned_ms_per_step': round(q_t, 3), 'steps': 60}
+            if q_t < 0.99 * q_tp:
+                pipe, conv_tuning = pipe_t, 'time (live autotune): the shipped throughput table was slower on this machine (%.3f vs %.3f ms per step)' % (q_tp, q_t)
+            else:
+                del pipe_t
+                eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
         outs = pipe.outs[0]
         counter = [0]
 
@@ -599,7 +623,7 @@ def main():
                            'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                            'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3),
                            'ms_per_forward_one_in_flight_timed_graphs': None if serial_tp_ms is None else round(serial_tp_ms, 3),
-                           'conv_tuning': conv_tuning, 'tunings_bit_identical': tunings_equal, 'weights': 'synthetic (dir_amd.synth seed 1234)',
+                           'conv_tuning': conv_tuning, 'conv_tuning_check': table_check, 'tunings_bit_identical': tunings_equal, 'weights': 'synthetic (dir_amd.synth seed 1234)',
                            'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite,
                            'overlapped_equals_one_at_a_time': reproducible, 'world_size_observed': world_observed,
                            'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',

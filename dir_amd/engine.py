@@ -1210,7 +1210,7 @@ class DirEngine(object):
         back on its real tensors, per variant, for `seconds` while rocm-smi is sampled (dir_amd/power.py); the choice minimises
         time x (power - idle power) among the variants within `slack` x the fastest.  ~50 calls x ~10 variants x seconds: 5-8 minutes -- run it
         once per (GPU model, batch size) and keep export_tuning()'s table (dir_amd/tuning/, load_tuning_table).  Results stay bit-identical
-        (same argument as autotune).  One forward alone gets ~10 % slower with this table: latency-bound callers keep autotune()."""
+        (same argument as autotune).  One forward alone gets ~15 % slower with this table: latency-bound callers keep autotune()."""
         import time as _time
         from . import power
         B = img.shape[0]
