@@ -7,6 +7,7 @@
 //   mode 4  lds      : the 16 ds_read_b128 alone
 //   mode 5  dma      : the 3 DMA pieces alone (L2 -> LDS)
 //   mode 6  hbm read : 16-byte loads streaming a 1 GiB buffer        mode 7  hbm copy : load + store
+//   mode 8  mall read: the same loads over a 96 MB buffer (Infinity-Cache resident after the first pass)      mode 9  l2 read: over 2 MB per XCD-ish (16 MB)
 //   arg 3: data 1 = random bf16 (default), 0 = zeros (modes 1-3)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -119,6 +120,8 @@ int main(int argc, char** argv) {
                 case 4: hipLaunchKernelGGL((k<false, true, false>), dim3(256), dim3(512), 0, 0, src, iters, sink, rnd); break;
                 case 5: hipLaunchKernelGGL((k<false, false, true>), dim3(256), dim3(512), 0, 0, src, iters, sink, rnd); break;
                 case 6: hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, nb / 16, (unsigned*)sink); break;
+                case 8: hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, (96ull << 20) / 16, (unsigned*)sink); break;
+                case 9: hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, (16ull << 20) / 16, (unsigned*)sink); break;
                 default: hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, 0, a, b, nb / 16); break;
             }
             ++launches;
@@ -133,6 +136,8 @@ int main(int argc, char** argv) {
     else if (mode == 5) { units = launches * per_launch_cu * 256 * 3 * 1024.0; unit = "DMA bytes"; }
     else if (mode == 6) { units = (double)launches * nb; unit = "HBM bytes"; }
     else if (mode == 7) { units = (double)launches * nb * 2; unit = "HBM bytes"; }
+    else if (mode == 8) { units = (double)launches * (96ull << 20); unit = "HBM bytes"; }
+    else if (mode == 9) { units = (double)launches * (16ull << 20); unit = "HBM bytes"; }
     else units = launches;
     printf("{\"mode\": %d, \"seconds\": %.3f, \"units\": %.6e, \"unit\": \"%s\", \"rate\": %.6e, \"data\": %d}\n", mode, dt, units, unit, units / dt, rnd);
     return 0;

@@ -9,9 +9,9 @@ SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
 exe = '/tmp/ubench_energy'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-o', exe, os.path.join(ROOT, 'tools', 'ubench_energy.hip')])
 names = {0: 'spin (s_sleep)', 1: 'mfma, operands in registers', 2: 'mfma + 16 ds_read_b128', 3: 'mfma + ds_read + 3 dma', 4: 'ds_read_b128 alone',
-         5: 'lds-dma alone (L2 -> LDS)', 6: 'hbm read', 7: 'hbm copy (r + w)'}
+         5: 'lds-dma alone (L2 -> LDS)', 6: 'hbm read', 7: 'hbm copy (r + w)', 8: 'read, 96 MB buffer (Infinity Cache)', 9: 'read, 16 MB buffer (L2)'}
 rows = []
-for mode, data in ((0, 1), (1, 1), (1, 0), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1)):
+for mode, data in ((0, 1), (1, 1), (1, 0), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1)):
     smp = power.Sampler(skip=0.6 * SECS, period=0.05).start()
     out = subprocess.run([exe, str(mode), str(SECS), str(data)], capture_output=True, text=True).stdout.strip().splitlines()[-1]
     s = smp.stop()
