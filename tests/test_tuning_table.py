@@ -23,3 +23,18 @@ def test_tuning_tables_are_well_formed():
         assert m['objective'].startswith('time x (socket power - idle power)') and m['idle_w'] > 100
         for r in m['layers']:                       # the measurement the choice was made from travels with the table
             assert r['chosen'] in DirEngine.CONV_VARIANTS and r['us'] > 0 and r['w'] > r['us'] * 0 + 100
+
+
+def test_power_sampler_degrades_without_rocm_smi():
+    """dir_amd/power.py on a box without a GPU / rocm-smi reading: smi_sample() is None (or a well-formed dict where the tool works), the
+    sampler thread starts and stops cleanly and returns what it got -- bench.py then reports `power: null` instead of failing."""
+    import time
+    from dir_amd import power
+    v = power.smi_sample()
+    assert v is None or (set(v) == {'w', 'sclk', 'cap'} and v['w'] >= 0)
+    smp = power.Sampler(skip=0.0, period=0.02).start()
+    time.sleep(0.1)
+    got = smp.stop()
+    assert isinstance(got, list) and (v is not None or got == [])
+    assert power.median([], 'w') != power.median([], 'w')          # NaN
+    assert power.median([{'w': 1.0}, {'w': 3.0}, {'w': 2.0}], 'w') == 2.0
