@@ -373,6 +373,11 @@ inline void choose_tile_order(ConvArgs& a, int es) {
     const double cost_row = abytes * frac(ceil_div(per, a.tiles_n), a.tiles_m) + wbytes * frac(per, a.tiles_n);
     const double cost_col = wbytes * frac(ceil_div(per, a.tiles_m), a.tiles_n) + abytes * frac(per, a.tiles_m);
     if (cost_col < 0.8 * cost_row) a.flags |= CONV_COL_MAJOR;
+    static const int log = getenv("DIR_ORDER_LOG") ? atoi(getenv("DIR_ORDER_LOG")) : 0;          // tuning aid: one line per launch
+    if (log)
+        fprintf(stderr, "tile_order M=%d N=%d K=%d tiles %dx%d %s: per-XCD unique MB row-major %.1f col-major %.1f, x8 = %.1f MB against operands %.1f MB\n", a.M, a.Cout, a.K,
+                a.tiles_m, a.tiles_n, (a.flags & CONV_COL_MAJOR) ? "COL" : "row", cost_row / 1e6, cost_col / 1e6,
+                8.0 * ((a.flags & CONV_COL_MAJOR) ? cost_col : cost_row) / 1e6, (abytes + wbytes) / 1e6);
 }
 // (tm, tn) of workgroup `bid` (after the XCD remap)
 __device__ __forceinline__ void tile_of(const ConvArgs& a, int bid, int& tm, int& tn) {
