@@ -239,7 +239,7 @@ def test_energy_autotune_rates_variants_by_power(dir_state):
     img = torch.randn(8, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(7))
     ref = eng.forward(img)
     ref = [ref[2]['pd_mesh_xyz_left'].clone(), ref[3]['seg'].clone()]
-    rep = eng.autotune_energy(img, seconds=0.15, max_calls=3)
+    rep = eng.autotune_energy(img, seconds=0.3, max_calls=3)
     assert len(rep['layers']) == 3
     for r in rep['layers']:
         assert r['chosen'] in eng.CONV_VARIANTS and r['fastest'] in eng.CONV_VARIANTS and r['w'] > 100 and r['us'] >= r['fastest_us'] * 0.95
