@@ -45,8 +45,11 @@ def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides():
         assert all(torch.equal(x, want) for x in outs), 'foreign kernel corrupted beside the forward (round %d)' % rnd
 
 
-def test_four_forwards_in_flight_reproduce_the_one_at_a_time_results():
-    """bench.py's default concurrency (four pipeline slots): every slot, every round, equals its stand-alone result bit for bit"""
+@pytest.mark.parametrize('tuning', ['time', 'throughput'])
+def test_four_forwards_in_flight_reproduce_the_one_at_a_time_results(tuning):
+    """bench.py's default concurrency (four pipeline slots), with the live time-tuned kernel choice and with the shipped throughput table
+    (large tiles on few CUs beside other forwards' kernels: another mix of co-resident kernels): every slot, every round, equals its stand-alone
+    result bit for bit, and the two tables agree with each other"""
     with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
@@ -54,13 +57,18 @@ def test_four_forwards_in_flight_reproduce_the_one_at_a_time_results():
     gen = torch.Generator(device='cuda').manual_seed(11)
     imgs = [torch.randn(64, 3, 256, 256, device='cuda', generator=gen) for _ in range(4)]
     eng.autotune(imgs[0])
-    pipe = ForwardPipeline(eng, imgs)
     keys = ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset')
+    o = eng.forward(imgs[0])
+    eager = [o[i][k].clone() for i in range(3) for k in keys] + [o[3]['seg'].clone()]
+    if tuning == 'throughput':
+        assert eng.load_tuning_table(imgs[0], 'gfx950_bf16_b64_throughput') is not None
+    pipe = ForwardPipeline(eng, imgs)
     ref = []
     for s in range(4):                                   # one at a time
         pipe.launch(s)
         o = pipe.wait(s)
         ref.append([o[i][k].clone() for i in range(3) for k in keys] + [o[3]['seg'].clone(), o[3]['proj_feat'].clone()])
+    assert all(torch.equal(a, b) for a, b in zip(eager, ref[0][:-1]))          # (slot 0 holds imgs[0]: the time-tuned eager forward's bits)
     for rnd in range(5):
         for s in range(4):
             pipe.launch(s)
