@@ -16,13 +16,18 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides():
+@pytest.mark.parametrize('tuning', ['heuristic', 'throughput'])
+def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides(tuning):
     with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
     eng = DirEngine(sd, dtype=torch.bfloat16)
     gen = torch.Generator(device='cuda').manual_seed(3)
     img = torch.randn(64, 3, 256, 256, device='cuda', generator=gen)
+    if tuning == 'throughput':                             # the shipped table's kernel mix (256 x 256 tiles, halo reuse, streaming 1x1) beside the foreign kernel
+        eng.forward(img)
+        eng.autotune(img, reps=1)
+        assert eng.load_tuning_table(img, 'gfx950_bf16_b64_throughput') is not None
     pipe = ForwardPipeline(eng, [img])
     pipe.launch(0)
     o = pipe.wait(0)
