@@ -5,7 +5,7 @@ import os, sys, time, threading, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dir_amd import functional as F
-from bench import smi_sample
+from dir_amd.power import smi_sample
 
 L = [  # name, H, Cin, Cout, k, stride, residual
     ('l2.c2 3x3 128->128 @32', 32, 128, 128, 3, 1, 0),
