@@ -77,6 +77,7 @@ def power_probe(step, sync, seconds, steps_per_burst):
     if idle is None:
         return None
     smp = P.Sampler(skip=1.0, period=0.25).start()
+    e0 = P.energy_joules()                       # the socket's energy accumulator (amdsmi): exact joules over the window
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < seconds:
@@ -85,11 +86,14 @@ def power_probe(step, sync, seconds, steps_per_burst):
         sync()
         n += steps_per_burst
     dt = time.perf_counter() - t0
+    e1 = P.energy_joules()
     samples = smp.stop()
     if not samples:
         return None
     w = P.median(samples, 'w')
-    return {'socket_w': w, 'cap_w': idle['cap'], 'frac_of_cap': round(w / idle['cap'], 3) if idle['cap'] else None,
+    ec = None if not (e0 and e1) else {'socket_w': round((e1[0] - e0[0]) / dt, 1), 'joules_per_step': round((e1[0] - e0[0]) / n, 3),
+                                         'source': 'amdsmi energy accumulator over the whole window'}
+    return {'energy_counter': ec, 'socket_w': w, 'cap_w': idle['cap'], 'frac_of_cap': round(w / idle['cap'], 3) if idle['cap'] else None,
             'sclk_mhz': P.median(samples, 'sclk'), 'w_before_probe': idle['w'], 'samples': len(samples),
             'ms_per_step_during_probe': round(dt / n * 1e3, 3), 'joules_per_step': round(w * dt / n, 3),
             'source': 'rocm-smi --showpower --showclocks, median of samples taken while the timed loop ran again for %.0f s' % seconds}
@@ -321,7 +325,7 @@ def main():
         power = power_probe(step, sync, 4.0, 50)
         if power is not None and pipe is not None:
             p1 = power_probe(lat_graph.replay if lat_graph is not None else one_slot, sync, 3.0, 20)
-            power['one_in_flight'] = None if p1 is None else {k: p1[k] for k in ('socket_w', 'sclk_mhz', 'ms_per_step_during_probe', 'joules_per_step')}
+            power['one_in_flight'] = None if p1 is None else {k: p1[k] for k in ('socket_w', 'sclk_mhz', 'ms_per_step_during_probe', 'joules_per_step', 'energy_counter')}
 
     # ---- serving variant: the same step without the proj_feat output (335 MB of fp32 per step that apps/eval.py:170-172 never
     #      reads).  Reported beside the headline, never as `value`.

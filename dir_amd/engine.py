@@ -1202,13 +1202,15 @@ class DirEngine(object):
         self._tuned_order[B] = [op for op in best]          # first-call order of one forward: stable for a given engine
         return {op: v for op, (t, v) in best.items()}
 
-    def autotune_energy(self, img, seconds=0.8, slack=2.6, idle_w=None, log=None, max_calls=None):
+    def autotune_energy(self, img, seconds=None, slack=2.6, idle_w=None, log=None, max_calls=None):
         """The per-layer kernel choice for THROUGHPUT with several forwards in flight.  Four bs-64 forwards in flight run the socket at its
         power cap (1.3-1.4 kW of 1.4 kW, 2.9 J per forward), so what raises images/s is the variant that costs the fewest joules
         above idle, not the one that finishes first alone: typically a larger tile on fewer CUs (less L2 -> LDS and LDS -> register traffic
         per MFMA), the idle CUs being filled by the other forwards.  Every convolution call of one forward is captured and replayed back to
-        back on its real tensors, per variant, for `seconds` while rocm-smi is sampled (dir_amd/power.py); the choice minimises
-        time x (power - idle power) among the variants within `slack` x the fastest.  ~50 calls x ~10 variants x seconds: 5-8 minutes -- run it
+        back on its real tensors, per variant, for `seconds`, and its energy is read from the socket's energy accumulator (amdsmi: exact joules
+        over the window; default 0.2 s) or, where that is not available, from rocm-smi's averaged power sampled over the last 40 % of a longer
+        window (default 0.8 s: the reading lags by about a second); the choice minimises joules above idle per launch among the variants within
+        `slack` x the fastest.  ~50 calls x ~10 variants x seconds: 2 minutes with the counter, 5-8 without -- run it
         once per (GPU model, batch size) and keep export_tuning()'s table (dir_amd/tuning/, load_tuning_table).  Results stay bit-identical
         (same argument as autotune).  One forward alone gets ~15 % slower with this table: latency-bound callers keep autotune()."""
         import time as _time
@@ -1216,8 +1218,11 @@ class DirEngine(object):
         B = img.shape[0]
         if B not in getattr(self, '_tuned_order', {}):
             self.autotune(img)                                         # the time-tuned choice first: op order, and the fallback for every op not replayed here
-        if power.smi_sample() is None:
-            raise RuntimeError('autotune_energy: rocm-smi gives no power reading on this machine')
+        counter = power.energy_joules() is not None
+        if not counter and power.smi_sample() is None:
+            raise RuntimeError('autotune_energy: neither the amdsmi energy counter nor rocm-smi gives a reading on this machine')
+        if seconds is None:
+            seconds = 0.2 if counter else 0.8
         saved_overlap, self.overlap = self.overlap, False
         torch.cuda.synchronize(self.device)
         if idle_w is None:
@@ -1253,16 +1258,27 @@ class DirEngine(object):
                     if us > slack * tb:
                         continue
                     _TLS.variant = v
-                    smp = power.Sampler(skip=0.6 * seconds, period=0.03).start()       # the first 60 % still carries the previous variant's level
-                    t0, n = _time.perf_counter(), 0
-                    while _time.perf_counter() - t0 < seconds:
-                        for _ in range(100):
+                    burst = max(10, min(100, int(0.02 / (us * 1e-6))))                  # ~20 ms of launches between host synchronisations
+                    if counter:
+                        for _ in range(burst):                                          # the loop is already running when the counter is read
                             op(*args, **kw)
                         torch.cuda.synchronize(self.device)
-                        n += 100
+                        e0 = power.energy_joules()
+                    else:
+                        smp = power.Sampler(skip=0.6 * seconds, period=0.03).start()    # the first 60 % still carries the previous variant's level
+                    t0, n = _time.perf_counter(), 0
+                    while _time.perf_counter() - t0 < seconds:
+                        for _ in range(burst):
+                            op(*args, **kw)
+                        torch.cuda.synchronize(self.device)
+                        n += burst
                     dt = _time.perf_counter() - t0
-                    w = power.median(smp.stop(), 'w')
-                    if w == w:                                         # (NaN: no sample landed in the window -- variant not rated)
+                    if counter:
+                        e1 = power.energy_joules()
+                        w = (e1[0] - e0[0]) / dt if e0 and e1 else float('nan')
+                    else:
+                        w = power.median(smp.stop(), 'w')
+                    if w == w:                                         # (NaN: no reading in the window -- variant not rated)
                         row[v] = (dt / n * 1e6, w)
                 _TLS.variant = None
                 if not row:
@@ -1278,7 +1294,7 @@ class DirEngine(object):
         finally:
             _TLS.capture, _TLS.variant = None, None
             self.overlap = saved_overlap
-        return {'idle_w': idle_w, 'layers': rows}
+        return {'idle_w': idle_w, 'layers': rows, 'instrument': 'amdsmi energy accumulator, %.2f s windows' % seconds if counter else 'rocm-smi power, last 40 %% of %.2f s windows' % seconds}
 
     TUNING_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning')
 

@@ -1,5 +1,6 @@
-"""Socket power / shader clock of the visible GPU, read from `rocm-smi --json` (tuning and reporting aid: DirEngine.autotune(objective='energy'),
-bench.py's `power` object).  Nothing on the forward path imports this module."""
+"""Socket power / shader clock of the visible GPU from `rocm-smi --json`, and the socket's energy accumulator from the amdsmi Python binding
+(15.3 uJ counts: exact joules over a window, no averaging lag) -- tuning and reporting aids (DirEngine.autotune_energy, bench.py's `power`
+object).  Nothing on the forward path imports this module."""
 import json
 import shutil
 import statistics
@@ -52,3 +53,28 @@ class Sampler(object):
 
 def median(samples, key):
     return statistics.median(v[key] for v in samples) if samples else float('nan')
+
+
+_smi = None          # (module, handle) once initialised, False when unavailable
+
+
+def energy_joules():
+    """(joules accumulated by the socket's energy counter, its timestamp in seconds) from amdsmi, or None when the binding / the counter is
+    not available.  Differences of two readings are exact energies (counter resolution 15.3 uJ); the first visible GPU is read."""
+    global _smi
+    if _smi is None:
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            _smi = (amdsmi, hs[0]) if hs else False
+        except Exception:
+            _smi = False
+    if not _smi:
+        return None
+    try:
+        d = _smi[0].amdsmi_get_energy_count(_smi[1])
+        acc = d.get('energy_accumulator', d.get('power'))
+        return float(acc) * float(d['counter_resolution']) * 1e-6, float(d['timestamp']) * 1e-9
+    except Exception:
+        return None

@@ -38,3 +38,5 @@ def test_power_sampler_degrades_without_rocm_smi():
     assert isinstance(got, list) and (v is not None or got == [])
     assert power.median([], 'w') != power.median([], 'w')          # NaN
     assert power.median([{'w': 1.0}, {'w': 3.0}, {'w': 2.0}], 'w') == 2.0
+    e = power.energy_joules()                                         # the amdsmi energy accumulator: None without a GPU, else (joules, seconds)
+    assert e is None or (len(e) == 2 and e[0] >= 0)

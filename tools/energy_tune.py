@@ -2,14 +2,14 @@
 the socket power cap: DESIGN.md 9), by DirEngine.autotune_energy -- every convolution call of a bf16 forward at B = 64 replayed per variant
 while rocm-smi is sampled, the choice minimising time x (power - idle power).  Then the four-in-flight step with the time-tuned and the
 energy-tuned tables, alternating on the same four streams.
-usage (GPU box): python tools/energy_tune.py [seconds per (layer, variant) = 0.8] [rounds = 3]      -> gpurun_out/tuning/*.json (copy into dir_amd/tuning/)"""
+usage (GPU box): python tools/energy_tune.py [seconds per (layer, variant); 0 = default: 0.2 with the energy counter, 0.8 with rocm-smi] [rounds = 3]      -> gpurun_out/tuning/*.json (copy into dir_amd/tuning/)"""
 import json, os, subprocess, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import numpy as np, torch
 from dir_amd import engine as E, synth, power
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 0.8
+SECS = float(sys.argv[1]) if len(sys.argv) > 1 and float(sys.argv[1]) > 0 else None
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 MODE = os.environ.get('MODE', 'bf16')          # bf16 | f16x3 | f16 (the fp32-tensor modes: DirEngine(dtype=float32, arith=MODE))
 NAME = 'gfx950_%s_b64_throughput' % MODE
@@ -34,7 +34,7 @@ out = eng.forward(img)
 same = all(torch.equal(a, b) for a, b in zip(ref, [out[i]['pd_mesh_xyz_left'] for i in range(3)] + [out[3]['seg']]))
 print('outputs bit-identical to the untuned forward:', same)
 head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=ROOT).stdout.strip() or os.environ.get('DIR_HEAD', '')
-meta = {'made_by': 'tools/energy_tune.py %.2f' % SECS, 'objective': 'time x (socket power - idle power) per launch, rocm-smi, launches replayed back to back',
+meta = {'made_by': 'tools/energy_tune.py', 'instrument': rep['instrument'], 'objective': 'time x (socket power - idle power) per launch, launches replayed back to back',
         'device': torch.cuda.get_device_name(0), 'idle_w': rep['idle_w'], 'head': head, 'weights': 'dir_amd.synth seed 1234 (the choice depends on shapes only)',
         'changed_vs_time_tuned': sum(1 for a, b in zip(t_time, t_energy) if a[5] != b[5]), 'layers': rep['layers']}
 os.makedirs(os.path.join(ROOT, 'gpurun_out', 'tuning'), exist_ok=True)
@@ -62,12 +62,15 @@ def run(tag, table):
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / 60 * 1e3)
     smp = power.Sampler(skip=1.0, period=0.2).start()
+    e0 = power.energy_joules()
     t0, n = time.perf_counter(), 0
     while time.perf_counter() - t0 < 3.0:
         for _ in range(50):
             step()
         torch.cuda.synchronize(); n += 50
     dt = time.perf_counter() - t0
+    e1 = power.energy_joules()
+    wc = (e1[0] - e0[0]) / dt if e0 and e1 else float('nan')
     s = smp.stop()
     one = []
     for _ in range(3):
@@ -76,8 +79,8 @@ def run(tag, table):
             pipe.launch(0)
         torch.cuda.synchronize()
         one.append((time.perf_counter() - t0) / 10 * 1e3)
-    print('%-14s %d in flight %.3f ms (regions %s), 3 s run %.3f ms at %4.0f W %4.0f MHz; one in flight %.3f ms' % (
-        tag, NSLOT, statistics.median(res), ' '.join('%.3f' % r for r in res), dt / n * 1e3, power.median(s, 'w'), power.median(s, 'sclk'),
+    print('%-14s %d in flight %.3f ms (regions %s), 3 s run %.3f ms at %4.0f W (energy counter %4.0f W = %.3f J per step) %4.0f MHz; one in flight %.3f ms' % (
+        tag, NSLOT, statistics.median(res), ' '.join('%.3f' % r for r in res), dt / n * 1e3, power.median(s, 'w'), wc, wc * dt / n, power.median(s, 'sclk'),
         statistics.median(one)), flush=True)
 
 
