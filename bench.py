@@ -289,6 +289,10 @@ def main():
             ser.append((time.perf_counter() - t0) / 10 * 1e3)
         serial_tp_ms = statistics.median(ser)   # the timed graphs, one forward at a time
 
+    if pipe is not None:                       # settle: the table check above rebuilt and released graphs; a few untimed rounds before the caller's warm-up
+        for _ in range(3 * args.inflight):
+            step()
+        sync()
     for _ in range(args.warmup):
         step()
     regions = timed_regions(step, args.steps, max(1, args.repeats), barrier, mx, sync)
