@@ -431,6 +431,8 @@ class BneckChainOp(object):
         """x: the block input -- the identity residual, or (dual) the projection shortcut's source"""
         residual, x2 = (None, x) if self.dual is not None else (x, None)
         B, H, W, _ = y1.shape
+        if getattr(_TLS, 'capture_fused', None) is not None:       # tools/energy_profile.py: replayable (allocates its own outputs)
+            _TLS.capture_fused.append((self, (y1, x), {}))
         out = torch.empty(B, H, W, 256, device=y1.device, dtype=y1.dtype)
         y1n = torch.empty(B, H, W, self.c1n.cout, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
         if _capi.PROFILE is not None:
@@ -516,6 +518,8 @@ class BneckTailOp(object):
         """y2: conv2's output [B,H,W,P]; x: the block input [B,H,W,4P] (identity residual) -> (block output, next y1)"""
         B, H, W, P = y2.shape
         M = B * H * W
+        if getattr(_TLS, 'capture_fused', None) is not None:
+            _TLS.capture_fused.append((self, (y2, x), {}))
         out = torch.empty(B, H, W, self.c3.cout, device=y2.device, dtype=y2.dtype)
         y1n = torch.empty(B, H, W, self.c1n.cout, device=y2.device, dtype=y2.dtype)
         if _capi.PROFILE is not None:
