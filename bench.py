@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-proj-feat-variant', action='store_true', help='skip the serving variant without the proj_feat output')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images timed on the numpy CPU baseline')
     ap.add_argument('--cpu-threads', type=int, default=16)
+    ap.add_argument('--detail-out', default='bench_detail.json', help='the full measurement record (the last stdout line is its compact form)')
     ap.add_argument('--dump-conv', action='store_true', help='print per-shape timings of every library call (stderr)')
     return ap.parse_args(argv)
 
@@ -638,7 +639,18 @@ def main():
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
                 'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf}
-        print(json.dumps(line))
+        # the full record (per-kernel tables, notes, sub-mode rooflines) goes to a side file and to stderr; the LAST stdout line is the compact
+        # headline (dir_amd/benchline.py: <= 4 KB, every contract key + roofline + cpu_baseline) -- round 3's 20 KB line went unparsed
+        from dir_amd import benchline
+        detail_path = args.detail_out
+        try:
+            with open(os.path.join(ROOT, detail_path) if not os.path.isabs(detail_path) else detail_path, 'w') as f:
+                json.dump(line, f)
+        except OSError as e:
+            sys.stderr.write('bench.py: could not write %s: %s\n' % (detail_path, e))
+        sys.stderr.write(json.dumps(line) + '\n')
+        sys.stderr.flush()
+        print(json.dumps(benchline.compact(line, detail_path)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -95,7 +95,7 @@ class ConvOp(object):
         if self.arith in ('f16x3', 'f16'):  # fp32 tensors, f16 hi / lo split arithmetic ('f16': hi only): weights split + pre-scaled here, 1 / p_n into the scale
             from .functional import pack_f16x3_weights
             self.w, scale = pack_f16x3_weights(self.w.reshape(self.cout, -1), scale)
-            self.scale0 = scale.float().contiguous()          # the epilogue scale at in_scale = 1
+            self.scale0 = scale.float().contiguous().clone()  # the epilogue scale at in_scale = 1 (a copy: set_in_scale overwrites self.scale in place)
         self.scale = None if scale is None else scale.float().contiguous()
         self.shift = None if shift is None else shift.float().contiguous()
         self.pre_scale, self.pre_shift = (None, None) if pre is None else (pre[0].contiguous(), pre[1].contiguous())
