@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 29          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 30          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -117,6 +117,7 @@ _SIGNATURES = {
     'dir_launch_log_reset': (None, []),
     'dir_launch_log_get': (C.c_int, [C.c_char_p, _i]),
     'dir_launch_log_note': (None, [C.c_char_p, C.c_longlong]),
+    'dir_probe_launch': (C.c_longlong, [_i, _p, C.c_longlong, _i, _p]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),

@@ -2,14 +2,14 @@
 
 Round 3's line had grown to 20 KB (three per-kernel tables, the power object, four sub-mode records) and no longer fitted the window the
 driver reads bench.py's stdout through: the record was unparsed.  bench.py now writes the full record to `bench_detail.json` (and to
-stderr) and prints `compact(detail)` -- at most LIMIT characters, every contract key of SURVEY.md section 8(d) / BASELINE.md section 4
+stderr) and prints `compact(detail)` -- at most LIMIT (5000) characters, every contract key of SURVEY.md section 8(d) / BASELINE.md section 4
 plus `roofline` and `cpu_baseline` and one-number summaries of the sub-modes -- as the LAST stdout line.
 
 Pure host logic (no torch, no GPU): tests/test_benchline.py holds it to round 3's kept 20 KB record.
 """
 import json
 
-LIMIT = 4000        # characters of json.dumps(compact(detail)); the driver's window is 8000
+LIMIT = 5000        # characters of json.dumps(compact(detail)); the driver parsed 6.9 KB in round 2 and lost 20 KB in round 3 (its window: 8000)
 
 _TOP = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
 _CONFIG = ('workload', 'batch_per_gpu', 'graph', 'forwards_in_flight', 'ms_per_forward_one_in_flight', 'conv_tuning', 'tunings_bit_identical',
@@ -66,6 +66,9 @@ def compact(detail, detail_path='bench_detail.json'):
         ov = roof.get('overlapped')
         if ov:
             r['overlapped'] = _pick(ov, ('achieved', 'unit', 'frac'))
+        mc = roof.get('measured_ceilings')
+        if mc:
+            r['measured_ceilings'] = {k: v for k, v in mc.items() if k != 'source'}
         tk = roof.get('token_path')
         if tk:
             r['token_path'] = tk

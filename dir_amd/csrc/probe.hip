@@ -1,0 +1,92 @@
+// Measurement aid (bench.py `roofline.measured_ceilings`): what THIS board sustains, measured inside the bench run
+// instead of quoted from another box.  Two loops, launched back to back by the caller for about a second each:
+//   mode 0  bf16 MFMA, operands in registers: 16 x v_mfma_f32_32x32x16_bf16 per wave and iteration on pseudo-random bf16 data (2 x 2 tiles
+//           of 32 x 32 per wave: the arithmetic of a 64 x 64 wave tile), 8 waves per workgroup, one workgroup per CU.  Random data matters:
+//           on all-zero operands the same loop runs 1.4x faster (the board's power / current limits pull the clock on real data).
+//   mode 1  HBM read: 16-byte loads streaming `bytes` of `buf` (make it larger than the 256 MB Infinity Cache).
+// Nothing in the product path calls this.
+#include "dir_common.h"
+
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+
+__global__ __launch_bounds__(512, 1) void probe_mfma_kernel(int iters, float* sink) {
+    const unsigned t = blockIdx.x * 512u + threadIdx.x;
+    u32x4 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // bf16 pairs in [1, 2) with pseudo-random mantissas and signs: finite sums, every operand bit toggling
+            unsigned h = (t * 8u + i * 4u + q) * 2654435761u;
+            u32x4 v, w;
+            v.x = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            v.y = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            v.z = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            v.w = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            w.x = 0x3c003c00u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            w.y = 0x3c003c00u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            w.z = 0x3c003c00u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
+            w.w = 0x3c003c00u ^ (h & 0x807f807fu);
+            fa[i][q] = v; fb[i][q] = w;
+        }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]), __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    if (s == 1.2345f) sink[0] = s;
+}
+
+__global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict__ p, size_t n, unsigned* sink) {
+    unsigned acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+}  // namespace
+
+extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int iters, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!buf || bytes < 64) { dir::set_error("dir_probe_launch: need a device buffer of at least 64 bytes"); return DIR_E_INVALID; }
+    if (mode == 0) {
+        if (iters <= 0) { dir::set_error("dir_probe_launch: iters must be positive"); return DIR_E_INVALID; }
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(probe_mfma_kernel, dim3(ncu), dim3(512), 0, s, iters, (float*)buf);
+        if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
+        return (long long)ncu * 8 * 16 * 32768LL * iters;               // FLOPs of this launch: CUs x waves x MFMAs x 2*32*32*16
+    }
+    if (mode == 1) {
+        const size_t n = (size_t)bytes / 16;
+        hipLaunchKernelGGL(probe_read_kernel, dim3(4096), dim3(256), 0, s, (const uint4*)buf, n, (unsigned*)buf);
+        if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
+        const size_t stride = 4096ull * 256, groups = n / (4 * stride);
+        return (long long)(groups * 4 * stride * 16);                    // bytes the loop really reads
+    }
+    dir::set_error("dir_probe_launch: mode must be 0 (bf16 MFMA) or 1 (HBM read)");
+    return DIR_E_INVALID;
+}

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 29
+#define DIR_ABI_VERSION 30
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -43,6 +43,11 @@ int dir_launch_log_get(char* buf_host, int len);
 /* as if `times` launches of kernel `name` had been noted: the counter dir_launch_log_get() returns SATURATES at INT_MAX (a serving process
  * never resets it), only the first 32 names since the last reset are kept.  Used by the CPU tests; launches nothing. */
 void dir_launch_log_note(const char* name, long long times);
+/* Measurement aid (bench.py `roofline.measured_ceilings`; nothing in the reference, nothing in the product path): ONE launch of a ceiling probe
+ * on `stream`.  mode 0: bf16 MFMA loop on pseudo-random operands held in registers (16 x v_mfma_f32_32x32x16_bf16 per wave and iteration, 8 waves
+ * per CU, every CU), `iters` iterations; mode 1: 16-byte loads streaming `bytes` of `buf` (larger than the Infinity Cache to price HBM).  `buf`: any
+ * device buffer >= 64 bytes (mode 0 only needs a sink).  Returns the FLOPs (mode 0) / bytes (mode 1) the launch performs, negative = error code. */
+long long dir_probe_launch(int mode, void* buf, long long bytes, int iters, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * a8 + a9: MANO forward + weak-perspective projection
