@@ -61,6 +61,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-ceiling-probe', action='store_true', help='skip the in-run MFMA / HBM ceiling probe (2 s, outside the timed regions)')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi socket power probe (7 s, outside the timed regions)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
+    ap.add_argument('--no-config5', action='store_true', help='skip the BASELINE configs[4] (HRNet-W48, 32 per GPU) sub-record')
     ap.add_argument('--no-train', action='store_true', help='skip the training-step sub-record (batch 32, fp32)')
     ap.add_argument('--no-proj-feat-variant', action='store_true', help='skip the serving variant without the proj_feat output')
     ap.add_argument('--cpu-sample', type=int, default=32, help='images timed on the numpy CPU baseline')
@@ -549,6 +550,61 @@ def main():
                           'rounded to f16 (one MFMA per product, fp32 accumulate); all three stages within 0.01 mm of the reference on trained-like '
                           'weights (init 0.007 mm, refined 0.0003 - 0.001 mm; bf16: 0.05 / 0.005); roofline priced against the dense f16 peak')
 
+    # ---- BASELINE configs[4] on one GPU: HRNet-W48 + init regression + 4 refinement stages ("5 refinement iters"), 32 images per GPU (batch 256
+    #      over 8), in bf16 and in the arithmetic the config names (fp16 MFMA path: fp32 feature maps, f16 operands); graph + live autotune +
+    #      the same forwards in flight as the headline.  No reference counterpart: parity is pinned to the build's oracle.
+    cfg5 = None
+    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_config5 and not args.no_graph:
+        from dir_amd.models.dir import DIR as _DIR
+        torch.cuda.empty_cache()
+        net5 = _DIR(21, 'x', 0, backbone='hrnet_w48', extra_stages=2)
+        shapes5 = {k: tuple(v.shape) for k, v in net5.state_dict().items()}
+        del net5
+        sd5 = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes5, 1234, cond=True).items()}
+        B5, nslot = 32, max(1, min(args.inflight, 4))
+        imgs5 = [torch.randn(B5, 3, 256, 256, device=dev, generator=g) for _ in range(nslot)]
+        cfg5 = {'batch_per_gpu': B5, 'forwards_in_flight': nslot, 'workload': 'BASELINE configs[4] per GPU: HRNet-W48 + init regression + 4 refinement stages, 32 images'}
+        for tag, dt5, ar5 in (('bf16', torch.bfloat16, None), ('fp16', torch.float32, 'f16')):
+            e5 = E.DirEngine(sd5, dtype=dt5, device=dev, arith=ar5)
+            e5.calibrate(imgs5[0])
+            e5.forward(imgs5[0])
+            sync()
+            if not args.no_autotune:
+                e5.autotune(imgs5[0], reps=1)
+            if tag == 'bf16':          # share of the convolutions' MFMA work spent on zero-padded channels (widths 48 / 96 run as 64 / 128)
+                e5.overlap = False
+                _capi.PROFILE = []
+                e5.forward(imgs5[0])
+                sync()
+                recs5, _capi.PROFILE = _capi.PROFILE, None
+                ex5 = sum(r.get('flops', 0.0) for r in recs5 if r.get('family') == 'conv')
+                re5 = sum(r.get('flops_real', r.get('flops', 0.0)) for r in recs5 if r.get('family') == 'conv')
+                cfg5['pad_waste'] = round(1.0 - re5 / ex5, 3)
+                cfg5['launches_per_step'] = len(recs5)
+                cfg5['conv_gflop_per_image_executed'] = round(ex5 / B5 / 1e9, 1)
+            p5 = E.ForwardPipeline(e5, imgs5)
+            c5 = [0]
+
+            def step5():
+                p5.launch(c5[0] % nslot)
+                c5[0] += 1
+            for _ in range(2 * nslot):
+                step5()
+            sync()
+            r5 = timed_regions(step5, 10, 3, sync, float, sync)
+            d5 = statistics.median(r5)
+            for _ in range(2):
+                p5.launch(0)
+            sync()
+            r51 = timed_regions(lambda: p5.launch(0), 5, 3, sync, float, sync)
+            key = 'images_per_sec' if tag == 'bf16' else 'fp16_images_per_sec'
+            cfg5[key] = round(B5 * 10 / d5, 1)
+            cfg5['ms_per_step' if tag == 'bf16' else 'fp16_ms_per_step'] = round(d5 / 10 * 1e3, 3)
+            cfg5['ms_per_forward_one_in_flight' if tag == 'bf16' else 'fp16_ms_per_forward_one_in_flight'] = round(statistics.median(r51) / 5 * 1e3, 3)
+            del p5, e5
+            torch.cuda.empty_cache()
+        del sd5, imgs5
+
     # ---- training step (BASELINE config 4's per-GPU batch: 32 images, fp32, the whole network: forward in training mode, 42-term
     #      objective, backward, flat gradient bucket, one AdamW launch -- dir_amd/train/step.py); rank 0, single-GPU runs only
     train = None
@@ -659,7 +715,7 @@ def main():
                            'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
-                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf}
+                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf, 'config5_hrnet': cfg5}
         # the full record (per-kernel tables, notes, sub-mode rooflines) goes to a side file and to stderr; the LAST stdout line is the compact
         # headline (dir_amd/benchline.py: <= 4 KB, every contract key + roofline + cpu_baseline) -- round 3's 20 KB line went unparsed
         from dir_amd import benchline

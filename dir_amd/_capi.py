@@ -153,6 +153,8 @@ _SIGNATURES = {
                                           C.POINTER(TokenMlp), C.POINTER(TokenMlp), _p, _p, _i, _p]),
     'dir_pgcn_stack_forward': (C.c_int, [C.POINTER(PgcnLayer), _i, _p, _p, _p, C.c_longlong, _p, _i, _p]),
     'dir_pgcn_stack_forward_pair': (C.c_int, [C.POINTER(PgcnLayer), C.POINTER(PgcnLayer), _i, _p, _p, _p, _p, _i, _p]),
+    'dir_pgcn_fused_sync_bytes': (C.c_longlong, []),
+    'dir_pgcn_stack_forward_fused': (C.c_int, [C.POINTER(PgcnLayer), C.POINTER(PgcnLayer), _i, _p, _p, _p, _p, _p, _i, _i, _p]),
     'dir_ste_forward': (C.c_int, [C.POINTER(SteParams), _p, _p, _p, _i, _p]),
     'dir_regress_forward': (C.c_int, [C.POINTER(RegressParams), _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     'dir_bone_fusion_scratch_bytes': (C.c_size_t, [_i]),

@@ -429,6 +429,259 @@ __global__ __launch_bounds__(256) void pgcn_mix_kernel(MixArgs args) {
     *reinterpret_cast<float4*>(a.out + (long long)b * args.out_bstride + j * 128 + cq) = o;
 }
 
+// --------------------------------------------------------------------------------------------- P-GCN, the whole stack in ONE launch
+// the 4-layer stack of both hands cost five launches of ~7 us each (35.6 us at B = 64), every one of them far below
+// a launch's worth of work (1.4 MB of weights per hand and layer).  Here the layers are separated by per-node FLAGS instead of launches:
+//   * one PERSISTENT workgroup per (hand, node j, batch split s): it runs all layers of its node for its share of the 16-sample chunks;
+//     layer l's W0[j] | W1[j] go straight to MFMA B-operand registers and are requested BEFORE the workgroup waits for its neighbours,
+//     so the weight stream (the algorithmic bytes of this operator) is never on the critical path after layer 0;
+//   * layer l of node j needs layer l-1 of j itself and of its <= 5 skeleton neighbours, nothing else: each workgroup publishes one flag
+//     per layer (flags[l][hand][j][s] = launch epoch + 1) after its h rows are out, and polls the <= 6 flags it depends on -- a dataflow
+//     over the hand skeleton, not a grid barrier (the thumb tip never waits for the little finger);
+//   * h rows and flags cross XCDs (one non-coherent L2 each): they are written / read as relaxed AGENT-scope atomics (sc1 accesses that go
+//     to the device-coherent level) ordered by hand -- vmcnt(0), workgroup barrier, then one lane stores the flag (the split-K idiom of
+//     conv.hip); weights, parameters, the stack input and its output are ordinary accesses;
+//   * flags are never reset: every launch raises each flag it owns by one, and a workgroup reads its own flags' values at entry (the
+//     launch epoch) before it publishes anything -- the sync words only have to start at zero once (HIP-graph replays carry no
+//     per-launch argument);
+//   * forward progress: all 42 x S workgroups of a launch must become resident while the others spin.  Kernels of other kinds always finish
+//     and free their CUs; what must never happen is the chip filling up with PARTLY resident launches of this kernel from several streams.
+//     Occupancy is pinned (bf16 weights: 4 waves per SIMD = 2 workgroups per CU = 512 on the chip; fp32: 3 waves per SIMD = 1 per CU = 256)
+//     and the default S (bf16 2 -> 84 workgroups, fp32 1 -> 42) keeps SIX concurrent launches inside that; a caller that knows it runs
+//     fewer streams may pass more splits.  A poll that sees nothing for ~1 s gives up, raises the error word
+//     (sync[PGF_ERR_WORD]) and lets the kernel end -- wrong tokens, never a hung queue.
+// Arithmetic per output element is that of pgcn_node_kernel + pgcn_mix_kernel (same fmaf chains, same k order): bit-identical results
+// (tests/test_gpu_tokens.py::test_pgcn_fused_equals_layered).
+constexpr int PGF_MAXL = 4, PGF_MAXS = 8;
+constexpr int PGF_ERR_WORD = PGF_MAXL * 2 * NJ * PGF_MAXS;           // sync words: flags [l][hand][node][split] | error word
+struct PgcnFusedHand {
+    const float* W[PGF_MAXL]; const float* e1[PGF_MAXL]; const float* bias[PGF_MAXL]; const float* bns[PGF_MAXL]; const float* bnb[PGF_MAXL];
+    int relu[PGF_MAXL];
+    const float* x_in; const float* add; float* out; float* hbuf[2];
+};
+struct PgcnFusedArgs {
+    PgcnFusedHand h[2];
+    int B, nchunk, S, L;
+    long long out_bstride;
+    unsigned* sync;
+    long long* stamps;
+};
+
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float4 ld_dev4(const float* p) { return make_float4(ld_dev(p), ld_dev(p + 1), ld_dev(p + 2), ld_dev(p + 3)); }
+
+template <bool WBF16>
+__device__ __forceinline__ void pgcn_fused_body(const PgcnFusedArgs& args) {
+    __shared__ float s_x[2][PG_BC * PG_LD];
+    __shared__ float s_adj[8];
+    __shared__ int s_nidx[8];
+    __shared__ unsigned s_epoch[PGF_MAXL];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = args.S, sp = blockIdx.x % S, pj = blockIdx.x / S, hand = pj / NJ, j = pj - hand * NJ;
+    const PgcnFusedHand& a = args.h[hand];
+    int nstamp = 0;
+    auto stamp = [&]() { if (args.stamps && blockIdx.x == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) args.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
+    auto flag = [&](int l, int node) -> unsigned* { return args.sync + ((l * 2 + hand) * NJ + node) * PGF_MAXS + sp; };
+    if (tid < args.L) s_epoch[tid] = __hip_atomic_load(flag(tid, j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // before anything is published
+
+    const int half = wave >> 2, ncol0 = (wave & 3) * 32, li = lane & 15, lk = lane >> 4;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+    bf16x8_t bw[WBF16 ? 2 : 1][WBF16 ? 4 : 1];
+    float bv[WBF16 ? 1 : 2][WBF16 ? 1 : 32];
+    const int bb = tid >> 5, cq = (tid & 31) * 4;          // mix role: sample bb of the chunk, channels cq .. cq+3
+
+    // waits until node j's and its neighbours' rows of layer `l` are out (lanes 0..5 of wave 0 poll one flag each), then the workgroup meets
+    auto wait_layer = [&](int l) {
+        if (tid < 6) {
+            const int o0 = kNbrOff[j], deg = kNbrOff[j + 1] - o0;
+            const int node = tid == 0 ? j : (tid - 1 < deg ? kNbrIdx[o0 + tid - 1] : j);
+            const unsigned want = s_epoch[l] + 1u;
+            const unsigned* f = flag(l, node);
+            int spins = 0;
+            while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 20)) { __hip_atomic_store(args.sync + PGF_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+    };
+    // row j of softmax(A_1) of layer `l` (padded to 5 terms: every gather is unconditional) -> LDS
+    auto adjacency = [&](int l) {
+        if (tid == 0) {
+            float wgt[5]; int nidx[5]; int deg = 0;
+            edge_softmax_row(a.e1[l], j, wgt, nidx, deg);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { s_adj[t] = t < deg ? wgt[t] : 0.f; s_nidx[t] = t < deg ? nidx[t] : j; }
+        }
+    };
+
+    for (int l = 0; l < args.L; ++l) {
+        // ---- this layer's weight fragments -> registers, requested before the wait below
+        if constexpr (WBF16) {
+            const unsigned short* w = reinterpret_cast<const unsigned short*>(a.W[l]) + (((long long)half * NJ + j) * 128 + ncol0 + li) * 128 + lk * 8;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bw[t][kk] = *reinterpret_cast<const bf16x8_t*>(w + t * 16 * 128 + kk * 32);
+        } else {
+            const float* w = a.W[l] + ((long long)half * NJ + j) * 128 * 128 + ncol0 + li;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) bv[t][kk] = w[(4 * kk + lk) * 128 + t * 16];
+        }
+        float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), ps = make_float4(1.f, 1.f, 1.f, 1.f), pn = pb;
+        int relu_prev = 0;
+        if (l) {
+            adjacency(l - 1);
+            pb = *reinterpret_cast<const float4*>(a.bias[l - 1] + cq);
+            ps = *reinterpret_cast<const float4*>(a.bns[l - 1] + cq);
+            pn = *reinterpret_cast<const float4*>(a.bnb[l - 1] + cq);
+            relu_prev = a.relu[l - 1];
+            wait_layer(l - 1);                    // (its barrier also publishes s_adj / s_nidx; layer 0: s_epoch is ordered by the first chunk's barrier)
+        }
+        const float* h_prev = l ? a.hbuf[(l - 1) & 1] : nullptr;
+        float* h_out = a.hbuf[l & 1];
+        float wgt[5]; int nidx[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { wgt[t] = l ? s_adj[t] : 0.f; nidx[t] = l ? s_nidx[t] : j; }
+
+        float4 self, nbv[5];
+        auto gather = [&](int chunk) {
+            const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
+            const long long b = b0 + min(bb, nb - 1);
+            if (!h_prev) self = *reinterpret_cast<const float4*>(a.x_in + (b * NJ + j) * 128 + cq);
+            else {
+                const float* hb = h_prev + b * NJ * 256;
+                self = ld_dev4(hb + j * 256 + cq);
+#pragma unroll
+                for (int t = 0; t < 5; ++t) nbv[t] = ld_dev4(hb + nidx[t] * 256 + 128 + cq);
+            }
+        };
+        auto mix1 = [&](float sv, float n0, float n1, float n2, float n3, float n4, float b_, float s_, float h_) -> float {
+            float acc = 0.f;
+            acc = fmaf(wgt[0], n0, acc); acc = fmaf(wgt[1], n1, acc); acc = fmaf(wgt[2], n2, acc);
+            acc = fmaf(wgt[3], n3, acc); acc = fmaf(wgt[4], n4, acc);
+            float v = sv + acc + b_;
+            v = fmaf(v, s_, h_);
+            return relu_prev ? fmaxf(v, 0.f) : v;
+        };
+        auto mix_store = [&](int chunk, int buf) {
+            const int nb = min(PG_BC, args.B - chunk * PG_BC);
+            float4 v = self;
+            if (h_prev) {
+                v.x = mix1(self.x, nbv[0].x, nbv[1].x, nbv[2].x, nbv[3].x, nbv[4].x, pb.x, ps.x, pn.x);
+                v.y = mix1(self.y, nbv[0].y, nbv[1].y, nbv[2].y, nbv[3].y, nbv[4].y, pb.y, ps.y, pn.y);
+                v.z = mix1(self.z, nbv[0].z, nbv[1].z, nbv[2].z, nbv[3].z, nbv[4].z, pb.z, ps.z, pn.z);
+                v.w = mix1(self.w, nbv[0].w, nbv[1].w, nbv[2].w, nbv[3].w, nbv[4].w, pb.w, ps.w, pn.w);
+            }
+            if (bb >= nb) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float* d = s_x[buf] + bb * PG_LD + cq;
+            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        };
+
+        int buf = 0;
+        if (sp < args.nchunk) gather(sp);
+        for (int chunk = sp; chunk < args.nchunk; chunk += S, buf ^= 1) {
+            mix_store(chunk, buf);
+            __syncthreads();
+            if (chunk + S < args.nchunk) gather(chunk + S);
+            const float* sx = s_x[buf];
+            f32x4 acc[2];
+            acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (WBF16) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float2* ap = reinterpret_cast<const float2*>(sx + li * PG_LD + kk * 32 + lk * 8);
+                    bf16x8_t av;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float2 t = ap[e];
+                        av[2 * e] = (__bf16)t.x;
+                        av[2 * e + 1] = (__bf16)t.y;
+                    }
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[0][kk], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[1][kk], acc[1], 0, 0, 0);
+                }
+            } else {
+                const float* ap = sx + li * PG_LD + lk;
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    const float av = ap[4 * kk];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[0][kk], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[1][kk], acc[1], 0, 0, 0);
+                }
+            }
+            const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = lk * 4 + r;
+                if (row < nb) {
+                    float* hb = h_out + ((long long)(b0 + row) * NJ + j) * 256 + half * 128 + ncol0 + li;
+                    st_dev(hb, acc[0][r]);
+                    st_dev(hb + 16, acc[1][r]);
+                }
+            }
+        }
+        // ---- publish: every wave's rows are out (vmcnt(0)), the workgroup meets, one lane raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flag(l, j), s_epoch[l] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stamp();
+    }
+
+    // ---- the last layer's mix (pgcn_mix_kernel's arithmetic): out[b][j][:] = relu(bn(h0 + A1 h1 + bias)) (+ add)
+    const int lz = args.L - 1;
+    adjacency(lz);
+    wait_layer(lz);
+    {
+        const float4 bi = *reinterpret_cast<const float4*>(a.bias[lz] + cq), sc = *reinterpret_cast<const float4*>(a.bns[lz] + cq),
+                     sh = *reinterpret_cast<const float4*>(a.bnb[lz] + cq);
+        const int o0 = kNbrOff[j], deg = kNbrOff[j + 1] - o0;
+        float wgt[5]; int nidx[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) { wgt[t] = s_adj[t]; nidx[t] = s_nidx[t]; }
+        const int relu = a.relu[lz];
+        const float* hz = a.hbuf[lz & 1];
+        for (int chunk = sp; chunk < args.nchunk; chunk += S) {
+            const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
+            if (bb >= nb) continue;
+            const long long b = b0 + bb;
+            const float* hb = hz + b * NJ * 256;
+            float4 nv[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) nv[t] = ld_dev4(hb + nidx[t] * 256 + 128 + cq);
+            const float4 self = ld_dev4(hb + j * 256 + cq);
+            float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.add) ad = *reinterpret_cast<const float4*>(a.add + (b * NJ + j) * 128 + cq);
+            auto one = [&](float sv, float n0, float n1, float n2, float n3, float n4, float b_, float s_, float h_, float ad_) -> float {
+                float acc = 0.f;
+                const float n[5] = {n0, n1, n2, n3, n4};
+#pragma unroll
+                for (int t = 0; t < 5; ++t) acc = t < deg ? fmaf(wgt[t], n[t], acc) : acc;
+                float v = sv + acc + b_;
+                v = fmaf(v, s_, h_);
+                if (relu) v = fmaxf(v, 0.f);
+                if (a.add) v += ad_;
+                return v;
+            };
+            float4 o;
+            o.x = one(self.x, nv[0].x, nv[1].x, nv[2].x, nv[3].x, nv[4].x, bi.x, sc.x, sh.x, ad.x);
+            o.y = one(self.y, nv[0].y, nv[1].y, nv[2].y, nv[3].y, nv[4].y, bi.y, sc.y, sh.y, ad.y);
+            o.z = one(self.z, nv[0].z, nv[1].z, nv[2].z, nv[3].z, nv[4].z, bi.z, sc.z, sh.z, ad.z);
+            o.w = one(self.w, nv[0].w, nv[1].w, nv[2].w, nv[3].w, nv[4].w, bi.w, sc.w, sh.w, ad.w);
+            *reinterpret_cast<float4*>(a.out + b * args.out_bstride + j * 128 + cq) = o;
+        }
+    }
+    stamp();
+}
+// occupancy is part of the forward-progress argument above, so it is pinned (second argument: waves per SIMD): bf16 weights 128 VGPRs, fp32 168, no spills
+__global__ __launch_bounds__(PG_T, 4) void pgcn_fused_bf16_kernel(PgcnFusedArgs args) { pgcn_fused_body<true>(args); }
+__global__ __launch_bounds__(PG_T, 3) void pgcn_fused_f32_kernel(PgcnFusedArgs args) { pgcn_fused_body<false>(args); }
+
 // --------------------------------------------------------------------------------------------- regressor
 struct RegArgs {
     dir_regress_params p;
@@ -622,6 +875,44 @@ extern "C" int dir_pgcn_stack_forward_pair(const dir_pgcn_layer* layers_left, co
     float* op[2] = {tokens, tokens + NJ * 128};
     float* sp[2] = {scratch, scratch + 2 * (long long)B * NJ * 256};
     return pgcn_run(lp, 2, num_layers, xp, add_lr ? ap : nullptr, op, 42 * 128, sp, B, (hipStream_t)stream);
+}
+
+extern "C" long long dir_pgcn_fused_sync_bytes(void) { return (long long)(PGF_ERR_WORD + 4) * sizeof(unsigned); }
+
+extern "C" int dir_pgcn_stack_forward_fused(const dir_pgcn_layer* layers_left, const dir_pgcn_layer* layers_right, int num_layers,
+                                            const float* x_lr, const float* add_lr, float* tokens, float* scratch, void* sync_ws,
+                                            int splits, int B, void* stream) {
+    DIR_REQUIRE(layers_left && layers_right && x_lr && tokens && scratch && sync_ws, "dir_pgcn_stack_forward_fused: null pointer");
+    DIR_REQUIRE(B > 0 && num_layers >= 1 && num_layers <= PGF_MAXL && splits >= 0 && splits <= PGF_MAXS, "dir_pgcn_stack_forward_fused: bad arguments");
+    const long long hs = (long long)B * NJ * 128;
+    const dir_pgcn_layer* lp[2] = {layers_left, layers_right};
+    PgcnFusedArgs a;
+    a.B = B; a.nchunk = (B + PG_BC - 1) / PG_BC; a.L = num_layers; a.out_bstride = 42 * 128; a.sync = (unsigned*)sync_ws;
+    bool wbf16 = false;
+    for (int h = 0; h < 2; ++h) {
+        PgcnFusedHand& g = a.h[h];
+        for (int l = 0; l < PGF_MAXL; ++l) {
+            const dir_pgcn_layer& L = lp[h][l < num_layers ? l : 0];
+            DIR_REQUIRE(L.W && L.e1 && L.bias && L.bn_scale && L.bn_shift, "dir_pgcn_stack_forward_fused: null layer parameter");
+            DIR_REQUIRE(L.w_dtype == DIR_DT_F32 || L.w_dtype == DIR_DT_BF16, "dir_pgcn_stack_forward_fused: w_dtype must be f32 or bf16");
+            if (h == 0 && l == 0) wbf16 = L.w_dtype == DIR_DT_BF16;
+            DIR_REQUIRE((L.w_dtype == DIR_DT_BF16) == wbf16, "dir_pgcn_stack_forward_fused: every layer of both hands must use the same weight dtype");
+            g.W[l] = L.W; g.e1[l] = L.e1; g.bias[l] = L.bias; g.bns[l] = L.bn_scale; g.bnb[l] = L.bn_shift; g.relu[l] = L.relu;
+        }
+        g.x_in = x_lr + h * hs; g.add = add_lr ? add_lr + h * hs : nullptr; g.out = tokens + h * NJ * 128;
+        g.hbuf[0] = scratch + (long long)h * 2 * B * NJ * 256; g.hbuf[1] = g.hbuf[0] + (long long)B * NJ * 256;
+    }
+    // batch splits per node: bounded so that six such launches on six streams stay co-resident (see the kernel's header comment)
+    int S = splits ? splits : (wbf16 ? 2 : 1);
+    if (const char* e = getenv("DIR_PGCN_SPLITS")) { const int v = atoi(e); if (v >= 1 && v <= PGF_MAXS) S = v; }
+    if (S > a.nchunk) S = a.nchunk;
+    a.S = S;
+    hipStream_t s = (hipStream_t)stream;
+    a.stamps = dir::stamps_begin("pgcn_fused");
+    if (wbf16) DIR_LAUNCH(pgcn_fused_bf16_kernel, dim3(2 * NJ * S), dim3(PG_T), 0, s, a);
+    else DIR_LAUNCH(pgcn_fused_f32_kernel, dim3(2 * NJ * S), dim3(PG_T), 0, s, a);
+    dir::stamps_end("pgcn_fused", a.stamps, s);
+    return dir::check_launch("dir_pgcn_stack_forward_fused");
 }
 
 extern "C" int dir_regress_forward(const dir_regress_params* p, const float* tok, const float* prev_para_left,

@@ -185,7 +185,7 @@ class ConvOp(object):
         if _capi.PROFILE is not None:
             nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
                       + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
-            _capi.annotate(family='conv', flops=2.0 * B * ho * wo * self.cout * self.alg_k, bytes=nbytes, op=self,
+            _capi.annotate(family='conv', flops=2.0 * B * ho * wo * self.cout * self.alg_k, bytes=nbytes, op=self, flops_real=2.0 * B * ho * wo * self.cout * self.alg_k * getattr(self, 'alg_scale', 1.0),
                            dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),
                            shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
                                                               self.kw, self.stride))
@@ -696,7 +696,9 @@ def _pad_conv_bn(sd, conv_key, bn_prefix, dtype, stride=1, relu=True):
     sc, sh = bn_fold(sd, bn_prefix)
     scp, shp = torch.zeros(_padc(co), device=w.device), torch.zeros(_padc(co), device=w.device)
     scp[:co], shp[:co] = sc.to(w.device), sh.to(w.device)
-    return ConvOp(wp, dtype, stride=stride, pad=kh // 2, scale=scp, shift=shp, relu=relu)
+    op = ConvOp(wp, dtype, stride=stride, pad=kh // 2, scale=scp, shift=shp, relu=relu)
+    op.alg_scale = (co * ci) / float(_padc(co) * _padc(ci))      # share of the launch's MFMA work that multiplies real channels (bench.py: pad_waste)
+    return op
 
 
 class HRNetOp(object):
@@ -950,6 +952,7 @@ class DirEngine(object):
         self.dtype, self.device = dtype, torch.device(device)
         sd = {k: v.detach().to(self.device) for k, v in state_dict.items()}
         self.keep = []
+        self._pgcn_ws = {}
         _TLS.arith = arith
         try:
             self._pack(sd, root_joint)
@@ -1064,8 +1067,12 @@ class DirEngine(object):
         wes = 2 if self.dtype == torch.bfloat16 else 4
         _ann('pgcn', 2.0 * 4 * 2 * B * 21 * 2 * 128 * 128, 4 * 2 * (2 * 21 * 128 * 128 * wes + 2 * B * 21 * 128 * 4),
              'B=%d 4 layers x 2 hands (per-node W0/W1 %s + neighbour mix + BN + ReLU)' % (B, 'bf16' if wes == 2 else 'f32'))
-        _capi.check(L.dir_pgcn_stack_forward_pair(st.gcn[0], st.gcn[1], 4, _capi.ptr(x0), _capi.ptr(gp), _capi.ptr(tok),
-                                                  _capi.ptr(scratch), B, sp), 'dir_pgcn_stack_forward_pair')
+        if self.pgcn_fused:      # the whole stack of both hands in one launch, layers separated by per-node flags (tokens.hip: pgcn_fused_kernel)
+            _capi.check(L.dir_pgcn_stack_forward_fused(st.gcn[0], st.gcn[1], 4, _capi.ptr(x0), _capi.ptr(gp), _capi.ptr(tok), _capi.ptr(scratch),
+                                                       _capi.ptr(self._pgcn_sync()), 0, B, sp), 'dir_pgcn_stack_forward_fused')
+        else:
+            _capi.check(L.dir_pgcn_stack_forward_pair(st.gcn[0], st.gcn[1], 4, _capi.ptr(x0), _capi.ptr(gp), _capi.ptr(tok),
+                                                      _capi.ptr(scratch), B, sp), 'dir_pgcn_stack_forward_pair')
         y = torch.empty(B, 42, 64, device=dev, dtype=F32)
         blk = 42 * 128 * 384 + 4 * 2 * 42 * 42 * 32 + 42 * 128 * 128 + 2 * 42 * 128 * 256
         _ann('ste', 2.0 * B * (3 * blk + 42 * 128 * 64), B * 42 * (128 + 64) * 4 + (3 * (128 * 384 + 128 * 128 + 2 * 128 * 256) + 128 * 64) * wes,
@@ -1125,6 +1132,24 @@ class DirEngine(object):
         res['joint_feat'] = emb
         res['vis_img_feat'] = vis
         return res
+
+    pgcn_fused = os.environ.get('DIR_PGCN_FUSED', '1') != '0'       # A/B aid: 0 = the five launches per stack of rounds 2-3
+
+    def _pgcn_sync(self):
+        """the fused P-GCN launch's flag words: zeroed once, one buffer per stream that runs forwards of this engine (two streams' launches must
+        not share flags); never reset afterwards -- every launch raises its flags by one (tokens.hip).  Allocated outside any capture when the
+        stream has run an eager forward first (ForwardPipeline does); allocated inside a capture it is re-zeroed by every replay, which is
+        equally correct."""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._pgcn_ws.get(key)
+        if ws is None:
+            ws = torch.zeros(int(_capi.lib().dir_pgcn_fused_sync_bytes()) // 4, dtype=torch.int32, device=self.device)
+            self._pgcn_ws[key] = ws
+        return ws
+
+    def pgcn_sync_error(self):
+        """True if a fused P-GCN workgroup of any stream ever gave up waiting for a neighbour (host read; tests and bench.py look)"""
+        return any(int(ws[-4].item()) != 0 for ws in self._pgcn_ws.values())
 
     def _stage_index(self, st):
         """position of the stage's dict in outs_list (0 = the init regression)"""

@@ -488,6 +488,17 @@ int dir_pgcn_stack_forward_pair(const dir_pgcn_layer* layers_left_host, const di
                                 int num_layers, const float* x_lr, const float* add_lr, float* tokens, float* scratch,
                                 int B, void* stream);
 
+/* The same stack of both hands in ONE launch (round 4; replaces the five launches of dir_pgcn_stack_forward_pair, same arithmetic, bit-identical
+ * tokens): one persistent workgroup per (hand, node, batch split) runs all layers of its node; layers are separated by per-node flags in
+ * `sync_ws` (device memory, dir_pgcn_fused_sync_bytes() bytes, ZEROED ONCE by the caller and then left alone -- every launch raises the flags it
+ * owns by one; one sync_ws per stream that may run this concurrently) instead of launches.  splits: batch splits per node (0 = the library's
+ * choice; <= 8; DIR_PGCN_SPLITS overrides).  The word at byte offset dir_pgcn_fused_sync_bytes() - 16 becomes nonzero if a workgroup ever gave up
+ * waiting (~1 s) for a neighbour -- the tokens of that launch are then invalid.  num_layers <= 4.  scratch as for the pair entry point. */
+long long dir_pgcn_fused_sync_bytes(void);
+int dir_pgcn_stack_forward_fused(const dir_pgcn_layer* layers_left_host, const dir_pgcn_layer* layers_right_host, int num_layers,
+                                 const float* x_lr, const float* add_lr, float* tokens, float* scratch, void* sync_ws, int splits, int B,
+                                 void* stream);
+
 /* a6: STE.forward (transformer/mixSTE.py:194-205) on [B,42,128] -> [B,42,64].
  * weight_dtype DIR_DT_F32: the six Linear weights per block (*_wt) and head_wt are fp32, k-major ([in][out]); exact fp32.
  * weight_dtype DIR_DT_BF16: they are bf16 in nn.Linear's own [out][in] layout and the Linears run on the bf16 matrix cores

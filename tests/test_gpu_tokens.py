@@ -72,6 +72,84 @@ def test_pgcn_batch_sizes_and_add():
         assert float(tok[:, :21].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('wdt', [torch.float32, torch.bfloat16])
+def test_pgcn_fused_equals_layered(wdt):
+    """Round 4: the 4-layer stack of both hands in ONE launch (tokens.hip: pgcn_fused_kernel -- persistent workgroup per (hand, node, split),
+    layers separated by per-node flags) against the five launches it replaces: the same fmaf chains in the same order, so the tokens must be
+    bit-identical -- at ragged and large batches, for every split count, with and without the `add` term, and over repeated launches on the
+    same sync words (the flags are never reset: each launch raises them by one).  The layered path is what G2 / the oracle hold
+    (test_pgcn_stack_vs_reference, test_pgcn_batch_sizes_and_add), so this pins the fused one to the reference through it; one size is also
+    compared with the oracle directly."""
+    L = _capi.lib()
+    sdn_l, sdn_r = synth.synth_state_dict(pgcn_shapes(), SEED), synth.synth_state_dict(pgcn_shapes(), SEED + 1)
+    keep = []
+    lay = [engine.pack_pgcn({('gcn.' + k): dev(v) for k, v in sdn.items()}, 'gcn', keep, weight_dtype=wdt) for sdn in (sdn_l, sdn_r)]
+    sync = torch.zeros(int(L.dir_pgcn_fused_sync_bytes()) // 4, dtype=torch.int32, device='cuda')
+    launches = 0
+    for B in (1, 7, 16, 33, 64, 150, 300):
+        x = dev(synth.synth_input('pgcnf.x%d' % B, (2, B, 21, 128), SEED))
+        add = dev(synth.synth_input('pgcnf.a%d' % B, (2, B, 21, 128), SEED))
+        for use_add in (True, False):
+            want = torch.zeros(B, 42, 128, device='cuda')
+            scratch = torch.empty(4, B, 21, 256, device='cuda')
+            _capi.check(L.dir_pgcn_stack_forward_pair(lay[0], lay[1], 4, _capi.ptr(x), _capi.ptr(add) if use_add else None, _capi.ptr(want),
+                                                      _capi.ptr(scratch), B, _capi.stream_ptr()), 'pair')
+            for splits in (0, 1, 2, 3, 4, 8):
+                got = torch.full((B, 42, 128), float('nan'), device='cuda')
+                sc2 = torch.full((4, B, 21, 256), float('nan'), device='cuda')
+                _capi.check(L.dir_pgcn_stack_forward_fused(lay[0], lay[1], 4, _capi.ptr(x), _capi.ptr(add) if use_add else None, _capi.ptr(got),
+                                                           _capi.ptr(sc2), _capi.ptr(sync), splits, B, _capi.stream_ptr()), 'fused')
+                launches += 1
+                assert torch.equal(got, want), (B, use_add, splits)
+        if B == 33 and wdt == torch.float32:
+            ref = np.concatenate([OT.pgcn_stack(x[0].cpu().numpy(), N.Params(sdn_l)), OT.pgcn_stack(x[1].cpu().numpy(), N.Params(sdn_r))], 1)
+            assert relerr(got.cpu().numpy(), ref) < 3e-6
+    torch.cuda.synchronize()
+    assert int(sync[-4]) == 0                                     # no workgroup ever gave up waiting
+    flags = sync[:-4].view(4, 2, 21, 8)
+    assert int(flags[:, :, :, 0].min()) == int(flags[:, :, :, 0].max()) == launches          # split 0 exists in every launch: one raise per launch
+    # fewer layers (the single-layer form the golden's per-layer activation uses)
+    x = dev(synth.synth_input('pgcnf.x1', (2, 5, 21, 128), SEED))
+    want, got = torch.zeros(5, 42, 128, device='cuda'), torch.zeros(5, 42, 128, device='cuda')
+    scratch = torch.empty(4, 5, 21, 256, device='cuda')
+    _capi.check(L.dir_pgcn_stack_forward_pair(lay[0], lay[1], 2, _capi.ptr(x), None, _capi.ptr(want), _capi.ptr(scratch), 5, _capi.stream_ptr()), 'pair')
+    _capi.check(L.dir_pgcn_stack_forward_fused(lay[0], lay[1], 2, _capi.ptr(x), None, _capi.ptr(got), _capi.ptr(scratch), _capi.ptr(sync), 0, 5,
+                                               _capi.stream_ptr()), 'fused')
+    assert torch.equal(got, want)
+
+
+def test_pgcn_fused_on_four_streams_at_once():
+    """the forward-progress argument of pgcn_fused_kernel: launches of it from four streams (bench.py's four forwards in flight), each with
+    its own sync words, interleaved with ordinary kernels, all finish and all give the one-at-a-time tokens"""
+    L = _capi.lib()
+    sdn = synth.synth_state_dict(pgcn_shapes(), SEED)
+    keep = []
+    lay = engine.pack_pgcn({('gcn.' + k): dev(v) for k, v in sdn.items()}, 'gcn', keep, weight_dtype=torch.bfloat16)
+    B = 64
+    x = dev(synth.synth_input('pgcnf.s', (2, B, 21, 128), SEED))
+    want = torch.zeros(B, 42, 128, device='cuda')
+    scratch = torch.empty(4, B, 21, 256, device='cuda')
+    _capi.check(L.dir_pgcn_stack_forward_pair(lay, lay, 4, _capi.ptr(x), None, _capi.ptr(want), _capi.ptr(scratch), B, _capi.stream_ptr()), 'pair')
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    syncs = [torch.zeros(int(L.dir_pgcn_fused_sync_bytes()) // 4, dtype=torch.int32, device='cuda') for _ in streams]
+    outs = [torch.zeros(B, 42, 128, device='cuda') for _ in streams]
+    scr = [torch.empty(4, B, 21, 256, device='cuda') for _ in streams]
+    filler = torch.randn(4096, 4096, device='cuda')
+    torch.cuda.synchronize()
+    for rnd in range(50):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                if (rnd + i) % 3 == 0:
+                    filler.mul(1.0001)                            # an ordinary all-CU kernel in between
+                _capi.check(L.dir_pgcn_stack_forward_fused(lay, lay, 4, _capi.ptr(x), None, _capi.ptr(outs[i]), _capi.ptr(scr[i]), _capi.ptr(syncs[i]),
+                                                           0, B, _capi.stream_ptr()), 'fused')
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(outs[i], want), i
+        assert int(syncs[i][-4]) == 0
+
+
 def ste_shapes(prefix):
     s = {'spatial_pos_embed': (1, 42, 128), 'spatial_norm.weight': (128,), 'spatial_norm.bias': (128,),
          'head.0.weight': (128,), 'head.0.bias': (128,), 'head.1.weight': (64, 128), 'head.1.bias': (64,)}
