@@ -467,9 +467,21 @@ struct PgcnFusedArgs {
     long long* stamps;
 };
 
-__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float4 ld_dev4(const float* p) { return make_float4(ld_dev(p), ld_dev(p + 1), ld_dev(p + 2), ld_dev(p + 3)); }
+// 16-byte device-coherent accesses (what __hip_atomic_load/store(relaxed, agent) lower to, four words at a time: a scalar sc1 access is one
+// fabric transaction each -- measured 36 us for the stack with dword accesses against 31.6 us for the five launches).  The loads are issued
+// and waited for inside ONE asm block: the compiler does not track an asm load's completion.
+typedef float __attribute__((ext_vector_type(4))) pgf4;
+__device__ __forceinline__ void st_dev4(float* p, pgf4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld_dev4x6(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4, const float* p5,
+                                          pgf4& v0, pgf4& v1, pgf4& v2, pgf4& v3, pgf4& v4, pgf4& v5) {
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %7, off sc1\n\tglobal_load_dwordx4 %2, %8, off sc1\n\t"
+                 "global_load_dwordx4 %3, %9, off sc1\n\tglobal_load_dwordx4 %4, %10, off sc1\n\tglobal_load_dwordx4 %5, %11, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+                 : "memory");
+}
+__device__ __forceinline__ float4 f4(pgf4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 template <bool WBF16>
 __device__ __forceinline__ void pgcn_fused_body(const PgcnFusedArgs& args) {
@@ -555,9 +567,10 @@ __device__ __forceinline__ void pgcn_fused_body(const PgcnFusedArgs& args) {
             if (!h_prev) self = *reinterpret_cast<const float4*>(a.x_in + (b * NJ + j) * 128 + cq);
             else {
                 const float* hb = h_prev + b * NJ * 256;
-                self = ld_dev4(hb + j * 256 + cq);
-#pragma unroll
-                for (int t = 0; t < 5; ++t) nbv[t] = ld_dev4(hb + nidx[t] * 256 + 128 + cq);
+                pgf4 v0, v1, v2, v3, v4, v5;
+                ld_dev4x6(hb + j * 256 + cq, hb + nidx[0] * 256 + 128 + cq, hb + nidx[1] * 256 + 128 + cq, hb + nidx[2] * 256 + 128 + cq,
+                          hb + nidx[3] * 256 + 128 + cq, hb + nidx[4] * 256 + 128 + cq, v0, v1, v2, v3, v4, v5);
+                self = f4(v0); nbv[0] = f4(v1); nbv[1] = f4(v2); nbv[2] = f4(v3); nbv[3] = f4(v4); nbv[4] = f4(v5);
             }
         };
         auto mix1 = [&](float sv, float n0, float n1, float n2, float n3, float n4, float b_, float s_, float h_) -> float {
@@ -588,7 +601,6 @@ __device__ __forceinline__ void pgcn_fused_body(const PgcnFusedArgs& args) {
         for (int chunk = sp; chunk < args.nchunk; chunk += S, buf ^= 1) {
             mix_store(chunk, buf);
             __syncthreads();
-            if (chunk + S < args.nchunk) gather(chunk + S);
             const float* sx = s_x[buf];
             f32x4 acc[2];
             acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -603,28 +615,26 @@ __device__ __forceinline__ void pgcn_fused_body(const PgcnFusedArgs& args) {
                         av[2 * e] = (__bf16)t.x;
                         av[2 * e + 1] = (__bf16)t.y;
                     }
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[0][kk], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw[1][kk], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0][kk], av, acc[0], 0, 0, 0);       // operands swapped: D = (x W)^T, the same
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[1][kk], av, acc[1], 0, 0, 0);       // products in the same k order
                 }
             } else {
                 const float* ap = sx + li * PG_LD + lk;
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     const float av = ap[4 * kk];
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[0][kk], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[1][kk], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0][kk], av, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[1][kk], av, acc[1], 0, 0, 0);
                 }
             }
+            // transposed accumulators: lane (sample li, output columns 4 lk .. +3 of each 16-column tile) -> one 16-byte write-through store per tile
             const int b0 = chunk * PG_BC, nb = min(PG_BC, args.B - b0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = lk * 4 + r;
-                if (row < nb) {
-                    float* hb = h_out + ((long long)(b0 + row) * NJ + j) * 256 + half * 128 + ncol0 + li;
-                    st_dev(hb, acc[0][r]);
-                    st_dev(hb + 16, acc[1][r]);
-                }
+            if (li < nb) {
+                float* hb = h_out + ((long long)(b0 + li) * NJ + j) * 256 + half * 128 + ncol0 + 4 * lk;
+                st_dev4(hb, pgf4{acc[0][0], acc[0][1], acc[0][2], acc[0][3]});
+                st_dev4(hb + 16, pgf4{acc[1][0], acc[1][1], acc[1][2], acc[1][3]});
             }
+            if (chunk + S < args.nchunk) gather(chunk + S);          // (waited for inside the asm block: after the stores, not before the MFMAs)
         }
         // ---- publish: every wave's rows are out (vmcnt(0)), the workgroup meets, one lane raises the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -652,9 +662,11 @@ __device__ __forceinline__ void pgcn_fused_body(const PgcnFusedArgs& args) {
             const long long b = b0 + bb;
             const float* hb = hz + b * NJ * 256;
             float4 nv[5];
-#pragma unroll
-            for (int t = 0; t < 5; ++t) nv[t] = ld_dev4(hb + nidx[t] * 256 + 128 + cq);
-            const float4 self = ld_dev4(hb + j * 256 + cq);
+            pgf4 v0, v1, v2, v3, v4, v5;
+            ld_dev4x6(hb + j * 256 + cq, hb + nidx[0] * 256 + 128 + cq, hb + nidx[1] * 256 + 128 + cq, hb + nidx[2] * 256 + 128 + cq,
+                      hb + nidx[3] * 256 + 128 + cq, hb + nidx[4] * 256 + 128 + cq, v0, v1, v2, v3, v4, v5);
+            const float4 self = f4(v0);
+            nv[0] = f4(v1); nv[1] = f4(v2); nv[2] = f4(v3); nv[3] = f4(v4); nv[4] = f4(v5);
             float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.add) ad = *reinterpret_cast<const float4*>(a.add + (b * NJ + j) * 128 + cq);
             auto one = [&](float sv, float n0, float n1, float n2, float n3, float n4, float b_, float s_, float h_, float ad_) -> float {

@@ -180,7 +180,7 @@ class ConvOp(object):
                                                   _replay_split=write_split)))
         if write_split:      # the only reader is the next convolution: write its pre-split operand instead of fp32 (same bytes, no split pass)
             d.out_split_scale = -cons.in_scale if cons.arith == 'f16' else cons.in_scale
-        v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
+        v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, self.variant.get(getattr(_TLS, 'parent_batch', None), 0))
         d.flags |= (v & 0xff) << 8
         if _capi.PROFILE is not None:
             nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
@@ -289,7 +289,7 @@ class DualConvOp(object):
         d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0,
                      DT_F16X3 if self.arith == 'f16x3' else DT_F16X1 if self.arith == 'f16' else _dt(self.dtype), _dt(self.dtype),
                      CONV_RELU if self.relu else 0, 0, 0, self.in_scale)
-        v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, 0)
+        v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, self.variant.get(getattr(_TLS, 'parent_batch', None), 0))
         d.flags |= (v & 0xff) << 8
         d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
         if _capi.PROFILE is not None:
@@ -514,14 +514,17 @@ class BneckTailOp(object):
                 and c1n.kh == 1 and c1n.stride == 1 and c1n.cin == c3.cout and c1n.scale is not None and c1n.pre_scale is None
                 and (c3.cin, c1n.cout) in BneckTailOp.GEOMETRIES)
 
-    def __call__(self, y2, x):
-        """y2: conv2's output [B,H,W,P]; x: the block input [B,H,W,4P] (identity residual) -> (block output, next y1)"""
+    def __call__(self, y2, x, out=None, y1n=None):
+        """y2: conv2's output [B,H,W,P]; x: the block input [B,H,W,4P] (identity residual) -> (block output, next y1); out / y1n: optional
+        contiguous destinations (the sub-batched high-resolution half writes slices of the whole batch's tensors)"""
         B, H, W, P = y2.shape
         M = B * H * W
         if getattr(_TLS, 'capture_fused', None) is not None:
             _TLS.capture_fused.append((self, (y2, x), {}))
-        out = torch.empty(B, H, W, self.c3.cout, device=y2.device, dtype=y2.dtype)
-        y1n = torch.empty(B, H, W, self.c1n.cout, device=y2.device, dtype=y2.dtype)
+        if out is None:
+            out = torch.empty(B, H, W, self.c3.cout, device=y2.device, dtype=y2.dtype)
+        if y1n is None:
+            y1n = torch.empty(B, H, W, self.c1n.cout, device=y2.device, dtype=y2.dtype)
         if _capi.PROFILE is not None:
             c4, n2 = self.c3.cout, self.c1n.cout
             _capi.annotate(family='conv', flops=2.0 * M * (P * c4 + c4 * n2), op=self, dtype='bf16',
@@ -629,6 +632,28 @@ class BackboneOp(object):
             u8 = img.dtype == torch.uint8
             _ann('stem', 2.0 * B * 128 * 128 * 64 * 147, img.numel() * img.element_size() + x.numel() * 2 + self.stem_w.numel() * 2,
                  'B=%d 7x7/2 conv + bn + relu + maxpool' % B)
+            nb = self.subbatch
+            last2 = self.layers[1][-1]
+            if nb and nb < B and B % nb == 0 and 'tail' in last2 and not getattr(_TLS, 'capture_fused', None) and not getattr(_TLS, 'no_out_split', False):
+                # Depth-first over sub-batches of `nb` images through the high-resolution half (stem -> layer1 -> layer2): the 64 x 64 and 32 x 32 maps
+                # of one sub-batch (<= 33 MB each at nb = 16) are written and read back while still in the 256 MB Infinity Cache instead of making
+                # HBM round trips of 134 MB per map; layer3 onwards runs on the whole batch.  Same kernels on the same rows: bit-identical.
+                c2 = torch.empty(B, 32, 32, 512, device=dev, dtype=dt)
+                y1n = torch.empty(B, 32, 32, last2['tail'].c1n.cout, device=dev, dtype=dt)
+                _TLS.parent_batch = B
+                try:
+                    for b0 in range(0, B, nb):
+                        isub = img[b0:b0 + nb]
+                        xs = x[b0:b0 + nb]
+                        _ann('stem', 2.0 * nb * 128 * 128 * 64 * 147, isub.numel() * isub.element_size() + xs.numel() * 2 + self.stem_w.numel() * 2,
+                             'B=%d 7x7/2 conv + bn + relu + maxpool' % nb)
+                        _capi.check(L.dir_stem_pool_forward(_capi.ptr(isub), 2 if u8 else 0, IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
+                                                            _capi.ptr(self.stem_scale), _capi.ptr(self.stem_shift), _capi.ptr(xs), nb, 256, 256,
+                                                            _capi.stream_ptr()), 'dir_stem_pool_forward')
+                        self._layers(xs, upto=2, out_last=(c2[b0:b0 + nb], y1n[b0:b0 + nb]))
+                finally:
+                    _TLS.parent_batch = None
+                return [None, c2] + self._layers(c2, start=2, y1=y1n)
             _capi.check(L.dir_stem_pool_forward(_capi.ptr(img), 2 if u8 else 0, IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
                                                 _capi.ptr(self.stem_scale), _capi.ptr(self.stem_shift), _capi.ptr(x), B, 256, 256,
                                                 _capi.stream_ptr()), 'dir_stem_pool_forward')
@@ -649,15 +674,22 @@ class BackboneOp(object):
                     'dir_maxpool3x3s2')
         return self._layers(x)
 
-    def _layers(self, x):
+    subbatch = int(os.environ.get('DIR_SUBBATCH', '0'))             # bf16 mode: images per depth-first pass of stem + layer1 + layer2 (0 = whole batch)
+
+    def _layers(self, x, start=0, upto=4, y1=None, out_last=None):
+        """layers [start, upto) of the pyramid; y1: the first block's conv1 output when the previous layer's last launch already made it;
+        out_last: (block output, next conv1 output) destinations of the LAST block's tail launch (sub-batched half)"""
         feats = []
-        y1 = None                                                    # conv1 output handed over by the previous block's chain kernel
-        for blocks in self.layers:
-            for blk in blocks:
+        for li in range(start, upto):
+            blocks = self.layers[li]
+            for bi, blk in enumerate(blocks):
                 if 'chain' in blk:
                     x, y1 = blk['chain'](y1 if y1 is not None else blk['c1'](x), x)
                     continue
                 if 'tail' in blk and (x.shape[0] * x.shape[1] * x.shape[2]) % 64 == 0:
+                    if out_last is not None and li == upto - 1 and bi == len(blocks) - 1:
+                        x, y1 = blk['tail'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x, out=out_last[0], y1n=out_last[1])
+                        continue
                     x, y1 = blk['tail'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x)
                 elif 'dual' in blk:                                  # conv3 + projection shortcut in one launch
                     x, y1 = blk['dual'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x), None
