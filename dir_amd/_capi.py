@@ -34,7 +34,7 @@ class ConvSrc2(C.Structure):
 
 class BneckChainParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n', 'wd')] + [
-        ('n_next', C.c_int32)]
+        ('n_next', C.c_int32), ('out_decimate', C.c_int32)]
 
 
 class BneckTailParams(C.Structure):
@@ -105,7 +105,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 30          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 32          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -178,6 +178,9 @@ _SIGNATURES = {
     'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
     'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
+    'dir_bn_frozen_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_bn_frozen_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, _i, _p, _p]),
+    'dir_bn_frozen_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_relu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),
     'dir_relu_backward': (C.c_int, [_p, _p, _p, C.c_longlong, _p]),
     'dir_pgcn_adjacency_forward': (C.c_int, [_p, _p, _p]),

@@ -119,24 +119,40 @@ class InterHandSplit(object):
 ANNO_FLOATS = 21 + 2 * 67
 
 
-def _decode_worker(data_path, split, tasks, done, frames, annos):
-    """decode process: (slot, first index, count) -> frames[slot][:count], annos[slot][:count]"""
+def _decode_worker(data_path, split, wid, workers, indices, bs, chunk, ready, frames, annos, flags, ctrl):
+    """decode process `wid` of `workers`: owns the chunks t = wid, wid + workers, ... of the flat (batch, chunk) sequence; chunk t of batch b
+    goes to rows [k * chunk, ...) of ring slot b % depth once batch b - depth has been released (ctrl[0] = batches released); flags[t] = 1 when
+    its frames and annotations are in place (2: failed).  No queue in the steady state: shared-memory words only."""
+    import time
     torch.set_num_threads(1)
     ds = InterHandSplit(data_path, split)
     fr, an = [f.numpy() for f in frames], [a.numpy() for a in annos]
-    done.put((-1, -1, None))            # ready (the interpreter and its imports are up)
-    while True:
-        t = tasks.get()
-        if t is None:
+    fl, ct = flags.numpy(), ctrl.numpy()
+    depth, n, npb = len(fr), len(indices), -(-bs // chunk)
+    nb = -(-n // bs)
+    ready.put(wid)                      # the interpreter and its imports are up
+    for t in range(wid, nb * npb, workers):
+        b, k = divmod(t, npb)
+        lo = b * bs + k * chunk
+        hi = min(lo + chunk, (b + 1) * bs, n)
+        if lo >= hi:
+            fl[t] = 1
+            continue
+        while b - depth >= ct[0]:       # the slot still holds a batch the consumer has not released
+            if ct[1]:
+                return
+            time.sleep(0.0002)
+        if ct[1]:
             return
-        slot, part, idxs = t
         try:
-            for j, idx in idxs:
-                fr[slot][j] = ds.frame(idx)
-                an[slot][j] = ds.anno(idx)
-            done.put((slot, part, None))
-        except Exception as e:          # noqa: BLE001  (reported to the consumer, which raises)
-            done.put((slot, part, repr(e)))
+            slot, j0 = b % depth, k * chunk
+            for j in range(hi - lo):
+                fr[slot][j0 + j] = ds.frame(indices[lo + j])
+                an[slot][j0 + j] = ds.anno(indices[lo + j])
+            fl[t] = 1
+        except Exception:               # noqa: BLE001  (the consumer raises when it sees the flag)
+            fl[t] = 2
+            return
 
 
 class DecodeRing(object):
@@ -145,72 +161,69 @@ class DecodeRing(object):
         ring = DecodeRing(data_path, 'test', batch_size=256)
         for frames_u8, annos, n in ring:          # pinned uint8 [B,256,256,3], float32 [B,155]; the first n rows are valid
             pipe.refill(slot, frames_u8[:n]) ...
-    A batch is split over all workers (so one batch's latency is 1/workers of its decode time); the next `depth - 1` batches are
-    decoded while the caller consumes the current one.  The buffers are shared memory registered with the HIP runtime
+    A batch is cut into chunks of `chunk` images; chunk t of the flat (batch, chunk) sequence belongs to worker t % workers, which writes it
+    into the ring slot of its batch as soon as that slot's previous batch has been released, and raises a flag word in shared memory; the
+    consumer polls the flags of the batch it wants.  There is no queue traffic after start-up: rounds 2-3 handed every batch to the workers
+    through multiprocessing queues (one task per worker and batch, completions of later batches re-queued) and the rate FELL with the worker
+    count (256-thread host: 12 workers 11.7 k images/s, 24: 8.5 k, 96: 3.4 k; with 32-image tasks still 17.1 k at 16 and 6.1 k at 96 --
+    profiles/r04_fromdisk_sweep_*.txt).  A batch counts as released when the consumer asks for the next one (it must have finished copying out
+    of the buffer by then, as evaluate_from_disk does).  One pass per ring.  The buffers are shared memory registered with the HIP runtime
     (cudaHostRegister), so the host -> device copy is an asynchronous DMA from where the decoders wrote."""
 
-    def __init__(self, data_path, split='test', batch_size=256, workers=8, depth=3, indices=None, pin=True):
+    def __init__(self, data_path, split='test', batch_size=256, workers=8, depth=None, indices=None, pin=True, chunk=32):
         import torch.multiprocessing as mp
         self.ds = InterHandSplit(data_path, split)
         self.indices = list(range(len(self.ds))) if indices is None else list(indices)
-        self.bs, self.depth, self.workers = batch_size, depth, max(1, workers)
+        self.bs, self.workers, self.chunk = batch_size, max(1, workers), max(1, min(chunk, batch_size))
+        if depth is None:
+            depth = max(3, -(-self.workers * self.chunk // batch_size) + 2)
+        self.depth = depth
+        self.npb = -(-batch_size // self.chunk)
         self.frames = [torch.zeros(batch_size, IMG_SIZE, IMG_SIZE, 3, dtype=torch.uint8).share_memory_() for _ in range(depth)]
         self.annos = [torch.zeros(batch_size, ANNO_FLOATS, dtype=torch.float32).share_memory_() for _ in range(depth)]
+        self.flags = torch.zeros(max(1, len(self) * self.npb), dtype=torch.uint8).share_memory_()
+        self.ctrl = torch.zeros(2, dtype=torch.int64).share_memory_()          # [batches released, stop]
         self.pinned = False
         if pin and torch.cuda.is_available():
             rt = torch.cuda.cudart()
             self.pinned = all(int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0 for t in self.frames + self.annos)
         ctx = mp.get_context('spawn')
-        self.tasks, self.done = ctx.Queue(), ctx.Queue()
-        self.procs = [ctx.Process(target=_decode_worker, args=(data_path, split, self.tasks, self.done, self.frames, self.annos), daemon=True)
-                      for _ in range(self.workers)]
+        ready = ctx.Queue()
+        self.procs = [ctx.Process(target=_decode_worker, args=(data_path, split, w, self.workers, self.indices, self.bs, self.chunk, ready, self.frames,
+                                                               self.annos, self.flags, self.ctrl), daemon=True) for w in range(self.workers)]
         for p in self.procs:
             p.start()
         for _ in self.procs:             # wait until every decoder is up: a spawned interpreter takes seconds to import
-            s_, _, err = self.done.get(timeout=600)
-            assert s_ == -1 and err is None
+            ready.get(timeout=600)
+        self._used = False
 
     def __len__(self):
         return (len(self.indices) + self.bs - 1) // self.bs
 
-    def _submit(self, b, slot):
-        idxs = list(enumerate(self.indices[b * self.bs:(b + 1) * self.bs]))
-        parts = [idxs[w::self.workers] for w in range(self.workers) if idxs[w::self.workers]]
-        for k, part in enumerate(parts):
-            self.tasks.put((slot, k, part))
-        return len(parts), len(idxs)
-
     def __iter__(self):
-        nb = len(self)
-        pending = {}
-        for b in range(min(self.depth - 1, nb)):
-            pending[b] = self._submit(b, b % self.depth)
+        import time
+        assert not self._used, 'DecodeRing: one pass per ring (the workers walk the index list once)'
+        self._used = True
+        fl, ct = self.flags.numpy(), self.ctrl.numpy()
+        nb, n_all = len(self), len(self.indices)
         for b in range(nb):
-            nxt = b + self.depth - 1
-            if nxt < nb:
-                pending[nxt] = self._submit(nxt, nxt % self.depth)
-            slot = b % self.depth
-            nparts, n = pending.pop(b)
-            got = 0
-            stash = []
-            while got < nparts:
-                try:
-                    s, k, err = self.done.get(timeout=600)
-                except queue.Empty:
+            ct[0] = b                                    # batches < b are released: their slots may be overwritten
+            mine = fl[b * self.npb:(b + 1) * self.npb]
+            t0 = time.perf_counter()
+            while not mine.all():
+                if (mine == 2).any() or not all(p.is_alive() or p.exitcode == 0 for p in self.procs):
+                    raise RuntimeError('DecodeRing: a decode worker failed')
+                if time.perf_counter() - t0 > 600:
                     raise RuntimeError('DecodeRing: decode workers made no progress for 600 s')
-                if err is not None:
-                    raise RuntimeError('DecodeRing: decode failed: ' + err)
-                if s == slot:
-                    got += 1
-                else:
-                    stash.append((s, k, err))
-            for item in stash:              # completions of later batches: put back for their turn
-                self.done.put(item)
-            yield self.frames[slot], self.annos[slot], n
+                time.sleep(0.0001)
+            if (mine == 2).any():
+                raise RuntimeError('DecodeRing: a decode worker failed')
+            slot = b % self.depth
+            yield self.frames[slot], self.annos[slot], min(self.bs, n_all - b * self.bs)
+        ct[0] = nb
 
     def close(self):
-        for _ in self.procs:
-            self.tasks.put(None)
+        self.ctrl[1] = 1
         for p in self.procs:
             p.join(timeout=10)
         if self.pinned:

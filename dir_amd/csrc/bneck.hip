@@ -51,6 +51,7 @@ struct ChainArgs {
     const bf16_t* w1n; const float* sc1n; const float* sh1n;
     const bf16_t* x2; const bf16_t* wd;                   // projection shortcut: second 64-channel source of conv3's GEMM
     int B, H, W, tiles_x, tiles_y, ntiles;
+    int decim;                                            // 1: only the pixels with even y and even x leave, as out [B][H/2][W/2][256]
 };
 
 __device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
@@ -307,10 +308,22 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
             }
             __syncthreads();                                                  // T = this half of the block output
             // block output: coalesced 16-byte stores from T
+            if (!a.decim) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = tid + NTHR * i;
-                *reinterpret_cast<uint4*>(out_ptr(mg, i, b, y0, x0)) = *reinterpret_cast<const uint4*>(s_t + (c >> 5) * TPITCH + (c & 31) * 16);
+                for (int i = 0; i < 4; ++i) {
+                    const int c = tid + NTHR * i;
+                    *reinterpret_cast<uint4*>(out_ptr(mg, i, b, y0, x0)) = *reinterpret_cast<const uint4*>(s_t + (c >> 5) * TPITCH + (c & 31) * 16);
+                }
+            } else {
+                // the only reader of this block output is a stride-2 1x1 convolution (layer2's projection shortcut, models/backbone/resnet.py:117-119,
+                // the next conv1 being computed right here): a quarter of the pixels ever leave the CU
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = tid + NTHR * i, P = 64 * mg + (c >> 5), py = P >> 4, px = P & 15;
+                    if (((py | px) & 1) == 0)
+                        *reinterpret_cast<uint4*>(a.out + (((long long)b * (a.H >> 1) + ((y0 + py) >> 1)) * (a.W >> 1) + ((x0 + px) >> 1)) * 256 + (c & 31) * 8) =
+                            *reinterpret_cast<const uint4*>(s_t + (c >> 5) * TPITCH + (c & 31) * 16);
+                }
             }
             if constexpr (HAS_NEXT) {
                 // ---- C. next block's conv1 (1x1, K = 256): 16 channels x NPT 16-pixel groups per wave
@@ -363,7 +376,7 @@ extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, con
     a.w3 = (const convk::bf16_t*)p->w3; a.sc3 = p->scale3; a.sh3 = p->shift3;
     a.w1n = (const convk::bf16_t*)p->w1n; a.sc1n = p->scale1n; a.sh1n = p->shift1n;
     a.x2 = (const convk::bf16_t*)x2; a.wd = (const convk::bf16_t*)p->wd;
-    a.B = B; a.H = H; a.W = W; a.tiles_x = W / TW; a.tiles_y = H / TH;
+    a.B = B; a.H = H; a.W = W; a.tiles_x = W / TW; a.tiles_y = H / TH; a.decim = p->out_decimate ? 1 : 0;
     const long long nt = (long long)B * a.tiles_x * a.tiles_y;
     DIR_REQUIRE(nt < (1ll << 31) && (long long)B * H * W * 256 < (1ll << 40), "dir_bottleneck_chain_forward: too large");
     a.ntiles = (int)nt;

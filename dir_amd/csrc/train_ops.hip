@@ -460,6 +460,16 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* gy, cons
     gx[o] = g * rs[c] * (gv - m1 - (x[o] - mu[c]) * rs[c] * m2);
 }
 
+// frozen statistics (dir_bn_frozen_*): save_mean = running_mean, save_rstd = 1 / sqrt(running_var + eps)
+__global__ __launch_bounds__(256) void bn_frozen_stats_kernel(const float* rm, const float* rv, float* mu, float* rs, int C, float eps) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) { mu[c] = rm[c]; rs[c] = 1.f / sqrtf(rv[c] + eps); }
+}
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 // ---- 16-byte versions for C % 4 == 0 (every BatchNorm2d of the path).  Forward statistics in ONE pass over HBM: a workgroup (64 channels x
 // one 256-row chunk) forms the chunk's column sums, then the squared deviations from the CHUNK mean on a second read that hits L2 (a chunk
 // is 64 KB); the finalise kernel combines the chunks exactly: var = sum_k [M2_k + n_k (mean_k - mean)^2] / R, in chunk order.
@@ -1127,6 +1137,56 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
         }
     }
     return check_launch("dir_bn_train_backward");
+}
+
+// BatchNorm with FROZEN statistics inside a training pass (nn.BatchNorm*.eval() under model.train(): the fine-tuning form, and the form in which
+// the reference's whole-step gradient is reproducible to 4e-5 -- tests/golden G20e): y = (x - running_mean) / sqrt(running_var + eps) * w + b, the
+// running statistics untouched.  Backward: g w = sum gy (x - mean) rstd, g b = sum gy (the same deterministic chunked column sums as the
+// training-mode backward), g x = gy w rstd (no batch-statistics terms).  save_mean / save_rstd are written by the forward for the backward.
+extern "C" long long dir_bn_frozen_workspace_bytes(int R, int C) {
+    if (R <= 0 || C <= 0) return -1;
+    const long long chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    return (2 * chunks + 2) * C * 4;
+}
+extern "C" int dir_bn_frozen_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, const float* running_mean,
+                                     const float* running_var, int R, int C, int ld, float eps, int relu, const float* residual, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && y && save_mean && save_rstd && running_mean && running_var && R > 0 && C > 0 && ld >= C, "dir_bn_frozen_forward: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DIR_LAUNCH(bn_frozen_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var, save_mean, save_rstd, C, eps);
+    if (bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, residual})) {
+        const long long nt = (long long)((R + 3) / 4) * (C / 4);
+        DIR_LAUNCH(bn_apply_fwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, R, C, ld, relu, residual);
+    } else {
+        const long long n = (long long)R * C;
+        DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld, relu, residual);
+    }
+    return check_launch("dir_bn_frozen_forward");
+}
+extern "C" int dir_bn_frozen_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
+                                      float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_frozen_backward: bad arguments");
+    DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_frozen_workspace_bytes(R, C), "dir_bn_frozen_backward: workspace too small (dir_bn_frozen_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    float* p1 = workspace; float* p2 = p1 + (long long)chunks * C; float* t1 = p2 + (long long)chunks * C; float* t2 = t1 + C;
+    const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
+    const bool vec = bn_vec4(C, ld, {x, gy, gx, w, b, save_mean, save_rstd, workspace});
+    if (vec) DIR_LAUNCH(bn_bwd_partial4_kernel, pg, dim3(256), 0, s, x, gy, w, b, save_mean, save_rstd, p1, p2, R, C, ld, relu);
+    else launch_bn_partial(pg, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2, w, b, relu);
+    DIR_LAUNCH(bn_bwd_combine_kernel, cg, dim3(256), 0, s, (const float*)p1, (const float*)p2, t1, t2, gb, gw, chunks, C);
+    if (gx) {
+        DIR_LAUNCH(zero_f32_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, t1, 2 * C);          // no batch-statistics terms: the apply kernels' column means are zero
+        if (vec) {
+            const long long nt = (long long)((R + 3) / 4) * (C / 4);
+            DIR_LAUNCH(bn_apply_bwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, R, C, ld, relu);
+        } else {
+            const long long n = (long long)R * C;
+            DIR_LAUNCH(bn_apply_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, n, R, C, ld, relu);
+        }
+    }
+    return check_launch("dir_bn_frozen_backward");
 }
 
 extern "C" int dir_relu_forward(const float* x, float* y, long long n, void* stream) {

@@ -278,20 +278,21 @@ class DualConvOp(object):
     set_in_scale = ConvOp.set_in_scale
     pre_scale = None
 
-    def __call__(self, y, x, out=None, out_coff=0):
+    def __call__(self, y, x, out=None, out_coff=0, x_decimated=False):
+        """x_decimated: x already holds only the pixels the stride-`stride2` shortcut reads ([B,H,W,Cin2] at y's resolution)"""
         B, H, W, cbuf = y.shape
         if self.arith is not None and getattr(_TLS, 'calibrating', False):
             ConvOp._calibrate(self, [y[..., :self.cin], x[..., :self.cin2]])
         if out is None:
             out = torch.empty(B, H, W, self.cout, device=y.device, dtype=self.dtype)
         if getattr(_TLS, 'capture', None) is not None:
-            _TLS.capture.append((self, (y, x), dict(out=out, out_coff=out_coff)))
+            _TLS.capture.append((self, (y, x), dict(out=out, out_coff=out_coff, x_decimated=x_decimated)))
         d = ConvDesc(B, H, W, self.cin, cbuf, 0, self.cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0,
                      DT_F16X3 if self.arith == 'f16x3' else DT_F16X1 if self.arith == 'f16' else _dt(self.dtype), _dt(self.dtype),
                      CONV_RELU if self.relu else 0, 0, 0, self.in_scale)
         v = _forced_variant() if _forced_variant() is not None else self.variant.get(B, self.variant.get(getattr(_TLS, 'parent_batch', None), 0))
         d.flags |= (v & 0xff) << 8
-        d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, self.stride2)
+        d2 = _capi.ConvSrc2(x.shape[1], x.shape[2], self.cin2, x.shape[3], 0, 1 if x_decimated else self.stride2)
         if _capi.PROFILE is not None:
             es, m = y.element_size(), B * H * W
             _capi.annotate(family='conv', flops=2.0 * m * self.cout * (self.cin + self.cin2), op=self,
@@ -427,20 +428,22 @@ class BneckChainOp(object):
             ok = ok and dual.cin == 64 and dual.cin2 == 64 and dual.cout == 256 and dual.stride2 == 1 and dual.relu
         return ok and (c1n is None or (c1n.cin == 256 and c1n.cout in (64, 128) and c1n.kh == 1 and c1n.stride == 1 and c1n.scale is not None))
 
-    def __call__(self, y1, x):
-        """x: the block input -- the identity residual, or (dual) the projection shortcut's source"""
+    def __call__(self, y1, x, decimate=False):
+        """x: the block input -- the identity residual, or (dual) the projection shortcut's source.  decimate: write only the even (y, x)
+        pixels of the block output, as [B,H/2,W/2,256] (the last layer1 block when nobody reads c1: dir_bneck_chain_params.out_decimate)"""
         residual, x2 = (None, x) if self.dual is not None else (x, None)
         B, H, W, _ = y1.shape
         if getattr(_TLS, 'capture_fused', None) is not None:       # tools/energy_profile.py: replayable (allocates its own outputs)
-            _TLS.capture_fused.append((self, (y1, x), {}))
-        out = torch.empty(B, H, W, 256, device=y1.device, dtype=y1.dtype)
+            _TLS.capture_fused.append((self, (y1, x), dict(decimate=decimate)))
+        self.params.out_decimate = 1 if decimate else 0
+        out = torch.empty((B, H // 2, W // 2, 256) if decimate else (B, H, W, 256), device=y1.device, dtype=y1.dtype)
         y1n = torch.empty(B, H, W, self.c1n.cout, device=y1.device, dtype=y1.dtype) if self.c1n is not None else None
         if _capi.PROFILE is not None:
             m, nx = B * H * W, self.c1n is not None
             n2 = self.c1n.cout if nx else 0
             _capi.annotate(family='conv', flops=2.0 * m * (64 * 576 + 256 * 64 * (2 if x2 is not None else 1) + n2 * 256), op=self, dtype='bf16',
                            shape='M=%d chain 3x3(64)+1x1(256)%s' % (m, '+1x1(%d)' % n2 if nx else ''),
-                           bytes=(m * (64 + 256 * (2 if residual is not None else 1) + n2 + (64 if x2 is not None else 0))
+                           bytes=(m * (64 + 256 * (1 if residual is not None else 0) + (64 if decimate else 256) + n2 + (64 if x2 is not None else 0))
                                   + self.c2.w.numel() + self.w3.numel() * (2 if x2 is not None else 1) + (self.w1n.numel() if nx else 0)) * 2)
         _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(self.params), _capi.ptr(y1), _capi.ptr(residual), _capi.ptr(x2), _capi.ptr(out),
                                                              _capi.ptr(y1n), B, H, W, _capi.stream_ptr()), 'dir_bottleneck_chain_forward')
@@ -674,17 +677,24 @@ class BackboneOp(object):
                     'dir_maxpool3x3s2')
         return self._layers(x)
 
+    decimate_c1 = os.environ.get('DIR_DECIMATE_C1', '1') != '0'     # bf16 mode: c1 is not produced unless asked for (taps / backbone_standalone)
     subbatch = int(os.environ.get('DIR_SUBBATCH', '0'))             # bf16 mode: images per depth-first pass of stem + layer1 + layer2 (0 = whole batch)
 
     def _layers(self, x, start=0, upto=4, y1=None, out_last=None):
         """layers [start, upto) of the pyramid; y1: the first block's conv1 output when the previous layer's last launch already made it;
         out_last: (block output, next conv1 output) destinations of the LAST block's tail launch (sub-batched half)"""
         feats = []
+        x_dec = False                                                # x holds only the even pixels of the previous layer's output (decimate_c1)
         for li in range(start, upto):
             blocks = self.layers[li]
             for bi, blk in enumerate(blocks):
                 if 'chain' in blk:
-                    x, y1 = blk['chain'](y1 if y1 is not None else blk['c1'](x), x)
+                    # the last layer1 block's output is read by layer2's stride-2 projection shortcut only (its conv1 is fused into this launch):
+                    # when nobody asks for c1, a quarter of its pixels are written (dir_bneck_chain_params.out_decimate)
+                    dec = (self.decimate_c1 and li == 0 and bi == len(blocks) - 1 and blk['chain'].c1n is not None and 'dual' in self.layers[1][0]
+                           and self.layers[1][0]['dual'].stride2 == 2 and 'chain' not in self.layers[1][0] and not getattr(_TLS, 'no_out_split', False))
+                    x, y1 = blk['chain'](y1 if y1 is not None else blk['c1'](x), x, decimate=dec)
+                    x_dec = dec
                     continue
                 if 'tail' in blk and (x.shape[0] * x.shape[1] * x.shape[2]) % 64 == 0:
                     if out_last is not None and li == upto - 1 and bi == len(blocks) - 1:
@@ -692,11 +702,12 @@ class BackboneOp(object):
                         continue
                     x, y1 = blk['tail'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x)
                 elif 'dual' in blk:                                  # conv3 + projection shortcut in one launch
-                    x, y1 = blk['dual'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x), None
+                    x, y1 = blk['dual'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), x, x_decimated=x_dec), None
+                    x_dec = False
                 else:
                     idn = blk['ds'](x) if blk['ds'] is not None else x
                     x, y1 = blk['c3'](blk['c2'](y1 if y1 is not None else blk['c1'](x)), residual=idn), None
-            feats.append(x)
+            feats.append(None if x_dec else x)                     # (c1 is not produced when its only reader is the strided shortcut)
         return feats
 
 
@@ -707,6 +718,7 @@ def backbone_standalone(module, x, compute_dtype=torch.float32):
         raise NotImplementedError('dir_amd implements the inference path (eval-mode BatchNorm); call .eval()')
     sd = {'b.' + k: v.detach() for k, v in module.state_dict().items()}
     op = BackboneOp(sd, 'b', compute_dtype, x.device)
+    op.decimate_c1 = False                                           # ResNet.forward returns c1
     with torch.cuda.device(x.device):
         feats = op(_capi.f32c(x.detach()))
     return [f.permute(0, 3, 1, 2).float() for f in feats]

@@ -162,20 +162,21 @@ def stem_pool(img, w_packed, scale, shift, mean=(0.485, 0.456, 0.406), std=(0.22
     return y
 
 
-def bottleneck_chain(y1, w2, s2, h2, w3, s3, h3, residual=None, nxt=None, dual=None):
+def bottleneck_chain(y1, w2, s2, h2, w3, s3, h3, residual=None, nxt=None, dual=None, decimate=False):
     """models/backbone/resnet.py:126-140 (+ :122-124 of the next block) in one launch, layer1 geometry, bf16 NHWC.
     y1 [B,H,W,64]; w2 packed [64,3,3,64] bf16; w3 [256,64] bf16; nxt = (w1n [64,256] bf16, scale, shift) or None;
     dual = (x2 [B,H,W,64], wd [256,64] bf16) = projection shortcut as 64 more K of conv3 (BN scales folded into w3 / wd, s3 = 1).
+    decimate: only the even (y, x) pixels of the block output are written, as out [B,H/2,W/2,256] (dir_bneck_chain_params.out_decimate).
     returns (out [B,H,W,256], y1_next [B,H,W,64] or None)"""
     _capi.require_cuda(y1)
     B, H, W, _ = y1.shape
-    out = torch.empty(B, H, W, 256, device=y1.device, dtype=torch.bfloat16)
+    out = torch.empty((B, H // 2, W // 2, 256) if decimate else (B, H, W, 256), device=y1.device, dtype=torch.bfloat16)
     y1n = torch.empty(B, H, W, nxt[0].shape[0], device=y1.device, dtype=torch.bfloat16) if nxt is not None else None
     keep = [_capi.f32c(t) for t in (s2, h2, s3, h3)] + ([_capi.f32c(nxt[1]), _capi.f32c(nxt[2])] if nxt is not None else [])
     p = _capi.BneckChainParams(_capi.ptr(w2), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(w3), _capi.ptr(keep[2]), _capi.ptr(keep[3]),
                                _capi.ptr(nxt[0]) if nxt is not None else None, _capi.ptr(keep[4]) if nxt is not None else None,
                                _capi.ptr(keep[5]) if nxt is not None else None, _capi.ptr(dual[1]) if dual is not None else None,
-                               nxt[0].shape[0] if nxt is not None else 0)
+                               nxt[0].shape[0] if nxt is not None else 0, 1 if decimate else 0)
     import ctypes as C
     _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(p), _capi.ptr(y1), _capi.ptr(residual) if residual is not None else None,
                                                          _capi.ptr(dual[0]) if dual is not None else None, _capi.ptr(out), _capi.ptr(y1n) if y1n is not None else None, B, H, W,

@@ -122,6 +122,24 @@ def attention_bwd(qkv, probs, gout, B, T, H, scale):
     return gqkv
 
 
+# BatchNorm with frozen statistics inside a training pass (every nn.BatchNorm* of the model in .eval() under model.train()): normalise with the
+# running statistics, leave them alone; gradients w.r.t. weight / bias / input only (dir_bn_frozen_*).  The reference trains with batch
+# statistics (train.py:64); this switch exists because the reference's whole-step gradient is reproducible to 4e-5 only in this form
+# (tests/golden G20e, tests/test_gpu_full_bwd.py) -- and it is what fine-tuning with frozen BatchNorm runs.
+BN_FROZEN = False
+
+
+class frozen_batchnorm(object):
+    """with frozen_batchnorm(): every bn_train_fwd / bn_train_bwd of the block uses the running statistics"""
+    def __enter__(self):
+        global BN_FROZEN
+        self.prev, BN_FROZEN = BN_FROZEN, True
+
+    def __exit__(self, *a):
+        global BN_FROZEN
+        BN_FROZEN = self.prev
+
+
 def _bn_ws(R, C, dev):
     n = _capi.lib().dir_bn_train_workspace_bytes(R, C)
     return (torch.empty(n // 4, device=dev) if n > 0 else None), n
@@ -134,6 +152,11 @@ def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentu
     assert residual is None or residual.shape == x.shape
     R, C = x.shape
     y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    if BN_FROZEN:
+        assert running_mean is not None and running_var is not None, 'frozen BatchNorm needs the running statistics'
+        _capi.check(_capi.lib().dir_bn_frozen_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
+                                                      _capi.ptr(running_var), R, C, C, float(eps), int(relu), _capi.ptr(residual), _capi.stream_ptr()), 'dir_bn_frozen_forward')
+        return y, (sm, sr)
     ws, n = _bn_ws(R, C, x.device)
     _capi.check(_capi.lib().dir_bn_train_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
                                                  _capi.ptr(running_var), R, C, C, float(eps), float(momentum), int(relu), _capi.ptr(residual), _capi.ptr(ws), n, _capi.stream_ptr()),
@@ -152,6 +175,12 @@ def bn_train_bwd(gy, x, w, stats, need_gx=True, b=None, relu=False):
     R, C = x.shape
     gx = torch.empty_like(x) if need_gx else None
     gw, gb = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    if BN_FROZEN:
+        n = _capi.lib().dir_bn_frozen_workspace_bytes(R, C)
+        ws = torch.empty(n // 4, device=x.device)
+        _capi.check(_capi.lib().dir_bn_frozen_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(gx),
+                                                       _capi.ptr(gw), _capi.ptr(gb), R, C, C, int(relu), _capi.ptr(ws), n, _capi.stream_ptr()), 'dir_bn_frozen_backward')
+        return gx, gw, gb
     ws, n = _bn_ws(R, C, x.device)
     _capi.check(_capi.lib().dir_bn_train_backward(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(gx),
                                                   _capi.ptr(gw), _capi.ptr(gb), R, C, C, int(relu), _capi.ptr(ws), n, _capi.stream_ptr()), 'dir_bn_train_backward')

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 30
+#define DIR_ABI_VERSION 32
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -175,6 +175,16 @@ int dir_bn_train_forward(const float* x, const float* w, const float* b, float* 
                          float* workspace, long long workspace_bytes, void* stream);
 int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                           float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
+/* BatchNorm with FROZEN statistics inside a training pass (a BatchNorm module put in .eval() under model.train(): torch then normalises with the
+ * running statistics and leaves them alone -- torch/nn/modules/batchnorm.py; the reference never freezes them, train.py:64; this form exists
+ * because the reference's whole-step gradient is only reproducible (to 4e-5) with it: tests/golden G20e): y = (x - running_mean) / sqrt(running_var
+ * + eps) * w + b (+ residual, ReLU as in the training-mode entry points); backward: g w, g b as there, g x = gy w rstd.  save_mean / save_rstd [C]
+ * are written by the forward for the backward.  workspace (backward): dir_bn_frozen_workspace_bytes(R, C). */
+long long dir_bn_frozen_workspace_bytes(int R, int C);
+int dir_bn_frozen_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, const float* running_mean,
+                          const float* running_var, int R, int C, int ld, float eps, int relu, const float* residual, void* stream);
+int dir_bn_frozen_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
+                           float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
 int dir_relu_forward(const float* x, float* y, long long n, void* stream);
 int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, void* stream);   /* g x = y > 0 ? g y : 0 */
 /* PGraphConv's adjacency (SemGCN/p_graph_conv.py:43-50): A_1 [21][21] = row-softmax of the hand-skeleton mask filled with e_1 [40]
@@ -635,6 +645,10 @@ typedef struct dir_bneck_chain_params {
                          rows, scale3 = 1 and shift3 = shift_bn3 + shift_bn_ds; `residual` must be NULL. */
     int32_t n_next;   /* output channels of the fused next conv1: 64 (next layer1 block) or 128 (layer2's first block); y1_next is
                          [B,H,W,n_next], w1n [n_next][256] */
+    int32_t out_decimate; /* 0: out is [B,H,W,256].  1: only the pixels with even y and even x are written, as out [B,H/2,W/2,256] -- for the last
+                         layer1 block, whose output is read by layer2's stride-2 projection shortcut alone (models/backbone/resnet.py:117-119;
+                         its conv1 is the fused y1_next): three quarters of the 256-channel map never leave the CU.  The ResNet's c1 feature is
+                         then not produced (models/dir.py never reads it: models/dir.py:437-483 use c2..c4) */
 } dir_bneck_chain_params;
 int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
                                  void* y1_next, int B, int H, int W, void* stream);

@@ -864,6 +864,56 @@ def gen_full_grad(cond=False):
     save('g20_full_grad', **res)
 
 
+def gen_full_grad_frozen():
+    """G20e: the reference's `sum(loss.values()).backward()` (train.py:66-68) through its own DIR in training mode with every
+    BatchNorm module in .eval() (running statistics, no batch statistics), on the trained-like parameters and G8c's input / targets.  In this form
+    the reference's fp32 gradient IS reproducible under a change of summation order (8 BLAS / oneDNN threads vs 1: stored per parameter as
+    'ref_repro.<key>', median ~4e-5 of each tensor's maximum -- against 2e-2 .. 4e-2 with training-mode BatchNorm, G20c), so every other fp32
+    implementation of everything EXCEPT the batch-statistics BatchNorm backward can be pinned tightly by it."""
+    from models.dir import DIR
+    g8 = np.load(os.path.join(OUT, 'g8c_loss.npz'))
+
+    def run():
+        net = DIR(21, 'unused', 0)
+        load_synth(net, cond=True)
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+        for side in ('left', 'right'):
+            fc = torch.from_numpy(synth.loss_faces(side, SEED))
+            getattr(net, 'normal_loss_' + side).face = fc
+            getattr(net, 'edge_loss_' + side).face = fc
+        img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED))
+        target = {k[3:]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith('gt_') and not k.endswith('_u8') and 'center' not in k}
+        target['seg'] = torch.from_numpy(g8['gt_seg_u8'].astype(np.float32))
+        target['dense'] = torch.from_numpy(g8['gt_dense_u8'].astype(np.float32) / np.float32(255.0))
+        meta = {k[3:]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith('gt_center')}
+        outs, loss = net({'img': img}, target, meta)
+        assert len(loss) == 42
+        total = sum(loss[k] for k in loss)
+        total.backward()
+        return net, loss, total
+    net, loss, total = run()
+    named = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    none = sorted(k for k, p in net.named_parameters() if p.grad is None)
+    torch.set_num_threads(1)
+    net1, _, _ = run()
+    torch.set_num_threads(8)
+    named1 = {k: p.grad for k, p in net1.named_parameters() if p.grad is not None}
+    res = {'total': total.detach(), 'none': np.array(none)}
+    res.update({'loss.' + k: v.detach() for k, v in loss.items()})
+    rep = []
+    for k in named:
+        e = float((named[k] - named1[k]).abs().max() / (named[k].abs().max() + 1e-30))
+        res['ref_repro.' + k] = np.float64(e)
+        rep.append(e)
+    print('   frozen BatchNorm: %d parameters with gradient; reference fp32, 8 threads vs 1 thread: median %.2e, worst %.2e of each gradient maximum'
+          % (len(named), float(np.median(rep)), max(rep)))
+    res.update({'g32.' + k: (v.float() if torch.is_tensor(v) else v) for k, v in compact_grads_sized(named, coarse=2).items()})
+    save('g20e_full_grad_frozen_bn', **res)
+
+
 def compact_grads_sized(named, coarse=1):
     """compact_grads with the column step growing with the tensor: <= ~1024 sampled values per row block"""
     res = {}
@@ -874,7 +924,7 @@ def compact_grads_sized(named, coarse=1):
     return res
 
 
-GENS = {'full_cond': lambda: gen_full(True), 'loss_cond': lambda: gen_loss(True), 'full_grad_cond': lambda: gen_full_grad(True),
+GENS = {'full_grad_frozen': gen_full_grad_frozen, 'full_cond': lambda: gen_full(True), 'loss_cond': lambda: gen_loss(True), 'full_grad_cond': lambda: gen_full_grad(True),
         'full_grad': gen_full_grad, 'bone_grad': gen_bone_grad, 'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 

@@ -151,3 +151,21 @@ def test_chain_rejects_bad_shape():
     w3 = dev(p['w3'].reshape(256, 64)).to(BF)
     with pytest.raises(DirHipError):
         F.bottleneck_chain(y1, w2, dev(p['s2']), dev(p['h2']), w3, dev(p['s3']), dev(p['h3']))
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 32), (1, 64, 64)])
+def test_chain_decimated_output_is_the_even_pixels_of_the_full_one(shape):
+    """dir_bneck_chain_params.out_decimate (round 4): the last layer1 block's output is read by layer2's stride-2 projection shortcut only, so
+    only its even (y, x) pixels are written -- bit for bit the even pixels of the full output; the fused next conv1 is unchanged"""
+    B, H, W = shape
+    p = make('bneck.dec.%d_%d_%d' % shape, B, H, W)
+    w2 = F.pack_conv_weight(dev(p['w2']), BF)
+    w3 = dev(p['w3'].reshape(256, 64)).to(BF)
+    w1 = dev(p['w1'].reshape(64, 256)).to(BF)
+    args = (nhwc(p['y1']), w2, dev(p['s2']), dev(p['h2']), w3, dev(p['s3']), dev(p['h3']))
+    kw = dict(residual=nhwc(p['res']), nxt=(w1, dev(p['s1']), dev(p['h1'])))
+    full, y1n = F.bottleneck_chain(*args, **kw)
+    dec, y1n_d = F.bottleneck_chain(*args, decimate=True, **kw)
+    assert dec.shape == (B, H // 2, W // 2, 256)
+    assert torch.equal(dec, full[:, ::2, ::2].contiguous())
+    assert torch.equal(y1n_d, y1n)

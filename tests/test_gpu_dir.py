@@ -496,3 +496,26 @@ def test_extra_refinement_stages_vs_oracle(mode):
         assert relerr(outs[5]['seg'].cpu().numpy(), ref[5]['seg']) < 5e-4
         pf = outs[5]['proj_feat'].cpu().numpy()
         assert relerr(pf[:, 0:1280:97], ref[5]['proj_feat'][:, 0:1280:97]) < 5e-4
+
+
+def test_c1_decimation_is_bit_identical_and_taps_still_see_c1(dir_state):
+    """Round 4: in bf16 mode the last layer1 block writes only the even pixels of its output (its one reader is layer2's stride-2 projection
+    shortcut; dir_bneck_chain_params.out_decimate) unless c1 itself is asked for.  Same values reach every later kernel: outputs are
+    bit-identical with the switch off, and a forward with taps (which returns c1) is unchanged."""
+    sd, img = dir_state
+    eng = DirEngine(sd, dtype=torch.bfloat16)
+    assert eng.bb.decimate_c1
+    a = eng.forward(img)
+    torch.cuda.synchronize()
+    keep = [a[i][k].clone() for i in range(3) for k in ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset')] + [a[3]['seg'].clone(), a[3]['proj_feat'].clone()]
+    eng.bb.decimate_c1 = False
+    b = eng.forward(img)
+    torch.cuda.synchronize()
+    got = [b[i][k] for i in range(3) for k in ('pd_mesh_xyz_left', 'pd_joint_uv_right', 'pd_offset')] + [b[3]['seg'], b[3]['proj_feat']]
+    assert all(torch.equal(x, y) for x, y in zip(keep, got))
+    eng.bb.decimate_c1 = True
+    taps = {}
+    c = eng.forward(img, taps=taps)
+    torch.cuda.synchronize()
+    assert taps['c1'] is not None and tuple(taps['c1'].shape) == (img.shape[0], 64, 64, 256)
+    assert torch.equal(c[2]['pd_mesh_xyz_left'], keep[6])

@@ -239,3 +239,67 @@ def test_full_training_step_gradient_trained_like_weights(golden):
     assert med < 2.5 * med_ref, (med, med_ref)            # measured 6.4e-2 vs 3.5e-2: a different ALGORITHM per layer, not just another thread count
     p90, p90_ref = float(np.percentile([e for e, _, _ in errs], 90)), float(np.percentile(refs, 90))
     assert p90 < 3.0 * p90_ref, (p90, p90_ref)
+
+
+def test_full_training_step_gradient_frozen_batchnorm_pinned_tightly(golden):
+    """VERDICT r3 item 6 -- the whole-step gradient pinned where it CAN be pinned.  G20e is the reference's `sum(loss).backward()` through its own DIR
+    (train.py:66-68) with every BatchNorm module in .eval(): in that form the reference's fp32 gradient is reproducible under a change of
+    summation order to a median 4e-5 of each tensor's maximum (stored per parameter as ref_repro.*), against 2e-2 .. 4e-2 with training-mode
+    BatchNorm (G20c, the test above).  dir_amd.train.ops.frozen_batchnorm() gives dir_amd/train/net.py the same switch (dir_bn_frozen_forward /
+    _backward), and then EVERY one of the 556 parameter gradients -- all convolutions' data and weight gradients in split precision, the token
+    path, MANO, the 42-term objective -- is held to 1e-3 of its maximum (measured: see the printed line), i.e. everything except the batch-statistics
+    BatchNorm backward, which keeps its own pin (G13-G19: tests/test_gpu_train_ops.py at 1e-5) and G20c as its end-to-end yardstick."""
+    from conftest import loss_case
+    from dir_amd.train import ops as O
+    g8, g20 = golden('g8c_loss'), golden('g20e_full_grad_frozen_bn')
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED, cond=True)
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if 'num_batches' not in k}
+    stats_before = {k: v.clone() for k, v in P.items() if 'running_' in k}
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+    keep = []
+    with O.frozen_batchnorm():
+        outs, ctx = TN.forward(P, img, keep)
+        loss = TN.losses(outs, target, meta, fc)
+        G = TN.backward(P, ctx, outs, target, meta, fc)
+    assert not O.BN_FROZEN
+    assert len(loss) == 42
+    for k, v in loss.items():
+        assert abs(float(v) - float(g20['loss.' + k])) < 2e-5 * max(1.0, abs(float(g20['loss.' + k]))), (k, float(v), float(g20['loss.' + k]))
+    for k, v in stats_before.items():
+        assert torch.equal(P[k], v), k                      # frozen: the running statistics are not touched
+    none = set(str(k) for k in g20['none'])
+    trained = {k for k in shapes if not any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight')) and k not in none}
+    assert set(G) == trained
+    errs = []
+    for k, v in G.items():
+        # (nothing is skipped here: the biases in front of a BatchNorm, whose gradient batch statistics cancel -- ZERO above --, carry a real
+        # gradient once the statistics are frozen; only PGraphConv's e_0 stays identically zero, SemGCN/p_graph_conv.py:45-48)
+        a = v.cpu().numpy().astype(np.float64)
+        while a.ndim > 2 and a.shape[-1] == 1:
+            a = a[..., 0]
+        if 'g32.grad.' + k in g20:
+            ref = g20['g32.grad.' + k]
+            if np.abs(ref).max() == 0:
+                assert np.abs(a).max() == 0, k
+                continue
+            e = np.abs(a.reshape(ref.shape) - ref).max() / (np.abs(ref).max() + 1e-30)
+        else:
+            a2 = a.reshape(a.shape[0], -1) if (a.ndim == 4 and a.shape[-1] <= 7) else a.reshape(-1, a.shape[-1])
+            ck = [q for q in g20 if q.startswith('g32.grad.' + k + '.cols')][0]
+            e = np.abs(a2[:, ::int(ck.rsplit('.cols', 1)[1])] - g20[ck]).max() / (np.abs(g20[ck]).max() + 1e-30)
+        errs.append((float(e), k, float(g20['ref_repro.' + k])))
+    errs.sort(reverse=True)
+    med, med_ref = float(np.median([e for e, _, _ in errs])), float(np.median([r for _, _, r in errs]))
+    print('whole step, frozen BatchNorm, trained-like weights: %d gradients; median distance to the reference gradient %.2e of each maximum (the reference, '
+          '8 vs 1 thread: %.2e); worst three %s' % (len(errs), med, med_ref, errs[:3]))
+    assert len(errs) >= 500
+    for e, k, r in errs:
+        assert e < 1e-3, (k, e, r)
