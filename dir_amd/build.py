@@ -28,7 +28,7 @@ FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++20', '-fPIC', '-Wall', '-Wno-
 if os.environ.get('DIR_PACKED_FP32') == '1':
     # investigation aid (tools/pkfp32_repro.hip, tools/aggressor_test.py): the library WITH packed-FP32 instructions, built beside the
     # product library as lib/libdir_hip_pk.so from its own object directory; never loaded unless DIR_LIB_PATH points at it
-    FLAGS = [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')]
+    FLAGS = [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')] + ['-DDIR_INVESTIGATE_RING_64x128=1']
     OBJ = os.path.join(HERE, 'build', 'obj_pk')
     LIB = os.path.join(LIBDIR, 'libdir_hip_pk.so')
 FLAGS += os.environ.get('DIR_HIPCC_EXTRA', '').split()       # tuning / debugging aid (changing it needs --force)

@@ -1177,7 +1177,10 @@ class DirEngine(object):
         res['vis_img_feat'] = vis
         return res
 
-    pgcn_fused = os.environ.get('DIR_PGCN_FUSED', '1') != '0'       # A/B aid: 0 = the five launches per stack of rounds 2-3
+    # The P-GCN stack of both hands as ONE launch (tokens.hip: pgcn_fused_kernel, layers separated by per-node flags): built, bit-identical, and
+    # measured no faster than the five launches it replaces (B = 64: 29.9 us with 4 splits against 31.4 us; 38 us with the 2 splits that keep six
+    # concurrent launches co-resident) -- a device-coherent hand-off costs what a kernel boundary costs.  Off unless DIR_PGCN_FUSED=1.
+    pgcn_fused = os.environ.get('DIR_PGCN_FUSED', '0') == '1'
 
     def _pgcn_sync(self):
         """the fused P-GCN launch's flag words: zeroed once, one buffer per stream that runs forwards of this engine (two streams' launches must

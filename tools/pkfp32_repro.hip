@@ -59,6 +59,112 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ tab, uns
     if (__float_as_uint(acc.y) != __float_as_uint(s1)) atomicAdd(bad_hi, 1u);
 }
 
+// Synthetic aggressors (round 4; variant < -1): which ingredient of the library's 64x128 ring tile does the victim need beside it?  One
+// 8-wave workgroup per CU, 128 KB of LDS (a 4-wave victim workgroup still fits beside it), per wave and iteration:
+//   -2  16 x v_mfma_f32_32x32x16_bf16 on registers      -3  16 ds_read_b128      -4  3 LDS-DMA pieces (buffer_load_dwordx4 ... lds) + vmcnt
+//   -5  MFMA + ds_read + DMA together (the K loop of the convolution)            -6  DMA + ds_read      -7  s_sleep only (resident, idle)
+//   -8  MFMA + ds_read      -9  MFMA + DMA
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+typedef __attribute__((ext_vector_type(16))) float af32x16;
+typedef int __attribute__((ext_vector_type(4))) ai32x4;
+typedef unsigned __attribute__((ext_vector_type(4))) au32x4;
+template <bool MFMA, bool LDSR, bool DMA>
+__global__ __launch_bounds__(512, 1) void aggr(const char* src, int iters, float* sink) {
+    __shared__ __attribute__((aligned(16))) char lds[128 * 1024];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const char* base = src + (size_t)(blockIdx.x % 16) * 262144;
+    const ai32x4 rs = {(int)(unsigned)(unsigned long long)base, (int)(unsigned)((unsigned long long)base >> 32), 262144, 0x00020000};
+    const unsigned lbase = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
+    for (int i = tid; i < 32 * 1024; i += 512)
+        reinterpret_cast<unsigned*>(lds)[i] = 0x3c003c00u ^ ((i * 2654435761u) >> 9 & 0x03ff03ffu) ^ ((i & 1) ? 0x80000000u : 0) ^ ((i & 2) ? 0x8000u : 0);
+    __syncthreads();
+    au32x4 fa[2][4], fb[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int q = 0; q < 4; ++q) {
+            fa[i][q] = *reinterpret_cast<const au32x4*>(lds + ((wave * 64 + i * 32 + (lane & 31)) * 128 + ((lane >> 5) * 4 + q) * 16) % 65536);
+            fb[i][q] = *reinterpret_cast<const au32x4*>(lds + 65536 + ((wave * 64 + i * 32 + (lane & 31)) * 128 + ((lane >> 5) * 4 + q) * 16) % 65536);
+        }
+    af32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    au32x4 x = fa[0][0];
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (LDSR) {
+            const int off = (it & 1) * 16384;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i][q] = *reinterpret_cast<const au32x4*>(lds + (off + (wave * 64 + i * 32 + (lane & 31)) * 128 + (((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) * 16) % 65536);
+                    fb[i][q] = *reinterpret_cast<const au32x4*>(lds + 65536 + (off + (i * 32 + (lane & 31)) * 128 + (((lane >> 5) * 4 + q) ^ ((lane >> 1) & 7)) * 16) % 65536);
+                }
+            if constexpr (!MFMA) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) x ^= fa[i][q] ^ fb[i][q];
+            }
+        }
+        if constexpr (DMA) {
+            for (int u = 0; u < 3; ++u) {
+                const unsigned voff = ((unsigned)((it * 3 + u) * 8 + wave) * 1024u + lane * 16u) & 262143u;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" ::"v"(voff), "s"(lbase + 98304 + wave * 1024 + u * 8192), "s"(rs) : "memory", "m0");
+            }
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        }
+        if constexpr (MFMA) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, fa[i][q]), __builtin_bit_cast(abf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+        }
+        if constexpr (!MFMA && !LDSR && !DMA) __builtin_amdgcn_s_sleep(8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sres = __uint_as_float(x.x ^ x.y ^ x.z ^ x.w);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) sres += acc[i][j][e];
+    if (sres == 1.2345f) sink[0] = sres;
+}
+static void launch_synthetic_aggressor(int variant, const char* src, float* sink, hipStream_t s) {
+    const int iters = 600;
+    switch (variant) {
+        case -2: hipLaunchKernelGGL((aggr<true, false, false>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        case -3: hipLaunchKernelGGL((aggr<false, true, false>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        case -4: hipLaunchKernelGGL((aggr<false, false, true>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        case -5: hipLaunchKernelGGL((aggr<true, true, true>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        case -6: hipLaunchKernelGGL((aggr<false, true, true>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        case -8: hipLaunchKernelGGL((aggr<true, true, false>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        case -9: hipLaunchKernelGGL((aggr<true, false, true>), dim3(256), dim3(512), 0, s, src, iters, sink); break;
+        default: hipLaunchKernelGGL((aggr<false, false, false>), dim3(256), dim3(512), 0, s, src, iters * 8, sink); break;
+    }
+}
+
+// victim 9 / 10 (round 4): the ONE form the ISA-level bisect of the MANO kernel left standing (tools/pkfp32_patch_build.py: replacing the 43
+// `v_pk_fma_f32 ... op_sel:[0,1,0]` of mano_forward_kernel<256,1> by their scalar halves clears all differences; replacing any other class of
+// packed instruction does not): the packed FMA whose LOW result takes src1's HIGH dword (src1.hi broadcast to both halves).  9: operands in
+// registers; 10: src1 re-read from LDS (ds_read_b64) in every iteration, as the MANO kernel's pose-map weights are.
+template <bool LDSFED>
+__global__ __launch_bounds__(256) void victim_opsel(unsigned* bad_lo, unsigned* bad_hi, int iters) {
+    __shared__ __attribute__((aligned(8))) float sm[256 * 2 * 8];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
+    for (int e = 0; e < 8; ++e) { sm[(e * 256 + tid) * 2] = 123.0f + e; sm[(e * 256 + tid) * 2 + 1] = 0.9990f + 1e-4f * ((tid + e) & 15); }
+    __syncthreads();
+    f2 acc = {1.0f + 1e-3f * (t & 255), 0.5f + 1e-3f * (t & 127)};
+    float s0 = acc.x, s1 = acc.y;
+    f2 a = {123.0f, 0.9995f}, b = {1e-3f, -2e-3f};                 // a.x is a decoy: a correct op_sel:[0,1,0] never reads it
+    for (int i = 0; i < iters; ++i) {
+        if (LDSFED) a = *reinterpret_cast<const f2*>(sm + (((i & 7) * 256 + tid) * 2));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0]" : "+v"(acc) : "v"(a), "v"(b));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s0) : "v"(a.y), "v"(b.x));
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(s1) : "v"(a.y), "v"(b.y));
+    }
+    if (__float_as_uint(acc.x) != __float_as_uint(s0)) atomicAdd(bad_lo, 1u);
+    if (__float_as_uint(acc.y) != __float_as_uint(s1)) atomicAdd(bad_hi, 1u);
+}
+
 // victim 2 / 3 / 4: LDS reads only.  The packed-FP32 build of the MANO kernel differs from the scalar one not just in its FMAs but in how it
 // READS LDS (43 ds_read2_b64 + 82 ds_read2_b32 against 11 + 37; 15 ds_read_b128 against 56): maybe what goes wrong beside the LDS-DMA
 // aggressor is an operand fetch.  Every thread fills its own LDS words with a known pattern, then re-reads them ITER times with the
@@ -225,6 +331,12 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(sv));
         for (int h = 0; h < 2; ++h) CK(hipMemcpy(mv.ref[h], mv.verts[h], (size_t)B * 778 * 3 * 4, hipMemcpyDeviceToHost));
         float* got = (float*)malloc((size_t)B * 778 * 3 * 4);
+        {   // FNV-1a over the reference launch's vertices: the same for every build of the victim that computes the same bits
+            unsigned long long cs = 1469598103934665603ull;
+            for (int h = 0; h < 2; ++h)
+                for (size_t i = 0; i < (size_t)B * 778 * 3; ++i) { unsigned u; memcpy(&u, &mv.ref[h][i], 4); cs = (cs ^ u) * 1099511628211ull; }
+            printf("victim alone: vertices checksum %016llx, v[0] = %.9g %.9g %.9g\n", cs, mv.ref[0][0], mv.ref[0][1], mv.ref[0][2]);
+        }
         int wrong_even = 0, wrong_odd = 0;
         for (int r = 0; r < rounds; ++r) {
             for (int k = 0; k < 24; ++k)
@@ -245,12 +357,16 @@ int main(int argc, char** argv) {
     }
     for (int r = 0; r < rounds; ++r) {
         CK(hipMemsetAsync(bad, 0, 8, sv));
-        for (int k = 0; k < 24; ++k)
+        for (int k = 0; k < 24; ++k) {
             if (variant >= 0 && p_dual(&d, y, &d2, x, w, shift, o, sa) != 0) { fprintf(stderr, "aggressor: %s\n", dir_last_error()); return 1; }
+            if (variant < -1) launch_synthetic_aggressor(variant, (const char*)x, (float*)o, sa);
+        }
         if (vmem == 1) hipLaunchKernelGGL(victim<true>, dim3(1024), dim3(256), 0, sv, tab, bad, bad + 1, 512);
         else if (vmem == 2) hipLaunchKernelGGL(victim_lds<2>, dim3(2048), dim3(256), 0, sv, bad, bad + 1, 2048);
         else if (vmem == 3) hipLaunchKernelGGL(victim_lds<3>, dim3(2048), dim3(256), 0, sv, bad, bad + 1, 2048);
         else if (vmem == 4) hipLaunchKernelGGL(victim_lds<4>, dim3(2048), dim3(256), 0, sv, bad, bad + 1, 2048);
+        else if (vmem == 9) hipLaunchKernelGGL(victim_opsel<false>, dim3(1024), dim3(256), 0, sv, bad, bad + 1, 4096);
+        else if (vmem == 10) hipLaunchKernelGGL(victim_opsel<true>, dim3(1024), dim3(256), 0, sv, bad, bad + 1, 4096);
         else if (vmem >= 6 && vmem <= 8) {
             for (int k = 0; k < 12; ++k) {
                 if (vmem == 6) hipLaunchKernelGGL(victim_gload<1>, dim3(512), dim3(256), 0, sv, itab, bad, bad + 1, 135);
@@ -265,6 +381,6 @@ int main(int argc, char** argv) {
         bad_launches[0] += hbad[0] != 0; bad_launches[1] += hbad[1] != 0; ++total;
     }
     printf("aggressor variant %d, victim %s: %d launches, low-half mismatches in %d, high-half mismatches in %d\n", variant,
-           vmem == 0 ? "pk_fma registers" : vmem == 1 ? "pk_fma memory-fed" : vmem == 2 ? "ds_read2_b64" : vmem == 3 ? "ds_read2_b32" : vmem == 4 ? "ds_read_b128" : vmem == 6 ? "global_load_dword" : vmem == 7 ? "global_load_dwordx2" : "global_load_dwordx4", total, bad_launches[0], bad_launches[1]);
+           vmem == 0 ? "pk_fma registers" : vmem == 1 ? "pk_fma memory-fed" : vmem == 2 ? "ds_read2_b64" : vmem == 3 ? "ds_read2_b32" : vmem == 4 ? "ds_read_b128" : vmem == 6 ? "global_load_dword" : vmem == 7 ? "global_load_dwordx2" : vmem == 9 ? "v_pk_fma_f32 op_sel:[0,1,0] registers" : vmem == 10 ? "v_pk_fma_f32 op_sel:[0,1,0] LDS-fed" : "global_load_dwordx4", total, bad_launches[0], bad_launches[1]);
     return 0;
 }
