@@ -147,7 +147,7 @@ class _TrainObjective(torch.autograd.Function):
         from ..train import net as TN
         P = {k: p.detach() for k, p in zip(keys, params)}
         P.update(buffers)
-        outs, c = TN.forward(P, img)
+        outs, c = TN.forward(P, img, scale_owner=box.get('owner'))
         loss = TN.losses(outs, target, meta_info, faces)
         ctx.saved = (P, c, outs, target, meta_info, faces, keys, list(loss))
         box['outs'], box['keys'] = outs, list(loss)
@@ -244,7 +244,7 @@ class DIR(nn.Module):
         named = [(k, p) for k, p in self.named_parameters()]
         buffers = {k: b for k, b in self.named_buffers() if 'num_batches_tracked' not in k}
         faces = (self.init_regressor.mano_layer_left.th_faces, self.init_regressor.mano_layer_right.th_faces)
-        box = {}
+        box = {'owner': self}
         vec = _TrainObjective.apply(box, x, target, meta_info, faces, buffers, [k for k, _ in named], *[p for _, p in named])
         with torch.no_grad():
             for k, b in self.named_buffers():

@@ -29,37 +29,50 @@ WGRAD_ARITH = os.environ.get('DIR_TRAIN_WGRAD_ARITH', ARITH)          # the weig
 RECALIBRATE = int(os.environ.get('DIR_TRAIN_RECALIBRATE', '50'))
 # (A step's backward must follow its own forward before another model's forward starts: the cache bound by begin_step stays active until
 # the next begin_step.)
-# one cache per trained model (keyed by the storage of its first parameter: stable across steps for FlatAdamW views and nn.Parameters alike), so
-# that two networks stepped in one process do not recalibrate each other; a handful of models at most (least recently used one dropped)
-_caches, _MAX_CACHES = {}, 8
-_scales, _state = [], {'call': 0, 'step': 0}
+# One cache per trained model, held BY THE CALLER'S OWNER OBJECT (the optimizer in dir_amd.train.step.train_step, the nn.Module in
+# dir_amd.models.dir.DIR): it lives exactly as long as that object.  Rounds 2-3 keyed a module-level table by the address of the model's first
+# parameter -- an address the caching allocator hands to the NEXT model once the first one is freed, which then inherited scales measured on
+# other weights (found by the round-4 frozen-BatchNorm gradient gate: 1.7e-2 instead of 6e-4 when other tests had run before it).  Without
+# an owner (owner=None: direct calls of dir_amd.train.net.forward) nothing is cached: every convolution measures its scale on what it is given.
+_scales, _state = [], {'call': 0, 'step': 0, 'cached': False}
 
 
-def begin_step(key=None):
-    """called by dir_amd.train.net.forward at the start of every training step; `key` identifies the model being stepped"""
+def begin_step(owner=None):
+    """called by dir_amd.train.net.forward at the start of every training step; `owner`: the object that owns this model's operand-scale
+    cache (any object that accepts attributes), or None = no cache"""
     global _scales, _state
-    if key not in _caches:
-        if len(_caches) >= _MAX_CACHES:
-            _caches.pop(next(iter(_caches)))
-        _caches[key] = ([], {'call': 0, 'step': 0})
-    else:
-        _caches[key] = _caches.pop(key)                    # most recently used last
-    _scales, _state = _caches[key]
+    if owner is None:
+        _scales, _state = [], {'call': 0, 'step': 1, 'cached': False}
+        return
+    cache = getattr(owner, '_dir_conv_scale_cache', None)
+    if cache is None:
+        cache = ([], {'call': 0, 'step': 0, 'cached': True})
+        setattr(owner, '_dir_conv_scale_cache', cache)
+    _scales, _state = cache
     _state['call'] = 0
     _state['step'] += 1
     if RECALIBRATE > 0 and _state['step'] % RECALIBRATE == 1 and _state['step'] > 1:
         del _scales[:]
 
 
-def reset_scales():
-    """forget every cached operand scale (the next step of each model calibrates again on the batch it sees)"""
-    _caches.clear()
-    del _scales[:]
-    _state['call'] = 0
-    _state['step'] = 0
+def end_step():
+    """called by dir_amd.train.net.backward when a step's gradients are complete: convolution calls outside a step (block-level callers, tests)
+    measure their scales again instead of walking on in the finished step's cache"""
+    global _scales, _state
+    _scales, _state = [], {'call': 0, 'step': 1, 'cached': False}
+
+
+def reset_scales(owner=None):
+    """forget the cached operand scales (of `owner`, and the ones bound right now): the next step calibrates again on the batch it sees"""
+    if owner is not None and getattr(owner, '_dir_conv_scale_cache', None) is not None:
+        del owner._dir_conv_scale_cache[0][:]
+        owner._dir_conv_scale_cache[1].update(call=0, step=0)
+    end_step()
 
 
 def _site_scale(x):
+    if not _state.get('cached', False):          # no owner: measure (one host synchronisation per call site)
+        return F.pow2_in_scale(x)
     i = _state['call']
     _state['call'] += 1
     if i < len(_scales) and _scales[i][0] == tuple(x.shape):

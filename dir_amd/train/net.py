@@ -102,10 +102,12 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
 
 
 # ----------------------------------------------------------------------------------------------------------------------------- forward
-def forward(P, img, keep=None):
-    """img NCHW fp32 [B,3,256,256] -> (outs: the three stage dicts + {'seg', 'dense'} NCHW, ctx)"""
+def forward(P, img, keep=None, scale_owner=None):
+    """img NCHW fp32 [B,3,256,256] -> (outs: the three stage dicts + {'seg', 'dense'} NCHW, ctx).  scale_owner: the object that owns this
+    model's cache of split-precision operand scales across steps (train_step passes the optimizer, DIR.forward the module); None = every
+    convolution measures its scale on this batch (a host synchronisation per call site: tests, one-off evaluations)"""
     keep = [] if keep is None else keep
-    TC.begin_step(next(iter(P.values())).data_ptr() if len(P) else None)       # operand-scale cache of THIS model (dir_amd/train/conv.py)
+    TC.begin_step(scale_owner)                                                 # operand-scale cache of THIS model (dir_amd/train/conv.py)
     B = img.shape[0]
     dev = img.device
     ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)
@@ -260,4 +262,5 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
     img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
     G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
     flush(G)
+    TC.end_step()
     return G

@@ -61,7 +61,7 @@ def train_step(named_params, buffers, img, target, meta_info, faces, optimizer, 
     from . import net as TN
     P = {k: v.data for k, v in named_params.items()}
     P.update(buffers)
-    outs, ctx = TN.forward(P, img)
+    outs, ctx = TN.forward(P, img, scale_owner=optimizer)
     loss = TN.losses(outs, target, meta_info, faces)
     optimizer.zero_grad()
     if not overlap_allreduce:

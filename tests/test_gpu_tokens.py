@@ -458,9 +458,18 @@ def test_ste_bf16_linears_autocast_semantics(golden):
     try:
         N.linear = lambda xx, w, b=None: orig(bf(xx), bf(w), b)
         want = OT.ste_forward(g['x'].copy(), N.Params(sdn))
+        # a ragged batch through the 16-wave kernel of round 4 (ste16_kernel: attention probabilities in registers, spatial_norm + LayerNorm fused)
+        xb = synth.synth_input('ste.bf16.big', (37, 42, 128), SEED)
+        want_b = OT.ste_forward(xb.copy(), N.Params(sdn))
     finally:
         N.linear = orig
     assert maxabs(got, want) < 2e-3 * sc, (maxabs(got, want), sc)
+    dxb = dev(xb)
+    xpos = torch.empty(37, 42, 128, device='cuda')
+    yb = torch.empty(37, 42, 64, device='cuda')
+    _capi.check(_capi.lib().dir_ste_forward(C.byref(P), _capi.ptr(dxb), _capi.ptr(xpos), _capi.ptr(yb), 37, _capi.stream_ptr()), 'ste bf16 batch')
+    assert maxabs(yb.cpu().numpy(), want_b) < 2e-3 * np.abs(want_b).max()
+    assert maxabs(xpos.cpu().numpy(), xb + sdn['spatial_pos_embed'].reshape(1, 42, 128)) < 1e-6          # the in-place `x += pos_embed` the reference performs
 
 
 def test_pgcn_bf16_matmuls_autocast_semantics(golden):
