@@ -413,33 +413,40 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------------- round 4: the bf16-weights kernel on 16 waves
-// ste_kernel<true> (8 waves, 11 barrier-separated phases per block) measured 68 us for B = 64 with every phase at 1.6 - 4 us although none of them
-// holds more than ~0.3 us of matrix-core work (DIR_STAMPS=ste): 256 VGPRs with 38 spills (weight fragments of four Linears prefetched in
-// registers), three LDS round trips through the [4][48][45] probability buffer, one wave per SIMD.  ste16_kernel is the same arithmetic laid out
-// for 16 waves (1024 threads, four per SIMD, <= 128 VGPRs) and 7 phases per block:
-//   * attention without the probability buffer: wave u < 12 owns (head u / 3, 16-query tile u % 3).  It forms S^T = K Q^T (keys x queries) on the
-//     exact-fp32 matrix cores, so a lane holds, for ONE query (lane & 15), twelve keys' scores (three key tiles x four accumulator registers):
-//     the row softmax is twelve in-lane values and two cross-lane steps (lanes +16, +32 hold the same query).  The probabilities are then already
-//     the A operand of P V -- MFMA step (key tile, register r) uses keys {16 kt + 4 g + r : g = lane >> 4}, and V's rows are read in that order --
-//     so P never leaves the registers.  (Keys are summed in a permuted order: fp32 rounding differs from ste_kernel's in the last bits.)
+// ------------------------------------------------------------------------------------------------- round 4: the bf16-weights kernel on 12 waves
+// ste_kernel<true> (8 waves, 11 barrier-separated phases per block) measured 58.8 us alone / 68 us inside a forward for B = 64 with every phase at
+// 1.6 - 4 us although none of them holds more than ~0.3 us of bf16 matrix-core work (DIR_STAMPS=ste): 256 VGPRs with 38 spills (weight fragments
+// of four Linears prefetched in registers), three LDS round trips through the [4][48][45] probability buffer.  ste12_kernel is the same
+// arithmetic laid out for 12 waves (768 threads, three per SIMD, 168 VGPRs, no spills) and 7 phases per block:
+//   * attention without the probability buffer: wave u owns (head u / 3, 16-query tile u % 3) -- twelve units, twelve waves.  It forms
+//     S^T = K Q^T (keys x queries) on the exact-fp32 matrix cores, so a lane holds, for ONE query (lane & 15), twelve keys' scores (three key
+//     tiles x four accumulator registers): the row softmax is twelve in-lane values and two cross-lane steps (lanes +16, +32 hold the same
+//     query).  The probabilities are then already the A operand of P V -- MFMA step (key tile, register r) uses keys {16 kt + 4 g + r : g =
+//     lane >> 4}, and V's rows are read in that order -- so P never leaves the registers.  (Keys are summed in a permuted order: fp32 rounding
+//     differs from ste_kernel's in the last bits.)
 //   * spatial_norm of block i and LayerNorm 1 of block i + 1 (or the head's LayerNorm) in one phase: same wave, same tokens, values in registers;
-//   * each wave requests its next Linear's weight tiles one phase early into one of two register buffers (51 VGPRs): no spills.
+//     every LayerNorm's parameters sit in LDS from the start (read from global at the point of use, each such phase began with an exposed L2
+//     round trip);
+//   * each wave requests its next Linear's weight tiles one phase early into one of three register buffers (two qkv / fc1 tiles, one K = 256
+//     fc2 tile, one proj / head tile), AFTER the phase's own loads (vmcnt is in order), and phases meet at an LDS-only barrier (wg_sync).
+// Measured (tools/bench_tokens.py, B = 64, alone): 53.5 us against 58.8 us; per block LN1 3.0, qkv 1.3, attention 5.8, proj 0.8, LN2 1.9, fc1 2.1,
+// fc2 1.1 us.  The attention phase is now bound by the fp32 matrix cores themselves: 552 v_mfma_f32_16x16x4_f32 per sample and block = 4.4 k
+// cycles per SIMD (1.9 us); going below needs split-precision bf16 products for q k^T and P v -- not done.
 // LayerNorm / softmax / residual stream fp32, Linears bf16 x bf16 -> fp32 exactly as ste_kernel<true>.
-constexpr int NTH16 = 1024, NW16 = 16;
+constexpr int NTH12 = 768, NW12 = 12;      // 12 waves = three per SIMD (<= 168 VGPRs): one attention unit each, two qkv tiles each
 
 // Weight tiles of the NEXT Linear live in one of two register buffers whose uses never overlap: W8 (8 fragments: qkv's two tiles per wave, or fc2's
 // one K = 256 tile) and W4 (4 fragments: proj, fc1 or the head) -- 51 VGPRs; one WFrag per Linear kept all five alive across the block loop (spills).
 struct W8 { bf16x8_t v[8]; float bb[2]; };
 struct W4 { bf16x8_t v[4]; float bb[2]; };
 template <int K, int NTW, typename WB>
-__device__ __forceinline__ void load_w16(const float* Wf, const float* __restrict__ bias, int N, int wave, int lane, WB& w) {
+__device__ __forceinline__ void load_w12(const float* Wf, const float* __restrict__ bias, int N, int wave, int lane, WB& w) {
     static_assert(NTW * (K / 32) <= (int)(sizeof(w.v) / sizeof(w.v[0])), "weight buffer too small");
     const unsigned short* __restrict__ W = reinterpret_cast<const unsigned short*>(Wf);
     const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int n = min(wave + NW16 * i, N / 16 - 1) * 16 + li;
+        const int n = min(wave + NW12 * i, N / 16 - 1) * 16 + li;
 #pragma unroll
         for (int kk = 0; kk < K / 32; ++kk) w.v[i * (K / 32) + kk] = *reinterpret_cast<const bf16x8_t*>(W + (long long)n * K + kk * 32 + lk * 8);
         w.bb[i] = bias[n];
@@ -447,7 +454,7 @@ __device__ __forceinline__ void load_w16(const float* Wf, const float* __restric
 }
 // out tile(s) wave + 16 i of  act[48][K] (bf16, LDS) x W^T : the A fragments are shared by the wave's tiles; a wave without a tile skips the phase
 template <int K, int NTW, typename WB, typename F>
-__device__ __forceinline__ void gemm16(const unsigned short* s_a, int lda, const WB& w, int N, int wave, int lane, F store) {
+__device__ __forceinline__ void gemm12(const unsigned short* s_a, int lda, const WB& w, int N, int wave, int lane, F store) {
     if (wave >= N / 16) return;
     const int li = lane & 15, lk = lane >> 4;
     f32x4 acc[NTW][3];
@@ -469,13 +476,13 @@ __device__ __forceinline__ void gemm16(const unsigned short* s_a, int lda, const
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
-                if (i == 0 || wave + NW16 * i < N / 16)
+                if (i == 0 || wave + NW12 * i < N / 16)
                     acc[i][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[kk & 1][m], w.v[i * (K / 32) + kk], acc[i][m], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-        const int nt = wave + NW16 * i;
+        const int nt = wave + NW12 * i;
         if (nt < N / 16) {
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -487,13 +494,22 @@ __device__ __forceinline__ void gemm16(const unsigned short* s_a, int lda, const
         }
     }
 }
-// token t = 4 wave + (lane >> 4) (one round for 42 tokens on 16 waves), 16 lanes per token.  PRE: first x <- LayerNorm_1e-6(x) * pw + pb written
+// token t = 4 wave + (lane >> 4) (one round for 42 tokens on 12 waves), 16 lanes per token.  PRE: first x <- LayerNorm_1e-6(x) * pw + pb written
 // back to the residual stream (spatial_norm, mixSTE.py:200); then LayerNorm_eps(x) * w + b -> bf16 operand rows (the next Linear's input).
-template <bool PRE>
-__device__ __forceinline__ void ln16(float* s_x, const float* pw, const float* pb, const float* w, const float* b, float eps, unsigned short* s_out,
-                                     int wave, int lane) {
+template <bool PRE, typename PF>
+__device__ __forceinline__ void ln12(float* s_x, const float* pw, const float* pb, const float* w, const float* b, float eps, unsigned short* s_out,
+                                     int wave, int lane, PF prefetch) {
     const int li = lane & 15, t = wave * 4 + (lane >> 4);
     const bool live = t < NT;
+    // this phase's own parameters first, THEN the next Linear's weight tiles: vmcnt is in order, so a wait for the parameters must not sit behind
+    // the weight stream (measured with the order reversed: 7 us per LayerNorm phase instead of ~1)
+    float gw[8], gb[8], gpw[PRE ? 8 : 1], gpb[PRE ? 8 : 1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        gw[e] = w[li + 16 * e]; gb[e] = b[li + 16 * e];
+        if constexpr (PRE) { gpw[e] = pw[li + 16 * e]; gpb[e] = pb[li + 16 * e]; }
+    }
+    prefetch();
     float* row = s_x + (live ? t : 0) * LDX + li;
     float v[8], sum = 0.f;
 #pragma unroll
@@ -507,7 +523,7 @@ __device__ __forceinline__ void ln16(float* s_x, const float* pw, const float* p
         sum = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[e] = v[e] * rstd * pw[li + 16 * e] + pb[li + 16 * e];
+            v[e] = v[e] * rstd * gpw[e] + gpb[e];
             if (live) row[16 * e] = v[e];
             sum += v[e];
         }
@@ -519,14 +535,22 @@ __device__ __forceinline__ void ln16(float* s_x, const float* pw, const float* p
     const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / D) + eps);
     if (live) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_out[t * LDB + li + 16 * e] = f2bf_rne(v[e] * rstd * w[li + 16 * e] + b[li + 16 * e]);
+        for (int e = 0; e < 8; ++e) s_out[t * LDB + li + 16 * e] = f2bf_rne(v[e] * rstd * gw[e] + gb[e]);
     }
 }
 
-__global__ __launch_bounds__(NTH16) void ste16_kernel(SteArgs a) {
+// Phase boundary of ste12_kernel: the phases hand over through LDS only, so the barrier waits for this wave's LDS traffic (lgkmcnt) and NOT for its
+// outstanding global loads -- __syncthreads() drains vmcnt too, which made every phase that requests the next Linear's weight tiles last as long
+// as that fetch (measured: 3.2 - 5.7 us for the LayerNorm / attention phases against 0.8 - 2 us for the others).
+__device__ __forceinline__ void wg_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(NTH12) void ste12_kernel(SteArgs a) {
     __shared__ __attribute__((aligned(16))) float sm16[NTP * LDX + NTP * LDB / 2 + NTP * LDQ];      // 24,960 + 13,056 + 74,112 B
     float* s_x = sm16;                                                // [48][130] residual stream (fp32)
     unsigned short* s_nb = reinterpret_cast<unsigned short*>(s_x + NTP * LDX);      // [48][136] bf16: LayerNorm / attention output (Linear operand)
+    // every LayerNorm's weight / bias (3 blocks x (ln1, ln2) + spatial_norm + the head's) in LDS from the start: read from global at the point of
+    // use, each LayerNorm phase began with an exposed L2 round trip (3.2 - 3.8 us per phase measured, ~1 us of it arithmetic)
+    __shared__ float s_ln[16][D];
     float* s_big = s_x + NTP * LDX + NTP * LDB / 2;                   // [48][386] q | k | v (fp32); later [48][264] bf16 MLP hidden at its start
     unsigned short* s_hb = reinterpret_cast<unsigned short*>(s_big);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -534,32 +558,40 @@ __global__ __launch_bounds__(NTH16) void ste16_kernel(SteArgs a) {
     auto stamp = [&]() { if (a.stamps && b == 0 && tid == 0 && nstamp < dir::MAX_STAMPS) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
     stamp();
     // padding rows 42..47: zero once (they are MFMA rows / V rows that must stay finite; no store ever targets them)
-    for (int i = tid; i < (NTP - NT) * LDX; i += NTH16) s_x[NT * LDX + i] = 0.f;
-    for (int i = tid; i < (NTP - NT) * LDB; i += NTH16) s_nb[NT * LDB + i] = 0;
-    for (int i = tid; i < (NTP - NT) * LDQ; i += NTH16) s_big[NT * LDQ + i] = 0.f;
+    for (int i = tid; i < (NTP - NT) * LDX; i += NTH12) s_x[NT * LDX + i] = 0.f;
+    for (int i = tid; i < (NTP - NT) * LDB; i += NTH12) s_nb[NT * LDB + i] = 0;
+    for (int i = tid; i < (NTP - NT) * LDQ; i += NTH12) s_big[NT * LDQ + i] = 0.f;
+    for (int i = tid; i < 16 * D; i += NTH12) {
+        const int v = i >> 7, c = i & (D - 1), blk = v >> 2, q = v & 3;
+        const float* src = v < 12 ? (blk < a.nblocks ? (q == 0 ? a.p.blocks[blk].ln1_w : q == 1 ? a.p.blocks[blk].ln1_b : q == 2 ? a.p.blocks[blk].ln2_w : a.p.blocks[blk].ln2_b) : nullptr)
+                                  : (v == 12 ? a.p.snorm_w : v == 13 ? a.p.snorm_b : v == 14 ? a.p.head_ln_w : a.p.head_ln_b);
+        s_ln[v][c] = src ? src[c] : 0.f;
+    }
     const float* xin = a.x_in + (long long)b * NT * D;
-    for (int i = tid; i < NT * D; i += NTH16) {
+    for (int i = tid; i < NT * D; i += NTH12) {
         const float v = xin[i] + a.p.pos_embed[i];                      // x += spatial_pos_embed (mixSTE.py:196)
         s_x[(i >> 7) * LDX + (i & 127)] = v;
         if (a.x_inout) a.x_inout[(long long)b * NT * D + i] = v;
     }
-    W8 w8;                    // qkv (two of its 24 column tiles on waves 0..7, one on 8..15)  |  fc2 (8 tiles, K = 256)
-    W4 w4;                    // proj (8 tiles)  |  fc1 (16 tiles)  |  head (4 tiles)
-    __syncthreads(); stamp();
+    W8 w8;                    // qkv (two of its 24 column tiles per wave)  |  fc2 (8 tiles, K = 256)
+    W8 w8b;                   // fc1 (16 tiles: two on waves 0..3)
+    W4 w4;                    // proj (8 tiles)  |  head (4 tiles)
+    wg_sync(); stamp();
 
     const int li = lane & 15, lk = lane >> 4;
     for (int blk = 0; blk < a.nblocks; ++blk) {
         const dir_ste_block& P = a.p.blocks[blk];
         // ---- 1. (spatial_norm of the previous block +) LayerNorm 1 -> bf16 operand; qkv's weight tiles are requested first
-        load_w16<D, 2>(P.qkv_wt, P.qkv_b, 384, wave, lane, w8);
-        if (blk == 0) ln16<false>(s_x, nullptr, nullptr, P.ln1_w, P.ln1_b, 1e-6f, s_nb, wave, lane);
-        else ln16<true>(s_x, a.p.snorm_w, a.p.snorm_b, P.ln1_w, P.ln1_b, 1e-6f, s_nb, wave, lane);
-        __syncthreads(); stamp();
+        auto pf_qkv = [&]() { load_w12<D, 2>(P.qkv_wt, P.qkv_b, 384, wave, lane, w8); };
+        if (blk == 0) ln12<false>(s_x, nullptr, nullptr, s_ln[4 * blk], s_ln[4 * blk + 1], 1e-6f, s_nb, wave, lane, pf_qkv);
+        else ln12<true>(s_x, s_ln[12], s_ln[13], s_ln[4 * blk], s_ln[4 * blk + 1], 1e-6f, s_nb, wave, lane, pf_qkv);
+        wg_sync(); stamp();
         // ---- 2. qkv -> s_big (fp32)
-        gemm16<D, 2>(s_nb, LDB, w8, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
-        __syncthreads(); stamp();
+        gemm12<D, 2>(s_nb, LDB, w8, 384, wave, lane, [&](int t, int n, float v) { s_big[t * LDQ + n] = v; });
+        wg_sync(); stamp();
         // ---- 3. attention, one (head, 16-query tile) per wave, probabilities in registers; proj's weight tile is requested first
-        load_w16<D, 1>(P.proj_wt, P.proj_b, D, wave, lane, w4);
+        load_w12<D, 1>(P.proj_wt, P.proj_b, D, wave, lane, w4);
+        load_w12<D, 2>(P.fc1_wt, P.fc1_b, 256, wave, lane, w8b);
         if (wave < HEADS * 3) {
             const int h = wave / 3, qt = wave - 3 * h;
             const float* qp = s_big + (qt * 16 + li) * LDQ + h * HD + lk;            // B operand: Q[query 16 qt + li][d = 4 kk + lk]
@@ -617,32 +649,30 @@ __global__ __launch_bounds__(NTH16) void ste16_kernel(SteArgs a) {
                     if (t < NT) s_nb[t * LDB + h * HD + nt * 16 + li] = f2bf_rne(o[nt][r]);
                 }
         }
-        __syncthreads(); stamp();
+        wg_sync(); stamp();
         // ---- 4. proj + residual
         auto add_x = [&](int t, int n, float v) { s_x[t * LDX + n] += v; };
-        gemm16<D, 1>(s_nb, LDB, w4, D, wave, lane, add_x);
-        __syncthreads(); stamp();
+        gemm12<D, 1>(s_nb, LDB, w4, D, wave, lane, add_x);
+        wg_sync(); stamp();
         // ---- 5. LayerNorm 2; fc1's and fc2's weight tiles are requested first (both buffers are free)
-        load_w16<D, 1>(P.fc1_wt, P.fc1_b, 256, wave, lane, w4);
-        load_w16<256, 1>(P.fc2_wt, P.fc2_b, D, wave, lane, w8);
-        ln16<false>(s_x, nullptr, nullptr, P.ln2_w, P.ln2_b, 1e-6f, s_nb, wave, lane);
-        __syncthreads(); stamp();
+        ln12<false>(s_x, nullptr, nullptr, s_ln[4 * blk + 2], s_ln[4 * blk + 3], 1e-6f, s_nb, wave, lane, [&]() { load_w12<256, 1>(P.fc2_wt, P.fc2_b, D, wave, lane, w8); });
+        wg_sync(); stamp();
         // ---- 6. fc1 + GELU -> bf16 hidden (q | k | v are dead)
-        gemm16<D, 1>(s_nb, LDB, w4, 256, wave, lane, [&](int t, int n, float v) {
+        gemm12<D, 2>(s_nb, LDB, w8b, 256, wave, lane, [&](int t, int n, float v) {
             s_hb[t * LDHB + n] = f2bf_rne(0.5f * v * (1.f + erf_as(v * 0.70710678118654752f)));
         });
-        __syncthreads(); stamp();
+        wg_sync(); stamp();
         // ---- 7. fc2 + residual
-        gemm16<256, 1>(s_hb, LDHB, w8, D, wave, lane, add_x);
-        __syncthreads(); stamp();
+        gemm12<256, 1>(s_hb, LDHB, w8, D, wave, lane, add_x);
+        wg_sync(); stamp();
     }
     // ---- (spatial_norm of the last block +) the head's LayerNorm (eps 1e-5), then Linear 128 -> 64 (mixSTE.py:187-190)
-    load_w16<D, 1>(a.p.head_wt, a.p.head_b, 64, wave, lane, w4);
-    if (a.nblocks > 0) ln16<true>(s_x, a.p.snorm_w, a.p.snorm_b, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, s_nb, wave, lane);
-    else ln16<false>(s_x, nullptr, nullptr, a.p.head_ln_w, a.p.head_ln_b, 1e-5f, s_nb, wave, lane);
-    __syncthreads(); stamp();
+    auto pf_head = [&]() { load_w12<D, 1>(a.p.head_wt, a.p.head_b, 64, wave, lane, w4); };
+    if (a.nblocks > 0) ln12<true>(s_x, s_ln[12], s_ln[13], s_ln[14], s_ln[15], 1e-5f, s_nb, wave, lane, pf_head);
+    else ln12<false>(s_x, nullptr, nullptr, s_ln[14], s_ln[15], 1e-5f, s_nb, wave, lane, pf_head);
+    wg_sync(); stamp();
     float* y = a.y + (long long)b * NT * 64;
-    gemm16<D, 1>(s_nb, LDB, w4, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    gemm12<D, 1>(s_nb, LDB, w4, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
     stamp();
 }
 
@@ -664,7 +694,7 @@ extern "C" int dir_ste_forward(const dir_ste_params* p, const float* x, float* x
     a.stamps = dir::stamps_begin("ste");
     DIR_REQUIRE(p->weight_dtype == DIR_DT_F32 || p->weight_dtype == DIR_DT_BF16, "dir_ste_forward: weight_dtype must be f32 or bf16");
     static const int v1 = getenv("DIR_STE_V1") ? atoi(getenv("DIR_STE_V1")) : 0;          // A/B aid: 1 = the 8-wave kernel of rounds 1-3 for bf16 weights too
-    if (p->weight_dtype == DIR_DT_BF16 && !v1) DIR_LAUNCH(ste16_kernel, dim3(B), dim3(NTH16), 0, (hipStream_t)stream, a);
+    if (p->weight_dtype == DIR_DT_BF16 && !v1) DIR_LAUNCH(ste12_kernel, dim3(B), dim3(NTH12), 0, (hipStream_t)stream, a);
     else if (p->weight_dtype == DIR_DT_BF16) DIR_LAUNCH(ste_kernel<true>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     else DIR_LAUNCH(ste_kernel<false>, dim3(B), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     dir::stamps_end("ste", a.stamps, (hipStream_t)stream);
