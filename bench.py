@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument('--tuning', choices=['throughput', 'time'], default='throughput',
                     help='per-layer conv kernel table of the timed graphs: throughput = dir_amd/tuning/ (fewest joules per launch: the socket power '
                          'cap is what bounds several forwards in flight, DESIGN.md 9) when it matches this engine, else the live time-tuned choice')
+    ap.add_argument('--force-table', action='store_true', help='load the throughput table even with one forward in flight / without graphs (profiling runs: the kernels of the timed graphs, one at a time)')
     ap.add_argument('--no-time-table-pass', action='store_true', help='skip the second per-launch pass with the time-tuned table (profiling runs: keeps the traces to the timed configuration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ceiling-probe', action='store_true', help='skip the in-run MFMA / HBM ceiling probe (2 s, outside the timed regions)')
@@ -228,7 +229,9 @@ def main():
             ser.append((time.perf_counter() - t0) / 10 * 1e3)
         serial_ms = statistics.median(ser)      # one forward at a time, time-tuned kernels (reported beside `value`)
     t_time = None
-    if args.tuning == 'throughput' and not args.no_autotune:
+    # (the throughput table is for several forwards in flight under captured graphs only: one forward alone runs ~15 % slower with it, so the
+    # single-graph and eager paths keep the time-tuned choice -- ADVICE r3)
+    if args.tuning == 'throughput' and not args.no_autotune and ((args.inflight > 1 and not args.no_graph) or args.force_table):
         t_time = eng.export_tuning(B)
         meta = eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
         if meta is not None:
@@ -266,7 +269,9 @@ def main():
             pipe_t = E.ForwardPipeline(eng, imgs, streams=pipe.streams)
             q_t = quick(pipe_t)
             table_check = {'throughput_table_ms_per_step': round(q_tp, 3), 'time_tuned_ms_per_step': round(q_t, 3), 'steps': 60}
-            if q_t < 0.99 * q_tp:
+            # one decision for the whole job: rank 0's (every rank must time the same table under one `conv_tuning` label)
+            take_time_tuned = mx(1.0 if (rank == 0 and q_t < 0.99 * q_tp) else 0.0) > 0.5
+            if take_time_tuned:
                 pipe, conv_tuning = pipe_t, 'time (live autotune): the shipped throughput table was slower on this machine (%.3f vs %.3f ms per step)' % (q_tp, q_t)
             else:
                 del pipe_t

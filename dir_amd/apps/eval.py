@@ -189,6 +189,12 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
     ring = (DecodeRing if source == 'jpeg' else ShardRing)(data_path, split, bs, workers=workers, indices=indices)
     m = EvalMetrics(J_regressor, root_joint, scale, stage_num)
     slots = [torch.zeros(bs, IMG_SIZE, IMG_SIZE, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+    batches = iter(ring)
+    first = next(batches, None)
+    if first is not None and eng.arith is not None and not eng.calibrated:
+        # f16 arithmetic modes: the per-layer power-of-two operand scales come from the first batch, BEFORE the slots' graphs are captured (the
+        # scales are launch arguments: a graph captured earlier would replay the uncalibrated ones)
+        eng.calibrate(first[0].to(dev))
     pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
     pending = [None, None]
 
@@ -202,7 +208,8 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
 
     t0, seen = time.perf_counter(), 0
     try:
-        for k, (frames, annos, n) in enumerate(ring):
+        import itertools
+        for k, (frames, annos, n) in enumerate(itertools.chain([first] if first is not None else [], batches)):
             slot = k % 2
             if pending[slot] is not None:
                 finish(slot)
@@ -239,16 +246,22 @@ def main(argv=None):
     ap.add_argument('--root_joint', type=int, default=0)              # 0 wrist, 9 middle MCP
     ap.add_argument('--scale', type=lambda v: str(v).lower() not in ('0', 'false', 'no'), default=True)
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16', help='bf16 feature maps (throughput mode) or exact fp32 (parity mode)')
-    ap.add_argument('--workers', type=int, default=8)
+    ap.add_argument('--arith', choices=['f16x3', 'f16'], default=None, help="with --dtype f32: convolutions on the f16 matrix cores -- 'f16x3' split "
+                    "precision (the 1e-4 mm parity mode at 10 k images/s), 'f16' one MFMA per product (every stage within 0.01 mm, 13 k images/s)")
+    ap.add_argument('--source', choices=['jpeg', 'u8'], default='jpeg', help="jpeg: <split>/img/<idx>.jpg as the reference prepares them; u8: the prepared "
+                    "uint8 shards of dir_amd.apps.dataset.write_u8_shards (no decode in the loop)")
+    ap.add_argument('--workers', type=int, default=16, help='decode processes (jpeg) / copy threads (u8); more than the CPUs the process may use is slower')
     ap.add_argument('--result_dir', type=str, default='./result/DIR-PoseEmb-Wrist')
     opt = ap.parse_args(argv)
     state = torch.load(opt.model, map_location='cpu', weights_only=False)
     state = state['net'] if isinstance(state, dict) and 'net' in state else state
-    eng = DirEngine(state, dtype=torch.bfloat16 if opt.dtype == 'bf16' else torch.float32, root_joint=0)     # apps/eval.py:104: DIR(21, './misc/mano')
+    if opt.arith is not None and opt.dtype != 'f32':
+        ap.error('--arith needs --dtype f32 (fp32 feature maps, f16 matrix-core arithmetic)')
+    eng = DirEngine(state, dtype=torch.bfloat16 if opt.dtype == 'bf16' else torch.float32, root_joint=0, arith=opt.arith)     # apps/eval.py:104: DIR(21, './misc/mano')
     mano_layer = gt_layers_from_checkpoint(state)
     J_regressor = {s: Jr(mano_layer[s].J_regressor) for s in ('left', 'right')}
     m, rate = evaluate_from_disk(eng, opt.data_path, J_regressor, mano_layer, bs=opt.bs, root_joint=opt.root_joint, scale=opt.scale,
-                                 workers=opt.workers)
+                                 workers=opt.workers, source=opt.source)
     m.save_txt(opt.result_dir)
     print(m.report())
     print('%d images in %.1f s: %.0f images/s from files' % (rate['images'], rate['seconds'], rate['images_per_sec']))

@@ -271,7 +271,8 @@ class DIR(nn.Module):
         with torch.cuda.device(x.device), torch.no_grad():
             x = x.contiguous() if x.dtype == torch.uint8 else _capi.f32c(x)       # uint8 BGR [B,256,256,3]: fused normalisation
             if not eng.calibrated and eng.arith is not None and not torch.cuda.is_current_stream_capturing():
-                eng.calibrate(x)          # f16x3: per-layer power-of-two input scales from the first batch seen
+                eng.calibrate(x)          # f16x3 / f16: per-layer power-of-two input scales from the FIRST batch this engine sees (64x headroom; a later
+                #                           batch with much larger activations saturates at the f16 maximum: call self.engine().calibrate(batch) again)
             if self.autotune and x.shape[0] not in eng.tuned_batches and not torch.cuda.is_current_stream_capturing():
                 eng.tune_for(x)             # per-layer conv kernel choice (bit-identical results): timed once, re-used for other batch sizes
             flags = torch.zeros(3 + self.extra_stages, 2, x.shape[0], device=x.device, dtype=torch.int32)

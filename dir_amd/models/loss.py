@@ -30,7 +30,8 @@ def _check_faces(faces, dev, n_vertices=778):
     """two [F,3] int tables of the same size with indices in [0, n_vertices): an index out of range would read out of bounds on the
     device.  The range check costs a host round trip, so it is done once per table OBJECT and version: the verdict is stored on the
     tensor itself (an address-keyed cache would be fooled by a freed-and-reused allocation, and would grow without bound)."""
-    fs = [torch.as_tensor(f).to(device=dev, dtype=torch.int32).contiguous() for f in faces]
+    fs = [torch.as_tensor(f).to(device=dev, dtype=torch.int32).contiguous() for f in faces]          # (callers that step in a loop should pass the
+    # same tensor objects every step -- train_step's `faces` tuple, the mirror's th_faces buffers do: a rebuilt tensor is a new object and is checked again)
     if fs[0].shape != fs[1].shape or fs[0].dim() != 2 or fs[0].shape[1] != 3:
         raise _capi.DirHipError('stage losses: faces must be two [F,3] tables of the same size')
     for f, src in zip(fs, faces):
