@@ -416,23 +416,25 @@ __global__ __launch_bounds__(NTHREADS) void ste_kernel(SteArgs a) {
 // ------------------------------------------------------------------------------------------------- round 4: the bf16-weights kernel on 12 waves
 // ste_kernel<true> (8 waves, 11 barrier-separated phases per block) measured 58.8 us alone / 68 us inside a forward for B = 64 with every phase at
 // 1.6 - 4 us although none of them holds more than ~0.3 us of bf16 matrix-core work (DIR_STAMPS=ste): 256 VGPRs with 38 spills (weight fragments
-// of four Linears prefetched in registers), three LDS round trips through the [4][48][45] probability buffer.  ste12_kernel is the same
-// arithmetic laid out for 12 waves (768 threads, three per SIMD, 168 VGPRs, no spills) and 7 phases per block:
+// of four Linears prefetched in registers), three LDS round trips through the [4][48][45] probability buffer, and 552 exact-fp32 MFMAs per sample
+// and block for q k^T and P v (1.9 us of matrix-core time per SIMD).  ste12_kernel is the same network laid out for 12 waves (768 threads, three
+// per SIMD, 168 VGPRs) and 7 phases per block:
 //   * attention without the probability buffer: wave u owns (head u / 3, 16-query tile u % 3) -- twelve units, twelve waves.  It forms
-//     S^T = K Q^T (keys x queries) on the exact-fp32 matrix cores, so a lane holds, for ONE query (lane & 15), twelve keys' scores (three key
-//     tiles x four accumulator registers): the row softmax is twelve in-lane values and two cross-lane steps (lanes +16, +32 hold the same
-//     query).  The probabilities are then already the A operand of P V -- MFMA step (key tile, register r) uses keys {16 kt + 4 g + r : g =
-//     lane >> 4}, and V's rows are read in that order -- so P never leaves the registers.  (Keys are summed in a permuted order: fp32 rounding
-//     differs from ste_kernel's in the last bits.)
-//   * spatial_norm of block i and LayerNorm 1 of block i + 1 (or the head's LayerNorm) in one phase: same wave, same tokens, values in registers;
-//     every LayerNorm's parameters sit in LDS from the start (read from global at the point of use, each such phase began with an exposed L2
-//     round trip);
-//   * each wave requests its next Linear's weight tiles one phase early into one of three register buffers (two qkv / fc1 tiles, one K = 256
-//     fc2 tile, one proj / head tile), AFTER the phase's own loads (vmcnt is in order), and phases meet at an LDS-only barrier (wg_sync).
-// Measured (tools/bench_tokens.py, B = 64, alone): 53.5 us against 58.8 us; per block LN1 3.0, qkv 1.3, attention 5.8, proj 0.8, LN2 1.9, fc1 2.1,
-// fc2 1.1 us.  The attention phase is now bound by the fp32 matrix cores themselves: 552 v_mfma_f32_16x16x4_f32 per sample and block = 4.4 k
-// cycles per SIMD (1.9 us); going below needs split-precision bf16 products for q k^T and P v -- not done.
-// LayerNorm / softmax / residual stream fp32, Linears bf16 x bf16 -> fp32 exactly as ste_kernel<true>.
+//     S^T = K Q^T (keys x queries), so a lane holds, for ONE query (lane & 15), twelve keys' scores (three key tiles x four accumulator
+//     registers): the row softmax is twelve in-lane values and two cross-lane steps (lanes +16, +32 hold the same query).  The probabilities are
+//     then already the A operand of P V -- MFMA k-step 0 takes its eight k slots from (key tile 0, r 0..3 | key tile 1, r 0..3), k-step 1 from
+//     (key tile 2 | zeros), and V's rows are gathered in that order -- so P never leaves the registers;
+//   * q k^T and P v in SPLIT PRECISION on the bf16 matrix cores: a = ah + al (bf16 halves made in registers from the fp32 LDS rows), a b = ah bh +
+//     ah bl + al bh with fp32 accumulation: 21 v_mfma_f32_16x16x32_bf16 per unit instead of 48 fp32 ones, ~2^-16 per product -- far inside this
+//     mode's bf16 Linears (the fp32-weights kernel keeps exact fp32);
+//   * spatial_norm of block i and LayerNorm 1 of block i + 1 (or the head's LayerNorm) in one phase; every LayerNorm's parameters in LDS from the
+//     start;
+//   * each wave requests its next Linear's weight tiles one phase early into one of three register buffers, AFTER the phase's own loads (vmcnt is
+//     in order); phases meet at an LDS-only barrier (wg_sync); the phases are straight-line code (all 48 rows computed, padding rows included: a
+//     predicate is a branch, and at a join hipcc's wait-count pass waits for the weight prefetch).
+// Measured (tools/bench_tokens.py, B = 64, alone): 58.8 -> 47.0 us (16 waves with 127 spills 75.7; 12 waves 58.4; LayerNorm parameters in LDS 53.5;
+// straight-line phases 50.8; split-precision attention 47.0); per block: LN1 2.4, qkv 1.2, attention 3.8 (5.3 in exact fp32), proj 0.8, LN2 2.3,
+// fc1 2.0, fc2 1.1 us.  What is left is per-phase latency (LDS round trip + cross-lane reduction + barrier ~0.8 us each), not arithmetic.
 constexpr int NTH12 = 768, NW12 = 12;      // 12 waves = three per SIMD (<= 168 VGPRs): one attention unit each, two qkv tiles each
 
 // Weight tiles of the NEXT Linear live in one of two register buffers whose uses never overlap: W8 (8 fragments: qkv's two tiles per wave, or fc2's
@@ -487,10 +489,7 @@ __device__ __forceinline__ void gemm12(const unsigned short* s_a, int lda, const
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = m * 16 + lk * 4 + r;
-                    if (t < NT) store(t, nt * 16 + li, acc[i][m][r] + w.bb[i]);
-                }
+                for (int r = 0; r < 4; ++r) store(m * 16 + lk * 4 + r, nt * 16 + li, acc[i][m][r] + w.bb[i]);      // rows 42..47: padding rows (the caller's store decides)
         }
     }
 }
@@ -500,7 +499,6 @@ template <bool PRE, typename PF>
 __device__ __forceinline__ void ln12(float* s_x, const float* pw, const float* pb, const float* w, const float* b, float eps, unsigned short* s_out,
                                      int wave, int lane, PF prefetch) {
     const int li = lane & 15, t = wave * 4 + (lane >> 4);
-    const bool live = t < NT;
     // this phase's own parameters first, THEN the next Linear's weight tiles: vmcnt is in order, so a wait for the parameters must not sit behind
     // the weight stream (measured with the order reversed: 7 us per LayerNorm phase instead of ~1)
     float gw[8], gb[8], gpw[PRE ? 8 : 1], gpb[PRE ? 8 : 1];
@@ -510,7 +508,8 @@ __device__ __forceinline__ void ln12(float* s_x, const float* pw, const float* p
         if constexpr (PRE) { gpw[e] = pw[li + 16 * e]; gpb[e] = pb[li + 16 * e]; }
     }
     prefetch();
-    float* row = s_x + (live ? t : 0) * LDX + li;
+    float* row = s_x + t * LDX + li;           // all 48 rows, padding rows included: straight-line code (a predicate here is a branch, and a branch
+    //                                            makes hipcc's wait-count pass wait for the weight prefetch at the join)
     float v[8], sum = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { v[e] = row[16 * e]; sum += v[e]; }
@@ -524,7 +523,7 @@ __device__ __forceinline__ void ln12(float* s_x, const float* pw, const float* p
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             v[e] = v[e] * rstd * gpw[e] + gpb[e];
-            if (live) row[16 * e] = v[e];
+            row[16 * e] = v[e];
             sum += v[e];
         }
     }
@@ -533,10 +532,8 @@ __device__ __forceinline__ void ln12(float* s_x, const float* pw, const float* p
 #pragma unroll
     for (int e = 0; e < 8; ++e) { v[e] -= mean; sq = fmaf(v[e], v[e], sq); }
     const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / D) + eps);
-    if (live) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s_out[t * LDB + li + 16 * e] = f2bf_rne(v[e] * rstd * gw[e] + gb[e]);
-    }
+    for (int e = 0; e < 8; ++e) s_out[t * LDB + li + 16 * e] = f2bf_rne(v[e] * rstd * gw[e] + gb[e]);
 }
 
 // Phase boundary of ste12_kernel: the phases hand over through LDS only, so the barrier waits for this wave's LDS traffic (lgkmcnt) and NOT for its
@@ -592,18 +589,33 @@ __global__ __launch_bounds__(NTH12) void ste12_kernel(SteArgs a) {
         // ---- 3. attention, one (head, 16-query tile) per wave, probabilities in registers; proj's weight tile is requested first
         load_w12<D, 1>(P.proj_wt, P.proj_b, D, wave, lane, w4);
         load_w12<D, 2>(P.fc1_wt, P.fc1_b, 256, wave, lane, w8b);
-        if (wave < HEADS * 3) {
+        {
+            // Split precision on the bf16 matrix cores (round 4; the exact-fp32 form cost 552 v_mfma_f32_16x16x4_f32 per sample and block: 1.9 us of
+            // matrix-core time per SIMD, 5.3 us per phase): every product of two fp32 numbers a = ah + al, b = bh + bl (bf16 halves) is
+            // ah bh + ah bl + al bh with fp32 accumulation -- relative error ~2^-16 per product, far inside this mode's bf16 Linears.
             const int h = wave / 3, qt = wave - 3 * h;
-            const float* qp = s_big + (qt * 16 + li) * LDQ + h * HD + lk;            // B operand: Q[query 16 qt + li][d = 4 kk + lk]
-            const float* kp = s_big + li * LDQ + 128 + h * HD + lk;                   // A operand: K[key 16 kt + li][d = 4 kk + lk]
+            // eight consecutive fp32 values of an LDS row -> bf16 hi | lo fragments (hi = rne(v), lo = rne(v - hi))
+            auto split8 = [&](const float* p, bf16x8_t& hi, bf16x8_t& lo) {
+                const float2* p2 = reinterpret_cast<const float2*>(p);         // (rows are 8-byte, not 16-byte aligned: pitch 386 floats)
+                const float2 a0 = p2[0], a1 = p2[1], a2 = p2[2], a3 = p2[3];
+                const float v[8] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned short hh = f2bf_rne(v[e]);
+                    hi[e] = __builtin_bit_cast(__bf16, hh);
+                    lo[e] = __builtin_bit_cast(__bf16, f2bf_rne(v[e] - __uint_as_float((unsigned)hh << 16)));
+                }
+            };
+            bf16x8_t qh, ql;
+            split8(s_big + (qt * 16 + li) * LDQ + h * HD + 8 * lk, qh, ql);          // B operand: Q[query 16 qt + li][d = 8 lk .. + 7]
             f32x4 sc[3];
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < HD / 4; ++kk) {
-                const float qv = qp[4 * kk];
-#pragma unroll
-                for (int kt = 0; kt < 3; ++kt) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kp[kt * 16 * LDQ + 4 * kk], qv, sc[kt], 0, 0, 0);
+            for (int kt = 0; kt < 3; ++kt) {
+                bf16x8_t kh, kl;
+                split8(s_big + (kt * 16 + li) * LDQ + 128 + h * HD + 8 * lk, kh, kl);  // A operand: K[key 16 kt + li][d = 8 lk .. + 7]
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql, sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh, sc[kt], 0, 0, 0);
             }
             // sc[kt][r] = <k[key 16 kt + 4 lk + r], q[query 16 qt + li]>: softmax over the keys of this lane's query
             const float scale = 0.17677669529663687f;                                // 32 ** -0.5
@@ -628,26 +640,44 @@ __global__ __launch_bounds__(NTH12) void ste12_kernel(SteArgs a) {
                 }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            // o = P v: MFMA step (kt, r) reduces over keys {16 kt + 4 g + r}: A = this lane's probability register, B = V's rows in that order
+            // o = P v.  The probabilities are already P V's A operand: lane (query li, group lk) holds keys 16 kt + 4 lk + r; MFMA k-step 0 takes its
+            // eight k slots from (kt 0, r 0..3 | kt 1, r 0..3), k-step 1 from (kt 2, r 0..3 | four zeros) -- and V's rows are gathered in exactly that slot order.
+            const float rs = 1.f / sum;
+            bf16x8_t ph[2], pl[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float p0 = sc[e >> 2][e & 3] * rs, p1 = e < 4 ? sc[2][e] * rs : 0.f;
+                const unsigned short h0 = f2bf_rne(p0), h1 = f2bf_rne(p1);
+                ph[0][e] = __builtin_bit_cast(__bf16, h0); ph[1][e] = __builtin_bit_cast(__bf16, h1);
+                pl[0][e] = __builtin_bit_cast(__bf16, f2bf_rne(p0 - __uint_as_float((unsigned)h0 << 16)));
+                pl[1][e] = __builtin_bit_cast(__bf16, f2bf_rne(p1 - __uint_as_float((unsigned)h1 << 16)));
+            }
             f32x4 o[2];
-            o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* vp = s_big + (4 * lk) * LDQ + 256 + h * HD + li;
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
+            for (int nt = 0; nt < 2; ++nt) {
+                o[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float* vc = s_big + 256 + h * HD + nt * 16 + li + (4 * lk) * LDQ;    // column of V, rows = keys 4 lk + ...
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = sc[kt][r] / sum;
-                    const float* vr = vp + (kt * 16 + r) * LDQ;
-                    o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vr[0], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv, vr[16], o[1], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    // B operand: V[key of slot 8 lk + e][column]: k-step 0 keys 4 lk + e (e < 4) | 16 + 4 lk + e - 4; k-step 1 keys 32 + 4 lk + e (e < 4) | nothing
+                    bf16x8_t vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int key0 = ks == 0 ? (e < 4 ? e : 16 + e - 4) : 32 + (e & 3);           // + 4 lk (in vc)
+                        const float v = (ks == 1 && e >= 4) ? 0.f : vc[key0 * LDQ];
+                        const unsigned short hh = f2bf_rne(v);
+                        vh[e] = __builtin_bit_cast(__bf16, hh);
+                        vl[e] = __builtin_bit_cast(__bf16, f2bf_rne(v - __uint_as_float((unsigned)hh << 16)));
+                    }
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[ks], vh, o[nt], 0, 0, 0);
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ks], vl, o[nt], 0, 0, 0);
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ks], vh, o[nt], 0, 0, 0);
                 }
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = qt * 16 + 4 * lk + r;
-                    if (t < NT) s_nb[t * LDB + h * HD + nt * 16 + li] = f2bf_rne(o[nt][r]);
-                }
+                for (int r = 0; r < 4; ++r) s_nb[(qt * 16 + 4 * lk + r) * LDB + h * HD + nt * 16 + li] = f2bf_rne(o[nt][r]);
         }
         wg_sync(); stamp();
         // ---- 4. proj + residual
@@ -672,7 +702,7 @@ __global__ __launch_bounds__(NTH12) void ste12_kernel(SteArgs a) {
     else ln12<false>(s_x, nullptr, nullptr, s_ln[14], s_ln[15], 1e-5f, s_nb, wave, lane, pf_head);
     wg_sync(); stamp();
     float* y = a.y + (long long)b * NT * 64;
-    gemm12<D, 1>(s_nb, LDB, w4, 64, wave, lane, [&](int t, int n, float v) { y[t * 64 + n] = v; });
+    gemm12<D, 1>(s_nb, LDB, w4, 64, wave, lane, [&](int t, int n, float v) { if (t < NT) y[t * 64 + n] = v; });
     stamp();
 }
 
