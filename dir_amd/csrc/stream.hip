@@ -30,7 +30,7 @@ using convk::f32x16;
 using convk::pack2bf;
 using convk::relu2bf;
 
-constexpr int SBM = 128;               // pixels per workgroup
+constexpr int SBM = 128;               // pixels per workgroup (NPB = 4 blocks of 32; the NPB = 2 variant: 64)
 constexpr int SKC = 64;                // channels per K-chunk
 constexpr int STHR = 256;
 constexpr int PRE_MAX = 2304;          // pre-activation parameters staged in LDS
@@ -43,9 +43,11 @@ struct StreamArgs {
     int HoWo, Wo, H2, W2, in_cs2, in_co2, stride2;        // second source geometry (nk > nk1)
 };
 
-// NCB: 32-channel blocks per wave (1: 128 output channels per workgroup, 2: 256)
-template <int NCB, bool PRE>
+// NCB: 32-channel blocks per wave (1: 128 output channels per workgroup, 2: 256); NPB: 32-pixel blocks per workgroup (4: 128 pixels; 2: 64 pixels --
+// twice the workgroups, each half as long: more of them per CU in different phases for the layers whose 128-pixel grid is only two tiles per CU)
+template <int NCB, bool PRE, int NPB>
 __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(StreamArgs a) {
+    constexpr int SBM = 32 * NPB;
     constexpr int NWG = 128 * NCB;                         // output channels per workgroup
     constexpr int OPITCH = 256 + 16;                       // bytes per pixel of the staged output half (128 channels), 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) char s_raw[SBM * OPITCH];      // two 16 KB activation chunks during the K loop, then the output stage
@@ -60,10 +62,10 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
 
     // ---- activation loads: thread = (row (tid >> 3) + 32 i, 16-byte column tid & 7) of the 128 x 64 chunk
     const int col = tid & 7;
-    unsigned off1[4], off2[4];                             // element offsets (tensors < 2^31 elements, checked by the launcher)
-    bool ok[4];
+    unsigned off1[NPB], off2[NPB];                             // element offsets (tensors < 2^31 elements, checked by the launcher)
+    bool ok[NPB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPB; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
         ok[i] = m < a.M;
         const int mc = ok[i] ? m : a.M - 1;
@@ -77,17 +79,17 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
     // Every load below is UNCONDITIONAL (chunk indices clamped, the source picked with a select): a load inside a branch makes
     // hipcc's wait-count pass assume the worst at the join -- vmcnt(0) at the top of every iteration, i.e. no load ever overlaps
     // a computation (first version of this kernel: 2 TB/s).
-    auto a_load = [&](int c, uint4 (&r)[4]) {
+    auto a_load = [&](int c, uint4 (&r)[NPB]) {
         const int cc = min(c, a.nk - 1);
         const bool first = cc < a.nk1;
         const bf16_t* base = first ? a.x : a.x2;
         const unsigned koff = (unsigned)((first ? cc : cc - a.nk1) * SKC);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const uint4*>(base + (first ? off1[i] : off2[i]) + koff);
+        for (int i = 0; i < NPB; ++i) r[i] = *reinterpret_cast<const uint4*>(base + (first ? off1[i] : off2[i]) + koff);
     };
-    auto a_store = [&](int c, int buf, uint4 (&r)[4]) {
+    auto a_store = [&](int c, int buf, uint4 (&r)[NPB]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPB; ++i) {
             const int row = (tid >> 3) + 32 * i;
             uint4 v = r[i];
             if constexpr (PRE) {
@@ -107,15 +109,15 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
             for (int cb = 0; cb < NCB; ++cb) wr[ks][cb] = __builtin_bit_cast(bf16x8, p[(ks * NCB + cb) * 64]);
     };
 
-    f32x16 acc[NCB][4];
+    f32x16 acc[NCB][NPB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
+        for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
 
-    uint4 ar[2][4];
+    uint4 ar[2][NPB];
     bf16x8 wr[2][4][NCB];
     w_load(0, wr[0]);
     a_load(0, ar[0]);
@@ -136,16 +138,16 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
         if (c < a.nk) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 bv[4];
+            bf16x8 bv[NPB];
 #pragma unroll
-            for (int pb = 0; pb < 4; ++pb) {
+            for (int pb = 0; pb < NPB; ++pb) {
                 const int row = 32 * pb + l32;
                 bv[pb] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + (((ks + 4 * h) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                for (int pb = 0; pb < 4; ++pb)
+                for (int pb = 0; pb < NPB; ++pb)
                     acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[par][ks][cb], bv[pb], acc[cb][pb], 0, 0, 0);
         }
         }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
                 if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
                 if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
 #pragma unroll
-                for (int pb = 0; pb < 4; ++pb) {
+                for (int pb = 0; pb < NPB; ++pb) {
                     uint2 o;
                     o.x = pack2bf(fmaf(acc[cb][pb][4 * q], sc.x, sh.x), fmaf(acc[cb][pb][4 * q + 1], sc.y, sh.y));
                     o.y = pack2bf(fmaf(acc[cb][pb][4 * q + 2], sc.z, sh.z), fmaf(acc[cb][pb][4 * q + 3], sc.w, sh.w));
@@ -232,15 +234,20 @@ extern "C" int dir_conv1x1_stream_forward(const dir_conv_desc* d, const void* x,
         a.nk += d2->Cin / SKC;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int tiles = (a.M + SBM - 1) / SBM;
+    // DIR_CONV_VARIANT 22 / 23 in d->flags: 64- / 32-pixel workgroups (same sums, same bits); anything else: 128-pixel workgroups
+    const int var = (d->flags >> 8) & 0xff;                 // 22: 64-pixel workgroups, 23: 32-pixel workgroups
+    const int sbm = var == 22 ? 64 : var == 23 ? 32 : 128;
+    const int tiles = (a.M + sbm - 1) / sbm;
+#define DIR_STREAM(NCB_, PRE_) do { if (var == 22) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 2>), grid, dim3(STHR), 0, s, a); \
+                                    else if (var == 23) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 1>), grid, dim3(STHR), 0, s, a); \
+                                    else DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 4>), grid, dim3(STHR), 0, s, a); } while (0)
     if (d->Cout % 256 == 0) {
         dim3 grid(tiles, d->Cout / 256);
-        if (pre_scale) DIR_LAUNCH((stream1x1_kernel<2, true>), grid, dim3(STHR), 0, s, a);
-        else DIR_LAUNCH((stream1x1_kernel<2, false>), grid, dim3(STHR), 0, s, a);
+        if (pre_scale) DIR_STREAM(2, true); else DIR_STREAM(2, false);
     } else {
         dim3 grid(tiles, d->Cout / 128);
-        if (pre_scale) DIR_LAUNCH((stream1x1_kernel<1, true>), grid, dim3(STHR), 0, s, a);
-        else DIR_LAUNCH((stream1x1_kernel<1, false>), grid, dim3(STHR), 0, s, a);
+        if (pre_scale) DIR_STREAM(1, true); else DIR_STREAM(1, false);
     }
+#undef DIR_STREAM
     return check_launch("dir_conv1x1_stream_forward");
 }

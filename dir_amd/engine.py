@@ -60,6 +60,9 @@ def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
 
 
 STREAM_VARIANT = 21      # DIR_CONV_VARIANT code: dir_conv1x1_stream_forward (1x1, bf16, Cout % 128 == 0), chosen per layer by autotune
+STREAM64_VARIANT = 22    # the same kernel on 64-pixel workgroups (twice as many, half as long)
+STREAM32_VARIANT = 23    # ... on 32-pixel workgroups (the 16x16 / 8x8 stages: 128-pixel tiles do not even cover the CUs there)
+STREAM_VARIANTS = (STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT)
 
 
 def pack_stream_weights(w_nk):
@@ -189,8 +192,8 @@ class ConvOp(object):
                            dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),
                            shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
                                                               self.kw, self.stride))
-        if v == STREAM_VARIANT and self.w_stream is not None and residual is None and bbox is None and out.dtype == torch.bfloat16:
-            d.flags &= 0xff
+        if v in STREAM_VARIANTS and self.w_stream is not None and residual is None and bbox is None and out.dtype == torch.bfloat16:
+            d.flags = (d.flags & 0xff) | ((v & 0xff) << 8 if v != STREAM_VARIANT else 0)
             _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(x), None, None, _capi.ptr(self.w_stream), _capi.ptr(self.scale),
                                                                _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
                                                                _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
@@ -299,8 +302,8 @@ class DualConvOp(object):
                            bytes=(m * self.cin + m * self.cin2 + self.w.numel() + m * self.cout) * es,
                            dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),
                            shape='M=%d N=%d K=%d+%d dual s%d' % (m, self.cout, self.cin, self.cin2, self.stride2))
-        if v == STREAM_VARIANT and self.w_stream is not None:
-            d.flags &= 0xff
+        if v in STREAM_VARIANTS and self.w_stream is not None:
+            d.flags = (d.flags & 0xff) | ((v & 0xff) << 8 if v != STREAM_VARIANT else 0)
             _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(y), d2, _capi.ptr(x), _capi.ptr(self.w_stream), None, _capi.ptr(self.shift),
                                                                None, None, _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
             return out
@@ -1226,7 +1229,7 @@ class DirEngine(object):
     # All of them -- including the streaming 1x1 kernel (STREAM_VARIANT, stream.hip), which feeds the MFMA the same k-slots in the
     # same order as the tiled kernels -- accumulate identically: outputs are bit-identical whichever is chosen
     # (tools/check_stream_layers.py, tests/test_gpu_dir.py::test_autotuned_engine_is_bit_identical).
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15, STREAM_VARIANT)
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15, STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT)
 
     def _profiled_forwards(self, img, n):
         """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""
@@ -1264,7 +1267,7 @@ class DirEngine(object):
                     acc.setdefault(rec['op'], []).append(rec['e0'].elapsed_time(rec['e1']))
                 for op, ts in acc.items():
                     t = min(ts)
-                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 11, 12, 13, 14, 15) else self.STREAM_MARGIN if v == STREAM_VARIANT else 0.03
+                    margin = self.PIPE_MARGIN if v in (8, 9, 10, 11, 12, 13, 14, 15) else self.STREAM_MARGIN if v in STREAM_VARIANTS else 0.03
                     if op not in best or t < best[op][0] * (1.0 - margin):  # a challenger must win by 3 % (timing noise)
                         best[op] = (t, v)
         finally:

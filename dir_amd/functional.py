@@ -203,9 +203,9 @@ def bottleneck_tail(y2, w3, s3, h3, residual, w1n, s1n, h1n, waves=8):
 
 
 def conv1x1_stream(x, w_nk, scale=None, shift=None, relu=False, pre_scale=None, pre_shift=None, pre_relu=False, x2=None, stride2=1,
-                   out=None, out_coff=0, in_coff=0, cin=None):
+                   out=None, out_coff=0, in_coff=0, cin=None, variant=0):
     """dir_conv1x1_stream_forward: y = act(scale * (x[..., in_coff:in_coff+cin] . W1^T + x2[::stride2, ::stride2] . W2^T) + shift), bf16 NHWC.
-    w_nk: fp32/bf16 [Cout, cin (+ Cin2)] (second source's columns appended)"""
+    w_nk: fp32/bf16 [Cout, cin (+ Cin2)] (second source's columns appended); variant 22: 64-pixel workgroups (same bits)"""
     from .engine import pack_stream_weights
     _capi.require_cuda(x, x2, out)
     B, H, W, cbuf = x.shape
@@ -217,7 +217,7 @@ def conv1x1_stream(x, w_nk, scale=None, shift=None, relu=False, pre_scale=None, 
     if out is None:
         out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.bfloat16)
     d = ConvDesc(B, H, W, cin, cbuf, in_coff, Cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, DT_BF16, DT_BF16,
-                 (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0))
+                 (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0) | ((variant & 0xff) << 8))
     d2 = _capi.ConvSrc2(x2.shape[1], x2.shape[2], cin2, x2.shape[3], 0, stride2) if x2 is not None else None
     keep = [None if t is None else _capi.f32c(t) for t in (scale, shift, pre_scale, pre_shift)]
     _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(x), d2, _capi.ptr(x2), _capi.ptr(ws), _capi.ptr(keep[0]), _capi.ptr(keep[1]),

@@ -281,7 +281,9 @@ int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h
  *   8..10 : 8-wave pipelined kernel (conv_pipe.hip), tile 256x128 | 128x128 | 256x64
  *   11    : 8-wave 256x256 tile, two-deep 64 KB slab ring (conv_big.hip; bf16 operands, Cout > 128, no pre-activation / second source)
  *   12..14: the same tiles with halo reuse (stride-1 kh x kw layers whose tile is a rectangle of image rows)
- *   15    : the 8-wave pipelined kernel on a 128x64 tile (32x32 wave tiles): the small-M layers (8x8 / 16x16 maps) */
+ *   15    : the 8-wave pipelined kernel on a 128x64 tile (32x32 wave tiles): the small-M layers (8x8 / 16x16 maps)
+ *   22, 23: dir_conv1x1_stream_forward only: 64- / 32-pixel workgroups instead of 128 (the 16x16 / 8x8 stages, whose 128-pixel grid does not
+ *           cover the CUs); (19 = 64x128 on the ring: not in the product build, see conv.hip) */
 #define DIR_CONV_VARIANT(v) (((v) & 0xff) << 8)
 
 typedef struct dir_conv_desc {

@@ -90,6 +90,26 @@ def test_stream_conv_vs_tiled_kernels_full_size():
     assert float(d.max()) <= float(b.float().abs().max()) * 2.0 ** -6 and float((d > 0).float().mean()) < 0.02
     a2 = F.conv1x1_stream(x, w, s, h, relu=True, pre_scale=ps, pre_shift=pb, pre_relu=True)
     assert torch.equal(a, a2)
+    a3 = F.conv1x1_stream(x, w, s, h, relu=True, pre_scale=ps, pre_shift=pb, pre_relu=True, variant=22)        # 64-pixel workgroups (round 4)
+    assert torch.equal(a, a3)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_stream_conv_64_pixel_workgroups_are_bit_identical(case):
+    """DIR_CONV_VARIANT 22: the streaming kernel on 64-pixel workgroups (twice as many, half as long) -- the same MFMA k-slots in the same order,
+    so every output bit equals the 128-pixel form's, ragged pixel counts, channel slices, second sources and pre-activation included"""
+    B, H, W, Cin, Cout, pre, relu, src2 = case
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(B, H, W, Cin + 24, device='cuda', generator=gen).to(BF)
+    K = Cin + (src2[0] if src2 else 0)
+    w = torch.randn(Cout, K, device='cuda', generator=gen) * (2.0 / K) ** 0.5
+    s, h = torch.rand(Cout, device='cuda', generator=gen) + 0.5, torch.randn(Cout, device='cuda', generator=gen) * 0.3
+    ps, pb = torch.rand(Cin, device='cuda', generator=gen) + 0.5, torch.randn(Cin, device='cuda', generator=gen) * 0.3
+    x2 = torch.randn(B, H * src2[1], W * src2[1], src2[0], device='cuda', generator=gen).to(BF) if src2 else None
+    kw = dict(relu=relu, pre_scale=ps if pre else None, pre_shift=pb if pre else None, pre_relu=pre, x2=x2, stride2=src2[1] if src2 else 1, in_coff=16, cin=Cin)
+    a = F.conv1x1_stream(x, w, s, h, **kw)
+    for v in (22, 23):              # 64- and 32-pixel workgroups
+        assert torch.equal(a, F.conv1x1_stream(x, w, s, h, variant=v, **kw)), v
 
 
 def test_stream_conv_rejects_bad_arguments():

@@ -48,13 +48,18 @@ for name, HW, Cin, Cout, pre, Cin2, s2 in LAYERS:
         call = lambda: op(x)  # noqa: E731
         nbytes = (M * (Cin + Cout) + op.w.numel()) * 2
     best = None
-    for v in tuple(v for v in E.DirEngine.CONV_VARIANTS if v != E.STREAM_VARIANT) + (E.STREAM_VARIANT,):
+    ts64 = None
+    for v in tuple(v for v in E.DirEngine.CONV_VARIANTS if v not in E.STREAM_VARIANTS) + E.STREAM_VARIANTS:
         E._TLS.variant = v
         t = timeit(call)
         if v == E.STREAM_VARIANT:
             ts = t
+        elif v == E.STREAM64_VARIANT:
+            ts64 = t
+        elif v == E.STREAM32_VARIANT:
+            ts32 = t
         elif best is None or t < best[0]:
             best = (t, v)
     E._TLS.variant = None
-    print('%-44s M=%6d  stream %6.1f us (%.2f TB/s)   best tiled %6.1f us (variant %2d, %.2f TB/s)   %.1f MB'
-          % (name, M, ts, nbytes / ts / 1e6, best[0], best[1], nbytes / best[0] / 1e6, nbytes / 1e6))
+    print('%-44s M=%6d  stream %6.1f us (%.2f TB/s)   64 px %6.1f us (%.2f TB/s)   32 px %6.1f us   best tiled %6.1f us (variant %2d, %.2f TB/s)   %.1f MB'
+          % (name, M, ts, nbytes / ts / 1e6, ts64, nbytes / ts64 / 1e6, ts32, best[0], best[1], nbytes / best[0] / 1e6, nbytes / 1e6))
