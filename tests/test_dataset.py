@@ -109,3 +109,35 @@ def test_u8_shards_round_trip(tmp_path, bs):
         assert seen == len(idx) and len(ring) == (len(idx) + bs - 1) // bs
     finally:
         ring.close()
+
+
+def test_decode_ring_reports_a_failing_worker_instead_of_hanging(tmp_path):
+    """round 4: the ring has no queues in the steady state (workers raise flag bytes in shared memory); a frame that cannot be decoded must
+    surface as an exception in the consumer, not as a flag that never comes"""
+    write_split(str(tmp_path), 6, seed=3)
+    ds = DS.InterHandSplit(str(tmp_path))
+    with open(ds.img_path(4), 'wb') as f:
+        f.write(b'not a jpeg')
+    ring = DS.DecodeRing(str(tmp_path), 'test', batch_size=2, workers=2, pin=False, chunk=1)
+    try:
+        with pytest.raises(RuntimeError):
+            for _ in ring:
+                pass
+    finally:
+        ring.close()
+
+
+def test_decode_ring_many_chunks_and_deep_ring(tmp_path):
+    """more chunks than workers, a ring deeper than the number of batches, a ragged last batch"""
+    write_split(str(tmp_path), 11, seed=5)
+    ds = DS.InterHandSplit(str(tmp_path))
+    ring = DS.DecodeRing(str(tmp_path), 'test', batch_size=4, workers=3, depth=6, pin=False, chunk=1)
+    try:
+        seen = 0
+        for frames, annos, n in ring:
+            for j in range(n):
+                assert np.array_equal(frames[j].numpy(), ds.frame(seen + j))
+            seen += n
+        assert seen == 11
+    finally:
+        ring.close()
