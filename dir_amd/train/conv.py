@@ -11,6 +11,7 @@ DIR_TRAIN_ARITH=f32) and its two gradients.
   insertion and the channel padding to the kernel's 32-channel granularity are copies -- no arithmetic happens outside the library.
 """
 import os
+import warnings
 
 import torch
 
@@ -27,6 +28,7 @@ WGRAD_ARITH = os.environ.get('DIR_TRAIN_WGRAD_ARITH', ARITH)          # the weig
 # convolution calls of a training step happen in a fixed order, so the call counter identifies the site.  64x headroom + saturation at the
 # f16 maximum make a stale scale a (bounded) precision loss, never an inf / nan.
 RECALIBRATE = int(os.environ.get('DIR_TRAIN_RECALIBRATE', '50'))
+HEADROOM = 64.0             # pow2_in_scale puts the largest |operand| in [2^9, 2^10): 64x below the f16 maximum
 # (A step's backward must follow its own forward before another model's forward starts: the cache bound by begin_step stays active until
 # the next begin_step.)
 # One cache per trained model, held BY THE CALLER'S OWNER OBJECT (the optimizer in dir_amd.train.step.train_step, the nn.Module in
@@ -52,7 +54,10 @@ def begin_step(owner=None):
     _state['call'] = 0
     _state['step'] += 1
     if RECALIBRATE > 0 and _state['step'] % RECALIBRATE == 1 and _state['step'] > 1:
+        _state['previous'] = list(_scales)       # kept for this one step: _site_scale compares what it measures now with what was in use
         del _scales[:]
+    else:
+        _state.pop('previous', None)
 
 
 def end_step():
@@ -78,6 +83,12 @@ def _site_scale(x):
     if i < len(_scales) and _scales[i][0] == tuple(x.shape):
         return _scales[i][1]
     s = F.pow2_in_scale(x)
+    prev = _state.get('previous')
+    if prev is not None and i < len(prev) and prev[i][0] == tuple(x.shape) and prev[i][1] >= HEADROOM * s:
+        # the operand grew past the headroom the stale scale left: values were clamped at the f16 maximum somewhere in the last RECALIBRATE steps
+        warnings.warn('dir_amd.train.conv: call site %d (%s) outgrew its cached f16x3 operand scale (%.3g in use, %.3g needed now): operands '
+                      'saturated during the last %d steps; lower DIR_TRAIN_RECALIBRATE or call reset_scales() after a learning-rate change'
+                      % (i, 'x'.join(map(str, x.shape)), prev[i][1], s, RECALIBRATE), RuntimeWarning, stacklevel=3)
     del _scales[i:]
     _scales.append((tuple(x.shape), s))
     return s

@@ -460,6 +460,23 @@ def test_engine_vs_reference_golden_trained_like_weights(golden, dir_state_cond,
         assert relerr(outs[3]['dense'].cpu().numpy(), g['dense']) < 5e-4
 
 
+@pytest.mark.parametrize('mode', ['f16x3', 'f16'])
+def test_calibrating_twice_changes_nothing(dir_state_cond, mode):
+    """ConvOp.set_in_scale rewrites the epilogue scale from scale0, which used to alias it -- a second calibrate() left the
+    scale divided twice and the outputs silently off by a power of two.  Calibrate on one batch, then on a 1/32-amplitude one, then on the first
+    again: the outputs of the first and third calibration are the same bytes."""
+    sd, img = dir_state_cond
+    eng = DirEngine(sd, dtype=torch.float32, arith=mode)
+    eng.calibrate(img)
+    first = {k: v.clone() for k, v in eng.forward(img)[2].items() if torch.is_tensor(v)}
+    eng.calibrate(img / 32)
+    eng.calibrate(img)
+    again = eng.forward(img)[2]
+    torch.cuda.synchronize()
+    for k, v in first.items():
+        assert torch.equal(v, again[k]), k
+
+
 # ---------------------------------------------------------------------------------------------------------------- f4: N refinement iterations
 @pytest.mark.parametrize('mode', ['f32', 'f16x3', 'bf16'])
 def test_extra_refinement_stages_vs_oracle(mode):
