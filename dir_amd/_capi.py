@@ -32,6 +32,11 @@ class ConvSrc2(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('H', 'W', 'Cin', 'in_cstride', 'in_coff', 'stride')]
 
 
+class TrainWeight(C.Structure):          # dir_train_weight
+    _fields_ = [(n, C.c_void_p) for n in ('w', 'fwd', 'fwd_scale', 'dgrad', 'dgrad_scale')] + [(n, C.c_int32) for n in ('Cout', 'Cin', 'kh', 'kw')] + [
+        ('fwd_inv_in', C.c_float), ('dgrad_inv_in', C.c_float)]
+
+
 class BneckChainParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n', 'wd')] + [
         ('n_next', C.c_int32), ('out_decimate', C.c_int32)]
@@ -105,7 +110,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 32          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 33          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -121,6 +126,7 @@ _SIGNATURES = {
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),
+    'dir_train_pack_conv_weights': (C.c_int, [_p, _p, _i, _i, _p]),
     'dir_gemm_f32_splitk_workspace_bytes': (C.c_longlong, [C.POINTER(GemmDesc)]),
     'dir_gemm_f32_splitk': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p, C.c_longlong, _p]),
     'dir_axpy_multi_f32': (C.c_int, [_p, _p, _p, _i, C.c_float, _p]),

@@ -774,6 +774,121 @@ extern "C" int dir_pack_f16x3_weights(const float* w, void* packed, float* scale
     return dir::check_launch("dir_pack_f16x3_weights");
 }
 
+// ---- dir_train_pack_conv_weights: EVERY convolution weight of a training step, in both operand forms, from the OIHW parameters in ONE launch.
+//      A step used to spend ~600 launches on this (per convolution: OIHW -> OHWI copy, pack, scale division for the forward; flip, transpose
+//      copy, channel padding, pack, division for the data gradient).  The tensor is [O][C][T] (T = kh * kw taps, contiguous):
+//        forward row o:        k = t * Cin + c      <-  w[o][c][t]            one workgroup per row; its source is ONE contiguous chunk
+//        data-gradient row c:  k = t * Cout32 + o   <-  w[o][c][T - 1 - t]    one workgroup per FOUR rows c .. c + 3 (16 T contiguous bytes per o)
+//      A thread always reads 16-byte pieces of which every byte is used by its own workgroup (a first version gathered single floats at tap
+//      stride and re-fetched every line once per tap: 2.3 ms for the network's 77 M weights), keeps 4 (inner) x T or 4 x 4 x T values in
+//      registers and emits 8-byte hi / lo stores into the [32 hi | 32 lo] slabs.  Same p, split and layout as pack_f16x3_kernel: bit-identical.
+namespace {
+__device__ __forceinline__ float pack_pow2(float m) {
+    const unsigned E = (__float_as_uint(m) >> 23) & 0xffu;
+    return (m > 0.f && E >= 13u && E <= 253u) ? __uint_as_float((266u - E) << 23) : 1.f;
+}
+__device__ __forceinline__ void pack_store(char* row_out, int c4, float v0, float v1, float v2, float v3, float p) {
+    const uint4 sp = split_f16x3(make_uint4(__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), __float_as_uint(v3)), p);
+    char* slab = row_out + (long long)(c4 & ~7) * 16;
+    *reinterpret_cast<uint2*>(slab + 8 * (c4 & 7)) = make_uint2(sp.x, sp.y);
+    *reinterpret_cast<uint2*>(slab + 64 + 8 * (c4 & 7)) = make_uint2(sp.z, sp.w);
+}
+template <int T>
+__device__ __forceinline__ void train_pack_body(const dir_train_weight& e, int n, bool fwd, float (&s_max)[4][4]) {
+    const int tid = threadIdx.x;
+    if (fwd) {
+        const int Cin = e.Cin, K4 = T * Cin / 4;
+        const float4* src = reinterpret_cast<const float4*>(e.w + (long long)n * Cin * T);
+        float m = 0.f;
+        for (int i = tid; i < K4; i += 256) { const float4 v = src[i]; m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); }
+        m = dir::wave_max(m);
+        if ((tid & 63) == 0) s_max[0][tid >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(s_max[0][0], s_max[0][1]), fmaxf(s_max[0][2], s_max[0][3]));
+        const float p = pack_pow2(m);
+        if (tid == 0) e.fwd_scale[n] = (1.f / p) * e.fwd_inv_in;                       // powers of two: exact
+        char* out = reinterpret_cast<char*>(e.fwd) + (long long)n * K4 * 16;
+        for (int j4 = tid; j4 < Cin / 4; j4 += 256) {                                 // channels 4 j4 .. + 3, all taps: 4 T contiguous floats
+            float v[4 * T];
+#pragma unroll
+            for (int q = 0; q < T; ++q) {
+                const float4 f = src[j4 * T + q];
+                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) pack_store(out, t * (Cin / 4) + j4, v[t], v[T + t], v[2 * T + t], v[3 * T + t], p);
+        }
+        return;
+    }
+    // data gradient: rows c0 .. c0 + 3
+    const int c0 = 4 * n, Cin = e.Cin, Cout = e.Cout, Co32 = (Cout + 31) & ~31, K4 = T * Co32 / 4;
+    const float* src = e.w + (long long)c0 * T;
+    const long long ostride = (long long)Cin * T;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < Cout * T; i += 256) {                                        // (o, float4 q of the 4 T floats): float 4 q + x is (c0 + (4 q + x) / T, tap)
+        const int o = i / T, q = i - o * T;
+        const float4 f = *reinterpret_cast<const float4*>(src + o * ostride + 4 * q);
+        const float a[4] = {fabsf(f.x), fabsf(f.y), fabsf(f.z), fabsf(f.w)};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int cl = (4 * q + x) / T;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m[r] = fmaxf(m[r], cl == r ? a[x] : 0.f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m[r] = dir::wave_max(m[r]);
+        if ((tid & 63) == 0) s_max[r][tid >> 6] = m[r];
+    }
+    __syncthreads();
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        p[r] = pack_pow2(fmaxf(fmaxf(s_max[r][0], s_max[r][1]), fmaxf(s_max[r][2], s_max[r][3])));
+        if (tid == r) e.dgrad_scale[c0 + r] = (1.f / p[r]) * e.dgrad_inv_in;
+    }
+    char* out = reinterpret_cast<char*>(e.dgrad) + (long long)c0 * K4 * 16;
+    for (int o4 = tid; o4 < Co32 / 4; o4 += 256) {
+        float v[4][4 * T];                                                             // [o of the quad][c local * T + tap]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = 4 * o4 + i;
+#pragma unroll
+            for (int q = 0; q < T; ++q) {
+                const float4 f = o < Cout ? *reinterpret_cast<const float4*>(src + o * ostride + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[i][4 * q] = f.x; v[i][4 * q + 1] = f.y; v[i][4 * q + 2] = f.z; v[i][4 * q + 3] = f.w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int u = r * T + (T - 1 - t);                                     // flipped tap
+                pack_store(out + (long long)r * K4 * 16, t * (Co32 / 4) + o4, v[0][u], v[1][u], v[2][u], v[3][u], p[r]);
+            }
+    }
+}
+__global__ __launch_bounds__(256) void train_pack_kernel(const dir_train_weight* __restrict__ table, const int* __restrict__ wg_start, int entries) {
+    __shared__ float s_max[4][4];
+    const int r = blockIdx.x;
+    int lo = 0, hi = entries;                                           // last entry with wg_start[e] <= r
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (wg_start[mid] <= r) lo = mid; else hi = mid; }
+    const dir_train_weight e = table[lo];
+    int n = r - wg_start[lo];
+    const bool fwd = e.fwd != nullptr && n < e.Cout;
+    if (!fwd && e.fwd != nullptr) n -= e.Cout;
+    if (e.kh * e.kw == 1) train_pack_body<1>(e, n, fwd, s_max);
+    else train_pack_body<9>(e, n, fwd, s_max);
+}
+}  // namespace
+
+extern "C" int dir_train_pack_conv_weights(const dir_train_weight* table, const int* wg_start, int entries, int total_workgroups, void* stream) {
+    DIR_REQUIRE(table && wg_start && entries > 0 && total_workgroups > 0, "dir_train_pack_conv_weights: bad arguments");
+    DIR_LAUNCH(train_pack_kernel, dim3(total_workgroups), dim3(256), 0, (hipStream_t)stream, table, wg_start, entries);
+    return dir::check_launch("dir_train_pack_conv_weights");
+}
+
 extern "C" int dir_split_f16_forward(const float* x, void* y, long long pixels, int C, int in_cstride, int in_coff, const float* pre_scale,
                                      const float* pre_shift, int pre_relu, float in_scale, int hi_only, void* stream) {
     DIR_REQUIRE(x && y && pixels >= 0 && C > 0 && C % 32 == 0, "dir_split_f16_forward: bad arguments (C must be a multiple of 32)");

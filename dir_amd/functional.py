@@ -78,27 +78,38 @@ def pow2_in_scale(x, pre_scale=None, pre_shift=None):
 
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
-                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False):
+                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False, prepacked=None):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
     if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
+    if prepacked is not None:
+        # (packed f16x3 weights [Cout][K/32][2][32], their epilogue scale WITH 1 / in_scale folded in, (Cout, kh, kw, Cin)): the training
+        # step's WeightPack (dir_amd/train/conv.py) -- nothing is packed or divided here
+        assert arith == 'f16x3' and w_ohwi is None and scale is None and in_scale is not None
+        w_ohwi, pscale, wshape = prepacked
+    else:
+        wshape = w_ohwi.shape
     _capi.require_cuda(x, w_ohwi, scale, shift, residual, pre_scale, pre_shift, out)
     assert x.is_contiguous() and w_ohwi.is_contiguous() and x.dim() == 4
     B, H, W, cbuf = x.shape
-    Cout, kh, kw, Cin = w_ohwi.shape
+    Cout, kh, kw, Cin = wshape
     if cin is None:
         cin = Cin
-    assert cin == Cin and w_ohwi.dtype == x.dtype
+    assert cin == Cin and (prepacked is not None or w_ohwi.dtype == x.dtype)
     assert arith in (None, 'f16x3', 'f16')               # 'f16': the hi parts only (DIR_DT_F16X1), same packing
     if arith is None:
         in_scale = 0.0
-    if arith is not None:
+    if prepacked is not None:
+        assert x.dtype == torch.float32 and splits == 1
+        scale = pscale
+    elif arith is not None:
         assert x.dtype == torch.float32 and splits == 1
         w_ohwi, scale = (pack_f16x3_weights_device if device_pack else pack_f16x3_weights)(w_ohwi.reshape(Cout, -1), scale)
         if in_scale is None:
             # input scale as DirEngine.calibrate picks it: the largest |activation| the split sees lands in [2^9, 2^10)  (host synchronisation)
             in_scale = pow2_in_scale(x[..., in_coff:in_coff + Cin], pre_scale, pre_shift)
         scale = scale / in_scale
+    if arith is not None:
         if presplit:     # activations split ONCE by dir_split_f16_forward (pre-activation and in_scale applied there), both operands by DMA
             xs = split_f16(x, Cin, in_coff, pre_scale, pre_shift, pre_relu, in_scale, hi_only=(arith == 'f16'))
             x, cbuf, in_coff, pre_scale, pre_shift, pre_relu = xs, Cin, 0, None, None, False

@@ -37,9 +37,8 @@ def bn_bwd(P, pre, saved, gy, G, relu=False):
 
 
 def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True):
-    w = _ohwi(P[key + 'weight'])
     has_bias = (key + 'bias') in P
-    gx, gw, gb = TC.conv_bwd(x, w, gy, stride, pad, need_gx=need_gx, has_bias=has_bias)
+    gx, gw, gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True)
     G[key + 'weight'] = _oihw(gw)
     if has_bias:
         G[key + 'bias'] = gb
@@ -49,13 +48,13 @@ def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True):
 # ------------------------------------------------------------------------------------------------------------------------ Bottleneck
 def bottleneck_forward(P, x, stride=1):
     ctx = {'x': x, 'stride': stride}
-    h = TC.conv_fwd(x, _ohwi(P['conv1.weight']))
+    h = TC.conv_fwd(x, P['conv1.weight'], oihw=True)
     a1, ctx['bn1'] = bn_fwd(P, 'bn1.', h, relu=True)
-    h = TC.conv_fwd(a1, _ohwi(P['conv2.weight']), None, stride, 1)
+    h = TC.conv_fwd(a1, P['conv2.weight'], None, stride, 1, oihw=True)
     a2, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
-    h = TC.conv_fwd(a2, _ohwi(P['conv3.weight']))
+    h = TC.conv_fwd(a2, P['conv3.weight'], oihw=True)
     if 'downsample.0.weight' in P:
-        idn = TC.conv_fwd(x, _ohwi(P['downsample.0.weight']), None, stride, 0)
+        idn = TC.conv_fwd(x, P['downsample.0.weight'], None, stride, 0, oihw=True)
         idn, ctx['bnd'] = bn_fwd(P, 'downsample.1.', idn)
     else:
         idn = x
@@ -88,14 +87,14 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
 def residual_forward(P, x):
     ctx = {'x': x}
     a0, ctx['bn1'] = bn_fwd(P, 'bn1.', x, relu=True)
-    h = TC.conv_fwd(a0, _ohwi(P['conv1.conv.weight']), P['conv1.conv.bias'])
+    h = TC.conv_fwd(a0, P['conv1.conv.weight'], P['conv1.conv.bias'], oihw=True)
     a1, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
-    h = TC.conv_fwd(a1, _ohwi(P['conv2.conv.weight']), P['conv2.conv.bias'], 1, 1)
+    h = TC.conv_fwd(a1, P['conv2.conv.weight'], P['conv2.conv.bias'], 1, 1, oihw=True)
     a2, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True)
-    y = TC.conv_fwd(a2, _ohwi(P['conv3.conv.weight']), P['conv3.conv.bias'])
+    y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True)
     need_skip = P['skip_layer.conv.weight'].shape[0] != P['skip_layer.conv.weight'].shape[1]          # hourglass.py:49-52
     if need_skip:
-        O.axpy(y, TC.conv_fwd(x, _ohwi(P['skip_layer.conv.weight']), P['skip_layer.conv.bias']))
+        O.axpy(y, TC.conv_fwd(x, P['skip_layer.conv.weight'], P['skip_layer.conv.bias'], oihw=True))
     else:
         O.axpy(y, x)
     ctx.update(a0=a0, a1=a1, a2=a2, need_skip=need_skip)

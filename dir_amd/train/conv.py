@@ -28,6 +28,7 @@ WGRAD_ARITH = os.environ.get('DIR_TRAIN_WGRAD_ARITH', ARITH)          # the weig
 # convolution calls of a training step happen in a fixed order, so the call counter identifies the site.  64x headroom + saturation at the
 # f16 maximum make a stale scale a (bounded) precision loss, never an inf / nan.
 RECALIBRATE = int(os.environ.get('DIR_TRAIN_RECALIBRATE', '50'))
+PREPACK = os.environ.get('DIR_TRAIN_PREPACK', '1') == '1'          # WeightPack below (0: pack per convolution call, rounds 2-3)
 HEADROOM = 64.0             # pow2_in_scale puts the largest |operand| in [2^9, 2^10): 64x below the f16 maximum
 # (A step's backward must follow its own forward before another model's forward starts: the cache bound by begin_step stays active until
 # the next begin_step.)
@@ -39,13 +40,112 @@ HEADROOM = 64.0             # pow2_in_scale puts the largest |operand| in [2^9, 
 _scales, _state = [], {'call': 0, 'step': 0, 'cached': False}
 
 
-def begin_step(owner=None):
+class _Packed:
+    """one convolution weight's two packed operand forms inside a WeightPack (views of its buffers)"""
+    __slots__ = ('shape', 'fwd', 'fwd_scale', 'dgrad', 'dgrad_scale', 'dshape', 'applied', 'want', 'index')
+
+
+class WeightPack:
+    """All convolution weights of a model in both DIR_DT_F16X3 operand forms, refreshed by ONE launch per step (dir_train_pack_conv_weights)
+    instead of ~600 (per convolution call: layout copy, pack, scale division; flip, transpose, pad, pack, division for the data gradient).
+    weights: the OIHW fp32 parameter tensors (their storage must stay where it is: FlatAdamW's views of the flat buffer do).  Each operand
+    form's epilogue scale carries 1 / in_scale of the call site that used it last step (`applied`); a site that asks for another in_scale
+    gets the ratio applied by one torch multiply and the table follows at the next refresh."""
+
+    def __init__(self, weights):
+        import ctypes as C
+        dev = weights[0].device
+        self.ptrs = tuple(w.data_ptr() for w in weights)
+        self.weights = list(weights)
+        n16 = nsc = 0
+        plan = []
+        for w in weights:
+            Cout, Cin, kh, kw = w.shape
+            T, Co32 = kh * kw, (Cout + 31) // 32 * 32
+            has_f = Cin % 32 == 0
+            plan.append((has_f, n16, nsc))
+            n16 += (Cout * T * Cin * 2 if has_f else 0) + Cin * T * Co32 * 2
+            nsc += (Cout if has_f else 0) + Cin
+        self.buf16 = torch.empty(n16, device=dev, dtype=torch.float16)
+        self.bufsc = torch.empty(nsc, device=dev, dtype=torch.float32)
+        self.entries, rows = [], [0]
+        for i, (w, (has_f, o16, osc)) in enumerate(zip(weights, plan)):
+            Cout, Cin, kh, kw = w.shape
+            T, Co32 = kh * kw, (Cout + 31) // 32 * 32
+            e = _Packed()
+            e.index, e.shape, e.dshape = i, (Cout, kh, kw, Cin), (Cin, kh, kw, Co32)
+            e.fwd = e.fwd_scale = None
+            if has_f:
+                e.fwd = self.buf16[o16:o16 + Cout * T * Cin * 2].view(Cout, T * Cin // 32, 2, 32)
+                e.fwd_scale = self.bufsc[osc:osc + Cout]
+                o16, osc = o16 + Cout * T * Cin * 2, osc + Cout
+            e.dgrad = self.buf16[o16:o16 + Cin * T * Co32 * 2].view(Cin, T * Co32 // 32, 2, 32)
+            e.dgrad_scale = self.bufsc[osc:osc + Cin]
+            e.applied, e.want = [1.0, 1.0], [None, None]          # in_scale folded into (forward, data-gradient) scales / asked for this step
+            self.entries.append(e)
+            rows.append(rows[-1] + (Cout if has_f else 0) + Cin // 4)          # workgroups: one per forward row, one per four data-gradient rows
+        self.by_ptr = {p: e for p, e in zip(self.ptrs, self.entries)}
+        self.total_rows = rows[-1]
+        self.row_start = torch.tensor(rows, dtype=torch.int32).to(dev)
+        self._ctable = (_capi.TrainWeight * len(weights))()
+        for t, w, e in zip(self._ctable, weights, self.entries):
+            t.w, t.Cout, t.Cin, t.kh, t.kw = w.data_ptr(), w.shape[0], w.shape[1], w.shape[2], w.shape[3]
+            t.fwd, t.fwd_scale = (e.fwd.data_ptr(), e.fwd_scale.data_ptr()) if e.fwd is not None else (None, None)
+            t.dgrad, t.dgrad_scale = e.dgrad.data_ptr(), e.dgrad_scale.data_ptr()
+            t.fwd_inv_in = t.dgrad_inv_in = 1.0
+        self._nbytes = C.sizeof(self._ctable)
+        self.table = torch.empty(self._nbytes, device=dev, dtype=torch.uint8)
+        self._upload()
+
+    def _upload(self):
+        import ctypes as C
+        host = torch.frombuffer(bytearray(C.string_at(C.addressof(self._ctable), self._nbytes)), dtype=torch.uint8)
+        self.table.copy_(host)
+
+    def refresh(self):
+        """pack the CURRENT values of every weight (call once per step, before the first convolution)"""
+        dirty = False
+        for t, e in zip(self._ctable, self.entries):
+            for f in (0, 1):
+                if e.want[f] is not None and e.want[f] != e.applied[f]:
+                    e.applied[f] = e.want[f]
+                    dirty = True
+                e.want[f] = None
+            t.fwd_inv_in, t.dgrad_inv_in = 1.0 / e.applied[0], 1.0 / e.applied[1]
+        if dirty:
+            self._upload()
+        with torch.cuda.device(self.table.device):
+            _capi.check(_capi.lib().dir_train_pack_conv_weights(_capi.ptr(self.table), _capi.ptr(self.row_start), len(self.entries), self.total_rows,
+                                                                _capi.stream_ptr()), 'dir_train_pack_conv_weights')
+
+
+_pack = None          # the WeightPack bound for the running step (begin_step .. end_step)
+
+
+def conv_weights(P):
+    """the convolution weights of a parameter dict that run through this module: every 4-D `.weight` except the 3-channel stem's"""
+    return [v for k, v in P.items() if k.endswith('.weight') and torch.is_tensor(v) and v.dim() == 4 and v.shape[1] % 4 == 0
+            and v.shape[2] == v.shape[3] and v.shape[2] in (1, 3)]
+
+
+def begin_step(owner=None, P=None):
     """called by dir_amd.train.net.forward at the start of every training step; `owner`: the object that owns this model's operand-scale
-    cache (any object that accepts attributes), or None = no cache"""
-    global _scales, _state
+    cache and packed weights (any object that accepts attributes), or None = no cache; P: the step's parameter dict (with an owner and
+    f16x3 arithmetic: all its convolution weights are packed now, in one launch)"""
+    global _scales, _state, _pack
+    _pack = None
     if owner is None:
         _scales, _state = [], {'call': 0, 'step': 1, 'cached': False}
         return
+    if P is not None and ARITH == 'f16x3' and PREPACK:
+        ws = conv_weights(P)
+        pk = getattr(owner, '_dir_weight_pack', None)
+        if ws and (pk is None or pk.ptrs != tuple(w.data_ptr() for w in ws)):
+            pk = WeightPack(ws)
+            setattr(owner, '_dir_weight_pack', pk)
+        if ws:
+            pk.refresh()
+            _pack = pk
     cache = getattr(owner, '_dir_conv_scale_cache', None)
     if cache is None:
         cache = ([], {'call': 0, 'step': 0, 'cached': True})
@@ -63,8 +163,8 @@ def begin_step(owner=None):
 def end_step():
     """called by dir_amd.train.net.backward when a step's gradients are complete: convolution calls outside a step (block-level callers, tests)
     measure their scales again instead of walking on in the finished step's cache"""
-    global _scales, _state
-    _scales, _state = [], {'call': 0, 'step': 1, 'cached': False}
+    global _scales, _state, _pack
+    _scales, _state, _pack = [], {'call': 0, 'step': 1, 'cached': False}, None
 
 
 def reset_scales(owner=None):
@@ -94,15 +194,43 @@ def _site_scale(x):
     return s
 
 
-def _conv(x, w, stride, pad, shift=None):
+def _conv(x, w, stride, pad, shift=None, packed=None):
+    """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient)"""
     if ARITH != 'f16x3':
         return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift)
-    kh = w.shape[1]
-    return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=_site_scale(x), device_pack=True,
-                         presplit=(kh >= 3 or (w.shape[0] >= 512 and w.shape[3] >= 128)))
+    shape = w.shape if packed is None else (packed[0].shape, packed[0].dshape)[packed[1]]
+    presplit = shape[1] >= 3 or (shape[0] >= 512 and shape[3] >= 128)
+    s = _site_scale(x)
+    if packed is None:
+        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, device_pack=True, presplit=presplit)
+    e, f = packed
+    sc = (e.fwd_scale, e.dgrad_scale)[f]
+    if e.applied[f] != s:                                  # (a calibration step, or a weight shared by sites of different magnitude)
+        sc = sc * (e.applied[f] / s)
+        if e.want[f] is None:
+            e.want[f] = s
+    elif e.want[f] is None:
+        e.want[f] = s
+    return F.conv2d_nhwc(x, None, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, presplit=presplit,
+                         prepacked=((e.fwd, e.dgrad)[f], sc, shape))
 
 
-def conv_fwd(x, w, bias=None, stride=1, pad=0):
+def _packed_of(w_oihw):
+    return _pack.by_ptr.get(w_oihw.data_ptr()) if _pack is not None else None
+
+
+def _ohwi(w):
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def conv_fwd(x, w, bias=None, stride=1, pad=0, oihw=False):
+    """w: OHWI [Cout,kh,kw,Cin], or with oihw=True the reference-layout parameter [Cout,Cin,kh,kw] itself (packed once per step when the
+    step has a WeightPack: begin_step)"""
+    if oihw:
+        e = _packed_of(w)
+        if e is not None and e.fwd is not None:
+            return _conv(x, None, stride, pad, bias, packed=(e, 0))
+        w = _ohwi(w)
     cin = w.shape[3]
     if cin % 32:                                           # the 3-channel image: channels padded to the kernel's K granularity
         x, w = _pad_last(x, 32), _pad_last(w, 32)
@@ -118,18 +246,21 @@ def _pad_last(t, mult):
     return out
 
 
-def conv_dgrad(w, gy, stride, pad, H, W):
+def conv_dgrad(w, gy, stride, pad, H, W, oihw=False):
     """d loss / d x [B,H,W,Cin] of y = conv(x, w, stride, pad) from gy [B,Ho,Wo,Cout]"""
-    Cout, kh, kw, Cin = w.shape
+    e = _packed_of(w) if oihw else None
+    if oihw and e is None:
+        w = _ohwi(w)
+    Cout, kh, kw, Cin = w.shape if e is None else e.shape
     assert kh == kw and stride in (1, 2)
-    wt = _pad_last(w.flip(1, 2).permute(3, 1, 2, 0).contiguous(), 32)          # [Cin][kh][kw][Cout (padded)]
+    wt = _pad_last(w.flip(1, 2).permute(3, 1, 2, 0).contiguous(), 32) if e is None else None          # [Cin][kh][kw][Cout (padded)]
     g = gy
     if stride == 2:
         B, Ho, Wo, _ = gy.shape
         g = torch.zeros(B, 2 * Ho, 2 * Wo, Cout, device=gy.device)
         g[:, ::2, ::2] = gy
     g = _pad_last(g.contiguous(), 32)
-    gx = _conv(g, wt, 1, kh - 1 - pad)
+    gx = _conv(g, wt, 1, kh - 1 - pad, packed=None if e is None else (e, 1))
     if gx.shape[1] != H or gx.shape[2] != W:               # odd H / W under stride 2
         assert gx.shape[1] >= H and gx.shape[2] >= W
         gx = gx[:, :H, :W].contiguous()
@@ -170,9 +301,11 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     return out
 
 
-def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True):
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False):
+    """-> (gx, gw [Cout,kh,kw,Cin], gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd)"""
     gy = gy.contiguous()
-    gw = conv_wgrad(x, gy, w.shape, stride, pad)
+    shape = (w.shape[0], w.shape[2], w.shape[3], w.shape[1]) if oihw else w.shape
+    gw = conv_wgrad(x, gy, shape, stride, pad)
     gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None
-    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2]) if need_gx else None
+    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw) if need_gx else None
     return gx, gw, gb

@@ -55,10 +55,9 @@ def _stem_forward(P, img):
 
 def _cbr_forward(P, pre, x, k):
     """Sequential(Conv2d(k, pad k//2), BatchNorm2d, ReLU, Conv2d(1)) -- conv_final, seg, dense, attention_*, fusion (models/dir.py:57-62,227-241,404-419)"""
-    w0 = TB._ohwi(P[pre + '0.weight'])
-    h = TC.conv_fwd(x, w0, P.get(pre + '0.bias'), 1, k // 2)
+    h = TC.conv_fwd(x, P[pre + '0.weight'], P.get(pre + '0.bias'), 1, k // 2, oihw=True)
     a, s_bn = TB.bn_fwd(P, pre + '1.', h, relu=True)
-    y = TC.conv_fwd(a, TB._ohwi(P[pre + '3.weight']), P.get(pre + '3.bias'))
+    y = TC.conv_fwd(a, P[pre + '3.weight'], P.get(pre + '3.bias'), oihw=True)
     return y, dict(x=x, bn=s_bn, a=a, k=k)
 
 
@@ -107,7 +106,7 @@ def forward(P, img, keep=None, scale_owner=None):
     model's cache of split-precision operand scales across steps (train_step passes the optimizer, DIR.forward the module); None = every
     convolution measures its scale on this batch (a host synchronisation per call site: tests, one-off evaluations)"""
     keep = [] if keep is None else keep
-    TC.begin_step(scale_owner)                                                 # operand-scale cache of THIS model (dir_amd/train/conv.py)
+    TC.begin_step(scale_owner, P)                                               # operand-scale cache of THIS model (dir_amd/train/conv.py)
     B = img.shape[0]
     dev = img.device
     ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)

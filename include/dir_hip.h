@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 32
+#define DIR_ABI_VERSION 33
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -318,6 +318,26 @@ int dir_split_f16_forward(const float* x, void* y, long long pixels, int C, int 
  * (training): packed = f16 [N][K/32][2][32], scale_out[n] = (scale_in ? scale_in[n] : 1) / p_n.  Same result as the host packing of
  * dir_amd/functional.py::pack_f16x3_weights (tests/test_gpu_f16x3.py). */
 int dir_pack_f16x3_weights(const float* w, void* packed, float* scale_out, const float* scale_in, int N, int K, void* stream);
+
+/* Every convolution weight of one training step in both DIR_DT_F16X3 operand forms, straight from the reference's OIHW parameters
+ * (nn.Conv2d.weight, models/backbone/resnet.py:23-40, hourglass.py:14, models/dir.py:58-61) in ONE launch -- the weights change every
+ * optimiser step (train.py:70), and packing them per convolution call cost ~600 launches per step.  `table` and `wg_start` live in DEVICE
+ * memory.  Per entry: w [Cout][Cin][kh][kw] fp32;
+ *   fwd   (may be NULL: skipped)  f16 [Cout][kh*kw*Cin/32][2][32]: rows of the OHWI matrix (k = tap * Cin + c), Cin % 32 == 0;
+ *                                 fwd_scale[o] = fwd_inv_in / p_o       (what dir_pack_f16x3_weights returns, times 1 / in_scale)
+ *   dgrad (may be NULL: skipped)  f16 [Cin][kh*kw*Cout32/32][2][32]: the transposed convolution's weights, row c, k = tap * Cout32 + o
+ *                                 = w[o][c][kh*kw - 1 - tap] (taps flipped, Cout padded to Cout32 = ceil32(Cout) with zeros);
+ *                                 dgrad_scale[c] = dgrad_inv_in / p_c.
+ * kh * kw must be 1 or 9 and Cin % 4 == 0 (every convolution of the path but the 3-channel stem, which keeps its own packing).
+ * wg_start[e] = first workgroup of entry e in the launch grid (workgroups of an entry: Cout if fwd -- one per row --, then Cin / 4 if dgrad --
+ * one per four rows), wg_start[entries] = total_workgroups.
+ * Bit-identical to dir_pack_f16x3_weights on the copied / flipped / padded matrices (tests/test_gpu_conv_bwd.py). */
+typedef struct {
+    const float* w; void* fwd; float* fwd_scale; void* dgrad; float* dgrad_scale;
+    int32_t Cout, Cin, kh, kw;
+    float fwd_inv_in, dgrad_inv_in;
+} dir_train_weight;
+int dir_train_pack_conv_weights(const dir_train_weight* table, const int* wg_start, int entries, int total_workgroups, void* stream);
 
 /* dir_conv2d_forward with the reduction split over `splits` workgroups per output tile (bf16 -> bf16 layers whose M x Cout grid is too
  * small to fill 256 CUs at the benchmark batch: ResNet layer4 at 8x8, the decoder's 16x16 Residual blocks).  128x128 tiles; every

@@ -114,3 +114,35 @@ def test_split_precision_weight_gradient_rejects_bad_arguments():
     d2 = _capi.ConvDesc(2, 8, 8, 62, 64, 0, 64, 64, 0, 0, 0, 1, 1, 1, 0, _capi.DT_F32, _capi.DT_F32, 0)
     assert call(d2, 1.0, 1.0, ws.numel() * 4) != 0 and b'multiples of 4' in L.dir_last_error()
     torch.cuda.synchronize()
+
+
+def test_weight_pack_is_the_per_call_packing_bit_for_bit():
+    """dir_train_pack_conv_weights (one launch for every convolution weight of a step, both operand forms, straight from OIHW) against what the
+    per-call path builds: OHWI copy -> dir_pack_f16x3_weights for the forward; flip, (Cin <-> Cout) transpose, Cout padded to 32 -> the same
+    packing for the data gradient.  Then with in_scales folded in: the scales are the per-call ones divided by the power of two."""
+    from dir_amd import functional as F
+    from dir_amd.train import conv as TC
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    shapes = [(64, 64, 3, 3), (256, 64, 1, 1), (6, 256, 1, 1), (1, 96, 3, 3), (128, 160, 3, 3), (40, 12, 1, 1), (512, 1024, 1, 1)]
+    ws = [torch.randn(*s, device='cuda', generator=gen) * (10.0 ** (i - 3)) for i, s in enumerate(shapes)]
+    ws[1][5] = 0                                              # an all-zero output channel (p = 1)
+    pk = TC.WeightPack(ws)
+    pk.refresh()
+    for w, e in zip(ws, pk.entries):
+        Cout, Cin, kh, kw = w.shape
+        if Cin % 32 == 0:
+            ref, sc = F.pack_f16x3_weights_device(w.permute(0, 2, 3, 1).contiguous().reshape(Cout, -1))
+            assert torch.equal(e.fwd.view(-1), ref.view(-1)) and torch.equal(e.fwd_scale, sc), w.shape
+        else:
+            assert e.fwd is None
+        wt = TC._pad_last(w.permute(0, 2, 3, 1).flip(1, 2).permute(3, 1, 2, 0).contiguous(), 32)
+        ref, sc = F.pack_f16x3_weights_device(wt.reshape(Cin, -1))
+        assert torch.equal(e.dgrad.view(-1), ref.view(-1)) and torch.equal(e.dgrad_scale, sc), w.shape
+    e = pk.entries[0]
+    before = (e.fwd_scale.clone(), e.dgrad_scale.clone())
+    e.want = [4.0, 0.125]
+    ws[0].mul_(3.0)                                           # and the refresh sees the new weight values
+    pk.refresh()
+    ref, sc = F.pack_f16x3_weights_device(ws[0].permute(0, 2, 3, 1).contiguous().reshape(64, -1))
+    assert torch.equal(e.fwd.view(-1), ref.view(-1)) and torch.equal(e.fwd_scale, sc / 4.0) and e.applied == [4.0, 0.125]
+    assert not torch.equal(e.fwd_scale, before[0]) and torch.equal(pk.entries[1].fwd_scale, F.pack_f16x3_weights_device(ws[1].reshape(256, -1))[1])

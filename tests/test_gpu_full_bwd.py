@@ -127,6 +127,44 @@ def test_whole_network_train_steps_reduce_the_objective():
     print('whole-network training steps: objective %s, %d parameter tensors updated' % (' -> '.join('%.4f' % t for t in totals), moved))
 
 
+def test_train_step_with_packed_weights_equals_per_call_packing():
+    """Round 4: the step packs every convolution weight once (dir_amd.train.conv.WeightPack, one launch) instead of per convolution call.
+    Same arithmetic, so three steps leave the SAME BITS in every parameter as the per-call path (DIR_TRAIN_PREPACK=0)."""
+    from conftest import loss_case
+    from dir_amd.optim import FlatAdamW
+    from dir_amd.train import conv as TC
+    from dir_amd.train import step as TSTEP
+    g8 = dict(np.load(os.path.join(HERE, 'golden', 'g8_loss.npz')))
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+    is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+    flats, losses = [], []
+    saved = TC.PREPACK
+    try:
+        for prepack in (True, False):
+            TC.PREPACK = prepack
+            params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
+            buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
+            opt = FlatAdamW(list(params.values()), lr=2e-5)
+            opt.set_inactive(TSTEP.inactive_parameters(params))
+            for _ in range(3):
+                loss = TSTEP.train_step(params, buffers, img, target, meta, fc, opt)
+            assert (getattr(opt, '_dir_weight_pack', None) is not None) == prepack
+            flats.append(opt.flat_param.clone())
+            losses.append({k: float(v) for k, v in loss.items()})
+    finally:
+        TC.PREPACK = saved
+    assert torch.equal(flats[0], flats[1]) and losses[0] == losses[1]
+
+
 def test_mirror_module_runs_the_reference_training_lines(golden):
     """train.py:64-70 verbatim on the mirror: model.train(); optimizer.zero_grad(); outs_list, loss = model(inputs, targets, meta_infos);
     sum(loss[k] for k in loss).backward(); optimizer.step() -- with a stock torch.optim.AdamW.  The 42 terms equal G8, the parameter
