@@ -36,9 +36,10 @@ def bn_bwd(P, pre, saved, gy, G, relu=False):
     return gx.view(x.shape)
 
 
-def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True):
+def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None):
+    """add_gx: another gradient of x, summed into gx in the data-gradient convolution's epilogue"""
     has_bias = (key + 'bias') in P
-    gx, gw, gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True)
+    gx, gw, gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx)
     G[key + 'weight'] = _oihw(gw)
     if has_bias:
         G[key + 'bias'] = gb
@@ -72,14 +73,13 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
     g2 = bn_bwd(P, 'bn2.', ctx['bn2'], g2, G, relu=True)
     g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G)
     g1 = bn_bwd(P, 'bn1.', ctx['bn1'], g1, G, relu=True)
-    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx)
+    # the identity / projection path's gradient joins conv1's data gradient in that convolution's epilogue (no separate dir_axpy_f32)
     if 'downsample.0.weight' in P:
         gd = bn_bwd(P, 'downsample.1.', ctx['bnd'], g, G)
-        gxd = _conv_bwd(P, 'downsample.0.', x, gd, stride, 0, G, need_gx=need_gx)
-        if need_gx:
-            O.axpy(gx, gxd)
-    elif need_gx:
-        O.axpy(gx, g)
+        other = _conv_bwd(P, 'downsample.0.', x, gd, stride, 0, G, need_gx=need_gx)
+    else:
+        other = g
+    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx, add_gx=other if need_gx else None)
     return gx, G
 
 
@@ -91,12 +91,12 @@ def residual_forward(P, x):
     a1, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
     h = TC.conv_fwd(a1, P['conv2.conv.weight'], P['conv2.conv.bias'], 1, 1, oihw=True)
     a2, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True)
-    y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True)
     need_skip = P['skip_layer.conv.weight'].shape[0] != P['skip_layer.conv.weight'].shape[1]          # hourglass.py:49-52
     if need_skip:
-        O.axpy(y, TC.conv_fwd(x, P['skip_layer.conv.weight'], P['skip_layer.conv.bias'], oihw=True))
+        y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True)
+        y = TC.conv_fwd(x, P['skip_layer.conv.weight'], P['skip_layer.conv.bias'], oihw=True, residual=y)       # + skip_layer(x), same launch
     else:
-        O.axpy(y, x)
+        y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True, residual=x)
     ctx.update(a0=a0, a1=a1, a2=a2, need_skip=need_skip)
     return y, ctx
 
@@ -112,9 +112,8 @@ def residual_backward(P, ctx, gy, need_gx=True):
     g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G)
     gx = bn_bwd(P, 'bn1.', ctx['bn1'], g, G, relu=True)
     if ctx['need_skip']:
-        gs = _conv_bwd(P, 'skip_layer.conv.', x, gy, 1, 0, G, need_gx=need_gx)
-        if need_gx:
-            O.axpy(gx, gs)
+        gs = _conv_bwd(P, 'skip_layer.conv.', x, gy, 1, 0, G, need_gx=need_gx, add_gx=gx if need_gx else None)      # + gx, same launch
+        gx = gs if need_gx else gx
     else:
         # an unused skip_layer keeps its parameters without gradient, like torch (hourglass.py:56-59)
         O.axpy(gx, gy)

@@ -194,15 +194,15 @@ def _site_scale(x):
     return s
 
 
-def _conv(x, w, stride, pad, shift=None, packed=None):
-    """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient)"""
+def _conv(x, w, stride, pad, shift=None, packed=None, residual=None):
+    """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient); residual: added in the epilogue"""
     if ARITH != 'f16x3':
-        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift)
+        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, residual=residual)
     shape = w.shape if packed is None else (packed[0].shape, packed[0].dshape)[packed[1]]
     presplit = shape[1] >= 3 or (shape[0] >= 512 and shape[3] >= 128)
     s = _site_scale(x)
     if packed is None:
-        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, device_pack=True, presplit=presplit)
+        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, device_pack=True, presplit=presplit, residual=residual)
     e, f = packed
     sc = (e.fwd_scale, e.dgrad_scale)[f]
     if e.applied[f] != s:                                  # (a calibration step, or a weight shared by sites of different magnitude)
@@ -212,7 +212,7 @@ def _conv(x, w, stride, pad, shift=None, packed=None):
     elif e.want[f] is None:
         e.want[f] = s
     return F.conv2d_nhwc(x, None, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, presplit=presplit,
-                         prepacked=((e.fwd, e.dgrad)[f], sc, shape))
+                         prepacked=((e.fwd, e.dgrad)[f], sc, shape), residual=residual)
 
 
 def _packed_of(w_oihw):
@@ -223,18 +223,21 @@ def _ohwi(w):
     return w.permute(0, 2, 3, 1).contiguous()
 
 
-def conv_fwd(x, w, bias=None, stride=1, pad=0, oihw=False):
+def conv_fwd(x, w, bias=None, stride=1, pad=0, oihw=False, residual=None):
     """w: OHWI [Cout,kh,kw,Cin], or with oihw=True the reference-layout parameter [Cout,Cin,kh,kw] itself (packed once per step when the
-    step has a WeightPack: begin_step)"""
+    step has a WeightPack: begin_step).  residual [B,Ho,Wo,Cout]: y = conv(x) + bias + residual in the convolution's epilogue (a Residual
+    block's skip path: one launch and two passes over the map less than a separate dir_axpy_f32)"""
+    if residual is not None:
+        residual = residual.contiguous()
     if oihw:
         e = _packed_of(w)
         if e is not None and e.fwd is not None:
-            return _conv(x, None, stride, pad, bias, packed=(e, 0))
+            return _conv(x, None, stride, pad, bias, packed=(e, 0), residual=residual)
         w = _ohwi(w)
     cin = w.shape[3]
     if cin % 32:                                           # the 3-channel image: channels padded to the kernel's K granularity
         x, w = _pad_last(x, 32), _pad_last(w, 32)
-    return _conv(x, w, stride, pad, bias)
+    return _conv(x, w, stride, pad, bias, residual=residual)
 
 
 def _pad_last(t, mult):
@@ -246,8 +249,9 @@ def _pad_last(t, mult):
     return out
 
 
-def conv_dgrad(w, gy, stride, pad, H, W, oihw=False):
-    """d loss / d x [B,H,W,Cin] of y = conv(x, w, stride, pad) from gy [B,Ho,Wo,Cout]"""
+def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None):
+    """d loss / d x [B,H,W,Cin] of y = conv(x, w, stride, pad) from gy [B,Ho,Wo,Cout]; add [B,H,W,Cin]: another gradient of x, summed in
+    the convolution's epilogue (the identity / projection path of a residual block)"""
     e = _packed_of(w) if oihw else None
     if oihw and e is None:
         w = _ohwi(w)
@@ -260,10 +264,14 @@ def conv_dgrad(w, gy, stride, pad, H, W, oihw=False):
         g = torch.zeros(B, 2 * Ho, 2 * Wo, Cout, device=gy.device)
         g[:, ::2, ::2] = gy
     g = _pad_last(g.contiguous(), 32)
-    gx = _conv(g, wt, 1, kh - 1 - pad, packed=None if e is None else (e, 1))
-    if gx.shape[1] != H or gx.shape[2] != W:               # odd H / W under stride 2
+    p2 = kh - 1 - pad
+    fits = g.shape[1] + 2 * p2 - kh + 1 == H and g.shape[2] + 2 * p2 - kw + 1 == W
+    gx = _conv(g, wt, 1, p2, packed=None if e is None else (e, 1), residual=add.contiguous() if (add is not None and fits) else None)
+    if not fits:                                           # odd H / W under stride 2
         assert gx.shape[1] >= H and gx.shape[2] >= W
         gx = gx[:, :H, :W].contiguous()
+        if add is not None:
+            O.axpy(gx, add.contiguous())
     return gx
 
 
@@ -301,11 +309,11 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     return out
 
 
-def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False):
-    """-> (gx, gw [Cout,kh,kw,Cin], gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd)"""
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None):
+    """-> (gx (+ add_gx), gw [Cout,kh,kw,Cin], gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd)"""
     gy = gy.contiguous()
     shape = (w.shape[0], w.shape[2], w.shape[3], w.shape[1]) if oihw else w.shape
     gw = conv_wgrad(x, gy, shape, stride, pad)
     gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None
-    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw) if need_gx else None
+    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw, add=add_gx) if need_gx else None
     return gx, gw, gb
