@@ -652,7 +652,7 @@ def main():
                  'frac_of_f16x3_mfma_peak': round(3 * ALG_GFLOP_PER_IMAGE * 1e9 * TB / best / PEAK['f16x3'], 4),
                  'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                  'note': 'dir_amd.train.step.train_step on one GPU (no exchange partner): training-mode forward, 42-term objective, backward, flat '
-                         'gradient bucket, one AdamW launch; eager, about 1500 library calls per step (round 2: 0.088 s; DESIGN.md section 9)'}
+                         'gradient bucket, one AdamW launch; eager, about 1300 library calls + 300 torch operators per step, every convolution weight packed by one launch (round 2: 0.088 s, round 3: 0.047 s; DESIGN.md section 10)'}
         del tparams, tbuf, topt
         torch.cuda.empty_cache()
 
