@@ -15,6 +15,8 @@
 // (deterministic, no atomics), like dir_conv2d_wgrad_f32 (train_ops.hip), whose result layout this reproduces.
 #include "conv_common.h"
 
+#include <stdlib.h>
+
 namespace dir {
 namespace {
 
@@ -29,7 +31,7 @@ struct WgradX3Args {
     unsigned mg_hw, sh_hw, mg_w, sh_w;                   // m / (Ho * Wo), r / Wo (convk::magic_u31)
 };
 
-template <int TM, int TN, bool ROW4>
+template <int TM, int TN, int ROW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradX3Args a) {
     constexpr int MI = TM / 64, NJ = TN / 64;            // 32 x 32 blocks per wave (waves 2 x 2)
     constexpr int BUF = (TM + TN) * 128;
@@ -59,12 +61,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradX3Args a) {
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) ra[p][e] = rb[p][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // per-lane constants of the ROW == 32 form: byte offsets of the lane's 4 pixels in the gy row piece, their column offsets, the x pixel pitch
+    unsigned goff[4];
+    int pixs[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { goff[e] = (unsigned)((4 * pg + e) * a.gy_cs + cha) * 4u; pixs[e] = (4 * pg + e) * a.stride; }
+    const unsigned xpitch = (unsigned)a.in_cs * 4u, xoff = (unsigned)chb * 4u;
     auto gload = [&](auto P, int k0) {
         constexpr int p = decltype(P)::value;
         const float* pa[4];
         const float* pb[4];
         oka[p] = okb[p] = 0;
-        if constexpr (ROW4) {                            // Wo % 4 == 0: a thread's 4 pixels are neighbours in one output row
+        if constexpr (ROW == 32) {
+            // Wo % 32 == 0 (the 64x64 and 32x32 maps: the large-M layers): the 32 pixels of a step are one piece of one output row, so the
+            // pixel -> (image, row, column) division, the row's base addresses and the row mask are UNIFORM -- scalar-unit work -- and a lane
+            // adds constant 32-bit offsets.  The per-lane form below spent ~45 quarter-rate 32 / 64-bit multiplies per lane and step on this, and
+            // the kernel was VALU-bound (1900 VALU cycles per wave and step against 768 of MFMA).
+            const int k0u = __builtin_amdgcn_readfirstlane(k0);
+            const bool sv = k0u < m_end;                 // (chunks are whole steps and M % 32 == 0: the whole step or nothing)
+            const int mc0 = sv ? k0u : m_end - XK;
+            const int b = convk::div_magic(mc0, a.mg_hw, a.sh_hw), r = mc0 - b * hw;
+            const int oy = convk::div_magic(r, a.mg_w, a.sh_w), ox0 = r - oy * a.Wo;
+            const int iy = oy * a.stride - a.pad + ky, ixb = ox0 * a.stride - a.pad + kx;
+            const bool rowin = sv && iy >= 0 && iy < a.H;
+            const char* xrow = reinterpret_cast<const char*>(a.x + ((long long)b * a.H + min(max(iy, 0), a.H - 1)) * a.W * a.in_cs);
+            const char* grow = reinterpret_cast<const char*>(a.gy + (long long)mc0 * a.gy_cs);
+            oka[p] = sv ? 15u : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ix = ixb + pixs[e];
+                okb[p] |= ((rowin && ix >= 0 && ix < a.W) ? 1u : 0u) << e;
+                pa[e] = reinterpret_cast<const float*>(grow + goff[e]);
+                pb[e] = reinterpret_cast<const float*>(xrow + (__umul24((unsigned)min(max(ix, 0), a.W - 1), xpitch) + xoff));
+            }
+        } else if constexpr (ROW == 4) {                 // Wo % 4 == 0: a thread's 4 pixels are neighbours in one output row
             const int m = k0 + 4 * pg;
             const bool mv = m < m_end;                   // (chunks are whole steps of 32 and M % 4 == 0: all four or none)
             const int mc = mv ? m : m_end - 4;
@@ -200,13 +230,41 @@ __global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel(const float* part,
 }
 
 int x3_tile(int c) { return c > 64 ? 128 : 64; }
+// workgroups of a tile shape the whole GPU holds at once (occupancy x CUs), asked from the runtime once per shape
+template <int TM, int TN>
+int x3_slots_of() {
+    static const int slots = []() {
+        int dev = 0, cus = 256, occ = 2;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv_wgrad_x3_kernel<TM, TN, 4>, 256, 0) != hipSuccess || occ < 1) occ = 2;
+        return cus * occ;
+    }();
+    return slots;
+}
+int x3_slots(int tm, int tn) {
+    return tm == 128 ? (tn == 128 ? x3_slots_of<128, 128>() : x3_slots_of<128, 64>()) : (tn == 128 ? x3_slots_of<64, 128>() : x3_slots_of<64, 64>());
+}
+// Number of pixel chunks.  Round 3 took ceil(768 / workgroups per chunk) -- "about three workgroups per CU" -- which ignores how the grid
+// quantises: the fusion convolution's weight gradient (360 workgroups per chunk) ran 1080 workgroups on 512 slots = three rounds for 2.1 rounds
+// of work, the 128-channel 3x3 layers 576 on 512.  Now: the c that minimises rounds(c) x (steps per chunk + a fixed prologue / epilogue) plus
+// the reduce pass over c partial copies, in units of one 32-pixel step (~1.8 us).  Deterministic for a given shape and device.
 int x3_chunks(const dir_conv_desc* d, long long M) {
     const int tm = x3_tile(d->Cout), tn = x3_tile(d->Cin);
     const long long per = (long long)((d->Cin + tn - 1) / tn) * ((d->Cout + tm - 1) / tm) * d->kh * d->kw;
-    long long c = (768 + per - 1) / per;                  // ~3 workgroups per CU in flight
     const long long cmax = (M + 511) / 512;               // at least 512 pixels (16 steps) per chunk
-    if (c > cmax) c = cmax;
-    return (int)(c < 1 ? 1 : c);
+    const long long slots = x3_slots(tm, tn), steps_total = (M + XK - 1) / XK;
+    const double n = (double)d->Cout * d->kh * d->kw * d->Cin;
+    long long best = 1;
+    double best_cost = 1e30;
+    for (long long c = 1; c <= cmax && c <= 1024; ++c) {
+        const long long rounds = (per * c + slots - 1) / slots, steps = (steps_total + c - 1) / c;
+        const double cost = (double)rounds * (double)(steps + 24) + (c > 1 ? 3.0 + (double)(c + 1) * n * 7.4e-7 : 0.0);
+        if (cost < best_cost * 0.999) { best_cost = cost; best = c; }
+    }
+    return (int)best;
 }
 bool pow2(float s) { int e; return s > 0.f && frexpf(s, &e) == 0.5f; }
 
@@ -256,10 +314,15 @@ extern "C" int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, co
     const dim3 grid(a.tiles_ci * ((d->Cout + tm - 1) / tm), d->kh * d->kw, chunks);
     hipStream_t s = (hipStream_t)stream;
     const bool row4 = a.Wo % 4 == 0;                      // then M % 4 == 0 too and a thread's 4 pixels share an output row
+    static const bool row32_on = []() { const char* e = getenv("DIR_WGRAD_ROW32"); return !(e && e[0] == '0'); }();
+    // a step's 32 pixels are one piece of one output row: uniform row arithmetic (needs 24-bit pitches and 32-bit byte offsets inside a row)
+    const bool row32 = row32_on && a.Wo % 32 == 0 && a.W < (1 << 20) && (long long)a.in_cs * 4 < (1 << 24) && (long long)a.W * a.in_cs * 4 < (1ll << 31) &&
+                       (long long)XK * a.gy_cs * 4 < (1ll << 31);
     auto launch = [&](auto TMc, auto TNc) {
         constexpr int TM = decltype(TMc)::value, TN = decltype(TNc)::value;
-        if (row4) DIR_LAUNCH((conv_wgrad_x3_kernel<TM, TN, true>), grid, dim3(256), 0, s, a);
-        else DIR_LAUNCH((conv_wgrad_x3_kernel<TM, TN, false>), grid, dim3(256), 0, s, a);
+        if (row32) DIR_LAUNCH((conv_wgrad_x3_kernel<TM, TN, 32>), grid, dim3(256), 0, s, a);
+        else if (row4) DIR_LAUNCH((conv_wgrad_x3_kernel<TM, TN, 4>), grid, dim3(256), 0, s, a);
+        else DIR_LAUNCH((conv_wgrad_x3_kernel<TM, TN, 0>), grid, dim3(256), 0, s, a);
     };
     using C64 = std::integral_constant<int, 64>;
     using C128 = std::integral_constant<int, 128>;

@@ -57,6 +57,8 @@ X3_CASES = [  # B, H, Cin, Cout, k, stride, pad, |gy| scale
     (4, 16, 192, 64, 1, 1, 0, 3e-7),      # 64 x 128 tiles with a ragged second tile; tiny gradients (the scale does the work)
     (3, 17, 36, 260, 3, 2, 1, 40.0),      # odd map, stride 2, ragged tiles on both sides
     (16, 32, 2560, 256, 3, 1, 1, 1e-3),   # the bone-fusion convolution's shape (models/dir.py:57-62)
+    (4, 64, 64, 128, 3, 2, 1, 1.0),       # stride 2 onto a 32-wide map: the uniform-row address form (Wo % 32 == 0) with column stride 2
+    (2, 64, 256, 96, 1, 2, 0, 0.1),       # the 1x1 / stride 2 projection shortcut, 32-wide output, ragged output-channel tile
 ]
 
 
