@@ -164,8 +164,8 @@ class _TrainObjective(torch.autograd.Function):
 class DIR(nn.Module):
     def __init__(self, joint_num, mano_path, root_joint=0, compute_dtype=torch.bfloat16, extra_stages=0, arith=None, backbone='resnet50'):
         """extra_stages / arith are this build's extensions (defaults = the reference's network): extra_stages = N more refinement iterations at
-        32x32 (config 5's "5 refinement iters" = extra_stages 2; outs_list then carries 3 + N stage dicts before the dense / seg dict; eval
-        mode only); arith = 'f16x3' with compute_dtype float32: the split-precision parity mode (DirEngine)."""
+        32x32 (config 5's "5 refinement iters" = extra_stages 2; outs_list then carries 3 + N stage dicts before the dense / seg dict; trains
+        like the rest: 3 + 13 (3 + N) loss terms); arith = 'f16x3' with compute_dtype float32: the split-precision parity mode (DirEngine)."""
         super().__init__()
         self.extra_stages, self.arith = int(extra_stages), arith
         self.joint_num = joint_num
@@ -232,7 +232,7 @@ class DIR(nn.Module):
         and weights (coord_weight 10, dense_weight 1, seg class weights .1/.45/.45), forward values only (validation loss)."""
         from .loss import DirLoss
         crit = DirLoss(self.init_regressor.mano_layer_left.th_faces, self.init_regressor.mano_layer_right.th_faces)
-        return crit(outs_list[:3], outs_list[3], target, meta_info)
+        return crit(outs_list[:-1], outs_list[-1], target, meta_info)
 
     def _forward_train(self, input, target, meta_info):
         """Training mode (train.py:66-68 runs `outs_list, loss = model(inputs, targets, meta_infos); sum(loss[k] ...).backward()`): the
@@ -255,16 +255,17 @@ class DIR(nn.Module):
         loss = {k: vec[i] for i, k in enumerate(box['keys'])}
         outs = box['outs']
         outs_list = [{k: o.get(k) for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left',
-                                             'pd_joint_xyz_right', 'pd_offset')} for o in outs[:3]]
-        for o, d in zip(outs[:3], outs_list):
+                                             'pd_joint_xyz_right', 'pd_offset')} for o in outs[:-1]]
+        for o, d in zip(outs[:-1], outs_list):
             d['pd_proj_left'], d['pd_proj_right'], d['pd_rel_joint'] = o['pd_mano_para_left'][:, 61:], o['pd_mano_para_right'][:, 61:], None
-        outs_list.append({'dense': outs[3]['dense'], 'seg': outs[3]['seg'], 'proj_feat': outs[3].get('proj_feat')})    # models/dir.py:536-540
+        outs_list.append({'dense': outs[-1]['dense'], 'seg': outs[-1]['seg'], 'proj_feat': outs[-1].get('proj_feat')})    # models/dir.py:536-540
         return outs_list, loss
 
     def forward(self, input, target, meta_info):
         if self.training:
-            if self.extra_stages or self.backbone_name != 'resnet50':
-                raise NotImplementedError('extra_stages (no reference counterpart) is built for inference only; training covers the reference network')
+            if self.backbone_name != 'resnet50':
+                raise NotImplementedError('the HRNet backbone (no reference counterpart) is built for inference only; training covers the ResNet-50 network'
+                                          ' (with any number of extra stages)')
             return self._forward_train(input, target, meta_info)
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()

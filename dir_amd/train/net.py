@@ -157,36 +157,52 @@ def forward(P, img, keep=None, scale_owner=None):
         tabs = mano_tables(P, pre + 'regressor.', keep)
         res, d['tok'] = TS.stage_tokens_forward(sub(P, pre), tabs, fusion_feat, prev)
         img_feat, d['img'] = _stage_image_forward(P, pre, res['joint_feat'], res['pd_joint_uv_left'], res['pd_joint_uv_right'], S, dist,
-                                                  want_vis=(si == 1))            # the last stage's map is an output (models/dir.py:481)
+                                                  want_vis=(si == 1 and 'decoder.projecter_x.0.fusion.0.weight' not in P))     # the LAST stage's map is an output (models/dir.py:481)
         enh_in = torch.cat((fusion_feat, img_feat), dim=3)
         feat_lo, d['enh'] = TB.residual_forward(sub(P, 'decoder.enhance_layer%s.' % tag), enh_in)
         d.update(tabs=tabs, Cup=Cup, S=S)
         ctx['dec'].append(d)
         outs.append(res)
         prev = res
+    # ---- N more refinement stages at 32 x 32 (this build's extension, config 5: decoder.projecter_x.<i> / enhance_layer_x.<i>; the reference's
+    #      classes chained the way its forward chains its two stages -- oracle/gen_golden.py::reference_with_extra_stages, goldens G7x / G21)
+    ctx['extra'] = []
+    while ('decoder.projecter_x.%d.fusion.0.weight' % len(ctx['extra'])) in P:
+        i, d = len(ctx['extra']), {}
+        pre = 'decoder.projecter_x.%d.' % i
+        tabs = mano_tables(P, pre + 'regressor.', keep)
+        x_in = feat_lo
+        res, d['tok'] = TS.stage_tokens_forward(sub(P, pre), tabs, x_in, prev)
+        last = ('decoder.projecter_x.%d.fusion.0.weight' % (i + 1)) not in P
+        img_feat, d['img'] = _stage_image_forward(P, pre, res['joint_feat'], res['pd_joint_uv_left'], res['pd_joint_uv_right'], 32, 2, want_vis=last)
+        feat_lo, d['enh'] = TB.residual_forward(sub(P, 'decoder.enhance_layer_x.%d.' % i), torch.cat((x_in, img_feat), dim=3))
+        d.update(tabs=tabs)
+        ctx['extra'].append(d)
+        outs.append(res)
+        prev = res
     feat, ctx['final'] = _cbr_forward(P, 'decoder.conv_final.', feat_lo, 3)
     seg, ctx['seg'] = _cbr_forward(P, 'decoder.seg.', feat, 3)
     dense, ctx['dense'] = _cbr_forward(P, 'decoder.dense.', feat, 3)
     outs.append({'seg': seg.permute(0, 3, 1, 2).contiguous(), 'dense': dense.permute(0, 3, 1, 2).contiguous(),
-                 'proj_feat': ctx['dec'][1]['img']['vis']})
+                 'proj_feat': (ctx['extra'][-1] if ctx['extra'] else ctx['dec'][1])['img']['vis']})      # the LAST stage's map (models/dir.py:481)
     ctx.update(feats=feats)
     return outs, ctx
 
 
 def losses(outs, target, meta_info, faces):
-    return L.DirLoss(faces[0], faces[1])(outs[:3], outs[3], target, meta_info)
+    return L.DirLoss(faces[0], faces[1])(outs[:-1], outs[-1], target, meta_info)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------- backward
-def _term_weights(grad_out):
+def _term_weights(grad_out, n_stages=3):
     """grad_out: None (every term weight 1: `sum(loss.values()).backward()`, train.py:68) or {loss key: 0-d tensor / float} -- the upstream
-    gradient of each of the 42 terms -> (dense 3-vector or None, [three 13-vectors or None])"""
+    gradient of each of the 3 + 13 n_stages terms -> (dense 3-vector or None, [n_stages 13-vectors or None])"""
     if grad_out is None:
-        return None, [None, None, None]
+        return None, [None] * n_stages
     dev = next(v for v in grad_out.values() if torch.is_tensor(v)).device
     f = lambda k: (grad_out[k].to(dev).float().reshape(()) if k in grad_out and grad_out[k] is not None else torch.zeros((), device=dev))  # noqa: E731
     dense = torch.stack([f('seg'), f('dense'), f('lovasz')])
-    return dense, [torch.stack([f('%s_%d' % (k, i)) for k in L.STAGE_KEYS]) for i in range(3)]
+    return dense, [torch.stack([f('%s_%d' % (k, i)) for k in L.STAGE_KEYS]) for i in range(n_stages)]
 
 
 def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
@@ -197,14 +213,28 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
     G = {}
     if flush is None:
         flush = lambda g: None      # noqa: E731
-    w_dense, w_stage = _term_weights(grad_out)
+    w_dense, w_stage = _term_weights(grad_out, len(outs) - 1)
     B = ctx['img'].shape[0]
     c1, c2, c3, c4 = ctx['feats']
-    g_seg, g_dense = L.dense_loss_grads(outs[3]['seg'], outs[3]['dense'], target['seg'], target['dense'], grad_out=w_dense)
+    g_seg, g_dense = L.dense_loss_grads(outs[-1]['seg'], outs[-1]['dense'], target['seg'], target['dense'], grad_out=w_dense)
     g_feat = _cbr_backward(P, 'decoder.seg.', ctx['seg'], g_seg.permute(0, 2, 3, 1).contiguous(), G)
     O.axpy(g_feat, _cbr_backward(P, 'decoder.dense.', ctx['dense'], g_dense.permute(0, 2, 3, 1).contiguous(), G))
-    g_lo = _cbr_backward(P, 'decoder.conv_final.', ctx['final'], g_feat, G)                      # gradient of enhance_layer3's output
+    g_lo = _cbr_backward(P, 'decoder.conv_final.', ctx['final'], g_feat, G)                      # gradient of the last enhance layer's output
     flush(G)
+    for i in range(len(ctx.get('extra', ())) - 1, -1, -1):                                       # the extra stages, last first
+        d, pre = ctx['extra'][i], 'decoder.projecter_x.%d.' % i
+        g_cat, g = TB.residual_backward(sub(P, 'decoder.enhance_layer_x.%d.' % i), d['enh'], g_lo)
+        put(G, 'decoder.enhance_layer_x.%d.' % i, g)
+        g_map = g_cat[..., :256].contiguous()                                                    # the running map enters the Residual directly ...
+        g_tok, gul, gur = _stage_image_backward(P, pre, d['img'], g_cat[..., 256:].contiguous(), G)
+        cot = L.stage_loss_grads(outs[3 + i], target, meta_info, faces, grad_out=w_stage[3 + i])
+        O.axpy(cot['pd_joint_uv_left'], gul)
+        O.axpy(cot['pd_joint_uv_right'], gur)
+        g_samp, g = TS.stage_tokens_backward(sub(P, pre), d['tabs'], d['tok'], cot, g_joint_feat=g_tok)
+        put(G, pre, g)
+        O.axpy(g_map, g_samp)                                                                    # ... and is what the stage samples its tokens from
+        g_lo = g_map
+        flush(G)
     g_skip_src = [None, None]
     for si in (1, 0):
         tag, d = ('4', '3')[si], ctx['dec'][si]

@@ -924,7 +924,116 @@ def compact_grads_sized(named, coarse=1):
     return res
 
 
-GENS = {'full_grad_frozen': gen_full_grad_frozen, 'full_cond': lambda: gen_full(True), 'loss_cond': lambda: gen_loss(True), 'full_grad_cond': lambda: gen_full_grad(True),
+# ----------------------------------------------------------------------------- G7x / G21: N more refinement stages, from the reference's OWN modules
+def reference_with_extra_stages(n):
+    """SURVEY.md 8f rank 4 (config 5: "5 refinement iters").  The reference's decoder hard-wires two stages (models/dir.py:395,401), so there is no
+    reference NETWORK with more -- but there are the reference's MODULES: this builds its DIR, then gives the decoder n more
+    `Joint2BoneFeature(256, 128, 64, joint_num, 32, ..., distance=2)` (the class and arguments of projecter_3, models/dir.py:401) and
+    `Residual(512, 256)` (enhance_layer3, :402) under the names this build's mirror uses (decoder.projecter_x.<i> / decoder.enhance_layer_x.<i>),
+    and runs them after the reference's own forward exactly as that forward chains its two stages (models/dir.py:449-472: previous stage's
+    predictions detached, cat(running map, img_feat) -> Residual).  The first two stages ARE the reference's forward (super().forward); the map
+    they end on is taken from enhance_layer3's output by a hook.  DIR.forward and its loss loop (models/dir.py:521-594) take any number of stages."""
+    from models import dir as RD
+
+    class DecoderX(RD.FusionJointInterIterDecoder):
+        def __init__(self, joint_num, mano_pth, root_joint):
+            super().__init__(joint_num, mano_pth, root_joint)
+            self.projecter_x = nn.ModuleList(RD.Joint2BoneFeature(256, 128, 64, joint_num, 32, mano_pth, root_joint, distance=2) for _ in range(n))
+            self.enhance_layer_x = nn.ModuleList(RD.Residual(512, 256) for _ in range(n))
+            self._map = None
+            self.enhance_layer3.register_forward_hook(lambda m, a, o: setattr(self, '_map', o))
+
+        def forward(self, x, result_dict):
+            out = super().forward(x, result_dict)               # the reference's two stages (its seg / dense of THAT map are discarded below)
+            feat_map, outputs = self._map, list(out['result_list'])
+            prev = outputs[-1]
+            for proj, enh in zip(self.projecter_x, self.enhance_layer_x):
+                res, out_feat = proj(feat_map, prev['pd_joint_xyz_left'].detach(), prev['pd_joint_xyz_right'].detach(),
+                                     prev['pd_joint_uv_left'].detach(), prev['pd_joint_uv_right'].detach(),
+                                     prev['pd_mano_para_left'].detach(), prev['pd_mano_para_right'].detach(), prev['pd_offset'].detach().unsqueeze(1))
+                feat_map = enh(torch.cat((feat_map, out_feat['img_feat']), dim=1))
+                outputs.append(dict(res, **out_feat))
+                prev = res
+            feat = self.conv_final(feat_map)
+            return {'result_list': outputs, 'seg': self.seg(feat), 'dense': self.dense(feat), 'proj_feat': outputs[-1]['vis_img_feat']}
+
+    net = RD.DIR(21, 'unused', 0)
+    net.decoder = DecoderX(21, 'unused', 0)
+    return net
+
+
+def gen_full_extra():
+    """G7x: the composed reference (reference_with_extra_stages(2): config 5's five refinement iterations) in eval mode on the trained-like
+    parameters and G7's input -- pins this build's N-stage extension (engine, mirror and numpy oracle) to the reference's own classes."""
+    net = reference_with_extra_stages(2).eval()
+    shapes = load_synth(net, cond=True)
+    assert len(shapes) == 963 + 2 * 240, len(shapes)
+    img = torch.from_numpy(synth.synth_input('dir.img', (2, 3, 256, 256), SEED))
+    with torch.no_grad():
+        outs, loss = net({'img': img}, None, None)
+    assert loss == {} and len(outs) == 6
+    out = {}
+    for i in range(5):
+        for k, v in outs[i].items():
+            if v is not None:
+                out['s%d.%s' % (i, k)] = v
+    out['seg'], out['dense'] = outs[5]['seg'], outs[5]['dense']
+    pf = outs[5]['proj_feat']
+    out['proj_feat.sum'] = pf.double().sum(dim=(2, 3))
+    out['proj_feat.slice'] = pf[:, 0:1280:97]
+    for i in range(5):
+        print('   stage %d verts absmax %.4f, moved by %.3e m from the stage before' % (i, float(outs[i]['pd_mesh_xyz_left'].abs().max()),
+              float((outs[i]['pd_mesh_xyz_left'] - outs[max(i - 1, 0)]['pd_mesh_xyz_left']).abs().max())))
+    save('g7x_dir_extra2', **out)
+
+
+def gen_full_grad_frozen_extra():
+    """G21: G20e's gradient (the reference's `sum(loss.values()).backward()` with every BatchNorm in .eval(), reproducible to ~4e-5) through the
+    composed reference with ONE extra stage: 55 loss terms, gradients of all parameters including decoder.projecter_x.0.* / enhance_layer_x.0.*."""
+    g8 = np.load(os.path.join(OUT, 'g8c_loss.npz'))
+
+    def run():
+        net = reference_with_extra_stages(1)
+        load_synth(net, cond=True)
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+        for side in ('left', 'right'):
+            fc = torch.from_numpy(synth.loss_faces(side, SEED))
+            getattr(net, 'normal_loss_' + side).face = fc
+            getattr(net, 'edge_loss_' + side).face = fc
+        img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED))
+        target = {k[3:]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith('gt_') and not k.endswith('_u8') and 'center' not in k}
+        target['seg'] = torch.from_numpy(g8['gt_seg_u8'].astype(np.float32))
+        target['dense'] = torch.from_numpy(g8['gt_dense_u8'].astype(np.float32) / np.float32(255.0))
+        meta = {k[3:]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith('gt_center')}
+        outs, loss = net({'img': img}, target, meta)
+        assert len(loss) == 3 + 13 * 4, len(loss)
+        total = sum(loss[k] for k in loss)
+        total.backward()
+        return net, loss, total
+    net, loss, total = run()
+    named = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    none = sorted(k for k, p in net.named_parameters() if p.grad is None)
+    torch.set_num_threads(1)
+    net1, _, _ = run()
+    torch.set_num_threads(8)
+    named1 = {k: p.grad for k, p in net1.named_parameters() if p.grad is not None}
+    res = {'total': total.detach(), 'none': np.array(none)}
+    res.update({'loss.' + k: v.detach() for k, v in loss.items()})
+    rep = []
+    for k in named:
+        e = float((named[k] - named1[k]).abs().max() / (named[k].abs().max() + 1e-30))
+        res['ref_repro.' + k] = np.float64(e)
+        rep.append(e)
+    print('   one extra stage, frozen BatchNorm: %d parameters with gradient (%d of the extra stage); reference fp32, 8 threads vs 1: median %.2e, worst %.2e'
+          % (len(named), sum('_x.0.' in k for k in named), float(np.median(rep)), max(rep)))
+    res.update({'g32.' + k: (v.float() if torch.is_tensor(v) else v) for k, v in compact_grads_sized(named, coarse=2).items()})
+    save('g21_full_grad_frozen_bn_extra1', **res)
+
+
+GENS = {'full_extra': gen_full_extra, 'full_grad_frozen_extra': gen_full_grad_frozen_extra, 'full_grad_frozen': gen_full_grad_frozen, 'full_cond': lambda: gen_full(True), 'loss_cond': lambda: gen_loss(True), 'full_grad_cond': lambda: gen_full_grad(True),
         'full_grad': gen_full_grad, 'bone_grad': gen_bone_grad, 'block_grad': gen_block_grad, 'stage_grad': gen_stage_grad, 'pgcn_grad': gen_pgcn_grad, 'ste_grad': gen_ste_grad, 'regress_grad': gen_regress_grad, 'mano_grad': gen_mano_grad, 'mano': gen_mano, 'pgcn': gen_pgcn, 'ste': gen_ste, 'grid': gen_grid, 'bone': gen_bone,
         'stage': gen_stage, 'full': gen_full, 'eval': gen_eval, 'gtmano': gen_gtmano, 'imgprep': gen_imgprep, 'loss': gen_loss, 'loss_grad': gen_loss_grad}
 

@@ -176,3 +176,16 @@ def bone_grad_inputs(S, B=3):
     """G19: one hand's joint uv [B,21,2], re-embedded joint features [B,21,64], cotangent of the rasterised map [B,1280,S,S]"""
     p = 'bonegrad%d.' % S
     return bone_uv(p + 'uv', B, S), synth.synth_input(p + 'feat', (B, 21, 64), SEED), synth.synth_input(p + 'g', (B, 1280, S, S), SEED)
+
+
+def extra_stage_shapes(shapes, n):
+    """parameter / buffer shapes of n extra refinement stages (decoder.projecter_x.<i>.* = the shapes of decoder.projecter_3.*,
+    decoder.enhance_layer_x.<i>.* = those of decoder.enhance_layer3.*: the same classes with the same arguments, models/dir.py:401-402)"""
+    out = {}
+    for i in range(n):
+        for k, v in shapes.items():
+            if k.startswith('decoder.projecter_3.'):
+                out['decoder.projecter_x.%d.' % i + k[len('decoder.projecter_3.'):]] = v
+            elif k.startswith('decoder.enhance_layer3.'):
+                out['decoder.enhance_layer_x.%d.' % i + k[len('decoder.enhance_layer3.'):]] = v
+    return out

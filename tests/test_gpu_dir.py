@@ -479,11 +479,12 @@ def test_calibrating_twice_changes_nothing(dir_state_cond, mode):
 
 # ---------------------------------------------------------------------------------------------------------------- f4: N refinement iterations
 @pytest.mark.parametrize('mode', ['f32', 'f16x3', 'bf16'])
-def test_extra_refinement_stages_vs_oracle(mode):
+def test_extra_refinement_stages_vs_oracle(mode, golden):
     """SURVEY.md 8f rank 4 (config 5: "5 refinement iters"): dir_amd.models.dir.DIR(extra_stages=2) -- two further Joint2BoneFeature + Residual
-    iterations at 32x32 with their own parameters -- against the numpy oracle extended the same way (oracle/dir_forward.py).  The reference has
-    no such network (models/dir.py:395,401 hard-wire two stages): parity is pinned to the oracle only, whose stage / Residual functions are the
-    ones the reference goldens G6 / G7 hold.  5 stage dicts + the dense / seg dict; proj_feat comes from the LAST stage."""
+    iterations at 32x32 with their own parameters -- against the numpy oracle extended the same way (oracle/dir_forward.py) AND against G7x: the
+    reference's own DIR with two more of its own `Joint2BoneFeature` / `Residual` modules chained the way its forward chains its two stages
+    (oracle/gen_golden.py::reference_with_extra_stages; the reference has no such network, models/dir.py:395,401, but it has the classes).
+    5 stage dicts + the dense / seg dict; proj_feat comes from the LAST stage."""
     from dir_amd.models.dir import DIR
     from oracle.dir_forward import dir_forward
     net = DIR(21, './misc/mano', 0, extra_stages=2, compute_dtype=torch.bfloat16 if mode == 'bf16' else torch.float32,
@@ -510,6 +511,12 @@ def test_extra_refinement_stages_vs_oracle(mode):
         assert max(mpjpe[1:]) < 0.012 and mpjpe[0] < 0.1, mpjpe
     else:
         assert worst < 1.25e-7, worst                    # vs the numpy oracle (itself up to 3e-8 m from a torch evaluation)
+        g = golden('g7x_dir_extra2')                     # the composed reference: north_star's 1e-4 mm on all five stages
+        worst_ref = max(maxabs(outs[i][k].cpu().numpy(), g['s%d.%s' % (i, k)]) for i in range(5)
+                        for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right'))
+        print('   vs the composed reference (G7x): worst |xyz| %.3e m' % worst_ref)
+        assert worst_ref < 1e-7, worst_ref
+        assert relerr(outs[5]['seg'].cpu().numpy(), g['seg']) < 5e-4 and relerr(outs[5]['dense'].cpu().numpy(), g['dense']) < 5e-4
         assert relerr(outs[5]['seg'].cpu().numpy(), ref[5]['seg']) < 5e-4
         pf = outs[5]['proj_feat'].cpu().numpy()
         assert relerr(pf[:, 0:1280:97], ref[5]['proj_feat'][:, 0:1280:97]) < 5e-4

@@ -341,3 +341,94 @@ def test_full_training_step_gradient_frozen_batchnorm_pinned_tightly(golden):
     assert len(errs) >= 500
     for e, k, r in errs:
         assert e < 1e-3, (k, e, r)
+
+
+def test_training_step_gradient_with_an_extra_stage_vs_the_composed_reference(golden):
+    """VERDICT r3 "missing" 4 (training of what f4 added), for the N-stage half of f4: dir_amd/train/net.py runs any number of
+    decoder.projecter_x.<i> / enhance_layer_x.<i> stages, forward and backward.  G21 is the gradient of G20e's set-up (BatchNorm frozen: the form in
+    which the reference's gradient is reproducible, median 7e-7 here) through the reference's own DIR with ONE more `Joint2BoneFeature` + `Residual`
+    of its own classes appended and chained as its forward chains its two stages (oracle/gen_golden.py::reference_with_extra_stages): 55 loss
+    terms, 709 parameter gradients, 153 of them the extra stage's -- every one within 1e-3 of its maximum."""
+    from conftest import loss_case
+    from oracle.golden_inputs import extra_stage_shapes
+    from dir_amd.train import ops as O
+    g8, g21 = golden('g8c_loss'), golden('g21_full_grad_frozen_bn_extra1')
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    shapes.update(extra_stage_shapes(shapes, 1))
+    sd = synth.synth_state_dict(shapes, SEED, cond=True)
+    P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if 'num_batches' not in k}
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+    keep = []
+    with O.frozen_batchnorm():
+        outs, ctx = TN.forward(P, img, keep)
+        loss = TN.losses(outs, target, meta, fc)
+        G = TN.backward(P, ctx, outs, target, meta, fc)
+    assert len(outs) == 5 and len(loss) == 3 + 13 * 4
+    for k, v in loss.items():
+        assert abs(float(v) - float(g21['loss.' + k])) < 2e-5 * max(1.0, abs(float(g21['loss.' + k]))), (k, float(v), float(g21['loss.' + k]))
+    none = set(str(k) for k in g21['none'])
+    trained = {k for k in shapes if not any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight')) and k not in none}
+    assert set(G) == trained
+    errs = []
+    for k, v in G.items():
+        a = v.cpu().numpy().astype(np.float64)
+        while a.ndim > 2 and a.shape[-1] == 1:
+            a = a[..., 0]
+        if 'g32.grad.' + k in g21:
+            ref = g21['g32.grad.' + k]
+            if np.abs(ref).max() == 0:
+                assert np.abs(a).max() == 0, k
+                continue
+            e = np.abs(a.reshape(ref.shape) - ref).max() / (np.abs(ref).max() + 1e-30)
+        else:
+            a2 = a.reshape(a.shape[0], -1) if (a.ndim == 4 and a.shape[-1] <= 7) else a.reshape(-1, a.shape[-1])
+            ck = [q for q in g21 if q.startswith('g32.grad.' + k + '.cols')][0]
+            e = np.abs(a2[:, ::int(ck.rsplit('.cols', 1)[1])] - g21[ck]).max() / (np.abs(g21[ck]).max() + 1e-30)
+        errs.append((float(e), k))
+    errs.sort(reverse=True)
+    extra = [e for e, k in errs if '_x.0.' in k]
+    print('one extra stage, frozen BatchNorm: %d gradients (%d of the extra stage); median distance to the composed reference %.2e, worst three %s'
+          % (len(errs), len(extra), float(np.median([e for e, _ in errs])), errs[:3]))
+    assert len(errs) >= 650 and len(extra) >= 140
+    # the extra stage's own parameters: 1e-3 like G20e; the rest of the network (whose gradients now also carry the extra stage's, nearly cancelling
+    # in a few backbone tensors: measured worst 1.6e-3 on layer4.0.conv3.weight, median 1.8e-6) 3e-3 -- a wiring error is O(1) everywhere upstream
+    assert float(np.median([e for e, _ in errs])) < 1e-5
+    for e, k in errs:
+        assert e < (1e-3 if '_x.0.' in k else 3e-3), (k, e)
+
+
+def test_mirror_module_trains_with_extra_stages():
+    """the mirror's training lines (train.py:64-70) with DIR(extra_stages=1): 55 loss terms, every trained parameter -- the extra stage's too -- gets a
+    gradient, and two AdamW steps lower the objective on the fixed batch"""
+    from conftest import loss_case
+    from dir_amd.models.dir import DIR
+    g8 = dict(np.load(os.path.join(HERE, 'golden', 'g8c_loss.npz')))
+    net = DIR(21, './misc/mano', 0, extra_stages=1)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, SEED, cond=True).items()}, strict=True)
+    net = net.cuda().train()
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-5)
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED))
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    target = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=torch.from_numpy(gt_seg), dense=torch.from_numpy(gt_dense))
+    meta = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in gt.items() if 'center' in k}
+    totals = []
+    for _ in range(3):
+        opt.zero_grad()
+        outs_list, loss = net({'img': img}, target, meta)
+        assert len(outs_list) == 5 and len(loss) == 55
+        total = sum(loss[k] for k in loss)
+        total.backward()
+        opt.step()
+        totals.append(float(total.detach()))
+    got = {k for k, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
+    assert any('projecter_x.0.' in k for k in got) and any('enhance_layer_x.0.' in k for k in got)
+    assert totals[2] < totals[0] and all(np.isfinite(totals)), totals

@@ -215,6 +215,30 @@ def test_full_dir_matches_reference(golden, cond):
     assert relerr(outs[3]['proj_feat'][:, 0:1280:97], g['proj_feat.slice']) < 5e-4
 
 
+def test_extra_stage_extension_matches_the_composed_reference(golden):
+    """G7x (round 4): the reference has no network with more than two refinement stages, but it has the MODULES -- oracle/gen_golden.py builds its
+    DIR, appends two more `Joint2BoneFeature` + `Residual` pairs of the classes and arguments of projecter_3 / enhance_layer3 and chains them the way
+    the reference's forward chains its own two stages.  The numpy oracle's N-stage extension (oracle/dir_forward.py) is held to that: the f4
+    extension is pinned to the reference's own classes, not only to this build's restatement of them."""
+    g = golden('g7x_dir_extra2')
+    shapes = shapes_of('manifest_dir.json')
+    from oracle.golden_inputs import extra_stage_shapes
+    shapes.update(extra_stage_shapes(shapes, 2))
+    assert len(shapes) == 963 + 2 * 240
+    sd = synth.synth_state_dict(shapes, SEED, cond=True)
+    outs = dir_forward(sd, synth.synth_input('dir.img', (2, 3, 256, 256), SEED))
+    assert len(outs) == 6
+    worst = 0.0
+    for i in range(5):
+        for k in ('pd_mesh_xyz_left', 'pd_mesh_xyz_right', 'pd_joint_xyz_left', 'pd_joint_xyz_right'):
+            worst = max(worst, maxabs(outs[i][k], g['s%d.%s' % (i, k)]))
+        for k in ('pd_joint_uv_left', 'pd_joint_uv_right', 'pd_proj_left', 'pd_proj_right', 'pd_offset'):
+            assert maxabs(outs[i][k], g['s%d.%s' % (i, k)]) < 5e-4, (i, k)
+    assert worst < 5e-7, worst                               # measured 5e-8 m
+    assert relerr(outs[5]['seg'], g['seg']) < 5e-4 and relerr(outs[5]['dense'], g['dense']) < 5e-4
+    assert relerr(outs[5]['proj_feat'][:, 0:1280:97], g['proj_feat.slice']) < 5e-4
+
+
 # ------------------------------------------------------------------ G9 eval metric maths (8f rank 1)
 @pytest.mark.parametrize('root_joint', [0, 9])
 @pytest.mark.parametrize('scale', [True, False])
