@@ -42,7 +42,7 @@ HBM_PEAK = 8.0e12                               # bytes/s, same guide
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median one is reported')
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
