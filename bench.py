@@ -147,7 +147,7 @@ def main():
         # bare `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU over RCCL)
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and os.environ.get('DIR_BENCH_BACKEND', 'nccl') == 'nccl':
             sys.stderr.write('bench.py: --gpus %d needs %d visible GPUs, this box has %d\n' % (args.gpus, args.gpus, have))
             sys.exit(2)
         from dir_amd import dist as D
@@ -169,9 +169,16 @@ def main():
         sys.stderr.write('bench.py: no GPU visible (the hot path has no CPU fallback)\n')
         sys.exit(2)
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # DIR_BENCH_BACKEND=gloo: the N > 1 control flow (rendezvous, barriers, max over ranks, rank 0's decisions and line) on a box with fewer GPUs
+    # than ranks -- ranks then SHARE devices, which RCCL refuses and which makes `value` meaningless: a test of the code path
+    # (tests/test_gpu_multi.py), never a measurement.  The line says which backend ran.
+    backend = os.environ.get('DIR_BENCH_BACKEND', 'nccl')
+    assert backend in ('nccl', 'gloo')
+    if backend == 'gloo':
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    rank, world, local = D.init_from_env('nccl', dev)          # nccl == RCCL on ROCm
+    rank, world, local = D.init_from_env(backend, dev)          # nccl == RCCL on ROCm
     assert world == args.gpus
     world_observed = dist.get_world_size() if dist.is_initialized() else 1
     assert world_observed == world
@@ -717,7 +724,7 @@ def main():
                            'conv_tuning': conv_tuning, 'conv_tuning_check': table_check, 'tunings_bit_identical': tunings_equal, 'weights': 'synthetic (dir_amd.synth seed 1234)',
                            'sharding': 'independent images per GPU, no data-path collective', 'outputs_finite': finite,
                            'overlapped_equals_one_at_a_time': reproducible, 'world_size_observed': world_observed,
-                           'backend': 'nccl (RCCL)' if world > 1 else 'none (single process)',
+                           'backend': ('nccl (RCCL)' if backend == 'nccl' else 'gloo (ranks may share a GPU: code-path test, not a measurement)') if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
                 'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf, 'config5_hrnet': cfg5}
@@ -734,6 +741,7 @@ def main():
         sys.stderr.flush()
         print(json.dumps(benchline.compact(line, detail_path)), flush=True)
     if world > 1:
+        barrier()                                 # rank 0 measured its roofline pass alone: the others leave the group together with it
         dist.destroy_process_group()
 
 

@@ -66,3 +66,24 @@ def test_training_steps_at_config_3_per_gpu_batch(tmp_path):
     obj = [float(t) for t in re.search(r'objective on rank 0 ([\d.\- >]+);', line).group(1).split(' -> ')]
     assert len(obj) == 4 and all(np.isfinite(obj)) and all(b < a for a, b in zip(obj, obj[1:])), obj
     assert min(times) < 0.08, times
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_code_path_over_gloo(tmp_path):
+    """bench.py's N > 1 path has never met more than one GPU (the driver's 8-GPU tier is the first to run it): rendezvous on 127.0.0.1, the
+    barriers around the timed regions, the max over ranks, rank 0 deciding the kernel table for everybody, ONE line from rank 0, everyone
+    leaving the process group together.  DIR_BENCH_BACKEND=gloo runs exactly that control flow with two ranks on whatever GPUs the box has
+    (sharing one here, which RCCL would refuse): the line must say n_gpus 2, weak scaling, a whole-job value of two ranks' images, and its backend."""
+    from dir_amd import dist as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / 'detail.json'
+    env = dict(os.environ, DIR_BENCH_BACKEND='gloo')
+    rc = D.spawn_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--repeats', '2', '--no-cpu-baseline', '--no-fp32-mode',
+                        '--no-train', '--no-proj-feat-variant', '--no-power', '--no-config5', '--no-ceiling-probe', '--no-time-table-pass',
+                        '--detail-out', str(out)], 2, env=env, timeout=900)
+    assert rc == 0
+    d = json.loads(out.read_text())
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['steps'] == 3 and d['config']['world_size_observed'] == 2
+    assert 'gloo' in d['config']['backend'] and d['config']['batch_per_gpu'] == 64
+    assert abs(d['value'] - 2 * 64 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']          # whole-job: both ranks' images over the slowest rank's time
+    assert d['roofline'] is not None and d['cpu_baseline'] is None
