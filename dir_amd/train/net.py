@@ -36,9 +36,26 @@ def put(G, pre, g):
         G[pre + k] = v
 
 
-def mano_tables(P, pre, keep):
-    """(left, right) dir_mano_tables of the two ManoLayers under `pre` ('init_regressor.' / 'decoder.projecter_4.regressor.')"""
-    return [E.pack_mano(P, pre + 'mano_layer_' + s, s, 0, keep) for s in SIDES]
+_MANO_KEYS = ('th_shapedirs', 'th_posedirs', 'th_v_template', 'th_J_regressor', 'th_weights', 'th_hands_mean', 'th_selected_comps')
+
+
+def mano_tables(P, pre, keep, owner=None):
+    """(left, right) dir_mano_tables of the two ManoLayers under `pre` ('init_regressor.' / 'decoder.projecter_4.regressor.').  The MANO tables are
+    BUFFERS (manopth registers them, they are never trained): with an `owner` (the step's scale_owner) the packed forms -- two float64 products
+    and a dozen copies per hand -- are made once and kept on it for as long as the buffers keep their storage and version (round 4: a step
+    re-packed all six layers, ~100 torch launches)."""
+    if owner is None:
+        return [E.pack_mano(P, pre + 'mano_layer_' + s, s, 0, keep) for s in SIDES]
+    cache = getattr(owner, '_dir_mano_cache', None)
+    if cache is None:
+        cache = {}
+        setattr(owner, '_dir_mano_cache', cache)
+    key = tuple((P[pre + 'mano_layer_' + s + '.' + k].data_ptr(), P[pre + 'mano_layer_' + s + '.' + k]._version) for s in SIDES for k in _MANO_KEYS)
+    hit = cache.get(pre)
+    if hit is None or hit[0] != key:
+        held = []
+        hit = cache[pre] = (key, [E.pack_mano(P, pre + 'mano_layer_' + s, s, 0, held) for s in SIDES], held)
+    return hit[1]
 
 
 # ------------------------------------------------------------------------------------------------------------------------------ pieces
@@ -135,7 +152,7 @@ def forward(P, img, keep=None, scale_owner=None):
             ctx['init']['mean'] = mean
     init['pd_offset'] = O.linear_fwd(ctx['init']['mean'], P['init_regressor.offset.weight'], P['init_regressor.offset.bias'])
     para = [O.linear_fwd(pooled[i], P['init_regressor.mano_%s.weight' % s], P['init_regressor.mano_%s.bias' % s]) for i, s in enumerate(SIDES)]
-    tabs0 = mano_tables(P, 'init_regressor.', keep)
+    tabs0 = mano_tables(P, 'init_regressor.', keep, scale_owner)
     mano = E.run_mano_pair(tabs0, para[0], para[1], B, mesh_uv=True)
     for i, s in enumerate(SIDES):
         init['pd_mano_para_' + s] = para[i]
@@ -154,7 +171,7 @@ def forward(P, img, keep=None, scale_owner=None):
         cat[..., Cup:] = skip
         fusion_feat, d['fusion'] = TB.residual_forward(sub(P, 'decoder.fusion_layer%s.' % tag), cat)
         pre = 'decoder.projecter_%s.' % tag
-        tabs = mano_tables(P, pre + 'regressor.', keep)
+        tabs = mano_tables(P, pre + 'regressor.', keep, scale_owner)
         res, d['tok'] = TS.stage_tokens_forward(sub(P, pre), tabs, fusion_feat, prev)
         img_feat, d['img'] = _stage_image_forward(P, pre, res['joint_feat'], res['pd_joint_uv_left'], res['pd_joint_uv_right'], S, dist,
                                                   want_vis=(si == 1 and 'decoder.projecter_x.0.fusion.0.weight' not in P))     # the LAST stage's map is an output (models/dir.py:481)
@@ -170,7 +187,7 @@ def forward(P, img, keep=None, scale_owner=None):
     while ('decoder.projecter_x.%d.fusion.0.weight' % len(ctx['extra'])) in P:
         i, d = len(ctx['extra']), {}
         pre = 'decoder.projecter_x.%d.' % i
-        tabs = mano_tables(P, pre + 'regressor.', keep)
+        tabs = mano_tables(P, pre + 'regressor.', keep, scale_owner)
         x_in = feat_lo
         res, d['tok'] = TS.stage_tokens_forward(sub(P, pre), tabs, x_in, prev)
         last = ('decoder.projecter_x.%d.fusion.0.weight' % (i + 1)) not in P

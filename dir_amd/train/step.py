@@ -90,3 +90,68 @@ def train_step(named_params, buffers, img, target, meta_info, faces, optimizer, 
     bucketer.finish()
     optimizer.step()
     return loss
+
+
+class GraphedTrainStep(object):
+    """train_step with everything but the optimiser replayed as ONE HIP graph ("graph-captured"): zero_grad, the training-mode
+    forward (with the one-launch weight packing), the objective, the backward pass and the moves into the flat gradient bucket are captured once
+    the operand scales are calibrated (`warm` eager steps), then replayed; FlatAdamW.step (whose learning rate and step count are launch
+    ARGUMENTS: train.py:127-149 changes them every step) and the gradient exchange of N > 1 ranks run after the replay.  The operand scales are
+    arguments too, so every DIR_TRAIN_RECALIBRATE steps one step runs eagerly (re-measuring them) and the graph is captured again.
+    Inputs are copied into fixed buffers; the returned loss tensors are the graph's own (valid until the next call).  Same kernels, same order:
+    the parameters after n steps equal train_step's bit for bit (tests/test_gpu_full_bwd.py)."""
+
+    def __init__(self, named_params, buffers, optimizer, faces, warm=2):
+        self.named_params, self.buffers, self.optimizer, self.faces, self.warm = named_params, buffers, optimizer, faces, int(warm)
+        self.graph, self.static, self.loss, self.calls, self.since_capture = None, None, None, 0, 0
+
+    def _stage(self, img, target, meta_info):
+        if self.static is None:
+            dev = self.optimizer.flat_param.device
+            mv = lambda t: torch.as_tensor(t).to(dev).clone()  # noqa: E731
+            self.static = (mv(img), {k: mv(v) for k, v in target.items()}, {k: mv(v) for k, v in meta_info.items()})
+        else:
+            self.static[0].copy_(img, non_blocking=True)
+            for d, src in ((self.static[1], target), (self.static[2], meta_info)):
+                for k, v in d.items():
+                    v.copy_(torch.as_tensor(src[k]), non_blocking=True)
+        return self.static
+
+    def _body(self):
+        from . import net as TN
+        img, target, meta = self.static
+        opt = self.optimizer
+        P = {k: v.data for k, v in self.named_params.items()}
+        P.update(self.buffers)
+        outs, ctx = TN.forward(P, img, scale_owner=opt)
+        loss = TN.losses(outs, target, meta, self.faces)
+        opt.zero_grad()
+        G = TN.backward(P, ctx, outs, target, meta, self.faces)
+        add_grads(self.named_params, '', G)
+        return loss
+
+    def __call__(self, img, target, meta_info):
+        from . import conv as TC
+        self._stage(img, target, meta_info)
+        self.calls += 1
+        recal = TC.RECALIBRATE > 0 and self.graph is not None and self.since_capture >= TC.RECALIBRATE
+        if self.graph is None or recal:
+            if recal:
+                TC.reset_scales(self.optimizer)
+                self.graph = None
+            if self.calls <= self.warm or recal:                   # eager: measures the operand scales (host synchronisations)
+                loss = self._body()
+                D.average_gradients(self.optimizer.flat_grad)
+                self.optimizer.step()
+                self.since_capture = 0
+                return loss
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss = self._body()
+            self.graph, self.since_capture = g, 0
+        self.graph.replay()
+        self.since_capture += 1
+        D.average_gradients(self.optimizer.flat_grad)
+        self.optimizer.step()
+        return self.loss

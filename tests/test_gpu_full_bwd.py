@@ -432,3 +432,44 @@ def test_mirror_module_trains_with_extra_stages():
     got = {k for k, p in net.named_parameters() if p.grad is not None and float(p.grad.abs().max()) > 0}
     assert any('projecter_x.0.' in k for k in got) and any('enhance_layer_x.0.' in k for k in got)
     assert totals[2] < totals[0] and all(np.isfinite(totals)), totals
+
+
+def test_graph_captured_train_step_equals_the_eager_one():
+    """VERDICT r3 item 5 ("graph-captured"): dir_amd.train.step.GraphedTrainStep replays zero_grad + forward + objective + backward + the moves
+    into the gradient bucket as ONE HIP graph (FlatAdamW.step, whose learning rate and step count are launch arguments, stays outside).  Two eager
+    warm steps calibrate the operand scales, the third call captures, the rest replay: after six steps the parameters equal six eager steps bit
+    for bit, and the returned loss is the eager one.  (It is no faster -- the step is GPU-bound, 39 ms of kernels in 39 ms -- which is why
+    bench.py's train_step record stays eager; tools/bench_train_graphed.py prints both times.)"""
+    from conftest import loss_case
+    from dir_amd.optim import FlatAdamW
+    from dir_amd.train import step as TSTEP
+    g8 = dict(np.load(os.path.join(HERE, 'golden', 'g8_loss.npz')))
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+    is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+
+    def make():
+        params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
+        buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
+        opt = FlatAdamW(list(params.values()), lr=2e-5)
+        opt.set_inactive(TSTEP.inactive_parameters(params))
+        return params, buffers, opt
+    p1, b1, o1 = make()
+    for _ in range(6):
+        l1 = TSTEP.train_step(p1, b1, img, target, meta, fc, o1, overlap_allreduce=False)
+    p2, b2, o2 = make()
+    gs = TSTEP.GraphedTrainStep(p2, b2, o2, fc)
+    for _ in range(6):
+        l2 = gs(img, target, meta)
+    assert gs.graph is not None and gs.since_capture == 4            # calls 1-2 eager, call 3 captures and replays, 4-6 replay
+    assert torch.equal(o1.flat_param, o2.flat_param)
+    assert all(torch.equal(b1[k], b2[k]) for k in b1)                       # BatchNorm running statistics too
+    assert {k: float(v) for k, v in l1.items()} == {k: float(v) for k, v in l2.items()}
