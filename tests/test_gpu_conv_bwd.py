@@ -148,3 +148,25 @@ def test_weight_pack_is_the_per_call_packing_bit_for_bit():
     ref, sc = F.pack_f16x3_weights_device(ws[0].permute(0, 2, 3, 1).contiguous().reshape(64, -1))
     assert torch.equal(e.fwd.view(-1), ref.view(-1)) and torch.equal(e.fwd_scale, sc / 4.0) and e.applied == [4.0, 0.125]
     assert not torch.equal(e.fwd_scale, before[0]) and torch.equal(pk.entries[1].fwd_scale, F.pack_f16x3_weights_device(ws[1].reshape(256, -1))[1])
+
+
+def test_training_convolution_variants_are_bit_identical():
+    """The forward kernels' variants (DIR_CONV_VARIANT: tile shapes / pipelines) all accumulate in the same order: the split-precision forward and
+    data-gradient convolutions of the training step give the SAME BITS whichever runs -- on a 3x3, a strided 3x3, a 1x1 with a residual operand, a
+    wide-K 3x3, a 1-channel head and a wide 1x1.  (Round 4 timed a per-shape choice among them for the training step, as DirEngine.autotune does per
+    layer: 0.0400 -> 0.0397 s, within noise -- the heuristic already picks well for fp32 maps -- so the step keeps the heuristic.)"""
+    from dir_amd import functional as F
+    candidates = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    cases = [(4, 32, 128, 128, 3, 1, 1, False), (4, 32, 128, 256, 3, 2, 1, False), (4, 32, 512, 128, 1, 1, 0, True), (2, 16, 2560, 256, 3, 1, 1, False),
+             (4, 32, 128, 1, 1, 1, 0, False), (2, 8, 512, 2048, 1, 1, 0, False)]
+    for B, H, Cin, Cout, k, stride, pad, res in cases:
+        x = torch.randn(B, H, H, Cin, device='cuda', generator=gen)
+        w = torch.randn(Cout, k, k, Cin, device='cuda', generator=gen) * 0.05
+        Ho = (H + 2 * pad - k) // stride + 1
+        r = torch.randn(B, Ho, Ho, Cout, device='cuda', generator=gen) if res else None
+        presplit = k >= 3 or (Cout >= 512 and Cin >= 128)
+        ref = F.conv2d_nhwc(x, w, stride=stride, pad=pad, arith='f16x3', in_scale=4.0, device_pack=True, presplit=presplit, residual=r, variant=0)
+        for v in candidates[1:]:
+            y = F.conv2d_nhwc(x, w, stride=stride, pad=pad, arith='f16x3', in_scale=4.0, device_pack=True, presplit=presplit, residual=r, variant=v)
+            assert torch.equal(y, ref), ((B, H, Cin, Cout, k, stride), v)
