@@ -73,3 +73,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 }  // namespace dir
+
+namespace dir {
+// s + p[0] + p[stride] + ... + p[(n - 1) stride], added IN THAT ORDER (the same bits as the plain loop), with eight loads in flight: the
+// chunk-partial reductions of the training step (weight gradients, split-K GEMMs, BatchNorm, column sums) were one dependent memory round trip
+// per term -- up to 64 per thread.
+__device__ __forceinline__ float sum_in_order(const float* p, long long stride, int n, float s) {
+    int c = 0;
+    for (; c + 8 <= n; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < n; ++c) s += p[(long long)c * stride];
+    return s;
+}
+}  // namespace dir

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel(const float* part,
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = accumulate ? gw[i] : 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(long long)c * n + i];
+    s = dir::sum_in_order(part + i, n, chunks, s);
     gw[i] = s;
 }
 
