@@ -279,11 +279,15 @@ __global__ __launch_bounds__(BT) void mano_backward_kernel(ManoBwdArgs args) {
     if (tid < NJ * 12) {
         const int k = tid / 12, e = tid - 12 * k, r = e >> 2, c = e & 3;
         float acc = 0.f;
-        for (int v = 0; v < NV; ++v) {
-            const float w = a.t.weights[16 * v + k];
-            const float t = s_gv[3 * v + r] * (c < 3 ? s_v[3 * v + c] : 1.f);
-            acc = fmaf(w, t, acc);
+        int v = 0;
+        for (; v + 8 <= NV; v += 8) {                      // eight skinning weights in flight, accumulated in vertex order (the same sum): the loop
+            float w[8];                                    // was 778 dependent global loads per thread, most of this kernel's 233 us
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = a.t.weights[16 * (v + u) + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(w[u], s_gv[3 * (v + u) + r] * (c < 3 ? s_v[3 * (v + u) + c] : 1.f), acc);
         }
+        for (; v < NV; ++v) acc = fmaf(a.t.weights[16 * v + k], s_gv[3 * v + r] * (c < 3 ? s_v[3 * v + c] : 1.f), acc);
         s_gA2[tid] = acc;
     }
     __syncthreads();
@@ -364,7 +368,15 @@ __global__ __launch_bounds__(BT) void mano_backward_kernel(ManoBwdArgs args) {
     for (int k = wave; k < 135; k += BT / 64) {
         const float* row = a.t.posedirs_t + (size_t)k * NV3P;
         float acc = 0.f;
-        for (int i = lane; i < NV3; i += 64) acc = fmaf(row[i], s_gvp[i], acc);
+        int i = lane;
+        for (; i + 448 < NV3; i += 512) {                  // eight table loads in flight, accumulated in order (the same sum)
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = row[i + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(t[u], s_gvp[i + 64 * u], acc);
+        }
+        for (; i < NV3; i += 64) acc = fmaf(row[i], s_gvp[i], acc);
         acc = dir::wave_sum(acc);
         if (lane == 0) s_pm[k] = acc;                     // (s_pm re-used: the forward value is not needed any more)
     }
@@ -437,7 +449,15 @@ __global__ __launch_bounds__(BT) void mano_backward_kernel(ManoBwdArgs args) {
     for (int k = wave; k < 10; k += BT / 64) {
         const float* row = a.t.shapedirs_t + (size_t)k * NV3P;
         float acc = 0.f;
-        for (int i = lane; i < NV3; i += 64) acc = fmaf(row[i], s_gvp[i], acc);
+        int i = lane;
+        for (; i + 448 < NV3; i += 512) {                  // eight table loads in flight, accumulated in order (the same sum)
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = row[i + 64 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(t[u], s_gvp[i + 64 * u], acc);
+        }
+        for (; i < NV3; i += 64) acc = fmaf(row[i], s_gvp[i], acc);
         if (lane < 48) acc = fmaf(a.t.j_shapedirs[lane * 10 + k], s_gJ[lane], acc);
         acc = dir::wave_sum(acc);
         if (lane == 0 && a.g_betas) a.g_betas[(size_t)b * a.g_betas_stride + k] = acc;
