@@ -727,7 +727,19 @@ __global__ __launch_bounds__(64) void pgcn_adj_bwd_edge_kernel(const float* gz, 
     while (kAdjOff[j + 1] <= e) ++j;
     const int k = kAdjIdx[e];
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {                           // eight samples' loads in flight, accumulated in sample order (the same sum)
+        float g0[8], g1[8], h0[8], h1v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* g = gz + ((long long)(b + u) * 21 + j) * 128;
+            const float* h = h1 + ((long long)(b + u) * 21 + k) * 128;
+            g0[u] = g[lane]; g1[u] = g[lane + 64]; h0[u] = h[lane]; h1v[u] = h[lane + 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc = fmaf(g0[u], h0[u], acc); acc = fmaf(g1[u], h1v[u], acc); }
+    }
+    for (; b < B; ++b) {
         const float* g = gz + ((long long)b * 21 + j) * 128;
         const float* h = h1 + ((long long)b * 21 + k) * 128;
         acc = fmaf(g[lane], h[lane], acc);

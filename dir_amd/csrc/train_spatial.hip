@@ -186,15 +186,14 @@ __global__ __launch_bounds__(64) void bone_bwd_kernel(BoneBwdArgs a) {
     const float* emb = a.emb + ((long long)b * 42 + hand * 21) * 64;
     const float fa = emb[ja * 64 + c], fb = emb[jb * 64 + c];
     float gfa = 0.f, gfb = 0.f, gAx = 0.f, gAy = 0.f, gBx = 0.f, gBy = 0.f;
-    for (int p = 0; p < S * S; ++p) {
+    const float* gbase = a.g_img + (long long)b * S * S * a.img_cs + a.img_co + (hand * 20 + k) * 64 + c;
+    auto pixel = [&](int p, float g) {               // one pixel inside the bone's mask: the sums in pixel order
         const int y = p / S, x = p - y * S;
         const float px = x + 0.5f, py = y + 0.5f;
         float wa, wb; bool in;
         dir::bone::bone_weights(px, py, Ax, Ay, Bx, By, a.distance, wa, wb, in);     // the forward's own mask and weights, bit for bit
-        if (!in) continue;                           // (wave-uniform: the mask does not depend on the channel)
         const float dax = px - Ax + 1e-6f, day = py - Ay + 1e-6f, dbx = px - Bx + 1e-6f, dby = py - By + 1e-6f;
         const float da = sqrtf(dax * dax + day * day), db = sqrtf(dbx * dbx + dby * dby), sum = da + db;
-        const float g = a.g_img[(((long long)b * S + y) * S + x) * a.img_cs + a.img_co + (hand * 20 + k) * 64 + c];
         gfa += wa * g; gfb += wb * g;
         float gwa = g * fa, gwb = g * fb;            // <g, f> over the 64 channels = one wave
         for (int o = 32; o > 0; o >>= 1) { gwa += __shfl_xor(gwa, o); gwb += __shfl_xor(gwb, o); }
@@ -202,6 +201,42 @@ __global__ __launch_bounds__(64) void bone_bwd_kernel(BoneBwdArgs a) {
         const float gda = (gwb - gwa) * db / (sum * sum), gdb = (gwa - gwb) * da / (sum * sum);
         gAx -= gda * dax / da; gAy -= gda * day / da;
         gBx -= gdb * dbx / db; gBy -= gdb * dby / db;
+    };
+    // The pixels inside the mask (wave-uniform: it does not depend on the channel), compacted IN PIXEL ORDER into LDS by ballots, then their
+    // gradients loaded eight at a time: the loop used to find each pixel and wait for its load in turn -- 100-200 dependent round trips, 166 us.
+    __shared__ unsigned short s_list[1024];
+    const int npix = S * S;
+    if (npix <= 1024) {
+        int n = 0;
+        for (int p0 = 0; p0 < npix; p0 += 64) {
+            const int p = p0 + c;
+            bool in = false;
+            if (p < npix) {
+                const int y = p / S, x = p - y * S;
+                float wa, wb;
+                dir::bone::bone_weights(x + 0.5f, y + 0.5f, Ax, Ay, Bx, By, a.distance, wa, wb, in);
+            }
+            const unsigned long long m = __ballot(in);
+            if (in) s_list[n + __popcll(m & ((1ull << c) - 1ull))] = (unsigned short)p;
+            n += __popcll(m);
+        }
+        __syncthreads();
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            int pp[8]; float g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { pp[u] = s_list[i + u]; g[u] = gbase[(long long)pp[u] * a.img_cs]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pixel(pp[u], g[u]);
+        }
+        for (; i < n; ++i) { const int p = s_list[i]; pixel(p, gbase[(long long)p * a.img_cs]); }
+    } else {
+        for (int p = 0; p < npix; ++p) {
+            const int y = p / S, x = p - y * S;
+            float wa, wb; bool in;
+            dir::bone::bone_weights(x + 0.5f, y + 0.5f, Ax, Ay, Bx, By, a.distance, wa, wb, in);
+            if (in) pixel(p, gbase[(long long)p * a.img_cs]);
+        }
     }
     float* gf = a.g_bone_f + ((((long long)b * a.hands + hand) * 20 + k) * 2) * 64;
     gf[c] = gfa; gf[64 + c] = gfb;
