@@ -110,7 +110,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 33          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 34          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -166,6 +166,8 @@ _SIGNATURES = {
     'dir_bone_fusion_scratch_bytes': (C.c_size_t, [_i]),
     'dir_bone_fusion_prepare': (C.c_int, [C.POINTER(BoneFusionParams), _p, _p, _i, _p]),
     'dir_bone_fusion_forward': (C.c_int, [C.POINTER(BoneFusionParams), _p, _p, _p, _p, _i, _i, C.c_float, _i, _i, _i, _p]),
+    'dir_bone_fusion_backward_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_bone_fusion_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, C.c_float, _p, _p, _p, _p, _p, C.c_longlong, _i, _i, _p]),
     'dir_gt_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p]),
     'dir_joint_regress_forward': (C.c_int, [_p, _p, _p, _i, _p]),
     'dir_eval_metrics_forward': (C.c_int, [C.POINTER(EvalInputs), C.POINTER(EvalOutputs), _i, _i, _i, _p]),

@@ -12,6 +12,8 @@ plain inputs.  Arithmetic (round 3): fp32 tensors; the convolutions' forward, da
 f16 matrix cores (dir_amd/train/conv.py: DIR_TRAIN_ARITH / DIR_TRAIN_WGRAD_ARITH = f16x3, 'f32' switches the exact kernels back), everything
 else exact fp32; BatchNorm + ReLU (+ the bottleneck's residual) one launch each way.  bench.py times a step as its train_step sub-record.
 """
+import os
+
 import torch
 
 from . import blocks as TB
@@ -24,6 +26,9 @@ from ..models import loss as L
 
 SIDES = ('left', 'right')
 LAYERS = (3, 4, 6, 3)
+# bone_proj + fusion.0 in the factorised form, forward and backward (dir_bone_fusion_*, csrc/bonefuse_bwd.hip); '0': the [B,S,S,2560] map and
+# the K = 23 040 convolution with its two gradient convolutions (rounds 2-3)
+FACTORISED_FUSION = os.environ.get('DIR_TRAIN_FACTORISED_FUSION', '1') != '0'
 
 
 def sub(P, pre):
@@ -95,19 +100,38 @@ def _stage_image_forward(P, pre, tok, uv_l, uv_r, S, distance, want_vis=False):
         y, c = TS.mlp_forward(Ps, 'proj_feat_emb.', rows)
         emb[:, 21 * h:21 * (h + 1)] = y.view(B, 21, 64)
         ctx_emb.append(c)
-    bone = SP.bone_proj_fwd(uv_l, uv_r, emb, S, distance, want_vis=want_vis)
     vis = None
-    if want_vis:
-        bone, vis = bone
-    img_feat, c_fus = _cbr_forward(P, pre + 'fusion.', bone, 3)
+    if FACTORISED_FUSION:
+        # bone_proj + fusion.0 as a K = 720 reduction in exact fp32 (dir_bone_fusion_*): no [B,S,S,2560] map, no 23 040-deep convolution
+        fpre = pre + 'fusion.'
+        h, c_bf = SP.bone_fusion_fwd(uv_l, uv_r, emb, SP.fusion_w_g(P[fpre + '0.weight']), P.get(fpre + '0.bias'), S, distance)
+        a, s_bn = TB.bn_fwd(P, fpre + '1.', h, relu=True)
+        img_feat = TC.conv_fwd(a, P[fpre + '3.weight'], P.get(fpre + '3.bias'), oihw=True)
+        c_fus = dict(bf=c_bf, bn=s_bn, a=a)
+        if want_vis:
+            vis = SP.bone_proj_vis(uv_l, uv_r, emb, S, distance)
+    else:
+        bone = SP.bone_proj_fwd(uv_l, uv_r, emb, S, distance, want_vis=want_vis)
+        if want_vis:
+            bone, vis = bone
+        img_feat, c_fus = _cbr_forward(P, pre + 'fusion.', bone, 3)
     return img_feat, dict(emb=emb, ctx_emb=ctx_emb, fus=c_fus, uv=(uv_l, uv_r), S=S, distance=distance, vis=vis)
 
 
 def _stage_image_backward(P, pre, s, g_img_feat, G):
     """-> (g joint_feat [B,42,64], g uv_left, g uv_right)"""
     B = s['emb'].shape[0]
-    g_bone = _cbr_backward(P, pre + 'fusion.', s['fus'], g_img_feat, G)
-    g_emb, gul, gur = SP.bone_proj_bwd(s['uv'][0], s['uv'][1], s['emb'], g_bone, s['S'], s['distance'])
+    if 'bf' in s['fus']:
+        fpre, f = pre + 'fusion.', s['fus']
+        g = TB._conv_bwd(P, fpre + '3.', f['a'], g_img_feat, 1, 0, G)
+        g = TB.bn_bwd(P, fpre + '1.', f['bn'], g, G, relu=True)
+        g_w_g, g_emb, gul, gur = SP.bone_fusion_bwd(f['bf'], g)
+        G[fpre + '0.weight'] = SP.fusion_w_g_grad_to_oihw(g_w_g)
+        if (fpre + '0.bias') in P:
+            G[fpre + '0.bias'] = O.colsum(g.view(-1, 256))
+    else:
+        g_bone = _cbr_backward(P, pre + 'fusion.', s['fus'], g_img_feat, G)
+        g_emb, gul, gur = SP.bone_proj_bwd(s['uv'][0], s['uv'][1], s['emb'], g_bone, s['S'], s['distance'])
     Ps, Gs = sub(P, pre), {}
     g_tok = torch.empty(B, 42, 64, device=g_emb.device)
     for h in range(2):

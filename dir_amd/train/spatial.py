@@ -77,6 +77,15 @@ def bone_proj_fwd(uv_l, uv_r, emb, S, distance, want_vis=False):
     return (out, vis) if want_vis else out
 
 
+def bone_proj_vis(uv_l, uv_r, emb, S, distance):
+    """only `vis_img_feat` (proj_feat, models/dir.py:128,481), NCHW fp32 [B,1280,S,S]: the factorised fusion needs no bone map"""
+    B = emb.shape[0]
+    vis = torch.empty(B, 1280, S, S, device=emb.device)
+    _capi.check(_capi.lib().dir_bone_proj_forward(_capi.ptr(uv_l), _capi.ptr(uv_r), _capi.ptr(emb), None, _capi.ptr(vis), None, B, S, float(distance),
+                                                  _capi.DT_F32, _capi.stream_ptr()), 'dir_bone_proj_forward')
+    return vis
+
+
 def bone_proj_bwd(uv_l, uv_r, emb, g_img, S, distance, coff=0):
     """g_img [B,S,S,Cbuf] -> (g emb [B,42,64], g uv_left [B,21,2], g uv_right [B,21,2])"""
     O._chk(uv_l, uv_r, emb, g_img)
@@ -89,3 +98,50 @@ def bone_proj_bwd(uv_l, uv_r, emb, g_img, S, distance, coff=0):
                                                    _capi.ptr(g_emb), P2(g_uv[0].data_ptr(), g_uv[1].data_ptr()), _capi.ptr(scratch), B, S, 2, _capi.stream_ptr()),
                 'dir_bone_proj_backward')
     return g_emb, g_uv[0], g_uv[1]
+
+
+# ---------------------------------------------------------------------------------------------- factorised bone fusion, training form
+def fusion_w_g(w_oihw):
+    """fusion.0.weight [256, 2560, 3, 3] -> w_g [9][40][64][256] (include/dir_hip.h: dir_bone_fusion_params.w_g), unrounded"""
+    return w_oihw.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous()
+
+
+def fusion_w_g_grad_to_oihw(g_w_g):
+    return g_w_g.permute(3, 1, 2, 0).reshape(256, 2560, 3, 3).contiguous()
+
+
+def bone_fusion_fwd(uv_l, uv_r, emb, w_g, bias, S, distance):
+    """bone_proj + fusion.0 (models/dir.py:57,132-174) without the [B,S,S,2560] map, exact fp32: -> (y [B,S,S,256] = the raw convolution + bias,
+    ctx for bone_fusion_bwd).  dir_bone_fusion_prepare + dir_bone_fusion_forward (exact_f32)."""
+    O._chk(uv_l, uv_r, emb, w_g, bias)
+    B, L = emb.shape[0], _capi.lib()
+    par = _capi.BoneFusionParams(w_g.data_ptr(), None, None if bias is None else bias.data_ptr(), 1, 0.0)
+    g = torch.empty(L.dir_bone_fusion_scratch_bytes(B) // 4, device=emb.device)
+    y = torch.empty(B, S, S, 256, device=emb.device)
+    if _capi.PROFILE is not None:
+        _capi.annotate(family='bone_fusion', flops=2.0 * B * 9 * 80 * 64 * 256, bytes=4.0 * (9 * 40 * 64 * 256 + B * 9 * 80 * 256), shape='G B=%d' % B)
+    _capi.check(L.dir_bone_fusion_prepare(par, _capi.ptr(emb), _capi.ptr(g), B, _capi.stream_ptr()), 'dir_bone_fusion_prepare')
+    if _capi.PROFILE is not None:
+        _capi.annotate(family='bone_fusion', flops=2.0 * B * S * S * 256 * 720, bytes=4.0 * (B * 9 * 80 * 256 + B * S * S * 256), shape='fuse B=%d S=%d f32' % (B, S))
+    _capi.check(L.dir_bone_fusion_forward(par, _capi.ptr(uv_l), _capi.ptr(uv_r), _capi.ptr(g), _capi.ptr(y), B, S, float(distance), 256, 0, 0, _capi.stream_ptr()),
+                'dir_bone_fusion_forward')
+    return y, dict(uv=(uv_l, uv_r), emb=emb, w_g=w_g, g=g, S=S, distance=distance)
+
+
+def bone_fusion_bwd(ctx, gy, need_uv=True):
+    """gy [B,S,S,256] -> (g w_g [9,40,64,256], g emb [B,42,64], g uv_left, g uv_right [B,21,2])   (dir_bone_fusion_backward)"""
+    O._chk(gy)
+    emb, S, L = ctx['emb'], ctx['S'], _capi.lib()
+    B = emb.shape[0]
+    g_w_g = torch.empty_like(ctx['w_g'])
+    g_emb = torch.empty(B, 42, 64, device=emb.device)
+    g_uv = [torch.empty(B, 21, 2, device=emb.device) if need_uv else None for _ in range(2)]
+    n = L.dir_bone_fusion_backward_workspace_bytes(B, S)
+    ws = torch.empty(n // 4, device=emb.device)
+    if _capi.PROFILE is not None:
+        _capi.annotate(family='bone_fusion', flops=2.0 * B * (2 * (S + 2) ** 2 * 720 * 256 + 2 * 720 * 64 * 256), bytes=4.0 * B * (2 * 720 * 256 + (S + 2) ** 2 * 336),
+                       shape='bwd B=%d S=%d' % (B, S))
+    _capi.check(L.dir_bone_fusion_backward(_capi.ptr(ctx['w_g']), _capi.ptr(emb), _capi.ptr(ctx['uv'][0]), _capi.ptr(ctx['uv'][1]), _capi.ptr(ctx['g']), _capi.ptr(gy),
+                                           float(ctx['distance']), _capi.ptr(g_w_g), _capi.ptr(g_emb), _capi.ptr(g_uv[0]), _capi.ptr(g_uv[1]), _capi.ptr(ws), n, B, S,
+                                           _capi.stream_ptr()), 'dir_bone_fusion_backward')
+    return g_w_g, g_emb, g_uv[0], g_uv[1]

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 33
+#define DIR_ABI_VERSION 34
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -593,6 +593,20 @@ int dir_bone_fusion_prepare(const dir_bone_fusion_params* params_host, const flo
 int dir_bone_fusion_forward(const dir_bone_fusion_params* params_host, const float* uv_left, const float* uv_right,
                             const void* scratch, void* y, int B, int S, float distance, int out_cstride, int out_coff,
                             int relu, void* stream);
+/* Backward of the factorised form for the training step (reference: torch autograd through models/dir.py:132-174 and the
+ * first convolution of `fusion`, models/dir.py:57-62, run by train.py:66-70).  Forward of the training path = dir_bone_fusion_prepare +
+ * dir_bone_fusion_forward with exact_f32 = 1, g_scale = 0, scale = NULL, shift = fusion.0.bias, relu = 0 (the raw convolution; BatchNorm
+ * with batch statistics follows as its own step).  From gy [B,S,S,256] (NHWC fp32, contiguous):
+ *   g_w_g  [9][40][64][256]   gradient of w_g (the caller permutes it back to fusion.0.weight's OIHW);
+ *   g_emb  [B,42,64]          gradient of the re-embedded joint features (both the G path and index_select's backward);
+ *   g_uv_* [B,21,2]           gradient of the stage's joint uv through the bone weights (optional, NULL to skip);
+ * g_scratch = the G that dir_bone_fusion_prepare(exact_f32 = 1) wrote for this batch.  No [B,S,S,2560] map or gradient map exists:
+ * four groups of exact-fp32 GEMMs (dir_gemm_f32) over zero-bordered pixel grids in which a tap is a pointer shift (csrc/bonefuse_bwd.hip).
+ * Deterministic.  workspace: dir_bone_fusion_backward_workspace_bytes(B, S) bytes, 16-byte aligned. */
+long long dir_bone_fusion_backward_workspace_bytes(int B, int S);
+int dir_bone_fusion_backward(const float* w_g, const float* emb, const float* uv_left, const float* uv_right, const void* g_scratch,
+                             const float* gy, float distance, float* g_w_g, float* g_emb, float* g_uv_left, float* g_uv_right,
+                             void* workspace, long long workspace_bytes, int B, int S, void* stream);
 
 /* ---- evaluation-metric maths of apps/eval.py --------------------------------------------------
  * f1a: Jr.__call__ (apps/eval.py:43-44): joints[B,21,3] = jr[21,778] @ verts[B,778,3].  `jr` is the Jr-processed

@@ -93,3 +93,43 @@ def test_bone_proj_backward_vs_reference_autograd_and_oracle(golden, S, dist):
     g2 = TSP.bone_proj_bwd(dv(uv), dv(uv2), emb, g_nhwc, S, dist)
     assert torch.equal(g_emb, g2[0]) and torch.equal(gul, g2[1])
     print('bone_proj backward S=%d vs torch autograd through the reference: g feat %.2e, g uv %.2e' % (S, e_f, e_u))
+
+
+@pytest.mark.parametrize('S,dist,B', [(16, 1, 3), (32, 2, 2), (32, 2, 5)])
+def test_factorised_bone_fusion_forward_and_backward_vs_float64_composition(S, dist, B):
+    """dir_bone_fusion_prepare / _forward (exact fp32) + dir_bone_fusion_backward -- the training step's bone_proj + fusion.0 -- against the
+    composition they replace: the float64 oracle's bone_proj, a float64 3x3 convolution differentiated by torch autograd (CPU) and the float64
+    oracle's bone_proj backward (models/dir.py:57,132-174).  Tolerance 1e-5 of each tensor's maximum (g uv 1e-4, as bone_proj's own test)."""
+    from oracle.tokens import bone_proj
+    from oracle.spatial_grad import bone_proj_backward
+    rng = np.random.default_rng(S * 100 + B)
+    uv_l = bone_grad_inputs(S, B)[0]
+    uv_r = uv_l[::-1].copy()
+    feat = rng.standard_normal((B, 42, 64)).astype(np.float32)
+    W = (rng.standard_normal((256, 2560, 3, 3)) * 0.02).astype(np.float32)
+    bias = rng.standard_normal(256).astype(np.float32)
+    gy = rng.standard_normal((B, S, S, 256)).astype(np.float32)
+    # float64 reference
+    img = np.concatenate([np.asarray(bone_proj(uv, feat[:, 21 * h:21 * h + 21], S, dist), np.float64) for h, uv in enumerate((uv_l, uv_r))], 1)   # [B,2560,S,S]
+    ti = torch.from_numpy(img).requires_grad_(True)
+    tw = torch.from_numpy(W.astype(np.float64)).requires_grad_(True)
+    y_ref = torch.nn.functional.conv2d(ti, tw, torch.from_numpy(bias.astype(np.float64)), padding=1)
+    y_ref.backward(torch.from_numpy(gy.astype(np.float64)).permute(0, 3, 1, 2))
+    g_img, g_w_ref = ti.grad.numpy(), tw.grad.numpy()
+    gu, gf = zip(*[bone_proj_backward(uv, feat[:, 21 * h:21 * h + 21], g_img[:, 1280 * h:1280 * h + 1280], S, dist) for h, uv in enumerate((uv_l, uv_r))])
+    # library
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    w_d = dv(W)
+    y, ctx = TSP.bone_fusion_fwd(dv(uv_l), dv(uv_r), dv(feat), TSP.fusion_w_g(w_d), dv(bias), S, dist)
+    yr = y_ref.detach().permute(0, 2, 3, 1).numpy()
+    e_y = float(np.abs(y.cpu().numpy() - yr).max() / np.abs(yr).max())
+    g_w_g, g_emb, gul, gur = TSP.bone_fusion_bwd(ctx, dv(gy))
+    g_w = TSP.fusion_w_g_grad_to_oihw(g_w_g).cpu().numpy()
+    e_w = float(np.abs(g_w - g_w_ref).max() / np.abs(g_w_ref).max())
+    gf_ref = np.concatenate(gf, 1)
+    e_f = float(np.abs(g_emb.cpu().numpy() - gf_ref).max() / np.abs(gf_ref).max())
+    e_u = max(float(np.abs(a.cpu().numpy() - r).max() / np.abs(r).max()) for a, r in ((gul, gu[0]), (gur, gu[1])))
+    print('factorised fusion S=%d B=%d vs float64: y %.2e, g weight %.2e, g emb %.2e, g uv %.2e' % (S, B, e_y, e_w, e_f, e_u))
+    assert e_y < 1e-5 and e_w < 1e-5 and e_f < 1e-5 and e_u < 1e-4, (e_y, e_w, e_f, e_u)
+    again = TSP.bone_fusion_bwd(ctx, dv(gy))
+    assert all(torch.equal(a, b) for a, b in zip((g_w_g, g_emb, gul, gur), again))          # deterministic
