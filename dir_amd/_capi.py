@@ -51,6 +51,10 @@ class GemmDesc(C.Structure):
                [(n, C.c_int64) for n in ('stride_a', 'stride_b', 'stride_c')]
 
 
+class GemmGroups(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('ny', 'nx', 'reduce', 'reserved')] + [(n, C.c_int64) for n in ('a_y', 'a_x', 'b_y', 'b_x', 'c_y', 'c_x')]
+
+
 class TokenMlp(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w1t', 's1', 'b1', 'w2t', 'b2')]
 
@@ -175,6 +179,7 @@ _SIGNATURES = {
     'dir_mano_backward_pair': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p, _i, _p, _i, _i, _i, _p]),
     'dir_regress_backward': (C.c_int, [_p] * 17 + [_i, _p]),
     'dir_gemm_f32': (C.c_int, [C.POINTER(GemmDesc), _p, _p, _p, _p, _p]),
+    'dir_gemm_f32_grouped': (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmGroups), _p, _p, _p, _p, _p]),
     'dir_colsum_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_colsum_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_layernorm_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, C.c_float, _p]),

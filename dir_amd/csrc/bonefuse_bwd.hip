@@ -221,15 +221,19 @@ extern "C" int dir_bone_fusion_backward(const float* w_g, const float* emb, cons
     if (rc != DIR_OK) return rc;
 
     const long long tapblk = (long long)NE * B * NCOUT;              // one tap of gt / dgt
-    for (int tap = 0; tap < NTAP; ++tap) {
-        const int off = (tap / 3 - 1) * PW + (tap % 3 - 1);
-        // (2) dwgt[b][q][e] (+)= gy_pad[b][q - off][:] . gt[tap][e][b][:]
-        dir_gemm_desc d2{PP, NE, NCOUT, NCOUT, B * NCOUT, NE, 0, 1, tap > 0, B, (long long)R * NCOUT, NCOUT, (long long)PP * NE};
-        rc = dir_gemm_f32(&d2, w.gyp + (long long)(MG - off) * NCOUT, w.gt + tap * tapblk, nullptr, w.dwgt, stream);
+    // tap (ky, kx) reads row q + off, off = (ky - 1) * PW + (kx - 1): a displacement of ky * PW + kx rows from the tap (0, 0) pointer
+    // (2) dwgt[b][q][e] = sum_tap gy_pad[b][q - off][:] . gt[tap][e][b][:]   -- the nine taps summed inside one workgroup
+    {
+        dir_gemm_desc d{PP, NE, NCOUT, NCOUT, B * NCOUT, NE, 0, 1, 0, B, (long long)R * NCOUT, NCOUT, (long long)PP * NE};
+        dir_gemm_groups g{3, 3, 1, 0, -(long long)PW * NCOUT, -(long long)NCOUT, 3 * tapblk, tapblk, 0, 0};
+        rc = dir_gemm_f32_grouped(&d, &g, w.gyp + (long long)(MG + PW + 1) * NCOUT, w.gt, nullptr, w.dwgt, stream);
         if (rc != DIR_OK) return rc;
-        // (1) dgt[tap][e][b][n] = sum_q wgt_pad[b][q + off][e] * gy_pad[b][q][n]
-        dir_gemm_desc d1{NE, NCOUT, PP, NE, NCOUT, B * NCOUT, 1, 0, 0, B, (long long)R * NE, (long long)R * NCOUT, NCOUT};
-        rc = dir_gemm_f32(&d1, w.wgt + (long long)(MG + off) * NE, w.gyp + (long long)MG * NCOUT, nullptr, w.dgt + tap * tapblk, stream);
+    }
+    // (1) dgt[tap][e][b][n] = sum_q wgt_pad[b][q + off][e] * gy_pad[b][q][n]   -- nine products per sample, one launch
+    {
+        dir_gemm_desc d{NE, NCOUT, PP, NE, NCOUT, B * NCOUT, 1, 0, 0, B, (long long)R * NE, (long long)R * NCOUT, NCOUT};
+        dir_gemm_groups g{3, 3, 0, 0, (long long)PW * NE, NE, 0, 0, 3 * tapblk, tapblk};
+        rc = dir_gemm_f32_grouped(&d, &g, w.wgt + (long long)(MG - PW - 1) * NE, w.gyp + (long long)MG * NCOUT, nullptr, w.dgt, stream);
         if (rc != DIR_OK) return rc;
     }
     // (3) part[(tap, hb)][(end, b)][c] = dgt block [2B][256] . w_g[tap][hb][c][:]^T

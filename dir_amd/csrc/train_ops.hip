@@ -113,6 +113,94 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
     }
 }
 
+// The same tile walk over GROUPS of displaced operands (dir_gemm_f32_grouped): group g = (gy, gx) of an ny x nx grid displaces A / B / C by
+// gy * *_y + gx * *_x elements (a convolution tap as a pointer shift: csrc/bonefuse_bwd.hip).  reduce = 0: blockIdx.z = batch * groups + g,
+// every group its own product (hundreds of co-resident workgroups instead of one launch per group with a wave per SIMD); reduce = 1: one
+// workgroup sums the groups' products in group order in its accumulators (one write of C instead of a read-modify-write per group).
+struct GemmGroups { int ny, nx, reduce; long long a_y, a_x, b_y, b_x, c_y, c_x; };
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmArgs a, GemmGroups gr) {
+    __shared__ float s_a[GT * MLD], s_b[GT * MLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+    const int ng = gr.ny * gr.nx;
+    const int bz = gr.reduce ? blockIdx.z : blockIdx.z / ng, g_own = gr.reduce ? 0 : blockIdx.z - bz * ng;
+    const float* A0 = a.A + bz * a.sA;
+    const float* B0 = a.B + bz * a.sB;
+    float* C = a.C + bz * a.sC;
+    if (!gr.reduce) { const int gy = g_own / gr.nx, gx = g_own - gy * gr.nx; C += gy * gr.c_y + gx * gr.c_x; }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4;
+    const int spg = (a.K + MK - 1) / MK, steps = gr.reduce ? spg * ng : spg;
+    float ra[8], rb[8];
+    unsigned oka = 0, okb = 0;
+    auto gload = [&](int t) {
+        const int gi = gr.reduce ? t / spg : 0, k0 = (t - gi * spg) * MK, g = gr.reduce ? gi : g_own;
+        const int gy = g / gr.nx, gx = g - gy * gr.nx;
+        const float* A = A0 + gy * gr.a_y + gx * gr.a_x;
+        const float* B = B0 + gy * gr.b_y + gx * gr.b_x;
+        oka = okb = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int r, k;
+            if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 31; r = e >> 5; }
+            const int m = m0 + r, kk = k0 + k;
+            oka |= (m < a.M && kk < a.K ? 1u : 0u) << i;
+            const int mc = min(m, a.M - 1), kc = min(kk, a.K - 1);
+            ra[i] = a.ta ? A[(long long)kc * a.lda + mc] : A[(long long)mc * a.lda + kc];
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 63; k2 = e >> 6; }
+            const int n = n0 + c, kb = k0 + k2;
+            okb |= (n < a.N && kb < a.K ? 1u : 0u) << i;
+            const int nc = min(n, a.N - 1), kbc = min(kb, a.K - 1);
+            rb[i] = a.tb ? B[(long long)nc * a.ldb + kbc] : B[(long long)kbc * a.ldb + nc];
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int r, k;
+            if (a.ta) { r = e & 63; k = e >> 6; } else { k = e & 31; r = e >> 5; }
+            s_a[r * MLD + k] = (oka >> i) & 1u ? ra[i] : 0.f;
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 63; k2 = e >> 6; }
+            s_b[c * MLD + k2] = (okb >> i) & 1u ? rb[i] : 0.f;
+        }
+    };
+    gload(0);
+    for (int t = 0; t < steps; ++t) {
+        lstore();
+        __syncthreads();
+        gload(min(t + 1, steps - 1));                    // the last step's operands again past the end (never stored)
+#pragma unroll
+        for (int ks = 0; ks < MK / 4; ++ks) {
+            const float av = s_a[(16 * wave + li) * MLD + 4 * ks + lk];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bv = s_b[(16 * j + li) * MLD + 4 * ks + lk];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 16 * j + li;
+        if (n >= a.N) continue;
+        const float bz_ = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 16 * wave + 4 * lk + r;
+            if (m >= a.M) continue;
+            float* p = C + (long long)m * a.ldc + n;
+            *p = a.accumulate ? *p + (acc[j][r] + bz_) : acc[j][r] + bz_;
+        }
+    }
+}
+
 // split-K second pass: C[m][n] = (accumulate ? C : 0) + (sum over the chunks IN ORDER of part[chunk][m][n]) + bias[n]   (deterministic)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* part, const float* bias, float* C, int M, int N, int ldc, int chunks, int accumulate) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1045,6 +1133,18 @@ extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float*
     GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c, 0, nullptr};
     DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, d->batch), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("dir_gemm_f32");
+}
+
+extern "C" int dir_gemm_f32_grouped(const dir_gemm_desc* d, const dir_gemm_groups* g, const float* A, const float* B, const float* bias, float* C, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(d && g && A && B && C, "dir_gemm_f32_grouped: null pointer");
+    DIR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->lda > 0 && d->ldb > 0 && d->ldc >= d->N, "dir_gemm_f32_grouped: bad shape");
+    DIR_REQUIRE(g->ny > 0 && g->nx > 0 && (long long)g->ny * g->nx * d->batch <= 65535, "dir_gemm_f32_grouped: groups %d x %d, batch %d", g->ny, g->nx, d->batch);
+    GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c, 0, nullptr};
+    GemmGroups gr{g->ny, g->nx, g->reduce ? 1 : 0, g->a_y, g->a_x, g->b_y, g->b_x, g->c_y, g->c_x};
+    const int z = g->reduce ? d->batch : d->batch * g->ny * g->nx;
+    DIR_LAUNCH(gemm_f32_grouped_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, z), dim3(256), 0, (hipStream_t)stream, a, gr);
+    return check_launch("dir_gemm_f32_grouped");
 }
 
 // Tall reductions with a small output (the weight gradients of the token path's Linear layers: gW [<= 384 x <= 256] = gy^T x over K = B * 21 .. 42

@@ -138,6 +138,16 @@ typedef struct dir_gemm_desc {
     int64_t stride_a, stride_b, stride_c;
 } dir_gemm_desc;
 int dir_gemm_f32(const dir_gemm_desc* desc_host, const float* A, const float* B, const float* bias, float* C, void* stream);
+/* dir_gemm_f32 over an ny x nx grid of GROUPS: group (gy, gx) displaces A, B and C by gy * *_y + gx * *_x elements -- a convolution tap
+ * as a pointer shift over a zero-bordered pixel grid (csrc/bonefuse_bwd.hip).  reduce = 0: every (batch entry, group) its own product in
+ * ONE launch (batch * ny * nx <= 65535); reduce = 1: C = sum over the groups (in group order, inside one workgroup) of the displaced
+ * products; c_y / c_x are ignored.  batch == 1 and one group: the same bits as dir_gemm_f32. */
+typedef struct dir_gemm_groups {
+    int32_t ny, nx, reduce, reserved;
+    int64_t a_y, a_x, b_y, b_x, c_y, c_x;
+} dir_gemm_groups;
+int dir_gemm_f32_grouped(const dir_gemm_desc* desc_host, const dir_gemm_groups* groups_host, const float* A, const float* B, const float* bias,
+                         float* C, void* stream);
 /* the same product (batch == 1) with the reduction cut into chunks of 64, one workgroup per (tile, chunk), partial tiles summed in chunk order by a
  * second launch (deterministic): for tall reductions with a small output -- the Linear weight gradients of the token path (K = rows = B * 21 .. 42).
  * Not bit-identical to dir_gemm_f32 (another summation order); workspace of dir_gemm_f32_splitk_workspace_bytes(d) bytes. */
