@@ -10,7 +10,7 @@
 //   (4) g W[tap][hb][c][n] = sum_b sum_end f_e[b][c] * g G[b,tap,e,n]
 // 24 GFLOP at 32 images and S = 32 instead of the 3 x 1.9 TFLOP of the materialised convolution's forward / data / weight gradients.
 //
-// All four are exact-fp32 GEMMs on dir_gemm_f32 (train_ops.hip) over operands laid out so that every tap is a POINTER SHIFT:
+// All four are exact-fp32 GEMMs on dir_gemm_f32 / dir_gemm_f32_grouped (train_ops.hip) over operands laid out so that every tap is a POINTER SHIFT:
 //   pixels live on the zero-bordered grid (S+2) x (S+2), flattened, with S+3 zero rows before and after (`R` rows per sample), so
 //   row q + (ky-1)*(S+2) + (kx-1) is the tap's neighbour of row q for every q, and the border rows carry the convolution's zero padding;
 //   G and g G are kept as [tap][e][b][n], so (tap, hand-bone) selects one contiguous [2B (end, b)][256] block for (3) and (4).
@@ -122,11 +122,11 @@ __global__ __launch_bounds__(64) void bone_uv_bwd_kernel(UvArgs a) {
     const float* uv = a.uv[hand] + (long long)b * 42;
     const float Ax = (uv[2 * ja] + 1.f) / 2.f * S, Ay = (uv[2 * ja + 1] + 1.f) / 2.f * S;
     const float Bx = (uv[2 * jb] + 1.f) / 2.f * S, By = (uv[2 * jb + 1] + 1.f) / 2.f * S;
-    const float2* gw = reinterpret_cast<const float2*>(a.dwgt + (long long)b * PP * NE) + hb;
+    const float* gw = a.dwgt + ((long long)b * NE + 2 * hb) * PP;             // rows (hb, end 0), (hb, end 1) of dwgt [B][80][PP]
     float gAx = 0.f, gAy = 0.f, gBx = 0.f, gBy = 0.f;
     for (int p = lane; p < S * S; p += 64) {
-        const int y = p / S, x = p - y * S;
-        const float2 g = gw[(long long)((y + 1) * PW + x + 1) * 40];       // requested before the mask is known (no dependent round trip)
+        const int y = p / S, x = p - y * S, q = (y + 1) * PW + x + 1;
+        const float2 g = make_float2(gw[q], gw[PP + q]);                         // requested before the mask is known (no dependent round trip)
         const float px = x + 0.5f, py = y + 0.5f;
         float wa, wb; bool in;
         dir::bone::bone_weights(px, py, Ax, Ay, Bx, By, a.distance, wa, wb, in);
@@ -222,11 +222,12 @@ extern "C" int dir_bone_fusion_backward(const float* w_g, const float* emb, cons
 
     const long long tapblk = (long long)NE * B * NCOUT;              // one tap of gt / dgt
     // tap (ky, kx) reads row q + off, off = (ky - 1) * PW + (kx - 1): a displacement of ky * PW + kx rows from the tap (0, 0) pointer
-    // (2) dwgt[b][q][e] = sum_tap gy_pad[b][q - off][:] . gt[tap][e][b][:]   -- the nine taps summed inside one workgroup
+    // (2) dwgt[b][e][q] = sum_tap gt[tap][e][b][:] . gy_pad[b][q - off][:]   -- the nine taps summed inside one workgroup; 80 rows (bone ends)
+    //     x pixels, so that the rows fill the short-output tile exactly and g uv reads its pixels contiguously
     {
-        dir_gemm_desc d{PP, NE, NCOUT, NCOUT, B * NCOUT, NE, 0, 1, 0, B, (long long)R * NCOUT, NCOUT, (long long)PP * NE};
-        dir_gemm_groups g{3, 3, 1, 0, -(long long)PW * NCOUT, -(long long)NCOUT, 3 * tapblk, tapblk, 0, 0};
-        rc = dir_gemm_f32_grouped(&d, &g, w.gyp + (long long)(MG + PW + 1) * NCOUT, w.gt, nullptr, w.dwgt, stream);
+        dir_gemm_desc d{NE, PP, NCOUT, B * NCOUT, NCOUT, PP, 0, 1, 0, B, NCOUT, (long long)R * NCOUT, (long long)NE * PP};
+        dir_gemm_groups g{3, 3, 1, 0, 3 * tapblk, tapblk, -(long long)PW * NCOUT, -(long long)NCOUT, 0, 0};
+        rc = dir_gemm_f32_grouped(&d, &g, w.gt, w.gyp + (long long)(MG + PW + 1) * NCOUT, nullptr, w.dwgt, stream);
         if (rc != DIR_OK) return rc;
     }
     // (1) dgt[tap][e][b][n] = sum_q wgt_pad[b][q + off][e] * gy_pad[b][q][n]   -- nine products per sample, one launch

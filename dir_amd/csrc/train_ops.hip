@@ -201,6 +201,105 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmArgs a, GemmG
     }
 }
 
+// Grouped walk for SHORT outputs: a tile of 16 * MB rows x 64 columns, the four waves split the columns (16 each) and every wave holds all MB
+// row blocks -- M = 80 (the bone fusion's 80 bone ends) fills an 80-row tile exactly; on the 64 x 64 tiles above it pays for 128 rows.
+template <int MB>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_short_kernel(GemmArgs a, GemmGroups gr) {
+    constexpr int TM = 16 * MB, NA = (TM * MK + 255) / 256;
+    __shared__ float s_a[TM * MLD], s_b[GT * MLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * GT;
+    const int ng = gr.ny * gr.nx;
+    const int bz = gr.reduce ? blockIdx.z : blockIdx.z / ng, g_own = gr.reduce ? 0 : blockIdx.z - bz * ng;
+    const float* A0 = a.A + bz * a.sA;
+    const float* B0 = a.B + bz * a.sB;
+    float* C = a.C + bz * a.sC;
+    if (!gr.reduce) { const int gy = g_own / gr.nx, gx = g_own - gy * gr.nx; C += gy * gr.c_y + gx * gr.c_x; }
+    f32x4 acc[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4;
+    const int spg = (a.K + MK - 1) / MK, steps = gr.reduce ? spg * ng : spg;
+    float ra[NA], rb[8];
+    unsigned oka = 0, okb = 0;
+    auto a_rk = [&](int e, int& r, int& k) { if (a.ta) { k = e / TM; r = e - k * TM; } else { k = e & 31; r = e >> 5; } };
+    auto gload = [&](int t) {
+        const int gi = gr.reduce ? t / spg : 0, k0 = (t - gi * spg) * MK, g = gr.reduce ? gi : g_own;
+        const int gy = g / gr.nx, gx = g - gy * gr.nx;
+        const float* A = A0 + gy * gr.a_y + gx * gr.a_x;
+        const float* B = B0 + gy * gr.b_y + gx * gr.b_x;
+        oka = okb = 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = min(tid + 256 * i, TM * MK - 1);
+            int r, k;
+            a_rk(e, r, k);
+            const int m = m0 + r, kk = k0 + k;
+            oka |= (m < a.M && kk < a.K ? 1u : 0u) << i;
+            const int mc = min(m, a.M - 1), kc = min(kk, a.K - 1);
+            ra[i] = a.ta ? A[(long long)kc * a.lda + mc] : A[(long long)mc * a.lda + kc];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 63; k2 = e >> 6; }
+            const int n = n0 + c, kb = k0 + k2;
+            okb |= (n < a.N && kb < a.K ? 1u : 0u) << i;
+            const int nc = min(n, a.N - 1), kbc = min(kb, a.K - 1);
+            rb[i] = a.tb ? B[(long long)nc * a.ldb + kbc] : B[(long long)kbc * a.ldb + nc];
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            if (e < TM * MK) {
+                int r, k;
+                a_rk(e, r, k);
+                s_a[r * MLD + k] = (oka >> i) & 1u ? ra[i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + 256 * i;
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 63; k2 = e >> 6; }
+            s_b[c * MLD + k2] = (okb >> i) & 1u ? rb[i] : 0.f;
+        }
+    };
+    gload(0);
+    for (int t = 0; t < steps; ++t) {
+        lstore();
+        __syncthreads();
+        gload(min(t + 1, steps - 1));
+#pragma unroll
+        for (int ks = 0; ks < MK / 4; ++ks) {
+            const float bv = s_b[(16 * wave + li) * MLD + 4 * ks + lk];
+#pragma unroll
+            for (int j = 0; j < MB; ++j) {
+                const float av = s_a[(16 * j + li) * MLD + 4 * ks + lk];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D layout: lane holds column n0 + 16 wave + li, rows m0 + 16 j + 4 lk + r
+    const int n = n0 + 16 * wave + li;
+    if (n < a.N) {
+        const float bz_ = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int j = 0; j < MB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 16 * j + 4 * lk + r;
+                if (m >= a.M) continue;
+                float* p = C + (long long)m * a.ldc + n;
+                *p = a.accumulate ? *p + (acc[j][r] + bz_) : acc[j][r] + bz_;
+            }
+    }
+}
+
 // split-K second pass: C[m][n] = (accumulate ? C : 0) + (sum over the chunks IN ORDER of part[chunk][m][n]) + bias[n]   (deterministic)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* part, const float* bias, float* C, int M, int N, int ldc, int chunks, int accumulate) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1143,7 +1242,10 @@ extern "C" int dir_gemm_f32_grouped(const dir_gemm_desc* d, const dir_gemm_group
     GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c, 0, nullptr};
     GemmGroups gr{g->ny, g->nx, g->reduce ? 1 : 0, g->a_y, g->a_x, g->b_y, g->b_x, g->c_y, g->c_x};
     const int z = g->reduce ? d->batch : d->batch * g->ny * g->nx;
-    DIR_LAUNCH(gemm_f32_grouped_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, z), dim3(256), 0, (hipStream_t)stream, a, gr);
+    if (d->M > 64 && d->M <= 80)          // one 80-row tile instead of two 64-row ones (other summation-independent layout: the same k order per element)
+        DIR_LAUNCH(gemm_f32_grouped_short_kernel<5>, dim3((d->N + GT - 1) / GT, 1, z), dim3(256), 0, (hipStream_t)stream, a, gr);
+    else
+        DIR_LAUNCH(gemm_f32_grouped_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, z), dim3(256), 0, (hipStream_t)stream, a, gr);
     return check_launch("dir_gemm_f32_grouped");
 }
 

@@ -3,7 +3,7 @@ dir_attention_*, dir_bn_train_*).  Plumbing only: shapes, strides, output alloca
 import torch
 
 from .. import _capi
-from .._capi import GemmDesc
+from .._capi import GemmDesc, GemmGroups
 
 F32 = torch.float32
 
@@ -206,6 +206,19 @@ def gemm_strided(A, B, C, M, N, K, lda, ldb, ldc, ta=False, tb=False, batch=1, s
                     'dir_gemm_f32_splitk')
         return C
     _capi.check(_capi.lib().dir_gemm_f32(d, p(A, a_off), p(B, b_off), _capi.ptr(bias), p(C, c_off), _capi.stream_ptr()), 'dir_gemm_f32')
+    return C
+
+
+def gemm_grouped(A, B, C, M, N, K, lda, ldb, ldc, groups, disp_a, disp_b, disp_c=(0, 0), reduce=False, ta=False, tb=False, batch=1, sa=0, sb=0, sc=0,
+                 a_off=0, b_off=0, c_off=0):
+    """dir_gemm_f32_grouped: an ny x nx grid of products whose operands (and, unless reduce, results) are displaced by gy * disp[0] + gx * disp[1]
+    elements; reduce: C = the sum of the groups' products"""
+    import ctypes as Ct
+    _chk(A, B, C)
+    d = GemmDesc(M, N, K, lda, ldb, ldc, int(ta), int(tb), 0, batch, sa, sb, sc)
+    g = GemmGroups(groups[0], groups[1], int(reduce), 0, disp_a[0], disp_a[1], disp_b[0], disp_b[1], disp_c[0], disp_c[1])
+    p = lambda t, off: Ct.c_void_p(t.data_ptr() + 4 * off)  # noqa: E731
+    _capi.check(_capi.lib().dir_gemm_f32_grouped(d, g, p(A, a_off), p(B, b_off), None, p(C, c_off), _capi.stream_ptr()), 'dir_gemm_f32_grouped')
     return C
 
 

@@ -231,3 +231,30 @@ def test_axpy_multi_matches_per_tensor_axpy():
     O.axpy_multi(dsts, srcs, 0.25)
     for d, w_ in zip(dsts, want):
         assert float((d - w_).abs().max()) <= 2.4e-7 * float(w_.abs().max())            # (the kernel's multiply-add is fused)
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(80, 150, 70, True, False), (80, 130, 64, False, True), (100, 70, 45, False, True), (37, 64, 33, True, False)])
+def test_gemm_grouped_equals_one_call_per_group(M, N, K, ta, tb):
+    """dir_gemm_f32_grouped (taps as pointer shifts, csrc/bonefuse_bwd.hip): independent groups = the same bits as one dir_gemm_f32 call per group
+    (the same k order per element on the 64 x 64 and on the 80-row tiles); reduced groups = their sum (another association: 5e-6 of the largest sum)."""
+    torch.manual_seed(M + N + K)
+    batch, ny, nx = 3, 3, 3
+    ra, ca = (K, M) if ta else (M, K)
+    rb, cb = (N, K) if tb else (K, N)
+    pa, pb = 5, 7                                                  # row displacement per gy step; gx steps one row
+    A = torch.randn(batch, ra + pa * ny + nx, ca, device='cuda')
+    Bm = torch.randn(batch, rb + pb * ny + nx, cb, device='cuda')
+    sa, sb = A[0].numel(), Bm[0].numel()
+    ref = torch.empty(batch, ny * nx, M, N, device='cuda')
+    for g in range(ny * nx):
+        gy, gx = divmod(g, nx)
+        O.gemm_strided(A, Bm, ref, M, N, K, ca, cb, N, ta=ta, tb=tb, batch=batch, sa=sa, sb=sb, sc=ny * nx * M * N,
+                       a_off=(gy * pa + gx) * ca, b_off=(gy * pb + gx) * cb, c_off=g * M * N)
+    out = torch.full_like(ref, float('nan'))
+    O.gemm_grouped(A, Bm, out, M, N, K, ca, cb, N, (ny, nx), (pa * ca, ca), (pb * cb, cb), (nx * M * N, M * N), ta=ta, tb=tb, batch=batch, sa=sa, sb=sb,
+                   sc=ny * nx * M * N)
+    assert torch.equal(out, ref)
+    red = torch.full((batch, M, N), float('nan'), device='cuda')
+    O.gemm_grouped(A, Bm, red, M, N, K, ca, cb, N, (ny, nx), (pa * ca, ca), (pb * cb, cb), reduce=True, ta=ta, tb=tb, batch=batch, sa=sa, sb=sb, sc=M * N)
+    want = ref.double().sum(1)
+    assert float((red.double() - want).abs().max() / want.abs().max()) < 5e-6
