@@ -39,8 +39,7 @@ def bn_bwd(P, pre, saved, gy, G, relu=False):
 def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None):
     """add_gx: another gradient of x, summed into gx in the data-gradient convolution's epilogue"""
     has_bias = (key + 'bias') in P
-    gx, gw, gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx)
-    G[key + 'weight'] = _oihw(gw)
+    gx, G[key + 'weight'], gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx, gw_oihw=True)
     if has_bias:
         G[key + 'bias'] = gb
     return gx

@@ -39,6 +39,51 @@ HEADROOM = 64.0             # pow2_in_scale puts the largest |operand| in [2^9, 
 # an owner (owner=None: direct calls of dir_amd.train.net.forward) nothing is cached: every convolution measures its scale on what it is given.
 _scales, _state = [], {'call': 0, 'step': 0, 'cached': False}
 
+# Weight gradients on a SIDE STREAM (round 4, measured, OFF by default: DIR_TRAIN_SIDE_WGRAD=1 switches it on).  Nothing in the backward pass
+# waits for a convolution's weight gradient -- only the optimiser does -- so inside dir_amd.train.net.backward (side_begin .. side_end) conv_bwd
+# can issue it (and its OIHW copy, and the gradient moves into the flat bucket) on a second stream behind an event of the compute stream,
+# which waits once at the end.  Same kernels on the same operands: bit-identical (the whole-step tests pass with it on).  It buys NOTHING at
+# 32 images: 0.032 s per step with and without at equal stream priority -- the two streams share the compute units evenly while the data
+# gradients run and the side stream is empty again by the time the joint-token path (the under-occupied part) starts; at the device's
+# lowest stream priority (hipStreamCreateWithPriority) the step is SLOWER and erratic, 0.033-0.039 s.  Off while a HIP graph is captured.
+SIDE_WGRAD = os.environ.get('DIR_TRAIN_SIDE_WGRAD', '0') == '1'
+_side = {'streams': {}, 'active': None}
+
+
+def side_begin():
+    """-> the side stream for this backward pass, or None (switched off / graph capture)"""
+    _side['active'] = None
+    if not SIDE_WGRAD or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return None
+    dev = torch.cuda.current_device()
+    st = _side['streams'].get(dev)
+    if st is None:
+        st = _side['streams'][dev] = torch.cuda.Stream(device=dev)
+    st.wait_stream(torch.cuda.current_stream())
+    _side['active'] = st
+    return st
+
+
+def side_run(fn, *reads):
+    """fn() on the side stream once everything the compute stream has issued so far is done; `reads`: tensors of the compute stream's
+    allocator that fn reads (kept from re-use until the side stream is through with them)"""
+    st = _side['active']
+    if st is None:
+        return fn()
+    st.wait_event(torch.cuda.current_stream().record_event())
+    with torch.cuda.stream(st):
+        out = fn()
+    for t in reads:
+        if t is not None:
+            t.record_stream(st)
+    return out
+
+
+def side_end():
+    st, _side['active'] = _side['active'], None
+    if st is not None:
+        torch.cuda.current_stream().wait_stream(st)
+
 
 class _Packed:
     """one convolution weight's two packed operand forms inside a WeightPack (views of its buffers)"""
@@ -309,11 +354,16 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     return out
 
 
-def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None):
-    """-> (gx (+ add_gx), gw [Cout,kh,kw,Cin], gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd)"""
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False):
+    """-> (gx (+ add_gx), gw [Cout,kh,kw,Cin] ([Cout,Cin,kh,kw] with gw_oihw), gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd).
+    Inside a backward pass (side_begin) gw is produced on the side stream: valid on the compute stream after side_end."""
     gy = gy.contiguous()
     shape = (w.shape[0], w.shape[2], w.shape[3], w.shape[1]) if oihw else w.shape
-    gw = conv_wgrad(x, gy, shape, stride, pad)
+
+    def wgrad():
+        g = conv_wgrad(x, gy, shape, stride, pad)
+        return g.permute(0, 3, 1, 2).contiguous() if gw_oihw else g
+    gw = side_run(wgrad, x, gy)
     gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None
     gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw, add=add_gx) if need_gx else None
     return gx, gw, gb

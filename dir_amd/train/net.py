@@ -252,8 +252,12 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
     (each parameter's gradient is written once, after all its uses), which lets the caller move gradients into the data-parallel
     bucket and start its all-reduce while the rest of the backward pass runs (dir_amd/train/step.py)."""
     G = {}
+    side = TC.side_begin()                                  # convolution weight gradients on a second stream (dir_amd/train/conv.py)
     if flush is None:
         flush = lambda g: None      # noqa: E731
+    elif side is not None:
+        caller_flush = flush
+        flush = lambda g: TC.side_run(lambda: caller_flush(g))      # noqa: E731  (the moves into the bucket follow the weight gradients on their stream)
     w_dense, w_stage = _term_weights(grad_out, len(outs) - 1)
     B = ctx['img'].shape[0]
     c1, c2, c3, c4 = ctx['feats']
@@ -332,5 +336,6 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
     img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
     G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
     flush(G)
+    TC.side_end()
     TC.end_step()
     return G
