@@ -258,3 +258,19 @@ def test_gemm_grouped_equals_one_call_per_group(M, N, K, ta, tb):
     O.gemm_grouped(A, Bm, red, M, N, K, ca, cb, N, (ny, nx), (pa * ca, ca), (pb * cb, cb), reduce=True, ta=ta, tb=tb, batch=batch, sa=sa, sb=sb, sc=M * N)
     want = ref.double().sum(1)
     assert float((red.double() - want).abs().max() / want.abs().max()) < 5e-6
+
+
+@pytest.mark.parametrize('M,N,K,batch,ta,tb', [(32, 128, 128, 21, False, True), (150, 130, 384, 1, False, False), (64, 128, 100, 3, True, False),
+                                               (70, 64, 257, 2, True, True)])
+def test_gemm_grouped_with_one_group_gives_the_bits_of_gemm(M, N, K, batch, ta, tb):
+    """include/dir_hip.h: "one group: the same bits as dir_gemm_f32" (the same tiles, the same k order per element)"""
+    torch.manual_seed(K)
+    A = torch.randn(batch, *((K, M) if ta else (M, K)), device='cuda')
+    Bm = torch.randn(batch, *((N, K) if tb else (K, N)), device='cuda')
+    c1 = torch.full((batch, M, N), float('nan'), device='cuda')
+    c2 = torch.full((batch, M, N), float('nan'), device='cuda')
+    O.gemm_strided(A, Bm, c1, M, N, K, A.shape[2], Bm.shape[2], N, ta=ta, tb=tb, batch=batch, sa=A[0].numel(), sb=Bm[0].numel(), sc=M * N)
+    O.gemm_grouped(A, Bm, c2, M, N, K, A.shape[2], Bm.shape[2], N, (1, 1), (0, 0), (0, 0), ta=ta, tb=tb, batch=batch, sa=A[0].numel(), sb=Bm[0].numel(), sc=M * N)
+    assert torch.equal(c1, c2)
+    ref = (A.double().transpose(1, 2) if ta else A.double()) @ (Bm.double().transpose(1, 2) if tb else Bm.double())
+    assert float((c1.double() - ref).abs().max() / ref.abs().max()) < 1e-5
