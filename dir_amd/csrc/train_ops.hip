@@ -13,6 +13,7 @@
 #include "dir_mfma.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <initializer_list>
 
 namespace {
@@ -109,6 +110,81 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
             if (split) { a.part[((long long)blockIdx.z * a.M + m) * a.N + n] = acc[j][r]; continue; }
             float* p = C + (long long)m * a.ldc + n;
             *p = a.accumulate ? *p + (acc[j][r] + bz) : acc[j][r] + bz;
+        }
+    }
+}
+
+// gemm_f32_kernel on 32 x 32 tiles (a wave owns ONE 16 x 16 block) for the products whose 64 x 64 grid leaves most of the GPU empty -- the
+// joint-token path: 317 launches per training step on 2 .. 126 workgroups.  There a K step is a serial chain inside each wave (8 x (5 LDS
+// reads -> 4 MFMAs): ~1.3 us, measured; requesting more K at once does not shorten it), so the time goes down with the work per WAVE: a
+// quarter of the MFMAs and a third of the LDS reads per step, four times the workgroups.  Same k order per element: the same bits.
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(GemmArgs a) {
+    constexpr int ST = 32;
+    __shared__ float s_a[ST * MLD], s_b[ST * MLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
+    const bool split = a.part != nullptr;                  // dir_gemm_f32_splitk: blockIdx.z = K chunk, raw partial tiles to part [chunk][M][N]
+    const float* A = a.A + (split ? 0 : blockIdx.z * a.sA);
+    const float* B = a.B + (split ? 0 : blockIdx.z * a.sB);
+    float* C = a.C + (split ? 0 : blockIdx.z * a.sC);
+    const int kbeg = split ? blockIdx.z * a.kchunk : 0, kend = split ? min(a.K, kbeg + a.kchunk) : a.K;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lk = lane >> 4, wr = 16 * (wave >> 1), wc = 16 * (wave & 1);
+    float ra[4], rb[4];
+    unsigned oka = 0, okb = 0;
+    auto gload = [&](int k0) {
+        oka = okb = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            int r, k;
+            if (a.ta) { r = e & 31; k = e >> 5; } else { k = e & 31; r = e >> 5; }
+            const int m = m0 + r, kk = k0 + k;
+            oka |= (m < a.M && kk < kend ? 1u : 0u) << i;
+            const int mc = min(m, a.M - 1), kc = min(kk, kend - 1);
+            ra[i] = a.ta ? A[(long long)kc * a.lda + mc] : A[(long long)mc * a.lda + kc];
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 31; k2 = e >> 5; }
+            const int n = n0 + c, kb = k0 + k2;
+            okb |= (n < a.N && kb < kend ? 1u : 0u) << i;
+            const int nc = min(n, a.N - 1), kbc = min(kb, kend - 1);
+            rb[i] = a.tb ? B[(long long)nc * a.ldb + kbc] : B[(long long)kbc * a.ldb + nc];
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            int r, k;
+            if (a.ta) { r = e & 31; k = e >> 5; } else { k = e & 31; r = e >> 5; }
+            s_a[r * MLD + k] = (oka >> i) & 1u ? ra[i] : 0.f;
+            int c, k2;
+            if (a.tb) { k2 = e & 31; c = e >> 5; } else { c = e & 31; k2 = e >> 5; }
+            s_b[c * MLD + k2] = (okb >> i) & 1u ? rb[i] : 0.f;
+        }
+    };
+    gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += MK) {
+        lstore();
+        __syncthreads();
+        gload(min(k0 + MK, kend - 1));
+        float av[MK / 4], bv[MK / 4];
+#pragma unroll
+        for (int ks = 0; ks < MK / 4; ++ks) { av[ks] = s_a[(wr + li) * MLD + 4 * ks + lk]; bv[ks] = s_b[(wc + li) * MLD + 4 * ks + lk]; }
+#pragma unroll
+        for (int ks = 0; ks < MK / 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = n0 + wc + li;
+    if (n < a.N) {
+        const float bz = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wr + 4 * lk + r;
+            if (m >= a.M) continue;
+            if (split) { a.part[((long long)blockIdx.z * a.M + m) * a.N + n] = acc[r]; continue; }
+            float* p = C + (long long)m * a.ldc + n;
+            *p = a.accumulate ? *p + (acc[r] + bz) : acc[r] + bz;
         }
     }
 }
@@ -1230,7 +1306,12 @@ extern "C" int dir_gemm_f32(const dir_gemm_desc* d, const float* A, const float*
     DIR_REQUIRE(d && A && B && C, "dir_gemm_f32: null pointer");
     DIR_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch > 0 && d->lda > 0 && d->ldb > 0 && d->ldc >= d->N, "dir_gemm_f32: bad shape");
     GemmArgs a{A, B, bias, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, d->accumulate, d->stride_a, d->stride_b, d->stride_c, 0, nullptr};
-    DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, d->batch), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, d->batch);
+    static const bool small = []() { const char* e = getenv("DIR_GEMM_SMALL"); return !(e && e[0] == '0'); }();
+    if (small && (long long)grid.x * grid.y * grid.z <= 128)           // the 64 x 64 grid fills at most half the CUs: 32 x 32 tiles (same bits)
+        DIR_LAUNCH(gemm_f32_small_kernel, dim3((d->N + 31) / 32, (d->M + 31) / 32, d->batch), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        DIR_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("dir_gemm_f32");
 }
 
@@ -1267,7 +1348,11 @@ extern "C" int dir_gemm_f32_splitk(const dir_gemm_desc* d, const float* A, const
     const int chunks = (d->K + GEMM_SPLIT_CHUNK - 1) / GEMM_SPLIT_CHUNK;
     GemmArgs a{A, B, nullptr, C, d->M, d->N, d->K, d->lda, d->ldb, d->ldc, d->trans_a, d->trans_b, 0, 0, 0, 0, GEMM_SPLIT_CHUNK, workspace};
     hipStream_t s = (hipStream_t)stream;
-    DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, chunks), dim3(256), 0, s, a);
+    static const bool small = []() { const char* e = getenv("DIR_GEMM_SMALL"); return !(e && e[0] == '0'); }();
+    if (small && (long long)((d->N + GT - 1) / GT) * ((d->M + GT - 1) / GT) * chunks <= 128)
+        DIR_LAUNCH(gemm_f32_small_kernel, dim3((d->N + 31) / 32, (d->M + 31) / 32, chunks), dim3(256), 0, s, a);
+    else
+        DIR_LAUNCH(gemm_f32_kernel, dim3((d->N + GT - 1) / GT, (d->M + GT - 1) / GT, chunks), dim3(256), 0, s, a);
     DIR_LAUNCH(gemm_splitk_reduce_kernel, dim3((unsigned)(((long long)d->M * d->N + 255) / 256)), dim3(256), 0, s, (const float*)workspace, bias, C, d->M, d->N,
                d->ldc, chunks, d->accumulate);
     return check_launch("dir_gemm_f32_splitk");

@@ -147,7 +147,8 @@ def forward(P, img, keep=None, scale_owner=None):
     model's cache of split-precision operand scales across steps (train_step passes the optimizer, DIR.forward the module); None = every
     convolution measures its scale on this batch (a host synchronisation per call site: tests, one-off evaluations)"""
     keep = [] if keep is None else keep
-    TC.begin_step(scale_owner, P)                                               # operand-scale cache of THIS model (dir_amd/train/conv.py)
+    # operand-scale cache and one-launch weight packing of THIS model (dir_amd/train/conv.py); the factorised fusion reads fusion.0.weight itself
+    TC.begin_step(scale_owner, {k: v for k, v in P.items() if not k.endswith('fusion.0.weight')} if FACTORISED_FUSION else P)
     B = img.shape[0]
     dev = img.device
     ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)

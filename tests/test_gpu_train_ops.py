@@ -24,7 +24,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('M,N,K,ta,tb', [(126, 384, 128, 0, 1), (384, 128, 126, 1, 0), (126, 128, 384, 0, 0), (1, 5376, 3, 0, 0), (70, 65, 17, 1, 1),
-                                        (2688, 256, 128, 0, 1)])
+                                        (2688, 256, 128, 0, 1), (128, 128, 672, 1, 0), (130, 3, 1344, 1, 0), (384, 128, 1344, 1, 0), (32, 64, 2050, 0, 1)])
 def test_gemm(M, N, K, ta, tb):
     rng = np.random.RandomState(M + N)
     A = rng.normal(0, 1, (K, M) if ta else (M, K)).astype(np.float32)
