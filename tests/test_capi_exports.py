@@ -69,3 +69,23 @@ def test_launch_log_counter_saturates_instead_of_overflowing():
     assert lib.dir_launch_log_get(buf, 4096) == 2 ** 31 - 1
     lib.dir_launch_log_reset()
     assert lib.dir_launch_log_get(buf, 4096) == 0 and buf.value == b''
+
+
+def test_bone_fusion_backward_host_side_contract():
+    """round 4 entry points, host side only (no launch): the workspace size is a pure function of (B, S) that rejects nonsense, and the
+    argument checks of dir_bone_fusion_backward / dir_gemm_f32_grouped fail with DIR_E_INVALID before anything touches a device"""
+    import torch  # noqa: F401
+    from dir_amd import _capi
+    L = _capi.lib()
+    assert L.dir_bone_fusion_backward_workspace_bytes(0, 32) == -1 and L.dir_bone_fusion_backward_workspace_bytes(4, 0) == -1
+    n16, n32 = L.dir_bone_fusion_backward_workspace_bytes(32, 16), L.dir_bone_fusion_backward_workspace_bytes(32, 32)
+    assert 0 < n16 < n32 < (1 << 30) and n32 % 256 == 0
+    assert L.dir_bone_fusion_backward_workspace_bytes(64, 32) > n32
+    # the padded grids alone: wgt [B][R][80] + gy [B][R][256] floats, R = (S+2)^2 + 2 (S+3)
+    assert n32 >= 32 * ((34 * 34 + 70) * (80 + 256)) * 4
+    rc = L.dir_bone_fusion_backward(None, None, None, None, None, None, 2.0, None, None, None, None, None, 0, 32, 32, None)
+    assert rc != 0 and b'null pointer' in L.dir_last_error()
+    d = _capi.GemmDesc(80, 64, 32, 80, 64, 64, 1, 0, 0, 70000, 0, 0, 0)
+    g = _capi.GemmGroups(3, 3, 0, 0, 0, 0, 0, 0, 0, 0)
+    one = ctypes.c_void_p(16)
+    assert L.dir_gemm_f32_grouped(d, g, one, one, None, one, None) != 0 and b'groups' in L.dir_last_error()      # batch * groups > 65535
