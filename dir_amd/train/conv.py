@@ -47,13 +47,14 @@ _scales, _state = [], {'call': 0, 'step': 0, 'cached': False}
 # gradients run and the side stream is empty again by the time the joint-token path (the under-occupied part) starts; at the device's
 # lowest stream priority (hipStreamCreateWithPriority) the step is SLOWER and erratic, 0.033-0.039 s.  Off while a HIP graph is captured.
 SIDE_WGRAD = os.environ.get('DIR_TRAIN_SIDE_WGRAD', '0') == '1'
+SIDE_IN_CAPTURE = os.environ.get('DIR_TRAIN_SIDE_IN_CAPTURE', '0') == '1'      # experiment: the side stream as a parallel branch of the captured graph
 _side = {'streams': {}, 'active': None}
 
 
 def side_begin():
     """-> the side stream for this backward pass, or None (switched off / graph capture)"""
     _side['active'] = None
-    if not SIDE_WGRAD or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+    if not SIDE_WGRAD or not torch.cuda.is_available() or (torch.cuda.is_current_stream_capturing() and not SIDE_IN_CAPTURE):
         return None
     dev = torch.cuda.current_device()
     st = _side['streams'].get(dev)
