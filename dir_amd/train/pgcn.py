@@ -28,8 +28,8 @@ def pgcn_forward(P, x, num_layers=4, momentum=0.1, eps=1e-5):
         z = h0.clone()
         # z[b] += A_1 h1[b] + bias: per sample [21,21] x [21,128]
         O.gemm_strided(A1, h1, z, NJ, C, NJ, NJ, C, C, batch=B, sa=0, sb=NJ * C, sc=NJ * C, bias=P[p + 'gconv.bias'], accumulate=True)
-        zn, st = O.bn_train_fwd(z.view(B * NJ, C), P[p + 'bn.weight'], P[p + 'bn.bias'], P.get(p + 'bn.running_mean'), P.get(p + 'bn.running_var'), eps, momentum)
-        y = O.relu_fwd(zn)
+        # BatchNorm1d + ReLU in one launch; the backward re-computes the mask from z (dir_bn_train_backward(relu))
+        y, st = O.bn_train_fwd(z.view(B * NJ, C), P[p + 'bn.weight'], P[p + 'bn.bias'], P.get(p + 'bn.running_mean'), P.get(p + 'bn.running_var'), eps, momentum, relu=True)
         ctx['layers'].append(dict(x=cur, h1=h1, A1=A1, z=z, st=st, y=y))
         cur = y.view(B, NJ, C)
     return cur, ctx
@@ -41,8 +41,7 @@ def pgcn_backward(P, ctx, gy):
     g = gy.contiguous().view(B * NJ, C)
     for l in range(len(ctx['layers']) - 1, -1, -1):
         p, s = 'gconv_layers.%d.' % l, ctx['layers'][l]
-        gzn = O.relu_bwd(g, s['y'])
-        gz, G[p + 'bn.weight'], G[p + 'bn.bias'] = O.bn_train_bwd(gzn, s['z'].view(B * NJ, C), P[p + 'bn.weight'], s['st'])
+        gz, G[p + 'bn.weight'], G[p + 'bn.bias'] = O.bn_train_bwd(g.contiguous(), s['z'].view(B * NJ, C), P[p + 'bn.weight'], s['st'], b=P[p + 'bn.bias'], relu=True)
         G[p + 'gconv.bias'] = O.colsum(gz)
         gz3 = gz.view(B, NJ, C)
         e1 = P[p + 'gconv.e_1'].reshape(-1).contiguous()

@@ -39,8 +39,7 @@ def _w2(P, key):
 def mlp_forward(P, pre, x, out=None, accumulate=False, momentum=0.1, eps=1e-5):
     """Sequential(Conv1d k=1, BatchNorm1d (batch statistics), ReLU, Conv1d k=1) on token rows x [R, Cin] -> ([R, Cout], ctx)"""
     h = O.linear_fwd(x, _w2(P, pre + '0.weight'), P[pre + '0.bias'])
-    hn, st = O.bn_train_fwd(h, P[pre + '1.weight'], P[pre + '1.bias'], P.get(pre + '1.running_mean'), P.get(pre + '1.running_var'), eps, momentum)
-    a = O.relu_fwd(hn)
+    a, st = O.bn_train_fwd(h, P[pre + '1.weight'], P[pre + '1.bias'], P.get(pre + '1.running_mean'), P.get(pre + '1.running_var'), eps, momentum, relu=True)
     y = O.linear_fwd(a, _w2(P, pre + '3.weight'), P[pre + '3.bias'], out=out, accumulate=accumulate)
     return y, dict(x=x, h=h, st=st, a=a)
 
@@ -51,8 +50,7 @@ def mlp_backward(P, pre, ctx, gy, G, need_gx=False):
     w3, w0 = P[pre + '3.weight'], P[pre + '0.weight']
     ga, gW3, gb3 = O.linear_bwd(gy, ctx['a'], _w2(P, pre + '3.weight'),
                                 gW=G[pre + '3.weight'].view(w3.shape[0], -1) if acc else None, gb=G.get(pre + '3.bias'), accumulate=acc)
-    ghn = O.relu_bwd(ga, ctx['a'])
-    gh, gw, gb = O.bn_train_bwd(ghn, ctx['h'], P[pre + '1.weight'], ctx['st'])
+    gh, gw, gb = O.bn_train_bwd(ga, ctx['h'], P[pre + '1.weight'], ctx['st'], b=P[pre + '1.bias'], relu=True)     # BatchNorm1d + ReLU undone in one call (mask from h)
     gx, gW0, gb0 = O.linear_bwd(gh, ctx['x'], _w2(P, pre + '0.weight'),
                                 gW=G[pre + '0.weight'].view(w0.shape[0], -1) if acc else None, gb=G.get(pre + '0.bias'), accumulate=acc, need_gx=need_gx)
     if acc:
@@ -92,8 +90,7 @@ def stage_tokens_forward(P, mano_tables_lr, feat_nhwc, prev):
         pre = 'global_pos_emb.'
         g_in = (gpos_l, gpos_r)[h]
         hh = O.linear_fwd(g_in, _w2(P, pre + '0.weight'), P[pre + '0.bias'])
-        hn, st = O.bn_train_fwd(hh, P[pre + '1.weight'], P[pre + '1.bias'], P.get(pre + '1.running_mean'), P.get(pre + '1.running_var'))
-        a = O.relu_fwd(hn)
+        a, st = O.bn_train_fwd(hh, P[pre + '1.weight'], P[pre + '1.bias'], P.get(pre + '1.running_mean'), P.get(pre + '1.running_var'), relu=True)
         O.gemm_strided(a, _w2(P, pre + '3.weight'), cat, NJ, EMB, EMB, EMB, EMB, EMB, tb=True, batch=B, sa=NJ * EMB, sb=0, sc=2 * NJ * EMB,
                        c_off=h * NJ * EMB, bias=P[pre + '3.bias'], accumulate=True)
         ctx['hand'].append(dict(img=c_img, pos=c_pos, gcn=c_gcn, gpos=dict(x=g_in, h=hh, st=st, a=a)))
