@@ -12,6 +12,16 @@ import torch
 from . import ops as O
 
 NJ, C = 21, 128
+_ZEROS = {}
+
+
+def _zeros_like(t):
+    """a shared all-zero gradient (read-only by contract: gradients in G are only ever read) instead of a fill launch per layer and hand"""
+    key = (tuple(t.shape), t.device)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros_like(t)
+    return z
 
 
 def pgcn_forward(P, x, num_layers=4, momentum=0.1, eps=1e-5):
@@ -21,11 +31,10 @@ def pgcn_forward(P, x, num_layers=4, momentum=0.1, eps=1e-5):
     for l in range(num_layers):
         p = 'gconv_layers.%d.' % l
         W = P[p + 'gconv.W']
-        h0, h1 = torch.empty(B, NJ, C, device=x.device), torch.empty(B, NJ, C, device=x.device)
-        for k, h in enumerate((h0, h1)):                 # per node j: [B,128] (pitch 21*128, offset 128 j) x W_k[j] [128,128]
+        z, h1 = torch.empty(B, NJ, C, device=x.device), torch.empty(B, NJ, C, device=x.device)      # h0 is written straight into z
+        for k, h in enumerate((z, h1)):                  # per node j: [B,128] (pitch 21*128, offset 128 j) x W_k[j] [128,128]
             O.gemm_strided(cur, W, h, B, C, C, NJ * C, C, NJ * C, batch=NJ, sa=C, sb=C * C, sc=C, b_off=k * NJ * C * C)
         A1 = O.pgcn_adjacency(P[p + 'gconv.e_1'].reshape(-1).contiguous())
-        z = h0.clone()
         # z[b] += A_1 h1[b] + bias: per sample [21,21] x [21,128]
         O.gemm_strided(A1, h1, z, NJ, C, NJ, NJ, C, C, batch=B, sa=0, sb=NJ * C, sc=NJ * C, bias=P[p + 'gconv.bias'], accumulate=True)
         # BatchNorm1d + ReLU in one launch; the backward re-computes the mask from z (dir_bn_train_backward(relu))
@@ -46,7 +55,7 @@ def pgcn_backward(P, ctx, gy):
         gz3 = gz.view(B, NJ, C)
         e1 = P[p + 'gconv.e_1'].reshape(-1).contiguous()
         G[p + 'gconv.e_1'] = O.pgcn_adjacency_bwd(e1, gz3, s['h1']).view_as(P[p + 'gconv.e_1'])
-        G[p + 'gconv.e_0'] = torch.zeros_like(P[p + 'gconv.e_0'])
+        G[p + 'gconv.e_0'] = _zeros_like(P[p + 'gconv.e_0'])
         gh1 = torch.empty(B, NJ, C, device=gz.device)          # g h1[b] = A_1^T g z[b]
         O.gemm_strided(s['A1'], gz3, gh1, NJ, C, NJ, NJ, C, C, ta=True, batch=B, sa=0, sb=NJ * C, sc=NJ * C)
         W = P[p + 'gconv.W']
