@@ -132,7 +132,9 @@ int dir_regress_backward(const float* w_left, const float* w_right, const float*
 /* C[b] (+)= op(A[b]) op(B[b]) (+ bias[n]):  op(X) = X or X^T; row-major, leading dimensions in elements, `batch` problems
  * `stride_*` elements apart.  trans_a = 0: A is [M][K]; 1: A is [K][M].  trans_b = 0: B is [K][N]; 1: B is [N][K] (nn.Linear weight).
  * accumulate != 0: C += product + bias (a residual branch lands on its trunk in place).  v_mfma_f32_16x16x4_f32: exact fp32
- * products, k ascending. */
+ * products, k ascending.  64 x 64 output tiles, or 32 x 32 when those would be <= 128 workgroups (the joint-token path's products: a wave
+ * then owns one 16 x 16 block and the per-step LDS -> MFMA chain is a quarter as long); the k order per element, and so the bits, are the same
+ * (DIR_GEMM_SMALL=0 keeps the 64 x 64 tiles). */
 typedef struct dir_gemm_desc {
     int32_t M, N, K, lda, ldb, ldc, trans_a, trans_b, accumulate, batch;
     int64_t stride_a, stride_b, stride_c;
