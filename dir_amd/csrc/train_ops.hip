@@ -396,6 +396,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out,
     out[n] = accumulate ? out[n] + acc : acc;
 }
 
+// A few hundred to a few thousand rows (the joint-token path's bias gradients: R = B * 21 .. 42): ONE launch -- 16 column quads x 64 row lanes,
+// every lane its rows in order with four loads in flight, the lanes added in lane order -- instead of chunk partials + a second launch.
+__global__ __launch_bounds__(1024) void colsum_mid_kernel(const float* x, float* out, int R, int N, int ld, int accumulate) {
+    __shared__ float4 s[64][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = min(blockIdx.x * 64 + cq * 4, N - 4);
+    auto at = [&](int r) { return *reinterpret_cast<const float4*>(x + (long long)r * ld + c); };
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = rl;
+    for (; r + 192 < R; r += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = at(r + 64 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; r < R; r += 64) { const float4 v = at(r); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    s[rl][cq] = a;
+    __syncthreads();
+    if (rl != 0 || blockIdx.x * 64 + cq * 4 >= N) return;
+    float4 t = s[0][cq];
+    for (int l = 1; l < 64; ++l) { const float4 q = s[l][cq]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+    float4* o = reinterpret_cast<float4*>(out + c);
+    if (accumulate) { const float4 p = *o; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+    *o = t;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ LayerNorm
 // one wave per row, C <= 256 (4 values per lane).  Statistics as torch: mean, biased variance (two passes in registers).
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
@@ -1366,6 +1392,11 @@ extern "C" int dir_colsum_f32(const float* x, float* out, int R, int N, int ld, 
     using namespace dir;
     DIR_REQUIRE(x && out && R > 0 && N > 0 && ld >= N, "dir_colsum_f32: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    static const bool mid = []() { const char* e = getenv("DIR_COLSUM_MID"); return !(e && e[0] == '0'); }();
+    if (mid && R >= 128 && R <= 4096 && N >= 4 && N % 4 == 0 && ld % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0) {
+        DIR_LAUNCH(colsum_mid_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, x, out, R, N, ld, accumulate);
+        return check_launch("dir_colsum_f32");
+    }
     if (R <= BN_SMALL_R) {
         DIR_LAUNCH(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x, out, R, N, ld, accumulate);
         return check_launch("dir_colsum_f32");

@@ -274,3 +274,18 @@ def test_gemm_grouped_with_one_group_gives_the_bits_of_gemm(M, N, K, batch, ta, 
     assert torch.equal(c1, c2)
     ref = (A.double().transpose(1, 2) if ta else A.double()) @ (Bm.double().transpose(1, 2) if tb else Bm.double())
     assert float((c1.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('R,N', [(1344, 200), (672, 64), (130, 4), (4096, 388), (5000, 128), (100, 36)])
+def test_colsum_every_path_vs_float64(R, N):
+    """dir_colsum_f32: the one-launch form of 128 .. 4096 rows (colsum_mid_kernel), the serial form below and the chunked form above it"""
+    torch.manual_seed(R + N)
+    x = torch.randn(R, N, device='cuda')
+    ref = x.double().sum(0)
+    got = O.colsum(x)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    acc = torch.randn(N, device='cuda')
+    want = acc.double() + ref
+    O.colsum(x, out=acc, accumulate=True)
+    assert float((acc.double() - want).abs().max() / want.abs().max()) < 2e-6
+    assert torch.equal(O.colsum(x), got)
