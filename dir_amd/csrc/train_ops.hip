@@ -983,6 +983,130 @@ __global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, con
     }
 }
 
+// ---- BatchNorm over at most BN_SMALL_R rows as a COOPERATIVE kernel (round 4): the kernels above walk a channel's rows with one thread, three
+// dependent passes of R loads each -- at 16 images (336 token rows) that made the training step SLOWER than at 32 (0.033 against 0.030 s,
+// profiles/r04_k_train_step_batch_sweep.txt).  A workgroup = 16 channels (4 quads) x 64 row lanes over all rows, lanes combined in lane order
+// (deterministic); the same formulas (bn_value, two-pass variance, the apply expressions), another summation order.  C % 4 == 0, 16-byte aligned.
+__device__ __forceinline__ float4 bn_mid_reduce(float4 v, float4 (*s)[4], int rl, int cq) {
+    __syncthreads();                                     // (the previous use of s is over)
+    s[rl][cq] = v;
+    __syncthreads();
+    float4 t = s[0][cq];
+    for (int l = 1; l < 64; ++l) { const float4 q = s[l][cq]; t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w; }
+    return t;                                            // every thread of the quad holds the same sums
+}
+__global__ __launch_bounds__(256) void bn_mid_fwd_kernel(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd,
+                                                        float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum, int relu,
+                                                        const float* res) {
+    __shared__ float4 s[64][4];
+    const int cq = threadIdx.x & 3, rl = threadIdx.x >> 2, c = min(blockIdx.x * 16 + cq * 4, C - 4);
+    const bool on = blockIdx.x * 16 + cq * 4 < C;
+    auto at = [&](const float* p, int r) { return *reinterpret_cast<const float4*>(p + (long long)r * ld + c); };
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = rl;
+    for (; r + 192 < R; r += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = at(x, r + 64 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; r < R; r += 64) { const float4 v = at(x, r); a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    const float4 t = bn_mid_reduce(a, s, rl, cq);
+    const float4 mu = make_float4(t.x / R, t.y / R, t.z / R, t.w / R);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto sq = [&](const float4 v) {
+        const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+        q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+    };
+    r = rl;
+    for (; r + 192 < R; r += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = at(x, r + 64 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sq(v[u]);
+    }
+    for (; r < R; r += 64) sq(at(x, r));
+    const float4 m2 = bn_mid_reduce(q, s, rl, cq);
+    const float4 var = make_float4(m2.x / R, m2.y / R, m2.z / R, m2.w / R);
+    const float4 rs = make_float4(1.f / sqrtf(var.x + eps), 1.f / sqrtf(var.y + eps), 1.f / sqrtf(var.z + eps), 1.f / sqrtf(var.w + eps));
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g = w ? *reinterpret_cast<const float4*>(w + c) : one, be = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+    if (rl == 0 && on) {
+        *reinterpret_cast<float4*>(save_mean + c) = mu;
+        *reinterpret_cast<float4*>(save_rstd + c) = rs;
+        if (running_mean) {                              // torch: running = (1 - momentum) running + momentum stat, with the UNBIASED variance
+            const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, m2s[4] = {m2.x, m2.y, m2.z, m2.w}, vs[4] = {var.x, var.y, var.z, var.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                running_mean[c + e] = (1.f - momentum) * running_mean[c + e] + momentum * mus[e];
+                running_var[c + e] = (1.f - momentum) * running_var[c + e] + momentum * (R > 1 ? m2s[e] / (R - 1) : vs[e]);
+            }
+        }
+    }
+    if (!on) return;
+    for (r = rl; r < R; r += 64) {
+        const float4 v = at(x, r);
+        float4 o = make_float4(bn_value(v.x, mu.x, rs.x, g.x, be.x), bn_value(v.y, mu.y, rs.y, g.y, be.y), bn_value(v.z, mu.z, rs.z, g.z, be.z),
+                               bn_value(v.w, mu.w, rs.w, g.w, be.w));
+        if (res) { const float4 e = at(res, r); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + (long long)r * ld + c) = o;
+    }
+}
+__global__ __launch_bounds__(256) void bn_mid_bwd_kernel(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                                                        float* gx, float* gw, float* gb, int R, int C, int ld, int relu) {
+    __shared__ float4 s[64][4];
+    const int cq = threadIdx.x & 3, rl = threadIdx.x >> 2, c = min(blockIdx.x * 16 + cq * 4, C - 4);
+    const bool on = blockIdx.x * 16 + cq * 4 < C;
+    auto at = [&](const float* p, int r) { return *reinterpret_cast<const float4*>(p + (long long)r * ld + c); };
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 m = *reinterpret_cast<const float4*>(save_mean + c), k = *reinterpret_cast<const float4*>(save_rstd + c);
+    const float4 g = w ? *reinterpret_cast<const float4*>(w + c) : one, be = b ? *reinterpret_cast<const float4*>(b + c) : zero;
+    auto masked = [&](const float4 v, float4 q) {
+        if (relu) {
+            if (!(bn_value(v.x, m.x, k.x, g.x, be.x) > 0.f)) q.x = 0.f;
+            if (!(bn_value(v.y, m.y, k.y, g.y, be.y) > 0.f)) q.y = 0.f;
+            if (!(bn_value(v.z, m.z, k.z, g.z, be.z) > 0.f)) q.z = 0.f;
+            if (!(bn_value(v.w, m.w, k.w, g.w, be.w) > 0.f)) q.w = 0.f;
+        }
+        return q;
+    };
+    float4 a1 = zero, a2 = zero;
+    auto acc = [&](const float4 v, const float4 q0) {
+        const float4 q = masked(v, q0);
+        a1.x += q.x; a1.y += q.y; a1.z += q.z; a1.w += q.w;
+        a2.x = fmaf(q.x, (v.x - m.x) * k.x, a2.x); a2.y = fmaf(q.y, (v.y - m.y) * k.y, a2.y);
+        a2.z = fmaf(q.z, (v.z - m.z) * k.z, a2.z); a2.w = fmaf(q.w, (v.w - m.w) * k.w, a2.w);
+    };
+    int r = rl;
+    for (; r + 192 < R; r += 256) {
+        float4 v[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = at(x, r + 64 * u); q[u] = at(gy, r + 64 * u); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc(v[u], q[u]);
+    }
+    for (; r < R; r += 64) acc(at(x, r), at(gy, r));
+    const float4 s1 = bn_mid_reduce(a1, s, rl, cq), s2 = bn_mid_reduce(a2, s, rl, cq);
+    if (rl == 0 && on) {
+        if (gw) *reinterpret_cast<float4*>(gw + c) = s2;
+        if (gb) *reinterpret_cast<float4*>(gb + c) = s1;
+    }
+    if (!gx || !on) return;
+    const float4 m1 = make_float4(s1.x / R, s1.y / R, s1.z / R, s1.w / R), m2 = make_float4(s2.x / R, s2.y / R, s2.z / R, s2.w / R);
+    for (r = rl; r < R; r += 64) {
+        const float4 v = at(x, r), q = masked(v, at(gy, r));
+        float4 o;
+        o.x = g.x * k.x * (q.x - m1.x - (v.x - m.x) * k.x * m2.x);
+        o.y = g.y * k.y * (q.y - m1.y - (v.y - m.y) * k.y * m2.y);
+        o.z = g.z * k.z * (q.z - m1.z - (v.z - m.z) * k.z * m2.z);
+        o.w = g.w * k.w * (q.w - m1.w - (v.w - m.w) * k.w * m2.w);
+        *reinterpret_cast<float4*>(gx + (long long)r * ld + c) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ ReLU
 __global__ __launch_bounds__(256) void relu_fwd_kernel(const float* x, float* y, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1472,6 +1596,10 @@ extern "C" int dir_bn_train_forward(const float* x, const float* w, const float*
     DIR_REQUIRE(x && y && save_mean && save_rstd && R > 0 && C > 0 && ld >= C && ((running_mean == nullptr) == (running_var == nullptr)),
                 "dir_bn_train_forward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (R <= BN_SMALL_R && R >= 16 && C >= 4 && bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, residual})) {
+        DIR_LAUNCH(bn_mid_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum, relu, residual);
+        return check_launch("dir_bn_train_forward");
+    }
     if (R <= BN_SMALL_R) {
         DIR_LAUNCH(bn_train_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, x, w, b, y, save_mean, save_rstd, running_mean, running_var, R, C, ld, eps, momentum, relu, residual);
         return check_launch("dir_bn_train_forward");
@@ -1501,6 +1629,10 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
     using namespace dir;
     DIR_REQUIRE(gy && x && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_train_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (R <= BN_SMALL_R && R >= 16 && C >= 4 && bn_vec4(C, ld, {x, gy, gx, w, b, save_mean, save_rstd, gw, gb})) {
+        DIR_LAUNCH(bn_mid_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, gx, gw, gb, R, C, ld, relu);
+        return check_launch("dir_bn_train_backward");
+    }
     if (R <= BN_SMALL_R) {
         DIR_LAUNCH(bn_train_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, gx, gw, gb, R, C, ld, relu);
         return check_launch("dir_bn_train_backward");
