@@ -39,11 +39,11 @@ class TrainWeight(C.Structure):          # dir_train_weight
 
 class BneckChainParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('w2', 'scale2', 'shift2', 'w3', 'scale3', 'shift3', 'w1n', 'scale1n', 'shift1n', 'wd')] + [
-        ('n_next', C.c_int32), ('out_decimate', C.c_int32)]
+        ('n_next', C.c_int32), ('out_decimate', C.c_int32), ('dtype', C.c_int32)]
 
 
 class BneckTailParams(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('wstream', 'scale3', 'shift3', 'scale1n', 'shift1n')] + [('planes', C.c_int32), ('n_next', C.c_int32), ('waves', C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ('wstream', 'scale3', 'shift3', 'scale1n', 'shift1n')] + [('planes', C.c_int32), ('n_next', C.c_int32), ('waves', C.c_int32), ('dtype', C.c_int32)]
 
 
 class GemmDesc(C.Structure):
@@ -114,8 +114,8 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 34          # DIR_ABI_VERSION (include/dir_hip.h)
-DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P = 0, 1, 3, 4, 5, 6
+ABI_VERSION = 35          # DIR_ABI_VERSION (include/dir_hip.h)
+DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P, DT_F16 = 0, 1, 3, 4, 5, 6, 7      # DT_F16: f16 STORAGE (round 5)
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
 _p, _i = C.c_void_p, C.c_int
@@ -151,6 +151,7 @@ _SIGNATURES = {
     'dir_bottleneck_chain_forward': (C.c_int, [C.POINTER(BneckChainParams), _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_bottleneck_tail_forward': (C.c_int, [C.POINTER(BneckTailParams), _p, _p, _p, _p, C.c_longlong, _p]),
     'dir_stem_pool_forward': (C.c_int, [_p, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p, _i, _i, _i, _p]),
+    'dir_stem_pool_forward_dt': (C.c_int, [_p, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p, _i, _i, _i, _p]),
     'dir_maxpool3x3s2': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_init_head_forward': (C.c_int, [C.POINTER(InitHeadParams), _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -30,10 +30,9 @@ namespace dir {
 namespace {
 
 using convk::bf16_t;
-using convk::bf16x8;
+using convk::f16s_t;
+using convk::Half;
 using convk::f32x16;
-using convk::pack2bf;
-using convk::relu2bf;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int TH = 8, TW = 16, NPX = TH * TW;            // tile: 8 rows x 16 cols = 128 pixels, pixel P = row * 16 + col
@@ -54,13 +53,14 @@ struct ChainArgs {
     int decim;                                            // 1: only the pixels with even y and even x leave, as out [B][H/2][W/2][256]
 };
 
-__device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+template <typename H> __device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
+    convk::unpack2<H>(v.x, f[0], f[1]);
+    convk::unpack2<H>(v.y, f[2], f[3]);
 }
 
 // N2: output channels of the fused next conv1 (0 = none, 64 = next layer1 block, 128 = first block of layer2)
-template <bool HAS_RES, int N2, bool HAS_DUAL>
+// H: the 16-bit storage kind (bf16_t | f16s_t = DIR_DT_BF16 | DIR_DT_F16) of every tensor, weight and LDS tile
+template <bool HAS_RES, int N2, bool HAS_DUAL, typename H = bf16_t>
 __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     constexpr bool HAS_NEXT = N2 > 0;
     __shared__ __attribute__((aligned(16))) char s_w2[64 * W2PITCH];
@@ -80,21 +80,21 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
     if (tid < 64) { s_ss[tid] = a.sc2[tid]; s_ss[64 + tid] = a.sh2[tid]; }
     if (tid < 256) { s_ss[128 + tid] = a.sc3[tid]; s_ss[384 + tid] = a.sh3[tid]; }
     if (HAS_NEXT && tid < N2) { s_ss[640 + tid] = a.sc1n[tid]; s_ss[768 + tid] = a.sh1n[tid]; }
-    bf16x8 w3f[4];                                                    // channel 32 wave + l32, k = 16 s + 8 h
+    convk::u32x4 w3f[4];                                                    // channel 32 wave + l32, k = 16 s + 8 h
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w3f[s] = *reinterpret_cast<const bf16x8*>(a.w3 + (32 * wave + l32) * 64 + 16 * s + 8 * h);
-    bf16x8 wdf[HAS_DUAL ? 4 : 1];                                     // projection weights, same fragment layout as w3f
+    for (int s = 0; s < 4; ++s) w3f[s] = *reinterpret_cast<const convk::u32x4*>(a.w3 + (32 * wave + l32) * 64 + 16 * s + 8 * h);
+    convk::u32x4 wdf[HAS_DUAL ? 4 : 1];                                     // projection weights, same fragment layout as w3f
     if constexpr (HAS_DUAL) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wdf[s] = *reinterpret_cast<const bf16x8*>(a.wd + (32 * wave + l32) * 64 + 16 * s + 8 * h);
+        for (int s = 0; s < 4; ++s) wdf[s] = *reinterpret_cast<const convk::u32x4*>(a.wd + (32 * wave + l32) * 64 + 16 * s + 8 * h);
     }
     // phase-C roles: 16 output channels per wave (N2 = 128: wave; 64: wave >> 1) x NPT 16-pixel groups of the half
     constexpr int NPT = N2 == 128 ? 4 : 2;
     const int ct = N2 == 128 ? wave : (wave >> 1), pt0 = N2 == 128 ? 0 : 2 * (wave & 1);
-    bf16x8 w1f[HAS_NEXT ? 8 : 1];                                     // channel 16 ct + l16, k = 32 s + 8 g
+    convk::u32x4 w1f[HAS_NEXT ? 8 : 1];                                     // channel 16 ct + l16, k = 32 s + 8 g
     if constexpr (HAS_NEXT) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) w1f[s] = *reinterpret_cast<const bf16x8*>(a.w1n + (16 * ct + l16) * 256 + 32 * s + 8 * g);
+        for (int s = 0; s < 8; ++s) w1f[s] = *reinterpret_cast<const convk::u32x4*>(a.w1n + (16 * ct + l16) * 256 + 32 * s + 8 * g);
     }
 
     // XCD-aware tile order: the 32 workgroups of one XCD walk one contiguous range of tiles (halo rows hit the same L2)
@@ -213,11 +213,11 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             // operand fragments are read two k-steps ahead of the MFMA that uses them (LDS latency ~ one MFMA)
-            bf16x8 wv[3], pv[3];
+            uint4 wv[3], pv[3];
             auto ldfrag = [&](int i, int slot) {
                 const int tap = i >> 2, s = i & 3, ky = tap / 3, kx = tap - 3 * ky;
-                wv[slot] = *reinterpret_cast<const bf16x8*>(pa_w + tap * 128 + 32 * s);
-                pv[slot] = *reinterpret_cast<const bf16x8*>(pa_b + (ky * PWD + kx) * PPITCH + 32 * s);
+                wv[slot] = *reinterpret_cast<const uint4*>(pa_w + tap * 128 + 32 * s);
+                pv[slot] = *reinterpret_cast<const uint4*>(pa_b + (ky * PWD + kx) * PPITCH + 32 * s);
             };
             ldfrag(0, 0);
             ldfrag(1, 1);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
             for (int i = 0; i < 36; ++i) {
                 if (i + 2 < 36) ldfrag(i + 2, (i + 2) % 3);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i % 3], pv[i % 3], acc, 0, 0, 0);
+                acc = Half<H>::mfma32(wv[i % 3], pv[i % 3], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // rows (channels) of the 32x32 tile held by this lane: 8 q + 4 h + {0..3}
@@ -235,8 +235,8 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                 const float4 sc = *reinterpret_cast<const float4*>(s_ss + c0);
                 const float4 sh = *reinterpret_cast<const float4*>(s_ss + 64 + c0);
                 uint2 o;
-                o.x = relu2bf(pack2bf(fmaf(acc[4 * q], sc.x, sh.x), fmaf(acc[4 * q + 1], sc.y, sh.y)));
-                o.y = relu2bf(pack2bf(fmaf(acc[4 * q + 2], sc.z, sh.z), fmaf(acc[4 * q + 3], sc.w, sh.w)));
+                o.x = Half<H>::pack2_relu(fmaf(acc[4 * q], sc.x, sh.x), fmaf(acc[4 * q + 1], sc.y, sh.y));
+                o.y = Half<H>::pack2_relu(fmaf(acc[4 * q + 2], sc.z, sh.z), fmaf(acc[4 * q + 3], sc.w, sh.w));
                 *reinterpret_cast<uint2*>(s_y2 + (32 * mt + l32) * PPITCH + c0 * 2) = o;
             }
         }
@@ -251,12 +251,12 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
         for (int mg = 0; mg < 2; ++mg) {
             // ---- B. conv3 (1x1, K = 64): this wave's 32 output channels x the half's 64 pixels
             f32x16 accb[2];
-            bf16x8 pvb[2][4];
+            uint4 pvb[2][4];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    pvb[j][s] = *reinterpret_cast<const bf16x8*>(s_y2 + (64 * mg + 32 * j + l32) * PPITCH + 32 * s + 16 * h);
+                    pvb[j][s] = *reinterpret_cast<const uint4*>(s_y2 + (64 * mg + 32 * j + l32) * PPITCH + 32 * s + 16 * h);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -264,17 +264,17 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[s], pvb[j][s], accb[j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) accb[j] = Half<H>::mfma32(w3f[s], pvb[j][s], accb[j]);
             if constexpr (HAS_DUAL) {                                         // + projection shortcut: K = 64 more, from the parked input tile
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        pvb[j][s] = *reinterpret_cast<const bf16x8*>(s_patch + (64 * mg + 32 * j + l32) * PPITCH + 32 * s + 16 * h);
+                        pvb[j][s] = *reinterpret_cast<const uint4*>(s_patch + (64 * mg + 32 * j + l32) * PPITCH + 32 * s + 16 * h);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wdf[s], pvb[j][s], accb[j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) accb[j] = Half<H>::mfma32(wdf[s], pvb[j][s], accb[j]);
             }
             // epilogue B -> T: lane = pixel 32 j + l32, channels 32 wave + 8 q + 4 h .. +4
 #pragma unroll
@@ -293,16 +293,16 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                         const uint4 c = xr[mg][j][q >> 1];            // (q even, q odd) = swap(lower 8 bytes, upper 8 bytes) with the partner lane
                         const auto sx = __builtin_amdgcn_permlane32_swap(c.x, c.z, false, false);
                         const auto sy = __builtin_amdgcn_permlane32_swap(c.y, c.w, false, false);
-                        unpack4(make_uint2(sx[q & 1], sy[q & 1]), rv);
+                        unpack4<H>(make_uint2(sx[q & 1], sy[q & 1]), rv);
 #else
-                        unpack4(xr[mg][j][q], rv);
+                        unpack4<H>(xr[mg][j][q], rv);
 #endif
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += rv[e];
                     }
                     uint2 o;
-                    o.x = relu2bf(pack2bf(v[0], v[1]));
-                    o.y = relu2bf(pack2bf(v[2], v[3]));
+                    o.x = Half<H>::pack2_relu(v[0], v[1]);
+                    o.y = Half<H>::pack2_relu(v[2], v[3]);
                     *reinterpret_cast<uint2*>(tp) = o;
                 }
             }
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                 for (int s = 0; s < 8; ++s)
 #pragma unroll
                     for (int u = 0; u < NPT; ++u) {
-                        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(s_t + (16 * (pt0 + u) + l16) * TPITCH + 64 * s + 16 * g);
-                        accc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[s], pv, accc[u], 0, 0, 0);
+                        const uint4 pv = *reinterpret_cast<const uint4*>(s_t + (16 * (pt0 + u) + l16) * TPITCH + 64 * s + 16 * g);
+                        accc[u] = Half<H>::mfma16(w1f[s], pv, accc[u]);
                     }
                 const int c0 = 16 * ct + 4 * g;
                 const float4 sc = *reinterpret_cast<const float4*>(s_ss + 640 + c0);
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
                 for (int u = 0; u < NPT; ++u) {
                     const int P = 64 * mg + 16 * (pt0 + u) + l16;
                     uint2 o;
-                    o.x = relu2bf(pack2bf(fmaf(accc[u][0], sc.x, sh.x), fmaf(accc[u][1], sc.y, sh.y)));
-                    o.y = relu2bf(pack2bf(fmaf(accc[u][2], sc.z, sh.z), fmaf(accc[u][3], sc.w, sh.w)));
+                    o.x = Half<H>::pack2_relu(fmaf(accc[u][0], sc.x, sh.x), fmaf(accc[u][1], sc.y, sh.y));
+                    o.y = Half<H>::pack2_relu(fmaf(accc[u][2], sc.z, sh.z), fmaf(accc[u][3], sc.w, sh.w));
                     *reinterpret_cast<uint2*>(a.y1n + (((long long)b * a.H + y0 + (P >> 4)) * a.W + x0 + (P & 15)) * N2 + c0) = o;
                 }
             }
@@ -390,7 +390,10 @@ extern "C" int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, con
     const bool res = residual != nullptr;
     const int n2 = next ? p->n_next : 0;
     DIR_REQUIRE(n2 == 0 || n2 == 64 || n2 == 128, "dir_bottleneck_chain_forward: n_next must be 64 or 128");
-#define DIR_CHAIN(RES_, N2_, DUAL_) DIR_LAUNCH((bneck_chain_kernel<RES_, N2_, DUAL_>), dim3(grid), dim3(NTHR), 0, s, a)
+    DIR_REQUIRE(p->dtype == 0 || p->dtype == DIR_DT_BF16 || p->dtype == DIR_DT_F16, "dir_bottleneck_chain_forward: dtype must be bf16 (or 0) or f16");
+    const bool f16 = p->dtype == DIR_DT_F16;
+#define DIR_CHAIN(RES_, N2_, DUAL_) do { if (f16) DIR_LAUNCH((bneck_chain_kernel<RES_, N2_, DUAL_, f16s_t>), dim3(grid), dim3(NTHR), 0, s, a); \
+                                         else DIR_LAUNCH((bneck_chain_kernel<RES_, N2_, DUAL_, bf16_t>), dim3(grid), dim3(NTHR), 0, s, a); } while (0)
     if (dual) { if (n2 == 128) DIR_CHAIN(false, 128, true); else if (n2) DIR_CHAIN(false, 64, true); else DIR_CHAIN(false, 0, true); }
     else if (res) { if (n2 == 128) DIR_CHAIN(true, 128, false); else if (n2) DIR_CHAIN(true, 64, false); else DIR_CHAIN(true, 0, false); }
     else { if (n2 == 128) DIR_CHAIN(false, 128, false); else if (n2) DIR_CHAIN(false, 64, false); else DIR_CHAIN(false, 0, false); }

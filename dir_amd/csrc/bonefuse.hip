@@ -47,7 +47,8 @@ struct GArgs {
 
 constexpr int G_ROWS = 128, G_LD = 66;      // (sample, end) rows per pass; lda % 32 == 2 (dir_mfma.h)
 
-template <bool F32>
+// H (F32 = false only): the 16-bit kind G is rounded to (bf16_t | f16s_t = the throughput modes DIR_DT_BF16 | DIR_DT_F16)
+template <bool F32, typename H = bf16_t>
 __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
     __shared__ float s_f[G_ROWS * G_LD];
     const int tap = blockIdx.x / 40, hb = blockIdx.x - tap * 40, hand = hb / 20, bone = hb - hand * 20;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
                     if (b < a.B) {
                         const long long o = (((long long)b * NTAP + tap) * 40 + hb) * NCOUT + n;
                         if constexpr (F32) reinterpret_cast<float2*>(a.g)[o] = make_float2(acc[m][2 * s], acc[m][2 * s + 1]);
-                        else a.g[o] = (unsigned)f2bf(acc[m][2 * s]) | ((unsigned)f2bf(acc[m][2 * s + 1]) << 16);
+                        else a.g[o] = Half<H>::pack2(acc[m][2 * s], acc[m][2 * s + 1]);
                     }
                 }
         }
@@ -116,6 +117,7 @@ struct FuseArgs {
 
 constexpr int FUSE_MAX_ROWS = 400;
 
+template <typename H>
 __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
     constexpr int MI = 2, NJ = 2, WM = 4, WN = 2, NT = 512, BM = 256, BN = 128;
     constexpr int PITCH = EP * 2;                                   // 176 B
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
             const float* sb = s_bone + 6 * hb;                        // (the parent / child tables are __constant__: indexed per lane
             float wa, wb;                                             //  they would be two global loads per item)
             if (dir::bone::bone_weights_fast((float)ix + 0.5f, (float)iy + 0.5f, sb[0], sb[1], sb[2], sb[3], sb[4], sb[5], a.distance, wa, wb))
-                word = (unsigned)f2bf(wa) | ((unsigned)f2bf(wb) << 16);   // torch.where(mask, v, 0), models/dir.py:172
+                word = Half<H>::pack2(wa, wb);   // torch.where(mask, v, 0), models/dir.py:172
         }
         *reinterpret_cast<unsigned*>(smem + prow * PITCH + hb * 4) = word;
     }
@@ -228,8 +230,7 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                        acc[i][j], 0, 0, 0);
+                    acc[i][j] = Half<H>::mfma32(fa[i], fb[j], acc[i][j]);
         }
         if (tap + 1 < NTAP) g_store((tap + 1) & 1);                   // buffer (tap+1)&1 was last read in tap-1
         __syncthreads();
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
 
     stamp();
     ConvArgs c = a.c;
-    epilogue_tile<bf16_t, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
+    epilogue_tile<H, MI, NJ, WM, WN>(c, acc, smem, m0, n0, wm, wn, tid, lane);
     stamp();
 }
 
@@ -517,8 +518,10 @@ extern "C" int dir_bone_fusion_prepare(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(B >= 0, "dir_bone_fusion_prepare: B=%d", B);
     if (B == 0) return DIR_OK;
     GArgs ga{p->w_g, emb, (unsigned*)scratch, B, stamps_begin("bone_g")};
-    if (p->exact_f32) DIR_LAUNCH(bone_g_kernel<true>, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
-    else DIR_LAUNCH(bone_g_kernel<false>, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    DIR_REQUIRE(p->exact_f32 >= 0 && p->exact_f32 <= 2, "dir_bone_fusion_prepare: exact_f32 must be 0 (bf16), 1 (fp32) or 2 (f16 storage)");
+    if (p->exact_f32 == 1) DIR_LAUNCH(bone_g_kernel<true>, dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    else if (p->exact_f32 == 2) DIR_LAUNCH((bone_g_kernel<false, f16s_t>), dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
+    else DIR_LAUNCH((bone_g_kernel<false, bf16_t>), dim3(NTAP * 40, 2), dim3(256), 0, (hipStream_t)stream, ga);
     stamps_end("bone_g", ga.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_prepare");
 }
@@ -533,7 +536,9 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(S > 0 && 256 % S == 0 && (S * S) % 256 == 0, "dir_bone_fusion_forward: S=%d (needs 256 %% S == 0 and S*S %% 256 == 0)", S);
     const int ocs = out_cstride ? out_cstride : NCOUT;
     DIR_REQUIRE(ocs % 8 == 0 && out_coff % 8 == 0 && out_coff + NCOUT <= ocs, "dir_bone_fusion_forward: output slice must be 16-byte aligned");
-    const int strip = p->exact_f32 ? F32_BM : 256;                     // output pixels per workgroup
+    DIR_REQUIRE(p->exact_f32 >= 0 && p->exact_f32 <= 2, "dir_bone_fusion_forward: exact_f32 must be 0 (bf16), 1 (fp32) or 2 (f16 storage)");
+    const bool exact = p->exact_f32 == 1;
+    const int strip = exact ? F32_BM : 256;                     // output pixels per workgroup
     const long long M = (long long)B * S * S;
     DIR_REQUIRE(M < (1ll << 31), "dir_bone_fusion_forward: too many pixels");
     FuseArgs fa{};
@@ -544,18 +549,19 @@ extern "C" int dir_bone_fusion_forward(const dir_bone_fusion_params* p, const fl
     DIR_REQUIRE(strip % S == 0, "dir_bone_fusion_forward: S=%d does not divide the %d-pixel strip", S, strip);
     const int rows = strip / S;
     fa.PW = S + 2; fa.PH = rows + 2; fa.npr = fa.PH * fa.PW;
-    DIR_REQUIRE(fa.npr <= (p->exact_f32 ? F32_MAX_ROWS : FUSE_MAX_ROWS), "dir_bone_fusion_forward: halo patch of %d rows does not fit", fa.npr);
+    DIR_REQUIRE(fa.npr <= (exact ? F32_MAX_ROWS : FUSE_MAX_ROWS), "dir_bone_fusion_forward: halo patch of %d rows does not fit", fa.npr);
     convk::magic_u31((unsigned)fa.npr, &fa.mg_npr, &fa.sh_npr);
     convk::magic_u31((unsigned)fa.PW, &fa.mg_pw, &fa.sh_pw);
     fa.stamps = stamps_begin("bone_fuse");
-    fa.g_scale = p->exact_f32 ? p->g_scale : 0.f;
+    fa.g_scale = exact ? p->g_scale : 0.f;
     convk::magic_u31((unsigned)((fa.npr + 7) >> 3), &fa.mg_pr8, &fa.sh_pr8);
-    if (p->exact_f32 && fa.g_scale > 0.f) {
+    if (exact && fa.g_scale > 0.f) {
         int e;
         DIR_REQUIRE(frexpf(fa.g_scale, &e) == 0.5f, "dir_bone_fusion_forward: g_scale must be a power of two");
         DIR_LAUNCH(bone_fuse_x3_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
-    } else if (p->exact_f32) DIR_LAUNCH(bone_fuse_f32_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
-    else DIR_LAUNCH(bone_fuse_kernel, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    } else if (exact) DIR_LAUNCH(bone_fuse_f32_kernel, dim3((unsigned)(M / F32_BM) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    else if (p->exact_f32 == 2) DIR_LAUNCH(bone_fuse_kernel<f16s_t>, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
+    else DIR_LAUNCH(bone_fuse_kernel<bf16_t>, dim3((unsigned)(M / 256) * 2), dim3(512), 0, (hipStream_t)stream, fa);
     stamps_end("bone_fuse", fa.stamps, (hipStream_t)stream);
     return dir::check_launch("dir_bone_fusion_forward");
 }

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 template <typename TI, typename TO>
 void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     if (a0.splits > 1) {                                   // dir_conv2d_splitk_forward: 128x128 tiles, 2-buffer loop
-        if constexpr (std::is_same<TI, bf16_t>::value && std::is_same<TO, bf16_t>::value) {
+        if constexpr (is_half<TI>::value && std::is_same<TO, TI>::value) {
             ConvArgs a = a0;
             a.tiles_m = (a.M + 127) / 128;
             a.tiles_n = (a.Cout + 127) / 128;
@@ -528,17 +528,17 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
         return;
     }
     constexpr int XM = std::is_same<TI, f16x3p_t>::value ? 3 : std::is_same<TI, f16x1p_t>::value ? 1 : 0;
-    if constexpr (std::is_same<TI, bf16_t>::value || XM != 0) {
+    if constexpr (is_half<TI>::value || XM != 0) {
         // MFMA-bound layers (long reduction, enough tiles for 8-wave workgroups): deep-pipelined kernel of conv_pipe.hip (bf16, or both operands
         // pre-split f16)
         if constexpr (XM == 0) {
-            if (a0.variant == 11 && launch_conv_big(a0, std::is_same<TO, float>::value, s)) return;      // DIR_CONV_VARIANT 11: 256 x 256 block tile
+            if (a0.variant == 11 && launch_conv_big(a0, std::is_same<TO, float>::value, s, std::is_same<TI, f16s_t>::value)) return;      // DIR_CONV_VARIANT 11: 256 x 256 block tile
         }
         const bool four_wave = ((a0.variant & 15) >= 1 && (a0.variant & 15) <= 4) || a0.x2;   // explicit DIR_CONV_VARIANT 1..4 (+16), or a second source
         if (!four_wave) {
             ConvArgs ap = a0;
             ap.stamps = dir::stamps_begin("conv_pipe");
-            const bool taken = launch_conv_pipe(ap, std::is_same<TO, float>::value, num_cu, s, XM);
+            const bool taken = launch_conv_pipe(ap, std::is_same<TO, float>::value, num_cu, s, XM, std::is_same<TI, f16s_t>::value);
             if (ap.stamps) {
                 fprintf(stderr, "conv M=%d N=%d K=%d %s: ", ap.M, ap.Cout, ap.K, taken ? "pipe" : "(not taken)");
                 dir::stamps_end("conv_pipe", ap.stamps, s);
@@ -572,7 +572,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
-    choose_tile_order(a, std::is_same<TI, bf16_t>::value ? 2 : 4);
+    choose_tile_order(a, is_half<TI>::value ? 2 : 4);
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     const bool pre = a.pre_scale != nullptr;
     // 3-buffer ring (two slabs in flight) pays once the reduction is long enough to amortise its two-slab prologue
@@ -621,9 +621,11 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     const bool x3 = d->in_dtype == DIR_DT_F16X3 || d->in_dtype == DIR_DT_F16X3P || x1;   // fp32-sized tensors, f16 arithmetic (split precision / hi only)
     DIR_REQUIRE(!(xp && pre_scale), "dir_conv2d_forward: pre-split activations carry their pre-activation already (dir_split_f16_forward)");
     const bool f32 = d->in_dtype == DIR_DT_F32 || x3;
-    DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16, "dir_conv2d_forward: in_dtype must be f32, bf16 or f16x3");
-    DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == DIR_DT_BF16, "dir_conv2d_forward: bad out_dtype");
-    DIR_REQUIRE(!(f32 && d->out_dtype == DIR_DT_BF16), "dir_conv2d_forward: f32 in / bf16 out not built");
+    const bool h16 = d->in_dtype == DIR_DT_F16;                 // f16 STORAGE (round 5): the bf16 data path on the f16 matrix cores
+    DIR_REQUIRE(f32 || d->in_dtype == DIR_DT_BF16 || h16, "dir_conv2d_forward: in_dtype must be f32, bf16, f16 or f16x3");
+    DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == DIR_DT_BF16 || d->out_dtype == DIR_DT_F16, "dir_conv2d_forward: bad out_dtype");
+    DIR_REQUIRE(!(f32 && d->out_dtype != DIR_DT_F32), "dir_conv2d_forward: f32 in / 16-bit out not built");
+    DIR_REQUIRE(d->out_dtype == DIR_DT_F32 || d->out_dtype == d->in_dtype, "dir_conv2d_forward: a 16-bit output must have the input's 16-bit type");
     const int BK = f32 ? 32 : 64, EPC = f32 ? 4 : 8;
     DIR_REQUIRE(d->Cin % BK == 0, "dir_conv2d_forward: Cin=%d must be a multiple of %d", d->Cin, BK);
     const int in_cs = d->in_cstride ? d->in_cstride : d->Cin;
@@ -697,7 +699,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     }
     a.splits = 0; a.ws_part = nullptr; a.ws_cnt = nullptr;
     if (splits > 1) {
-        DIR_REQUIRE(!f32 && d->out_dtype == DIR_DT_BF16 && vec && bbox == nullptr, "dir_conv2d_splitk_forward: bf16 -> bf16 layers with 16-byte aligned output rows only");
+        DIR_REQUIRE(!f32 && d->out_dtype != DIR_DT_F32 && vec && bbox == nullptr, "dir_conv2d_splitk_forward: 16-bit -> 16-bit layers with 16-byte aligned output rows only");
         DIR_REQUIRE(splits <= a.nk && splits <= 16, "dir_conv2d_splitk_forward: splits must be <= min(16, K / 64)");
         const long long tiles = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
         const long long need = SPLITK_COUNTER_BYTES + (long long)splits * tiles * 128 * 128 * 4;
@@ -711,6 +713,8 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     else if (x1) launch_conv<f16x1_t, float>(a, num_cu, s);
     else if (x3) launch_conv<f16x3_t, float>(a, num_cu, s);
     else if (f32) launch_conv<float, float>(a, num_cu, s);
+    else if (h16 && d->out_dtype == DIR_DT_F16) launch_conv<f16s_t, f16s_t>(a, num_cu, s);
+    else if (h16) launch_conv<f16s_t, float>(a, num_cu, s);
     else if (d->out_dtype == DIR_DT_BF16) launch_conv<bf16_t, bf16_t>(a, num_cu, s);
     else launch_conv<bf16_t, float>(a, num_cu, s);
     return dir::check_launch("dir_conv2d_forward");

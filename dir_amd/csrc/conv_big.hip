@@ -21,9 +21,9 @@ namespace {
 
 struct BSlab { int tap, toff, k0; };
 
-template <typename TO>
+template <typename TO, typename TIN = bf16_t>
 __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
-    typedef bf16_t TI;
+    typedef TIN TI;
     constexpr int MI = 4, NJ = 2, WM = 2, WN = 4, NT = 512, BM = 256, BN = 256, ROW = 128;
     constexpr int RPP = NT / 8, ACH = BM / RPP, BCH = BN / RPP, NP = ACH + BCH;      // 64 rows per DMA pass; 4 + 4 pieces per thread and slab
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;
@@ -123,8 +123,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i]), __builtin_bit_cast(bf16x8, fb[set][j]),
-                                                                    acc[i][j], 0, 0, 0);
+                acc[i][j] = Half<TI>::mfma32(fa[set][i], fb[set][j], acc[i][j]);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
 }  // namespace
 
 // DIR_CONV_VARIANT 11: returns true if it took the launch (bf16 operands, dense, no pre-activation / second source / split output, vector epilogue)
-bool launch_conv_big(const ConvArgs& a0, bool out_f32, hipStream_t s) {
+bool launch_conv_big(const ConvArgs& a0, bool out_f32, hipStream_t s, bool f16) {
     if (a0.pre_scale || a0.bbox || a0.x2 || !(a0.flags & 4) || a0.nk < 1 || a0.out_split_scale > 0.f) return false;
     if (a0.Cin % 64 != 0 || a0.splits > 1) return false;
     if (a0.Cout <= 128 || a0.M <= 128) return false;                            // (a half-empty tile: the other variants serve these)
@@ -209,7 +208,9 @@ bool launch_conv_big(const ConvArgs& a0, bool out_f32, hipStream_t s) {
     a.tiles_n = (a.Cout + 255) / 256;
     choose_tile_order(a, 2);
     const dim3 grid(a.tiles_m * a.tiles_n), block(512);
-    if (out_f32) DIR_LAUNCH((conv_big_kernel<float>), grid, block, 0, s, a);
+    if (f16 && out_f32) DIR_LAUNCH((conv_big_kernel<float, f16s_t>), grid, block, 0, s, a);
+    else if (f16) DIR_LAUNCH((conv_big_kernel<f16s_t, f16s_t>), grid, block, 0, s, a);
+    else if (out_f32) DIR_LAUNCH((conv_big_kernel<float>), grid, block, 0, s, a);
     else DIR_LAUNCH((conv_big_kernel<bf16_t>), grid, block, 0, s, a);
     return true;
 }

@@ -62,6 +62,57 @@ __device__ __forceinline__ uint32_t relu2bf(uint32_t v) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, v), i16x2_t{0, 0}));
 }
 
+// f16 STORAGE (DIR_DT_F16, round 5): feature maps and weights held as IEEE binary16 -- the bytes, addressing, LDS-DMA path and MFMA rate of
+// the bf16 mode with an 11-bit significand instead of 8: the rounding of every stored map is 8x finer (the bf16 mode's 0.036 / 0.050 mm at
+// the init stage is the accumulated rounding of the backbone's 53 stored maps).  The range is 65504: stores clamp (v_med3_f32)
+// instead of producing inf.  A distinct tag type so that every kernel template instantiates twice; 2 bytes like bf16_t.
+struct f16s_t { unsigned short u; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <typename T> struct is_half { static constexpr bool value = std::is_same<T, bf16_t>::value || std::is_same<T, f16s_t>::value; };
+constexpr float F16_MAX = 65504.f;
+
+// the two 16-bit storage kinds behind one interface: H = bf16_t | f16s_t
+template <typename H> struct Half;
+template <> struct Half<bf16_t> {
+    static constexpr int DT = DIR_DT_BF16;
+    static __device__ __forceinline__ float to_f32(unsigned short v) { return __uint_as_float(((uint32_t)v) << 16); }
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack2bf(lo, hi); }
+    static __device__ __forceinline__ uint32_t pack2_relu(float lo, float hi) { return relu2bf(pack2bf(lo, hi)); }
+    template <typename A, typename B> static __device__ __forceinline__ f32x16 mfma32(const A a, const B b, const f32x16 c) {      // A, B: any 16-byte type
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    template <typename A, typename B> static __device__ __forceinline__ f32x4_t mfma16(const A a, const B b, const f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Half<f16s_t> {
+    static constexpr int DT = DIR_DT_F16;
+    static __device__ __forceinline__ float to_f32(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+    // round to nearest even after clamping to the finite range (one v_med3_f32 per value)
+    static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+        const f32x2_t c = {__builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX)};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2_t));
+    }
+    // ReLU and the clamp in the same v_med3_f32: med3(v, 0, 65504)
+    static __device__ __forceinline__ uint32_t pack2_relu(float lo, float hi) {
+        const f32x2_t c = {__builtin_amdgcn_fmed3f(lo, 0.f, F16_MAX), __builtin_amdgcn_fmed3f(hi, 0.f, F16_MAX)};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2_t));
+    }
+    template <typename A, typename B> static __device__ __forceinline__ f32x16 mfma32(const A a, const B b, const f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    template <typename A, typename B> static __device__ __forceinline__ f32x4_t mfma16(const A a, const B b, const f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+// a packed pair of 16-bit values -> two floats
+template <typename H> __device__ __forceinline__ void unpack2(uint32_t u, float& lo, float& hi) {
+    lo = Half<H>::to_f32((unsigned short)(u & 0xffffu));
+    hi = Half<H>::to_f32((unsigned short)(u >> 16));
+}
+
 // f16x3 "split precision" operand tag (DIR_DT_F16X3): tensors are fp32 in memory, every product a*w is evaluated as
 //   hi(a)*hi(w) + lo(a)*hi(w) + hi(a)*lo(w),   hi(x) = f16(x), lo(x) = f16(x - hi(x))           (3 x v_mfma_f32_32x32x16_f16, fp32 accumulate)
 // hi + lo carries 22 significant bits (the dropped lo*lo and residual terms are ~2^-22 |a w|), against 24 for the exact fp32 MFMA at
@@ -74,8 +125,6 @@ struct f16x3_t { float v; };
 // bits, 8x finer than bf16), fp32 accumulation: what torch.autocast(float16) does to a convolution, on fp32 tensors.  The "fp16 MFMA path"
 // of BASELINE config 5; weights come in the f16x3 packing (their lo halves are simply not read into the products).
 struct f16x1_t { float v; };
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 // hi parts only (f16x1): {hi01, hi23, 0, 0}
 __device__ __forceinline__ uint4 split_f16x1(const uint4 v, const float s) {
@@ -94,6 +143,7 @@ struct f16x1p_t { float v; };
 template <typename T> struct Tr;
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };    // EPC = elems per 16-B chunk
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
+template <> struct Tr<f16s_t> { static constexpr int EPC = 8, BK = 64; };
 template <> struct Tr<f16x3_t> { static constexpr int EPC = 4, BK = 32; };
 template <> struct Tr<f16x1_t> { static constexpr int EPC = 4, BK = 32; };
 template <> struct Tr<f16x3p_t> { static constexpr int EPC = 4, BK = 32; };
@@ -139,9 +189,11 @@ constexpr int MAX_SLABS = 768;
 template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
 template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void store_out<f16s_t>(f16s_t* p, float v) { p->u = (unsigned short)(Half<f16s_t>::pack2(v, 0.f) & 0xffffu); }
 template <typename TO> __device__ __forceinline__ float load_res(const TO* p);
 template <> __device__ __forceinline__ float load_res<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float load_res<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float load_res<f16s_t>(const f16s_t* p) { return Half<f16s_t>::to_f32(p->u); }
 
 template <typename TI>
 __device__ __forceinline__ void mma_slab(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc);
@@ -161,6 +213,11 @@ __device__ __forceinline__ void mma_slab<bf16_t>(const uint4 (&af)[4], const uin
     for (int q = 0; q < 4; ++q)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q]),
                                                       __builtin_bit_cast(bf16x8, bf[q]), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_slab<f16s_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = Half<f16s_t>::mfma32(af[q], bf[q], acc);
 }
 template <>
 __device__ __forceinline__ void mma_slab<f16x3p_t>(const uint4 (&af)[4], const uint4 (&bf)[4], f32x16& acc);
@@ -250,28 +307,31 @@ __device__ __forceinline__ void store_split4(float* y, long long m, int n, int C
     *reinterpret_cast<uint2*>(row + 64 + 2 * (n & 31)) = make_uint2(sp.z, sp.w);
 }
 
-template <> struct OutVec<bf16_t> {
+// 16-bit storage kinds (8 values per 16-byte vector)
+template <typename H> struct OutVecHalf {
     static constexpr int N = 8;
-    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
+    static __device__ __forceinline__ void load(const H* p, float (&v)[8]) { unpack(*reinterpret_cast<const uint4*>(p), v); }
     static __device__ __forceinline__ void unpack(const uint4 t, float (&v)[8]) {
         const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f((bf16_t)(u[e] & 0xffffu)); v[2 * e + 1] = bf2f((bf16_t)(u[e] >> 16)); }
+        for (int e = 0; e < 4; ++e) unpack2<H>(u[e], v[2 * e], v[2 * e + 1]);
     }
-    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    static __device__ __forceinline__ void store(H* p, const float (&v)[8]) {
         uint32_t u[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) u[e] = pack2bf(v[2 * e], v[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) u[e] = Half<H>::pack2(v[2 * e], v[2 * e + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
     }
     // round, then ReLU on the packed pairs (rounding is monotonic and sign-preserving: same result as ReLU in fp32 first)
-    static __device__ __forceinline__ void store_act(bf16_t* p, const float (&v)[8], bool relu) {
+    static __device__ __forceinline__ void store_act(H* p, const float (&v)[8], bool relu) {
         uint32_t u[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { u[e] = pack2bf(v[2 * e], v[2 * e + 1]); if (relu) u[e] = relu2bf(u[e]); }
+        for (int e = 0; e < 4; ++e) u[e] = relu ? Half<H>::pack2_relu(v[2 * e], v[2 * e + 1]) : Half<H>::pack2(v[2 * e], v[2 * e + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
     }
 };
+template <> struct OutVec<bf16_t> : OutVecHalf<bf16_t> {};
+template <> struct OutVec<f16s_t> : OutVecHalf<f16s_t> {};
 
 
 // pre-activation BN (+ReLU) applied to one 16-byte chunk of input channels starting at channel c
@@ -295,19 +355,24 @@ template <>
 __device__ __forceinline__ uint4 prologue<f16x3p_t>(uint4 v, const float*, const float*, int, bool) { return v; }      // (never instantiated with PRE)
 template <>
 __device__ __forceinline__ uint4 prologue<f16x1p_t>(uint4 v, const float*, const float*, int, bool) { return v; }
-template <>
-__device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) {
+template <typename H>
+__device__ __forceinline__ uint4 prologue_half(uint4 v, const float* ps, const float* pb, int c, bool relu) {
     uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float lo = bf2f((bf16_t)(u[e] & 0xffffu)), hi = bf2f((bf16_t)(u[e] >> 16));
+        float lo, hi;
+        unpack2<H>(u[e], lo, hi);
         lo = fmaf(lo, ps[c + 2 * e], pb[c + 2 * e]);
         hi = fmaf(hi, ps[c + 2 * e + 1], pb[c + 2 * e + 1]);
         if (relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-        u[e] = pack2bf(lo, hi);
+        u[e] = Half<H>::pack2(lo, hi);
     }
     return make_uint4(u[0], u[1], u[2], u[3]);
 }
+template <>
+__device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue_half<bf16_t>(v, ps, pb, c, relu); }
+template <>
+__device__ __forceinline__ uint4 prologue<f16s_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue_half<f16s_t>(v, ps, pb, c, relu); }
 
 // Epilogue of the 8-wave kernels (conv_pipe.hip, bonefuse.hip): tile of (32*MI*WM) x (32*NJ*WN), wave (wm, wn).
 // scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM (conv.hip's epilogue)
@@ -386,9 +451,9 @@ __device__ __forceinline__ void tile_of(const ConvArgs& a, int bid, int& tm, int
 }
 
 // conv_big.hip (DIR_CONV_VARIANT 11, the 256 x 256 block tile): returns true if it took the launch
-bool launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t s);
+bool launch_conv_big(const ConvArgs& a, bool out_f32, hipStream_t s, bool f16 = false);
 // conv_pipe.hip: returns true if it took the launch (bf16 input, no pre-activation, long reduction, enough tiles)
-bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s, int xm = 0);      // xm 3 / 1: both operands pre-split f16 (F16X3P / F16X1P)
+bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s, int xm = 0, bool f16 = false);      // xm 3 / 1: both operands pre-split f16 (F16X3P / F16X1P); f16: DIR_DT_F16 storage instead of bf16
 
 }  // namespace convk
 }  // namespace dir

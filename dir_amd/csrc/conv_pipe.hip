@@ -36,9 +36,10 @@ constexpr int PRE_MAX_CIN = 2304;      // pre-activation parameters staged in LD
 
 // XM: 0 = bf16 operands; 3 / 1 = both operands pre-split f16 hi | lo slabs (DIR_DT_F16X3P / F16X1P: 32 channels per 128-byte row, three / one
 // v_mfma_f32_32x32x16_f16 per product and k16-step) -- the same ring, the same slot plan with 6 / 2 instead of 4 MFMAs per tile and slab
-template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false, int NBUF = 3, int XM = 0>
+// TIN: the 16-bit storage kind of the operands when XM == 0 (bf16_t | f16s_t: same bytes and data path, the other matrix-core instruction)
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false, int NBUF = 3, int XM = 0, typename TIN = bf16_t>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) {
-    typedef bf16_t TI;
+    typedef TIN TI;
     static_assert(XM == 0 || (!SPARSE && !PRE && std::is_same<TO, float>::value), "pre-split operands: dense, no pre-activation, fp32 output");
     constexpr int NT = 64 * WM * WN;               // threads
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
             for (int i = 0; i < ACH; ++i) {
                 if ((amask[i] >> r_tap) & 1u) {                       // zero padding / M tail stay zero: conv pads the ACTIVATED input
                     uint4* cp = reinterpret_cast<uint4*>(base + i * (RPP * ROW));
-                    *cp = prologue<bf16_t>(*cp, s_pre, s_pre + PRE_MAX_CIN, r_c0 + col * EPC, pre_relu);
+                    *cp = prologue<TI>(*cp, s_pre, s_pre + PRE_MAX_CIN, r_c0 + col * EPC, pre_relu);
                 }
             }
             if (++r_tap == ntaps) { r_tap = 0; r_c0 += BK; }
@@ -273,8 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
                  constexpr int t = T;
                  constexpr int q = t / (MI * NJ), ij = t - q * (MI * NJ), i = ij / NJ, j = ij - i * NJ;
                  if constexpr (XM == 0) {
-                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[P][i][q]),
-                                                                         __builtin_bit_cast(bf16x8, fb[P][j][q]), acc[i][j], 0, 0, 0);
+                     acc[i][j] = Half<TI>::mfma32(fa[P][i][q], fb[P][j][q], acc[i][j]);
                  } else {           // q counts (k16-step, product): hi*hi, lo*hi, hi*lo (XM = 3) or hi*hi only (XM = 1)
                      constexpr int ks16 = XM == 3 ? q / 3 : q, part = XM == 3 ? q % 3 : 0;
                      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[P][i][2 * ks16 + (part == 1)]),
@@ -341,9 +341,9 @@ struct KPos {        // position in the (channel slab, tap) stream
 
 // PRELOAD (single channel slab, e.g. ResNet layer1's 3x3 64 -> 64): the patch AND every tap's weight slab are fetched in one
 // burst, one barrier, then all kh*kw taps run back to back with no ring, no counted waits and no per-tap barrier.
-template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRELOAD = false, int PMAX = PATCH_MAX_ROWS>
+template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRELOAD = false, int PMAX = PATCH_MAX_ROWS, typename TIN = bf16_t>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a, PatchGeom g) {
-    typedef bf16_t TI;
+    typedef TIN TI;
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
     constexpr int RPP = NT / 8;                        // rows per DMA pass of the workgroup
@@ -524,8 +524,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]),
-                                                                            __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = Half<TI>::mfma32(fa[i][q], fb[j][q], acc[i][j]);
             advance(cur);
         }
         __syncthreads();
@@ -591,8 +590,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]),
-                                                                        __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = Half<TI>::mfma32(fa[i][q], fb[j][q], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         if (!grp) {
             if (pp) wait_vmcnt<BCH + 1>();
@@ -636,7 +634,7 @@ static bool patch_geometry(const ConvArgs& a, int bm, PatchGeom* g) {
     return true;
 }
 
-template <typename TO, int MI, int NJ, int WM, int WN, int XM = 0>
+template <typename TO, int MI, int NJ, int WM, int WN, int XM = 0, typename TIN = bf16_t>
 void launch_tile(ConvArgs a, hipStream_t s) {
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -653,27 +651,27 @@ void launch_tile(ConvArgs a, hipStream_t s) {
     if (want_patch && !a.pre_scale && patch_geometry(a, BM, &g) && (!a.bbox || a.Cin / 64 <= 64)) {
         if constexpr (MI == 2 && NJ == 1 && WM == 4 && WN == 2) {      // 256x64: patch + 9 weight slabs = 125 KB
             if (!a.bbox && a.Cin == 64 && a.kh * a.kw <= 9) {
-                DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a, g);
+                DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, false, true, PATCH_MAX_ROWS, TIN>), grid, block, 0, s, a, g);
                 return;
             }
         }
-        if (a.bbox) DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a, g);
-        else DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a, g);
+        if (a.bbox) DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, true, false, PATCH_MAX_ROWS, TIN>), grid, block, 0, s, a, g);
+        else DIR_LAUNCH((conv_patch_kernel<TO, MI, NJ, WM, WN, false, false, PATCH_MAX_ROWS, TIN>), grid, block, 0, s, a, g);
         return;
     }
     if constexpr (!(MI == 2 && NJ == 2)) {                // pre-activation variant: the tiles whose ring leaves room for s_pre
         if (a.pre_scale) {
-            DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, false, true>), grid, block, 0, s, a);
+            DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, false, true, 3, 0, TIN>), grid, block, 0, s, a);
             return;
         }
     }
-    if (a.bbox) DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, true>), grid, block, 0, s, a);
-    else DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, false>), grid, block, 0, s, a);
+    if (a.bbox) DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, true, false, 3, 0, TIN>), grid, block, 0, s, a);
+    else DIR_LAUNCH((conv_pipe_kernel<TO, MI, NJ, WM, WN, false, false, 3, 0, TIN>), grid, block, 0, s, a);
 }
 
 }  // namespace
 
-bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s, int xm) {
+bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s, int xm, bool f16) {
     // DIR_PIPE: 0 = never, 1 = 256x128, 2 = 128x128, 3 = 256x64, unset = automatic (tuning aid)
     static const int force = getenv("DIR_PIPE") ? atoi(getenv("DIR_PIPE")) : -1;
     static const int min_nk = getenv("DIR_PIPE_MIN_NK") ? atoi(getenv("DIR_PIPE_MIN_NK")) : 8;
@@ -699,6 +697,14 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
             b.tiles_n = (b.Cout + 63) / 64;
             choose_tile_order(b, 2);
             const dim3 grid(b.tiles_m * b.tiles_n), block(512);
+            if (f16) {
+                if (pre) {
+                    if (out_f32) DIR_LAUNCH((conv_pipe_kernel<float, 1, 1, 4, 2, false, true, DIR_P15_NBUF, 0, f16s_t>), grid, block, 0, s, b);
+                    else DIR_LAUNCH((conv_pipe_kernel<f16s_t, 1, 1, 4, 2, false, true, DIR_P15_NBUF, 0, f16s_t>), grid, block, 0, s, b);
+                } else if (out_f32) DIR_LAUNCH((conv_pipe_kernel<float, 1, 1, 4, 2, false, false, DIR_P15_NBUF, 0, f16s_t>), grid, block, 0, s, b);
+                else DIR_LAUNCH((conv_pipe_kernel<f16s_t, 1, 1, 4, 2, false, false, DIR_P15_NBUF, 0, f16s_t>), grid, block, 0, s, b);
+                return true;
+            }
             if (pre) {
                 if (out_f32) DIR_LAUNCH((conv_pipe_kernel<float, 1, 1, 4, 2, false, true, DIR_P15_NBUF>), grid, block, 0, s, b);
                 else DIR_LAUNCH((conv_pipe_kernel<bf16_t, 1, 1, 4, 2, false, true, DIR_P15_NBUF>), grid, block, 0, s, b);
@@ -722,6 +728,8 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
     do {                                                                          \
         if (xm == 3) launch_tile<float, MI_, NJ_, WM_, WN_, 3>(b, s);             \
         else if (xm == 1) launch_tile<float, MI_, NJ_, WM_, WN_, 1>(b, s);        \
+        else if (f16 && out_f32) launch_tile<float, MI_, NJ_, WM_, WN_, 0, f16s_t>(b, s);   \
+        else if (f16) launch_tile<f16s_t, MI_, NJ_, WM_, WN_, 0, f16s_t>(b, s);   \
         else if (out_f32) launch_tile<float, MI_, NJ_, WM_, WN_>(b, s);           \
         else launch_tile<bf16_t, MI_, NJ_, WM_, WN_>(b, s);                       \
     } while (0)

@@ -22,6 +22,12 @@ template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { retur
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+// f16 STORAGE (DIR_DT_F16, round 5; csrc/conv_common.h): the same 2-byte layouts, IEEE binary16, stores clamped to +-65504
+struct f16s_t { unsigned short u; };
+__device__ __forceinline__ float h2f(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ unsigned short f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f)); }
+template <> __device__ __forceinline__ float ld<f16s_t>(const f16s_t* p) { return h2f(p->u); }
+template <> __device__ __forceinline__ void st<f16s_t>(f16s_t* p, float v) { p->u = f2h(v); }
 
 // 16-byte vectors of T
 template <typename T> struct Vec;
@@ -47,6 +53,22 @@ template <> struct Vec<bf16_t> {
         uint32_t u[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2bf(v[2 * e]) | ((uint32_t)f2bf(v[2 * e + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+template <> struct Vec<f16s_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const f16s_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = h2f((unsigned short)(u[e] & 0xffffu)); v[2 * e + 1] = h2f((unsigned short)(u[e] >> 16)); }
+    }
+    static __device__ __forceinline__ void store(f16s_t* p, const float (&v)[8]) {
+        uint32_t u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = (uint32_t)f2h(v[2 * e]) | ((uint32_t)f2h(v[2 * e + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(u[0], u[1], u[2], u[3]);
     }
 };
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(256) void bone_proj_kernel(BoneArgs a) {
 #pragma clang fp contract(off)
             v[e] = masked ? 0.f : fa[e] * wa + fb[e] * wb;             // models/dir.py:170-172
         }
-        if (sizeof(T) == 2) Vec<bf16_t>::store(reinterpret_cast<bf16_t*>(o), v);
+        if constexpr (sizeof(T) == 2) Vec<T>::store(o, v);
         else {
             const float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
             Vec<float>::store(reinterpret_cast<float*>(o), lo);
@@ -604,6 +626,7 @@ extern "C" int dir_stem_prep(const float* img_nchw, void* out, int B, int H, int
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) DIR_LAUNCH((stem_prep_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hp, Wp, pad);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((stem_prep_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hp, Wp, pad);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((stem_prep_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (f16s_t*)out, B, H, W, Hp, Wp, pad);
     else DIR_REQUIRE(false, "dir_stem_prep: bad dtype");
     return dir::check_launch("dir_stem_prep");
 }
@@ -615,6 +638,7 @@ extern "C" int dir_stem_prep_s2d(const float* img_nchw, void* out, int B, int H,
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) DIR_LAUNCH((stem_prep_s2d_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (float*)out, B, H, W, Hs, Ws);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((stem_prep_s2d_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (bf16_t*)out, B, H, W, Hs, Ws);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((stem_prep_s2d_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, img_nchw, (f16s_t*)out, B, H, W, Hs, Ws);
     else DIR_REQUIRE(false, "dir_stem_prep_s2d: bad dtype");
     return dir::check_launch("dir_stem_prep_s2d");
 }
@@ -650,6 +674,7 @@ extern "C" int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) DIR_LAUNCH((stem_prep_s2d_u8_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (float*)out, B, H, W, Hs, Ws, nm);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((stem_prep_s2d_u8_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (bf16_t*)out, B, H, W, Hs, Ws, nm);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((stem_prep_s2d_u8_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, img_bgr_hwc, (f16s_t*)out, B, H, W, Hs, Ws, nm);
     else DIR_REQUIRE(false, "dir_stem_prep_s2d_u8: bad dtype");
     return dir::check_launch("dir_stem_prep_s2d_u8");
 }
@@ -662,6 +687,7 @@ extern "C" int dir_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) DIR_LAUNCH((maxpool_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, Ho, Wo);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((maxpool_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, Ho, Wo);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((maxpool_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, (const f16s_t*)x, (f16s_t*)y, B, H, W, C, Ho, Wo);
     else DIR_REQUIRE(false, "dir_maxpool3x3s2: bad dtype");
     return dir::check_launch("dir_maxpool3x3s2");
 }
@@ -673,6 +699,7 @@ extern "C" int dir_add_upsampled(void* acc, const void* src, int B, int H, int W
     hipStream_t s = (hipStream_t)stream;
     if (dtype == DIR_DT_F32) DIR_LAUNCH((add_upsampled_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (float*)acc, (const float*)src, B, H, W, C, factor, relu);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((add_upsampled_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)acc, (const bf16_t*)src, B, H, W, C, factor, relu);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((add_upsampled_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, (f16s_t*)acc, (const f16s_t*)src, B, H, W, C, factor, relu);
     else DIR_REQUIRE(false, "dir_add_upsampled: bad dtype");
     return dir::check_launch("dir_add_upsampled");
 }
@@ -688,6 +715,7 @@ extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int
     const dim3 grid((unsigned)((n + 255) / 256));
     if (dtype == DIR_DT_F32) DIR_LAUNCH((upsample_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C, ocs, out_coff);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((upsample_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, ocs, out_coff);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((upsample_kernel<f16s_t>), grid, dim3(256), 0, s, (const f16s_t*)x, (f16s_t*)y, B, H, W, C, ocs, out_coff);
     else DIR_REQUIRE(false, "dir_upsample2x_bilinear: bad dtype");
     return dir::check_launch("dir_upsample2x_bilinear");
 }
@@ -708,6 +736,7 @@ extern "C" int dir_init_head_forward(const dir_init_head_params* p, const void* 
     a.stamps = dir::stamps_begin("init_head");
     if (dtype == DIR_DT_F32) DIR_LAUNCH((init_head_kernel<float>), dim3(B), dim3(512), lds, s, a);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((init_head_kernel<bf16_t>), dim3(B), dim3(512), lds, s, a);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((init_head_kernel<f16s_t>), dim3(B), dim3(512), lds, s, a);
     else DIR_REQUIRE(false, "dir_init_head_forward: bad dtype");
     dir::stamps_end("init_head", a.stamps, s);
     return dir::check_launch("dir_init_head_forward");
@@ -731,6 +760,7 @@ extern "C" int dir_bone_proj_forward(const float* uv_left, const float* uv_right
     }
     if (dtype == DIR_DT_F32) DIR_LAUNCH((bone_proj_kernel<float>), dim3(B * S), dim3(256), lds, s, a);
     else if (dtype == DIR_DT_BF16) DIR_LAUNCH((bone_proj_kernel<bf16_t>), dim3(B * S), dim3(256), lds, s, a);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((bone_proj_kernel<f16s_t>), dim3(B * S), dim3(256), lds, s, a);
     else DIR_REQUIRE(false, "dir_bone_proj_forward: bad dtype");
     return dir::check_launch("dir_bone_proj_forward");
 }

@@ -23,9 +23,8 @@ namespace dir {
 namespace {
 
 using convk::bf16_t;
-using convk::bf16x8;
-using convk::bf2f;
-using convk::f2bf;
+using convk::f16s_t;
+using convk::Half;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -34,14 +33,13 @@ typedef __attribute__((ext_vector_type(2))) short i16x2;
 // The VALU work per conv output is what bounds this kernel (75.8 M outputs at B = 64), so the epilogue and the pooling run on
 // packed instructions: v_cvt_pk_bf16_f32 (round to nearest even, = convk::f2bf on finite values),
 // and ReLU / max as v_pk_max_i16 on the bf16 bit patterns (sign bit set -> negative int16 -> 0; non-negative bf16 order = int16 order).
-__device__ __forceinline__ unsigned pack_bf16(f32x2 v) {
-    const bf16x2 b = __builtin_convertvector(v, bf16x2);
-    return __builtin_bit_cast(unsigned, b);
-}
+// H = the 16-bit storage kind of the output, the LDS tiles and the weights (bf16_t | f16s_t); f16 clamps to +-65504 first.  The packed
+// max works on f16 bit patterns for the same reason (non-negative values: integer order = float order).
+template <typename H> __device__ __forceinline__ unsigned pack_h(f32x2 v) { return Half<H>::pack2(v[0], v[1]); }
 __device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, a), __builtin_bit_cast(i16x2, b)));
 }
-__device__ __forceinline__ bf16_t cvt_bf16(float v) { return (bf16_t)(pack_bf16(f32x2{v, 0.f}) & 0xffffu); }
+template <typename H> __device__ __forceinline__ bf16_t cvt_h(float v) { return (bf16_t)(pack_h<H>(f32x2{v, 0.f}) & 0xffffu); }
 
 constexpr int TP = 8;                    // pooled tile edge
 constexpr int CR = 2 * TP + 1;           // conv rows / cols per tile (17)
@@ -62,13 +60,13 @@ __device__ __forceinline__ float norm_px(unsigned char v, float mean, float stdv
 }
 
 struct StemArgs {
-    const void* img; const bf16x8* w; const float* scale; const float* shift; bf16_t* y;
+    const void* img; const convk::u32x4* w; const float* scale; const float* shift; bf16_t* y;
     int B, H, W, Hc, Wc, Hp, Wp, tiles_y, tiles_x, ntiles;
     NormArgs nm;
     long long* stamps;      // DIR_STAMPS=stem (tuning aid, else NULL): workgroup 0, one stamp per phase of its first tiles
 };
 
-template <bool U8>
+template <bool U8, typename H = bf16_t>
 __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
     __shared__ __attribute__((aligned(16))) char s_patch[PR * PPITCH];
     __shared__ __attribute__((aligned(16))) char s_conv[NPIX * CPITCH];
@@ -82,11 +80,11 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
     if (tid < 64) { s_ss[tid] = a.scale[tid]; s_ss[64 + tid] = a.shift[tid]; }
     if constexpr (U8) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_lut[c * 256 + tid] = cvt_bf16(norm_px((unsigned char)tid, a.nm.mean[c], a.nm.stdv[c]));
+        for (int c = 0; c < 3; ++c) s_lut[c * 256 + tid] = cvt_h<H>(norm_px((unsigned char)tid, a.nm.mean[c], a.nm.stdv[c]));
     }
 
     // weights: A fragments, row = channel 16*mt + li, k = ky*32 + 8*g .. +8   (a.w = [64][28] 16-byte vectors)
-    bf16x8 wf[4][7];
+    convk::u32x4 wf[4][7];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -141,19 +139,19 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
             for (int k = 0; k < RH; ++k)
                 if (half * RH + k < PR) {
                     bf16_t v;
-                    if constexpr (U8) v = s_lut[pc * 256 + pre[k]]; else v = cvt_bf16(pre[k]);
+                    if constexpr (U8) v = s_lut[pc * 256 + pre[k]]; else v = cvt_h<H>(pre[k]);
                     sp[((half * RH + k) * PW + pcol) * 4 + pc] = (okmask >> k) & 1u ? v : (bf16_t)0;
                 }
         }
     };
     // B fragments of one 16-pixel column tile: step ky = the two patch pixels (2 xc + 2 g, +1) of patch row 2 yc + ky
-    auto load_b = [&](int nt, bf16x8 (&bv)[7]) {
+    auto load_b = [&](int nt, uint4 (&bv)[7]) {
         const int n = nt * 16 + li;
         const int pix = n < NPIX ? n : NPIX - 1;
         const int yc = pix / CR, xc = pix - yc * CR;
         const char* bp = s_patch + (2 * yc) * PPITCH + (2 * xc + 2 * g) * 8;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) bv[ky] = *reinterpret_cast<const bf16x8*>(bp + ky * PPITCH);
+        for (int ky = 0; ky < 7; ++ky) bv[ky] = *reinterpret_cast<const uint4*>(bp + ky * PPITCH);
     };
 
     if (t < tend) fetch(t);
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
         tile_origin(t, b, py0, px0);
         // ---- conv pixels of this tile
         for (int nt = wave; nt < NTILE; nt += 4) {
-            bf16x8 bcur[7];
+            uint4 bcur[7];
             load_b(nt, bcur);                                     // all 7 reads in flight; the MFMAs consume them as they land
             __builtin_amdgcn_sched_barrier(0);
             const int n = nt * 16 + li;
@@ -184,7 +182,7 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
 #pragma unroll
             for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][ky], bcur[ky], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = Half<H>::mfma16(wf[mt][ky], bcur[ky], acc[mt]);
             {
                 const int nn = n < NPIX ? n : NPIX - 1;              // lanes past the last pixel rewrite pixel 288 with its own value
                 const int yc = nn / CR, xc = nn - yc * CR;
@@ -202,8 +200,8 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
                         const f32x2 v01 = f32x2{acc[mt][0], acc[mt][1]} * f32x2{sc[mt].x, sc[mt].y} + f32x2{sh[mt].x, sh[mt].y};
                         const f32x2 v23 = f32x2{acc[mt][2], acc[mt][3]} * f32x2{sc[mt].z, sc[mt].w} + f32x2{sh[mt].z, sh[mt].w};
                         uint2 o;
-                        o.x = pk_max_i16(pack_bf16(v01), 0u) & vm;
-                        o.y = pk_max_i16(pack_bf16(v23), 0u) & vm;
+                        o.x = pk_max_i16(pack_h<H>(v01), 0u) & vm;
+                        o.y = pk_max_i16(pack_h<H>(v23), 0u) & vm;
                         *reinterpret_cast<uint2*>(s_conv + n * CPITCH + (16 * mt + 4 * g) * 2) = o;
                     }
                 }
@@ -244,14 +242,15 @@ __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
 // w_packed: [64][7][8][4] bf16 = w[n, c, ky, kx] at [n][ky][kx][c], zero for kx = 7 and c = 3; scale / shift: folded bn1.
 // img: fp32 NCHW [B,3,H,W] (img_dtype DIR_DT_F32, already normalised) or uint8 BGR HWC [B,H,W,3] (DIR_DT_U8; mean / std =
 // host pointers to 3 floats).  y: bf16 NHWC [B, H/4, W/4, 64].
-extern "C" int dir_stem_pool_forward(const void* img, int img_dtype, const float* mean_host, const float* std_host, const void* w_packed,
-                                     const float* scale, const float* shift, void* y, int B, int H, int W, void* stream) {
+extern "C" int dir_stem_pool_forward_dt(const void* img, int img_dtype, int out_dtype, const float* mean_host, const float* std_host, const void* w_packed,
+                                        const float* scale, const float* shift, void* y, int B, int H, int W, void* stream) {
     using namespace dir;
+    DIR_REQUIRE(out_dtype == DIR_DT_BF16 || out_dtype == DIR_DT_F16, "dir_stem_pool_forward_dt: out_dtype must be DIR_DT_BF16 or DIR_DT_F16");
     DIR_REQUIRE(img && w_packed && scale && shift && y && B > 0, "dir_stem_pool_forward: bad args");
     DIR_REQUIRE(H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "dir_stem_pool_forward: H and W must be positive multiples of 4");
     DIR_REQUIRE(img_dtype == DIR_DT_F32 || img_dtype == DIR_DT_U8, "dir_stem_pool_forward: img_dtype must be DIR_DT_F32 or DIR_DT_U8");
     StemArgs a;
-    a.img = img; a.w = (const convk::bf16x8*)w_packed; a.scale = scale; a.shift = shift; a.y = (convk::bf16_t*)y;
+    a.img = img; a.w = (const convk::u32x4*)w_packed; a.scale = scale; a.shift = shift; a.y = (convk::bf16_t*)y;
     a.B = B; a.H = H; a.W = W; a.Hc = H / 2; a.Wc = W / 2; a.Hp = H / 4; a.Wp = W / 4;
     a.tiles_y = (a.Hp + TP - 1) / TP; a.tiles_x = (a.Wp + TP - 1) / TP;
     const long long nt = (long long)B * a.tiles_y * a.tiles_x;
@@ -273,8 +272,16 @@ extern "C" int dir_stem_pool_forward(const void* img, int img_dtype, const float
     const int grid = (int)(nt < 2ll * num_cu ? nt : 2ll * num_cu);
     hipStream_t s = (hipStream_t)stream;
     a.stamps = dir::stamps_begin("stem");
-    if (img_dtype == DIR_DT_U8) DIR_LAUNCH((stem_pool_kernel<true>), dim3(grid), dim3(NTHR), 0, s, a);
-    else DIR_LAUNCH((stem_pool_kernel<false>), dim3(grid), dim3(NTHR), 0, s, a);
+    if (out_dtype == DIR_DT_F16) {
+        if (img_dtype == DIR_DT_U8) DIR_LAUNCH((stem_pool_kernel<true, f16s_t>), dim3(grid), dim3(NTHR), 0, s, a);
+        else DIR_LAUNCH((stem_pool_kernel<false, f16s_t>), dim3(grid), dim3(NTHR), 0, s, a);
+    } else if (img_dtype == DIR_DT_U8) DIR_LAUNCH((stem_pool_kernel<true, bf16_t>), dim3(grid), dim3(NTHR), 0, s, a);
+    else DIR_LAUNCH((stem_pool_kernel<false, bf16_t>), dim3(grid), dim3(NTHR), 0, s, a);
     dir::stamps_end("stem", a.stamps, s);
     return check_launch("dir_stem_pool_forward");
+}
+
+extern "C" int dir_stem_pool_forward(const void* img, int img_dtype, const float* mean_host, const float* std_host, const void* w_packed,
+                                     const float* scale, const float* shift, void* y, int B, int H, int W, void* stream) {
+    return dir_stem_pool_forward_dt(img, img_dtype, DIR_DT_BF16, mean_host, std_host, w_packed, scale, shift, y, B, H, W, stream);
 }

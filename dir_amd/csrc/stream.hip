@@ -25,10 +25,9 @@ namespace dir {
 namespace {
 
 using convk::bf16_t;
-using convk::bf16x8;
+using convk::f16s_t;
 using convk::f32x16;
-using convk::pack2bf;
-using convk::relu2bf;
+using convk::Half;
 
 constexpr int SBM = 128;               // pixels per workgroup (NPB = 4 blocks of 32; the NPB = 2 variant: 64)
 constexpr int SKC = 64;                // channels per K-chunk
@@ -45,7 +44,8 @@ struct StreamArgs {
 
 // NCB: 32-channel blocks per wave (1: 128 output channels per workgroup, 2: 256); NPB: 32-pixel blocks per workgroup (4: 128 pixels; 2: 64 pixels --
 // twice the workgroups, each half as long: more of them per CU in different phases for the layers whose 128-pixel grid is only two tiles per CU)
-template <int NCB, bool PRE, int NPB>
+// H: the 16-bit storage kind of activations, weights and outputs (bf16_t | f16s_t: DIR_DT_BF16 | DIR_DT_F16)
+template <int NCB, bool PRE, int NPB, typename H = bf16_t>
 __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(StreamArgs a) {
     constexpr int SBM = 32 * NPB;
     constexpr int NWG = 128 * NCB;                         // output channels per workgroup
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
             const int row = (tid >> 3) + 32 * i;
             uint4 v = r[i];
             if constexpr (PRE) {
-                if (c < a.nk1) v = convk::prologue<bf16_t>(v, s_pre, s_pre + PRE_MAX, c * SKC + col * 8, a.pre_relu != 0);
+                if (c < a.nk1) v = convk::prologue<H>(v, s_pre, s_pre + PRE_MAX, c * SKC + col * 8, a.pre_relu != 0);
             }
             if (!ok[i]) v = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(s_a[buf] + row * 128 + ((col ^ ((row >> 1) & 7)) << 4)) = v;
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
     };
     // ---- weight fragments of a chunk: [4 k-steps][NCB]
     const uint4* wbase = a.w + ((long long)(nchunk * 4 + wave) * a.nk) * (4 * NCB * 64) + lane;
-    auto w_load = [&](int c, bf16x8 (&wr)[4][NCB]) {
+    auto w_load = [&](int c, uint4 (&wr)[4][NCB]) {
         const uint4* p = wbase + (long long)min(c, a.nk - 1) * (4 * NCB * 64);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) wr[ks][cb] = __builtin_bit_cast(bf16x8, p[(ks * NCB + cb) * 64]);
+            for (int cb = 0; cb < NCB; ++cb) wr[ks][cb] = p[(ks * NCB + cb) * 64];
     };
 
     f32x16 acc[NCB][NPB];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
             for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
 
     uint4 ar[2][NPB];
-    bf16x8 wr[2][4][NCB];
+    uint4 wr[2][4][NCB];
     w_load(0, wr[0]);
     a_load(0, ar[0]);
     a_load(1, ar[1]);
@@ -138,17 +138,17 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
         if (c < a.nk) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 bv[NPB];
+            uint4 bv[NPB];
 #pragma unroll
             for (int pb = 0; pb < NPB; ++pb) {
                 const int row = 32 * pb + l32;
-                bv[pb] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + (((ks + 4 * h) ^ ((row >> 1) & 7)) << 4));
+                bv[pb] = *reinterpret_cast<const uint4*>(sa + row * 128 + (((ks + 4 * h) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb)
-                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[par][ks][cb], bv[pb], acc[cb][pb], 0, 0, 0);
+                    acc[cb][pb] = Half<H>::mfma32(wr[par][ks][cb], bv[pb], acc[cb][pb]);
         }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -180,9 +180,10 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
 #pragma unroll
                 for (int pb = 0; pb < NPB; ++pb) {
                     uint2 o;
-                    o.x = pack2bf(fmaf(acc[cb][pb][4 * q], sc.x, sh.x), fmaf(acc[cb][pb][4 * q + 1], sc.y, sh.y));
-                    o.y = pack2bf(fmaf(acc[cb][pb][4 * q + 2], sc.z, sh.z), fmaf(acc[cb][pb][4 * q + 3], sc.w, sh.w));
-                    if (relu) { o.x = relu2bf(o.x); o.y = relu2bf(o.y); }
+                    const float v0 = fmaf(acc[cb][pb][4 * q], sc.x, sh.x), v1 = fmaf(acc[cb][pb][4 * q + 1], sc.y, sh.y);
+                    const float v2 = fmaf(acc[cb][pb][4 * q + 2], sc.z, sh.z), v3 = fmaf(acc[cb][pb][4 * q + 3], sc.w, sh.w);
+                    if (relu) { o.x = Half<H>::pack2_relu(v0, v1); o.y = Half<H>::pack2_relu(v2, v3); }
+                    else { o.x = Half<H>::pack2(v0, v1); o.y = Half<H>::pack2(v2, v3); }
                     *reinterpret_cast<uint2*>(s_raw + (32 * pb + l32) * OPITCH + (nl - 128 * half) * 2) = o;
                 }
             }
@@ -209,7 +210,8 @@ extern "C" int dir_conv1x1_stream_forward(const dir_conv_desc* d, const void* x,
     using namespace dir;
     DIR_REQUIRE(d && x && w_stream && y, "dir_conv1x1_stream_forward: null pointer");
     DIR_REQUIRE(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0, "dir_conv1x1_stream_forward: 1x1 stride-1 convolutions only");
-    DIR_REQUIRE(d->in_dtype == DIR_DT_BF16 && d->out_dtype == DIR_DT_BF16, "dir_conv1x1_stream_forward: bf16 only");
+    DIR_REQUIRE((d->in_dtype == DIR_DT_BF16 || d->in_dtype == DIR_DT_F16) && d->out_dtype == d->in_dtype, "dir_conv1x1_stream_forward: bf16 -> bf16 or f16 -> f16 only");
+    const bool f16 = d->in_dtype == DIR_DT_F16;
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % SKC == 0 && d->Cout > 0 && d->Cout % 128 == 0,
                 "dir_conv1x1_stream_forward: Cin must be a multiple of 64, Cout of 128");
     DIR_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr) && (!pre_scale || d->Cin <= PRE_MAX), "dir_conv1x1_stream_forward: bad pre-activation");
@@ -238,9 +240,10 @@ extern "C" int dir_conv1x1_stream_forward(const dir_conv_desc* d, const void* x,
     const int var = (d->flags >> 8) & 0xff;                 // 22: 64-pixel workgroups, 23: 32-pixel workgroups
     const int sbm = var == 22 ? 64 : var == 23 ? 32 : 128;
     const int tiles = (a.M + sbm - 1) / sbm;
-#define DIR_STREAM(NCB_, PRE_) do { if (var == 22) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 2>), grid, dim3(STHR), 0, s, a); \
-                                    else if (var == 23) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 1>), grid, dim3(STHR), 0, s, a); \
-                                    else DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 4>), grid, dim3(STHR), 0, s, a); } while (0)
+#define DIR_STREAM_H(NCB_, PRE_, H_) do { if (var == 22) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 2, H_>), grid, dim3(STHR), 0, s, a); \
+                                    else if (var == 23) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 1, H_>), grid, dim3(STHR), 0, s, a); \
+                                    else DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 4, H_>), grid, dim3(STHR), 0, s, a); } while (0)
+#define DIR_STREAM(NCB_, PRE_) do { if (f16) DIR_STREAM_H(NCB_, PRE_, convk::f16s_t); else DIR_STREAM_H(NCB_, PRE_, convk::bf16_t); } while (0)
     if (d->Cout % 256 == 0) {
         dim3 grid(tiles, d->Cout / 256);
         if (pre_scale) DIR_STREAM(2, true); else DIR_STREAM(2, false);
@@ -249,5 +252,6 @@ extern "C" int dir_conv1x1_stream_forward(const dir_conv_desc* d, const void* x,
         if (pre_scale) DIR_STREAM(1, true); else DIR_STREAM(1, false);
     }
 #undef DIR_STREAM
+#undef DIR_STREAM_H
     return check_launch("dir_conv1x1_stream_forward");
 }

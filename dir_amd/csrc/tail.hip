@@ -27,10 +27,9 @@ namespace dir {
 namespace {
 
 using convk::bf16_t;
-using convk::bf16x8;
+using convk::f16s_t;
 using convk::f32x16;
-using convk::pack2bf;
-using convk::relu2bf;
+using convk::Half;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 // The activations are touched once per launch; the weight stream is re-read by every workgroup.  DIR_TAIL_NT (compile-time A/B
@@ -67,14 +66,15 @@ struct TailArgs {
     int ntiles; unsigned y2_bytes;
 };
 
-__device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
-    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+template <typename H> __device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
+    convk::unpack2<H>(v.x, f[0], f[1]);
+    convk::unpack2<H>(v.y, f[2], f[3]);
 }
 
 // P: planes (K of conv3); N2: output channels of the next conv1 (128: 16 per wave on v_mfma_f32_16x16x32_bf16; 256: 32 per wave
 // on v_mfma_f32_32x32x16_bf16)
-template <int P, int N2>
+// H: the 16-bit storage kind (bf16_t | f16s_t = DIR_DT_BF16 | DIR_DT_F16): tensors, weight stream and the T tile
+template <int P, int N2, typename H = bf16_t>
 __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
     constexpr int C4 = 4 * P, NH = C4 / HC;
     constexpr int YROW = P * 2;                         // bytes per y2 pixel (unpadded: 16-byte chunk c of row r sits at c ^ (r & 15))
@@ -141,12 +141,12 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
 #endif
     };
     // ---- weight stream of this wave: fragment f of half hf at wstream[((hf * 8 + wave) * NF + f) * 64 + lane]
-    bf16x8 ring[2][GRP];
+    uint4 ring[2][GRP];
     auto ring_load = [&](auto Slot, int hf, int grp) {
         constexpr int slot = decltype(Slot)::value;
         const uint4* p = a.wstream + ((long long)(hf * 8 + wave) * NF + grp * GRP) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < GRP; ++i) ring[slot][i] = __builtin_bit_cast(bf16x8, p[i * 64]);
+        for (int i = 0; i < GRP; ++i) ring[slot][i] = p[i * 64];
     };
 
     y2_dma(t, 0);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
     f32x4 accc16[C16 ? 4 : 1];                           // next conv1, 16x16 path: [16-pixel group]
     // activation (MFMA B) operands of a fragment step, read from LDS one step ahead of the MFMAs that use them
     constexpr int NOP = C16 ? 4 : 2;
-    bf16x8 bop[2][NOP];
+    uint4 bop[2][NOP];
     const char* ycur = s_y2[0];
     auto act_read = [&](auto F, auto Set) {
         constexpr int f = decltype(F)::value, set = decltype(Set)::value;
@@ -169,15 +169,15 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
             constexpr int ks = f % KBS;
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
-                bop[set][pb] = *reinterpret_cast<const bf16x8*>(ycur + (32 * pb + l32) * YROW + (((2 * ks + h) ^ (l32 & 15)) << 4));
+                bop[set][pb] = *reinterpret_cast<const uint4*>(ycur + (32 * pb + l32) * YROW + (((2 * ks + h) ^ (l32 & 15)) << 4));
         } else {
             constexpr int fc = f - NBF;
             if constexpr (C16) {                         // T[pixel 16 u + l16][32 fc + 8 g ..]
 #pragma unroll
-                for (int u = 0; u < 4; ++u) bop[set][u] = *reinterpret_cast<const bf16x8*>(s_t + (16 * u + l16) * TPITCH + 64 * fc + 16 * g16);
+                for (int u = 0; u < 4; ++u) bop[set][u] = *reinterpret_cast<const uint4*>(s_t + (16 * u + l16) * TPITCH + 64 * fc + 16 * g16);
             } else {                                     // T[pixel 32 pb + l32][16 fc + 8 h ..]
 #pragma unroll
-                for (int pb = 0; pb < 2; ++pb) bop[set][pb] = *reinterpret_cast<const bf16x8*>(s_t + (32 * pb + l32) * TPITCH + 32 * fc + 16 * h);
+                for (int pb = 0; pb < 2; ++pb) bop[set][pb] = *reinterpret_cast<const uint4*>(s_t + (32 * pb + l32) * TPITCH + 32 * fc + 16 * h);
             }
         }
     };
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
                                   }
 #pragma unroll
                                   for (int pb = 0; pb < 2; ++pb)
-                                      accb[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set][pb], accb[pb], 0, 0, 0);
+                                      accb[pb] = Half<H>::mfma32(ring[slot][I], bop[set][pb], accb[pb]);
                                   if constexpr (ks == KBS - 1) {
                                       // ---- epilogue B of this channel block -> T: bn3 + residual + ReLU, bf16
 #pragma unroll
@@ -241,16 +241,16 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
                                                   const uint4 c = xr[cb][pb][q >> 1];
                                                   const auto sx = __builtin_amdgcn_permlane32_swap(c.x, c.z, false, false);
                                                   const auto sy = __builtin_amdgcn_permlane32_swap(c.y, c.w, false, false);
-                                                  unpack4(make_uint2(sx[q & 1], sy[q & 1]), rv);
+                                                  unpack4<H>(make_uint2(sx[q & 1], sy[q & 1]), rv);
                                               }
 #else
-                                              unpack4(xr[cb][pb][q], rv);
+                                              unpack4<H>(xr[cb][pb][q], rv);
 #endif
 #pragma unroll
                                               for (int e = 0; e < 4; ++e) v[e] += rv[e];
                                               uint2 o;
-                                              o.x = relu2bf(pack2bf(v[0], v[1]));
-                                              o.y = relu2bf(pack2bf(v[2], v[3]));
+                                              o.x = Half<H>::pack2_relu(v[0], v[1]);
+                                              o.y = Half<H>::pack2_relu(v[2], v[3]);
                                               *reinterpret_cast<uint2*>(s_t + (32 * pb + l32) * TPITCH + cl * 2) = o;
                                           }
                                           __builtin_amdgcn_sched_barrier(0);          // keep the (sc, sh) reads of later q's out of this one's registers
@@ -276,11 +276,11 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
                                   if constexpr (C16) {
 #pragma unroll
                                       for (int u = 0; u < 4; ++u)
-                                          accc16[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[slot][I], bop[set][u], accc16[u], 0, 0, 0);
+                                          accc16[u] = Half<H>::mfma16(ring[slot][I], bop[set][u], accc16[u]);
                                   } else {
 #pragma unroll
                                       for (int pb = 0; pb < 2; ++pb)
-                                          accc32[pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set][pb], accc32[pb], 0, 0, 0);
+                                          accc32[pb] = Half<H>::mfma32(ring[slot][I], bop[set][pb], accc32[pb]);
                                   }
                               }
                               // the next tile's y2 DMA is the oldest thing this wave can still have in flight: everything but the ring
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         uint2 o;
-                        o.x = relu2bf(pack2bf(fmaf(accc16[u][0], sc.x, sh.x), fmaf(accc16[u][1], sc.y, sh.y)));
-                        o.y = relu2bf(pack2bf(fmaf(accc16[u][2], sc.z, sh.z), fmaf(accc16[u][3], sc.w, sh.w)));
+                        o.x = Half<H>::pack2_relu(fmaf(accc16[u][0], sc.x, sh.x), fmaf(accc16[u][1], sc.y, sh.y));
+                        o.y = Half<H>::pack2_relu(fmaf(accc16[u][2], sc.z, sh.z), fmaf(accc16[u][3], sc.w, sh.w));
                         *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TM + 16 * u + l16) * N2 + c0) = o;
                     }
                 } else {
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
                             const int c0 = 32 * wave + 8 * q + 4 * h;
                             const float4 sc = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + c0);
                             const float4 sh = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + N2 + c0);
-                            o[q].x = relu2bf(pack2bf(fmaf(accc32[pb][4 * q], sc.x, sh.x), fmaf(accc32[pb][4 * q + 1], sc.y, sh.y)));
-                            o[q].y = relu2bf(pack2bf(fmaf(accc32[pb][4 * q + 2], sc.z, sh.z), fmaf(accc32[pb][4 * q + 3], sc.w, sh.w)));
+                            o[q].x = Half<H>::pack2_relu(fmaf(accc32[pb][4 * q], sc.x, sh.x), fmaf(accc32[pb][4 * q + 1], sc.y, sh.y));
+                            o[q].y = Half<H>::pack2_relu(fmaf(accc32[pb][4 * q + 2], sc.z, sh.z), fmaf(accc32[pb][4 * q + 3], sc.w, sh.w));
                         }
 #if DIR_TAIL_RES16
                         // the residual fetch's swap in reverse: lane half h ends up with channels 16 j + 8 h .. + 8 -- one 16-byte store per j
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
 // (dir_amd/engine.py::pack_tail_stream(..., waves=4)).
 constexpr int TTM = 32, TTHR = 256;
 
-template <int P, int N2>
+template <int P, int N2, typename H = bf16_t>
 __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
     constexpr int C4 = 4 * P, NH = C4 / HC;
     constexpr int YROW = P * 2;
@@ -393,12 +393,12 @@ __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) xr[cb][q] = NT_LOAD(reinterpret_cast<const uint2*>(rp + 32 * cb + 8 * q));
     };
-    bf16x8 ring[2][GRP];
+    uint4 ring[2][GRP];
     auto ring_load = [&](auto Slot, int hf, int grp) {
         constexpr int slot = decltype(Slot)::value;
         const uint4* p = a.wstream + ((long long)(hf * 4 + wave) * NF + grp * GRP) * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < GRP; ++i) ring[slot][i] = __builtin_bit_cast(bf16x8, p[i * 64]);
+        for (int i = 0; i < GRP; ++i) ring[slot][i] = p[i * 64];
     };
 
     y2_dma(t, 0);
@@ -410,16 +410,16 @@ __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
 
     f32x16 accb;
     f32x16 accc[NCC];
-    bf16x8 bop[2];
+    uint4 bop[2];
     const char* ycur = s_y2[0];
     auto act_read = [&](auto F, auto Set) {
         constexpr int f = decltype(F)::value, set = decltype(Set)::value;
         if constexpr (f < NBF) {
             constexpr int ks = f % KBS;
-            bop[set] = *reinterpret_cast<const bf16x8*>(ycur + l32 * YROW + (((2 * ks + h) ^ (l32 & 15)) << 4));
+            bop[set] = *reinterpret_cast<const uint4*>(ycur + l32 * YROW + (((2 * ks + h) ^ (l32 & 15)) << 4));
         } else {
             constexpr int ks = (f - NBF) / NCC;
-            bop[set] = *reinterpret_cast<const bf16x8*>(s_t + l32 * TPITCH + 32 * ks + 16 * h);
+            bop[set] = *reinterpret_cast<const uint4*>(s_t + l32 * TPITCH + 32 * ks + 16 * h);
         }
     };
 
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
 #pragma unroll
                                       for (int r = 0; r < 16; ++r) accb[r] = 0.f;
                                   }
-                                  accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set], accb, 0, 0, 0);
+                                  accb = Half<H>::mfma32(ring[slot][I], bop[set], accb);
                                   if constexpr (ks == KBS - 1) {
 #pragma unroll
                                       for (int q = 0; q < 4; ++q) {
@@ -467,12 +467,12 @@ __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
                                           float v[4] = {fmaf(accb[4 * q], sc.x, sh.x), fmaf(accb[4 * q + 1], sc.y, sh.y),
                                                         fmaf(accb[4 * q + 2], sc.z, sh.z), fmaf(accb[4 * q + 3], sc.w, sh.w)};
                                           float rv[4];
-                                          unpack4(xr[cb][q], rv);
+                                          unpack4<H>(xr[cb][q], rv);
 #pragma unroll
                                           for (int e = 0; e < 4; ++e) v[e] += rv[e];
                                           uint2 o;
-                                          o.x = relu2bf(pack2bf(v[0], v[1]));
-                                          o.y = relu2bf(pack2bf(v[2], v[3]));
+                                          o.x = Half<H>::pack2_relu(v[0], v[1]);
+                                          o.y = Half<H>::pack2_relu(v[2], v[3]);
                                           *reinterpret_cast<uint2*>(s_t + l32 * TPITCH + cl * 2) = o;
                                       }
                                   }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
                                   }
                               } else {
                                   constexpr int cc = (f - NBF) % NCC;
-                                  accc[cc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[slot][I], bop[set], accc[cc], 0, 0, 0);
+                                  accc[cc] = Half<H>::mfma32(ring[slot][I], bop[set], accc[cc]);
                               }
                               if constexpr (f == NF - 1) convk::wait_vmcnt<GRP>();
                               __builtin_amdgcn_sched_barrier(0);
@@ -510,8 +510,8 @@ __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
                         const float4 sc = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + c0);
                         const float4 sh = *reinterpret_cast<const float4*>(s_ss + 2 * C4 + N2 + c0);
                         uint2 o;
-                        o.x = relu2bf(pack2bf(fmaf(accc[cc][4 * q], sc.x, sh.x), fmaf(accc[cc][4 * q + 1], sc.y, sh.y)));
-                        o.y = relu2bf(pack2bf(fmaf(accc[cc][4 * q + 2], sc.z, sh.z), fmaf(accc[cc][4 * q + 3], sc.w, sh.w)));
+                        o.x = Half<H>::pack2_relu(fmaf(accc[cc][4 * q], sc.x, sh.x), fmaf(accc[cc][4 * q + 1], sc.y, sh.y));
+                        o.y = Half<H>::pack2_relu(fmaf(accc[cc][4 * q + 2], sc.z, sh.z), fmaf(accc[cc][4 * q + 3], sc.w, sh.w));
                         *reinterpret_cast<uint2*>(a.y1n + ((long long)t * TTM + l32) * N2 + c0) = o;
                     }
             }
@@ -531,6 +531,8 @@ extern "C" int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const
     DIR_REQUIRE(p->wstream && p->scale3 && p->shift3 && p->scale1n && p->shift1n, "dir_bottleneck_tail_forward: missing parameters");
     DIR_REQUIRE(M > 0 && M % TM == 0 && M / TM < (1ll << 31), "dir_bottleneck_tail_forward: M must be a positive multiple of 64");
     DIR_REQUIRE(p->waves == 8 || p->waves == 4, "dir_bottleneck_tail_forward: the stream must be packed for 8 or 4 waves");
+    DIR_REQUIRE(p->dtype == 0 || p->dtype == DIR_DT_BF16 || p->dtype == DIR_DT_F16, "dir_bottleneck_tail_forward: dtype must be bf16 (or 0) or f16");
+    const bool f16 = p->dtype == DIR_DT_F16;
     TailArgs a;
     a.y2 = (const convk::bf16_t*)y2; a.res = (const convk::bf16_t*)residual; a.out = (convk::bf16_t*)out; a.y1n = (convk::bf16_t*)y1_next;
     a.wstream = (const uint4*)p->wstream; a.sc3 = p->scale3; a.sh3 = p->shift3; a.sc1n = p->scale1n; a.sh1n = p->shift1n;
@@ -546,7 +548,8 @@ extern "C" int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const
     if (p->waves == 4) {               // thin variant: 32-pixel tiles, two workgroups per CU
         a.ntiles = (int)(M / TTM);
         const int grid4 = a.ntiles < 2 * num_cu ? a.ntiles : 2 * num_cu;
-#define DIR_TAIL4(P_, N2_) DIR_LAUNCH((tail_thin_kernel<P_, N2_>), dim3(grid4), dim3(TTHR), 0, s, a)
+#define DIR_TAIL4(P_, N2_) do { if (f16) DIR_LAUNCH((tail_thin_kernel<P_, N2_, f16s_t>), dim3(grid4), dim3(TTHR), 0, s, a); \
+                                 else DIR_LAUNCH((tail_thin_kernel<P_, N2_, bf16_t>), dim3(grid4), dim3(TTHR), 0, s, a); } while (0)
         if (p->planes == 128 && p->n_next == 128) DIR_TAIL4(128, 128);
         else if (p->planes == 128 && p->n_next == 256) DIR_TAIL4(128, 256);
         else if (p->planes == 256 && p->n_next == 256) DIR_TAIL4(256, 256);
@@ -555,7 +558,8 @@ extern "C" int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const
         return check_launch("dir_bottleneck_tail_forward");
     }
     const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
-#define DIR_TAIL(P_, N2_) DIR_LAUNCH((tail_chain_kernel<P_, N2_>), dim3(grid), dim3(NTHR), 0, s, a)
+#define DIR_TAIL(P_, N2_) do { if (f16) DIR_LAUNCH((tail_chain_kernel<P_, N2_, f16s_t>), dim3(grid), dim3(NTHR), 0, s, a); \
+                                else DIR_LAUNCH((tail_chain_kernel<P_, N2_, bf16_t>), dim3(grid), dim3(NTHR), 0, s, a); } while (0)
     if (p->planes == 128 && p->n_next == 128) DIR_TAIL(128, 128);
     else if (p->planes == 128 && p->n_next == 256) DIR_TAIL(128, 256);
     else if (p->planes == 256 && p->n_next == 256) DIR_TAIL(256, 256);

@@ -24,6 +24,8 @@ __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint3
 template <typename T> __device__ __forceinline__ float ld(const T* p);
 template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+struct f16s_t { unsigned short u; };      // f16 STORAGE of the feature map (DIR_DT_F16, round 5)
+template <> __device__ __forceinline__ float ld<f16s_t>(const f16s_t* p) { return (float)__builtin_bit_cast(_Float16, p->u); }
 
 constexpr int NJ = 21;
 
@@ -815,6 +817,7 @@ extern "C" int dir_grid_tokens_forward(const void* feat, int feat_dtype, int S, 
     a.stamps = dir::stamps_begin("grid_tokens");
     if (feat_dtype == DIR_DT_F32) DIR_LAUNCH((grid_tokens_kernel<float>), dim3(B, 2), dim3(GT_THR), 0, s, a);
     else if (feat_dtype == DIR_DT_BF16) DIR_LAUNCH((grid_tokens_kernel<bf16_t>), dim3(B, 2), dim3(GT_THR), 0, s, a);
+    else if (feat_dtype == DIR_DT_F16) DIR_LAUNCH((grid_tokens_kernel<f16s_t>), dim3(B, 2), dim3(GT_THR), 0, s, a);
     else DIR_REQUIRE(false, "dir_grid_tokens_forward: bad dtype");
     dir::stamps_end("grid_tokens", a.stamps, s);
     return dir::check_launch("dir_grid_tokens_forward");

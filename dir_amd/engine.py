@@ -18,7 +18,7 @@ import threading
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X1P, DT_F16X3, DT_F16X3P, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16, DT_F16X1, DT_F16X1P, DT_F16X3, DT_F16X3P, DT_F32, ConvDesc
 
 F32 = torch.float32
 IMAGENET_MEAN = (C.c_float * 3)(0.485, 0.456, 0.406)      # apps/eval.py:49-50
@@ -44,8 +44,17 @@ def _ann(family, flops, nbytes, shape):
         _capi.annotate(family=family, flops=float(flops), bytes=float(nbytes), shape=shape)
 
 
+HALF = (torch.bfloat16, torch.float16)      # the two 16-bit STORAGE kinds of the throughput modes: DIR_DT_BF16 | DIR_DT_F16 (round 5: f16 storage)
+
+
 def _dt(dtype):
-    return DT_F32 if dtype == torch.float32 else DT_BF16
+    return DT_F32 if dtype == torch.float32 else DT_F16 if dtype == torch.float16 else DT_BF16
+
+
+def _tok_wdt(dtype):
+    """weight dtype of the token path (P-GCN / STE Linears) for a feature-map dtype: the f16-storage mode keeps the bf16 weights (autocast
+    semantics) -- its kernels take F32 | BF16, and the refined stages they feed are already inside 0.004 mm in the bf16 mode"""
+    return torch.bfloat16 if dtype in HALF else torch.float32
 
 
 def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
@@ -65,7 +74,7 @@ STREAM32_VARIANT = 23    # ... on 32-pixel workgroups (the 16x16 / 8x8 stages: 1
 STREAM_VARIANTS = (STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT)
 
 
-def pack_stream_weights(w_nk):
+def pack_stream_weights(w_nk, dtype=torch.bfloat16):
     """dir_conv1x1_stream_forward's weight stream (include/dir_hip.h) from W [Cout, K] (K = Cin, or Cin + Cin2 for two sources):
     bf16 [Cout/NWG][4 waves][K/64][4 k-steps][NCB][64 lanes][8]."""
     out_dev = w_nk.device
@@ -81,7 +90,7 @@ def pack_stream_weights(w_nk):
                                       torch.arange(4, device=dev), torch.arange(ncb, device=dev), indexing='ij')
     row = (g * (128 * ncb) + (wv * ncb + cb) * 32)[..., None] + l32                    # [G,4,nk,4,ncb,64]
     k0 = (64 * c + 8 * ks)[..., None] + 32 * h            # the k-slot assignment of conv.hip's MFMAs (bit-identical sums)
-    return w[row[..., None], k0[..., None] + e].to(torch.bfloat16).contiguous().to(out_dev)
+    return w[row[..., None], k0[..., None] + e].to(dtype).contiguous().to(out_dev)
 
 
 class ConvOp(object):
@@ -116,9 +125,9 @@ class ConvOp(object):
         self.split, self._ws = {}, {}                      # batch size -> split-K factor; (B, S, stream) -> workspace
         # streaming alternative for the HBM-bound 1x1 layers (dir_conv1x1_stream_forward), taken when autotune prefers it
         self.w_stream = None
-        if (dtype == torch.bfloat16 and self.out_dtype == torch.bfloat16 and self.kh == 1 and self.kw == 1 and stride == 1 and pad == 0
+        if (dtype in HALF and self.out_dtype == dtype and self.kh == 1 and self.kw == 1 and stride == 1 and pad == 0
                 and self.cin % 64 == 0 and self.cout % 128 == 0 and self.cin <= 2304):
-            self.w_stream = pack_stream_weights(self.w.reshape(self.cout, self.cin))
+            self.w_stream = pack_stream_weights(self.w.reshape(self.cout, self.cin), dtype)
 
     PRESPLIT = int(os.environ.get('DIR_PRESPLIT', '1'))
     OUT_SPLIT = os.environ.get('DIR_OUT_SPLIT', '1') != '0'      # producers write the next convolution's pre-split operand (link_split)
@@ -189,16 +198,16 @@ class ConvOp(object):
             nbytes = (B * H * W * self.cin * x.element_size() + self.w.numel() * self.w.element_size()
                       + B * ho * wo * self.cout * out.element_size() * (2 if residual is not None else 1))
             _capi.annotate(family='conv', flops=2.0 * B * ho * wo * self.cout * self.alg_k, bytes=nbytes, op=self, flops_real=2.0 * B * ho * wo * self.cout * self.alg_k * getattr(self, 'alg_scale', 1.0),
-                           dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),
+                           dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),        # (roofline class: f16 storage runs at the bf16 MFMA rate)
                            shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
                                                               self.kw, self.stride))
-        if v in STREAM_VARIANTS and self.w_stream is not None and residual is None and bbox is None and out.dtype == torch.bfloat16:
+        if v in STREAM_VARIANTS and self.w_stream is not None and residual is None and bbox is None and out.dtype == self.dtype:
             d.flags = (d.flags & 0xff) | ((v & 0xff) << 8 if v != STREAM_VARIANT else 0)
             _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(x), None, None, _capi.ptr(self.w_stream), _capi.ptr(self.scale),
                                                                _capi.ptr(self.shift), _capi.ptr(self.pre_scale), _capi.ptr(self.pre_shift),
                                                                _capi.ptr(out), _capi.stream_ptr()), 'dir_conv1x1_stream_forward')
             return out
-        S = self.splits(B, ho, wo) if (bbox is None and out.dtype == torch.bfloat16 and self.dtype == torch.bfloat16) else 1
+        S = self.splits(B, ho, wo) if (bbox is None and out.dtype in HALF and self.dtype in HALF) else 1
         if S > 1 and (_forced_variant() in (None, 0)):
             d.flags &= 0xff
             ws = self._splitk_ws(d, S, B, x.device)
@@ -275,8 +284,8 @@ class DualConvOp(object):
         self.pre_scale = None
         self.variant = {}
         self.w_stream = None
-        if dtype == torch.bfloat16 and self.cin % 64 == 0 and self.cin2 % 64 == 0 and self.cout % 128 == 0:
-            self.w_stream = pack_stream_weights(self.w)
+        if dtype in HALF and self.cin % 64 == 0 and self.cin2 % 64 == 0 and self.cout % 128 == 0:
+            self.w_stream = pack_stream_weights(self.w, dtype)
 
     set_in_scale = ConvOp.set_in_scale
     pre_scale = None
@@ -420,11 +429,11 @@ class BneckChainOp(object):
         self.params = _capi.BneckChainParams(_capi.ptr(c2.w), _capi.ptr(c2.scale), _capi.ptr(c2.shift), _capi.ptr(self.w3),
                                              _capi.ptr(self.s3), _capi.ptr(self.h3), n(self.w1n),
                                              n(c1n.scale if c1n is not None else None), n(c1n.shift if c1n is not None else None),
-                                             _capi.ptr(self.wd) if self.wd is not None else None, c1n.cout if c1n is not None else 0)
+                                             _capi.ptr(self.wd) if self.wd is not None else None, c1n.cout if c1n is not None else 0, 0, _dt(c2.dtype))
 
     @staticmethod
     def applies(c2, c3, c1n, dtype, dual=None):
-        ok = dtype == torch.bfloat16 and c2.cin == 64 and c2.cout == 64 and c2.kh == 3 and c2.stride == 1 and c2.scale is not None
+        ok = dtype in HALF and c2.cin == 64 and c2.cout == 64 and c2.kh == 3 and c2.stride == 1 and c2.scale is not None
         if dual is None:
             ok = ok and c3.cin == 64 and c3.cout == 256 and c3.scale is not None
         else:
@@ -453,7 +462,7 @@ class BneckChainOp(object):
         return out, y1n
 
 
-def pack_tail_stream(w3, w1n, waves=8):
+def pack_tail_stream(w3, w1n, waves=8, dtype=torch.bfloat16):
     """dir_bottleneck_tail_forward's weight stream (include/dir_hip.h): conv3.weight [4P, P] and the next conv1.weight [N2, 4P]
     as bf16 MFMA A-operand fragments in the order the kernel's waves consume them, [4P/512][waves][NBF + NCF][64 lanes][8]
     (waves = 8: 64-pixel tiles, one workgroup per CU; waves = 4: the thin variant, 32-pixel tiles, two workgroups per CU)."""
@@ -479,7 +488,7 @@ def pack_tail_stream(w3, w1n, waves=8):
                 for ks in range(32):
                     for cc in range(ncc):
                         out.append(w1n[((N2 // 4) * w + 32 * cc + l32)[:, None], (hf * 512 + 16 * ks + 8 * h)[:, None] + e])
-        return torch.stack(out).to(torch.bfloat16).contiguous().to(out_dev)
+        return torch.stack(out).to(dtype).contiguous().to(out_dev)
     for hf in range(C4 // 512):
         for w in range(8):
             for cb in range(2):
@@ -493,7 +502,7 @@ def pack_tail_stream(w3, w1n, waves=8):
             else:
                 for fc in range(32):
                     out.append(w1n[(32 * w + l32)[:, None], (hf * 512 + 16 * fc + 8 * h)[:, None] + e])
-    return torch.stack(out).to(torch.bfloat16).contiguous().to(out_dev)
+    return torch.stack(out).to(dtype).contiguous().to(out_dev)
 
 
 class BneckTailOp(object):
@@ -510,13 +519,13 @@ class BneckTailOp(object):
         self.c3, self.c1n = c3, c1n
         self.cout, self.cin, self.kh, self.kw, self.stride = c3.cout, c3.cin, 1, 1, 1
         self.variant = {}
-        self.stream = {n: pack_tail_stream(c3.w.reshape(c3.cout, c3.cin), c1n.w.reshape(c1n.cout, c1n.cin), n) for n in (8, 4)}
+        self.stream = {n: pack_tail_stream(c3.w.reshape(c3.cout, c3.cin), c1n.w.reshape(c1n.cout, c1n.cin), n, dtype=c3.dtype) for n in (8, 4)}
         self.params = {n: _capi.BneckTailParams(_capi.ptr(self.stream[n]), _capi.ptr(c3.scale), _capi.ptr(c3.shift), _capi.ptr(c1n.scale),
-                                                _capi.ptr(c1n.shift), c3.cin, c1n.cout, n) for n in (8, 4)}
+                                                _capi.ptr(c1n.shift), c3.cin, c1n.cout, n, _dt(c3.dtype)) for n in (8, 4)}
 
     @staticmethod
     def applies(c3, c1n, dtype):
-        return (dtype == torch.bfloat16 and c3.kh == 1 and c3.stride == 1 and c3.scale is not None and c3.cout == 4 * c3.cin
+        return (dtype in HALF and c3.kh == 1 and c3.stride == 1 and c3.scale is not None and c3.cout == 4 * c3.cin
                 and c1n.kh == 1 and c1n.stride == 1 and c1n.cin == c3.cout and c1n.scale is not None and c1n.pre_scale is None
                 and (c3.cin, c1n.cout) in BneckTailOp.GEOMETRIES)
 
@@ -581,7 +590,7 @@ class BackboneOp(object):
         w = sd[p + '.conv1.weight']
         wk = torch.zeros(64, 7, 8, 4, device=w.device, dtype=F32)
         wk[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-        self.stem_w = wk.to(torch.bfloat16).contiguous().to(device)
+        self.stem_w = wk.to(dtype if dtype in HALF else torch.bfloat16).contiguous().to(device)
         s_, h_ = bn_fold(sd, p + '.bn1')
         self.stem_scale, self.stem_shift = s_.float().contiguous().to(device), h_.float().contiguous().to(device)
         self.stem = stem_conv_op(sd[p + '.conv1.weight'], s_, h_, dt)     # staged path (fp32 mode, DIR_FUSED_STEM=0)
@@ -633,7 +642,7 @@ class BackboneOp(object):
     def __call__(self, img):
         L, dt, dev = _capi.lib(), self.dtype, self.device
         B = img.shape[0]
-        if self.fused_stem and dt == torch.bfloat16:
+        if self.fused_stem and dt in HALF:
             x = torch.empty(B, 64, 64, 64, device=dev, dtype=dt)
             u8 = img.dtype == torch.uint8
             _ann('stem', 2.0 * B * 128 * 128 * 64 * 147, img.numel() * img.element_size() + x.numel() * 2 + self.stem_w.numel() * 2,
@@ -653,14 +662,14 @@ class BackboneOp(object):
                         xs = x[b0:b0 + nb]
                         _ann('stem', 2.0 * nb * 128 * 128 * 64 * 147, isub.numel() * isub.element_size() + xs.numel() * 2 + self.stem_w.numel() * 2,
                              'B=%d 7x7/2 conv + bn + relu + maxpool' % nb)
-                        _capi.check(L.dir_stem_pool_forward(_capi.ptr(isub), 2 if u8 else 0, IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
+                        _capi.check(L.dir_stem_pool_forward_dt(_capi.ptr(isub), 2 if u8 else 0, _dt(dt), IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
                                                             _capi.ptr(self.stem_scale), _capi.ptr(self.stem_shift), _capi.ptr(xs), nb, 256, 256,
                                                             _capi.stream_ptr()), 'dir_stem_pool_forward')
                         self._layers(xs, upto=2, out_last=(c2[b0:b0 + nb], y1n[b0:b0 + nb]))
                 finally:
                     _TLS.parent_batch = None
                 return [None, c2] + self._layers(c2, start=2, y1=y1n)
-            _capi.check(L.dir_stem_pool_forward(_capi.ptr(img), 2 if u8 else 0, IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
+            _capi.check(L.dir_stem_pool_forward_dt(_capi.ptr(img), 2 if u8 else 0, _dt(dt), IMAGENET_MEAN, IMAGENET_STD, _capi.ptr(self.stem_w),
                                                 _capi.ptr(self.stem_scale), _capi.ptr(self.stem_shift), _capi.ptr(x), B, 256, 256,
                                                 _capi.stream_ptr()), 'dir_stem_pool_forward')
             return self._layers(x)
@@ -926,8 +935,8 @@ class StageOp(object):
         self.pos_emb = (_capi.TokenMlp * 2)(pack_token_mlp(sd, p + '.pos_emb_left', keep),
                                             pack_token_mlp(sd, p + '.pos_emb_right', keep))
         self.gpos = pack_token_mlp(sd, p + '.global_pos_emb', keep)
-        self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep, weight_dtype=dtype), pack_pgcn(sd, p + '.gcn_right', keep, weight_dtype=dtype))
-        self.ste = pack_ste(sd, p + '.interaction', keep, weight_dtype=dtype)
+        self.gcn = (pack_pgcn(sd, p + '.gcn_left', keep, weight_dtype=_tok_wdt(dtype)), pack_pgcn(sd, p + '.gcn_right', keep, weight_dtype=_tok_wdt(dtype)))
+        self.ste = pack_ste(sd, p + '.interaction', keep, weight_dtype=_tok_wdt(dtype))
         R = _capi.RegressParams()
         t = dict(wt=torch.cat([sd[p + '.regressor.mano_left.weight'].float().t(),
                                sd[p + '.regressor.mano_right.weight'].float().t()], 1).contiguous(),     # [1408][128]
@@ -945,17 +954,17 @@ class StageOp(object):
         s, h = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])
         self.fusion0 = ConvOp(sd[p + '.fusion.0.weight'], dtype, pad=1, scale=s, shift=h, relu=True)
         self.bone_fusion = None
-        if dtype == torch.bfloat16 or _packing_arith() is not None:
+        if dtype in HALF or _packing_arith() is not None:
             # factorised bone fusion (dir_bone_fusion_forward): w_g[tap][hb][c][n] = weight[n, hb*64+c, ky, kx]; bf16 mode: rounded to
             # bf16, bf16 matrix cores; f16 arithmetic modes: unrounded fp32 operands (exact_f32 = 1), on the exact fp32 matrix cores until
             # DirEngine.calibrate has measured G (g_scale = 0), in split precision on the f16 matrix cores afterwards
             exact = dtype == torch.float32
             w = sd[p + '.fusion.0.weight'].detach()
-            w = w.float() if exact else w.to(torch.bfloat16).float()                          # [256, 2560, 3, 3]
+            w = w.float() if exact else w.to(dtype).float()                                   # [256, 2560, 3, 3]  (rounded to the 16-bit storage kind)
             s_f, h_f = bn_fold(sd, p + '.fusion.1', sd[p + '.fusion.0.bias'])                   # (fusion0.scale carries the f16x3 prescale)
             t = dict(w_g=w.reshape(256, 40, 64, 9).permute(3, 1, 2, 0).contiguous(), scale=s_f.to(w.device), shift=h_f.to(w.device))
             keep.append(t)
-            self.bone_fusion = _capi.BoneFusionParams(t['w_g'].data_ptr(), t['scale'].data_ptr(), t['shift'].data_ptr(), 1 if exact else 0)
+            self.bone_fusion = _capi.BoneFusionParams(t['w_g'].data_ptr(), t['scale'].data_ptr(), t['shift'].data_ptr(), 1 if exact else 2 if dtype == torch.float16 else 0)
         self.fusion3 = ConvOp(sd[p + '.fusion.3.weight'], dtype, shift=sd[p + '.fusion.3.bias'])
 
 
@@ -990,7 +999,7 @@ class DirEngine(object):
         everywhere (the parity mode of rounds 1-2); float32 with arith='f16x3': the same fp32 feature maps and token path, the
         convolutions on the f16 matrix cores in split precision (3 products per multiply, DIR_DT_F16X3) -- meets the same 1e-4 mm
         budget several times faster."""
-        assert dtype in (torch.bfloat16, torch.float32)
+        assert dtype in (torch.bfloat16, torch.float16, torch.float32)       # float16: f16 STORAGE (round 5), the bf16 data path with 11-bit significands
         assert arith in (None, 'f16x3', 'f16') and (arith is None or dtype == torch.float32)     # 'f16': one f16 MFMA per product (DIR_DT_F16X1)
         self.arith = arith
         self.tuned_batches = set()
@@ -1111,7 +1120,7 @@ class DirEngine(object):
             C.byref(st.gpos), _capi.ptr(x0), _capi.ptr(gp), B, sp), 'dir_grid_tokens_forward')
         tok = torch.empty(B, 42, 128, device=dev, dtype=F32)
         scratch = torch.empty(4, B, 21, 256, device=dev, dtype=F32)
-        wes = 2 if self.dtype == torch.bfloat16 else 4
+        wes = 2 if self.dtype in HALF else 4
         _ann('pgcn', 2.0 * 4 * 2 * B * 21 * 2 * 128 * 128, 4 * 2 * (2 * 21 * 128 * 128 * wes + 2 * B * 21 * 128 * 4),
              'B=%d 4 layers x 2 hands (per-node W0/W1 %s + neighbour mix + BN + ReLU)' % (B, 'bf16' if wes == 2 else 'f32'))
         if self.pgcn_fused:      # the whole stack of both hands in one launch, layers separated by per-node flags (tokens.hip: pgcn_fused_kernel)

@@ -3,7 +3,7 @@ Feature maps are NHWC torch tensors (float32 or bfloat16) on the GPU."""
 import torch
 
 from . import _capi
-from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16X1, DT_F16X1P, DT_F16X3, DT_F16X3P, DT_F32, ConvDesc
+from ._capi import CONV_PRE_RELU, CONV_RELU, DT_BF16, DT_F16, DT_F16X1, DT_F16X1P, DT_F16X3, DT_F16X3P, DT_F32, ConvDesc
 
 
 def _dt(t):
@@ -11,6 +11,8 @@ def _dt(t):
         return DT_F32
     if t.dtype == torch.bfloat16:
         return DT_BF16
+    if t.dtype == torch.float16:         # f16 STORAGE (include/dir_hip.h: DIR_DT_F16)
+        return DT_F16
     raise _capi.DirHipError('unsupported dtype %s' % t.dtype)
 
 
@@ -147,11 +149,11 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
     return out
 
 
-def pack_stem_weight(w_oihw):
+def pack_stem_weight(w_oihw, dtype=torch.bfloat16):
     """conv1.weight [64,3,7,7] -> bf16 [64][ky 7][kx 8][c 4] for dir_stem_pool_forward (zero for kx = 7, c = 3)"""
     wk = torch.zeros(64, 7, 8, 4, device=w_oihw.device, dtype=torch.float32)
     wk[:, :, :7, :3] = w_oihw.float().permute(0, 2, 3, 1)
-    return wk.to(torch.bfloat16).contiguous()
+    return wk.to(dtype).contiguous()
 
 
 def stem_pool(img, w_packed, scale, shift, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
@@ -166,8 +168,8 @@ def stem_pool(img, w_packed, scale, shift, mean=(0.485, 0.456, 0.406), std=(0.22
         img = _capi.f32c(img)
         B, H, W = img.shape[0], img.shape[2], img.shape[3]
     img = img.contiguous()
-    y = torch.empty(B, H // 4, W // 4, 64, device=img.device, dtype=torch.bfloat16)
-    _capi.check(_capi.lib().dir_stem_pool_forward(_capi.ptr(img), 2 if u8 else 0, (C.c_float * 3)(*mean), (C.c_float * 3)(*std),
+    y = torch.empty(B, H // 4, W // 4, 64, device=img.device, dtype=w_packed.dtype)          # bf16 | f16 storage: the packed weights' kind
+    _capi.check(_capi.lib().dir_stem_pool_forward_dt(_capi.ptr(img), 2 if u8 else 0, _dt(w_packed), (C.c_float * 3)(*mean), (C.c_float * 3)(*std),
                                                   _capi.ptr(w_packed), _capi.ptr(_capi.f32c(scale)), _capi.ptr(_capi.f32c(shift)),
                                                   _capi.ptr(y), B, H, W, _capi.stream_ptr()), 'dir_stem_pool_forward')
     return y
@@ -181,13 +183,13 @@ def bottleneck_chain(y1, w2, s2, h2, w3, s3, h3, residual=None, nxt=None, dual=N
     returns (out [B,H,W,256], y1_next [B,H,W,64] or None)"""
     _capi.require_cuda(y1)
     B, H, W, _ = y1.shape
-    out = torch.empty((B, H // 2, W // 2, 256) if decimate else (B, H, W, 256), device=y1.device, dtype=torch.bfloat16)
-    y1n = torch.empty(B, H, W, nxt[0].shape[0], device=y1.device, dtype=torch.bfloat16) if nxt is not None else None
+    out = torch.empty((B, H // 2, W // 2, 256) if decimate else (B, H, W, 256), device=y1.device, dtype=y1.dtype)
+    y1n = torch.empty(B, H, W, nxt[0].shape[0], device=y1.device, dtype=y1.dtype) if nxt is not None else None
     keep = [_capi.f32c(t) for t in (s2, h2, s3, h3)] + ([_capi.f32c(nxt[1]), _capi.f32c(nxt[2])] if nxt is not None else [])
     p = _capi.BneckChainParams(_capi.ptr(w2), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(w3), _capi.ptr(keep[2]), _capi.ptr(keep[3]),
                                _capi.ptr(nxt[0]) if nxt is not None else None, _capi.ptr(keep[4]) if nxt is not None else None,
                                _capi.ptr(keep[5]) if nxt is not None else None, _capi.ptr(dual[1]) if dual is not None else None,
-                               nxt[0].shape[0] if nxt is not None else 0, 1 if decimate else 0)
+                               nxt[0].shape[0] if nxt is not None else 0, 1 if decimate else 0, _dt(y1))
     import ctypes as C
     _capi.check(_capi.lib().dir_bottleneck_chain_forward(C.byref(p), _capi.ptr(y1), _capi.ptr(residual) if residual is not None else None,
                                                          _capi.ptr(dual[0]) if dual is not None else None, _capi.ptr(out), _capi.ptr(y1n) if y1n is not None else None, B, H, W,
@@ -203,11 +205,11 @@ def bottleneck_tail(y2, w3, s3, h3, residual, w1n, s1n, h1n, waves=8):
     _capi.require_cuda(y2, residual)
     B, H, W, P = y2.shape
     C4, N2 = w3.shape[0], w1n.shape[0]
-    stream = pack_tail_stream(w3, w1n, waves)
+    stream = pack_tail_stream(w3, w1n, waves, dtype=y2.dtype)
     keep = [_capi.f32c(t) for t in (s3, h3, s1n, h1n)]
-    out = torch.empty(B, H, W, C4, device=y2.device, dtype=torch.bfloat16)
-    y1n = torch.empty(B, H, W, N2, device=y2.device, dtype=torch.bfloat16)
-    p = _capi.BneckTailParams(_capi.ptr(stream), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(keep[2]), _capi.ptr(keep[3]), P, N2, waves)
+    out = torch.empty(B, H, W, C4, device=y2.device, dtype=y2.dtype)
+    y1n = torch.empty(B, H, W, N2, device=y2.device, dtype=y2.dtype)
+    p = _capi.BneckTailParams(_capi.ptr(stream), _capi.ptr(keep[0]), _capi.ptr(keep[1]), _capi.ptr(keep[2]), _capi.ptr(keep[3]), P, N2, waves, _dt(y2))
     _capi.check(_capi.lib().dir_bottleneck_tail_forward(C.byref(p), _capi.ptr(y2.contiguous()), _capi.ptr(residual.contiguous()), _capi.ptr(out),
                                                         _capi.ptr(y1n), B * H * W, _capi.stream_ptr()), 'dir_bottleneck_tail_forward')
     return out, y1n
@@ -224,10 +226,10 @@ def conv1x1_stream(x, w_nk, scale=None, shift=None, relu=False, pre_scale=None, 
     cin2 = x2.shape[3] if x2 is not None else 0
     cin = cin if cin is not None else K - cin2
     assert cin + cin2 == K
-    ws = pack_stream_weights(w_nk)
+    ws = pack_stream_weights(w_nk, dtype=x.dtype)
     if out is None:
-        out = torch.empty(B, H, W, Cout, device=x.device, dtype=torch.bfloat16)
-    d = ConvDesc(B, H, W, cin, cbuf, in_coff, Cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, DT_BF16, DT_BF16,
+        out = torch.empty(B, H, W, Cout, device=x.device, dtype=x.dtype)
+    d = ConvDesc(B, H, W, cin, cbuf, in_coff, Cout, out.shape[3], out_coff, 0, 0, 1, 1, 1, 0, _dt(x), _dt(out),
                  (CONV_RELU if relu else 0) | (CONV_PRE_RELU if pre_relu else 0) | ((variant & 0xff) << 8))
     d2 = _capi.ConvSrc2(x2.shape[1], x2.shape[2], cin2, x2.shape[3], 0, stride2) if x2 is not None else None
     keep = [None if t is None else _capi.f32c(t) for t in (scale, shift, pre_scale, pre_shift)]

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 34
+#define DIR_ABI_VERSION 35
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -284,6 +284,11 @@ int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h
  * output-channel tiles. */
 #define DIR_DT_F16X3P 5
 #define DIR_DT_F16X1P 6
+/* f16 STORAGE (round 5): feature maps and convolution weights held as IEEE binary16 -- byte for byte the layouts, entry points and kernels of
+ * DIR_DT_BF16 (64-channel K-slabs, LDS-DMA operand path, v_mfma_f32_32x32x16_f16 instead of _bf16, fp32 accumulation and epilogue), with an
+ * 11-bit significand per stored value instead of 8.  Outputs are rounded to nearest even after clamping to +-65504 (no inf is ever stored).
+ * Accepted wherever DIR_DT_BF16 is, for the feature-map / convolution-weight side; the token path's weight_dtype / w_dtype stay F32 | BF16. */
+#define DIR_DT_F16 7
 #define DIR_CONV_RELU 1
 #define DIR_CONV_PRE_RELU 2
 /* Optional kernel choice in bits 8..15 of dir_conv_desc.flags (0 = the library's per-layer heuristic).  Every variant
@@ -595,7 +600,8 @@ typedef struct dir_bone_fusion_params {
     const float* shift; /* [256] folded BatchNorm shift (+ fusion.0 bias)   */
     int32_t exact_f32;  /* 0: bf16 operands (w_g rounded to bf16 by the caller, G and Wgt rounded to bf16, y bf16) -- the throughput mode;
                            1: everything fp32 on the exact fp32 matrix cores (w_g unrounded, y NHWC fp32) -- the parity modes: differs from
-                           bone_proj + conv3x3 only by the association of the sum (fp32 rounding noise)                                   */
+                           bone_proj + conv3x3 only by the association of the sum (fp32 rounding noise);
+                           2 (round 5): as 0 with f16 instead of bf16 everywhere (w_g rounded to f16 by the caller, G / Wgt / y f16: DIR_DT_F16)      */
     float g_scale;      /* exact_f32 only.  0: the exact fp32 matrix cores.  A power of two > 0: split precision on the f16 matrix cores (the
                            arithmetic of DIR_DT_F16X3: hi*hi + lo*hi + hi*lo per product, ~2^-22) -- G is multiplied by g_scale before its f16
                            hi / lo split (the largest |G| belongs near 2^9 .. 2^10: DirEngine.calibrate; values saturate, never inf / nan)      */
@@ -676,6 +682,10 @@ int dir_stem_prep_s2d_u8(const uint8_t* img_bgr_hwc, void* out, const float* mea
  * dir_maxpool3x3s2 (bf16 operands, fp32 accumulation, bf16 conv output); only the summation order inside K differs. */
 int dir_stem_pool_forward(const void* img, int img_dtype, const float* mean_host, const float* std_host, const void* w_packed,
                           const float* scale, const float* shift, void* y, int B, int H, int W, void* stream);
+/* the same with the 16-bit storage kind of y and w_packed chosen by the caller: out_dtype DIR_DT_BF16 (what the entry point above passes) or
+ * DIR_DT_F16 (round 5: f16 feature maps and weights, v_mfma_f32_16x16x32_f16) */
+int dir_stem_pool_forward_dt(const void* img, int img_dtype, int out_dtype, const float* mean_host, const float* std_host, const void* w_packed,
+                             const float* scale, const float* shift, void* y, int B, int H, int W, void* stream);
 
 /* a1 (layer1 bottlenecks), bf16 mode: models/backbone/resnet.py:126-140 of block i -- conv2 3x3/s1/p1 (64->64) + bn2 + ReLU +
  * conv3 1x1 (64->256) + bn3 + identity + ReLU -- and, optionally, :122-124 of block i+1 -- conv1 1x1 (256->64) + bn1 + ReLU --
@@ -697,6 +707,7 @@ typedef struct dir_bneck_chain_params {
                          layer1 block, whose output is read by layer2's stride-2 projection shortcut alone (models/backbone/resnet.py:117-119;
                          its conv1 is the fused y1_next): three quarters of the 256-channel map never leave the CU.  The ResNet's c1 feature is
                          then not produced (models/dir.py never reads it: models/dir.py:437-483 use c2..c4) */
+    int32_t dtype;    /* storage kind of every 16-bit tensor and weight of the call: 0 or DIR_DT_BF16 -> bf16, DIR_DT_F16 -> f16 (round 5) */
 } dir_bneck_chain_params;
 int dir_bottleneck_chain_forward(const dir_bneck_chain_params* p, const void* y1, const void* residual, const void* x2, void* out,
                                  void* y1_next, int B, int H, int W, void* stream);
@@ -724,6 +735,7 @@ typedef struct dir_bneck_tail_params {
                          conv3 fragment f < P/4: cb = f / (P/16), ks = f % (P/16): w3[half*512 + 128*wave + 32*cb + (l&31)][16*ks + 8*(l>>5)..],
                          conv1' fragment fc: ks = fc / (n_next/128), cc = fc % (n_next/128):
                          w1n[(n_next/4)*wave + 32*cc + (l&31)][half*512 + 16*ks + 8*(l>>5)..] */
+    int32_t dtype;    /* storage kind of the tensors and of the weight stream: 0 or DIR_DT_BF16 -> bf16, DIR_DT_F16 -> f16 (round 5) */
 } dir_bneck_tail_params;
 int dir_bottleneck_tail_forward(const dir_bneck_tail_params* p, const void* y2, const void* residual, void* out, void* y1_next,
                                 long long M, void* stream);
