@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 # on 8 queues 2.23 ms).  Must be set before the runtime initialises; an explicit setting of the user wins.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
-PEAK = {'bf16': 2.5e15, 'f32': 157.3e12,         # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK = {'bf16': 2.5e15, 'f16': 2.5e15, 'f32': 157.3e12,         # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
         'f16x3': 2.5e15 / 3, 'f16': 2.5e15}                     # split precision: three f16 MFMAs (dense f16 peak = bf16's) per algorithmic product
 ALG_GFLOP_PER_IMAGE = 36.80                     # BASELINE.md section 2 (reference, torch flop counter)
 HBM_PEAK = 8.0e12                               # bytes/s, same guide
@@ -46,7 +46,8 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median one is reported')
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'], help="storage of feature maps and convolution weights: bf16 (BASELINE configs[1]), "
+                    "f16 = the same data path and MFMA rate on IEEE f16 (11-bit significands: every stage inside 0.01 mm), f32 = exact parity mode")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--inflight', type=int, default=4, help='forwards in flight per GPU (engine.ForwardPipeline: one captured graph + '
                     'stream + input batch per slot, steps alternate between them); 1 = one graph replayed back to back')
@@ -62,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-ceiling-probe', action='store_true', help='skip the in-run MFMA / HBM ceiling probe (2 s, outside the timed regions)')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi socket power probe (7 s, outside the timed regions)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
+    ap.add_argument('--no-other-half', action='store_true', help='skip the sub-record of the other 16-bit storage kind (f16 when --dtype bf16, bf16 when --dtype f16)')
     ap.add_argument('--no-config5', action='store_true', help='skip the BASELINE configs[4] (HRNet-W48, 32 per GPU) sub-record')
     ap.add_argument('--no-train', action='store_true', help='skip the training-step sub-record (batch 32, fp32)')
     ap.add_argument('--no-proj-feat-variant', action='store_true', help='skip the serving variant without the proj_feat output')
@@ -187,7 +189,9 @@ def main():
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
     sd_np = synth.synth_state_dict(shapes, 1234)
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
-    tdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    tdt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
+    half = args.dtype in ('bf16', 'f16')
+    tbl_dtype = 'bf16' if half else args.dtype        # the shipped throughput table is keyed by layer shapes and kernel variants only: both 16-bit kinds share it
     eng = E.DirEngine(sd, dtype=tdt, device=dev)
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -240,10 +244,10 @@ def main():
     # single-graph and eager paths keep the time-tuned choice -- ADVICE r3)
     if args.tuning == 'throughput' and not args.no_autotune and ((args.inflight > 1 and not args.no_graph) or args.force_table):
         t_time = eng.export_tuning(B)
-        meta = eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
+        meta = eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (tbl_dtype, B))
         if meta is not None:
             conv_tuning = 'throughput table dir_amd/tuning/gfx950_%s_b%d_throughput.json (HEAD %s, %d layers differ from the time-tuned choice)' % (
-                args.dtype, B, meta.get('head', '?'), meta.get('changed_vs_time_tuned', -1))
+                tbl_dtype, B, meta.get('head', '?'), meta.get('changed_vs_time_tuned', -1))
     if args.no_graph:
         step = fwd
         args.inflight = 1
@@ -282,7 +286,7 @@ def main():
                 pipe, conv_tuning = pipe_t, 'time (live autotune): the shipped throughput table was slower on this machine (%.3f vs %.3f ms per step)' % (q_tp, q_t)
             else:
                 del pipe_t
-                eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
+                eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (tbl_dtype, B))
         outs = pipe.outs[0]
         counter = [0]
 
@@ -400,7 +404,7 @@ def main():
         traffic, traffic_src = None, None
         import glob
         pm = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
-        if pm and dtype_key == 'bf16' and B == 64 and with_traffic:
+        if pm and dtype_key in ('bf16', 'f16') and B == 64 and with_traffic:
             with open(pm[-1]) as f:
                 pj = json.load(f)
             traffic = round(pj['hbm_bytes_per_launch'])
@@ -447,7 +451,7 @@ def main():
 
 
     roof = live_roofline(eng, img, args.dtype, ms_per_step) if rank == 0 else None
-    if roof is not None and args.dtype == 'bf16' and not args.no_ceiling_probe:
+    if roof is not None and half and not args.no_ceiling_probe:
         # What THIS board sustains, measured in this run (dir_probe_launch: VERDICT r3 item 9 -- the constants quoted here in round 3 came from
         # another box): a bf16 MFMA loop on pseudo-random operands held in registers (the guide's 2.5 PFLOP/s is reached on all-zero operands
         # only: on real data the board's power / current limits pull the clock) and a streaming read of 1 GiB.  ~1 s each, after the timed
@@ -489,11 +493,43 @@ def main():
                                       "other forwards' kernels, so per-launch durations do not add up to the step)" % args.inflight}
         roof['note_tables'] = ('kernel durations above: the table of the timed graphs (throughput); time_tuned_table: the same launches with '
                                'the per-layer fastest variant (what one forward at a time runs)')
-        eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (args.dtype, B))
+        eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (tbl_dtype, B))
+
+    # ---- the OTHER 16-bit storage kind (bf16 <-> f16), same kernels' twin instantiations, same kernel table, same streams, measured right after
+    #      the headline and again beside it (alternating regions: same clocks): VERDICT r4 item 2 -- "an fp16-storage throughput mode that meets
+    #      0.01 mm at every stage at bf16 speed" (tests/test_gpu_dir.py::test_engine_vs_reference_golden_trained_like_weights[f16s])
+    other_half = None
+    if rank == 0 and world == 1 and half and pipe is not None and not args.no_other_half:
+        odt, oname = (torch.float16, 'f16') if args.dtype == 'bf16' else (torch.bfloat16, 'bf16')
+        engo = E.DirEngine(sd, dtype=odt, device=dev)
+        engo.forward(img)
+        sync()
+        if not args.no_autotune:
+            engo.import_tuning(img, eng.export_tuning(B))          # the headline's kernel table (layer shapes are identical)
+        pipeo = E.ForwardPipeline(engo, pipe.imgs, streams=pipe.streams)
+        co = [0]
+
+        def stepo():
+            pipeo.launch(co[0] % args.inflight)
+            co[0] += 1
+        for _ in range(args.warmup + 2 * args.inflight):
+            stepo()
+        sync()
+        ro, rh = [], []
+        for _ in range(3):                                         # alternate: other kind, headline kind
+            ro += timed_regions(stepo, args.steps, 1, sync, float, sync)
+            rh += timed_regions(step, args.steps, 1, sync, float, sync)
+        do, dh = statistics.median(ro), statistics.median(rh)
+        other_half = {'dtype': oname, 'images_per_sec': round(B * args.steps / do, 1), 'ms_per_step': round(do / args.steps * 1e3, 3),
+                      'forwards_in_flight': args.inflight, 'headline_dtype_alternating_ms_per_step': round(dh / args.steps * 1e3, 3),
+                      'steps': args.steps, 'regions': 3,
+                      'note': 'DirEngine(dtype=%s): feature maps and convolution weights stored as %s, the same data path / kernel table / streams as the '
+                              'headline; regions alternate with the headline pipeline' % (str(odt)[6:], oname)}
+        del pipeo, engo
 
     # ---- fp32 exact-parity mode (the mode that meets the 1e-4 mm budget, tests/test_gpu_dir.py): one graph, a few steps
     fp32 = None
-    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_fp32_mode and not args.no_graph:
+    if rank == 0 and world == 1 and half and not args.no_fp32_mode and not args.no_graph:
         del pipe
         eng32 = E.DirEngine(sd, dtype=torch.float32, device=dev)
         eng32.forward(img)
@@ -554,7 +590,7 @@ def main():
         return rec
 
     parity, f16m = None, None
-    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_fp32_mode and not args.no_graph:
+    if rank == 0 and world == 1 and half and not args.no_fp32_mode and not args.no_graph:
         parity = arith_mode('f16x3', "DirEngine(dtype=float32, arith='f16x3'): fp32 feature maps / token path, every convolution product as three f16 "
                             'MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulate); meets the 1e-4 mm budget like fp32_mode (8.0e-8 m vs the reference '
                             'golden); roofline priced against the dense f16 peak / 3')
@@ -566,7 +602,7 @@ def main():
     #      over 8), in bf16 and in the arithmetic the config names (fp16 MFMA path: fp32 feature maps, f16 operands); graph + live autotune +
     #      the same forwards in flight as the headline.  No reference counterpart: parity is pinned to the build's oracle.
     cfg5 = None
-    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_config5 and not args.no_graph:
+    if rank == 0 and world == 1 and half and not args.no_config5 and not args.no_graph:
         from dir_amd.models.dir import DIR as _DIR
         torch.cuda.empty_cache()
         net5 = _DIR(21, 'x', 0, backbone='hrnet_w48', extra_stages=2)
@@ -620,7 +656,7 @@ def main():
     # ---- training step (BASELINE config 4's per-GPU batch: 32 images, fp32, the whole network: forward in training mode, 42-term
     #      objective, backward, flat gradient bucket, one AdamW launch -- dir_amd/train/step.py); rank 0, single-GPU runs only
     train = None
-    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_train:
+    if rank == 0 and world == 1 and half and not args.no_train:
         from dir_amd.optim import FlatAdamW
         from dir_amd.train import step as TSTEP
         torch.cuda.empty_cache()
@@ -727,7 +763,7 @@ def main():
                            'backend': ('nccl (RCCL)' if backend == 'nccl' else 'gloo (ranks may share a GPU: code-path test, not a measurement)') if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
-                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'train_step': train, 'without_proj_feat': no_pf, 'config5_hrnet': cfg5}
+                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'fp16_storage_mode' if args.dtype == 'bf16' else 'bf16_storage_mode': other_half, 'train_step': train, 'without_proj_feat': no_pf, 'config5_hrnet': cfg5}
         # the full record (per-kernel tables, notes, sub-mode rooflines) goes to a side file and to stderr; the LAST stdout line is the compact
         # headline (dir_amd/benchline.py: <= 4 KB, every contract key + roofline + cpu_baseline) -- round 3's 20 KB line went unparsed
         from dir_amd import benchline

@@ -39,7 +39,7 @@ def _mode(rec):
     if not rec:
         return None
     out = _pick(rec, ('images_per_sec', 'ms_per_step', 'forwards_in_flight', 'ms_per_forward_one_in_flight', 'batch_per_gpu', 'seconds_per_step',
-                      'launches_per_step', 'frac_of_f16x3_mfma_peak', 'pad_waste', 'fp16_images_per_sec', 'fp16_ms_per_step'))
+                      'launches_per_step', 'frac_of_f16x3_mfma_peak', 'pad_waste', 'fp16_images_per_sec', 'fp16_ms_per_step', 'headline_dtype_alternating_ms_per_step'))
     r = rec.get('roofline')
     if r:
         out['roofline_frac'] = r.get('frac')
@@ -96,7 +96,7 @@ def compact(detail, detail_path='bench_detail.json'):
         if ec:
             p['joules_per_step_energy_counter'] = ec.get('joules_per_step')
         line['power'] = p
-    for k in ('fp32_mode', 'parity_mode_f16x3', 'fp16_mode', 'train_step', 'without_proj_feat', 'config5_hrnet'):
+    for k in ('fp32_mode', 'parity_mode_f16x3', 'fp16_mode', 'fp16_storage_mode', 'bf16_storage_mode', 'train_step', 'without_proj_feat', 'config5_hrnet'):
         if detail.get(k):
             line[k] = _mode(detail[k])
     line['detail'] = detail_path

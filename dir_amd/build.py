@@ -32,6 +32,12 @@ if os.environ.get('DIR_PACKED_FP32') == '1':
     OBJ = os.path.join(HERE, 'build', 'obj_pk')
     LIB = os.path.join(LIBDIR, 'libdir_hip_pk.so')
 FLAGS += os.environ.get('DIR_HIPCC_EXTRA', '').split()       # tuning / debugging aid (changing it needs --force)
+if os.environ.get('DIR_BUILD_TAG'):
+    # A/B aid: a SECOND library beside the product one, from its own object directory, e.g.
+    #   DIR_BUILD_TAG=noclamp DIR_HIPCC_EXTRA=-DDIR_F16_NOCLAMP=1 python -m dir_amd.build      ->  lib/libdir_hip_noclamp.so
+    # never loaded unless DIR_LIB_PATH points at it
+    OBJ = os.path.join(HERE, 'build', 'obj_' + os.environ['DIR_BUILD_TAG'])
+    LIB = os.path.join(LIBDIR, 'libdir_hip_%s.so' % os.environ['DIR_BUILD_TAG'])
 
 
 def hipcc():

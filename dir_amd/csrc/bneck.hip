@@ -62,6 +62,7 @@ template <typename H> __device__ __forceinline__ void unpack4(uint2 v, float (&f
 // H: the 16-bit storage kind (bf16_t | f16s_t = DIR_DT_BF16 | DIR_DT_F16) of every tensor, weight and LDS tile
 template <bool HAS_RES, int N2, bool HAS_DUAL, typename H = bf16_t>
 __global__ __launch_bounds__(NTHR, 1) void bneck_chain_kernel(ChainArgs a) {
+    convk::half_kernel_init<H>();
     constexpr bool HAS_NEXT = N2 > 0;
     __shared__ __attribute__((aligned(16))) char s_w2[64 * W2PITCH];
     __shared__ __attribute__((aligned(16))) char s_patch[NPP * PPITCH];

@@ -50,6 +50,7 @@ constexpr int G_ROWS = 128, G_LD = 66;      // (sample, end) rows per pass; lda 
 // H (F32 = false only): the 16-bit kind G is rounded to (bf16_t | f16s_t = the throughput modes DIR_DT_BF16 | DIR_DT_F16)
 template <bool F32, typename H = bf16_t>
 __global__ __launch_bounds__(256) void bone_g_kernel(GArgs a) {
+    half_kernel_init<H>();
     __shared__ float s_f[G_ROWS * G_LD];
     const int tap = blockIdx.x / 40, hb = blockIdx.x - tap * 40, hand = hb / 20, bone = hb - hand * 20;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,6 +120,7 @@ constexpr int FUSE_MAX_ROWS = 400;
 
 template <typename H>
 __global__ __launch_bounds__(512, 1) void bone_fuse_kernel(FuseArgs a) {
+    half_kernel_init<H>();
     constexpr int MI = 2, NJ = 2, WM = 4, WN = 2, NT = 512, BM = 256, BN = 128;
     constexpr int PITCH = EP * 2;                                   // 176 B
     constexpr int P_BYTES = FUSE_MAX_ROWS * PITCH, G_BYTES = BN * PITCH;

@@ -37,6 +37,7 @@ constexpr long long SPLITK_COUNTER_BYTES = 16384;      // head of a split-K work
 // MI x NJ = 32x32 MFMA tiles per wave; block tile (2*MI*32) x (2*NJ*32), 2x2 waves.
 template <typename TI, typename TO, int MI, int NJ, bool PRE, bool RING, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+    half_kernel_init<TO>();
     // DMA: K-slabs go global -> LDS directly (buffer_load ... lds): no VGPR round trip, no ds_write.  The LDS image of a
     // wave-level DMA is lane-linear (8 rows x 128 B per instruction), so rows are unpadded and the bank-conflict-free
     // layout is obtained by XOR-swizzling the 16-byte chunk index on the SOURCE address: chunk c of row r lives at

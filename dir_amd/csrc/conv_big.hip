@@ -24,6 +24,7 @@ struct BSlab { int tap, toff, k0; };
 template <typename TO, typename TIN = bf16_t>
 __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
     typedef TIN TI;
+    half_kernel_init<TO>();
     constexpr int MI = 4, NJ = 2, WM = 2, WN = 4, NT = 512, BM = 256, BN = 256, ROW = 128;
     constexpr int RPP = NT / 8, ACH = BM / RPP, BCH = BN / RPP, NP = ACH + BCH;      // 64 rows per DMA pass; 4 + 4 pieces per thread and slab
     constexpr int A_BYTES = BM * ROW, B_BYTES = BN * ROW, BUF_BYTES = A_BYTES + B_BYTES;

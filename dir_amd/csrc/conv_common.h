@@ -64,8 +64,8 @@ __device__ __forceinline__ uint32_t relu2bf(uint32_t v) {
 
 // f16 STORAGE (DIR_DT_F16, round 5): feature maps and weights held as IEEE binary16 -- the bytes, addressing, LDS-DMA path and MFMA rate of
 // the bf16 mode with an 11-bit significand instead of 8: the rounding of every stored map is 8x finer (the bf16 mode's 0.036 / 0.050 mm at
-// the init stage is the accumulated rounding of the backbone's 53 stored maps).  The range is 65504: stores clamp (v_med3_f32)
-// instead of producing inf.  A distinct tag type so that every kernel template instantiates twice; 2 bytes like bf16_t.
+// the init stage is the accumulated rounding of the backbone's 53 stored maps).  The range is 65504: stores saturate (MODE.FP16_OVFL,
+// half_kernel_init) instead of producing inf.  A distinct tag type so that every kernel template instantiates twice; 2 bytes like bf16_t.
 struct f16s_t { unsigned short u; };
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
@@ -90,16 +90,14 @@ template <> struct Half<bf16_t> {
 template <> struct Half<f16s_t> {
     static constexpr int DT = DIR_DT_F16;
     static __device__ __forceinline__ float to_f32(unsigned short v) { return (float)__builtin_bit_cast(_Float16, v); }
-    // round to nearest even after clamping to the finite range (one v_med3_f32 per value)
+    // Round to nearest even; SATURATING at +-65504 through the wave's MODE.FP16_OVFL bit, which every f16-storage kernel sets first thing
+    // (half_kernel_init below): measured on gfx950 (tools/ubench_f16_ovfl.hip) v_cvt_pk_f16_f32 then turns 70000 / 1e6 / 65520 into 0x7bff and
+    // keeps a true inf -- a clamp that costs no VALU instruction (the first version clamped with v_med3_f32 per value: +1.5 % on the step).
     static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-        const f32x2_t c = {__builtin_amdgcn_fmed3f(lo, -F16_MAX, F16_MAX), __builtin_amdgcn_fmed3f(hi, -F16_MAX, F16_MAX)};
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2_t));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
     }
-    // ReLU and the clamp in the same v_med3_f32: med3(v, 0, 65504)
-    static __device__ __forceinline__ uint32_t pack2_relu(float lo, float hi) {
-        const f32x2_t c = {__builtin_amdgcn_fmed3f(lo, 0.f, F16_MAX), __builtin_amdgcn_fmed3f(hi, 0.f, F16_MAX)};
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2_t));
-    }
+    // ReLU on the packed bit patterns, as for bf16 (sign bit set = negative int16 -> 0)
+    static __device__ __forceinline__ uint32_t pack2_relu(float lo, float hi) { return relu2bf(pack2(lo, hi)); }
     template <typename A, typename B> static __device__ __forceinline__ f32x16 mfma32(const A a, const B b, const f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
@@ -107,6 +105,11 @@ template <> struct Half<f16s_t> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+// First statement of every kernel that STORES the 16-bit kind T: f16 -> MODE.FP16_OVFL = 1 for this wave (hwreg(HW_REG_MODE, 23, 1)): fp32 -> f16
+// conversions saturate instead of overflowing to inf.  Nothing for bf16 / fp32.
+template <typename T> __device__ __forceinline__ void half_kernel_init() {
+    if constexpr (std::is_same<T, f16s_t>::value) __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);
+}
 // a packed pair of 16-bit values -> two floats
 template <typename H> __device__ __forceinline__ void unpack2(uint32_t u, float& lo, float& hi) {
     lo = Half<H>::to_f32((unsigned short)(u & 0xffffu));

@@ -40,6 +40,7 @@ constexpr int PRE_MAX_CIN = 2304;      // pre-activation parameters staged in LD
 template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRE = false, int NBUF = 3, int XM = 0, typename TIN = bf16_t>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) {
     typedef TIN TI;
+    half_kernel_init<TO>();
     static_assert(XM == 0 || (!SPARSE && !PRE && std::is_same<TO, float>::value), "pre-split operands: dense, no pre-activation, fp32 output");
     constexpr int NT = 64 * WM * WN;               // threads
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
@@ -344,6 +345,7 @@ struct KPos {        // position in the (channel slab, tap) stream
 template <typename TO, int MI, int NJ, int WM, int WN, bool SPARSE, bool PRELOAD = false, int PMAX = PATCH_MAX_ROWS, typename TIN = bf16_t>
 __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a, PatchGeom g) {
     typedef TIN TI;
+    half_kernel_init<TO>();
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
     constexpr int RPP = NT / 8;                        // rows per DMA pass of the workgroup
@@ -385,8 +387,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
     const int b0 = m0 / hw, y0 = (m0 - b0 * hw) / a.Wo;        // the tile starts at the beginning of an image row
 
     // ---- patch DMA source of this thread: patch row RPP * i + (tid >> 3), chunk (tid & 7) ^ swizzle, channel slab 0
+    // Swizzle of the PATCH rows (round 5, profiles/r05_a_sq_counters.txt: SQ_LDS_BANK_CONFLICT was 25 % of this kernel's LDS cycles): chunk c of
+    // patch row r sits at position c ^ key(r), key(r) = ((r - (kw - 1) * (r / PW)) >> 1) & 7 -- the row index with the halo columns of the
+    // patch lines above it taken out.  A wave's 32 output pixels read rows that are consecutive EXCEPT for a jump of kw - 1 at every image-row
+    // end (Wo = 16: two image rows per 32 lanes, Wo = 8: four); with the plain (r >> 1) & 7 key those jumps put two rows of a 16-lane ds_read_b128
+    // group on the same 16-byte slot.  In t = r - (kw - 1) * line the lanes of a 32-pixel block are linear again (t = t0 + lane for every tap),
+    // row parity = parity of t, and a 16-lane group covers 16 distinct (parity, key) pairs for any t0: conflict free at every tap.
     unsigned pvoff[MAXPP];
-    const int col = (tid & 7) ^ ((tid >> 4) & 7);
+    const int col = (tid & 7) ^ ((tid >> 4) & 7);           // (weight rows: the plain key)
     const int pseg = g.PH * g.PW;
 #pragma unroll
     for (int i = 0; i < MAXPP; ++i) {
@@ -397,8 +405,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
             const int py = rem / g.PW, px = rem - py * g.PW;
             const int b = g.nseg > 1 ? b0 + seg : b0;
             const int iy = (g.nseg > 1 ? 0 : y0) + py - a.pad, ix = px - a.pad;
+            const int pcol = (tid & 7) ^ (((prow - (a.kw - 1) * (seg * g.PH + py)) >> 1) & 7);
             if (b < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                pvoff[i] = (unsigned)((((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + col * 8) * ES);
+                pvoff[i] = (unsigned)((((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + pcol * 8) * ES);
         }
     }
     // passes this wave takes part in (a piece always writes the wave's 8 rows; rows >= npr are zero-filled)
@@ -471,13 +480,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
 
     // ---- fragment addressing.  A: lane (i = lane & 31, h = lane >> 5) reads chunks h*4+q of the patch row of its output
     //      pixel shifted by the tap; B: as in conv.hip.  Chunk c of LDS row r sits at position c ^ ((r >> 1) & 7).
-    int pr0[MI];
+    int pr0[MI], pt0[MI];                             // patch row of the pixel's first tap, and its key index t0 = row - (kw - 1) * line
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int r = wm * MI * 32 + i * 32 + (lane & 31);
         const int seg = r / g.seg_px, rr = r - seg * g.seg_px;
         const int y = rr / a.Wo, xx = rr - y * a.Wo;
         pr0[i] = seg * pseg + y * g.PW + xx;
+        pt0[i] = pr0[i] - (a.kw - 1) * (seg * g.PH + y);
     }
     int hq4[4], qoff[4];
 #pragma unroll
@@ -489,14 +499,14 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
 
     uint4 fa[MI][4], fb[NJ][4];
     auto frag_load = [&](const KPos& p, const char* bbuf) {
-        const int shift = p.ky * g.PW + p.kx;
+        const int shift = p.ky * g.PW + p.kx, tshift = p.ky * (g.PW - (a.kw - 1)) + p.kx;      // (row, key index) of tap (ky, kx) relative to tap 0
         const int pbase = (p.ci & 1) * P_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int row = pr0[i] + shift;
-                fa[i][q] = *reinterpret_cast<const uint4*>(smem + pbase + row * ROW + (hq4[q] ^ ((row << 3) & 0x70)));
+                fa[i][q] = *reinterpret_cast<const uint4*>(smem + pbase + row * ROW + (hq4[q] ^ (((pt0[i] + tshift) << 3) & 0x70)));
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) fb[j][q] = *reinterpret_cast<const uint4*>(bbuf + frag_b + j * 32 * ROW + qoff[q]);

@@ -68,6 +68,7 @@ struct StemArgs {
 
 template <bool U8, typename H = bf16_t>
 __global__ __launch_bounds__(NTHR, 2) void stem_pool_kernel(StemArgs a) {
+    convk::half_kernel_init<H>();
     __shared__ __attribute__((aligned(16))) char s_patch[PR * PPITCH];
     __shared__ __attribute__((aligned(16))) char s_conv[NPIX * CPITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

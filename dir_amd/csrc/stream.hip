@@ -47,6 +47,7 @@ struct StreamArgs {
 // H: the 16-bit storage kind of activations, weights and outputs (bf16_t | f16s_t: DIR_DT_BF16 | DIR_DT_F16)
 template <int NCB, bool PRE, int NPB, typename H = bf16_t>
 __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(StreamArgs a) {
+    convk::half_kernel_init<H>();
     constexpr int SBM = 32 * NPB;
     constexpr int NWG = 128 * NCB;                         // output channels per workgroup
     constexpr int OPITCH = 256 + 16;                       // bytes per pixel of the staged output half (128 channels), 16-byte aligned rows

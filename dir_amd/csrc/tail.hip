@@ -76,6 +76,7 @@ template <typename H> __device__ __forceinline__ void unpack4(uint2 v, float (&f
 // H: the 16-bit storage kind (bf16_t | f16s_t = DIR_DT_BF16 | DIR_DT_F16): tensors, weight stream and the T tile
 template <int P, int N2, typename H = bf16_t>
 __global__ __launch_bounds__(NTHR, 1) void tail_chain_kernel(TailArgs a) {
+    convk::half_kernel_init<H>();
     constexpr int C4 = 4 * P, NH = C4 / HC;
     constexpr int YROW = P * 2;                         // bytes per y2 pixel (unpadded: 16-byte chunk c of row r sits at c ^ (r & 15))
     constexpr int GRP = P == 256 ? 4 : 8;               // weight fragments per ring group (1 KB each per wave): register budget
@@ -351,6 +352,7 @@ constexpr int TTM = 32, TTHR = 256;
 
 template <int P, int N2, typename H = bf16_t>
 __global__ __launch_bounds__(TTHR, 2) void tail_thin_kernel(TailArgs a) {
+    convk::half_kernel_init<H>();
     constexpr int C4 = 4 * P, NH = C4 / HC;
     constexpr int YROW = P * 2;
     constexpr int GRP = 8;
