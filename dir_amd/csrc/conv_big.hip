@@ -89,10 +89,10 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < ACH; ++p) {
             const bool ok = (amask[p] >> s.tap) & 1u;
-            lds_dma16_untracked(xd, ba + p * (RPP * ROW), ok ? (unsigned)(avoff[p] + s.toff) : OOB, 0);
+            lds_dma16_m0(xd, ba + p * (RPP * ROW), ok ? (unsigned)(avoff[p] + s.toff) : OOB, 0);
         }
 #pragma unroll
-        for (int p = 0; p < BCH; ++p) lds_dma16_untracked(wd, ba + A_BYTES + p * (RPP * ROW), bvoff[p], (unsigned)(s.k0 * ES));
+        for (int p = 0; p < BCH; ++p) lds_dma16_m0(wd, ba + A_BYTES + p * (RPP * ROW), bvoff[p], (unsigned)(s.k0 * ES));
     };
 
     f32x16 acc[MI][NJ];

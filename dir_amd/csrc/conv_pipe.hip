@@ -22,6 +22,9 @@
 #ifndef DIR_P15_NBUF
 #define DIR_P15_NBUF 3
 #endif
+#ifndef DIR_PATCH_PLAIN_KEY
+#define DIR_PATCH_PLAIN_KEY 0
+#endif
 
 namespace dir {
 namespace convk {
@@ -180,10 +183,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_pipe_kernel(ConvArgs a) 
         constexpr int p = decltype(PIdx)::value;
         if constexpr (p < ACH) {
             const bool ok = ((amask[p] >> s.tap) & 1u) && live;
-            lds_dma16_untracked(xd, bufaddr + p * (RPP * ROW), ok ? (unsigned)(avoff[p] + s.toff) : OOB, 0);
+            lds_dma16_m0(xd, bufaddr + p * (RPP * ROW), ok ? (unsigned)(avoff[p] + s.toff) : OOB, 0);
         } else {
             constexpr int i = p - ACH;
-            lds_dma16_untracked(wd, bufaddr + A_BYTES + i * (RPP * ROW), live ? bvoff[i] : OOB, (unsigned)(s.k0 * ES));
+            lds_dma16_m0(wd, bufaddr + A_BYTES + i * (RPP * ROW), live ? bvoff[i] : OOB, (unsigned)(s.k0 * ES));
         }
     };
     auto dma_slab = [&](const Slab& s, int buf, bool live) {
@@ -405,7 +408,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
             const int py = rem / g.PW, px = rem - py * g.PW;
             const int b = g.nseg > 1 ? b0 + seg : b0;
             const int iy = (g.nseg > 1 ? 0 : y0) + py - a.pad, ix = px - a.pad;
+#if DIR_PATCH_PLAIN_KEY            // (A/B aid, -DDIR_PATCH_PLAIN_KEY=1: the pre-round-5 key (row >> 1) & 7)
+            const int pcol = (tid & 7) ^ ((prow >> 1) & 7);
+#else
             const int pcol = (tid & 7) ^ (((prow - (a.kw - 1) * (seg * g.PH + py)) >> 1) & 7);
+#endif
             if (b < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
                 pvoff[i] = (unsigned)((((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + pcol * 8) * ES);
         }
@@ -487,7 +494,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
         const int seg = r / g.seg_px, rr = r - seg * g.seg_px;
         const int y = rr / a.Wo, xx = rr - y * a.Wo;
         pr0[i] = seg * pseg + y * g.PW + xx;
+#if DIR_PATCH_PLAIN_KEY
+        pt0[i] = pr0[i];
+#else
         pt0[i] = pr0[i] - (a.kw - 1) * (seg * g.PH + y);
+#endif
     }
     int hq4[4], qoff[4];
 #pragma unroll
@@ -499,7 +510,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_patch_kernel(ConvArgs a,
 
     uint4 fa[MI][4], fb[NJ][4];
     auto frag_load = [&](const KPos& p, const char* bbuf) {
+#if DIR_PATCH_PLAIN_KEY
+        const int shift = p.ky * g.PW + p.kx, tshift = shift;
+#else
         const int shift = p.ky * g.PW + p.kx, tshift = p.ky * (g.PW - (a.kw - 1)) + p.kx;      // (row, key index) of tap (ky, kx) relative to tap 0
+#endif
         const int pbase = (p.ci & 1) * P_BYTES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -145,11 +145,14 @@ class WeightPack:
 
     def _upload(self):
         import ctypes as C
+        if torch.cuda.is_current_stream_capturing():
+            # a pageable host -> device copy (and its stream synchronisation) is not capturable: GraphedTrainStep calls sync_table() before it captures
+            raise RuntimeError('WeightPack: operand scales changed inside a HIP-graph capture; call sync_table() before capturing (ADVICE r4)')
         host = torch.frombuffer(bytearray(C.string_at(C.addressof(self._ctable), self._nbytes)), dtype=torch.uint8)
         self.table.copy_(host)
 
-    def refresh(self):
-        """pack the CURRENT values of every weight (call once per step, before the first convolution)"""
+    def _apply_pending(self):
+        """operand scales asked for during the last step (want) become the applied ones; True if the device table must be re-uploaded"""
         dirty = False
         for t, e in zip(self._ctable, self.entries):
             for f in (0, 1):
@@ -158,7 +161,18 @@ class WeightPack:
                     dirty = True
                 e.want[f] = None
             t.fwd_inv_in, t.dgrad_inv_in = 1.0 / e.applied[0], 1.0 / e.applied[1]
-        if dirty:
+        return dirty
+
+    def sync_table(self):
+        """apply pending operand-scale changes to the device table NOW.  GraphedTrainStep calls this before every capture: the eager step before it
+        (warm-up or re-calibration) re-measured the scales, and refresh() inside the capture would otherwise find the table dirty and upload it
+        from pageable host memory in the middle of the capture"""
+        if self._apply_pending():
+            self._upload()
+
+    def refresh(self):
+        """pack the CURRENT values of every weight (call once per step, before the first convolution)"""
+        if self._apply_pending():
             self._upload()
         with torch.cuda.device(self.table.device):
             _capi.check(_capi.lib().dir_train_pack_conv_weights(_capi.ptr(self.table), _capi.ptr(self.row_start), len(self.entries), self.total_rows,

@@ -145,6 +145,9 @@ class GraphedTrainStep(object):
                 self.optimizer.step()
                 self.since_capture = 0
                 return loss
+            pk = getattr(self.optimizer, '_dir_weight_pack', None)
+            if pk is not None:
+                pk.sync_table()            # scales re-measured by the eager step before this one reach the device table OUTSIDE the capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
