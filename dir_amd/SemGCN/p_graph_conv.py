@@ -45,8 +45,29 @@ class PGraphConv(nn.Module):
         keep.append(t)
         return _capi.PgcnLayer(*(x.data_ptr() for x in t), int(relu))
 
+    def _train_forward(self, input):
+        """.train(): SemGCN/p_graph_conv.py:39-59 with autograd (one node: dir_amd/train/pgcn.py gconv_forward / gconv_backward)"""
+        from ..train import autograd as AG
+        from ..train import pgcn as TP
+        params = {'W': self.W, 'e_0': self.e_0, 'e_1': self.e_1}
+        if self.bias is not None:
+            params['bias'] = self.bias
+
+        def fwd(P, xx):
+            z, saved = TP.gconv_forward(P, '', _capi.f32c(xx))
+            return (z,), saved
+
+        def bwd(P, saved, gz):
+            G = {}
+            gx = TP.gconv_backward(P, '', saved, gz.reshape(-1, 128), G)
+            return (gx,), G
+        with torch.cuda.device(input.device):
+            return AG.run(fwd, bwd, [input], params)[0]
+
     def forward(self, input):
         _capi.require_cuda(input, self.W)
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(input)
         x = _capi.f32c(input.detach())
         B = x.shape[0]
         keep = []

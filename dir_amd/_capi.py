@@ -193,6 +193,11 @@ _SIGNATURES = {
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
     'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_bn_frozen_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_bn_sync_workspace_bytes': (C.c_longlong, [_i, _i]),
+    'dir_bn_sync_local_stats': (C.c_int, [_p, _p, _i, _i, _i, _p, C.c_longlong, _p]),
+    'dir_bn_sync_combine': (C.c_int, [_p, _i, _i, _p, _p, _p, _p, C.c_float, _p]),
+    'dir_bn_sync_backward_sums': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
+    'dir_bn_sync_backward_apply': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, C.c_float, _i, _i, _i, _p]),
     'dir_bn_frozen_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, _i, _p, _p]),
     'dir_bn_frozen_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_relu_forward': (C.c_int, [_p, _p, C.c_longlong, _p]),
@@ -227,7 +232,7 @@ PROFILE = None
 _pending = {}
 _NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
                'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes',
-               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
+               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_bn_sync_workspace_bytes', 'dir_bn_frozen_workspace_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
 
 
 def annotate(**kw):

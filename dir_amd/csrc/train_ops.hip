@@ -866,6 +866,61 @@ __global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, 
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (R > 1 ? q / (R - 1) : var);
     }
 }
+// ---- SyncBN (round 5; SURVEY.md 8e "optionally offer SyncBN": the reference trains 64 images on ONE GPU, config.py:13-15 -- 8 x 32 changes the
+// BatchNorm batch unless the statistics are pooled).  The local part of the statistics: this rank's mean and M2 = sum (x - mean_local)^2 per
+// channel from the same chunk partials as bn_stats_combine_kernel, combined in the same (chunk) order.
+__global__ __launch_bounds__(256) void bn_stats_local_kernel(const float* p1, const float* p2, float* mean_out, float* m2_out, int chunks, int R, int C) {
+    __shared__ float s[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    const float mu = chunk_sum16(p1, chunks, C, c, s) / R;
+    __syncthreads();
+    float a = 0.f;
+    if (c < C)
+        for (int k = rl; k < chunks; k += 16) {
+            const int nk = min(BN_CHUNK_ROWS, R - k * BN_CHUNK_ROWS);
+            const float d = p1[(long long)k * C + c] / nk - mu;
+            a += fmaf((float)nk * d, d, p2[(long long)k * C + c]);
+        }
+    s[rl][cl] = a;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    float q = 0.f;
+    for (int l = 0; l < 16; ++l) q += s[l][cl];
+    mean_out[c] = mu; m2_out[c] = q;
+}
+// The ranks' parts [W][2 C + 4] = (mean_r [C] | M2_r [C] | rows_r, 0, 0, 0), gathered in rank order, pooled exactly (Chan): n = sum n_r,
+// mean = sum n_r mean_r / n, M2 = sum [M2_r + n_r (mean_r - mean)^2]; every rank runs this on the same gathered bytes -> the same statistics
+// everywhere.  Writes the pooled mean and BIASED variance (what dir_bn_frozen_forward normalises with) and updates the running statistics with
+// the unbiased one over the pooled count, like nn.SyncBatchNorm.
+__global__ __launch_bounds__(256) void bn_sync_combine_kernel(const float* parts, int W, int C, float* mean_out, float* var_out, float* running_mean,
+                                                             float* running_var, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int stride = 2 * C + 4;
+    float n = 0.f, sm = 0.f;
+    for (int r = 0; r < W; ++r) { const float nr = parts[(long long)r * stride + 2 * C]; n += nr; sm = fmaf(nr, parts[(long long)r * stride + c], sm); }
+    const float mu = sm / n;
+    float q = 0.f;
+    for (int r = 0; r < W; ++r) {
+        const float nr = parts[(long long)r * stride + 2 * C], d = parts[(long long)r * stride + c] - mu;
+        q += fmaf(nr * d, d, parts[(long long)r * stride + C + c]);
+    }
+    mean_out[c] = mu; var_out[c] = q / n;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? q / (n - 1.f) : q / n);
+    }
+}
+// backward: the two column sums of this rank (t1 = sum g, t2 = sum g xhat, g = gy under the ReLU mask) side by side in sums [2 C]
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const float* p1, const float* p2, float* sums, int chunks, int C) {
+    __shared__ float s[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const float a = chunk_sum16(p1, chunks, C, c, s);
+    __syncthreads();
+    const float b = chunk_sum16(p2, chunks, C, c, s);
+    if ((threadIdx.x >> 4) != 0 || c >= C) return;
+    sums[c] = a; sums[C + c] = b;
+}
 // one thread = 4 channels of 4 rows
 __global__ __launch_bounds__(256) void bn_apply_fwd4_kernel(const float* x, const float* w, const float* b, const float* mu, const float* rs, float* y,
                                                            int R, int C, int ld, int relu, const float* res) {
@@ -951,7 +1006,7 @@ __global__ __launch_bounds__(256) void bn_bwd_combine_kernel(const float* p1, co
     if (gw) gw[c] = b;
 }
 __global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, const float* x, const float* w, const float* b, const float* mu, const float* rs,
-                                                           const float* s1, const float* s2, float* gx, int R, int C, int ld, int relu) {
+                                                           const float* s1, const float* s2, float* gx, int R, int C, int ld, int relu, float n_pool = 0.f) {
     const int cq = C >> 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = (int)(i % cq) * 4;
@@ -961,7 +1016,8 @@ __global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, con
     const float4 m = *reinterpret_cast<const float4*>(mu + c), k = *reinterpret_cast<const float4*>(rs + c);
     const float4 g = w ? *reinterpret_cast<const float4*>(w + c) : one, be = b ? *reinterpret_cast<const float4*>(b + c) : zero;
     const float4 a1 = *reinterpret_cast<const float4*>(s1 + c), a2 = *reinterpret_cast<const float4*>(s2 + c);
-    const float4 m1 = make_float4(a1.x / R, a1.y / R, a1.z / R, a1.w / R), m2 = make_float4(a2.x / R, a2.y / R, a2.z / R, a2.w / R);
+    const float nn = n_pool > 0.f ? n_pool : (float)R;          // SyncBN: the sums were pooled over all ranks' rows
+    const float4 m1 = make_float4(a1.x / nn, a1.y / nn, a1.z / nn, a1.w / nn), m2 = make_float4(a2.x / nn, a2.y / nn, a2.z / nn, a2.w / nn);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const long long r = r0 + e;
@@ -1655,6 +1711,55 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
         }
     }
     return check_launch("dir_bn_train_backward");
+}
+
+// ---- SyncBN building blocks (dir_amd/train/ops.py: sync_bn_fwd / sync_bn_bwd put the collectives between them)
+extern "C" long long dir_bn_sync_workspace_bytes(int R, int C) {
+    if (R <= 0 || C <= 0) return -1;
+    const long long chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    return 2 * chunks * C * 4;
+}
+extern "C" int dir_bn_sync_local_stats(const float* x, float* part, int R, int C, int ld, float* workspace, long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && part && R > 0 && C > 0 && ld >= C, "dir_bn_sync_local_stats: bad arguments");
+    DIR_REQUIRE(bn_vec4(C, ld, {x, part, workspace}), "dir_bn_sync_local_stats: C and ld must be multiples of 4, pointers 16-byte aligned");
+    DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_sync_workspace_bytes(R, C), "dir_bn_sync_local_stats: workspace too small (dir_bn_sync_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    float* p1 = workspace; float* p2 = p1 + (long long)chunks * C;
+    DIR_LAUNCH(bn_stats4_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, x, p1, p2, R, C, ld);
+    DIR_LAUNCH(bn_stats_local_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)p1, (const float*)p2, part, part + C, chunks, R, C);
+    return check_launch("dir_bn_sync_local_stats");
+}
+extern "C" int dir_bn_sync_combine(const float* parts, int world, int C, float* mean, float* var, float* running_mean, float* running_var, float momentum,
+                                   void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(parts && mean && var && world > 0 && C > 0 && ((running_mean == nullptr) == (running_var == nullptr)), "dir_bn_sync_combine: bad arguments");
+    DIR_LAUNCH(bn_sync_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, parts, world, C, mean, var, running_mean, running_var, momentum);
+    return check_launch("dir_bn_sync_combine");
+}
+extern "C" int dir_bn_sync_backward_sums(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                                         float* sums, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && save_mean && save_rstd && sums && R > 0 && C > 0 && ld >= C, "dir_bn_sync_backward_sums: bad arguments");
+    DIR_REQUIRE(bn_vec4(C, ld, {x, gy, w, b, save_mean, save_rstd, sums, workspace}), "dir_bn_sync_backward_sums: C and ld must be multiples of 4, pointers 16-byte aligned");
+    DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_sync_workspace_bytes(R, C), "dir_bn_sync_backward_sums: workspace too small (dir_bn_sync_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    float* p1 = workspace; float* p2 = p1 + (long long)chunks * C;
+    DIR_LAUNCH(bn_bwd_partial4_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, s, x, gy, w, b, save_mean, save_rstd, p1, p2, R, C, ld, relu);
+    DIR_LAUNCH(bn_bwd_sums_kernel, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)p1, (const float*)p2, sums, chunks, C);
+    return check_launch("dir_bn_sync_backward_sums");
+}
+extern "C" int dir_bn_sync_backward_apply(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                                          const float* sums_pooled, float* gx, int R, float rows_pooled, int C, int ld, int relu, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && save_mean && save_rstd && sums_pooled && gx && R > 0 && C > 0 && ld >= C && rows_pooled >= (float)R, "dir_bn_sync_backward_apply: bad arguments");
+    DIR_REQUIRE(bn_vec4(C, ld, {x, gy, gx, w, b, save_mean, save_rstd, sums_pooled}), "dir_bn_sync_backward_apply: C and ld must be multiples of 4, pointers 16-byte aligned");
+    const long long nt = (long long)((R + 3) / 4) * (C / 4);
+    DIR_LAUNCH(bn_apply_bwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gy, x, w, b, save_mean, save_rstd, sums_pooled,
+               sums_pooled + C, gx, R, C, ld, relu, rows_pooled);
+    return check_launch("dir_bn_sync_backward_apply");
 }
 
 // BatchNorm with FROZEN statistics inside a training pass (nn.BatchNorm*.eval() under model.train(): the fine-tuning form, and the form in which

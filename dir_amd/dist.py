@@ -75,6 +75,36 @@ def gather_shards(local, n_total):
     return torch.cat(out, 0)
 
 
+def _collective_view(t):
+    """gloo (the CPU test backend, and DIR_BENCH_BACKEND=gloo on a box with fewer GPUs than ranks) reduces host memory: a device tensor goes
+    through a host copy there; RCCL takes the device tensor itself"""
+    if t.is_cuda and dist.get_backend() != 'nccl':
+        return t.cpu(), True
+    return t, False
+
+
+def all_gather_rows(t):
+    """[n] -> [world, n]: every rank's vector, in rank order, on every rank (SyncBN forward: the per-channel (mean | M2 | rows) parts).
+    One process: t[None]."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t.unsqueeze(0)
+    world = dist.get_world_size()
+    src, staged = _collective_view(t.contiguous())
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src)
+    out = torch.stack(parts, 0)
+    return out.to(t.device) if staged else out
+
+
+def all_reduce_sum(t):
+    """sum over the ranks, returned as a new tensor on t's device (SyncBN backward: the pooled (sum g | sum g xhat)).  One process: t."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    src, staged = _collective_view(t.contiguous().clone())
+    dist.all_reduce(src, op=dist.ReduceOp.SUM)
+    return src.to(t.device) if staged else src
+
+
 def average_gradients(flat_grad, bucket_elems=64 << 20):
     """Data-parallel gradient exchange of the reference's training set-up (one all-reduce of the 92.7 M gradients per
     step, divided by the world size): `flat_grad` is dir_amd.optim.FlatAdamW.flat_grad, already one contiguous buffer, reduced in

@@ -4,7 +4,8 @@ computed by ONE fused HIP kernel (dir_mano_forward, dir_amd/csrc/mano.hip) inste
 
 Supported configuration = the one the network uses (models/dir.py:221-224,315-318): root_rot_mode='6D',
 joint_rot_mode='axisang', use_pca=True, robust_rot=True.  Other modes raise NotImplementedError: they
-are not on the DIR hot path.  Forward only (inference); outputs carry no autograd graph.
+are not on the DIR hot path.  When an input requires grad the outputs carry ONE autograd node whose backward is
+dir_mano_backward_pair (round 5); otherwise no graph is built.
 
 MANO tables: the licensed MANO_{LEFT,RIGHT}.pkl needs chumpy to unpickle and is out of scope
 (SURVEY.md 2); the published checkpoint already carries every th_* buffer, so
@@ -72,8 +73,46 @@ class ManoLayer(Module):
                                 p['comps'].data_ptr(), 0 if self.side == 'right' else 1,
                                 -1 if center_idx is None else int(center_idx), int(bool(root_palm)))
 
+    def _grad_forward(self, th_pose_coeffs, th_betas, th_trans, root_palm, share_betas):
+        """the same forward with an autograd node behind it (the reference's layer is differentiable,
+        manopth/manopth/manolayer.py:110-270 under train.py:64-70): dir_mano_forward, and dir_mano_backward_pair for the gradients w.r.t.
+        th_pose_coeffs [B,51] and th_betas [B,10] (the forward is recomputed inside the backward kernel, nothing is saved but the inputs)"""
+        from .. import functional as F
+        if share_betas:
+            raise NotImplementedError('share_betas is not differentiated here (not on the DIR path: models/dir.py never passes it)')
+        B = th_pose_coeffs.shape[0]
+        own_betas = th_betas is None or th_betas.numel() == 1
+        betas_in = self.th_betas.expand(B, 10).contiguous() if own_betas else th_betas.to(th_pose_coeffs.device)
+        use_trans = th_trans is not None and bool(torch.norm(th_trans) != 0)
+        layer = self
+
+        class _Mano(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, pose, betas):
+                verts, joints = layer._raw(pose.detach(), betas.detach(), use_trans, root_palm)
+                ctx.save_for_backward(pose.detach(), betas.detach())
+                ctx.set_materialize_grads(False)
+                return verts, joints
+
+            @staticmethod
+            def backward(ctx, g_verts, g_joints):
+                pose, betas = ctx.saved_tensors
+                para = torch.cat([_capi.f32c(pose), _capi.f32c(betas), torch.zeros(B, 3, device=pose.device)], 1).contiguous()     # the 64-vector layout of the kernel
+                t = layer.c_tables(None if use_trans else layer.center_idx, root_palm)
+                with torch.cuda.device(pose.device):
+                    g = F.mano_backward([t], [para], g_verts=None if g_verts is None else [g_verts.contiguous()],
+                                        g_joints=None if g_joints is None else [g_joints.contiguous()])[0]
+                return g[:, :51].contiguous(), (g[:, 51:61].contiguous() if ctx.needs_input_grad[1] else None)
+        verts, joints = _Mano.apply(th_pose_coeffs, betas_in)
+        if use_trans:                         # (translation: plain torch adds on the node's outputs, differentiated by autograd itself)
+            joints = joints + th_trans.unsqueeze(1)
+            verts = verts + th_trans.unsqueeze(1)
+        return verts, joints
+
     def forward(self, th_pose_coeffs, th_betas=torch.zeros(1), th_trans=None, root_palm=False, share_betas=False):
         _capi.require_cuda(th_pose_coeffs)
+        if torch.is_grad_enabled() and (th_pose_coeffs.requires_grad or (torch.is_tensor(th_betas) and th_betas.requires_grad)):
+            return self._grad_forward(th_pose_coeffs, th_betas, th_trans, root_palm, share_betas)
         B = th_pose_coeffs.shape[0]
         pose = th_pose_coeffs.detach()
         if pose.dtype != torch.float32 or pose.stride(-1) != 1:
@@ -87,6 +126,19 @@ class ManoLayer(Module):
             if betas.dtype != torch.float32 or betas.stride(-1) != 1 or (B > 1 and betas.stride(0) == 0):
                 betas = _capi.f32c(betas)
         use_trans = th_trans is not None and bool(torch.norm(th_trans) != 0)
+        verts, joints = self._raw(pose, betas, use_trans, root_palm)
+        if use_trans:
+            joints = joints + th_trans.unsqueeze(1)
+            verts = verts + th_trans.unsqueeze(1)
+        return verts, joints
+
+    def _raw(self, pose, betas, use_trans, root_palm):
+        """the kernel call: pose [B,51] / betas [B,10] fp32 (detached) -> verts, joints before the optional translation"""
+        B = pose.shape[0]
+        if pose.dtype != torch.float32 or pose.stride(-1) != 1:
+            pose = _capi.f32c(pose)
+        if betas.dtype != torch.float32 or betas.stride(-1) != 1 or (B > 1 and betas.stride(0) == 0):
+            betas = _capi.f32c(betas)
         t = self.c_tables(None if use_trans else self.center_idx, root_palm)
         verts = torch.empty(B, 778, 3, device=pose.device, dtype=torch.float32)
         joints = torch.empty(B, 21, 3, device=pose.device, dtype=torch.float32)
@@ -100,7 +152,4 @@ class ManoLayer(Module):
         if self.check_reflection and B > 0:
             # rot6d.py:50 of the reference asserts "no reflection" per sample (host sync there too)
             assert int(flags[:B].sum().item()) == 0
-        if use_trans:
-            joints = joints + th_trans.unsqueeze(1)
-            verts = verts + th_trans.unsqueeze(1)
         return verts, joints

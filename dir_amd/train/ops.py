@@ -140,6 +140,78 @@ class frozen_batchnorm(object):
         BN_FROZEN = self.prev
 
 
+# SyncBN (SURVEY.md 8e "optionally offer"; torch.nn.SyncBatchNorm semantics): with SYNC_BN on and more than one rank, every training-mode
+# BatchNorm of the step pools its statistics over the ranks -- the reference's batch of 64 on one GPU (config.py:13-15) split over N GPUs then
+# normalises exactly like the single-GPU batch.  Two small collectives per layer and direction (2 C + 4 floats gathered forward, 2 C floats
+# reduced backward): not capturable in a HIP graph, so GraphedTrainStep is not for this mode.  Unmeasured on multi-GPU hardware (no node).
+SYNC_BN = False
+
+
+class sync_batchnorm(object):
+    """with sync_batchnorm(): every bn_train_fwd / bn_train_bwd of the block pools its statistics over the ranks (a no-op with one rank)"""
+    def __enter__(self):
+        global SYNC_BN
+        self.prev, SYNC_BN = SYNC_BN, True
+
+    def __exit__(self, *a):
+        global SYNC_BN
+        SYNC_BN = self.prev
+
+
+def _sync_active(C, *ts):
+    from .. import dist as D
+    import torch.distributed as dist
+    return (SYNC_BN and not BN_FROZEN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and C % 4 == 0
+            and all(t is None or t.data_ptr() % 16 == 0 for t in ts)) and D is not None
+
+
+def _sync_ws(R, C, dev):
+    n = _capi.lib().dir_bn_sync_workspace_bytes(R, C)
+    return torch.empty(n // 4, device=dev), n
+
+
+def sync_bn_fwd(x, w, b, running_mean, running_var, eps, momentum, relu, residual):
+    """bn_train_fwd with the statistics pooled over the ranks: local (mean | M2) -> all-gather -> exact pooling (dir_bn_sync_combine, the same
+    bytes on every rank) -> normalisation with the pooled statistics (dir_bn_frozen_forward).  -> (y, (save_mean, save_rstd, rows_pooled))"""
+    from .. import dist as D
+    R, C = x.shape
+    L = _capi.lib()
+    part = torch.zeros(2 * C + 4, device=x.device)
+    ws, n = _sync_ws(R, C, x.device)
+    _capi.check(L.dir_bn_sync_local_stats(_capi.ptr(x), _capi.ptr(part), R, C, C, _capi.ptr(ws), n, _capi.stream_ptr()), 'dir_bn_sync_local_stats')
+    part[2 * C] = float(R)
+    parts = D.all_gather_rows(part).contiguous()
+    mean, var = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    _capi.check(L.dir_bn_sync_combine(_capi.ptr(parts), parts.shape[0], C, _capi.ptr(mean), _capi.ptr(var), _capi.ptr(running_mean), _capi.ptr(running_var),
+                                      float(momentum), _capi.stream_ptr()), 'dir_bn_sync_combine')
+    y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    _capi.check(L.dir_bn_frozen_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(mean), _capi.ptr(var),
+                                        R, C, C, float(eps), int(relu), _capi.ptr(residual), _capi.stream_ptr()), 'dir_bn_frozen_forward')
+    written = [t for t in (running_mean, running_var) if t is not None]
+    if written:
+        torch._C._increment_version(written)
+    return y, (sm, sr, float(parts[:, 2 * C].sum()))
+
+
+def sync_bn_bwd(gy, x, w, stats, need_gx, b, relu):
+    """bn_train_bwd for sync_bn_fwd: g w, g b are this rank's sums (the gradient exchange averages them); g x uses the sums pooled over the ranks"""
+    from .. import dist as D
+    R, C = x.shape
+    L = _capi.lib()
+    sums = torch.empty(2 * C, device=x.device)
+    ws, n = _sync_ws(R, C, x.device)
+    _capi.check(L.dir_bn_sync_backward_sums(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(sums),
+                                            R, C, C, int(relu), _capi.ptr(ws), n, _capi.stream_ptr()), 'dir_bn_sync_backward_sums')
+    gb, gw = sums[:C].clone(), sums[C:].clone()
+    gx = None
+    if need_gx:
+        pooled = D.all_reduce_sum(sums)
+        gx = torch.empty_like(x)
+        _capi.check(L.dir_bn_sync_backward_apply(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(pooled),
+                                                 _capi.ptr(gx), R, float(stats[2]), C, C, int(relu), _capi.stream_ptr()), 'dir_bn_sync_backward_apply')
+    return gx, gw, gb
+
+
 def _bn_ws(R, C, dev):
     n = _capi.lib().dir_bn_train_workspace_bytes(R, C)
     return (torch.empty(n // 4, device=dev) if n > 0 else None), n
@@ -152,6 +224,8 @@ def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentu
     assert residual is None or residual.shape == x.shape
     R, C = x.shape
     y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    if _sync_active(C, x, w, b, residual):
+        return sync_bn_fwd(x, w, b, running_mean, running_var, eps, momentum, relu, residual)
     if BN_FROZEN:
         assert running_mean is not None and running_var is not None, 'frozen BatchNorm needs the running statistics'
         _capi.check(_capi.lib().dir_bn_frozen_forward(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(y), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean),
@@ -173,6 +247,8 @@ def bn_train_bwd(gy, x, w, stats, need_gx=True, b=None, relu=False):
     _chk(gy, x, w, b)
     assert not relu or b is not None
     R, C = x.shape
+    if len(stats) == 3:                                     # saved by sync_bn_fwd (pooled row count in stats[2])
+        return sync_bn_bwd(gy, x, w, stats, need_gx, b, relu)
     gx = torch.empty_like(x) if need_gx else None
     gw, gb = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
     if BN_FROZEN:

@@ -60,10 +60,34 @@ class STE(nn.Module):
         self.spatial_norm = norm_layer(in_chans)
         self.head = nn.Sequential(nn.LayerNorm(in_chans), nn.Linear(in_chans, out_dim))
 
+    def _train_forward(self, x):
+        """.train(): transformer/mixSTE.py:194-205 with autograd -- dir_amd/train/ste.py's forward / backward (the whole-network training step's
+        kernels) behind one node; x is updated in place (x += spatial_pos_embed, mixSTE.py:196) and marked dirty, STEblocks[0] gets no gradient
+        like in the reference (it is never executed, mixSTE.py:197)"""
+        from ..train import autograd as AG
+        from ..train import ops as O
+        from ..train import ste as TS
+        params = dict(self.named_parameters())
+
+        def fwd(P, xx):
+            y, ctx = TS.ste_forward(P, xx, depth=self.block_depth)          # (xx IS x's storage: updated in place)
+            return (y,), ctx
+
+        def bwd(P, ctx, gy, g_dirty=None):
+            gx, G = TS.ste_backward(P, ctx, gy)
+            if g_dirty is not None:            # later uses of the updated x: d(x + pos)/dx = I, d/dpos = sum over the batch
+                O.axpy(gx, g_dirty)
+                O.axpy(G['spatial_pos_embed'].view(-1), O.colsum(g_dirty.view(g_dirty.shape[0], -1)))
+            return (gx,), G
+        with torch.cuda.device(x.device):
+            return AG.run(fwd, bwd, [x], params, dirty_first=True)[0]
+
     def forward(self, x):
         _capi.require_cuda(x)
         if x.dtype != torch.float32 or not x.is_contiguous():
             raise _capi.DirHipError('STE.forward expects a contiguous float32 [B,42,128] tensor (it is updated in place)')
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(x)
         b = x.shape[0]
         keep = []
         sd = {'ste.' + k: v.detach() for k, v in self.state_dict().items()}

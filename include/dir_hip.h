@@ -197,6 +197,25 @@ int dir_bn_frozen_forward(const float* x, const float* w, const float* b, float*
                           const float* running_var, int R, int C, int ld, float eps, int relu, const float* residual, void* stream);
 int dir_bn_frozen_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                            float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
+/* SyncBN building blocks (round 5; SURVEY.md 8e: the reference trains its batch of 64 on one GPU, config.py:13-15 -- data parallelism over 8 GPUs x 32
+ * images changes the BatchNorm batch unless the statistics are pooled; torch.nn.SyncBatchNorm semantics).  The library computes, the caller moves
+ * the 2 C (+ 4) floats between the ranks (dir_amd/train/ops.py: all-gather of the parts forward, all-reduce of the sums backward):
+ *   dir_bn_sync_local_stats     part [2 C] = this rank's (mean | M2 = sum (x - mean)^2) over its R rows        (the chunked one-pass statistics of
+ *                               dir_bn_train_forward);  the caller appends its row count: parts [W][2 C + 4] = (mean | M2 | rows, 0, 0, 0) per rank
+ *   dir_bn_sync_combine         pooled mean / BIASED variance [C] from the gathered parts (Chan's exact formula, rank order: identical on every
+ *                               rank); running statistics updated with the unbiased variance over the pooled count.  The forward is then
+ *                               dir_bn_frozen_forward(x, w, b, y, save_mean, save_rstd, mean, var, ...) -- normalise with GIVEN statistics.
+ *   dir_bn_sync_backward_sums   sums [2 C] = this rank's (sum g | sum g xhat), g = gy under the ReLU mask: g b and g w of THIS rank (the data-parallel
+ *                               gradient exchange averages them like every other parameter gradient)
+ *   dir_bn_sync_backward_apply  g x = w rstd (g - S1 / n - xhat S2 / n) with the sums pooled over all ranks (all-reduce SUM) and n = rows_pooled
+ * C and ld multiples of 4, 16-byte aligned pointers; workspace: dir_bn_sync_workspace_bytes(R, C). */
+long long dir_bn_sync_workspace_bytes(int R, int C);
+int dir_bn_sync_local_stats(const float* x, float* part, int R, int C, int ld, float* workspace, long long workspace_bytes, void* stream);
+int dir_bn_sync_combine(const float* parts, int world, int C, float* mean, float* var, float* running_mean, float* running_var, float momentum, void* stream);
+int dir_bn_sync_backward_sums(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* sums,
+                              int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
+int dir_bn_sync_backward_apply(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                               const float* sums_pooled, float* gx, int R, float rows_pooled, int C, int ld, int relu, void* stream);
 int dir_relu_forward(const float* x, float* y, long long n, void* stream);
 int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, void* stream);   /* g x = y > 0 ? g y : 0 */
 /* PGraphConv's adjacency (SemGCN/p_graph_conv.py:43-50): A_1 [21][21] = row-softmax of the hand-skeleton mask filled with e_1 [40]

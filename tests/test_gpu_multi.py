@@ -87,3 +87,22 @@ def test_bench_multi_rank_code_path_over_gloo(tmp_path):
     assert 'gloo' in d['config']['backend'] and d['config']['batch_per_gpu'] == 64
     assert abs(d['value'] - 2 * 64 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']          # whole-job: both ranks' images over the slowest rank's time
     assert d['roofline'] is not None and d['cpu_baseline'] is None
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_two_ranks_equal_the_single_process_batch(tmp_path):
+    """SURVEY.md 8e / VERDICT r4 item 8: opt-in SyncBN (dir_amd.train.ops.sync_batchnorm).  The reference normalises its 64 images on ONE GPU
+    (config.py:13-15); two ranks holding uneven halves of a batch pool (mean | M2 | rows) forward and (sum g | sum g xhat) backward and must
+    reproduce the single-process BatchNorm over the whole batch: y, saved / running statistics and g x to fp32 rounding, g w / g b as the sum of
+    the ranks' local ones; the pooled statistics are the same bytes on both ranks.  gloo group (both ranks share this box's GPU; RCCL on a
+    multi-GPU node is the same call) -- unmeasured on multi-GPU hardware."""
+    from dir_amd import dist as D
+    out = tmp_path / 'syncbn.json'
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'helpers', 'two_rank_syncbn.py')
+    assert D.spawn_ranks([script, str(out)], 2, timeout=900) == 0
+    got = json.loads(out.read_text())
+    assert got['world'] == 2 and len(got['cases']) == 3
+    for name, d in got['cases'].items():
+        assert d['ranks_agree'] == 0.0, (name, d)
+        for k in ('y', 'gx', 'gw', 'gb', 'running_mean', 'running_var', 'save_mean', 'save_rstd'):
+            assert d[k] < 2e-5, (name, k, d)
