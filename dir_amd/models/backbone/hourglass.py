@@ -28,10 +28,36 @@ class Residual(nn.Module):
         self.skip_layer = Conv(inp_dim, out_dim, 1, relu=False)
         self.need_skip = inp_dim != out_dim
 
+    def _train_forward(self, x):
+        """.train(): models/backbone/hourglass.py:55-70 with batch-statistics BatchNorm and autograd (dir_amd/train/blocks.py behind one node)"""
+        from ... import _capi
+        from ...train import autograd as AG
+        from ...train import blocks as TB
+        from ...train import conv as TC
+        params = dict(self.named_parameters())
+        buffers = {k: b for k, b in self.named_buffers() if 'num_batches_tracked' not in k}
+        for m in (self.bn1, self.bn2, self.bn3):
+            if m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+
+        def fwd(P, xx):
+            TC.begin_step(None)
+            y, ctx = TB.residual_forward(P, _capi.f32c(xx.permute(0, 2, 3, 1)))
+            return (y.permute(0, 3, 1, 2),), ctx
+
+        def bwd(P, ctx, gy):
+            gx, G = TB.residual_backward(P, ctx, gy.permute(0, 2, 3, 1).contiguous())
+            TC.end_step()
+            return (gx.permute(0, 3, 1, 2),), G
+        with torch.cuda.device(x.device):
+            return AG.run(fwd, bwd, [x], params, buffers)[0]
+
     def forward(self, x, compute_dtype=torch.float32):
         from ...engine import ResidualOp
         from ... import _capi
         _capi.require_cuda(x)
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(x)
         sd = {'r.' + k: v.detach() for k, v in self.state_dict().items()}
         op = ResidualOp(sd, 'r', compute_dtype)
         y = op(x.detach().permute(0, 2, 3, 1).contiguous().to(compute_dtype))

@@ -49,7 +49,38 @@ class ResNet(nn.Module):
 
     def forward(self, x, compute_dtype=torch.float32):
         from ...engine import backbone_standalone
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(x)
         return backbone_standalone(self, x, compute_dtype)
+
+    def _train_forward(self, x):
+        """.train(): models/backbone/resnet.py:243-255 with batch-statistics BatchNorm and autograd -- the backbone part of the whole-network
+        training step (dir_amd/train/net.py: backbone_forward / backbone_backward) behind ONE autograd node; returns [c1, c2, c3, c4] NCHW.
+        The classifier `fc` is never called (resnet.py:243-255 returns the pyramid): no gradient, like under torch."""
+        from ... import _capi
+        from ...train import autograd as AG
+        from ...train import conv as TC
+        from ...train import net as TN
+        _capi.require_cuda(x)
+        params = {'backbone.' + k: p for k, p in self.named_parameters() if not k.startswith('fc.')}
+        buffers = {'backbone.' + k: b for k, b in self.named_buffers() if 'num_batches_tracked' not in k}
+        for m in self.modules():
+            if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+
+        def fwd(P, img):
+            TC.begin_step(None)
+            ctx = {}
+            feats = TN.backbone_forward(P, _capi.f32c(img), ctx)
+            return tuple(f.permute(0, 3, 1, 2) for f in feats), ctx
+
+        def bwd(P, ctx, *g_feats):
+            G = {}
+            TN.backbone_backward(P, ctx, [None if g is None else g.permute(0, 2, 3, 1).contiguous() for g in g_feats], G)
+            TC.end_step()
+            return (None,), G              # the image is data (conv1's input gradient is never formed, as in the training step)
+        with torch.cuda.device(x.device):
+            return list(AG.run(fwd, bwd, [x], params, buffers))
 
 
 def resnet50(**kwargs):

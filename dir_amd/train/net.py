@@ -142,6 +142,53 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
 
 
 # ----------------------------------------------------------------------------------------------------------------------------- forward
+def backbone_forward(P, img, ctx, pre='backbone.'):
+    """ResNet.forward in training form (models/backbone/resnet.py:243-255): stem conv + bn1 + ReLU + max-pool + the 16 bottlenecks.
+    -> [c1, c2, c3, c4] NHWC fp32; ctx receives what backbone_backward needs.  Used by the whole-network step below and by the stand-alone
+    mirror module in .train() mode (dir_amd/models/backbone/resnet.py)."""
+    Pb = P if pre == 'backbone.' else {'backbone.' + k[len(pre):]: v for k, v in P.items() if k.startswith(pre)}
+    h = _stem_forward(Pb, img)
+    a, ctx['bn1'] = TB.bn_fwd(Pb, 'backbone.bn1.', h, relu=True)
+    x = SP.maxpool_fwd(a)
+    ctx['stem'] = (a, x)
+    ctx['img'] = img
+    feats, ctx['blocks'] = [], []
+    for li, nb in enumerate(LAYERS):
+        for bi in range(nb):
+            p = 'backbone.layer%d.%d.' % (li + 1, bi)
+            x, c = TB.bottleneck_forward(sub(Pb, p), x, 2 if (bi == 0 and li > 0) else 1)
+            ctx['blocks'].append((p, c))
+        feats.append(x)
+    return feats
+
+
+def backbone_backward(P, ctx, g_feats, G, flush=None, pre='backbone.'):
+    """g_feats: gradients of [c1, c2, c3, c4] (None where a feature has no outside consumer).  Fills G['backbone.*'] (conv1 has no input gradient:
+    the image is data)"""
+    Pb = P if pre == 'backbone.' else {'backbone.' + k[len(pre):]: v for k, v in P.items() if k.startswith(pre)}
+    if flush is None:
+        flush = lambda g_: None      # noqa: E731
+    g = None
+    bi_end = len(ctx['blocks'])
+    for li in (3, 2, 1, 0):
+        if g is None:
+            g = g_feats[li]
+        elif g_feats[li] is not None:
+            O.axpy(g, g_feats[li])
+        for _ in range(LAYERS[li]):
+            bi_end -= 1
+            p, c = ctx['blocks'][bi_end]
+            g, gb = TB.bottleneck_backward(sub(Pb, p), c, g)
+            put(G, p, gb)
+        flush(G)
+    a, x_pool = ctx['stem']
+    g = SP.maxpool_bwd(a, g)
+    g = TB.bn_bwd(Pb, 'backbone.bn1.', ctx['bn1'], g, G, relu=True)
+    img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
+    G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
+    flush(G)
+
+
 def forward(P, img, keep=None, scale_owner=None):
     """img NCHW fp32 [B,3,256,256] -> (outs: the three stage dicts + {'seg', 'dense'} NCHW, ctx).  scale_owner: the object that owns this
     model's cache of split-precision operand scales across steps (train_step passes the optimizer, DIR.forward the module); None = every
@@ -153,17 +200,7 @@ def forward(P, img, keep=None, scale_owner=None):
     dev = img.device
     ctx = {'img': img, 'keep': keep}                       # the packed MANO tables must outlive the backward pass (raw pointers in dir_mano_tables)
     # ---- backbone (models/backbone/resnet.py:243-255)
-    h = _stem_forward(P, img)
-    a, ctx['bn1'] = TB.bn_fwd(P, 'backbone.bn1.', h, relu=True)
-    x = SP.maxpool_fwd(a)
-    ctx['stem'] = (a, x)
-    feats, ctx['blocks'] = [], []
-    for li, nb in enumerate(LAYERS):
-        for bi in range(nb):
-            pre = 'backbone.layer%d.%d.' % (li + 1, bi)
-            x, c = TB.bottleneck_forward(sub(P, pre), x, 2 if (bi == 0 and li > 0) else 1)
-            ctx['blocks'].append((pre, c))
-        feats.append(x)
+    feats = backbone_forward(P, img, ctx)
     c1, c2, c3, c4 = feats
     # ---- InitRegressor (models/dir.py:260-305)
     init, ctx['init'] = {}, {}
@@ -317,26 +354,7 @@ def backward(P, ctx, outs, target, meta_info, faces, grad_out=None, flush=None):
         O.axpy(g_c4, _cbr_backward(P, 'init_regressor.attention_%s.' % s, ci[s]['att'], g_logit.view(B, 8, 8, 1), G))
     flush(G)
     # ---- backbone
-    g_feats = [None, g_skip_src[1], g_skip_src[0], g_c4]                                         # c1 has no consumer besides layer2
-    g = None
-    bi_end = len(ctx['blocks'])
-    for li in (3, 2, 1, 0):
-        if g is None:
-            g = g_feats[li]
-        elif g_feats[li] is not None:
-            O.axpy(g, g_feats[li])
-        for _ in range(LAYERS[li]):
-            bi_end -= 1
-            pre, c = ctx['blocks'][bi_end]
-            g, gb = TB.bottleneck_backward(sub(P, pre), c, g)
-            put(G, pre, gb)
-        flush(G)
-    a, x_pool = ctx['stem']
-    g = SP.maxpool_bwd(a, g)
-    g = TB.bn_bwd(P, 'backbone.bn1.', ctx['bn1'], g, G, relu=True)
-    img_nhwc = ctx['img'].permute(0, 2, 3, 1).contiguous()
-    G['backbone.conv1.weight'] = TB._oihw(TC.conv_wgrad(img_nhwc, g, (64, 7, 7, 3), 2, 3))
-    flush(G)
+    backbone_backward(P, ctx, [None, g_skip_src[1], g_skip_src[0], g_c4], G, flush)              # c1 has no consumer besides layer2
     TC.side_end()
     TC.end_step()
     return G

@@ -134,3 +134,76 @@ def test_manolayer_module_is_differentiable_like_the_reference(golden, side):
         (v2.sum() + j2.sum()).backward()
         assert float((tr.grad - (778 + 21)).abs().max()) < 1e-3
     print('ManoLayer through the module API vs torch autograd through the reference (G13, %s): worst %.2e' % (side, worst))
+
+
+@pytest.mark.parametrize('name', ['res_same', 'res_skip'])
+def test_hourglass_residual_module_trains_like_the_reference(golden, name):
+    """models/backbone/hourglass.py:33-70 in .train() through the module API against G18 (torch autograd through the reference's own Residual)"""
+    import json
+    import os
+    from dir_amd.models.backbone.hourglass import Residual
+    from oracle.golden_inputs import block_grad_inputs
+    g = golden('g18_block_grad_' + name)
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, 'golden', 'manifest_blocks.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f)[name].items()}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, SEED).items()}
+    cin, cout = shapes['skip_layer.conv.weight'][1], shapes['skip_layer.conv.weight'][0]
+    net = Residual(cin, cout).cuda()
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    x, gy = block_grad_inputs(name)
+    xt = dev(x).requires_grad_(True)
+    y = net(xt)
+    (y * dev(gy)).sum().backward()
+    yn, gn = y.detach().cpu().numpy().astype(np.float64), xt.grad.cpu().numpy().astype(np.float64)
+    assert np.abs(yn[:, ::8] - g['y.ch8']).max() < 2e-5 * np.abs(g['y.ch8']).max()
+    assert np.abs(gn[:, ::8] - g['gx.ch8']).max() / np.abs(g['gx.ch8']).max() < 1e-5
+    G = {k: p.grad.cpu().numpy() for k, p in net.named_parameters() if p.grad is not None}
+    worst = check_compact_grads(G, g, 1e-5, zero_suffixes=('conv1.conv.bias', 'conv2.conv.bias'))
+    for k in g:
+        if k.startswith('after.') and 'running' in k:
+            assert rel(net.state_dict()[k[6:]], g[k]) < 1e-5, k
+    print('hourglass.Residual.train() (%s) through the module API vs G18: worst %.2e' % (name, worst))
+
+
+def test_resnet_module_trains_and_matches_the_training_step_backbone():
+    """models/backbone/resnet.py:243-255 in .train() through the module API: [c1..c4] carry ONE autograd node; parameter gradients equal the ones
+    dir_amd/train/net.py's backbone functions produce when called directly (the whole-network training step's code path, pinned by G18 / G20e),
+    `fc` gets none, running statistics move, and .eval() afterwards is the fused inference path again"""
+    import json
+    import os
+    from dir_amd.models.backbone.resnet import resnet50
+    from dir_amd.train import conv as TC
+    from dir_amd.train import net as TN
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k[9:]: tuple(v) for k, v in json.load(f).items() if k.startswith('backbone.')}
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict({'backbone.' + k: v for k, v in shapes.items()}, SEED, cond=True).items()}
+    sd = {k[9:]: v for k, v in sd.items()}
+    net = resnet50().cuda()
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    img = dev(synth.synth_input('dir.img', (2, 3, 256, 256), SEED))
+    rm0 = net.bn1.running_mean.clone()
+    feats = net(img)
+    assert [tuple(f.shape) for f in feats] == [(2, 256, 64, 64), (2, 512, 32, 32), (2, 1024, 16, 16), (2, 2048, 8, 8)] and all(f.requires_grad for f in feats)
+    gens = [torch.randn(f.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(9 + i)) for i, f in enumerate(feats)]
+    sum((f * g_).sum() for f, g_ in zip(feats[1:], gens[1:])).backward()           # c1 has no outside consumer on the path (models/dir.py:437-483)
+    assert not torch.equal(net.bn1.running_mean, rm0)
+    assert net.fc.weight.grad is None and net.conv1.weight.grad is not None
+    # the same through the functions, on a fresh copy of the buffers
+    P = {'backbone.' + k: v.detach().clone().cuda() for k, v in sd.items() if 'num_batches' not in k}
+    TC.begin_step(None)
+    ctx = {}
+    f2 = TN.backbone_forward(P, img, ctx)
+    G = {}
+    TN.backbone_backward(P, ctx, [None] + [g_.permute(0, 2, 3, 1).contiguous() for g_ in gens[1:]], G)
+    TC.end_step()
+    for a, b in zip(feats, f2):
+        assert torch.equal(a.detach(), b.permute(0, 3, 1, 2))
+    for k, p in net.named_parameters():
+        if not k.startswith('fc.'):
+            assert torch.equal(p.grad, G['backbone.' + k]), k
+    net.eval()
+    assert not net(img)[3].requires_grad
