@@ -221,6 +221,8 @@ _SIGNATURES = {
     'dir_grid_rows_forward': (C.c_int, [_p, _p, _p, _i, _i, _i, _p]),
     'dir_grid_rows_backward': (C.c_int, [_p, _p, _i, _p, _i, _i, _i, _i, _p]),
     'dir_mano_forward': (C.c_int, [C.POINTER(ManoTables), _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _p]),
+    'dir_jpeg_planes_bytes': (C.c_longlong, [C.c_longlong]),
+    'dir_jpeg_decode_records': (C.c_int, [_p, C.c_longlong, _i, _i, _i, _p, C.c_longlong, _p, _p, _p]),
 }
 
 
@@ -232,7 +234,7 @@ PROFILE = None
 _pending = {}
 _NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
                'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes',
-               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_bn_sync_workspace_bytes', 'dir_bn_frozen_workspace_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
+               'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_bn_sync_workspace_bytes', 'dir_bn_frozen_workspace_bytes', 'dir_jpeg_planes_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
 
 
 def annotate(**kw):

@@ -119,13 +119,15 @@ class InterHandSplit(object):
 ANNO_FLOATS = 21 + 2 * 67
 
 
-def _decode_worker(data_path, split, wid, workers, indices, bs, chunk, ready, frames, annos, flags, ctrl):
+def _decode_worker(data_path, split, wid, workers, indices, bs, chunk, ready, frames, annos, flags, ctrl, records=False):
     """decode process `wid` of `workers`: owns the chunks t = wid, wid + workers, ... of the flat (batch, chunk) sequence; chunk t of batch b
     goes to rows [k * chunk, ...) of ring slot b % depth once batch b - depth has been released (ctrl[0] = batches released); flags[t] = 1 when
     its frames and annotations are in place (2: failed).  No queue in the steady state: shared-memory words only."""
     import time
     torch.set_num_threads(1)
     ds = InterHandSplit(data_path, split)
+    if records:
+        from .jpeg import file_to_record
     fr, an = [f.numpy() for f in frames], [a.numpy() for a in annos]
     fl, ct = flags.numpy(), ctrl.numpy()
     depth, n, npb = len(fr), len(indices), -(-bs // chunk)
@@ -147,7 +149,10 @@ def _decode_worker(data_path, split, wid, workers, indices, bs, chunk, ready, fr
         try:
             slot, j0 = b % depth, k * chunk
             for j in range(hi - lo):
-                fr[slot][j0 + j] = ds.frame(indices[lo + j])
+                if records:                 # entropy decode only (libdir_jpeg.so): the row becomes a coefficient record, decoded further on the GPU
+                    file_to_record(ds.img_path(indices[lo + j]), fr[slot][j0 + j], IMG_SIZE)
+                else:
+                    fr[slot][j0 + j] = ds.frame(indices[lo + j])
                 an[slot][j0 + j] = ds.anno(indices[lo + j])
             fl[t] = 1
         except Exception:               # noqa: BLE001  (the consumer raises when it sees the flag)
@@ -170,7 +175,7 @@ class DecodeRing(object):
     of the buffer by then, as evaluate_from_disk does).  One pass per ring.  The buffers are shared memory registered with the HIP runtime
     (cudaHostRegister), so the host -> device copy is an asynchronous DMA from where the decoders wrote."""
 
-    def __init__(self, data_path, split='test', batch_size=256, workers=8, depth=None, indices=None, pin=True, chunk=32):
+    def __init__(self, data_path, split='test', batch_size=256, workers=8, depth=None, indices=None, pin=True, chunk=32, records=False):
         import torch.multiprocessing as mp
         self.ds = InterHandSplit(data_path, split)
         self.indices = list(range(len(self.ds))) if indices is None else list(indices)
@@ -179,7 +184,15 @@ class DecodeRing(object):
             depth = max(3, -(-self.workers * self.chunk // batch_size) + 2)
         self.depth = depth
         self.npb = -(-batch_size // self.chunk)
-        self.frames = [torch.zeros(batch_size, IMG_SIZE, IMG_SIZE, 3, dtype=torch.uint8).share_memory_() for _ in range(depth)]
+        # records=True (round 5): the workers only decode the Huffman stream (apps/jpeg.py); a row is then a coefficient record of `record_bytes`
+        # bytes (the size of the frame for 4:2:0) that dir_jpeg_decode_records turns into the frame on the GPU
+        self.records = bool(records)
+        if self.records:
+            from .jpeg import record_bytes
+            self.record_bytes = record_bytes(IMG_SIZE)
+            self.frames = [torch.zeros(batch_size, self.record_bytes, dtype=torch.uint8).share_memory_() for _ in range(depth)]
+        else:
+            self.frames = [torch.zeros(batch_size, IMG_SIZE, IMG_SIZE, 3, dtype=torch.uint8).share_memory_() for _ in range(depth)]
         self.annos = [torch.zeros(batch_size, ANNO_FLOATS, dtype=torch.float32).share_memory_() for _ in range(depth)]
         self.flags = torch.zeros(max(1, len(self) * self.npb), dtype=torch.uint8).share_memory_()
         self.ctrl = torch.zeros(2, dtype=torch.int64).share_memory_()          # [batches released, stop]
@@ -190,7 +203,7 @@ class DecodeRing(object):
         ctx = mp.get_context('spawn')
         ready = ctx.Queue()
         self.procs = [ctx.Process(target=_decode_worker, args=(data_path, split, w, self.workers, self.indices, self.bs, self.chunk, ready, self.frames,
-                                                               self.annos, self.flags, self.ctrl), daemon=True) for w in range(self.workers)]
+                                                               self.annos, self.flags, self.ctrl, self.records), daemon=True) for w in range(self.workers)]
         for p in self.procs:
             p.start()
         for _ in self.procs:             # wait until every decoder is up: a spawned interpreter takes seconds to import

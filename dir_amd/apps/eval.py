@@ -185,16 +185,27 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
     from ..engine import ForwardPipeline
     from .dataset import IMG_SIZE, DecodeRing, ShardRing, gt_batch
     dev = eng.device
-    assert source in ('jpeg', 'u8')      # 'u8': the prepared uint8 split (dataset.write_u8_shards): no JPEG decode in the loop
-    ring = (DecodeRing if source == 'jpeg' else ShardRing)(data_path, split, bs, workers=workers, indices=indices)
+    # 'jpeg': the host decodes the Huffman stream only, the GPU does the rest of cv.imread (apps/jpeg.py, round 5); 'jpeg-host': the whole decode
+    # on the host (PIL's libjpeg-turbo, rounds 2-4); 'u8': the prepared uint8 split (dataset.write_u8_shards), no JPEG decode in the loop
+    assert source in ('jpeg', 'jpeg-host', 'u8')
+    if source == 'u8':
+        ring = ShardRing(data_path, split, bs, workers=workers, indices=indices)
+    else:
+        ring = DecodeRing(data_path, split, bs, workers=workers, indices=indices, records=(source == 'jpeg'))
     m = EvalMetrics(J_regressor, root_joint, scale, stage_num)
     slots = [torch.zeros(bs, IMG_SIZE, IMG_SIZE, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+    rec_dev, rec_dec = None, None
+    if source == 'jpeg':
+        from .jpeg import RecordDecoder
+        rec_dev = [torch.zeros(bs, ring.record_bytes, device=dev, dtype=torch.uint8) for _ in range(2)]
+        rec_dec = [RecordDecoder(bs, ring.record_bytes, IMG_SIZE, dev) for _ in range(2)]
     batches = iter(ring)
     first = next(batches, None)
     if first is not None and eng.arith is not None and not eng.calibrated:
         # f16 arithmetic modes: the per-layer power-of-two operand scales come from the first batch, BEFORE the slots' graphs are captured (the
         # scales are launch arguments: a graph captured earlier would replay the uncalibrated ones)
-        eng.calibrate(first[0].to(dev))
+        f0 = first[0].to(dev)
+        eng.calibrate(rec_dec[0](f0, slots[0].clone()) if source == 'jpeg' else f0)
     pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
     pending = [None, None]
 
@@ -213,7 +224,12 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
             slot = k % 2
             if pending[slot] is not None:
                 finish(slot)
-            pipe.refill(slot, frames)                                  # async DMA from the ring's page-locked buffer, on the slot's stream
+            if source == 'jpeg':
+                with torch.cuda.stream(pipe.streams[slot]):            # records by DMA, then the rest of the JPEG decode straight into the slot's input
+                    rec_dev[slot].copy_(frames, non_blocking=True)
+                    rec_dec[slot](rec_dev[slot], pipe.imgs[slot], n)
+            else:
+                pipe.refill(slot, frames)                              # async DMA from the ring's page-locked buffer, on the slot's stream
             with torch.cuda.stream(pipe.streams[slot]):
                 annos_dev = annos.to(dev, non_blocking=True)
                 copied = torch.cuda.Event()
@@ -228,6 +244,8 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
             if pending[slot] is not None:
                 finish(slot)
         torch.cuda.synchronize(dev)
+        for d_ in rec_dec or ():
+            d_.check()                                                 # a record that was not a 256x256 image would have left its frame stale
     finally:
         ring.close()
     dt = time.perf_counter() - t0
@@ -248,7 +266,7 @@ def main(argv=None):
     ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16', help='bf16 feature maps (throughput mode) or exact fp32 (parity mode)')
     ap.add_argument('--arith', choices=['f16x3', 'f16'], default=None, help="with --dtype f32: convolutions on the f16 matrix cores -- 'f16x3' split "
                     "precision (the 1e-4 mm parity mode at 10 k images/s), 'f16' one MFMA per product (every stage within 0.01 mm, 13 k images/s)")
-    ap.add_argument('--source', choices=['jpeg', 'u8'], default='jpeg', help="jpeg: <split>/img/<idx>.jpg as the reference prepares them; u8: the prepared "
+    ap.add_argument('--source', choices=['jpeg', 'jpeg-host', 'u8'], default='jpeg', help="jpeg: <split>/img/<idx>.jpg as the reference prepares them (Huffman decode on the host, the rest of the decode on the GPU); jpeg-host: the whole decode on the host; u8: the prepared "
                     "uint8 shards of dir_amd.apps.dataset.write_u8_shards (no decode in the loop)")
     ap.add_argument('--workers', type=int, default=16, help='decode processes (jpeg) / copy threads (u8); more than the CPUs the process may use is slower')
     ap.add_argument('--result_dir', type=str, default='./result/DIR-PoseEmb-Wrist')

@@ -82,8 +82,31 @@ def build(force=False, verbose=True):
             print('[dir_amd.build] linked %s (%d objects, %d recompiled)' % (LIB, len(objs), sum(c for _, c in res)))
     elif verbose:
         print('[dir_amd.build] %s up to date' % LIB)
+    if not os.environ.get('DIR_BUILD_TAG'):
+        build_jpeg_host(force, verbose)
     return LIB
+
+
+JPEG_SRC = os.path.join(CSRC, 'jpeg_huff.c')
+JPEG_LIB = os.path.join(LIBDIR, 'libdir_jpeg.so')
+
+
+def build_jpeg_host(force=False, verbose=True):
+    """lib/libdir_jpeg.so: the HOST half of the from-files path (csrc/jpeg_huff.c: baseline-JPEG entropy decode, plain C, no GPU runtime -- the
+    decode worker processes load it), compiled with gcc"""
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdr = os.path.join(HERE, '..', 'include', 'dir_jpeg.h')
+    if not force and os.path.exists(JPEG_LIB) and os.path.getmtime(JPEG_LIB) > max(os.path.getmtime(JPEG_SRC), os.path.getmtime(hdr)):
+        return JPEG_LIB
+    cc = shutil.which('gcc') or shutil.which('cc') or hipcc()
+    r = subprocess.run([cc, '-O3', '-std=c11', '-Wall', '-Wextra', '-fPIC', '-shared', JPEG_SRC, '-o', JPEG_LIB], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('building libdir_jpeg.so failed:\n%s\n%s' % (r.stdout, r.stderr))
+    if verbose:
+        print('[dir_amd.build] built %s' % JPEG_LIB)
+    return JPEG_LIB
 
 
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
+    build_jpeg_host(force='--force' in sys.argv)

@@ -818,6 +818,20 @@ int dir_dense_losses_backward(const float* seg_logits, const float* dense_pred, 
                               const float* class_weight_host, float dense_weight, const float* grad_out3, void* workspace,
                               long long workspace_bytes, float* grad_seg, float* grad_dense, int B, int S, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------
+ * f3, from files: the GPU half of the JPEG decode (round 5).  cv.imread of the reference's input pipeline (apps/eval.py:56,
+ * dataset/interhand.py:223 over dataset/prepare_data.py:123-166's files) = libjpeg's default decode.  The host decodes the Huffman stream only
+ * (include/dir_jpeg.h: dir_jpeg_decode_coefficients -> one record per image = dir_jpeg_header + quantised int16 coefficients); this entry point
+ * takes a batch of records that sit `record_stride` bytes apart in device memory and writes the uint8 BGR frames [B,H,W,3] that
+ * dir_stem_pool_forward(_dt) / dir_stem_prep_s2d_u8 / dir_image_normalize_forward read: dequantisation, the "islow" integer IDCT with its range
+ * limit, "fancy" h2v2 / h2v1 chroma upsampling, 16-bit fixed-point YCbCr -> RGB -- integer arithmetic, bit-exact with libjpeg(-turbo)
+ * (oracle/jpeg.py, pinned to Pillow's decoder).  Every record must describe an H x W image (4:2:0, 4:2:2, 4:4:4 or grayscale); a record that
+ * does not sets *err_flag (device int32, zeroed by the caller) to 1 + its index and its frame is left untouched.
+ * planes_scratch: B x round_up_16(dir_jpeg_planes_bytes(record_stride)) bytes of device memory. */
+long long dir_jpeg_planes_bytes(long long record_bytes);
+int dir_jpeg_decode_records(const void* records, long long record_stride, int B, int H, int W, void* planes_scratch, long long scratch_bytes, void* out_bgr,
+                            int32_t* err_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,9 +40,17 @@ if __name__ == '__main__':
         jreg = {s: EV.Jr(mano[s].J_regressor) for s in ('left', 'right')}
         idx = [i % 256 for i in range(n)]
         eng.autotune(torch.randn(bs, 3, 256, 256, device='cuda'))
-        for w in workers:
-            m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx)
-            print('workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))
+        # round 5: the workers decode the Huffman stream only (lib/libdir_jpeg.so), the GPU does the rest of cv.imread (dir_jpeg_decode_records)
+        from dir_amd.apps import jpeg as AJ
+        row = np.zeros(AJ.record_bytes(256), np.uint8)
+        t0 = time.perf_counter()
+        for i in range(256):
+            AJ.file_to_record(ds.img_path(i), row, 256)
+        print('one process entropy-decodes %.0f files/s into coefficient records (read + Huffman)' % (256 / (time.perf_counter() - t0)))
+        for src in ('jpeg', 'jpeg-host'):
+            for w in workers:
+                m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source=src)
+                print('%-9s workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (src, w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))
         # the prepared uint8 split (dataset.write_u8_shards): the same loop without the JPEG decode
         t0 = time.perf_counter()
         DS.write_u8_shards(d, 'test', shard_size=128, workers=8)
