@@ -176,7 +176,7 @@ def evaluate(network, dataloader, J_regressor, root_joint=0, scale=True, stage_n
 
 
 def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joint=0, scale=True, split='test', workers=8,
-                       stage_num=3, indices=None, progress=None, source='jpeg'):
+                       stage_num=3, indices=None, progress=None, source='jpeg', nslot=3):
     """apps/eval.py:121-241 from the prepared split on disk, at pipeline speed: decode processes (dataset.DecodeRing) -> pinned uint8
     batches -> two forwards in flight (engine.ForwardPipeline over uint8 input slots; the normalisation runs inside the stem kernel,
     proj_feat is not produced: the evaluation never reads it) -> GT MANO + metrics on the GPU.  `eng`: a DirEngine.
@@ -193,12 +193,15 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
     else:
         ring = DecodeRing(data_path, split, bs, workers=workers, indices=indices, records=(source == 'jpeg'))
     m = EvalMetrics(J_regressor, root_joint, scale, stage_num)
-    slots = [torch.zeros(bs, IMG_SIZE, IMG_SIZE, 3, device=dev, dtype=torch.uint8) for _ in range(2)]
+    # nslot forwards in flight (round 5: 3 -- with 2, only ONE forward is on the GPU while the host scores the batch that just finished and hands the
+    # next one over, a third of the time)
+    nslot = max(2, int(nslot))
+    slots = [torch.zeros(bs, IMG_SIZE, IMG_SIZE, 3, device=dev, dtype=torch.uint8) for _ in range(nslot)]
     rec_dev, rec_dec = None, None
     if source == 'jpeg':
         from .jpeg import RecordDecoder
-        rec_dev = [torch.zeros(bs, ring.record_bytes, device=dev, dtype=torch.uint8) for _ in range(2)]
-        rec_dec = [RecordDecoder(bs, ring.record_bytes, IMG_SIZE, dev) for _ in range(2)]
+        rec_dev = [torch.zeros(bs, ring.record_bytes, device=dev, dtype=torch.uint8) for _ in range(nslot)]
+        rec_dec = [RecordDecoder(bs, ring.record_bytes, IMG_SIZE, dev) for _ in range(nslot)]
     batches = iter(ring)
     first = next(batches, None)
     if first is not None and eng.arith is not None and not eng.calibrated:
@@ -207,7 +210,7 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
         f0 = first[0].to(dev)
         eng.calibrate(rec_dec[0](f0, slots[0].clone()) if source == 'jpeg' else f0)
     pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
-    pending = [None, None]
+    pending = [None] * nslot
 
     def finish(slot):
         n, annos = pending[slot]
@@ -221,7 +224,7 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
     try:
         import itertools
         for k, (frames, annos, n) in enumerate(itertools.chain([first] if first is not None else [], batches)):
-            slot = k % 2
+            slot = k % nslot
             if pending[slot] is not None:
                 finish(slot)
             if source == 'jpeg':
@@ -240,7 +243,7 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
             seen += n
             if progress:
                 progress(seen)
-        for slot in ((k + 1) % 2, k % 2) if seen else ():              # flush in launch order: the older slot first
+        for slot in [(k + 1 + j) % nslot for j in range(nslot)] if seen else ():      # flush in launch order: the oldest slot first
             if pending[slot] is not None:
                 finish(slot)
         torch.cuda.synchronize(dev)

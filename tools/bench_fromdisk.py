@@ -49,7 +49,7 @@ if __name__ == '__main__':
         print('one process entropy-decodes %.0f files/s into coefficient records (read + Huffman)' % (256 / (time.perf_counter() - t0)))
         for src in ('jpeg', 'jpeg-host'):
             for w in workers:
-                m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source=src)
+                m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source=src, nslot=int(os.environ.get("NSLOT", "3")))
                 print('%-9s workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (src, w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))
         # the prepared uint8 split (dataset.write_u8_shards): the same loop without the JPEG decode
         t0 = time.perf_counter()
