@@ -451,6 +451,15 @@ def main():
 
 
     roof = live_roofline(eng, img, args.dtype, ms_per_step) if rank == 0 else None
+    if roof is not None and serial_ms is not None:
+        # `all_kernels_ms_per_step` is the SUM of HIP-event brackets around every library call of an EAGER forward (each bracket =
+        # the call's kernel(s) + its own dispatch gap on an otherwise idle stream); `ms_per_forward_one_in_flight` is ONE graph replay of the same
+        # launches (no host in the loop, dispatches back to back).  Their difference over the call count is the eager bracket's overhead per call.
+        roof['eager_bracket_overhead_us_per_call'] = round((roof['all_kernels_ms_per_step'] - serial_ms) * 1e3 / max(roof['library_calls_per_step'], 1), 2)
+        roof['reconcile'] = ('all_kernels_ms_per_step %.3f (eager, %d event-bracketed library calls, time-tuned or throughput table as timed) = ms_per_forward_one_in_flight '
+                             '%.3f (one HIP-graph replay, time-tuned table) + %.2f us per call of dispatch gap / event granularity (+ the table difference when the throughput '
+                             'table is loaded: see time_tuned_table.all_conv_ms_per_step)' % (roof['all_kernels_ms_per_step'], roof['library_calls_per_step'], serial_ms,
+                                                                                               roof['eager_bracket_overhead_us_per_call']))
     if roof is not None and half and not args.no_ceiling_probe:
         # What THIS board sustains, measured in this run (dir_probe_launch: VERDICT r3 item 9 -- the constants quoted here in round 3 came from
         # another box): a bf16 MFMA loop on pseudo-random operands held in registers (the guide's 2.5 PFLOP/s is reached on all-zero operands
@@ -471,13 +480,17 @@ def main():
         big = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         big.fill_(1)
         ce = {'mfma_bf16_random_operands_in_registers_tflops': round(probe(0, big, 64, 20000, 1.0) / 1e12, 1),
+              'mfma_f16_random_operands_in_registers_tflops': round(probe(3, big, 64, 20000, 1.0) / 1e12, 1),
               'hbm_read_1gib_tbps': round(probe(1, big, 1 << 30, 0, 1.0) / 1e12, 3),
+              # a float4 COPY of 512 MiB -> 512 MiB (bytes read + written): what a streaming kernel does; the read-only loop under-reports the ceiling
+              # (5.1 TB/s, below bone_vis_kernel's own 6.3 TB/s)
+              'hbm_copy_1gib_tbps': round(probe(2, big, 1 << 30, 0, 1.0) / 1e12, 3),
               'source': 'dir_probe_launch in this run, ~1 s per loop, after the timed regions'}
         del big
         if 'mfma' in roof.get('by_class', {}):
-            ce['by_class_mfma_frac_of_measured'] = round(roof['by_class']['mfma']['achieved'] / ce['mfma_bf16_random_operands_in_registers_tflops'], 3)
+            ce['by_class_mfma_frac_of_measured'] = round(roof['by_class']['mfma']['achieved'] / ce['mfma_%s_random_operands_in_registers_tflops' % args.dtype], 3)
         if 'hbm' in roof.get('by_class', {}):
-            ce['by_class_hbm_frac_of_measured'] = round(roof['by_class']['hbm']['achieved'] / 1e3 / ce['hbm_read_1gib_tbps'], 3)
+            ce['by_class_hbm_frac_of_measured'] = round(roof['by_class']['hbm']['achieved'] / 1e3 / max(ce['hbm_read_1gib_tbps'], ce['hbm_copy_1gib_tbps']), 3)
         roof['measured_ceilings'] = ce
     if roof is not None and t_time is not None and conv_tuning.startswith('throughput') and not args.no_time_table_pass:
         # the same pass with the TIME-tuned table: the throughput table trades per-kernel duration (one forward alone) for joules, so its launches

@@ -15,7 +15,8 @@ _TOP = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', '
 _CONFIG = ('workload', 'batch_per_gpu', 'graph', 'forwards_in_flight', 'ms_per_forward_one_in_flight', 'conv_tuning', 'tunings_bit_identical',
            'outputs_finite', 'overlapped_equals_one_at_a_time', 'world_size_observed', 'backend', 'timed_regions', 'region_ms_per_step', 'statistic')
 _ROOF = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'frac_mfma', 'frac_hbm', 'alg_bytes_per_launch',
-         'alg_gflop_per_launch', 'launches_per_step', 'avg_launch_us', 'all_conv_ms_per_step', 'all_kernels_ms_per_step', 'library_calls_per_step')
+         'alg_gflop_per_launch', 'launches_per_step', 'avg_launch_us', 'all_conv_ms_per_step', 'all_kernels_ms_per_step', 'library_calls_per_step',
+         'eager_bracket_overhead_us_per_call')
 
 
 def _pick(d, keys):

@@ -4,6 +4,10 @@
 //           of 32 x 32 per wave: the arithmetic of a 64 x 64 wave tile), 8 waves per workgroup, one workgroup per CU.  Random data matters:
 //           on all-zero operands the same loop runs 1.4x faster (the board's power / current limits pull the clock on real data).
 //   mode 1  HBM read: 16-byte loads streaming `bytes` of `buf` (make it larger than the 256 MB Infinity Cache).
+//   mode 2  HBM copy (round 5): the first half of `buf` copied to the second half with 16-byte loads and stores -- what a
+//           streaming kernel does (it reads AND writes); returns bytes read + bytes written.  A read-only loop under-reports the ceiling (5.1 TB/s
+//           on these boards, below what bone_vis_kernel achieves).
+//   mode 3  as mode 0 on the f16 matrix-core instruction (v_mfma_f32_32x32x16_f16) with pseudo-random f16 operands: the f16-storage mode's ceiling.
 // Nothing in the product path calls this.
 #include "dir_common.h"
 
@@ -12,6 +16,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool F16>
 __global__ __launch_bounds__(512, 1) void probe_mfma_kernel(int iters, float* sink) {
     const unsigned t = blockIdx.x * 512u + threadIdx.x;
     u32x4 fa[2][4], fb[2][4];
@@ -22,14 +28,16 @@ __global__ __launch_bounds__(512, 1) void probe_mfma_kernel(int iters, float* si
             // bf16 pairs in [1, 2) with pseudo-random mantissas and signs: finite sums, every operand bit toggling
             unsigned h = (t * 8u + i * 4u + q) * 2654435761u;
             u32x4 v, w;
-            v.x = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            v.y = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            v.z = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            v.w = 0x3f803f80u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            w.x = 0x3c003c00u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            w.y = 0x3c003c00u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            w.z = 0x3c003c00u ^ (h & 0x807f807fu); h = h * 1664525u + 1013904223u;
-            w.w = 0x3c003c00u ^ (h & 0x807f807fu);
+            // (F16: f16 pairs in [1, 2) and [2^-5, 2^-4) with all 10 mantissa bits and the sign pseudo-random)
+            const unsigned ba = F16 ? 0x3c003c00u : 0x3f803f80u, bb = F16 ? 0x28002800u : 0x3c003c00u, mk = F16 ? 0x83ff83ffu : 0x807f807fu;
+            v.x = ba ^ (h & mk); h = h * 1664525u + 1013904223u;
+            v.y = ba ^ (h & mk); h = h * 1664525u + 1013904223u;
+            v.z = ba ^ (h & mk); h = h * 1664525u + 1013904223u;
+            v.w = ba ^ (h & mk); h = h * 1664525u + 1013904223u;
+            w.x = bb ^ (h & mk); h = h * 1664525u + 1013904223u;
+            w.y = bb ^ (h & mk); h = h * 1664525u + 1013904223u;
+            w.z = bb ^ (h & mk); h = h * 1664525u + 1013904223u;
+            w.w = bb ^ (h & mk);
             fa[i][q] = v; fb[i][q] = w;
         }
     f32x16 acc[2][2];
@@ -46,7 +54,8 @@ __global__ __launch_bounds__(512, 1) void probe_mfma_kernel(int iters, float* si
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]), __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][q]), __builtin_bit_cast(f16x8, fb[j][q]), acc[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][q]), __builtin_bit_cast(bf16x8, fb[j][q]), acc[i][j], 0, 0, 0);
     }
     float s = 0.f;
 #pragma unroll
@@ -67,16 +76,24 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
+__global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+}
 }  // namespace
 
 extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int iters, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!buf || bytes < 64) { dir::set_error("dir_probe_launch: need a device buffer of at least 64 bytes"); return DIR_E_INVALID; }
-    if (mode == 0) {
+    if (mode == 0 || mode == 3) {
         if (iters <= 0) { dir::set_error("dir_probe_launch: iters must be positive"); return DIR_E_INVALID; }
         int dev = 0, ncu = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        hipLaunchKernelGGL(probe_mfma_kernel, dim3(ncu), dim3(512), 0, s, iters, (float*)buf);
+        if (mode == 3) hipLaunchKernelGGL(probe_mfma_kernel<true>, dim3(ncu), dim3(512), 0, s, iters, (float*)buf);
+        else hipLaunchKernelGGL(probe_mfma_kernel<false>, dim3(ncu), dim3(512), 0, s, iters, (float*)buf);
         if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
         return (long long)ncu * 8 * 16 * 32768LL * iters;               // FLOPs of this launch: CUs x waves x MFMAs x 2*32*32*16
     }
@@ -87,6 +104,13 @@ extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int 
         const size_t stride = 4096ull * 256, groups = n / (4 * stride);
         return (long long)(groups * 4 * stride * 16);                    // bytes the loop really reads
     }
-    dir::set_error("dir_probe_launch: mode must be 0 (bf16 MFMA) or 1 (HBM read)");
+    if (mode == 2) {
+        const size_t n = (size_t)bytes / 32;                             // 16-byte elements per half
+        hipLaunchKernelGGL(probe_copy_kernel, dim3(4096), dim3(256), 0, s, (const uint4*)buf, (uint4*)buf + n, n);
+        if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
+        const size_t stride = 4096ull * 256, groups = n / (4 * stride);
+        return (long long)(groups * 4 * stride * 32);                    // bytes read + bytes written
+    }
+    dir::set_error("dir_probe_launch: mode must be 0 (bf16 MFMA), 1 (HBM read), 2 (HBM copy) or 3 (f16 MFMA)");
     return DIR_E_INVALID;
 }

@@ -46,7 +46,9 @@ void dir_launch_log_note(const char* name, long long times);
 /* Measurement aid (bench.py `roofline.measured_ceilings`; nothing in the reference, nothing in the product path): ONE launch of a ceiling probe
  * on `stream`.  mode 0: bf16 MFMA loop on pseudo-random operands held in registers (16 x v_mfma_f32_32x32x16_bf16 per wave and iteration, 8 waves
  * per CU, every CU), `iters` iterations; mode 1: 16-byte loads streaming `bytes` of `buf` (larger than the Infinity Cache to price HBM).  `buf`: any
- * device buffer >= 64 bytes (mode 0 only needs a sink).  Returns the FLOPs (mode 0) / bytes (mode 1) the launch performs, negative = error code. */
+ * device buffer >= 64 bytes (mode 0 only needs a sink); mode 2 (round 5): the first half of `buf` copied to the second half (a streaming kernel reads AND
+ * writes: the read-only loop under-reports the HBM ceiling); mode 3: mode 0 on v_mfma_f32_32x32x16_f16 with pseudo-random f16 operands.  Returns the
+ * FLOPs (modes 0, 3) / bytes read (mode 1) / bytes read + written (mode 2) of the launch, negative = error code. */
 long long dir_probe_launch(int mode, void* buf, long long bytes, int iters, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
