@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-ceiling-probe', action='store_true', help='skip the in-run MFMA / HBM ceiling probe (2 s, outside the timed regions)')
     ap.add_argument('--no-power', action='store_true', help='skip the rocm-smi socket power probe (7 s, outside the timed regions)')
     ap.add_argument('--no-fp32-mode', action='store_true', help='skip the fp32 (exact-parity mode) sub-record')
+    ap.add_argument('--no-pgcn', action='store_true', help='skip the P-GCN (SemGCN gather) sub-record')
     ap.add_argument('--no-other-half', action='store_true', help='skip the sub-record of the other 16-bit storage kind (f16 when --dtype bf16, bf16 when --dtype f16)')
     ap.add_argument('--no-config5', action='store_true', help='skip the BASELINE configs[4] (HRNet-W48, 32 per GPU) sub-record')
     ap.add_argument('--no-train', action='store_true', help='skip the training-step sub-record (batch 32, fp32)')
@@ -540,6 +541,44 @@ def main():
                               'headline; regions alternate with the headline pipeline' % (str(odt)[6:], oname)}
         del pipeo, engo
 
+    # ---- the SemGCN gather path alone (north_star: ">= 60 % of HBM peak on the SemGCN gather at batch 64"): the P-GCN stack of both
+    #      hands (4 PGraphConv layers + mix = 5 dependent launches, dir_pgcn_stack_forward_pair) timed with HIP events at B = 64 and at the batch where
+    #      it saturates, algorithmic bytes = weights once + every layer's activations in and out, beside the counted PMC bytes of the
+    #      tracked sweep (profiles/r03_pgcn_batch_sweep_pmc.txt: FETCH_SIZE x 2 + WRITE_SIZE per launch)
+    pgcn = None
+    if rank == 0 and world == 1 and half and not args.no_pgcn:
+        import ctypes as C
+        st3 = eng.stage3
+        Lb = _capi.lib()
+        pgcn = {'target': '>= 0.60 of 8 TB/s at batch 64 (BASELINE.json north_star)'}
+        for Bp in (64, 1024):
+            x0p = torch.randn(2, Bp, 21, 128, device=dev)
+            gpp = torch.randn(2, Bp, 21, 128, device=dev)
+            tokp = torch.empty(Bp, 42, 128, device=dev)
+            scp = torch.empty(4, Bp, 21, 256, device=dev)
+            sp_ = torch.cuda.current_stream().cuda_stream
+
+            def call():
+                _capi.check(Lb.dir_pgcn_stack_forward_pair(st3.gcn[0], st3.gcn[1], 4, _capi.ptr(x0p), _capi.ptr(gpp), _capi.ptr(tokp), _capi.ptr(scp), Bp, C.c_void_p(sp_)), 'pgcn')
+            for _ in range(5):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                call()
+            e1.record()
+            sync()
+            us = e0.elapsed_time(e1) / 50 * 1e3
+            alg = 4 * 2 * 2 * 21 * 128 * 128 * 2 + 4 * 2 * 2 * Bp * 21 * 128 * 4
+            pgcn['B=%d' % Bp] = {'us_per_stack_pair': round(us, 1), 'alg_mb': round(alg / 1e6, 1), 'alg_gbps': round(alg / us / 1e3, 1),
+                                 'frac_of_hbm_peak': round(alg / (us * 1e-6) / HBM_PEAK, 4)}
+        pgcn['pmc_counted'] = ('profiles/r03_pgcn_batch_sweep_pmc.txt (same kernels: tokens.hip pgcn_node / pgcn_mix unchanged since): B=64 40 MB counted per stack in 34.5 us = '
+                               '1.2 TB/s (0.15); B=1024 479 MB in 114.6 us = 4.2 TB/s (0.52); B=4096 1976 MB in 494 us = 4.0 TB/s (0.50) -- counted bytes exceed the '
+                               'algorithmic ones 2.6x at large batch (the W0 | W1 halves travel through a 256-wide scratch tensor between node and mix launches)')
+        pgcn['latency_bound'] = ('at B = 64 the stack is 5 DEPENDENT launches that move <= 10 MB each (1.2 us at 8 TB/s): each costs one launch boundary + one gather -> '
+                                 'barrier -> weight fragment -> MFMA -> store chain, ~5 us measured floor per layer (one-launch rebuild with flag hand-offs: 29.9 us, DESIGN.md 10); '
+                                 '0.60 of peak would be 4.6 us for the whole stack -- below ONE launch; the rate the kernels sustain appears at B >= 1024')
+
     # ---- fp32 exact-parity mode (the mode that meets the 1e-4 mm budget, tests/test_gpu_dir.py): one graph, a few steps
     fp32 = None
     if rank == 0 and world == 1 and half and not args.no_fp32_mode and not args.no_graph:
@@ -776,7 +815,7 @@ def main():
                            'backend': ('nccl (RCCL)' if backend == 'nccl' else 'gloo (ranks may share a GPU: code-path test, not a measurement)') if world > 1 else 'none (single process)',
                            'timed_regions': len(regions), 'region_ms_per_step': [round(r / args.steps * 1e3, 3) for r in regions],
                            'statistic': 'median region'},
-                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'fp16_storage_mode' if args.dtype == 'bf16' else 'bf16_storage_mode': other_half, 'train_step': train, 'without_proj_feat': no_pf, 'config5_hrnet': cfg5}
+                'roofline': roof, 'power': power, 'cpu_baseline': cpu, 'fp32_mode': fp32, 'parity_mode_f16x3': parity, 'fp16_mode': f16m, 'fp16_storage_mode' if args.dtype == 'bf16' else 'bf16_storage_mode': other_half, 'pgcn': pgcn, 'train_step': train, 'without_proj_feat': no_pf, 'config5_hrnet': cfg5}
         # the full record (per-kernel tables, notes, sub-mode rooflines) goes to a side file and to stderr; the LAST stdout line is the compact
         # headline (dir_amd/benchline.py: <= 4 KB, every contract key + roofline + cpu_baseline) -- round 3's 20 KB line went unparsed
         from dir_amd import benchline

@@ -100,6 +100,10 @@ def compact(detail, detail_path='bench_detail.json'):
     for k in ('fp32_mode', 'parity_mode_f16x3', 'fp16_mode', 'fp16_storage_mode', 'bf16_storage_mode', 'train_step', 'without_proj_feat', 'config5_hrnet'):
         if detail.get(k):
             line[k] = _mode(detail[k])
+    pg = detail.get('pgcn')
+    if pg:
+        line['pgcn'] = {k: ({kk: v[kk] for kk in ('us_per_stack_pair', 'alg_gbps', 'frac_of_hbm_peak')} if isinstance(v, dict) else None) for k, v in pg.items() if k.startswith('B=')}
+        line['pgcn']['target'] = 0.6
     line['detail'] = detail_path
     # never over the limit: drop the optional parts, least important first
     for drop in (('roofline', 'top_kernels'), ('roofline', 'top_kernels_columns'), ('roofline', 'time_tuned_table'), ('power',), ('without_proj_feat',),

@@ -202,6 +202,159 @@ __global__ __launch_bounds__(STHR, NCB == 1 ? 3 : 2) void stream1x1_kernel(Strea
     }
 }
 
+
+// ---- the PIPELINED form (round 5, DIR_CONV_VARIANT 24; VERDICT r4 item 1b: "break the load -> compute -> store lock-step").  The kernel above keeps an
+// activation chunk two K-iterations ahead in registers -- at 0.25 us of MFMAs per iteration that is 0.5 us of lead against 1 - 2 us of HBM latency, so
+// every iteration waits (profiles/r05_a_sq_counters.txt: 58 % of its wave cycles in s_waitcnt, MFMA pipe 24 % busy).  Here a FIFTH wave does nothing but
+// move activation chunks global -> LDS by DMA into a ring of D buffers, D - 1 chunks (48 KB) ahead; the four MFMA waves never issue an activation
+// load, so their only vector-memory traffic is the compiler-tracked weight stream (the in-order vmcnt problem of mixing invisible DMAs with tracked
+// loads in ONE wave -- the reason the kernel above stages through registers -- does not arise across waves).  One barrier per chunk: it tells the
+// consumers that chunk c has landed (the producer waited for its own DMAs first) and the producer that buffer (c - 1) % D is free again.
+// Same k-slots in the same order, same epilogue: bit-identical to the kernel above and to the tiled kernels.  No pre-activation form (that one
+// must touch the data in registers).
+constexpr int PD = 4;                  // ring depth: PD - 1 chunks in flight
+template <int NCB, typename H>
+__global__ __launch_bounds__(320, 2) void stream1x1p_kernel(StreamArgs a, unsigned x_bytes, unsigned x2_bytes) {
+    convk::half_kernel_init<H>();
+    constexpr int NPB = 4, SBM = 128, NWG = 128 * NCB, OPITCH = 256 + 16, CH = SBM * 128;       // CH: bytes of one activation chunk
+    static_assert(PD * CH >= SBM * OPITCH, "the output stage re-uses the ring");
+    __shared__ __attribute__((aligned(16))) char s_raw[PD * CH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * SBM, nchunk = blockIdx.y;
+    constexpr unsigned OOB = 0x80000000u;
+
+    if (wave == 4) {
+        // ---- producer: DMA instruction j of a chunk fills rows 8 j .. 8 j + 7 (1 KB); lane = (row 8 j + (lane >> 3), position lane & 7) and fetches the
+        //      16-byte column that belongs at that position under the XOR swizzle the consumers read with
+        const convk::i32x4 d1 = {(int)(unsigned)(unsigned long long)a.x, (int)(unsigned)((unsigned long long)a.x >> 32), (int)x_bytes, 0x00020000};
+        const convk::i32x4 d2 = {(int)(unsigned)(unsigned long long)a.x2, (int)(unsigned)((unsigned long long)a.x2 >> 32), (int)x2_bytes, 0x00020000};
+        unsigned o1[16], o2[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = 8 * j + (lane >> 3), col = (lane & 7) ^ ((row >> 1) & 7), m = m0 + row;
+            o1[j] = o2[j] = OOB;
+            if (m < a.M) {
+                o1[j] = (unsigned)(((long long)m * a.in_cs + a.in_co + col * 8) * 2);
+                if (a.nk > a.nk1) {
+                    const int b = m / a.HoWo, rem = m - b * a.HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+                    o2[j] = (unsigned)(((((long long)b * a.H2 + oy * a.stride2) * a.W2 + ox * a.stride2) * a.in_cs2 + a.in_co2 + col * 8) * 2);
+                }
+            }
+        }
+        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)s_raw;
+        auto issue = [&](int c) {                              // chunk c (past the end: all lanes out of range -> zeros nobody reads) into buffer c % PD
+            const bool live = c < a.nk, first = c < a.nk1;
+            const unsigned soff = (unsigned)((first ? c : c - a.nk1) * SKC * 2);
+            const unsigned dst = lds0 + (unsigned)(c % PD) * CH;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const unsigned vo = !live ? OOB : first ? o1[j] : o2[j];
+                if (first) convk::lds_dma16_m0(d1, dst + j * 1024, vo, soff);
+                else convk::lds_dma16_m0(d2, dst + j * 1024, vo, soff);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < PD - 1; ++c) issue(c);
+        for (int c = 0; c < a.nk; ++c) {
+            convk::wait_vmcnt<(PD - 2) * 16>();                 // chunk c has landed: only the PD - 2 chunks behind it may still be in flight
+            __syncthreads();                                     // consumers: chunk c is there; producer: they are done with chunk c - 1
+            issue(c + PD - 1);                                   // -> buffer (c - 1) % PD
+        }
+        convk::wait_vmcnt<0>();                                  // the trailing (out-of-range) transfers land before the ring becomes the output stage
+        __syncthreads();
+        for (int half = 0; half < NCB; ++half) {                 // (the output stage's barriers)
+            __syncthreads();
+            if (half + 1 < NCB) __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumers: four waves, 32 * NCB output channels each, weights as MFMA A operands straight from the packed stream (L2), one chunk ahead
+    const uint4* wbase = a.w + ((long long)(nchunk * 4 + wave) * a.nk) * (4 * NCB * 64) + lane;
+    auto w_load = [&](int c, uint4 (&wr)[4][NCB]) {
+        const uint4* p = wbase + (long long)min(c, a.nk - 1) * (4 * NCB * 64);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) wr[ks][cb] = p[(ks * NCB + cb) * 64];
+    };
+    f32x16 acc[NCB][NPB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
+    uint4 wr[2][4][NCB];
+    w_load(0, wr[0]);
+    auto iteration = [&](auto Par, int c) {
+        constexpr int par = decltype(Par)::value;
+        w_load(c + 1, wr[par ^ 1]);
+        __syncthreads();                                         // chunk c is in buffer c % PD
+        const char* sa = s_raw + (c % PD) * CH;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 bv[NPB];
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) {
+                const int row = 32 * pb + l32;
+                bv[pb] = *reinterpret_cast<const uint4*>(sa + row * 128 + (((ks + 4 * h) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) acc[cb][pb] = Half<H>::mfma32(wr[par][ks][cb], bv[pb], acc[cb][pb]);
+        }
+    };
+    int c = 0;
+    for (; c + 1 < a.nk; c += 2) {
+        iteration(std::integral_constant<int, 0>{}, c);
+        iteration(std::integral_constant<int, 1>{}, c + 1);
+    }
+    if (c < a.nk) {                                              // odd chunk count: the last chunk's weights are in wr[0]
+        iteration(std::integral_constant<int, 0>{}, c);
+    }
+    __syncthreads();                                             // every consumer is done with the ring (and the producer's last transfers have landed)
+
+    // ---- epilogue: as in the kernel above (the tile leaves through LDS, 128 channels at a time, coalesced 16-byte row segments out)
+    const bool relu = a.relu != 0;
+#pragma unroll
+    for (int half = 0; half < NCB; ++half) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int blk = wave * NCB + cb;
+            if ((blk >> 2) != half) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = blk * 32 + 8 * q + 4 * h, n = nchunk * NWG + nl;
+                float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+                if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) {
+                    uint2 o;
+                    const float v0 = fmaf(acc[cb][pb][4 * q], sc.x, sh.x), v1 = fmaf(acc[cb][pb][4 * q + 1], sc.y, sh.y);
+                    const float v2 = fmaf(acc[cb][pb][4 * q + 2], sc.z, sh.z), v3 = fmaf(acc[cb][pb][4 * q + 3], sc.w, sh.w);
+                    if (relu) { o.x = Half<H>::pack2_relu(v0, v1); o.y = Half<H>::pack2_relu(v2, v3); }
+                    else { o.x = Half<H>::pack2(v0, v1); o.y = Half<H>::pack2(v2, v3); }
+                    *reinterpret_cast<uint2*>(s_raw + (32 * pb + l32) * OPITCH + (nl - 128 * half) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SBM * 16 / 256; ++i) {
+            const int cc_ = tid + 256 * i, row = cc_ >> 4, cc = cc_ & 15;
+            const int m = m0 + row;
+            if (m < a.M)
+                *reinterpret_cast<uint4*>(a.y + (long long)m * a.out_cs + a.out_co + nchunk * NWG + 128 * half + cc * 8) =
+                    *reinterpret_cast<const uint4*>(s_raw + row * OPITCH + cc * 16);
+        }
+        if (half + 1 < NCB) __syncthreads();
+    }
+}
+
 }  // namespace
 }  // namespace dir
 
@@ -245,6 +398,19 @@ extern "C" int dir_conv1x1_stream_forward(const dir_conv_desc* d, const void* x,
                                     else if (var == 23) DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 1, H_>), grid, dim3(STHR), 0, s, a); \
                                     else DIR_LAUNCH((stream1x1_kernel<NCB_, PRE_, 4, H_>), grid, dim3(STHR), 0, s, a); } while (0)
 #define DIR_STREAM(NCB_, PRE_) do { if (f16) DIR_STREAM_H(NCB_, PRE_, convk::f16s_t); else DIR_STREAM_H(NCB_, PRE_, convk::bf16_t); } while (0)
+    // DIR_CONV_VARIANT 24: the pipelined form (a fifth wave feeds the activation ring by DMA); no pre-activation; sources < 2 GiB (32-bit buffer offsets)
+    const long long xb = M * a.in_cs * 2, x2b = d2 ? (long long)d->B * d2->H * d2->W * a.in_cs2 * 2 : 0;
+    if (var == 24 && !pre_scale && xb < (1ll << 31) && x2b < (1ll << 31)) {
+        const dim3 gridp((a.M + 127) / 128, d->Cout / (d->Cout % 256 == 0 ? 256 : 128));
+        if (d->Cout % 256 == 0) {
+            if (f16) DIR_LAUNCH((stream1x1p_kernel<2, convk::f16s_t>), gridp, dim3(320), 0, s, a, (unsigned)xb, (unsigned)x2b);
+            else DIR_LAUNCH((stream1x1p_kernel<2, convk::bf16_t>), gridp, dim3(320), 0, s, a, (unsigned)xb, (unsigned)x2b);
+        } else {
+            if (f16) DIR_LAUNCH((stream1x1p_kernel<1, convk::f16s_t>), gridp, dim3(320), 0, s, a, (unsigned)xb, (unsigned)x2b);
+            else DIR_LAUNCH((stream1x1p_kernel<1, convk::bf16_t>), gridp, dim3(320), 0, s, a, (unsigned)xb, (unsigned)x2b);
+        }
+        return check_launch("dir_conv1x1_stream_forward");
+    }
     if (d->Cout % 256 == 0) {
         dim3 grid(tiles, d->Cout / 256);
         if (pre_scale) DIR_STREAM(2, true); else DIR_STREAM(2, false);

@@ -71,7 +71,8 @@ def bn_fold(sd, prefix, conv_bias=None, eps=1e-5):
 STREAM_VARIANT = 21      # DIR_CONV_VARIANT code: dir_conv1x1_stream_forward (1x1, bf16, Cout % 128 == 0), chosen per layer by autotune
 STREAM64_VARIANT = 22    # the same kernel on 64-pixel workgroups (twice as many, half as long)
 STREAM32_VARIANT = 23    # ... on 32-pixel workgroups (the 16x16 / 8x8 stages: 128-pixel tiles do not even cover the CUs there)
-STREAM_VARIANTS = (STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT)
+STREAMP_VARIANT = 24     # round 5: the pipelined form -- a fifth (producer) wave feeds a ring of activation chunks by LDS-DMA (no pre-activation form: those layers run 21)
+STREAM_VARIANTS = (STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT, STREAMP_VARIANT)
 
 
 def pack_stream_weights(w_nk, dtype=torch.bfloat16):
@@ -1238,6 +1239,8 @@ class DirEngine(object):
     # All of them -- including the streaming 1x1 kernel (STREAM_VARIANT, stream.hip), which feeds the MFMA the same k-slots in the
     # same order as the tiled kernels -- accumulate identically: outputs are bit-identical whichever is chosen
     # (tools/check_stream_layers.py, tests/test_gpu_dir.py::test_autotuned_engine_is_bit_identical).
+    # (STREAMP_VARIANT = 24, the pipelined streaming kernel of round 5, is built, bit-identical and tested but NOT offered: measured slower than 21 / 22 on
+    #  every layer it could serve -- one producer wave cannot issue 16 KB of LDS-DMA per 0.25 us of MFMAs; tools/bench_stream.py)
     CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15, STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT)
 
     def _profiled_forwards(self, img, n):

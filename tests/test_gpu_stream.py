@@ -108,7 +108,7 @@ def test_stream_conv_64_pixel_workgroups_are_bit_identical(case):
     x2 = torch.randn(B, H * src2[1], W * src2[1], src2[0], device='cuda', generator=gen).to(BF) if src2 else None
     kw = dict(relu=relu, pre_scale=ps if pre else None, pre_shift=pb if pre else None, pre_relu=pre, x2=x2, stride2=src2[1] if src2 else 1, in_coff=16, cin=Cin)
     a = F.conv1x1_stream(x, w, s, h, **kw)
-    for v in (22, 23):              # 64- and 32-pixel workgroups
+    for v in (22, 23, 24):          # 64- and 32-pixel workgroups; 24 (round 5): the pipelined form with a DMA producer wave (falls back to the plain kernel under a pre-activation)
         assert torch.equal(a, F.conv1x1_stream(x, w, s, h, variant=v, **kw)), v
 
 
@@ -119,3 +119,23 @@ def test_stream_conv_rejects_bad_arguments():
         F.conv1x1_stream(x, torch.zeros(128, 96, device='cuda'))
     with pytest.raises((DirHipError, AssertionError)):           # Cout not a multiple of 128
         F.conv1x1_stream(torch.zeros(1, 8, 8, 64, device='cuda', dtype=BF), torch.zeros(64, 64, device='cuda'))
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(64, 32, 32, 128, 256, 512, 1), (64, 16, 16, 256, 1024, 0, 1), (64, 32, 32, 128, 512, 256, 2), (7, 16, 16, 2304, 128, 0, 1), (3, 9, 11, 64, 384, 0, 1)])
+def test_pipelined_stream_kernel_full_size_is_bit_identical(shape, dt):
+    """DIR_CONV_VARIANT 24 (round 5: a fifth wave feeds a 4-deep ring of activation chunks by LDS-DMA, the MFMA waves only stream weights): the
+    layers it serves at full size (B = 64), odd / even chunk counts, second sources with stride, ragged pixel counts, both 16-bit storage kinds --
+    every output bit equals the register-staged kernel's, twice in a row (ring re-use across launches)"""
+    B, H, W, Cin, Cout, Cin2, s2 = shape
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(B, H, W, Cin, device='cuda', generator=gen).to(dt)
+    K = Cin + Cin2
+    w = torch.randn(Cout, K, device='cuda', generator=gen) * (2.0 / K) ** 0.5
+    s, h = torch.rand(Cout, device='cuda', generator=gen) + 0.5, torch.randn(Cout, device='cuda', generator=gen) * 0.3
+    x2 = torch.randn(B, H * s2, W * s2, Cin2, device='cuda', generator=gen).to(dt) if Cin2 else None
+    kw = dict(relu=True, x2=x2, stride2=s2)
+    a = F.conv1x1_stream(x, w, s, h, **kw)
+    b1 = F.conv1x1_stream(x, w, s, h, variant=24, **kw)
+    b2 = F.conv1x1_stream(x, w, s, h, variant=24, **kw)
+    assert torch.equal(a, b1) and torch.equal(a, b2)

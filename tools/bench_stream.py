@@ -58,8 +58,10 @@ for name, HW, Cin, Cout, pre, Cin2, s2 in LAYERS:
             ts64 = t
         elif v == E.STREAM32_VARIANT:
             ts32 = t
+        elif v == E.STREAMP_VARIANT:
+            tsp = t
         elif best is None or t < best[0]:
             best = (t, v)
     E._TLS.variant = None
-    print('%-44s M=%6d  stream %6.1f us (%.2f TB/s)   64 px %6.1f us (%.2f TB/s)   32 px %6.1f us   best tiled %6.1f us (variant %2d, %.2f TB/s)   %.1f MB'
-          % (name, M, ts, nbytes / ts / 1e6, ts64, nbytes / ts64 / 1e6, ts32, best[0], best[1], nbytes / best[0] / 1e6, nbytes / 1e6))
+    print('%-44s M=%6d  stream %6.1f us (%.2f TB/s)   pipelined (24) %6.1f us (%.2f TB/s)   64 px %6.1f us (%.2f TB/s)   32 px %6.1f us   best tiled %6.1f us (variant %2d, %.2f TB/s)   %.1f MB'
+          % (name, M, ts, nbytes / ts / 1e6, tsp, nbytes / tsp / 1e6, ts64, nbytes / ts64 / 1e6, ts32, best[0], best[1], nbytes / best[0] / 1e6, nbytes / 1e6))
