@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median one is reported')
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'], help="storage of feature maps and convolution weights: bf16 (BASELINE configs[1]), "
+    ap.add_argument('--dtype', default='f16', choices=['bf16', 'f16', 'f32'], help="storage of feature maps and convolution weights: bf16 (BASELINE configs[1]), "
                     "f16 = the same data path and MFMA rate on IEEE f16 (11-bit significands: every stage inside 0.01 mm), f32 = exact parity mode")
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--inflight', type=int, default=4, help='forwards in flight per GPU (engine.ForwardPipeline: one captured graph + '
@@ -804,7 +804,8 @@ def main():
                 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': args.dtype, 'data': 'synthetic',
                 'config': {'workload': 'BASELINE configs[1]: batch 64 synthetic 256x256 per GPU, ResNet-50 + init '
-                                       'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads',
+                                       'regression + 2 refinement stages (3 stage outputs), seg/dense/proj_feat heads; 16-bit storage = %s' % (
+                                           'IEEE f16 (the bf16 data path and MFMA rate, 11-bit significands: every stage within 0.01 mm; bf16 in bf16_storage_mode)' if args.dtype == 'f16' else args.dtype),
                            'batch_per_gpu': B, 'graph': not args.no_graph, 'forwards_in_flight': args.inflight,
                            'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                            'ms_per_forward_one_in_flight': None if serial_ms is None else round(serial_ms, 3),

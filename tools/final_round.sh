@@ -1,7 +1,7 @@
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/r04_l
+out=$R/gpurun_out/${TAG:-r05_a}
 mkdir -p $out
 cd $R
 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $out/gpu_tests.txt
