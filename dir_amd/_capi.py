@@ -114,7 +114,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 35          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 36          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P, DT_F16 = 0, 1, 3, 4, 5, 6, 7      # DT_F16: f16 STORAGE (round 5)
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -191,6 +191,8 @@ _SIGNATURES = {
     'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
+    'dir_bn_one_launch_status': (C.c_int, []),
+    'dir_bn_one_launch_enable': (C.c_int, [_i]),
     'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_bn_frozen_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_bn_sync_workspace_bytes': (C.c_longlong, [_i, _i]),
@@ -232,7 +234,7 @@ _SIGNATURES = {
 #    + whatever the caller announced for this call with annotate(): 'flops', 'bytes' (algorithmic work), 'shape', 'op'}
 PROFILE = None
 _pending = {}
-_NO_PROFILE = ('dir_abi_version', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
+_NO_PROFILE = ('dir_abi_version', 'dir_bn_one_launch_status', 'dir_bn_one_launch_enable', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
                'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes',
                'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_bn_sync_workspace_bytes', 'dir_bn_frozen_workspace_bytes', 'dir_jpeg_planes_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
 

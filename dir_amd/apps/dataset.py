@@ -122,7 +122,10 @@ ANNO_FLOATS = 21 + 2 * 67
 def _decode_worker(data_path, split, wid, workers, indices, bs, chunk, ready, frames, annos, flags, ctrl, records=False):
     """decode process `wid` of `workers`: owns the chunks t = wid, wid + workers, ... of the flat (batch, chunk) sequence; chunk t of batch b
     goes to rows [k * chunk, ...) of ring slot b % depth once batch b - depth has been released (ctrl[0] = batches released); flags[t] = 1 when
-    its frames and annotations are in place (2: failed).  No queue in the steady state: shared-memory words only."""
+    its frames and annotations are in place (2: failed).  No queue in the steady state: shared-memory words only.
+    Ordering: the frame bytes and then the flag are plain stores from this process, the consumer polls with plain loads -- correct on x86 (total
+    store order: stores become visible in program order), which is what every MI355X host is; a weakly ordered host would need a release
+    store for the flag."""
     import time
     torch.set_num_threads(1)
     ds = InterHandSplit(data_path, split)

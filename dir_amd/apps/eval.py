@@ -202,15 +202,8 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
         from .jpeg import RecordDecoder
         rec_dev = [torch.zeros(bs, ring.record_bytes, device=dev, dtype=torch.uint8) for _ in range(nslot)]
         rec_dec = [RecordDecoder(bs, ring.record_bytes, IMG_SIZE, dev) for _ in range(nslot)]
-    batches = iter(ring)
-    first = next(batches, None)
-    if first is not None and eng.arith is not None and not eng.calibrated:
-        # f16 arithmetic modes: the per-layer power-of-two operand scales come from the first batch, BEFORE the slots' graphs are captured (the
-        # scales are launch arguments: a graph captured earlier would replay the uncalibrated ones)
-        f0 = first[0].to(dev)
-        eng.calibrate(rec_dec[0](f0, slots[0].clone()) if source == 'jpeg' else f0)
-    pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
     pending = [None] * nslot
+    pipe = None
 
     def finish(slot):
         n, annos = pending[slot]
@@ -221,8 +214,17 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
         pending[slot] = None
 
     t0, seen = time.perf_counter(), 0
-    try:
+    try:                                                               # everything that can raise while the decode workers run: the ring is closed on the way out
         import itertools
+        batches = iter(ring)
+        first = next(batches, None)
+        if first is not None and eng.arith is not None and not eng.calibrated:
+            # f16 arithmetic modes: the per-layer power-of-two operand scales come from the first batch, BEFORE the slots' graphs are captured
+            # (the scales are launch arguments: a graph captured earlier would replay the uncalibrated ones)
+            f0 = first[0].to(dev)
+            eng.calibrate(rec_dec[0](f0, slots[0].clone()) if source == 'jpeg' else f0)
+        pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
+        t0 = time.perf_counter()
         for k, (frames, annos, n) in enumerate(itertools.chain([first] if first is not None else [], batches)):
             slot = k % nslot
             if pending[slot] is not None:

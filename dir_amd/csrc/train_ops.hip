@@ -15,6 +15,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <initializer_list>
+#include <mutex>
 
 namespace {
 
@@ -789,9 +790,8 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int n) {
 // ---- 16-byte versions for C % 4 == 0 (every BatchNorm2d of the path).  Forward statistics in ONE pass over HBM: a workgroup (64 channels x
 // one 256-row chunk) forms the chunk's column sums, then the squared deviations from the CHUNK mean on a second read that hits L2 (a chunk
 // is 64 KB); the finalise kernel combines the chunks exactly: var = sum_k [M2_k + n_k (mean_k - mean)^2] / R, in chunk order.
-__global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p1, float* p2, int R, int C, int ld) {
-    __shared__ float4 s1[16][16];
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 64 + cq * 4, ch = blockIdx.y;
+__device__ __forceinline__ void bn_stats4_tile(const float* x, float* p1, float* p2, int R, int C, int ld, int cg, int ch, float4 (&s1)[16][16]) {
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = cg * 64 + cq * 4;
     const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
     const bool on = c < C;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -841,10 +841,14 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p
         *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
     }
 }
-__global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, const float* p2, float* save_mean, float* save_rstd, float* running_mean,
-                                                              float* running_var, int chunks, int R, int C, float eps, float momentum) {
-    __shared__ float s[16][17];
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+__global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p1, float* p2, int R, int C, int ld) {
+    __shared__ float4 s1[16][16];
+    bn_stats4_tile(x, p1, p2, R, C, ld, blockIdx.x, blockIdx.y, s1);
+}
+// the statistics of 16 channels (c16 = first channel / 16) from the chunk partials
+__device__ __forceinline__ void bn_stats_combine16(const float* p1, const float* p2, float* save_mean, float* save_rstd, float* running_mean,
+                                                   float* running_var, int chunks, int R, int C, float eps, float momentum, int c16, float (&s)[16][17]) {
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = c16 * 16 + cl;
     const float mu = chunk_sum16(p1, chunks, C, c, s) / R;
     __syncthreads();
     float a = 0.f;
@@ -865,6 +869,11 @@ __global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, 
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (R > 1 ? q / (R - 1) : var);
     }
+}
+__global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, const float* p2, float* save_mean, float* save_rstd, float* running_mean,
+                                                              float* running_var, int chunks, int R, int C, float eps, float momentum) {
+    __shared__ float s[16][17];
+    bn_stats_combine16(p1, p2, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum, blockIdx.x, s);
 }
 // ---- SyncBN (round 5; SURVEY.md 8e "optionally offer SyncBN": the reference trains 64 images on ONE GPU, config.py:13-15 -- 8 x 32 changes the
 // BatchNorm batch unless the statistics are pooled).  The local part of the statistics: this rank's mean and M2 = sum (x - mean_local)^2 per
@@ -945,10 +954,10 @@ __global__ __launch_bounds__(256) void bn_apply_fwd4_kernel(const float* x, cons
     }
 }
 // backward partial sums (the vec4 form of bn_partial_kernel's mode 2) with the ReLU mask re-computed from x
-__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, const float* gy, const float* w, const float* b, const float* mu, const float* rs,
-                                                             float* p1, float* p2, int R, int C, int ld, int relu) {
-    __shared__ float4 s1[16][16], s2[16][16];
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 64 + cq * 4, ch = blockIdx.y;
+__device__ __forceinline__ void bn_bwd_partial4_tile(const float* x, const float* gy, const float* w, const float* b, const float* mu, const float* rs,
+                                                     float* p1, float* p2, int R, int C, int ld, int relu, int cg, int ch, float4 (&s1)[16][16],
+                                                     float4 (&s2)[16][16]) {
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = cg * 64 + cq * 4;
     const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), bb = a;
     if (c < C) {
@@ -993,10 +1002,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, co
         *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
     }
 }
+__global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, const float* gy, const float* w, const float* b, const float* mu, const float* rs,
+                                                             float* p1, float* p2, int R, int C, int ld, int relu) {
+    __shared__ float4 s1[16][16], s2[16][16];
+    bn_bwd_partial4_tile(x, gy, w, b, mu, rs, p1, p2, R, C, ld, relu, blockIdx.x, blockIdx.y, s1, s2);
+}
 // both column sums of the backward pass in one launch: t1 = g b, t2 = g w (also kept for the apply kernel)
-__global__ __launch_bounds__(256) void bn_bwd_combine_kernel(const float* p1, const float* p2, float* t1, float* t2, float* gb, float* gw, int chunks, int C) {
-    __shared__ float s[16][17];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+__device__ __forceinline__ void bn_bwd_combine16(const float* p1, const float* p2, float* t1, float* t2, float* gb, float* gw, int chunks, int C, int c16,
+                                                 float (&s)[16][17]) {
+    const int c = c16 * 16 + (threadIdx.x & 15);
     const float a = chunk_sum16(p1, chunks, C, c, s);
     __syncthreads();
     const float b = chunk_sum16(p2, chunks, C, c, s);
@@ -1004,6 +1018,10 @@ __global__ __launch_bounds__(256) void bn_bwd_combine_kernel(const float* p1, co
     t1[c] = a; t2[c] = b;
     if (gb) gb[c] = a;
     if (gw) gw[c] = b;
+}
+__global__ __launch_bounds__(256) void bn_bwd_combine_kernel(const float* p1, const float* p2, float* t1, float* t2, float* gb, float* gw, int chunks, int C) {
+    __shared__ float s[16][17];
+    bn_bwd_combine16(p1, p2, t1, t2, gb, gw, chunks, C, blockIdx.x, s);
 }
 __global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, const float* x, const float* w, const float* b, const float* mu, const float* rs,
                                                            const float* s1, const float* s2, float* gx, int R, int C, int ld, int relu, float n_pool = 0.f) {
@@ -1036,6 +1054,175 @@ __global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, con
         o.z = g.z * k.z * (q.z - m1.z - (v.z - m.z) * k.z * m2.z);
         o.w = g.w * k.w * (q.w - m1.w - (v.w - m.w) * k.w * m2.w);
         *reinterpret_cast<float4*>(gx + r * ld + c) = o;
+    }
+}
+
+// ---- BatchNorm over more than BN_SMALL_R rows in ONE launch (round 5; VERDICT r4 item 3: "BatchNorm out of its six launches").  The three
+// launches above (chunk partials -> combine -> apply) are dependent and small: at 32 images per GPU a launch boundary (~5 us) costs as much as
+// the median BatchNorm kernel runs, 660 of the step's 2 440 launches.  Here a PERSISTENT grid (every workgroup resident: grid <= what the GPU
+// holds) walks the same (64 channels x 256 rows) tiles; a channel group's statistics are combined by the workgroup whose tile arrives LAST
+// at the group's counter (in chunk order whatever the arrival order: the same bits as bn_stats_combine_kernel), the others wait on the
+// group's flag -- NOT on a grid-wide barrier: a 64-channel group is ready as soon as its own chunks are -- and then normalise the tiles they read.
+// words: [arrive | flag | depart][BN_ONE_GROUPS] + an error word, zero before the launch and zero again after it (the last tile to leave a
+// group clears it), owned by the library per stream (bn_one_words).  Visibility across the 8 XCDs' L2s: agent-scope release / acquire fences.
+constexpr int BN_ONE_GROUPS = 256, BN_ONE_WORDS = 3 * BN_ONE_GROUPS + 4;
+struct BnOne {
+    const float *x, *gy, *w, *b, *res;
+    float *y, *gx, *save_mean, *save_rstd, *running_mean, *running_var, *gw, *gb, *p1, *p2, *t1, *t2;
+    int* words;
+    int R, C, ld, relu, chunks, cgroups;
+    float eps, momentum;
+};
+__device__ __forceinline__ int bn_one_arrive(int* counter) {          // every writer fenced its own stores already
+    __shared__ int old;
+    __syncthreads();
+    if (threadIdx.x == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return old;
+}
+__device__ __forceinline__ void bn_one_wait(int* flag, int* err) {
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 400000000ll) {                 // 4 s at 100 MHz: a workgroup of this launch never ran (see dir_bn_one_launch_status)
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // the statistics another XCD wrote are read from memory, not from this XCD's L2
+}
+__device__ __forceinline__ void bn_one_leave(int* depart, int* flag, int chunks) {
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(depart, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == chunks - 1) {
+        __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every tile of the group has seen the flag: clean for the next launch
+        __hip_atomic_store(depart, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ __launch_bounds__(256) void bn_one_fwd_kernel(const BnOne a) {
+    __shared__ float4 s1[16][16];
+    __shared__ float s[16][17];
+    const int ntile = a.cgroups * a.chunks, G = gridDim.x;
+    int *arrive = a.words, *flag = a.words + BN_ONE_GROUPS, *depart = a.words + 2 * BN_ONE_GROUPS, *err = a.words + 3 * BN_ONE_GROUPS;
+    for (int t = blockIdx.x; t < ntile; t += G) {
+        const int cg = t % a.cgroups, ch = t / a.cgroups;
+        __syncthreads();
+        bn_stats4_tile(a.x, a.p1, a.p2, a.R, a.C, a.ld, cg, ch, s1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (bn_one_arrive(arrive + cg) != a.chunks - 1) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                       // the last tile of the group: every chunk partial of these 64 channels is in memory
+        for (int j = 0; j < 4; ++j) {
+            __syncthreads();
+            bn_stats_combine16(a.p1, a.p2, a.save_mean, a.save_rstd, a.running_mean, a.running_var, a.chunks, a.R, a.C, a.eps, a.momentum, cg * 4 + j, s);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(arrive + cg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag + cg, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = blockIdx.x; t < ntile; t += G) {
+        const int cg = t % a.cgroups, ch = t / a.cgroups, c = cg * 64 + cq * 4;
+        bn_one_wait(flag + cg, err);
+        if (c < a.C) {
+            const float4 m = *reinterpret_cast<const float4*>(a.save_mean + c), k = *reinterpret_cast<const float4*>(a.save_rstd + c);
+            const float4 g = a.w ? *reinterpret_cast<const float4*>(a.w + c) : one, be = a.b ? *reinterpret_cast<const float4*>(a.b + c) : zero;
+            const int r1 = min(a.R, (ch + 1) * BN_CHUNK_ROWS);
+            auto put = [&](int r, const float4 v, const float4 q) {
+                float4 o = make_float4(bn_value(v.x, m.x, k.x, g.x, be.x), bn_value(v.y, m.y, k.y, g.y, be.y), bn_value(v.z, m.z, k.z, g.z, be.z),
+                                       bn_value(v.w, m.w, k.w, g.w, be.w));
+                if (a.res) { o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+                if (a.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+                *reinterpret_cast<float4*>(a.y + (long long)r * a.ld + c) = o;
+            };
+            int r = ch * BN_CHUNK_ROWS + rl;
+            for (; r + 48 < r1; r += 64) {
+                float4 v[4], q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = *reinterpret_cast<const float4*>(a.x + (long long)(r + 16 * u) * a.ld + c);
+                    q[u] = a.res ? *reinterpret_cast<const float4*>(a.res + (long long)(r + 16 * u) * a.ld + c) : zero;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(r + 16 * u, v[u], q[u]);
+            }
+            for (; r < r1; r += 16)
+                put(r, *reinterpret_cast<const float4*>(a.x + (long long)r * a.ld + c),
+                    a.res ? *reinterpret_cast<const float4*>(a.res + (long long)r * a.ld + c) : zero);
+        }
+        bn_one_leave(depart + cg, flag + cg, a.chunks);
+    }
+}
+__global__ __launch_bounds__(256) void bn_one_bwd_kernel(const BnOne a) {
+    __shared__ float4 s1[16][16], s2[16][16];
+    __shared__ float s[16][17];
+    const int ntile = a.cgroups * a.chunks, G = gridDim.x;
+    int *arrive = a.words, *flag = a.words + BN_ONE_GROUPS, *depart = a.words + 2 * BN_ONE_GROUPS, *err = a.words + 3 * BN_ONE_GROUPS;
+    for (int t = blockIdx.x; t < ntile; t += G) {
+        const int cg = t % a.cgroups, ch = t / a.cgroups;
+        __syncthreads();
+        bn_bwd_partial4_tile(a.x, a.gy, a.w, a.b, a.save_mean, a.save_rstd, a.p1, a.p2, a.R, a.C, a.ld, a.relu, cg, ch, s1, s2);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (bn_one_arrive(arrive + cg) != a.chunks - 1) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int j = 0; j < 4; ++j) {
+            __syncthreads();
+            bn_bwd_combine16(a.p1, a.p2, a.t1, a.t2, a.gb, a.gw, a.chunks, a.C, cg * 4 + j, s);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(arrive + cg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.gx) __hip_atomic_store(flag + cg, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!a.gx) return;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float nn = (float)a.R;
+    for (int t = blockIdx.x; t < ntile; t += G) {
+        const int cg = t % a.cgroups, ch = t / a.cgroups, c = cg * 64 + cq * 4;
+        bn_one_wait(flag + cg, err);
+        if (c < a.C) {
+            const float4 m = *reinterpret_cast<const float4*>(a.save_mean + c), k = *reinterpret_cast<const float4*>(a.save_rstd + c);
+            const float4 g = a.w ? *reinterpret_cast<const float4*>(a.w + c) : one, be = a.b ? *reinterpret_cast<const float4*>(a.b + c) : zero;
+            const float4 a1 = *reinterpret_cast<const float4*>(a.t1 + c), a2 = *reinterpret_cast<const float4*>(a.t2 + c);
+            const float4 m1 = make_float4(a1.x / nn, a1.y / nn, a1.z / nn, a1.w / nn), m2 = make_float4(a2.x / nn, a2.y / nn, a2.z / nn, a2.w / nn);
+            const int r1 = min(a.R, (ch + 1) * BN_CHUNK_ROWS);
+            auto put = [&](int r, const float4 v, float4 q) {             // the expressions of bn_apply_bwd4_kernel
+                if (a.relu) {
+                    if (!(bn_value(v.x, m.x, k.x, g.x, be.x) > 0.f)) q.x = 0.f;
+                    if (!(bn_value(v.y, m.y, k.y, g.y, be.y) > 0.f)) q.y = 0.f;
+                    if (!(bn_value(v.z, m.z, k.z, g.z, be.z) > 0.f)) q.z = 0.f;
+                    if (!(bn_value(v.w, m.w, k.w, g.w, be.w) > 0.f)) q.w = 0.f;
+                }
+                float4 o;
+                o.x = g.x * k.x * (q.x - m1.x - (v.x - m.x) * k.x * m2.x);
+                o.y = g.y * k.y * (q.y - m1.y - (v.y - m.y) * k.y * m2.y);
+                o.z = g.z * k.z * (q.z - m1.z - (v.z - m.z) * k.z * m2.z);
+                o.w = g.w * k.w * (q.w - m1.w - (v.w - m.w) * k.w * m2.w);
+                *reinterpret_cast<float4*>(a.gx + (long long)r * a.ld + c) = o;
+            };
+            int r = ch * BN_CHUNK_ROWS + rl;
+            for (; r + 48 < r1; r += 64) {
+                float4 v[4], q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = *reinterpret_cast<const float4*>(a.x + (long long)(r + 16 * u) * a.ld + c);
+                    q[u] = *reinterpret_cast<const float4*>(a.gy + (long long)(r + 16 * u) * a.ld + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(r + 16 * u, v[u], q[u]);
+            }
+            for (; r < r1; r += 16)
+                put(r, *reinterpret_cast<const float4*>(a.x + (long long)r * a.ld + c), *reinterpret_cast<const float4*>(a.gy + (long long)r * a.ld + c));
+        }
+        bn_one_leave(depart + cg, flag + cg, a.chunks);
     }
 }
 
@@ -1645,6 +1832,72 @@ static bool bn_vec4(int C, int ld, std::initializer_list<const void*> ps) {
     for (const void* q : ps) if (q && ((uintptr_t)q & 15)) return false;
     return true;
 }
+// ---- one-launch BatchNorm: the library-owned sync words (one block per stream that ever ran a BatchNorm, from a pool allocated and zeroed at the
+// first call -- never inside a stream capture: a stream first seen while capturing takes a block of the pool, and with the pool absent or spent
+// the three-launch path runs) and the persistent grid's size
+constexpr int BN_ONE_POOL = 16, BN_ONE_DEVICES = 16;
+struct BnOnePool { int* base = nullptr; int used = 0; hipStream_t streams[BN_ONE_POOL]; };
+static std::mutex bn_one_mu;
+static int bn_one_switch = -1;           // -1: not read yet (DIR_BN_ONE_LAUNCH, default on) | 0 | 1; dir_bn_one_launch_enable sets it
+static bool bn_one_enabled() {
+    std::lock_guard<std::mutex> lock(bn_one_mu);
+    if (bn_one_switch < 0) { const char* e = getenv("DIR_BN_ONE_LAUNCH"); bn_one_switch = !(e && e[0] == '0'); }
+    return bn_one_switch != 0;
+}
+static BnOnePool bn_one_pools[BN_ONE_DEVICES];
+static int* bn_one_words(hipStream_t s) {
+    if (!bn_one_enabled()) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BN_ONE_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(bn_one_mu);
+    BnOnePool& p = bn_one_pools[dev];
+    if (!p.base) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+        int* q = nullptr;
+        if (hipMalloc(&q, sizeof(int) * BN_ONE_WORDS * BN_ONE_POOL) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(q, 0, sizeof(int) * BN_ONE_WORDS * BN_ONE_POOL) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(q); return nullptr; }
+        p.base = q;
+    }
+    for (int i = 0; i < p.used; ++i) if (p.streams[i] == s) return p.base + (long long)i * BN_ONE_WORDS;
+    if (p.used == BN_ONE_POOL) return nullptr;
+    p.streams[p.used] = s;
+    return p.base + (long long)(p.used++) * BN_ONE_WORDS;
+}
+template <typename K>
+static int bn_one_grid(K kernel, int ntile) {
+    static const int slots = [kernel]() {
+        int dev = 0, cus = 256, occ = 4;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t pr;
+            if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) cus = pr.multiProcessorCount;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        return cus * (occ > 1 ? occ * 3 / 4 : 1);          // every workgroup of the launch must be resident at once (they wait on each other): below what fits
+    }();
+    return ntile < slots ? ntile : slots;
+}
+// 0, or 1 if a workgroup of a one-launch BatchNorm on the current device ever gave up waiting (that launch's outputs were wrong); the sync words
+// of the device are cleared.  Synchronises the device: nothing in the training step calls this -- tests and the eager (calibration) steps do.
+extern "C" int dir_bn_one_launch_enable(int on) {
+    const bool was = bn_one_enabled();
+    std::lock_guard<std::mutex> lock(bn_one_mu);
+    bn_one_switch = on != 0;
+    return was;
+}
+extern "C" int dir_bn_one_launch_status(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BN_ONE_DEVICES) return 0;
+    std::lock_guard<std::mutex> lock(bn_one_mu);
+    BnOnePool& p = bn_one_pools[dev];
+    if (!p.base) return 0;
+    static int host[BN_ONE_WORDS * BN_ONE_POOL];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host, p.base, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int bad = 0;
+    for (int i = 0; i < BN_ONE_POOL; ++i) bad |= host[i * BN_ONE_WORDS + 3 * BN_ONE_GROUPS] != 0;
+    if (bad && hipMemset(p.base, 0, sizeof(host)) != hipSuccess) return -1;
+    return bad;
+}
 extern "C" int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
                                     float* running_var, int R, int C, int ld, float eps, float momentum, int relu, const float* residual,
                                     float* workspace, long long workspace_bytes, void* stream) {
@@ -1666,6 +1919,15 @@ extern "C" int dir_bn_train_forward(const float* x, const float* w, const float*
     const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
     if (bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, workspace, residual})) {
         float* p2 = part + (long long)chunks * C;
+        int* words = (int)pg.x <= BN_ONE_GROUPS ? bn_one_words(s) : nullptr;
+        if (words) {
+            BnOne a{};
+            a.x = x; a.w = w; a.b = b; a.res = residual; a.y = y; a.save_mean = save_mean; a.save_rstd = save_rstd; a.running_mean = running_mean;
+            a.running_var = running_var; a.p1 = part; a.p2 = p2; a.words = words; a.R = R; a.C = C; a.ld = ld; a.relu = relu; a.chunks = chunks;
+            a.cgroups = (int)pg.x; a.eps = eps; a.momentum = momentum;
+            DIR_LAUNCH(bn_one_fwd_kernel, dim3(bn_one_grid(bn_one_fwd_kernel, a.cgroups * chunks)), dim3(256), 0, s, a);
+            return check_launch("dir_bn_train_forward");
+        }
         DIR_LAUNCH(bn_stats4_kernel, pg, dim3(256), 0, s, x, part, p2, R, C, ld);
         DIR_LAUNCH(bn_stats_combine_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)p2, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum);
         const long long nt = (long long)((R + 3) / 4) * (C / 4);
@@ -1698,6 +1960,15 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
     float* p1 = workspace; float* p2 = p1 + (long long)chunks * C; float* t1 = p2 + (long long)chunks * C; float* t2 = t1 + C;
     const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
     const bool vec = bn_vec4(C, ld, {x, gy, gx, w, b, save_mean, save_rstd, workspace});
+    int* words = vec && (int)pg.x <= BN_ONE_GROUPS ? bn_one_words(s) : nullptr;
+    if (words) {
+        BnOne a{};
+        a.x = x; a.gy = gy; a.w = w; a.b = b; a.gx = gx; a.save_mean = const_cast<float*>(save_mean); a.save_rstd = const_cast<float*>(save_rstd);
+        a.gw = gw; a.gb = gb; a.p1 = p1; a.p2 = p2; a.t1 = t1; a.t2 = t2; a.words = words; a.R = R; a.C = C; a.ld = ld; a.relu = relu; a.chunks = chunks;
+        a.cgroups = (int)pg.x;
+        DIR_LAUNCH(bn_one_bwd_kernel, dim3(bn_one_grid(bn_one_bwd_kernel, a.cgroups * chunks)), dim3(256), 0, s, a);
+        return check_launch("dir_bn_train_backward");
+    }
     if (vec) DIR_LAUNCH(bn_bwd_partial4_kernel, pg, dim3(256), 0, s, x, gy, w, b, save_mean, save_rstd, p1, p2, R, C, ld, relu);
     else launch_bn_partial(pg, s, x, gy, save_mean, save_rstd, p1, p2, R, C, ld, 2, w, b, relu);
     DIR_LAUNCH(bn_bwd_combine_kernel, cg, dim3(256), 0, s, (const float*)p1, (const float*)p2, t1, t2, gb, gw, chunks, C);

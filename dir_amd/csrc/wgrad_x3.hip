@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_reduce_kernel(const float* part,
 
 int x3_tile(int c) { return c > 64 ? 128 : 64; }
 // workgroups of a tile shape the whole GPU holds at once (occupancy x CUs), asked from the runtime once per shape
+// (once per PROCESS, for the device current at the first call: one process drives one GPU here.  The chunk count -- hence the summation order and the
+// last bits of a weight gradient -- follows CU count and occupancy: gradients reproduce run to run on one device model, not across models.)
 template <int TM, int TN>
 int x3_slots_of() {
     static const int slots = []() {

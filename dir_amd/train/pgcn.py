@@ -20,8 +20,10 @@ def _zeros_like(t):
     key = (tuple(t.shape), t.device)
     z = _ZEROS.get(key)
     if z is None:
-        z = _ZEROS[key] = torch.zeros_like(t)
-    return z
+        z = torch.zeros_like(t)
+        if not torch.cuda.is_current_stream_capturing():   # a tensor first made inside a capture lives in that graph's pool: never cache that one
+            _ZEROS[key] = z
+    return z                                               # shared and READ-ONLY by convention (tests/test_gpu_pgcn_bwd.py checks it stays zero)
 
 
 def gconv_forward(P, p, cur):

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 35
+#define DIR_ABI_VERSION 36
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -182,8 +182,17 @@ int dir_attention_backward(const float* qkv, const float* probs, const float* go
  * (models/backbone/resnet.py:136-140); the backward of THAT form masks with the saved output instead (dir_relu_backward) and passes relu = 0.  R <= 512: one
  * thread per channel walks the rows in order, no workspace.  Larger R (BatchNorm2d over feature maps): the column reductions are cut
  * into 256-row chunks whose partials are combined in chunk order (deterministic; the variance as sum_k [M2_k + n_k (mean_k - mean)^2] / R,
- * one pass over HBM); workspace of dir_bn_train_workspace_bytes(R, C). */
+ * one pass over HBM); workspace of dir_bn_train_workspace_bytes(R, C).
+ * R > 512, C % 4 == 0 (round 5): ONE launch each way instead of three -- a persistent grid (every workgroup resident) walks the same chunks; the
+ * workgroup whose chunk reaches a 64-channel group's counter last combines that group's partials (in chunk order: the same bits as the three
+ * launches), the others wait on the group's flag and then normalise the chunks they read.  The counters live in library-owned device words, one
+ * block per stream (allocated at the first call outside a stream capture; no block -> the three launches run), and are left zero by every
+ * launch.  A workgroup that waits longer than 4 s gives up and raises the error word dir_bn_one_launch_status() reports (0 | 1; it synchronises
+ * the device and clears the words; the step never calls it).  DIR_BN_ONE_LAUNCH=0 in the environment, or dir_bn_one_launch_enable(0) (returns the
+ * previous setting), selects the three launches (A/B; the results are the same bits). */
 long long dir_bn_train_workspace_bytes(int R, int C);
+int dir_bn_one_launch_status(void);
+int dir_bn_one_launch_enable(int on);
 int dir_bn_train_forward(const float* x, const float* w, const float* b, float* y, float* save_mean, float* save_rstd, float* running_mean,
                          float* running_var, int R, int C, int ld, float eps, float momentum, int relu, const float* residual,
                          float* workspace, long long workspace_bytes, void* stream);

@@ -473,3 +473,57 @@ def test_graph_captured_train_step_equals_the_eager_one():
     assert torch.equal(o1.flat_param, o2.flat_param)
     assert all(torch.equal(b1[k], b2[k]) for k in b1)                       # BatchNorm running statistics too
     assert {k: float(v) for k, v in l1.items()} == {k: float(v) for k, v in l2.items()}
+
+
+def test_graph_captured_train_step_survives_a_recalibration(monkeypatch):
+    """the call after a recalibration captures again, and the eager step before it has re-measured every operand scale.  With
+    the batch's magnitude changed between the captures the power-of-two scales of many call sites move, so the packed weight table has pending
+    scale changes when the second capture starts: they must reach the device OUTSIDE the capture (WeightPack.sync_table; an upload inside it
+    raises).  DIR_TRAIN_RECALIBRATE = 2 here: calls 1-2 eager, 3 captures, 4 replays, 5 eager (recalibrates on the brighter batch), 6 captures
+    again, 7 replays.  The losses follow an all-eager run of the same batches to f16x3 rounding (the two runs recalibrate on different steps)."""
+    from conftest import loss_case
+    from dir_amd.optim import FlatAdamW
+    from dir_amd.train import step as TSTEP, conv as TC
+    monkeypatch.setattr(TC, 'RECALIBRATE', 2)
+    g8 = dict(np.load(os.path.join(HERE, 'golden', 'g8_loss.npz')))
+    with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, SEED)
+    is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
+    img = torch.from_numpy(synth.synth_input('loss.img', (2, 3, 256, 256), SEED)).cuda()
+    preds, gt, faces, _, _, gt_seg, gt_dense = loss_case(g8)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    target = {k: dv(v) for k, v in gt.items() if 'center' not in k}
+    target.update(seg=dv(gt_seg), dense=dv(gt_dense))
+    meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
+    fc = tuple(dv(f.astype(np.int64)) for f in faces)
+    batches = [img] * 4 + [img * 6.0] * 3                                  # x 6: the first convolution's operand scale moves by 4 or 8
+
+    def make():
+        params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
+        buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
+        opt = FlatAdamW(list(params.values()), lr=2e-5)
+        opt.set_inactive(TSTEP.inactive_parameters(params))
+        return params, buffers, opt
+    p2, b2, o2 = make()
+    gs = TSTEP.GraphedTrainStep(p2, b2, o2, fc)
+    graphs, got, uploads = [], [], []
+    upload = TC.WeightPack._upload
+    monkeypatch.setattr(TC.WeightPack, '_upload', lambda self: (uploads.append(len(got)), upload(self))[1])
+    for x in batches:
+        loss = gs(x, target, meta)
+        got.append(sum(float(v) for v in loss.values()))
+        graphs.append(gs.graph)
+    monkeypatch.setattr(TC.WeightPack, '_upload', upload)
+    assert 5 in uploads, uploads                   # the scales the eager call 5 measured were uploaded by call 6 (before its capture: inside, _upload raises)
+    assert graphs[2] is not None and graphs[4] is None and graphs[5] is not None and graphs[5] is not graphs[2]
+    assert gs.since_capture == 2 and all(np.isfinite(got)), got
+    p1, b1, o1 = make()
+    TC.reset_scales()
+    want = []
+    for x in batches:
+        loss = TSTEP.train_step(p1, b1, x, target, meta, fc, o1, overlap_allreduce=False)
+        want.append(sum(float(v) for v in loss.values()))
+    np.testing.assert_allclose(got, want, rtol=2e-4)
+    rel = float((o1.flat_param - o2.flat_param).abs().max() / o1.flat_param.abs().max())
+    assert rel < 1e-4, rel

@@ -78,6 +78,13 @@ def test_pgraphconv_module_alone_trains():
     assert rel(x.grad, xr.grad.numpy()) < 2e-5 and rel(m.W.grad, W.grad.numpy()) < 2e-5
     assert rel(m.e_1.grad, e1.grad.numpy()) < 2e-5 and rel(m.bias.grad, b.grad.numpy()) < 2e-5
     assert float(m.e_0.grad.abs().max()) == 0.0                                  # identically zero, as under torch (a one-entry softmax row)
+    # the training kernels hand out ONE shared all-zero tensor for e_0's gradient; autograd must not adopt it as .grad (an optimiser or
+    # a gradient clip writing into .grad would then corrupt every later step's e_0 gradient)
+    from dir_amd.train import pgcn as TP
+    shared = [z for z in TP._ZEROS.values() if z.shape == m.e_0.shape]
+    assert shared and all(z.data_ptr() != m.e_0.grad.data_ptr() for z in shared)
+    m.e_0.grad.add_(1.0)
+    assert all(float(z.abs().max()) == 0.0 for z in shared)
 
 
 def test_ste_module_trains_like_the_reference(golden):

@@ -217,6 +217,55 @@ def test_batchnorm_relu_fused(R, C, relu):
     assert rel(y3, (torch.relu(want) if relu else want).numpy()) < 5e-6
 
 
+@pytest.mark.parametrize('R,C', [(5000, 64), (70000, 256), (131072, 64), (2048, 2048), (8192, 1024), (1537, 36), (33000, 48)])
+def test_batchnorm_one_launch_gives_the_bits_of_the_three_launches(R, C):
+    """BatchNorm over feature maps in ONE launch each way (bn_one_fwd_kernel / bn_one_bwd_kernel: persistent grid, per 64-channel
+    group the last chunk to arrive combines, the others wait on the group's flag) against the three dependent launches it replaces
+    (dir_bn_one_launch_enable(0)): the same chunk partials combined in the same order -> y, running statistics, saved statistics, g x, g w, g b
+    equal bit for bit; with ReLU, with a residual, without g x; again on a second stream and from a replayed HIP graph (the sync words are left
+    clean by every launch); and no workgroup ever gave up waiting (dir_bn_one_launch_status)."""
+    from dir_amd import _capi
+    L = _capi.lib()
+    rng = np.random.RandomState(R + C)
+    x = dev((rng.normal(0, 1, (R, C)) * rng.uniform(0.5, 3, C) + rng.normal(0, 2, C)).astype(np.float32))
+    w, b, gy = dev(rng.normal(0, 1, C).astype(np.float32)), dev(rng.normal(0, 0.5, C).astype(np.float32)), dev(rng.normal(0, 1, (R, C)).astype(np.float32))
+    res = dev(rng.normal(0, 1, (R, C)).astype(np.float32))
+
+    def run(relu, residual, need_gx=True):
+        rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        y, st = O.bn_train_fwd(x, w, b, rm, rv, relu=relu, residual=residual)
+        gx, gw, gb = O.bn_train_bwd(gy, x, w, st, need_gx=need_gx, b=b, relu=relu and residual is None)
+        return [y, st[0], st[1], rm, rv, gw, gb] + ([gx] if need_gx else [])
+    cases = [(False, None, True), (True, None, True), (True, res, True), (False, None, False)]
+    was = L.dir_bn_one_launch_enable(0)
+    try:
+        want = [run(*c) for c in cases]
+        L.dir_bn_one_launch_enable(1)
+        got = [run(*c) for c in cases]
+        again = [run(*c) for c in cases]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            on_side = [run(*c) for c in cases]
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            captured = [run(*c) for c in cases]
+        for t in (t for c in captured for t in c):
+            t.zero_()
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+    finally:
+        L.dir_bn_one_launch_enable(was)
+    for name, other in (('one launch', got), ('second call', again), ('side stream', on_side), ('graph replay', captured)):
+        for c, ws, gs in zip(cases, want, other):
+            for i, (a_, b_) in enumerate(zip(ws, gs)):
+                assert torch.equal(a_, b_), (name, c[0], c[1] is not None, c[2], i, float((a_ - b_).abs().max()))
+    assert L.dir_bn_one_launch_status() == 0
+
+
 def test_axpy_multi_matches_per_tensor_axpy():
     """dir_axpy_multi_f32 (work split by elements: one huge tensor beside hundreds of tiny ones, odd lengths, unaligned views)"""
     g = torch.Generator(device='cuda').manual_seed(5)

@@ -9,12 +9,12 @@ out=$R/gpurun_out/$tag
 mkdir -p $out
 # the per-layer kernel choice is made once OUTSIDE the profiler and re-used, so the traces hold only the timed configuration
 rm -f /tmp/dir_autotune.json
-python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-train --no-proj-feat-variant --no-power --no-time-table-pass --force-table --no-config5 --no-ceiling-probe --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
-cmd="python $R/bench.py --inflight 1 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-train --no-proj-feat-variant --no-power --no-time-table-pass --force-table --no-config5 --no-ceiling-probe --dump-conv --autotune-cache /tmp/dir_autotune.json"
+python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-train --no-proj-feat-variant --no-power --no-time-table-pass --force-table --no-config5 --no-ceiling-probe --no-other-half --no-pgcn --autotune-cache /tmp/dir_autotune.json > $out/tune.log 2>&1
+cmd="python $R/bench.py --inflight 1 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-train --no-proj-feat-variant --no-power --no-time-table-pass --force-table --no-config5 --no-ceiling-probe --no-other-half --no-pgcn --dump-conv --autotune-cache /tmp/dir_autotune.json"
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $out/trace -o r -- $cmd > $out/trace.log 2>&1 )
 # counter passes: the same kernels launched eagerly (--no-graph) -- under --pmc the HIP-graph RNG bookkeeping kernel of torch.cuda.graph
 # segfaulted inside the profiler on this stack (r02); counters are per dispatch, so graph or no graph makes no difference to them
-pcmd="python $R/bench.py --no-graph --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-train --no-proj-feat-variant --no-power --no-time-table-pass --force-table --no-config5 --no-ceiling-probe --autotune-cache /tmp/dir_autotune.json"
+pcmd="python $R/bench.py --no-graph --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --no-fp32-mode --no-train --no-proj-feat-variant --no-power --no-time-table-pass --force-table --no-config5 --no-ceiling-probe --no-other-half --no-pgcn --autotune-cache /tmp/dir_autotune.json"
 ( cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $out/pmcF -o r -- $pcmd > $out/pmcF.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $out/pmcW -o r -- $pcmd > $out/pmcW.log 2>&1 )
 ( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $out/pmcS -o r -- $pcmd > $out/pmcS.log 2>&1 )
