@@ -539,6 +539,10 @@ def main():
                       'steps': args.steps, 'regions': 3,
                       'note': 'DirEngine(dtype=%s): feature maps and convolution weights stored as %s, the same data path / kernel table / streams as the '
                               'headline; regions alternate with the headline pipeline' % (str(odt)[6:], oname)}
+        if roof is not None:
+            # the same per-launch pass as `roofline` (one forward in flight, the timed kernel table), so the two storage kinds compare like for like
+            ro_ = live_roofline(engo, img, oname, do / args.steps * 1e3, with_traffic=False)
+            other_half['roofline'] = {k: ro_[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_mfma', 'frac_hbm', 'avg_launch_us', 'all_conv_ms_per_step') if k in ro_}
         del pipeo, engo
 
     # ---- the SemGCN gather path alone (north_star: ">= 60 % of HBM peak on the SemGCN gather at batch 64"): the P-GCN stack of both

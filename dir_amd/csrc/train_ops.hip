@@ -725,11 +725,44 @@ __global__ __launch_bounds__(256) void bn_partial4_kernel(const float* x, const 
         if (mode == 2) *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
     }
 }
+// Loads and stores that are coherent across the GPU's eight L2s WITHOUT a fence (agent-scope monotonic: `sc1` on gfx950): what workgroups of one
+// launch hand each other (the one-launch BatchNorm below).  CO = false: plain accesses.
+template <bool CO> __device__ __forceinline__ float ld_co(const float* p) {
+    if constexpr (CO) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool CO> __device__ __forceinline__ void st_co(float* p, float v) {
+    if constexpr (CO) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool CO> __device__ __forceinline__ float4 ld_co4(const float* p) {
+    if constexpr (CO) return make_float4(ld_co<true>(p), ld_co<true>(p + 1), ld_co<true>(p + 2), ld_co<true>(p + 3));
+    else return *reinterpret_cast<const float4*>(p);
+}
+template <bool CO> __device__ __forceinline__ void st_co4(float* p, const float4 v) {
+    if constexpr (CO) { st_co<true>(p, v.x); st_co<true>(p + 1, v.y); st_co<true>(p + 2, v.z); st_co<true>(p + 3, v.w); }
+    else *reinterpret_cast<float4*>(p) = v;
+}
+// dir::sum_in_order (the same order, the same bits) over coherent loads
+template <bool CO> __device__ __forceinline__ float sum_in_order_co(const float* p, long long stride, int n, float s) {
+    if constexpr (!CO) return dir::sum_in_order(p, stride, n, s);
+    int c = 0;
+    for (; c + 8 <= n; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ld_co<true>(p + (long long)(c + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < n; ++c) s += ld_co<true>(p + (long long)c * stride);
+    return s;
+}
 // sums of the chunk partials: a workgroup = 16 channels x 16 lanes (lane l adds chunks l, l + 16, ... in order; lanes combined in lane order)
+template <bool CO = false>
 __device__ __forceinline__ float chunk_sum16(const float* p, int chunks, int C, int c, float (&s)[16][17]) {
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     float a = 0.f;
-    if (c < C && rl < chunks) a = dir::sum_in_order(p + (long long)rl * C + c, 16ll * C, (chunks - rl + 15) / 16, a);
+    if (c < C && rl < chunks) a = sum_in_order_co<CO>(p + (long long)rl * C + c, 16ll * C, (chunks - rl + 15) / 16, a);
     s[rl][cl] = a;
     __syncthreads();
     float t = 0.f;
@@ -790,6 +823,7 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int n) {
 // ---- 16-byte versions for C % 4 == 0 (every BatchNorm2d of the path).  Forward statistics in ONE pass over HBM: a workgroup (64 channels x
 // one 256-row chunk) forms the chunk's column sums, then the squared deviations from the CHUNK mean on a second read that hits L2 (a chunk
 // is 64 KB); the finalise kernel combines the chunks exactly: var = sum_k [M2_k + n_k (mean_k - mean)^2] / R, in chunk order.
+template <bool CO = false>
 __device__ __forceinline__ void bn_stats4_tile(const float* x, float* p1, float* p2, int R, int C, int ld, int cg, int ch, float4 (&s1)[16][16]) {
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = cg * 64 + cq * 4;
     const int r0 = ch * BN_CHUNK_ROWS, r1 = min(R, r0 + BN_CHUNK_ROWS);
@@ -837,8 +871,8 @@ __device__ __forceinline__ void bn_stats4_tile(const float* x, float* p1, float*
     if (rl == 0 && on) {
         float4 u = s1[0][cq];
         for (int l = 1; l < 16; ++l) { const float4 q = s1[l][cq]; u.x += q.x; u.y += q.y; u.z += q.z; u.w += q.w; }
-        *reinterpret_cast<float4*>(p1 + (long long)ch * C + c) = t;
-        *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
+        st_co4<CO>(p1 + (long long)ch * C + c, t);
+        st_co4<CO>(p2 + (long long)ch * C + c, u);
     }
 }
 __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p1, float* p2, int R, int C, int ld) {
@@ -846,17 +880,18 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p
     bn_stats4_tile(x, p1, p2, R, C, ld, blockIdx.x, blockIdx.y, s1);
 }
 // the statistics of 16 channels (c16 = first channel / 16) from the chunk partials
+template <bool CO = false>
 __device__ __forceinline__ void bn_stats_combine16(const float* p1, const float* p2, float* save_mean, float* save_rstd, float* running_mean,
                                                    float* running_var, int chunks, int R, int C, float eps, float momentum, int c16, float (&s)[16][17]) {
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = c16 * 16 + cl;
-    const float mu = chunk_sum16(p1, chunks, C, c, s) / R;
+    const float mu = chunk_sum16<CO>(p1, chunks, C, c, s) / R;
     __syncthreads();
     float a = 0.f;
     if (c < C)
         for (int k = rl; k < chunks; k += 16) {
             const int nk = min(BN_CHUNK_ROWS, R - k * BN_CHUNK_ROWS);
-            const float d = p1[(long long)k * C + c] / nk - mu;
-            a += fmaf((float)nk * d, d, p2[(long long)k * C + c]);
+            const float d = ld_co<CO>(p1 + (long long)k * C + c) / nk - mu;
+            a += fmaf((float)nk * d, d, ld_co<CO>(p2 + (long long)k * C + c));
         }
     s[rl][cl] = a;
     __syncthreads();
@@ -864,7 +899,7 @@ __device__ __forceinline__ void bn_stats_combine16(const float* p1, const float*
     float q = 0.f;
     for (int l = 0; l < 16; ++l) q += s[l][cl];
     const float var = q / R;
-    save_mean[c] = mu; save_rstd[c] = 1.f / sqrtf(var + eps);
+    st_co<CO>(save_mean + c, mu); st_co<CO>(save_rstd + c, 1.f / sqrtf(var + eps));
     if (running_mean) {
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (R > 1 ? q / (R - 1) : var);
@@ -954,6 +989,7 @@ __global__ __launch_bounds__(256) void bn_apply_fwd4_kernel(const float* x, cons
     }
 }
 // backward partial sums (the vec4 form of bn_partial_kernel's mode 2) with the ReLU mask re-computed from x
+template <bool CO = false>
 __device__ __forceinline__ void bn_bwd_partial4_tile(const float* x, const float* gy, const float* w, const float* b, const float* mu, const float* rs,
                                                      float* p1, float* p2, int R, int C, int ld, int relu, int cg, int ch, float4 (&s1)[16][16],
                                                      float4 (&s2)[16][16]) {
@@ -998,8 +1034,8 @@ __device__ __forceinline__ void bn_bwd_partial4_tile(const float* x, const float
             t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
             u.x += z.x; u.y += z.y; u.z += z.z; u.w += z.w;
         }
-        *reinterpret_cast<float4*>(p1 + (long long)ch * C + c) = t;
-        *reinterpret_cast<float4*>(p2 + (long long)ch * C + c) = u;
+        st_co4<CO>(p1 + (long long)ch * C + c, t);
+        st_co4<CO>(p2 + (long long)ch * C + c, u);
     }
 }
 __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, const float* gy, const float* w, const float* b, const float* mu, const float* rs,
@@ -1008,14 +1044,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial4_kernel(const float* x, co
     bn_bwd_partial4_tile(x, gy, w, b, mu, rs, p1, p2, R, C, ld, relu, blockIdx.x, blockIdx.y, s1, s2);
 }
 // both column sums of the backward pass in one launch: t1 = g b, t2 = g w (also kept for the apply kernel)
+template <bool CO = false>
 __device__ __forceinline__ void bn_bwd_combine16(const float* p1, const float* p2, float* t1, float* t2, float* gb, float* gw, int chunks, int C, int c16,
                                                  float (&s)[16][17]) {
     const int c = c16 * 16 + (threadIdx.x & 15);
-    const float a = chunk_sum16(p1, chunks, C, c, s);
+    const float a = chunk_sum16<CO>(p1, chunks, C, c, s);
     __syncthreads();
-    const float b = chunk_sum16(p2, chunks, C, c, s);
+    const float b = chunk_sum16<CO>(p2, chunks, C, c, s);
     if ((threadIdx.x >> 4) != 0 || c >= C) return;
-    t1[c] = a; t2[c] = b;
+    st_co<CO>(t1 + c, a); st_co<CO>(t2 + c, b);
     if (gb) gb[c] = a;
     if (gw) gw[c] = b;
 }
@@ -1064,7 +1101,16 @@ __global__ __launch_bounds__(256) void bn_apply_bwd4_kernel(const float* gy, con
 // at the group's counter (in chunk order whatever the arrival order: the same bits as bn_stats_combine_kernel), the others wait on the
 // group's flag -- NOT on a grid-wide barrier: a 64-channel group is ready as soon as its own chunks are -- and then normalise the tiles they read.
 // words: [arrive | flag | depart][BN_ONE_GROUPS] + an error word, zero before the launch and zero again after it (the last tile to leave a
-// group clears it), owned by the library per stream (bn_one_words).  Visibility across the 8 XCDs' L2s: agent-scope release / acquire fences.
+// group clears it), owned by the library per stream (bn_one_words).  Visibility across the 8 XCDs' L2s: everything workgroups hand each other
+// (chunk partials, the group's statistics, the words) moves through agent-scope monotonic loads / stores (`sc1`: ld_co / st_co) ordered by
+// s_waitcnt vmcnt(0) -- NOT through release / acquire fences: a fence writes back / invalidates the XCD's whole L2, and one per tile made the
+// first version of this kernel a third SLOWER than the three launches (0.041 against 0.031 s per step).
+// MEASURED (MI355X, 32 images, profiles/r05_bn_one_launch_ab.txt): the same bits as the three launches, 220 launches instead of 660 per step -- and
+// 0.0325 s per step against 0.0315 s.  At this batch a launch boundary inside a busy stream costs ~1 us (the next dispatch is staged while the
+// previous kernel drains), less than what the one launch loses: every workgroup of a 64-channel group idles while ONE workgroup combines the
+// group's chunks (the combine kernel spreads that over C / 16 workgroups), and the grid is 3/4 of what fits.  So it is OFF by default
+// (DIR_BN_ONE_LAUNCH=1 / dir_bn_one_launch_enable(1) turns it on); what BatchNorm costs the step is its 6 passes over the feature maps, which only
+// the producing / consuming convolutions can absorb.
 constexpr int BN_ONE_GROUPS = 256, BN_ONE_WORDS = 3 * BN_ONE_GROUPS + 4;
 struct BnOne {
     const float *x, *gy, *w, *b, *res;
@@ -1073,10 +1119,12 @@ struct BnOne {
     int R, C, ld, relu, chunks, cgroups;
     float eps, momentum;
 };
-__device__ __forceinline__ int bn_one_arrive(int* counter) {          // every writer fenced its own stores already
+__device__ __forceinline__ void bn_one_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ int bn_one_arrive(int* counter) {
     __shared__ int old;
-    __syncthreads();
-    if (threadIdx.x == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    bn_one_stores_done();              // this thread's coherent stores have reached memory
+    __syncthreads();                   // ... every thread's
+    if (threadIdx.x == 0) old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     return old;
 }
@@ -1091,8 +1139,7 @@ __device__ __forceinline__ void bn_one_wait(int* flag, int* err) {
             }
         }
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                 // the statistics another XCD wrote are read from memory, not from this XCD's L2
+    __syncthreads();                   // the statistics are then read with ld_co (from memory, not from this XCD's L2)
 }
 __device__ __forceinline__ void bn_one_leave(int* depart, int* flag, int chunks) {
     __syncthreads();
@@ -1109,19 +1156,17 @@ __global__ __launch_bounds__(256) void bn_one_fwd_kernel(const BnOne a) {
     for (int t = blockIdx.x; t < ntile; t += G) {
         const int cg = t % a.cgroups, ch = t / a.cgroups;
         __syncthreads();
-        bn_stats4_tile(a.x, a.p1, a.p2, a.R, a.C, a.ld, cg, ch, s1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bn_stats4_tile<true>(a.x, a.p1, a.p2, a.R, a.C, a.ld, cg, ch, s1);
         if (bn_one_arrive(arrive + cg) != a.chunks - 1) continue;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                       // the last tile of the group: every chunk partial of these 64 channels is in memory
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {                                  // the last tile of the group: every chunk partial of these 64 channels is in memory
             __syncthreads();
-            bn_stats_combine16(a.p1, a.p2, a.save_mean, a.save_rstd, a.running_mean, a.running_var, a.chunks, a.R, a.C, a.eps, a.momentum, cg * 4 + j, s);
+            bn_stats_combine16<true>(a.p1, a.p2, a.save_mean, a.save_rstd, a.running_mean, a.running_var, a.chunks, a.R, a.C, a.eps, a.momentum, cg * 4 + j, s);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bn_one_stores_done();
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_store(arrive + cg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(flag + cg, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag + cg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -1130,7 +1175,7 @@ __global__ __launch_bounds__(256) void bn_one_fwd_kernel(const BnOne a) {
         const int cg = t % a.cgroups, ch = t / a.cgroups, c = cg * 64 + cq * 4;
         bn_one_wait(flag + cg, err);
         if (c < a.C) {
-            const float4 m = *reinterpret_cast<const float4*>(a.save_mean + c), k = *reinterpret_cast<const float4*>(a.save_rstd + c);
+            const float4 m = ld_co4<true>(a.save_mean + c), k = ld_co4<true>(a.save_rstd + c);
             const float4 g = a.w ? *reinterpret_cast<const float4*>(a.w + c) : one, be = a.b ? *reinterpret_cast<const float4*>(a.b + c) : zero;
             const int r1 = min(a.R, (ch + 1) * BN_CHUNK_ROWS);
             auto put = [&](int r, const float4 v, const float4 q) {
@@ -1166,19 +1211,17 @@ __global__ __launch_bounds__(256) void bn_one_bwd_kernel(const BnOne a) {
     for (int t = blockIdx.x; t < ntile; t += G) {
         const int cg = t % a.cgroups, ch = t / a.cgroups;
         __syncthreads();
-        bn_bwd_partial4_tile(a.x, a.gy, a.w, a.b, a.save_mean, a.save_rstd, a.p1, a.p2, a.R, a.C, a.ld, a.relu, cg, ch, s1, s2);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bn_bwd_partial4_tile<true>(a.x, a.gy, a.w, a.b, a.save_mean, a.save_rstd, a.p1, a.p2, a.R, a.C, a.ld, a.relu, cg, ch, s1, s2);
         if (bn_one_arrive(arrive + cg) != a.chunks - 1) continue;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         for (int j = 0; j < 4; ++j) {
             __syncthreads();
-            bn_bwd_combine16(a.p1, a.p2, a.t1, a.t2, a.gb, a.gw, a.chunks, a.C, cg * 4 + j, s);
+            bn_bwd_combine16<true>(a.p1, a.p2, a.t1, a.t2, a.gb, a.gw, a.chunks, a.C, cg * 4 + j, s);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        bn_one_stores_done();
         __syncthreads();
         if (threadIdx.x == 0) {
             __hip_atomic_store(arrive + cg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.gx) __hip_atomic_store(flag + cg, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.gx) __hip_atomic_store(flag + cg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (!a.gx) return;
@@ -1191,7 +1234,7 @@ __global__ __launch_bounds__(256) void bn_one_bwd_kernel(const BnOne a) {
         if (c < a.C) {
             const float4 m = *reinterpret_cast<const float4*>(a.save_mean + c), k = *reinterpret_cast<const float4*>(a.save_rstd + c);
             const float4 g = a.w ? *reinterpret_cast<const float4*>(a.w + c) : one, be = a.b ? *reinterpret_cast<const float4*>(a.b + c) : zero;
-            const float4 a1 = *reinterpret_cast<const float4*>(a.t1 + c), a2 = *reinterpret_cast<const float4*>(a.t2 + c);
+            const float4 a1 = ld_co4<true>(a.t1 + c), a2 = ld_co4<true>(a.t2 + c);
             const float4 m1 = make_float4(a1.x / nn, a1.y / nn, a1.z / nn, a1.w / nn), m2 = make_float4(a2.x / nn, a2.y / nn, a2.z / nn, a2.w / nn);
             const int r1 = min(a.R, (ch + 1) * BN_CHUNK_ROWS);
             auto put = [&](int r, const float4 v, float4 q) {             // the expressions of bn_apply_bwd4_kernel
@@ -1838,10 +1881,10 @@ static bool bn_vec4(int C, int ld, std::initializer_list<const void*> ps) {
 constexpr int BN_ONE_POOL = 16, BN_ONE_DEVICES = 16;
 struct BnOnePool { int* base = nullptr; int used = 0; hipStream_t streams[BN_ONE_POOL]; };
 static std::mutex bn_one_mu;
-static int bn_one_switch = -1;           // -1: not read yet (DIR_BN_ONE_LAUNCH, default on) | 0 | 1; dir_bn_one_launch_enable sets it
+static int bn_one_switch = -1;           // -1: not read yet (DIR_BN_ONE_LAUNCH, default OFF: measured slower, below) | 0 | 1; dir_bn_one_launch_enable sets it
 static bool bn_one_enabled() {
     std::lock_guard<std::mutex> lock(bn_one_mu);
-    if (bn_one_switch < 0) { const char* e = getenv("DIR_BN_ONE_LAUNCH"); bn_one_switch = !(e && e[0] == '0'); }
+    if (bn_one_switch < 0) { const char* e = getenv("DIR_BN_ONE_LAUNCH"); bn_one_switch = e && e[0] == '1'; }
     return bn_one_switch != 0;
 }
 static BnOnePool bn_one_pools[BN_ONE_DEVICES];

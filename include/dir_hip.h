@@ -183,13 +183,14 @@ int dir_attention_backward(const float* qkv, const float* probs, const float* go
  * thread per channel walks the rows in order, no workspace.  Larger R (BatchNorm2d over feature maps): the column reductions are cut
  * into 256-row chunks whose partials are combined in chunk order (deterministic; the variance as sum_k [M2_k + n_k (mean_k - mean)^2] / R,
  * one pass over HBM); workspace of dir_bn_train_workspace_bytes(R, C).
- * R > 512, C % 4 == 0 (round 5): ONE launch each way instead of three -- a persistent grid (every workgroup resident) walks the same chunks; the
- * workgroup whose chunk reaches a 64-channel group's counter last combines that group's partials (in chunk order: the same bits as the three
- * launches), the others wait on the group's flag and then normalise the chunks they read.  The counters live in library-owned device words, one
- * block per stream (allocated at the first call outside a stream capture; no block -> the three launches run), and are left zero by every
- * launch.  A workgroup that waits longer than 4 s gives up and raises the error word dir_bn_one_launch_status() reports (0 | 1; it synchronises
- * the device and clears the words; the step never calls it).  DIR_BN_ONE_LAUNCH=0 in the environment, or dir_bn_one_launch_enable(0) (returns the
- * previous setting), selects the three launches (A/B; the results are the same bits). */
+ * R > 512, C % 4 == 0 (round 5), OPTIONAL: one launch each way instead of three -- a persistent grid (every workgroup resident) walks the same
+ * chunks; the workgroup whose chunk reaches a 64-channel group's counter last combines that group's partials (in chunk order: the same bits as
+ * the three launches), the others wait on the group's flag and then normalise the chunks they read.  The counters live in library-owned device
+ * words, one block per stream (allocated at the first call outside a stream capture; no block -> the three launches run), and are left zero by
+ * every launch.  A workgroup that waits longer than 4 s gives up and raises the error word dir_bn_one_launch_status() reports (0 | 1; it
+ * synchronises the device and clears the words; the step never calls it).  OFF by default: measured 3 % slower per training step than the three
+ * launches at 32 images (profiles/r05_bn_one_launch_ab.txt); DIR_BN_ONE_LAUNCH=1 in the environment or dir_bn_one_launch_enable(1) (returns the
+ * previous setting) turns it on. */
 long long dir_bn_train_workspace_bytes(int R, int C);
 int dir_bn_one_launch_status(void);
 int dir_bn_one_launch_enable(int on);

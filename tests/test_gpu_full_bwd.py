@@ -219,8 +219,12 @@ def test_mirror_module_runs_the_reference_training_lines(golden):
     assert torch.isfinite(outs_eval[2]['pd_mesh_xyz_left']).all()
 
 
-def test_full_training_step_gradient_trained_like_weights(golden):
-    """VERDICT r2 item 5 asked for the whole-step gradient within 1e-4 of each tensor's maximum on well-conditioned parameters.  Measured
+def test_full_training_step_gradient_batch_statistics_sanity_band_not_a_pin(golden):
+    """NOT A PIN: a sanity band around the reference's own irreproducibility.  The whole-step gradient is pinned with frozen
+    statistics by G20e (the next test: all 540 non-zero tensors < 1e-3, median ~1e-6) and the BatchNorm-train backward by its component goldens
+    (G13-G19 at 1e-5); what is left for THIS test is the end-to-end composition with batch statistics, which no fp32 implementation -- the
+    reference's included -- reproduces tighter than a few percent:
+    VERDICT r2 item 5 asked for the whole-step gradient within 1e-4 of each tensor's maximum on well-conditioned parameters.  Measured
     instead (tools/ref_grad_sensitivity.py, the generator of this fixture): the REFERENCE's own fp32 gradient is reproducible only to
     2e-2 .. 4e-2 under a change of summation order (8 threads vs 1 thread of the same kernels; bit-identical at equal thread counts; 4e-5 with
     the BatchNorm layers in eval mode; the same at B = 8) -- the training-mode BatchNorm backward of this 70-layer network amplifies fp32
@@ -477,14 +481,16 @@ def test_graph_captured_train_step_equals_the_eager_one():
 
 def test_graph_captured_train_step_survives_a_recalibration(monkeypatch):
     """the call after a recalibration captures again, and the eager step before it has re-measured every operand scale.  With
-    the batch's magnitude changed between the captures the power-of-two scales of many call sites move, so the packed weight table has pending
+    the BatchNorm gains of the backbone's first convolutions multiplied by 8 between the captures (the image's own magnitude would not do: batch
+    statistics normalise it away after the stem) the power-of-two scales of the convolutions behind them move, so the packed weight table has pending
     scale changes when the second capture starts: they must reach the device OUTSIDE the capture (WeightPack.sync_table; an upload inside it
-    raises).  DIR_TRAIN_RECALIBRATE = 2 here: calls 1-2 eager, 3 captures, 4 replays, 5 eager (recalibrates on the brighter batch), 6 captures
-    again, 7 replays.  The losses follow an all-eager run of the same batches to f16x3 rounding (the two runs recalibrate on different steps)."""
+    raises).  DIR_TRAIN_RECALIBRATE = 3 here: calls 1-2 eager, 3 captures and replays, 4-6 replay, 7 eager (recalibrates, on the grown gains),
+    8 captures again, 9 replays.  The losses follow an all-eager run of the same batches to f16x3 rounding (the two runs recalibrate on
+    different steps)."""
     from conftest import loss_case
     from dir_amd.optim import FlatAdamW
     from dir_amd.train import step as TSTEP, conv as TC
-    monkeypatch.setattr(TC, 'RECALIBRATE', 2)
+    monkeypatch.setattr(TC, 'RECALIBRATE', 3)
     g8 = dict(np.load(os.path.join(HERE, 'golden', 'g8_loss.npz')))
     with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
@@ -497,7 +503,13 @@ def test_graph_captured_train_step_survives_a_recalibration(monkeypatch):
     target.update(seg=dv(gt_seg), dense=dv(gt_dense))
     meta = {k: dv(v) for k, v in gt.items() if 'center' in k}
     fc = tuple(dv(f.astype(np.int64)) for f in faces)
-    batches = [img] * 4 + [img * 6.0] * 3                                  # x 6: the first convolution's operand scale moves by 4 or 8
+    batches = [img] * 9
+
+    def grow(params):                                                      # before call 7: bn1's output, the operand of conv2, x 8
+        with torch.no_grad():
+            for k, v in params.items():
+                if k.startswith('backbone.layer') and k.endswith(('bn1.weight', 'bn1.bias')):
+                    v.mul_(8.0)
 
     def make():
         params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
@@ -510,18 +522,22 @@ def test_graph_captured_train_step_survives_a_recalibration(monkeypatch):
     graphs, got, uploads = [], [], []
     upload = TC.WeightPack._upload
     monkeypatch.setattr(TC.WeightPack, '_upload', lambda self: (uploads.append(len(got)), upload(self))[1])
-    for x in batches:
+    for i, x in enumerate(batches):
+        if i == 6:
+            grow(p2)
         loss = gs(x, target, meta)
         got.append(sum(float(v) for v in loss.values()))
         graphs.append(gs.graph)
     monkeypatch.setattr(TC.WeightPack, '_upload', upload)
-    assert 5 in uploads, uploads                   # the scales the eager call 5 measured were uploaded by call 6 (before its capture: inside, _upload raises)
-    assert graphs[2] is not None and graphs[4] is None and graphs[5] is not None and graphs[5] is not graphs[2]
+    assert 7 in uploads, uploads                   # the scales the eager call 7 measured were uploaded by call 8 (before its capture: inside, _upload raises)
+    assert graphs[2] is not None and graphs[6] is None and graphs[7] is not None and graphs[7] is not graphs[2]
     assert gs.since_capture == 2 and all(np.isfinite(got)), got
     p1, b1, o1 = make()
     TC.reset_scales()
     want = []
-    for x in batches:
+    for i, x in enumerate(batches):
+        if i == 6:
+            grow(p1)
         loss = TSTEP.train_step(p1, b1, x, target, meta, fc, o1, overlap_allreduce=False)
         want.append(sum(float(v) for v in loss.values()))
     np.testing.assert_allclose(got, want, rtol=2e-4)
