@@ -114,7 +114,7 @@ class EvalOutputs(C.Structure):
                                           'root_err')]
 
 
-ABI_VERSION = 36          # DIR_ABI_VERSION (include/dir_hip.h)
+ABI_VERSION = 37          # DIR_ABI_VERSION (include/dir_hip.h)
 DT_F32, DT_BF16, DT_F16X3, DT_F16X1, DT_F16X3P, DT_F16X1P, DT_F16 = 0, 1, 3, 4, 5, 6, 7      # DT_F16: f16 STORAGE (round 5)
 CONV_RELU, CONV_PRE_RELU = 1, 2
 
@@ -192,6 +192,8 @@ _SIGNATURES = {
     'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
     'dir_bn_one_launch_status': (C.c_int, []),
+    'dir_upsample_nearest_add_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    'dir_upsample_nearest_backward_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_bn_one_launch_enable': (C.c_int, [_i]),
     'dir_bn_train_backward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_bn_frozen_workspace_bytes': (C.c_longlong, [_i, _i]),

@@ -886,9 +886,7 @@ class HRNetOp(object):
 def hrnet_standalone(module, x, compute_dtype=torch.float32):
     """HRNetW48.forward of the mirror module: NCHW float32 in, [c1..c4] NCHW float32 out."""
     _capi.require_cuda(x)
-    if module.training:
-        raise NotImplementedError('the HRNet backbone (no reference counterpart) is built for inference: call .eval()')
-    sd = {'b.' + k: v.detach() for k, v in module.state_dict().items()}
+    sd = {'b.' + k: v.detach() for k, v in module.state_dict().items()}      # (.train() with autograd on goes through HRNetW48._train_forward)
     op = HRNetOp(sd, 'b', compute_dtype, x.device)
     with torch.cuda.device(x.device):
         feats = op(_capi.f32c(x.detach()))

@@ -12,7 +12,8 @@
     incre       the four branch outputs (48@64^2, 96@32^2, 192@16^2, 384@8^2) -> conv1x1 bn relu to DIR's pyramid widths (256, 512, 1024, 2048)
 
 forward(x) -> [c1, c2, c3, c4] like models/backbone/resnet.py:243-255, so DIR's InitRegressor / decoder are unchanged.  The module is a
-parameter container (same convention as resnet.py here); the arithmetic is dir_amd.engine.HRNetOp on libdir_hip.so."""
+parameter container (same convention as resnet.py here); the arithmetic is dir_amd.engine.HRNetOp on libdir_hip.so in .eval() mode and
+dir_amd/train/hrnet.py (training kernels behind one autograd node) in .train() mode."""
 import torch
 import torch.nn as nn
 
@@ -71,7 +72,37 @@ class HRNetW48(nn.Module):
 
     def forward(self, x, compute_dtype=torch.float32):
         from ...engine import hrnet_standalone
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(x)
         return hrnet_standalone(self, x, compute_dtype)
+
+    def _train_forward(self, x):
+        """.train(): batch-statistics BatchNorm and autograd -- dir_amd/train/hrnet.py (hrnet_forward / hrnet_backward, the backbone part of the
+        whole-network training step of a DIR built on this backbone) behind ONE autograd node; returns [c1, c2, c3, c4] NCHW."""
+        from ... import _capi
+        from ...train import autograd as AG
+        from ...train import conv as TC
+        from ...train import hrnet as TH
+        _capi.require_cuda(x)
+        params = {'backbone.' + k: p for k, p in self.named_parameters()}
+        buffers = {'backbone.' + k: b for k, b in self.named_buffers() if 'num_batches_tracked' not in k}
+        for m in self.modules():
+            if isinstance(m, torch.nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+
+        def fwd(P, img):
+            TC.begin_step(None)
+            ctx = {}
+            feats = TH.hrnet_forward(P, _capi.f32c(img), ctx)
+            return tuple(f.permute(0, 3, 1, 2) for f in feats), ctx
+
+        def bwd(P, ctx, *g_feats):
+            G = {}
+            TH.hrnet_backward(P, ctx, [None if g is None else g.permute(0, 2, 3, 1).contiguous() for g in g_feats], G)
+            TC.end_step()
+            return (None,), G              # the image is data
+        with torch.cuda.device(x.device):
+            return list(AG.run(fwd, bwd, [x], params, buffers))
 
 
 def hrnet_w48():

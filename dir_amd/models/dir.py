@@ -172,7 +172,7 @@ class DIR(nn.Module):
         self.root_joint = root_joint
         self.compute_dtype = compute_dtype
         assert backbone in ('resnet50', 'hrnet_w48')
-        if backbone == 'hrnet_w48':       # BASELINE config 5; no reference counterpart (dir_amd/models/backbone/hrnet.py); inference only
+        if backbone == 'hrnet_w48':       # BASELINE config 5; no reference counterpart (dir_amd/models/backbone/hrnet.py)
             from .backbone.hrnet import hrnet_w48
             self.backbone = hrnet_w48()
         else:
@@ -263,10 +263,7 @@ class DIR(nn.Module):
 
     def forward(self, input, target, meta_info):
         if self.training:
-            if self.backbone_name != 'resnet50':
-                raise NotImplementedError('the HRNet backbone (no reference counterpart) is built for inference only; training covers the ResNet-50 network'
-                                          ' (with any number of extra stages)')
-            return self._forward_train(input, target, meta_info)
+            return self._forward_train(input, target, meta_info)      # either backbone (HRNet-W48 since round 5: dir_amd/train/hrnet.py)
         x = input['img'].cuda()                                   # the reference moves the input itself (models/dir.py:514)
         eng = self.engine()
         with torch.cuda.device(x.device), torch.no_grad():

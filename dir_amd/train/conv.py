@@ -184,8 +184,8 @@ _pack = None          # the WeightPack bound for the running step (begin_step ..
 
 def conv_weights(P):
     """the convolution weights of a parameter dict that run through this module: every 4-D `.weight` except the 3-channel stem's"""
-    return [v for k, v in P.items() if k.endswith('.weight') and torch.is_tensor(v) and v.dim() == 4 and v.shape[1] % 4 == 0
-            and v.shape[2] == v.shape[3] and v.shape[2] in (1, 3)]
+    return [v for k, v in P.items() if k.endswith('.weight') and torch.is_tensor(v) and v.dim() == 4 and v.shape[1] % 32 == 0
+            and v.shape[2] == v.shape[3] and v.shape[2] in (1, 3)]          # (Cin % 32: whole reduction slabs; HRNet's 48-wide convolutions pad per call)
 
 
 def begin_step(owner=None, P=None):

@@ -18,6 +18,7 @@ import torch
 
 from . import blocks as TB
 from . import conv as TC
+from . import hrnet as TH
 from . import ops as O
 from . import spatial as SP
 from . import stage as TS
@@ -146,6 +147,8 @@ def backbone_forward(P, img, ctx, pre='backbone.'):
     """ResNet.forward in training form (models/backbone/resnet.py:243-255): stem conv + bn1 + ReLU + max-pool + the 16 bottlenecks.
     -> [c1, c2, c3, c4] NHWC fp32; ctx receives what backbone_backward needs.  Used by the whole-network step below and by the stand-alone
     mirror module in .train() mode (dir_amd/models/backbone/resnet.py)."""
+    if TH.is_hrnet(P, pre):                                # BASELINE config 5's backbone (no reference counterpart): dir_amd/train/hrnet.py
+        return TH.hrnet_forward(P, img, ctx, pre)
     Pb = P if pre == 'backbone.' else {'backbone.' + k[len(pre):]: v for k, v in P.items() if k.startswith(pre)}
     h = _stem_forward(Pb, img)
     a, ctx['bn1'] = TB.bn_fwd(Pb, 'backbone.bn1.', h, relu=True)
@@ -165,6 +168,8 @@ def backbone_forward(P, img, ctx, pre='backbone.'):
 def backbone_backward(P, ctx, g_feats, G, flush=None, pre='backbone.'):
     """g_feats: gradients of [c1, c2, c3, c4] (None where a feature has no outside consumer).  Fills G['backbone.*'] (conv1 has no input gradient:
     the image is data)"""
+    if 'hr' in ctx:
+        return TH.hrnet_backward(P, ctx, g_feats, G, flush, pre)
     Pb = P if pre == 'backbone.' else {'backbone.' + k[len(pre):]: v for k, v in P.items() if k.startswith(pre)}
     if flush is None:
         flush = lambda g_: None      # noqa: E731

@@ -34,8 +34,12 @@ def inactive_parameters(named_params):
       * `*.interaction.STEblocks.0.*`         -- the first STE block, skipped by the loop (transformer/mixSTE.py:197).
     PGraphConv's `e_0` is NOT in the list: it enters the graph through a one-entry softmax row (SemGCN/p_graph_conv.py:45-48), so torch hands
     it an identically-zero gradient tensor and AdamW still applies weight decay to it -- it stays active here too.  Works for the whole
-    state dict and for any sub-tree of it (tests, tools/bench_train.py and train_step's callers all use this one function)."""
-    return [p for k, p in named_params.items() if ('.' + k).startswith('.backbone.fc.') or '.interaction.STEblocks.0.' in '.' + k]
+    state dict and for any sub-tree of it (tests, tools/bench_train.py and train_step's callers all use this one function).
+    With the HRNet-W48 backbone (no reference counterpart) DIR reads c2, c3, c4 only: what feeds c1 alone -- `backbone.incre.0.*` and the last
+    module's `backbone.stage4.2.fuse_layers.0.*` -- has no path to the loss and is inactive too (dir_amd/train/hrnet.py forms no gradient for it)."""
+    hr_dead = ('.backbone.incre.0.', '.backbone.stage4.2.fuse_layers.0.')
+    return [p for k, p in named_params.items() if ('.' + k).startswith('.backbone.fc.') or '.interaction.STEblocks.0.' in '.' + k
+            or ('.' + k).startswith(hr_dead)]
 
 
 def token_stage_train_step(named_params, prefix, mano_tables_lr, feat_nhwc, prev, target, meta_info, faces, optimizer, coord_weight=10.0,

@@ -29,7 +29,7 @@ extern "C" {
 #define DIR_E_LAUNCH (-2)   /* hipLaunchKernel / HIP runtime error          */
 #define DIR_E_NODEVICE (-3) /* no gfx950 device visible                     */
 
-#define DIR_ABI_VERSION 36
+#define DIR_ABI_VERSION 37
 
 int dir_abi_version(void);
 const char* dir_last_error(void);
@@ -230,6 +230,11 @@ int dir_bn_sync_backward_apply(const float* gy, const float* x, const float* w, 
                                const float* sums_pooled, float* gx, int R, float rows_pooled, int C, int ld, int relu, void* stream);
 int dir_relu_forward(const float* x, float* y, long long n, void* stream);
 int dir_relu_backward(const float* gy, const float* y, float* gx, long long n, void* stream);   /* g x = y > 0 ? g y : 0 */
+/* Nearest-neighbour upsampling by a power-of-two factor in training form (the fuse layers of an HRNet module, y_i = relu(sum_j f_ij(x_j)) with
+ * f_ij = upsample(bn(conv1x1(x_j))) for j > i; no reference counterpart: dir_amd/models/backbone/hrnet.py): dst [B][h f][w f][C] += up(src [B][h][w][C]),
+ * and the backward gx [B][h][w][C] = the sum of gy over each f x f block.  NHWC fp32, C % 4 == 0, 16-byte aligned. */
+int dir_upsample_nearest_add_f32(const float* src, float* dst, int B, int h, int w, int C, int factor, void* stream);
+int dir_upsample_nearest_backward_f32(const float* gy, float* gx, int B, int h, int w, int C, int factor, void* stream);
 /* PGraphConv's adjacency (SemGCN/p_graph_conv.py:43-50): A_1 [21][21] = row-softmax of the hand-skeleton mask filled with e_1 [40]
  * (row-major nonzero order); backward: g e_1 from g z [B,21,128] (gradient of the layer's pre-BatchNorm output) and h1 = x W_1 [B,21,128]
  * (g A_1[j][k] = sum_b <g z[b][j], h1[b][k]> on the edges, then the softmax chain rule).  scratch40: 40 floats. */

@@ -529,7 +529,9 @@ def test_graph_captured_train_step_survives_a_recalibration(monkeypatch):
         got.append(sum(float(v) for v in loss.values()))
         graphs.append(gs.graph)
     monkeypatch.setattr(TC.WeightPack, '_upload', upload)
-    assert 7 in uploads, uploads                   # the scales the eager call 7 measured were uploaded by call 8 (before its capture: inside, _upload raises)
+    # the scales the eager call 7 measured reached the device table in call 7 itself (its backward pass packs again) or by call 8's sync_table(), never
+    # inside call 8's capture (there _upload raises)
+    assert 6 in uploads or 7 in uploads, uploads
     assert graphs[2] is not None and graphs[6] is None and graphs[7] is not None and graphs[7] is not graphs[2]
     assert gs.since_capture == 2 and all(np.isfinite(got)), got
     p1, b1, o1 = make()

@@ -2,7 +2,7 @@
 gradients averaged by dist.average_gradients over RCCL -- BASELINE config 3's data-parallel set-up; rank 0 prints the aggregate.)
 Time of one whole-network training step (dir_amd.train.step.train_step: training-mode forward, 42-term objective, backward, flat gradient
 bucket, AdamW) at BASELINE config 3's per-GPU batch (32), synthetic data, 1 GPU.  This path is correctness-first (not tuned); the number is a
-baseline for the rounds that tune it.  usage: bench_train.py [batch] [steps]"""
+baseline for the rounds that tune it.  usage: [BACKBONE=hrnet_w48 [EXTRA_STAGES=2]] bench_train.py [batch] [steps]"""
 import json
 import os
 import sys
@@ -23,9 +23,14 @@ torch.cuda.set_device(local)
 rank, world, _ = D.init_from_env('nccl', torch.device('cuda', local))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
-    shapes = {k: tuple(v) for k, v in json.load(f).items()}
-sd = synth.synth_state_dict(shapes, 1234)
+if os.environ.get('BACKBONE', 'resnet50') == 'hrnet_w48':        # BASELINE configs[4]: HRNet-W48 + init + 4 refinement stages (no reference counterpart)
+    from dir_amd.models.dir import DIR
+    shapes = {k: tuple(v.shape) for k, v in DIR(21, 'unused', 0, backbone='hrnet_w48', extra_stages=int(os.environ.get('EXTRA_STAGES', '2'))).state_dict().items()}
+    sd = synth.synth_state_dict(shapes, 1234, cond=True)
+else:
+    with open(os.path.join(ROOT, 'tests', 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items()}
+    sd = synth.synth_state_dict(shapes, 1234)
 is_buf = lambda k: any(t in k for t in ('running_', 'num_batches', 'mano_layer', 'img_gird', 'seg_loss.weight'))  # noqa: E731
 params = {k: torch.nn.Parameter(torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in sd.items() if not is_buf(k)}
 buffers = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if is_buf(k) and 'num_batches' not in k}
