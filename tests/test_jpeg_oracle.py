@@ -112,3 +112,50 @@ def test_file_to_record_falls_back_to_pixel_records(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / 'bad.jpg').write_bytes(b'not a jpeg at all')
         AJ.file_to_record(str(tmp_path / 'bad.jpg'), row, 256)
+
+
+def test_host_library_survives_corrupt_files():
+    """the decode workers read files they did not write: truncated, bit-flipped and spliced streams must come back as an error code (or decode to
+    something) -- never crash, never write past the record.  6 000 mutations of the committed files, in a child process (a segfault there is a
+    failure here), with guard bytes behind every record."""
+    import subprocess
+    import sys
+    host()
+    code = r'''
+import ctypes as C, os, sys, numpy as np
+sys.path.insert(0, %r)
+from dir_amd.apps import jpeg as AJ
+lib = AJ.host_lib()
+lib.dir_jpeg_decode_coefficients.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
+g = np.load(%r)
+files = [g[k].tobytes() for k in g.files if k.endswith('.jpg')]
+rng = np.random.RandomState(11)
+cap = 1 << 20
+buf = np.empty(cap + 64, np.uint8)
+codes = {}
+for it in range(6000):
+    d = bytearray(files[it %% len(files)])
+    kind = it %% 4
+    if kind == 0:                                   # truncate
+        d = d[:rng.randint(0, len(d))]
+    elif kind == 1:                                 # flip a few bytes anywhere (markers, lengths, tables, entropy data)
+        for _ in range(rng.randint(1, 6)):
+            d[rng.randint(0, len(d))] = rng.randint(0, 256)
+    elif kind == 2:                                 # corrupt the header region only: segment lengths, sampling factors, table ids
+        for _ in range(rng.randint(1, 4)):
+            d[rng.randint(2, min(len(d), 700))] = rng.randint(0, 256)
+    else:                                           # splice two files
+        o = bytearray(files[rng.randint(0, len(files))])
+        c = rng.randint(2, len(d))
+        d = d[:c] + o[rng.randint(2, len(o)):]
+    n = [cap, 4096, 600, 512, 100][rng.randint(0, 5)]      # also records that are too small
+    buf[n:n + 64] = 0xA5
+    rc = lib.dir_jpeg_decode_coefficients(bytes(d), len(d), buf.ctypes.data, n)
+    assert (buf[n:n + 64] == 0xA5).all(), ('wrote past the record', it, n, rc)
+    assert rc in (0, -1, -2, -3, -4), rc
+    codes[rc] = codes.get(rc, 0) + 1
+print('codes', sorted(codes.items()))
+''' % (ROOT, GOLD)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert 'codes' in r.stdout

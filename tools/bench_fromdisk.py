@@ -1,5 +1,5 @@
 """Sustained images/s of the evaluation loop FROM FILES (JPEG decode on the host cores -> uint8 frames -> two forwards in flight ->
-GT MANO + metrics on the GPU), on a synthetic split in the reference's layout.  python tools/bench_fromdisk.py [n_images] [bs] [workers]"""
+GT MANO + metrics on the GPU), on a synthetic split in the reference's layout.  [NSLOT=3] [DTYPE=f16|bf16] python tools/bench_fromdisk.py [n_images] [bs] [workers]"""
 import json
 import os
 import sys
@@ -35,7 +35,7 @@ if __name__ == '__main__':
         for i in range(64):
             ds.frame(i)
         print('one process decodes %.0f frames/s' % (64 / (time.perf_counter() - t0)))
-        eng = DirEngine(state, dtype=torch.bfloat16)
+        eng = DirEngine(state, dtype={'bf16': torch.bfloat16, 'f16': torch.float16}[os.environ.get('DTYPE', 'f16')])      # f16 storage: bench.py's headline mode
         mano = DS.gt_layers_from_checkpoint(state)
         jreg = {s: EV.Jr(mano[s].J_regressor) for s in ('left', 'right')}
         idx = [i % 256 for i in range(n)]
@@ -47,7 +47,7 @@ if __name__ == '__main__':
         for i in range(256):
             AJ.file_to_record(ds.img_path(i), row, 256)
         print('one process entropy-decodes %.0f files/s into coefficient records (read + Huffman)' % (256 / (time.perf_counter() - t0)))
-        for src in ('jpeg', 'jpeg-host'):
+        for src in os.environ.get('SOURCES', 'jpeg,jpeg-host').split(','):
             for w in workers:
                 m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source=src, nslot=int(os.environ.get("NSLOT", "3")))
                 print('%-9s workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (src, w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))
