@@ -143,6 +143,34 @@ def kernel_table(records, reps, dtype):
     return rows
 
 
+def four_in_flight_profile(dtype):
+    """Per-launch mean of the conv family WHILE four forwards are in flight, from the tracked rocprofv3 kernel trace of that configuration
+    (tools/profile_four_in_flight.sh -> profiles/r*_kernel_stats_four_in_flight.txt: a trace cannot be taken inside the timed run).  The kernel
+    names in that file are cut at 80 characters, so the family is matched by kernel name + storage kind; forwards = init_head_kernel launches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats_four_in_flight.txt')))
+    if not files or dtype not in ('bf16', 'f16'):
+        return None
+    fam = ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_patch_kernel', 'conv_big_kernel', 'bneck_chain_kernel', 'tail_chain_kernel', 'stream1x1_kernel')
+    calls, total, forwards = 0, 0.0, 0
+    with open(files[-1]) as f:
+        for ln in f:
+            t = ln.split()
+            if len(t) < 4 or not t[1].isdigit():
+                continue
+            is_f16 = 'f16s_t' in t[0]
+            if 'init_head_kernel' in t[0] and is_f16 == (dtype == 'f16'):
+                forwards += int(t[1])
+            if any(k in t[0] for k in fam) and is_f16 == (dtype == 'f16'):
+                calls += int(t[1])
+                total += float(t[2])
+    if not calls or not forwards:
+        return None
+    return {'source': os.path.relpath(files[-1], ROOT), 'forwards_traced': forwards, 'launches_per_forward': round(calls / forwards, 1),
+            'avg_launch_us': round(total / calls, 2), 'conv_ms_per_forward': round(total / forwards / 1e3, 3),
+            'note': 'kernel durations under contention (four graphs replaying on four streams): longer per launch than one at a time, overlapped in wall time'}
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get('WORLD_SIZE')
@@ -505,6 +533,9 @@ def main():
         roof['overlapped'] = {'achieved': round(fl_step / (ms_per_step * 1e-3) / 1e12, 2), 'unit': 'TFLOP/s', 'frac': round(fl_step / (ms_per_step * 1e-3) / PEAK[args.dtype], 4),
                               'note': "the family's algorithmic FLOPs of one step over the whole timed step (%d forwards in flight: its launches overlap "
                                       "other forwards' kernels, so per-launch durations do not add up to the step)" % args.inflight}
+        fif = four_in_flight_profile(args.dtype)
+        if fif is not None:
+            roof['overlapped']['four_in_flight_profile'] = fif
         roof['note_tables'] = ('kernel durations above: the table of the timed graphs (throughput); time_tuned_table: the same launches with '
                                'the per-layer fastest variant (what one forward at a time runs)')
         eng.load_tuning_table(img, 'gfx950_%s_b%d_throughput' % (tbl_dtype, B))

@@ -67,6 +67,9 @@ def compact(detail, detail_path='bench_detail.json'):
         ov = roof.get('overlapped')
         if ov:
             r['overlapped'] = _pick(ov, ('achieved', 'unit', 'frac'))
+            fif = ov.get('four_in_flight_profile')
+            if fif:                                          # per-launch mean under contention, from the tracked four-in-flight kernel trace
+                r['overlapped']['four_in_flight_profile'] = _pick(fif, ('source', 'avg_launch_us', 'launches_per_forward', 'conv_ms_per_forward'))
         mc = roof.get('measured_ceilings')
         if mc:
             r['measured_ceilings'] = {k: v for k, v in mc.items() if k != 'source'}
