@@ -4,8 +4,12 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/${TAG:-r05_a}
 mkdir -p $out
 cd $R
+t0=$SECONDS
 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $out/gpu_tests.txt
+echo "pytest -m gpu: $((SECONDS - t0)) s" > $out/durations.txt
+t0=$SECONDS
 python bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
+echo "python bench.py (default flags): $((SECONDS - t0)) s" >> $out/durations.txt
 tail -1 $out/bench_stdout.txt > $out/bench_line.txt
 cp bench_detail.json $out/bench_detail.json
 TOP=180 python tools/bench_train.py 32 7 2>&1 | grep -v amdgpu.ids > $out/train_step_library_calls.txt
