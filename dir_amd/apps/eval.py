@@ -229,16 +229,16 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
             slot = k % nslot
             if pending[slot] is not None:
                 finish(slot)
-            if source == 'jpeg':
-                with torch.cuda.stream(pipe.streams[slot]):            # records by DMA, then the rest of the JPEG decode straight into the slot's input
-                    rec_dev[slot].copy_(frames, non_blocking=True)
-                    rec_dec[slot](rec_dev[slot], pipe.imgs[slot], n)
-            else:
-                pipe.refill(slot, frames)                              # async DMA from the ring's page-locked buffer, on the slot's stream
             with torch.cuda.stream(pipe.streams[slot]):
+                if source == 'jpeg':
+                    rec_dev[slot].copy_(frames, non_blocking=True)     # the coefficient records by DMA
+                else:
+                    pipe.imgs[slot].copy_(frames, non_blocking=True)   # async DMA from the ring's page-locked buffer, on the slot's stream (= pipe.refill)
                 annos_dev = annos.to(dev, non_blocking=True)
                 copied = torch.cuda.Event()
-                copied.record()
+                copied.record()                                        # both DMAs done = the ring's buffer is free: recorded BEFORE any kernel of this
+                if source == 'jpeg':                                   # slot, so the host never waits behind compute that queues with the other slots' forwards
+                    rec_dec[slot](rec_dev[slot], pipe.imgs[slot], n)   # the rest of the JPEG decode, straight into the slot's input
             pipe.launch(slot)
             pending[slot] = (n, annos_dev)
             copied.synchronize()                                       # the ring may hand this buffer back to the decoders
