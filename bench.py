@@ -699,7 +699,9 @@ def main():
         B5, nslot = 32, max(1, min(args.inflight, 4))
         imgs5 = [torch.randn(B5, 3, 256, 256, device=dev, generator=g) for _ in range(nslot)]
         cfg5 = {'batch_per_gpu': B5, 'forwards_in_flight': nslot, 'workload': 'BASELINE configs[4] per GPU: HRNet-W48 + init regression + 4 refinement stages, 32 images'}
-        for tag, dt5, ar5 in (('bf16', torch.bfloat16, None), ('fp16', torch.float32, 'f16')):
+        # bf16 storage | f16 STORAGE (round 5: the bf16 data path on IEEE f16 maps and weights, fp16 MFMAs -- the 'fp16' configs[4] names, at bf16 speed) |
+        # fp32 storage with one f16 MFMA per product (rounds 3-4's reading of 'fp16': the slow, scale-calibrated path)
+        for tag, dt5, ar5 in (('bf16', torch.bfloat16, None), ('f16s', torch.float16, None), ('fp16', torch.float32, 'f16')):
             e5 = E.DirEngine(sd5, dtype=dt5, device=dev, arith=ar5)
             e5.calibrate(imgs5[0])
             e5.forward(imgs5[0])
@@ -732,10 +734,10 @@ def main():
                 p5.launch(0)
             sync()
             r51 = timed_regions(lambda: p5.launch(0), 5, 3, sync, float, sync)
-            key = 'images_per_sec' if tag == 'bf16' else 'fp16_images_per_sec'
-            cfg5[key] = round(B5 * 10 / d5, 1)
-            cfg5['ms_per_step' if tag == 'bf16' else 'fp16_ms_per_step'] = round(d5 / 10 * 1e3, 3)
-            cfg5['ms_per_forward_one_in_flight' if tag == 'bf16' else 'fp16_ms_per_forward_one_in_flight'] = round(statistics.median(r51) / 5 * 1e3, 3)
+            pre5 = {'bf16': '', 'f16s': 'f16_storage_', 'fp16': 'fp16_'}[tag]
+            cfg5[pre5 + 'images_per_sec'] = round(B5 * 10 / d5, 1)
+            cfg5[pre5 + 'ms_per_step'] = round(d5 / 10 * 1e3, 3)
+            cfg5[pre5 + 'ms_per_forward_one_in_flight'] = round(statistics.median(r51) / 5 * 1e3, 3)
             del p5, e5
             torch.cuda.empty_cache()
         del sd5, imgs5
