@@ -159,6 +159,55 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(JpegArgs a) {
     const unsigned char* base = a.planes + (long long)img * a.pstride;
     const unsigned char* py = base + h->coef_offset[0] + (long long)y * (h->blocks_x[0] * 8);
     unsigned char px[12];
+    // ---- the files of the path (dataset/prepare_data.py:123-166: cv.imwrite's default 4:2:0) in 9 dword loads instead of 36 byte loads: a thread's
+    //      four pixels need luma x0 .. x0 + 3 and, per chroma component and row, the samples cx0 - 1 .. cx0 + 2 (cx0 = x0 / 2); same formulas as
+    //      chroma_at (h2v2_fancy), so the same bits.  W % 8 == 0, H even, at least 8 chroma columns.
+    if (h->ncomp == 3 && h->hmax == 2 && h->vmax == 2 && h->h[0] == 2 && h->v[0] == 2 && h->h[1] == 1 && h->v[1] == 1 && h->h[2] == 1 && h->v[2] == 1 &&
+        (a.W & 7) == 0 && (a.H & 1) == 0 && a.W >= 16) {
+        const int dw = a.W >> 1, dh = a.H >> 1, cx0 = x0 >> 1, cy = y >> 1;
+        int oy = (y & 1) ? cy + 1 : cy - 1;
+        oy = oy < 0 ? 0 : oy > dh - 1 ? dh - 1 : oy;
+        const unsigned yq = *reinterpret_cast<const unsigned*>(py + x0);
+        const int s0 = cx0 - 1, a0 = s0 & ~3, sh = (s0 - a0) * 8;          // first sample wanted, its dword, its bit offset (cx0 is even: 8 or 24)
+        int cur[2][4];                                                     // [component][k]: 3 * r0[cx0 - 1 + k] + r1[cx0 - 1 + k]
+#pragma unroll
+        for (int c = 1; c <= 2; ++c) {
+            const int pitch = h->blocks_x[c] * 8;
+            const unsigned char* pl = base + h->coef_offset[c];
+            unsigned long long v[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned char* row = pl + (long long)(r == 0 ? cy : oy) * pitch;
+                const unsigned lo = a0 >= 0 ? *reinterpret_cast<const unsigned*>(row + a0) : 0u;      // (cx0 = 0: sample -1 does not exist and is not used)
+                const int a1 = min(a0 + 4, pitch - 4);                                                 // (the last quad: sample dw may lie past the row; not used)
+                unsigned hi = *reinterpret_cast<const unsigned*>(row + a1);
+                if (a1 != a0 + 4) hi = 0u;
+                v[r] = ((unsigned long long)hi << 32 | lo) >> sh;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[c - 1][k] = 3 * (int)((v[0] >> (8 * k)) & 255u) + (int)((v[1] >> (8 * k)) & 255u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int Y = (int)((yq >> (8 * e)) & 255u), cx = cx0 + (e >> 1), k = 1 + (e >> 1);
+            int cc[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int m = cur[c][k];
+                int val;
+                if (e & 1) val = cx == dw - 1 ? (m * 4 + 7) >> 4 : (3 * m + cur[c][k + 1] + 7) >> 4;
+                else val = cx == 0 ? (m * 4 + 8) >> 4 : (3 * m + cur[c][k - 1] + 8) >> 4;
+                cc[c] = val - 128;
+            }
+            px[3 * e] = (unsigned char)clamp255(Y + ((116130 * cc[0] + 32768) >> 16));
+            px[3 * e + 1] = (unsigned char)clamp255(Y + ((-22554 * cc[0] + 32768 - 46802 * cc[1]) >> 16));
+            px[3 * e + 2] = (unsigned char)clamp255(Y + ((91881 * cc[1] + 32768) >> 16));
+        }
+        unsigned* o32 = reinterpret_cast<unsigned*>(a.out + ((long long)img * a.H * a.W + (long long)y * a.W + x0) * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o32[k] = px[4 * k] | (px[4 * k + 1] << 8) | (px[4 * k + 2] << 16) | ((unsigned)px[4 * k + 3] << 24);
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int x = min(x0 + e, a.W - 1);
