@@ -7,6 +7,8 @@ cd $R
 t0=$SECONDS
 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $out/gpu_tests.txt
 echo "pytest -m gpu: $((SECONDS - t0)) s" > $out/durations.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1
+echo "smoke(): rc $? in $((SECONDS - t0)) s (incl. pytest)" >> $out/durations.txt
 t0=$SECONDS
 python bench.py > $out/bench_stdout.txt 2> $out/bench_stderr.txt
 echo "python bench.py (default flags): $((SECONDS - t0)) s" >> $out/durations.txt
