@@ -128,7 +128,9 @@ _SIGNATURES = {
     'dir_launch_log_note': (None, [C.c_char_p, C.c_longlong]),
     'dir_probe_launch': (C.c_longlong, [_i, _p, C.c_longlong, _i, _p]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'dir_conv2d_forward_stats': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int), _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'dir_fuse_sum': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),
     'dir_train_pack_conv_weights': (C.c_int, [_p, _p, _i, _i, _p]),
     'dir_gemm_f32_splitk_workspace_bytes': (C.c_longlong, [C.POINTER(GemmDesc)]),
@@ -191,6 +193,9 @@ _SIGNATURES = {
     'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
+    'dir_bn_train_stats': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p, C.c_longlong, _p]),
+    'dir_bn_train_stats_from_partials': (C.c_int, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_float, C.c_float, _p]),
+    'dir_bn_train_apply': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     'dir_bn_one_launch_status': (C.c_int, []),
     'dir_upsample_nearest_add_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample_nearest_backward_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
@@ -214,6 +219,7 @@ _SIGNATURES = {
     'dir_conv2d_wgrad_f32': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, _p]),
     'dir_conv2d_wgrad_f16x3_workspace_bytes': (C.c_longlong, [C.POINTER(ConvDesc)]),
     'dir_conv2d_wgrad_f16x3': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, C.c_float, C.c_float, _p]),
+    'dir_conv2d_wgrad_f16x3_pre': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _i, _p, C.c_longlong, C.c_float, C.c_float, _p, _p, _i, _p]),
     'dir_maxpool3x3s2_backward': (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p]),
     'dir_upsample2x_bilinear_backward': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'dir_attn_pool_forward': (C.c_int, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),

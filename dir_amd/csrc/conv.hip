@@ -30,6 +30,8 @@
 
 using namespace dir::convk;
 
+namespace dir { namespace convk { thread_local int stats_rows_launched = 0; } }
+
 namespace {
 
 constexpr long long SPLITK_COUNTER_BYTES = 16384;      // head of a split-K workspace: one arrival counter per output tile (<= 4096 tiles)
@@ -453,6 +455,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     if (a.flags & 4) {
         // coalesced path: scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM
         float* st = reinterpret_cast<float*>(smem);
+        if constexpr (std::is_same<TO, float>::value && !SPLIT) {
+            if (a.st_p1) tile_col_stats<MI, NJ, 2, 2>(a, acc, st, m0, n0, wm, wn, lane);        // (round 5: the following BatchNorm's chunk partials)
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int cl = wn * NJ * 32 + j * 32 + (lane & 31);
@@ -573,6 +578,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
+    if (a.st_p1 && std::is_same<TO, float>::value && (a.flags & 4)) stats_rows_launched = bm;      // this kernel's epilogue forms the statistics (tile_col_stats)
     choose_tile_order(a, is_half<TI>::value ? 2 : 4);
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     const bool pre = a.pre_scale != nullptr;
@@ -613,7 +619,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
 static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                         const float* pre_scale, const float* pre_shift, const void* residual, void* y,
                         const int32_t* bbox, void* stream, const dir_conv_src2* d2 = nullptr, const void* x2 = nullptr,
-                        int splits = 0, void* workspace = nullptr, long long workspace_bytes = 0) {
+                        int splits = 0, void* workspace = nullptr, long long workspace_bytes = 0, float* st_p1 = nullptr, float* st_p2 = nullptr) {
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
@@ -699,6 +705,8 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
         num_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
     }
     a.splits = 0; a.ws_part = nullptr; a.ws_cnt = nullptr;
+    a.st_p1 = st_p1; a.st_p2 = st_p2;
+    stats_rows_launched = 0;
     if (splits > 1) {
         DIR_REQUIRE(!f32 && d->out_dtype != DIR_DT_F32 && vec && bbox == nullptr, "dir_conv2d_splitk_forward: 16-bit -> 16-bit layers with 16-byte aligned output rows only");
         DIR_REQUIRE(splits <= a.nk && splits <= 16, "dir_conv2d_splitk_forward: splits must be <= min(16, K / 64)");
@@ -911,6 +919,19 @@ extern "C" int dir_conv2d_forward(const dir_conv_desc* d, const void* x, const v
                                   const float* shift, const float* pre_scale, const float* pre_shift,
                                   const void* residual, void* y, void* stream) {
     return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream);
+}
+
+// round 5: dir_conv2d_forward + the chunk partials of the training-mode BatchNorm that follows it (tile_col_stats in the epilogue).  *chunk_rows
+// receives the rows per chunk (the M tile of the kernel that took the launch), or 0 when that kernel does not form them (the caller then runs
+// dir_bn_train_stats on the stored map).  p1 / p2: room for ceil(M / 64) x Cout floats each.
+extern "C" int dir_conv2d_forward_stats(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
+                                        const float* pre_shift, void* y, float* p1, float* p2, int* chunk_rows, void* stream) {
+    DIR_REQUIRE(d && p1 && p2 && chunk_rows, "dir_conv2d_forward_stats: null pointer");
+    DIR_REQUIRE(d->out_dtype == DIR_DT_F32 && (d->out_cstride == 0 || d->out_cstride == d->Cout) && d->out_coff == 0 && !(d->flags & 1) && d->out_split_scale == 0.f,
+                "dir_conv2d_forward_stats: the statistics are those of a whole fp32 output tensor without activation");
+    const int rc = conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, nullptr, y, nullptr, stream, nullptr, nullptr, 0, nullptr, 0, p1, p2);
+    *chunk_rows = rc == 0 ? stats_rows_launched : 0;
+    return rc;
 }
 
 extern "C" long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits) {

@@ -185,7 +185,13 @@ struct ConvArgs {
     // of K-slabs; raw fp32 partial tiles go to ws_part [split][tile][128*128], the last workgroup to arrive at ws_cnt[tile] sums
     // them in split order (deterministic) and runs the epilogue.  0 / 1 = off.
     int splits; float* ws_part; unsigned* ws_cnt;
+    // round 5 (dir_conv2d_forward_stats): the chunk partials of the BatchNorm (training mode) that FOLLOWS this convolution, from the output tile while
+    // it is still in registers -- st_p1 [tiles_m][Cout] = per tile row and output channel the sum of the tile's valid rows of y, st_p2 = sum (y - tile
+    // mean)^2 (what bn_stats4_kernel forms from the stored map with 256-row chunks; here the chunk is the M tile).  NULL = off.
+    float* st_p1 = nullptr; float* st_p2 = nullptr;
 };
+// rows of the M tile the last launch on this thread formed the statistics over (0: the kernel that took the launch does not form them)
+extern thread_local int stats_rows_launched;
 
 constexpr int MAX_SLABS = 768;
 
@@ -377,6 +383,61 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* ps, cons
 template <>
 __device__ __forceinline__ uint4 prologue<f16s_t>(uint4 v, const float* ps, const float* pb, int c, bool relu) { return prologue_half<f16s_t>(v, ps, pb, c, relu); }
 
+// Column statistics of the output tile (values fmaf(acc, scale, shift): what the epilogue stores when there is no residual / activation) over
+// the tile's valid rows, two passes over the accumulators (sum -> tile mean -> sum of squared deviations), combined across the two lane
+// halves by a cross-lane move and across the WM waves of a column through `red` (LDS, 2 * WM * BN floats, free at the epilogue's start) in wave
+// order: deterministic.  Ends with a barrier: `red` may be overwritten by the staging that follows.
+template <int MI, int NJ, int WM, int WN>
+__device__ __forceinline__ void tile_col_stats(const ConvArgs& a, f32x16 (&acc)[MI][NJ], float* red, int m0, int n0, int wm, int wn, int lane) {
+    constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    const int nvalid = min(BM, a.M - m0), tm = m0 / BM, l32 = lane & 31, rbase = wm * MI * 32 + 4 * (lane >> 5);
+    float sc[NJ], sh[NJ], mean[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cl = wn * NJ * 32 + j * 32 + l32, n = n0 + cl;
+        sc[j] = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+        sh[j] = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < nvalid) t += fmaf(acc[i][j][r], sc[j], sh[j]);
+        t += __shfl_xor(t, 32);
+        if (lane < 32) red[wm * BN + cl] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cl = wn * NJ * 32 + j * 32 + l32;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) t += red[w * BN + cl];
+        mean[j] = t / (float)nvalid;
+        if (wm == 0 && lane < 32 && n0 + cl < a.Cout) a.st_p1[(long long)tm * a.Cout + n0 + cl] = t;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < nvalid) { const float d = fmaf(acc[i][j][r], sc[j], sh[j]) - mean[j]; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 32);
+        if (lane < 32) red[(WM + wm) * BN + cl] = q;
+    }
+    __syncthreads();
+    if (wm == 0 && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cl = wn * NJ * 32 + j * 32 + l32;
+            float q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) q += red[(WM + w) * BN + cl];
+            if (n0 + cl < a.Cout) a.st_p2[(long long)tm * a.Cout + n0 + cl] = q;
+        }
+    }
+    __syncthreads();
+}
+
 // Epilogue of the 8-wave kernels (conv_pipe.hip, bonefuse.hip): tile of (32*MI*WM) x (32*NJ*WN), wave (wm, wn).
 // scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM (conv.hip's epilogue)
 template <typename TO, int MI, int NJ, int WM, int WN>
@@ -387,6 +448,9 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
     const TO* __restrict__ res = (const TO*)a.res;
     const bool relu = (a.flags & 1) != 0;
     float* st = reinterpret_cast<float*>(smem);
+    if constexpr (std::is_same<TO, float>::value) {
+        if (a.st_p1) tile_col_stats<MI, NJ, WM, WN>(a, acc, st, m0, n0, wm, wn, lane);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int cl = wn * NJ * 32 + j * 32 + (lane & 31);

@@ -215,6 +215,41 @@ __global__ __launch_bounds__(256) void add_upsampled_kernel(T* __restrict__ acc,
     }
 }
 
+// round 5: the whole sum of an HRNet fuse row in ONE pass -- out = act(base + sum_t nearest_upsample(src_t, f_t)), fp32 sum, one rounding.
+// The term-by-term form above makes 2 passes over the row's (largest) map per term plus a copy for the first one: 8 passes for the
+// full-resolution row of a four-branch module; this is 2.  out may be base (in place).
+struct FuseSumArgs { const void* src[4]; int f[4]; int nsrc; };
+template <typename T>
+__global__ __launch_bounds__(256) void fuse_sum_kernel(T* out, const T* base, FuseSumArgs fs, int B, int H, int W, int C, int relu) {
+    constexpr int VN = Vec<T>::N;
+    const long long n = (long long)B * H * W * (C / VN);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % (C / VN));
+        long long p = i / (C / VN);
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        float a[VN], s[4][VN];
+        const long long o = (((long long)b * H + y) * W + x) * C + cv * VN;
+        Vec<T>::load(base + o, a);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < fs.nsrc) {
+                const int f = fs.f[t];
+                Vec<T>::load((const T*)fs.src[t] + (((long long)b * (H / f) + y / f) * (W / f) + x / f) * C + cv * VN, s[t]);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < fs.nsrc)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) a[e] += s[t][e];
+        if (relu)
+#pragma unroll
+            for (int e = 0; e < VN; ++e) a[e] = fmaxf(a[e], 0.f);
+        Vec<T>::store(out + o, a);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ upsample
 // One thread = one INPUT pixel x one 16-byte channel vector -> its 2x2 output quad: the quad's four bilinear footprints lie inside the
 // pixel's 3x3 neighbourhood, so 9 vector loads (clamped addresses, all independent) serve 4 output vectors instead of 16, and the
@@ -702,6 +737,26 @@ extern "C" int dir_add_upsampled(void* acc, const void* src, int B, int H, int W
     else if (dtype == DIR_DT_F16) DIR_LAUNCH((add_upsampled_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, (f16s_t*)acc, (const f16s_t*)src, B, H, W, C, factor, relu);
     else DIR_REQUIRE(false, "dir_add_upsampled: bad dtype");
     return dir::check_launch("dir_add_upsampled");
+}
+
+extern "C" int dir_fuse_sum(void* out, const void* base, const void* const* srcs, const int* factors, int nsrc, int B, int H, int W, int C, int relu, int dtype,
+                            void* stream) {
+    DIR_REQUIRE(out && base && B > 0 && H > 0 && W > 0 && C > 0 && nsrc >= 0 && nsrc <= 4 && (nsrc == 0 || (srcs && factors)), "dir_fuse_sum: bad args (at most 4 sources)");
+    DIR_REQUIRE(C % 8 == 0, "dir_fuse_sum: C must be a multiple of 8");
+    FuseSumArgs fs;
+    for (int t = 0; t < 4; ++t) { fs.src[t] = nullptr; fs.f[t] = 1; }
+    fs.nsrc = nsrc;
+    for (int t = 0; t < nsrc; ++t) {
+        DIR_REQUIRE(srcs[t] && factors[t] >= 1 && H % factors[t] == 0 && W % factors[t] == 0, "dir_fuse_sum: H and W must be multiples of every factor");
+        fs.src[t] = srcs[t]; fs.f[t] = factors[t];
+    }
+    const long long n = (long long)B * H * W * (C / (dtype == DIR_DT_F32 ? 4 : 8));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DIR_DT_F32) DIR_LAUNCH((fuse_sum_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (float*)out, (const float*)base, fs, B, H, W, C, relu);
+    else if (dtype == DIR_DT_BF16) DIR_LAUNCH((fuse_sum_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, s, (bf16_t*)out, (const bf16_t*)base, fs, B, H, W, C, relu);
+    else if (dtype == DIR_DT_F16) DIR_LAUNCH((fuse_sum_kernel<f16s_t>), dim3(grid_for(n)), dim3(256), 0, s, (f16s_t*)out, (const f16s_t*)base, fs, B, H, W, C, relu);
+    else DIR_REQUIRE(false, "dir_fuse_sum: bad dtype");
+    return dir::check_launch("dir_fuse_sum");
 }
 
 extern "C" int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, int out_cstride,

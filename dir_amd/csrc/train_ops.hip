@@ -882,14 +882,15 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const float* x, float* p
 // the statistics of 16 channels (c16 = first channel / 16) from the chunk partials
 template <bool CO = false>
 __device__ __forceinline__ void bn_stats_combine16(const float* p1, const float* p2, float* save_mean, float* save_rstd, float* running_mean,
-                                                   float* running_var, int chunks, int R, int C, float eps, float momentum, int c16, float (&s)[16][17]) {
+                                                   float* running_var, int chunks, int R, int C, float eps, float momentum, int c16, float (&s)[16][17],
+                                                   int crows = BN_CHUNK_ROWS) {
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = c16 * 16 + cl;
     const float mu = chunk_sum16<CO>(p1, chunks, C, c, s) / R;
     __syncthreads();
     float a = 0.f;
     if (c < C)
         for (int k = rl; k < chunks; k += 16) {
-            const int nk = min(BN_CHUNK_ROWS, R - k * BN_CHUNK_ROWS);
+            const int nk = min(crows, R - k * crows);
             const float d = ld_co<CO>(p1 + (long long)k * C + c) / nk - mu;
             a += fmaf((float)nk * d, d, ld_co<CO>(p2 + (long long)k * C + c));
         }
@@ -909,6 +910,20 @@ __global__ __launch_bounds__(256) void bn_stats_combine_kernel(const float* p1, 
                                                               float* running_var, int chunks, int R, int C, float eps, float momentum) {
     __shared__ float s[16][17];
     bn_stats_combine16(p1, p2, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum, blockIdx.x, s);
+}
+// round 5 (dir_bn_train_stats): the statistics only, plus the affine form the CONSUMING convolution applies where it reads the map --
+// pre_scale = gamma rstd, pre_shift = beta - mean gamma rstd (dir_conv2d_forward's pre-activation, dir_split_f16_forward's, dir_conv2d_wgrad_f16x3_pre's):
+// the normalised map is never written.  Same statistics kernels, same bits of mean / rstd / running statistics as dir_bn_train_forward.
+__global__ __launch_bounds__(256) void bn_stats_combine_pre_kernel(const float* p1, const float* p2, const float* w, const float* b, float* save_mean, float* save_rstd,
+                                                                  float* pre_scale, float* pre_shift, float* running_mean, float* running_var, int chunks, int R, int C,
+                                                                  float eps, float momentum, int crows) {
+    __shared__ float s[16][17];
+    bn_stats_combine16(p1, p2, save_mean, save_rstd, running_mean, running_var, chunks, R, C, eps, momentum, blockIdx.x, s, crows);
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    if (rl != 0 || c >= C || !pre_scale) return;         // (the thread that wrote save_mean[c] / save_rstd[c] above)
+    const float g = w ? w[c] : 1.f, be = b ? b[c] : 0.f, k = g * save_rstd[c];
+    pre_scale[c] = k;
+    pre_shift[c] = fmaf(-save_mean[c], k, be);
 }
 // ---- SyncBN (round 5; SURVEY.md 8e "optionally offer SyncBN": the reference trains 64 images on ONE GPU, config.py:13-15 -- 8 x 32 changes the
 // BatchNorm batch unless the statistics are pooled).  The local part of the statistics: this rank's mean and M2 = sum (x - mean_local)^2 per
@@ -2022,6 +2037,88 @@ extern "C" int dir_bn_train_forward(const float* x, const float* w, const float*
     const long long n = (long long)R * C;
     DIR_LAUNCH(bn_apply_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, w, b, (const float*)save_mean, (const float*)save_rstd, y, n, C, ld, relu, residual);
     return check_launch("dir_bn_train_forward");
+}
+extern "C" int dir_bn_train_stats(const float* x, const float* w, const float* b, float* save_mean, float* save_rstd, float* pre_scale, float* pre_shift,
+                                  float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum, float* workspace,
+                                  long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && save_mean && save_rstd && pre_scale && pre_shift && R > BN_SMALL_R && C > 0 && ld >= C && ((running_mean == nullptr) == (running_var == nullptr)),
+                "dir_bn_train_stats: bad arguments (maps of more than %d rows: smaller ones go through dir_bn_train_forward)", BN_SMALL_R);
+    DIR_REQUIRE(bn_vec4(C, ld, {x, w, b, save_mean, save_rstd, workspace}), "dir_bn_train_stats: C and ld must be multiples of 4, pointers 16-byte aligned");
+    DIR_REQUIRE(workspace && workspace_bytes >= dir_bn_train_workspace_bytes(R, C), "dir_bn_train_stats: workspace too small (dir_bn_train_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (R + BN_CHUNK_ROWS - 1) / BN_CHUNK_ROWS;
+    float* part = workspace; float* p2 = part + (long long)chunks * C;
+    const dim3 pg((C + 63) / 64, chunks), cg((C + 15) / 16);
+    DIR_LAUNCH(bn_stats4_kernel, pg, dim3(256), 0, s, x, part, p2, R, C, ld);
+    DIR_LAUNCH(bn_stats_combine_pre_kernel, cg, dim3(256), 0, s, (const float*)part, (const float*)p2, w, b, save_mean, save_rstd, pre_scale, pre_shift, running_mean,
+               running_var, chunks, R, C, eps, momentum, BN_CHUNK_ROWS);
+    return check_launch("dir_bn_train_stats");
+}
+// Chunk partials -> partials of GROUPS of `per` consecutive chunks (same meaning: column sum | sum of squared deviations from the group's own mean),
+// one workgroup per (16 channels, group): q1[g][c] = sum_k p1[k][c], q2[g][c] = sum_k [p2[k][c] + n_k (p1[k][c] / n_k - mean_g)^2] (exact pooling of
+// variances, chunks in order).  A 64-row convolution tile over 131 072 pixels leaves 2 048 chunks per channel, which the 16 lanes per channel of the
+// combine kernel walk in 14 us; groups of 32 first, in parallel, then 64 groups: 2 x 3 us.
+__global__ __launch_bounds__(256) void bn_partials_coarsen_kernel(const float* p1, const float* p2, float* q1, float* q2, int chunks, int per, int crows, int R, int C) {
+    __shared__ float s[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + cl, g = blockIdx.y;
+    const int k0 = g * per, k1 = min(chunks, k0 + per);
+    const int rows_g = min(R, k1 * crows) - k0 * crows;
+    float a = 0.f;
+    if (c < C)
+        for (int k = k0 + rl; k < k1; k += 16) a += p1[(long long)k * C + c];
+    s[rl][cl] = a;
+    __syncthreads();
+    float t = 0.f;
+    for (int l = 0; l < 16; ++l) t += s[l][cl];
+    const float mu = t / rows_g;
+    __syncthreads();
+    a = 0.f;
+    if (c < C)
+        for (int k = k0 + rl; k < k1; k += 16) {
+            const int nk = min(crows, R - k * crows);
+            const float d = p1[(long long)k * C + c] / nk - mu;
+            a += fmaf((float)nk * d, d, p2[(long long)k * C + c]);
+        }
+    s[rl][cl] = a;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    float q = 0.f;
+    for (int l = 0; l < 16; ++l) q += s[l][cl];
+    q1[(long long)g * C + c] = t; q2[(long long)g * C + c] = q;
+}
+// the statistics from chunk partials a convolution's epilogue formed (dir_conv2d_forward_stats): p1 / p2 [ceil(R / chunk_rows)][C]; cap_rows: rows
+// of C floats p1 and p2 each have room for -- with more than 256 chunks and room for the groups behind the chunks, the partials are pooled in two levels
+extern "C" int dir_bn_train_stats_from_partials(float* p1, float* p2, int chunk_rows, int cap_rows, const float* w, const float* b, float* save_mean, float* save_rstd,
+                                                float* pre_scale, float* pre_shift, float* running_mean, float* running_var, int R, int C, float eps, float momentum,
+                                                void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(p1 && p2 && chunk_rows > 0 && save_mean && save_rstd && R > 0 && C > 0 && ((pre_scale == nullptr) == (pre_shift == nullptr)) &&
+                    ((running_mean == nullptr) == (running_var == nullptr)), "dir_bn_train_stats_from_partials: bad arguments");
+    int chunks = (R + chunk_rows - 1) / chunk_rows;
+    DIR_REQUIRE(cap_rows >= chunks, "dir_bn_train_stats_from_partials: cap_rows is smaller than the number of chunks");
+    hipStream_t s = (hipStream_t)stream;
+    const float* c1 = p1; const float* c2 = p2;
+    constexpr int PER = 32;
+    const int groups = (chunks + PER - 1) / PER;
+    if (chunks > 256 && cap_rows >= chunks + groups) {
+        float* q1 = p1 + (long long)chunks * C; float* q2 = p2 + (long long)chunks * C;
+        DIR_LAUNCH(bn_partials_coarsen_kernel, dim3((C + 15) / 16, groups), dim3(256), 0, s, c1, c2, q1, q2, chunks, PER, chunk_rows, R, C);
+        c1 = q1; c2 = q2; chunks = groups; chunk_rows *= PER;
+    }
+    DIR_LAUNCH(bn_stats_combine_pre_kernel, dim3((C + 15) / 16), dim3(256), 0, s, c1, c2, w, b, save_mean, save_rstd, pre_scale, pre_shift, running_mean,
+               running_var, chunks, R, C, eps, momentum, chunk_rows);
+    return check_launch("dir_bn_train_stats_from_partials");
+}
+// the normalisation alone, from statistics already formed (dir_bn_train_stats / _from_partials): y = act(BatchNorm(x) + residual) like dir_bn_train_forward
+extern "C" int dir_bn_train_apply(const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* y, int R, int C, int ld,
+                                  int relu, const float* residual, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(x && y && save_mean && save_rstd && R > 0 && C > 0 && ld >= C, "dir_bn_train_apply: bad arguments");
+    DIR_REQUIRE(bn_vec4(C, ld, {x, y, w, b, save_mean, save_rstd, residual}), "dir_bn_train_apply: C and ld must be multiples of 4, pointers 16-byte aligned");
+    const long long nt = (long long)((R + 3) / 4) * (C / 4);
+    DIR_LAUNCH(bn_apply_fwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, save_mean, save_rstd, y, R, C, ld, relu, residual);
+    return check_launch("dir_bn_train_apply");
 }
 extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                                      float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream) {

@@ -28,6 +28,9 @@ struct WgradX3Args {
     const float* x; const float* gy; float* out;        // out: gw, or the workspace [chunks][Cout][taps][Cin]
     int B, H, W, Cin, in_cs, in_co, Cout, gy_cs, gy_co, kh, kw, stride, pad, Ho, Wo, M, chunk, tiles_ci;
     float sx, sg, inv;                                   // power-of-two operand scales and 1 / (sx * sg)
+    const float* pre_s; const float* pre_b; int pre_relu; // optional pre-activation of the x operand: x <- act(x * pre_s[c] + pre_b[c]) per input channel
+                                                         // (round 5: the BatchNorm + ReLU between two convolutions, applied where x is read -- the
+                                                         // normalised map is never written; padding taps stay zero: the mask is applied after it)
     unsigned mg_hw, sh_hw, mg_w, sh_w;                   // m / (Ho * Wo), r / Wo (convk::magic_u31)
 };
 
@@ -53,6 +56,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradX3Args a) {
     const bool a_on = co0 + 4 * cqa < a.Cout, b_on = ci0 + 4 * cqb < a.Cin;
     const int cha = a.gy_co + (a_on ? co0 + 4 * cqa : co0), chb = a.in_co + (b_on ? ci0 + 4 * cqb : ci0);
     const float sga = a_on ? a.sg : 0.f, sxb = b_on ? a.sx : 0.f;
+    const bool pre = a.pre_s != nullptr;
+    float4 ps4 = make_float4(1.f, 1.f, 1.f, 1.f), pb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pre && b_on) {
+        ps4 = *reinterpret_cast<const float4*>(a.pre_s + ci0 + 4 * cqb);
+        pb4 = *reinterpret_cast<const float4*>(a.pre_b + ci0 + 4 * cqb);
+    }
     // two register sets: the operands of step k + 2 are requested while step k runs and are written to LDS at the end of step k + 1 --
     // one workgroup has two steps of global loads in flight (two workgroups per CU: four), which covers an HBM round trip
     float4 ra[2][4], rb[2][4];
@@ -135,9 +144,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradX3Args a) {
         for (int e = 0; e < 4; ++e) rb[p][e] = *reinterpret_cast<const float4*>(pb[e]);
     };
     // 4 pixels x 4 channels -> per channel 4 hi halves + 4 lo halves (8 bytes each) of row 4 cq + c; masked pixels are scaled by 0
-    auto lstore_tile = [&](char* base, const float4 (&r)[4], unsigned ok, float s) {
-        const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
-                               {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+    auto lstore_tile = [&](char* base, const float4 (&r)[4], unsigned ok, float s, bool act) {
+        float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w},
+                         {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+        if (act) {                                       // (uniform per launch)
+            const float sc[4] = {ps4.x, ps4.y, ps4.z, ps4.w}, sh[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float t = fmaf(v[e][c], sc[c], sh[c]);
+                    v[e][c] = a.pre_relu ? fmaxf(t, 0.f) : t;
+                }
+        }
         const float se[4] = {(ok & 1u) ? s : 0.f, (ok & 2u) ? s : 0.f, (ok & 4u) ? s : 0.f, (ok & 8u) ? s : 0.f};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -153,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(WgradX3Args a) {
     auto lstore = [&](auto P, int buf) {
         constexpr int p = decltype(P)::value;
         char* as = smem + buf * BUF;
-        if (4 * cq < TM) lstore_tile(as, ra[p], oka[p], sga);
-        if (4 * cq < TN) lstore_tile(as + TM * 128, rb[p], okb[p], sxb);
+        if (4 * cq < TM) lstore_tile(as, ra[p], oka[p], sga, false);
+        if (4 * cq < TN) lstore_tile(as + TM * 128, rb[p], okb[p], sxb, pre);
     };
 
     f32x16 acc[MI][NJ];
@@ -281,9 +300,11 @@ extern "C" long long dir_conv2d_wgrad_f16x3_workspace_bytes(const dir_conv_desc*
     return c > 1 ? (long long)c * d->Cout * d->kh * d->kw * d->Cin * 4 : 0;
 }
 
-extern "C" int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
-                                      long long workspace_bytes, float x_scale, float gy_scale, void* stream) {
+static int wgrad_f16x3(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                      long long workspace_bytes, float x_scale, float gy_scale, const float* pre_scale, const float* pre_shift, int pre_relu, void* stream) {
     using namespace dir;
+    DIR_REQUIRE((pre_scale == nullptr) == (pre_shift == nullptr) && (((uintptr_t)pre_scale | (uintptr_t)pre_shift) & 15) == 0,
+                "dir_conv2d_wgrad_f16x3_pre: pre_scale / pre_shift go together, 16-byte aligned");
     DIR_REQUIRE(d && x && gy && gw, "dir_conv2d_wgrad_f16x3: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0,
                 "dir_conv2d_wgrad_f16x3: bad geometry");
@@ -309,6 +330,7 @@ extern "C" int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, co
     a.chunk = (int)(((M + chunks - 1) / chunks + XK - 1) / XK * XK);
     a.out = direct ? gw : workspace;
     a.sx = x_scale; a.sg = gy_scale; a.inv = 1.f / (x_scale * gy_scale);
+    a.pre_s = pre_scale; a.pre_b = pre_shift; a.pre_relu = pre_relu;
     convk::magic_u31((unsigned)(a.Ho * a.Wo), &a.mg_hw, &a.sh_hw);
     convk::magic_u31((unsigned)a.Wo, &a.mg_w, &a.sh_w);
     const int tm = x3_tile(d->Cout), tn = x3_tile(d->Cin);
@@ -334,4 +356,14 @@ extern "C" int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, co
     else launch(C64{}, C64{});
     if (!direct) DIR_LAUNCH(wgrad_x3_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)workspace, gw, n, chunks, accumulate);
     return check_launch("dir_conv2d_wgrad_f16x3");
+}
+
+extern "C" int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                                      long long workspace_bytes, float x_scale, float gy_scale, void* stream) {
+    return wgrad_f16x3(d, x, gy, gw, accumulate, workspace, workspace_bytes, x_scale, gy_scale, nullptr, nullptr, 0, stream);
+}
+extern "C" int dir_conv2d_wgrad_f16x3_pre(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                                          long long workspace_bytes, float x_scale, float gy_scale, const float* pre_scale, const float* pre_shift,
+                                          int pre_relu, void* stream) {
+    return wgrad_f16x3(d, x, gy, gw, accumulate, workspace, workspace_bytes, x_scale, gy_scale, pre_scale, pre_shift, pre_relu, stream);
 }

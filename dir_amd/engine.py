@@ -825,11 +825,17 @@ class HRNetOp(object):
             self.stages.append(mods)
         self.incre = [_pad_conv_bn(sd, '%s.incre.%d.0.weight' % (p, b), '%s.incre.%d.1' % (p, b), dt) for b in range(4)]
 
-    def _add(self, acc, src, factor, relu):
-        B, H, W, Cc = acc.shape
-        _ann('hr_fuse', 0, (2 * acc.numel() + src.numel()) * acc.element_size(), 'add %dx%dx%d (x%d)' % (H, W, Cc, factor))
-        _capi.check(_capi.lib().dir_add_upsampled(_capi.ptr(acc), _capi.ptr(src), B, H, W, Cc, factor, 1 if relu else 0, _dt(self.dtype),
-                                                  _capi.stream_ptr()), 'dir_add_upsampled')
+    def _fuse_sum(self, base, srcs, factors, relu, out=None):
+        """out = act(base + sum_t nearest_upsample(srcs[t], factors[t])) in one pass (dir_fuse_sum); out None: a new map"""
+        import ctypes as C
+        B, H, W, Cc = base.shape
+        out = torch.empty_like(base) if out is None else out
+        n = len(srcs)
+        _ann('hr_fuse', 0, (2 * base.numel() + sum(t.numel() for t in srcs)) * base.element_size(), 'sum %dx%dx%d (%d terms)' % (H, W, Cc, n + 1))
+        ps = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in srcs])
+        fs = (C.c_int * max(n, 1))(*factors)
+        _capi.check(_capi.lib().dir_fuse_sum(_capi.ptr(out), _capi.ptr(base), ps, fs, n, B, H, W, Cc, 1 if relu else 0, _dt(self.dtype), _capi.stream_ptr()), 'dir_fuse_sum')
+        return out
 
     def _module(self, xs, mod):
         branches, fuse = mod
@@ -842,23 +848,22 @@ class HRNetOp(object):
             ys.append(y)
         outs = []
         for i in range(nb):
+            # row i: the strided-conv terms (j < i) accumulate through the last convolution's residual input; the identity term and the
+            # upsampled 1x1-conv terms (j > i) are summed with them in ONE pass (round 5: dir_fuse_sum; rounds 3-4 added them one launch
+            # and two passes over the row's map at a time, after a copy of the branch output)
             acc = None
-            for j in range(nb):
-                last = j == nb - 1
-                if j == i:
-                    if acc is None:
-                        acc = ys[j].clone()                  # (a copy: the branch output also feeds the other fuse rows)
-                    else:
-                        self._add(acc, ys[j], 1, last)
-                elif j > i:
-                    self._add(acc, fuse[(i, j)][0](ys[j]), 2 ** (j - i), last)
-                else:
-                    t = ys[j]
-                    chain = fuse[(i, j)]
-                    for op in chain[:-1]:
-                        t = op(t)
-                    acc = chain[-1](t) if acc is None else chain[-1](t, residual=acc)
-            outs.append(acc)
+            for j in range(i):
+                t = ys[j]
+                chain = fuse[(i, j)]
+                for op in chain[:-1]:
+                    t = op(t)
+                acc = chain[-1](t) if acc is None else chain[-1](t, residual=acc)
+            ups = [fuse[(i, j)][0](ys[j]) for j in range(i + 1, nb)]
+            facs = [2 ** (j - i) for j in range(i + 1, nb)]
+            if acc is None:
+                outs.append(self._fuse_sum(ys[i], ups, facs, True))
+            else:
+                outs.append(self._fuse_sum(acc, [ys[i]] + ups, [1] + facs, True, out=acc))
         return outs
 
     def __call__(self, img):

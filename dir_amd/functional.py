@@ -80,7 +80,8 @@ def pow2_in_scale(x, pre_scale=None, pre_shift=None):
 
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
-                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False, prepacked=None):
+                res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False, prepacked=None,
+                stats_out=None):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
     if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
@@ -142,6 +143,20 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
         if _capi.PROFILE is not None:
             _capi.annotate(family='conv', flops=2.0 * B * Ho * Wo * Cout * kh * kw * Cin, bytes=float(x.numel() * x.element_size() + out.numel() * out.element_size()),
                            shape='conv M=%d N=%d K=%d k%d s%d %s' % (B * Ho * Wo, Cout, kh * kw * Cin, kh, stride, arith or str(x.dtype)[6:]))
+        if stats_out is not None and residual is None and not relu and out.dtype == torch.float32 and out.shape[3] == Cout and out_coff == 0:
+            # round 5: the chunk partials of the BatchNorm (training mode) that follows, formed in the epilogue (dir_conv2d_forward_stats);
+            # stats_out (a list) receives (p1, p2, rows per chunk) -- rows 0: the kernel that ran does not form them
+            import ctypes as C
+            nch = (B * Ho * Wo + 63) // 64
+            nch += (nch + 31) // 32            # + room for the two-level pooling of dir_bn_train_stats_from_partials
+            part = torch.empty(2, nch, Cout, device=x.device, dtype=torch.float32)
+            rows = C.c_int(0)
+            rc = _capi.lib().dir_conv2d_forward_stats(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift), _capi.ptr(pre_scale),
+                                                      _capi.ptr(pre_shift), _capi.ptr(out), _capi.ptr(part[0]), _capi.ptr(part[1]), C.byref(rows),
+                                                      _capi.stream_ptr())
+            _capi.check(rc, 'dir_conv2d_forward_stats')
+            stats_out.append((part[0], part[1], rows.value))
+            return out
         rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift),
                                             _capi.ptr(pre_scale), _capi.ptr(pre_shift), _capi.ptr(residual),
                                             _capi.ptr(out), _capi.stream_ptr())

@@ -20,13 +20,37 @@ def _oihw(g):
     return g.permute(0, 3, 1, 2).contiguous()
 
 
-def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5, relu=False, residual=None):
+def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5, relu=False, residual=None, partials=None):
     """BatchNorm2d in training mode; relu=True: the nn.ReLU that follows it in the same launch (bn_bwd(..., relu=True) undoes both);
-    residual: added before that ReLU (a bottleneck's tail; its backward masks with the saved output: relu_bwd, then bn_bwd(relu=False))"""
+    residual: added before that ReLU (a bottleneck's tail; its backward masks with the saved output: relu_bwd, then bn_bwd(relu=False));
+    partials: the chunk partials the producing convolution's epilogue formed (conv_fwd(stats=[...])) -- the statistics pass over x is then skipped"""
     C = x.shape[-1]
+    if partials:
+        x2, w, b = x.view(-1, C), P.get(pre + 'weight'), P.get(pre + 'bias')
+        r2 = None if residual is None else residual.contiguous().view(-1, C)
+        if O.bn_partials_usable(x2, w, b, partials, r2):
+            st, _ = O.bn_train_stats_from_partials(partials[-1], x2.shape[0], w, b, P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum, want_pre=False)
+            return O.bn_train_apply(x2, w, b, st, relu=relu, residual=r2).view(x.shape), (x, st)
     y, st = O.bn_train_fwd(x.view(-1, C), P[pre + 'weight'], P[pre + 'bias'], P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum,
                            relu=relu, residual=None if residual is None else residual.contiguous().view(-1, C))
     return y.view(x.shape), (x, st)
+
+
+def bn_relu_into_conv(P, pre, x, momentum=0.1, eps=1e-5, partials=None):
+    """BatchNorm2d (training mode) + ReLU whose only consumer is ONE convolution.  -> (operand, pre_act, saved): with the fused path (ops.FUSE_BN,
+    maps of more than 512 rows) the operand is x itself and pre_act = (pre_scale, pre_shift) goes to conv_fwd / conv_bwd(pre=...) -- the
+    normalised map is never written (round 5); otherwise the operand is the normalised map and pre_act is None.  saved: for bn_bwd(relu=True)"""
+    C = x.shape[-1]
+    x2 = x.view(-1, C)
+    w, b = P.get(pre + 'weight'), P.get(pre + 'bias')
+    if O.bn_can_fuse(x2, w, b):
+        if O.bn_partials_usable(x2, w, b, partials):       # the producing convolution formed the chunk partials: the map is not read for its statistics
+            st, pa = O.bn_train_stats_from_partials(partials[-1], x2.shape[0], w, b, P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum)
+        else:
+            st, pa = O.bn_train_stats(x2, w, b, P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum)
+        return x, pa, (x, st)
+    a, saved = bn_fwd(P, pre, x, momentum, eps, relu=True, partials=partials)
+    return a, None, saved
 
 
 def bn_bwd(P, pre, saved, gy, G, relu=False):
@@ -36,10 +60,12 @@ def bn_bwd(P, pre, saved, gy, G, relu=False):
     return gx.view(x.shape)
 
 
-def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None):
-    """add_gx: another gradient of x, summed into gx in the data-gradient convolution's epilogue"""
+def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None, pre=None):
+    """add_gx: another gradient of x, summed into gx in the data-gradient convolution's epilogue; pre: the pre-activation the forward convolution
+    applied to x (bn_relu_into_conv) -- gx is then the gradient of the ACTIVATED operand, as before"""
     has_bias = (key + 'bias') in P
-    gx, G[key + 'weight'], gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx, gw_oihw=True)
+    gx, G[key + 'weight'], gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx, gw_oihw=True,
+                                            pre=pre)
     if has_bias:
         G[key + 'bias'] = gb
     return gx
@@ -48,18 +74,19 @@ def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None):
 # ------------------------------------------------------------------------------------------------------------------------ Bottleneck
 def bottleneck_forward(P, x, stride=1):
     ctx = {'x': x, 'stride': stride}
-    h = TC.conv_fwd(x, P['conv1.weight'], oihw=True)
-    a1, ctx['bn1'] = bn_fwd(P, 'bn1.', h, relu=True)
-    h = TC.conv_fwd(a1, P['conv2.weight'], None, stride, 1, oihw=True)
-    a2, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
-    h = TC.conv_fwd(a2, P['conv3.weight'], oihw=True)
+    s1, s2, s3, sd = [], [], [], []                                # chunk partials of bn1 / bn2 / bn3 / downsample.1 from the convolutions' epilogues
+    h = TC.conv_fwd(x, P['conv1.weight'], oihw=True, stats=s1)
+    a1, p1, ctx['bn1'] = bn_relu_into_conv(P, 'bn1.', h, partials=s1)             # (a1 = conv1's raw output + the affine conv2 applies, or the normalised map)
+    h = TC.conv_fwd(a1, P['conv2.weight'], None, stride, 1, oihw=True, pre=p1, stats=s2)
+    a2, p2, ctx['bn2'] = bn_relu_into_conv(P, 'bn2.', h, partials=s2)
+    h = TC.conv_fwd(a2, P['conv3.weight'], oihw=True, pre=p2, stats=s3)
     if 'downsample.0.weight' in P:
-        idn = TC.conv_fwd(x, P['downsample.0.weight'], None, stride, 0, oihw=True)
-        idn, ctx['bnd'] = bn_fwd(P, 'downsample.1.', idn)
+        idn = TC.conv_fwd(x, P['downsample.0.weight'], None, stride, 0, oihw=True, stats=sd)
+        idn, ctx['bnd'] = bn_fwd(P, 'downsample.1.', idn, partials=sd)
     else:
         idn = x
-    y, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True, residual=idn)                   # relu(bn3(.) + identity) (resnet.py:136-140), one launch
-    ctx.update(a1=a1, a2=a2, y=y)
+    y, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True, residual=idn, partials=s3)      # relu(bn3(.) + identity) (resnet.py:136-140), one launch
+    ctx.update(a1=a1, a2=a2, p1=p1, p2=p2, y=y)
     return y, ctx
 
 
@@ -68,9 +95,9 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
     x, stride = ctx['x'], ctx['stride']
     g = O.relu_bwd(gy.contiguous(), ctx['y'])               # gradient of (bn3 out + identity)
     g3 = bn_bwd(P, 'bn3.', ctx['bn3'], g, G)
-    g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G)
+    g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G, pre=ctx.get('p2'))
     g2 = bn_bwd(P, 'bn2.', ctx['bn2'], g2, G, relu=True)
-    g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G)
+    g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G, pre=ctx.get('p1'))
     g1 = bn_bwd(P, 'bn1.', ctx['bn1'], g1, G, relu=True)
     # the identity / projection path's gradient joins conv1's data gradient in that convolution's epilogue (no separate dir_axpy_f32)
     if 'downsample.0.weight' in P:
@@ -85,18 +112,19 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
 # -------------------------------------------------------------------------------------------------------------------------- Residual
 def residual_forward(P, x):
     ctx = {'x': x}
-    a0, ctx['bn1'] = bn_fwd(P, 'bn1.', x, relu=True)
-    h = TC.conv_fwd(a0, P['conv1.conv.weight'], P['conv1.conv.bias'], oihw=True)
-    a1, ctx['bn2'] = bn_fwd(P, 'bn2.', h, relu=True)
-    h = TC.conv_fwd(a1, P['conv2.conv.weight'], P['conv2.conv.bias'], 1, 1, oihw=True)
-    a2, ctx['bn3'] = bn_fwd(P, 'bn3.', h, relu=True)
+    a0, p0, ctx['bn1'] = bn_relu_into_conv(P, 'bn1.', x)           # pre-activation block: every BatchNorm + ReLU feeds exactly one convolution
+    s2, s3 = [], []
+    h = TC.conv_fwd(a0, P['conv1.conv.weight'], P['conv1.conv.bias'], oihw=True, pre=p0, stats=s2)
+    a1, p1, ctx['bn2'] = bn_relu_into_conv(P, 'bn2.', h, partials=s2)
+    h = TC.conv_fwd(a1, P['conv2.conv.weight'], P['conv2.conv.bias'], 1, 1, oihw=True, pre=p1, stats=s3)
+    a2, p2, ctx['bn3'] = bn_relu_into_conv(P, 'bn3.', h, partials=s3)
     need_skip = P['skip_layer.conv.weight'].shape[0] != P['skip_layer.conv.weight'].shape[1]          # hourglass.py:49-52
     if need_skip:
-        y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True)
+        y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True, pre=p2)
         y = TC.conv_fwd(x, P['skip_layer.conv.weight'], P['skip_layer.conv.bias'], oihw=True, residual=y)       # + skip_layer(x), same launch
     else:
-        y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True, residual=x)
-    ctx.update(a0=a0, a1=a1, a2=a2, need_skip=need_skip)
+        y = TC.conv_fwd(a2, P['conv3.conv.weight'], P['conv3.conv.bias'], oihw=True, residual=x, pre=p2)
+    ctx.update(a0=a0, a1=a1, a2=a2, p0=p0, p1=p1, p2=p2, need_skip=need_skip)
     return y, ctx
 
 
@@ -104,11 +132,11 @@ def residual_backward(P, ctx, gy, need_gx=True):
     G = {}
     x = ctx['x']
     gy = gy.contiguous()
-    g = _conv_bwd(P, 'conv3.conv.', ctx['a2'], gy, 1, 0, G)
+    g = _conv_bwd(P, 'conv3.conv.', ctx['a2'], gy, 1, 0, G, pre=ctx.get('p2'))
     g = bn_bwd(P, 'bn3.', ctx['bn3'], g, G, relu=True)
-    g = _conv_bwd(P, 'conv2.conv.', ctx['a1'], g, 1, 1, G)
+    g = _conv_bwd(P, 'conv2.conv.', ctx['a1'], g, 1, 1, G, pre=ctx.get('p1'))
     g = bn_bwd(P, 'bn2.', ctx['bn2'], g, G, relu=True)
-    g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G)
+    g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G, pre=ctx.get('p0'))
     gx = bn_bwd(P, 'bn1.', ctx['bn1'], g, G, relu=True)
     if ctx['need_skip']:
         gs = _conv_bwd(P, 'skip_layer.conv.', x, gy, 1, 0, G, need_gx=need_gx, add_gx=gx if need_gx else None)      # + gx, same launch

@@ -29,6 +29,9 @@ WGRAD_ARITH = os.environ.get('DIR_TRAIN_WGRAD_ARITH', ARITH)          # the weig
 # f16 maximum make a stale scale a (bounded) precision loss, never an inf / nan.
 RECALIBRATE = int(os.environ.get('DIR_TRAIN_RECALIBRATE', '50'))
 PREPACK = os.environ.get('DIR_TRAIN_PREPACK', '1') == '1'          # WeightPack below (0: pack per convolution call, rounds 2-3)
+# round 5: conv_fwd(stats=[]) asks the convolution's epilogue for the chunk partials of the BatchNorm that follows it (dir_conv2d_forward_stats):
+# that BatchNorm's statistics pass over the stored map is not run.  DIR_TRAIN_STATS_IN_EPILOGUE=0: the separate statistics kernel (rounds 2-4).
+STATS_IN_EPILOGUE = os.environ.get('DIR_TRAIN_STATS_IN_EPILOGUE', '1') == '1'
 HEADROOM = 64.0             # pow2_in_scale puts the largest |operand| in [2^9, 2^10): 64x below the f16 maximum
 # (A step's backward must follow its own forward before another model's forward starts: the cache bound by begin_step stays active until
 # the next begin_step.)
@@ -235,14 +238,22 @@ def reset_scales(owner=None):
     end_step()
 
 
-def _site_scale(x):
-    if not _state.get('cached', False):          # no owner: measure (one host synchronisation per call site)
+def _measure(x, pre):
+    """the power-of-two operand scale of x as the convolution sees it: through the pre-activation max(x ps + pb, 0) when there is one (measured
+    exactly, on a temporary: this runs on calibration steps only)"""
+    if pre is None:
         return F.pow2_in_scale(x)
+    return F.pow2_in_scale(torch.relu(torch.addcmul(pre[1], x, pre[0])))
+
+
+def _site_scale(x, pre=None):
+    if not _state.get('cached', False):          # no owner: measure (one host synchronisation per call site)
+        return _measure(x, pre)
     i = _state['call']
     _state['call'] += 1
     if i < len(_scales) and _scales[i][0] == tuple(x.shape):
         return _scales[i][1]
-    s = F.pow2_in_scale(x)
+    s = _measure(x, pre)
     prev = _state.get('previous')
     if prev is not None and i < len(prev) and prev[i][0] == tuple(x.shape) and prev[i][1] >= HEADROOM * s:
         # the operand grew past the headroom the stale scale left: values were clamped at the f16 maximum somewhere in the last RECALIBRATE steps
@@ -254,15 +265,19 @@ def _site_scale(x):
     return s
 
 
-def _conv(x, w, stride, pad, shift=None, packed=None, residual=None):
-    """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient); residual: added in the epilogue"""
+def _conv(x, w, stride, pad, shift=None, packed=None, residual=None, pre=None, stats=None):
+    """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient); residual: added in the epilogue;
+    pre = (pre_scale, pre_shift) [Cin]: the convolution reads max(x pre_scale + pre_shift, 0) (a BatchNorm + ReLU that is not materialised)"""
+    pk = {} if pre is None else dict(pre_scale=pre[0], pre_shift=pre[1], pre_relu=True)
+    if stats is not None and STATS_IN_EPILOGUE:
+        pk['stats_out'] = stats          # the following BatchNorm's chunk partials from this convolution's epilogue (dir_conv2d_forward_stats)
     if ARITH != 'f16x3':
-        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, residual=residual)
+        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, residual=residual, **pk)
     shape = w.shape if packed is None else (packed[0].shape, packed[0].dshape)[packed[1]]
     presplit = shape[1] >= 3 or (shape[0] >= 512 and shape[3] >= 128)
-    s = _site_scale(x)
+    s = _site_scale(x, pre)
     if packed is None:
-        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, device_pack=True, presplit=presplit, residual=residual)
+        return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, device_pack=True, presplit=presplit, residual=residual, **pk)
     e, f = packed
     sc = (e.fwd_scale, e.dgrad_scale)[f]
     if e.applied[f] != s:                                  # (a calibration step, or a weight shared by sites of different magnitude)
@@ -272,7 +287,7 @@ def _conv(x, w, stride, pad, shift=None, packed=None, residual=None):
     elif e.want[f] is None:
         e.want[f] = s
     return F.conv2d_nhwc(x, None, stride=stride, pad=pad, shift=shift, arith='f16x3', in_scale=s, presplit=presplit,
-                         prepacked=((e.fwd, e.dgrad)[f], sc, shape), residual=residual)
+                         prepacked=((e.fwd, e.dgrad)[f], sc, shape), residual=residual, **pk)
 
 
 def _packed_of(w_oihw):
@@ -283,7 +298,7 @@ def _ohwi(w):
     return w.permute(0, 2, 3, 1).contiguous()
 
 
-def conv_fwd(x, w, bias=None, stride=1, pad=0, oihw=False, residual=None):
+def conv_fwd(x, w, bias=None, stride=1, pad=0, oihw=False, residual=None, pre=None, stats=None):
     """w: OHWI [Cout,kh,kw,Cin], or with oihw=True the reference-layout parameter [Cout,Cin,kh,kw] itself (packed once per step when the
     step has a WeightPack: begin_step).  residual [B,Ho,Wo,Cout]: y = conv(x) + bias + residual in the convolution's epilogue (a Residual
     block's skip path: one launch and two passes over the map less than a separate dir_axpy_f32)"""
@@ -292,12 +307,13 @@ def conv_fwd(x, w, bias=None, stride=1, pad=0, oihw=False, residual=None):
     if oihw:
         e = _packed_of(w)
         if e is not None and e.fwd is not None:
-            return _conv(x, None, stride, pad, bias, packed=(e, 0), residual=residual)
+            return _conv(x, None, stride, pad, bias, packed=(e, 0), residual=residual, pre=pre, stats=stats)
         w = _ohwi(w)
     cin = w.shape[3]
     if cin % 32:                                           # the 3-channel image: channels padded to the kernel's K granularity
+        assert pre is None
         x, w = _pad_last(x, 32), _pad_last(w, 32)
-    return _conv(x, w, stride, pad, bias, residual=residual)
+    return _conv(x, w, stride, pad, bias, residual=residual, pre=pre, stats=stats)
 
 
 def _pad_last(t, mult):
@@ -335,7 +351,9 @@ def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None):
     return gx
 
 
-def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
+def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False, pre=None):
+    """pre = (pre_scale, pre_shift): x is the INPUT of a BatchNorm + ReLU that the forward convolution applied on the fly (conv_fwd(pre=...)):
+    the weight gradient applies it the same way (dir_conv2d_wgrad_f16x3_pre)"""
     Cout, kh, kw, Cin = w_shape
     B, H, W, cs = x.shape
     O._chk(x, gy, out)
@@ -346,7 +364,7 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     # split-precision kernel for every layer wide enough to fill its 64-channel tiles (the 3-channel stem and the 1- / 3- / 6-channel heads keep
     # the exact fp32 kernel); one power-of-two scale per operand and call site, cached like the forward's (_site_scale)
     if WGRAD_ARITH == 'f16x3' and Cin % 4 == 0 and Cout % 4 == 0 and cs % 4 == 0 and gy.shape[3] % 4 == 0 and Cin >= 32 and Cout >= 32:
-        sx, sg = _site_scale(x), _site_scale(gy)
+        sx, sg = _site_scale(x, pre), _site_scale(gy)
         n = _capi.lib().dir_conv2d_wgrad_f16x3_workspace_bytes(d)
         if accumulate:
             n = max(n, out.numel() * 4)
@@ -354,9 +372,15 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
         if _capi.PROFILE is not None:
             _capi.annotate(family='wgrad', flops=2.0 * B * gy.shape[1] * gy.shape[2] * Cout * kh * kw * Cin, bytes=4.0 * (x.numel() + gy.numel() + Cout * kh * kw * Cin),
                            shape='wgrad M=%d Cout=%d Cin=%d k%d s%d' % (B * gy.shape[1] * gy.shape[2], Cout, Cin, kh, stride))
+        if pre is not None:
+            _capi.check(_capi.lib().dir_conv2d_wgrad_f16x3_pre(d, _capi.ptr(x), _capi.ptr(gy), _capi.ptr(out), int(accumulate), _capi.ptr(ws), n, sx, sg,
+                                                               _capi.ptr(pre[0]), _capi.ptr(pre[1]), 1, _capi.stream_ptr()), 'dir_conv2d_wgrad_f16x3_pre')
+            return out
         _capi.check(_capi.lib().dir_conv2d_wgrad_f16x3(d, _capi.ptr(x), _capi.ptr(gy), _capi.ptr(out), int(accumulate), _capi.ptr(ws), n, sx, sg,
                                                        _capi.stream_ptr()), 'dir_conv2d_wgrad_f16x3')
         return out
+    if pre is not None:                                    # (the exact-fp32 weight gradient has no pre-activation: materialise the operand)
+        x = torch.relu(torch.addcmul(pre[1], x, pre[0]))
     n = _capi.lib().dir_conv2d_wgrad_workspace_bytes(d)
     if accumulate:
         n = max(n, out.numel() * 4)
@@ -369,14 +393,14 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False):
     return out
 
 
-def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False):
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False, pre=None):
     """-> (gx (+ add_gx), gw [Cout,kh,kw,Cin] ([Cout,Cin,kh,kw] with gw_oihw), gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd).
     Inside a backward pass (side_begin) gw is produced on the side stream: valid on the compute stream after side_end."""
     gy = gy.contiguous()
     shape = (w.shape[0], w.shape[2], w.shape[3], w.shape[1]) if oihw else w.shape
 
     def wgrad():
-        g = conv_wgrad(x, gy, shape, stride, pad)
+        g = conv_wgrad(x, gy, shape, stride, pad, pre=pre)
         return g.permute(0, 3, 1, 2).contiguous() if gw_oihw else g
     gw = side_run(wgrad, x, gy)
     gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None

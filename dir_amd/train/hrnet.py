@@ -67,17 +67,17 @@ def cb_backward(P, pre, s, gy, G, need_gx=True, add_gx=None):
 def basic_forward(P, x):
     """BasicBlock: conv3x3 bn relu conv3x3 bn, + x, relu"""
     h = TC.conv_fwd(x, P['conv1.weight'], None, 1, 1, oihw=True)
-    a1, s1 = TB.bn_fwd(P, 'bn1.', h, relu=True)
-    h = TC.conv_fwd(a1, P['conv2.weight'], None, 1, 1, oihw=True)
+    a1, p1, s1 = TB.bn_relu_into_conv(P, 'bn1.', h)          # widths that are whole 32-channel slabs: applied where conv2 reads the map (round 5)
+    h = TC.conv_fwd(a1, P['conv2.weight'], None, 1, 1, oihw=True, pre=p1)
     y, s2 = TB.bn_fwd(P, 'bn2.', h, relu=True, residual=x)
-    return y, dict(x=x, a1=a1, bn1=s1, bn2=s2, y=y)
+    return y, dict(x=x, a1=a1, p1=p1, bn1=s1, bn2=s2, y=y)
 
 
 def basic_backward(P, s, gy):
     G = {}
     g = O.relu_bwd(gy.contiguous(), s['y'])                  # gradient of (bn2 out + x)
     g2 = TB.bn_bwd(P, 'bn2.', s['bn2'], g, G)
-    g1 = TB._conv_bwd(P, 'conv2.', s['a1'], g2, 1, 1, G)
+    g1 = TB._conv_bwd(P, 'conv2.', s['a1'], g2, 1, 1, G, pre=s.get('p1'))
     g1 = TB.bn_bwd(P, 'bn1.', s['bn1'], g1, G, relu=True)
     gx = TB._conv_bwd(P, 'conv1.', s['x'], g1, 1, 1, G, add_gx=g)
     return gx, G

@@ -106,9 +106,9 @@ def _stage_image_forward(P, pre, tok, uv_l, uv_r, S, distance, want_vis=False):
         # bone_proj + fusion.0 as a K = 720 reduction in exact fp32 (dir_bone_fusion_*): no [B,S,S,2560] map, no 23 040-deep convolution
         fpre = pre + 'fusion.'
         h, c_bf = SP.bone_fusion_fwd(uv_l, uv_r, emb, SP.fusion_w_g(P[fpre + '0.weight']), P.get(fpre + '0.bias'), S, distance)
-        a, s_bn = TB.bn_fwd(P, fpre + '1.', h, relu=True)
-        img_feat = TC.conv_fwd(a, P[fpre + '3.weight'], P.get(fpre + '3.bias'), oihw=True)
-        c_fus = dict(bf=c_bf, bn=s_bn, a=a)
+        a, pa, s_bn = TB.bn_relu_into_conv(P, fpre + '1.', h)          # fusion.1 / .2 applied where fusion.3 reads the map (round 5)
+        img_feat = TC.conv_fwd(a, P[fpre + '3.weight'], P.get(fpre + '3.bias'), oihw=True, pre=pa)
+        c_fus = dict(bf=c_bf, bn=s_bn, a=a, pa=pa)
         if want_vis:
             vis = SP.bone_proj_vis(uv_l, uv_r, emb, S, distance)
     else:
@@ -124,7 +124,7 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
     B = s['emb'].shape[0]
     if 'bf' in s['fus']:
         fpre, f = pre + 'fusion.', s['fus']
-        g = TB._conv_bwd(P, fpre + '3.', f['a'], g_img_feat, 1, 0, G)
+        g = TB._conv_bwd(P, fpre + '3.', f['a'], g_img_feat, 1, 0, G, pre=f.get('pa'))
         g = TB.bn_bwd(P, fpre + '1.', f['bn'], g, G, relu=True)
         g_w_g, g_emb, gul, gur = SP.bone_fusion_bwd(f['bf'], g)
         G[fpre + '0.weight'] = SP.fusion_w_g_grad_to_oihw(g_w_g)

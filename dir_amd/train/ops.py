@@ -1,5 +1,7 @@
 """Thin tensor front ends of the training building blocks of libdir_hip.so (include/dir_hip.h: dir_gemm_f32, dir_layernorm_*, dir_gelu_*,
 dir_attention_*, dir_bn_train_*).  Plumbing only: shapes, strides, output allocation -- every arithmetic step is a library call."""
+import os
+
 import torch
 
 from .. import _capi
@@ -241,6 +243,69 @@ def bn_train_fwd(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentu
     if written:
         torch._C._increment_version(written)
     return y, (sm, sr)
+
+
+# round 5: a training-mode BatchNorm (+ ReLU) whose ONLY consumer is a convolution is not applied as a pass of its own: dir_bn_train_stats forms the
+# statistics and the per-channel affine (pre_scale, pre_shift), and the consuming convolution (forward: dir_conv2d_forward's pre-activation or
+# dir_split_f16_forward's; weight gradient: dir_conv2d_wgrad_f16x3_pre) applies max(x pre_scale + pre_shift, 0) where it reads x.  One launch and
+# two passes over the map less per layer, and the normalised map is not stored for the backward pass.  DIR_TRAIN_FUSE_BN=0 switches it off.
+FUSE_BN = os.environ.get('DIR_TRAIN_FUSE_BN', '1') == '1'
+FUSE_BN_MIN_ROWS = 513          # dir_bn_train_stats: maps above BN_SMALL_R rows (smaller ones are one cooperative launch already)
+
+
+def bn_can_fuse(x2d, w, b):
+    R, C = x2d.shape
+    return (FUSE_BN and not BN_FROZEN and R >= FUSE_BN_MIN_ROWS and C % 32 == 0 and w is not None and b is not None and x2d.data_ptr() % 16 == 0
+            and not _sync_active(C, x2d, w, b))
+
+
+def bn_train_stats(x, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """statistics of BatchNorm (training mode) over x [R, C] without the normalised map: -> ((save_mean, save_rstd), (pre_scale, pre_shift));
+    running statistics updated in place like bn_train_fwd"""
+    _chk(x, w, b, running_mean, running_var)
+    R, C = x.shape
+    sm, sr, ps, pb = (torch.empty(C, device=x.device) for _ in range(4))
+    ws, n = _bn_ws(R, C, x.device)
+    _capi.check(_capi.lib().dir_bn_train_stats(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(ps), _capi.ptr(pb),
+                                               _capi.ptr(running_mean), _capi.ptr(running_var), R, C, C, float(eps), float(momentum), _capi.ptr(ws), n,
+                                               _capi.stream_ptr()), 'dir_bn_train_stats')
+    written = [t for t in (running_mean, running_var) if t is not None]
+    if written:
+        torch._C._increment_version(written)
+    return (sm, sr), (ps, pb)
+
+
+def bn_partials_usable(x2d, w, b, partials, residual=None):
+    """partials: what conv_fwd(stats=[...]) collected -- usable when the convolution's kernel formed them and this BatchNorm runs the plain path"""
+    R, C = x2d.shape
+    return (bool(partials) and partials[-1][2] > 0 and FUSE_BN and not BN_FROZEN and R >= FUSE_BN_MIN_ROWS and C % 4 == 0 and w is not None and b is not None
+            and x2d.data_ptr() % 16 == 0 and (residual is None or residual.data_ptr() % 16 == 0) and not _sync_active(C, x2d, w, b))
+
+
+def bn_train_stats_from_partials(partials, R, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, want_pre=True):
+    """bn_train_stats without reading the map: the chunk partials came out of the producing convolution's epilogue (p1, p2, rows per chunk)"""
+    p1, p2, rows = partials
+    C = p1.shape[-1]
+    _chk(p1, p2, w, b, running_mean, running_var)
+    sm, sr = torch.empty(C, device=p1.device), torch.empty(C, device=p1.device)
+    ps, pb = (torch.empty(C, device=p1.device), torch.empty(C, device=p1.device)) if want_pre else (None, None)
+    _capi.check(_capi.lib().dir_bn_train_stats_from_partials(_capi.ptr(p1), _capi.ptr(p2), rows, p1.shape[0], _capi.ptr(w), _capi.ptr(b), _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(ps),
+                                                             _capi.ptr(pb), _capi.ptr(running_mean), _capi.ptr(running_var), R, C, float(eps), float(momentum),
+                                                             _capi.stream_ptr()), 'dir_bn_train_stats_from_partials')
+    written = [t for t in (running_mean, running_var) if t is not None]
+    if written:
+        torch._C._increment_version(written)
+    return (sm, sr), (ps, pb)
+
+
+def bn_train_apply(x, w, b, stats, relu=False, residual=None):
+    """y = act(BatchNorm(x) + residual) from statistics already formed (the third launch of bn_train_fwd)"""
+    _chk(x, w, b, residual)
+    R, C = x.shape
+    y = torch.empty_like(x)
+    _capi.check(_capi.lib().dir_bn_train_apply(_capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(stats[0]), _capi.ptr(stats[1]), _capi.ptr(y), R, C, C, int(relu),
+                                               _capi.ptr(residual), _capi.stream_ptr()), 'dir_bn_train_apply')
+    return y
 
 
 def bn_train_bwd(gy, x, w, stats, need_gx=True, b=None, relu=False):

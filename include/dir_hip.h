@@ -199,6 +199,27 @@ int dir_bn_train_forward(const float* x, const float* w, const float* b, float* 
                          float* workspace, long long workspace_bytes, void* stream);
 int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                           float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
+/* round 5 -- BatchNorm2d (training mode) whose output feeds exactly ONE convolution (Bottleneck bn1 / bn2, models/backbone/resnet.py:125-131;
+ * every BatchNorm of the pre-activation Residual, models/backbone/hourglass.py:60-67): only the statistics are formed here (the same kernels and bits
+ * as dir_bn_train_forward: save_mean, save_rstd, running statistics) plus pre_scale = w rstd and pre_shift = b - mean w rstd [C]; the normalised
+ * map is never written -- the consuming convolution applies act(x pre_scale + pre_shift) where it reads x (dir_conv2d_forward's pre_scale /
+ * pre_shift + DIR_CONV_PRE_RELU, dir_split_f16_forward's, and dir_conv2d_wgrad_f16x3_pre for its weight gradient).  dir_bn_train_backward is
+ * unchanged (it re-computes the ReLU mask from x).  R > 512 rows, C % 4 == 0 (the Python step takes it for C % 32 == 0: whole reduction slabs of the consumer); workspace: dir_bn_train_workspace_bytes(R, C). */
+int dir_bn_train_stats(const float* x, const float* w, const float* b, float* save_mean, float* save_rstd, float* pre_scale, float* pre_shift,
+                       float* running_mean, float* running_var, int R, int C, int ld, float eps, float momentum, float* workspace,
+                       long long workspace_bytes, void* stream);
+/* ... from chunk partials the PRODUCING convolution's epilogue formed (dir_conv2d_forward_stats: the map is not read again for its statistics):
+ * p1 / p2 [ceil(R / chunk_rows)][C] = per chunk the column sums and the sums of squared deviations from the chunk's own mean; combined in chunk
+ * order like dir_bn_train_forward's (deterministic).  pre_scale / pre_shift may both be NULL (a BatchNorm that is applied by dir_bn_train_apply).
+ * cap_rows: how many rows of C floats p1 and p2 each have room for; with more than 256 chunks and cap_rows >= chunks + ceil(chunks / 32) the chunks
+ * are first pooled in groups of 32 behind the chunk rows (one more launch, both short) -- the buffers are scratch after the call. */
+int dir_bn_train_stats_from_partials(float* p1, float* p2, int chunk_rows, int cap_rows, const float* w, const float* b, float* save_mean, float* save_rstd,
+                                     float* pre_scale, float* pre_shift, float* running_mean, float* running_var, int R, int C, float eps, float momentum,
+                                     void* stream);
+/* the normalisation alone from statistics already formed: y = act(BatchNorm(x) + residual), the third launch of dir_bn_train_forward (a Bottleneck's
+ * bn3 + identity + ReLU, models/backbone/resnet.py:133-140, whose statistics came out of conv3's epilogue).  C % 4 == 0, 16-byte aligned. */
+int dir_bn_train_apply(const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* y, int R, int C, int ld,
+                       int relu, const float* residual, void* stream);
 /* BatchNorm with FROZEN statistics inside a training pass (a BatchNorm module put in .eval() under model.train(): torch then normalises with the
  * running statistics and leaves them alone -- torch/nn/modules/batchnorm.py; the reference never freezes them, train.py:64; this form exists
  * because the reference's whole-step gradient is only reproducible (to 4e-5) with it: tests/golden G20e): y = (x - running_mean) / sqrt(running_var
@@ -360,6 +381,13 @@ typedef struct dir_conv_desc {
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
+/* round 5 -- dir_conv2d_forward (no residual, no activation, whole fp32 output tensor) that ALSO forms the chunk partials of the training-mode
+ * BatchNorm that follows the convolution (nn.Conv2d -> nn.BatchNorm2d, models/backbone/resnet.py:123-133, hourglass.py:14-27) from the output
+ * tile while it is in registers: p1 / p2 [ceil(M / rows)][Cout] (room for ceil(M / 64) x Cout floats each), *chunk_rows = rows (the M tile of the
+ * kernel that took the launch: 64 / 128 / 256), or 0 when that kernel does not form them -- then run dir_bn_train_stats on y.  Feed them to
+ * dir_bn_train_stats_from_partials. */
+int dir_conv2d_forward_stats(const dir_conv_desc* desc, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
+                             const float* pre_shift, void* y, float* p1, float* p2, int* chunk_rows, void* stream);
 
 /* fp32 NHWC channel slice x[pixel][in_cstride] (channels [in_coff, in_coff + C)) -> y = the pre-split operand of DIR_DT_F16X3P / F16X1P:
  * v = x (* pre_scale + pre_shift, ReLU if pre_relu: the pre-activation of hourglass.Residual) * in_scale, clamped to +-65504, stored per
@@ -429,6 +457,12 @@ int dir_conv2d_wgrad_f32(const dir_conv_desc* d, const float* x, const float* gy
 long long dir_conv2d_wgrad_f16x3_workspace_bytes(const dir_conv_desc* d);
 int dir_conv2d_wgrad_f16x3(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
                            long long workspace_bytes, float x_scale, float gy_scale, void* stream);
+/* the same with a pre-activation on the x operand: x <- act(x pre_scale[c] + pre_shift[c]) per input channel (pre_relu != 0: max(., 0)) where the
+ * kernel reads it, padding taps zero -- the weight gradient of a convolution whose input is a BatchNorm (+ ReLU) that was never materialised
+ * (dir_bn_train_stats).  x_scale is the power-of-two scale of the ACTIVATED operand. */
+int dir_conv2d_wgrad_f16x3_pre(const dir_conv_desc* d, const float* x, const float* gy, float* gw, int accumulate, float* workspace,
+                               long long workspace_bytes, float x_scale, float gy_scale, const float* pre_scale, const float* pre_shift, int pre_relu,
+                               void* stream);
 
 /* A convolution with a SECOND source accumulated into the same output tile:
  *   y = epilogue( conv(x; kh x kw, stride, pad) + conv1x1(x2; stride2) )
@@ -492,6 +526,11 @@ int dir_upsample2x_bilinear(const void* x, void* y, int B, int H, int W, int C, 
 /* f4 (HRNet fuse layers; no reference counterpart): acc [B,H,W,C] = act(acc + nearest_upsample(src [B,H/f,W/f,C], f)), in place, one term
  * of `y = y + fuse_layers[i][j](x[j])` at a time; factor 1 = a plain add; relu != 0 on the last term (the fuse layer's ReLU). */
 int dir_add_upsampled(void* acc, const void* src, int B, int H, int W, int C, int factor, int relu, int dtype, void* stream);
+/* the whole fuse row in one pass (round 5): out [B,H,W,C] = act(base + sum over t < nsrc (<= 4) of nearest_upsample(srcs[t] [B,H/f_t,W/f_t,C], f_t)),
+ * summed in fp32 in source order and rounded once; out may be base.  `y = sum_j fuse_layers[i][j](x[j])` + ReLU of an HRNet module (no reference
+ * counterpart): 2 passes over the row's map instead of 2 per term + a copy. */
+int dir_fuse_sum(void* out, const void* base, const void* const* srcs, const int* factors, int nsrc, int B, int H, int W, int C, int relu, int dtype,
+                 void* stream);
 
 /* InitRegressor tail (models/dir.py:263-270): 1x1 conv Ch->1 + sigmoid attention, attention-weighted pooling
  * of c4 (+1e-8), plain mean, Linear C->64 (left, right) and C->3 (offset). */

@@ -1,0 +1,145 @@
+"""Round 5: a training-mode BatchNorm + ReLU whose only consumer is a convolution is applied where that convolution READS the map
+(dir_bn_train_stats -> pre_scale / pre_shift; dir_conv2d_forward's pre-activation / dir_split_f16_forward's; dir_conv2d_wgrad_f16x3_pre)
+instead of in a pass of its own (models/backbone/resnet.py:125-131 bn1 / bn2, models/backbone/hourglass.py:60-67).  Held to the unfused
+step (same statistics bits, outputs and gradients to fp32 rounding) and -- through tests/test_gpu_blocks_bwd.py, test_gpu_full_bwd.py -- to the
+reference's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from dir_amd import _capi
+from dir_amd.train import blocks as TB
+from dir_amd.train import conv as TC
+from dir_amd.train import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def test_bn_train_stats_gives_the_statistics_of_bn_train_forward():
+    g = torch.Generator(device='cuda').manual_seed(11)
+    for R, C in ((3000, 64), (8192, 256), (700, 32)):
+        x = torch.randn(R, C, device='cuda', generator=g) * 3 + 0.7
+        w, b = torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g)
+        rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+        rm2, rv2 = rm.clone(), rv.clone()
+        y, (sm, sr) = O.bn_train_fwd(x, w, b, rm, rv, relu=True)
+        (sm2, sr2), (ps, pb) = O.bn_train_stats(x, w, b, rm2, rv2)
+        assert torch.equal(sm, sm2) and torch.equal(sr, sr2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
+        y2 = torch.relu(x * ps + pb)
+        assert float((y - y2).abs().max()) < 1e-5 * float(y.abs().max())
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 32, 64, 64, 3, 1), (2, 64, 64, 128, 256, 1, 1), (3, 17, 20, 32, 96, 3, 2), (2, 16, 16, 256, 128, 1, 1)])
+def test_wgrad_with_pre_activation_equals_wgrad_of_the_materialised_operand(shape):
+    B, H, W, Cin, Cout, k, stride = shape
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(B, H, W, Cin, device='cuda', generator=g)
+    ps, pb = torch.rand(Cin, device='cuda', generator=g) + 0.5, torch.randn(Cin, device='cuda', generator=g) * 0.5
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randn(B, Ho, Wo, Cout, device='cuda', generator=g)
+    a = torch.relu(torch.addcmul(pb, x, ps))
+    TC.end_step()
+    want = TC.conv_wgrad(a, gy, (Cout, k, k, Cin), stride, pad)
+    got = TC.conv_wgrad(x, gy, (Cout, k, k, Cin), stride, pad, pre=(ps, pb))
+    assert rel(got, want) < 2e-6, rel(got, want)          # (the operand differs by the rounding of fmaf vs multiply-add only)
+
+
+@pytest.mark.parametrize('kind', ['bottleneck', 'bottleneck_s2', 'residual', 'residual_skip'])
+def test_blocks_with_the_batchnorm_applied_in_the_consumer_equal_the_unfused_blocks(kind):
+    g = torch.Generator(device='cuda').manual_seed(3)
+
+    def rnd(*s, scale=1.0):
+        return torch.randn(*s, device='cuda', generator=g) * scale
+    B, S = 4, 32
+    if kind.startswith('bottleneck'):
+        stride = 2 if kind.endswith('s2') else 1
+        cin, pl = 256, 64
+        P = {'conv1.weight': rnd(pl, cin, 1, 1, scale=0.06), 'conv2.weight': rnd(pl, pl, 3, 3, scale=0.04), 'conv3.weight': rnd(4 * pl, pl, 1, 1, scale=0.1)}
+        for n, c in (('bn1.', pl), ('bn2.', pl), ('bn3.', 4 * pl)):
+            P.update({n + 'weight': torch.rand(c, device='cuda', generator=g) + 0.5, n + 'bias': rnd(c, scale=0.3), n + 'running_mean': torch.zeros(c, device='cuda'),
+                      n + 'running_var': torch.ones(c, device='cuda')})
+        if stride == 2:
+            P['downsample.0.weight'] = rnd(4 * pl, cin, 1, 1, scale=0.06)
+            P.update({'downsample.1.weight': torch.rand(4 * pl, device='cuda', generator=g) + 0.5, 'downsample.1.bias': rnd(4 * pl, scale=0.3),
+                      'downsample.1.running_mean': torch.zeros(4 * pl, device='cuda'), 'downsample.1.running_var': torch.ones(4 * pl, device='cuda')})
+        fwd = lambda P_, x_: TB.bottleneck_forward(P_, x_, stride)          # noqa: E731
+        bwd = TB.bottleneck_backward
+        x = rnd(B, S, S, cin)
+    else:
+        cin, cout = (128, 256) if kind.endswith('skip') else (256, 256)
+        mid = cout // 2
+        P = {'conv1.conv.weight': rnd(mid, cin, 1, 1, scale=0.08), 'conv1.conv.bias': rnd(mid, scale=0.1), 'conv2.conv.weight': rnd(mid, mid, 3, 3, scale=0.03),
+             'conv2.conv.bias': rnd(mid, scale=0.1), 'conv3.conv.weight': rnd(cout, mid, 1, 1, scale=0.08), 'conv3.conv.bias': rnd(cout, scale=0.1),
+             'skip_layer.conv.weight': rnd(cout, cin, 1, 1, scale=0.08), 'skip_layer.conv.bias': rnd(cout, scale=0.1)}
+        for n, c in (('bn1.', cin), ('bn2.', mid), ('bn3.', mid)):
+            P.update({n + 'weight': torch.rand(c, device='cuda', generator=g) + 0.5, n + 'bias': rnd(c, scale=0.3), n + 'running_mean': torch.zeros(c, device='cuda'),
+                      n + 'running_var': torch.ones(c, device='cuda')})
+        fwd, bwd = TB.residual_forward, TB.residual_backward
+        x = rnd(B, S, S, cin)
+    res = {}
+    for fused in (False, True):
+        O.FUSE_BN = fused
+        try:
+            Pc = {k: v.clone() for k, v in P.items()}
+            TC.end_step()
+            y, ctx = fwd(Pc, x)
+            assert ('p1' in ctx and ctx['p1'] is not None) == fused
+            gy = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(9))
+            gx, G = bwd(Pc, ctx, gy)
+            res[fused] = (y, gx, G, Pc)
+        finally:
+            O.FUSE_BN = True
+    (y0, gx0, G0, P0), (y1, gx1, G1, P1) = res[False], res[True]
+    assert rel(y1, y0) < 2e-6 and rel(gx1, gx0) < 2e-5, (rel(y1, y0), rel(gx1, gx0))
+    assert set(G0) == set(G1)
+    gmax = max(float(v.abs().max()) for v in G0.values())
+    for k in G0:
+        if k in ('conv1.conv.bias', 'conv2.conv.bias'):          # a bias in front of a BatchNorm: its gradient is rounding noise around zero both ways
+            assert float(G1[k].abs().max()) < 1e-4 * gmax and float(G0[k].abs().max()) < 1e-4 * gmax, k
+            continue
+        assert rel(G1[k], G0[k]) < 2e-5, (k, rel(G1[k], G0[k]))
+    for k in P0:
+        if 'running' in k:
+            assert rel(P1[k], P0[k]) < 1e-6, k
+
+
+@pytest.mark.parametrize('shape', [(4, 32, 32, 64, 64, 3, 1), (2, 64, 64, 64, 256, 1, 1), (32, 16, 16, 256, 256, 3, 1), (3, 17, 20, 32, 96, 3, 2),
+                                   (8, 8, 8, 512, 2048, 1, 1), (2, 64, 64, 256, 64, 1, 1)])
+def test_convolution_epilogue_forms_the_chunk_partials_of_the_following_batchnorm(shape):
+    """dir_conv2d_forward_stats: p1 = per M tile and channel the sum of the output's valid rows, p2 = the sum of squared deviations from the tile mean;
+    the BatchNorm statistics combined from them equal those formed from the stored map (dir_bn_train_forward)"""
+    B, H, W, Cin, Cout, k, stride = shape
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(B, H, W, Cin, device='cuda', generator=g)
+    w = torch.randn(Cout, Cin, k, k, device='cuda', generator=g) * (1.0 / (Cin * k * k) ** 0.5)
+    bias = torch.randn(Cout, device='cuda', generator=g)
+    TC.end_step()
+    st = []
+    y = TC.conv_fwd(x, w, bias, stride, k // 2, oihw=True, stats=st)
+    y0 = TC.conv_fwd(x, w, bias, stride, k // 2, oihw=True)
+    assert torch.equal(y, y0)
+    assert len(st) == 1 and st[0][2] in (64, 128, 256), st and st[0][2]
+    p1, p2, rows = st[0]
+    y2 = y.reshape(-1, Cout).double()
+    R = y2.shape[0]
+    nch = (R + rows - 1) // rows
+    for c in range(nch):
+        blk = y2[c * rows:(c + 1) * rows]
+        s1 = blk.sum(0)
+        m2 = ((blk - blk.mean(0)) ** 2).sum(0)
+        assert float((p1[c].double() - s1).abs().max()) < 1e-5 * float(s1.abs().max() + blk.abs().max()), (c, 'sum')
+        assert float((p2[c].double() - m2).abs().max()) < 1e-5 * float(m2.abs().max()), (c, 'M2')
+    if R > 512:
+        wbn, bbn = torch.rand(Cout, device='cuda', generator=g) + 0.5, torch.randn(Cout, device='cuda', generator=g)
+        rm, rv = torch.zeros(Cout, device='cuda'), torch.ones(Cout, device='cuda')
+        rm2, rv2 = rm.clone(), rv.clone()
+        yb, (sm, sr) = O.bn_train_fwd(y.view(-1, Cout), wbn, bbn, rm, rv, relu=True)
+        (sm2, sr2), (ps, pb) = O.bn_train_stats_from_partials(st[0], R, wbn, bbn, rm2, rv2)
+        assert rel(sm2, sm) < 1e-5 and rel(sr2, sr) < 1e-5 and rel(rm2, rm) < 1e-5 and rel(rv2, rv) < 1e-5
+        ya = O.bn_train_apply(y.view(-1, Cout), wbn, bbn, (sm2, sr2), relu=True)
+        assert float((ya - yb).abs().max()) < 1e-5 * float(yb.abs().max())

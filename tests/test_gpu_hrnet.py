@@ -29,6 +29,31 @@ def test_dir_add_upsampled():
                 assert torch.equal(a, w), (dt, f, relu)
 
 
+def test_dir_fuse_sum_is_the_sum_rounded_once():
+    """out = act(base + sum_t up(src_t, f_t)) in fp32, one rounding (dir_fuse_sum); in place and into a new map; 0 .. 4 sources"""
+    import ctypes as C
+    from dir_amd import _capi
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1), (torch.float16, _capi.DT_F16)):
+        base = torch.randn(3, 16, 24, 64, device='cuda', generator=g).to(dt)
+        for facs in ((), (1,), (2, 4, 8), (1, 2, 4, 8)):
+            srcs = [torch.randn(3, 16 // f, 24 // f, 64, device='cuda', generator=g).to(dt) for f in facs]
+            want = base.float()
+            for f, t in zip(facs, srcs):
+                want = want + t.float().repeat_interleave(f, 1).repeat_interleave(f, 2)
+            n = len(facs)
+            ps = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in srcs])
+            fs = (C.c_int * max(n, 1))(*facs)
+            for relu in (0, 1):
+                w = (torch.relu(want) if relu else want).to(dt)
+                out = torch.empty_like(base)
+                _capi.check(_capi.lib().dir_fuse_sum(_capi.ptr(out), _capi.ptr(base), ps, fs, n, 3, 16, 24, 64, relu, code, _capi.stream_ptr()), 'fuse_sum')
+                assert torch.equal(out, w), (dt, facs, relu)
+                a = base.clone()
+                _capi.check(_capi.lib().dir_fuse_sum(_capi.ptr(a), _capi.ptr(a), ps, fs, n, 3, 16, 24, 64, relu, code, _capi.stream_ptr()), 'fuse_sum')
+                assert torch.equal(a, w), (dt, facs, relu, 'in place')
+
+
 @pytest.mark.parametrize('mode', ['f32', 'f16x3', 'f16', 'bf16', 'f16s'])
 def test_hrnet_w48_backbone_vs_oracle(mode):
     from dir_amd.engine import HRNetOp

@@ -14,10 +14,11 @@ del net
 sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234, cond=True).items()}
 g = torch.Generator(device='cuda').manual_seed(5)
 img = torch.randn(B, 3, 256, 256, device='cuda', generator=g)
-eng = DirEngine(sd, dtype=torch.bfloat16)
+eng = DirEngine(sd, dtype={'bf16': torch.bfloat16, 'f16': torch.float16}[os.environ.get('DTYPE', 'f16')])
 eng.calibrate(img)
 eng.forward(img); torch.cuda.synchronize()
-eng.autotune(img, reps=1)
+if os.environ.get('AUTOTUNE', '1') == '1':          # AUTOTUNE=0: the trace then holds the forwards only (heuristic kernel choice), not every candidate variant
+    eng.autotune(img, reps=1)
 torch.cuda.synchronize()
 print('PROFILE_BEGIN', flush=True)
 for _ in range(10):
