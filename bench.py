@@ -785,6 +785,24 @@ def main():
                  'peak_memory_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                  'note': 'dir_amd.train.step.train_step on one GPU (no exchange partner): training-mode forward, 42-term objective, backward, flat '
                          'gradient bucket, one AdamW launch; eager, about 1300 library calls + 300 torch operators per step, every convolution weight packed by one launch (round 2: 0.088 s, round 3: 0.047 s; DESIGN.md section 10)'}
+        # the same step with everything but the optimiser replayed as one HIP graph (dir_amd.train.step.GraphedTrainStep: same kernels, same bits):
+        # two eager calibration steps, one capture, then timed replays -- how a training loop would run it
+        try:
+            gstep = TSTEP.GraphedTrainStep(tparams, tbuf, topt, tfaces)
+            for _ in range(4):
+                gstep(timg, ttar, tmeta)
+            sync()
+            gt = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                gstep(timg, ttar, tmeta)
+                sync()
+                gt.append(time.perf_counter() - t0)
+            train['graph_captured_seconds_per_step'] = round(statistics.median(gt), 4)
+            train['graph_captured_images_per_sec'] = round(TB / statistics.median(gt), 1)
+            del gstep
+        except Exception as e:          # (the eager figure above stands on its own)
+            train['graph_captured_error'] = repr(e)[:200]
         del tparams, tbuf, topt
         torch.cuda.empty_cache()
 

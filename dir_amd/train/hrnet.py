@@ -53,8 +53,9 @@ def _up_bwd(gy, f):
 
 def cb_forward(P, pre, x, stride, pad, relu, residual=None):
     """Sequential(Conv2d(bias=False), BatchNorm2d) (+ ReLU) (+ residual before it): keys pre + '0.weight', pre + '1.*'"""
-    h = TC.conv_fwd(x, P[pre + '0.weight'], None, stride, pad, oihw=True)
-    y, s_bn = TB.bn_fwd(P, pre + '1.', h, relu=relu, residual=residual)
+    st = []                                                # the BatchNorm's chunk partials from the convolution's epilogue (round 5)
+    h = TC.conv_fwd(x, P[pre + '0.weight'], None, stride, pad, oihw=True, stats=st)
+    y, s_bn = TB.bn_fwd(P, pre + '1.', h, relu=relu, residual=residual, partials=st)
     return y, dict(x=x, bn=s_bn, stride=stride, pad=pad, relu=relu)
 
 
@@ -66,10 +67,11 @@ def cb_backward(P, pre, s, gy, G, need_gx=True, add_gx=None):
 
 def basic_forward(P, x):
     """BasicBlock: conv3x3 bn relu conv3x3 bn, + x, relu"""
-    h = TC.conv_fwd(x, P['conv1.weight'], None, 1, 1, oihw=True)
-    a1, p1, s1 = TB.bn_relu_into_conv(P, 'bn1.', h)          # widths that are whole 32-channel slabs: applied where conv2 reads the map (round 5)
-    h = TC.conv_fwd(a1, P['conv2.weight'], None, 1, 1, oihw=True, pre=p1)
-    y, s2 = TB.bn_fwd(P, 'bn2.', h, relu=True, residual=x)
+    st1, st2 = [], []
+    h = TC.conv_fwd(x, P['conv1.weight'], None, 1, 1, oihw=True, stats=st1)
+    a1, p1, s1 = TB.bn_relu_into_conv(P, 'bn1.', h, partials=st1)          # widths that are whole 32-channel slabs: applied where conv2 reads the map (round 5)
+    h = TC.conv_fwd(a1, P['conv2.weight'], None, 1, 1, oihw=True, pre=p1, stats=st2)
+    y, s2 = TB.bn_fwd(P, 'bn2.', h, relu=True, residual=x, partials=st2)
     return y, dict(x=x, a1=a1, p1=p1, bn1=s1, bn2=s2, y=y)
 
 
@@ -198,8 +200,9 @@ def hrnet_forward(P, img, ctx, pre='backbone.'):
 
 
 def _stem(Pb, wkey, bnpre, x):
-    h = TC.conv_fwd(x, Pb[wkey], None, 2, 1, oihw=True)
-    y, s_bn = TB.bn_fwd(Pb, bnpre, h, relu=True)
+    st = []
+    h = TC.conv_fwd(x, Pb[wkey], None, 2, 1, oihw=True, stats=st)
+    y, s_bn = TB.bn_fwd(Pb, bnpre, h, relu=True, partials=st)
     return y, dict(x=x, bn=s_bn)
 
 

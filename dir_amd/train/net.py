@@ -78,8 +78,9 @@ def _stem_forward(P, img):
 
 def _cbr_forward(P, pre, x, k):
     """Sequential(Conv2d(k, pad k//2), BatchNorm2d, ReLU, Conv2d(1)) -- conv_final, seg, dense, attention_*, fusion (models/dir.py:57-62,227-241,404-419)"""
-    h = TC.conv_fwd(x, P[pre + '0.weight'], P.get(pre + '0.bias'), 1, k // 2, oihw=True)
-    a, s_bn = TB.bn_fwd(P, pre + '1.', h, relu=True)
+    st = []                                                # the BatchNorm's chunk partials from the convolution's epilogue (round 5)
+    h = TC.conv_fwd(x, P[pre + '0.weight'], P.get(pre + '0.bias'), 1, k // 2, oihw=True, stats=st)
+    a, s_bn = TB.bn_fwd(P, pre + '1.', h, relu=True, partials=st)
     y = TC.conv_fwd(a, P[pre + '3.weight'], P.get(pre + '3.bias'), oihw=True)
     return y, dict(x=x, bn=s_bn, a=a, k=k)
 
