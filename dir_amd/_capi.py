@@ -196,6 +196,7 @@ _SIGNATURES = {
     'dir_bn_train_stats': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p, C.c_longlong, _p]),
     'dir_bn_train_stats_from_partials': (C.c_int, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_float, C.c_float, _p]),
     'dir_bn_train_apply': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    'dir_bn_train_forward_from_partials': (C.c_int, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p]),
     'dir_bn_one_launch_status': (C.c_int, []),
     'dir_upsample_nearest_add_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'dir_upsample_nearest_backward_f32': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _p]),

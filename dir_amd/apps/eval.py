@@ -268,7 +268,8 @@ def main(argv=None):
     ap.add_argument('--bs', type=int, default=256)
     ap.add_argument('--root_joint', type=int, default=0)              # 0 wrist, 9 middle MCP
     ap.add_argument('--scale', type=lambda v: str(v).lower() not in ('0', 'false', 'no'), default=True)
-    ap.add_argument('--dtype', choices=['bf16', 'f32'], default='bf16', help='bf16 feature maps (throughput mode) or exact fp32 (parity mode)')
+    ap.add_argument('--dtype', choices=['f16', 'bf16', 'f32'], default='f16', help='f16 feature maps (the throughput mode of round 5: every stage inside 0.01 mm of the '
+                    'reference), bf16 feature maps (rounds 1-4: 0.04-0.05 mm at the init stage, 2 %% faster) or exact fp32 (parity mode)')
     ap.add_argument('--arith', choices=['f16x3', 'f16'], default=None, help="with --dtype f32: convolutions on the f16 matrix cores -- 'f16x3' split "
                     "precision (the 1e-4 mm parity mode at 10 k images/s), 'f16' one MFMA per product (every stage within 0.01 mm, 13 k images/s)")
     ap.add_argument('--source', choices=['jpeg', 'jpeg-host', 'u8'], default='jpeg', help="jpeg: <split>/img/<idx>.jpg as the reference prepares them (Huffman decode on the host, the rest of the decode on the GPU); jpeg-host: the whole decode on the host; u8: the prepared "
@@ -280,7 +281,7 @@ def main(argv=None):
     state = state['net'] if isinstance(state, dict) and 'net' in state else state
     if opt.arith is not None and opt.dtype != 'f32':
         ap.error('--arith needs --dtype f32 (fp32 feature maps, f16 matrix-core arithmetic)')
-    eng = DirEngine(state, dtype=torch.bfloat16 if opt.dtype == 'bf16' else torch.float32, root_joint=0, arith=opt.arith)     # apps/eval.py:104: DIR(21, './misc/mano')
+    eng = DirEngine(state, dtype={'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': torch.float32}[opt.dtype], root_joint=0, arith=opt.arith)     # apps/eval.py:104: DIR(21, './misc/mano')
     mano_layer = gt_layers_from_checkpoint(state)
     J_regressor = {s: Jr(mano_layer[s].J_regressor) for s in ('left', 'right')}
     m, rate = evaluate_from_disk(eng, opt.data_path, J_regressor, mano_layer, bs=opt.bs, root_joint=opt.root_joint, scale=opt.scale,

@@ -2120,6 +2120,15 @@ extern "C" int dir_bn_train_apply(const float* x, const float* w, const float* b
     DIR_LAUNCH(bn_apply_fwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w, b, save_mean, save_rstd, y, R, C, ld, relu, residual);
     return check_launch("dir_bn_train_apply");
 }
+// both in one call: statistics from the producing convolution's chunk partials, then y = act(BatchNorm(x) + residual)
+extern "C" int dir_bn_train_forward_from_partials(const float* x, float* p1, float* p2, int chunk_rows, int cap_rows, const float* w, const float* b, float* y,
+                                                  float* save_mean, float* save_rstd, float* running_mean, float* running_var, int R, int C, int ld, float eps,
+                                                  float momentum, int relu, const float* residual, void* stream) {
+    const int rc = dir_bn_train_stats_from_partials(p1, p2, chunk_rows, cap_rows, w, b, save_mean, save_rstd, nullptr, nullptr, running_mean, running_var, R, C, eps,
+                                                    momentum, stream);
+    if (rc != 0) return rc;
+    return dir_bn_train_apply(x, w, b, save_mean, save_rstd, y, R, C, ld, relu, residual, stream);
+}
 extern "C" int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                                      float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream) {
     using namespace dir;

@@ -29,8 +29,8 @@ def bn_fwd(P, pre, x, momentum=0.1, eps=1e-5, relu=False, residual=None, partial
         x2, w, b = x.view(-1, C), P.get(pre + 'weight'), P.get(pre + 'bias')
         r2 = None if residual is None else residual.contiguous().view(-1, C)
         if O.bn_partials_usable(x2, w, b, partials, r2):
-            st, _ = O.bn_train_stats_from_partials(partials[-1], x2.shape[0], w, b, P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum, want_pre=False)
-            return O.bn_train_apply(x2, w, b, st, relu=relu, residual=r2).view(x.shape), (x, st)
+            y, st = O.bn_train_fwd_from_partials(x2, partials[-1], w, b, P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum, relu=relu, residual=r2)
+            return y.view(x.shape), (x, st)
     y, st = O.bn_train_fwd(x.view(-1, C), P[pre + 'weight'], P[pre + 'bias'], P.get(pre + 'running_mean'), P.get(pre + 'running_var'), eps, momentum,
                            relu=relu, residual=None if residual is None else residual.contiguous().view(-1, C))
     return y.view(x.shape), (x, st)

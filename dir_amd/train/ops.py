@@ -298,6 +298,21 @@ def bn_train_stats_from_partials(partials, R, w, b, running_mean=None, running_v
     return (sm, sr), (ps, pb)
 
 
+def bn_train_fwd_from_partials(x, partials, w, b, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, relu=False, residual=None):
+    """bn_train_fwd whose statistics pass over x is replaced by the producing convolution's chunk partials (one library call)"""
+    p1, p2, rows = partials
+    _chk(x, p1, p2, w, b, running_mean, running_var, residual)
+    R, C = x.shape
+    y, sm, sr = torch.empty_like(x), torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    _capi.check(_capi.lib().dir_bn_train_forward_from_partials(_capi.ptr(x), _capi.ptr(p1), _capi.ptr(p2), rows, p1.shape[0], _capi.ptr(w), _capi.ptr(b), _capi.ptr(y),
+                                                               _capi.ptr(sm), _capi.ptr(sr), _capi.ptr(running_mean), _capi.ptr(running_var), R, C, C, float(eps),
+                                                               float(momentum), int(relu), _capi.ptr(residual), _capi.stream_ptr()), 'dir_bn_train_forward_from_partials')
+    written = [t for t in (running_mean, running_var) if t is not None]
+    if written:
+        torch._C._increment_version(written)
+    return y, (sm, sr)
+
+
 def bn_train_apply(x, w, b, stats, relu=False, residual=None):
     """y = act(BatchNorm(x) + residual) from statistics already formed (the third launch of bn_train_fwd)"""
     _chk(x, w, b, residual)

@@ -220,6 +220,11 @@ int dir_bn_train_stats_from_partials(float* p1, float* p2, int chunk_rows, int c
  * bn3 + identity + ReLU, models/backbone/resnet.py:133-140, whose statistics came out of conv3's epilogue).  C % 4 == 0, 16-byte aligned. */
 int dir_bn_train_apply(const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* y, int R, int C, int ld,
                        int relu, const float* residual, void* stream);
+/* dir_bn_train_stats_from_partials (without the affine) + dir_bn_train_apply in one call: dir_bn_train_forward whose statistics pass is replaced by the
+ * producing convolution's chunk partials. */
+int dir_bn_train_forward_from_partials(const float* x, float* p1, float* p2, int chunk_rows, int cap_rows, const float* w, const float* b, float* y,
+                                       float* save_mean, float* save_rstd, float* running_mean, float* running_var, int R, int C, int ld, float eps,
+                                       float momentum, int relu, const float* residual, void* stream);
 /* BatchNorm with FROZEN statistics inside a training pass (a BatchNorm module put in .eval() under model.train(): torch then normalises with the
  * running statistics and leaves them alone -- torch/nn/modules/batchnorm.py; the reference never freezes them, train.py:64; this form exists
  * because the reference's whole-step gradient is only reproducible (to 4e-5) with it: tests/golden G20e): y = (x - running_mean) / sqrt(running_var

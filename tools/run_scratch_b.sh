@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for e in "DIR_TRAIN_STATS_IN_EPILOGUE=0" "DIR_TRAIN_FUSE_BN=0" "X=1"; do
-  echo "=== $e"
-  env $e python -m pytest "tests/test_gpu_hrnet_train.py::test_hrnet_module_trains_like_torch_autograd" -q -s 2>&1 | grep -E "HRNet-W48 training|passed|failed|forward c1"
-done
+python -m pytest tests/test_gpu_bn_fused.py tests/test_gpu_blocks_bwd.py tests/test_gpu_hrnet_train.py tests/test_gpu_full_bwd.py -x -q 2>&1 | tail -4
+BACKBONE=hrnet_w48 TOP=3 python tools/bench_train.py 32 5 2>&1 | grep -v amdgpu.ids | head -4
+TOP=3 python tools/bench_train.py 32 7 2>&1 | grep -v amdgpu.ids | head -4
