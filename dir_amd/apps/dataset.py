@@ -128,6 +128,12 @@ def _decode_worker(data_path, split, wid, workers, indices, bs, chunk, ready, fr
     store for the flag."""
     import time
     torch.set_num_threads(1)
+    nice = int(os.environ.get('DIR_RING_NICE', '0'))          # tuning aid: run the decoders below the consumer's priority (the consumer issues the GPU's work)
+    if nice > 0:
+        try:
+            os.nice(nice)
+        except OSError:
+            pass
     ds = InterHandSplit(data_path, split)
     if records:
         from .jpeg import file_to_record

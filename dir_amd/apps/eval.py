@@ -175,6 +175,11 @@ def evaluate(network, dataloader, J_regressor, root_joint=0, scale=True, stage_n
     return m
 
 
+# tuning aid (tools/bench_fromdisk.py): DIR_EVAL_SKIP_DEVICE_DECODE=1 leaves the device half of the JPEG decode out of the loop (the forwards then see
+# stale frames: rates only) -- what the two decode kernels cost the loop under contention
+_SKIP_DEVICE_DECODE = __import__('os').environ.get('DIR_EVAL_SKIP_DEVICE_DECODE', '0') == '1'
+
+
 def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joint=0, scale=True, split='test', workers=8,
                        stage_num=3, indices=None, progress=None, source='jpeg', nslot=3):
     """apps/eval.py:121-241 from the prepared split on disk, at pipeline speed: decode processes (dataset.DecodeRing) -> pinned uint8
@@ -237,7 +242,7 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
                 annos_dev = annos.to(dev, non_blocking=True)
                 copied = torch.cuda.Event()
                 copied.record()                                        # both DMAs done = the ring's buffer is free: recorded BEFORE any kernel of this
-                if source == 'jpeg':                                   # slot, so the host never waits behind compute that queues with the other slots' forwards
+                if source == 'jpeg' and not _SKIP_DEVICE_DECODE:       # slot, so the host never waits behind compute that queues with the other slots' forwards
                     rec_dec[slot](rec_dev[slot], pipe.imgs[slot], n)   # the rest of the JPEG decode, straight into the slot's input
             pipe.launch(slot)
             pending[slot] = (n, annos_dev)

@@ -41,7 +41,7 @@ def _mode(rec):
         return None
     out = _pick(rec, ('images_per_sec', 'ms_per_step', 'forwards_in_flight', 'ms_per_forward_one_in_flight', 'batch_per_gpu', 'seconds_per_step',
                       'launches_per_step', 'frac_of_f16x3_mfma_peak', 'pad_waste', 'f16_storage_images_per_sec', 'f16_storage_ms_per_step', 'fp16_images_per_sec', 'fp16_ms_per_step',
-                      'headline_dtype_alternating_ms_per_step'))
+                      'headline_dtype_alternating_ms_per_step', 'graph_captured_seconds_per_step', 'eager_seconds_per_step'))
     r = rec.get('roofline')
     if r:
         out['roofline_frac'] = r.get('frac')

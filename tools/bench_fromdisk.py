@@ -47,7 +47,7 @@ if __name__ == '__main__':
         for i in range(256):
             AJ.file_to_record(ds.img_path(i), row, 256)
         print('one process entropy-decodes %.0f files/s into coefficient records (read + Huffman)' % (256 / (time.perf_counter() - t0)))
-        for src in os.environ.get('SOURCES', 'jpeg,jpeg-host').split(','):
+        for src in [s_ for s_ in os.environ.get('SOURCES', 'jpeg,jpeg-host').split(',') if s_ in ('jpeg', 'jpeg-host')]:
             for w in workers:
                 m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source=src, nslot=int(os.environ.get("NSLOT", "3")))
                 print('%-9s workers %3d  bs %d: %d images in %.2f s = %.0f images/s from files' % (src, w, bs, rate['images'], rate['seconds'], rate['images_per_sec']))

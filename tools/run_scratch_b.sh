@@ -1,4 +1,13 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_bn_fused.py tests/test_gpu_blocks_bwd.py tests/test_gpu_hrnet_train.py tests/test_gpu_full_bwd.py -x -q 2>&1 | tail -4
-BACKBONE=hrnet_w48 TOP=3 python tools/bench_train.py 32 5 2>&1 | grep -v amdgpu.ids | head -4
-TOP=3 python tools/bench_train.py 32 7 2>&1 | grep -v amdgpu.ids | head -4
+cat /sys/fs/cgroup/cpu.max 2>/dev/null; nproc
+echo "=== u8 alone"
+SOURCES=none python tools/bench_fromdisk.py 131072 256 8 2>&1 | grep -E "u8 shards, 4"
+echo "=== u8 with 8 busy processes"
+pids=""
+for i in 1 2 3 4 5 6 7 8; do python -c "
+while True: pass" & pids="$pids $!"; done
+SOURCES=none python tools/bench_fromdisk.py 131072 256 8 2>&1 | grep -E "u8 shards, 4"
+kill $pids
+sleep 1
+echo "=== jpeg, workers niced"
+DIR_RING_NICE=15 SOURCES=jpeg python tools/bench_fromdisk.py 131072 256 8 2>&1 | grep -E "jpeg  "
