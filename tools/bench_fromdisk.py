@@ -47,6 +47,9 @@ if __name__ == '__main__':
         for i in range(256):
             AJ.file_to_record(ds.img_path(i), row, 256)
         print('one process entropy-decodes %.0f files/s into coefficient records (read + Huffman)' % (256 / (time.perf_counter() - t0)))
+        # one short untimed pass first: the first scored batch of a process initialises the BLAS library behind the metric's J_regressor products
+        # (a 0.2 s stall, found in the round-5 kernel trace: profiles/r05_fromdisk_sweep.txt) -- a per-process cost, not the loop's rate
+        EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=2, indices=idx[:4 * bs], source='jpeg', nslot=int(os.environ.get("NSLOT", "3")))
         for src in [s_ for s_ in os.environ.get('SOURCES', 'jpeg,jpeg-host').split(',') if s_ in ('jpeg', 'jpeg-host')]:
             for w in workers:
                 m, rate = EV.evaluate_from_disk(eng, d, jreg, mano, bs=bs, workers=w, indices=idx, source=src, nslot=int(os.environ.get("NSLOT", "3")))
