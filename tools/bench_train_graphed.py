@@ -1,4 +1,4 @@
-"""train_step eager against GraphedTrainStep (everything but the optimiser as one HIP graph) at B images: seconds per step and bit-equality of the
+"""train_step eager against GraphedTrainStep (everything but the optimiser as one HIP graph) at B images ([BACKBONE=hrnet_w48]): seconds per step and bit-equality of the
 parameters after the same number of steps.  python tools/bench_train_graphed.py [batch]"""
 import json, os, sys, time
 import numpy as np, torch
@@ -8,6 +8,9 @@ from dir_amd.optim import FlatAdamW
 from dir_amd.train import step as TSTEP
 B=int(sys.argv[1]) if len(sys.argv)>1 else 32
 shapes={k:tuple(v) for k,v in json.load(open(os.path.join(ROOT,'tests','golden','manifest_dir.json'))).items()}
+if os.environ.get('BACKBONE','resnet50')=='hrnet_w48':        # BASELINE configs[4]: HRNet-W48 + init + 4 refinement stages
+    from dir_amd.models.dir import DIR
+    shapes={k:tuple(v.shape) for k,v in DIR(21,'unused',0,backbone='hrnet_w48',extra_stages=int(os.environ.get('EXTRA_STAGES','2'))).state_dict().items()}
 sd=synth.synth_state_dict(shapes,1234)
 is_buf=lambda k: any(t in k for t in ('running_','num_batches','mano_layer','img_gird','seg_loss.weight'))
 def make():
@@ -25,7 +28,7 @@ for s in ('left','right'):
     meta['center_'+s]=dv(rng.normal(0,0.1,(B,1,3)).astype(np.float32))
 target['seg']=dv(rng.randint(0,3,(B,1,256,256)).astype(np.float32)); target['dense']=dv(rng.rand(B,3,256,256).astype(np.float32))
 faces=tuple(dv(synth.loss_faces(s,1234).astype(np.int64)) for s in ('left','right'))
-N=8
+N=int(os.environ.get('NSTEP','8'))
 p1,b1,o1=make()
 for i in range(N): TSTEP.train_step(p1,b1,img,target,meta,faces,o1,overlap_allreduce=False)
 torch.cuda.synchronize(); t0=time.time()
