@@ -129,6 +129,7 @@ _SIGNATURES = {
     'dir_probe_launch': (C.c_longlong, [_i, _p, C.c_longlong, _i, _p]),
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_conv2d_forward_stats': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int), _p]),
+    'dir_conv2d_forward_masked': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_fuse_sum': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),

@@ -493,6 +493,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 for (int e = 0; e < VN; ++e) v[e] += rv[e];
             }
             if constexpr (std::is_same<TO, float>::value) {
+                if (a.mask) {                  // (round 5: the producing block's ReLU backward, see ConvArgs::mask)
+                    const float4 mk = *reinterpret_cast<const float4*>(a.mask + (long long)m * a.out_cs + a.out_co + n);
+                    v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f; v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
+                }
                 if (a.out_split_scale > 0.f) { store_split4(y, m, n, a.Cout, v, relu, a.out_split_scale, a.out_split_hi_only != 0); continue; }
             }
             OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
@@ -619,7 +623,8 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
 static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
                         const float* pre_scale, const float* pre_shift, const void* residual, void* y,
                         const int32_t* bbox, void* stream, const dir_conv_src2* d2 = nullptr, const void* x2 = nullptr,
-                        int splits = 0, void* workspace = nullptr, long long workspace_bytes = 0, float* st_p1 = nullptr, float* st_p2 = nullptr) {
+                        int splits = 0, void* workspace = nullptr, long long workspace_bytes = 0, float* st_p1 = nullptr, float* st_p2 = nullptr,
+                        const float* mask = nullptr) {
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
@@ -707,6 +712,9 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     a.splits = 0; a.ws_part = nullptr; a.ws_cnt = nullptr;
     a.st_p1 = st_p1; a.st_p2 = st_p2;
     stats_rows_launched = 0;
+    a.mask = mask;
+    DIR_REQUIRE(!mask || (vec && d->out_dtype == DIR_DT_F32 && ((uintptr_t)mask & 15) == 0),
+                "dir_conv2d_forward_masked: an fp32 output with 16-byte aligned rows (and mask) only");
     if (splits > 1) {
         DIR_REQUIRE(!f32 && d->out_dtype != DIR_DT_F32 && vec && bbox == nullptr, "dir_conv2d_splitk_forward: 16-bit -> 16-bit layers with 16-byte aligned output rows only");
         DIR_REQUIRE(splits <= a.nk && splits <= 16, "dir_conv2d_splitk_forward: splits must be <= min(16, K / 64)");
@@ -932,6 +940,13 @@ extern "C" int dir_conv2d_forward_stats(const dir_conv_desc* d, const void* x, c
     const int rc = conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, nullptr, y, nullptr, stream, nullptr, nullptr, 0, nullptr, 0, p1, p2);
     *chunk_rows = rc == 0 ? stats_rows_launched : 0;
     return rc;
+}
+
+// round 5: y = mask > 0 ? conv(x) (+ residual) : 0, mask [.., out_cstride] fp32 laid out like y (see ConvArgs::mask)
+extern "C" int dir_conv2d_forward_masked(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
+                                         const float* pre_shift, const void* residual, const float* mask, void* y, void* stream) {
+    DIR_REQUIRE(mask, "dir_conv2d_forward_masked: null mask");
+    return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, mask);
 }
 
 extern "C" long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits) {

@@ -189,6 +189,10 @@ struct ConvArgs {
     // it is still in registers -- st_p1 [tiles_m][Cout] = per tile row and output channel the sum of the tile's valid rows of y, st_p2 = sum (y - tile
     // mean)^2 (what bn_stats4_kernel forms from the stored map with 256-row chunks; here the chunk is the M tile).  NULL = off.
     float* st_p1 = nullptr; float* st_p2 = nullptr;
+    // round 5 (dir_conv2d_forward_masked, fp32 outputs): y = mask > 0 ? (conv + residual) : 0 with mask a tensor of y's shape (row stride out_cs, offset
+    // out_co) -- the ReLU backward of the block that PRODUCED this convolution's input, applied where a data-gradient convolution writes that
+    // input's gradient (the mask is the block's stored output): the separate pass over (gradient, output) -> masked gradient goes away.  NULL = off.
+    const float* mask = nullptr;
 };
 // rows of the M tile the last launch on this thread formed the statistics over (0: the kernel that took the launch does not form them)
 extern thread_local int stats_rows_launched;
@@ -482,6 +486,10 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
             for (int e = 0; e < VN; ++e) v[e] += rv[e];
         }
         if constexpr (std::is_same<TO, float>::value) {
+            if (a.mask) {
+                const float4 mk = *reinterpret_cast<const float4*>(a.mask + (long long)m * a.out_cs + a.out_co + n);
+                v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f; v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
+            }
             if (a.out_split_scale > 0.f) { store_split4(y, m, n, a.Cout, v, relu, a.out_split_scale, a.out_split_hi_only != 0); continue; }
         }
         OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);

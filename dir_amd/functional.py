@@ -81,7 +81,7 @@ def pow2_in_scale(x, pre_scale=None, pre_shift=None):
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
                 res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False, prepacked=None,
-                stats_out=None):
+                stats_out=None, mask=None):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
     if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
@@ -156,6 +156,12 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
                                                       _capi.stream_ptr())
             _capi.check(rc, 'dir_conv2d_forward_stats')
             stats_out.append((part[0], part[1], rows.value))
+            return out
+        if mask is not None:               # y = mask > 0 ? conv (+ residual) : 0 (dir_conv2d_forward_masked: a ReLU backward applied where the gradient is written)
+            assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.shape == out.shape and out_coff == 0
+            rc = _capi.lib().dir_conv2d_forward_masked(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift), _capi.ptr(pre_scale),
+                                                       _capi.ptr(pre_shift), _capi.ptr(residual), _capi.ptr(mask), _capi.ptr(out), _capi.stream_ptr())
+            _capi.check(rc, 'dir_conv2d_forward_masked')
             return out
         rc = _capi.lib().dir_conv2d_forward(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift),
                                             _capi.ptr(pre_scale), _capi.ptr(pre_shift), _capi.ptr(residual),

@@ -60,12 +60,12 @@ def bn_bwd(P, pre, saved, gy, G, relu=False):
     return gx.view(x.shape)
 
 
-def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None, pre=None):
+def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None, pre=None, mask_gx=None):
     """add_gx: another gradient of x, summed into gx in the data-gradient convolution's epilogue; pre: the pre-activation the forward convolution
     applied to x (bn_relu_into_conv) -- gx is then the gradient of the ACTIVATED operand, as before"""
     has_bias = (key + 'bias') in P
     gx, G[key + 'weight'], gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx, gw_oihw=True,
-                                            pre=pre)
+                                            pre=pre, mask_gx=mask_gx)
     if has_bias:
         G[key + 'bias'] = gb
     return gx
@@ -90,10 +90,13 @@ def bottleneck_forward(P, x, stride=1):
     return y, ctx
 
 
-def bottleneck_backward(P, ctx, gy, need_gx=True):
+def bottleneck_backward(P, ctx, gy, need_gx=True, gy_masked=False, mask_gx=None):
+    """gy_masked: gy already went through this block's final ReLU backward (the NEXT block's conv1 data gradient applied it: mask_gx there);
+    mask_gx: the stored output of the block that produced x -- its ReLU backward is applied to the returned gx in conv1's data-gradient epilogue
+    (round 5: one pass over (gradient, output) per block boundary less; only where nothing else is added to that gradient first)"""
     G = {}
     x, stride = ctx['x'], ctx['stride']
-    g = O.relu_bwd(gy.contiguous(), ctx['y'])               # gradient of (bn3 out + identity)
+    g = gy.contiguous() if gy_masked else O.relu_bwd(gy.contiguous(), ctx['y'])               # gradient of (bn3 out + identity)
     g3 = bn_bwd(P, 'bn3.', ctx['bn3'], g, G)
     g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G, pre=ctx.get('p2'))
     g2 = bn_bwd(P, 'bn2.', ctx['bn2'], g2, G, relu=True)
@@ -105,7 +108,7 @@ def bottleneck_backward(P, ctx, gy, need_gx=True):
         other = _conv_bwd(P, 'downsample.0.', x, gd, stride, 0, G, need_gx=need_gx)
     else:
         other = g
-    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx, add_gx=other if need_gx else None)
+    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx, add_gx=other if need_gx else None, mask_gx=mask_gx if need_gx else None)
     return gx, G
 
 

@@ -265,12 +265,14 @@ def _site_scale(x, pre=None):
     return s
 
 
-def _conv(x, w, stride, pad, shift=None, packed=None, residual=None, pre=None, stats=None):
+def _conv(x, w, stride, pad, shift=None, packed=None, residual=None, pre=None, stats=None, mask=None):
     """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient); residual: added in the epilogue;
     pre = (pre_scale, pre_shift) [Cin]: the convolution reads max(x pre_scale + pre_shift, 0) (a BatchNorm + ReLU that is not materialised)"""
     pk = {} if pre is None else dict(pre_scale=pre[0], pre_shift=pre[1], pre_relu=True)
     if stats is not None and STATS_IN_EPILOGUE:
         pk['stats_out'] = stats          # the following BatchNorm's chunk partials from this convolution's epilogue (dir_conv2d_forward_stats)
+    if mask is not None:
+        pk['mask'] = mask                # y = mask > 0 ? y : 0 in the epilogue (dir_conv2d_forward_masked)
     if ARITH != 'f16x3':
         return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, residual=residual, **pk)
     shape = w.shape if packed is None else (packed[0].shape, packed[0].dshape)[packed[1]]
@@ -325,9 +327,10 @@ def _pad_last(t, mult):
     return out
 
 
-def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None):
+def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None, mask=None):
     """d loss / d x [B,H,W,Cin] of y = conv(x, w, stride, pad) from gy [B,Ho,Wo,Cout]; add [B,H,W,Cin]: another gradient of x, summed in
-    the convolution's epilogue (the identity / projection path of a residual block)"""
+    the convolution's epilogue (the identity / projection path of a residual block); mask [B,H,W,Cin]: the result is zeroed where mask <= 0 (x is
+    the output of a ReLU and mask that output: the ReLU's backward, applied in the same epilogue)"""
     e = _packed_of(w) if oihw else None
     if oihw and e is None:
         w = _ohwi(w)
@@ -342,12 +345,15 @@ def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None):
     g = _pad_last(g.contiguous(), 32)
     p2 = kh - 1 - pad
     fits = g.shape[1] + 2 * p2 - kh + 1 == H and g.shape[2] + 2 * p2 - kw + 1 == W
-    gx = _conv(g, wt, 1, p2, packed=None if e is None else (e, 1), residual=add.contiguous() if (add is not None and fits) else None)
+    fused_mask = mask.contiguous() if (mask is not None and fits and mask.shape[3] % 4 == 0) else None
+    gx = _conv(g, wt, 1, p2, packed=None if e is None else (e, 1), residual=add.contiguous() if (add is not None and fits) else None, mask=fused_mask)
     if not fits:                                           # odd H / W under stride 2
         assert gx.shape[1] >= H and gx.shape[2] >= W
         gx = gx[:, :H, :W].contiguous()
         if add is not None:
             O.axpy(gx, add.contiguous())
+    if mask is not None and fused_mask is None:
+        gx = O.relu_bwd(gx, mask)
     return gx
 
 
@@ -393,7 +399,7 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False, pre=None
     return out
 
 
-def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False, pre=None):
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False, pre=None, mask_gx=None):
     """-> (gx (+ add_gx), gw [Cout,kh,kw,Cin] ([Cout,Cin,kh,kw] with gw_oihw), gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd).
     Inside a backward pass (side_begin) gw is produced on the side stream: valid on the compute stream after side_end."""
     gy = gy.contiguous()
@@ -404,5 +410,5 @@ def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False,
         return g.permute(0, 3, 1, 2).contiguous() if gw_oihw else g
     gw = side_run(wgrad, x, gy)
     gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None
-    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw, add=add_gx) if need_gx else None
+    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw, add=add_gx, mask=mask_gx) if need_gx else None
     return gx, gw, gb

@@ -69,6 +69,7 @@ def _stem_forward(P, img):
     """conv1 7x7/2 (no bias) through the engine's space-to-depth form (dir_stem_prep_s2d + a 4x4 stride-1 implicit GEMM, engine.stem_conv_op)"""
     from .. import _capi
     B = img.shape[0]
+    assert tuple(img.shape[1:]) == (3, 256, 256), 'the training stem is written for 256 x 256 images (config.py: the reference trains on 256 x 256 crops); got %s' % (tuple(img.shape),)
     op = E.stem_conv_op(P['backbone.conv1.weight'], None, None, torch.float32)
     op.flags = 0                                           # raw convolution: BatchNorm (batch statistics) and ReLU follow as their own steps
     xp = torch.empty(B, 131, 132, 16, device=img.device)
@@ -143,6 +144,9 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
     return g_tok, gul, gur
 
 
+FUSE_RELU_BWD = os.environ.get('DIR_TRAIN_FUSE_RELU_BWD', '1') == '1'      # round 5: a bottleneck's final ReLU backward inside the next block's conv1 data gradient
+
+
 # ----------------------------------------------------------------------------------------------------------------------------- forward
 def backbone_forward(P, img, ctx, pre='backbone.'):
     """ResNet.forward in training form (models/backbone/resnet.py:243-255): stem conv + bn1 + ReLU + max-pool + the 16 bottlenecks.
@@ -181,10 +185,15 @@ def backbone_backward(P, ctx, g_feats, G, flush=None, pre='backbone.'):
             g = g_feats[li]
         elif g_feats[li] is not None:
             O.axpy(g, g_feats[li])
-        for _ in range(LAYERS[li]):
+        masked = False                                     # the gradient entering a layer's LAST block still needs that block's ReLU backward
+        for k in range(LAYERS[li] - 1, -1, -1):
             bi_end -= 1
             p, c = ctx['blocks'][bi_end]
-            g, gb = TB.bottleneck_backward(sub(Pb, p), c, g)
+            # inside a layer a block's input IS the previous block's output: that block's ReLU backward is applied where this block's conv1 data
+            # gradient is written (round 5); a layer's first block hands its gradient to the previous layer's tap, which the decoder's gradient joins first
+            prev_y = ctx['blocks'][bi_end - 1][1]['y'] if (k > 0 and FUSE_RELU_BWD) else None
+            g, gb = TB.bottleneck_backward(sub(Pb, p), c, g, gy_masked=masked, mask_gx=prev_y)
+            masked = prev_y is not None
             put(G, p, gb)
         flush(G)
     a, x_pool = ctx['stem']

@@ -386,6 +386,12 @@ typedef struct dir_conv_desc {
 int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void* w, const float* scale,
                        const float* shift, const float* pre_scale, const float* pre_shift,
                        const void* residual, void* y, void* stream);
+/* round 5 -- dir_conv2d_forward (fp32 output, 16-byte aligned rows) with an output MASK: y = mask > 0 ? (conv(x) + residual) : 0, mask an fp32 tensor laid
+ * out like y.  The training step's use: the data gradient of a Bottleneck's conv1 is the gradient of the PREVIOUS block's output, whose ReLU backward
+ * (`out = relu(...)`, models/backbone/resnet.py:140) is this mask with that block's stored output -- applied where the gradient is written instead of
+ * in a pass of its own over (gradient, output). */
+int dir_conv2d_forward_masked(const dir_conv_desc* desc, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
+                              const float* pre_shift, const void* residual, const float* mask, void* y, void* stream);
 /* round 5 -- dir_conv2d_forward (no residual, no activation, whole fp32 output tensor) that ALSO forms the chunk partials of the training-mode
  * BatchNorm that follows the convolution (nn.Conv2d -> nn.BatchNorm2d, models/backbone/resnet.py:123-133, hourglass.py:14-27) from the output
  * tile while it is in registers: p1 / p2 [ceil(M / rows)][Cout] (room for ceil(M / 64) x Cout floats each), *chunk_rows = rows (the M tile of the

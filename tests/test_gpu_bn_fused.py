@@ -143,3 +143,48 @@ def test_convolution_epilogue_forms_the_chunk_partials_of_the_following_batchnor
         assert rel(sm2, sm) < 1e-5 and rel(sr2, sr) < 1e-5 and rel(rm2, rm) < 1e-5 and rel(rv2, rv) < 1e-5
         ya = O.bn_train_apply(y.view(-1, Cout), wbn, bbn, (sm2, sr2), relu=True)
         assert float((ya - yb).abs().max()) < 1e-5 * float(yb.abs().max())
+
+
+def test_data_gradient_with_the_relu_mask_in_its_epilogue():
+    """dir_conv2d_forward_masked through conv_dgrad(mask=...): gx = (dgrad + add) where mask > 0, else 0 -- bit for bit the separate relu_bwd pass"""
+    g = torch.Generator(device='cuda').manual_seed(13)
+    for (B, H, Cin, Cout, k) in ((4, 32, 256, 64, 1), (2, 64, 64, 64, 3), (8, 16, 1024, 256, 1)):
+        w = torch.randn(Cout, Cin, k, k, device='cuda', generator=g) * 0.05
+        gy = torch.randn(B, H, H, Cout, device='cuda', generator=g)
+        add = torch.randn(B, H, H, Cin, device='cuda', generator=g)
+        y_prev = torch.relu(torch.randn(B, H, H, Cin, device='cuda', generator=g))
+        TC.end_step()
+        want = O.relu_bwd(TC.conv_dgrad(w, gy, 1, k // 2, H, H, oihw=True, add=add), y_prev)
+        got = TC.conv_dgrad(w, gy, 1, k // 2, H, H, oihw=True, add=add, mask=y_prev)
+        assert torch.equal(got, want), (B, H, Cin, Cout, k)
+
+
+def test_backbone_backward_with_and_without_the_fused_relu_backward():
+    """the 12 in-layer block boundaries of the ResNet take their ReLU backward in the next block's conv1 data gradient: same gradients bit for bit"""
+    import json
+    import os
+    from dir_amd import synth
+    from dir_amd.train import net as TN
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, 'golden', 'manifest_dir.json')) as f:
+        shapes = {k: tuple(v) for k, v in json.load(f).items() if k.startswith('backbone.')}
+    sd = synth.synth_state_dict(shapes, 1234)
+    img = torch.from_numpy(synth.synth_input('relu_bwd.img', (2, 3, 256, 256), 1234)).cuda()          # (the training stem is written for 256 x 256 inputs, like the reference's data)
+    res = {}
+    for fused in (True, False):
+        TN.FUSE_RELU_BWD = fused
+        try:
+            P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if 'num_batches' not in k}
+            TC.end_step()
+            ctx = {}
+            feats = TN.backbone_forward(P, img, ctx)
+            gen = torch.Generator(device='cuda').manual_seed(4)
+            gf = [torch.randn(f.shape, device='cuda', generator=gen) for f in feats]
+            G = {}
+            TN.backbone_backward(P, ctx, gf, G)
+            res[fused] = G
+        finally:
+            TN.FUSE_RELU_BWD = True
+    assert set(res[True]) == set(res[False])
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), k
