@@ -12,6 +12,11 @@ from . import conv as TC
 from . import ops as O
 
 
+import os
+
+FUSE_RELU_BWD = os.environ.get('DIR_TRAIN_FUSE_RELU_BWD', '1') == '1'      # round 5: a block's final ReLU backward inside the next block's conv1 data gradient
+
+
 def _ohwi(w):
     return w.permute(0, 2, 3, 1).contiguous()
 

@@ -75,13 +75,15 @@ def basic_forward(P, x):
     return y, dict(x=x, a1=a1, p1=p1, bn1=s1, bn2=s2, y=y)
 
 
-def basic_backward(P, s, gy):
+def basic_backward(P, s, gy, gy_masked=False, mask_gx=None):
+    """gy_masked / mask_gx: the block's final ReLU backward applied by the NEXT block's conv1 data gradient / the previous block's applied here
+    (dir_amd.train.blocks.bottleneck_backward; inside a branch a block's input is the previous block's output)"""
     G = {}
-    g = O.relu_bwd(gy.contiguous(), s['y'])                  # gradient of (bn2 out + x)
+    g = gy.contiguous() if gy_masked else O.relu_bwd(gy.contiguous(), s['y'])                  # gradient of (bn2 out + x)
     g2 = TB.bn_bwd(P, 'bn2.', s['bn2'], g, G)
     g1 = TB._conv_bwd(P, 'conv2.', s['a1'], g2, 1, 1, G, pre=s.get('p1'))
     g1 = TB.bn_bwd(P, 'bn1.', s['bn1'], g1, G, relu=True)
-    gx = TB._conv_bwd(P, 'conv1.', s['x'], g1, 1, 1, G, add_gx=g)
+    gx = TB._conv_bwd(P, 'conv1.', s['x'], g1, 1, 1, G, add_gx=g, mask_gx=mask_gx)
     return gx, G
 
 
@@ -152,10 +154,13 @@ def module_backward(P, ctx, gys, G):
     bi = len(ctx['blocks'])
     for b in reversed(range(nb)):
         g = g_ys[b]
-        for _ in range(4):
+        masked = False
+        for k in range(3, -1, -1):
             bi -= 1
             p, c = ctx['blocks'][bi]
-            g, gb = basic_backward(_sub(P, p), c, g)
+            prev_y = ctx['blocks'][bi - 1][1]['y'] if (k > 0 and TB.FUSE_RELU_BWD and c['x'].shape[-1] % 32 == 0) else None
+            g, gb = basic_backward(_sub(P, p), c, g, gy_masked=masked, mask_gx=prev_y)
+            masked = prev_y is not None
             _put(G, p, gb)
         gxs.append(g)
     return gxs[::-1]

@@ -144,9 +144,6 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
     return g_tok, gul, gur
 
 
-FUSE_RELU_BWD = os.environ.get('DIR_TRAIN_FUSE_RELU_BWD', '1') == '1'      # round 5: a bottleneck's final ReLU backward inside the next block's conv1 data gradient
-
-
 # ----------------------------------------------------------------------------------------------------------------------------- forward
 def backbone_forward(P, img, ctx, pre='backbone.'):
     """ResNet.forward in training form (models/backbone/resnet.py:243-255): stem conv + bn1 + ReLU + max-pool + the 16 bottlenecks.
@@ -191,7 +188,7 @@ def backbone_backward(P, ctx, g_feats, G, flush=None, pre='backbone.'):
             p, c = ctx['blocks'][bi_end]
             # inside a layer a block's input IS the previous block's output: that block's ReLU backward is applied where this block's conv1 data
             # gradient is written (round 5); a layer's first block hands its gradient to the previous layer's tap, which the decoder's gradient joins first
-            prev_y = ctx['blocks'][bi_end - 1][1]['y'] if (k > 0 and FUSE_RELU_BWD) else None
+            prev_y = ctx['blocks'][bi_end - 1][1]['y'] if (k > 0 and TB.FUSE_RELU_BWD) else None
             g, gb = TB.bottleneck_backward(sub(Pb, p), c, g, gy_masked=masked, mask_gx=prev_y)
             masked = prev_y is not None
             put(G, p, gb)

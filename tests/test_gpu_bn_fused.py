@@ -172,7 +172,7 @@ def test_backbone_backward_with_and_without_the_fused_relu_backward():
     img = torch.from_numpy(synth.synth_input('relu_bwd.img', (2, 3, 256, 256), 1234)).cuda()          # (the training stem is written for 256 x 256 inputs, like the reference's data)
     res = {}
     for fused in (True, False):
-        TN.FUSE_RELU_BWD = fused
+        TB.FUSE_RELU_BWD = fused
         try:
             P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in sd.items() if 'num_batches' not in k}
             TC.end_step()
@@ -184,7 +184,7 @@ def test_backbone_backward_with_and_without_the_fused_relu_backward():
             TN.backbone_backward(P, ctx, gf, G)
             res[fused] = G
         finally:
-            TN.FUSE_RELU_BWD = True
+            TB.FUSE_RELU_BWD = True
     assert set(res[True]) == set(res[False])
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), k
