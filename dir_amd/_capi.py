@@ -28,6 +28,10 @@ class ConvDesc(C.Structure):
         'kh', 'kw', 'stride', 'pad', 'in_dtype', 'out_dtype', 'flags', 'Ho', 'Wo')] + [('in_scale', C.c_float), ('out_split_scale', C.c_float)]
 
 
+class ConvBnBwd(C.Structure):          # dir_conv_bn_bwd
+    _fields_ = [(n, C.c_void_p) for n in ('z', 'mean', 'rstd', 'w', 'b')] + [('relu', C.c_int32)] + [(n, C.c_void_p) for n in ('p1', 'p2')]
+
+
 class ConvSrc2(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('H', 'W', 'Cin', 'in_cstride', 'in_coff', 'stride')]
 
@@ -130,6 +134,7 @@ _SIGNATURES = {
     'dir_conv2d_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_conv2d_forward_stats': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(C.c_int), _p]),
     'dir_conv2d_forward_masked': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'dir_conv2d_forward_ex': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(ConvBnBwd), C.POINTER(C.c_int), _p]),
     'dir_add_upsampled': (C.c_int, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_fuse_sum': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     'dir_pack_f16x3_weights': (C.c_int, [_p, _p, _p, _p, _i, _i, _p]),
@@ -194,6 +199,7 @@ _SIGNATURES = {
     'dir_attention_backward': (C.c_int, [_p, _p, _p, _p, _i, _i, _i, C.c_float, _p]),
     'dir_bn_train_workspace_bytes': (C.c_longlong, [_i, _i]),
     'dir_bn_train_forward': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _i, _p, _p, C.c_longlong, _p]),
+    'dir_bn_train_backward_from_partials': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, C.c_longlong, _p]),
     'dir_bn_train_stats': (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, C.c_float, C.c_float, _p, C.c_longlong, _p]),
     'dir_bn_train_stats_from_partials': (C.c_int, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_float, C.c_float, _p]),
     'dir_bn_train_apply': (C.c_int, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),

@@ -475,6 +475,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
         constexpr int VN = OutVec<TO>::N, CPR = BN / VN;          // chunks per tile row
         constexpr int EPI_UNROLL = sizeof(TO) == 2 ? RCH : 1;      // rpre[] needs static indices (bf16 outputs only)
+        BnBwdAcc bs;
+        const bool bs_on = std::is_same<TO, float>::value && !SPLIT && a.bs_p1 != nullptr;
+        if constexpr (std::is_same<TO, float>::value) {
+            if (bs_on) bn_bwd_acc_init(a, n0 + (tid % CPR) * VN, bs);
+        }
 #pragma unroll EPI_UNROLL
         for (int k = 0; k < RCH; ++k) {
             const int c = tid + 256 * k;
@@ -497,9 +502,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                     const float4 mk = *reinterpret_cast<const float4*>(a.mask + (long long)m * a.out_cs + a.out_co + n);
                     v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f; v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
                 }
+                if (bs_on) bn_bwd_acc_add(a, m, n, v, bs);
                 if (a.out_split_scale > 0.f) { store_split4(y, m, n, a.Cout, v, relu, a.out_split_scale, a.out_split_hi_only != 0); continue; }
             }
             OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
+        }
+        if constexpr (std::is_same<TO, float>::value) {
+            if (bs_on) bn_bwd_acc_finish<256, BN>(a, st, tid, tm, n0, bs);         // (round 5: the BatchNorm backward's chunk partials, ConvArgs::bs_*)
         }
         return;
     }
@@ -582,7 +591,7 @@ void launch_conv(const ConvArgs& a0, int num_cu, hipStream_t s) {
     const int bm = m64 ? 64 : 128;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = tiles_n;
-    if (a.st_p1 && std::is_same<TO, float>::value && (a.flags & 4)) stats_rows_launched = bm;      // this kernel's epilogue forms the statistics (tile_col_stats)
+    if ((a.st_p1 || a.bs_p1) && std::is_same<TO, float>::value && (a.flags & 4)) stats_rows_launched = bm;      // this kernel's epilogue forms the statistics (tile_col_stats / bn_bwd_acc_*)
     choose_tile_order(a, is_half<TI>::value ? 2 : 4);
     dim3 grid(a.tiles_m * a.tiles_n), block(256);
     const bool pre = a.pre_scale != nullptr;
@@ -624,7 +633,7 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
                         const float* pre_scale, const float* pre_shift, const void* residual, void* y,
                         const int32_t* bbox, void* stream, const dir_conv_src2* d2 = nullptr, const void* x2 = nullptr,
                         int splits = 0, void* workspace = nullptr, long long workspace_bytes = 0, float* st_p1 = nullptr, float* st_p2 = nullptr,
-                        const float* mask = nullptr) {
+                        const float* mask = nullptr, const dir_conv_bn_bwd* bs = nullptr) {
     DIR_REQUIRE(d && x && w && y, "dir_conv2d_forward: null pointer");
     DIR_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "dir_conv2d_forward: bad shape");
     DIR_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "dir_conv2d_forward: bad kernel geometry");
@@ -715,6 +724,13 @@ static int conv_forward(const dir_conv_desc* d, const void* x, const void* w, co
     a.mask = mask;
     DIR_REQUIRE(!mask || (vec && d->out_dtype == DIR_DT_F32 && ((uintptr_t)mask & 15) == 0),
                 "dir_conv2d_forward_masked: an fp32 output with 16-byte aligned rows (and mask) only");
+    if (bs) {
+        DIR_REQUIRE(bs->z && bs->mean && bs->rstd && bs->p1 && bs->p2, "dir_conv2d_forward_ex: incomplete dir_conv_bn_bwd");
+        DIR_REQUIRE(vec && d->out_dtype == DIR_DT_F32 && out_cs == d->Cout && d->out_coff == 0 && d->Cout % 4 == 0 && a.out_split_scale == 0.f && splits <= 1 &&
+                        (((uintptr_t)bs->z | (uintptr_t)bs->mean | (uintptr_t)bs->rstd | (uintptr_t)bs->w | (uintptr_t)bs->b) & 15) == 0,
+                    "dir_conv2d_forward_ex: the BatchNorm-backward sums need a whole fp32 output tensor, Cout %% 4 == 0, 16-byte aligned vectors");
+        a.bs_z = bs->z; a.bs_mu = bs->mean; a.bs_rs = bs->rstd; a.bs_w = bs->w; a.bs_b = bs->b; a.bs_relu = bs->relu; a.bs_p1 = bs->p1; a.bs_p2 = bs->p2;
+    }
     if (splits > 1) {
         DIR_REQUIRE(!f32 && d->out_dtype != DIR_DT_F32 && vec && bbox == nullptr, "dir_conv2d_splitk_forward: 16-bit -> 16-bit layers with 16-byte aligned output rows only");
         DIR_REQUIRE(splits <= a.nk && splits <= 16, "dir_conv2d_splitk_forward: splits must be <= min(16, K / 64)");
@@ -947,6 +963,17 @@ extern "C" int dir_conv2d_forward_masked(const dir_conv_desc* d, const void* x, 
                                          const float* pre_shift, const void* residual, const float* mask, void* y, void* stream) {
     DIR_REQUIRE(mask, "dir_conv2d_forward_masked: null mask");
     return conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, mask);
+}
+
+// round 5: everything the fp32 epilogue can do for the training step's data-gradient convolutions in one entry point: residual, output mask, and the
+// chunk partials of the backward pass of the BatchNorm whose output's gradient this convolution writes (*chunk_rows as in dir_conv2d_forward_stats)
+extern "C" int dir_conv2d_forward_ex(const dir_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
+                                     const float* pre_shift, const void* residual, const float* mask, void* y, const dir_conv_bn_bwd* bn, int* chunk_rows,
+                                     void* stream) {
+    DIR_REQUIRE(!bn || chunk_rows, "dir_conv2d_forward_ex: chunk_rows is needed with bn");
+    const int rc = conv_forward(d, x, w, scale, shift, pre_scale, pre_shift, residual, y, nullptr, stream, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, mask, bn);
+    if (chunk_rows) *chunk_rows = (rc == 0 && bn) ? stats_rows_launched : 0;
+    return rc;
 }
 
 extern "C" long long dir_conv2d_splitk_workspace_bytes(const dir_conv_desc* d, int splits) {

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(ConvArgs a) {
 
 // DIR_CONV_VARIANT 11: returns true if it took the launch (bf16 operands, dense, no pre-activation / second source / split output, vector epilogue)
 bool launch_conv_big(const ConvArgs& a0, bool out_f32, hipStream_t s, bool f16) {
-    if (a0.pre_scale || a0.bbox || a0.x2 || !(a0.flags & 4) || a0.nk < 1 || a0.out_split_scale > 0.f || a0.st_p1 || a0.mask) return false;
+    if (a0.pre_scale || a0.bbox || a0.x2 || !(a0.flags & 4) || a0.nk < 1 || a0.out_split_scale > 0.f || a0.st_p1 || a0.mask || a0.bs_p1) return false;
     if (a0.Cin % 64 != 0 || a0.splits > 1) return false;
     if (a0.Cout <= 128 || a0.M <= 128) return false;                            // (a half-empty tile: the other variants serve these)
     ConvArgs a = a0;

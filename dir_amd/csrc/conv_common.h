@@ -193,6 +193,12 @@ struct ConvArgs {
     // out_co) -- the ReLU backward of the block that PRODUCED this convolution's input, applied where a data-gradient convolution writes that
     // input's gradient (the mask is the block's stored output): the separate pass over (gradient, output) -> masked gradient goes away.  NULL = off.
     const float* mask = nullptr;
+    // round 5 (dir_conv2d_forward_ex): this convolution is a DATA-GRADIENT convolution whose output g [M][Cout] is the gradient of a training-mode
+    // BatchNorm's (+ ReLU's) output; bs_z [M][Cout] is that BatchNorm's input, bs_mu / bs_rs / bs_w / bs_b its statistics and affine.  The
+    // epilogue then also forms the BatchNorm backward's chunk partials over the tile's rows -- bs_p1 [tiles_m][Cout] = sum of g under the ReLU mask
+    // (bs_relu: BatchNorm(z) > 0), bs_p2 = sum of the same times xhat = (z - mean) rstd -- what bn_bwd_partial4_kernel forms from the stored maps.
+    const float* bs_z = nullptr; const float* bs_mu = nullptr; const float* bs_rs = nullptr; const float* bs_w = nullptr; const float* bs_b = nullptr;
+    int bs_relu = 0; float* bs_p1 = nullptr; float* bs_p2 = nullptr;
 };
 // rows of the M tile the last launch on this thread formed the statistics over (0: the kernel that took the launch does not form them)
 extern thread_local int stats_rows_launched;
@@ -442,6 +448,49 @@ __device__ __forceinline__ void tile_col_stats(const ConvArgs& a, f32x16 (&acc)[
     __syncthreads();
 }
 
+// BatchNorm-backward chunk partials in the fp32 epilogues (ConvArgs::bs_*).  A thread of the store loop owns 4 consecutive columns (fixed) and a
+// strided set of rows: it keeps the two sums of its columns in registers, the threads of a column group are then added in LDS in thread order
+// (deterministic) and one thread per column writes the tile's partial.
+struct BnBwdAcc { float t1[4], t2[4], mu[4], rs[4], g[4], be[4]; };
+__device__ __forceinline__ void bn_bwd_acc_init(const ConvArgs& a, int n, BnBwdAcc& s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s.t1[e] = s.t2[e] = 0.f; s.mu[e] = 0.f; s.rs[e] = 0.f; s.g[e] = 1.f; s.be[e] = 0.f; }
+    if (n + 3 < a.Cout) {
+        const float4 m = *reinterpret_cast<const float4*>(a.bs_mu + n), k = *reinterpret_cast<const float4*>(a.bs_rs + n);
+        s.mu[0] = m.x; s.mu[1] = m.y; s.mu[2] = m.z; s.mu[3] = m.w; s.rs[0] = k.x; s.rs[1] = k.y; s.rs[2] = k.z; s.rs[3] = k.w;
+        if (a.bs_w) { const float4 t = *reinterpret_cast<const float4*>(a.bs_w + n); s.g[0] = t.x; s.g[1] = t.y; s.g[2] = t.z; s.g[3] = t.w; }
+        if (a.bs_b) { const float4 t = *reinterpret_cast<const float4*>(a.bs_b + n); s.be[0] = t.x; s.be[1] = t.y; s.be[2] = t.z; s.be[3] = t.w; }
+    }
+}
+__device__ __forceinline__ void bn_bwd_acc_add(const ConvArgs& a, long long m, int n, const float (&v)[4], BnBwdAcc& s) {
+    const float4 zz = *reinterpret_cast<const float4*>(a.bs_z + m * a.Cout + n);
+    const float z[4] = {zz.x, zz.y, zz.z, zz.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (z[e] - s.mu[e]) * s.rs[e];
+        float gm = v[e];
+        if (a.bs_relu && !(fmaf(xh, s.g[e], s.be[e]) > 0.f)) gm = 0.f;          // (bn_value of train_ops.hip: the mask the BatchNorm backward re-computes)
+        s.t1[e] += gm;
+        s.t2[e] = fmaf(gm, xh, s.t2[e]);
+    }
+}
+template <int NT, int BN>
+__device__ __forceinline__ void bn_bwd_acc_finish(const ConvArgs& a, float* red, int tid, int tm, int n0, const BnBwdAcc& s) {
+    constexpr int CPR = BN / 4, G = NT / CPR;
+    static_assert(NT % CPR == 0, "a thread's columns must not change between its rows");
+    __syncthreads();                                       // every thread is done reading the staged tile: red may overwrite it
+    const int grp = tid / CPR, cc = (tid - grp * CPR) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[grp * BN + cc + e] = s.t1[e]; red[(G + grp) * BN + cc + e] = s.t2[e]; }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < G; ++q) { u1 += red[q * BN + c]; u2 += red[(G + q) * BN + c]; }
+        if (n0 + c < a.Cout) { a.bs_p1[(long long)tm * a.Cout + n0 + c] = u1; a.bs_p2[(long long)tm * a.Cout + n0 + c] = u2; }
+    }
+}
+
 // Epilogue of the 8-wave kernels (conv_pipe.hip, bonefuse.hip): tile of (32*MI*WM) x (32*NJ*WN), wave (wm, wn).
 // scale/shift in registers -> fp32 tile in LDS -> 16-byte row segments (+ residual, ReLU) to HBM (conv.hip's epilogue)
 template <typename TO, int MI, int NJ, int WM, int WN>
@@ -471,6 +520,11 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
     }
     __syncthreads();
     constexpr int VN = OutVec<TO>::N, CPR = BN / VN;
+    BnBwdAcc bs;
+    const bool bs_on = std::is_same<TO, float>::value && a.bs_p1 != nullptr;
+    if constexpr (std::is_same<TO, float>::value) {
+        if (bs_on) bn_bwd_acc_init(a, n0 + (tid % CPR) * VN, bs);
+    }
     for (int c = tid; c < BM * CPR; c += NT) {
         const int rl = c / CPR, cc = (c - rl * CPR) * VN;
         const int m = m0 + rl, n = n0 + cc;
@@ -490,9 +544,13 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, f32x16 (&acc)[M
                 const float4 mk = *reinterpret_cast<const float4*>(a.mask + (long long)m * a.out_cs + a.out_co + n);
                 v[0] = mk.x > 0.f ? v[0] : 0.f; v[1] = mk.y > 0.f ? v[1] : 0.f; v[2] = mk.z > 0.f ? v[2] : 0.f; v[3] = mk.w > 0.f ? v[3] : 0.f;
             }
+            if (bs_on) bn_bwd_acc_add(a, m, n, v, bs);
             if (a.out_split_scale > 0.f) { store_split4(y, m, n, a.Cout, v, relu, a.out_split_scale, a.out_split_hi_only != 0); continue; }
         }
         OutVec<TO>::store_act(y + (long long)m * a.out_cs + a.out_co + n, v, relu);
+    }
+    if constexpr (std::is_same<TO, float>::value) {
+        if (bs_on) bn_bwd_acc_finish<NT, BN>(a, st, tid, m0 / BM, n0, bs);
     }
 }
 

@@ -666,7 +666,7 @@ void launch_tile(ConvArgs a, hipStream_t s) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     choose_tile_order(a, XM ? 4 : 2);
     dim3 grid(a.tiles_m * a.tiles_n), block(64 * WM * WN);
-    if (a.st_p1 && std::is_same<TO, float>::value) stats_rows_launched = BM;          // every kernel below ends in epilogue_tile, which forms the statistics
+    if ((a.st_p1 || a.bs_p1) && std::is_same<TO, float>::value) stats_rows_launched = BM;          // every kernel below ends in epilogue_tile, which forms the statistics
     if constexpr (XM != 0) {
         DIR_LAUNCH((conv_pipe_kernel<float, MI, NJ, WM, WN, false, false, 3, XM>), grid, block, 0, s, a);
         return;
@@ -719,7 +719,7 @@ bool launch_conv_pipe(const ConvArgs& a, bool out_f32, int num_cu, hipStream_t s
             // Ring depth DIR_P15_NBUF: 3 .. 6 measured equal (layer4 3x3: 33-35 us), so the shallow one, which lets two workgroups share a CU
             if (a.bbox || xm) return false;
             ConvArgs b = a;
-            if (b.st_p1 && out_f32) stats_rows_launched = 128;
+            if ((b.st_p1 || b.bs_p1) && out_f32) stats_rows_launched = 128;
             b.tiles_m = (b.M + 127) / 128;
             b.tiles_n = (b.Cout + 63) / 64;
             choose_tile_order(b, 2);

@@ -2171,6 +2171,23 @@ extern "C" int dir_bn_train_backward(const float* gy, const float* x, const floa
     return check_launch("dir_bn_train_backward");
 }
 
+extern "C" int dir_bn_train_backward_from_partials(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                                                   const float* p1, const float* p2, int chunks, float* gx, float* gw, float* gb, int R, int C, int ld, int relu,
+                                                   float* workspace, long long workspace_bytes, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(gy && x && save_mean && save_rstd && p1 && p2 && chunks > 0 && R > 0 && C > 0 && ld >= C && workspace && workspace_bytes >= 2ll * C * 4,
+                "dir_bn_train_backward_from_partials: bad arguments (workspace: 2 C floats)");
+    DIR_REQUIRE(bn_vec4(C, ld, {x, gy, gx, w, b, save_mean, save_rstd, workspace}), "dir_bn_train_backward_from_partials: C and ld must be multiples of 4, pointers 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* t1 = workspace; float* t2 = t1 + C;
+    DIR_LAUNCH(bn_bwd_combine_kernel, dim3((C + 15) / 16), dim3(256), 0, s, p1, p2, t1, t2, gb, gw, chunks, C);
+    if (gx) {
+        const long long nt = (long long)((R + 3) / 4) * (C / 4);
+        DIR_LAUNCH(bn_apply_bwd4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, gy, x, w, b, save_mean, save_rstd, (const float*)t1, (const float*)t2, gx, R, C, ld, relu);
+    }
+    return check_launch("dir_bn_train_backward_from_partials");
+}
+
 // ---- SyncBN building blocks (dir_amd/train/ops.py: sync_bn_fwd / sync_bn_bwd put the collectives between them)
 extern "C" long long dir_bn_sync_workspace_bytes(int R, int C) {
     if (R <= 0 || C <= 0) return -1;

@@ -81,7 +81,7 @@ def pow2_in_scale(x, pre_scale=None, pre_shift=None):
 def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, residual=None, pre_scale=None,
                 pre_shift=None, pre_relu=False, out=None, out_coff=0, in_coff=0, cin=None, out_dtype=None,
                 res_coff=0, splits=1, workspace=None, arith=None, variant=0, presplit=False, in_scale=None, device_pack=False, prepacked=None,
-                stats_out=None, mask=None):
+                stats_out=None, mask=None, bn_bwd=None):
     """x [B,H,W,Cbuf] NHWC; reads channels [in_coff, in_coff+cin).  Returns/updates `out` [B,Ho,Wo,Cobuf].
     splits > 1: dir_conv2d_splitk_forward (workspace: uint8 tensor of dir_conv2d_splitk_workspace_bytes, first 16 KiB zero; made here
     if None).  arith='f16x3' (fp32 tensors only): split-precision arithmetic, DIR_DT_F16X3 -- the fp32 weights are packed here."""
@@ -156,6 +156,27 @@ def conv2d_nhwc(x, w_ohwi, stride=1, pad=0, scale=None, shift=None, relu=False, 
                                                       _capi.stream_ptr())
             _capi.check(rc, 'dir_conv2d_forward_stats')
             stats_out.append((part[0], part[1], rows.value))
+            return out
+        if bn_bwd is not None and out.dtype == torch.float32 and out.shape[3] == Cout and out_coff == 0 and Cout % 4 == 0 and not relu:
+            # round 5 (dir_conv2d_forward_ex): this is a data-gradient convolution whose output is the gradient of a training-mode BatchNorm's (+ ReLU's)
+            # output; bn_bwd = {'z', 'mean', 'rstd', 'w', 'b', 'relu', 'out': []}: the epilogue also forms that BatchNorm backward's chunk partials,
+            # bn_bwd['out'] receives (p1, p2, chunks) -- nothing when the kernel that ran does not form them
+            import ctypes as C
+            from ._capi import ConvBnBwd
+            z = bn_bwd['z']
+            assert z.dtype == torch.float32 and z.is_contiguous() and z.numel() == out.numel()
+            M_ = B * Ho * Wo
+            part = torch.empty(2, (M_ + 63) // 64, Cout, device=x.device, dtype=torch.float32)
+            bb = ConvBnBwd(z.data_ptr(), bn_bwd['mean'].data_ptr(), bn_bwd['rstd'].data_ptr(), bn_bwd['w'].data_ptr() if bn_bwd.get('w') is not None else None,
+                           bn_bwd['b'].data_ptr() if bn_bwd.get('b') is not None else None, int(bool(bn_bwd.get('relu'))), part[0].data_ptr(), part[1].data_ptr())
+            rows = C.c_int(0)
+            if mask is not None:
+                assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.shape == out.shape
+            rc = _capi.lib().dir_conv2d_forward_ex(d, _capi.ptr(x), _capi.ptr(w_ohwi), _capi.ptr(scale), _capi.ptr(shift), _capi.ptr(pre_scale), _capi.ptr(pre_shift),
+                                                   _capi.ptr(residual), _capi.ptr(mask), _capi.ptr(out), C.byref(bb), C.byref(rows), _capi.stream_ptr())
+            _capi.check(rc, 'dir_conv2d_forward_ex')
+            if rows.value > 0:
+                bn_bwd['out'].append((part[0], part[1], (M_ + rows.value - 1) // rows.value))
             return out
         if mask is not None:               # y = mask > 0 ? conv (+ residual) : 0 (dir_conv2d_forward_masked: a ReLU backward applied where the gradient is written)
             assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.shape == out.shape and out_coff == 0

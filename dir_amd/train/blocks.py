@@ -58,19 +58,31 @@ def bn_relu_into_conv(P, pre, x, momentum=0.1, eps=1e-5, partials=None):
     return a, None, saved
 
 
-def bn_bwd(P, pre, saved, gy, G, relu=False):
+def bn_bwd(P, pre, saved, gy, G, relu=False, spec=None):
+    """spec: what bn_bwd_spec returned for this BatchNorm and was handed to the data-gradient convolution that wrote gy (conv_bwd(bn_bwd=spec)): when that
+    convolution's epilogue formed the backward sums (spec['out']), the pass over (gy, x) for them is skipped"""
     x, st = saved
     C = x.shape[-1]
-    gx, G[pre + 'weight'], G[pre + 'bias'] = O.bn_train_bwd(gy.contiguous().view(-1, C), x.view(-1, C), P[pre + 'weight'], st, b=P[pre + 'bias'], relu=relu)
+    pt = spec['out'][-1] if (spec is not None and spec['out']) else None
+    gx, G[pre + 'weight'], G[pre + 'bias'] = O.bn_train_bwd(gy.contiguous().view(-1, C), x.view(-1, C), P[pre + 'weight'], st, b=P[pre + 'bias'], relu=relu,
+                                                            partials=pt)
     return gx.view(x.shape)
 
 
-def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None, pre=None, mask_gx=None):
+def bn_bwd_spec(P, pre, saved, relu):
+    """the backward sums of BatchNorm `pre` out of the data-gradient convolution that writes the gradient of its output (round 5): pass the result to
+    _conv_bwd(bn_bwd=...) and then to bn_bwd(spec=...); None = the separate pass"""
+    x, st = saved
+    C = x.shape[-1]
+    return O.bn_bwd_spec(x.view(-1, C), P.get(pre + 'weight'), P.get(pre + 'bias'), st, relu)
+
+
+def _conv_bwd(P, key, x, gy, stride, pad, G, need_gx=True, add_gx=None, pre=None, mask_gx=None, bn_bwd=None):
     """add_gx: another gradient of x, summed into gx in the data-gradient convolution's epilogue; pre: the pre-activation the forward convolution
     applied to x (bn_relu_into_conv) -- gx is then the gradient of the ACTIVATED operand, as before"""
     has_bias = (key + 'bias') in P
     gx, G[key + 'weight'], gb = TC.conv_bwd(x, P[key + 'weight'], gy, stride, pad, need_gx=need_gx, has_bias=has_bias, oihw=True, add_gx=add_gx, gw_oihw=True,
-                                            pre=pre, mask_gx=mask_gx)
+                                            pre=pre, mask_gx=mask_gx, bn_bwd=bn_bwd)
     if has_bias:
         G[key + 'bias'] = gb
     return gx
@@ -95,25 +107,30 @@ def bottleneck_forward(P, x, stride=1):
     return y, ctx
 
 
-def bottleneck_backward(P, ctx, gy, need_gx=True, gy_masked=False, mask_gx=None):
+def bottleneck_backward(P, ctx, gy, need_gx=True, gy_masked=False, mask_gx=None, bn3_spec=None, prev_bn3=None):
     """gy_masked: gy already went through this block's final ReLU backward (the NEXT block's conv1 data gradient applied it: mask_gx there);
     mask_gx: the stored output of the block that produced x -- its ReLU backward is applied to the returned gx in conv1's data-gradient epilogue
-    (round 5: one pass over (gradient, output) per block boundary less; only where nothing else is added to that gradient first)"""
+    (round 5: one pass over (gradient, output) per block boundary less; only where nothing else is added to that gradient first).
+    prev_bn3: bn_bwd_spec of the PREVIOUS block's bn3 (with mask_gx: the masked gx is exactly the gradient of that BatchNorm's output) -- its
+    backward sums are then formed in the same epilogue; the previous block receives the spec back as bn3_spec"""
     G = {}
     x, stride = ctx['x'], ctx['stride']
     g = gy.contiguous() if gy_masked else O.relu_bwd(gy.contiguous(), ctx['y'])               # gradient of (bn3 out + identity)
-    g3 = bn_bwd(P, 'bn3.', ctx['bn3'], g, G)
-    g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G, pre=ctx.get('p2'))
-    g2 = bn_bwd(P, 'bn2.', ctx['bn2'], g2, G, relu=True)
-    g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G, pre=ctx.get('p1'))
-    g1 = bn_bwd(P, 'bn1.', ctx['bn1'], g1, G, relu=True)
+    g3 = bn_bwd(P, 'bn3.', ctx['bn3'], g, G, spec=bn3_spec)
+    s2 = bn_bwd_spec(P, 'bn2.', ctx['bn2'], True)            # bn2's / bn1's backward sums out of the data-gradient convolution that writes their gradient
+    g2 = _conv_bwd(P, 'conv3.', ctx['a2'], g3, 1, 0, G, pre=ctx.get('p2'), bn_bwd=s2)
+    g2 = bn_bwd(P, 'bn2.', ctx['bn2'], g2, G, relu=True, spec=s2)
+    s1 = bn_bwd_spec(P, 'bn1.', ctx['bn1'], True)
+    g1 = _conv_bwd(P, 'conv2.', ctx['a1'], g2, stride, 1, G, pre=ctx.get('p1'), bn_bwd=s1)
+    g1 = bn_bwd(P, 'bn1.', ctx['bn1'], g1, G, relu=True, spec=s1)
     # the identity / projection path's gradient joins conv1's data gradient in that convolution's epilogue (no separate dir_axpy_f32)
     if 'downsample.0.weight' in P:
         gd = bn_bwd(P, 'downsample.1.', ctx['bnd'], g, G)
         other = _conv_bwd(P, 'downsample.0.', x, gd, stride, 0, G, need_gx=need_gx)
     else:
         other = g
-    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx, add_gx=other if need_gx else None, mask_gx=mask_gx if need_gx else None)
+    gx = _conv_bwd(P, 'conv1.', x, g1, 1, 0, G, need_gx=need_gx, add_gx=other if need_gx else None, mask_gx=mask_gx if need_gx else None,
+                   bn_bwd=prev_bn3 if (need_gx and mask_gx is not None) else None)
     return gx, G
 
 
@@ -140,12 +157,15 @@ def residual_backward(P, ctx, gy, need_gx=True):
     G = {}
     x = ctx['x']
     gy = gy.contiguous()
-    g = _conv_bwd(P, 'conv3.conv.', ctx['a2'], gy, 1, 0, G, pre=ctx.get('p2'))
-    g = bn_bwd(P, 'bn3.', ctx['bn3'], g, G, relu=True)
-    g = _conv_bwd(P, 'conv2.conv.', ctx['a1'], g, 1, 1, G, pre=ctx.get('p1'))
-    g = bn_bwd(P, 'bn2.', ctx['bn2'], g, G, relu=True)
-    g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G, pre=ctx.get('p0'))
-    gx = bn_bwd(P, 'bn1.', ctx['bn1'], g, G, relu=True)
+    s3 = bn_bwd_spec(P, 'bn3.', ctx['bn3'], True)            # each BatchNorm's backward sums out of the data-gradient convolution that writes its output's gradient
+    g = _conv_bwd(P, 'conv3.conv.', ctx['a2'], gy, 1, 0, G, pre=ctx.get('p2'), bn_bwd=s3)
+    g = bn_bwd(P, 'bn3.', ctx['bn3'], g, G, relu=True, spec=s3)
+    s2 = bn_bwd_spec(P, 'bn2.', ctx['bn2'], True)
+    g = _conv_bwd(P, 'conv2.conv.', ctx['a1'], g, 1, 1, G, pre=ctx.get('p1'), bn_bwd=s2)
+    g = bn_bwd(P, 'bn2.', ctx['bn2'], g, G, relu=True, spec=s2)
+    s1 = bn_bwd_spec(P, 'bn1.', ctx['bn1'], True)
+    g = _conv_bwd(P, 'conv1.conv.', ctx['a0'], g, 1, 0, G, pre=ctx.get('p0'), bn_bwd=s1)
+    gx = bn_bwd(P, 'bn1.', ctx['bn1'], g, G, relu=True, spec=s1)
     if ctx['need_skip']:
         gs = _conv_bwd(P, 'skip_layer.conv.', x, gy, 1, 0, G, need_gx=need_gx, add_gx=gx if need_gx else None)      # + gx, same launch
         gx = gs if need_gx else gx

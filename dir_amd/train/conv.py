@@ -32,6 +32,9 @@ PREPACK = os.environ.get('DIR_TRAIN_PREPACK', '1') == '1'          # WeightPack 
 # round 5: conv_fwd(stats=[]) asks the convolution's epilogue for the chunk partials of the BatchNorm that follows it (dir_conv2d_forward_stats):
 # that BatchNorm's statistics pass over the stored map is not run.  DIR_TRAIN_STATS_IN_EPILOGUE=0: the separate statistics kernel (rounds 2-4).
 STATS_IN_EPILOGUE = os.environ.get('DIR_TRAIN_STATS_IN_EPILOGUE', '1') == '1'
+# ... and conv_dgrad(bn_bwd=...) for the sums of a BatchNorm's BACKWARD pass from the data-gradient convolution that writes the gradient of its output
+# (dir_conv2d_forward_ex).  DIR_TRAIN_BN_BWD_IN_EPILOGUE=0: the separate pass over (gradient, input).
+BN_BWD_IN_EPILOGUE = os.environ.get('DIR_TRAIN_BN_BWD_IN_EPILOGUE', '1') == '1'
 HEADROOM = 64.0             # pow2_in_scale puts the largest |operand| in [2^9, 2^10): 64x below the f16 maximum
 # (A step's backward must follow its own forward before another model's forward starts: the cache bound by begin_step stays active until
 # the next begin_step.)
@@ -265,7 +268,7 @@ def _site_scale(x, pre=None):
     return s
 
 
-def _conv(x, w, stride, pad, shift=None, packed=None, residual=None, pre=None, stats=None, mask=None):
+def _conv(x, w, stride, pad, shift=None, packed=None, residual=None, pre=None, stats=None, mask=None, bn_bwd=None):
     """w: OHWI fp32 tensor, or None with packed = (_Packed entry, form 0 forward | 1 data gradient); residual: added in the epilogue;
     pre = (pre_scale, pre_shift) [Cin]: the convolution reads max(x pre_scale + pre_shift, 0) (a BatchNorm + ReLU that is not materialised)"""
     pk = {} if pre is None else dict(pre_scale=pre[0], pre_shift=pre[1], pre_relu=True)
@@ -273,6 +276,8 @@ def _conv(x, w, stride, pad, shift=None, packed=None, residual=None, pre=None, s
         pk['stats_out'] = stats          # the following BatchNorm's chunk partials from this convolution's epilogue (dir_conv2d_forward_stats)
     if mask is not None:
         pk['mask'] = mask                # y = mask > 0 ? y : 0 in the epilogue (dir_conv2d_forward_masked)
+    if bn_bwd is not None and BN_BWD_IN_EPILOGUE:
+        pk['bn_bwd'] = bn_bwd            # the chunk partials of the backward pass of the BatchNorm whose output's gradient this convolution writes (dir_conv2d_forward_ex)
     if ARITH != 'f16x3':
         return F.conv2d_nhwc(x, w, stride=stride, pad=pad, shift=shift, residual=residual, **pk)
     shape = w.shape if packed is None else (packed[0].shape, packed[0].dshape)[packed[1]]
@@ -327,7 +332,7 @@ def _pad_last(t, mult):
     return out
 
 
-def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None, mask=None):
+def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None, mask=None, bn_bwd=None):
     """d loss / d x [B,H,W,Cin] of y = conv(x, w, stride, pad) from gy [B,Ho,Wo,Cout]; add [B,H,W,Cin]: another gradient of x, summed in
     the convolution's epilogue (the identity / projection path of a residual block); mask [B,H,W,Cin]: the result is zeroed where mask <= 0 (x is
     the output of a ReLU and mask that output: the ReLU's backward, applied in the same epilogue)"""
@@ -346,7 +351,9 @@ def conv_dgrad(w, gy, stride, pad, H, W, oihw=False, add=None, mask=None):
     p2 = kh - 1 - pad
     fits = g.shape[1] + 2 * p2 - kh + 1 == H and g.shape[2] + 2 * p2 - kw + 1 == W
     fused_mask = mask.contiguous() if (mask is not None and fits and mask.shape[3] % 4 == 0) else None
-    gx = _conv(g, wt, 1, p2, packed=None if e is None else (e, 1), residual=add.contiguous() if (add is not None and fits) else None, mask=fused_mask)
+    # bn_bwd (see _conv): only when the epilogue writes the FINAL gradient (everything that is added to it is added there, any mask applied there)
+    bb = bn_bwd if (bn_bwd is not None and fits and (mask is None or fused_mask is not None) and g.shape[3] % 4 == 0) else None
+    gx = _conv(g, wt, 1, p2, packed=None if e is None else (e, 1), residual=add.contiguous() if (add is not None and fits) else None, mask=fused_mask, bn_bwd=bb)
     if not fits:                                           # odd H / W under stride 2
         assert gx.shape[1] >= H and gx.shape[2] >= W
         gx = gx[:, :H, :W].contiguous()
@@ -399,7 +406,7 @@ def conv_wgrad(x, gy, w_shape, stride, pad, out=None, accumulate=False, pre=None
     return out
 
 
-def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False, pre=None, mask_gx=None):
+def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False, add_gx=None, gw_oihw=False, pre=None, mask_gx=None, bn_bwd=None):
     """-> (gx (+ add_gx), gw [Cout,kh,kw,Cin] ([Cout,Cin,kh,kw] with gw_oihw), gb); w OHWI, or the OIHW parameter with oihw=True (conv_fwd).
     Inside a backward pass (side_begin) gw is produced on the side stream: valid on the compute stream after side_end."""
     gy = gy.contiguous()
@@ -410,5 +417,5 @@ def conv_bwd(x, w, gy, stride=1, pad=0, need_gx=True, has_bias=True, oihw=False,
         return g.permute(0, 3, 1, 2).contiguous() if gw_oihw else g
     gw = side_run(wgrad, x, gy)
     gb = O.colsum(gy.view(-1, gy.shape[3])) if has_bias else None
-    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw, add=add_gx, mask=mask_gx) if need_gx else None
+    gx = conv_dgrad(w, gy, stride, pad, x.shape[1], x.shape[2], oihw=oihw, add=add_gx, mask=mask_gx, bn_bwd=bn_bwd) if need_gx else None
     return gx, gw, gb

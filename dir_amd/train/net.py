@@ -126,8 +126,9 @@ def _stage_image_backward(P, pre, s, g_img_feat, G):
     B = s['emb'].shape[0]
     if 'bf' in s['fus']:
         fpre, f = pre + 'fusion.', s['fus']
-        g = TB._conv_bwd(P, fpre + '3.', f['a'], g_img_feat, 1, 0, G, pre=f.get('pa'))
-        g = TB.bn_bwd(P, fpre + '1.', f['bn'], g, G, relu=True)
+        sp = TB.bn_bwd_spec(P, fpre + '1.', f['bn'], True)
+        g = TB._conv_bwd(P, fpre + '3.', f['a'], g_img_feat, 1, 0, G, pre=f.get('pa'), bn_bwd=sp)
+        g = TB.bn_bwd(P, fpre + '1.', f['bn'], g, G, relu=True, spec=sp)
         g_w_g, g_emb, gul, gur = SP.bone_fusion_bwd(f['bf'], g)
         G[fpre + '0.weight'] = SP.fusion_w_g_grad_to_oihw(g_w_g)
         if (fpre + '0.bias') in P:
@@ -182,15 +183,18 @@ def backbone_backward(P, ctx, g_feats, G, flush=None, pre='backbone.'):
             g = g_feats[li]
         elif g_feats[li] is not None:
             O.axpy(g, g_feats[li])
-        masked = False                                     # the gradient entering a layer's LAST block still needs that block's ReLU backward
+        masked, spec_mine = False, None                    # the gradient entering a layer's LAST block still needs that block's ReLU backward
         for k in range(LAYERS[li] - 1, -1, -1):
             bi_end -= 1
             p, c = ctx['blocks'][bi_end]
             # inside a layer a block's input IS the previous block's output: that block's ReLU backward is applied where this block's conv1 data
             # gradient is written (round 5); a layer's first block hands its gradient to the previous layer's tap, which the decoder's gradient joins first
             prev_y = ctx['blocks'][bi_end - 1][1]['y'] if (k > 0 and TB.FUSE_RELU_BWD) else None
-            g, gb = TB.bottleneck_backward(sub(Pb, p), c, g, gy_masked=masked, mask_gx=prev_y)
-            masked = prev_y is not None
+            # ... and with the mask applied there, that gradient is the gradient of the previous block's bn3 output: its backward sums in the same epilogue
+            pp, pc = ctx['blocks'][bi_end - 1] if prev_y is not None else (None, None)
+            spec_prev = TB.bn_bwd_spec(sub(Pb, pp), 'bn3.', pc['bn3'], False) if prev_y is not None else None
+            g, gb = TB.bottleneck_backward(sub(Pb, p), c, g, gy_masked=masked, mask_gx=prev_y, bn3_spec=spec_mine, prev_bn3=spec_prev)
+            masked, spec_mine = prev_y is not None, spec_prev
             put(G, p, gb)
         flush(G)
     a, x_pool = ctx['stem']

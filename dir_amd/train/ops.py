@@ -323,7 +323,19 @@ def bn_train_apply(x, w, b, stats, relu=False, residual=None):
     return y
 
 
-def bn_train_bwd(gy, x, w, stats, need_gx=True, b=None, relu=False):
+def bn_bwd_spec(x2d, w, b, stats, relu):
+    """what conv_dgrad(bn_bwd=...) needs to form this BatchNorm backward's sums in the data-gradient convolution's epilogue, or None when this
+    BatchNorm does not run the plain large-map path (frozen / pooled statistics, small maps, odd widths)"""
+    R, C = x2d.shape
+    if (not FUSE_BN or BN_FROZEN or len(stats) != 2 or R < FUSE_BN_MIN_ROWS or C % 4 or w is None or b is None or x2d.data_ptr() % 16
+            or _sync_active(C, x2d, w, b)):
+        return None
+    return dict(z=x2d, mean=stats[0], rstd=stats[1], w=w, b=b, relu=bool(relu), out=[])
+
+
+def bn_train_bwd(gy, x, w, stats, need_gx=True, b=None, relu=False, partials=None):
+    """partials: (p1, p2, chunks) formed by the data-gradient convolution that wrote gy (dir_conv2d_forward_ex): the pass over (gy, x) for the two column
+    sums is skipped (dir_bn_train_backward_from_partials)"""
     _chk(gy, x, w, b)
     assert not relu or b is not None
     R, C = x.shape
@@ -331,6 +343,13 @@ def bn_train_bwd(gy, x, w, stats, need_gx=True, b=None, relu=False):
         return sync_bn_bwd(gy, x, w, stats, need_gx, b, relu)
     gx = torch.empty_like(x) if need_gx else None
     gw, gb = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    if partials is not None and not BN_FROZEN and C % 4 == 0 and gy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+        p1, p2, chunks = partials
+        ws = torch.empty(2 * C, device=x.device)
+        _capi.check(_capi.lib().dir_bn_train_backward_from_partials(_capi.ptr(gy), _capi.ptr(x), _capi.ptr(w), _capi.ptr(b), _capi.ptr(stats[0]), _capi.ptr(stats[1]),
+                                                                    _capi.ptr(p1), _capi.ptr(p2), chunks, _capi.ptr(gx), _capi.ptr(gw), _capi.ptr(gb), R, C, C, int(relu),
+                                                                    _capi.ptr(ws), 2 * C * 4, _capi.stream_ptr()), 'dir_bn_train_backward_from_partials')
+        return gx, gw, gb
     if BN_FROZEN:
         n = _capi.lib().dir_bn_frozen_workspace_bytes(R, C)
         ws = torch.empty(n // 4, device=x.device)

@@ -199,6 +199,11 @@ int dir_bn_train_forward(const float* x, const float* w, const float* b, float* 
                          float* workspace, long long workspace_bytes, void* stream);
 int dir_bn_train_backward(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd, float* gx,
                           float* gw, float* gb, int R, int C, int ld, int relu, float* workspace, long long workspace_bytes, void* stream);
+/* dir_bn_train_backward whose first pass (the two column sums) is replaced by chunk partials a data-gradient convolution's epilogue formed
+ * (dir_conv2d_forward_ex): p1 / p2 [chunks][C]; workspace: 2 C floats.  Same combine (chunk order) and apply kernels. */
+int dir_bn_train_backward_from_partials(const float* gy, const float* x, const float* w, const float* b, const float* save_mean, const float* save_rstd,
+                                        const float* p1, const float* p2, int chunks, float* gx, float* gw, float* gb, int R, int C, int ld, int relu,
+                                        float* workspace, long long workspace_bytes, void* stream);
 /* round 5 -- BatchNorm2d (training mode) whose output feeds exactly ONE convolution (Bottleneck bn1 / bn2, models/backbone/resnet.py:125-131;
  * every BatchNorm of the pre-activation Residual, models/backbone/hourglass.py:60-67): only the statistics are formed here (the same kernels and bits
  * as dir_bn_train_forward: save_mean, save_rstd, running statistics) plus pre_scale = w rstd and pre_shift = b - mean w rstd [C]; the normalised
@@ -392,6 +397,20 @@ int dir_conv2d_forward(const dir_conv_desc* desc_host, const void* x, const void
  * in a pass of its own over (gradient, output). */
 int dir_conv2d_forward_masked(const dir_conv_desc* desc, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
                               const float* pre_shift, const void* residual, const float* mask, void* y, void* stream);
+/* round 5 -- the data-gradient convolutions of the training step: dir_conv2d_forward (fp32 output) + residual + output mask (dir_conv2d_forward_masked) + the
+ * chunk partials of the BACKWARD pass of the BatchNorm (+ ReLU) whose output's gradient the convolution writes.  y [M][Cout] is d loss / d (BatchNorm
+ * output); bn->z [M][Cout] the BatchNorm's input, mean / rstd / w / b [Cout] its saved statistics and affine (w, b may be NULL), relu != 0: the ReLU after it
+ * (mask BatchNorm(z) > 0, re-computed like dir_bn_train_backward does).  p1 / p2 [ceil(M / rows)][Cout] (room for ceil(M / 64) x Cout each) receive per M tile
+ * the sums of the masked gradient and of the masked gradient times xhat = (z - mean) rstd; *chunk_rows = rows per tile, 0 when the kernel that took the
+ * launch does not form them.  Feed them to dir_bn_train_backward_from_partials.  nn.Conv2d <- nn.BatchNorm2d <- nn.ReLU under autograd
+ * (models/backbone/resnet.py:125-140, hourglass.py:60-69). */
+typedef struct dir_conv_bn_bwd {
+    const float *z, *mean, *rstd, *w, *b;
+    int32_t relu;
+    float *p1, *p2;
+} dir_conv_bn_bwd;
+int dir_conv2d_forward_ex(const dir_conv_desc* desc, const void* x, const void* w, const float* scale, const float* shift, const float* pre_scale,
+                          const float* pre_shift, const void* residual, const float* mask, void* y, const dir_conv_bn_bwd* bn, int* chunk_rows, void* stream);
 /* round 5 -- dir_conv2d_forward (no residual, no activation, whole fp32 output tensor) that ALSO forms the chunk partials of the training-mode
  * BatchNorm that follows the convolution (nn.Conv2d -> nn.BatchNorm2d, models/backbone/resnet.py:123-133, hourglass.py:14-27) from the output
  * tile while it is in registers: p1 / p2 [ceil(M / rows)][Cout] (room for ceil(M / 64) x Cout floats each), *chunk_rows = rows (the M tile of the

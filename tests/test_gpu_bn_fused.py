@@ -171,6 +171,7 @@ def test_backbone_backward_with_and_without_the_fused_relu_backward():
     sd = synth.synth_state_dict(shapes, 1234)
     img = torch.from_numpy(synth.synth_input('relu_bwd.img', (2, 3, 256, 256), 1234)).cuda()          # (the training stem is written for 256 x 256 inputs, like the reference's data)
     res = {}
+    TC.BN_BWD_IN_EPILOGUE = False          # (bit equality is about the mask alone: with it, bn3's backward sums move into the same epilogue -- another summation order)
     for fused in (True, False):
         TB.FUSE_RELU_BWD = fused
         try:
@@ -185,6 +186,86 @@ def test_backbone_backward_with_and_without_the_fused_relu_backward():
             res[fused] = G
         finally:
             TB.FUSE_RELU_BWD = True
+    TC.BN_BWD_IN_EPILOGUE = True
     assert set(res[True]) == set(res[False])
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), k
+
+
+def test_data_gradient_epilogue_forms_the_batchnorm_backward_sums():
+    """dir_conv2d_forward_ex through conv_dgrad(bn_bwd=spec): the chunk partials of sum(g m) and sum(g m xhat) (m: the ReLU mask BatchNorm(z) > 0, or the
+    output mask already applied) pooled over the chunks equal the sums formed from the stored gradient; dir_bn_train_backward_from_partials then gives
+    dir_bn_train_backward's gradients"""
+    g = torch.Generator(device='cuda').manual_seed(17)
+    for (B, H, Cin, Cout, k, relu, masked) in ((4, 32, 256, 64, 1, True, False), (2, 64, 64, 64, 3, True, False), (8, 16, 1024, 256, 1, False, True), (3, 20, 96, 32, 3, True, False)):
+        w = torch.randn(Cout, Cin, k, k, device='cuda', generator=g) * 0.05
+        gy = torch.randn(B, H, H, Cout, device='cuda', generator=g)
+        z = torch.randn(B, H, H, Cin, device='cuda', generator=g) * 2 + 0.3
+        wbn, bbn = torch.rand(Cin, device='cuda', generator=g) + 0.5, torch.randn(Cin, device='cuda', generator=g) * 0.3
+        _, st = O.bn_train_fwd(z.view(-1, Cin), wbn, bbn, relu=relu)
+        add = torch.randn(B, H, H, Cin, device='cuda', generator=g) if masked else None
+        y_prev = torch.relu(torch.randn(B, H, H, Cin, device='cuda', generator=g)) if masked else None
+        TC.end_step()
+        want_g = TC.conv_dgrad(w, gy, 1, k // 2, H, H, oihw=True, add=add, mask=y_prev)
+        spec = O.bn_bwd_spec(z.view(-1, Cin), wbn, bbn, st, relu)
+        assert spec is not None
+        got_g = TC.conv_dgrad(w, gy, 1, k // 2, H, H, oihw=True, add=add, mask=y_prev, bn_bwd=spec)
+        assert torch.equal(got_g, want_g)
+        assert len(spec['out']) == 1, 'the epilogue did not form the sums'
+        p1, p2, chunks = spec['out'][0]
+        xh = ((z.view(-1, Cin) - st[0]) * st[1]).double()
+        gm = want_g.view(-1, Cin).double()
+        if relu:
+            gm = gm * ((xh.float() * wbn + bbn) > 0)
+        t1, t2 = gm.sum(0), (gm * xh).sum(0)
+        assert float((p1[:chunks].double().sum(0) - t1).abs().max()) < 2e-5 * float(gm.abs().sum(0).max())
+        assert float((p2[:chunks].double().sum(0) - t2).abs().max()) < 2e-5 * float((gm * xh).abs().sum(0).max())
+        a = O.bn_train_bwd(want_g.view(-1, Cin), z.view(-1, Cin), wbn, st, b=bbn, relu=relu)
+        b = O.bn_train_bwd(want_g.view(-1, Cin), z.view(-1, Cin), wbn, st, b=bbn, relu=relu, partials=spec['out'][0])
+        for u, v in zip(a, b):
+            assert rel(v, u) < 2e-5, rel(v, u)
+
+
+@pytest.mark.parametrize('kind', ['bottleneck', 'residual_skip'])
+def test_blocks_with_the_backward_sums_from_the_epilogue_equal_the_separate_pass(kind):
+    g = torch.Generator(device='cuda').manual_seed(5)
+
+    def rnd(*s, scale=1.0):
+        return torch.randn(*s, device='cuda', generator=g) * scale
+    B, S = 4, 32
+    if kind == 'bottleneck':
+        cin, pl = 256, 64
+        P = {'conv1.weight': rnd(pl, cin, 1, 1, scale=0.06), 'conv2.weight': rnd(pl, pl, 3, 3, scale=0.04), 'conv3.weight': rnd(4 * pl, pl, 1, 1, scale=0.1)}
+        bns = (('bn1.', pl), ('bn2.', pl), ('bn3.', 4 * pl))
+        fwd, bwd = (lambda P_, x_: TB.bottleneck_forward(P_, x_, 1)), TB.bottleneck_backward
+    else:
+        cin, cout = 128, 256
+        mid = cout // 2
+        P = {'conv1.conv.weight': rnd(mid, cin, 1, 1, scale=0.08), 'conv1.conv.bias': rnd(mid, scale=0.1), 'conv2.conv.weight': rnd(mid, mid, 3, 3, scale=0.03),
+             'conv2.conv.bias': rnd(mid, scale=0.1), 'conv3.conv.weight': rnd(cout, mid, 1, 1, scale=0.08), 'conv3.conv.bias': rnd(cout, scale=0.1),
+             'skip_layer.conv.weight': rnd(cout, cin, 1, 1, scale=0.08), 'skip_layer.conv.bias': rnd(cout, scale=0.1)}
+        bns = (('bn1.', cin), ('bn2.', mid), ('bn3.', mid))
+        fwd, bwd = TB.residual_forward, TB.residual_backward
+    for n, c in bns:
+        P.update({n + 'weight': torch.rand(c, device='cuda', generator=g) + 0.5, n + 'bias': rnd(c, scale=0.3), n + 'running_mean': torch.zeros(c, device='cuda'),
+                  n + 'running_var': torch.ones(c, device='cuda')})
+    x = rnd(B, S, S, cin)
+    res = {}
+    for on in (False, True):
+        TC.BN_BWD_IN_EPILOGUE = on
+        try:
+            Pc = {k: v.clone() for k, v in P.items()}
+            TC.end_step()
+            y, ctx = fwd(Pc, x)
+            gy = torch.randn(y.shape, device='cuda', generator=torch.Generator(device='cuda').manual_seed(9))
+            res[on] = bwd(Pc, ctx, gy)
+        finally:
+            TC.BN_BWD_IN_EPILOGUE = True
+    (gx0, G0), (gx1, G1) = res[False], res[True]
+    assert rel(gx1, gx0) < 2e-5, rel(gx1, gx0)
+    gmax = max(float(v.abs().max()) for v in G0.values())
+    for k in G0:
+        if k in ('conv1.conv.bias', 'conv2.conv.bias'):
+            assert float(G1[k].abs().max()) < 1e-4 * gmax
+            continue
+        assert rel(G1[k], G0[k]) < 2e-5, (k, rel(G1[k], G0[k]))
