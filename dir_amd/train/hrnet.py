@@ -81,8 +81,9 @@ def basic_backward(P, s, gy, gy_masked=False, mask_gx=None):
     G = {}
     g = gy.contiguous() if gy_masked else O.relu_bwd(gy.contiguous(), s['y'])                  # gradient of (bn2 out + x)
     g2 = TB.bn_bwd(P, 'bn2.', s['bn2'], g, G)
-    g1 = TB._conv_bwd(P, 'conv2.', s['a1'], g2, 1, 1, G, pre=s.get('p1'))
-    g1 = TB.bn_bwd(P, 'bn1.', s['bn1'], g1, G, relu=True)
+    sp = TB.bn_bwd_spec(P, 'bn1.', s['bn1'], True)
+    g1 = TB._conv_bwd(P, 'conv2.', s['a1'], g2, 1, 1, G, pre=s.get('p1'), bn_bwd=sp)
+    g1 = TB.bn_bwd(P, 'bn1.', s['bn1'], g1, G, relu=True, spec=sp)
     gx = TB._conv_bwd(P, 'conv1.', s['x'], g1, 1, 1, G, add_gx=g, mask_gx=mask_gx)
     return gx, G
 

@@ -87,8 +87,9 @@ def _cbr_forward(P, pre, x, k):
 
 
 def _cbr_backward(P, pre, s, gy, G, need_gx=True):
-    g = TB._conv_bwd(P, pre + '3.', s['a'], gy, 1, 0, G)
-    g = TB.bn_bwd(P, pre + '1.', s['bn'], g, G, relu=True)
+    sp = TB.bn_bwd_spec(P, pre + '1.', s['bn'], True)
+    g = TB._conv_bwd(P, pre + '3.', s['a'], gy, 1, 0, G, bn_bwd=sp)
+    g = TB.bn_bwd(P, pre + '1.', s['bn'], g, G, relu=True, spec=sp)
     return TB._conv_bwd(P, pre + '0.', s['x'], g, 1, s['k'] // 2, G, need_gx=need_gx)
 
 
