@@ -89,3 +89,34 @@ def test_bone_fusion_backward_host_side_contract():
     g = _capi.GemmGroups(3, 3, 0, 0, 0, 0, 0, 0, 0, 0)
     one = ctypes.c_void_p(16)
     assert L.dir_gemm_f32_grouped(d, g, one, one, None, one, None) != 0 and b'groups' in L.dir_last_error()      # batch * groups > 65535
+
+
+def test_round5_training_entry_points_host_side_contract():
+    """round 5 entry points (BatchNorm split into statistics / apply, statistics and backward sums out of the convolution epilogues, the fused HRNet
+    sum): argument checks fail with an error code and a message before anything touches a device"""
+    import torch  # noqa: F401
+    from dir_amd import _capi
+    L = _capi.lib()
+    one = ctypes.c_void_p(16)
+
+    def bad(rc, word):
+        assert rc != 0 and word in L.dir_last_error(), (rc, L.dir_last_error())
+    bad(L.dir_fuse_sum(None, one, None, None, 0, 2, 8, 8, 64, 1, 1, None), b'bad args')
+    bad(L.dir_fuse_sum(one, one, None, None, 5, 2, 8, 8, 64, 1, 1, None), b'at most 4')
+    bad(L.dir_fuse_sum(one, one, None, None, 0, 2, 8, 8, 60, 1, 1, None), b'multiple of 8')
+    # dir_bn_train_stats is for maps of more than 512 rows (smaller ones are one cooperative launch in dir_bn_train_forward)
+    bad(L.dir_bn_train_stats(one, one, one, one, one, one, one, None, None, 512, 64, 64, 1e-5, 0.1, one, 1 << 20, None), b'512')
+    bad(L.dir_bn_train_stats(one, one, one, one, one, one, one, None, None, 4096, 64, 64, 1e-5, 0.1, one, 8, None), b'workspace too small')
+    bad(L.dir_bn_train_stats_from_partials(one, one, 128, 3, one, one, one, one, None, None, None, None, 4096, 64, 1e-5, 0.1, None), b'cap_rows')
+    bad(L.dir_bn_train_stats_from_partials(one, one, 0, 64, one, one, one, one, None, None, None, None, 4096, 64, 1e-5, 0.1, None), b'bad arguments')
+    bad(L.dir_bn_train_apply(one, one, one, one, one, one, 4096, 62, 62, 1, None, None), b'multiples of 4')
+    bad(L.dir_bn_train_backward_from_partials(one, one, one, one, one, one, one, one, 32, one, one, one, 4096, 64, 64, 1, one, 8, None), b'workspace')
+    d = _capi.ConvDesc(2, 16, 16, 64, 64, 0, 64, 64, 0, 0, 0, 1, 1, 1, 0, _capi.DT_F32, _capi.DT_F32, 0, 0, 0, 1.0, 0.0)
+    rows = ctypes.c_int(7)
+    bad(L.dir_conv2d_forward_stats(d, one, one, None, None, None, None, one, None, one, ctypes.byref(rows), None), b'null pointer')
+    dr = _capi.ConvDesc(2, 16, 16, 64, 64, 0, 64, 64, 0, 0, 0, 1, 1, 1, 0, _capi.DT_F32, _capi.DT_F32, 1, 0, 0, 1.0, 0.0)          # DIR_CONV_RELU: not the BatchNorm's input any more
+    bad(L.dir_conv2d_forward_stats(dr, one, one, None, None, None, None, one, one, one, ctypes.byref(rows), None), b'without activation')
+    bad(L.dir_conv2d_forward_masked(d, one, one, None, None, None, None, None, None, one, None), b'null mask')
+    bb = _capi.ConvBnBwd(16, 16, 16, None, None, 1, 16, 16)
+    bad(L.dir_conv2d_forward_ex(d, one, one, None, None, None, None, None, None, one, ctypes.byref(bb), None, None), b'chunk_rows')
+    bad(L.dir_conv2d_wgrad_f16x3_pre(d, one, one, one, 0, None, 0, 1.0, 1.0, one, None, 1, None), b'go together')
