@@ -13,7 +13,8 @@ LIMIT = 5000        # characters of json.dumps(compact(detail)); the driver pars
 
 _TOP = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')
 _CONFIG = ('workload', 'batch_per_gpu', 'graph', 'forwards_in_flight', 'ms_per_forward_one_in_flight', 'conv_tuning', 'tunings_bit_identical',
-           'outputs_finite', 'overlapped_equals_one_at_a_time', 'world_size_observed', 'backend', 'timed_regions', 'region_ms_per_step', 'statistic')
+           'outputs_finite', 'overlapped_equals_one_at_a_time', 'world_size_observed', 'backend', 'timed_regions', 'region_ms_per_step', 'region_spread',
+           'statistic', 'weights_kind', 'parity', 'images_per_sec_by_mode', 'parity_by_mode')
 _ROOF = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'frac_mfma', 'frac_hbm', 'alg_bytes_per_launch',
          'alg_gflop_per_launch', 'launches_per_step', 'avg_launch_us', 'all_conv_ms_per_step', 'all_kernels_ms_per_step', 'library_calls_per_step',
          'eager_bracket_overhead_us_per_call')
@@ -55,7 +56,11 @@ def compact(detail, detail_path='bench_detail.json'):
     c = _pick(cfg, _CONFIG)
     c['workload'] = _short(c.get('workload'), 170)
     c['conv_tuning'] = _short(c.get('conv_tuning'), 90)
+    if c.get('parity'):
+        c['parity'] = dict(c['parity'], vs=_short(c['parity'].get('vs'), 60))
     line['config'] = c
+    if detail.get('parity'):                                 # the headline mode against the reference golden, rows of the timed batch
+        line['parity'] = dict(detail['parity'], vs=_short(detail['parity'].get('vs'), 60))
     roof = detail.get('roofline')
     if roof:
         r = _pick(roof, _ROOF)
@@ -111,7 +116,8 @@ def compact(detail, detail_path='bench_detail.json'):
     line['detail'] = detail_path
     # never over the limit: drop the optional parts, least important first
     for drop in (('roofline', 'top_kernels'), ('roofline', 'top_kernels_columns'), ('roofline', 'time_tuned_table'), ('power',), ('without_proj_feat',),
-                 ('roofline', 'traffic_source'), ('config', 'region_ms_per_step'), ('cpu_baseline', 'sample'), ('roofline', 'kernel')):
+                 ('roofline', 'traffic_source'), ('fp16_mode',), ('cpu_baseline', 'sample'), ('roofline', 'kernel'), ('config5_hrnet',), ('pgcn',),
+                 ('config', 'region_ms_per_step')):
         if len(json.dumps(line)) <= LIMIT:
             break
         o = line

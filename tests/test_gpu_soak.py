@@ -16,12 +16,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize('tuning', ['heuristic', 'throughput'])
-def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides(tuning):
+@pytest.mark.parametrize('tuning,dt', [('heuristic', torch.bfloat16), ('throughput', torch.bfloat16), ('throughput', torch.float16)])
+def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides(tuning, dt):
     with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
-    eng = DirEngine(sd, dtype=torch.bfloat16)
+    eng = DirEngine(sd, dtype=dt)                           # torch.float16: f16 storage, bench.py's headline mode
     gen = torch.Generator(device='cuda').manual_seed(3)
     img = torch.randn(64, 3, 256, 256, device='cuda', generator=gen)
     if tuning == 'throughput':                             # the shipped table's kernel mix (256 x 256 tiles, halo reuse, streaming 1x1) beside the foreign kernel
@@ -50,15 +50,15 @@ def test_foreign_fma_kernel_beside_the_forward_is_bit_exact_on_both_sides(tuning
         assert all(torch.equal(x, want) for x in outs), 'foreign kernel corrupted beside the forward (round %d)' % rnd
 
 
-@pytest.mark.parametrize('tuning', ['time', 'throughput'])
-def test_four_forwards_in_flight_reproduce_the_one_at_a_time_results(tuning):
+@pytest.mark.parametrize('tuning,dt', [('time', torch.bfloat16), ('throughput', torch.bfloat16), ('throughput', torch.float16)])
+def test_four_forwards_in_flight_reproduce_the_one_at_a_time_results(tuning, dt):
     """bench.py's default concurrency (four pipeline slots), with the live time-tuned kernel choice and with the shipped throughput table
     (large tiles on few CUs beside other forwards' kernels: another mix of co-resident kernels): every slot, every round, equals its stand-alone
     result bit for bit, and the two tables agree with each other"""
     with open(os.path.join(HERE, 'golden', 'manifest_dir.json')) as f:
         shapes = {k: tuple(v) for k, v in json.load(f).items()}
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(shapes, 1234).items()}
-    eng = DirEngine(sd, dtype=torch.bfloat16)
+    eng = DirEngine(sd, dtype=dt)                           # torch.float16: f16 storage, bench.py's headline mode
     gen = torch.Generator(device='cuda').manual_seed(11)
     imgs = [torch.randn(64, 3, 256, 256, device='cuda', generator=gen) for _ in range(4)]
     eng.autotune(imgs[0])
