@@ -227,7 +227,10 @@ def evaluate_from_disk(eng, data_path, J_regressor, mano_layer, bs=256, root_joi
             # f16 arithmetic modes: the per-layer power-of-two operand scales come from the first batch, BEFORE the slots' graphs are captured
             # (the scales are launch arguments: a graph captured earlier would replay the uncalibrated ones)
             f0 = first[0].to(dev)
-            eng.calibrate(rec_dec[0](f0, slots[0].clone()) if source == 'jpeg' else f0)
+            # (only the first[2] valid rows: in a partial first batch the rows beyond it are still the ring's zero-initialised records, which
+            # the device decoder would report as unusable -- and evaluate would raise after every image had been scored)
+            n0 = int(first[2])
+            eng.calibrate(rec_dec[0](f0, slots[0].clone(), n0)[:n0].contiguous() if source == 'jpeg' else f0[:n0].contiguous())
         pipe = ForwardPipeline(eng, slots, want_proj_feat=False)
         t0 = time.perf_counter()
         for k, (frames, annos, n) in enumerate(itertools.chain([first] if first is not None else [], batches)):

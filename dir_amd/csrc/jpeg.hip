@@ -62,8 +62,24 @@ struct JpegArgs {
     int* err;                                    // set to 1 + image index when a record does not describe an H x W image this kernel handles
 };
 
+// A record is trusted for plane addressing and divisions only if its geometry is the one its own (W, H, sampling) imply -- a slot of the shared-memory
+// ring that a crashed worker left half-written, or a stale one, must raise the error flag instead of writing outside the image's plane scratch or
+// dividing by blocks_x == 0.  Supported sampling: luma (1,1), (2,1), (2,2), chroma (1,1) -- what jpeg_huff.c emits.
 __device__ __forceinline__ bool record_ok(const dir_jpeg_header* h, int H, int W, long long pstride) {
-    return h->magic == DIR_JPEG_MAGIC && h->width == W && h->height == H && (h->ncomp == 1 || h->ncomp == 3) && h->total_coef > 0 && h->total_coef <= pstride;
+    if (!(h->magic == DIR_JPEG_MAGIC && h->width == W && h->height == H && (h->ncomp == 1 || h->ncomp == 3) && h->total_coef > 0 && h->total_coef <= pstride))
+        return false;
+    const int hm = h->hmax, vm = h->vmax;
+    if (!((hm == 1 && vm == 1) || (hm == 2 && vm == 1) || (hm == 2 && vm == 2))) return false;
+    if (h->h[0] != hm || h->v[0] != vm || (h->ncomp == 1 && hm != 1)) return false;
+    const int mcux = (W + 8 * hm - 1) / (8 * hm), mcuy = (H + 8 * vm - 1) / (8 * vm);
+    if (h->mcux != mcux || h->mcuy != mcuy) return false;
+    long long total = 0;
+    for (int c = 0; c < h->ncomp; ++c) {
+        if (c > 0 && (h->h[c] != 1 || h->v[c] != 1)) return false;
+        if (h->blocks_x[c] != mcux * h->h[c] || h->blocks_y[c] != mcuy * h->v[c] || h->coef_offset[c] != total) return false;
+        total += (long long)h->blocks_x[c] * h->blocks_y[c] * 64;
+    }
+    return total == h->total_coef;
 }
 __device__ __forceinline__ bool record_is_pixels(const dir_jpeg_header* h, int H, int W, long long stride) {
     return h->magic == DIR_JPEG_MAGIC_PIXELS && h->width == W && h->height == H && (long long)sizeof(dir_jpeg_header) + 3ll * H * W <= stride;

@@ -209,6 +209,9 @@ int dir_jpeg_decode_coefficients(const uint8_t* data, size_t n, void* record, si
         if (H->v[c] > vmax) vmax = H->v[c];
     }
     if (H->ncomp == 3 && (H->h[1] != 1 || H->v[1] != 1 || H->h[2] != 1 || H->v[2] != 1)) return DIR_JPEG_E_UNSUPPORTED; /* chroma at the base rate only */
+    /* luma 1x2 (4:4:0) has no device upsampler (jpeg.hip: h1v1, h2v1, h2v2 only) and no oracle (oracle/jpeg.py raises): such a file must travel as a
+       pixel record, not decode to silently wrong chroma */
+    if (H->ncomp == 3 && H->h[0] == 1 && H->v[0] == 2) return DIR_JPEG_E_UNSUPPORTED;
     H->hmax = hmax;
     H->vmax = vmax;
     H->mcux = (H->width + 8 * hmax - 1) / (8 * hmax);
@@ -221,6 +224,7 @@ int dir_jpeg_decode_coefficients(const uint8_t* data, size_t n, void* record, si
         total += (int64_t)H->blocks_x[c] * H->blocks_y[c] * 64;
         memcpy(H->quant[c], qt[comp_tq[c]], sizeof(H->quant[c]));
     }
+    if (total > 0x7fffffffll) return DIR_JPEG_E_UNSUPPORTED; /* the header's 32-bit offsets could not hold it (65535 x 65535 frames) */
     H->total_coef = (int32_t)total;
     H->magic = DIR_JPEG_MAGIC;
     if (sizeof(dir_jpeg_header) + (size_t)total * 2 > record_bytes) return DIR_JPEG_E_SPACE;
@@ -248,8 +252,9 @@ int dir_jpeg_decode_coefficients(const uint8_t* data, size_t n, void* record, si
                     for (int bx = 0; bx < H->h[c]; ++bx) {
                         int16_t* blk = coef + H->coef_offset[c] + ((int64_t)(my * H->v[c] + by) * H->blocks_x[c] + (mx * H->h[c] + bx)) * 64;
                         const int t = decode_symbol(&b, hd);
-                        if (t < 0 || t > 15) return DIR_JPEG_E_FORMAT;
+                        if (t < 0 || t > 11) return DIR_JPEG_E_FORMAT; /* 8-bit baseline: DC difference categories 0..11 (T.81 F.1.2.1.1) */
                         pred[c] += extend(get_bits(&b, t), t);
+                        if (pred[c] < -32768 || pred[c] > 32767) return DIR_JPEG_E_FORMAT; /* a crafted stream must not wrap the predictor */
                         blk[0] = (int16_t)pred[c];
                         for (int k = 1; k < 64;) {
                             if (b.n < 16) refill(&b);

@@ -7,6 +7,11 @@
 //   mode 2  HBM copy (round 5): the first half of `buf` copied to the second half with 16-byte loads and stores -- what a
 //           streaming kernel does (it reads AND writes); returns bytes read + bytes written.  A read-only loop under-reports the ceiling (5.1 TB/s
 //           on these boards, below what bone_vis_kernel achieves).
+//           Round 6: the first version (4096 x 256 grid-stride, four loads 16 MB apart, dst exactly 512 MiB behind src)
+//           reported 4.1 TB/s where the guide's float4 copy reaches 6.29 and bone_vis_kernel 6.5: power-of-two strides and a power-of-two
+//           src -> dst distance put a wave's four streams and its stores on the same channels.  Now: CUs x 8 persistent workgroups, each
+//           iteration moves one CONTIGUOUS 32 KB block (8 independent 16-byte loads per lane in flight, 4 KB apart), non-temporal stores
+//           (every byte is touched once), dst placed an odd number of 4 KB pages (+ 256 B) behind the middle of the buffer.
 //   mode 3  as mode 0 on the f16 matrix-core instruction (v_mfma_f32_32x32x16_f16) with pseudo-random f16 operands: the f16-storage mode's ceiling.
 // Nothing in the product path calls this.
 #include "dir_common.h"
@@ -76,11 +81,16 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-__global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+constexpr int CPY_U = 8;                                  // independent 16-byte loads per lane and iteration
+// persistent workgroups; block b of the buffer = CPY_U x 256 consecutive 16-byte elements (32 KB), blocks dealt round-robin
+__global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t nblocks) {
+    for (size_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const size_t base = b * (CPY_U * 256) + threadIdx.x;
+        u32x4 v[CPY_U];
+#pragma unroll
+        for (int u = 0; u < CPY_U; ++u) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+#pragma unroll
+        for (int u = 0; u < CPY_U; ++u) __builtin_nontemporal_store(v[u], dst + base + u * 256);
     }
 }
 }  // namespace
@@ -105,11 +115,15 @@ extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int 
         return (long long)(groups * 4 * stride * 16);                    // bytes the loop really reads
     }
     if (mode == 2) {
-        const size_t n = (size_t)bytes / 32;                             // 16-byte elements per half
-        hipLaunchKernelGGL(probe_copy_kernel, dim3(4096), dim3(256), 0, s, (const uint4*)buf, (uint4*)buf + n, n);
+        if (bytes < (4ll << 20)) { dir::set_error("dir_probe_launch: the copy probe needs at least 4 MiB"); return DIR_E_INVALID; }
+        const size_t skew = 37 * 4096 + 256;                             // dst starts an odd number of pages (+ 256 B) behind the middle
+        const size_t half = (size_t)bytes / 2, blk = (size_t)CPY_U * 256 * 16;
+        const size_t nblocks = (half - skew) / blk;
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(probe_copy_kernel, dim3(ncu * 8), dim3(256), 0, s, (const u32x4*)buf, (u32x4*)((char*)buf + half + skew), nblocks);
         if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
-        const size_t stride = 4096ull * 256, groups = n / (4 * stride);
-        return (long long)(groups * 4 * stride * 32);                    // bytes read + bytes written
+        return (long long)(nblocks * blk * 2);                           // bytes read + bytes written
     }
     dir::set_error("dir_probe_launch: mode must be 0 (bf16 MFMA), 1 (HBM read), 2 (HBM copy) or 3 (f16 MFMA)");
     return DIR_E_INVALID;

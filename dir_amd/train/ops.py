@@ -163,8 +163,13 @@ class sync_batchnorm(object):
 def _sync_active(C, *ts):
     from .. import dist as D
     import torch.distributed as dist
-    return (SYNC_BN and not BN_FROZEN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and C % 4 == 0
-            and all(t is None or t.data_ptr() % 16 == 0 for t in ts)) and D is not None
+    # rank-INVARIANT facts only: a rank that fell back to the local path because one of its tensors happened to be misaligned would
+    # leave the others waiting in all_gather / all_reduce.  Alignment is asserted instead (torch's caching allocator hands out 512-byte aligned
+    # blocks; a sliced view with an odd offset is a caller error in this mode).
+    on = SYNC_BN and not BN_FROZEN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and C % 4 == 0 and D is not None
+    if on:
+        assert all(t is None or t.data_ptr() % 16 == 0 for t in ts), 'SyncBN: tensors must be 16-byte aligned (a rank cannot fall back on its own)'
+    return on
 
 
 def _sync_ws(R, C, dev):
@@ -192,7 +197,16 @@ def sync_bn_fwd(x, w, b, running_mean, running_var, eps, momentum, relu, residua
     written = [t for t in (running_mean, running_var) if t is not None]
     if written:
         torch._C._increment_version(written)
-    return y, (sm, sr, float(parts[:, 2 * C].sum()))
+    # pooled row count: one host read per distinct (rows, world size) of this process instead of one per BatchNorm layer and step -- the
+    # shards of a run are fixed (dir_amd.dist.shard_range), so the other ranks' row counts do not change between steps
+    import torch.distributed as dist
+    key = (R, dist.get_world_size())
+    if key not in _POOLED_ROWS:
+        _POOLED_ROWS[key] = float(parts[:, 2 * C].sum())
+    return y, (sm, sr, _POOLED_ROWS[key])
+
+
+_POOLED_ROWS = {}
 
 
 def sync_bn_bwd(gy, x, w, stats, need_gx, b, relu):

@@ -109,6 +109,20 @@ def test_file_to_record_falls_back_to_pixel_records(tmp_path):
         if kind == 'pixels':
             assert row[:16].view(np.int32)[0] == AJ.MAGIC_PIXELS
             assert np.array_equal(row[512:512 + 256 * 256 * 3].reshape(256, 256, 3), DS.decode_bgr(p, 256)), name
+    # 4:4:0 (luma sampled 1x2): no device upsampler and no oracle for it -> the host decoder must refuse it (it used to return a
+    # coefficient record that the colour kernel then read with the h2v2 formulas).  PIL cannot write 4:4:0, but a 4:2:2 stream of a 256x256 frame
+    # has the same MCU count and blocks per MCU, so its SOF0 luma sampling byte 0x21 -> 0x12 gives a legal 4:4:0 file (other picture, same syntax)
+    p422 = str(tmp_path / 'c422.jpg')
+    Image.fromarray(a).save(p422, quality=90, subsampling=1)
+    raw = bytearray(open(p422, 'rb').read())
+    i = raw.index(b'\xff\xc0')
+    assert raw[i + 11] == 0x21                      # FFC0 Lf(2) P(1) Y(2) X(2) Nf(1) C1(1) H1V1(1)
+    raw[i + 11] = 0x12
+    p440 = str(tmp_path / 'c440.jpg')
+    open(p440, 'wb').write(bytes(raw))
+    assert host().dir_jpeg_decode_coefficients(bytes(raw), len(raw), row.ctypes.data, row.size) == -3
+    assert AJ.file_to_record(p440, row, 256) == 'pixels'
+    assert np.array_equal(row[512:512 + 256 * 256 * 3].reshape(256, 256, 3), DS.decode_bgr(p440, 256))
     with pytest.raises(ValueError):
         (tmp_path / 'bad.jpg').write_bytes(b'not a jpeg at all')
         AJ.file_to_record(str(tmp_path / 'bad.jpg'), row, 256)
