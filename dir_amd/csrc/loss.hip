@@ -6,13 +6,12 @@
 //     scratch table and reduced over the batch in a fixed order by a second tiny launch (deterministic; no float atomics).
 //   * dense_pixel_kernel / lovasz_kernel / dense_final_kernel: models/dir.py:562-569 -- F.interpolate (nearest labels, bilinear
 //     dense map), class-weighted cross entropy, SmoothL1 on the dense map, and lovasz_softmax (models/lovasz_loss.py:155-202) on the
-//     raw logits exactly as the reference calls it.  The descending sort of the per-class errors is ONE rocPRIM device radix sort over
-//     composite (class, error) keys (a library primitive, like a plain library GEMM); the Jaccard scan runs one workgroup per class with a carried prefix.
+//     raw logits exactly as the reference calls it.  The descending sort of the per-class errors (models/lovasz_loss.py:107-111: torch.sort) is a
+//     hand-written stable LSD radix sort, one segment per class (seg_radix_sort_desc below; rounds 1-5 called rocPRIM here -- the last vendor-library
+//     primitive of libdir_hip.so); the Jaccard scan runs one workgroup per class with a carried prefix.
 // Elementwise arithmetic is fp32 in the reference's operation order (contraction off); sums accumulate in fp64.
 // HBM-bound and tiny: 2 x (778 x 5 + ...) floats per sample and stage.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "dir_common.h"
 
@@ -235,6 +234,121 @@ __global__ __launch_bounds__(LT) void dense_pixel_kernel(DenseArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Stable descending radix sort of `nseg` equal segments of P (key, value) pairs, keys ordered by their LOW 32 bits (the error's float bits: errors
+// are >= 0, so unsigned order = float order; the class sits in the bits above and is constant inside a segment).  Four LSD passes of 8 bits, two
+// launches each, ping-pong between (k0, v0) and (k1, v1): the sorted pairs end up where they started, in (k0, v0).
+//   radix_hist_kernel     workgroup = (2048-element tile, segment): the tile's 256-bin digit histogram -> hist[(seg * 256 + digit) * nblk + tile]
+//   radix_scatter_kernel  the same workgroup: its 256 start offsets from the table (bins before its digit in the whole segment + the same digit in
+//                         earlier tiles), then the tile in chunks of 256 elements IN INDEX ORDER: a wave finds the lanes that share a digit with
+//                         eight ballots (rank among them = popcount below the lane), per-wave counts meet in LDS, offsets follow wave order --
+//                         so equal keys keep their input order (what rocPRIM's radix sort gave; the goldens G8 / G12 hold ties bit for bit).
+// "Descending" = ascending on the complemented digit.  Integer counts only: deterministic.  3 x 65 536 pairs (B = 64, S = 32): 8 launches of
+// <= 96 workgroups, 2.4 MB moved per pass.
+constexpr int RS_T = 256, RS_E = 8, RS_TILE = RS_T * RS_E;
+
+__global__ __launch_bounds__(RS_T) void radix_hist_kernel(const unsigned long long* __restrict__ keys, int P, int shift, int nblk, unsigned* __restrict__ hist) {
+    __shared__ unsigned s_h[256];
+    const int tid = threadIdx.x, blk = blockIdx.x, seg = blockIdx.y;
+    s_h[tid] = 0;
+    __syncthreads();
+    const unsigned long long* k = keys + (size_t)seg * P;
+#pragma unroll
+    for (int e = 0; e < RS_E; ++e) {
+        const int i = blk * RS_TILE + e * RS_T + tid;
+        if (i < P) atomicAdd(&s_h[255u - (((unsigned)k[i] >> shift) & 255u)], 1u);
+    }
+    __syncthreads();
+    hist[((size_t)seg * 256 + tid) * nblk + blk] = s_h[tid];
+}
+
+template <typename V>
+__global__ __launch_bounds__(RS_T) void radix_scatter_kernel(const unsigned long long* __restrict__ kin, const V* __restrict__ vin, unsigned long long* __restrict__ kout,
+                                                             V* __restrict__ vout, int P, int shift, int nblk, const unsigned* __restrict__ hist) {
+    __shared__ unsigned s_run[256];                 // next free output slot of every digit for this tile
+    __shared__ unsigned s_cnt[RS_T / 64][256];      // per-wave digit counts of the current chunk
+    __shared__ unsigned s_scan[RS_T / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, seg = blockIdx.y;
+    {   // digit `tid`: elements of the whole segment with this digit, and those in earlier tiles
+        const unsigned* hrow = hist + ((size_t)seg * 256 + tid) * nblk;
+        unsigned tot = 0, below = 0;
+        for (int b = 0; b < nblk; ++b) {
+            const unsigned h = hrow[b];
+            below += b < blk ? h : 0u;
+            tot += h;
+        }
+        unsigned x = tot;                           // exclusive scan of tot over the 256 digits
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_scan[wave] = x;
+        __syncthreads();
+        unsigned woff = 0;
+#pragma unroll
+        for (int w = 0; w < RS_T / 64; ++w) woff += w < wave ? s_scan[w] : 0u;
+        s_run[tid] = woff + x - tot + below;
+    }
+    const unsigned long long* k = kin + (size_t)seg * P;
+    const V* v = vin + (size_t)seg * P;
+    unsigned long long* ko = kout + (size_t)seg * P;
+    V* vo = vout + (size_t)seg * P;
+    for (int e = 0; e < RS_E; ++e) {
+        const int i = blk * RS_TILE + e * RS_T + tid;
+        const bool ok = i < P;
+        const unsigned long long key = ok ? k[i] : 0ull;
+        const V val = ok ? v[i] : V(0);
+        const unsigned d = 255u - (((unsigned)key >> shift) & 255u);
+#pragma unroll
+        for (int w = 0; w < RS_T / 64; ++w) s_cnt[w][tid] = 0;
+        unsigned long long same = __ballot(ok);     // valid lanes of this wave with my digit
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long b = __ballot((d >> bit) & 1u);
+            same &= ((d >> bit) & 1u) ? b : ~b;
+        }
+        const unsigned rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+        __syncthreads();                            // counts zeroed; s_run of the previous chunk (or the set-up) final
+        if (ok && rank == 0) s_cnt[wave][d] = (unsigned)__popcll(same);
+        __syncthreads();
+        if (ok) {
+            unsigned off = s_run[d] + rank;
+#pragma unroll
+            for (int w = 0; w < RS_T / 64; ++w) off += w < wave ? s_cnt[w][d] : 0u;
+            ko[off] = key;
+            vo[off] = val;
+        }
+        __syncthreads();                            // every offset read s_run before it moves
+        {
+            unsigned add = 0;
+#pragma unroll
+            for (int w = 0; w < RS_T / 64; ++w) add += s_cnt[w][tid];
+            s_run[tid] += add;
+        }
+        __syncthreads();                            // ... and s_cnt before the next chunk zeroes it
+    }
+}
+
+inline int radix_tiles(size_t P) { return (int)((P + RS_TILE - 1) / RS_TILE); }
+inline size_t radix_hist_bytes(size_t P, int nseg) { return (size_t)nseg * 256 * radix_tiles(P) * sizeof(unsigned); }
+
+// sorted pairs end in (k0, v0); (k1, v1) and hist are scratch
+template <typename V>
+int seg_radix_sort_desc(unsigned long long* k0, V* v0, unsigned long long* k1, V* v1, unsigned* hist, int P, int nseg, hipStream_t s) {
+    const int nblk = radix_tiles((size_t)P);
+    for (int pass = 0; pass < 4; ++pass) {
+        const unsigned long long* ki = pass & 1 ? k1 : k0;
+        const V* vi = pass & 1 ? v1 : v0;
+        unsigned long long* ko = pass & 1 ? k0 : k1;
+        V* vo = pass & 1 ? v0 : v1;
+        DIR_LAUNCH(radix_hist_kernel, dim3(nblk, nseg), dim3(RS_T), 0, s, ki, P, 8 * pass, nblk, hist);
+        DIR_LAUNCH((radix_scatter_kernel<V>), dim3(nblk, nseg), dim3(RS_T), 0, s, ki, vi, ko, vo, P, 8 * pass, nblk, (const unsigned*)hist);
+    }
+    return 0;
+}
+
 constexpr int LV_T = 1024, LV_E = 8;
 // one workgroup per class: loss_c = sum_i err_sorted[i] * (J_i - J_{i-1}), J_i = 1 - (G - cumfg_i) / (G + cumbg_i)
 // (models/lovasz_loss.py:19-31,194-197); result[c] = loss, result[3 + c] = G (0 -> class absent, skipped by 'present').
@@ -331,7 +445,6 @@ __global__ __launch_bounds__(64) void dense_final_kernel(const double* __restric
 // workspace carve-up (all offsets 256-byte aligned)
 struct DenseWs { size_t keys_in, keys_out, vals_in, vals_out, partial, lov, temp, temp_bytes, total; };
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
-constexpr unsigned KEY_BITS = 34;            // 32 bits of error + 2 bits of class
 int dense_ws(int B, int S, DenseWs& w) {
     const size_t P = (size_t)B * S * S;
     const int chunks = (S * S + LT - 1) / LT;
@@ -342,10 +455,7 @@ int dense_ws(int B, int S, DenseWs& w) {
     w.vals_out = o; o = al(o + 3 * P);
     w.partial = o; o = al(o + (size_t)B * chunks * 6 * sizeof(double));
     w.lov = o; o = al(o + 6 * sizeof(double));
-    size_t tb = 0;
-    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                                        (const unsigned char*)nullptr, (unsigned char*)nullptr, 3 * P, 0u, KEY_BITS, (hipStream_t)0);
-    if (e != hipSuccess) return -1;
+    const size_t tb = radix_hist_bytes(P, 3);     // the sort's digit histograms
     w.temp = o; w.temp_bytes = tb; o = al(o + tb);
     w.total = o;
     return 0;
@@ -626,10 +736,7 @@ int dense_bwd_ws(int B, int S, DenseBwdWs& w) {
     w.result = o; o = al(o + 4 * sizeof(double));
     w.label = o; o = al(o + P);
     w.glov = o; o = al(o + 3 * P * 4);
-    size_t tb = 0;
-    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)nullptr, tb, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                                        (const unsigned*)nullptr, (unsigned*)nullptr, 3 * P, 0u, KEY_BITS, (hipStream_t)0);
-    if (e != hipSuccess) return -1;
+    const size_t tb = radix_hist_bytes(P, 3);
     w.temp = o; w.temp_bytes = tb; o = al(o + tb);
     w.total = o;
     return 0;
@@ -683,7 +790,7 @@ extern "C" int dir_dense_losses_backward(const float* seg_logits, const float* d
                 "dir_dense_losses_backward: null pointer");
     DIR_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && (long long)B * S * S * 3 < (1ll << 31), "dir_dense_losses_backward: bad shape");
     DenseBwdWs w;
-    DIR_REQUIRE(dense_bwd_ws(B, S, w) == 0, "dir_dense_losses_backward: rocPRIM size query failed");
+    DIR_REQUIRE(dense_bwd_ws(B, S, w) == 0, "dir_dense_losses_backward: workspace layout failed");
     DIR_REQUIRE(workspace_bytes >= (long long)w.total, "dir_dense_losses_backward: workspace too small (%lld < %zu)", workspace_bytes, w.total);
     char* ws = (char*)workspace;
     hipStream_t s = (hipStream_t)stream;
@@ -694,13 +801,11 @@ extern "C" int dir_dense_losses_backward(const float* seg_logits, const float* d
     a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT; a.dense_weight = dense_weight;
     for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
     DIR_LAUNCH(dense_bwd_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
-    size_t tb = w.temp_bytes;
-    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const unsigned long long*)a.keys, (unsigned long long*)(ws + w.keys_out),
-                                                        (const unsigned*)a.vals, (unsigned*)(ws + w.vals_out), (size_t)3 * a.P, 0u, KEY_BITS, s);
-    DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_backward: rocPRIM sort: %s", hipGetErrorString(e));
+    // per-class descending stable sort; the sorted pairs come back in (keys_in, vals_in)
+    seg_radix_sort_desc<unsigned>(a.keys, a.vals, (unsigned long long*)(ws + w.keys_out), (unsigned*)(ws + w.vals_out), (unsigned*)(ws + w.temp), a.P, 3, s);
     double* result = (double*)(ws + w.result);
     float* glov = (float*)(ws + w.glov);
-    DIR_LAUNCH(lovasz_bwd_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned*)(ws + w.vals_out),
+    DIR_LAUNCH(lovasz_bwd_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)a.keys, (const unsigned*)a.vals,
                        seg_logits, (const double*)a.partial, B * a.chunks, a.P, S * S, glov, result);
     DIR_LAUNCH(dense_bwd_final_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a, (const float*)glov, (const double*)result, grad_seg);
     return check_launch("dir_dense_losses_backward");
@@ -740,7 +845,7 @@ extern "C" int dir_dense_losses_forward(const float* seg_logits, const float* de
                 "dir_dense_losses_forward: null pointer");
     DIR_REQUIRE(B > 0 && S > 0 && H > 0 && W > 0 && (long long)B * S * S * 3 < (1ll << 31), "dir_dense_losses_forward: bad shape");
     DenseWs w;
-    DIR_REQUIRE(dense_ws(B, S, w) == 0, "dir_dense_losses_forward: rocPRIM size query failed");
+    DIR_REQUIRE(dense_ws(B, S, w) == 0, "dir_dense_losses_forward: workspace layout failed");
     DIR_REQUIRE(workspace_bytes >= (long long)w.total, "dir_dense_losses_forward: workspace too small (%lld < %zu)", workspace_bytes, w.total);
     char* ws = (char*)workspace;
     hipStream_t s = (hipStream_t)stream;
@@ -750,12 +855,9 @@ extern "C" int dir_dense_losses_forward(const float* seg_logits, const float* de
     a.B = B; a.S = S; a.H = H; a.W = W; a.P = B * S * S; a.chunks = (S * S + LT - 1) / LT;
     for (int c = 0; c < 3; ++c) a.cw[c] = class_weight_host[c];
     DIR_LAUNCH(dense_pixel_kernel, dim3(a.chunks, B), dim3(LT), 0, s, a);
-    size_t tb = w.temp_bytes;
-    const hipError_t e = rocprim::radix_sort_pairs_desc((void*)(ws + w.temp), tb, (const unsigned long long*)a.keys, (unsigned long long*)(ws + w.keys_out),
-                                                        (const unsigned char*)a.vals, (unsigned char*)(ws + w.vals_out), (size_t)3 * a.P, 0u, KEY_BITS, s);
-    DIR_REQUIRE(e == hipSuccess, "dir_dense_losses_forward: rocPRIM sort: %s", hipGetErrorString(e));
+    seg_radix_sort_desc<unsigned char>(a.keys, a.vals, (unsigned long long*)(ws + w.keys_out), (unsigned char*)(ws + w.vals_out), (unsigned*)(ws + w.temp), a.P, 3, s);
     double* lov = (double*)(ws + w.lov);
-    DIR_LAUNCH(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)(ws + w.keys_out), (const unsigned char*)(ws + w.vals_out),
+    DIR_LAUNCH(lovasz_kernel, dim3(3), dim3(LV_T), 0, s, (const unsigned long long*)a.keys, (const unsigned char*)a.vals,
                        (const double*)a.partial, B * a.chunks, a.P, lov);
     DIR_LAUNCH(dense_final_kernel, dim3(1), dim3(64), 0, s, (const double*)a.partial, a.chunks, B, S, (const double*)lov, dense_weight, out3);
     return check_launch("dir_dense_losses_forward");

@@ -874,7 +874,7 @@ int dir_stage_losses_forward(const dir_loss_pred* pred_host, const dir_loss_targ
 /* models/dir.py:562-569: seg (weighted cross entropy x0.1), dense (SmoothL1), lovasz (x0.1), each x dense_weight -> out3.
  * seg_logits / dense_pred [B,3,S,S]; gt_seg [B,1,H,W] labels 0..2 stored as floats (F.interpolate nearest -> .long());
  * gt_dense [B,3,H,W] (F.interpolate bilinear).  class_weight_host: 3 floats (0.1, 0.45, 0.45).  workspace: device bytes,
- * dir_dense_losses_workspace_bytes(B, S) of them (sort keys / values and rocPRIM's temporary storage). */
+ * dir_dense_losses_workspace_bytes(B, S) of them (sort keys / values, both halves of the radix sort's ping-pong, and its digit histograms). */
 long long dir_dense_losses_workspace_bytes(int B, int S);
 int dir_dense_losses_forward(const float* seg_logits, const float* dense_pred, const float* gt_seg, const float* gt_dense,
                              const float* class_weight_host, float dense_weight, void* workspace, long long workspace_bytes,
