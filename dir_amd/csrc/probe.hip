@@ -9,9 +9,10 @@
 //           on these boards, below what bone_vis_kernel achieves).
 //           Round 6: the first version (4096 x 256 grid-stride, four loads 16 MB apart, dst exactly 512 MiB behind src)
 //           reported 4.1 TB/s where the guide's float4 copy reaches 6.29 and bone_vis_kernel 6.5: power-of-two strides and a power-of-two
-//           src -> dst distance put a wave's four streams and its stores on the same channels.  Now: CUs x 8 persistent workgroups, each
-//           iteration moves one CONTIGUOUS 32 KB block (8 independent 16-byte loads per lane in flight, 4 KB apart), non-temporal stores
-//           (every byte is touched once), dst placed an odd number of 4 KB pages (+ 256 B) behind the middle of the buffer.
+//           src -> dst distance put a wave's four streams and its stores on the same channels.  Now: CUs x 2 persistent workgroups, each
+//           iteration moves one CONTIGUOUS 16 KB block (4 independent 16-byte loads per lane in flight, 4 KB apart), non-temporal stores
+//           (every byte is touched once), dst placed an odd number of 4 KB pages (+ 256 B) behind the middle of the buffer.  Shipped shape after a
+//           sweep (tools/probe_sweep.py): 4 loads per lane, 2 workgroups per CU, non-temporal: 6.1 TB/s.
 //   mode 3  as mode 0 on the f16 matrix-core instruction (v_mfma_f32_32x32x16_f16) with pseudo-random f16 operands: the f16-storage mode's ceiling.
 // Nothing in the product path calls this.
 #include "dir_common.h"
@@ -81,16 +82,16 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const uint4* __restrict
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-constexpr int CPY_U = 8;                                  // independent 16-byte loads per lane and iteration
-// persistent workgroups; block b of the buffer = CPY_U x 256 consecutive 16-byte elements (32 KB), blocks dealt round-robin
+// persistent workgroups; block b of the buffer = U x 256 consecutive 16-byte elements, blocks dealt round-robin
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t nblocks) {
     for (size_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        const size_t base = b * (CPY_U * 256) + threadIdx.x;
-        u32x4 v[CPY_U];
+        const size_t base = b * (U * 256) + threadIdx.x;
+        u32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < CPY_U; ++u) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + base + u * 256) : src[base + u * 256];
 #pragma unroll
-        for (int u = 0; u < CPY_U; ++u) __builtin_nontemporal_store(v[u], dst + base + u * 256);
+        for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + base + u * 256); else dst[base + u * 256] = v[u]; }
     }
 }
 }  // namespace
@@ -115,13 +116,25 @@ extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int 
         return (long long)(groups * 4 * stride * 16);                    // bytes the loop really reads
     }
     if (mode == 2) {
+        // iters selects the shape (0 = the default the bench uses): bits 0-3 loads in flight per lane (4 | 8 | 16, 0 = 4), bits 4-7 workgroups per CU
+        // (0 = 2), bit 8 plain instead of non-temporal accesses -- tools/probe_sweep.py; measured (profiles/r06_probe_sweep.txt): non-temporal 4 x 2
+        // 6.12 TB/s, 5.7 - 6.1 for the other non-temporal shapes, 5.3 - 5.6 with plain accesses; the round-5 kernel 4.1
         if (bytes < (4ll << 20)) { dir::set_error("dir_probe_launch: the copy probe needs at least 4 MiB"); return DIR_E_INVALID; }
+        const int U = (iters & 15) ? (iters & 15) : 4, wpc = ((iters >> 4) & 15) ? ((iters >> 4) & 15) : 2;
+        const bool nt = !((iters >> 8) & 1);
         const size_t skew = 37 * 4096 + 256;                             // dst starts an odd number of pages (+ 256 B) behind the middle
-        const size_t half = (size_t)bytes / 2, blk = (size_t)CPY_U * 256 * 16;
+        const size_t half = (size_t)bytes / 2, blk = (size_t)U * 256 * 16;
         const size_t nblocks = (half - skew) / blk;
         int dev = 0, ncu = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        hipLaunchKernelGGL(probe_copy_kernel, dim3(ncu * 8), dim3(256), 0, s, (const u32x4*)buf, (u32x4*)((char*)buf + half + skew), nblocks);
+        const u32x4* sp = (const u32x4*)buf;
+        u32x4* dp = (u32x4*)((char*)buf + half + skew);
+        const dim3 grid(ncu * wpc);
+#define DIR_CPY(U_) do { if (nt) hipLaunchKernelGGL((probe_copy_kernel<U_, true>), grid, dim3(256), 0, s, sp, dp, nblocks); \
+                         else hipLaunchKernelGGL((probe_copy_kernel<U_, false>), grid, dim3(256), 0, s, sp, dp, nblocks); } while (0)
+        if (U == 4) DIR_CPY(4); else if (U == 16) DIR_CPY(16); else if (U == 8) DIR_CPY(8);
+        else { dir::set_error("dir_probe_launch: copy shape: 4, 8 or 16 loads per lane"); return DIR_E_INVALID; }
+#undef DIR_CPY
         if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
         return (long long)(nblocks * blk * 2);                           // bytes read + bytes written
     }
