@@ -167,6 +167,8 @@ _SIGNATURES = {
     'dir_conv2d_dual_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p]),
     'dir_conv2d_dual_scaled_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p, _p]),
     'dir_conv1x1_stream_forward': (C.c_int, [C.POINTER(ConvDesc), _p, C.POINTER(ConvSrc2), _p, _p, _p, _p, _p, _p, _p, _p]),
+    'dir_conv2d_as_supported': (C.c_int, [C.POINTER(ConvDesc), _i, _i]),
+    'dir_conv2d_as_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     'dir_conv2d_sparse_forward': (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p, _p, _p, _p, _p, _p]),
     'dir_grid_tokens_forward': (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, C.POINTER(TokenMlp),
                                           C.POINTER(TokenMlp), C.POINTER(TokenMlp), _p, _p, _i, _p]),
@@ -250,7 +252,7 @@ _SIGNATURES = {
 #    + whatever the caller announced for this call with annotate(): 'flops', 'bytes' (algorithmic work), 'shape', 'op'}
 PROFILE = None
 _pending = {}
-_NO_PROFILE = ('dir_abi_version', 'dir_bn_one_launch_status', 'dir_bn_one_launch_enable', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
+_NO_PROFILE = ('dir_conv2d_as_supported', 'dir_abi_version', 'dir_bn_one_launch_status', 'dir_bn_one_launch_enable', 'dir_last_error', 'dir_device_info', 'dir_launch_log_reset', 'dir_launch_log_get', 'dir_launch_log_note',
                'dir_bone_fusion_scratch_bytes', 'dir_dense_losses_workspace_bytes', 'dir_dense_losses_backward_workspace_bytes',
                'dir_gemm_f32_splitk_workspace_bytes', 'dir_bn_train_workspace_bytes', 'dir_bn_sync_workspace_bytes', 'dir_bn_frozen_workspace_bytes', 'dir_jpeg_planes_bytes', 'dir_colsum_workspace_bytes', 'dir_conv2d_wgrad_workspace_bytes', 'dir_conv2d_wgrad_f16x3_workspace_bytes')
 

@@ -1,0 +1,290 @@
+// dir_conv2d_as_forward: the convolutions on SMALL maps (8x8, 16x16, 32x32: ResNet layer3 / layer4, the decoder's first stage) as an
+// ACTIVATION-STATIONARY kernel (round 6, VERDICT r5 item 2: "the 33 launches with M <= 16 384 are 58 % of the convolution time at ~0.10 of the
+// MFMA peak -- change the structure").
+//   models/backbone/resnet.py:120-140     Bottleneck conv1 / conv2 (3x3) / conv3 (+ identity) at 16x16 and 8x8
+//   models/backbone/hourglass.py:55-70    Residual conv2 (3x3) and the 1x1 layers without pre-activation
+//   models/dir.py:227-241                 the attention / head convolutions on c4
+// What the tiled implicit-GEMM kernels (conv.hip, conv_pipe.hip) do on these layers: one 128 x 128 tile per CU and launch, every K-slab of BOTH
+// operands through an LDS ring (two or three barriers per 64 channels), a pipeline that has no second tile to overlap its fill and its epilogue
+// with -- 39 - 64 us for 7.7 us of MFMA work (profiles/r05_h_bench_line_one_in_flight.txt).  Here:
+//   * a workgroup owns 32 PB pixels of ONE image (PB x 32 / W whole rows) x 128 A output channels.  Its whole input patch -- every input channel,
+//     the 3x3 halo included, zeros outside the image -- goes global -> LDS ONCE by DMA (16 x 16 x 256 @ 3x3: 55 KB; 8 x 8 x 512: 100 KB) and stays;
+//   * the weights never touch LDS: the GEMM is D[channel][pixel] (weights = MFMA A operand), wave w owns channels [32 A w, 32 A (w + 1)) of the
+//     workgroup's slice, and the host packs every wave's fragments in exactly the order its MFMAs consume them (dir_amd/engine.py::pack_as_weights),
+//     so the K loop is: one coalesced 1 KB load per fragment into a register ring NSTG - 1 steps ahead, ds_read_b128 of the pixels' channels,
+//     MFMA -- NO barrier and NO LDS write between the first and the last MFMA of the workgroup;
+//   * per 32x32x16 MFMA a wave reads 1 / A KB from LDS and 1 / PB KB from L2 (the tiled kernels' 64 x 64 wave tiles: 1 KB from LDS, and every byte of
+//     it was first written there), so neither port is the limit at A = PB = 2;
+//   * epilogue as conv.hip's: fmaf(acc, scale, shift) staged as fp32 in LDS (the patch is dead by then), + residual, round, ReLU, 16-byte stores.
+// K order and k-slot assignment are conv.hip's (64-channel slab outer, taps inner; MFMA ks of a slab multiplies channels 8 ks .. + 8 in lanes 0-31 and
+// 32 + 8 ks .. + 8 in lanes 32-63; taps outside the image multiply zeros, as the tiled kernels' hardware-zeroed halo does): the same fp32 chains, so
+// the outputs are bit-identical and the engine's autotune may pick this kernel per layer (DIR_CONV_VARIANT 25 .. 28).
+#include "conv_common.h"
+
+namespace dir {
+namespace {
+
+using convk::bf16_t;
+using convk::f16s_t;
+using convk::f32x16;
+using convk::Half;
+using convk::OutVec;
+
+constexpr unsigned OOB = 0x80000000u;
+constexpr int AS_THR = 256;
+
+struct AsArgs {
+    const void* x; const uint4* w; const float* scale; const float* shift; const void* res; void* y;
+    int B, H, W, logW, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
+    int TR;                            // image rows per workgroup tile (32 PB / W)
+    int tiles_per_img, ntile, nslice, nsteps, relu, xcd_map;
+    int q, PW, NP, ninstr;             // 16-byte chunks per patch position (Cin / 8); patch width; patch positions; 1 KB DMA instructions
+    unsigned mg_q, sh_q, mg_pw, sh_pw; // magic divisors (conv_common.h: magic_u31) of q and PW
+    unsigned x_bytes;
+    long long* stamps;                 // DIR_STAMPS=conv_as (tuning aid, else NULL): phase times of workgroup 0
+};
+
+// A: 32-channel blocks per wave (workgroup = 128 A output channels); PB: 32-pixel blocks per workgroup; K3: 3x3 / pad 1 (else 1x1);
+// NSTG: depth of the weight ring in steps (a step = one (64-channel slab, tap) = 4 k-steps = 4 A fragments per wave)
+template <typename H, int A, int PB, bool K3, int NSTG>
+__global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void conv_as_kernel(AsArgs a) {
+    convk::half_kernel_init<H>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NWG = 128 * A, TPX = 32 * PB, NTAP = K3 ? 9 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, h = lane >> 5;
+    int nstamp = 0;
+    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    stamp();
+
+    // ---- (pixel tile, output-channel slice) of this workgroup.  Workgroup b runs on XCD b % 8 (observed dispatch): the slices of one pixel tile are
+    //      given to ONE XCD, so the patch is fetched from HBM / the Infinity Cache once and re-read through that XCD's L2
+    int tile, slice;
+    {
+        const int bid = blockIdx.x;
+        if (a.xcd_map) {
+            const int xcd = bid & 7, j = bid >> 3, tl = j / a.nslice;
+            slice = j - tl * a.nslice;
+            tile = tl * 8 + xcd;
+        } else {
+            tile = bid / a.nslice;
+            slice = bid - tile * a.nslice;
+        }
+    }
+    const int img = tile / a.tiles_per_img, trow = (tile - img * a.tiles_per_img) * a.TR;
+
+    // ---- the patch: global -> LDS by DMA, 1 KB per instruction; slot s = (position s / q, chunk s % q); position p = patch row p / PW, column p % PW.
+    //      The chunk that lands at slot (p, c) is the pixel's channel chunk c ^ (p & 7): consecutive positions put one logical chunk into eight
+    //      different 16-byte bank groups, which is what a ds_read_b128 of 32 pixels' SAME chunk needs (rows are unpadded: 2 Cin bytes, a
+    //      multiple of 128)
+    {
+        const convk::i32x4 xd = {(int)(unsigned)(unsigned long long)a.x, (int)(unsigned)((unsigned long long)a.x >> 32), (int)a.x_bytes, 0x00020000};
+        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+        for (int i = wave; i < a.ninstr; i += 4) {
+            const int slot = i * 64 + lane;
+            const int pos = convk::div_magic(slot, a.mg_q, a.sh_q), ch = slot - pos * a.q;
+            const int pr = convk::div_magic(pos, a.mg_pw, a.sh_pw), pc = pos - pr * a.PW;
+            const int iy = trow + pr - (K3 ? 1 : 0), ix = pc - (K3 ? 1 : 0);
+            const bool ok = pos < a.NP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.in_cs + a.in_co) * 2 + ((ch ^ (pos & 7)) << 4)) : OOB;
+            convk::lds_dma16_m0(xd, lds0 + (unsigned)i * 1024u, voff, 0);
+        }
+    }
+
+    stamp();                           // patch DMA issued
+    // ---- the weight stream of this wave: fragment (step, ks, cb) at w[(((slice * 4 + wave) * nsteps + step) * 4 + ks) * A + cb][lane]
+    const uint4* wb = a.w + ((long long)(slice * 4 + wave) * a.nsteps) * (4 * A * 64) + lane;
+    uint4 wr[NSTG][4][A];
+    auto wload = [&](auto S, int step) {
+        constexpr int s = decltype(S)::value;
+        const uint4* p = wb + (long long)min(step, a.nsteps - 1) * (4 * A * 64);      // unconditional (clamped): a load in a branch costs a full wait at the join
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < A; ++cb) wr[s][ks][cb] = p[(ks * A + cb) * 64];
+    };
+    [&]<int... S>(std::integer_sequence<int, S...>) { (wload(std::integral_constant<int, S>{}, S), ...); }(std::make_integer_sequence<int, NSTG - 1>{});
+
+    f32x16 acc[A][PB];
+#pragma unroll
+    for (int cb = 0; cb < A; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][pb][r] = 0.f;
+
+    // lane's pixels: p = 32 pb + l32 of the tile -> patch position of tap (0, 0)
+    int pos0[PB];
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+        const int p = 32 * pb + l32;
+        pos0[pb] = (p >> a.logW) * a.PW + (p & (a.W - 1));
+    }
+    const int CB = a.Cin * 2;
+
+    convk::wait_vmcnt<0>();            // the patch has landed (and the first ring stages with it)
+    __syncthreads();
+    stamp();                           // patch + first ring stages landed
+
+    int cs = 0, tap = 0;
+    for (int s0 = 0; s0 < a.nsteps; s0 += NSTG) {
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (([&] {
+                 const int step = s0 + S;
+                 wload(std::integral_constant<int, (S + NSTG - 1) % NSTG>{}, step + NSTG - 1);
+                 if (step < a.nsteps) {
+                     const int ky = K3 ? (tap * 11) >> 5 : 0, toff = K3 ? ky * a.PW + (tap - 3 * ky) : 0;
+                     int ra[PB], kx[PB];
+#pragma unroll
+                     for (int pb = 0; pb < PB; ++pb) {
+                         const int pos = pos0[pb] + toff;
+                         ra[pb] = pos * CB + cs * 128;
+                         kx[pb] = ((4 * h) ^ (pos & 7)) << 4;
+                     }
+                     uint4 bv[2][PB];
+#pragma unroll
+                     for (int pb = 0; pb < PB; ++pb) bv[0][pb] = *reinterpret_cast<const uint4*>(smem + ra[pb] + kx[pb]);
+#pragma unroll
+                     for (int ks = 0; ks < 4; ++ks) {
+                         if (ks + 1 < 4) {
+#pragma unroll
+                             for (int pb = 0; pb < PB; ++pb) bv[(ks + 1) & 1][pb] = *reinterpret_cast<const uint4*>(smem + ra[pb] + (kx[pb] ^ ((ks + 1) << 4)));
+                         }
+#pragma unroll
+                         for (int cb = 0; cb < A; ++cb)
+#pragma unroll
+                             for (int pb = 0; pb < PB; ++pb) acc[cb][pb] = Half<H>::mfma32(wr[S][ks][cb], bv[ks & 1][pb], acc[cb][pb]);
+                     }
+                 }
+                 if (++tap == NTAP) { tap = 0; ++cs; }
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, NSTG>{});
+    }
+
+    // ---- epilogue (conv.hip's arithmetic): fmaf(acc, scale, shift) as fp32 through LDS, then per 16-byte output chunk + residual, round, ReLU
+    stamp();                           // K loop done (this wave)
+    __syncthreads();                   // every wave is done with the patch
+    constexpr int SP = NWG * 4 + 16;   // bytes per staged pixel (the 16-byte skew spreads a wave's 32 pixels over the bank groups)
+#pragma unroll
+    for (int cb = 0; cb < A; ++cb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cl = (wave * A + cb) * 32 + 8 * q + 4 * h, n = slice * NWG + cl;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+            if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + n);
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb)
+                *reinterpret_cast<float4*>(smem + (32 * pb + l32) * SP + cl * 4) =
+                    make_float4(fmaf(acc[cb][pb][4 * q], sc.x, sh.x), fmaf(acc[cb][pb][4 * q + 1], sc.y, sh.y),
+                                fmaf(acc[cb][pb][4 * q + 2], sc.z, sh.z), fmaf(acc[cb][pb][4 * q + 3], sc.w, sh.w));
+        }
+    __syncthreads();
+    stamp();                           // tile staged
+    {
+        constexpr int CPR = NWG / 8;   // 16-byte output chunks per pixel
+        H* __restrict__ y = (H*)a.y;
+        const H* __restrict__ res = (const H*)a.res;
+        const long long m0 = ((long long)img * a.H + trow) * a.W;          // the tile's pixels are consecutive in NHW order (whole rows)
+        const bool relu = a.relu != 0;
+#pragma unroll 4
+        for (int c = tid; c < TPX * CPR; c += AS_THR) {
+            const int px = c / CPR, cc = c - px * CPR;
+            float v[8];
+            const float4 t0 = *reinterpret_cast<const float4*>(smem + px * SP + cc * 32), t1 = *reinterpret_cast<const float4*>(smem + px * SP + cc * 32 + 16);
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+            const int n = slice * NWG + cc * 8;
+            if (res) {
+                float rv[8];
+                OutVec<H>::load(res + (m0 + px) * a.res_cs + a.res_co + n, rv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+            OutVec<H>::store_act(y + (m0 + px) * a.out_cs + a.out_co + n, v, relu);
+        }
+    }
+    stamp();
+}
+
+template <typename H, int A, int PB, bool K3, int NSTG>
+int launch_as(const AsArgs& a, size_t lds, hipStream_t s) {
+    static bool attr_set = false;      // (per instantiation)
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_as_kernel<H, A, PB, K3, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            set_error("dir_conv2d_as_forward: cannot raise the dynamic LDS limit");
+            return DIR_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    AsArgs b = a;
+    b.stamps = stamps_begin("conv_as");
+    DIR_LAUNCH((conv_as_kernel<H, A, PB, K3, NSTG>), dim3(a.ntile * a.nslice), dim3(AS_THR), lds, s, b);
+    stamps_end("conv_as", b.stamps, s);
+    return check_launch("dir_conv2d_as_forward");
+}
+
+}  // namespace
+}  // namespace dir
+
+extern "C" int dir_conv2d_as_supported(const dir_conv_desc* d, int blocks_per_wave, int pixel_blocks) {
+    if (!d) return 0;
+    const int A = blocks_per_wave, PB = pixel_blocks;
+    if (!((A == 2 && PB == 2) || (A == 2 && PB == 4) || (A == 4 && PB == 2) || (A == 1 && PB == 2))) return 0;      // the built shapes
+    if (!((d->in_dtype == DIR_DT_BF16 || d->in_dtype == DIR_DT_F16) && d->out_dtype == d->in_dtype)) return 0;
+    const bool k3 = d->kh == 3 && d->kw == 3 && d->pad == 1, k1 = d->kh == 1 && d->kw == 1 && d->pad == 0;
+    if (!(k3 || k1) || d->stride != 1 || d->B <= 0) return 0;
+    if (d->Ho && (d->Ho != d->H || d->Wo != d->W)) return 0;
+    if (!(d->W == 8 || d->W == 16 || d->W == 32) || d->H <= 0) return 0;
+    const int tpx = 32 * PB;
+    if (tpx % d->W || (d->H * d->W) % tpx) return 0;
+    if (d->Cin <= 0 || d->Cin % 64 || d->Cout <= 0 || d->Cout % (128 * A)) return 0;
+    const int in_cs = d->in_cstride ? d->in_cstride : d->Cin, out_cs = d->out_cstride ? d->out_cstride : d->Cout;
+    if (in_cs % 8 || d->in_coff % 8 || out_cs % 8 || d->out_coff % 8 || d->res_cstride % 8 || d->res_coff % 8) return 0;
+    const int TR = tpx / d->W, PW = k3 ? d->W + 2 : d->W, NP = (k3 ? TR + 2 : TR) * PW;
+    const long long patch = ((long long)NP * d->Cin * 2 + 1023) / 1024 * 1024, stage = (long long)tpx * (128 * A * 4 + 16);
+    if ((patch > stage ? patch : stage) > 160 * 1024) return 0;
+    if ((long long)d->B * d->H * d->W * in_cs * 2 >= (1ll << 31)) return 0;           // 32-bit buffer offsets, and OOB must be out of range
+    return 1;
+}
+
+extern "C" int dir_conv2d_as_forward(const dir_conv_desc* d, const void* x, const void* w_as, const float* scale, const float* shift,
+                                     const void* residual, void* y, int blocks_per_wave, int pixel_blocks, void* stream) {
+    using namespace dir;
+    DIR_REQUIRE(d && x && w_as && y, "dir_conv2d_as_forward: null pointer");
+    DIR_REQUIRE(dir_conv2d_as_supported(d, blocks_per_wave, pixel_blocks), "dir_conv2d_as_forward: layer not supported (16-bit storage, 1x1 / 3x3 pad 1 stride 1, "
+                "W in {8, 16, 32}, whole rows per tile, Cin %% 64 == 0, Cout %% (128 A) == 0, patch <= 160 KB)");
+    const int A = blocks_per_wave, PB = pixel_blocks;
+    const bool k3 = d->kh == 3, f16 = d->in_dtype == DIR_DT_F16;
+    AsArgs a;
+    a.x = x; a.w = (const uint4*)w_as; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.logW = d->W == 8 ? 3 : d->W == 16 ? 4 : 5;
+    a.Cin = d->Cin; a.in_cs = d->in_cstride ? d->in_cstride : d->Cin; a.in_co = d->in_coff;
+    a.Cout = d->Cout; a.out_cs = d->out_cstride ? d->out_cstride : d->Cout; a.out_co = d->out_coff;
+    a.res_cs = d->res_cstride ? d->res_cstride : d->Cout; a.res_co = d->res_coff;
+    a.TR = 32 * PB / d->W;
+    a.tiles_per_img = d->H * d->W / (32 * PB); a.ntile = d->B * a.tiles_per_img; a.nslice = d->Cout / (128 * A);
+    a.nsteps = (k3 ? 9 : 1) * d->Cin / 64; a.relu = (d->flags & DIR_CONV_RELU) != 0;
+    a.xcd_map = a.ntile % 8 == 0;
+    a.q = d->Cin / 8; a.PW = k3 ? d->W + 2 : d->W; a.NP = (k3 ? a.TR + 2 : a.TR) * a.PW;
+    a.ninstr = (int)(((long long)a.NP * a.q + 63) / 64);
+    convk::magic_u31((unsigned)a.q, &a.mg_q, &a.sh_q);
+    convk::magic_u31((unsigned)a.PW, &a.mg_pw, &a.sh_pw);
+    a.x_bytes = (unsigned)((long long)d->B * d->H * d->W * a.in_cs * 2);
+    a.stamps = nullptr;
+    const size_t patch = (size_t)a.ninstr * 1024, stage = (size_t)(32 * PB) * (128 * A * 4 + 16);
+    const size_t lds = patch > stage ? patch : stage;
+    hipStream_t s = (hipStream_t)stream;
+    // ring depth: 3 steps where two workgroups fit a CU (<= 256 registers, <= 80 KB), else 4
+    const bool two = A * PB <= 4 && lds <= 80 * 1024;
+#define DIR_AS3(A_, PB_, NS_) do { if (k3) { if (f16) return launch_as<convk::f16s_t, A_, PB_, true, NS_>(a, lds, s); return launch_as<convk::bf16_t, A_, PB_, true, NS_>(a, lds, s); } \
+                                   if (f16) return launch_as<convk::f16s_t, A_, PB_, false, NS_>(a, lds, s); return launch_as<convk::bf16_t, A_, PB_, false, NS_>(a, lds, s); } while (0)
+#define DIR_AS(A_, PB_) do { if (A_ * PB_ <= 4 && two) DIR_AS3(A_, PB_, 3); else DIR_AS3(A_, PB_, 4); } while (0)
+    if (A == 2 && PB == 2) DIR_AS(2, 2);
+    if (A == 2 && PB == 4) DIR_AS(2, 4);
+    if (A == 4 && PB == 2) DIR_AS(4, 2);
+    if (A == 1 && PB == 2) DIR_AS(1, 2);
+#undef DIR_AS
+#undef DIR_AS3
+    DIR_REQUIRE(false, "dir_conv2d_as_forward: unsupported (A, PB) = (%d, %d)", A, PB);
+}

@@ -73,6 +73,29 @@ STREAM64_VARIANT = 22    # the same kernel on 64-pixel workgroups (twice as many
 STREAM32_VARIANT = 23    # ... on 32-pixel workgroups (the 16x16 / 8x8 stages: 128-pixel tiles do not even cover the CUs there)
 STREAMP_VARIANT = 24     # round 5: the pipelined form -- a fifth (producer) wave feeds a ring of activation chunks by LDS-DMA (no pre-activation form: those layers run 21)
 STREAM_VARIANTS = (STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT, STREAMP_VARIANT)
+# round 6: the activation-stationary kernel for the small maps (conv_as.hip, dir_conv2d_as_forward): DIR_CONV_VARIANT -> (A = 32-channel blocks per
+# wave, PB = 32-pixel blocks per workgroup).  Bit-identical to the tiled kernels (same K order and k-slots), so autotune may pick it per layer.
+AS_VARIANTS = {25: (2, 2), 26: (2, 4), 27: (4, 2), 28: (1, 2)}
+
+
+def pack_as_weights(w_ohwi, A):
+    """dir_conv2d_as_forward's weight stream (include/dir_hip.h) from W [Cout][kh][kw][Cin] (16-bit): [Cout / (128 A)][4 waves][kh kw Cin / 64 steps]
+    [4 k-steps][A][64 lanes][8], step = (64-channel slab) * (kh kw) + tap -- every wave's MFMA A fragments in the order it consumes them, with the
+    k-slot assignment of conv.hip's MFMAs (lanes 0-31: channels 8 ks .. + 8 of the slab, lanes 32-63: 32 + 8 ks .. + 8)."""
+    N, kh, kw, Cin = w_ohwi.shape
+    assert N % (128 * A) == 0 and Cin % 64 == 0
+    nt = kh * kw
+    dev = w_ohwi.device
+    w = w_ohwi.reshape(N, nt * Cin)
+    lane = torch.arange(64, device=dev)
+    l32, h = lane & 31, lane >> 5
+    e = torch.arange(8, device=dev)
+    g, wv, st, ks, cb = torch.meshgrid(torch.arange(N // (128 * A), device=dev), torch.arange(4, device=dev), torch.arange(nt * Cin // 64, device=dev),
+                                       torch.arange(4, device=dev), torch.arange(A, device=dev), indexing='ij')
+    row = (g * (128 * A) + (wv * A + cb) * 32)[..., None] + l32                       # [G,4,steps,4,A,64]
+    slab, tap = st // nt, st % nt
+    k0 = (tap * Cin + 64 * slab + 8 * ks)[..., None] + 32 * h
+    return w[row[..., None], k0[..., None] + e].contiguous()
 
 
 def pack_stream_weights(w_nk, dtype=torch.bfloat16):
@@ -124,6 +147,7 @@ class ConvOp(object):
         self.alg_k = self.kh * self.kw * self.cin          # reduction length the reference computes (stem: 147)
         self.variant = {}                                  # batch size -> DIR_CONV_VARIANT code chosen by DirEngine.autotune
         self.split, self._ws = {}, {}                      # batch size -> split-K factor; (B, S, stream) -> workspace
+        self._w_as = {}                                    # A -> the activation-stationary kernel's weight stream (pack_as_weights), packed on first use
         # streaming alternative for the HBM-bound 1x1 layers (dir_conv1x1_stream_forward), taken when autotune prefers it
         self.w_stream = None
         if (dtype in HALF and self.out_dtype == dtype and self.kh == 1 and self.kw == 1 and stride == 1 and pad == 0
@@ -202,6 +226,17 @@ class ConvOp(object):
                            dtype=self.arith or ('f32' if self.dtype == F32 else 'bf16'),        # (roofline class: f16 storage runs at the bf16 MFMA rate)
                            shape='M=%d N=%d K=%d k%dx%d s%d' % (B * ho * wo, self.cout, self.kh * self.kw * self.cin, self.kh,
                                                               self.kw, self.stride))
+        if v in AS_VARIANTS and bbox is None and pre_scale is None and self.dtype in HALF and out.dtype == self.dtype and self.arith is None:
+            A_, PB_ = AS_VARIANTS[v]
+            if _capi.lib().dir_conv2d_as_supported(d, A_, PB_):
+                was = self._w_as.get(A_)
+                if was is None:
+                    was = self._w_as[A_] = pack_as_weights(self.w, A_)
+                d.flags &= 0xff
+                _capi.check(_capi.lib().dir_conv2d_as_forward(d, _capi.ptr(x), _capi.ptr(was), _capi.ptr(self.scale), _capi.ptr(self.shift), _capi.ptr(residual),
+                                                              _capi.ptr(out), A_, PB_, _capi.stream_ptr()), 'dir_conv2d_as_forward')
+                return out
+            d.flags &= 0xff                                    # does not apply to this layer: the library's heuristic, like every other variant
         if v in STREAM_VARIANTS and self.w_stream is not None and residual is None and bbox is None and out.dtype == self.dtype:
             d.flags = (d.flags & 0xff) | ((v & 0xff) << 8 if v != STREAM_VARIANT else 0)
             _capi.check(_capi.lib().dir_conv1x1_stream_forward(d, _capi.ptr(x), None, None, _capi.ptr(self.w_stream), _capi.ptr(self.scale),
@@ -1244,7 +1279,7 @@ class DirEngine(object):
     # (tools/check_stream_layers.py, tests/test_gpu_dir.py::test_autotuned_engine_is_bit_identical).
     # (STREAMP_VARIANT = 24, the pipelined streaming kernel of round 5, is built, bit-identical and tested but NOT offered: measured slower than 21 / 22 on
     #  every layer it could serve -- one producer wave cannot issue 16 KB of LDS-DMA per 0.25 us of MFMAs; tools/bench_stream.py)
-    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15, STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT)
+    CONV_VARIANTS = (0, 1, 2, 3, 4, 17, 18, 20, 8, 9, 10, 11, 12, 13, 14, 15, STREAM_VARIANT, STREAM64_VARIANT, STREAM32_VARIANT, 25, 26, 27, 28)
 
     def _profiled_forwards(self, img, n):
         """n eager forwards with every library call timed; returns the records of the conv family (those that carry an `op`)"""

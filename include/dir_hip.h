@@ -367,7 +367,8 @@ int dir_pgcn_adjacency_backward(const float* e1, const float* gz, const float* h
  *   12..14: the same tiles with halo reuse (stride-1 kh x kw layers whose tile is a rectangle of image rows)
  *   15    : the 8-wave pipelined kernel on a 128x64 tile (32x32 wave tiles): the small-M layers (8x8 / 16x16 maps)
  *   22, 23: dir_conv1x1_stream_forward only: 64- / 32-pixel workgroups instead of 128 (the 16x16 / 8x8 stages, whose 128-pixel grid does not
- *           cover the CUs); (19 = 64x128 on the ring: not in the product build, see conv.hip) */
+ *           cover the CUs); (19 = 64x128 on the ring: not in the product build, see conv.hip)
+ *   25..28: dir_conv2d_as_forward only (activation-stationary kernel for the small maps): (A, PB) = (2,2) | (2,4) | (4,2) | (1,2) */
 #define DIR_CONV_VARIANT(v) (((v) & 0xff) << 8)
 
 typedef struct dir_conv_desc {
@@ -524,6 +525,21 @@ int dir_conv2d_dual_scaled_forward(const dir_conv_desc* desc, const void* x, con
 int dir_conv1x1_stream_forward(const dir_conv_desc* desc, const void* x, const dir_conv_src2* src2, const void* x2,
                                const void* w_stream, const float* scale, const float* shift, const float* pre_scale,
                                const float* pre_shift, void* y, void* stream);
+
+/* The convolutions on SMALL maps (W = 8 | 16 | 32, stride 1, 1x1 or 3x3 / pad 1, 16-bit storage in = out) as an ACTIVATION-STATIONARY kernel
+ * (conv_as.hip, round 6): a workgroup owns 32 * pixel_blocks pixels of one image (whole rows) x 128 * blocks_per_wave output channels, its whole input
+ * patch (every input channel, halo included) goes global -> LDS once by DMA, the weights stream L2 -> MFMA operand registers from a buffer packed in
+ * consumption order, and there is no barrier inside the reduction.  Same mathematics, K order and k-slot assignment as dir_conv2d_forward
+ * (bit-identical outputs): y = act(scale * conv(x) + shift (+ residual)) -- models/backbone/resnet.py:120-140 (Bottleneck conv1 / conv2 / conv3 +
+ * identity at 16x16 and 8x8), models/backbone/hourglass.py:55-70 (Residual conv2), models/dir.py:227-241.  No pre-activation, no second source.
+ * (blocks_per_wave A, pixel_blocks PB) in {(2,2), (2,4), (4,2), (1,2)}; Cin % 64 == 0, Cout % (128 A) == 0, (H W) % (32 PB) == 0, (32 PB) % W == 0,
+ * patch and staging <= 160 KB of LDS.  dir_conv2d_as_supported returns 1 when a layer qualifies.
+ * w_as: 16-bit [Cout / (128 A)][4 waves][kh kw Cin / 64 steps][4 k-steps][A][64 lanes][8]; step s = (64-channel slab s / (kh kw), tap s % (kh kw)); lane l of
+ * fragment (step, ks, cb) of wave w in slice g holds W[g 128 A + (w A + cb) 32 + (l & 31)][tap][64 slab + 8 ks + 32 (l >> 5) .. + 8] of the
+ * [Cout][kh][kw][Cin] weights (dir_amd/engine.py::pack_as_weights). */
+int dir_conv2d_as_supported(const dir_conv_desc* desc, int blocks_per_wave, int pixel_blocks);
+int dir_conv2d_as_forward(const dir_conv_desc* desc, const void* x, const void* w_as, const float* scale, const float* shift,
+                          const void* residual, void* y, int blocks_per_wave, int pixel_blocks, void* stream);
 
 /* a11 with a10's sparsity: same as dir_conv2d_forward (no prologue), plus group_bbox int32 [B][Cin/64][4] = for every
  * image and every 64-channel input group the pixel box (ymin,ymax,xmin,xmax) outside which that group is exactly zero.
