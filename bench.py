@@ -154,7 +154,7 @@ def four_in_flight_profile(dtype):
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_kernel_stats_four_in_flight.txt')))
     if not files or dtype not in ('bf16', 'f16'):
         return None
-    fam = ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_patch_kernel', 'conv_big_kernel', 'bneck_chain_kernel', 'tail_chain_kernel', 'stream1x1_kernel')
+    fam = ('conv_igemm_kernel', 'conv_pipe_kernel', 'conv_patch_kernel', 'conv_big_kernel', 'bneck_chain_kernel', 'tail_chain_kernel', 'stream1x1_kernel', 'conv_as_kernel')
     calls, total, forwards = 0, 0.0, 0
     with open(files[-1]) as f:
         for ln in f:

@@ -3,7 +3,7 @@
 # SQ wait / issue / LDS / MFMA counters of the forward convolution kernels inside the bench forward (eager launches of the timed
 # configuration, one forward in flight), as tools/pmc_wgrad.sh does for the weight-gradient kernel.  Result: gpurun_out/<tag>/sq_counters.txt
 tag=$1; shift
-pats="${@:-conv_patch_kernel conv_big_kernel stream1x1_kernel conv_pipe_kernel conv_igemm_kernel tail_chain_kernel bneck_chain_kernel}"
+pats="${@:-conv_patch_kernel conv_big_kernel stream1x1_kernel conv_pipe_kernel conv_igemm_kernel tail_chain_kernel bneck_chain_kernel conv_as_kernel}"
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag

@@ -18,7 +18,7 @@ def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     m = re.match(r'_ZN.*?(\d+)([a-z_0-9]+_kernel)', name)
     base = re.sub(r'\(.*\)$', '', name)
-    for key in ('conv_pipe_kernel', 'conv_patch_kernel', 'conv_big_kernel', 'conv_igemm_kernel', 'ste_kernel', 'pgcn_layer_kernel', 'pgcn_mix_kernel',
+    for key in ('conv_as_kernel', 'conv_pipe_kernel', 'conv_patch_kernel', 'conv_big_kernel', 'conv_igemm_kernel', 'ste_kernel', 'pgcn_layer_kernel', 'pgcn_mix_kernel',
                 'mano_forward_kernel', 'grid_tokens_kernel', 'bone_fuse_kernel', 'bone_g_kernel', 'bone_vis_kernel', 'bone_proj_kernel',
                 'init_head_kernel', 'regress_kernel', 'upsample_kernel', 'maxpool_kernel', 'stem_pool_kernel', 'bneck_chain_kernel', 'stem_prep_s2d', 'eval_metrics', 'gt_mano',
                 'tail_chain_kernel', 'stream1x1_kernel', 'pgcn_node_kernel'):

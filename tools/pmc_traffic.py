@@ -23,10 +23,10 @@ if __name__ == '__main__':
     # and conv_pipe.hip (8-wave pipelined / halo-reuse) kernels, the chains and the streaming 1x1
     h = 'f16s_tE'
     pat = ['conv_igemm_kernelItt', 'conv_igemm_kernelIN3dir5convk6' + h + 'S3_', 'conv_pipe_kernelIt', 'conv_pipe_kernelINS0_6' + h, 'conv_patch_kernelIt',
-           'conv_patch_kernelINS0_6' + h, 'conv_big_kernelIt', 'conv_big_kernelINS0_6' + h, 'bneck_chain_kernel', 'tail_chain_kernel', 'stream1x1_kernel']
+           'conv_patch_kernelINS0_6' + h, 'conv_big_kernelIt', 'conv_big_kernelINS0_6' + h, 'bneck_chain_kernel', 'tail_chain_kernel', 'stream1x1_kernel', 'conv_as_kernel']
     nf, f = per_kernel(fetch_db, 'FETCH_SIZE', pat)
     nw, w = per_kernel(write_db, 'WRITE_SIZE', pat)
-    res = {'kernel': 'conv family (conv_igemm / conv_pipe / conv_patch / conv_big / bneck_chain / tail_chain / stream1x1; 16-bit storage)', 'launches_fetch_pass': nf, 'launches_write_pass': nw,
+    res = {'kernel': 'conv family (conv_igemm / conv_pipe / conv_patch / conv_big / bneck_chain / tail_chain / stream1x1 / conv_as; 16-bit storage)', 'launches_fetch_pass': nf, 'launches_write_pass': nw,
            'fetch_kib_per_launch_raw': f / nf, 'write_kib_per_launch_raw': w / nw,
            'hbm_bytes_per_launch': (2.0 * f / nf + w / nw) * 1024.0,
            'head': os.environ.get('DIR_HEAD', 'unrecorded'),     # git HEAD the counters were taken at (the GPU box has no .git: passed in)
