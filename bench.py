@@ -561,6 +561,10 @@ def main():
               # a float4 COPY of 512 MiB -> 512 MiB (bytes read + written): what a streaming kernel does; the read-only loop under-reports the ceiling
               # (5.1 TB/s, below bone_vis_kernel's own 6.3 TB/s)
               'hbm_copy_1gib_tbps': round(probe(2, big, 1 << 30, 0, 1.0) / 1e12, 3),
+              # round 6: the two on-chip roofs of a small-pixel-tile convolution -- every CU streaming the SAME 1.2 MB (one 3x3 256 -> 256 layer's weights)
+              # out of the L2s, and ds_read_b128 from LDS (DESIGN.md "balance": 64 FLOP per weight byte x this rate bounds the 64-pixel tiles)
+              'l2_same_stream_all_cus_tbps': round(probe(4, big, 1179648, 64, 0.5) / 1e12, 2),
+              'lds_read_all_cus_tbps': round(probe(5, big, 64, 2000, 0.5) / 1e12, 1),
               'source': 'dir_probe_launch in this run, ~1 s per loop, after the timed regions'}
         del big
         if 'mfma' in roof.get('by_class', {}):

@@ -14,6 +14,12 @@
 //           (every byte is touched once), dst placed an odd number of 4 KB pages (+ 256 B) behind the middle of the buffer.  Shipped shape after a
 //           sweep (tools/probe_sweep.py): 4 loads per lane, 2 workgroups per CU, non-temporal: 6.1 TB/s.
 //   mode 3  as mode 0 on the f16 matrix-core instruction (v_mfma_f32_32x32x16_f16) with pseudo-random f16 operands: the f16-storage mode's ceiling.
+//   mode 4  (round 6) L2 -> CU "weight stream": EVERY workgroup (CUs x 2, 256 threads) reads the SAME first `bytes` of buf (1 - 2 MB: what a small-map
+//           convolution's weights are) over and over, 8 independent 16-byte loads per lane in flight -- the aggregate rate at which the eight L2s can
+//           feed all CUs the same stream.  This is the roof of every convolution whose pixel tile is small: a 64-pixel tile does 64 FLOP per weight
+//           byte, so at R TB/s of this rate the matrix cores cannot exceed 64 R TFLOP/s on it (balance table).  Returns bytes delivered.
+//   mode 5  (round 6) LDS read: every CU's 8 waves issue ds_read_b128 from a 64 KB tile in a loop; returns bytes read.  The other roof of an
+//           operand-from-LDS MFMA loop (64 x 64 wave tiles read 1 KB per 32x32x16 MFMA).
 // Nothing in the product path calls this.
 #include "dir_common.h"
 
@@ -94,6 +100,38 @@ __global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict
         for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + base + u * 256); else dst[base + u * 256] = v[u]; }
     }
 }
+// every workgroup streams the same n16 16-byte elements `reps` times (mode 4)
+__global__ __launch_bounds__(256) void probe_l2_stream_kernel(const u32x4* __restrict__ p, size_t n16, int reps, unsigned* sink) {
+    unsigned acc = 0;
+    for (int r = 0; r < reps; ++r) {
+        for (size_t i = threadIdx.x; i + 7 * 256 < n16; i += 8 * 256) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+// mode 5: 8 waves per CU read a 64 KB LDS tile with ds_read_b128, `reps` passes of 16 reads per lane
+__global__ __launch_bounds__(512, 1) void probe_lds_read_kernel(int reps, unsigned* sink) {
+    __shared__ __attribute__((aligned(16))) u32x4 tile[4096];            // 64 KB
+    for (int i = threadIdx.x; i < 4096; i += 512) tile[i] = u32x4{(unsigned)i, 1u, 2u, 3u};
+    __syncthreads();
+    unsigned acc = 0;
+    const int base = threadIdx.x & 255;
+    for (int r = 0; r < reps; ++r) {
+        u32x4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = tile[base + 256 * u];      // lane-consecutive 16-byte slots: conflict-free
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc ^= v[u].x ^ v[u].z;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 }  // namespace
 
 extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int iters, void* stream) {
@@ -138,6 +176,24 @@ extern "C" long long dir_probe_launch(int mode, void* buf, long long bytes, int 
         if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
         return (long long)(nblocks * blk * 2);                           // bytes read + bytes written
     }
-    dir::set_error("dir_probe_launch: mode must be 0 (bf16 MFMA), 1 (HBM read), 2 (HBM copy) or 3 (f16 MFMA)");
+    if (mode == 4 || mode == 6) {          // 6: ONE workgroup per CU (no second workgroup whose loads could hit the first one's L1 lines)
+        if (iters <= 0 || bytes < 65536) { dir::set_error("dir_probe_launch: the L2 stream probe needs iters > 0 and at least 64 KB"); return DIR_E_INVALID; }
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const size_t n16 = (size_t)bytes / 16, per_pass = (n16 / (8 * 256)) * (8 * 256);
+        const int wpc = mode == 4 ? 2 : 1;
+        hipLaunchKernelGGL(probe_l2_stream_kernel, dim3(ncu * wpc), dim3(256), 0, s, (const u32x4*)buf, n16, iters, (unsigned*)buf);
+        if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
+        return (long long)((size_t)ncu * wpc * iters * per_pass * 16);
+    }
+    if (mode == 5) {
+        if (iters <= 0) { dir::set_error("dir_probe_launch: iters must be positive"); return DIR_E_INVALID; }
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(probe_lds_read_kernel, dim3(ncu), dim3(512), 0, s, iters, (unsigned*)buf);
+        if (dir::check_launch("dir_probe_launch") != 0) return DIR_E_LAUNCH;
+        return (long long)ncu * 512 * 16 * 16 * iters;
+    }
+    dir::set_error("dir_probe_launch: mode must be 0 (bf16 MFMA), 1 (HBM read), 2 (HBM copy), 3 (f16 MFMA), 4 / 6 (L2 weight stream, 2 / 1 workgroups per CU) or 5 (LDS read)");
     return DIR_E_INVALID;
 }

@@ -48,7 +48,10 @@ void dir_launch_log_note(const char* name, long long times);
  * per CU, every CU), `iters` iterations; mode 1: 16-byte loads streaming `bytes` of `buf` (larger than the Infinity Cache to price HBM).  `buf`: any
  * device buffer >= 64 bytes (mode 0 only needs a sink); mode 2 (round 5): the first half of `buf` copied to the second half (a streaming kernel reads AND
  * writes: the read-only loop under-reports the HBM ceiling); mode 3: mode 0 on v_mfma_f32_32x32x16_f16 with pseudo-random f16 operands.  Returns the
- * FLOPs (modes 0, 3) / bytes read (mode 1) / bytes read + written (mode 2) of the launch, negative = error code. */
+ * FLOPs (modes 0, 3) / bytes read (mode 1) / bytes read + written (mode 2) of the launch, negative = error code.  Round 6: mode 2's `iters` selects the
+ * copy shape (0 = the shipped one); mode 4: every workgroup (2 per CU) streams the SAME first `bytes` of buf `iters` times -- the aggregate L2 -> CU
+ * rate at which a small-map convolution's weights reach all CUs; mode 5: ds_read_b128 from a 64 KB LDS tile, 8 waves per CU, `iters` passes of 16
+ * reads per lane.  Both return bytes delivered. */
 long long dir_probe_launch(int mode, void* buf, long long bytes, int iters, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
