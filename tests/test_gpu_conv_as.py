@@ -82,3 +82,37 @@ def test_as_variants_match_oracle_and_the_tiled_kernel_bit_for_bit(case, dt):
         assert torch.equal(out, base), 'variant %d (A=%d, PB=%d) differs from the tiled kernel' % (v, A, PB)          # incl. the untouched slices of the buffer
     if (Ci, k) != (2048, 1):
         assert ran >= (2 if Co % 256 == 0 else 1), 'the kernel should serve this layer'
+
+
+def test_first_use_inside_a_graph_capture():
+    """The kernel opts into > 64 KB of dynamic LDS (hipFuncSetAttribute) the first time an instantiation is launched.  A caller that loads a kernel
+    table and captures its first forward straight away (engine.ForwardPipeline after load_tuning_table) makes that first launch INSIDE a stream
+    capture: it must work there too.  Own process, so that no earlier test has launched the instantiation."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from dir_amd import engine as E
+g = torch.Generator(device='cuda').manual_seed(3)
+w = torch.randn(256, 256, 3, 3, device='cuda', generator=g) * 0.02
+op = E.ConvOp(w, torch.float16, stride=1, pad=1, scale=torch.ones(256, device='cuda'), shift=torch.zeros(256, device='cuda'), relu=True)
+x = torch.randn(4, 16, 16, 256, device='cuda', generator=g).half()
+ref = op(x).clone()                                   # the library's own choice (a tiled kernel), eager
+torch.cuda.synchronize()
+out = torch.empty_like(ref)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    gr = torch.cuda.CUDAGraph()
+    E._TLS.variant = 25
+    with torch.cuda.graph(gr, stream=s):
+        op(x, out=out)                                # first launch of this conv_as_kernel instantiation: inside the capture
+    E._TLS.variant = None
+    gr.replay()
+torch.cuda.synchronize()
+assert torch.equal(out, ref), 'captured first use differs'
+print('OK')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
