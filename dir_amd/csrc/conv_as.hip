@@ -54,7 +54,9 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, h = lane >> 5;
     int nstamp = 0;
-    auto stamp = [&]() { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[nstamp++] = (long long)__builtin_amdgcn_s_memtime(); };
+    auto stamp = [&]() {            // workgroup 0: slots 0.., the last workgroup: slots 6.. (all relative to workgroup 0's first stamp when printed)
+        if (a.stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) a.stamps[(blockIdx.x == 0 ? 0 : 6) + nstamp++] = (long long)__builtin_amdgcn_s_memtime();
+    };
     stamp();
 
     // ---- (pixel tile, output-channel slice) of this workgroup.  Workgroup b runs on XCD b % 8 (observed dispatch): the slices of one pixel tile are
@@ -168,15 +170,25 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
     constexpr int UNR = (NSTG % 2 == 0) ? NSTG : 2 * NSTG;          // steps per unrolled iteration: ring stage and operand parity both compile-time
     int cs = 0, tap = 0;                                            // (slab, tap) of the step whose operands are being read: one ahead of the MFMAs
     bread(std::integral_constant<int, 0>{}, 0, 0);
-    for (int s0 = 0; s0 < a.nsteps; s0 += UNR) {
+    // One group of UNR steps.  GUARD = false: every step of the group exists -- the body is ONE basic block, and the scheduler is told to deal the
+    // step's memory instructions out between its MFMAs (one weight fragment load and one operand read per A x PB / 2 ... MFMAs) instead of
+    // issuing eight loads and eight reads in a row: a 64-lane 16-byte load occupies the wave's issue for about half an MFMA, and with one wave per
+    // SIMD eight of them back to back leave the matrix pipe idle for three (DIR_AS_NO_SCHED: the compiler's own order, A/B aid).
+    auto group = [&](auto Guard, int s0) {
+        constexpr bool GUARD = decltype(Guard)::value;
         [&]<int... S>(std::integer_sequence<int, S...>) {
             (([&] {
                  const int step = s0 + S;
                  constexpr int stage = S % NSTG, par = S & 1;
                  wload(std::integral_constant<int, (stage + NSTG - 1) % NSTG>{}, step + NSTG - 1);
-                 if (step + 1 < a.nsteps) { if (++tap == NTAP) { tap = 0; ++cs; } }      // past the end: the last step's operands again (nobody uses them)
+                 {   // next step's (slab, tap), branch-free; past the end: the last step's operands again (nobody uses them)
+                     const bool adv = step + 1 < a.nsteps, wrap = tap + 1 == NTAP;
+                     const int ntap = wrap ? 0 : tap + 1, ncs = wrap ? cs + 1 : cs;
+                     tap = adv ? ntap : tap;
+                     cs = adv ? ncs : cs;
+                 }
                  bread(std::integral_constant<int, par ^ 1>{}, cs, tap);
-                 if (step < a.nsteps) {
+                 if (!GUARD || step < a.nsteps) {
 #pragma unroll
                      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -184,10 +196,24 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
 #pragma unroll
                              for (int pb = 0; pb < PB; ++pb) acc[cb][pb] = Half<H>::mfma32(wr[stage][ks][cb], bv[par][ks][pb], acc[cb][pb]);
                  }
+#if !defined(DIR_AS_NO_SCHED)
+                 if constexpr (!GUARD) {
+                     constexpr int NMEM = 4 * A > 4 * PB ? 4 * A : 4 * PB, MPM = 4 * A * PB / NMEM;          // memory slots per step; MFMAs between them
+#pragma unroll
+                     for (int i = 0; i < NMEM; ++i) {
+                         __builtin_amdgcn_sched_group_barrier(0x008, MPM, 0);                                 // MFMA
+                         if (i < 4 * A) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    // one weight fragment load (VMEM read)
+                         if (i < 4 * PB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // one operand read (DS read)
+                     }
+                 }
+#endif
              }()),
              ...);
         }(std::make_integer_sequence<int, UNR>{});
-    }
+    };
+    int s0 = 0;
+    for (; s0 + UNR <= a.nsteps; s0 += UNR) group(std::false_type{}, s0);
+    if (s0 < a.nsteps) group(std::true_type{}, s0);
 
     // ---- epilogue (conv.hip's arithmetic): fmaf(acc, scale, shift) as fp32 through LDS, then per 16-byte output chunk + residual, round, ReLU
     stamp();                           // K loop done (this wave)

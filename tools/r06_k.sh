@@ -4,8 +4,5 @@ out=$R/gpurun_out/${TAG:-r06_k}
 mkdir -p $out
 cd $R
 timeout 600 python -m pytest tests/test_gpu_conv_as.py -m gpu -q 2>&1 | tail -3 > $out/tests_as.txt
-for t in "" _dbgb; do
-  echo "=== library libdir_hip$t.so" >> $out/stamps_dbg2.txt
-  DIR_LIB_PATH=$R/dir_amd/lib/libdir_hip$t.so DIR_STAMPS=conv_as timeout 300 python tools/stamps_as.py 2>&1 | grep -v amdgpu >> $out/stamps_dbg2.txt
-done
+DIR_STAMPS=conv_as timeout 300 python tools/stamps_as.py 2>&1 | grep -v amdgpu > $out/stamps.txt
 timeout 600 python tools/bench_as.py f16 > $out/bench_as_f16.txt 2>&1
