@@ -92,6 +92,8 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
             const int pr = convk::div_magic(pos, a.mg_pw, a.sh_pw), pc = pos - pr * a.PW;
             const int iy = trow + pr - (K3 ? 1 : 0), ix = pc - (K3 ? 1 : 0);
             const bool ok = pos < a.NP && ch < a.q && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            // (measured and dropped, round 6: advancing (position, chunk, row, column) with adds and carries instead of dividing every slot made the
+            //  prologue SLOWER, 3.9 -> 5.3 k ticks: the carried chain serialises what are otherwise independent iterations.  DMA issue alone: 1.4 - 2.6 k.)
             const unsigned voff = ok ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.in_cs + a.in_co) * 2 + (ch << 4)) : OOB;
             convk::lds_dma16_m0(xd, lds0 + (unsigned)i * 1024u, voff, 0);
         }
