@@ -1331,7 +1331,7 @@ class DirEngine(object):
         self._tuned_order[B] = [op for op in best]          # first-call order of one forward: stable for a given engine
         return {op: v for op, (t, v) in best.items()}
 
-    def autotune_energy(self, img, seconds=None, slack=2.6, idle_w=None, log=None, max_calls=None):
+    def autotune_energy(self, img, seconds=None, slack=2.6, idle_w=None, log=None, max_calls=None, min_saving=0.0, near=1.12):
         """The per-layer kernel choice for THROUGHPUT with several forwards in flight.  Four bs-64 forwards in flight run the socket at its
         power cap (1.3-1.4 kW of 1.4 kW, 2.9 J per forward), so what raises images/s is the variant that costs the fewest joules
         above idle, not the one that finishes first alone: typically a larger tile on fewer CUs (less L2 -> LDS and LDS -> register traffic
@@ -1341,7 +1341,11 @@ class DirEngine(object):
         window (default 0.8 s: the reading lags by about a second); the choice minimises joules above idle per launch among the variants within
         `slack` x the fastest.  ~50 calls x ~10 variants x seconds: 2 minutes with the counter, 5-8 without -- run it
         once per (GPU model, batch size) and keep export_tuning()'s table (dir_amd/tuning/, load_tuning_table).  Results stay bit-identical
-        (same argument as autotune).  One forward alone gets ~15 % slower with this table: latency-bound callers keep autotune()."""
+        (same argument as autotune).  One forward alone gets ~15 % slower with this table: latency-bound callers keep autotune().
+        min_saving (round 6): a variant slower than `near` x the fastest is taken only if it saves at least this fraction of the joules of the best
+        variant that IS within `near` x the fastest.  With 0 (rounds 3-5) the table held a dozen launches that were 1.4 - 2.5x slower one at a time for
+        1 - 5 % fewer joules -- inside the 0.2 s windows' noise -- which cost 0.17 ms of one-forward latency and a tenth of the per-launch roofline
+        fraction for nothing measurable at four in flight (profiles/r06_energy_rule_ab.txt)."""
         import time as _time
         from . import power
         B = img.shape[0]
@@ -1412,8 +1416,12 @@ class DirEngine(object):
                 _TLS.variant = None
                 if not row:
                     continue
-                best = min(row, key=lambda v: row[v][0] * max(row[v][1] - idle_w, 1.0))
+                joules = lambda v: row[v][0] * max(row[v][1] - idle_w, 1.0)  # noqa: E731
                 fastest = min(row, key=lambda v: row[v][0])
+                base = min((v for v in row if row[v][0] <= near * row[fastest][0]), key=joules)
+                best = min(row, key=joules)
+                if joules(best) > (1.0 - min_saving) * joules(base):
+                    best = base
                 op.variant[B] = best
                 rows.append(dict(cout=op.cout, cin=getattr(op, 'cin', 0), kh=getattr(op, 'kh', 1), stride=getattr(op, 'stride', 1), chosen=best,
                                  us=round(row[best][0], 1), w=round(row[best][1]), fastest=fastest, fastest_us=round(row[fastest][0], 1),

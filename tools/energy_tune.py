@@ -27,14 +27,14 @@ ref = [ref[i]['pd_mesh_xyz_left'].clone() for i in range(3)] + [ref[3]['seg'].cl
 eng.autotune(img)
 t_time = eng.export_tuning(B)
 t0 = time.perf_counter()
-rep = eng.autotune_energy(img, seconds=SECS, log=lambda r: print(r, flush=True))
+rep = eng.autotune_energy(img, seconds=SECS, log=lambda r: print(r, flush=True), min_saving=float(os.environ.get('MIN_SAVING', '0.08')))
 print('autotune_energy: %.0f s, idle %.0f W' % (time.perf_counter() - t0, rep['idle_w']), flush=True)
 t_energy = eng.export_tuning(B)
 out = eng.forward(img)
 same = all(torch.equal(a, b) for a, b in zip(ref, [out[i]['pd_mesh_xyz_left'] for i in range(3)] + [out[3]['seg']]))
 print('outputs bit-identical to the untuned forward:', same)
 head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, cwd=ROOT).stdout.strip() or os.environ.get('DIR_HEAD', '')
-meta = {'made_by': 'tools/energy_tune.py', 'instrument': rep['instrument'], 'objective': 'time x (socket power - idle power) per launch, launches replayed back to back',
+meta = {'made_by': 'tools/energy_tune.py', 'min_saving': float(os.environ.get('MIN_SAVING', '0.08')), 'instrument': rep['instrument'], 'objective': 'time x (socket power - idle power) per launch, launches replayed back to back',
         'device': torch.cuda.get_device_name(0), 'idle_w': rep['idle_w'], 'head': head, 'weights': 'dir_amd.synth seed 1234 (the choice depends on shapes only)',
         'changed_vs_time_tuned': sum(1 for a, b in zip(t_time, t_energy) if a[5] != b[5]), 'layers': rep['layers']}
 os.makedirs(os.path.join(ROOT, 'gpurun_out', 'tuning'), exist_ok=True)
