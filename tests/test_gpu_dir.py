@@ -517,6 +517,26 @@ def test_full_size_batch_64_rows_inside_the_reference_gate_trained_like_weights(
             assert worst < 1.5e-7, worst
 
 
+def test_batch_128_f16_storage_rows_inside_the_reference_gate(golden, dir_state_cond):
+    """BASELINE configs[2]'s batch size (128; its dataset and checkpoint are not available here) in the headline mode: the two G7c images at rows 0 and
+    127 of a batch of 126 others, f16 storage, the library's own kernel choice for this batch size -- every stage inside the 0.01 mm MPJPE gate
+    against the REFERENCE golden (apps/eval.py:167-172 reads these tensors)."""
+    g = golden('g7c_dir')
+    sd, img = dir_state_cond
+    eng = DirEngine(sd, dtype=torch.float16)
+    big = torch.randn(128, 3, 256, 256, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1280))
+    big[0], big[127] = img[0], img[1]
+    o = eng.forward(big)
+    torch.cuda.synchronize()
+    mpjpe = []
+    for i in range(3):
+        for side in ('left', 'right'):
+            d = o[i]['pd_joint_xyz_' + side][[0, 127]].cpu().numpy() - g['s%d.pd_joint_xyz_%s' % (i, side)]
+            mpjpe.append(float(np.sqrt((d ** 2).sum(-1)).mean()) * 1e3)
+    print('f16 storage B=128 rows 0/127 vs the reference golden: MPJPE per stage / hand (mm): %s' % np.round(mpjpe, 5))
+    assert max(mpjpe) < 0.01, mpjpe
+
+
 @pytest.mark.parametrize('mode', ['f16x3', 'f16'])
 def test_calibrating_twice_changes_nothing(dir_state_cond, mode):
     """ConvOp.set_in_scale rewrites the epilogue scale from scale0, which used to alias it -- a second calibrate() left the
