@@ -38,7 +38,8 @@ struct AsArgs {
     int B, H, W, logW, Cin, in_cs, in_co, Cout, out_cs, out_co, res_cs, res_co;
     int TR;                            // image rows per workgroup tile (32 PB / W)
     int tiles_per_img, ntile, nslice, nsteps, relu, xcd_map;
-    int q, PW, NP, ninstr;             // 16-byte chunks per patch position (Cin / 8); patch width; patch positions; 1 KB DMA instructions
+    int KC, nchunk, csteps, chunk_bytes;   // patch chunk: channels resident at a time (Cin when the whole patch fits), chunks, steps per chunk, LDS bytes of one ring buffer
+    int q, PW, NP, ninstr;             // 16-byte chunks per patch position (KC / 8); patch width; patch positions; 1 KB DMA instructions per patch chunk
     unsigned mg_q, sh_q, mg_pw, sh_pw; // magic divisors (conv_common.h: magic_u31) of q + 1 and PW
     unsigned x_bytes;
     long long* stamps;                 // DIR_STAMPS=conv_as (tuning aid, else NULL): phase times of workgroup 0
@@ -46,8 +47,11 @@ struct AsArgs {
 
 // A: 32-channel blocks per wave (workgroup = 128 A output channels); PB: 32-pixel blocks per workgroup; K3: 3x3 / pad 1 (else 1x1);
 // NSTG: depth of the weight ring in steps (a step = one (64-channel slab, tap) = 4 k-steps = 4 A fragments per wave)
-template <typename H, int A, int PB, bool K3, int NSTG>
-__global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void conv_as_kernel(AsArgs a) {
+// CHK: the patch does not fit LDS as a whole (the attention convolution: 100 positions x 2048 channels = 411 KB): it is brought in KC channels at a
+// time into a ring of TWO buffers -- chunk c + 1's DMA is issued (from source offsets kept in registers: one add per instruction) while chunk c is
+// multiplied; one wait + barrier per chunk.  The K order is unchanged (slab outer, taps inner: a chunk is KC / 64 whole slabs).
+template <typename H, int A, int PB, bool K3, int NSTG, bool CHK = false>
+__global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3 && !CHK) ? 2 : 1) void conv_as_kernel(AsArgs a) {
     convk::half_kernel_init<H>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NWG = 128 * A, TPX = 32 * PB, NTAP = K3 ? 9 : 1;
@@ -82,22 +86,38 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
     //      32 pixels and step beside 8 MFMAs, and a key that ignored ds_read_b128's lane groups -- SQ_LDS_BANK_CONFLICT was 47 - 74 % of the
     //      LDS-active cycles, profiles/r06_a_fwd_sq_counters.txt.)  The DMA sees the padded patch as a linear run of 16-byte slots, 64 per
     //      instruction: slot s = (position s / (q + 1), chunk s % (q + 1)); the pad chunk and positions outside the image fetch out of range = zeros.
-    const int CB = a.Cin * 2, PITCH = CB + 16;
-    {
-        const convk::i32x4 xd = {(int)(unsigned)(unsigned long long)a.x, (int)(unsigned)((unsigned long long)a.x >> 32), (int)a.x_bytes, 0x00020000};
-        const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-        for (int i = wave; i < a.ninstr; i += 4) {
-            const int slot = i * 64 + lane;
-            const int pos = convk::div_magic(slot, a.mg_q, a.sh_q), ch = slot - pos * (a.q + 1);
-            const int pr = convk::div_magic(pos, a.mg_pw, a.sh_pw), pc = pos - pr * a.PW;
-            const int iy = trow + pr - (K3 ? 1 : 0), ix = pc - (K3 ? 1 : 0);
-            const bool ok = pos < a.NP && ch < a.q && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            // (measured and dropped, round 6: advancing (position, chunk, row, column) with adds and carries instead of dividing every slot made the
-            //  prologue SLOWER, 3.9 -> 5.3 k ticks: the carried chain serialises what are otherwise independent iterations.  DMA issue alone: 1.4 - 2.6 k.)
-            const unsigned voff = ok ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.in_cs + a.in_co) * 2 + (ch << 4)) : OOB;
-            convk::lds_dma16_m0(xd, lds0 + (unsigned)i * 1024u, voff, 0);
+    const int CB = a.KC * 2, PITCH = CB + 16;
+    const convk::i32x4 xd = {(int)(unsigned)(unsigned long long)a.x, (int)(unsigned)((unsigned long long)a.x >> 32), (int)a.x_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    constexpr int MAXI = CHK ? 20 : 1;             // CHK: DMA instructions per wave and chunk whose source offsets are kept (launcher: ninstr <= 4 MAXI)
+    unsigned voff0[MAXI];
+    auto slot_voff = [&](int i) -> unsigned {     // source byte offset of lane's slot of instruction i (chunk 0), or OOB
+        const int slot = i * 64 + lane;
+        const int pos = convk::div_magic(slot, a.mg_q, a.sh_q), ch = slot - pos * (a.q + 1);
+        const int pr = convk::div_magic(pos, a.mg_pw, a.sh_pw), pc = pos - pr * a.PW;
+        const int iy = trow + pr - (K3 ? 1 : 0), ix = pc - (K3 ? 1 : 0);
+        const bool ok = pos < a.NP && ch < a.q && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        // (measured and dropped, round 6: advancing (position, chunk, row, column) with adds and carries instead of dividing every slot made the
+        //  prologue SLOWER, 3.9 -> 5.3 k ticks: the carried chain serialises what are otherwise independent iterations.  DMA issue alone: 1.4 - 2.6 k.)
+        return ok ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.in_cs + a.in_co) * 2 + (ch << 4)) : OOB;
+    };
+    if constexpr (CHK) {
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            voff0[j] = wave + 4 * j < a.ninstr ? slot_voff(wave + 4 * j) : OOB;
+            if (wave + 4 * j < a.ninstr) convk::lds_dma16_m0(xd, lds0 + (unsigned)(wave + 4 * j) * 1024u, voff0[j], 0);          // chunk 0 -> buffer 0
         }
+    } else {
+        for (int i = wave; i < a.ninstr; i += 4) convk::lds_dma16_m0(xd, lds0 + (unsigned)i * 1024u, slot_voff(i), 0);
     }
+    auto chunk_dma = [&](int c, int buf) {        // CHK: patch chunk c (channels [c KC, (c + 1) KC)) -> ring buffer buf
+        if constexpr (CHK) {
+            const unsigned coff = (unsigned)(c * CB), dst = lds0 + (unsigned)(buf * a.chunk_bytes);
+#pragma unroll
+            for (int j = 0; j < MAXI; ++j)
+                if (wave + 4 * j < a.ninstr) convk::lds_dma16_m0(xd, dst + (unsigned)(wave + 4 * j) * 1024u, voff0[j] == OOB ? OOB : voff0[j] + coff, 0);
+        }
+    };
 
     stamp();                           // patch DMA issued
     // ---- the weight stream of this wave: fragment (step, ks, cb) at w[(((slice * 4 + wave) * nsteps + step) * 4 + ks) * A + cb][lane]
@@ -146,14 +166,11 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
         }
     }
 
-    convk::wait_vmcnt<0>();            // the patch has landed (and the first ring stages with it)
-    __syncthreads();
-    stamp();                           // patch + first ring stages landed
-
     // The pixels' channels (MFMA B operands) of a step are read from LDS a whole STEP ahead of the MFMAs that use them: with one wave per SIMD
     // (A x PB >= 4: 256 workgroups or fewer) nothing else covers a ds_read_b128's latency, and reading one k-step ahead left the matrix pipe idle
     // ~45 % of the K loop (phase stamps, profiles/r06_as_phase_stamps.txt: 933 ticks per step for 512 of MFMAs).
     uint4 bv[2][4][PB];
+    const char* pbuf = smem;                      // the ring buffer of the chunk being multiplied
     auto bread = [&](auto Par, int cs_, int tap_) {
         constexpr int par = decltype(Par)::value;
         const int ky = K3 ? (tap_ * 11) >> 5 : 0;
@@ -163,15 +180,15 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
 #if defined(DIR_AS_DBG_B)             // investigation aid: the same reads from a fixed kilobyte (what the loop costs without the gather)
             const char* rp = smem + (lane << 4) + 0 * soff;
 #else
-            const char* rp = smem + posb[pb] + soff;
+            const char* rp = pbuf + posb[pb] + soff;
 #endif
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) bv[par][ks][pb] = *reinterpret_cast<const uint4*>(rp + 16 * ks);
         }
     };
     constexpr int UNR = (NSTG % 2 == 0) ? NSTG : 2 * NSTG;          // steps per unrolled iteration: ring stage and operand parity both compile-time
-    int cs = 0, tap = 0;                                            // (slab, tap) of the step whose operands are being read: one ahead of the MFMAs
-    bread(std::integral_constant<int, 0>{}, 0, 0);
+    int cs = 0, tap = 0;                                            // (slab of the chunk, tap) of the step whose operands are being read: one ahead of the MFMAs
+    int sbase = 0;                                                  // global index of the chunk's first step (the weight stream does not know about chunks)
     // One group of UNR steps.  GUARD = false: every step of the group exists -- the body is ONE basic block, and the scheduler is told to deal the
     // step's memory instructions out between its MFMAs (one weight fragment load and one operand read per A x PB / 2 ... MFMAs) instead of
     // issuing eight loads and eight reads in a row: a 64-lane 16-byte load occupies the wave's issue for about half an MFMA, and with one wave per
@@ -182,15 +199,15 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
             (([&] {
                  const int step = s0 + S;
                  constexpr int stage = S % NSTG, par = S & 1;
-                 wload(std::integral_constant<int, (stage + NSTG - 1) % NSTG>{}, step + NSTG - 1);
+                 wload(std::integral_constant<int, (stage + NSTG - 1) % NSTG>{}, sbase + step + NSTG - 1);
                  {   // next step's (slab, tap), branch-free; past the end: the last step's operands again (nobody uses them)
-                     const bool adv = step + 1 < a.nsteps, wrap = tap + 1 == NTAP;
+                     const bool adv = step + 1 < a.csteps, wrap = tap + 1 == NTAP;
                      const int ntap = wrap ? 0 : tap + 1, ncs = wrap ? cs + 1 : cs;
                      tap = adv ? ntap : tap;
                      cs = adv ? ncs : cs;
                  }
                  bread(std::integral_constant<int, par ^ 1>{}, cs, tap);
-                 if (!GUARD || step < a.nsteps) {
+                 if (!GUARD || step < a.csteps) {
 #pragma unroll
                      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -213,9 +230,19 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
              ...);
         }(std::make_integer_sequence<int, UNR>{});
     };
-    int s0 = 0;
-    for (; s0 + UNR <= a.nsteps; s0 += UNR) group(std::false_type{}, s0);
-    if (s0 < a.nsteps) group(std::true_type{}, s0);
+    for (int c = 0; c < a.nchunk; ++c) {
+        convk::wait_vmcnt<0>();        // this wave's share of chunk c has landed (and the ring stages in flight with it)
+        __syncthreads();               // ... everybody's; and every wave is done with the buffer chunk c + 1 goes into
+        if (c == 0) stamp();           // patch (chunk 0) + first ring stages landed
+        if (CHK && c + 1 < a.nchunk) chunk_dma(c + 1, (c + 1) & 1);
+        pbuf = smem + (CHK ? (c & 1) * a.chunk_bytes : 0);
+        sbase = c * a.csteps;
+        cs = 0; tap = 0;
+        bread(std::integral_constant<int, 0>{}, 0, 0);
+        int s0 = 0;
+        for (; s0 + UNR <= a.csteps; s0 += UNR) group(std::false_type{}, s0);
+        if (s0 < a.csteps) group(std::true_type{}, s0);
+    }
 
     // ---- epilogue (conv.hip's arithmetic): fmaf(acc, scale, shift) as fp32 through LDS, then per 16-byte output chunk + residual, round, ReLU
     stamp();                           // K loop done (this wave)
@@ -262,11 +289,11 @@ __global__ __launch_bounds__(AS_THR, (A * PB <= 4 && NSTG <= 3) ? 2 : 1) void co
     stamp();
 }
 
-template <typename H, int A, int PB, bool K3, int NSTG>
+template <typename H, int A, int PB, bool K3, int NSTG, bool CHK = false>
 int launch_as(const AsArgs& a, size_t lds, hipStream_t s) {
     static bool attr_set = false;      // (per instantiation)
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_as_kernel<H, A, PB, K3, NSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)conv_as_kernel<H, A, PB, K3, NSTG, CHK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             set_error("dir_conv2d_as_forward: cannot raise the dynamic LDS limit");
             return DIR_E_LAUNCH;
         }
@@ -274,9 +301,37 @@ int launch_as(const AsArgs& a, size_t lds, hipStream_t s) {
     }
     AsArgs b = a;
     b.stamps = stamps_begin("conv_as");
-    DIR_LAUNCH((conv_as_kernel<H, A, PB, K3, NSTG>), dim3(a.ntile * a.nslice), dim3(AS_THR), lds, s, b);
+    DIR_LAUNCH((conv_as_kernel<H, A, PB, K3, NSTG, CHK>), dim3(a.ntile * a.nslice), dim3(AS_THR), lds, s, b);
     stamps_end("conv_as", b.stamps, s);
     return check_launch("dir_conv2d_as_forward");
+}
+
+
+// How a layer's patch is held: whole (KC = Cin, one buffer) when it fits 160 KB beside nothing else, otherwise -- for the one shape built with a
+// chunk ring, (A, PB) = (4, 2) -- in the largest KC in {1024, 512, 256, 128} whose TWO buffers fit, whose steps per chunk are a multiple of the
+// unrolled group (ring stage and operand parity stay compile-time across chunks: NSTG = 4 -> 4 steps) and whose DMA instructions per wave fit the
+// registers that keep their source offsets (<= 20).  Returns false when the layer cannot be served.
+struct AsPlan { int KC, nchunk, csteps, ninstr, chunk_bytes; size_t lds; bool chunked; };
+bool as_plan(const dir_conv_desc* d, int A, int PB, AsPlan& p) {
+    const bool k3 = d->kh == 3;
+    const int tpx = 32 * PB, TR = tpx / d->W, PW = k3 ? d->W + 2 : d->W, NP = (k3 ? TR + 2 : TR) * PW, ntap = k3 ? 9 : 1;
+    const size_t stage = (size_t)tpx * (128 * A * 4 + 16);
+    auto bytes = [&](int kc) { return (size_t)(((long long)NP * (kc / 8 + 1) + 63) / 64) * 1024; };
+    if (bytes(d->Cin) <= 160 * 1024 && stage <= 160 * 1024) {
+        p.KC = d->Cin; p.nchunk = 1; p.csteps = ntap * d->Cin / 64; p.ninstr = (int)(bytes(d->Cin) / 1024); p.chunk_bytes = (int)bytes(d->Cin);
+        p.lds = bytes(d->Cin) > stage ? bytes(d->Cin) : stage; p.chunked = false;
+        return true;
+    }
+    if (!(A == 4 && PB == 2) || stage > 160 * 1024) return false;
+    for (int kc = 1024; kc >= 128; kc >>= 1) {
+        if (d->Cin % kc || d->Cin / kc < 2) continue;
+        const size_t b = bytes(kc);
+        if (2 * b > 160 * 1024 || (ntap * kc / 64) % 4 || b / 1024 > 80) continue;
+        p.KC = kc; p.nchunk = d->Cin / kc; p.csteps = ntap * kc / 64; p.ninstr = (int)(b / 1024); p.chunk_bytes = (int)b;
+        p.lds = 2 * b > stage ? 2 * b : stage; p.chunked = true;
+        return true;
+    }
+    return false;
 }
 
 }  // namespace
@@ -296,9 +351,8 @@ extern "C" int dir_conv2d_as_supported(const dir_conv_desc* d, int blocks_per_wa
     if (d->Cin <= 0 || d->Cin % 64 || d->Cout <= 0 || d->Cout % (128 * A)) return 0;
     const int in_cs = d->in_cstride ? d->in_cstride : d->Cin, out_cs = d->out_cstride ? d->out_cstride : d->Cout;
     if (in_cs % 8 || d->in_coff % 8 || out_cs % 8 || d->out_coff % 8 || d->res_cstride % 8 || d->res_coff % 8) return 0;
-    const int TR = tpx / d->W, PW = k3 ? d->W + 2 : d->W, NP = (k3 ? TR + 2 : TR) * PW;
-    const long long patch = (long long)NP * (d->Cin * 2 + 16) + 1024, stage = (long long)tpx * (128 * A * 4 + 16);
-    if ((patch > stage ? patch : stage) > 160 * 1024) return 0;
+    dir::AsPlan plan;
+    if (!dir::as_plan(d, A, PB, plan)) return 0;                                      // the patch (or two chunks of it) and the staged tile must fit 160 KB
     if ((long long)d->B * d->H * d->W * in_cs * 2 >= (1ll << 31)) return 0;           // 32-bit buffer offsets, and OOB must be out of range
     return 1;
 }
@@ -308,7 +362,7 @@ extern "C" int dir_conv2d_as_forward(const dir_conv_desc* d, const void* x, cons
     using namespace dir;
     DIR_REQUIRE(d && x && w_as && y, "dir_conv2d_as_forward: null pointer");
     DIR_REQUIRE(dir_conv2d_as_supported(d, blocks_per_wave, pixel_blocks), "dir_conv2d_as_forward: layer not supported (16-bit storage, 1x1 / 3x3 pad 1 stride 1, "
-                "W in {8, 16, 32}, whole rows per tile, Cin %% 64 == 0, Cout %% (128 A) == 0, patch <= 160 KB)");
+                "W in {8, 16, 32}, whole rows per tile, Cin %% 64 == 0, Cout %% (128 A) == 0, patch (or, for (4, 2), two chunks of it) <= 160 KB)");
     const int A = blocks_per_wave, PB = pixel_blocks;
     const bool k3 = d->kh == 3, f16 = d->in_dtype == DIR_DT_F16;
     AsArgs a;
@@ -321,15 +375,21 @@ extern "C" int dir_conv2d_as_forward(const dir_conv_desc* d, const void* x, cons
     a.tiles_per_img = d->H * d->W / (32 * PB); a.ntile = d->B * a.tiles_per_img; a.nslice = d->Cout / (128 * A);
     a.nsteps = (k3 ? 9 : 1) * d->Cin / 64; a.relu = (d->flags & DIR_CONV_RELU) != 0;
     a.xcd_map = a.ntile % 8 == 0;
-    a.q = d->Cin / 8; a.PW = k3 ? d->W + 2 : d->W; a.NP = (k3 ? a.TR + 2 : a.TR) * a.PW;
-    a.ninstr = (int)(((long long)a.NP * (a.q + 1) + 63) / 64);
+    AsPlan plan;
+    DIR_REQUIRE(as_plan(d, A, PB, plan), "dir_conv2d_as_forward: no LDS plan for this layer");
+    a.KC = plan.KC; a.nchunk = plan.nchunk; a.csteps = plan.csteps; a.chunk_bytes = plan.chunk_bytes; a.ninstr = plan.ninstr;
+    a.q = a.KC / 8; a.PW = k3 ? d->W + 2 : d->W; a.NP = (k3 ? a.TR + 2 : a.TR) * a.PW;
     convk::magic_u31((unsigned)(a.q + 1), &a.mg_q, &a.sh_q);
     convk::magic_u31((unsigned)a.PW, &a.mg_pw, &a.sh_pw);
     a.x_bytes = (unsigned)((long long)d->B * d->H * d->W * a.in_cs * 2);
     a.stamps = nullptr;
-    const size_t patch = (size_t)a.ninstr * 1024, stage = (size_t)(32 * PB) * (128 * A * 4 + 16);
-    const size_t lds = patch > stage ? patch : stage;
+    const size_t lds = plan.lds;
     hipStream_t s = (hipStream_t)stream;
+    if (plan.chunked) {                // (A, PB) = (4, 2) on a ring of two patch chunks, weight ring of 4 steps
+        if (k3) { if (f16) return launch_as<convk::f16s_t, 4, 2, true, 4, true>(a, lds, s); return launch_as<convk::bf16_t, 4, 2, true, 4, true>(a, lds, s); }
+        if (f16) return launch_as<convk::f16s_t, 4, 2, false, 4, true>(a, lds, s);
+        return launch_as<convk::bf16_t, 4, 2, false, 4, true>(a, lds, s);
+    }
     // ring depth: 3 steps where two workgroups fit a CU (<= 256 registers, <= 80 KB), else 4
     const bool two = A * PB <= 4 && lds <= 80 * 1024;
 #define DIR_AS3(A_, PB_, NS_) do { if (k3) { if (f16) return launch_as<convk::f16s_t, A_, PB_, true, NS_>(a, lds, s); return launch_as<convk::bf16_t, A_, PB_, true, NS_>(a, lds, s); } \

@@ -536,7 +536,8 @@ int dir_conv1x1_stream_forward(const dir_conv_desc* desc, const void* x, const d
  * (bit-identical outputs): y = act(scale * conv(x) + shift (+ residual)) -- models/backbone/resnet.py:120-140 (Bottleneck conv1 / conv2 / conv3 +
  * identity at 16x16 and 8x8), models/backbone/hourglass.py:55-70 (Residual conv2), models/dir.py:227-241.  No pre-activation, no second source.
  * (blocks_per_wave A, pixel_blocks PB) in {(2,2), (2,4), (4,2), (1,2)}; Cin % 64 == 0, Cout % (128 A) == 0, (H W) % (32 PB) == 0, (32 PB) % W == 0,
- * patch and staging <= 160 KB of LDS.  dir_conv2d_as_supported returns 1 when a layer qualifies.
+ * patch and staging <= 160 KB of LDS -- or, for (4, 2), a ring of TWO patch chunks of 128 .. 1024 channels (the attention convolution, 8x8x2048:
+ * 8 chunks of 256 channels; same K order, bit-identical).  dir_conv2d_as_supported returns 1 when a layer qualifies.
  * w_as: 16-bit [Cout / (128 A)][4 waves][kh kw Cin / 64 steps][4 k-steps][A][64 lanes][8]; step s = (64-channel slab s / (kh kw), tap s % (kh kw)); lane l of
  * fragment (step, ks, cb) of wave w in slice g holds W[g 128 A + (w A + cb) 32 + (l & 31)][tap][64 slab + 8 ks + 32 (l >> 5) .. + 8] of the
  * [Cout][kh][kw][Cin] weights (dir_amd/engine.py::pack_as_weights). */

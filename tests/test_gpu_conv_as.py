@@ -24,7 +24,8 @@ CASES = [
     (2, 16, 16, 1024, 256, 1, False, True),     # layer3 conv1
     (2, 16, 16, 256, 1024, 1, True, True),      # layer3 conv3 + identity
     (2, 32, 32, 128, 128, 3, False, False),     # decoder Residual conv2 @32x32
-    (1, 8, 8, 2048, 512, 1, False, True),       # layer4 conv1 (patch 256 KB: not supported at 64 pixels -> must fall back, still correct)
+    (1, 8, 8, 2048, 512, 1, False, True),       # layer4 conv1 (patch 263 KB: served by (4, 2) on a ring of two 512-channel chunks, the others fall back)
+    (2, 8, 8, 2048, 512, 3, False, True),       # the attention convolution's geometry (models/dir.py:227-241; Cout cut down): 8 chunks of 256 channels
     (2, 16, 16, 128, 256, 3, True, False),
 ]
 
@@ -80,8 +81,7 @@ def test_as_variants_match_oracle_and_the_tiled_kernel_bit_for_bit(case, dt):
         assert ('conv_as_kernel' in names) == supported, (v, names, supported)
         ran += supported
         assert torch.equal(out, base), 'variant %d (A=%d, PB=%d) differs from the tiled kernel' % (v, A, PB)          # incl. the untouched slices of the buffer
-    if (Ci, k) != (2048, 1):
-        assert ran >= (2 if Co % 256 == 0 else 1), 'the kernel should serve this layer'
+    assert ran >= (1 if Ci == 2048 or Co % 256 else 2), 'the kernel should serve this layer'
 
 
 def test_first_use_inside_a_graph_capture():

@@ -5,7 +5,7 @@ import torch
 from dir_amd import engine as E
 dt = torch.float16
 g = torch.Generator(device='cuda').manual_seed(1)
-for (B, H, W, Ci, Co, k) in [(64, 16, 16, 256, 256, 3), (64, 8, 8, 512, 512, 3), (64, 16, 16, 1024, 256, 1)]:
+for (B, H, W, Ci, Co, k) in [(64, 16, 16, 256, 256, 3), (64, 8, 8, 512, 512, 3), (64, 16, 16, 1024, 256, 1), (64, 8, 8, 2048, 2048, 3), (64, 8, 8, 2048, 512, 1)]:
     w = torch.randn(Co, Ci, k, k, device='cuda', generator=g) * (2.0 / (k * k * Ci)) ** 0.5
     op = E.ConvOp(w, dt, stride=1, pad=k // 2, scale=torch.ones(Co, device='cuda'), shift=torch.zeros(Co, device='cuda'), relu=True)
     x = torch.randn(B, H, W, Ci, device='cuda', generator=g).to(dt)
